@@ -1,0 +1,165 @@
+""" ctypes binding of `libdeepcv_hip.so` (C-ABI in `include/deepcv_hip.h`).
+
+This is the only place where Python meets the native kernels: raw device pointers (`tensor.data_ptr()`), explicit sizes and the
+current HIP stream go in, an `int` status comes out; a non-zero status is raised as `RuntimeError` (the reference signals every
+failure as a Python exception, e.g. `src/deepcv/meta/nn_spec.py:100,166,189`).  There is NO fallback: if the shared library is
+missing or a tensor is not on a HIP device, the call fails loudly. """
+import ctypes
+import os
+import subprocess
+import threading
+from pathlib import Path
+from typing import Optional
+
+import torch
+
+__all__ = ['lib', 'load', 'is_available', 'check', 'current_stream', 'Conv2dDesc', 'Pool2dDesc', 'TensorList', 'LIB_PATH', 'build',
+           'ACT_NONE', 'ACT_RELU', 'ACT_LEAKY_RELU', 'ACT_SIGMOID', 'ACT_TANH', 'POOL_AVG', 'POOL_MAX', 'LAYOUT_NHWC', 'LAYOUT_NCHW',
+           'MAX_TENSORS', 'HYP_COUNT', 'HYP']
+
+_PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = _PKG_DIR / 'lib' / 'libdeepcv_hip.so'
+CSRC_DIR = _PKG_DIR / 'csrc'
+
+ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
+POOL_AVG, POOL_MAX = 0, 1
+LAYOUT_NHWC, LAYOUT_NCHW = 0, 1
+MAX_TENSORS = 64
+HYP_COUNT = 16
+HYP = {'lr': 0, 'beta1': 1, 'beta2': 2, 'eps': 3, 'weight_decay': 4, 'grad_scale': 5, 'bias_corr1': 6, 'bias_corr2': 7, 'first_step': 8}
+
+_c_int, _c_float, _c_size_t, _c_void_p, _c_int64 = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int64
+
+
+class Conv2dDesc(ctypes.Structure):
+    """ `dcv_conv2d_desc` """
+    _fields_ = [('n', _c_int), ('h', _c_int), ('w', _c_int), ('cin', _c_int), ('cout', _c_int), ('r', _c_int), ('s', _c_int),
+                ('stride_h', _c_int), ('stride_w', _c_int), ('pad_h', _c_int), ('pad_w', _c_int), ('dil_h', _c_int), ('dil_w', _c_int),
+                ('groups', _c_int), ('ho', _c_int), ('wo', _c_int), ('x_layout', _c_int), ('act', _c_int), ('act_slope', _c_float)]
+
+
+class Pool2dDesc(ctypes.Structure):
+    """ `dcv_pool2d_desc` """
+    _fields_ = [('n', _c_int), ('h', _c_int), ('w', _c_int), ('c', _c_int), ('kh', _c_int), ('kw', _c_int), ('stride_h', _c_int),
+                ('stride_w', _c_int), ('pad_h', _c_int), ('pad_w', _c_int), ('ho', _c_int), ('wo', _c_int), ('mode', _c_int)]
+
+
+class TensorList(ctypes.Structure):
+    """ `dcv_tensor_list` """
+    _fields_ = [('count', _c_int), ('param', _c_void_p * MAX_TENSORS), ('grad', _c_void_p * MAX_TENSORS), ('state1', _c_void_p * MAX_TENSORS),
+                ('state2', _c_void_p * MAX_TENSORS), ('state3', _c_void_p * MAX_TENSORS), ('numel', _c_int64 * MAX_TENSORS)]
+
+
+_P = _c_void_p
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    'dcv_strerror': (ctypes.c_char_p, [_c_int]),
+    'dcv_version': (_c_int, []),
+    'dcv_device_info': (_c_int, [_c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int), ctypes.c_char_p, _c_int]),
+    'dcv_conv2d_fwd_workspace_bytes': (_c_size_t, [ctypes.POINTER(Conv2dDesc)]),
+    'dcv_conv2d_dgrad_workspace_bytes': (_c_size_t, [ctypes.POINTER(Conv2dDesc)]),
+    'dcv_conv2d_wgrad_workspace_bytes': (_c_size_t, [ctypes.POINTER(Conv2dDesc)]),
+    'dcv_conv2d_fwd': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _P, _c_size_t, _P]),
+    'dcv_conv2d_dgrad': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _c_size_t, _P]),
+    'dcv_conv2d_wgrad': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _P, _c_size_t, _P]),
+    'dcv_act_fwd': (_c_int, [_P, _P, _c_size_t, _c_int, _c_float, _P]),
+    'dcv_act_bwd_workspace_bytes': (_c_size_t, [_c_size_t, _c_int]),
+    'dcv_act_bwd': (_c_int, [_P, _P, _P, _c_size_t, _c_int, _c_int, _c_float, _P, _P, _c_size_t, _P]),
+    'dcv_channel_sum': (_c_int, [_P, _P, _c_size_t, _c_int, _P, _c_size_t, _P]),
+    'dcv_batchnorm_workspace_bytes': (_c_size_t, [_c_size_t, _c_int]),
+    'dcv_batchnorm_fwd_train': (_c_int, [_P, _P, _c_size_t, _c_int, _P, _P, _P, _P, _P, _c_float, _c_float, _P, _P, _P, _c_size_t, _P]),
+    'dcv_batchnorm_fwd_eval': (_c_int, [_P, _P, _c_size_t, _c_int, _P, _P, _P, _P, _c_float, _P, _c_size_t, _P]),
+    'dcv_batchnorm_bwd': (_c_int, [_P, _P, _P, _c_size_t, _c_int, _P, _P, _P, _P, _P, _P, _c_size_t, _P]),
+    'dcv_groupnorm_workspace_bytes': (_c_size_t, [_c_int, _c_int]),
+    'dcv_groupnorm_fwd': (_c_int, [_P, _P, _c_int, _c_int, _c_int, _c_int, _P, _P, _c_float, _P, _P, _P]),
+    'dcv_groupnorm_bwd': (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _P, _c_size_t, _P]),
+    'dcv_pool2d_fwd': (_c_int, [ctypes.POINTER(Pool2dDesc), _P, _P, _P, _P]),
+    'dcv_pool2d_bwd': (_c_int, [ctypes.POINTER(Pool2dDesc), _P, _P, _P, _P]),
+    'dcv_interp_bilinear_fwd': (_c_int, [_P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _P]),
+    'dcv_interp_bilinear_bwd': (_c_int, [_P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _P]),
+    'dcv_copy_channels': (_c_int, [_P, _c_int, _c_int, _P, _c_int, _c_int, _c_int, _c_size_t, _P]),
+    'dcv_add': (_c_int, [_P, _P, _P, _c_size_t, _P]),
+    'dcv_scale': (_c_int, [_P, _c_float, _P, _c_size_t, _P]),
+    'dcv_transpose_inner': (_c_int, [_P, _P, _c_int, _c_int, _c_int, _P]),
+    'dcv_linear_wgrad_workspace_bytes': (_c_size_t, [_c_int, _c_int, _c_int]),
+    'dcv_linear_fwd': (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_float, _P]),
+    'dcv_linear_dgrad': (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _P]),
+    'dcv_linear_wgrad': (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _P, _c_size_t, _P]),
+    'dcv_cross_entropy_workspace_bytes': (_c_size_t, [_c_int]),
+    'dcv_cross_entropy_fwd': (_c_int, [_P, _P, _P, _P, _P, _c_int, _c_int, _P, _c_size_t, _P]),
+    'dcv_cross_entropy_bwd': (_c_int, [_P, _P, _P, _P, _P, _c_int, _c_int, _P]),
+    'dcv_optim_prepare': (_c_int, [_P, _P, _P]),
+    'dcv_adamw_step': (_c_int, [ctypes.POINTER(TensorList), _P, _c_int, _P]),
+    'dcv_sgd_step': (_c_int, [ctypes.POINTER(TensorList), _P, _c_int, _P]),
+    'dcv_pack_grads': (_c_int, [ctypes.POINTER(TensorList), _P, _P]),
+}
+
+_lib: Optional[ctypes.CDLL] = None
+_lock = threading.Lock()
+
+
+def build(force: bool = False) -> Path:
+    """ Compiles `deepcv_amd/csrc/*.hip` for gfx950 with hipcc (cross-compiles without a GPU) into `deepcv_amd/lib/libdeepcv_hip.so`. """
+    if force and LIB_PATH.exists():
+        LIB_PATH.unlink()
+    jobs = str(min(8, os.cpu_count() or 1))
+    subprocess.run(['make', '-C', str(CSRC_DIR), f'-j{jobs}'], check=True)
+    if not LIB_PATH.exists():
+        raise RuntimeError(f'deepcv_amd: build did not produce {LIB_PATH}')
+    return LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    """ Loads the shared library (once) and declares every prototype of `include/deepcv_hip.h`.  Raises if it is absent. """
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not LIB_PATH.exists():
+                raise RuntimeError(f'deepcv_amd: native library {LIB_PATH} is missing. Build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                                   f'or `make -C {CSRC_DIR}`; there is no CPU / PyTorch fallback for the hot path.')
+            cdll = ctypes.CDLL(str(LIB_PATH))
+            for name, (restype, argtypes) in _SIGNATURES.items():
+                fn = getattr(cdll, name)   # AttributeError if the library does not export a declared symbol
+                fn.restype, fn.argtypes = restype, argtypes
+            _lib = cdll
+    return _lib
+
+
+class _LazyLib:
+    """ `lib.dcv_xxx(...)` resolves the symbol on first use. """
+
+    def __getattr__(self, name):
+        fn = getattr(load(), name)
+        setattr(self, name, fn)
+        return fn
+
+
+lib = _LazyLib()
+
+
+def is_available() -> bool:
+    """ True when the native library is built AND a HIP device is visible to torch. """
+    return LIB_PATH.exists() and torch.cuda.is_available()
+
+
+def check(code: int, what: str = ''):
+    if code != 0:
+        msg = load().dcv_strerror(code).decode()
+        raise RuntimeError(f'deepcv_amd: {what or "native call"} failed with code {code}: {msg}')
+
+
+def current_stream(device: Optional[torch.device] = None) -> int:
+    """ Raw `hipStream_t` of torch's current stream (honours `torch.cuda.stream(...)` contexts and graph capture). """
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_device(t: torch.Tensor, what: str = 'tensor'):
+    if not t.is_cuda:
+        raise RuntimeError(f'deepcv_amd: {what} must live on a HIP device (got device "{t.device}"); the native hot path has no CPU fallback. '
+                           'Use the reference PyTorch modules (or `oracle/`) for CPU runs.')
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,89 @@
+// colreduce.h — per-channel ("column") reductions of an NHWC activation viewed as [rows][C], the shared building block of the
+// BatchNorm / GroupNorm / bias-gradient kernels.  HBM-bound: every element is read once with coalesced (float4 when C % 4 == 0)
+// loads; partial sums are kept per thread in fp32 over a short run of rows, merged across the block through LDS in a FIXED
+// order and promoted to fp64 there, so results are bit-reproducible and free of E[x^2]-E[x]^2 cancellation at N*H*W ~ 5e5.
+#pragma once
+#include "common.h"
+
+#define DCV_CR_THREADS 256
+
+// Functor contract:  f.template load<VEC>(size_t elem_index, int c, float (&q)[NQ][VEC])
+//   elem_index = row * C + c is the flat offset of the first of VEC consecutive channels.
+//
+// Reduces rows [row_begin, row_end) for all channels; on return (after an internal __syncthreads) `out[q * C + c]` (LDS or global,
+// double) holds the block's sum for quantity q / channel c.  `scratch` must hold NQ * DCV_CR_THREADS * VEC floats of LDS.
+// Must be called by all DCV_CR_THREADS threads of the block.
+template <int NQ, int VEC, typename F>
+__device__ __forceinline__ void dcv_colreduce_block(const F& f, size_t row_begin, size_t row_end, int C, float* scratch, double* out) {
+    const int t = threadIdx.x;
+    const int CV = C / VEC;                       // channel-vectors per row (C % VEC == 0 guaranteed by the caller)
+    if (CV <= DCV_CR_THREADS) {
+        const int rows_per_iter = DCV_CR_THREADS / CV;
+        const int active = rows_per_iter * CV;
+        const int cv = t % CV, rsub = t / CV;
+        float acc[NQ][VEC];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[q][v] = 0.f;
+        if (t < active) {
+            for (size_t r = row_begin + rsub; r < row_end; r += rows_per_iter) {
+                float qv[NQ][VEC];
+                f.template load<VEC>(r * (size_t)C + (size_t)cv * VEC, cv * VEC, qv);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[q][v] += qv[q][v];
+            }
+        }
+        __syncthreads();                          // scratch may still be in use by a previous call
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) scratch[(q * VEC + v) * DCV_CR_THREADS + t] = acc[q][v];
+        __syncthreads();
+        // ordered merge over the row sub-streams: thread (q, c) sums rsub = 0..rows_per_iter-1
+        for (int idx = t; idx < NQ * C; idx += DCV_CR_THREADS) {
+            const int q = idx / C, c = idx % C;
+            const int cvi = c / VEC, v = c % VEC;
+            double s = 0.0;
+            for (int rs = 0; rs < rows_per_iter; ++rs) s += (double)scratch[(q * VEC + v) * DCV_CR_THREADS + rs * CV + cvi];
+            out[q * C + c] = s;
+        }
+        __syncthreads();
+    } else {
+        // wide rows: each thread owns channel-vectors cv = t, t + 256, ... and walks every row of the range
+        for (int cv = t; cv < CV; cv += DCV_CR_THREADS) {
+            double acc[NQ][VEC];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[q][v] = 0.0;
+            for (size_t r = row_begin; r < row_end; ++r) {
+                float qv[NQ][VEC];
+                f.template load<VEC>(r * (size_t)C + (size_t)cv * VEC, cv * VEC, qv);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[q][v] += (double)qv[q][v];
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) out[q * C + cv * VEC + v] = acc[q][v];
+        }
+        __syncthreads();
+    }
+}
+
+// Row partition used by every two-stage reduction: block b of nb handles rows [b*rpb, min(rows,(b+1)*rpb)).
+static inline unsigned dcv_colreduce_blocks(size_t rows, int C) {
+    // 4096 elements per block keep per-thread fp32 runs short (<= 16 adds) while giving >= 2 blocks per CU at the stock sizes
+    size_t elems_per_block = 4096;
+    size_t rows_per_block = elems_per_block / (size_t)C;
+    if (rows_per_block < 1) rows_per_block = 1;
+    size_t nb = dcv_ceil_div(rows, rows_per_block);
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    return (unsigned)nb;
+}

@@ -1,0 +1,71 @@
+// conv2d.hip — public C-ABI of the convolution family; validates the descriptor and dispatches to a back-end:
+//   * MFMA implicit GEMM (conv2d_mfma.hip) when the layer is wide enough to feed the matrix cores,
+//   * direct convolution (conv2d_direct.hip) otherwise (the stock small-channel layers, and every shape as fallback).
+// Replaces torch.nn.Conv2d (reference src/deepcv/meta/submodule_creators.py:251) forward and autograd backward.
+#include "conv2d_internal.h"
+
+namespace {
+
+inline bool desc_ok(const dcv_conv2d_desc* d) {
+    if (!d) return false;
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cin <= 0 || d->cout <= 0 || d->r <= 0 || d->s <= 0) return false;
+    if (d->stride_h <= 0 || d->stride_w <= 0 || d->pad_h < 0 || d->pad_w < 0 || d->dil_h <= 0 || d->dil_w <= 0) return false;
+    const int ho = (d->h + 2 * d->pad_h - d->dil_h * (d->r - 1) - 1) / d->stride_h + 1;
+    const int wo = (d->w + 2 * d->pad_w - d->dil_w * (d->s - 1) - 1) / d->stride_w + 1;
+    if (ho != d->ho || wo != d->wo || ho <= 0 || wo <= 0) return false;
+    if (d->act < DCV_ACT_NONE || d->act > DCV_ACT_TANH) return false;
+    if (d->x_layout != DCV_LAYOUT_NHWC && d->x_layout != DCV_LAYOUT_NCHW) return false;
+    return true;
+}
+
+inline size_t db_ws(const dcv_conv2d_desc* d) { return dcv_act_bwd_workspace_bytes((size_t)d->n * d->ho * d->wo, d->cout); }
+
+}  // namespace
+
+extern "C" {
+
+size_t dcv_conv2d_fwd_workspace_bytes(const dcv_conv2d_desc* d) {
+    if (!desc_ok(d)) return 0;
+    return dcv_mfma_conv2d_supported(d, 0) ? dcv_mfma_conv2d_ws(d, 0) : 0;
+}
+
+size_t dcv_conv2d_dgrad_workspace_bytes(const dcv_conv2d_desc* d) {
+    if (!desc_ok(d)) return 0;
+    return dcv_mfma_conv2d_supported(d, 1) ? dcv_mfma_conv2d_ws(d, 1) : 0;
+}
+
+size_t dcv_conv2d_wgrad_workspace_bytes(const dcv_conv2d_desc* d) {
+    if (!desc_ok(d)) return 0;
+    const size_t main_ws = dcv_mfma_conv2d_supported(d, 2) ? dcv_mfma_conv2d_ws(d, 2) : dcv_direct_conv2d_wgrad_ws(d);
+    return dcv_align_up(main_ws, 256) + db_ws(d);
+}
+
+int dcv_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, void* stream) {
+    DCV_CHECK_ARG(desc_ok(d) && x && w && y);
+    if (d->groups != 1) return DCV_ERR_UNSUPPORTED;
+    if (dcv_mfma_conv2d_supported(d, 0)) return dcv_mfma_conv2d_fwd(d, x, w, bias, y, ws, ws_bytes, dcv_stream(stream));
+    return dcv_direct_conv2d_fwd(d, x, w, bias, y, dcv_stream(stream));
+}
+
+int dcv_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, void* stream) {
+    DCV_CHECK_ARG(desc_ok(d) && dy && w && dx);
+    if (d->groups != 1) return DCV_ERR_UNSUPPORTED;
+    if (d->x_layout != DCV_LAYOUT_NHWC) return DCV_ERR_UNSUPPORTED;   // dx is always produced NHWC
+    if (dcv_mfma_conv2d_supported(d, 1)) return dcv_mfma_conv2d_dgrad(d, dy, w, dx, ws, ws_bytes, dcv_stream(stream));
+    return dcv_direct_conv2d_dgrad(d, dy, w, dx, dcv_stream(stream));
+}
+
+int dcv_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, void* stream) {
+    DCV_CHECK_ARG(desc_ok(d) && x && dy && dw);
+    if (d->groups != 1) return DCV_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < dcv_conv2d_wgrad_workspace_bytes(d)) return DCV_ERR_WORKSPACE;
+    const bool mfma = dcv_mfma_conv2d_supported(d, 2);
+    const size_t main_ws = dcv_align_up(mfma ? dcv_mfma_conv2d_ws(d, 2) : dcv_direct_conv2d_wgrad_ws(d), 256);
+    int rc = mfma ? dcv_mfma_conv2d_wgrad(d, x, dy, dw, ws, main_ws, dcv_stream(stream))
+                  : dcv_direct_conv2d_wgrad(d, x, dy, dw, ws, main_ws, dcv_stream(stream));
+    if (rc != DCV_OK) return rc;
+    if (db) rc = dcv_channel_sum(dy, db, (size_t)d->n * d->ho * d->wo, d->cout, reinterpret_cast<char*>(ws) + main_ws, db_ws(d), stream);
+    return rc;
+}
+
+}  // extern "C"

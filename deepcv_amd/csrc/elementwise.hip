@@ -1,0 +1,355 @@
+// elementwise.hip — activation fwd/bwd (+ fused bias-gradient reduction), channel-slice copy (concat / split), add, scale,
+// inner transpose (NHWC <-> NCHW), bilinear resize fwd/bwd.  All HBM-bound, 16-B vectorised where the shape allows.
+//
+// Replaces: `act_fn()` modules (reference src/deepcv/meta/nn.py:553), torch.cat (submodule_creators.py:56,323),
+// F.interpolate (nn.py:675), torch.nn.Flatten on channels-last data (conf/base/parameters.yml:87).
+#include "colreduce.h"
+#include <string.h>
+
+namespace {
+
+template <int VEC>
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t nv, int act, float slope) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+        if constexpr (VEC == 4) {
+            const float4 v = reinterpret_cast<const float4*>(x)[i];
+            float4 o; o.x = dcv_act_apply(v.x, act, slope); o.y = dcv_act_apply(v.y, act, slope);
+            o.z = dcv_act_apply(v.z, act, slope); o.w = dcv_act_apply(v.w, act, slope);
+            reinterpret_cast<float4*>(y)[i] = o;
+        } else y[i] = dcv_act_apply(x[i], act, slope);
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx,
+                                                       size_t nv, int act, float slope) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+        if constexpr (VEC == 4) {
+            const float4 d = reinterpret_cast<const float4*>(dy)[i]; const float4 v = reinterpret_cast<const float4*>(y)[i];
+            float4 o; o.x = d.x * dcv_act_grad_from_out(v.x, act, slope); o.y = d.y * dcv_act_grad_from_out(v.y, act, slope);
+            o.z = d.z * dcv_act_grad_from_out(v.z, act, slope); o.w = d.w * dcv_act_grad_from_out(v.w, act, slope);
+            reinterpret_cast<float4*>(dx)[i] = o;
+        } else dx[i] = dy[i] * dcv_act_grad_from_out(y[i], act, slope);
+    }
+}
+
+// dx = dy * act'(y) written in the same pass that accumulates the per-channel sum of dx (bias gradient)
+struct ActBwdLoader {
+    const float* dy; const float* y; float* dx; int act; float slope;
+    template <int VEC>
+    __device__ __forceinline__ void load(size_t idx, int, float (&q)[1][VEC]) const {
+        if constexpr (VEC == 4) {
+            const float4 d = *reinterpret_cast<const float4*>(dy + idx); const float4 v = *reinterpret_cast<const float4*>(y + idx);
+            float4 o; o.x = d.x * dcv_act_grad_from_out(v.x, act, slope); o.y = d.y * dcv_act_grad_from_out(v.y, act, slope);
+            o.z = d.z * dcv_act_grad_from_out(v.z, act, slope); o.w = d.w * dcv_act_grad_from_out(v.w, act, slope);
+            *reinterpret_cast<float4*>(dx + idx) = o;
+            q[0][0] = o.x; q[0][1] = o.y; q[0][2] = o.z; q[0][3] = o.w;
+        } else {
+            const float o = dy[idx] * dcv_act_grad_from_out(y[idx], act, slope);
+            dx[idx] = o; q[0][0] = o;
+        }
+    }
+};
+
+template <int VEC>
+__global__ __launch_bounds__(DCV_CR_THREADS) void act_bwd_bias_kernel(ActBwdLoader ld, size_t rows, int C, double* __restrict__ partial) {
+    __shared__ float scratch[DCV_CR_THREADS * VEC];
+    const size_t rpb = (rows + gridDim.x - 1) / gridDim.x;
+    const size_t r0 = (size_t)blockIdx.x * rpb;
+    size_t r1 = r0 + rpb; if (r1 > rows) r1 = rows;
+    dcv_colreduce_block<1, VEC>(ld, r0 < rows ? r0 : rows, r1, C, scratch, partial + (size_t)blockIdx.x * C);
+}
+
+__global__ void sum_partials_kernel(const double* __restrict__ partial, int nb, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += partial[(size_t)b * C + c];
+    out[c] = (float)s;
+}
+
+struct PlainLoader {
+    const float* x;
+    template <int VEC>
+    __device__ __forceinline__ void load(size_t idx, int, float (&q)[1][VEC]) const {
+        if constexpr (VEC == 4) { const float4 v = *reinterpret_cast<const float4*>(x + idx); q[0][0] = v.x; q[0][1] = v.y; q[0][2] = v.z; q[0][3] = v.w; }
+        else q[0][0] = x[idx];
+    }
+};
+
+template <int VEC>
+__global__ __launch_bounds__(DCV_CR_THREADS) void channel_sum_kernel(PlainLoader ld, size_t rows, int C, double* __restrict__ partial) {
+    __shared__ float scratch[DCV_CR_THREADS * VEC];
+    const size_t rpb = (rows + gridDim.x - 1) / gridDim.x;
+    const size_t r0 = (size_t)blockIdx.x * rpb;
+    size_t r1 = r0 + rpb; if (r1 > rows) r1 = rows;
+    dcv_colreduce_block<1, VEC>(ld, r0 < rows ? r0 : rows, r1, C, scratch, partial + (size_t)blockIdx.x * C);
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restrict__ src, int src_c, int src_off, float* __restrict__ dst, int dst_c, int dst_off,
+                                                             int copy_c, size_t rows) {
+    const int cv = copy_c / VEC;
+    const size_t total = rows * (size_t)cv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / cv; const int c = (int)(i % cv) * VEC;
+        if constexpr (VEC == 4) *reinterpret_cast<float4*>(dst + r * dst_c + dst_off + c) = *reinterpret_cast<const float4*>(src + r * src_c + src_off + c);
+        else dst[r * dst_c + dst_off + c] = src[r * src_c + src_off + c];
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t nv) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+        if constexpr (VEC == 4) {
+            const float4 u = reinterpret_cast<const float4*>(a)[i]; const float4 v = reinterpret_cast<const float4*>(b)[i];
+            float4 o; o.x = u.x + v.x; o.y = u.y + v.y; o.z = u.z + v.z; o.w = u.w + v.w;
+            reinterpret_cast<float4*>(out)[i] = o;
+        } else out[i] = a[i] + b[i];
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ a, float alpha, float* __restrict__ out, size_t nv) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+        if constexpr (VEC == 4) {
+            const float4 u = reinterpret_cast<const float4*>(a)[i];
+            float4 o; o.x = u.x * alpha; o.y = u.y * alpha; o.z = u.z * alpha; o.w = u.w * alpha;
+            reinterpret_cast<float4*>(out)[i] = o;
+        } else out[i] = a[i] * alpha;
+    }
+}
+
+// [N][A][B] -> [N][B][A] through a 32x33 LDS tile (coalesced on both sides; +1 padding avoids bank conflicts)
+__global__ __launch_bounds__(256) void transpose_inner_kernel(const float* __restrict__ x, float* __restrict__ y, int A, int B) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const int a0 = blockIdx.y * 32, b0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+    const float* xs = x + (size_t)n * A * B;
+    float* ys = y + (size_t)n * A * B;
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        const int a = a0 + ty + k, b = b0 + tx;
+        if (a < A && b < B) tile[ty + k][tx] = xs[(size_t)a * B + b];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        const int b = b0 + ty + k, a = a0 + tx;
+        if (a < A && b < B) ys[(size_t)b * A + a] = tile[tx][ty + k];
+    }
+}
+
+// source coordinate of torch's bilinear upsample kernel (area_pixel_compute_source_index)
+__device__ __forceinline__ float src_index(float scale, int dst, bool align_corners) {
+    if (align_corners) return scale * dst;
+    const float s = scale * (dst + 0.5f) - 0.5f;
+    return s < 0.f ? 0.f : s;
+}
+
+__device__ __forceinline__ void bilinear_taps(float scale, int dst, int in_size, bool align_corners, int& i0, int& i1, float& l1) {
+    const float s = src_index(scale, dst, align_corners);
+    i0 = (int)s; if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+    l1 = s - (float)i0;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void interp_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo,
+                                                          float sh, float sw, int align) {
+    const int CV = C / VEC;
+    const size_t total = (size_t)N * Ho * Wo * CV;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % CV) * VEC; size_t p = i / CV;
+        const int wo = (int)(p % Wo); p /= Wo; const int ho = (int)(p % Ho); const int n = (int)(p / Ho);
+        int h0, h1, w0, w1; float lh, lw;
+        bilinear_taps(sh, ho, H, align, h0, h1, lh); bilinear_taps(sw, wo, W, align, w0, w1, lw);
+        const float* xs = x + (size_t)n * H * W * C;
+        const float c00 = (1.f - lh) * (1.f - lw), c01 = (1.f - lh) * lw, c10 = lh * (1.f - lw), c11 = lh * lw;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const float v = c00 * xs[((size_t)h0 * W + w0) * C + c + k] + c01 * xs[((size_t)h0 * W + w1) * C + c + k]
+                          + c10 * xs[((size_t)h1 * W + w0) * C + c + k] + c11 * xs[((size_t)h1 * W + w1) * C + c + k];
+            y[(((size_t)n * Ho + ho) * Wo + wo) * C + c + k] = v;
+        }
+    }
+}
+
+// Deterministic gather form of the backward: each INPUT pixel sums the output pixels whose 2x2 footprint contains it.
+__device__ __forceinline__ void cand_range(float scale, int i, int out_size, int& lo, int& hi) {
+    // outputs whose source coordinate s satisfies i-1 <= s < i+1 ; widened by one on both sides, exact test done by the caller
+    const float inv = scale > 0.f ? 1.f / scale : 0.f;
+    float a = ((float)i - 1.5f) * inv - 1.5f, b = ((float)i + 1.5f) * inv + 1.5f;
+    lo = (int)floorf(a); hi = (int)ceilf(b);
+    if (lo < 0) lo = 0;
+    if (hi > out_size - 1) hi = out_size - 1;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void interp_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo,
+                                                          float sh, float sw, int align) {
+    const int CV = C / VEC;
+    const size_t total = (size_t)N * H * W * CV;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % CV) * VEC; size_t p = i / CV;
+        const int w = (int)(p % W); p /= W; const int h = (int)(p % H); const int n = (int)(p / H);
+        int holo, hohi, wolo, wohi;
+        cand_range(sh, h, Ho, holo, hohi); cand_range(sw, w, Wo, wolo, wohi);
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+        const float* dys = dy + (size_t)n * Ho * Wo * C;
+        for (int ho = holo; ho <= hohi; ++ho) {
+            int h0, h1; float lh; bilinear_taps(sh, ho, H, align, h0, h1, lh);
+            float wh = 0.f;
+            if (h0 == h) wh += 1.f - lh;
+            if (h1 == h) wh += lh;
+            if (wh == 0.f) continue;
+            for (int wo = wolo; wo <= wohi; ++wo) {
+                int w0, w1; float lw; bilinear_taps(sw, wo, W, align, w0, w1, lw);
+                float ww = 0.f;
+                if (w0 == w) ww += 1.f - lw;
+                if (w1 == w) ww += lw;
+                if (ww == 0.f) continue;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] += wh * ww * dys[((size_t)ho * Wo + wo) * C + c + k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) dx[(((size_t)n * H + h) * W + w) * C + c + k] = acc[k];
+    }
+}
+
+inline float interp_scale(int in_size, int out_size, int align) {
+    if (align) return out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+    return (float)in_size / (float)out_size;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+const char* dcv_strerror(int code) {
+    switch (code) {
+        case DCV_OK: return "ok";
+        case DCV_ERR_INVALID_ARG: return "invalid argument (null pointer, non-positive dimension or inconsistent shapes)";
+        case DCV_ERR_UNSUPPORTED: return "unsupported configuration for this build of libdeepcv_hip";
+        case DCV_ERR_WORKSPACE: return "workspace too small (query the matching *_workspace_bytes function)";
+        case DCV_ERR_LAUNCH: return "HIP kernel launch failed (hipGetLastError != hipSuccess)";
+        default: return "unknown deepcv_hip error code";
+    }
+}
+
+int dcv_version(void) { return 100; }
+
+int dcv_device_info(int device, int* cu_count, int* wave_size, char* arch, int arch_len) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return DCV_ERR_INVALID_ARG;
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (wave_size) *wave_size = prop.warpSize;
+    if (arch && arch_len > 0) { strncpy(arch, prop.gcnArchName, (size_t)arch_len - 1); arch[arch_len - 1] = 0; }
+    return DCV_OK;
+}
+
+int dcv_act_fwd(const float* x, float* y, size_t numel, int act, float slope, void* stream) {
+    DCV_CHECK_ARG(x && y && numel > 0 && act >= DCV_ACT_NONE && act <= DCV_ACT_TANH);
+    hipStream_t st = dcv_stream(stream);
+    if (numel % 4 == 0 && aligned16(x) && aligned16(y)) hipLaunchKernelGGL((act_fwd_kernel<4>), dim3(dcv_stream_grid(numel / 4, 256)), dim3(256), 0, st, x, y, numel / 4, act, slope);
+    else hipLaunchKernelGGL((act_fwd_kernel<1>), dim3(dcv_stream_grid(numel, 256)), dim3(256), 0, st, x, y, numel, act, slope);
+    DCV_RETURN_LAUNCH();
+}
+
+size_t dcv_act_bwd_workspace_bytes(size_t rows, int channels) {
+    if (rows == 0 || channels <= 0) return 0;
+    return dcv_align_up((size_t)dcv_colreduce_blocks(rows, channels) * channels * sizeof(double), 256);
+}
+
+int dcv_act_bwd(const float* dy, const float* y, float* dx, size_t rows, int C, int act, float slope, float* db, void* ws, size_t ws_bytes, void* stream) {
+    DCV_CHECK_ARG(dy && y && dx && rows > 0 && C > 0 && act >= DCV_ACT_NONE && act <= DCV_ACT_TANH);
+    hipStream_t st = dcv_stream(stream);
+    const size_t numel = rows * (size_t)C;
+    if (!db) {
+        if (numel % 4 == 0 && aligned16(dy) && aligned16(y) && aligned16(dx))
+            hipLaunchKernelGGL((act_bwd_kernel<4>), dim3(dcv_stream_grid(numel / 4, 256)), dim3(256), 0, st, dy, y, dx, numel / 4, act, slope);
+        else hipLaunchKernelGGL((act_bwd_kernel<1>), dim3(dcv_stream_grid(numel, 256)), dim3(256), 0, st, dy, y, dx, numel, act, slope);
+        DCV_RETURN_LAUNCH();
+    }
+    if (!ws || ws_bytes < dcv_act_bwd_workspace_bytes(rows, C)) return DCV_ERR_WORKSPACE;
+    double* partial = reinterpret_cast<double*>(ws);
+    const unsigned nb = dcv_colreduce_blocks(rows, C);
+    ActBwdLoader ld{dy, y, dx, act, slope};
+    if (C % 4 == 0) hipLaunchKernelGGL((act_bwd_bias_kernel<4>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
+    else hipLaunchKernelGGL((act_bwd_bias_kernel<1>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)dcv_ceil_div(C, 64)), dim3(64), 0, st, partial, (int)nb, C, db);
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_channel_sum(const float* x, float* out, size_t rows, int C, void* ws, size_t ws_bytes, void* stream) {
+    DCV_CHECK_ARG(x && out && rows > 0 && C > 0);
+    if (!ws || ws_bytes < dcv_act_bwd_workspace_bytes(rows, C)) return DCV_ERR_WORKSPACE;
+    hipStream_t st = dcv_stream(stream);
+    double* partial = reinterpret_cast<double*>(ws);
+    const unsigned nb = dcv_colreduce_blocks(rows, C);
+    PlainLoader ld{x};
+    if (C % 4 == 0 && aligned16(x)) hipLaunchKernelGGL((channel_sum_kernel<4>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
+    else hipLaunchKernelGGL((channel_sum_kernel<1>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)dcv_ceil_div(C, 64)), dim3(64), 0, st, partial, (int)nb, C, out);
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_copy_channels(const float* src, int src_c, int src_off, float* dst, int dst_c, int dst_off, int copy_c, size_t rows, void* stream) {
+    DCV_CHECK_ARG(src && dst && rows > 0 && copy_c > 0 && src_off >= 0 && dst_off >= 0 && src_off + copy_c <= src_c && dst_off + copy_c <= dst_c);
+    hipStream_t st = dcv_stream(stream);
+    const bool v4 = (copy_c % 4 == 0) && (src_c % 4 == 0) && (dst_c % 4 == 0) && (src_off % 4 == 0) && (dst_off % 4 == 0) && aligned16(src) && aligned16(dst);
+    if (v4) hipLaunchKernelGGL((copy_channels_kernel<4>), dim3(dcv_stream_grid(rows * (size_t)(copy_c / 4), 256)), dim3(256), 0, st, src, src_c, src_off, dst, dst_c, dst_off, copy_c, rows);
+    else hipLaunchKernelGGL((copy_channels_kernel<1>), dim3(dcv_stream_grid(rows * (size_t)copy_c, 256)), dim3(256), 0, st, src, src_c, src_off, dst, dst_c, dst_off, copy_c, rows);
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_add(const float* a, const float* b, float* out, size_t numel, void* stream) {
+    DCV_CHECK_ARG(a && b && out && numel > 0);
+    hipStream_t st = dcv_stream(stream);
+    if (numel % 4 == 0 && aligned16(a) && aligned16(b) && aligned16(out)) hipLaunchKernelGGL((add_kernel<4>), dim3(dcv_stream_grid(numel / 4, 256)), dim3(256), 0, st, a, b, out, numel / 4);
+    else hipLaunchKernelGGL((add_kernel<1>), dim3(dcv_stream_grid(numel, 256)), dim3(256), 0, st, a, b, out, numel);
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_scale(const float* a, float alpha, float* out, size_t numel, void* stream) {
+    DCV_CHECK_ARG(a && out && numel > 0);
+    hipStream_t st = dcv_stream(stream);
+    if (numel % 4 == 0 && aligned16(a) && aligned16(out)) hipLaunchKernelGGL((scale_kernel<4>), dim3(dcv_stream_grid(numel / 4, 256)), dim3(256), 0, st, a, alpha, out, numel / 4);
+    else hipLaunchKernelGGL((scale_kernel<1>), dim3(dcv_stream_grid(numel, 256)), dim3(256), 0, st, a, alpha, out, numel);
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_transpose_inner(const float* x, float* y, int n, int a, int b, void* stream) {
+    DCV_CHECK_ARG(x && y && n > 0 && a > 0 && b > 0 && n <= 65535);
+    hipStream_t st = dcv_stream(stream);
+    dim3 grid((unsigned)dcv_ceil_div(b, 32), (unsigned)dcv_ceil_div(a, 32), (unsigned)n);
+    DCV_CHECK_ARG(grid.y <= 65535);
+    hipLaunchKernelGGL(transpose_inner_kernel, grid, dim3(256), 0, st, x, y, a, b);
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_interp_bilinear_fwd(const float* x, float* y, int n, int h, int w, int c, int ho, int wo, int align_corners, void* stream) {
+    DCV_CHECK_ARG(x && y && n > 0 && h > 0 && w > 0 && c > 0 && ho > 0 && wo > 0);
+    hipStream_t st = dcv_stream(stream);
+    const float sh = interp_scale(h, ho, align_corners), sw = interp_scale(w, wo, align_corners);
+    if (c % 4 == 0) hipLaunchKernelGGL((interp_fwd_kernel<4>), dim3(dcv_stream_grid((size_t)n * ho * wo * (c / 4), 256)), dim3(256), 0, st, x, y, n, h, w, c, ho, wo, sh, sw, align_corners);
+    else hipLaunchKernelGGL((interp_fwd_kernel<1>), dim3(dcv_stream_grid((size_t)n * ho * wo * c, 256)), dim3(256), 0, st, x, y, n, h, w, c, ho, wo, sh, sw, align_corners);
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_interp_bilinear_bwd(const float* dy, float* dx, int n, int h, int w, int c, int ho, int wo, int align_corners, void* stream) {
+    DCV_CHECK_ARG(dy && dx && n > 0 && h > 0 && w > 0 && c > 0 && ho > 0 && wo > 0);
+    hipStream_t st = dcv_stream(stream);
+    const float sh = interp_scale(h, ho, align_corners), sw = interp_scale(w, wo, align_corners);
+    if (c % 4 == 0) hipLaunchKernelGGL((interp_bwd_kernel<4>), dim3(dcv_stream_grid((size_t)n * h * w * (c / 4), 256)), dim3(256), 0, st, dy, dx, n, h, w, c, ho, wo, sh, sw, align_corners);
+    else hipLaunchKernelGGL((interp_bwd_kernel<1>), dim3(dcv_stream_grid((size_t)n * h * w * c, 256)), dim3(256), 0, st, dy, dx, n, h, w, c, ho, wo, sh, sw, align_corners);
+    DCV_RETURN_LAUNCH();
+}
+
+}  // extern "C"

@@ -1,0 +1,232 @@
+// linear_loss.hip — fully-connected layer (fwd / dgrad / wgrad) and softmax cross-entropy (fwd / bwd).
+//
+// The classifier head is tiny next to the convolutions (stock: 1280 -> 10, 25.6 kFLOP/img), so these kernels are
+// bandwidth/latency-bound wave-level dot products with fused bias + activation, not an MFMA GEMM.  Reductions are fixed-order.
+//
+// Replaces torch.nn.Linear (reference submodule_creators.py:268-269) and torch.nn.CrossEntropyLoss() (classification/image.py:70).
+#include "common.h"
+#include <float.h>
+
+namespace {
+
+// one wave per sample row; lanes stride over K; one shuffle-reduction per output feature
+template <int VEC>
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                          float* __restrict__ y, int N, int K, int O, int act, float slope) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float* xr = x + (size_t)n * K;
+    const int KV = K / VEC;
+    for (int o = 0; o < O; ++o) {
+        const float* wr = w + (size_t)o * K;
+        float acc = 0.f;
+        for (int k = lane; k < KV; k += 64) {
+            if constexpr (VEC == 4) {
+                const float4 a = reinterpret_cast<const float4*>(xr)[k]; const float4 b = reinterpret_cast<const float4*>(wr)[k];
+                acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+            } else acc += xr[k] * wr[k];
+        }
+        acc = dcv_wave_sum(acc);
+        if (lane == 0) y[(size_t)n * O + o] = dcv_act_apply(acc + (bias ? bias[o] : 0.f), act, slope);
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int N, int K, int O) {
+    const int KV = K / VEC;
+    const size_t total = (size_t)N * KV;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / KV), k = (int)(i % KV);
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        for (int o = 0; o < O; ++o) {
+            const float g = dy[(size_t)n * O + o];
+            if constexpr (VEC == 4) {
+                const float4 b = reinterpret_cast<const float4*>(w + (size_t)o * K)[k];
+                acc[0] += g * b.x; acc[1] += g * b.y; acc[2] += g * b.z; acc[3] += g * b.w;
+            } else acc[0] += g * w[(size_t)o * K + k];
+        }
+        if constexpr (VEC == 4) { float4 o4; o4.x = acc[0]; o4.y = acc[1]; o4.z = acc[2]; o4.w = acc[3]; reinterpret_cast<float4*>(dx + (size_t)n * K)[k] = o4; }
+        else dx[(size_t)n * K + k] = acc[0];
+    }
+}
+
+#define LIN_WG_CHUNK 32          // samples per partial slab
+// grid (k-vector tiles, O, chunks): partial[chunk][o][k] = sum_{n in chunk} dy[n][o] * x[n][k]
+template <int VEC>
+__global__ __launch_bounds__(256) void linear_wgrad_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int N, int K, int O) {
+    const int KV = K / VEC;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= KV) return;
+    const int o = blockIdx.y, chunk = blockIdx.z;
+    const int n0 = chunk * LIN_WG_CHUNK;
+    int n1 = n0 + LIN_WG_CHUNK; if (n1 > N) n1 = N;
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+    for (int n = n0; n < n1; ++n) {
+        const float g = dy[(size_t)n * O + o];
+        if constexpr (VEC == 4) {
+            const float4 a = reinterpret_cast<const float4*>(x + (size_t)n * K)[k];
+            acc[0] += g * a.x; acc[1] += g * a.y; acc[2] += g * a.z; acc[3] += g * a.w;
+        } else acc[0] += g * x[(size_t)n * K + k];
+    }
+    float* dst = partial + ((size_t)chunk * O + o) * K;
+    if constexpr (VEC == 4) { float4 o4; o4.x = acc[0]; o4.y = acc[1]; o4.z = acc[2]; o4.w = acc[3]; reinterpret_cast<float4*>(dst)[k] = o4; }
+    else dst[k] = acc[0];
+}
+
+__global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int chunks, size_t ok) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ok; i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int c = 0; c < chunks; ++c) s += partial[(size_t)c * ok + i];
+        dw[i] = s;
+    }
+}
+
+// db[o] = sum_n dy[n][o]: one wave per output feature, ordered shuffle reduction
+__global__ __launch_bounds__(64) void linear_bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db, int N, int O) {
+    const int o = blockIdx.x, lane = threadIdx.x;
+    float acc = 0.f;
+    for (int n = lane; n < N; n += 64) acc += dy[(size_t)n * O + o];
+    acc = dcv_wave_sum(acc);
+    if (lane == 0) db[o] = acc;
+}
+
+// ---------------------------------------------------------------- cross entropy
+#define CE_THREADS 256           // 4 waves per block, one sample per wave per iteration
+// stage 1: per-block partial loss sum (double) and correct count
+__global__ __launch_bounds__(CE_THREADS) void ce_fwd_partial_kernel(const float* __restrict__ z, const int64_t* __restrict__ target, float* __restrict__ lse_out,
+                                                                    double* __restrict__ part_loss, int* __restrict__ part_correct, int N, int C) {
+    __shared__ double wl[CE_THREADS / 64];
+    __shared__ int wc[CE_THREADS / 64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = CE_THREADS / 64;
+    double lsum = 0.0; int correct = 0;
+    for (int n = blockIdx.x * nw + wid; n < N; n += gridDim.x * nw) {
+        const float* zr = z + (size_t)n * C;
+        float m = -INFINITY; int mi = 0x7fffffff;
+        for (int c = lane; c < C; c += 64) { const float v = zr[c]; if (v > m || (v != v)) { m = v; mi = c; } }
+        // wave arg-max with "lowest index wins" tie-break
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float om = __shfl_xor(m, off, 64); const int oi = __shfl_xor(mi, off, 64);
+            if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+        }
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += expf(zr[c] - m);
+        s = dcv_wave_sum(s);
+        const float lse = m + logf(s);
+        if (lane == 0) {
+            const int64_t t = target[n];
+            lse_out[n] = lse;
+            const float zt = (t >= 0 && t < C) ? zr[t] : 0.f;
+            lsum += (double)(lse - zt);
+            correct += (mi == (int)t) ? 1 : 0;
+        }
+    }
+    if (lane == 0) { wl[wid] = lsum; wc[wid] = correct; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0; int k = 0;
+        for (int i = 0; i < nw; ++i) { s += wl[i]; k += wc[i]; }
+        part_loss[blockIdx.x] = s; part_correct[blockIdx.x] = k;
+    }
+}
+
+__global__ void ce_fwd_final_kernel(const double* __restrict__ part_loss, const int* __restrict__ part_correct, int nb, int N, float* __restrict__ loss, int32_t* __restrict__ correct) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0.0; int k = 0;
+    for (int i = 0; i < nb; ++i) { s += part_loss[i]; k += part_correct[i]; }
+    loss[0] = (float)(s / (double)N);
+    if (correct) correct[0] = k;
+}
+
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ z, const int64_t* __restrict__ target, const float* __restrict__ lse,
+                                                      const float* __restrict__ dloss, float* __restrict__ dz, int N, int C) {
+    const float g = dloss[0] / (float)N;
+    const size_t total = (size_t)N * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / C), c = (int)(i % C);
+        const float p = expf(z[i] - lse[n]);
+        dz[i] = (p - ((int64_t)c == target[n] ? 1.f : 0.f)) * g;
+    }
+}
+
+#define CE_MAX_BLOCKS 256
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int dcv_linear_fwd(const float* x, const float* w, const float* bias, float* y, int n, int K, int O, int act, float slope, void* stream) {
+    DCV_CHECK_ARG(x && w && y && n > 0 && K > 0 && O > 0 && act >= DCV_ACT_NONE && act <= DCV_ACT_TANH);
+    hipStream_t st = dcv_stream(stream);
+    const unsigned grid = (unsigned)dcv_ceil_div(n, 4);
+    if (K % 4 == 0 && aligned16(x) && aligned16(w)) hipLaunchKernelGGL((linear_fwd_kernel<4>), dim3(grid), dim3(256), 0, st, x, w, bias, y, n, K, O, act, slope);
+    else hipLaunchKernelGGL((linear_fwd_kernel<1>), dim3(grid), dim3(256), 0, st, x, w, bias, y, n, K, O, act, slope);
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_linear_dgrad(const float* dy, const float* w, float* dx, int n, int K, int O, void* stream) {
+    DCV_CHECK_ARG(dy && w && dx && n > 0 && K > 0 && O > 0);
+    hipStream_t st = dcv_stream(stream);
+    if (K % 4 == 0 && aligned16(w) && aligned16(dx)) hipLaunchKernelGGL((linear_dgrad_kernel<4>), dim3(dcv_stream_grid((size_t)n * (K / 4), 256)), dim3(256), 0, st, dy, w, dx, n, K, O);
+    else hipLaunchKernelGGL((linear_dgrad_kernel<1>), dim3(dcv_stream_grid((size_t)n * K, 256)), dim3(256), 0, st, dy, w, dx, n, K, O);
+    DCV_RETURN_LAUNCH();
+}
+
+size_t dcv_linear_wgrad_workspace_bytes(int n, int K, int O) {
+    if (n <= 0 || K <= 0 || O <= 0) return 0;
+    return dcv_align_up(dcv_ceil_div(n, LIN_WG_CHUNK) * (size_t)O * K * sizeof(float), 256);
+}
+
+int dcv_linear_wgrad(const float* x, const float* dy, float* dw, float* db, int n, int K, int O, void* ws, size_t ws_bytes, void* stream) {
+    DCV_CHECK_ARG(x && dy && dw && n > 0 && K > 0 && O > 0 && O <= 65535);
+    if (!ws || ws_bytes < dcv_linear_wgrad_workspace_bytes(n, K, O)) return DCV_ERR_WORKSPACE;
+    hipStream_t st = dcv_stream(stream);
+    const int chunks = (int)dcv_ceil_div(n, LIN_WG_CHUNK);
+    DCV_CHECK_ARG(chunks <= 65535);
+    float* partial = reinterpret_cast<float*>(ws);
+    if (K % 4 == 0 && aligned16(x)) {
+        dim3 grid((unsigned)dcv_ceil_div(K / 4, 256), (unsigned)O, (unsigned)chunks);
+        hipLaunchKernelGGL((linear_wgrad_partial_kernel<4>), grid, dim3(256), 0, st, x, dy, partial, n, K, O);
+    } else {
+        dim3 grid((unsigned)dcv_ceil_div(K, 256), (unsigned)O, (unsigned)chunks);
+        hipLaunchKernelGGL((linear_wgrad_partial_kernel<1>), grid, dim3(256), 0, st, x, dy, partial, n, K, O);
+    }
+    const size_t ok = (size_t)O * K;
+    hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3(dcv_stream_grid(ok, 256)), dim3(256), 0, st, partial, dw, chunks, ok);
+    if (db) hipLaunchKernelGGL(linear_bias_grad_kernel, dim3((unsigned)O), dim3(64), 0, st, dy, db, n, O);
+    DCV_RETURN_LAUNCH();
+}
+
+size_t dcv_cross_entropy_workspace_bytes(int n) {
+    (void)n;
+    return dcv_align_up(CE_MAX_BLOCKS * (sizeof(double) + sizeof(int)), 256);
+}
+
+int dcv_cross_entropy_fwd(const float* logits, const int64_t* target, float* loss, float* lse, int32_t* correct, int n, int classes,
+                          void* ws, size_t ws_bytes, void* stream) {
+    DCV_CHECK_ARG(logits && target && loss && lse && n > 0 && classes > 0);
+    if (!ws || ws_bytes < dcv_cross_entropy_workspace_bytes(n)) return DCV_ERR_WORKSPACE;
+    hipStream_t st = dcv_stream(stream);
+    double* part_loss = reinterpret_cast<double*>(ws);
+    int* part_correct = reinterpret_cast<int*>(part_loss + CE_MAX_BLOCKS);
+    unsigned nb = (unsigned)dcv_ceil_div(n, CE_THREADS / 64);
+    if (nb > CE_MAX_BLOCKS) nb = CE_MAX_BLOCKS;
+    hipLaunchKernelGGL(ce_fwd_partial_kernel, dim3(nb), dim3(CE_THREADS), 0, st, logits, target, lse, part_loss, part_correct, n, classes);
+    hipLaunchKernelGGL(ce_fwd_final_kernel, dim3(1), dim3(64), 0, st, part_loss, part_correct, (int)nb, n, loss, correct);
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_cross_entropy_bwd(const float* logits, const int64_t* target, const float* lse, const float* dloss, float* dlogits, int n, int classes, void* stream) {
+    DCV_CHECK_ARG(logits && target && lse && dloss && dlogits && n > 0 && classes > 0);
+    hipStream_t st = dcv_stream(stream);
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3(dcv_stream_grid((size_t)n * classes, 256)), dim3(256), 0, st, logits, target, lse, dloss, dlogits, n, classes);
+    DCV_RETURN_LAUNCH();
+}
+
+}  // extern "C"

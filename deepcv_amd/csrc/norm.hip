@@ -1,0 +1,387 @@
+// norm.hip — BatchNorm (train / eval / backward) and GroupNorm (forward / backward) for NHWC fp32 activations.
+//
+// Roofline: HBM.  Algorithmic bytes: BN train fwd = 3 * 4 B * rows * C (two reads + one write),
+// BN bwd = 5 * 4 B * rows * C, GN fwd = 3x, GN bwd = 5x.  All loads/stores are 16-B vectors when C % 4 == 0.
+//
+// Replaces torch.nn.BatchNorm2d (reference src/deepcv/meta/nn.py:418,487-491,501) and torch.nn.GroupNorm (nn.py:494-495,501).
+#include "colreduce.h"
+
+namespace {
+
+// ---------------------------------------------------------------- load functors for dcv_colreduce_block
+struct SumSqLoader {            // q0 = x, q1 = x^2
+    const float* x;
+    template <int VEC>
+    __device__ __forceinline__ void load(size_t idx, int, float (&q)[2][VEC]) const {
+        if constexpr (VEC == 4) {
+            const float4 v = *reinterpret_cast<const float4*>(x + idx);
+            q[0][0] = v.x; q[0][1] = v.y; q[0][2] = v.z; q[0][3] = v.w;
+        } else {
+            q[0][0] = x[idx];
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) q[1][i] = q[0][i] * q[0][i];
+    }
+};
+
+struct BnBwdLoader {            // q0 = dy, q1 = dy * xhat   with per-channel mean / rstd
+    const float* dy; const float* x; const float* mean; const float* rstd;
+    template <int VEC>
+    __device__ __forceinline__ void load(size_t idx, int c, float (&q)[2][VEC]) const {
+        float xv[VEC];
+        if constexpr (VEC == 4) {
+            const float4 d = *reinterpret_cast<const float4*>(dy + idx);
+            const float4 v = *reinterpret_cast<const float4*>(x + idx);
+            q[0][0] = d.x; q[0][1] = d.y; q[0][2] = d.z; q[0][3] = d.w;
+            xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w;
+        } else {
+            q[0][0] = dy[idx]; xv[0] = x[idx];
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) q[1][i] = q[0][i] * ((xv[i] - mean[c + i]) * rstd[c + i]);
+    }
+};
+
+struct GnBwdLoader {            // q0 = dy, q1 = dy * xhat   with the sample's per-group mean / rstd
+    const float* dy; const float* x; const float* mean; const float* rstd; int cpg;   // mean/rstd already offset to sample n
+    template <int VEC>
+    __device__ __forceinline__ void load(size_t idx, int c, float (&q)[2][VEC]) const {
+        float xv[VEC];
+        if constexpr (VEC == 4) {
+            const float4 d = *reinterpret_cast<const float4*>(dy + idx);
+            const float4 v = *reinterpret_cast<const float4*>(x + idx);
+            q[0][0] = d.x; q[0][1] = d.y; q[0][2] = d.z; q[0][3] = d.w;
+            xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w;
+        } else {
+            q[0][0] = dy[idx]; xv[0] = x[idx];
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { const int g = (c + i) / cpg; q[1][i] = q[0][i] * ((xv[i] - mean[g]) * rstd[g]); }
+    }
+};
+
+// ---------------------------------------------------------------- stage 1: per-block partial sums -> ws [nb][2][C] (double)
+template <int VEC, typename Loader>
+__global__ __launch_bounds__(DCV_CR_THREADS) void colreduce2_kernel(Loader ld, size_t rows, int C, double* __restrict__ partial) {
+    __shared__ float scratch[2 * DCV_CR_THREADS * VEC];
+    const size_t rpb = (rows + gridDim.x - 1) / gridDim.x;
+    const size_t r0 = (size_t)blockIdx.x * rpb;
+    size_t r1 = r0 + rpb; if (r1 > rows) r1 = rows;
+    dcv_colreduce_block<2, VEC>(ld, r0 < rows ? r0 : rows, r1, C, scratch, partial + (size_t)blockIdx.x * 2 * C);
+}
+
+// ---------------------------------------------------------------- BN stage 2 (forward): statistics, running stats, scale/shift
+__global__ void bn_finalize_fwd_kernel(const double* __restrict__ partial, int nb, size_t rows, int C,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps,
+                                       float* __restrict__ save_mean, float* __restrict__ save_rstd, float* __restrict__ scale_shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) nbt[0] += 1;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < nb; ++b) { s += partial[((size_t)b * 2 + 0) * C + c]; ss += partial[((size_t)b * 2 + 1) * C + c]; }
+    const double n = (double)rows;
+    const double mean = s / n;
+    double var = ss / n - mean * mean;               // fp64: no cancellation issue at these magnitudes
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    save_mean[c] = (float)mean;
+    save_rstd[c] = rstd;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) {
+        const double unbiased = rows > 1 ? var * n / (n - 1.0) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * rstd;
+    scale_shift[c] = sc;
+    scale_shift[C + c] = b - (float)mean * sc;
+}
+
+__global__ void bn_finalize_eval_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                        const float* __restrict__ rm, const float* __restrict__ rv, float eps, float* __restrict__ scale_shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float rstd = 1.f / sqrtf(rv[c] + eps);
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    scale_shift[c] = g * rstd;
+    scale_shift[C + c] = b - rm[c] * g * rstd;
+}
+
+// ---------------------------------------------------------------- stage 3: y = x * scale[c] + shift[c]
+template <int VEC>
+__global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restrict__ x, float* __restrict__ y, size_t numel_v, int C,
+                                                            const float* __restrict__ scale_shift) {
+    const int CV = C / VEC;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel_v; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % CV) * VEC;
+        if constexpr (VEC == 4) {
+            const float4 v = reinterpret_cast<const float4*>(x)[i];
+            const float4 sc = *reinterpret_cast<const float4*>(scale_shift + c);
+            const float4 sh = *reinterpret_cast<const float4*>(scale_shift + C + c);
+            float4 o; o.x = v.x * sc.x + sh.x; o.y = v.y * sc.y + sh.y; o.z = v.z * sc.z + sh.z; o.w = v.w * sc.w + sh.w;
+            reinterpret_cast<float4*>(y)[i] = o;
+        } else {
+            y[i] = x[i] * scale_shift[c] + scale_shift[C + c];
+        }
+    }
+}
+
+// ---------------------------------------------------------------- BN backward stage 2 / 3
+// coef layout (float [3][C]): a = gamma*rstd, b = sum(dy)/rows, d = sum(dy*xhat)/rows   ->  dx = a * (dy - b - xhat * d)
+__global__ void bn_finalize_bwd_kernel(const double* __restrict__ partial, int nb, size_t rows, int C, const float* __restrict__ gamma,
+                                       const float* __restrict__ rstd, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nb; ++b) { s1 += partial[((size_t)b * 2 + 0) * C + c]; s2 += partial[((size_t)b * 2 + 1) * C + c]; }
+    if (dbeta) dbeta[c] = (float)s1;
+    if (dgamma) dgamma[c] = (float)s2;
+    const float g = gamma ? gamma[c] : 1.f;
+    coef[c] = g * rstd[c];
+    coef[C + c] = (float)(s1 / (double)rows);
+    coef[2 * C + c] = (float)(s2 / (double)rows);
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx,
+                                                            size_t numel_v, int C, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ coef) {
+    const int CV = C / VEC;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel_v; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % CV) * VEC;
+        float d[VEC], v[VEC], o[VEC];
+        if constexpr (VEC == 4) {
+            const float4 d4 = reinterpret_cast<const float4*>(dy)[i]; const float4 v4 = reinterpret_cast<const float4*>(x)[i];
+            d[0] = d4.x; d[1] = d4.y; d[2] = d4.z; d[3] = d4.w; v[0] = v4.x; v[1] = v4.y; v[2] = v4.z; v[3] = v4.w;
+        } else { d[0] = dy[i]; v[0] = x[i]; }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const float xhat = (v[k] - mean[c + k]) * rstd[c + k];
+            o[k] = coef[c + k] * (d[k] - coef[C + c + k] - xhat * coef[2 * C + c + k]);
+        }
+        if constexpr (VEC == 4) { float4 o4; o4.x = o[0]; o4.y = o[1]; o4.z = o[2]; o4.w = o[3]; reinterpret_cast<float4*>(dx)[i] = o4; }
+        else dx[i] = o[0];
+    }
+}
+
+// ---------------------------------------------------------------- GroupNorm: one block per sample (its [HW][C] slab is re-read from L2 for pass 2)
+template <int VEC>
+__global__ __launch_bounds__(DCV_CR_THREADS) void gn_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int HW, int C, int G,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                                 float* __restrict__ save_mean, float* __restrict__ save_rstd) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* chan = reinterpret_cast<double*>(smem);                      // [2][C]
+    float* scale = reinterpret_cast<float*>(chan + 2 * (size_t)C);       // [C]
+    float* shift = scale + C;                                            // [C]
+    float* scratch = shift + C;                                          // [2 * 256 * VEC]
+    const int n = blockIdx.x;
+    const size_t base = (size_t)n * HW * C;
+    SumSqLoader ld{x + base};
+    dcv_colreduce_block<2, VEC>(ld, 0, (size_t)HW, C, scratch, chan);
+    const int cpg = C / G;
+    // per-group statistics, then per-channel scale/shift for this sample
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / cpg;
+        double s = 0.0, ss = 0.0;
+        for (int k = g * cpg; k < (g + 1) * cpg; ++k) { s += chan[k]; ss += chan[C + k]; }
+        const double m = (double)cpg * (double)HW;
+        const double mean = s / m;
+        double var = ss / m - mean * mean; if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        if (c == g * cpg) { save_mean[(size_t)n * G + g] = (float)mean; save_rstd[(size_t)n * G + g] = rstd; }
+        const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+        scale[c] = gm * rstd;
+        shift[c] = bt - (float)mean * gm * rstd;
+    }
+    __syncthreads();
+    const int CV = C / VEC;
+    const size_t nv = (size_t)HW * CV;
+    for (size_t i = threadIdx.x; i < nv; i += blockDim.x) {
+        const int c = (int)(i % CV) * VEC;
+        if constexpr (VEC == 4) {
+            const float4 v = reinterpret_cast<const float4*>(x + base)[i];
+            float4 o; o.x = v.x * scale[c] + shift[c]; o.y = v.y * scale[c + 1] + shift[c + 1];
+            o.z = v.z * scale[c + 2] + shift[c + 2]; o.w = v.w * scale[c + 3] + shift[c + 3];
+            reinterpret_cast<float4*>(y + base)[i] = o;
+        } else {
+            y[base + i] = x[base + i] * scale[c] + shift[c];
+        }
+    }
+}
+
+// backward: dx = rstd_g * (gamma_c*dy - A_g/m - xhat * B_g/m),  A_g = sum_{c in g} gamma_c * S1_c,  B_g = sum gamma_c * S2_c,
+// S1_c = sum_hw dy, S2_c = sum_hw dy*xhat;  per-sample S1/S2 are also written to `partial` [N][2][C] for the dgamma/dbeta reduce.
+template <int VEC>
+__global__ __launch_bounds__(DCV_CR_THREADS) void gn_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx,
+                                                                 int HW, int C, int G, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
+                                                                 double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* chan = reinterpret_cast<double*>(smem);                      // [2][C]  S1, S2
+    float* ca = reinterpret_cast<float*>(chan + 2 * (size_t)C);          // [C] gamma*rstd
+    float* cb = ca + C;                                                  // [C] rstd * A_g / m
+    float* cd = cb + C;                                                  // [C] rstd * B_g / m
+    float* scratch = cd + C;
+    const int n = blockIdx.x;
+    const size_t base = (size_t)n * HW * C;
+    const int cpg = C / G;
+    const float* mean = save_mean + (size_t)n * G;
+    const float* rstd = save_rstd + (size_t)n * G;
+    GnBwdLoader ld{dy + base, x + base, mean, rstd, cpg};
+    dcv_colreduce_block<2, VEC>(ld, 0, (size_t)HW, C, scratch, chan);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / cpg;
+        double A = 0.0, B = 0.0;
+        for (int k = g * cpg; k < (g + 1) * cpg; ++k) { const double gm = gamma ? (double)gamma[k] : 1.0; A += gm * chan[k]; B += gm * chan[C + k]; }
+        const double m = (double)cpg * (double)HW;
+        const float gm = gamma ? gamma[c] : 1.f;
+        ca[c] = gm * rstd[g];
+        cb[c] = (float)(A / m) * rstd[g];
+        cd[c] = (float)(B / m) * rstd[g];
+        if (partial) { partial[((size_t)n * 2 + 0) * C + c] = chan[c]; partial[((size_t)n * 2 + 1) * C + c] = chan[C + c]; }
+    }
+    __syncthreads();
+    const int CV = C / VEC;
+    const size_t nv = (size_t)HW * CV;
+    for (size_t i = threadIdx.x; i < nv; i += blockDim.x) {
+        const int c = (int)(i % CV) * VEC;
+        float d[VEC], v[VEC], o[VEC];
+        if constexpr (VEC == 4) {
+            const float4 d4 = reinterpret_cast<const float4*>(dy + base)[i]; const float4 v4 = reinterpret_cast<const float4*>(x + base)[i];
+            d[0] = d4.x; d[1] = d4.y; d[2] = d4.z; d[3] = d4.w; v[0] = v4.x; v[1] = v4.y; v[2] = v4.z; v[3] = v4.w;
+        } else { d[0] = dy[base + i]; v[0] = x[base + i]; }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const int g = (c + k) / cpg;
+            const float xhat = (v[k] - mean[g]) * rstd[g];
+            o[k] = ca[c + k] * d[k] - cb[c + k] - xhat * cd[c + k];
+        }
+        if constexpr (VEC == 4) { float4 o4; o4.x = o[0]; o4.y = o[1]; o4.z = o[2]; o4.w = o[3]; reinterpret_cast<float4*>(dx + base)[i] = o4; }
+        else dx[base + i] = o[0];
+    }
+}
+
+// dgamma[c] = sum_n partial[n][1][c], dbeta[c] = sum_n partial[n][0][c]   (ordered, fp64)
+__global__ void gn_param_grad_kernel(const double* __restrict__ partial, int N, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int n = 0; n < N; ++n) { s1 += partial[((size_t)n * 2 + 0) * C + c]; s2 += partial[((size_t)n * 2 + 1) * C + c]; }
+    if (dbeta) dbeta[c] = (float)s1;
+    if (dgamma) dgamma[c] = (float)s2;
+}
+
+inline size_t bn_ws_partial_bytes(size_t rows, int C) { return dcv_align_up((size_t)dcv_colreduce_blocks(rows, C) * 2 * C * sizeof(double), 256); }
+
+}  // namespace
+
+extern "C" {
+
+size_t dcv_batchnorm_workspace_bytes(size_t rows, int channels) {
+    if (rows == 0 || channels <= 0) return 0;
+    return bn_ws_partial_bytes(rows, channels) + dcv_align_up((size_t)3 * channels * sizeof(float), 256);
+}
+
+int dcv_batchnorm_fwd_train(const float* x, float* y, size_t rows, int C, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps,
+                            float* save_mean, float* save_rstd, void* ws, size_t ws_bytes, void* stream) {
+    DCV_CHECK_ARG(x && y && save_mean && save_rstd && ws && rows > 0 && C > 0);
+    if (ws_bytes < dcv_batchnorm_workspace_bytes(rows, C)) return DCV_ERR_WORKSPACE;
+    hipStream_t st = dcv_stream(stream);
+    double* partial = reinterpret_cast<double*>(ws);
+    float* scale_shift = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + bn_ws_partial_bytes(rows, C));
+    const unsigned nb = dcv_colreduce_blocks(rows, C);
+    SumSqLoader ld{x};
+    if (C % 4 == 0) hipLaunchKernelGGL((colreduce2_kernel<4, SumSqLoader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
+    else hipLaunchKernelGGL((colreduce2_kernel<1, SumSqLoader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((unsigned)dcv_ceil_div(C, 64)), dim3(64), 0, st, partial, (int)nb, rows, C, gamma, beta,
+                       running_mean, running_var, nbt, momentum, eps, save_mean, save_rstd, scale_shift);
+    if (C % 4 == 0) {
+        const size_t nv = rows * (size_t)C / 4;
+        hipLaunchKernelGGL((affine_apply_kernel<4>), dim3(dcv_stream_grid(nv, 256)), dim3(256), 0, st, x, y, nv, C, scale_shift);
+    } else {
+        const size_t nv = rows * (size_t)C;
+        hipLaunchKernelGGL((affine_apply_kernel<1>), dim3(dcv_stream_grid(nv, 256)), dim3(256), 0, st, x, y, nv, C, scale_shift);
+    }
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_batchnorm_fwd_eval(const float* x, float* y, size_t rows, int C, const float* gamma, const float* beta,
+                           const float* running_mean, const float* running_var, float eps, void* ws, size_t ws_bytes, void* stream) {
+    DCV_CHECK_ARG(x && y && running_mean && running_var && ws && rows > 0 && C > 0);
+    if (ws_bytes < dcv_batchnorm_workspace_bytes(rows, C)) return DCV_ERR_WORKSPACE;
+    hipStream_t st = dcv_stream(stream);
+    float* scale_shift = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + bn_ws_partial_bytes(rows, C));
+    hipLaunchKernelGGL(bn_finalize_eval_kernel, dim3((unsigned)dcv_ceil_div(C, 64)), dim3(64), 0, st, C, gamma, beta, running_mean, running_var, eps, scale_shift);
+    if (C % 4 == 0) {
+        const size_t nv = rows * (size_t)C / 4;
+        hipLaunchKernelGGL((affine_apply_kernel<4>), dim3(dcv_stream_grid(nv, 256)), dim3(256), 0, st, x, y, nv, C, scale_shift);
+    } else {
+        const size_t nv = rows * (size_t)C;
+        hipLaunchKernelGGL((affine_apply_kernel<1>), dim3(dcv_stream_grid(nv, 256)), dim3(256), 0, st, x, y, nv, C, scale_shift);
+    }
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_batchnorm_bwd(const float* dy, const float* x, float* dx, size_t rows, int C, const float* gamma,
+                      const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream) {
+    DCV_CHECK_ARG(dy && x && dx && save_mean && save_rstd && ws && rows > 0 && C > 0);
+    if (ws_bytes < dcv_batchnorm_workspace_bytes(rows, C)) return DCV_ERR_WORKSPACE;
+    hipStream_t st = dcv_stream(stream);
+    double* partial = reinterpret_cast<double*>(ws);
+    float* coef = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + bn_ws_partial_bytes(rows, C));
+    const unsigned nb = dcv_colreduce_blocks(rows, C);
+    BnBwdLoader ld{dy, x, save_mean, save_rstd};
+    if (C % 4 == 0) hipLaunchKernelGGL((colreduce2_kernel<4, BnBwdLoader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
+    else hipLaunchKernelGGL((colreduce2_kernel<1, BnBwdLoader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((unsigned)dcv_ceil_div(C, 64)), dim3(64), 0, st, partial, (int)nb, rows, C, gamma, save_rstd, dgamma, dbeta, coef);
+    if (C % 4 == 0) {
+        const size_t nv = rows * (size_t)C / 4;
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(dcv_stream_grid(nv, 256)), dim3(256), 0, st, dy, x, dx, nv, C, save_mean, save_rstd, coef);
+    } else {
+        const size_t nv = rows * (size_t)C;
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(dcv_stream_grid(nv, 256)), dim3(256), 0, st, dy, x, dx, nv, C, save_mean, save_rstd, coef);
+    }
+    DCV_RETURN_LAUNCH();
+}
+
+size_t dcv_groupnorm_workspace_bytes(int n, int channels) {
+    if (n <= 0 || channels <= 0) return 0;
+    return dcv_align_up((size_t)n * 2 * channels * sizeof(double), 256);
+}
+
+static size_t gn_smem_bytes(int C, int vec, int nfloat_arrays) {
+    return 2 * (size_t)C * sizeof(double) + (size_t)nfloat_arrays * C * sizeof(float) + (size_t)2 * DCV_CR_THREADS * vec * sizeof(float);
+}
+
+int dcv_groupnorm_fwd(const float* x, float* y, int n, int hw, int C, int G, const float* gamma, const float* beta, float eps,
+                      float* save_mean, float* save_rstd, void* stream) {
+    DCV_CHECK_ARG(x && y && save_mean && save_rstd && n > 0 && hw > 0 && C > 0 && G > 0 && C % G == 0);
+    hipStream_t st = dcv_stream(stream);
+    const int vec = (C % 4 == 0) ? 4 : 1;
+    const size_t smem = gn_smem_bytes(C, vec, 2);
+    if (smem > 64 * 1024) return DCV_ERR_UNSUPPORTED;
+    if (vec == 4) hipLaunchKernelGGL((gn_fwd_kernel<4>), dim3(n), dim3(DCV_CR_THREADS), smem, st, x, y, hw, C, G, gamma, beta, eps, save_mean, save_rstd);
+    else hipLaunchKernelGGL((gn_fwd_kernel<1>), dim3(n), dim3(DCV_CR_THREADS), smem, st, x, y, hw, C, G, gamma, beta, eps, save_mean, save_rstd);
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_groupnorm_bwd(const float* dy, const float* x, float* dx, int n, int hw, int C, int G, const float* gamma,
+                      const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream) {
+    DCV_CHECK_ARG(dy && x && dx && save_mean && save_rstd && n > 0 && hw > 0 && C > 0 && G > 0 && C % G == 0);
+    const bool need_param_grads = (dgamma != nullptr) || (dbeta != nullptr);
+    if (need_param_grads && (!ws || ws_bytes < dcv_groupnorm_workspace_bytes(n, C))) return DCV_ERR_WORKSPACE;
+    hipStream_t st = dcv_stream(stream);
+    const int vec = (C % 4 == 0) ? 4 : 1;
+    const size_t smem = gn_smem_bytes(C, vec, 3);
+    if (smem > 64 * 1024) return DCV_ERR_UNSUPPORTED;
+    double* partial = need_param_grads ? reinterpret_cast<double*>(ws) : nullptr;
+    if (vec == 4) hipLaunchKernelGGL((gn_bwd_kernel<4>), dim3(n), dim3(DCV_CR_THREADS), smem, st, dy, x, dx, hw, C, G, gamma, save_mean, save_rstd, partial);
+    else hipLaunchKernelGGL((gn_bwd_kernel<1>), dim3(n), dim3(DCV_CR_THREADS), smem, st, dy, x, dx, hw, C, G, gamma, save_mean, save_rstd, partial);
+    if (need_param_grads)
+        hipLaunchKernelGGL(gn_param_grad_kernel, dim3((unsigned)dcv_ceil_div(C, 64)), dim3(64), 0, st, partial, n, C, dgamma, dbeta);
+    DCV_RETURN_LAUNCH();
+}
+
+}  // extern "C"

@@ -1,0 +1,157 @@
+// optim.hip — fused multi-tensor AdamW / SGD steps and the data-parallel gradient-bucket pack.
+//
+// Roofline: HBM.  Algorithmic bytes per parameter: AdamW 28 B (read p,g,m,v; write p,m,v), SGD-momentum 20 B.
+// One launch updates up to DCV_MAX_TENSORS parameter tensors: the tensor table travels by value in the kernel arguments (no
+// H2D copy), grid = (chunks of the largest tensor, tensors).  Step-dependent scalars (lr, momentum, bias corrections) are read
+// from DEVICE memory so that a captured hipGraph replays with the scheduler's current values.
+//
+// Replaces torch.optim.AdamW (reference classification/image.py:71; options conf/base/parameters.yml:129-134), torch.optim.SGD
+// (parameters.yml:136) as called at ignite_training.py:254, and DDP's gradient bucketing (ignite_training.py:380).
+#include "common.h"
+
+namespace {
+
+#define OPT_BLOCK 256
+#define OPT_ELEMS_PER_BLOCK (OPT_BLOCK * 4)
+
+__global__ void optim_prepare_kernel(float* __restrict__ hyper, int64_t* __restrict__ step) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int64_t s = step[0] + 1;
+    step[0] = s;
+    hyper[DCV_HYP_BIAS_CORR1] = (float)(1.0 - pow((double)hyper[DCV_HYP_BETA1], (double)s));
+    hyper[DCV_HYP_BIAS_CORR2] = (float)(1.0 - pow((double)hyper[DCV_HYP_BETA2], (double)s));
+    hyper[DCV_HYP_FIRST_STEP] = (s == 1) ? 1.f : 0.f;
+}
+
+// torch.optim.AdamW single-tensor semantics:  p *= 1 - lr*wd ; m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ;
+// denom = sqrt(v)/sqrt(bc2) + eps ; p -= (lr/bc1) * m / denom      (amsgrad: denom from max(v_max, v))
+template <bool AMSGRAD>
+__global__ __launch_bounds__(OPT_BLOCK) void adamw_kernel(dcv_tensor_list tl, const float* __restrict__ hyper) {
+    const int t = blockIdx.y;
+    const int64_t n = tl.numel[t];
+    const int64_t base = (int64_t)blockIdx.x * OPT_ELEMS_PER_BLOCK;
+    if (base >= n) return;
+    const float lr = hyper[DCV_HYP_LR], b1 = hyper[DCV_HYP_BETA1], b2 = hyper[DCV_HYP_BETA2], eps = hyper[DCV_HYP_EPS];
+    const float wd = hyper[DCV_HYP_WEIGHT_DECAY], gs = hyper[DCV_HYP_GRAD_SCALE];
+    const float bc1 = hyper[DCV_HYP_BIAS_CORR1], bc2_sqrt = sqrtf(hyper[DCV_HYP_BIAS_CORR2]);
+    const float step_size = lr / bc1;
+    float* __restrict__ p = tl.param[t]; const float* __restrict__ g = tl.grad[t];
+    float* __restrict__ m = tl.state1[t]; float* __restrict__ v = tl.state2[t]; float* __restrict__ vmax = tl.state3[t];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t i = base + (int64_t)k * OPT_BLOCK + threadIdx.x;
+        if (i < n) {
+            const float gi = g[i] * gs;
+            float pi = p[i] * (1.f - lr * wd);
+            const float m0 = m[i];
+            const float mi = m0 + (1.f - b1) * (gi - m0);      // torch: exp_avg.lerp_(grad, 1 - beta1)
+            const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+            m[i] = mi; v[i] = vi;
+            float vden = vi;
+            if (AMSGRAD) { vden = fmaxf(vmax[i], vi); vmax[i] = vden; }
+            const float denom = sqrtf(vden) / bc2_sqrt + eps;
+            pi -= step_size * (mi / denom);
+            p[i] = pi;
+        }
+    }
+}
+
+// torch.optim.SGD semantics: g += wd*p ; buf = (first step) g : mu*buf + (1-dampening)*g ; g = nesterov ? g + mu*buf : buf ; p -= lr*g
+template <bool NESTEROV>
+__global__ __launch_bounds__(OPT_BLOCK) void sgd_kernel(dcv_tensor_list tl, const float* __restrict__ hyper) {
+    const int t = blockIdx.y;
+    const int64_t n = tl.numel[t];
+    const int64_t base = (int64_t)blockIdx.x * OPT_ELEMS_PER_BLOCK;
+    if (base >= n) return;
+    const float lr = hyper[DCV_HYP_LR], mu = hyper[DCV_HYP_BETA1], damp = hyper[DCV_HYP_BETA2];
+    const float wd = hyper[DCV_HYP_WEIGHT_DECAY], gs = hyper[DCV_HYP_GRAD_SCALE];
+    const bool first = hyper[DCV_HYP_FIRST_STEP] != 0.f;
+    float* __restrict__ p = tl.param[t]; const float* __restrict__ g = tl.grad[t]; float* __restrict__ buf = tl.state1[t];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t i = base + (int64_t)k * OPT_BLOCK + threadIdx.x;
+        if (i < n) {
+            const float pi = p[i];
+            float gi = g[i] * gs + wd * pi;
+            if (buf != nullptr) {
+                const float bi = first ? gi : mu * buf[i] + (1.f - damp) * gi;
+                buf[i] = bi;
+                gi = NESTEROV ? gi + mu * bi : bi;
+            }
+            p[i] = pi - lr * gi;
+        }
+    }
+}
+
+__global__ __launch_bounds__(OPT_BLOCK) void pack_kernel(dcv_tensor_list tl, float* __restrict__ dst) {
+    const int t = blockIdx.y;
+    const int64_t n = tl.numel[t];
+    const int64_t base = (int64_t)blockIdx.x * OPT_ELEMS_PER_BLOCK;
+    if (base >= n) return;
+    int64_t off = 0;
+    for (int k = 0; k < t; ++k) off += tl.numel[k];
+    const float* __restrict__ g = tl.grad[t];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t i = base + (int64_t)k * OPT_BLOCK + threadIdx.x;
+        if (i < n) dst[off + i] = g[i];
+    }
+}
+
+inline int list_grid(const dcv_tensor_list* tl, dim3* grid, bool need_param, bool need_state1, bool need_state2, bool need_state3) {
+    if (!tl || tl->count <= 0 || tl->count > DCV_MAX_TENSORS) return DCV_ERR_INVALID_ARG;
+    int64_t mx = 0;
+    for (int i = 0; i < tl->count; ++i) {
+        if (tl->numel[i] <= 0 || !tl->grad[i]) return DCV_ERR_INVALID_ARG;
+        if (need_param && !tl->param[i]) return DCV_ERR_INVALID_ARG;
+        if (need_state1 && !tl->state1[i]) return DCV_ERR_INVALID_ARG;
+        if (need_state2 && !tl->state2[i]) return DCV_ERR_INVALID_ARG;
+        if (need_state3 && !tl->state3[i]) return DCV_ERR_INVALID_ARG;
+        if (tl->numel[i] > mx) mx = tl->numel[i];
+    }
+    const int64_t bx = (mx + OPT_ELEMS_PER_BLOCK - 1) / OPT_ELEMS_PER_BLOCK;
+    if (bx > 0x7fffffffLL) return DCV_ERR_UNSUPPORTED;
+    *grid = dim3((unsigned)bx, (unsigned)tl->count, 1);
+    return DCV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dcv_optim_prepare(float* hyper, int64_t* step, void* stream) {
+    DCV_CHECK_ARG(hyper && step);
+    hipLaunchKernelGGL(optim_prepare_kernel, dim3(1), dim3(64), 0, dcv_stream(stream), hyper, step);
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_adamw_step(const dcv_tensor_list* tl, const float* hyper, int amsgrad, void* stream) {
+    DCV_CHECK_ARG(hyper);
+    dim3 grid;
+    const int rc = list_grid(tl, &grid, true, true, true, amsgrad != 0);
+    if (rc != DCV_OK) return rc;
+    if (amsgrad) hipLaunchKernelGGL((adamw_kernel<true>), grid, dim3(OPT_BLOCK), 0, dcv_stream(stream), *tl, hyper);
+    else hipLaunchKernelGGL((adamw_kernel<false>), grid, dim3(OPT_BLOCK), 0, dcv_stream(stream), *tl, hyper);
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_sgd_step(const dcv_tensor_list* tl, const float* hyper, int nesterov, void* stream) {
+    DCV_CHECK_ARG(hyper);
+    dim3 grid;
+    const int rc = list_grid(tl, &grid, true, false, false, false);
+    if (rc != DCV_OK) return rc;
+    if (nesterov) hipLaunchKernelGGL((sgd_kernel<true>), grid, dim3(OPT_BLOCK), 0, dcv_stream(stream), *tl, hyper);
+    else hipLaunchKernelGGL((sgd_kernel<false>), grid, dim3(OPT_BLOCK), 0, dcv_stream(stream), *tl, hyper);
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_pack_grads(const dcv_tensor_list* tl, float* dst_flat, void* stream) {
+    DCV_CHECK_ARG(dst_flat);
+    dim3 grid;
+    const int rc = list_grid(tl, &grid, false, false, false, false);
+    if (rc != DCV_OK) return rc;
+    hipLaunchKernelGGL(pack_kernel, grid, dim3(OPT_BLOCK), 0, dcv_stream(stream), *tl, dst_flat);
+    DCV_RETURN_LAUNCH();
+}
+
+}  // extern "C"

@@ -1,0 +1,133 @@
+// pool.hip — 2-D average / max pooling forward + backward on NHWC fp32 activations.
+//
+// Roofline: HBM.  Algorithmic bytes for 2x2/2: fwd 1.25 * 4 B * N*C*H*W, bwd 1.25 * 4 B * N*C*H*W
+// (+ 4 B per output element of argmax for max pooling).  One thread per (pixel, 4-channel vector): 16-B coalesced accesses.
+// The backward is a gather (each input pixel visits the windows that cover it), so it is deterministic without atomics.
+//
+// Replaces torch.nn.AvgPool2d (reference submodule_creators.py:168 -> nn.py:416) and torch.nn.MaxPool2d (reachable through nn_spec.py:158-169).
+#include "common.h"
+#include <float.h>
+
+namespace {
+
+template <int VEC, int MODE>
+__global__ __launch_bounds__(256) void pool_fwd_kernel(dcv_pool2d_desc d, const float* __restrict__ x, float* __restrict__ y, int32_t* __restrict__ argmax) {
+    const int CV = d.c / VEC;
+    const size_t total = (size_t)d.n * d.ho * d.wo * CV;
+    const float inv = 1.f / (float)(d.kh * d.kw);                        // count_include_pad=True
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % CV) * VEC; size_t p = i / CV;
+        const int wo = (int)(p % d.wo); p /= d.wo; const int ho = (int)(p % d.ho); const int n = (int)(p / d.ho);
+        const float* xs = x + (size_t)n * d.h * d.w * d.c;
+        float acc[VEC]; int32_t arg[VEC];
+        const int h0 = ho * d.stride_h - d.pad_h, w0 = wo * d.stride_w - d.pad_w;
+        const int32_t first = (h0 < 0 ? 0 : h0) * d.w + (w0 < 0 ? 0 : w0);   // torch initialises maxindex to the window's first in-range element
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) { acc[k] = (MODE == DCV_POOL_MAX) ? -INFINITY : 0.f; arg[k] = first; }
+        for (int r = 0; r < d.kh; ++r) {
+            const int h = h0 + r;
+            if (h < 0 || h >= d.h) continue;
+            for (int s = 0; s < d.kw; ++s) {
+                const int w = w0 + s;
+                if (w < 0 || w >= d.w) continue;
+                float v[VEC];
+                if constexpr (VEC == 4) { const float4 t = *reinterpret_cast<const float4*>(xs + ((size_t)h * d.w + w) * d.c + c); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+                else v[0] = xs[((size_t)h * d.w + w) * d.c + c];
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    if (MODE == DCV_POOL_MAX) {
+                        // torch semantics: strict '>' (first maximum wins), a NaN always replaces the running value
+                        if (v[k] > acc[k] || v[k] != v[k]) { acc[k] = v[k]; arg[k] = h * d.w + w; }
+                    } else acc[k] += v[k];
+                }
+            }
+        }
+        const size_t o = (((size_t)n * d.ho + ho) * d.wo + wo) * d.c + c;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            y[o + k] = (MODE == DCV_POOL_MAX) ? acc[k] : acc[k] * inv;
+            if (MODE == DCV_POOL_MAX) argmax[o + k] = arg[k];
+        }
+    }
+}
+
+__device__ __forceinline__ void window_range(int i, int pad, int k, int stride, int out_size, int& lo, int& hi) {
+    // windows o with o*stride - pad <= i < o*stride - pad + k
+    const int t = i + pad;
+    hi = t / stride; if (hi > out_size - 1) hi = out_size - 1;
+    const int u = t - k + 1;
+    lo = u <= 0 ? 0 : (u + stride - 1) / stride;
+}
+
+template <int VEC, int MODE>
+__global__ __launch_bounds__(256) void pool_bwd_kernel(dcv_pool2d_desc d, const float* __restrict__ dy, const int32_t* __restrict__ argmax, float* __restrict__ dx) {
+    const int CV = d.c / VEC;
+    const size_t total = (size_t)d.n * d.h * d.w * CV;
+    const float inv = 1.f / (float)(d.kh * d.kw);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % CV) * VEC; size_t p = i / CV;
+        const int w = (int)(p % d.w); p /= d.w; const int h = (int)(p % d.h); const int n = (int)(p / d.h);
+        int holo, hohi, wolo, wohi;
+        window_range(h, d.pad_h, d.kh, d.stride_h, d.ho, holo, hohi);
+        window_range(w, d.pad_w, d.kw, d.stride_w, d.wo, wolo, wohi);
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+        const int me = h * d.w + w;
+        for (int ho = holo; ho <= hohi; ++ho)
+            for (int wo = wolo; wo <= wohi; ++wo) {
+                const size_t o = (((size_t)n * d.ho + ho) * d.wo + wo) * d.c + c;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    if (MODE == DCV_POOL_MAX) { if (argmax[o + k] == me) acc[k] += dy[o + k]; }
+                    else acc[k] += dy[o + k] * inv;
+                }
+            }
+        const size_t xi = (((size_t)n * d.h + h) * d.w + w) * d.c + c;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) dx[xi + k] = acc[k];
+    }
+}
+
+inline bool pool_desc_ok(const dcv_pool2d_desc* d) {
+    if (!d || d->n <= 0 || d->h <= 0 || d->w <= 0 || d->c <= 0 || d->kh <= 0 || d->kw <= 0 || d->stride_h <= 0 || d->stride_w <= 0 || d->pad_h < 0 || d->pad_w < 0) return false;
+    if (d->pad_h * 2 > d->kh || d->pad_w * 2 > d->kw) return false;     // same restriction as torch
+    const int ho = (d->h + 2 * d->pad_h - d->kh) / d->stride_h + 1, wo = (d->w + 2 * d->pad_w - d->kw) / d->stride_w + 1;
+    return ho == d->ho && wo == d->wo && ho > 0 && wo > 0 && (d->mode == DCV_POOL_AVG || d->mode == DCV_POOL_MAX);
+}
+
+}  // namespace
+
+extern "C" {
+
+int dcv_pool2d_fwd(const dcv_pool2d_desc* d, const float* x, float* y, int32_t* argmax, void* stream) {
+    DCV_CHECK_ARG(pool_desc_ok(d) && x && y && (d->mode == DCV_POOL_AVG || argmax));
+    hipStream_t st = dcv_stream(stream);
+    const int vec = d->c % 4 == 0 ? 4 : 1;
+    const unsigned grid = dcv_stream_grid((size_t)d->n * d->ho * d->wo * (d->c / vec), 256);
+    if (d->mode == DCV_POOL_AVG) {
+        if (vec == 4) hipLaunchKernelGGL((pool_fwd_kernel<4, DCV_POOL_AVG>), dim3(grid), dim3(256), 0, st, *d, x, y, argmax);
+        else hipLaunchKernelGGL((pool_fwd_kernel<1, DCV_POOL_AVG>), dim3(grid), dim3(256), 0, st, *d, x, y, argmax);
+    } else {
+        if (vec == 4) hipLaunchKernelGGL((pool_fwd_kernel<4, DCV_POOL_MAX>), dim3(grid), dim3(256), 0, st, *d, x, y, argmax);
+        else hipLaunchKernelGGL((pool_fwd_kernel<1, DCV_POOL_MAX>), dim3(grid), dim3(256), 0, st, *d, x, y, argmax);
+    }
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_pool2d_bwd(const dcv_pool2d_desc* d, const float* dy, const int32_t* argmax, float* dx, void* stream) {
+    DCV_CHECK_ARG(pool_desc_ok(d) && dy && dx && (d->mode == DCV_POOL_AVG || argmax));
+    hipStream_t st = dcv_stream(stream);
+    const int vec = d->c % 4 == 0 ? 4 : 1;
+    const unsigned grid = dcv_stream_grid((size_t)d->n * d->h * d->w * (d->c / vec), 256);
+    if (d->mode == DCV_POOL_AVG) {
+        if (vec == 4) hipLaunchKernelGGL((pool_bwd_kernel<4, DCV_POOL_AVG>), dim3(grid), dim3(256), 0, st, *d, dy, argmax, dx);
+        else hipLaunchKernelGGL((pool_bwd_kernel<1, DCV_POOL_AVG>), dim3(grid), dim3(256), 0, st, *d, dy, argmax, dx);
+    } else {
+        if (vec == 4) hipLaunchKernelGGL((pool_bwd_kernel<4, DCV_POOL_MAX>), dim3(grid), dim3(256), 0, st, *d, dy, argmax, dx);
+        else hipLaunchKernelGGL((pool_bwd_kernel<1, DCV_POOL_MAX>), dim3(grid), dim3(256), 0, st, *d, dy, argmax, dx);
+    }
+    DCV_RETURN_LAUNCH();
+}
+
+}  // extern "C"

@@ -1,0 +1,169 @@
+""" DeepCV model base class (host-side mirror of `src/deepcv/meta/base_module.py:39-264`).
+
+`DeepcvModule(input_shape, hp, additional_submodule_creators=None, extend_basic_submodule_creators_dict=True, additional_init_logic=None)` builds a
+`torch.nn.Module` from a YAML architecture spec (`hp['architecture']`, see `deepcv_amd.meta.nn_spec`) exactly as the reference does — same
+constructor signature, `HP_DEFAULTS`, sub-module names, `_child_modules` container (hence `state_dict` keys) and parameter initialisation order
+(Xavier init consuming the CPU RNG in `Module.apply` post-order, `base_module.py:230-264`) — but the sub-modules the creators instantiate run on the
+hand-written HIP kernels.  `DeepcvModuleWithSharedImageBlock` (half-implemented in the reference, `:267-349`) is out of scope
+(SURVEY.md §2.1 row 1); `DeepcvModuleDescriptor` is kept in a compact form for `describe()` / `__str__`. """
+import copy
+import logging
+from collections import OrderedDict
+from functools import partial
+from typing import Any, Callable, Dict, List, Optional, Sequence, Set, Tuple, Type, Union
+
+import numpy as np
+import torch
+import torch.nn
+
+from ..utils import NL, NUMBER_T, human_readable_size
+from . import nn as deepcv_nn
+from . import nn_spec
+from .submodule_creators import ForwardCallbackSubmodule
+from .types_aliases import *
+
+__all__ = ['DeepcvModule', 'DeepcvModuleDescriptor']
+
+
+class DeepcvModule(torch.nn.Module):
+    """ DeepCV PyTorch Module model base class: NN architecture definition from a YAML spec, parameter initialisation and required/default
+    hyper-parameter logic.  By default `hp` must hold `architecture` and `act_fn`; `batch_norm`, `dropout_prob`, ... may be given globally in `hp`
+    or locally in a sub-module spec (local wins), and are handed to the sub-module creators whose signature names them (`nn_spec.py:172-182`).
+    `*args` / `**kwargs` creators are not supported (reference docstring `base_module.py:53`). """
+
+    # `...` marks required hyper-parameters (reference `base_module.py:68`)
+    HP_DEFAULTS = {'architecture': ..., 'act_fn': ..., 'weight_norm': None, 'spectral_norm': None}
+    SUBM_CREATOR_SPECIAL_ARGS = {'submodule_params', 'prev_shapes', 'input_shape', 'input_shapes'}
+
+    def __init__(self, input_shape: SIZE_OR_SEQ_OF_SIZE_T, hp: HYPERPARAMS_T, additional_submodule_creators: Optional[Dict[str, Union[Callable, Type[torch.nn.Module]]]] = None,
+                 extend_basic_submodule_creators_dict: bool = True, additional_init_logic: Callable[[torch.nn.Module, 'xavier_gain'], None] = None):
+        """ Args (reference `base_module.py:76-86`):
+            - input_shape: input tensor shape(s) without minibatch dim, channel dim first then spatial dims.
+            - hp: hyper-parameters mapping; `hp['architecture']` holds the NN architecture spec (see `conf/base/parameters.yml`).
+            - additional_submodule_creators: extra / overriding sub-module creators (name -> creator).
+            - extend_basic_submodule_creators_dict: whether the creators above extend `BASIC_SUBMODULE_CREATORS` or replace it.
+            - additional_init_logic: `fn(module, xavier_gain=...)` called for parametrised modules `_initialize_parameters` has no rule for. """
+        super().__init__()
+        from .hyperparams import to_hyperparameters
+        self._input_shape = tuple(input_shape) if isinstance(input_shape[0], NUMBER_T) else [tuple(s) for s in input_shape]
+        self._single_input_shape = isinstance(input_shape[0], NUMBER_T)
+        self._spatial_dims = len(input_shape[1:]) if self._single_input_shape else len(input_shape[0][1:])
+        self._uses_nni_nas_mutables = False
+        self._uses_forward_callback_submodules = False
+        self._additional_init_logic = additional_init_logic
+        self._child_modules = None
+
+        assert self.HP_DEFAULTS is not ..., f'Error: Module classes which inherits from "DeepcvModule" ({type(self).__name__}) must define "HP_DEFAULTS" class attribute dict.'
+        self._hp, _missing = to_hyperparameters(hp, defaults=self.HP_DEFAULTS, raise_if_missing=True)
+
+        nn_spec.define_nn_architecture(self, self._hp['architecture'], submodule_creators=additional_submodule_creators,
+                                       extend_basic_submodule_creators_dict=extend_basic_submodule_creators_dict)
+        self._initialize_parameters(self._hp['act_fn'], additional_init_logic=self._additional_init_logic)
+
+        # The reference applies torch's weight/spectral norm hooks to the *container*, which has no `weight` (base_module.py:106-111 -> KeyError);
+        # intended semantics are undefined and it is outside the hot path: refuse loudly rather than silently differ.
+        if self._hp['weight_norm'] is not None or self._hp['spectral_norm'] is not None:
+            raise NotImplementedError('`weight_norm` / `spectral_norm` hyper-parameters are not supported by deepcv_amd (set them to null); the reference applies them '
+                                      'to the container module which has no `weight` parameter (SURVEY.md Appendix A #22).')
+
+    def forward(self, x: TENSOR_OR_SEQ_OF_TENSORS_T) -> torch.Tensor:
+        """ Reference `base_module.py:113-155` (intended semantics). """
+        if not isinstance(x, torch.Tensor) and (self._single_input_shape or len(x) < len(self._input_shape)):
+            if self._single_input_shape and len(x) == 1:
+                x = x[0]
+            else:
+                raise ValueError(f'Error: No enought input tensors in "{type(self).__name__}", was expecting {1 if self._single_input_shape else len(self._input_shape)} '
+                                 f'tensor(s) but got {len(x)}.')
+        if self.is_sequential_nn():
+            return self._child_modules(x)
+
+        # Output tensor reference(s) (`_from`) need specific handling: stash referenced outputs until their last referrer consumed them
+        referenced_output_features: Dict[str, TENSOR_OR_SEQ_OF_TENSORS_T] = {}
+        remaining_refs = dict(self._submodule_references)
+        for name, subm in self._child_modules.items():
+            refs = getattr(subm, 'referenced_submodules', None)
+            if refs:
+                current = OrderedDict((ref, referenced_output_features[ref]) for ref in refs)
+                del remaining_refs[name]
+                for ref in refs:
+                    if not any(ref in r for r in remaining_refs.values()):
+                        del referenced_output_features[ref]   # no remaining referrer: release the stashed tensor
+                x = subm(x, referenced_submodules_out=current)
+            else:
+                x = subm(x)
+            if any(name in r for r in remaining_refs.values()):
+                referenced_output_features[name] = x
+        return x
+
+    def __str__(self) -> str:
+        return str(self.describe())
+
+    def uses_nni_nas_mutables(self, recursive: bool = False) -> bool:
+        if not recursive:
+            return self._uses_nni_nas_mutables
+        return self._uses_nni_nas_mutables or any(subm.uses_nni_nas_mutables(recursive=True) for subm in self._submodules.values() if isinstance(subm, DeepcvModule))
+
+    def uses_forward_callback_submodules(self, recursive: bool = False) -> bool:
+        if not recursive:
+            return self._uses_forward_callback_submodules
+        return self._uses_forward_callback_submodules or any(subm.uses_forward_callback_submodules(recursive=True) for subm in self._submodules.values() if isinstance(subm, DeepcvModule))
+
+    def is_sequential_nn(self, recursive: bool = False) -> bool:
+        """ Whether the architecture can be applied as a plain `torch.nn.Sequential` (no tensor references / forward-callback sub-modules). """
+        return not self.uses_nni_nas_mutables(recursive=recursive) and not self.uses_forward_callback_submodules(recursive=recursive)
+
+    def describe(self) -> 'DeepcvModuleDescriptor':
+        return DeepcvModuleDescriptor(self)
+
+    def _initialize_parameters(self, act_fn: Type[torch.nn.Module] = None, additional_init_logic: Callable[[torch.nn.Module, 'xavier_gain'], None] = None):
+        """ Xavier initialisation with a gain derived from the (global) activation function (reference `base_module.py:230-264`):
+        convolutions: `xavier_normal_` weights, zero bias; `Linear`: `xavier_uniform_`, zero bias; BatchNorm*d: gamma ~ U[0, 1), beta = 0.
+        Draws come from torch's CPU generator in `Module.apply` order (children first), so weights are bit-identical to the reference recipe for a
+        given seed; nested `DeepcvModule`s are (re-)initialised by their parent like in the reference.
+        Other parametrised modules (GroupNorm, LayerNorm, ...) go to `additional_init_logic` when given; otherwise they keep torch's default
+        initialisation (SURVEY.md Appendix A #21 — the reference raises `TypeError` there, which would make its own stock spec unusable). """
+        xavier_gain = torch.nn.init.calculate_gain(deepcv_nn.get_gain_name(act_fn)) if act_fn else None
+
+        def _raise_if_no_act_fn(sub_module_name: str):
+            if xavier_gain is None:
+                raise ValueError(f'Error: Must specify `act_fn` argument in `DeepcvModule._initialize_parameters` function in order to initialize '
+                                 f'{sub_module_name} sub-module(s) with Xavier Init.')
+
+        def _xavier_init(module: torch.nn.Module, additional_init: Callable[[torch.nn.Module, 'xavier_gain'], None]):
+            if deepcv_nn.is_conv(module):
+                _raise_if_no_act_fn('convolution')
+                torch.nn.init.xavier_normal_(module.weight.data, gain=xavier_gain)
+                if module.bias is not None:
+                    module.bias.data.fill_(0.)
+            elif deepcv_nn.is_fully_connected(module):
+                _raise_if_no_act_fn('fully connected')
+                torch.nn.init.xavier_uniform_(module.weight.data, gain=xavier_gain)
+                if module.bias is not None:
+                    module.bias.data.fill_(0.)
+            elif isinstance(module, torch.nn.modules.batchnorm._BatchNorm):
+                if module.weight is not None:
+                    torch.nn.init.uniform_(module.weight.data)   # gamma
+                    module.bias.data.fill_(0.)                   # beta
+            elif len(list(module.parameters(recurse=False))) > 0 and additional_init is not None:
+                additional_init(module, xavier_gain=xavier_gain)
+        self.apply(partial(_xavier_init, additional_init=additional_init_logic))
+
+
+class DeepcvModuleDescriptor:
+    """ Human-readable description of a `DeepcvModule`: capacity, sub-modules, feature shapes (compact form of reference `base_module.py:352-413`). """
+
+    def __init__(self, module: DeepcvModule):
+        self.module = module
+        self.capacity = deepcv_nn.get_model_capacity(module)
+        self.human_readable_capacity = human_readable_size(self.capacity * 4)
+        self.model_class_name = type(module).__name__
+        self.architecture = list(module._architecture_spec) if hasattr(module, '_architecture_spec') else []
+        self.submodules_names = list(module._submodules.keys())
+        self.submodules_capacities = list(module._submodules_capacities)
+        self.submodules_features_shapes = list(module._features_shapes[1:])
+
+    def __str__(self) -> str:
+        lines = [f'{self.model_class_name} (capacity: {self.capacity} parameters, {self.human_readable_capacity} as fp32)']
+        for name, cap, shape in zip(self.submodules_names, self.submodules_capacities, self.submodules_features_shapes):
+            lines.append(f'\t- {name}: capacity={cap}, output_features_shape={tuple(shape) if not isinstance(shape, list) else shape}')
+        return NL.join(lines)

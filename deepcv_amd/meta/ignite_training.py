@@ -1,0 +1,495 @@
+""" Training loop (host-side mirror of `src/deepcv/meta/ignite_training.py:1-404`, intended semantics of SURVEY.md Appendix A #24-39).
+
+`train(hp, model, losses, datasets, opt, backend_conf=BackendConfig(), loss_weights=None, metrics={}, callbacks_handler=None,
+nni_compression_pruner=None) -> (valid_metrics, state)` and `BackendConfig(device_or_id=None, dist_backend=None, dist_url=None)` keep the
+reference's signatures, hyper-parameter keys (`TRAINING_HP_DEFAULTS`, `ignite_training.py:201-203`), event order, per-iteration LR scheduling,
+checkpoint contents (`{'trainer', 'model', 'optimizer'[, 'scheduler']}`, `:263`), `crash_iteration` / `resume_from` behaviour and returned tuple.
+
+What is MI355X-native underneath:
+  * one optimisation step (`process_function`, `:233-255`) = native forward, softmax-CE, backward and fused optimizer kernels; for small models the
+    whole step is captured ONCE into a hipGraph and replayed (launch-latency bound otherwise) — the LR still changes every
+    iteration because the optimizer kernels read their scalars from device memory;
+  * `opt` / loss / metric TYPES injected by the caller are honoured; `torch.optim.AdamW|SGD` and `torch.nn.CrossEntropyLoss` are transparently
+    swapped for their native drop-ins when the model lives on a HIP device (same constructor arguments and state);
+  * data-parallel training = `deepcv_amd.parallel.DataParallelModel` (flat-bucket RCCL all-reduce over xGMI) instead of DDP (`:380`).
+pytorch-ignite, mlflow, tensorboard, nni and kedro are not dependencies: the engine subset is `deepcv_amd.meta.engine`; MLflow / TensorBoard logging
+hooks of the reference (`:278-283,300-307,365-367`) are observability only and are skipped when those packages are absent. """
+import logging
+import multiprocessing
+import traceback
+from collections import OrderedDict
+from datetime import datetime
+from pathlib import Path
+from typing import Any, Callable, Dict, Iterable, List, Mapping, Optional, Sequence, Tuple, Type, Union
+
+import torch
+import torch.distributed as dist
+import torch.nn
+from torch.utils.data import DataLoader, Dataset
+
+from .. import modules as native
+from .. import optim as native_optim
+from .. import utils
+from ..parallel import DataParallelModel
+from .data.datasets import dataloader_prefetch_batches
+from .engine import Accuracy, Engine, Events, Loss, Metric, RunningAverage, State, TerminateOnNan, create_supervised_evaluator
+from .hyperparams import to_hyperparameters
+from .types_aliases import *
+
+__all__ = ['MAIN_TRAINING_LOSS_NAME', 'BackendConfig', 'TRAINING_EVENTS', 'train', 'add_training_output_dir', 'GraphedTrainStep']
+
+MAIN_TRAINING_LOSS_NAME = 'main_loss'
+
+TRAINING_EVENTS = {'TRAINING_INIT', 'AFTER_TRAINING_INIT', 'ON_EPOCH_STARTED', 'ON_EPOCH_COMPLETED', 'ON_ITERATION_STARTED', 'ON_ITERATION_COMPLETED',
+                   'ON_EVAL_STARTED', 'ON_EVAL_COMPLETED', 'ON_TRAINING_COMPLETED'}
+
+
+class BackendConfig:
+    """ Training backend configuration for device and distributed training setup (reference `ignite_training.py:78-117`). """
+
+    def __init__(self, device_or_id: Union[None, str, int, torch.device] = None, dist_backend: Optional[str] = None, dist_url: Optional[str] = None):
+        if device_or_id is None:
+            self.device = utils.get_device()
+        elif isinstance(device_or_id, (str, torch.device)):
+            self.device = torch.device(device_or_id)
+        else:
+            self.device = utils.get_device(devid=device_or_id)
+        self.is_cpu = self.device.type == 'cpu'
+        self.is_cuda = self.device.type == 'cuda'   # HIP devices are exposed as 'cuda' by PyTorch-ROCm
+        self.ncpu = multiprocessing.cpu_count()
+        self.dist_backend = dist_backend
+        self.dist_url = dist_url
+        self.local_rank = getattr(self.device, 'index', None)
+        self.ngpus_current_node = torch.cuda.device_count()
+        self.rank, self.nnodes, self.gpus_world_size = 0, 1, 1
+        if self.distributed and dist.is_available() and dist.is_initialized():
+            self._refresh_from_process_group()
+
+    def _refresh_from_process_group(self):
+        self.rank = dist.get_rank()
+        self.gpus_world_size = dist.get_world_size()
+        self.nnodes = max(1, dist.get_world_size() // max(1, self.ngpus_current_node))
+
+    @property
+    def distributed(self) -> bool:
+        return self.dist_backend is not None and self.dist_backend != '' and self.dist_url is not None and self.dist_url != ''
+
+    def __repr__(self) -> str:
+        return self.__str__()
+
+    def __str__(self) -> str:
+        if self.is_cpu:
+            return f'single-node-cpu-{self.ncpu}'
+        if self.distributed:
+            return f'distributed-{self.nnodes}avg_nodes-{self.gpus_world_size}gpus_world_size-{self.ngpus_current_node}current-node-gpus(rank={self.rank})'
+        return f'single-node-{self.ngpus_current_node}-available-gpus'
+
+
+def add_training_output_dir(output_path: Union[str, Path], backend_conf: BackendConfig = None, prefix: str = '', named_after_datetime_now: bool = True) -> Path:
+    """ Determines the training experiment output directory and creates it on rank 0 (reference `ignite_training.py:124-135`, Appendix A #26). """
+    now = '-' + datetime.now().strftime(r'%Y_%m_%d-%HH_%Mmin') if named_after_datetime_now else ''
+    conf = '' if backend_conf is None else f'-{str(backend_conf)}'
+    out = Path(output_path) / f'{prefix}exp_output{now}{conf}'
+    if backend_conf is None or not backend_conf.distributed or backend_conf.rank == 0:
+        out.mkdir(parents=True, exist_ok=True)
+    return out
+
+
+def _nativize_loss(loss: Any, device: torch.device) -> Any:
+    if device.type == 'cuda' and type(loss) is torch.nn.CrossEntropyLoss:
+        try:
+            return native.CrossEntropyLoss(weight=loss.weight, ignore_index=loss.ignore_index, reduction=loss.reduction, label_smoothing=loss.label_smoothing)
+        except NotImplementedError:
+            logging.warning('deepcv_amd: non-default CrossEntropyLoss configuration: keeping the torch implementation for the loss')
+    return loss
+
+
+def _setup_losses(losses: LOSS_FN_TERMS_T, loss_weights=None, device: Union[str, torch.device] = None, default_name_prefix: str = 'loss_term_',
+                  main_training_loss_name: str = MAIN_TRAINING_LOSS_NAME) -> Tuple['OrderedDict[str, Callable]', 'OrderedDict[str, float]']:
+    """ Normalises `losses` / `loss_weights` (single callable, sequence or mapping; reference `ignite_training.py:138-176`) to named callables and weights.
+    A single term is named `main_loss` with weight 1 (`:152-153`); with several terms, `main_loss` = sum_i w_i * loss_i / sum_i w_i (Appendix A #27). """
+    device = torch.device(device) if device is not None else torch.device('cpu')
+    if loss_weights is not None and (isinstance(loss_weights, Mapping) != isinstance(losses, Mapping) or
+                                     getattr(losses, '__len__', lambda: 1)() != getattr(loss_weights, '__len__', lambda: 1)()):
+        raise TypeError(f'Error: `loss_weights` and `losses` should either both be mapping/dicts or both sequences of the same size (or single loss term and weight).{utils.NL}'
+                        f'Got `loss_weights="{loss_weights}"` and `losses="{losses}"`')
+    if not isinstance(losses, (Sequence, Mapping)):
+        named, weights = OrderedDict([(main_training_loss_name, losses)]), OrderedDict([(main_training_loss_name, 1.)])
+    elif isinstance(losses, Sequence):
+        names = [f'{default_name_prefix}{i}' if len(losses) > 1 else main_training_loss_name for i in range(len(losses))]
+        ws = list(loss_weights) if (loss_weights is not None and len(losses) > 1) else [1.] * len(losses)
+        named, weights = OrderedDict(zip(names, losses)), OrderedDict(zip(names, (float(w) for w in ws)))
+    else:
+        named = OrderedDict(losses)
+        weights = OrderedDict((n, float(loss_weights[n]) if (loss_weights is not None and len(losses) > 1) else 1.) for n in named)
+    for n, fn in list(named.items()):
+        fn = _nativize_loss(fn, device)
+        named[n] = fn.to(device) if isinstance(fn, torch.nn.Module) else fn
+    if sum(weights.values()) == 0.:
+        raise ValueError('Error: the sum of `loss_weights` must be different from zero')
+    return named, weights
+
+
+def _batch_losses(losses: 'OrderedDict[str, Callable]', weights: 'OrderedDict[str, float]', y_pred, y) -> 'OrderedDict[str, torch.Tensor]':
+    if len(losses) == 1:
+        name, fn = next(iter(losses.items()))
+        value = fn(y_pred, y)
+        out = OrderedDict([(name, value)])
+        out[MAIN_TRAINING_LOSS_NAME] = value   # a single term IS the training loss, whatever its name
+        return out
+    terms = OrderedDict((n, weights[n] * fn(y_pred, y)) for n, fn in losses.items())
+    if MAIN_TRAINING_LOSS_NAME not in terms:
+        total = None
+        for v in terms.values():
+            total = v if total is None else total + v
+        terms[MAIN_TRAINING_LOSS_NAME] = total / sum(weights.values())
+    return terms
+
+
+def _native_optimizer_type(opt: Type[torch.optim.Optimizer], device: torch.device) -> Type[torch.optim.Optimizer]:
+    """ torch.optim.AdamW / SGD -> fused HIP drop-ins when training on a HIP device (identical constructor arguments). """
+    if device.type != 'cuda':
+        return opt
+    return {torch.optim.AdamW: native_optim.AdamW, torch.optim.SGD: native_optim.SGD}.get(opt, opt)
+
+
+class GraphedTrainStep:
+    """ One optimisation step captured into hipGraph(s) and replayed: forward, losses, backward and optimizer kernels become a handful of graph launches
+    instead of ~100 host-side launches (the stock model's step is launch-latency bound).
+    Without data parallelism the whole step is ONE graph.  With a `GradientAllReducer`, forward+backward is one graph, the bucket pack + RCCL all-reduce
+    run eagerly in between, and the optimizer step is a second graph reading the reduced gradients from the bucket.
+    The first call runs eagerly (it creates the lazily allocated optimizer state), the second call captures, later calls replay.  Batches whose shape
+    differs from the captured one (last, smaller batch of an epoch) run eagerly. """
+
+    def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, losses, weights, reducer=None):
+        self.model, self.optimizer, self.losses, self.weights, self.reducer = model, optimizer, losses, weights, reducer
+        self.calls = 0
+        self.graph_fb = self.graph_opt = None
+        self.static_x = self.static_y = None
+        self.static_losses: Optional['OrderedDict[str, torch.Tensor]'] = None
+        self.static_pred = None
+
+    def _eager(self, x, y):
+        self.model.train()
+        y_pred = self.model(x)
+        batch_losses = _batch_losses(self.losses, self.weights, y_pred, y)
+        self.optimizer.zero_grad()
+        batch_losses[MAIN_TRAINING_LOSS_NAME].backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        self.optimizer.step()
+        return batch_losses, y_pred
+
+    def _capture(self, x, y):
+        dev = x.device
+        self.static_x, self.static_y = x.clone(), (y.clone() if isinstance(y, torch.Tensor) else y)
+        self.model.train()
+        self.optimizer.zero_grad(set_to_none=True)
+        hooks_were = None
+        if self.reducer is not None:
+            hooks_were, self.reducer.enabled = self.reducer.enabled, False     # no collectives inside the captured backward
+        torch.cuda.synchronize(dev)
+        self.graph_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_fb):
+            self.static_pred = self.model(self.static_x)
+            self.static_losses = _batch_losses(self.losses, self.weights, self.static_pred, self.static_y)
+            self.static_losses[MAIN_TRAINING_LOSS_NAME].backward()
+            if self.reducer is None:
+                self.optimizer.step()
+        if self.reducer is not None:
+            self.reducer.enabled = hooks_were
+            self._static_grads = [p.grad for p in self.reducer.params]       # graph-pool gradient tensors written by every replay
+            self.reducer.finish()                                            # p.grad -> bucket views (static addresses)
+            self.graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_opt):
+                self.optimizer.step()
+        torch.cuda.synchronize(dev)
+
+    def _replay(self, x, y):
+        self.static_x.copy_(x, non_blocking=True)
+        if isinstance(y, torch.Tensor):
+            self.static_y.copy_(y, non_blocking=True)
+        if hasattr(self.optimizer, 'sync_hyper'):
+            self.optimizer.sync_hyper()
+        self.graph_fb.replay()
+        if self.reducer is not None:
+            for p, g in zip(self.reducer.params, self._static_grads):
+                p.grad = g
+            self.reducer.finish()
+            self.graph_opt.replay()
+        return self.static_losses, self.static_pred
+
+    def __call__(self, x, y):
+        self.calls += 1
+        if self.calls == 1:
+            return self._eager(x, y)
+        if self.graph_fb is None:
+            self._capture(x, y)
+        if x.shape != self.static_x.shape or (isinstance(y, torch.Tensor) and y.shape != self.static_y.shape):
+            return self._eager(x, y)
+        return self._replay(x, y)
+
+
+def train(hp: HYPERPARAMS_T, model: torch.nn.Module, losses: LOSS_FN_TERMS_T = None, datasets: Union[Dict[str, Dataset], Tuple[Dataset, ...]] = None,
+          opt: Type[torch.optim.Optimizer] = None, backend_conf: BackendConfig = None, loss_weights: Sequence[FLOAT_OR_FLOAT_TENSOR_T] = None,
+          metrics: Dict[str, METRIC_FN_T] = None, callbacks_handler=None, nni_compression_pruner=None, loss: LOSS_FN_TERMS_T = None) -> Tuple[METRICS_DICT_T, State]:
+    """ PyTorch model training procedure (reference `ignite_training.py:178-370`).
+
+    Args:
+        - hp: hyper-parameters; required: `optimizer_opts`, `epochs`, `batch_size`; optional: see `TRAINING_HP_DEFAULTS` below (reference `:201-203`), plus
+          `hip_graph` (None = auto: capture the step into a hipGraph when the model has fewer than 5M parameters), `num_workers`, `bucket_cap_mb`.
+        - model: `torch.nn.Module` to train (e.g. a `DeepcvModule`)
+        - losses (alias `loss`, Appendix A #24): a loss callable/module, a sequence, or a mapping name -> loss; see `loss_weights`
+        - datasets: `{'trainset': ..., 'validset': ...[, 'testset': ...]}` (or a 2/3-tuple in that order) of `torch.utils.data.Dataset`s (Appendix A #29)
+        - opt: optimizer TYPE, instantiated as `opt(model.parameters(), **hp['optimizer_opts'])` (`:224`)
+        - backend_conf: device / distributed configuration
+        - loss_weights: weights of the loss terms; the trained loss is their weighted mean (`:190-192`)
+        - metrics: additional evaluation metrics (name -> `deepcv_amd.meta.engine.Metric` or callable `(y_pred, y) -> value`); losses are always evaluated
+        - callbacks_handler: optional object with `fire(event_name, **kwargs)`; events of `TRAINING_EVENTS` are fired (`:120-122`)
+        - nni_compression_pruner: optional object with `update_epoch(epoch)` / `step()` notified like the reference (`:335-344`)
+    Returns `(valid_metrics, state)`: metrics of the last validation run and the trainer's final `State`. """
+    TRAINING_HP_DEFAULTS = {'optimizer_opts': ..., 'epochs': ..., 'batch_size': ..., 'scheduler': None, 'output_path': Path.cwd() / 'data/04_training/',
+                            'log_output_dir_to_mlflow': True, 'validate_every_epochs': 1, 'save_every_iters': 1000, 'log_grads_every_iters': -1,
+                            'log_progress_every_iters': 100, 'seed': None, 'prefetch_batches': True, 'resume_from': '', 'crash_iteration': -1,
+                            'deterministic_cudnn': False, 'use_sync_batch_norm': False, 'hip_graph': None, 'num_workers': None, 'bucket_cap_mb': 32.}
+    losses = losses if losses is not None else loss
+    backend_conf = backend_conf if backend_conf is not None else BackendConfig()
+    metrics = dict(metrics) if metrics else {}
+    if losses is None or datasets is None or opt is None:
+        raise ValueError('Error: `losses` (or `loss`), `datasets` and `opt` arguments are mandatory')
+    if not isinstance(datasets, Mapping):
+        datasets = OrderedDict(zip(('trainset', 'validset', 'testset'), datasets))
+    assert len(datasets) in (2, 3) and 'trainset' in datasets, 'Error: datasets must contain `trainset`, `validset` and optionally `testset`'
+    logging.info(f'Starting training procedure to train "{type(model).__name__}" model...')
+    hp = dict(hp)
+    if 'deterministic' in hp and 'deterministic_cudnn' not in hp:
+        hp['deterministic_cudnn'] = hp['deterministic']   # both spellings accepted (Appendix A #28)
+    hp, _ = to_hyperparameters(hp, TRAINING_HP_DEFAULTS, raise_if_missing=True)
+    device = backend_conf.device
+    if hp['seed'] is not None:
+        utils.setup_cudnn(deterministic=hp['deterministic_cudnn'], seed=backend_conf.rank + hp['seed'])   # different seed per worker (`:208`)
+
+    def _fire(event: str, **kwargs):
+        if callbacks_handler is not None and hasattr(callbacks_handler, 'fire'):
+            callbacks_handler.fire(event, **kwargs)
+    _fire('TRAINING_INIT', hp=hp, model=model)
+
+    # Distributed setup first: samplers need the process group (`:373-390`, Appendix A #34)
+    model = model.to(device, non_blocking=True)
+    model, reducer = _setup_distributed_training(device, backend_conf, model, use_sync_batch_norm=hp['use_sync_batch_norm'], bucket_cap_mb=hp['bucket_cap_mb'])
+
+    # Dataloaders (`:210-219`); evaluation batches are 32x larger than training ones (`:215`)
+    if hp['num_workers'] is not None:
+        num_workers = int(hp['num_workers'])
+    else:
+        num_workers = max(1, (backend_conf.ncpu - 1) // (backend_conf.ngpus_current_node if backend_conf.ngpus_current_node > 0 and backend_conf.distributed else 1))
+    train_sampler = None
+    dataloaders = OrderedDict()
+    for n, ds in datasets.items():
+        is_train = n == 'trainset'
+        sampler = None
+        if is_train and backend_conf.distributed:
+            train_sampler = sampler = torch.utils.data.distributed.DistributedSampler(ds, seed=hp['seed'] or 0)   # sampler over the DATASET (Appendix A #31)
+        dl = DataLoader(ds, batch_size=hp['batch_size'] if is_train else hp['batch_size'] * 32, shuffle=(is_train and sampler is None), sampler=sampler,
+                        num_workers=num_workers, pin_memory=backend_conf.is_cuda, persistent_workers=num_workers > 0)   # pin for GPU training (Appendix A #30)
+        dataloaders[n] = dataloader_prefetch_batches(dl, device=device) if (hp['prefetch_batches'] and backend_conf.is_cuda) else dl
+    trainset = dataloaders['trainset']
+    validset = dataloaders.get('validset', None)
+
+    losses, weights = _setup_losses(losses=losses, loss_weights=loss_weights, device=device)
+    opt = _native_optimizer_type(opt, device)
+    optimizer = opt(model.parameters(), **dict(hp['optimizer_opts']))
+    output_path = add_training_output_dir(hp['output_path'], backend_conf)
+    scheduler = None
+    if hp['scheduler'] is not None:
+        args_to_eval = hp['scheduler']['eval_args'] if 'eval_args' in hp['scheduler'] else {}
+        scheduler_kwargs = {n: eval(v, {'hp': hp, 'iterations': len(trainset)}) if n in args_to_eval else v for n, v in hp['scheduler'].get('kwargs', {}).items()}
+        scheduler = hp['scheduler']['type'](optimizer=optimizer, **scheduler_kwargs)
+
+    use_graph = hp['hip_graph']
+    if use_graph is None:
+        use_graph = backend_conf.is_cuda and sum(p.numel() for p in model.parameters()) < 5_000_000
+    graphed_step = GraphedTrainStep(model, optimizer, losses, weights, reducer=reducer) if (use_graph and backend_conf.is_cuda) else None
+    if graphed_step is not None and reducer is not None:
+        reducer.remove_hooks()   # the captured backward cannot launch collectives; finish() reduces everything after the replay
+
+    def _split_batch(batch):
+        x, *y = batch
+        return x, (y[0] if len(y) == 1 else y)
+
+    def process_function(engine: Engine, batch) -> Dict[str, float]:
+        """ One optimisation step (reference `ignite_training.py:233-255`). """
+        if hp['prefetch_batches'] and hasattr(engine._dataloader_iter, '_prefetched_batch'):
+            x, y = _split_batch(batch)   # already on the device (prefetched on the copy stream)
+        else:
+            x, y = _split_batch(tuple(b.to(device, non_blocking=True) if isinstance(b, torch.Tensor) else b for b in batch))
+        if graphed_step is not None:
+            batch_losses, _ = graphed_step(x, y)
+        else:
+            model.train()
+            y_pred = model(x)
+            batch_losses = _batch_losses(losses, weights, y_pred, y)
+            optimizer.zero_grad()
+            batch_losses[MAIN_TRAINING_LOSS_NAME].backward()
+            if reducer is not None:
+                reducer.finish()
+            optimizer.step()
+        return {n: v.item() for n, v in batch_losses.items()}   # device -> host sync every step, like the reference (`:255`)
+
+    trainer = Engine(process_function)
+
+    # Common training handlers (what `setup_common_training_handlers` installs at `:265-276`)
+    if train_sampler is not None:
+        trainer.add_event_handler(Events.EPOCH_STARTED, lambda e: train_sampler.set_epoch(e.state.epoch - 1))
+    if scheduler is not None:
+        trainer.add_event_handler(Events.ITERATION_STARTED, scheduler)
+    trainer.add_event_handler(Events.ITERATION_COMPLETED, TerminateOnNan())
+    metric_names = list(losses.keys()) + ([MAIN_TRAINING_LOSS_NAME] if MAIN_TRAINING_LOSS_NAME not in losses else [])
+    for n in metric_names:
+        RunningAverage(output_transform=lambda out, n=n: out[n]).attach(trainer, n)
+    to_save = {'trainer': trainer, 'model': model, 'optimizer': optimizer, **({} if scheduler is None else {'scheduler': scheduler})}   # Appendix A #32
+    if hp['save_every_iters'] and hp['save_every_iters'] > 0 and backend_conf.rank == 0:
+        @trainer.on(Events.ITERATION_COMPLETED(every=int(hp['save_every_iters'])))
+        def _save_checkpoint(engine: Engine):
+            _save_objects(to_save, output_path / f'training_checkpoint_{engine.state.iteration}.pt')
+    if backend_conf.rank == 0 and hp['log_progress_every_iters']:
+        @trainer.on(Events.ITERATION_COMPLETED(every=int(hp['log_progress_every_iters'])))
+        def _log_progress(engine: Engine):
+            lr = optimizer.param_groups[0]['lr']
+            logging.info(f'Epoch {engine.state.epoch}/{engine.state.max_epochs} it {engine.state.iteration}: ' +
+                         ', '.join(f'{n}={v:.5f}' for n, v in engine.state.metrics.items()) + f', lr={lr:.3e}')
+
+    # Evaluators (`:285-311`): metrics + loss terms, prefixed with 'valid_' / 'train_'
+    def _metrics(prefix: str) -> Dict[str, Metric]:
+        ms = {}
+        for n, m in metrics.items():
+            ms[f'{prefix}_{n}'] = m if isinstance(m, Metric) else Loss(m)
+        for n, fn in losses.items():
+            ms[f'{prefix}_{n}'] = Loss(fn)
+        return ms
+
+    def _prepare(batch):
+        x, y = _split_batch(batch)
+        if isinstance(x, torch.Tensor) and x.device != device:
+            x = x.to(device, non_blocking=True)
+        if isinstance(y, torch.Tensor) and y.device != device:
+            y = y.to(device, non_blocking=True)
+        return x, y
+    valid_evaluator = create_supervised_evaluator(model, metrics=_metrics('valid'), device=device, non_blocking=True, prepare_batch=_prepare)
+    train_evaluator = create_supervised_evaluator(model, metrics=_metrics('train'), device=device, non_blocking=True, prepare_batch=_prepare)
+    best_scores: List[Tuple[float, Path]] = []
+
+    @trainer.on(Events.EPOCH_STARTED(every=int(hp['validate_every_epochs'])))
+    @trainer.on(Events.COMPLETED)
+    def _run_validation(engine: Engine):
+        if backend_conf.is_cuda:
+            torch.cuda.synchronize(device)
+        _fire('ON_EVAL_STARTED', engine=engine)
+        train_state = train_evaluator.run(trainset)
+        train_metrics = {n: float(v) for n, v in train_state.metrics.items()}
+        valid_metrics = {}
+        if validset is not None:
+            valid_state = valid_evaluator.run(validset)
+            valid_metrics = {n: float(v) for n, v in valid_state.metrics.items()}
+        _log_metrics_to_mlflow({**train_metrics, **valid_metrics}, step=engine.state.epoch)
+        logging.info(f'Evaluation at epoch {engine.state.epoch}: ' + ', '.join(f'{n}={v:.5f}' for n, v in {**train_metrics, **valid_metrics}.items()))
+        # keep the 3 best models by validation accuracy (`:325`)
+        if backend_conf.rank == 0 and 'valid_accuracy' in valid_metrics:
+            score = valid_metrics['valid_accuracy']
+            if len(best_scores) < 3 or score > min(s for s, _ in best_scores):
+                fp = output_path / f'best_model_val_accuracy={score:.4f}_{engine.state.iteration}.pt'
+                torch.save(_unwrap(model).state_dict(), fp)
+                best_scores.append((score, fp))
+                best_scores.sort(key=lambda t: t[0], reverse=True)
+                for _, old in best_scores[3:]:
+                    old.unlink(missing_ok=True)
+                del best_scores[3:]
+        _fire('ON_EVAL_COMPLETED', engine=engine, train_metrics=train_metrics, valid_metrics=valid_metrics)
+
+    if hp['crash_iteration'] is not None and hp['crash_iteration'] >= 0:
+        @trainer.on(Events.ITERATION_STARTED(once=int(hp['crash_iteration'])))
+        def _crash(engine: Engine):
+            raise Exception('STOP at iteration: {}'.format(engine.state.iteration))   # fault injection hook (`:330-333`)
+
+    if nni_compression_pruner is not None:
+        trainer.add_event_handler(Events.EPOCH_STARTED, lambda e: nni_compression_pruner.update_epoch(e.state.epoch))
+        if callable(getattr(nni_compression_pruner, 'step', None)):
+            trainer.add_event_handler(Events.ITERATION_COMPLETED, lambda e: nni_compression_pruner.step())
+
+    trainer.add_event_handler(Events.EPOCH_STARTED, lambda e: _fire('ON_EPOCH_STARTED', engine=e))
+    trainer.add_event_handler(Events.EPOCH_COMPLETED, lambda e: _fire('ON_EPOCH_COMPLETED', engine=e))
+    trainer.add_event_handler(Events.ITERATION_STARTED, lambda e: _fire('ON_ITERATION_STARTED', engine=e))
+    trainer.add_event_handler(Events.ITERATION_COMPLETED, lambda e: _fire('ON_ITERATION_COMPLETED', engine=e))
+
+    _resume_training(hp.get('resume_from'), to_save)
+    _fire('AFTER_TRAINING_INIT', trainer=trainer, optimizer=optimizer, scheduler=scheduler)
+
+    try:
+        logging.info(f'> running training loop for "{type(model).__name__}" model...')
+        state = trainer.run(trainset, max_epochs=hp['epochs'])
+        logging.info(f'Training of "{type(model).__name__}" model done sucessfully.')
+        _fire('ON_TRAINING_COMPLETED', state=state)
+        return (dict(valid_evaluator.state.metrics), state)
+    except Exception as e:
+        logging.error(f'Training loop of "{type(model).__name__}" model failed, exception "{e}" raised{utils.NL}### Traceback ###{utils.NL}{traceback.format_exc()}')
+        raise RuntimeError(f'Error: `{e}` exception raised during training loop of "{type(model).__name__}" model...') from e
+    finally:
+        if hp['log_output_dir_to_mlflow']:
+            _log_artifacts_to_mlflow(output_path)
+
+
+def _unwrap(model: torch.nn.Module) -> torch.nn.Module:
+    return model.module if isinstance(model, DataParallelModel) else model
+
+
+def _setup_distributed_training(device, backend_conf: BackendConfig, model: torch.nn.Module, use_sync_batch_norm: bool = False, bucket_cap_mb: float = 32.):
+    """ Process-group initialisation + data-parallel wrapping (reference `ignite_training.py:373-390`).  The reference asserts CUDA; this build also accepts
+    the `gloo` backend on CPU so that the sharding / averaging logic is testable without GPUs.  Returns `(model, reducer | None)`. """
+    if not backend_conf.distributed:
+        return model, None   # single-process DataParallel fallback of the reference (`:387-389`) is superseded
+    if not dist.is_initialized():
+        dist.init_process_group(backend_conf.dist_backend, init_method=backend_conf.dist_url)
+    backend_conf._refresh_from_process_group()
+    if backend_conf.is_cuda:
+        torch.cuda.set_device(backend_conf.device)
+    if use_sync_batch_norm and any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in model.modules()):
+        raise NotImplementedError('`use_sync_batch_norm` (collective C4, SURVEY.md §2.3) is not implemented yet: BatchNorm statistics stay per GPU (the reference default)')
+    wrapped = DataParallelModel(model, bucket_cap_mb=bucket_cap_mb, overlap=True)
+    return wrapped, wrapped.reducer
+
+
+def _save_objects(to_save: Dict[str, Any], path: Path):
+    """ ignite `Checkpoint` layout: one dict of `state_dict()`s keyed like `to_save` (`ignite_training.py:263-268`). """
+    path.parent.mkdir(parents=True, exist_ok=True)
+    torch.save({k: (_unwrap(v).state_dict() if isinstance(v, torch.nn.Module) else v.state_dict()) for k, v in to_save.items()}, path)
+
+
+def _resume_training(resume_from: Union[str, Path, None], to_save: Dict[str, Any]):
+    """ Reference `ignite_training.py:393-399`. """
+    if resume_from:
+        checkpoint_fp = Path(resume_from)
+        assert checkpoint_fp.exists(), f'Checkpoint "{checkpoint_fp}" is not found'
+        logging.info(f'Resuming from a checkpoint: {checkpoint_fp}')
+        checkpoint = torch.load(checkpoint_fp.as_posix(), map_location='cpu', weights_only=False)
+        for k, obj in to_save.items():
+            if k in checkpoint:
+                (_unwrap(obj) if isinstance(obj, torch.nn.Module) else obj).load_state_dict(checkpoint[k])
+
+
+def _log_metrics_to_mlflow(metrics: Dict[str, float], step: int):
+    try:
+        import mlflow
+    except ImportError:
+        return
+    if mlflow.active_run():
+        for n, v in metrics.items():
+            mlflow.log_metric(n, v, step=step)
+
+
+def _log_artifacts_to_mlflow(output_path: Path):
+    try:
+        import mlflow
+    except ImportError:
+        return
+    if mlflow.active_run():
+        mlflow.log_artifacts(str(output_path))

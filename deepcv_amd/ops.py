@@ -1,0 +1,544 @@
+""" `torch.autograd.Function`s over the native HIP kernels (`deepcv_amd/_native.py` -> `libdeepcv_hip.so`).
+
+PyTorch is plumbing here (device memory from the caching allocator, the current HIP stream, autograd bookkeeping); every
+arithmetic op of the hot path — K1..K11 of SURVEY.md §2.3 — runs in a hand-written gfx950 kernel.  Activations are 4-D tensors
+with logical NCHW shape (what the reference's modules expose, `src/deepcv/meta/base_module.py:80`) and `torch.channels_last`
+strides, i.e. NHWC in memory, which is the layout the kernels are written for.  There is no CPU / eager fallback. """
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _native as nat
+from ._native import lib
+
+__all__ = ['conv2d', 'activation', 'batch_norm', 'group_norm', 'pool2d', 'interpolate_bilinear', 'concat_channels', 'add_tensors', 'flatten_nchw_order',
+           'linear', 'cross_entropy', 'act_code', 'to_nhwc', 'nchw_to_nhwc']
+
+_CL = torch.channels_last
+
+
+def _require_f32(*tensors):
+    for t in tensors:
+        if t is not None:
+            nat.require_device(t)
+            if t.dtype != torch.float32:
+                raise TypeError(f'deepcv_amd: fp32 tensors expected, got {t.dtype}')
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def _is_nhwc(t: torch.Tensor) -> bool:
+    return t.dim() == 4 and t.is_contiguous(memory_format=_CL)
+
+
+def to_nhwc(t: torch.Tensor) -> torch.Tensor:
+    """ Returns `t` with channels-last strides; uses the native transpose kernel when a real layout change is needed. """
+    if _is_nhwc(t):
+        return t
+    if t.dim() == 4 and t.is_contiguous():
+        return nchw_to_nhwc(t)
+    return t.contiguous(memory_format=_CL)   # exotic strides coming from foreign torch ops: let torch normalise them
+
+
+def nchw_to_nhwc(t: torch.Tensor) -> torch.Tensor:
+    """ NCHW-contiguous -> channels_last copy through `dcv_transpose_inner` ([N][C][HW] -> [N][HW][C]). """
+    _require_f32(t)
+    n, c, h, w = t.shape
+    out = torch.empty((n, c, h, w), dtype=t.dtype, device=t.device, memory_format=_CL)
+    nat.check(lib.dcv_transpose_inner(t.data_ptr(), out.data_ptr(), n, c, h * w, nat.current_stream(t.device)), 'dcv_transpose_inner')
+    return out
+
+
+def act_code(act_fn) -> Tuple[int, float]:
+    """ Maps an activation module / type / None to (`DCV_ACT_*`, slope); raises for activations without a native kernel. """
+    if act_fn is None or act_fn is torch.nn.Identity or isinstance(act_fn, torch.nn.Identity):
+        return nat.ACT_NONE, 0.
+    inst = act_fn() if isinstance(act_fn, type) else act_fn
+    if isinstance(inst, torch.nn.LeakyReLU):
+        return nat.ACT_LEAKY_RELU, float(inst.negative_slope)
+    if isinstance(inst, torch.nn.ReLU):
+        return nat.ACT_RELU, 0.
+    if isinstance(inst, torch.nn.Sigmoid):
+        return nat.ACT_SIGMOID, 0.
+    if isinstance(inst, torch.nn.Tanh):
+        return nat.ACT_TANH, 0.
+    raise NotImplementedError(f'deepcv_amd: no native kernel for activation {type(inst).__name__} (supported: ReLU, LeakyReLU, Sigmoid, Tanh, Identity)')
+
+
+# ------------------------------------------------------------------------------------------------ conv2d (+ fused bias / activation)
+
+def _conv_desc(x_shape, w_shape, stride, padding, dilation, x_layout, act, slope) -> nat.Conv2dDesc:
+    n, cin, h, w = x_shape
+    cout, cin_w, r, s = w_shape
+    if cin_w != cin:
+        raise ValueError(f'deepcv_amd.conv2d: weight expects {cin_w} input channels, input has {cin} (groups != 1 is unsupported)')
+    ho = (h + 2 * padding[0] - dilation[0] * (r - 1) - 1) // stride[0] + 1
+    wo = (w + 2 * padding[1] - dilation[1] * (s - 1) - 1) // stride[1] + 1
+    if ho <= 0 or wo <= 0:
+        raise ValueError(f'deepcv_amd.conv2d: empty output for input {tuple(x_shape)} and kernel {(r, s)}')
+    return nat.Conv2dDesc(n, h, w, cin, cout, r, s, stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1], 1, ho, wo,
+                          x_layout, act, slope)
+
+
+class _Conv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, dilation, act, slope):
+        _require_f32(x, weight, bias)
+        if _is_nhwc(x):
+            layout = nat.LAYOUT_NHWC
+        elif x.is_contiguous():
+            layout = nat.LAYOUT_NCHW          # e.g. the dataloader's NCHW batch feeding the first layer: read in place, no copy
+        else:
+            x, layout = to_nhwc(x), nat.LAYOUT_NHWC
+        weight = weight.contiguous()
+        d = _conv_desc(x.shape, weight.shape, stride, padding, dilation, layout, act, slope)
+        y = torch.empty((d.n, d.cout, d.ho, d.wo), dtype=x.dtype, device=x.device, memory_format=_CL)
+        ws = _ws(lib.dcv_conv2d_fwd_workspace_bytes(d), x.device)
+        nat.check(lib.dcv_conv2d_fwd(d, x.data_ptr(), weight.data_ptr(), nat.ptr(bias), y.data_ptr(), ws.data_ptr(), ws.numel(),
+                                     nat.current_stream(x.device)), 'dcv_conv2d_fwd')
+        ctx.desc, ctx.has_bias = d, bias is not None
+        ctx.save_for_backward(x, weight, y if act != nat.ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        d = ctx.desc
+        dev = dy.device
+        st = nat.current_stream(dev)
+        dy = to_nhwc(dy)
+        rows = d.n * d.ho * d.wo
+        db = torch.empty(d.cout, dtype=dy.dtype, device=dev) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        db_done = False
+        if d.act != nat.ACT_NONE:
+            # dz = dy * act'(y), fused with the bias-gradient reduction
+            dz = torch.empty_like(dy)
+            ws = _ws(lib.dcv_act_bwd_workspace_bytes(rows, d.cout), dev)
+            nat.check(lib.dcv_act_bwd(dy.data_ptr(), y.data_ptr(), dz.data_ptr(), rows, d.cout, d.act, d.act_slope, nat.ptr(db),
+                                      ws.data_ptr(), ws.numel(), st), 'dcv_act_bwd')
+            db_done = True
+        else:
+            dz = dy
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dd = nat.Conv2dDesc.from_buffer_copy(d)
+            dd.x_layout = nat.LAYOUT_NHWC
+            dx = torch.empty((d.n, d.cin, d.h, d.w), dtype=dy.dtype, device=dev, memory_format=_CL)
+            ws = _ws(lib.dcv_conv2d_dgrad_workspace_bytes(dd), dev)
+            nat.check(lib.dcv_conv2d_dgrad(dd, dz.data_ptr(), weight.data_ptr(), dx.data_ptr(), ws.data_ptr(), ws.numel(), st), 'dcv_conv2d_dgrad')
+        if ctx.needs_input_grad[1] or (db is not None and not db_done):
+            dw = torch.empty_like(weight)
+            ws = _ws(lib.dcv_conv2d_wgrad_workspace_bytes(d), dev)
+            nat.check(lib.dcv_conv2d_wgrad(d, x.data_ptr(), dz.data_ptr(), dw.data_ptr(), None if db_done else nat.ptr(db),
+                                           ws.data_ptr(), ws.numel(), st), 'dcv_conv2d_wgrad')
+        return dx, dw, db, None, None, None, None, None
+
+
+def _pair(v) -> Tuple[int, int]:
+    if isinstance(v, (list, tuple)):
+        if len(v) == 1:
+            return int(v[0]), int(v[0])
+        return int(v[0]), int(v[1])
+    return int(v), int(v)
+
+
+def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stride=1, padding=0, dilation=1, act: int = nat.ACT_NONE,
+           slope: float = 0.) -> torch.Tensor:
+    """ y = act(conv2d(x, weight) + bias) — HIP kernels `dcv_conv2d_fwd/dgrad/wgrad` (+ `dcv_act_bwd` for the fused epilogue). """
+    return _Conv2dFn.apply(x, weight, bias, _pair(stride), _pair(padding), _pair(dilation), int(act), float(slope))
+
+
+# ------------------------------------------------------------------------------------------------ standalone activation
+
+class _ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        _require_f32(x)
+        x = x if (x.is_contiguous() or _is_nhwc(x)) else x.contiguous()
+        y = torch.empty_like(x)
+        nat.check(lib.dcv_act_fwd(x.data_ptr(), y.data_ptr(), x.numel(), act, slope, nat.current_stream(x.device)), 'dcv_act_fwd')
+        ctx.act, ctx.slope = act, slope
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        if dy.stride() != y.stride():
+            dy = dy.contiguous(memory_format=_CL) if _is_nhwc(y) else dy.contiguous()
+        dx = torch.empty_like(y)
+        nat.check(lib.dcv_act_bwd(dy.data_ptr(), y.data_ptr(), dx.data_ptr(), y.numel(), 1, ctx.act, ctx.slope, None, None, 0,
+                                  nat.current_stream(dy.device)), 'dcv_act_bwd')
+        return dx, None, None
+
+
+def activation(x: torch.Tensor, act: int, slope: float = 0.) -> torch.Tensor:
+    if act == nat.ACT_NONE:
+        return x
+    return _ActFn.apply(x, int(act), float(slope))
+
+
+# ------------------------------------------------------------------------------------------------ batch norm
+
+def _rows_channels(x: torch.Tensor) -> Tuple[torch.Tensor, int, int]:
+    """ Views an activation as [rows][C]: 4-D -> NHWC rows = N*H*W; 2-D [N][C] -> rows = N. """
+    if x.dim() == 4:
+        x = to_nhwc(x)
+        return x, x.shape[0] * x.shape[2] * x.shape[3], x.shape[1]
+    if x.dim() == 2:
+        x = x.contiguous()
+        return x, x.shape[0], x.shape[1]
+    raise NotImplementedError(f'deepcv_amd: normalisation kernels support 2-D [N,C] and 4-D [N,C,H,W] inputs, got {x.dim()}-D')
+
+
+class _BatchNormTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps):
+        _require_f32(x, gamma, beta, running_mean, running_var)
+        x, rows, c = _rows_channels(x)
+        dev = x.device
+        y = torch.empty_like(x)
+        save_mean = torch.empty(c, dtype=torch.float32, device=dev)
+        save_rstd = torch.empty(c, dtype=torch.float32, device=dev)
+        ws = _ws(lib.dcv_batchnorm_workspace_bytes(rows, c), dev)
+        nat.check(lib.dcv_batchnorm_fwd_train(x.data_ptr(), y.data_ptr(), rows, c, nat.ptr(gamma), nat.ptr(beta), nat.ptr(running_mean), nat.ptr(running_var),
+                                              nat.ptr(num_batches_tracked), momentum, eps, save_mean.data_ptr(), save_rstd.data_ptr(),
+                                              ws.data_ptr(), ws.numel(), nat.current_stream(dev)), 'dcv_batchnorm_fwd_train')
+        ctx.rows, ctx.c = rows, c
+        ctx.save_for_backward(x, gamma, save_mean, save_rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, save_mean, save_rstd = ctx.saved_tensors
+        dev = dy.device
+        dy = to_nhwc(dy) if dy.dim() == 4 else dy.contiguous()
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(ctx.c, dtype=torch.float32, device=dev) if gamma is not None else None
+        dbeta = torch.empty(ctx.c, dtype=torch.float32, device=dev) if gamma is not None else None
+        ws = _ws(lib.dcv_batchnorm_workspace_bytes(ctx.rows, ctx.c), dev)
+        nat.check(lib.dcv_batchnorm_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), ctx.rows, ctx.c, nat.ptr(gamma), save_mean.data_ptr(), save_rstd.data_ptr(),
+                                        nat.ptr(dgamma), nat.ptr(dbeta), ws.data_ptr(), ws.numel(), nat.current_stream(dev)), 'dcv_batchnorm_bwd')
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+def batch_norm(x, gamma, beta, running_mean, running_var, num_batches_tracked, training: bool, momentum: float, eps: float) -> torch.Tensor:
+    """ BatchNorm over all dims but the channel dim (dim 1).  Training: batch statistics + running-stat EMA (`dcv_batchnorm_fwd_train`);
+    inference: running statistics (`dcv_batchnorm_fwd_eval`, not differentiable w.r.t. its input in this build). """
+    use_batch_stats = training or running_mean is None
+    if use_batch_stats:
+        return _BatchNormTrainFn.apply(x, gamma, beta, running_mean if training else None, running_var if training else None,
+                                       num_batches_tracked if training else None, float(momentum), float(eps))
+    if torch.is_grad_enabled() and (x.requires_grad or (gamma is not None and gamma.requires_grad)):
+        raise NotImplementedError('deepcv_amd: differentiating through BatchNorm in eval() mode is not supported; call under torch.no_grad()')
+    _require_f32(x, gamma, beta, running_mean, running_var)
+    x, rows, c = _rows_channels(x)
+    y = torch.empty_like(x)
+    ws = _ws(lib.dcv_batchnorm_workspace_bytes(rows, c), x.device)
+    nat.check(lib.dcv_batchnorm_fwd_eval(x.data_ptr(), y.data_ptr(), rows, c, nat.ptr(gamma), nat.ptr(beta), running_mean.data_ptr(), running_var.data_ptr(),
+                                         float(eps), ws.data_ptr(), ws.numel(), nat.current_stream(x.device)), 'dcv_batchnorm_fwd_eval')
+    return y
+
+
+# ------------------------------------------------------------------------------------------------ group norm
+
+class _GroupNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps):
+        _require_f32(x, gamma, beta)
+        if x.dim() != 4:
+            raise NotImplementedError('deepcv_amd: GroupNorm kernel expects a 4-D [N,C,H,W] input')
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        dev = x.device
+        y = torch.empty_like(x)
+        save_mean = torch.empty(n * groups, dtype=torch.float32, device=dev)
+        save_rstd = torch.empty(n * groups, dtype=torch.float32, device=dev)
+        nat.check(lib.dcv_groupnorm_fwd(x.data_ptr(), y.data_ptr(), n, h * w, c, groups, nat.ptr(gamma), nat.ptr(beta), eps, save_mean.data_ptr(),
+                                        save_rstd.data_ptr(), nat.current_stream(dev)), 'dcv_groupnorm_fwd')
+        ctx.groups = groups
+        ctx.save_for_backward(x, gamma, save_mean, save_rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, save_mean, save_rstd = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dev = dy.device
+        dy = to_nhwc(dy)
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(c, dtype=torch.float32, device=dev) if gamma is not None else None
+        dbeta = torch.empty(c, dtype=torch.float32, device=dev) if gamma is not None else None
+        ws = _ws(lib.dcv_groupnorm_workspace_bytes(n, c), dev)
+        nat.check(lib.dcv_groupnorm_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), n, h * w, c, ctx.groups, nat.ptr(gamma), save_mean.data_ptr(),
+                                        save_rstd.data_ptr(), nat.ptr(dgamma), nat.ptr(dbeta), ws.data_ptr(), ws.numel(), nat.current_stream(dev)),
+                  'dcv_groupnorm_bwd')
+        return dx, dgamma, dbeta, None, None
+
+
+def group_norm(x, gamma, beta, groups: int, eps: float) -> torch.Tensor:
+    return _GroupNormFn.apply(x, gamma, beta, int(groups), float(eps))
+
+
+# ------------------------------------------------------------------------------------------------ pooling
+
+class _Pool2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kernel, stride, padding, mode):
+        _require_f32(x)
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        ho = (h + 2 * padding[0] - kernel[0]) // stride[0] + 1
+        wo = (w + 2 * padding[1] - kernel[1]) // stride[1] + 1
+        if ho <= 0 or wo <= 0:
+            raise ValueError(f'deepcv_amd.pool2d: empty output for input {tuple(x.shape)} and kernel {kernel}')
+        d = nat.Pool2dDesc(n, h, w, c, kernel[0], kernel[1], stride[0], stride[1], padding[0], padding[1], ho, wo, mode)
+        y = torch.empty((n, c, ho, wo), dtype=x.dtype, device=x.device, memory_format=_CL)
+        argmax = torch.empty((n, c, ho, wo), dtype=torch.int32, device=x.device, memory_format=_CL) if mode == nat.POOL_MAX else None
+        nat.check(lib.dcv_pool2d_fwd(d, x.data_ptr(), y.data_ptr(), nat.ptr(argmax), nat.current_stream(x.device)), 'dcv_pool2d_fwd')
+        ctx.desc = d
+        ctx.save_for_backward(argmax)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (argmax,) = ctx.saved_tensors
+        d = ctx.desc
+        dy = to_nhwc(dy)
+        dx = torch.empty((d.n, d.c, d.h, d.w), dtype=dy.dtype, device=dy.device, memory_format=_CL)
+        nat.check(lib.dcv_pool2d_bwd(d, dy.data_ptr(), nat.ptr(argmax), dx.data_ptr(), nat.current_stream(dy.device)), 'dcv_pool2d_bwd')
+        return dx, None, None, None, None
+
+
+def pool2d(x: torch.Tensor, kernel_size, stride=None, padding=0, mode: int = nat.POOL_AVG) -> torch.Tensor:
+    k = _pair(kernel_size)
+    s = _pair(stride) if stride is not None else k
+    return _Pool2dFn.apply(x, k, s, _pair(padding), int(mode))
+
+
+# ------------------------------------------------------------------------------------------------ link helpers: resize, concat, add
+
+class _InterpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, out_hw, align_corners):
+        _require_f32(x)
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        y = torch.empty((n, c, out_hw[0], out_hw[1]), dtype=x.dtype, device=x.device, memory_format=_CL)
+        nat.check(lib.dcv_interp_bilinear_fwd(x.data_ptr(), y.data_ptr(), n, h, w, c, out_hw[0], out_hw[1], int(align_corners), nat.current_stream(x.device)),
+                  'dcv_interp_bilinear_fwd')
+        ctx.geom = (n, h, w, c, out_hw[0], out_hw[1], int(align_corners))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, h, w, c, ho, wo, align = ctx.geom
+        dy = to_nhwc(dy)
+        dx = torch.empty((n, c, h, w), dtype=dy.dtype, device=dy.device, memory_format=_CL)
+        nat.check(lib.dcv_interp_bilinear_bwd(dy.data_ptr(), dx.data_ptr(), n, h, w, c, ho, wo, align, nat.current_stream(dy.device)), 'dcv_interp_bilinear_bwd')
+        return dx, None, None
+
+
+def interpolate_bilinear(x: torch.Tensor, out_hw: Sequence[int], align_corners: bool = False) -> torch.Tensor:
+    return _InterpFn.apply(x, (int(out_hw[0]), int(out_hw[1])), bool(align_corners))
+
+
+class _ConcatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *tensors):
+        _require_f32(*tensors)
+        tensors = [to_nhwc(t) for t in tensors]
+        n, _, h, w = tensors[0].shape
+        for t in tensors:
+            if (t.shape[0], t.shape[2], t.shape[3]) != (n, h, w):
+                raise RuntimeError(f'deepcv_amd.concat_channels: mismatching shapes {[tuple(t.shape) for t in tensors]}')
+        chans = [t.shape[1] for t in tensors]
+        ctot = sum(chans)
+        out = torch.empty((n, ctot, h, w), dtype=tensors[0].dtype, device=tensors[0].device, memory_format=_CL)
+        st, rows, off = nat.current_stream(out.device), n * h * w, 0
+        for t, c in zip(tensors, chans):
+            nat.check(lib.dcv_copy_channels(t.data_ptr(), c, 0, out.data_ptr(), ctot, off, c, rows, st), 'dcv_copy_channels')
+            off += c
+        ctx.chans, ctx.geom = chans, (n, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, h, w = ctx.geom
+        dy = to_nhwc(dy)
+        ctot, rows, st, off = sum(ctx.chans), n * h * w, nat.current_stream(dy.device), 0
+        grads = []
+        for i, c in enumerate(ctx.chans):
+            if ctx.needs_input_grad[i]:
+                g = torch.empty((n, c, h, w), dtype=dy.dtype, device=dy.device, memory_format=_CL)
+                nat.check(lib.dcv_copy_channels(dy.data_ptr(), ctot, off, g.data_ptr(), c, 0, c, rows, st), 'dcv_copy_channels')
+                grads.append(g)
+            else:
+                grads.append(None)
+            off += c
+        return tuple(grads)
+
+
+def concat_channels(tensors: Sequence[torch.Tensor]) -> torch.Tensor:
+    tensors = list(tensors)
+    return tensors[0] if len(tensors) == 1 else _ConcatFn.apply(*tensors)
+
+
+class _AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scale, *tensors):
+        _require_f32(*tensors)
+        ref = tensors[0]
+        nhwc = ref.dim() == 4
+        tensors = [to_nhwc(t) if nhwc else t.contiguous() for t in tensors]
+        for t in tensors:
+            if t.shape != ref.shape:
+                raise RuntimeError(f'deepcv_amd.add_tensors: mismatching shapes {[tuple(t.shape) for t in tensors]}')
+        st = nat.current_stream(ref.device)
+        out = torch.empty_like(tensors[0])
+        nat.check(lib.dcv_add(tensors[0].data_ptr(), tensors[1].data_ptr(), out.data_ptr(), out.numel(), st), 'dcv_add')
+        for t in tensors[2:]:
+            nat.check(lib.dcv_add(out.data_ptr(), t.data_ptr(), out.data_ptr(), out.numel(), st), 'dcv_add')
+        if scale != 1.:
+            nat.check(lib.dcv_scale(out.data_ptr(), scale, out.data_ptr(), out.numel(), st), 'dcv_scale')
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.scale != 1.:
+            dyc = dy if (dy.is_contiguous() or _is_nhwc(dy)) else dy.contiguous()
+            g = torch.empty_like(dyc)
+            nat.check(lib.dcv_scale(dyc.data_ptr(), ctx.scale, g.data_ptr(), g.numel(), nat.current_stream(dy.device)), 'dcv_scale')
+            dy = g
+        return (None,) + tuple(dy if need else None for need in ctx.needs_input_grad[1:])
+
+
+def add_tensors(tensors: Sequence[torch.Tensor], mean: bool = False) -> torch.Tensor:
+    """ Elementwise sum (or mean) of same-shape tensors: the 'sum' / 'mean' link reductions. """
+    tensors = list(tensors)
+    if len(tensors) == 1:
+        return tensors[0]
+    return _AddFn.apply(1. / len(tensors) if mean else 1., *tensors)
+
+
+# ------------------------------------------------------------------------------------------------ flatten (NHWC memory -> reference C-major feature order)
+
+class _FlattenFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require_f32(x)
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        ctx.shape = (n, c, h, w)
+        if c == 1 or h * w == 1:
+            return x.reshape(n, c * h * w)
+        out = torch.empty((n, c * h * w), dtype=x.dtype, device=x.device)
+        nat.check(lib.dcv_transpose_inner(x.data_ptr(), out.data_ptr(), n, h * w, c, nat.current_stream(x.device)), 'dcv_transpose_inner')
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, c, h, w = ctx.shape
+        dy = dy.contiguous()
+        if c == 1 or h * w == 1:
+            return dy.view(n, c, h, w).contiguous(memory_format=_CL)
+        dx = torch.empty((n, c, h, w), dtype=dy.dtype, device=dy.device, memory_format=_CL)
+        nat.check(lib.dcv_transpose_inner(dy.data_ptr(), dx.data_ptr(), n, c, h * w, nat.current_stream(dy.device)), 'dcv_transpose_inner')
+        return dx
+
+
+def flatten_nchw_order(x: torch.Tensor) -> torch.Tensor:
+    """ `[N,C,H,W]` (NHWC memory) -> `[N, C*H*W]` in the reference's C-major feature order (what `torch.nn.Flatten` yields on NCHW data),
+    so that the stored FC weight keeps the reference layout. """
+    if x.dim() == 2:
+        return x
+    if x.dim() != 4:
+        return torch.flatten(x, 1)
+    return _FlattenFn.apply(x)
+
+
+# ------------------------------------------------------------------------------------------------ linear (+ fused bias / activation)
+
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, slope):
+        _require_f32(x, weight, bias)
+        x, weight = x.contiguous(), weight.contiguous()
+        n, k = x.shape
+        o = weight.shape[0]
+        if weight.shape[1] != k:
+            raise ValueError(f'deepcv_amd.linear: weight {tuple(weight.shape)} does not match input features {k}')
+        y = torch.empty((n, o), dtype=x.dtype, device=x.device)
+        nat.check(lib.dcv_linear_fwd(x.data_ptr(), weight.data_ptr(), nat.ptr(bias), y.data_ptr(), n, k, o, act, slope, nat.current_stream(x.device)), 'dcv_linear_fwd')
+        ctx.act, ctx.slope, ctx.has_bias = act, slope, bias is not None
+        ctx.save_for_backward(x, weight, y if act != nat.ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        n, k = x.shape
+        o = weight.shape[0]
+        dev, st = dy.device, nat.current_stream(dy.device)
+        dy = dy.contiguous()
+        if ctx.act != nat.ACT_NONE:
+            dz = torch.empty_like(dy)
+            nat.check(lib.dcv_act_bwd(dy.data_ptr(), y.data_ptr(), dz.data_ptr(), n, o, ctx.act, ctx.slope, None, None, 0, st), 'dcv_act_bwd')
+        else:
+            dz = dy
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            nat.check(lib.dcv_linear_dgrad(dz.data_ptr(), weight.data_ptr(), dx.data_ptr(), n, k, o, st), 'dcv_linear_dgrad')
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty_like(weight)
+            db = torch.empty(o, dtype=dy.dtype, device=dev) if ctx.has_bias else None
+            ws = _ws(lib.dcv_linear_wgrad_workspace_bytes(n, k, o), dev)
+            nat.check(lib.dcv_linear_wgrad(x.data_ptr(), dz.data_ptr(), dw.data_ptr(), nat.ptr(db), n, k, o, ws.data_ptr(), ws.numel(), st), 'dcv_linear_wgrad')
+        return dx, dw, db, None, None
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = nat.ACT_NONE, slope: float = 0.) -> torch.Tensor:
+    if x.dim() != 2:
+        x = x.reshape(-1, x.shape[-1]) if x.dim() > 2 else x.unsqueeze(0)
+    return _LinearFn.apply(x, weight, bias, int(act), float(slope))
+
+
+# ------------------------------------------------------------------------------------------------ softmax cross-entropy
+
+class _CrossEntropyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, correct_out):
+        _require_f32(logits)
+        nat.require_device(target, 'target')
+        if target.dtype != torch.int64:
+            raise TypeError(f'deepcv_amd.cross_entropy: int64 class-index targets expected, got {target.dtype}')
+        logits, target = logits.contiguous(), target.contiguous()
+        n, c = logits.shape
+        dev = logits.device
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        lse = torch.empty(n, dtype=torch.float32, device=dev)
+        ws = _ws(lib.dcv_cross_entropy_workspace_bytes(n), dev)
+        nat.check(lib.dcv_cross_entropy_fwd(logits.data_ptr(), target.data_ptr(), loss.data_ptr(), lse.data_ptr(), nat.ptr(correct_out), n, c,
+                                            ws.data_ptr(), ws.numel(), nat.current_stream(dev)), 'dcv_cross_entropy_fwd')
+        ctx.save_for_backward(logits, target, lse)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logits, target, lse = ctx.saved_tensors
+        n, c = logits.shape
+        dloss = dloss.contiguous().to(torch.float32)
+        dz = torch.empty_like(logits)
+        nat.check(lib.dcv_cross_entropy_bwd(logits.data_ptr(), target.data_ptr(), lse.data_ptr(), dloss.data_ptr(), dz.data_ptr(), n, c,
+                                            nat.current_stream(logits.device)), 'dcv_cross_entropy_bwd')
+        return dz, None, None
+
+
+def cross_entropy(logits: torch.Tensor, target: torch.Tensor, correct_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """ Mean softmax cross-entropy over the batch (`torch.nn.CrossEntropyLoss()` defaults).  If `correct_out` (int32[1], device) is given,
+    the kernel also writes the number of samples whose arg-max equals the target (accuracy numerator). """
+    return _CrossEntropyFn.apply(logits, target, correct_out)

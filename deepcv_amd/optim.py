@@ -1,0 +1,199 @@
+""" Native optimizers: drop-in types for `opt` of `train()` (reference `src/deepcv/meta/ignite_training.py:224,252-254`).
+
+`AdamW` mirrors `torch.optim.AdamW` (wired by the reference at `src/deepcv/classification/image.py:71`, options
+`conf/base/parameters.yml:129-134`) and `SGD` mirrors `torch.optim.SGD` (`parameters.yml:136`): same constructor arguments, `param_groups`
+keys (so ignite-style schedulers writing `param_groups[i]['lr'|'momentum'|'betas']` work unchanged) and `state_dict` entry names
+(`step`, `exp_avg`, `exp_avg_sq`, `max_exp_avg_sq`, `momentum_buffer`).  `step()` is ONE fused multi-tensor HIP launch per 64 parameter tensors
+(`dcv_adamw_step` / `dcv_sgd_step`) preceded by a one-thread `dcv_optim_prepare` which advances the device-side step counter and derives the bias
+corrections; the scalars that change over time (lr, momentum, ...) are read by the kernels from a 64-byte device buffer refreshed from pinned host
+memory, so the captured hipGraph of a training step replays with the scheduler's current values. """
+import ctypes
+from typing import Any, Dict, Iterable, List, Optional, Tuple
+
+import torch
+
+from . import _native as nat
+from ._native import lib
+
+__all__ = ['AdamW', 'SGD']
+
+
+class _NativeOptimizer(torch.optim.Optimizer):
+    _state_names: Tuple[str, ...] = ()
+
+    def __init__(self, params, defaults):
+        super().__init__(params, defaults)
+        self._dev: Dict[int, Dict[str, Any]] = {}     # per param-group device-side buffers
+        self._lists: Dict[int, Tuple[tuple, List[nat.TensorList], List[list]]] = {}
+
+    # -- per-group device buffers ----------------------------------------------------------------------
+    def _group_buffers(self, gi: int, device: torch.device) -> Dict[str, Any]:
+        buf = self._dev.get(gi)
+        if buf is None or buf['hyper'].device != device:
+            # ring of pinned staging rows: an async H2D copy may still be reading row k while the host already prepares row k+1
+            host = torch.zeros(16, nat.HYP_COUNT, dtype=torch.float32)
+            if device.type == 'cuda':
+                host = host.pin_memory()
+            buf = {'hyper_host': host, 'slot': 0, 'hyper': torch.zeros(nat.HYP_COUNT, dtype=torch.float32, device=device),
+                   'step': torch.zeros(1, dtype=torch.int64, device=device), 'last': None}
+            pending = getattr(self, '_pending_steps', {}).pop(gi, None)
+            if pending is not None:
+                buf['step'].fill_(int(pending))
+            self._dev[gi] = buf
+        return buf
+
+    def _hyper_values(self, group: Dict[str, Any]) -> List[float]:
+        raise NotImplementedError
+
+    def sync_hyper(self):
+        """ Copies the current `param_groups` scalars to the device (one async 64-B H2D copy per group, skipped when nothing changed).
+        `step()` calls it itself, except while a hipGraph is being captured: replay loops call it before every replay. """
+        for gi, group in enumerate(self.param_groups):
+            p0 = next((p for p in group['params']), None)
+            if p0 is None:
+                continue
+            buf = self._group_buffers(gi, p0.device)
+            vals = self._hyper_values(group) + [float(group.get('grad_scale', 1.0))]
+            if buf['last'] != vals:
+                buf['slot'] = (buf['slot'] + 1) % buf['hyper_host'].shape[0]
+                h = buf['hyper_host'][buf['slot']]
+                for i, v in enumerate(vals):
+                    h[i] = v
+                buf['hyper'][:len(vals)].copy_(h[:len(vals)], non_blocking=True)
+                buf['last'] = list(vals)
+
+    # -- tensor tables ---------------------------------------------------------------------------------
+    def _tensor_lists(self, gi: int, group: Dict[str, Any]) -> List[nat.TensorList]:
+        params = [p for p in group['params'] if p.grad is not None]
+        if not params:
+            return []
+        names = self._active_state_names(group)
+        for p in params:
+            nat.require_device(p, 'optimizer parameter')
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError('deepcv_amd optimizers need contiguous fp32 parameters')
+            st = self.state[p]
+            for name in names:
+                if name not in st:
+                    st[name] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in params]
+        key = tuple((p.data_ptr(), g.data_ptr()) for p, g in zip(params, grads))
+        cached = self._lists.get(gi)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        lists, keep = [], []
+        for i in range(0, len(params), nat.MAX_TENSORS):
+            tl = nat.TensorList()
+            chunk = params[i:i + nat.MAX_TENSORS]
+            tl.count = len(chunk)
+            for j, p in enumerate(chunk):
+                st = self.state[p]
+                tl.param[j] = p.data_ptr()
+                tl.grad[j] = grads[i + j].data_ptr()
+                for slot, name in zip(('state1', 'state2', 'state3'), self._state_names):
+                    getattr(tl, slot)[j] = st[name].data_ptr() if name in st and name in names else None
+                tl.numel[j] = p.numel()
+            lists.append(tl)
+        keep.append(grads)   # keep possibly re-laid-out gradient copies alive until the next rebuild
+        self._lists[gi] = (key, lists, keep)
+        return lists
+
+    def _active_state_names(self, group) -> Tuple[str, ...]:
+        return self._state_names
+
+    def _launch(self, tl: nat.TensorList, hyper_ptr: int, group: Dict[str, Any], stream: int):
+        raise NotImplementedError
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            self.sync_hyper()
+        for gi, group in enumerate(self.param_groups):
+            lists = self._tensor_lists(gi, group)
+            if not lists:
+                continue
+            dev = group['params'][0].device
+            buf = self._group_buffers(gi, dev)
+            stream = nat.current_stream(dev)
+            nat.check(lib.dcv_optim_prepare(buf['hyper'].data_ptr(), buf['step'].data_ptr(), stream), 'dcv_optim_prepare')
+            for tl in lists:
+                self._launch(tl, buf['hyper'].data_ptr(), group, stream)
+        return loss
+
+    # -- checkpoint compatibility with torch.optim state_dicts ------------------------------------------
+    def state_dict(self):
+        for gi, group in enumerate(self.param_groups):
+            buf = self._dev.get(gi)
+            step = int(buf['step'].item()) if buf is not None else 0
+            for p in group['params']:
+                if p in self.state and len(self.state[p]) > 0:
+                    self.state[p]['step'] = torch.tensor(float(step))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._lists.clear()
+        self._pending_steps = {}
+        for gi, group in enumerate(self.param_groups):
+            steps = [float(self.state[p]['step']) for p in group['params'] if p in self.state and 'step' in self.state[p]]
+            step = int(max(steps)) if steps else 0
+            if gi in self._dev:
+                self._dev[gi]['step'].fill_(step)
+                self._dev[gi]['last'] = None
+            else:
+                self._pending_steps[gi] = step
+
+
+class AdamW(_NativeOptimizer):
+    """ `torch.optim.AdamW(params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False)` on the fused HIP kernel. """
+    _state_names = ('exp_avg', 'exp_avg_sq', 'max_exp_avg_sq')
+
+    def __init__(self, params, lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, amsgrad: bool = False, **unused):
+        if lr < 0.0:
+            raise ValueError(f'Invalid learning rate: {lr}')
+        if eps < 0.0:
+            raise ValueError(f'Invalid epsilon value: {eps}')
+        if not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
+            raise ValueError(f'Invalid beta parameters: {betas}')
+        if weight_decay < 0.0:
+            raise ValueError(f'Invalid weight_decay value: {weight_decay}')
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=amsgrad))
+
+    def _active_state_names(self, group):
+        return self._state_names if group['amsgrad'] else self._state_names[:2]
+
+    def _hyper_values(self, g):
+        return [float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), float(g['weight_decay'])]
+
+    def _launch(self, tl, hyper_ptr, group, stream):
+        nat.check(lib.dcv_adamw_step(ctypes.byref(tl), hyper_ptr, int(bool(group['amsgrad'])), stream), 'dcv_adamw_step')
+
+
+class SGD(_NativeOptimizer):
+    """ `torch.optim.SGD(params, lr, momentum=0, dampening=0, weight_decay=0, nesterov=False)` on the fused HIP kernel. """
+    _state_names = ('momentum_buffer',)
+
+    def __init__(self, params, lr: float = 1e-3, momentum: float = 0., dampening: float = 0., weight_decay: float = 0., nesterov: bool = False, **unused):
+        if lr < 0.0:
+            raise ValueError(f'Invalid learning rate: {lr}')
+        if momentum < 0.0:
+            raise ValueError(f'Invalid momentum value: {momentum}')
+        if weight_decay < 0.0:
+            raise ValueError(f'Invalid weight_decay value: {weight_decay}')
+        if nesterov and (momentum <= 0 or dampening != 0):
+            raise ValueError('Nesterov momentum requires a momentum and zero dampening')
+        super().__init__(params, dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay, nesterov=nesterov))
+
+    def _active_state_names(self, group):
+        return self._state_names if group['momentum'] != 0 else ()
+
+    def _hyper_values(self, g):
+        return [float(g['lr']), float(g['momentum']), float(g['dampening']), 0.0, float(g['weight_decay'])]
+
+    def _launch(self, tl, hyper_ptr, group, stream):
+        nat.check(lib.dcv_sgd_step(ctypes.byref(tl), hyper_ptr, int(bool(group['nesterov'])), stream), 'dcv_sgd_step')

@@ -1,0 +1,234 @@
+/* deepcv_hip.h — C-ABI of libdeepcv_hip.so: hand-written HIP kernels (gfx950 / MI355X) for DeepCV's
+ * image-classifier training hot path.
+ *
+ * The reference (PaulEmmanuelSotir/DeepCV) is 100 % Python and has NO native layer; every
+ * FLOP of its hot path is dispatched to third-party PyTorch ATen ops through `torch.nn` modules.  Each entry
+ * point below therefore cites the reference line that *triggers* the ATen op it replaces (SURVEY.md §2.3
+ * rows K1..K12).  How a reference maintainer would bind these (ctypes stubs behind the submodule-creator
+ * registry) is shown in INTEGRATION.md; `deepcv_amd/_native.py` is that binding.
+ *
+ * Conventions
+ *   - plain device pointers + explicit dims; no torch types.  `stream` is a `hipStream_t` passed as `void*`
+ *     (0 = the null stream).  Launchers never allocate, never synchronise, never throw: they validate the
+ *     arguments on the host, enqueue kernels on `stream` and return 0, or a negative `DCV_ERR_*` code
+ *     (`dcv_strerror`).  They are re-entrant and safe to capture into a hipGraph.
+ *   - activations are fp32 **NHWC** (channels-last): element (n, h, w, c) at ((n*H + h)*W + w)*C + c.
+ *   - parameters keep the reference's `state_dict` layouts: conv weight [Cout][Cin/groups][R][S] (OIHW),
+ *     linear weight [out][in], per-channel vectors [C].
+ *   - reductions are fixed-order (per-block partial slabs + ordered second stage): every kernel is
+ *     bit-reproducible run to run; no floating-point atomics anywhere.
+ *   - `ws`/`ws_bytes`: caller-provided scratch; query the size with the matching `*_workspace_bytes`.
+ */
+#ifndef DEEPCV_HIP_H
+#define DEEPCV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCV_OK 0
+#define DCV_ERR_INVALID_ARG (-1)   /* NULL pointer, non-positive dim, inconsistent shapes */
+#define DCV_ERR_UNSUPPORTED (-2)   /* valid request this build has no kernel for (e.g. groups > 1) */
+#define DCV_ERR_WORKSPACE (-3)     /* ws_bytes smaller than *_workspace_bytes() */
+#define DCV_ERR_LAUNCH (-4)        /* hipGetLastError() != hipSuccess after enqueue */
+
+/* fused epilogue / elementwise activation codes (reference: `act_fn()` in nn.py:553) */
+#define DCV_ACT_NONE 0
+#define DCV_ACT_RELU 1
+#define DCV_ACT_LEAKY_RELU 2
+#define DCV_ACT_SIGMOID 3
+#define DCV_ACT_TANH 4
+
+#define DCV_POOL_AVG 0
+#define DCV_POOL_MAX 1
+
+#define DCV_LAYOUT_NHWC 0
+#define DCV_LAYOUT_NCHW 1
+
+const char* dcv_strerror(int code);
+int dcv_version(void);
+/* Fills multiprocessor (CU) count, wavefront size and the gcn arch name of HIP device `device`. */
+int dcv_device_info(int device, int* cu_count, int* wave_size, char* arch, int arch_len);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K1-K3  conv2d forward / data-gradient / weight-gradient
+ * replaces torch.nn.Conv2d created at submodule_creators.py:251 (fwd) and its autograd (ignite_training.py:253)
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int n, h, w, cin;            /* input  N x H x W x Cin                                     */
+    int cout, r, s;              /* filter Cout x Cin x R x S (OIHW)                           */
+    int stride_h, stride_w;
+    int pad_h, pad_w;
+    int dil_h, dil_w;
+    int groups;                  /* only 1 is supported                                        */
+    int ho, wo;                  /* output spatial dims; must equal the conv formula           */
+    int x_layout;                /* DCV_LAYOUT_NHWC, or DCV_LAYOUT_NCHW for the forward input  */
+    int act;                     /* forward: fused activation applied after bias (DCV_ACT_*)   */
+    float act_slope;             /* negative slope for DCV_ACT_LEAKY_RELU                      */
+} dcv_conv2d_desc;
+
+size_t dcv_conv2d_fwd_workspace_bytes(const dcv_conv2d_desc* d);
+size_t dcv_conv2d_dgrad_workspace_bytes(const dcv_conv2d_desc* d);
+size_t dcv_conv2d_wgrad_workspace_bytes(const dcv_conv2d_desc* d);
+/* y[N,Ho,Wo,Cout] = act(conv(x, w) + bias);  bias may be NULL */
+int dcv_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y,
+                   void* ws, size_t ws_bytes, void* stream);
+/* dx[N,H,W,Cin] = conv_transpose(dy[N,Ho,Wo,Cout], w)   (dy is the gradient w.r.t. the PRE-activation output) */
+int dcv_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx,
+                     void* ws, size_t ws_bytes, void* stream);
+/* dw[Cout,Cin,R,S] = x (*) dy ; db[Cout] = sum dy (db may be NULL).  x honours d->x_layout. */
+int dcv_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, float* db,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K4  elementwise activation (standalone; conv/linear fuse it into their epilogue)
+ * replaces `act_fn()` modules of nn.py:553 (ReLU parameters.yml:9, LeakyReLU :80, Sigmoid :88)
+ * ------------------------------------------------------------------------------------------------- */
+int dcv_act_fwd(const float* x, float* y, size_t numel, int act, float slope, void* stream);
+/* dx = dy * act'(.) evaluated from the activation OUTPUT y (all supported activations allow it).
+ * If db != NULL, also reduces db[c] = sum over rows of dx for a [rows][channels] view (bias gradient);
+ * needs ws of dcv_act_bwd_workspace_bytes(). */
+size_t dcv_act_bwd_workspace_bytes(size_t rows, int channels);
+int dcv_act_bwd(const float* dy, const float* y, float* dx, size_t rows, int channels, int act, float slope,
+                float* db, void* ws, size_t ws_bytes, void* stream);
+
+/* out[c] = sum over rows of x[rows][channels] (ordered two-stage reduction; ws of dcv_act_bwd_workspace_bytes) — the bias
+ * gradient of a conv / linear layer without fused activation. */
+int dcv_channel_sum(const float* x, float* out, size_t rows, int channels, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K5  BatchNorm (training + inference), NHWC view [rows = N*H*W][C]
+ * replaces torch.nn.BatchNorm2d built at nn.py:418,487-491,501
+ * ------------------------------------------------------------------------------------------------- */
+size_t dcv_batchnorm_workspace_bytes(size_t rows, int channels);
+/* Training forward: batch statistics (biased var for normalisation, unbiased for running_var), running stats EMA
+ * with `momentum` (if running_mean/var != NULL), num_batches_tracked += 1 (if != NULL).
+ * save_mean / save_rstd [C] are outputs kept for the backward.  gamma/beta may be NULL (affine=False). */
+int dcv_batchnorm_fwd_train(const float* x, float* y, size_t rows, int channels, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                            float momentum, float eps, float* save_mean, float* save_rstd,
+                            void* ws, size_t ws_bytes, void* stream);
+/* Inference forward from running statistics. */
+int dcv_batchnorm_fwd_eval(const float* x, float* y, size_t rows, int channels, const float* gamma, const float* beta,
+                           const float* running_mean, const float* running_var, float eps,
+                           void* ws, size_t ws_bytes, void* stream);
+/* Backward of the training forward: dx, dgamma, dbeta (dgamma/dbeta may be NULL when affine=False). */
+int dcv_batchnorm_bwd(const float* dy, const float* x, float* dx, size_t rows, int channels, const float* gamma,
+                      const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
+                      void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K6  GroupNorm, NHWC [N][HW][C], `groups` groups of C/groups channels
+ * replaces torch.nn.GroupNorm built at nn.py:494-495,501 (parameters.yml:10)
+ * ------------------------------------------------------------------------------------------------- */
+size_t dcv_groupnorm_workspace_bytes(int n, int channels);
+int dcv_groupnorm_fwd(const float* x, float* y, int n, int hw, int channels, int groups, const float* gamma, const float* beta,
+                      float eps, float* save_mean, float* save_rstd /* [N][groups] */, void* stream);
+int dcv_groupnorm_bwd(const float* dy, const float* x, float* dx, int n, int hw, int channels, int groups, const float* gamma,
+                      const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
+                      void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K7 / K7'  2-D average / max pooling, NHWC
+ * replaces torch.nn.AvgPool2d (submodule_creators.py:168 -> nn.py:416) and torch.nn.MaxPool2d (nn_spec.py:158-169)
+ * avg: count_include_pad=True, ceil_mode=False (torch defaults).  max: first maximum wins on ties.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int n, h, w, c;
+    int kh, kw, stride_h, stride_w, pad_h, pad_w;
+    int ho, wo;
+    int mode;                    /* DCV_POOL_AVG | DCV_POOL_MAX */
+} dcv_pool2d_desc;
+/* argmax: int32 [N,Ho,Wo,C] flat input offset (h*W + w) of the selected element; required for DCV_POOL_MAX, else NULL */
+int dcv_pool2d_fwd(const dcv_pool2d_desc* d, const float* x, float* y, int32_t* argmax, void* stream);
+int dcv_pool2d_bwd(const dcv_pool2d_desc* d, const float* dy, const int32_t* argmax, float* dx, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K8  dense / residual link helpers: bilinear resize, channel concat (slice copy), n-ary add
+ * replaces F.interpolate (nn.py:675) + torch.cat (submodule_creators.py:56,323)
+ * ------------------------------------------------------------------------------------------------- */
+int dcv_interp_bilinear_fwd(const float* x, float* y, int n, int h, int w, int c, int ho, int wo, int align_corners, void* stream);
+int dcv_interp_bilinear_bwd(const float* dy, float* dx, int n, int h, int w, int c, int ho, int wo, int align_corners, void* stream);
+/* dst[row][dst_off : dst_off+copy_c] = src[row][src_off : src_off+copy_c] for [rows][dst_c] / [rows][src_c] views */
+int dcv_copy_channels(const float* src, int src_c, int src_off, float* dst, int dst_c, int dst_off, int copy_c, size_t rows, void* stream);
+/* out = a + b (elementwise; out may alias a) */
+int dcv_add(const float* a, const float* b, float* out, size_t numel, void* stream);
+/* out = alpha * a */
+int dcv_scale(const float* a, float alpha, float* out, size_t numel, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K9  layout change + Linear
+ * replaces torch.nn.Flatten (parameters.yml:87) on NHWC activations and torch.nn.Linear (submodule_creators.py:268-269)
+ * ------------------------------------------------------------------------------------------------- */
+/* [N][A][B] -> [N][B][A]  (NHWC->NCHW flatten order: A=HW, B=C;  NCHW->NHWC: A=C, B=HW) */
+int dcv_transpose_inner(const float* x, float* y, int n, int a, int b, void* stream);
+size_t dcv_linear_wgrad_workspace_bytes(int n, int in_features, int out_features);
+/* y[N][O] = act(x[N][K] . w[O][K]^T + bias) */
+int dcv_linear_fwd(const float* x, const float* w, const float* bias, float* y, int n, int in_features, int out_features,
+                   int act, float slope, void* stream);
+/* dx[N][K] = dy[N][O] . w[O][K] */
+int dcv_linear_dgrad(const float* dy, const float* w, float* dx, int n, int in_features, int out_features, void* stream);
+/* dw[O][K] = dy^T . x ; db[O] = sum_n dy (db may be NULL) */
+int dcv_linear_wgrad(const float* x, const float* dy, float* dw, float* db, int n, int in_features, int out_features,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K10  softmax cross-entropy (mean reduction) on logits [N][C] with int64 targets
+ * replaces torch.nn.CrossEntropyLoss() of classification/image.py:70
+ * ------------------------------------------------------------------------------------------------- */
+/* loss[0] = mean_n (logsumexp(z_n) - z_n[t_n]); lse[N] saved for the backward.  Also counts argmax==target into
+ * correct[0] (int32) when correct != NULL (ignite Accuracy, classification/image.py:72). */
+size_t dcv_cross_entropy_workspace_bytes(int n);
+int dcv_cross_entropy_fwd(const float* logits, const int64_t* target, float* loss, float* lse, int32_t* correct,
+                          int n, int classes, void* ws, size_t ws_bytes, void* stream);
+/* dlogits[n][c] = (exp(z - lse_n) - [c == t_n]) * dloss[0] / N */
+int dcv_cross_entropy_bwd(const float* logits, const int64_t* target, const float* lse, const float* dloss, float* dlogits,
+                          int n, int classes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K11  fused multi-tensor optimizer steps (fp32 master params)
+ * replaces torch.optim.AdamW (classification/image.py:71, opts parameters.yml:129-134) and torch.optim.SGD (:136)
+ * Scalars that change from step to step live in DEVICE memory (`hyper`), so that a captured hipGraph replays with the
+ * current learning rate: the host refreshes `hyper` with one small async H2D copy per step.
+ * ------------------------------------------------------------------------------------------------- */
+#define DCV_MAX_TENSORS 64
+typedef struct {
+    int count;                               /* number of tensors in this launch (<= DCV_MAX_TENSORS)     */
+    float* param[DCV_MAX_TENSORS];
+    const float* grad[DCV_MAX_TENSORS];
+    float* state1[DCV_MAX_TENSORS];          /* AdamW: exp_avg      | SGD: momentum buffer (or NULL)      */
+    float* state2[DCV_MAX_TENSORS];          /* AdamW: exp_avg_sq   | SGD: unused                         */
+    float* state3[DCV_MAX_TENSORS];          /* AdamW: max_exp_avg_sq when amsgrad, else NULL             */
+    int64_t numel[DCV_MAX_TENSORS];
+} dcv_tensor_list;
+
+/* hyper layout (float[16], device): see DCV_HYP_* ; step counter: int64 on device, incremented by *_prepare. */
+#define DCV_HYP_LR 0
+#define DCV_HYP_BETA1 1          /* SGD: momentum   */
+#define DCV_HYP_BETA2 2          /* SGD: dampening  */
+#define DCV_HYP_EPS 3
+#define DCV_HYP_WEIGHT_DECAY 4
+#define DCV_HYP_GRAD_SCALE 5     /* gradients are multiplied by this (1/world_size for data-parallel mean) */
+#define DCV_HYP_BIAS_CORR1 6     /* written by dcv_adamw_prepare */
+#define DCV_HYP_BIAS_CORR2 7     /* written by dcv_adamw_prepare */
+#define DCV_HYP_FIRST_STEP 8     /* written by *_prepare: 1.0 on the first step (SGD momentum buffer init) */
+#define DCV_HYP_COUNT 16
+/* step[0] += 1, then derive the bias corrections 1 - beta^step in double precision */
+int dcv_optim_prepare(float* hyper, int64_t* step, void* stream);
+int dcv_adamw_step(const dcv_tensor_list* tl, const float* hyper, int amsgrad, void* stream);
+int dcv_sgd_step(const dcv_tensor_list* tl, const float* hyper, int nesterov, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * C1 helper  gradient bucket pack for the data-parallel all-reduce (RCCL over xGMI is driven from Python through
+ * torch.distributed; the bucket is what gets reduced).  replaces DDP's bucket copy (ignite_training.py:380)
+ * dst_flat[offset_i : offset_i + numel_i] = grad_i  (offsets = running sum of numel in list order)
+ * ------------------------------------------------------------------------------------------------- */
+int dcv_pack_grads(const dcv_tensor_list* tl, float* dst_flat, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPCV_HIP_H */
