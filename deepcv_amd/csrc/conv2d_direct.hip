@@ -296,11 +296,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_partial_kernel(WgradArgs a, co
     }
 }
 
+// dw[i] = sum over chunks of partial[chunk][i]: block = 32 consecutive weights x 8 chunk lanes (coalesced 128-B rows, chunks/8 serial loads per thread),
+// merged through LDS in a fixed order
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int chunks, size_t wtotal) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < wtotal; i += (size_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int c = 0; c < chunks; ++c) s += partial[(size_t)c * wtotal + i];
-        dw[i] = s;
+    __shared__ float red[8][32];
+    const int wl = threadIdx.x & 31, cl = threadIdx.x >> 5;
+    const size_t wi = (size_t)blockIdx.x * 32 + wl;
+    float s = 0.f;
+    if (wi < wtotal)
+        for (int c = cl; c < chunks; c += 8) s += partial[(size_t)c * wtotal + wi];
+    red[cl][wl] = s;
+    __syncthreads();
+    if (cl == 0 && wi < wtotal) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][wl];
+        dw[wi] = t;
     }
 }
 
@@ -400,9 +411,9 @@ inline void wgrad_plan(const dcv_conv2d_desc* d, WgradArgs* a, int* chunks, int*
     a->pixels = (size_t)d->n * d->ho * d->wo;
     a->wtotal = (size_t)d->cout * d->cin * d->r * d->s;
     *unit_batches = (int)dcv_ceil_div(a->units, a->ub);
-    // ~64 pixels per sub-stream per chunk, at most 1024 chunks, and keep the partial slabs under 64 MiB
+    // ~64 pixels per sub-stream per chunk, at most 512 chunks, and keep the partial slabs under 64 MiB
     size_t ch = dcv_ceil_div(a->pixels, (size_t)a->nsub * 64);
-    if (ch > 1024) ch = 1024;
+    if (ch > 512) ch = 512;
     const size_t max_by_bytes = ((size_t)64 << 20) / (a->wtotal * sizeof(float));
     if (ch > max_by_bytes) ch = max_by_bytes;
     if (ch < 1) ch = 1;
@@ -455,6 +466,6 @@ int dcv_direct_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const floa
     if (vec == 4 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) hipLaunchKernelGGL((conv_wgrad_partial_kernel<4>), grid, dim3(256), 0, st, a, x, dy, partial);
     else if (vec == 4) return DCV_ERR_INVALID_ARG;   // NHWC activations are always 16-B aligned (torch allocator); anything else is a caller bug
     else hipLaunchKernelGGL((conv_wgrad_partial_kernel<1>), grid, dim3(256), 0, st, a, x, dy, partial);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(dcv_stream_grid(a.wtotal, 256)), dim3(256), 0, st, partial, dw, chunks, a.wtotal);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)dcv_ceil_div(a.wtotal, 32)), dim3(256), 0, st, partial, dw, chunks, a.wtotal);
     return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
 }

@@ -60,12 +60,13 @@ __global__ __launch_bounds__(DCV_CR_THREADS) void act_bwd_bias_kernel(ActBwdLoad
     dcv_colreduce_block<1, VEC>(ld, r0 < rows ? r0 : rows, r1, C, scratch, partial + (size_t)blockIdx.x * C);
 }
 
-__global__ void sum_partials_kernel(const double* __restrict__ partial, int nb, int C, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// one wave per channel: lanes stride over the per-block partials, then a fixed-order butterfly -> deterministic and ~nb/64 serial loads per lane
+__global__ __launch_bounds__(64) void sum_partials_kernel(const double* __restrict__ partial, int nb, int C, float* __restrict__ out) {
+    const int c = blockIdx.x, lane = threadIdx.x;
     double s = 0.0;
-    for (int b = 0; b < nb; ++b) s += partial[(size_t)b * C + c];
-    out[c] = (float)s;
+    for (int b = lane; b < nb; b += DCV_WAVE) s += partial[(size_t)b * C + c];
+    s = dcv_wave_sum(s);
+    if (lane == 0) out[c] = (float)s;
 }
 
 struct PlainLoader {
@@ -283,7 +284,7 @@ int dcv_act_bwd(const float* dy, const float* y, float* dx, size_t rows, int C, 
     ActBwdLoader ld{dy, y, dx, act, slope};
     if (C % 4 == 0) hipLaunchKernelGGL((act_bwd_bias_kernel<4>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
     else hipLaunchKernelGGL((act_bwd_bias_kernel<1>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)dcv_ceil_div(C, 64)), dim3(64), 0, st, partial, (int)nb, C, db);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)C), dim3(64), 0, st, partial, (int)nb, C, db);
     DCV_RETURN_LAUNCH();
 }
 
@@ -296,7 +297,7 @@ int dcv_channel_sum(const float* x, float* out, size_t rows, int C, void* ws, si
     PlainLoader ld{x};
     if (C % 4 == 0 && aligned16(x)) hipLaunchKernelGGL((channel_sum_kernel<4>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
     else hipLaunchKernelGGL((channel_sum_kernel<1>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)dcv_ceil_div(C, 64)), dim3(64), 0, st, partial, (int)nb, C, out);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)C), dim3(64), 0, st, partial, (int)nb, C, out);
     DCV_RETURN_LAUNCH();
 }
 

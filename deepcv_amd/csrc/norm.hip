@@ -75,11 +75,13 @@ __global__ void bn_finalize_fwd_kernel(const double* __restrict__ partial, int n
                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                        float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps,
                                        float* __restrict__ save_mean, float* __restrict__ save_rstd, float* __restrict__ scale_shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && nbt) nbt[0] += 1;
-    if (c >= C) return;
+    // one wave per channel; lanes stride over the per-block partials, fixed-order butterfly merge
+    const int c = blockIdx.x, lane = threadIdx.x;
+    if (c == 0 && lane == 0 && nbt) nbt[0] += 1;
     double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nb; ++b) { s += partial[((size_t)b * 2 + 0) * C + c]; ss += partial[((size_t)b * 2 + 1) * C + c]; }
+    for (int b = lane; b < nb; b += DCV_WAVE) { s += partial[((size_t)b * 2 + 0) * C + c]; ss += partial[((size_t)b * 2 + 1) * C + c]; }
+    s = dcv_wave_sum(s); ss = dcv_wave_sum(ss);
+    if (lane != 0) return;
     const double n = (double)rows;
     const double mean = s / n;
     double var = ss / n - mean * mean;               // fp64: no cancellation issue at these magnitudes
@@ -131,10 +133,11 @@ __global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restri
 // coef layout (float [3][C]): a = gamma*rstd, b = sum(dy)/rows, d = sum(dy*xhat)/rows   ->  dx = a * (dy - b - xhat * d)
 __global__ void bn_finalize_bwd_kernel(const double* __restrict__ partial, int nb, size_t rows, int C, const float* __restrict__ gamma,
                                        const float* __restrict__ rstd, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x, lane = threadIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nb; ++b) { s1 += partial[((size_t)b * 2 + 0) * C + c]; s2 += partial[((size_t)b * 2 + 1) * C + c]; }
+    for (int b = lane; b < nb; b += DCV_WAVE) { s1 += partial[((size_t)b * 2 + 0) * C + c]; s2 += partial[((size_t)b * 2 + 1) * C + c]; }
+    s1 = dcv_wave_sum(s1); s2 = dcv_wave_sum(s2);
+    if (lane != 0) return;
     if (dbeta) dbeta[c] = (float)s1;
     if (dgamma) dgamma[c] = (float)s2;
     const float g = gamma ? gamma[c] : 1.f;
@@ -264,10 +267,11 @@ __global__ __launch_bounds__(DCV_CR_THREADS) void gn_bwd_kernel(const float* __r
 
 // dgamma[c] = sum_n partial[n][1][c], dbeta[c] = sum_n partial[n][0][c]   (ordered, fp64)
 __global__ void gn_param_grad_kernel(const double* __restrict__ partial, int N, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x, lane = threadIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    for (int n = 0; n < N; ++n) { s1 += partial[((size_t)n * 2 + 0) * C + c]; s2 += partial[((size_t)n * 2 + 1) * C + c]; }
+    for (int n = lane; n < N; n += DCV_WAVE) { s1 += partial[((size_t)n * 2 + 0) * C + c]; s2 += partial[((size_t)n * 2 + 1) * C + c]; }
+    s1 = dcv_wave_sum(s1); s2 = dcv_wave_sum(s2);
+    if (lane != 0) return;
     if (dbeta) dbeta[c] = (float)s1;
     if (dgamma) dgamma[c] = (float)s2;
 }
@@ -295,7 +299,7 @@ int dcv_batchnorm_fwd_train(const float* x, float* y, size_t rows, int C, const 
     SumSqLoader ld{x};
     if (C % 4 == 0) hipLaunchKernelGGL((colreduce2_kernel<4, SumSqLoader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
     else hipLaunchKernelGGL((colreduce2_kernel<1, SumSqLoader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((unsigned)dcv_ceil_div(C, 64)), dim3(64), 0, st, partial, (int)nb, rows, C, gamma, beta,
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((unsigned)C), dim3(64), 0, st, partial, (int)nb, rows, C, gamma, beta,
                        running_mean, running_var, nbt, momentum, eps, save_mean, save_rstd, scale_shift);
     if (C % 4 == 0) {
         const size_t nv = rows * (size_t)C / 4;
@@ -335,7 +339,7 @@ int dcv_batchnorm_bwd(const float* dy, const float* x, float* dx, size_t rows, i
     BnBwdLoader ld{dy, x, save_mean, save_rstd};
     if (C % 4 == 0) hipLaunchKernelGGL((colreduce2_kernel<4, BnBwdLoader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
     else hipLaunchKernelGGL((colreduce2_kernel<1, BnBwdLoader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((unsigned)dcv_ceil_div(C, 64)), dim3(64), 0, st, partial, (int)nb, rows, C, gamma, save_rstd, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((unsigned)C), dim3(64), 0, st, partial, (int)nb, rows, C, gamma, save_rstd, dgamma, dbeta, coef);
     if (C % 4 == 0) {
         const size_t nv = rows * (size_t)C / 4;
         hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(dcv_stream_grid(nv, 256)), dim3(256), 0, st, dy, x, dx, nv, C, save_mean, save_rstd, coef);
@@ -380,7 +384,7 @@ int dcv_groupnorm_bwd(const float* dy, const float* x, float* dx, int n, int hw,
     if (vec == 4) hipLaunchKernelGGL((gn_bwd_kernel<4>), dim3(n), dim3(DCV_CR_THREADS), smem, st, dy, x, dx, hw, C, G, gamma, save_mean, save_rstd, partial);
     else hipLaunchKernelGGL((gn_bwd_kernel<1>), dim3(n), dim3(DCV_CR_THREADS), smem, st, dy, x, dx, hw, C, G, gamma, save_mean, save_rstd, partial);
     if (need_param_grads)
-        hipLaunchKernelGGL(gn_param_grad_kernel, dim3((unsigned)dcv_ceil_div(C, 64)), dim3(64), 0, st, partial, n, C, dgamma, dbeta);
+        hipLaunchKernelGGL(gn_param_grad_kernel, dim3((unsigned)C), dim3(64), 0, st, partial, n, C, dgamma, dbeta);
     DCV_RETURN_LAUNCH();
 }
 

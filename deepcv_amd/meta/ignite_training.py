@@ -168,6 +168,7 @@ class GraphedTrainStep:
         self.static_x = self.static_y = None
         self.static_losses: Optional['OrderedDict[str, torch.Tensor]'] = None
         self.static_pred = None
+        self.stream: Optional[torch.cuda.Stream] = None
 
     def _eager(self, x, y):
         self.model.train()
@@ -178,7 +179,22 @@ class GraphedTrainStep:
         if self.reducer is not None:
             self.reducer.finish()
         self.optimizer.step()
-        return batch_losses, y_pred
+        # detached: no autograd graph of an eager iteration may outlive it (see `_on_side_stream`)
+        return OrderedDict((n, v.detach()) for n, v in batch_losses.items()), y_pred.detach()
+
+    def _on_side_stream(self, fn, *args):
+        """ Everything which creates autograd nodes before / during capture runs on ONE dedicated side stream: autograd's AccumulateGrad nodes remember the
+        stream they were created on, and a backward captured on another stream than a still-alive node's would drag that stream (the legacy null stream
+        for eager code) into the capture — an unjoined capture, which crashes hipStreamEndCapture. """
+        dev = next(self.model.parameters()).device
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream(dev)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            out = fn(*args)
+        cur.wait_stream(self.stream)
+        return out
 
     def _capture(self, x, y):
         dev = x.device
@@ -190,7 +206,7 @@ class GraphedTrainStep:
             hooks_were, self.reducer.enabled = self.reducer.enabled, False     # no collectives inside the captured backward
         torch.cuda.synchronize(dev)
         self.graph_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_fb):
+        with torch.cuda.graph(self.graph_fb, stream=self.stream):
             self.static_pred = self.model(self.static_x)
             self.static_losses = _batch_losses(self.losses, self.weights, self.static_pred, self.static_y)
             self.static_losses[MAIN_TRAINING_LOSS_NAME].backward()
@@ -201,7 +217,7 @@ class GraphedTrainStep:
             self._static_grads = [p.grad for p in self.reducer.params]       # graph-pool gradient tensors written by every replay
             self.reducer.finish()                                            # p.grad -> bucket views (static addresses)
             self.graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_opt):
+            with torch.cuda.graph(self.graph_opt, stream=self.stream):
                 self.optimizer.step()
         torch.cuda.synchronize(dev)
 
@@ -222,11 +238,13 @@ class GraphedTrainStep:
     def __call__(self, x, y):
         self.calls += 1
         if self.calls == 1:
-            return self._eager(x, y)
+            return self._on_side_stream(self._eager, x, y)
         if self.graph_fb is None:
+            if self.stream is None:
+                self._on_side_stream(lambda: None)
             self._capture(x, y)
         if x.shape != self.static_x.shape or (isinstance(y, torch.Tensor) and y.shape != self.static_y.shape):
-            return self._eager(x, y)
+            return self._on_side_stream(self._eager, x, y)
         return self._replay(x, y)
 
 

@@ -1,0 +1,307 @@
+""" GPU parity tests, per native op: HIP kernels (through the C-ABI, `deepcv_amd.ops`) vs the CPU oracle (`oracle/ops_ref.py`, fp64 torch ops) on the
+same seeded inputs.  Tolerances are relative to the reference's magnitude: `max|got - ref| <= tol * max|ref|`; fp32 kernels with fp32 accumulation over
+K <= 4608 products / N*H*W <= 5e5 rows land around 1e-6..1e-5, the asserted bounds (1e-4 forward, 3e-4 gradients) leave an order of magnitude. """
+import os
+from pathlib import Path
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+REPORT = Path(__file__).resolve().parent.parent / 'gpurun_out' / 'ops_report.txt'
+
+
+def _report(line: str):
+    try:
+        REPORT.parent.mkdir(parents=True, exist_ok=True)
+        with open(REPORT, 'a') as f:
+            f.write(line + '\n')
+    except OSError:
+        pass
+
+
+def _check(name: str, got: torch.Tensor, ref: torch.Tensor, tol: float):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, f'{name}: shape {tuple(got.shape)} != {tuple(ref.shape)}'
+    scale = ref.abs().max().item() + 1e-12
+    err = (got - ref).abs().max().item() / scale
+    finite = bool(torch.isfinite(got).all())
+    _report(f'{name}: rel_err={err:.3e} (tol {tol:.0e}) finite={finite} ref_max={scale:.3e}')
+    assert finite, f'{name}: non-finite values'
+    assert err <= tol, f'{name}: relative error {err:.3e} > {tol:.0e}'
+
+
+def _cl(t: torch.Tensor) -> torch.Tensor:
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+CONV_CASES = [
+    # (N, Cin, H, W, Cout, k, stride, pad, dil, act, nchw_input)   -- stock layers first (conf/base/parameters.yml:12-17)
+    (8, 3, 32, 32, 4, 5, 1, 2, 1, 1, True),
+    (8, 4, 32, 32, 4, 5, 1, 2, 1, 1, False),
+    (8, 4, 16, 16, 16, 3, 1, 1, 1, 1, False),
+    (8, 16, 16, 16, 16, 3, 1, 1, 1, 2, False),
+    (4, 3, 32, 32, 4, 5, 1, 2, 1, 0, False),       # Cin=3 NHWC scalar path, no activation
+    (2, 8, 9, 11, 10, 3, 1, 1, 1, 3, False),       # ragged sizes, Cout not a multiple of 4, sigmoid
+    (2, 16, 12, 12, 8, 1, 1, 0, 1, 4, False),      # 1x1, tanh
+    (2, 4, 15, 15, 6, 7, 1, 3, 1, 1, False),       # 7x7
+    (2, 3, 33, 33, 8, 7, 2, 3, 1, 1, True),        # strided stem (generic kernel), NCHW input
+    (2, 8, 16, 16, 12, 3, 2, 1, 1, 0, False),      # stride 2 (generic fwd + gather dgrad)
+    (2, 4, 14, 14, 4, 3, 1, 2, 2, 1, False),       # dilation 2 (generic)
+    (2, 4, 10, 10, 4, 2, 1, 0, 1, 0, False),       # even kernel (generic)
+    (1, 40, 8, 8, 24, 3, 1, 1, 1, 1, False),       # wider channels through the direct fallback (units > 256 in wgrad)
+    (2, 5, 8, 8, 3, 3, 1, 0, 1, 0, False),         # no padding, odd channels
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'x'.join(str(v) for v in c))
+def test_conv2d_fwd_bwd(device, case):
+    from deepcv_amd import ops
+    from oracle import ops_ref
+    n, cin, h, w, cout, k, stride, pad, dil, act, nchw = case
+    g = torch.Generator().manual_seed(1234 + sum(int(v) for v in case))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * 0.2
+    b = torch.randn(cout, generator=g)
+    ho = (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    wo = (w + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    dy = torch.randn(n, cout, ho, wo, generator=g)
+    ref = ops_ref.conv2d_act(x, wt, b, stride, pad, dil, act, 0.01, dy)
+
+    xd = x.to(device) if nchw else _cl(x.to(device))
+    xd.requires_grad_(True)
+    wd, bd = wt.to(device).requires_grad_(True), b.to(device).requires_grad_(True)
+    y = ops.conv2d(xd, wd, bd, stride, pad, dil, act, 0.01)
+    assert y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(_cl(dy.to(device)))
+    torch.cuda.synchronize()
+    name = f'conv{case}'
+    _check(name + '.y', y, ref['y'], 1e-4)
+    _check(name + '.dx', xd.grad, ref['dx'], 3e-4)
+    _check(name + '.dw', wd.grad, ref['dw'], 3e-4)
+    _check(name + '.db', bd.grad, ref['db'], 3e-4)
+
+
+def test_conv2d_no_bias_no_input_grad(device):
+    from deepcv_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(7)
+    x, wt, dy = torch.randn(4, 4, 12, 12, generator=g), torch.randn(8, 4, 3, 3, generator=g), torch.randn(4, 8, 12, 12, generator=g)
+    ref = ops_ref.conv2d_act(x, wt, None, 1, 1, 1, 0, 0., dy)
+    wd = wt.to(device).requires_grad_(True)
+    y = ops.conv2d(_cl(x.to(device)), wd, None, 1, 1, 1)
+    y.backward(_cl(dy.to(device)))
+    _check('conv_nobias.y', y, ref['y'], 1e-4)
+    _check('conv_nobias.dw', wd.grad, ref['dw'], 3e-4)
+
+
+@pytest.mark.parametrize('shape', [(8, 4, 32, 32), (8, 16, 16, 16), (4, 64, 8, 8), (3, 10, 7, 5), (2, 3, 9, 9), (64, 10)], ids=str)
+@pytest.mark.parametrize('affine', [True, False])
+def test_batch_norm(device, shape, affine):
+    from deepcv_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(11 + len(shape) + shape[1])
+    c = shape[1]
+    x = torch.randn(*shape, generator=g) * 2.0 + 0.5
+    gamma = torch.rand(c, generator=g) if affine else None
+    beta = torch.randn(c, generator=g) if affine else None
+    rm, rv = torch.randn(c, generator=g), torch.rand(c, generator=g) + 0.5
+    dy = torch.randn(*shape, generator=g)
+    mom, eps = 0.07359778246238029, 1e-5
+    ref = ops_ref.batch_norm_train(x, gamma, beta, rm, rv, mom, eps, dy)
+
+    xd = (_cl(x.to(device)) if x.dim() == 4 else x.to(device)).requires_grad_(True)
+    gd = gamma.to(device).requires_grad_(True) if affine else None
+    bd = beta.to(device).requires_grad_(True) if affine else None
+    rmd, rvd, nbt = rm.to(device), rv.to(device), torch.zeros((), dtype=torch.int64, device=device)
+    y = ops.batch_norm(xd, gd, bd, rmd, rvd, nbt, True, mom, eps)
+    y.backward(_cl(dy.to(device)) if x.dim() == 4 else dy.to(device))
+    name = f'bn{shape}{"A" if affine else ""}'
+    _check(name + '.y', y, ref['y'], 1e-4)
+    _check(name + '.dx', xd.grad, ref['dx'], 3e-4)
+    if affine:
+        _check(name + '.dgamma', gd.grad, ref['dgamma'], 3e-4)
+        _check(name + '.dbeta', bd.grad, ref['dbeta'], 3e-4)
+    _check(name + '.running_mean', rmd, ref['running_mean'], 1e-5)
+    _check(name + '.running_var', rvd, ref['running_var'], 1e-5)
+    assert int(nbt) == 1
+    with torch.no_grad():
+        ye = ops.batch_norm(xd.detach(), gd, bd, rmd, rvd, nbt, False, mom, eps)
+    _check(name + '.eval', ye, ops_ref.batch_norm_eval(x, gamma, beta, ref['running_mean'], ref['running_var'], eps), 1e-4)
+
+
+@pytest.mark.parametrize('shape,groups', [((8, 4, 32, 32), 4), ((8, 16, 16, 16), 4), ((3, 12, 5, 7), 3), ((2, 6, 4, 4), 2), ((2, 64, 8, 8), 32)], ids=str)
+def test_group_norm(device, shape, groups):
+    from deepcv_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(5 + shape[1])
+    c = shape[1]
+    x = torch.randn(*shape, generator=g) * 1.5 - 0.3
+    gamma, beta, dy = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g), torch.randn(*shape, generator=g)
+    ref = ops_ref.group_norm(x, groups, gamma, beta, 1e-5, dy)
+    xd = _cl(x.to(device)).requires_grad_(True)
+    gd, bd = gamma.to(device).requires_grad_(True), beta.to(device).requires_grad_(True)
+    y = ops.group_norm(xd, gd, bd, groups, 1e-5)
+    y.backward(_cl(dy.to(device)))
+    name = f'gn{shape}g{groups}'
+    _check(name + '.y', y, ref['y'], 1e-4)
+    _check(name + '.dx', xd.grad, ref['dx'], 3e-4)
+    _check(name + '.dgamma', gd.grad, ref['dgamma'], 3e-4)
+    _check(name + '.dbeta', bd.grad, ref['dbeta'], 3e-4)
+
+
+@pytest.mark.parametrize('mode', ['avg', 'max'])
+@pytest.mark.parametrize('shape,k,s,p', [((8, 4, 32, 32), 2, 2, 0), ((8, 16, 16, 16), 2, 2, 0), ((2, 8, 15, 17), 3, 2, 1), ((2, 3, 9, 9), 3, 1, 1), ((2, 64, 7, 7), 7, 7, 0)], ids=str)
+def test_pool2d(device, mode, shape, k, s, p):
+    from deepcv_amd import ops, _native as nat
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(3 + shape[1] + k)
+    x = torch.randn(*shape, generator=g)
+    ho, wo = (shape[2] + 2 * p - k) // s + 1, (shape[3] + 2 * p - k) // s + 1
+    dy = torch.randn(shape[0], shape[1], ho, wo, generator=g)
+    ref = ops_ref.pool2d(x, k, s, p, mode, dy)
+    xd = _cl(x.to(device)).requires_grad_(True)
+    y = ops.pool2d(xd, k, s, p, nat.POOL_AVG if mode == 'avg' else nat.POOL_MAX)
+    y.backward(_cl(dy.to(device)))
+    name = f'pool_{mode}{shape}k{k}s{s}p{p}'
+    _check(name + '.y', y, ref['y'], 1e-6)
+    _check(name + '.dx', xd.grad, ref['dx'], 1e-5)
+
+
+@pytest.mark.parametrize('shape,size,align', [((8, 4, 16, 16), (8, 8), False), ((2, 8, 7, 9), (14, 18), False), ((2, 3, 8, 8), (5, 11), False), ((2, 4, 9, 9), (4, 4), True),
+                                              ((2, 4, 5, 5), (12, 12), True)], ids=str)
+def test_interpolate_bilinear(device, shape, size, align):
+    from deepcv_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(17 + shape[2])
+    x, dy = torch.randn(*shape, generator=g), torch.randn(shape[0], shape[1], *size, generator=g)
+    ref = ops_ref.interpolate_bilinear(x, size, align, dy)
+    xd = _cl(x.to(device)).requires_grad_(True)
+    y = ops.interpolate_bilinear(xd, size, align)
+    y.backward(_cl(dy.to(device)))
+    name = f'interp{shape}->{size}a{int(align)}'
+    _check(name + '.y', y, ref['y'], 1e-5)
+    _check(name + '.dx', xd.grad, ref['dx'], 1e-5)
+
+
+def test_concat_add_flatten(device):
+    from deepcv_amd import ops
+    g = torch.Generator().manual_seed(23)
+    a, b, c = torch.randn(4, 16, 8, 8, generator=g), torch.randn(4, 4, 8, 8, generator=g), torch.randn(4, 3, 8, 8, generator=g)
+    ad, bd, cd = (_cl(t.to(device)).requires_grad_(True) for t in (a, b, c))
+    y = ops.concat_channels([ad, bd, cd])
+    ref = torch.cat([a, b, c], 1)
+    _check('concat.y', y, ref, 0.)
+    dy = torch.randn(*ref.shape, generator=g)
+    y.backward(_cl(dy.to(device)))
+    _check('concat.da', ad.grad, dy[:, :16], 0.)
+    _check('concat.db', bd.grad, dy[:, 16:20], 0.)
+    _check('concat.dc', cd.grad, dy[:, 20:], 0.)
+
+    u, v, w_ = (torch.randn(4, 8, 6, 6, generator=g) for _ in range(3))
+    ud, vd, wd = (_cl(t.to(device)).requires_grad_(True) for t in (u, v, w_))
+    s = ops.add_tensors([ud, vd, wd])
+    _check('add3.y', s, u + v + w_, 1e-6)
+    m = ops.add_tensors([ud, vd], mean=True)
+    _check('mean2.y', m, (u + v) / 2, 1e-6)
+    (s.sum() + m.sum()).backward()
+    _check('add.du', ud.grad, torch.full_like(u, 1.5), 1e-6)
+    _check('add.dw', wd.grad, torch.ones_like(w_), 1e-6)
+
+    f = torch.randn(4, 20, 8, 8, generator=g)
+    fd = _cl(f.to(device)).requires_grad_(True)
+    flat = ops.flatten_nchw_order(fd)
+    _check('flatten.y', flat, f.flatten(1), 0.)
+    dflat = torch.randn(4, 20 * 64, generator=g)
+    flat.backward(dflat.to(device))
+    _check('flatten.dx', fd.grad, dflat.view(4, 20, 8, 8), 0.)
+    x = torch.randn(3, 5, 6, 7, generator=g)
+    _check('nchw_to_nhwc', ops.nchw_to_nhwc(x.to(device)), x, 0.)
+
+
+@pytest.mark.parametrize('n,k,o,act', [(8, 1280, 10, 3), (64, 512, 100, 0), (5, 37, 7, 1), (4, 64, 3, 4)], ids=str)
+def test_linear(device, n, k, o, act):
+    from deepcv_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(31 + k)
+    x, w, b, dy = torch.randn(n, k, generator=g), torch.randn(o, k, generator=g) * 0.05, torch.randn(o, generator=g), torch.randn(n, o, generator=g)
+    ref = ops_ref.linear_act(x, w, b, act, 0.01, dy)
+    xd, wd, bd = x.to(device).requires_grad_(True), w.to(device).requires_grad_(True), b.to(device).requires_grad_(True)
+    y = ops.linear(xd, wd, bd, act, 0.01)
+    y.backward(dy.to(device))
+    name = f'linear{(n, k, o, act)}'
+    _check(name + '.y', y, ref['y'], 1e-4)
+    _check(name + '.dx', xd.grad, ref['dx'], 3e-4)
+    _check(name + '.dw', wd.grad, ref['dw'], 3e-4)
+    _check(name + '.db', bd.grad, ref['db'], 3e-4)
+
+
+@pytest.mark.parametrize('n,c', [(8, 10), (512, 10), (64, 100), (7, 1000), (1500, 3)], ids=str)
+def test_cross_entropy(device, n, c):
+    from deepcv_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(41 + c)
+    z, t = torch.randn(n, c, generator=g) * 3, torch.randint(0, c, (n,), generator=g)
+    ref = ops_ref.cross_entropy(z, t)
+    zd = z.to(device).requires_grad_(True)
+    correct = torch.zeros(1, dtype=torch.int32, device=device)
+    loss = ops.cross_entropy(zd, t.to(device), correct)
+    loss.backward()
+    _check(f'ce{(n, c)}.loss', loss, ref['loss'], 1e-5)
+    _check(f'ce{(n, c)}.dlogits', zd.grad, ref['dlogits'], 1e-4)
+    assert int(correct) == int(ref['correct'])
+
+
+@pytest.mark.parametrize('act', [1, 2, 3, 4])
+def test_activation(device, act):
+    from deepcv_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(act)
+    x, dy = torch.randn(4, 6, 5, 5, generator=g), torch.randn(4, 6, 5, 5, generator=g)
+    xd = _cl(x.to(device)).requires_grad_(True)
+    y = ops.activation(xd, act, 0.01)
+    y.backward(_cl(dy.to(device)))
+    x_ = x.clone().double().requires_grad_(True)
+    r = ops_ref._ACTS[act](x_, 0.01)
+    r.backward(dy.double())
+    _check(f'act{act}.y', y, r.detach().float(), 1e-5)
+    _check(f'act{act}.dx', xd.grad, x_.grad.float(), 1e-5)
+
+
+@pytest.mark.parametrize('kind', ['adamw', 'adamw_amsgrad', 'sgd', 'sgd_momentum', 'sgd_nesterov'])
+def test_optimizers(device, kind):
+    from deepcv_amd import optim
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(53)
+    shapes = [(4, 3, 5, 5), (4,), (16, 16, 3, 3), (10, 1280), (10,), (1,)] + [(3, 3)] * 70   # > 64 tensors: two launches
+    params = [torch.randn(*s, generator=g) for s in shapes]
+    grads = [[torch.randn(*s, generator=g) for s in shapes] for _ in range(4)]
+    lrs = [0.0, 1e-3, 2e-3, 5e-4]
+    if kind.startswith('adamw'):
+        kw = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=kind.endswith('amsgrad'))
+        ref_cls, cls = torch.optim.AdamW, optim.AdamW
+    else:
+        kw = dict(lr=0.1, momentum=0.9 if kind != 'sgd' else 0., dampening=0., weight_decay=5e-4, nesterov=kind == 'sgd_nesterov')
+        ref_cls, cls = torch.optim.SGD, optim.SGD
+    ref = ops_ref.optimizer_steps(ref_cls, kw, params, grads, lrs)
+    ps = [torch.nn.Parameter(p.to(device)) for p in params]
+    opt = cls(ps, **kw)
+    for t, gs in enumerate(grads):
+        for grp in opt.param_groups:
+            grp['lr'] = lrs[t]
+        for p, gr in zip(ps, gs):
+            p.grad = gr.to(device)
+        opt.step()
+    for i, (p, r) in enumerate(zip(ps, ref)):
+        _check(f'{kind}.p{i}', p, r, 2e-5)
+    sd = opt.state_dict()
+    if kind != 'sgd':   # plain SGD keeps no per-parameter state
+        assert int(sd['state'][0]['step']) == 4
+
+
+def test_native_rejects_cpu_tensors():
+    from deepcv_amd import ops
+    with pytest.raises(RuntimeError, match='HIP device'):
+        ops.conv2d(torch.zeros(1, 3, 8, 8), torch.zeros(4, 3, 3, 3), None, 1, 1, 1)
