@@ -80,9 +80,10 @@ def dominant_kernel_roofline(device, launches: int = 200):
     y = torch.empty_like(x)
     d = nat.Conv2dDesc(n, h, w, c, c, k, k, 1, 1, 2, 2, 1, 1, 1, h, w, nat.LAYOUT_NHWC, nat.ACT_RELU, 0.)
     st = nat.current_stream(device)
+    ws = torch.empty(max(16, nat.lib.dcv_conv2d_fwd_workspace_bytes(d)), dtype=torch.uint8, device=device)
 
     def launch():
-        nat.check(nat.lib.dcv_conv2d_fwd(d, x.data_ptr(), wt.data_ptr(), b.data_ptr(), y.data_ptr(), None, 0, st), 'dcv_conv2d_fwd')
+        nat.check(nat.lib.dcv_conv2d_fwd(d, x.data_ptr(), wt.data_ptr(), b.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(), st), 'dcv_conv2d_fwd')
     for _ in range(20):
         launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -26,12 +26,12 @@ extern "C" {
 
 size_t dcv_conv2d_fwd_workspace_bytes(const dcv_conv2d_desc* d) {
     if (!desc_ok(d)) return 0;
-    return dcv_mfma_conv2d_supported(d, 0) ? dcv_mfma_conv2d_ws(d, 0) : 0;
+    return dcv_mfma_conv2d_supported(d, 0) ? dcv_mfma_conv2d_ws(d, 0) : dcv_direct_conv2d_fwd_ws(d);
 }
 
 size_t dcv_conv2d_dgrad_workspace_bytes(const dcv_conv2d_desc* d) {
     if (!desc_ok(d)) return 0;
-    return dcv_mfma_conv2d_supported(d, 1) ? dcv_mfma_conv2d_ws(d, 1) : 0;
+    return dcv_mfma_conv2d_supported(d, 1) ? dcv_mfma_conv2d_ws(d, 1) : dcv_direct_conv2d_dgrad_ws(d);
 }
 
 size_t dcv_conv2d_wgrad_workspace_bytes(const dcv_conv2d_desc* d) {
@@ -44,7 +44,7 @@ int dcv_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, con
     DCV_CHECK_ARG(desc_ok(d) && x && w && y);
     if (d->groups != 1) return DCV_ERR_UNSUPPORTED;
     if (dcv_mfma_conv2d_supported(d, 0)) return dcv_mfma_conv2d_fwd(d, x, w, bias, y, ws, ws_bytes, dcv_stream(stream));
-    return dcv_direct_conv2d_fwd(d, x, w, bias, y, dcv_stream(stream));
+    return dcv_direct_conv2d_fwd(d, x, w, bias, y, ws, ws_bytes, dcv_stream(stream));
 }
 
 int dcv_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, void* stream) {
@@ -52,7 +52,7 @@ int dcv_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, 
     if (d->groups != 1) return DCV_ERR_UNSUPPORTED;
     if (d->x_layout != DCV_LAYOUT_NHWC) return DCV_ERR_UNSUPPORTED;   // dx is always produced NHWC
     if (dcv_mfma_conv2d_supported(d, 1)) return dcv_mfma_conv2d_dgrad(d, dy, w, dx, ws, ws_bytes, dcv_stream(stream));
-    return dcv_direct_conv2d_dgrad(d, dy, w, dx, dcv_stream(stream));
+    return dcv_direct_conv2d_dgrad(d, dy, w, dx, ws, ws_bytes, dcv_stream(stream));
 }
 
 int dcv_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, void* stream) {

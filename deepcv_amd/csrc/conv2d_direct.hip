@@ -15,6 +15,7 @@
 // Algorithmic bytes per launch (roofline "hbm"): 4 B * (N*H*W*Cin + Cout*Cin*R*S + N*Ho*Wo*Cout)   (SURVEY.md §8d).
 // Replaces torch.nn.Conv2d forward (reference src/deepcv/meta/submodule_creators.py:251) and its autograd (ignite_training.py:253).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -51,99 +52,231 @@ __device__ __forceinline__ void stage_weights(const DirectArgs& a, const float* 
     }
 }
 
-// ------------------------------------------------------------------------------------------------ stride-1 strip kernel
-// IN_MODE: 0 = NHWC with Cin % 4 == 0 (16-B loads), 1 = NHWC scalar, 2 = NCHW scalar
-template <int TCO, int S, int IN_MODE>
-__global__ __launch_bounds__(256) void conv_s1_kernel(DirectArgs a, const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                       float* __restrict__ y) {
-    constexpr int PW = 4;
-    constexpr int VEC = (IN_MODE == 0) ? 4 : 1;
+// Re-lays the OIHW filter out as wt[cout tile][R][S][Cin][TCO] (zero-padded output channels) for the scalar-cache weight path of conv_s1_kernel.
+// dgrad: kernel-input channel = original Cout, kernel-output channel = original Cin, taps flipped.
+__global__ __launch_bounds__(256) void prep_weights_kernel(DirectArgs a, const float* __restrict__ w, float* __restrict__ wt, int tco, int tiles, int cin_pad, int flip) {
+    const int total = tiles * a.R * a.S * cin_pad * tco;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int co = i % tco; int t = i / tco;
+        const int ci = t % cin_pad; t /= cin_pad;
+        const int s = t % a.S; t /= a.S;
+        const int r = t % a.R; const int tile = t / a.R;
+        const int cog = tile * tco + co;
+        float v = 0.f;
+        if (cog < a.Cout && ci < a.Cin) {
+            if (!a.dgrad) v = w[(((size_t)cog * a.w_cin + ci) * a.R + r) * a.S + s];
+            else {
+                const int rr = flip ? a.R - 1 - r : r, ss = flip ? a.S - 1 - s : s;
+                v = w[(((size_t)ci * a.w_cin + cog) * a.R + rr) * a.S + ss];
+            }
+        }
+        wt[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ LDS-tiled forward / stride-1 data gradient
+// One block = 256 output pixels (TH rows x Wout columns of one image; several whole images when they are small).  The zero-padded input halo tile is
+// staged ONCE into LDS with fully coalesced 16-B loads (lanes walk consecutive NHWC pixels: 1 KiB per wave-instruction) in a channel-vector-planar
+// layout [Cin/4][rows][cols] of float4, so that the compute phase — one output pixel per lane — reads it with conflict-free ds_read_b128 (consecutive
+// lanes = consecutive 16-B slots).  A strip-per-thread kernel reading straight from global memory was texture-addresser bound: 64-B lane strides make
+// every load instruction touch 64 separate segments.  Filter weights come from the SCALAR cache: prep_weights_kernel re-lays them out as
+// [cout tile][R][S][Cin_pad][TCO], their address is wave-uniform (s_load_dwordx4..x16 -> SGPR operands of v_fma), so they cost neither LDS bandwidth
+// nor VGPRs.  Per lane and LDS read: 4 * TCO FMAs.  Bias + activation are fused in the epilogue.
+struct TileArgs {
+    int N, Hin, Win, Cin;          // tensor read by the kernel   (fwd: x      dgrad: dy)
+    int Hout, Wout, Cout;          // tensor written by the kernel (fwd: y      dgrad: dx)
+    int R, S, sh, sw, ph, pw, dh, dw;
+    int in_nchw, act; float slope;
+    int cin_pad;                   // Cin rounded up to a multiple of 4 (padding channels are zero in LDS and in the re-laid filter)
+    int CC;                        // channels staged per LDS pass (multiple of 4)
+    int TH, XH, XW;                // output rows per sub-tile, halo tile rows / cols
+    int nsub;                      // sub-tiles (image row bands) per block
+    int tiles_per_img, total_subtiles;
+};
+
+// ST: compile-time filter width (the taps of one filter row are unrolled so that their LDS / scalar loads are issued together), 0 = runtime.
+// PPT: output pixels per thread (lane l owns pixels l, l+256, ... of the block's PPT*256-pixel tile): the per-thread setup, the scalar weight loads and
+// the loop overhead are amortised over PPT independent FMA streams.
+template <int TCO, int ST, int PPT>
+__global__ __launch_bounds__(256) void conv_tile_kernel(TileArgs a, const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
+                                                         float* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* wl = reinterpret_cast<float*>(smem);
-
-    const int strips_w = (a.Wout + PW - 1) / PW;
-    const size_t total = (size_t)a.N * a.Hout * strips_w;
-    const size_t sid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = sid < total;
-    int n = 0, ho = 0, wo0 = 0;
-    if (active) { size_t t = sid; wo0 = (int)(t % strips_w) * PW; t /= strips_w; ho = (int)(t % a.Hout); n = (int)(t / a.Hout); }
+    float4* xs = reinterpret_cast<float4*>(smem);            // [CC/4][nsub][XH][XW]
+    const int t = threadIdx.x;
+    const int px_per_sub = a.TH * a.Wout;
     const int co0 = blockIdx.y * TCO;
+    const int plane = a.nsub * a.XH * a.XW;                  // float4 elements per channel-vector plane
+    const float* __restrict__ wtile = wt + (size_t)blockIdx.y * a.R * a.S * a.cin_pad * TCO;
 
-    float acc[PW][TCO];
+    int lds_off[PPT];                                        // float4 offset of the pixel's window origin inside plane 0
+    size_t out_off[PPT];
+    bool active[PPT];
 #pragma unroll
-    for (int p = 0; p < PW; ++p)
-#pragma unroll
-        for (int c = 0; c < TCO; ++c) acc[p][c] = 0.f;
+    for (int k = 0; k < PPT; ++k) {
+        const int q = t + 256 * k;
+        const int sub = q / px_per_sub, lp = q - sub * px_per_sub;
+        const int hl = lp / a.Wout, wl = lp - hl * a.Wout;
+        const int g = blockIdx.x * a.nsub + sub;
+        const int n = g / a.tiles_per_img, ho = (g - n * a.tiles_per_img) * a.TH + hl;
+        active[k] = (sub < a.nsub) && (g < a.total_subtiles) && (ho < a.Hout);
+        lds_off[k] = active[k] ? (sub * a.XH + hl * a.sh) * a.XW + wl * a.sw : 0;
+        out_off[k] = (((size_t)n * a.Hout + ho) * a.Wout + wl) * a.Cout + co0;
+    }
 
-    for (int ci0 = 0; ci0 < a.Cin; ci0 += a.cin_chunk) {
-        const int cc = (a.Cin - ci0 < a.cin_chunk) ? (a.Cin - ci0) : a.cin_chunk;
-        __syncthreads();
-        stage_weights<TCO>(a, w, wl, co0, ci0, cc, true);
-        __syncthreads();
-        if (!active) continue;
-        for (int r = 0; r < a.R; ++r) {
-            const int hi = ho + r - a.ph;
-            if (hi < 0 || hi >= a.Hin) continue;
-            for (int ci = 0; ci < cc; ci += VEC) {
-                float xin[PW + S - 1][VEC];
+    float acc[PPT][TCO];
 #pragma unroll
-                for (int j = 0; j < PW + S - 1; ++j) {
-                    const int wi = wo0 + j - a.pw;
-                    const bool ok = (wi >= 0) && (wi < a.Win);
-                    if constexpr (IN_MODE == 0) {
-                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (ok) v = *reinterpret_cast<const float4*>(x + (((size_t)n * a.Hin + hi) * a.Win + wi) * a.Cin + ci0 + ci);
-                        xin[j][0] = v.x; xin[j][1] = v.y; xin[j][2] = v.z; xin[j][3] = v.w;
-                    } else if constexpr (IN_MODE == 1) {
-                        xin[j][0] = ok ? x[(((size_t)n * a.Hin + hi) * a.Win + wi) * a.Cin + ci0 + ci] : 0.f;
-                    } else {
-                        xin[j][0] = ok ? x[(((size_t)n * a.Cin + ci0 + ci) * a.Hin + hi) * a.Win + wi] : 0.f;
+    for (int k = 0; k < PPT; ++k)
+#pragma unroll
+        for (int c = 0; c < TCO; ++c) acc[k][c] = 0.f;
+
+    for (int ci0 = 0; ci0 < a.cin_pad; ci0 += a.CC) {
+        const int cc = (a.cin_pad - ci0 < a.CC) ? (a.cin_pad - ci0) : a.CC;
+        const int cv = cc >> 2;
+        __syncthreads();
+        // ---- stage the halo tiles of this block (all sub-tiles) for channels [ci0, ci0 + cc)
+        // Integer division is ~40 VALU instructions on this ISA: every index decode below is hoisted out of the copy loops (two divisions per thread),
+        // the loops themselves only add strides.
+        if (!a.in_nchw && (a.Cin & 3) == 0) {
+            const int rowlen = a.XW * cv;                                  // float4 elements per halo row: (column, channel-vector) pairs, contiguous in HBM
+            if (rowlen <= 256) {
+                const int rows_per_iter = 256 / rowlen;
+                const int r0 = t / rowlen, e = t - r0 * rowlen;
+                const int xc = e / cv, c4 = e - xc * cv;
+                const int wi = xc - a.pw;
+                const bool col_ok = wi >= 0 && wi < a.Win;
+                const int wic = wi < 0 ? 0 : (wi >= a.Win ? a.Win - 1 : wi);
+                if (r0 < rows_per_iter) {
+                    for (int sb = 0; sb < a.nsub; ++sb) {
+                        const int gs = blockIdx.x * a.nsub + sb;
+                        const int ns = gs / a.tiles_per_img, h0 = (gs - ns * a.tiles_per_img) * a.TH;   // wave-uniform: scalar ALU
+                        const int nc = ns < a.N ? ns : a.N - 1;
+                        const bool sub_ok = gs < a.total_subtiles;
+                        for (int xr = r0; xr < a.XH; xr += rows_per_iter) {
+                            const int hi = h0 * a.sh - a.ph + xr;
+                            const bool ok = sub_ok && col_ok && hi >= 0 && hi < a.Hin;
+                            const int hic = hi < 0 ? 0 : (hi >= a.Hin ? a.Hin - 1 : hi);
+                            float4 v = *reinterpret_cast<const float4*>(x + (((size_t)nc * a.Hin + hic) * a.Win + wic) * a.Cin + ci0 + c4 * 4);   // unconditional (clamped) load
+                            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                            xs[(size_t)c4 * plane + ((size_t)sb * a.XH + xr) * a.XW + xc] = v;
+                        }
                     }
                 }
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) {
-                        const float* wp = wl + ((size_t)(r * S + s) * cc + ci + v) * TCO;
-                        float wv[TCO];
-#pragma unroll
-                        for (int c = 0; c < TCO; c += 4) {
-                            const float4 t = *reinterpret_cast<const float4*>(wp + c);
-                            wv[c] = t.x; wv[c + 1] = t.y; wv[c + 2] = t.z; wv[c + 3] = t.w;
+            } else {
+                // very wide rows: walk (column, channel-vector) pairs with a stride of 256 inside each row
+                for (int sb = 0; sb < a.nsub; ++sb) {
+                    const int gs = blockIdx.x * a.nsub + sb;
+                    const int ns = gs / a.tiles_per_img, h0 = (gs - ns * a.tiles_per_img) * a.TH;
+                    const int nc = ns < a.N ? ns : a.N - 1;
+                    for (int xr = 0; xr < a.XH; ++xr) {
+                        const int hi = h0 * a.sh - a.ph + xr;
+                        const bool row_ok = gs < a.total_subtiles && hi >= 0 && hi < a.Hin;
+                        const int hic = hi < 0 ? 0 : (hi >= a.Hin ? a.Hin - 1 : hi);
+                        for (int e = t; e < rowlen; e += 256) {
+                            const int xc = e / cv, c4 = e - xc * cv;
+                            const int wi = xc - a.pw;
+                            const int wic = wi < 0 ? 0 : (wi >= a.Win ? a.Win - 1 : wi);
+                            float4 v = *reinterpret_cast<const float4*>(x + (((size_t)nc * a.Hin + hic) * a.Win + wic) * a.Cin + ci0 + c4 * 4);
+                            if (!(row_ok && wi >= 0 && wi < a.Win)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                            xs[(size_t)c4 * plane + ((size_t)sb * a.XH + xr) * a.XW + xc] = v;
                         }
+                    }
+                }
+            }
+        } else {
+            // scalar staging: NCHW planes (column index fastest -> coalesced) or NHWC with Cin % 4 != 0; padding channels are written as zeros.
+            // Thread = fixed (column, channel) pair chosen once; loops walk rows.
+            float* xf = reinterpret_cast<float*>(smem);
+            const int rowlen = a.XW * cc;
+            for (int e0 = 0; e0 < rowlen; e0 += 256) {
+                const int e = e0 + t;
+                if (e < rowlen) {
+                    int xc, c;
+                    if (a.in_nchw) { c = e / a.XW; xc = e - c * a.XW; } else { xc = e / cc; c = e - xc * cc; }
+                    const int wi = xc - a.pw, cg = ci0 + c;
+                    const bool col_ok = wi >= 0 && wi < a.Win && cg < a.Cin;
+                    const int wic = wi < 0 ? 0 : (wi >= a.Win ? a.Win - 1 : wi), cgc = cg < a.Cin ? cg : a.Cin - 1;
+                    for (int sb = 0; sb < a.nsub; ++sb) {
+                        const int gs = blockIdx.x * a.nsub + sb;
+                        const int ns = gs / a.tiles_per_img, h0 = (gs - ns * a.tiles_per_img) * a.TH;
+                        const int nc = ns < a.N ? ns : a.N - 1;
+                        const bool sub_ok = gs < a.total_subtiles;
+                        for (int xr = 0; xr < a.XH; ++xr) {
+                            const int hi = h0 * a.sh - a.ph + xr;
+                            const bool ok = sub_ok && col_ok && hi >= 0 && hi < a.Hin;
+                            const int hic = hi < 0 ? 0 : (hi >= a.Hin ? a.Hin - 1 : hi);
+                            const float v = a.in_nchw ? x[(((size_t)nc * a.Cin + cgc) * a.Hin + hic) * a.Win + wic] : x[(((size_t)nc * a.Hin + hic) * a.Win + wic) * a.Cin + cgc];
+                            xf[((size_t)(c >> 2) * plane + ((size_t)sb * a.XH + xr) * a.XW + xc) * 4 + (c & 3)] = ok ? v : 0.f;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const int SW = ST > 0 ? ST : a.S;
+            for (int r = 0; r < a.R; ++r) {
+                const int rowoff = (r * a.dh) * a.XW;
+                const float* __restrict__ wrow = wtile + ((size_t)(r * SW) * a.cin_pad + ci0) * TCO;   // wave-uniform -> scalar loads
+                for (int c4 = 0; c4 < cv; ++c4) {
+                    const float4* __restrict__ pl = xs + (size_t)c4 * plane + rowoff;
+                    if constexpr (ST > 0) {
 #pragma unroll
-                        for (int p = 0; p < PW; ++p)
+                        for (int s = 0; s < ST; ++s) {
+                            const float* __restrict__ w4 = wrow + ((size_t)s * a.cin_pad + c4 * 4) * TCO;
 #pragma unroll
-                            for (int c = 0; c < TCO; ++c) acc[p][c] = fmaf(xin[p + s][v], wv[c], acc[p][c]);
+                            for (int k = 0; k < PPT; ++k) {
+                                const float4 xv = pl[lds_off[k] + s * a.dw];
+#pragma unroll
+                                for (int c = 0; c < TCO; ++c) {
+                                    acc[k][c] = fmaf(xv.x, w4[c], acc[k][c]);
+                                    acc[k][c] = fmaf(xv.y, w4[TCO + c], acc[k][c]);
+                                    acc[k][c] = fmaf(xv.z, w4[2 * TCO + c], acc[k][c]);
+                                    acc[k][c] = fmaf(xv.w, w4[3 * TCO + c], acc[k][c]);
+                                }
+                            }
+                        }
+                    } else {
+                        for (int s = 0; s < SW; ++s) {
+                            const float* __restrict__ w4 = wrow + ((size_t)s * a.cin_pad + c4 * 4) * TCO;
+#pragma unroll
+                            for (int k = 0; k < PPT; ++k) {
+                                const float4 xv = pl[lds_off[k] + s * a.dw];
+#pragma unroll
+                                for (int c = 0; c < TCO; ++c) {
+                                    acc[k][c] = fmaf(xv.x, w4[c], acc[k][c]);
+                                    acc[k][c] = fmaf(xv.y, w4[TCO + c], acc[k][c]);
+                                    acc[k][c] = fmaf(xv.z, w4[2 * TCO + c], acc[k][c]);
+                                    acc[k][c] = fmaf(xv.w, w4[3 * TCO + c], acc[k][c]);
+                                }
+                            }
+                        }
                     }
                 }
             }
         }
     }
-    if (!active) return;
     float bv[TCO];
 #pragma unroll
     for (int c = 0; c < TCO; ++c) bv[c] = (bias != nullptr && co0 + c < a.Cout) ? bias[co0 + c] : 0.f;
-    const bool vec_store = (a.Cout % 4 == 0);
+    const bool vec_store = (a.Cout & 3) == 0;
 #pragma unroll
-    for (int p = 0; p < PW; ++p) {
-        const int wo = wo0 + p;
-        if (wo >= a.Wout) break;
-        float* yp = y + (((size_t)n * a.Hout + ho) * a.Wout + wo) * a.Cout + co0;
+    for (int k = 0; k < PPT; ++k) {
+        if (!active[k]) continue;
+        float* yp = y + out_off[k];
         if (vec_store) {
 #pragma unroll
             for (int c = 0; c < TCO; c += 4) {
                 if (co0 + c < a.Cout) {
                     float4 o;
-                    o.x = dcv_act_apply(acc[p][c] + bv[c], a.act, a.slope); o.y = dcv_act_apply(acc[p][c + 1] + bv[c + 1], a.act, a.slope);
-                    o.z = dcv_act_apply(acc[p][c + 2] + bv[c + 2], a.act, a.slope); o.w = dcv_act_apply(acc[p][c + 3] + bv[c + 3], a.act, a.slope);
+                    o.x = dcv_act_apply(acc[k][c] + bv[c], a.act, a.slope); o.y = dcv_act_apply(acc[k][c + 1] + bv[c + 1], a.act, a.slope);
+                    o.z = dcv_act_apply(acc[k][c + 2] + bv[c + 2], a.act, a.slope); o.w = dcv_act_apply(acc[k][c + 3] + bv[c + 3], a.act, a.slope);
                     *reinterpret_cast<float4*>(yp + c) = o;
                 }
             }
         } else {
 #pragma unroll
             for (int c = 0; c < TCO; ++c)
-                if (co0 + c < a.Cout) yp[c] = dcv_act_apply(acc[p][c] + bv[c], a.act, a.slope);
+                if (co0 + c < a.Cout) yp[c] = dcv_act_apply(acc[k][c] + bv[c], a.act, a.slope);
         }
     }
 }
@@ -296,22 +429,155 @@ __global__ __launch_bounds__(256) void conv_wgrad_partial_kernel(WgradArgs a, co
     }
 }
 
-// dw[i] = sum over chunks of partial[chunk][i]: block = 32 consecutive weights x 8 chunk lanes (coalesced 128-B rows, chunks/8 serial loads per thread),
-// merged through LDS in a fixed order
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int chunks, size_t wtotal) {
-    __shared__ float red[8][32];
+// dw[i] = sum over chunks of partial[chunk][i]: block = 32 consecutive weights x 32 chunk lanes (coalesced 128-B rows, chunks/32 serial loads per
+// thread), merged through LDS in a fixed order
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int chunks, size_t wtotal) {
+    __shared__ float red[32][33];
     const int wl = threadIdx.x & 31, cl = threadIdx.x >> 5;
     const size_t wi = (size_t)blockIdx.x * 32 + wl;
     float s = 0.f;
     if (wi < wtotal)
-        for (int c = cl; c < chunks; c += 8) s += partial[(size_t)c * wtotal + wi];
+        for (int c = cl; c < chunks; c += 32) s += partial[(size_t)c * wtotal + wi];
     red[cl][wl] = s;
     __syncthreads();
     if (cl == 0 && wi < wtotal) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[k][wl];
+        for (int k = 0; k < 32; ++k) t += red[k][wl];
         dw[wi] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ LDS-tiled weight gradient
+// One block walks tiles of TH output rows x Wo columns of one image: the zero-padded input halo tile [XH][XW][Cin] and the dy tile [TH*Wo][TCO]
+// are staged in LDS with coalesced 16-B loads (padding resolved while staging: no bounds checks in the inner loop), then every thread owns one
+// "unit" = (VEC input channels, tap r, tap s) x ALL TCO output channels of the tile and sweeps the tile's pixels from LDS: per pixel one
+// ds_read_b128 of x, TCO/4 wave-broadcast ds_read_b128 of dy and TCO*VEC FMAs.  Units fewer than 256 are replicated over `nsub` pixel sub-streams.
+// Accumulators stay in registers across all tiles of the block; sub-streams are merged through LDS in a fixed order and ONE partial slab per block
+// goes to the ordered second stage (wgrad_reduce_kernel) -> deterministic.
+struct WgTiledArgs {
+    int N, H, W, Cin, Ho, Wo, Cout, R, S, sh, sw, ph, pw, dh, dw;
+    int x_nchw;
+    int TH, XH, XW;                // tile height (output rows), halo tile dims (input rows / cols incl. padding)
+    int units, civ, nsub;          // units = civ * R * S ; civ = Cin / VEC ; nsub = 256 / units
+    int tiles_per_img, total_tiles;
+    size_t wtotal;
+};
+
+template <int TCO, int VEC>
+__global__ __launch_bounds__(256) void conv_wgrad_tiled_kernel(WgTiledArgs a, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = reinterpret_cast<float*>(smem);                       // [XH][XW][Cin]
+    float* dys = xs + (size_t)a.XH * a.XW * a.Cin;                    // [TH*Wo][TCO]
+    const int t = threadIdx.x;
+    const int ul = t % a.units, sub = t / a.units;
+    const bool active = sub < a.nsub;
+    const int s = ul % a.S, r = (ul / a.S) % a.R, civ = ul / (a.S * a.R);
+    const int ci0 = civ * VEC;
+    const int xbase = ((r * a.dh) * a.XW + s * a.dw) * a.Cin + ci0;
+    const int co0 = blockIdx.y * TCO;
+
+    float acc[TCO][VEC];
+#pragma unroll
+    for (int j = 0; j < TCO; ++j)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[j][v] = 0.f;
+
+    for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+        const int n = tile / a.tiles_per_img, ho0 = (tile % a.tiles_per_img) * a.TH;
+        const int th = (a.Ho - ho0 < a.TH) ? (a.Ho - ho0) : a.TH;
+        const int hi0 = ho0 * a.sh - a.ph, wi0 = -a.pw;
+        __syncthreads();
+        if (!a.x_nchw) {
+            if constexpr (VEC == 4) {
+                const int cv = a.Cin / 4, tot = a.XH * a.XW * cv;
+                for (int i = t; i < tot; i += 256) {
+                    const int c4 = i % cv; int q = i / cv; const int xc = q % a.XW, xr = q / a.XW;
+                    const int hi = hi0 + xr, wi = wi0 + xc;
+                    const bool ok = hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+                    const int hic = hi < 0 ? 0 : (hi >= a.H ? a.H - 1 : hi), wic = wi < 0 ? 0 : (wi >= a.W ? a.W - 1 : wi);
+                    float4 v = *reinterpret_cast<const float4*>(x + (((size_t)n * a.H + hic) * a.W + wic) * a.Cin + c4 * 4);   // unconditional, zeroed below
+                    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(xs + ((size_t)xr * a.XW + xc) * a.Cin + c4 * 4) = v;
+                }
+            } else {
+                const int tot = a.XH * a.XW * a.Cin;
+                for (int i = t; i < tot; i += 256) {
+                    const int c = i % a.Cin; int q = i / a.Cin; const int xc = q % a.XW, xr = q / a.XW;
+                    const int hi = hi0 + xr, wi = wi0 + xc;
+                    const bool ok = hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+                    const int hic = hi < 0 ? 0 : (hi >= a.H ? a.H - 1 : hi), wic = wi < 0 ? 0 : (wi >= a.W ? a.W - 1 : wi);
+                    const float v = x[(((size_t)n * a.H + hic) * a.W + wic) * a.Cin + c];
+                    xs[i] = ok ? v : 0.f;
+                }
+            }
+        } else {
+            const int tot = a.Cin * a.XH * a.XW;                      // column index fastest: coalesced reads of the NCHW planes
+            for (int i = t; i < tot; i += 256) {
+                const int xc = i % a.XW; int q = i / a.XW; const int xr = q % a.XH, c = q / a.XH;
+                const int hi = hi0 + xr, wi = wi0 + xc;
+                const bool ok = hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+                const int hic = hi < 0 ? 0 : (hi >= a.H ? a.H - 1 : hi), wic = wi < 0 ? 0 : (wi >= a.W ? a.W - 1 : wi);
+                const float v = x[(((size_t)n * a.Cin + c) * a.H + hic) * a.W + wic];
+                xs[((size_t)xr * a.XW + xc) * a.Cin + c] = ok ? v : 0.f;
+            }
+        }
+        {
+            const int npx = a.TH * a.Wo, tot = npx * (TCO / 4);
+            const bool full = (a.Cout % 4 == 0);
+            for (int i = t; i < tot; i += 256) {
+                const int c4 = i % (TCO / 4), p = i / (TCO / 4);
+                const int hl = p / a.Wo, wl = p - hl * a.Wo;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int co = co0 + c4 * 4;
+                if (hl < th && co < a.Cout) {
+                    const float* src = dy + (((size_t)n * a.Ho + ho0 + hl) * a.Wo + wl) * a.Cout + co;
+                    if (full) v = *reinterpret_cast<const float4*>(src);
+                    else { v.x = src[0]; if (co + 1 < a.Cout) v.y = src[1]; if (co + 2 < a.Cout) v.z = src[2]; if (co + 3 < a.Cout) v.w = src[3]; }
+                }
+                *reinterpret_cast<float4*>(dys + (size_t)p * TCO + c4 * 4) = v;
+            }
+        }
+        __syncthreads();
+        if (active) {
+            const int npx = th * a.Wo;
+            for (int p = sub; p < npx; p += a.nsub) {
+                const int hl = p / a.Wo, wl = p - hl * a.Wo;
+                const float* xp = xs + xbase + ((hl * a.sh) * a.XW + wl * a.sw) * a.Cin;
+                float xv[VEC];
+                if constexpr (VEC == 4) { const float4 v = *reinterpret_cast<const float4*>(xp); xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w; }
+                else xv[0] = xp[0];
+                const float* gp = dys + (size_t)p * TCO;
+#pragma unroll
+                for (int j = 0; j < TCO; j += 4) {
+                    const float4 g = *reinterpret_cast<const float4*>(gp + j);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        acc[j][v] = fmaf(g.x, xv[v], acc[j][v]); acc[j + 1][v] = fmaf(g.y, xv[v], acc[j + 1][v]);
+                        acc[j + 2][v] = fmaf(g.z, xv[v], acc[j + 2][v]); acc[j + 3][v] = fmaf(g.w, xv[v], acc[j + 3][v]);
+                    }
+                }
+            }
+        }
+    }
+    // merge the pixel sub-streams (fixed order) one output channel at a time through LDS, then write this block's partial slab
+    float* red = reinterpret_cast<float*>(smem);                      // 256 * VEC floats (tile buffers are dead now)
+    float* dst = partial + (size_t)blockIdx.x * a.wtotal;
+#pragma unroll
+    for (int j = 0; j < TCO; ++j) {
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) red[v * 256 + t] = acc[j][v];
+        __syncthreads();
+        const int co = co0 + j;
+        if (sub == 0 && co < a.Cout) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                float sum = 0.f;
+                for (int k = 0; k < a.nsub; ++k) sum += red[v * 256 + k * a.units + ul];
+                dst[(((size_t)co * a.Cin + ci0 + v) * a.R + r) * a.S + s] = sum;
+            }
+        }
     }
 }
 
@@ -342,22 +608,6 @@ inline int pick_cin_chunk(int cin, int r, int s, int tco, int vec) {
 }
 
 template <int TCO, int IN_MODE>
-int launch_s1(const DirectArgs& a, const float* x, const float* w, const float* bias, float* y, hipStream_t st) {
-    const int strips_w = (a.Wout + 3) / 4;
-    const size_t total = (size_t)a.N * a.Hout * strips_w;
-    dim3 grid((unsigned)dcv_ceil_div(total, 256), (unsigned)dcv_ceil_div(a.Cout, TCO));
-    const size_t smem = (size_t)a.R * a.S * a.cin_chunk * TCO * sizeof(float);
-    switch (a.S) {
-        case 1: hipLaunchKernelGGL((conv_s1_kernel<TCO, 1, IN_MODE>), grid, dim3(256), smem, st, a, x, w, bias, y); break;
-        case 3: hipLaunchKernelGGL((conv_s1_kernel<TCO, 3, IN_MODE>), grid, dim3(256), smem, st, a, x, w, bias, y); break;
-        case 5: hipLaunchKernelGGL((conv_s1_kernel<TCO, 5, IN_MODE>), grid, dim3(256), smem, st, a, x, w, bias, y); break;
-        case 7: hipLaunchKernelGGL((conv_s1_kernel<TCO, 7, IN_MODE>), grid, dim3(256), smem, st, a, x, w, bias, y); break;
-        default: return DCV_ERR_UNSUPPORTED;
-    }
-    return DCV_OK;
-}
-
-template <int TCO, int IN_MODE>
 int launch_generic(const DirectArgs& a, const float* x, const float* w, const float* bias, float* y, hipStream_t st) {
     const size_t total = (size_t)a.N * a.Hout * a.Wout;
     dim3 grid((unsigned)dcv_ceil_div(total, 256), (unsigned)dcv_ceil_div(a.Cout, TCO));
@@ -367,14 +617,7 @@ int launch_generic(const DirectArgs& a, const float* x, const float* w, const fl
 }
 
 template <int IN_MODE>
-int dispatch_tco(bool s1, int tco, const DirectArgs& a, const float* x, const float* w, const float* bias, float* y, hipStream_t st) {
-    if (s1) {
-        switch (tco) {
-            case 4: return launch_s1<4, IN_MODE>(a, x, w, bias, y, st);
-            case 8: return launch_s1<8, IN_MODE>(a, x, w, bias, y, st);
-            default: return launch_s1<16, IN_MODE>(a, x, w, bias, y, st);
-        }
-    }
+int dispatch_generic(int tco, const DirectArgs& a, const float* x, const float* w, const float* bias, float* y, hipStream_t st) {
     switch (tco) {
         case 4: return launch_generic<4, IN_MODE>(a, x, w, bias, y, st);
         case 8: return launch_generic<8, IN_MODE>(a, x, w, bias, y, st);
@@ -382,19 +625,100 @@ int dispatch_tco(bool s1, int tco, const DirectArgs& a, const float* x, const fl
     }
 }
 
-int run_direct(DirectArgs a, const float* x, const float* w, const float* bias, float* y, hipStream_t st) {
-    const bool s1 = (a.sh == 1 && a.sw == 1 && a.dh == 1 && a.dw == 1) && (a.S == 1 || a.S == 3 || a.S == 5 || a.S == 7);
+// Blocks the tiled launch should have at least (4 per CU): the kernel alternates a staging phase and a compute phase, so a CU needs several resident
+// blocks to overlap them; with fewer, the output channels are split over more, narrower tiles (blockIdx.y).  DCV_CONV_TARGET_BLOCKS overrides.
+inline long conv_target_blocks() {
+    static long v = -1;
+    if (v < 0) { const char* e = getenv("DCV_CONV_TARGET_BLOCKS"); v = e ? atol(e) : 1024; }
+    return v;
+}
+
+#define TILE_LDS_BYTES (48 * 1024)
+
+bool tile_plan_ppt(const DirectArgs& a, int ppt, TileArgs* t) {
+    const int px = 256 * ppt;
+    t->N = a.N; t->Hin = a.Hin; t->Win = a.Win; t->Cin = a.Cin; t->Hout = a.Hout; t->Wout = a.Wout; t->Cout = a.Cout;
+    t->R = a.R; t->S = a.S; t->sh = a.sh; t->sw = a.sw; t->ph = a.ph; t->pw = a.pw; t->dh = a.dh; t->dw = a.dw;
+    t->in_nchw = a.in_nchw; t->act = a.act; t->slope = a.slope;
+    t->cin_pad = (int)dcv_align_up(a.Cin, 4);
+    int th = px / a.Wout; if (th > a.Hout) th = a.Hout;
+    if (th < 1) return false;
+    t->TH = th;
+    t->XH = (th - 1) * a.sh + (a.R - 1) * a.dh + 1;
+    t->XW = (a.Wout - 1) * a.sw + (a.S - 1) * a.dw + 1;
+    t->tiles_per_img = (a.Hout + th - 1) / th;
+    t->nsub = (th == a.Hout) ? px / (th * a.Wout) : 1;
+    if (t->nsub < 1) t->nsub = 1;
+    if ((long)t->nsub > (long)a.N) t->nsub = a.N;
+    t->total_subtiles = a.N * t->tiles_per_img;
+    const size_t per_c4 = (size_t)t->nsub * t->XH * t->XW * 16;     // bytes per channel-vector plane
+    if (per_c4 > TILE_LDS_BYTES) return false;
+    int cc = (int)(TILE_LDS_BYTES / per_c4) * 4;
+    if (cc > t->cin_pad) cc = t->cin_pad;
+    t->CC = cc;
+    return true;
+}
+
+// Plans conv_tile_kernel for the kernel-view problem `a` (forward: as is; stride-1 dgrad: flipped filter).  False -> use the generic kernel.
+// Among (pixels per thread, output-channel tile) it keeps the largest per-thread work which still yields DCV_CONV_TARGET_BLOCKS blocks.
+bool tile_plan(const DirectArgs& a, TileArgs* t, int* tco_out, int* ppt_out) {
+    if (a.dgrad == 2) return false;
+    const int tco_max = pick_tco(a.Cout);
+    static const int cand[9][2] = {{4, 16}, {4, 8}, {2, 16}, {4, 4}, {2, 8}, {1, 16}, {2, 4}, {1, 8}, {1, 4}};   // {PPT, TCO}, by PPT*TCO then PPT
+    int best = -1; TileArgs bt{};
+    for (int i = 0; i < 9; ++i) {
+        const int ppt = cand[i][0], tco = cand[i][1];
+        if (tco > tco_max) continue;
+        TileArgs c{};
+        if (!tile_plan_ppt(a, ppt, &c)) continue;
+        const long blocks = (long)dcv_ceil_div(c.total_subtiles, c.nsub) * (long)dcv_ceil_div(a.Cout, tco);
+        best = i; bt = c;                                        // keep shrinking work per thread while the grid is too small
+        if (blocks >= conv_target_blocks()) break;
+    }
+    if (best < 0) return false;
+    *t = bt; *tco_out = cand[best][1]; *ppt_out = cand[best][0];
+    return true;
+}
+
+int run_direct(DirectArgs a, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st) {
+    TileArgs t{}; int tco, ppt;
+    if (tile_plan(a, &t, &tco, &ppt)) {
+        const int tiles = (int)dcv_ceil_div(a.Cout, tco);
+        const size_t need = (size_t)tiles * a.R * a.S * t.cin_pad * tco * sizeof(float);
+        if (!ws || ws_bytes < need) return DCV_ERR_WORKSPACE;
+        float* wt = reinterpret_cast<float*>(ws);
+        const int total = tiles * a.R * a.S * t.cin_pad * tco;
+        const int pblocks = (total + 255) / 256 > 128 ? 128 : (total + 255) / 256;
+        hipLaunchKernelGGL(prep_weights_kernel, dim3((unsigned)pblocks), dim3(256), 0, st, a, w, wt, tco, tiles, t.cin_pad, 1);
+        dim3 grid((unsigned)dcv_ceil_div(t.total_subtiles, t.nsub), (unsigned)tiles);
+        const size_t smem = (size_t)t.nsub * t.XH * t.XW * t.CC * sizeof(float);
+#define DCV_TILE_LAUNCH(TCO_, ST_, PPT_) hipLaunchKernelGGL((conv_tile_kernel<TCO_, ST_, PPT_>), grid, dim3(256), smem, st, t, x, wt, bias, y)
+#define DCV_TILE_PPT(TCO_, ST_) switch (ppt) { case 4: DCV_TILE_LAUNCH(TCO_, ST_, 4); break; case 2: DCV_TILE_LAUNCH(TCO_, ST_, 2); break; default: DCV_TILE_LAUNCH(TCO_, ST_, 1); break; }
+#define DCV_TILE_SWITCH(TCO_) switch (a.S) { case 1: DCV_TILE_PPT(TCO_, 1); break; case 3: DCV_TILE_PPT(TCO_, 3); break; case 5: DCV_TILE_PPT(TCO_, 5); break; \
+                                             case 7: DCV_TILE_PPT(TCO_, 7); break; default: DCV_TILE_PPT(TCO_, 0); break; }
+        switch (tco) {
+            case 4: DCV_TILE_SWITCH(4); break;
+            case 8: DCV_TILE_SWITCH(8); break;
+            default: DCV_TILE_SWITCH(16); break;
+        }
+#undef DCV_TILE_PPT
+#undef DCV_TILE_SWITCH
+#undef DCV_TILE_LAUNCH
+        return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
+    }
+    // generic kernel: LDS-resident filter slice, one output pixel per thread (strided dgrad gather, very wide rows)
+    if (a.dgrad == 2) a.dgrad = 1;
     const int in_mode = a.in_nchw ? 2 : ((a.Cin % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) ? 0 : 1);
     const int vec = in_mode == 0 ? 4 : 1;
-    int tco = pick_tco(a.Cout);
-    int chunk = pick_cin_chunk(a.Cin, a.R, a.S, tco, vec);
-    while (chunk == 0 && tco > 4) { tco /= 2; chunk = pick_cin_chunk(a.Cin, a.R, a.S, tco, vec); }
+    int gtco = pick_tco(a.Cout);
+    int chunk = pick_cin_chunk(a.Cin, a.R, a.S, gtco, vec);
+    while (chunk == 0 && gtco > 4) { gtco /= 2; chunk = pick_cin_chunk(a.Cin, a.R, a.S, gtco, vec); }
     if (chunk == 0) return DCV_ERR_UNSUPPORTED;
     a.cin_chunk = chunk;
     int rc;
-    if (in_mode == 0) rc = dispatch_tco<0>(s1, tco, a, x, w, bias, y, st);
-    else if (in_mode == 1) rc = dispatch_tco<1>(s1, tco, a, x, w, bias, y, st);
-    else rc = dispatch_tco<2>(s1, tco, a, x, w, bias, y, st);
+    if (in_mode == 0) rc = dispatch_generic<0>(gtco, a, x, w, bias, y, st);
+    else if (in_mode == 1) rc = dispatch_generic<1>(gtco, a, x, w, bias, y, st);
+    else rc = dispatch_generic<2>(gtco, a, x, w, bias, y, st);
     if (rc != DCV_OK) return rc;
     return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
 }
@@ -425,47 +749,105 @@ inline void wgrad_plan(const dcv_conv2d_desc* d, WgradArgs* a, int* chunks, int*
 }  // namespace
 
 // entry points used by conv2d.hip's dispatcher
-int dcv_direct_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, hipStream_t st) {
+size_t dcv_direct_conv2d_fwd_ws(const dcv_conv2d_desc* d) { return dcv_align_up((size_t)d->r * d->s * dcv_align_up(d->cin, 4) * dcv_align_up(d->cout, 16) * sizeof(float), 256); }
+size_t dcv_direct_conv2d_dgrad_ws(const dcv_conv2d_desc* d) { return dcv_align_up((size_t)d->r * d->s * dcv_align_up(d->cout, 4) * dcv_align_up(d->cin, 16) * sizeof(float), 256); }
+
+int dcv_direct_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st) {
     DirectArgs a{};
     a.N = d->n; a.Hin = d->h; a.Win = d->w; a.Cin = d->cin; a.Hout = d->ho; a.Wout = d->wo; a.Cout = d->cout;
     a.R = d->r; a.S = d->s; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
     a.w_cout = d->cout; a.w_cin = d->cin; a.dgrad = 0; a.act = d->act; a.slope = d->act_slope; a.in_nchw = d->x_layout == DCV_LAYOUT_NCHW;
-    return run_direct(a, x, w, bias, y, st);
+    return run_direct(a, x, w, bias, y, ws, ws_bytes, st);
 }
 
-int dcv_direct_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, hipStream_t st) {
+int dcv_direct_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t st) {
     DirectArgs a{};
     a.N = d->n; a.Hin = d->ho; a.Win = d->wo; a.Cin = d->cout; a.Hout = d->h; a.Wout = d->w; a.Cout = d->cin;
     a.R = d->r; a.S = d->s; a.dh = d->dil_h; a.dw = d->dil_w;
     a.w_cout = d->cout; a.w_cin = d->cin; a.dgrad = 1; a.act = DCV_ACT_NONE; a.slope = 0.f; a.in_nchw = 0;
-    const bool s1 = d->stride_h == 1 && d->stride_w == 1 && d->dil_h == 1 && d->dil_w == 1 && (d->s == 1 || d->s == 3 || d->s == 5 || d->s == 7);
-    if (s1) {
-        // stride-1 data gradient == forward convolution of dy with the flipped, transposed filter and pad' = R-1-pad
-        a.sh = 1; a.sw = 1; a.ph = d->r - 1 - d->pad_h; a.pw = d->s - 1 - d->pad_w;
-        if (a.ph < 0 || a.pw < 0) return DCV_ERR_UNSUPPORTED;
+    if (d->stride_h == 1 && d->stride_w == 1 && d->r - 1 - d->pad_h >= 0 && d->s - 1 - d->pad_w >= 0 && (d->r - 1) * d->dil_h >= d->pad_h && (d->s - 1) * d->dil_w >= d->pad_w) {
+        // stride-1 data gradient == forward convolution of dy with the flipped, transposed filter and pad' = dil*(R-1) - pad
+        a.sh = 1; a.sw = 1; a.ph = d->dil_h * (d->r - 1) - d->pad_h; a.pw = d->dil_w * (d->s - 1) - d->pad_w;
     } else {
         // gather form handled by the generic kernel (dgrad addressing: ho = (hi + pad - r*dil) / stride when divisible)
+        a.dgrad = 2;
         a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w;
     }
-    return run_direct(a, dy, w, nullptr, dx, st);
+    return run_direct(a, dy, w, nullptr, dx, ws, ws_bytes, st);
 }
 
+namespace {
+
+// Plans the LDS-tiled weight gradient; returns false when the layer does not fit it (too many units / tile larger than 48 KiB of LDS).
+bool wgrad_tiled_plan(const dcv_conv2d_desc* d, WgTiledArgs* a, int* tco, int* vec, int* blocks, size_t* smem) {
+    const int v = (d->x_layout == DCV_LAYOUT_NHWC && d->cin % 4 == 0) ? 4 : 1;
+    const int civ = d->cin / v;
+    const long units = (long)civ * d->r * d->s;
+    if (units > 256) return false;
+    const int tc = pick_tco(d->cout);
+    a->N = d->n; a->H = d->h; a->W = d->w; a->Cin = d->cin; a->Ho = d->ho; a->Wo = d->wo; a->Cout = d->cout; a->R = d->r; a->S = d->s;
+    a->sh = d->stride_h; a->sw = d->stride_w; a->ph = d->pad_h; a->pw = d->pad_w; a->dh = d->dil_h; a->dw = d->dil_w;
+    a->x_nchw = d->x_layout == DCV_LAYOUT_NCHW;
+    a->XW = (d->wo - 1) * d->stride_w + (d->s - 1) * d->dil_w + 1;
+    int th = 256 / d->wo; if (th < 1) th = 1; if (th > d->ho) th = d->ho;
+    size_t bytes = 0;
+    for (;;) {
+        a->TH = th; a->XH = (th - 1) * d->stride_h + (d->r - 1) * d->dil_h + 1;
+        bytes = ((size_t)a->XH * a->XW * d->cin + (size_t)th * d->wo * tc) * sizeof(float);
+        if (bytes <= 48 * 1024 || th == 1) break;
+        th = th / 2;
+    }
+    if (bytes > 48 * 1024) return false;
+    if (bytes < (size_t)256 * v * sizeof(float)) bytes = (size_t)256 * v * sizeof(float);
+    a->units = (int)units; a->civ = civ; a->nsub = 256 / (int)units;
+    a->tiles_per_img = (d->ho + th - 1) / th;
+    a->total_tiles = d->n * a->tiles_per_img;
+    a->wtotal = (size_t)d->cout * d->cin * d->r * d->s;
+    int nb = a->total_tiles < 512 ? a->total_tiles : 512;
+    const size_t max_by_bytes = ((size_t)64 << 20) / (a->wtotal * sizeof(float));
+    if ((size_t)nb > max_by_bytes) nb = (int)(max_by_bytes > 0 ? max_by_bytes : 1);
+    *tco = tc; *vec = v; *blocks = nb; *smem = bytes;
+    return true;
+}
+
+template <int VEC>
+void launch_wgrad_tiled(int tco, dim3 grid, size_t smem, hipStream_t st, const WgTiledArgs& a, const float* x, const float* dy, float* partial) {
+    switch (tco) {
+        case 4: hipLaunchKernelGGL((conv_wgrad_tiled_kernel<4, VEC>), grid, dim3(256), smem, st, a, x, dy, partial); break;
+        case 8: hipLaunchKernelGGL((conv_wgrad_tiled_kernel<8, VEC>), grid, dim3(256), smem, st, a, x, dy, partial); break;
+        default: hipLaunchKernelGGL((conv_wgrad_tiled_kernel<16, VEC>), grid, dim3(256), smem, st, a, x, dy, partial); break;
+    }
+}
+
+}  // namespace
+
 size_t dcv_direct_conv2d_wgrad_ws(const dcv_conv2d_desc* d) {
+    WgTiledArgs ta{}; int tco, tvec, blocks; size_t smem;
+    if (wgrad_tiled_plan(d, &ta, &tco, &tvec, &blocks, &smem)) return dcv_align_up((size_t)blocks * ta.wtotal * sizeof(float), 256);
     WgradArgs a{}; int chunks, ub, vec;
     wgrad_plan(d, &a, &chunks, &ub, &vec);
     return dcv_align_up((size_t)chunks * a.wtotal * sizeof(float), 256);
 }
 
 int dcv_direct_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
+    float* partial = reinterpret_cast<float*>(ws);
+    WgTiledArgs ta{}; int tco, tvec, blocks; size_t smem;
+    if (wgrad_tiled_plan(d, &ta, &tco, &tvec, &blocks, &smem) && (tvec == 1 || (reinterpret_cast<uintptr_t>(x) & 15) == 0)) {
+        if (!ws || ws_bytes < (size_t)blocks * ta.wtotal * sizeof(float)) return DCV_ERR_WORKSPACE;
+        dim3 grid((unsigned)blocks, (unsigned)dcv_ceil_div(d->cout, tco));
+        if (tvec == 4) launch_wgrad_tiled<4>(tco, grid, smem, st, ta, x, dy, partial);
+        else launch_wgrad_tiled<1>(tco, grid, smem, st, ta, x, dy, partial);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)dcv_ceil_div(ta.wtotal, 32)), dim3(1024), 0, st, partial, dw, blocks, ta.wtotal);
+        return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
+    }
     WgradArgs a{}; int chunks, ubatches, vec;
     wgrad_plan(d, &a, &chunks, &ubatches, &vec);
     if (!ws || ws_bytes < (size_t)chunks * a.wtotal * sizeof(float)) return DCV_ERR_WORKSPACE;
     if (ubatches > 65535) return DCV_ERR_UNSUPPORTED;
-    float* partial = reinterpret_cast<float*>(ws);
     dim3 grid((unsigned)chunks, (unsigned)ubatches);
     if (vec == 4 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) hipLaunchKernelGGL((conv_wgrad_partial_kernel<4>), grid, dim3(256), 0, st, a, x, dy, partial);
     else if (vec == 4) return DCV_ERR_INVALID_ARG;   // NHWC activations are always 16-B aligned (torch allocator); anything else is a caller bug
     else hipLaunchKernelGGL((conv_wgrad_partial_kernel<1>), grid, dim3(256), 0, st, a, x, dy, partial);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)dcv_ceil_div(a.wtotal, 32)), dim3(256), 0, st, partial, dw, chunks, a.wtotal);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)dcv_ceil_div(a.wtotal, 32)), dim3(1024), 0, st, partial, dw, chunks, a.wtotal);
     return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
 }

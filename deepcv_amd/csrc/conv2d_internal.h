@@ -3,8 +3,10 @@
 #include "common.h"
 
 // direct (register-blocked, LDS-resident filter) back-end: any shape, tuned for the small-channel stock layers
-int dcv_direct_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, hipStream_t st);
-int dcv_direct_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, hipStream_t st);
+size_t dcv_direct_conv2d_fwd_ws(const dcv_conv2d_desc* d);
+size_t dcv_direct_conv2d_dgrad_ws(const dcv_conv2d_desc* d);
+int dcv_direct_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st);
+int dcv_direct_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t st);
 size_t dcv_direct_conv2d_wgrad_ws(const dcv_conv2d_desc* d);
 int dcv_direct_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
 

@@ -53,6 +53,9 @@ CONV_CASES = [
     (2, 4, 10, 10, 4, 2, 1, 0, 1, 0, False),       # even kernel (generic)
     (1, 40, 8, 8, 24, 3, 1, 1, 1, 1, False),       # wider channels through the direct fallback (units > 256 in wgrad)
     (2, 5, 8, 8, 3, 3, 1, 0, 1, 0, False),         # no padding, odd channels
+    (1, 128, 6, 6, 8, 3, 1, 1, 1, 0, False),       # > 256 wgrad units: un-tiled weight-gradient fallback
+    (3, 4, 40, 24, 4, 3, 1, 1, 1, 1, False),       # several row tiles per image, ragged last tile (tiled weight gradient)
+    (2, 3, 37, 29, 5, 5, 2, 2, 1, 0, True),        # strided + NCHW input + ragged tiles
 ]
 
 

@@ -1,0 +1,37 @@
+"""Micro-benchmark of single C-ABI entry points (used under rocprofv3 --pmc / --kernel-trace).  usage: kbench.py <case> [launches]"""
+import sys, time
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+import torch
+from deepcv_amd import _native as nat
+dev = torch.device('cuda:0')
+case = sys.argv[1] if len(sys.argv) > 1 else 'conv450'
+launches = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+NB = int(sys.argv[3]) if len(sys.argv) > 3 else 512
+cl = torch.channels_last
+def conv_case(n, cin, h, w, cout, k, pad):
+    x = torch.randn(n, cin, h, w, device=dev).contiguous(memory_format=cl)
+    wt = torch.randn(cout, cin, k, k, device=dev) * 0.1
+    b = torch.zeros(cout, device=dev)
+    y = torch.empty(n, cout, h, w, device=dev).contiguous(memory_format=cl)
+    dy = torch.randn(n, cout, h, w, device=dev).contiguous(memory_format=cl)
+    d = nat.Conv2dDesc(n, h, w, cin, cout, k, k, 1, 1, pad, pad, 1, 1, 1, h, w, nat.LAYOUT_NHWC, nat.ACT_RELU, 0.)
+    return x, wt, b, y, dy, d
+st = nat.current_stream(dev)
+if case in ('conv450', 'conv1630', 'conv430'):
+    cfg = {'conv450': (NB, 4, 32, 32, 4, 5, 2), 'conv1630': (NB, 16, 16, 16, 16, 3, 1), 'conv430': (NB, 4, 16, 16, 16, 3, 1)}[case]
+    x, wt, b, y, dy, d = conv_case(*cfg)
+    wsf = torch.empty(max(16, nat.lib.dcv_conv2d_fwd_workspace_bytes(d)), dtype=torch.uint8, device=dev)
+    fn = lambda: nat.check(nat.lib.dcv_conv2d_fwd(d, x.data_ptr(), wt.data_ptr(), b.data_ptr(), y.data_ptr(), wsf.data_ptr(), wsf.numel(), st))
+elif case in ('wgrad450', 'wgrad1630'):
+    cfg = {'wgrad450': (NB, 4, 32, 32, 4, 5, 2), 'wgrad1630': (NB, 16, 16, 16, 16, 3, 1)}[case]
+    x, wt, b, y, dy, d = conv_case(*cfg)
+    dw = torch.empty_like(wt)
+    ws = torch.empty(nat.lib.dcv_conv2d_wgrad_workspace_bytes(d), dtype=torch.uint8, device=dev)
+    fn = lambda: nat.check(nat.lib.dcv_conv2d_wgrad(d, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), ws.numel(), st))
+for _ in range(5): fn()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(launches): fn()
+e1.record(); torch.cuda.synchronize()
+print(case, 'avg us', e0.elapsed_time(e1) * 1e3 / launches)
