@@ -1,0 +1,66 @@
+""" The C-ABI shared library loads on a GPU-less host and exports every symbol `include/deepcv_hip.h` declares (no compute call is made). """
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _declared_symbols():
+    text = (ROOT / 'include' / 'deepcv_hip.h').read_text()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(dcv_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_declares_the_expected_families():
+    syms = _declared_symbols()
+    for fam in ('dcv_conv2d_fwd', 'dcv_conv2d_dgrad', 'dcv_conv2d_wgrad', 'dcv_batchnorm_fwd_train', 'dcv_batchnorm_bwd', 'dcv_groupnorm_fwd', 'dcv_pool2d_fwd',
+                'dcv_pool2d_bwd', 'dcv_linear_fwd', 'dcv_cross_entropy_fwd', 'dcv_adamw_step', 'dcv_sgd_step', 'dcv_pack_grads', 'dcv_strerror'):
+        assert fam in syms
+    assert len(syms) >= 38
+
+
+def test_library_exports_every_declared_symbol():
+    from deepcv_amd import _native
+    assert _native.LIB_PATH.exists(), 'run `python -c "import __graft_entry__ as g; g.build()"` first'
+    lib = ctypes.CDLL(str(_native.LIB_PATH))
+    missing = [s for s in _declared_symbols() if not hasattr(lib, s)]
+    assert not missing, f'symbols declared in include/deepcv_hip.h but not exported: {missing}'
+
+
+def test_python_binding_covers_the_header():
+    from deepcv_amd import _native
+    declared = set(_declared_symbols())
+    bound = set(_native._SIGNATURES.keys())
+    assert declared == bound, f'header-only: {declared - bound}; binding-only: {bound - declared}'
+    lib = _native.load()
+    assert lib.dcv_version() >= 100
+    assert b'workspace' in lib.dcv_strerror(-3) and lib.dcv_strerror(0) == b'ok'
+
+
+def test_struct_layouts_match_the_header():
+    from deepcv_amd import _native
+    assert ctypes.sizeof(_native.Conv2dDesc) == 19 * 4
+    assert ctypes.sizeof(_native.Pool2dDesc) == 13 * 4
+    assert ctypes.sizeof(_native.TensorList) == 8 + 6 * 8 * _native.MAX_TENSORS
+    text = (ROOT / 'include' / 'deepcv_hip.h').read_text()
+    assert f'#define DCV_MAX_TENSORS {_native.MAX_TENSORS}' in text and f'#define DCV_HYP_COUNT {_native.HYP_COUNT}' in text
+    for name, idx in _native.HYP.items():
+        macro = {'lr': 'LR', 'beta1': 'BETA1', 'beta2': 'BETA2', 'eps': 'EPS', 'weight_decay': 'WEIGHT_DECAY', 'grad_scale': 'GRAD_SCALE',
+                 'bias_corr1': 'BIAS_CORR1', 'bias_corr2': 'BIAS_CORR2', 'first_step': 'FIRST_STEP'}[name]
+        assert re.search(rf'#define DCV_HYP_{macro} {idx}\b', text)
+
+
+def test_invalid_arguments_are_rejected_on_the_host():
+    """ Launchers validate before touching the GPU: these calls must return error codes (never launch) even without a device. """
+    from deepcv_amd import _native
+    lib = _native.load()
+    d = _native.Conv2dDesc(1, 8, 8, 3, 4, 3, 3, 1, 1, 1, 1, 1, 1, 1, 7, 7, 0, 0, 0.)   # wrong ho/wo for pad 1
+    assert lib.dcv_conv2d_fwd(d, 1, 1, None, 1, None, 0, None) == -1
+    assert lib.dcv_act_fwd(None, None, 16, 1, 0., None) == -1
+    assert lib.dcv_batchnorm_workspace_bytes(0, 4) == 0 and lib.dcv_batchnorm_workspace_bytes(1024, 4) > 0
+    good = _native.Conv2dDesc(2, 8, 8, 4, 4, 3, 3, 1, 1, 1, 1, 1, 1, 1, 8, 8, 0, 0, 0.)
+    assert lib.dcv_conv2d_wgrad_workspace_bytes(good) > 0 and lib.dcv_conv2d_fwd_workspace_bytes(good) > 0
+    assert lib.dcv_conv2d_wgrad(good, 1, 1, 1, None, None, 0, None) == -3   # workspace too small
