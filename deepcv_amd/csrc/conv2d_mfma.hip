@@ -1,8 +1,345 @@
-// conv2d_mfma.hip — MFMA implicit-GEMM convolution back-end for wide layers (placeholder dispatcher until the kernels land).
+// conv2d_mfma.hip — MFMA implicit-GEMM convolution back-end for wide layers (Cin % 16 == 0, Cout % 16 == 0): forward, stride-1 data gradient and
+// weight gradient on `v_mfma_f32_16x16x4_f32` (fp32 in / fp32 accumulate: bit-wise an fmaf chain, 155 TF measured peak on MI355X).
+//
+// GEMM view (forward):  D[m][n] = sum_k A[m][k] * B[k][n],  m = output pixel (n, ho, wo), n = output channel, k = (r, s, ci) with ci fastest.
+//   * A is never materialised: every K chunk (16 consecutive input channels of one filter tap) of a 128-pixel tile is gathered from the NHWC activation
+//     with 16-B loads (4 lanes cover the 64 contiguous bytes of one pixel), zero-filled outside the image, and staged in LDS as [pixel][16 + 4 pad].
+//   * B is the filter re-laid out once per launch as wb[cout][tap][cin] (K contiguous), staged as [cout][16 + 4 pad].
+//   * K permutation: inside a 16-wide chunk lane group g = lane >> 4 owns k = 4g..4g+3 and uses element t in MFMA step t, for A and B alike, so each
+//     lane fetches its four k-steps with ONE conflict-free ds_read_b128 (row stride 80 B spreads 16 rows over 16 distinct 16-B slots).
+//   * block = 256 threads = 4 waves, tile 128 pixels x BN channels (BN in {16, 32, 64}); wave w owns pixels [32w, 32w+32) x BN: 2 x BN/16 accumulator
+//     tiles; per chunk and wave: 2 + BN/16 ds_read_b128 for 8 * BN/16 MFMAs.  Global loads of chunk c+1 are issued before the MFMAs of chunk c and
+//     written to the other LDS buffer afterwards (one barrier per chunk).
+//   * epilogue: bias + activation, accumulator layout row = 4*(lane>>4) + reg (pixel), col = lane & 15 (channel) -> 64-B channel runs per pixel.
+// dgrad (stride 1) = the same kernel on dy with the filter flipped / transposed by the prep kernel and pad' = dil*(R-1) - pad.
+// wgrad: D[co][(tap, ci)] = sum over pixels; split over pixel chunks, per-chunk slabs + ordered reduce (deterministic).
+//
+// Roofline: MFMA fp32 (157.3 TF spec).  FLOPs per launch = 2 * N*Ho*Wo * Cout * Cin*R*S.
+// Replaces torch.nn.Conv2d forward/backward (reference src/deepcv/meta/submodule_creators.py:251, ignite_training.py:253) for wide layers.
 #include "conv2d_internal.h"
+#include <stdlib.h>
 
-bool dcv_mfma_conv2d_supported(const dcv_conv2d_desc*, int) { return false; }
-size_t dcv_mfma_conv2d_ws(const dcv_conv2d_desc*, int) { return 0; }
-int dcv_mfma_conv2d_fwd(const dcv_conv2d_desc*, const float*, const float*, const float*, float*, void*, size_t, hipStream_t) { return DCV_ERR_UNSUPPORTED; }
-int dcv_mfma_conv2d_dgrad(const dcv_conv2d_desc*, const float*, const float*, float*, void*, size_t, hipStream_t) { return DCV_ERR_UNSUPPORTED; }
-int dcv_mfma_conv2d_wgrad(const dcv_conv2d_desc*, const float*, const float*, float*, void*, size_t, hipStream_t) { return DCV_ERR_UNSUPPORTED; }
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MF_BM 128
+#define MF_BK 16
+#define MF_LD 20                 // padded LDS row length (floats): 80 B stride -> conflict-free ds_read_b128 across 16 rows
+
+struct MfmaArgs {
+    int N, Hin, Win, Cin;          // tensor read (fwd: x, dgrad: dy)
+    int Hout, Wout, Cout;          // tensor written
+    int R, S, sh, sw, ph, pw, dh, dw;
+    int act; float slope;
+    long M;                        // N * Hout * Wout
+};
+
+// wb[co][tap][ci] (fwd: w[co][ci][r][s]; dgrad: kernel-cout = original cin, kernel-cin = original cout, taps flipped)
+__global__ __launch_bounds__(256) void mfma_prep_weights_kernel(const float* __restrict__ w, float* __restrict__ wb, int kcout, int kcin, int R, int S, int w_cin, int dgrad) {
+    const int total = kcout * R * S * kcin;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int ci = i % kcin; int t = i / kcin;
+        const int s = t % S; t /= S;
+        const int r = t % R; const int co = t / R;
+        float v;
+        if (!dgrad) v = w[(((size_t)co * w_cin + ci) * R + r) * S + s];
+        else v = w[(((size_t)ci * w_cin + co) * R + (R - 1 - r)) * S + (S - 1 - s)];
+        wb[i] = v;
+    }
+}
+
+template <int BN>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaArgs a, const float* __restrict__ x, const float* __restrict__ wb, const float* __restrict__ bias,
+                                                         float* __restrict__ y) {
+    constexpr int NT = BN / 16;                                   // accumulator tiles along N per wave
+    __shared__ __attribute__((aligned(16))) float As[2][MF_BM * MF_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * MF_LD];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const long m0 = (long)blockIdx.x * MF_BM;
+    const int n0 = blockIdx.y * BN;
+
+    // ---- staging roles: thread stages A rows (t >> 2) and (t >> 2) + 64, channel quad q = t & 3; B row (t >> 2) when < BN
+    const int q = t & 3;
+    int an[2], aho[2], awo[2]; bool arow_ok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const long m = m0 + (t >> 2) + 64 * j;
+        arow_ok[j] = m < a.M;
+        const long mm = arow_ok[j] ? m : 0;
+        awo[j] = (int)(mm % a.Wout); const long r1 = mm / a.Wout; aho[j] = (int)(r1 % a.Hout); an[j] = (int)(r1 / a.Hout);
+    }
+    const int brow = t >> 2;
+    const bool b_active = brow < BN;
+    const int taps = a.R * a.S;
+    const size_t wb_row = (size_t)taps * a.Cin;                   // floats per output channel in wb
+
+    auto load_a = [&](int r, int s, int ci0, float4 (&v)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int hi = aho[j] * a.sh - a.ph + r * a.dh, wi = awo[j] * a.sw - a.pw + s * a.dw;
+            const bool ok = arow_ok[j] && hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win;
+            const int hic = hi < 0 ? 0 : (hi >= a.Hin ? a.Hin - 1 : hi), wic = wi < 0 ? 0 : (wi >= a.Win ? a.Win - 1 : wi);
+            const float4 g = *reinterpret_cast<const float4*>(x + (((size_t)an[j] * a.Hin + hic) * a.Win + wic) * a.Cin + ci0 + 4 * q);   // unconditional, clamped
+            v[j] = ok ? g : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto load_b = [&](int tap, int ci0) -> float4 {
+        if (!b_active) return make_float4(0.f, 0.f, 0.f, 0.f);
+        return *reinterpret_cast<const float4*>(wb + (size_t)(n0 + brow) * wb_row + (size_t)tap * a.Cin + ci0 + 4 * q);
+    };
+    auto store_stage = [&](int buf, const float4 (&va)[2], const float4& vb) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(&As[buf][((t >> 2) + 64 * j) * MF_LD + 4 * q]) = va[j];
+        if (b_active) *reinterpret_cast<float4*>(&Bs[buf][brow * MF_LD + 4 * q]) = vb;
+    };
+
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int cchunks = a.Cin / MF_BK;
+    const int nchunks = taps * cchunks;
+    float4 va[2]; float4 vb;
+    load_a(0, 0, 0, va); vb = load_b(0, 0);
+    store_stage(0, va, vb);
+    __syncthreads();
+
+    int r = 0, s = 0, cc = 0;                                     // position of the chunk being COMPUTED
+    const int li = lane & 15, lg = lane >> 4;
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        // next chunk position
+        int nr = r, ns = s, ncc = cc + 1;
+        if (ncc == cchunks) { ncc = 0; ++ns; if (ns == a.S) { ns = 0; ++nr; } }
+        const bool has_next = (c + 1) < nchunks;
+        if (has_next) { load_a(nr, ns, ncc * MF_BK, va); vb = load_b(nr * a.S + ns, ncc * MF_BK); }
+
+        // ---- MFMAs on buffer `buf`
+        f32x4 af[2], bf[NT];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f32x4*>(&As[buf][(wave * 32 + i * 16 + li) * MF_LD + 4 * lg]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(&Bs[buf][(j * 16 + li) * MF_LD + 4 * lg]);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+
+        if (has_next) store_stage(buf ^ 1, va, vb);
+        __syncthreads();
+        r = nr; s = ns; cc = ncc;
+    }
+
+    // ---- epilogue: acc[i][j][reg] -> pixel m0 + wave*32 + i*16 + 4*lg + reg, channel n0 + j*16 + li
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int co = n0 + j * 16 + li;
+        const float bv = bias ? bias[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const long m = m0 + wave * 32 + i * 16 + 4 * lg + reg;
+                if (m < a.M) y[(size_t)m * a.Cout + co] = dcv_act_apply(acc[i][j][reg] + bv, a.act, a.slope);
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dW[co][tap][ci] = sum_m dy[m][co] * x[m (+) tap][ci].  Block = (pixel chunk, tap, 64-channel column tile of ci, 64-row tile of co).
+// MFMA roles: A'[i = co][k = pixel], B'[k = pixel][j = ci].  Pixel tiles of 16 are staged in LDS in their natural [pixel][channel] layouts; lane (i, g)
+// reads the four pixels 4g..4g+3 of its column with four ds_read_b32 (k permutation as in the forward kernel).
+struct MfmaWgArgs {
+    int N, H, W, Cin, Ho, Wo, Cout, R, S, sh, sw, ph, pw, dh, dw;
+    long M, m_per_chunk;           // output pixels, pixels per split-K chunk (multiple of 16)
+    size_t wtotal;
+};
+
+#define WG_T 64                    // tile of output channels (rows) and of input channels (columns) per block
+#define WG_LD 68                   // padded row length of the [16 pixels][64 channels] LDS tiles
+
+__global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(MfmaWgArgs a, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float Gs[2][16 * WG_LD];     // dy tile  [pixel][co]
+    __shared__ __attribute__((aligned(16))) float Xs[2][16 * WG_LD];     // x  tile  [pixel][ci]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int ci_tiles = a.Cin / WG_T;
+    const int tap = blockIdx.y / ci_tiles, ci0 = (blockIdx.y % ci_tiles) * WG_T;
+    const int r = tap / a.S, s = tap % a.S;
+    const int co0 = blockIdx.z * WG_T;
+    const long mb = (long)blockIdx.x * a.m_per_chunk;
+    long me = mb + a.m_per_chunk; if (me > a.M) me = a.M;
+
+    // staging role: thread loads pixel row (t >> 4) (0..15), float4 column (t & 15) of both tiles
+    const int prow = t >> 4, pc4 = t & 15;
+    auto load_tiles = [&](long mbase, float4& g, float4& xv) {
+        const long m = mbase + prow;
+        const bool ok = m < me;
+        const long mm = ok ? m : mb;
+        const int wo = (int)(mm % a.Wo); const long r1 = mm / a.Wo; const int ho = (int)(r1 % a.Ho); const int n = (int)(r1 / a.Ho);
+        const float4 gg = *reinterpret_cast<const float4*>(dy + (size_t)mm * a.Cout + co0 + 4 * pc4);
+        const int hi = ho * a.sh - a.ph + r * a.dh, wi = wo * a.sw - a.pw + s * a.dw;
+        const bool xok = ok && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+        const int hic = hi < 0 ? 0 : (hi >= a.H ? a.H - 1 : hi), wic = wi < 0 ? 0 : (wi >= a.W ? a.W - 1 : wi);
+        const float4 xx = *reinterpret_cast<const float4*>(x + (((size_t)n * a.H + hic) * a.W + wic) * a.Cin + ci0 + 4 * pc4);
+        g = ok ? gg : make_float4(0.f, 0.f, 0.f, 0.f);
+        xv = xok ? xx : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto store_tiles = [&](int buf, const float4& g, const float4& xv) {
+        *reinterpret_cast<float4*>(&Gs[buf][prow * WG_LD + 4 * pc4]) = g;
+        *reinterpret_cast<float4*>(&Xs[buf][prow * WG_LD + 4 * pc4]) = xv;
+    };
+
+    // wave w owns output-channel rows [16w, 16w+16) x all 64 input-channel columns: 4 accumulator tiles
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float4 g, xv;
+    load_tiles(mb, g, xv);
+    store_tiles(0, g, xv);
+    __syncthreads();
+    int it = 0;
+    for (long m = mb; m < me; m += 16, ++it) {
+        const int buf = it & 1;
+        const bool has_next = (m + 16) < me;
+        if (has_next) load_tiles(m + 16, g, xv);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const float av = Gs[buf][(4 * lg + kk) * WG_LD + wave * 16 + li];               // A'[i = co][k = pixel 4g+kk]
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float bvv = Xs[buf][(4 * lg + kk) * WG_LD + j * 16 + li];             // B'[k][j = ci]
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bvv, acc[j], 0, 0, 0);
+            }
+        }
+        if (has_next) store_tiles(buf ^ 1, g, xv);
+        __syncthreads();
+    }
+    // partial[chunk][co][ci][r][s]  (OIHW so that the shared ordered reduce kernel can sum slabs directly)
+    float* dst = partial + (size_t)blockIdx.x * a.wtotal;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int co = co0 + wave * 16 + 4 * lg + reg, ci = ci0 + j * 16 + li;
+            dst[(((size_t)co * a.Cin + ci) * a.R + r) * a.S + s] = acc[j][reg];
+        }
+}
+
+__global__ __launch_bounds__(1024) void mfma_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int chunks, size_t wtotal) {
+    __shared__ float red[32][33];
+    const int wl = threadIdx.x & 31, cl = threadIdx.x >> 5;
+    const size_t wi = (size_t)blockIdx.x * 32 + wl;
+    float s = 0.f;
+    if (wi < wtotal)
+        for (int c = cl; c < chunks; c += 32) s += partial[(size_t)c * wtotal + wi];
+    red[cl][wl] = s;
+    __syncthreads();
+    if (cl == 0 && wi < wtotal) {
+        float tsum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) tsum += red[k][wl];
+        dw[wi] = tsum;
+    }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+inline int pick_bn(int cout) { return cout % 64 == 0 ? 64 : (cout % 32 == 0 ? 32 : 16); }
+
+inline void wg_plan(const dcv_conv2d_desc* d, MfmaWgArgs* a, int* chunks) {
+    a->N = d->n; a->H = d->h; a->W = d->w; a->Cin = d->cin; a->Ho = d->ho; a->Wo = d->wo; a->Cout = d->cout; a->R = d->r; a->S = d->s;
+    a->sh = d->stride_h; a->sw = d->stride_w; a->ph = d->pad_h; a->pw = d->pad_w; a->dh = d->dil_h; a->dw = d->dil_w;
+    a->M = (long)d->n * d->ho * d->wo;
+    a->wtotal = (size_t)d->cout * d->cin * d->r * d->s;
+    // enough blocks to fill the chip (>= ~2048) but partial slabs bounded to 256 MiB
+    const long blocks_per_chunk = (long)d->r * d->s * (d->cin / WG_T) * (d->cout / WG_T);
+    long ch = (2048 + blocks_per_chunk - 1) / blocks_per_chunk;
+    const long max_by_m = (a->M + 255) / 256;                      // at least 256 pixels per chunk
+    if (ch > max_by_m) ch = max_by_m;
+    const long max_by_bytes = (long)(((size_t)256 << 20) / (a->wtotal * sizeof(float)));
+    if (ch > max_by_bytes) ch = max_by_bytes;
+    if (ch < 1) ch = 1;
+    long mpc = (a->M + ch - 1) / ch;
+    mpc = (mpc + 15) / 16 * 16;
+    a->m_per_chunk = mpc;
+    *chunks = (int)((a->M + mpc - 1) / mpc);
+}
+
+}  // namespace
+
+bool dcv_mfma_conv2d_supported(const dcv_conv2d_desc* d, int op) {
+    if (d->groups != 1 || d->x_layout != DCV_LAYOUT_NHWC) return false;
+    if (d->cin % 16 != 0 || d->cout % 16 != 0) return false;
+    if (op == 1) {   // data gradient through the forward kernel: stride 1 and non-negative transposed padding only
+        if (d->stride_h != 1 || d->stride_w != 1) return false;
+        if (d->dil_h * (d->r - 1) < d->pad_h || d->dil_w * (d->s - 1) < d->pad_w) return false;
+    }
+    if (op == 2 && (d->cin % WG_T != 0 || d->cout % WG_T != 0)) return false;
+    // measured on MI355X: from 16 channels on either side the MFMA kernel already beats the direct one (16->16 3x3 @16x16, N=512: 18.7 vs 29.5 us)
+    static int min_c = -1;
+    if (min_c < 0) { const char* e = getenv("DCV_MFMA_MIN_C"); min_c = e ? atoi(e) : 16; }
+    return (d->cin >= min_c || d->cout >= min_c);
+}
+
+size_t dcv_mfma_conv2d_ws(const dcv_conv2d_desc* d, int op) {
+    if (op == 2) { MfmaWgArgs a{}; int chunks; wg_plan(d, &a, &chunks); return dcv_align_up((size_t)chunks * a.wtotal * sizeof(float), 256); }
+    return dcv_align_up((size_t)d->cout * d->cin * d->r * d->s * sizeof(float), 256);
+}
+
+static int run_mfma(const MfmaArgs& a, const float* x, const float* wb, const float* bias, float* y, hipStream_t st) {
+    const int bn = pick_bn(a.Cout);
+    dim3 grid((unsigned)dcv_ceil_div((size_t)a.M, MF_BM), (unsigned)(a.Cout / bn));
+    switch (bn) {
+        case 64: hipLaunchKernelGGL((conv_mfma_kernel<64>), grid, dim3(256), 0, st, a, x, wb, bias, y); break;
+        case 32: hipLaunchKernelGGL((conv_mfma_kernel<32>), grid, dim3(256), 0, st, a, x, wb, bias, y); break;
+        default: hipLaunchKernelGGL((conv_mfma_kernel<16>), grid, dim3(256), 0, st, a, x, wb, bias, y); break;
+    }
+    return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
+}
+
+int dcv_mfma_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!ws || ws_bytes < dcv_mfma_conv2d_ws(d, 0)) return DCV_ERR_WORKSPACE;
+    if (!aligned16(x) || !aligned16(ws)) return DCV_ERR_INVALID_ARG;
+    float* wb = reinterpret_cast<float*>(ws);
+    const int total = d->cout * d->cin * d->r * d->s;
+    hipLaunchKernelGGL(mfma_prep_weights_kernel, dim3((unsigned)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256)), dim3(256), 0, st, w, wb, d->cout, d->cin, d->r, d->s, d->cin, 0);
+    MfmaArgs a{};
+    a.N = d->n; a.Hin = d->h; a.Win = d->w; a.Cin = d->cin; a.Hout = d->ho; a.Wout = d->wo; a.Cout = d->cout;
+    a.R = d->r; a.S = d->s; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
+    a.act = d->act; a.slope = d->act_slope; a.M = (long)d->n * d->ho * d->wo;
+    return run_mfma(a, x, wb, bias, y, st);
+}
+
+int dcv_mfma_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!ws || ws_bytes < dcv_mfma_conv2d_ws(d, 1)) return DCV_ERR_WORKSPACE;
+    if (!aligned16(dy) || !aligned16(ws)) return DCV_ERR_INVALID_ARG;
+    float* wb = reinterpret_cast<float*>(ws);
+    const int total = d->cout * d->cin * d->r * d->s;
+    // kernel view: reads dy (Cin' = Cout), writes dx (Cout' = Cin), filter flipped + transposed, pad' = dil*(R-1) - pad
+    hipLaunchKernelGGL(mfma_prep_weights_kernel, dim3((unsigned)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256)), dim3(256), 0, st, w, wb, d->cin, d->cout, d->r, d->s, d->cin, 1);
+    MfmaArgs a{};
+    a.N = d->n; a.Hin = d->ho; a.Win = d->wo; a.Cin = d->cout; a.Hout = d->h; a.Wout = d->w; a.Cout = d->cin;
+    a.R = d->r; a.S = d->s; a.sh = 1; a.sw = 1; a.ph = d->dil_h * (d->r - 1) - d->pad_h; a.pw = d->dil_w * (d->s - 1) - d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
+    a.act = DCV_ACT_NONE; a.slope = 0.f; a.M = (long)d->n * d->h * d->w;
+    return run_mfma(a, dy, wb, nullptr, dx, st);
+}
+
+int dcv_mfma_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
+    MfmaWgArgs a{}; int chunks;
+    wg_plan(d, &a, &chunks);
+    if (!ws || ws_bytes < (size_t)chunks * a.wtotal * sizeof(float)) return DCV_ERR_WORKSPACE;
+    if (!aligned16(x) || !aligned16(dy)) return DCV_ERR_INVALID_ARG;
+    float* partial = reinterpret_cast<float*>(ws);
+    dim3 grid((unsigned)chunks, (unsigned)(d->r * d->s * (d->cin / WG_T)), (unsigned)(d->cout / WG_T));
+    if (grid.y > 65535 || grid.z > 65535) return DCV_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(conv_mfma_wgrad_kernel, grid, dim3(256), 0, st, a, x, dy, partial);
+    hipLaunchKernelGGL(mfma_wgrad_reduce_kernel, dim3((unsigned)dcv_ceil_div(a.wtotal, 32)), dim3(1024), 0, st, partial, dw, chunks, a.wtotal);
+    return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
+}

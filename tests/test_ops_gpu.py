@@ -56,6 +56,14 @@ CONV_CASES = [
     (1, 128, 6, 6, 8, 3, 1, 1, 1, 0, False),       # > 256 wgrad units: un-tiled weight-gradient fallback
     (3, 4, 40, 24, 4, 3, 1, 1, 1, 1, False),       # several row tiles per image, ragged last tile (tiled weight gradient)
     (2, 3, 37, 29, 5, 5, 2, 2, 1, 0, True),        # strided + NCHW input + ragged tiles
+    # wide layers: MFMA implicit-GEMM back-end (fwd / stride-1 dgrad / wgrad when both channel counts are multiples of 64)
+    (2, 64, 16, 16, 64, 3, 1, 1, 1, 1, False),
+    (3, 32, 9, 11, 64, 3, 1, 1, 1, 2, False),      # ragged pixel count (not a multiple of the 128-pixel tile), wgrad on the direct fallback
+    (1, 64, 8, 8, 128, 1, 1, 0, 1, 0, False),      # 1x1
+    (2, 64, 16, 16, 128, 3, 2, 1, 1, 1, False),    # stride 2: MFMA forward + wgrad, gather dgrad
+    (1, 32, 12, 12, 48, 5, 1, 2, 1, 3, False),     # 5x5, Cout = 48 (BN = 16 tiles)
+    (2, 128, 8, 8, 64, 3, 1, 2, 2, 1, False),      # dilation 2
+    (1, 64, 7, 7, 64, 3, 1, 0, 1, 0, False),       # no padding (pad' = 2 in the data gradient)
 ]
 
 

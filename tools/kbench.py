@@ -17,13 +17,15 @@ def conv_case(n, cin, h, w, cout, k, pad):
     d = nat.Conv2dDesc(n, h, w, cin, cout, k, k, 1, 1, pad, pad, 1, 1, 1, h, w, nat.LAYOUT_NHWC, nat.ACT_RELU, 0.)
     return x, wt, b, y, dy, d
 st = nat.current_stream(dev)
-if case in ('conv450', 'conv1630', 'conv430'):
-    cfg = {'conv450': (NB, 4, 32, 32, 4, 5, 2), 'conv1630': (NB, 16, 16, 16, 16, 3, 1), 'conv430': (NB, 4, 16, 16, 16, 3, 1)}[case]
+CONVS = {'conv450': (NB, 4, 32, 32, 4, 5, 2), 'conv1630': (NB, 16, 16, 16, 16, 3, 1), 'conv430': (NB, 4, 16, 16, 16, 3, 1), 'conv6430': (NB, 64, 32, 32, 64, 3, 1),
+         'conv12830': (NB, 128, 16, 16, 128, 3, 1), 'conv51230': (NB, 512, 4, 4, 512, 3, 1)}
+if case in CONVS:
+    cfg = CONVS[case]
     x, wt, b, y, dy, d = conv_case(*cfg)
     wsf = torch.empty(max(16, nat.lib.dcv_conv2d_fwd_workspace_bytes(d)), dtype=torch.uint8, device=dev)
     fn = lambda: nat.check(nat.lib.dcv_conv2d_fwd(d, x.data_ptr(), wt.data_ptr(), b.data_ptr(), y.data_ptr(), wsf.data_ptr(), wsf.numel(), st))
-elif case in ('wgrad450', 'wgrad1630'):
-    cfg = {'wgrad450': (NB, 4, 32, 32, 4, 5, 2), 'wgrad1630': (NB, 16, 16, 16, 16, 3, 1)}[case]
+elif case.startswith('wgrad') and ('conv' + case[5:]) in CONVS:
+    cfg = CONVS['conv' + case[5:]]
     x, wt, b, y, dy, d = conv_case(*cfg)
     dw = torch.empty_like(wt)
     ws = torch.empty(nat.lib.dcv_conv2d_wgrad_workspace_bytes(d), dtype=torch.uint8, device=dev)
@@ -34,4 +36,7 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record()
 for _ in range(launches): fn()
 e1.record(); torch.cuda.synchronize()
-print(case, 'avg us', e0.elapsed_time(e1) * 1e3 / launches)
+us = e0.elapsed_time(e1) * 1e3 / launches
+n_, cin_, h_, w_, cout_, k_, _p = cfg
+flops = 2.0 * n_ * h_ * w_ * cout_ * cin_ * k_ * k_
+print(case, 'avg us', round(us, 2), 'TFLOP/s', round(flops / us / 1e6, 2))
