@@ -8,7 +8,7 @@ A step = one pass of the hot path over one batch of 512 synthetic 3x32x32 images
 all-reduce (N > 1) and AdamW update with the stock piecewise-linear LR schedule, plus the per-step loss read-back of the reference's `process_function`
 (`src/deepcv/meta/ignite_training.py:233-255`).  Inputs are resident in HBM when the timed region starts (a pool of 16 device batches is cycled).
 Rank 0 prints ONE JSON line.  Besides the whole-job throughput it carries
-  * `roofline`: the dominant kernel (direct 5x5 4->4 convolution, `conv_s1_kernel<4,5,0>`, 4 launches per step: 2 forward + 2 data-gradient), timed
+  * `roofline`: the dominant kernel (direct 5x5 4->4 convolution, `conv_tile_kernel<4,5,2>`, 4 launches per step: 2 forward + 2 data-gradient), timed
     live with HIP events on the launch stream; achieved = algorithmic bytes per launch (SURVEY.md §8d) / average launch duration, against 8 TB/s HBM;
   * `cpu_baseline`: the PyTorch-CPU oracle restatement of the same step on the host cores of this box, on a bounded sample (rank 0, N = 1 only). """
 import argparse
@@ -70,7 +70,7 @@ def cpu_baseline(params, budget_s: float = 20.0):
 
 
 def dominant_kernel_roofline(device, launches: int = 200):
-    """ Times `conv_s1_kernel<4,5,0>` (N=512, 32x32, 4 -> 4 channels, 5x5, pad 2, fused bias + ReLU: layers 2-3 forward and, with the flipped filter,
+    """ Times `conv_tile_kernel<4,5,2>` (N=512, 32x32, 4 -> 4 channels, 5x5, pad 2, fused bias + ReLU: layers 2-3 forward and, with the flipped filter,
     their data gradients) through the C-ABI with HIP events recorded on the stream the kernel is launched on (torch's current stream). """
     from deepcv_amd import _native as nat
     n, c, h, w, k = BATCH_PER_GPU, 4, 32, 32, 5
@@ -96,7 +96,7 @@ def dominant_kernel_roofline(device, launches: int = 200):
     us = e0.elapsed_time(e1) * 1e3 / launches
     algo_bytes = 4 * (n * h * w * c + c * c * k * k + n * h * w * c)
     achieved = algo_bytes / (us * 1e-6) / 1e9
-    return {'bound': 'hbm', 'kernel': 'conv_s1_kernel<4,5,0> (dcv_conv2d_fwd, 512x32x32x4 -> 4, 5x5)', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+    return {'bound': 'hbm', 'kernel': 'conv_tile_kernel<4,5,2> (dcv_conv2d_fwd, 512x32x32x4 -> 4, 5x5)', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None, 'avg_launch_us': round(us, 2), 'algorithmic_bytes_per_launch': algo_bytes}
 
 

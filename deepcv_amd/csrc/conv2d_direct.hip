@@ -52,7 +52,7 @@ __device__ __forceinline__ void stage_weights(const DirectArgs& a, const float* 
     }
 }
 
-// Re-lays the OIHW filter out as wt[cout tile][R][S][Cin][TCO] (zero-padded output channels) for the scalar-cache weight path of conv_s1_kernel.
+// Re-lays the OIHW filter out as wt[cout tile][R][S][Cin][TCO] (zero-padded output channels) for the scalar-cache weight path of conv_tile_kernel.
 // dgrad: kernel-input channel = original Cout, kernel-output channel = original Cin, taps flipped.
 __global__ __launch_bounds__(256) void prep_weights_kernel(DirectArgs a, const float* __restrict__ w, float* __restrict__ wt, int tco, int tiles, int cin_pad, int flip) {
     const int total = tiles * a.R * a.S * cin_pad * tco;

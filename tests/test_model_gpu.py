@@ -130,15 +130,8 @@ def test_training_steps_match_oracle(device, params, graph):
     assert compared >= 12
 
 
-@pytest.mark.parametrize('spec,nc,shape,n', [('cifar100_deep_model', 100, (3, 32, 32), 4), ('resnet18_style_model', 1000, (3, 224, 224), 2)])
-def test_wide_models_match_oracle(device, params, spec, nc, shape, n):
-    """ BASELINE.json configs 3 and 5 (specs authored in the reference's YAML grammar): wide layers run on the MFMA implicit-GEMM kernels, residual links,
-    max pooling, strided convolutions; forward / loss / gradients against the CPU oracle (fp32). """
+def _fwd_bwd_pair(native, oracle, x, y, device):
     from deepcv_amd import modules as native_modules
-    native, oracle = _build(params, spec, nc, image_shape=shape)
-    native = native.to(device)
-    g = torch.Generator().manual_seed(DATA_SEED)
-    x, y = torch.randn(n, *shape, generator=g), torch.randint(0, nc, (n,), generator=g)
     oracle.train(); native.train()
     lo = oracle(x)
     loss_o = torch.nn.functional.cross_entropy(lo, y)
@@ -147,16 +140,52 @@ def test_wide_models_match_oracle(device, params, spec, nc, shape, n):
     loss_n = native_modules.CrossEntropyLoss()(ln, y.to(device))
     loss_n.backward()
     torch.cuda.synchronize()
-    e_logits, e_loss = _rel(ln, lo), abs(loss_n.item() - loss_o.item()) / abs(loss_o.item())
-    _report(f'{spec}: logits rel err {e_logits:.3e}, loss rel err {e_loss:.3e}')
-    assert e_logits <= 1e-3 and e_loss <= 1e-4
+    return _rel(ln, lo), abs(loss_n.item() - loss_o.item()) / abs(loss_o.item())
+
+
+def _grad_rel_errors(native, oracle):
+    """ Per weight tensor: max |g_hip - g_oracle| / max |g_oracle|, gauge directions (exact gradient 0, see above) skipped. """
     gscale = max(p.grad.abs().max().item() for p in oracle.parameters())
+    errs = {}
     for (name, p_n), (_, p_o) in zip(native.named_parameters(), oracle.named_parameters()):
-        abs_err = (p_n.grad.detach().cpu() - p_o.grad).abs().max().item()
-        # 20+ layers of BatchNorm at batch size 2-4 amplify fp32 rounding differences of the two implementations (the fp32 CPU reference is as far
-        # from an fp64 evaluation as the HIP path is): 2 % of each tensor's gradient magnitude
-        bound = 2e-2 * p_o.grad.abs().max().item() + 1e-5 * gscale
-        assert abs_err <= bound, f'{name}: gradient error {abs_err:.3e} > {bound:.3e}'
+        if p_o.grad.abs().max().item() < 1e-4 * gscale:
+            continue
+        errs[name] = (p_n.grad.detach().cpu() - p_o.grad).abs().max().item() / p_o.grad.abs().max().item()
+    return errs
+
+
+@pytest.mark.parametrize('spec,nc,shape,n', [('cifar100_deep_model', 100, (3, 32, 32), 4), ('resnet18_style_model', 1000, (3, 224, 224), 8)])
+def test_wide_models_match_oracle(device, params, spec, nc, shape, n):
+    """ BASELINE.json configs 3 and 5 (specs authored in the reference's YAML grammar): wide layers run on the MFMA implicit-GEMM kernels, residual links,
+    max pooling, strided convolutions; forward / loss / gradients against the CPU oracle (fp32).
+
+    Gradients are checked twice.  (1) On a smooth twin of the spec (`act_fn: Tanh`), strictly: every kernel of the backward path is exercised at the
+    model's shapes and no kink can hide an error.  (2) On the spec itself (ReLU), loosely: after 10-20 layers the forward rounding difference between
+    two fp32 implementations (~1e-5 of the activation range) flips the sign of about one pre-activation per layer out of 1e5-1e6 (measured against an
+    fp64 evaluation with tools/layer_grads.py: the HIP path and the fp32 CPU path each flip 0-2 per layer, at |pre-activation| <= 1e-5), and one flipped
+    ReLU in a 7x7 or 14x14 feature map moves that layer's weight gradient by 1e-2..2e-1 of its maximum in EITHER implementation.  No tolerance can tell
+    that apart from a 1 % kernel error, which is what (1) is for. """
+    import copy
+    g = torch.Generator().manual_seed(DATA_SEED)
+    x, y = torch.randn(n, *shape, generator=g), torch.randint(0, nc, (n,), generator=g)
+
+    smooth = dict(copy.deepcopy(dict(params[spec])))
+    smooth['act_fn'] = torch.nn.Tanh
+    native, oracle = _build({'smooth': smooth}, 'smooth', nc, image_shape=shape)
+    e_logits, e_loss = _fwd_bwd_pair(native.to(device), oracle, x, y, device)
+    errs = _grad_rel_errors(native, oracle)
+    _report(f'{spec}[tanh twin]: logits rel err {e_logits:.3e}, loss rel err {e_loss:.3e}, worst grad rel err {max(errs.values()):.3e} ({max(errs, key=errs.get)})')
+    assert e_logits <= 1e-3 and e_loss <= 1e-4
+    assert max(errs.values()) <= 2e-3, f'smooth twin: gradient rel err {max(errs.values()):.3e} at {max(errs, key=errs.get)}'
+    del native, oracle
+
+    native, oracle = _build(params, spec, nc, image_shape=shape)
+    e_logits, e_loss = _fwd_bwd_pair(native.to(device), oracle, x, y, device)
+    errs = _grad_rel_errors(native, oracle)
+    med = sorted(errs.values())[len(errs) // 2]
+    _report(f'{spec}: logits rel err {e_logits:.3e}, loss rel err {e_loss:.3e}, grad rel err median {med:.3e} worst {max(errs.values()):.3e} ({max(errs, key=errs.get)})')
+    assert e_logits <= 1e-3 and e_loss <= 1e-4
+    assert med <= 3e-2 and max(errs.values()) <= 0.5, f'gradient rel err: median {med:.3e}, worst {max(errs.values()):.3e} at {max(errs, key=errs.get)}'
 
 
 def test_eval_mode_and_accuracy(device, params):

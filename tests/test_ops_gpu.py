@@ -64,6 +64,12 @@ CONV_CASES = [
     (1, 32, 12, 12, 48, 5, 1, 2, 1, 3, False),     # 5x5, Cout = 48 (BN = 16 tiles)
     (2, 128, 8, 8, 64, 3, 1, 2, 2, 1, False),      # dilation 2
     (1, 64, 7, 7, 64, 3, 1, 0, 1, 0, False),       # no padding (pad' = 2 in the data gradient)
+    # the layer shapes of `resnet18_style_model` at batch 8 (BASELINE.json configs[5])
+    (8, 256, 14, 14, 256, 3, 1, 1, 1, 1, False),
+    (8, 512, 7, 7, 512, 3, 1, 1, 1, 1, False),     # 392 pixels: ragged 128-pixel tile and ragged 16-pixel wgrad step
+    (8, 256, 14, 14, 512, 3, 2, 1, 1, 1, False),
+    (8, 64, 56, 56, 128, 3, 2, 1, 1, 1, False),
+    (2, 3, 224, 224, 64, 7, 2, 3, 1, 1, True),     # stem
 ]
 
 
