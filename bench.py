@@ -107,6 +107,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true', help='do not capture the step into a hipGraph')
+    ap.add_argument('--force-dp', action='store_true', help='rehearsal: take the data-parallel code path (process group, buckets, RCCL all-reduce) even at world size 1')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -117,8 +118,11 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs a HIP device'
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
-    if world > 1:
+    use_dp = world > 1 or args.force_dp
+    if use_dp:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=device)   # "nccl" is RCCL on ROCm
 
     from deepcv_amd import modules, optim
@@ -134,9 +138,10 @@ def main():
     torch.manual_seed(MODEL_SEED)
     model = create_model({'trainset': SyntheticImageDataset(2, IMAGE_SHAPE, NUM_CLASSES)}, params['image_classifier_model']).to(device)
     reducer = None
-    if world > 1:
+    if use_dp:
         wrapped = DataParallelModel(model, overlap=args.eager)   # autograd hooks only serve the eager path; the graph path reduces after the replay
         reducer = wrapped.reducer
+        reducer.force_collective = args.force_dp
     opt = optim.AdamW(model.parameters(), **hp['optimizer_opts'])
     total_iters = args.warmup + args.steps + 4
     sched = PiecewiseLinear(opt, 'lr', [[0, 0.0], [int(0.2 * total_iters), hp['optimizer_opts']['lr']], [total_iters, 0.0]])
@@ -156,7 +161,7 @@ def main():
     for _ in range(args.warmup):
         one_step(it); it += 1
     torch.cuda.synchronize(device)
-    if world > 1:
+    if use_dp:
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
@@ -164,11 +169,11 @@ def main():
     for _ in range(args.steps):
         last = one_step(it); it += 1
     torch.cuda.synchronize(device)
-    if world > 1:
+    if use_dp:
         dist.barrier()
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dp:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -187,7 +192,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(params)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dp:
         dist.barrier()
         dist.destroy_process_group()
 

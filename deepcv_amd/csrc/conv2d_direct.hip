@@ -581,6 +581,218 @@ __global__ __launch_bounds__(256) void conv_wgrad_tiled_kernel(WgTiledArgs a, co
     }
 }
 
+// ------------------------------------------------------------------------------------------------ sliding-window weight gradient (stride_w = dil_w = 1)
+// Same tiling as above (zero-padded x halo tile + dy tile of TH output rows in LDS, one partial slab per block, ordered second stage), but a thread owns
+// a unit = (VEC input channels, filter ROW r, 4 output channels) with ALL S taps of that row, and walks SEG consecutive output pixels of one image row at
+// a time: the SEG+S-1 input pixels under the window and the SEG dy vectors are fetched with one ds_read each and feed SEG*S*4*VEC FMAs from registers
+// (4->4 5x5: 12 LDS reads per 320 FMAs, against 2 per 16 for the one-tap-per-thread kernel, whose loop was LDS-latency and address-arithmetic bound).
+// Units fewer than 256 are replicated over `nsub` segment sub-streams; consecutive sub-streams work on consecutive tile ROWS and both tiles have a row
+// stride of an odd number of 16-B slots, so the ds_read_b128 of neighbouring lanes fall into different banks.  Sub-streams are merged through LDS in a
+// fixed order (row stride congruent to `units` mod 32: conflict-free for the writers and for the readers) -> deterministic.
+struct WgSlideArgs {
+    int N, H, W, Cin, Ho, Wo, Cout, R, sh, ph, pw, dh;
+    int x_nchw;
+    int TH, XH, XW, WoP;           // output rows per tile, halo tile rows / cols, tile width rounded up to a multiple of SEG
+    int xrs, drs;                  // LDS row strides (floats) of the x and dy tiles
+    int civ, cogb, units, nsub;    // input-channel vectors, 4-wide output-channel groups per block, units = civ * R * cogb, sub-streams = 256 / units
+    int spr;                       // segments per tile row
+    int xs_floats;                 // size of the x tile
+    int cv_shift, cogb_shift;      // log2 of Cin/VEC and of cogb when they are powers of two, else -1
+    int red_rs;                    // row stride of the merge buffer
+    int tiles_per_img, total_tiles;
+    int nt;                        // threads per block
+    size_t wtotal;
+};
+
+__device__ __forceinline__ void dcv_divmod(int j, int d, int shift, int& q, int& r) {
+    if (shift >= 0) { q = j >> shift; r = j & (d - 1); } else { q = j / d; r = j - q * d; }
+}
+
+template <int S, int VEC, int SEG>
+__global__ __launch_bounds__(256) void conv_wgrad_slide_kernel(WgSlideArgs a, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = reinterpret_cast<float*>(smem);                       // [XH][xrs]   (pixel-major, channel fastest)
+    float* dys = xs + a.xs_floats;                                    // [TH][drs]   (pixel-major, 4 * cogb channels)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
+    const int ul = t % a.units, sub = t / a.units;
+    const bool active = sub < a.nsub;
+    const int cog = ul % a.cogb, r = (ul / a.cogb) % a.R, civ = ul / (a.cogb * a.R);   // cog fastest: neighbouring lanes share the x address (broadcast)
+    const int ci0 = civ * VEC;
+    const int tcob = 4 * a.cogb;
+    const int co_base = blockIdx.y * tcob;
+
+    float acc[S][4][VEC];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[s][j][v] = 0.f;
+
+    for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+        const int n = tile / a.tiles_per_img, ho0 = (tile % a.tiles_per_img) * a.TH;
+        const int th = (a.Ho - ho0 < a.TH) ? (a.Ho - ho0) : a.TH;
+        const int hi0 = ho0 * a.sh - a.ph, wi0 = -a.pw;
+        __syncthreads();
+        // ---- stage the x halo tile: a wave takes tile rows wave, wave + nw, ...; lanes run along the row (coalesced); four rows are loaded before any
+        //      of them is written to LDS so that their global-memory latencies overlap; padding is resolved here (clamped address + select)
+        if (!a.x_nchw) {
+            const int cv = a.Cin / VEC, per_row = a.XW * cv;
+            for (int j = lane; j < per_row; j += 64) {
+                int xc, c; dcv_divmod(j, cv, a.cv_shift, xc, c);
+                const int wi = wi0 + xc;
+                const bool wok = wi >= 0 && wi < a.W;
+                const int wic = wi < 0 ? 0 : (wi >= a.W ? a.W - 1 : wi);
+                const float* col = x + (size_t)n * a.H * a.W * a.Cin + (size_t)wic * a.Cin + c * VEC;
+                for (int xr0 = wave; xr0 < a.XH; xr0 += 4 * nw) {
+                    float vv[4][VEC];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int hi = hi0 + xr0 + u * nw;
+                        const int hic = hi < 0 ? 0 : (hi >= a.H ? a.H - 1 : hi);
+                        const float* sp = col + (size_t)hic * a.W * a.Cin;
+                        if constexpr (VEC == 4) { const float4 q = *reinterpret_cast<const float4*>(sp); vv[u][0] = q.x; vv[u][1] = q.y; vv[u][2] = q.z; vv[u][3] = q.w; }
+                        else vv[u][0] = sp[0];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int xr = xr0 + u * nw, hi = hi0 + xr;
+                        const bool ok = wok && hi >= 0 && hi < a.H;
+                        if (xr < a.XH) {
+                            float* dp = xs + (size_t)xr * a.xrs + j * VEC;
+                            if constexpr (VEC == 4) *reinterpret_cast<float4*>(dp) = ok ? make_float4(vv[u][0], vv[u][1], vv[u][2], vv[u][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                            else dp[0] = ok ? vv[u][0] : 0.f;
+                        }
+                    }
+                }
+            }
+        } else {
+            const int pairs = a.Cin * a.XH;                           // (channel, tile row) pairs; lanes along the NCHW row
+            for (int xc = lane; xc < a.XW; xc += 64) {
+                const int wi = wi0 + xc;
+                const bool wok = wi >= 0 && wi < a.W;
+                const int wic = wi < 0 ? 0 : (wi >= a.W ? a.W - 1 : wi);
+                for (int q0 = wave; q0 < pairs; q0 += 4 * nw) {
+                    float vv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        int q = q0 + u * nw; q = q < pairs ? q : pairs - 1;
+                        const int c = q / a.XH, xr = q - c * a.XH;
+                        const int hi = hi0 + xr;
+                        const int hic = hi < 0 ? 0 : (hi >= a.H ? a.H - 1 : hi);
+                        vv[u] = x[(((size_t)n * a.Cin + c) * a.H + hic) * a.W + wic];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int q = q0 + u * nw;
+                        if (q < pairs) {
+                            const int c = q / a.XH, xr = q - c * a.XH;
+                            const int hi = hi0 + xr;
+                            const bool ok = wok && hi >= 0 && hi < a.H;
+                            xs[(size_t)xr * a.xrs + xc * a.Cin + c] = ok ? vv[u] : 0.f;
+                        }
+                    }
+                }
+            }
+        }
+        // ---- stage the dy tile (zero beyond Wo, beyond the last row of the image and beyond Cout), same four-rows-in-flight scheme
+        {
+            const int per_row = a.WoP * a.cogb;
+            const bool full = (a.Cout % 4 == 0);
+            for (int j = lane; j < per_row; j += 64) {
+                int wl, c4; dcv_divmod(j, a.cogb, a.cogb_shift, wl, c4);
+                const int co = co_base + c4 * 4;
+                const bool cok = wl < a.Wo && co < a.Cout;
+                const float* col = dy + ((size_t)n * a.Ho + ho0) * a.Wo * a.Cout + (size_t)(wl < a.Wo ? wl : 0) * a.Cout + (co < a.Cout ? co : 0);
+                for (int h0 = wave; h0 < a.TH; h0 += 4 * nw) {
+                    float4 vv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int hl = h0 + u * nw;
+                        const float* sp = col + (size_t)(hl < th ? hl : 0) * a.Wo * a.Cout;
+                        if (full) vv[u] = *reinterpret_cast<const float4*>(sp);
+                        else {
+                            vv[u] = make_float4(sp[0], 0.f, 0.f, 0.f);
+                            if (co + 1 < a.Cout) vv[u].y = sp[1];
+                            if (co + 2 < a.Cout) vv[u].z = sp[2];
+                            if (co + 3 < a.Cout) vv[u].w = sp[3];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int hl = h0 + u * nw;
+                        if (hl < a.TH) *reinterpret_cast<float4*>(dys + (size_t)hl * a.drs + j * 4) = (cok && hl < th) ? vv[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (active) {
+            // segment index = sg * th + hl (row fastest): consecutive sub-streams sit on consecutive rows; rows beyond th hold zero dy and are skipped
+            const int nsegs = th * a.spr;
+            int sg = sub / th, hl = sub - sg * th;
+            const int dsg = a.nsub / th, dhl = a.nsub - dsg * th;
+            for (int seg = sub; seg < nsegs; seg += a.nsub) {
+                const int w0 = sg * SEG;
+                const float* xp = xs + (size_t)(hl * a.sh + r * a.dh) * a.xrs + w0 * a.Cin + ci0;
+                const float* gp = dys + (size_t)hl * a.drs + w0 * tcob + 4 * cog;
+                float xw[SEG + S - 1][VEC];
+                float4 g[SEG];
+#pragma unroll
+                for (int k = 0; k < SEG + S - 1; ++k) {
+                    if constexpr (VEC == 4) {
+                        const float4 v = *reinterpret_cast<const float4*>(xp + k * a.Cin);
+                        xw[k][0] = v.x; xw[k][1] = v.y; xw[k][2] = v.z; xw[k][3] = v.w;
+                    } else {
+                        xw[k][0] = xp[k * a.Cin];
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < SEG; ++p) g[p] = *reinterpret_cast<const float4*>(gp + p * tcob);
+#pragma unroll
+                for (int p = 0; p < SEG; ++p)
+#pragma unroll
+                    for (int s = 0; s < S; ++s)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) {
+                            acc[s][0][v] = fmaf(g[p].x, xw[p + s][v], acc[s][0][v]);
+                            acc[s][1][v] = fmaf(g[p].y, xw[p + s][v], acc[s][1][v]);
+                            acc[s][2][v] = fmaf(g[p].z, xw[p + s][v], acc[s][2][v]);
+                            acc[s][3][v] = fmaf(g[p].w, xw[p + s][v], acc[s][3][v]);
+                        }
+                sg += dsg; hl += dhl;
+                if (hl >= th) { hl -= th; ++sg; }
+            }
+        }
+    }
+    // ---- merge the sub-streams in a fixed order, one filter column s at a time, through red[4 * VEC][red_rs]: thread (sub, unit) sums element
+    //      e = sub, sub + nsub, ... of ITS unit over all sub-streams (no index arithmetic: the unit's coordinates are already in registers)
+    float* red = reinterpret_cast<float*>(smem);
+    float* dst = partial + (size_t)blockIdx.x * a.wtotal;
+    constexpr int E = 4 * VEC;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) red[(j * VEC + v) * a.red_rs + t] = acc[s][j][v];
+        }
+        __syncthreads();
+        if (active) {
+            for (int e = sub; e < E; e += a.nsub) {
+                const float* q = red + e * a.red_rs + ul;             // bank(e * red_rs + ul) = (e * units + ul) mod 32: conflict-free across lanes
+                float sum = 0.f;
+#pragma unroll 8
+                for (int k = 0; k < a.nsub; ++k) { sum += *q; q += a.units; }
+                const int co = co_base + 4 * cog + e / VEC, ci = ci0 + e % VEC;
+                if (co < a.Cout) dst[(((size_t)co * a.Cin + ci) * a.R + r) * S + s] = sum;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host helpers
 inline bool conv_desc_ok(const dcv_conv2d_desc* d) {
     if (!d) return false;
@@ -810,6 +1022,72 @@ bool wgrad_tiled_plan(const dcv_conv2d_desc* d, WgTiledArgs* a, int* tco, int* v
     return true;
 }
 
+// Plans the sliding-window weight gradient; false when the layer does not fit it (strided / dilated columns, unusual filter width, too many units).
+bool wgrad_slide_plan(const dcv_conv2d_desc* d, WgSlideArgs* a, int* vec, int* seg, int* blocks, int* ygrid, size_t* smem) {
+    static int enabled = -1;
+    if (enabled < 0) { const char* e = getenv("DCV_WGRAD_SLIDE"); enabled = e ? atoi(e) : 1; }
+    if (!enabled) return false;
+    if (d->stride_w != 1 || d->dil_w != 1) return false;
+    if (!(d->s == 1 || d->s == 3 || d->s == 5 || d->s == 7)) return false;
+    const int v = (d->x_layout == DCV_LAYOUT_NHWC && d->cin % 4 == 0) ? 4 : 1;
+    const int civ = d->cin / v;
+    static int nt = -1;
+    if (nt < 0) { const char* e = getenv("DCV_WGRAD_THREADS"); nt = e ? atoi(e) : 256; }
+    if ((long)civ * d->r > nt) return false;
+    const int cogs = (d->cout + 3) / 4;
+    int cogb = nt / (civ * d->r); if (cogb > cogs) cogb = cogs;
+    a->nt = nt;
+    const int sg = (d->s == 7 && v == 4) ? 2 : 4;
+    a->N = d->n; a->H = d->h; a->W = d->w; a->Cin = d->cin; a->Ho = d->ho; a->Wo = d->wo; a->Cout = d->cout; a->R = d->r;
+    a->sh = d->stride_h; a->ph = d->pad_h; a->pw = d->pad_w; a->dh = d->dil_h;
+    a->x_nchw = d->x_layout == DCV_LAYOUT_NCHW;
+    a->WoP = (d->wo + sg - 1) / sg * sg;
+    a->XW = a->WoP + d->s - 1;
+    a->spr = a->WoP / sg;
+    a->civ = civ; a->cogb = cogb; a->units = civ * d->r * cogb; a->nsub = nt / a->units;
+    auto log2_or_neg = [](int n) { int sft = 0; while ((1 << sft) < n) ++sft; return (1 << sft) == n ? sft : -1; };
+    a->cv_shift = log2_or_neg(civ); a->cogb_shift = log2_or_neg(cogb);
+    // LDS row strides: an odd number of 16-B slots (VEC = 4) / an odd number of words (VEC = 1)
+    a->xrs = a->XW * d->cin;
+    if (v == 4) { if ((a->xrs / 4) % 2 == 0) a->xrs += 4; } else { a->xrs = (a->xrs + 3) / 4 * 4; if ((a->xrs / 4) % 2 == 0) a->xrs += 4; }
+    a->drs = a->WoP * 4 * cogb; if ((a->drs / 4) % 2 == 0) a->drs += 4;
+    a->red_rs = nt + (a->units % 32);                                   // red_rs = units (mod 32)
+    static int target_tiles = -1, target_blocks = -1;
+    if (target_tiles < 0) { const char* e = getenv("DCV_WGRAD_TILES"); target_tiles = e ? atoi(e) : 512; }
+    if (target_blocks < 0) { const char* e = getenv("DCV_WGRAD_BLOCKS"); target_blocks = e ? atoi(e) : 512; }
+    int th = d->ho;
+    size_t bytes = 0;
+    for (;;) {
+        a->TH = th; a->XH = (th - 1) * d->stride_h + (d->r - 1) * d->dil_h + 1;
+        a->xs_floats = a->XH * a->xrs;
+        bytes = ((size_t)a->xs_floats + (size_t)th * a->drs) * sizeof(float);
+        const long tiles = (long)d->n * ((d->ho + th - 1) / th);
+        if (th == 1 || (bytes <= 40 * 1024 && (tiles >= target_tiles || th <= 4))) break;
+        th = (th + 1) / 2;
+    }
+    if (bytes > 64 * 1024) return false;
+    const size_t red_bytes = (size_t)4 * v * a->red_rs * sizeof(float);
+    if (bytes < red_bytes) bytes = red_bytes;
+    a->tiles_per_img = (d->ho + th - 1) / th;
+    a->total_tiles = d->n * a->tiles_per_img;
+    a->wtotal = (size_t)d->cout * d->cin * d->r * d->s;
+    int nb = a->total_tiles < target_blocks ? a->total_tiles : target_blocks;
+    const size_t max_by_bytes = ((size_t)64 << 20) / (a->wtotal * sizeof(float));
+    if ((size_t)nb > max_by_bytes) nb = (int)(max_by_bytes > 0 ? max_by_bytes : 1);
+    *vec = v; *seg = sg; *blocks = nb; *ygrid = (cogs + cogb - 1) / cogb; *smem = bytes;
+    return true;
+}
+
+template <int VEC>
+void launch_wgrad_slide(int s, dim3 grid, size_t smem, hipStream_t st, const WgSlideArgs& a, const float* x, const float* dy, float* partial) {
+    switch (s) {
+        case 1: hipLaunchKernelGGL((conv_wgrad_slide_kernel<1, VEC, 4>), grid, dim3(a.nt), smem, st, a, x, dy, partial); break;
+        case 3: hipLaunchKernelGGL((conv_wgrad_slide_kernel<3, VEC, 4>), grid, dim3(a.nt), smem, st, a, x, dy, partial); break;
+        case 5: hipLaunchKernelGGL((conv_wgrad_slide_kernel<5, VEC, 4>), grid, dim3(a.nt), smem, st, a, x, dy, partial); break;
+        default: hipLaunchKernelGGL((conv_wgrad_slide_kernel<7, VEC, (VEC == 4 ? 2 : 4)>), grid, dim3(a.nt), smem, st, a, x, dy, partial); break;
+    }
+}
+
 template <int VEC>
 void launch_wgrad_tiled(int tco, dim3 grid, size_t smem, hipStream_t st, const WgTiledArgs& a, const float* x, const float* dy, float* partial) {
     switch (tco) {
@@ -823,6 +1101,8 @@ void launch_wgrad_tiled(int tco, dim3 grid, size_t smem, hipStream_t st, const W
 
 size_t dcv_direct_conv2d_wgrad_ws(const dcv_conv2d_desc* d) {
     WgTiledArgs ta{}; int tco, tvec, blocks; size_t smem;
+    { WgSlideArgs sa{}; int sv, sseg, sb, sy; size_t ssm;
+      if (wgrad_slide_plan(d, &sa, &sv, &sseg, &sb, &sy, &ssm)) return dcv_align_up((size_t)sb * sa.wtotal * sizeof(float), 256); }
     if (wgrad_tiled_plan(d, &ta, &tco, &tvec, &blocks, &smem)) return dcv_align_up((size_t)blocks * ta.wtotal * sizeof(float), 256);
     WgradArgs a{}; int chunks, ub, vec;
     wgrad_plan(d, &a, &chunks, &ub, &vec);
@@ -832,6 +1112,17 @@ size_t dcv_direct_conv2d_wgrad_ws(const dcv_conv2d_desc* d) {
 int dcv_direct_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
     float* partial = reinterpret_cast<float*>(ws);
     WgTiledArgs ta{}; int tco, tvec, blocks; size_t smem;
+    {
+        WgSlideArgs sa{}; int sv, sseg, sb, sy; size_t ssm;
+        if (wgrad_slide_plan(d, &sa, &sv, &sseg, &sb, &sy, &ssm) && (sv == 1 || (reinterpret_cast<uintptr_t>(x) & 15) == 0) && (reinterpret_cast<uintptr_t>(dy) & 15) == 0) {
+            if (!ws || ws_bytes < (size_t)sb * sa.wtotal * sizeof(float)) return DCV_ERR_WORKSPACE;
+            dim3 grid((unsigned)sb, (unsigned)sy);
+            if (sv == 4) launch_wgrad_slide<4>(d->s, grid, ssm, st, sa, x, dy, partial);
+            else launch_wgrad_slide<1>(d->s, grid, ssm, st, sa, x, dy, partial);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)dcv_ceil_div(sa.wtotal, 32)), dim3(1024), 0, st, partial, dw, sb, sa.wtotal);
+            return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
+        }
+    }
     if (wgrad_tiled_plan(d, &ta, &tco, &tvec, &blocks, &smem) && (tvec == 1 || (reinterpret_cast<uintptr_t>(x) & 15) == 0)) {
         if (!ws || ws_bytes < (size_t)blocks * ta.wtotal * sizeof(float)) return DCV_ERR_WORKSPACE;
         dim3 grid((unsigned)blocks, (unsigned)dcv_ceil_div(d->cout, tco));

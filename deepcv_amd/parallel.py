@@ -57,6 +57,7 @@ class GradientAllReducer:
         self.params = [p for p in params if p.requires_grad]
         self.enabled = True
         self.overlap = overlap
+        self.force_collective = False     # rehearsal switch: run the collective even in a group of one
         cap = max(1, int(bucket_cap_mb * 1024 * 1024 / 4))
         self.buckets: List[_Bucket] = []
         cur, cur_n = [], 0
@@ -105,7 +106,7 @@ class GradientAllReducer:
 
     def _launch(self, b: _Bucket):
         self._pack(b)
-        if self.world_size > 1:
+        if self.world_size > 1 or self.force_collective:
             if self.comm_stream is not None:
                 self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))   # bucket must be packed before the collective reads it
                 with torch.cuda.stream(self.comm_stream):

@@ -17,7 +17,7 @@ def conv_case(n, cin, h, w, cout, k, pad):
     d = nat.Conv2dDesc(n, h, w, cin, cout, k, k, 1, 1, pad, pad, 1, 1, 1, h, w, nat.LAYOUT_NHWC, nat.ACT_RELU, 0.)
     return x, wt, b, y, dy, d
 st = nat.current_stream(dev)
-CONVS = {'conv450': (NB, 4, 32, 32, 4, 5, 2), 'conv1630': (NB, 16, 16, 16, 16, 3, 1), 'conv430': (NB, 4, 16, 16, 16, 3, 1), 'conv6430': (NB, 64, 32, 32, 64, 3, 1),
+CONVS = {'conv350': (NB, 3, 32, 32, 4, 5, 2), 'conv450': (NB, 4, 32, 32, 4, 5, 2), 'conv1630': (NB, 16, 16, 16, 16, 3, 1), 'conv430': (NB, 4, 16, 16, 16, 3, 1), 'conv6430': (NB, 64, 32, 32, 64, 3, 1),
          'conv12830': (NB, 128, 16, 16, 128, 3, 1), 'conv51230': (NB, 512, 4, 4, 512, 3, 1)}
 if case in CONVS:
     cfg = CONVS[case]
