@@ -200,12 +200,24 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TileArgs a, const float*
                         const int ns = gs / a.tiles_per_img, h0 = (gs - ns * a.tiles_per_img) * a.TH;
                         const int nc = ns < a.N ? ns : a.N - 1;
                         const bool sub_ok = gs < a.total_subtiles;
-                        for (int xr = 0; xr < a.XH; ++xr) {
-                            const int hi = h0 * a.sh - a.ph + xr;
-                            const bool ok = sub_ok && col_ok && hi >= 0 && hi < a.Hin;
-                            const int hic = hi < 0 ? 0 : (hi >= a.Hin ? a.Hin - 1 : hi);
-                            const float v = a.in_nchw ? x[(((size_t)nc * a.Cin + cgc) * a.Hin + hic) * a.Win + wic] : x[(((size_t)nc * a.Hin + hic) * a.Win + wic) * a.Cin + cgc];
-                            xf[((size_t)(c >> 2) * plane + ((size_t)sb * a.XH + xr) * a.XW + xc) * 4 + (c & 3)] = ok ? v : 0.f;
+                        // row stride / base of this thread's (column, channel) in the source; eight rows in flight per batch
+                        const size_t rstride = a.in_nchw ? (size_t)a.Win : (size_t)a.Win * a.Cin;
+                        const float* colp = a.in_nchw ? x + ((size_t)nc * a.Cin + cgc) * a.Hin * a.Win + wic : x + ((size_t)nc * a.Hin * a.Win + wic) * a.Cin + cgc;
+                        float* dcol = xf + ((size_t)(c >> 2) * plane + (size_t)sb * a.XH * a.XW + xc) * 4 + (c & 3);
+                        for (int xr0 = 0; xr0 < a.XH; xr0 += 8) {
+                            float v[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                const int hi = h0 * a.sh - a.ph + xr0 + u;
+                                const int hic = hi < 0 ? 0 : (hi >= a.Hin ? a.Hin - 1 : hi);
+                                v[u] = colp[(size_t)hic * rstride];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                const int xr = xr0 + u, hi = h0 * a.sh - a.ph + xr;
+                                const bool ok = sub_ok && col_ok && hi >= 0 && hi < a.Hin;
+                                if (xr < a.XH) dcol[(size_t)xr * a.XW * 4] = ok ? v[u] : 0.f;
+                            }
                         }
                     }
                 }

@@ -276,6 +276,223 @@ __global__ void gn_param_grad_kernel(const double* __restrict__ partial, int N, 
     if (dgamma) dgamma[c] = (float)s2;
 }
 
+// ================================================================================================ fused normalisation chain
+// The reference layer is Conv -> act -> BatchNorm [-> GroupNorm] (src/deepcv/meta/nn.py:553).  On the stock model every standalone kernel of that
+// chain runs for ~5 us, which is the launch-to-launch floor rather than its data movement, so the chain is expressed in fewer, fatter launches:
+//   forward : statistics partials + finalize (as the standalone BatchNorm), then ONE kernel applying the BN affine and the GroupNorm of the BN output,
+//             which is never written to HBM (3 launches instead of 4, one 8 MB write + read less);
+//   backward: (1) GroupNorm backward on the recomputed BN output fused with the BatchNorm reduction terms, (2) one finalize for ALL parameter gradients
+//             of the chain, (3) BatchNorm backward apply * act'(x) -> dz (what the convolution's dgrad / wgrad consume) with the bias-gradient partials,
+//             (4) their ordered sum  (4 launches instead of 7, two 8 MB round trips less).
+// A single-launch variant in which the last block to finish (integer ticket + __threadfence) performs the finalize was measured on MI355X and rejected:
+// the device-scope release of every block writes back its XCD's L2, which made each of those kernels 40-70 us instead of ~8.
+struct AffineSumSqLoader {      // v = x * scale[c] + shift[c];  q0 = v, q1 = v^2      (scale / shift in LDS)
+    const float* x; const float* sc; const float* sh;
+    template <int VEC>
+    __device__ __forceinline__ void load(size_t idx, int c, float (&q)[2][VEC]) const {
+        if constexpr (VEC == 4) {
+            const float4 v = *reinterpret_cast<const float4*>(x + idx);
+            q[0][0] = v.x; q[0][1] = v.y; q[0][2] = v.z; q[0][3] = v.w;
+        } else {
+            q[0][0] = x[idx];
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { q[0][i] = q[0][i] * sc[c + i] + sh[c + i]; q[1][i] = q[0][i] * q[0][i]; }
+    }
+};
+
+// forward (2): out = GroupNorm(x * bn_scale + bn_shift), one block per sample; the BN output only exists in registers.
+template <int VEC>
+__global__ __launch_bounds__(DCV_CR_THREADS) void nf_bn_gn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, int HW, int C, int G,
+                                                                         const float* __restrict__ bn_scale_shift, const float* __restrict__ gamma,
+                                                                         const float* __restrict__ beta, float eps,
+                                                                         float* __restrict__ save_mean, float* __restrict__ save_rstd) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* chan = reinterpret_cast<double*>(smem);                      // [2][C]
+    float* bsc = reinterpret_cast<float*>(chan + 2 * (size_t)C);         // [C] BN scale
+    float* bsh = bsc + C;                                                // [C] BN shift
+    float* scale = bsh + C;                                              // [C] combined scale
+    float* shift = scale + C;                                            // [C] combined shift
+    float* scratch = shift + C;                                          // [2 * 256 * VEC]
+    const int n = blockIdx.x;
+    const size_t base = (size_t)n * HW * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) { bsc[c] = bn_scale_shift[c]; bsh[c] = bn_scale_shift[C + c]; }
+    __syncthreads();
+    AffineSumSqLoader ld{x + base, bsc, bsh};
+    dcv_colreduce_block<2, VEC>(ld, 0, (size_t)HW, C, scratch, chan);
+    const int cpg = C / G;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / cpg;
+        double s = 0.0, ss = 0.0;
+        for (int k = g * cpg; k < (g + 1) * cpg; ++k) { s += chan[k]; ss += chan[C + k]; }
+        const double m = (double)cpg * (double)HW;
+        const double mean = s / m;
+        double var = ss / m - mean * mean; if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        if (c == g * cpg) { save_mean[(size_t)n * G + g] = (float)mean; save_rstd[(size_t)n * G + g] = rstd; }
+        const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+        // out = gm * ((x * bsc + bsh) - mean) * rstd + bt
+        scale[c] = bsc[c] * rstd * gm;
+        shift[c] = (bsh[c] - (float)mean) * rstd * gm + bt;
+    }
+    __syncthreads();
+    const int CV = C / VEC;
+    const size_t nv = (size_t)HW * CV;
+    for (size_t i = threadIdx.x; i < nv; i += blockDim.x) {
+        const int c = (int)(i % CV) * VEC;
+        if constexpr (VEC == 4) {
+            const float4 v = reinterpret_cast<const float4*>(x + base)[i];
+            float4 o; o.x = v.x * scale[c] + shift[c]; o.y = v.y * scale[c + 1] + shift[c + 1];
+            o.z = v.z * scale[c + 2] + shift[c + 2]; o.w = v.w * scale[c + 3] + shift[c + 3];
+            reinterpret_cast<float4*>(y + base)[i] = o;
+        } else {
+            y[base + i] = x[base + i] * scale[c] + shift[c];
+        }
+    }
+}
+
+// finalize of the fused backward: one wave per channel, lanes stride over the per-sample partials [N][4][C] (S1, S2, T1, T2), fixed-order butterfly
+__global__ void nf_gn_bn_finalize_kernel(const double* __restrict__ partial, int N, size_t rows, int C, const float* __restrict__ bn_gamma,
+                                         const float* __restrict__ bn_rstd, float* __restrict__ d_bn_gamma, float* __restrict__ d_bn_beta,
+                                         float* __restrict__ d_gn_gamma, float* __restrict__ d_gn_beta, float* __restrict__ coef) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0, t1 = 0.0, t2 = 0.0;
+    for (int n = lane; n < N; n += DCV_WAVE) {
+        const double* pp = partial + (size_t)n * 4 * C + c;
+        s1 += pp[0]; s2 += pp[C]; t1 += pp[2 * (size_t)C]; t2 += pp[3 * (size_t)C];
+    }
+    s1 = dcv_wave_sum(s1); s2 = dcv_wave_sum(s2); t1 = dcv_wave_sum(t1); t2 = dcv_wave_sum(t2);
+    if (lane != 0) return;
+    if (d_gn_beta) d_gn_beta[c] = (float)s1;
+    if (d_gn_gamma) d_gn_gamma[c] = (float)s2;
+    if (d_bn_beta) d_bn_beta[c] = (float)t1;
+    if (d_bn_gamma) d_bn_gamma[c] = (float)t2;
+    const float g = bn_gamma ? bn_gamma[c] : 1.f;
+    coef[c] = g * bn_rstd[c];
+    coef[C + c] = (float)(t1 / (double)rows);
+    coef[2 * C + c] = (float)(t2 / (double)rows);
+}
+
+__global__ __launch_bounds__(64) void nf_sum_partials_kernel(const double* __restrict__ partial, int nb, int C, float* __restrict__ out) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    double s = 0.0;
+    for (int b = lane; b < nb; b += DCV_WAVE) s += partial[(size_t)b * C + c];
+    s = dcv_wave_sum(s);
+    if (lane == 0) out[c] = (float)s;
+}
+
+struct NfGnBwdLoaderA {         // pass A: q0 = dout, q1 = dout * w,  w = (x * bsc + bsh - mean_g) * rstd_g
+    const float* dout; const float* x; const float* bsc; const float* bsh; const float* mean; const float* rstd; int cpg;
+    template <int VEC>
+    __device__ __forceinline__ void load(size_t idx, int c, float (&q)[2][VEC]) const {
+        float xv[VEC];
+        if constexpr (VEC == 4) {
+            const float4 d = *reinterpret_cast<const float4*>(dout + idx);
+            const float4 v = *reinterpret_cast<const float4*>(x + idx);
+            q[0][0] = d.x; q[0][1] = d.y; q[0][2] = d.z; q[0][3] = d.w;
+            xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w;
+        } else { q[0][0] = dout[idx]; xv[0] = x[idx]; }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { const int g = (c + i) / cpg; q[1][i] = q[0][i] * ((xv[i] * bsc[c + i] + bsh[c + i] - mean[g]) * rstd[g]); }
+    }
+};
+
+struct NfGnBwdLoaderB {         // pass B: dv = ca * dout - cb - w * cd  (stored to dv_out);  q0 = dv, q1 = dv * u,  u = (x - bn_mean) * bn_rstd
+    const float* dout; const float* x; float* dv_out; const float* bsc; const float* bsh; const float* mean; const float* rstd; int cpg;
+    const float* ca; const float* cb; const float* cd; const float* bmean; const float* brstd;
+    template <int VEC>
+    __device__ __forceinline__ void load(size_t idx, int c, float (&q)[2][VEC]) const {
+        float xv[VEC], dv[VEC];
+        if constexpr (VEC == 4) {
+            const float4 d = *reinterpret_cast<const float4*>(dout + idx);
+            const float4 v = *reinterpret_cast<const float4*>(x + idx);
+            dv[0] = d.x; dv[1] = d.y; dv[2] = d.z; dv[3] = d.w;
+            xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w;
+        } else { dv[0] = dout[idx]; xv[0] = x[idx]; }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const int g = (c + i) / cpg;
+            const float w = (xv[i] * bsc[c + i] + bsh[c + i] - mean[g]) * rstd[g];
+            dv[i] = ca[c + i] * dv[i] - cb[c + i] - w * cd[c + i];
+            q[0][i] = dv[i];
+            q[1][i] = dv[i] * ((xv[i] - bmean[c + i]) * brstd[c + i]);
+        }
+        if constexpr (VEC == 4) { float4 o; o.x = dv[0]; o.y = dv[1]; o.z = dv[2]; o.w = dv[3]; *reinterpret_cast<float4*>(dv_out + idx) = o; }
+        else dv_out[idx] = dv[0];
+    }
+};
+
+// backward (1), BN + GN: one block per sample.  GroupNorm backward on the recomputed BN output -> dv (gradient w.r.t. the BN output, written to `dv_out`),
+// per-sample sums S1 = sum dout, S2 = sum dout*w (GN parameter gradients), T1 = sum dv, T2 = sum dv*u (BN terms) -> partial [N][4][C].
+template <int VEC>
+__global__ __launch_bounds__(DCV_CR_THREADS) void nf_gn_bn_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ x, float* __restrict__ dv_out,
+                                                                       int HW, int C, int G, const float* __restrict__ bn_gamma, const float* __restrict__ bn_beta,
+                                                                       const float* __restrict__ bn_mean, const float* __restrict__ bn_rstd,
+                                                                       const float* __restrict__ gn_gamma, const float* __restrict__ gn_mean,
+                                                                       const float* __restrict__ gn_rstd, double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* chan = reinterpret_cast<double*>(smem);                      // [4][C]
+    float* bsc = reinterpret_cast<float*>(chan + 4 * (size_t)C);         // [C] each:
+    float* bsh = bsc + C; float* bm = bsh + C; float* br = bm + C; float* ca = br + C; float* cb = ca + C; float* cd = cb + C;
+    float* scratch = cd + C;                                             // [2 * 256 * VEC]
+    const int n = blockIdx.x;
+    const size_t base = (size_t)n * HW * C;
+    const int cpg = C / G;
+    const float* mean = gn_mean + (size_t)n * G;
+    const float* rstd = gn_rstd + (size_t)n * G;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float g = bn_gamma ? bn_gamma[c] : 1.f, b = bn_beta ? bn_beta[c] : 0.f;
+        const float sc = g * bn_rstd[c];
+        bsc[c] = sc; bsh[c] = b - bn_mean[c] * sc; bm[c] = bn_mean[c]; br[c] = bn_rstd[c];
+    }
+    __syncthreads();
+    NfGnBwdLoaderA la{dout + base, x + base, bsc, bsh, mean, rstd, cpg};
+    dcv_colreduce_block<2, VEC>(la, 0, (size_t)HW, C, scratch, chan);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / cpg;
+        double A = 0.0, B = 0.0;
+        for (int k = g * cpg; k < (g + 1) * cpg; ++k) { const double gm = gn_gamma ? (double)gn_gamma[k] : 1.0; A += gm * chan[k]; B += gm * chan[C + k]; }
+        const double m = (double)cpg * (double)HW;
+        const float gm = gn_gamma ? gn_gamma[c] : 1.f;
+        ca[c] = gm * rstd[g];
+        cb[c] = (float)(A / m) * rstd[g];
+        cd[c] = (float)(B / m) * rstd[g];
+    }
+    __syncthreads();
+    NfGnBwdLoaderB lb{dout + base, x + base, dv_out + base, bsc, bsh, mean, rstd, cpg, ca, cb, cd, bm, br};
+    dcv_colreduce_block<2, VEC>(lb, 0, (size_t)HW, C, scratch, chan + 2 * (size_t)C);
+    for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) partial[(size_t)n * 4 * C + i] = chan[i];
+}
+
+struct NfApplyActLoader {       // dz = act'(x) * a * (dv - b - u * d), stored to dz;  q0 = dz  (bias gradient)
+    const float* dv; const float* x; float* dz; const float* mean; const float* rstd; const float* coef; int C; int act; float slope;
+    template <int VEC>
+    __device__ __forceinline__ void load(size_t idx, int c, float (&q)[1][VEC]) const {
+        float d[VEC], v[VEC];
+        if constexpr (VEC == 4) {
+            const float4 d4 = *reinterpret_cast<const float4*>(dv + idx); const float4 v4 = *reinterpret_cast<const float4*>(x + idx);
+            d[0] = d4.x; d[1] = d4.y; d[2] = d4.z; d[3] = d4.w; v[0] = v4.x; v[1] = v4.y; v[2] = v4.z; v[3] = v4.w;
+        } else { d[0] = dv[idx]; v[0] = x[idx]; }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const float u = (v[k] - mean[c + k]) * rstd[c + k];
+            q[0][k] = coef[c + k] * (d[k] - coef[C + c + k] - u * coef[2 * C + c + k]) * dcv_act_grad_from_out(v[k], act, slope);
+        }
+        if constexpr (VEC == 4) { float4 o4; o4.x = q[0][0]; o4.y = q[0][1]; o4.z = q[0][2]; o4.w = q[0][3]; *reinterpret_cast<float4*>(dz + idx) = o4; }
+        else dz[idx] = q[0][0];
+    }
+};
+
+// backward (3): BN backward apply fused with the activation derivative; per-block column sums of dz (bias gradient) -> partial [nb][C]
+template <int VEC>
+__global__ __launch_bounds__(DCV_CR_THREADS) void nf_bn_apply_act_bwd_kernel(NfApplyActLoader ld, size_t rows, int C, double* __restrict__ partial) {
+    __shared__ float scratch[DCV_CR_THREADS * VEC];
+    const size_t rpb = (rows + gridDim.x - 1) / gridDim.x;
+    const size_t r0 = (size_t)blockIdx.x * rpb;
+    size_t r1 = r0 + rpb; if (r1 > rows) r1 = rows;
+    dcv_colreduce_block<1, VEC>(ld, r0 < rows ? r0 : rows, r1, C, scratch, partial + (size_t)blockIdx.x * C);
+}
+
 inline size_t bn_ws_partial_bytes(size_t rows, int C) { return dcv_align_up((size_t)dcv_colreduce_blocks(rows, C) * 2 * C * sizeof(double), 256); }
 
 }  // namespace
@@ -385,6 +602,92 @@ int dcv_groupnorm_bwd(const float* dy, const float* x, float* dx, int n, int hw,
     else hipLaunchKernelGGL((gn_bwd_kernel<1>), dim3(n), dim3(DCV_CR_THREADS), smem, st, dy, x, dx, hw, C, G, gamma, save_mean, save_rstd, partial);
     if (need_param_grads)
         hipLaunchKernelGGL(gn_param_grad_kernel, dim3((unsigned)C), dim3(64), 0, st, partial, n, C, dgamma, dbeta);
+    DCV_RETURN_LAUNCH();
+}
+
+
+// ------------------------------------------------------------------------------------------------ fused chain entry points
+static inline size_t nf_partial_bytes(int n, int hw, int C) {
+    const size_t rows = (size_t)n * hw;
+    size_t a = (size_t)dcv_colreduce_blocks(rows, C) * 2 * C, b = (size_t)n * 4 * C;
+    return dcv_align_up((a > b ? a : b) * sizeof(double), 256);
+}
+
+size_t dcv_norm_chain_workspace_bytes(int n, int hw, int channels) {
+    if (n <= 0 || hw <= 0 || channels <= 0) return 0;
+    return nf_partial_bytes(n, hw, channels) + dcv_align_up((size_t)3 * channels * sizeof(float), 256);
+}
+
+int dcv_bn_gn_fwd_train(const float* x, float* y, int n, int hw, int C,
+                        const float* bn_gamma, const float* bn_beta, float* running_mean, float* running_var, int64_t* nbt, float momentum, float bn_eps,
+                        float* bn_save_mean, float* bn_save_rstd,
+                        int G, const float* gn_gamma, const float* gn_beta, float gn_eps, float* gn_save_mean, float* gn_save_rstd,
+                        void* ws, size_t ws_bytes, void* stream) {
+    DCV_CHECK_ARG(x && y && bn_save_mean && bn_save_rstd && ws && n > 0 && hw > 0 && C > 0 && G >= 0);
+    DCV_CHECK_ARG(G == 0 || (C % G == 0 && gn_save_mean && gn_save_rstd));
+    if (ws_bytes < dcv_norm_chain_workspace_bytes(n, hw, C)) return DCV_ERR_WORKSPACE;
+    hipStream_t st = dcv_stream(stream);
+    const size_t rows = (size_t)n * hw;
+    double* partial = reinterpret_cast<double*>(ws);
+    float* scale_shift = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + nf_partial_bytes(n, hw, C));
+    const unsigned nb = dcv_colreduce_blocks(rows, C);
+    const int vec = (C % 4 == 0) ? 4 : 1;
+    SumSqLoader ld{x};
+    if (vec == 4) hipLaunchKernelGGL((colreduce2_kernel<4, SumSqLoader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
+    else hipLaunchKernelGGL((colreduce2_kernel<1, SumSqLoader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((unsigned)C), dim3(64), 0, st, partial, (int)nb, rows, C, bn_gamma, bn_beta,
+                       running_mean, running_var, nbt, momentum, bn_eps, bn_save_mean, bn_save_rstd, scale_shift);
+    if (G > 0) {
+        const size_t smem = 2 * (size_t)C * sizeof(double) + (size_t)4 * C * sizeof(float) + (size_t)2 * DCV_CR_THREADS * vec * sizeof(float);
+        if (smem > 64 * 1024) return DCV_ERR_UNSUPPORTED;
+        if (vec == 4) hipLaunchKernelGGL((nf_bn_gn_apply_kernel<4>), dim3(n), dim3(DCV_CR_THREADS), smem, st, x, y, hw, C, G, scale_shift, gn_gamma, gn_beta, gn_eps, gn_save_mean, gn_save_rstd);
+        else hipLaunchKernelGGL((nf_bn_gn_apply_kernel<1>), dim3(n), dim3(DCV_CR_THREADS), smem, st, x, y, hw, C, G, scale_shift, gn_gamma, gn_beta, gn_eps, gn_save_mean, gn_save_rstd);
+    } else if (vec == 4) {
+        const size_t nv = rows * (size_t)C / 4;
+        hipLaunchKernelGGL((affine_apply_kernel<4>), dim3(dcv_stream_grid(nv, 256)), dim3(256), 0, st, x, y, nv, C, scale_shift);
+    } else {
+        const size_t nv = rows * (size_t)C;
+        hipLaunchKernelGGL((affine_apply_kernel<1>), dim3(dcv_stream_grid(nv, 256)), dim3(256), 0, st, x, y, nv, C, scale_shift);
+    }
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_bn_gn_act_bwd(const float* dout, const float* x, float* dz, int n, int hw, int C,
+                      const float* bn_gamma, const float* bn_beta, const float* bn_save_mean, const float* bn_save_rstd,
+                      int G, const float* gn_gamma, const float* gn_save_mean, const float* gn_save_rstd,
+                      int act, float slope,
+                      float* d_bn_gamma, float* d_bn_beta, float* d_gn_gamma, float* d_gn_beta, float* d_bias,
+                      void* ws, size_t ws_bytes, void* stream) {
+    DCV_CHECK_ARG(dout && x && dz && bn_save_mean && bn_save_rstd && ws && n > 0 && hw > 0 && C > 0 && G >= 0);
+    DCV_CHECK_ARG(G == 0 || (C % G == 0 && gn_save_mean && gn_save_rstd));
+    if (ws_bytes < dcv_norm_chain_workspace_bytes(n, hw, C)) return DCV_ERR_WORKSPACE;
+    hipStream_t st = dcv_stream(stream);
+    const size_t rows = (size_t)n * hw;
+    double* partial = reinterpret_cast<double*>(ws);
+    float* coef = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + nf_partial_bytes(n, hw, C));
+    const unsigned nb = dcv_colreduce_blocks(rows, C);
+    const int vec = (C % 4 == 0) ? 4 : 1;
+    const float* dv = dout;
+    if (G > 0) {
+        const size_t smem = 4 * (size_t)C * sizeof(double) + (size_t)7 * C * sizeof(float) + (size_t)2 * DCV_CR_THREADS * vec * sizeof(float);
+        if (smem > 64 * 1024) return DCV_ERR_UNSUPPORTED;
+        if (vec == 4) hipLaunchKernelGGL((nf_gn_bn_bwd_kernel<4>), dim3(n), dim3(DCV_CR_THREADS), smem, st, dout, x, dz, hw, C, G, bn_gamma, bn_beta, bn_save_mean, bn_save_rstd,
+                                         gn_gamma, gn_save_mean, gn_save_rstd, partial);
+        else hipLaunchKernelGGL((nf_gn_bn_bwd_kernel<1>), dim3(n), dim3(DCV_CR_THREADS), smem, st, dout, x, dz, hw, C, G, bn_gamma, bn_beta, bn_save_mean, bn_save_rstd,
+                                gn_gamma, gn_save_mean, gn_save_rstd, partial);
+        hipLaunchKernelGGL(nf_gn_bn_finalize_kernel, dim3((unsigned)C), dim3(64), 0, st, partial, n, rows, C, bn_gamma, bn_save_rstd,
+                           d_bn_gamma, d_bn_beta, d_gn_gamma, d_gn_beta, coef);
+        dv = dz;                                             // the apply pass runs in place on dz
+    } else {
+        BnBwdLoader ld{dout, x, bn_save_mean, bn_save_rstd};
+        if (vec == 4) hipLaunchKernelGGL((colreduce2_kernel<4, BnBwdLoader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
+        else hipLaunchKernelGGL((colreduce2_kernel<1, BnBwdLoader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
+        hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((unsigned)C), dim3(64), 0, st, partial, (int)nb, rows, C, bn_gamma, bn_save_rstd, d_bn_gamma, d_bn_beta, coef);
+    }
+    NfApplyActLoader ld{dv, x, dz, bn_save_mean, bn_save_rstd, coef, C, act, slope};
+    if (vec == 4) hipLaunchKernelGGL((nf_bn_apply_act_bwd_kernel<4>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
+    else hipLaunchKernelGGL((nf_bn_apply_act_bwd_kernel<1>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
+    if (d_bias) hipLaunchKernelGGL(nf_sum_partials_kernel, dim3((unsigned)C), dim3(64), 0, st, partial, (int)nb, C, d_bias);
     DCV_RETURN_LAUNCH();
 }
 

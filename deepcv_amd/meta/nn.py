@@ -234,9 +234,36 @@ class LayerSequential(torch.nn.Sequential):
             return outs if len(outs) != 1 else outs[0]
         return self._forward_one(x)
 
+    def _fused_layer_plan(self, mods):
+        """ (conv, act, batch_norm, group_norm | None, next index) when the children start with `Conv2d - act? - BatchNorm2d - GroupNorm?` (the post-activation
+        layout of `layer()`) in a state the fused training kernels cover, else None. """
+        if not (self.training and len(mods) >= 2 and isinstance(mods[0], native.Conv2d)) or native.in_shape_inference():
+            return None
+        i, act = 1, None
+        if isinstance(mods[i], native._NativeAct):
+            act, i = mods[i], i + 1
+        if i >= len(mods) or type(mods[i]) is not native.BatchNorm2d:
+            return None
+        bn, i = mods[i], i + 1
+        if not (bn.training and bn.track_running_stats and bn.momentum is not None and bn.affine):
+            return None
+        gn = None
+        if i < len(mods) and type(mods[i]) is native.GroupNorm and mods[i].affine:
+            gn, i = mods[i], i + 1
+        return mods[0], act, bn, gn, i
+
     def _forward_one(self, x: torch.Tensor) -> torch.Tensor:
         mods = list(self._modules.values())
         i, n = 0, len(mods)
+        plan = self._fused_layer_plan(mods) if (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4) else None
+        if plan is not None:
+            conv, act, bn, gn, i = plan
+            conv._check()
+            code, slope = ops.act_code(act)
+            x = ops.conv_norm_layer(x, conv.weight, conv.bias, conv.stride, conv._padding_pair(), conv.dilation, code, slope,
+                                    bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum, bn.eps,
+                                    gn.num_groups if gn is not None else 0, gn.weight if gn is not None else None, gn.bias if gn is not None else None,
+                                    gn.eps if gn is not None else 1e-5)
         while i < n:
             m = mods[i]
             if isinstance(m, (native.Conv2d, native.Linear)) and i + 1 < n and isinstance(mods[i + 1], native._NativeAct) and not native.in_shape_inference():

@@ -11,7 +11,7 @@ import torch
 from . import _native as nat
 from ._native import lib
 
-__all__ = ['conv2d', 'activation', 'batch_norm', 'group_norm', 'pool2d', 'interpolate_bilinear', 'concat_channels', 'add_tensors', 'flatten_nchw_order',
+__all__ = ['conv2d', 'conv_norm_layer', 'activation', 'batch_norm', 'group_norm', 'pool2d', 'interpolate_bilinear', 'concat_channels', 'add_tensors', 'flatten_nchw_order',
            'linear', 'cross_entropy', 'act_code', 'to_nhwc', 'nchw_to_nhwc']
 
 _CL = torch.channels_last
@@ -280,6 +280,85 @@ class _GroupNormFn(torch.autograd.Function):
 
 def group_norm(x, gamma, beta, groups: int, eps: float) -> torch.Tensor:
     return _GroupNormFn.apply(x, gamma, beta, int(groups), float(eps))
+
+
+# ------------------------------------------------------------------------------------------------ fused layer: conv + act + BatchNorm [+ GroupNorm]
+
+class _ConvNormLayerFn(torch.autograd.Function):
+    """ One reference layer in training mode, Conv2d -> act -> BatchNorm2d [-> GroupNorm] (`layer()`, reference `nn.py:553`), as ONE autograd node:
+    forward = convolution (+ bias + activation epilogue) and `dcv_bn_gn_fwd_train`; backward = `dcv_bn_gn_act_bwd` (GroupNorm / BatchNorm / activation
+    backward + every parameter gradient of the chain + the bias gradient in two launches), then the convolution's data and weight gradients. """
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn_w, bn_b, running_mean, running_var, nbt, gn_w, gn_b, cfg):
+        stride, padding, dilation, act, slope, momentum, bn_eps, groups, gn_eps = cfg
+        _require_f32(x, weight, bias, bn_w, bn_b, running_mean, running_var, gn_w, gn_b)
+        if _is_nhwc(x):
+            layout = nat.LAYOUT_NHWC
+        elif x.is_contiguous():
+            layout = nat.LAYOUT_NCHW
+        else:
+            x, layout = to_nhwc(x), nat.LAYOUT_NHWC
+        weight = weight.contiguous()
+        d = _conv_desc(x.shape, weight.shape, stride, padding, dilation, layout, act, slope)
+        dev, st = x.device, nat.current_stream(x.device)
+        y = torch.empty((d.n, d.cout, d.ho, d.wo), dtype=x.dtype, device=dev, memory_format=_CL)
+        ws = _ws(lib.dcv_conv2d_fwd_workspace_bytes(d), dev)
+        nat.check(lib.dcv_conv2d_fwd(d, x.data_ptr(), weight.data_ptr(), nat.ptr(bias), y.data_ptr(), ws.data_ptr(), ws.numel(), st), 'dcv_conv2d_fwd')
+        out = torch.empty_like(y)
+        c, hw = d.cout, d.ho * d.wo
+        bn_mean = torch.empty(c, dtype=torch.float32, device=dev)
+        bn_rstd = torch.empty(c, dtype=torch.float32, device=dev)
+        gn_mean = torch.empty(d.n * groups, dtype=torch.float32, device=dev) if groups else None
+        gn_rstd = torch.empty(d.n * groups, dtype=torch.float32, device=dev) if groups else None
+        ws = _ws(lib.dcv_norm_chain_workspace_bytes(d.n, hw, c), dev)
+        nat.check(lib.dcv_bn_gn_fwd_train(y.data_ptr(), out.data_ptr(), d.n, hw, c, nat.ptr(bn_w), nat.ptr(bn_b), nat.ptr(running_mean), nat.ptr(running_var),
+                                          nat.ptr(nbt), momentum, bn_eps, bn_mean.data_ptr(), bn_rstd.data_ptr(), groups, nat.ptr(gn_w), nat.ptr(gn_b), gn_eps,
+                                          nat.ptr(gn_mean), nat.ptr(gn_rstd), ws.data_ptr(), ws.numel(), st), 'dcv_bn_gn_fwd_train')
+        ctx.desc, ctx.cfg = d, cfg
+        ctx.save_for_backward(x, weight, bias, y, bn_w, bn_b, bn_mean, bn_rstd, gn_w, gn_mean, gn_rstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight, bias, y, bn_w, bn_b, bn_mean, bn_rstd, gn_w, gn_mean, gn_rstd = ctx.saved_tensors
+        d = ctx.desc
+        stride, padding, dilation, act, slope, momentum, bn_eps, groups, gn_eps = ctx.cfg
+        dev, st = dout.device, nat.current_stream(dout.device)
+        dout = to_nhwc(dout)
+        c, hw = d.cout, d.ho * d.wo
+        new = lambda: torch.empty(c, dtype=torch.float32, device=dev)
+        need = ctx.needs_input_grad
+        db = new() if (bias is not None and need[2]) else None
+        d_bn_w = new() if (bn_w is not None and need[3]) else None
+        d_bn_b = new() if (bn_b is not None and need[4]) else None
+        d_gn_w = new() if (gn_w is not None and need[8]) else None
+        d_gn_b = new() if (groups and need[9]) else None
+        dz = torch.empty_like(y)
+        ws = _ws(lib.dcv_norm_chain_workspace_bytes(d.n, hw, c), dev)
+        nat.check(lib.dcv_bn_gn_act_bwd(dout.data_ptr(), y.data_ptr(), dz.data_ptr(), d.n, hw, c, nat.ptr(bn_w), nat.ptr(bn_b), bn_mean.data_ptr(), bn_rstd.data_ptr(),
+                                        groups, nat.ptr(gn_w), nat.ptr(gn_mean), nat.ptr(gn_rstd), act, slope,
+                                        nat.ptr(d_bn_w), nat.ptr(d_bn_b), nat.ptr(d_gn_w), nat.ptr(d_gn_b), nat.ptr(db),
+                                        ws.data_ptr(), ws.numel(), st), 'dcv_bn_gn_act_bwd')
+        dx = dw = None
+        if need[0]:
+            dd = nat.Conv2dDesc.from_buffer_copy(d)
+            dd.x_layout = nat.LAYOUT_NHWC
+            dx = torch.empty((d.n, d.cin, d.h, d.w), dtype=dz.dtype, device=dev, memory_format=_CL)
+            ws = _ws(lib.dcv_conv2d_dgrad_workspace_bytes(dd), dev)
+            nat.check(lib.dcv_conv2d_dgrad(dd, dz.data_ptr(), weight.data_ptr(), dx.data_ptr(), ws.data_ptr(), ws.numel(), st), 'dcv_conv2d_dgrad')
+        if need[1]:
+            dw = torch.empty_like(weight)
+            ws = _ws(lib.dcv_conv2d_wgrad_workspace_bytes(d), dev)
+            nat.check(lib.dcv_conv2d_wgrad(d, x.data_ptr(), dz.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), ws.numel(), st), 'dcv_conv2d_wgrad')
+        return dx, dw, db, d_bn_w, d_bn_b, None, None, None, d_gn_w, d_gn_b, None
+
+
+def conv_norm_layer(x, weight, bias, stride, padding, dilation, act: int, slope: float, bn_w, bn_b, running_mean, running_var, num_batches_tracked,
+                    momentum: float, bn_eps: float, gn_groups: int = 0, gn_w=None, gn_b=None, gn_eps: float = 1e-5) -> torch.Tensor:
+    """ Training-mode `GroupNorm?(BatchNorm(act(conv2d(x))))` with batch statistics and running-stat update, fused (see `_ConvNormLayerFn`). """
+    cfg = (_pair(stride), _pair(padding), _pair(dilation), int(act), float(slope), float(momentum), float(bn_eps), int(gn_groups), float(gn_eps))
+    return _ConvNormLayerFn.apply(x, weight, bias, bn_w, bn_b, running_mean, running_var, num_batches_tracked, gn_w, gn_b, cfg)
 
 
 # ------------------------------------------------------------------------------------------------ pooling

@@ -132,6 +132,29 @@ int dcv_groupnorm_bwd(const float* dy, const float* x, float* dx, int n, int hw,
                       void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * K5+K6 fused: the normalisation chain of one reference layer, Conv -> act -> BatchNorm [-> GroupNorm] (op order of layer(), nn.py:553; norm stack
+ * of normalization_techniques(), nn.py:448-516), two launches per direction.  x is the activated convolution output, groups == 0 means "no GroupNorm".
+ *   forward : y = GN(BN(x)); batch statistics -> bn_save_mean / bn_save_rstd [C] and running stats; GroupNorm statistics -> gn_save_* [N][groups];
+ *             the BatchNorm output is never materialised.
+ *   backward: dz = d loss / d (pre-activation convolution output) given dout = d loss / d y: GroupNorm backward (on the recomputed BN output), BatchNorm
+ *             backward and the activation derivative (from its output x) in one pass; parameter gradients and the convolution bias gradient
+ *             (sum of dz over rows) are produced by the same launches.  dz may not alias dout or x.
+ * replaces what autograd runs for the BatchNorm2d / GroupNorm / activation modules built at nn.py:487-501,553 during ignite_training.py:253.
+ * ------------------------------------------------------------------------------------------------- */
+size_t dcv_norm_chain_workspace_bytes(int n, int hw, int channels);
+int dcv_bn_gn_fwd_train(const float* x, float* y, int n, int hw, int channels,
+                        const float* bn_gamma, const float* bn_beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                        float momentum, float bn_eps, float* bn_save_mean, float* bn_save_rstd,
+                        int groups, const float* gn_gamma, const float* gn_beta, float gn_eps, float* gn_save_mean, float* gn_save_rstd,
+                        void* ws, size_t ws_bytes, void* stream);
+int dcv_bn_gn_act_bwd(const float* dout, const float* x, float* dz, int n, int hw, int channels,
+                      const float* bn_gamma, const float* bn_beta, const float* bn_save_mean, const float* bn_save_rstd,
+                      int groups, const float* gn_gamma, const float* gn_save_mean, const float* gn_save_rstd,
+                      int act, float act_slope,
+                      float* d_bn_gamma, float* d_bn_beta, float* d_gn_gamma, float* d_gn_beta, float* d_bias /* all nullable */,
+                      void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * K7 / K7'  2-D average / max pooling, NHWC
  * replaces torch.nn.AvgPool2d (submodule_creators.py:168 -> nn.py:416) and torch.nn.MaxPool2d (nn_spec.py:158-169)
  * avg: count_include_pad=True, ceil_mode=False (torch defaults).  max: first maximum wins on ties.

@@ -47,6 +47,22 @@ def group_norm(x, groups, gamma, beta, eps, dy) -> Dict[str, torch.Tensor]:
     return {'y': y.detach().float(), 'dx': x_.grad.float(), 'dgamma': None if g_ is None else g_.grad.float(), 'dbeta': None if b_ is None else b_.grad.float()}
 
 
+def conv_norm_layer(x, w, b, stride, padding, dilation, act: int, slope: float, bn_gamma, bn_beta, running_mean, running_var, momentum, bn_eps,
+                    groups: int, gn_gamma, gn_beta, gn_eps, dout) -> Dict[str, torch.Tensor]:
+    """ One reference layer in training mode, `Conv2d -> act_fn() -> BatchNorm2d [-> GroupNorm]` (src/deepcv/meta/nn.py:553 with the norm stack of
+    nn.py:448-516), fp64: output, updated running statistics and every gradient. """
+    x_, w_, b_, g1, b1, g2, b2 = _leaf(x), _leaf(w), _leaf(b), _leaf(bn_gamma), _leaf(bn_beta), _leaf(gn_gamma), _leaf(gn_beta)
+    rm, rv = running_mean.clone().double(), running_var.clone().double()
+    y = _ACTS[act](F.conv2d(x_, w_, b_, stride=stride, padding=padding, dilation=dilation), slope)
+    out = F.batch_norm(y, rm, rv, g1, b1, training=True, momentum=momentum, eps=bn_eps)
+    if groups:
+        out = F.group_norm(out, groups, g2, b2, gn_eps)
+    out.backward(dout.double())
+    f = lambda t: None if t is None or t.grad is None else t.grad.float()
+    return {'out': out.detach().float(), 'dx': f(x_), 'dw': f(w_), 'db': f(b_), 'd_bn_gamma': f(g1), 'd_bn_beta': f(b1), 'd_gn_gamma': f(g2), 'd_gn_beta': f(b2),
+            'running_mean': rm.float(), 'running_var': rv.float()}
+
+
 def pool2d(x, kernel, stride, padding, mode: str, dy) -> Dict[str, torch.Tensor]:
     """ K7 / K7': `AvgPool2d` (src/deepcv/meta/submodule_creators.py:168) / `MaxPool2d` (nn_spec.py:158-169). """
     x_ = _leaf(x)

@@ -322,3 +322,59 @@ def test_native_rejects_cpu_tensors():
     from deepcv_amd import ops
     with pytest.raises(RuntimeError, match='HIP device'):
         ops.conv2d(torch.zeros(1, 3, 8, 8), torch.zeros(4, 3, 3, 3), None, 1, 1, 1)
+
+
+# (N, Cin, H, W, Cout, k, stride, pad, act, groups, nchw_input): the fused layer chain conv -> act -> BatchNorm [-> GroupNorm] (reference nn.py:553)
+LAYER_CASES = [
+    (8, 3, 32, 32, 4, 5, 1, 2, 1, 4, True),        # stock layer 1 (parameters.yml:12): BN + GN(4 groups), NCHW batch read in place
+    (8, 4, 16, 16, 16, 3, 1, 1, 2, 4, False),      # stock layer 4, LeakyReLU epilogue
+    (6, 16, 16, 16, 16, 3, 1, 1, 1, 0, False),     # BN only (image_classifier_bn_only_model), MFMA convolution
+    (3, 5, 9, 11, 6, 3, 1, 1, 3, 2, False),        # ragged sizes, C % 4 != 0 (scalar paths), sigmoid, 2 groups
+    (2, 8, 12, 12, 12, 3, 2, 1, 4, 3, False),      # stride 2, tanh, 3 groups
+    (70, 4, 8, 8, 8, 3, 1, 1, 0, 8, False),        # no activation; more samples than one wave of partials; one channel per group
+    (2, 64, 14, 14, 64, 3, 1, 1, 1, 0, False),     # wide BN-only layer (resnet18_style shapes)
+]
+
+
+@pytest.mark.parametrize('case', LAYER_CASES, ids=lambda c: 'x'.join(str(v) for v in c))
+def test_conv_norm_layer_fused(device, case):
+    """ `ops.conv_norm_layer` (dcv_conv2d_* + dcv_bn_gn_fwd_train / dcv_bn_gn_act_bwd: last-block finalize, BN output never materialised) against the
+    fp64 composition conv2d -> act -> batch_norm -> group_norm. """
+    from deepcv_amd import ops
+    from oracle import ops_ref
+    n, cin, h, w, cout, k, stride, pad, act, groups, nchw = case
+    g = torch.Generator().manual_seed(4321 + sum(int(v) for v in case))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * 0.3
+    b = torch.randn(cout, generator=g) * 0.5
+    bn_g, bn_b = torch.rand(cout, generator=g) + 0.25, torch.randn(cout, generator=g) * 0.2
+    gn_g, gn_b = (torch.rand(cout, generator=g) + 0.25, torch.randn(cout, generator=g) * 0.2) if groups else (None, None)
+    rm, rv = torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    dout = torch.randn(n, cout, ho, wo, generator=g)
+    mom, eps = 0.07359778246238029, 1e-5
+    ref = ops_ref.conv_norm_layer(x, wt, b, stride, pad, 1, act, 0.01, bn_g, bn_b, rm, rv, mom, eps, groups, gn_g, gn_b, eps, dout)
+
+    dev = lambda t: None if t is None else t.to(device).requires_grad_(True)
+    xd = (x.to(device) if nchw else _cl(x.to(device))).requires_grad_(True)
+    wd, bd, g1, b1, g2, b2 = dev(wt), dev(b), dev(bn_g), dev(bn_b), dev(gn_g), dev(gn_b)
+    rmd, rvd, nbt = rm.to(device), rv.to(device), torch.zeros((), dtype=torch.int64, device=device)
+    out = ops.conv_norm_layer(xd, wd, bd, stride, pad, 1, act, 0.01, g1, b1, rmd, rvd, nbt, mom, eps, groups, g2, b2, eps)
+    out.backward(_cl(dout.to(device)))
+    torch.cuda.synchronize()
+    name = f'layer{case}'
+    _check(name + '.out', out, ref['out'], 2e-4)
+    _check(name + '.running_mean', rmd, ref['running_mean'], 1e-5)
+    _check(name + '.running_var', rvd, ref['running_var'], 1e-5)
+    assert int(nbt) == 1
+    gauge = 1e-4 * ref['dw'].abs().max().item() + 1e-6
+    for key, got in (('dx', xd.grad), ('dw', wd.grad), ('d_bn_gamma', g1.grad), ('d_bn_beta', b1.grad)) + ((('d_gn_gamma', g2.grad), ('d_gn_beta', b2.grad)) if groups else ()):
+        if key.startswith('d_bn_') and groups == cout:
+            # one channel per group: the BatchNorm affine pair is undone by the GroupNorm that follows, its exact gradient is 0 (gauge direction)
+            assert got.abs().max().item() <= gauge, f'{name}.{key}: {got.abs().max().item():.3e}'
+        else:
+            _check(f'{name}.{key}', got, ref[key], 1e-3)
+    if act == 0:   # a bias feeding BatchNorm directly is a gauge direction too
+        assert bd.grad.abs().max().item() <= gauge
+    else:
+        _check(f'{name}.db', bd.grad, ref['db'], 1e-3)

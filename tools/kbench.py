@@ -19,7 +19,13 @@ def conv_case(n, cin, h, w, cout, k, pad):
 st = nat.current_stream(dev)
 CONVS = {'conv350': (NB, 3, 32, 32, 4, 5, 2), 'conv450': (NB, 4, 32, 32, 4, 5, 2), 'conv1630': (NB, 16, 16, 16, 16, 3, 1), 'conv430': (NB, 4, 16, 16, 16, 3, 1), 'conv6430': (NB, 64, 32, 32, 64, 3, 1),
          'conv12830': (NB, 128, 16, 16, 128, 3, 1), 'conv51230': (NB, 512, 4, 4, 512, 3, 1)}
-if case in CONVS:
+if case == 'conv350n':     # first layer: NCHW input read in place
+    cfg = CONVS['conv350']
+    x, wt, b, y, dy, d = conv_case(*cfg)
+    x = x.contiguous(); d.x_layout = nat.LAYOUT_NCHW
+    wsf = torch.empty(max(16, nat.lib.dcv_conv2d_fwd_workspace_bytes(d)), dtype=torch.uint8, device=dev)
+    fn = lambda: nat.check(nat.lib.dcv_conv2d_fwd(d, x.data_ptr(), wt.data_ptr(), b.data_ptr(), y.data_ptr(), wsf.data_ptr(), wsf.numel(), st))
+elif case in CONVS:
     cfg = CONVS[case]
     x, wt, b, y, dy, d = conv_case(*cfg)
     wsf = torch.empty(max(16, nat.lib.dcv_conv2d_fwd_workspace_bytes(d)), dtype=torch.uint8, device=dev)
