@@ -42,13 +42,39 @@ __device__ __forceinline__ void dcv_colreduce_block(const F& f, size_t row_begin
 #pragma unroll
             for (int v = 0; v < VEC; ++v) scratch[(q * VEC + v) * DCV_CR_THREADS + t] = acc[q][v];
         __syncthreads();
-        // ordered merge over the row sub-streams: thread (q, c) sums rsub = 0..rows_per_iter-1
-        for (int idx = t; idx < NQ * C; idx += DCV_CR_THREADS) {
-            const int q = idx / C, c = idx % C;
-            const int cvi = c / VEC, v = c % VEC;
-            double s = 0.0;
-            for (int rs = 0; rs < rows_per_iter; ++rs) s += (double)scratch[(q * VEC + v) * DCV_CR_THREADS + rs * CV + cvi];
-            out[q * C + c] = s;
+        const int NO = NQ * C;
+        if (NO <= DCV_CR_THREADS / 2) {
+            // few outputs (small C), many row sub-streams: ordered two-level merge.  Thread (part, o) sums a contiguous run of sub-streams of output o,
+            // then thread o sums the `P` run totals in order -> a serial chain of rows_per_iter / P + P adds instead of rows_per_iter.
+            __shared__ double cr_part[DCV_CR_THREADS];
+            const int P = DCV_CR_THREADS / NO;
+            const int part = t / NO, o = t - part * NO;
+            if (part < P) {
+                const int q = o / C, c = o - q * C;
+                const int cvi = c / VEC, v = c - cvi * VEC;
+                const int chunk = (rows_per_iter + P - 1) / P;
+                const int rs0 = part * chunk;
+                int rs1 = rs0 + chunk; if (rs1 > rows_per_iter) rs1 = rows_per_iter;
+                const float* sp = scratch + (q * VEC + v) * DCV_CR_THREADS + cvi;
+                double s = 0.0;
+                for (int rs = rs0; rs < rs1; ++rs) s += (double)sp[rs * CV];
+                cr_part[part * NO + o] = s;
+            }
+            __syncthreads();
+            if (t < NO) {
+                double s = 0.0;
+                for (int pp = 0; pp < P; ++pp) s += cr_part[pp * NO + t];
+                out[t] = s;                                   // t = q * C + c
+            }
+        } else {
+            // ordered merge over the row sub-streams: thread (q, c) sums rsub = 0..rows_per_iter-1
+            for (int idx = t; idx < NO; idx += DCV_CR_THREADS) {
+                const int q = idx / C, c = idx % C;
+                const int cvi = c / VEC, v = c % VEC;
+                double s = 0.0;
+                for (int rs = 0; rs < rows_per_iter; ++rs) s += (double)scratch[(q * VEC + v) * DCV_CR_THREADS + rs * CV + cvi];
+                out[q * C + c] = s;
+            }
         }
         __syncthreads();
     } else {

@@ -381,8 +381,8 @@ __global__ __launch_bounds__(64) void nf_sum_partials_kernel(const double* __res
     if (lane == 0) out[c] = (float)s;
 }
 
-struct NfGnBwdLoaderA {         // pass A: q0 = dout, q1 = dout * w,  w = (x * bsc + bsh - mean_g) * rstd_g
-    const float* dout; const float* x; const float* bsc; const float* bsh; const float* mean; const float* rstd; int cpg;
+struct NfGnBwdLoaderA {         // pass A: q0 = dout, q1 = dout * w,  w = (x * bsc + bsh - mean_g) * rstd_g   (mean / rstd expanded per CHANNEL in LDS)
+    const float* dout; const float* x; const float* bsc; const float* bsh; const float* mean; const float* rstd;
     template <int VEC>
     __device__ __forceinline__ void load(size_t idx, int c, float (&q)[2][VEC]) const {
         float xv[VEC];
@@ -393,12 +393,12 @@ struct NfGnBwdLoaderA {         // pass A: q0 = dout, q1 = dout * w,  w = (x * b
             xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w;
         } else { q[0][0] = dout[idx]; xv[0] = x[idx]; }
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) { const int g = (c + i) / cpg; q[1][i] = q[0][i] * ((xv[i] * bsc[c + i] + bsh[c + i] - mean[g]) * rstd[g]); }
+        for (int i = 0; i < VEC; ++i) q[1][i] = q[0][i] * ((xv[i] * bsc[c + i] + bsh[c + i] - mean[c + i]) * rstd[c + i]);
     }
 };
 
 struct NfGnBwdLoaderB {         // pass B: dv = ca * dout - cb - w * cd  (stored to dv_out);  q0 = dv, q1 = dv * u,  u = (x - bn_mean) * bn_rstd
-    const float* dout; const float* x; float* dv_out; const float* bsc; const float* bsh; const float* mean; const float* rstd; int cpg;
+    const float* dout; const float* x; float* dv_out; const float* bsc; const float* bsh; const float* mean; const float* rstd;
     const float* ca; const float* cb; const float* cd; const float* bmean; const float* brstd;
     template <int VEC>
     __device__ __forceinline__ void load(size_t idx, int c, float (&q)[2][VEC]) const {
@@ -411,8 +411,7 @@ struct NfGnBwdLoaderB {         // pass B: dv = ca * dout - cb - w * cd  (stored
         } else { dv[0] = dout[idx]; xv[0] = x[idx]; }
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-            const int g = (c + i) / cpg;
-            const float w = (xv[i] * bsc[c + i] + bsh[c + i] - mean[g]) * rstd[g];
+            const float w = (xv[i] * bsc[c + i] + bsh[c + i] - mean[c + i]) * rstd[c + i];
             dv[i] = ca[c + i] * dv[i] - cb[c + i] - w * cd[c + i];
             q[0][i] = dv[i];
             q[1][i] = dv[i] * ((xv[i] - bmean[c + i]) * brstd[c + i]);
@@ -434,7 +433,8 @@ __global__ __launch_bounds__(DCV_CR_THREADS) void nf_gn_bn_bwd_kernel(const floa
     double* chan = reinterpret_cast<double*>(smem);                      // [4][C]
     float* bsc = reinterpret_cast<float*>(chan + 4 * (size_t)C);         // [C] each:
     float* bsh = bsc + C; float* bm = bsh + C; float* br = bm + C; float* ca = br + C; float* cb = ca + C; float* cd = cb + C;
-    float* scratch = cd + C;                                             // [2 * 256 * VEC]
+    float* gmc = cd + C; float* grc = gmc + C;                           // this sample's GroupNorm mean / rstd expanded per channel
+    float* scratch = grc + C;                                            // [2 * 256 * VEC]
     const int n = blockIdx.x;
     const size_t base = (size_t)n * HW * C;
     const int cpg = C / G;
@@ -444,9 +444,10 @@ __global__ __launch_bounds__(DCV_CR_THREADS) void nf_gn_bn_bwd_kernel(const floa
         const float g = bn_gamma ? bn_gamma[c] : 1.f, b = bn_beta ? bn_beta[c] : 0.f;
         const float sc = g * bn_rstd[c];
         bsc[c] = sc; bsh[c] = b - bn_mean[c] * sc; bm[c] = bn_mean[c]; br[c] = bn_rstd[c];
+        gmc[c] = mean[c / cpg]; grc[c] = rstd[c / cpg];
     }
     __syncthreads();
-    NfGnBwdLoaderA la{dout + base, x + base, bsc, bsh, mean, rstd, cpg};
+    NfGnBwdLoaderA la{dout + base, x + base, bsc, bsh, gmc, grc};
     dcv_colreduce_block<2, VEC>(la, 0, (size_t)HW, C, scratch, chan);
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const int g = c / cpg;
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(DCV_CR_THREADS) void nf_gn_bn_bwd_kernel(const floa
         cd[c] = (float)(B / m) * rstd[g];
     }
     __syncthreads();
-    NfGnBwdLoaderB lb{dout + base, x + base, dv_out + base, bsc, bsh, mean, rstd, cpg, ca, cb, cd, bm, br};
+    NfGnBwdLoaderB lb{dout + base, x + base, dv_out + base, bsc, bsh, gmc, grc, ca, cb, cd, bm, br};
     dcv_colreduce_block<2, VEC>(lb, 0, (size_t)HW, C, scratch, chan + 2 * (size_t)C);
     for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) partial[(size_t)n * 4 * C + i] = chan[i];
 }
@@ -669,7 +670,7 @@ int dcv_bn_gn_act_bwd(const float* dout, const float* x, float* dz, int n, int h
     const int vec = (C % 4 == 0) ? 4 : 1;
     const float* dv = dout;
     if (G > 0) {
-        const size_t smem = 4 * (size_t)C * sizeof(double) + (size_t)7 * C * sizeof(float) + (size_t)2 * DCV_CR_THREADS * vec * sizeof(float);
+        const size_t smem = 4 * (size_t)C * sizeof(double) + (size_t)9 * C * sizeof(float) + (size_t)2 * DCV_CR_THREADS * vec * sizeof(float);
         if (smem > 64 * 1024) return DCV_ERR_UNSUPPORTED;
         if (vec == 4) hipLaunchKernelGGL((nf_gn_bn_bwd_kernel<4>), dim3(n), dim3(DCV_CR_THREADS), smem, st, dout, x, dz, hw, C, G, bn_gamma, bn_beta, bn_save_mean, bn_save_rstd,
                                          gn_gamma, gn_save_mean, gn_save_rstd, partial);
