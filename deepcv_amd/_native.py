@@ -62,6 +62,7 @@ _SIGNATURES = {
     'dcv_conv2d_fwd': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _P, _c_size_t, _P]),
     'dcv_conv2d_dgrad': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _c_size_t, _P]),
     'dcv_conv2d_wgrad': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _P, _c_size_t, _P]),
+    'dcv_conv2d_wgrad_fuses_bias': (_c_int, [ctypes.POINTER(Conv2dDesc)]),
     'dcv_act_fwd': (_c_int, [_P, _P, _c_size_t, _c_int, _c_float, _P]),
     'dcv_act_bwd_workspace_bytes': (_c_size_t, [_c_size_t, _c_int]),
     'dcv_act_bwd': (_c_int, [_P, _P, _P, _c_size_t, _c_int, _c_int, _c_float, _P, _P, _c_size_t, _P]),

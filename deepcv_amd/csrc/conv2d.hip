@@ -55,16 +55,22 @@ int dcv_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, 
     return dcv_direct_conv2d_dgrad(d, dy, w, dx, ws, ws_bytes, dcv_stream(stream));
 }
 
+int dcv_conv2d_wgrad_fuses_bias(const dcv_conv2d_desc* d) {
+    if (!desc_ok(d) || d->groups != 1 || dcv_mfma_conv2d_supported(d, 2)) return 0;
+    return dcv_direct_conv2d_wgrad_fuses_bias(d) ? 1 : 0;
+}
+
 int dcv_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, void* stream) {
     DCV_CHECK_ARG(desc_ok(d) && x && dy && dw);
     if (d->groups != 1) return DCV_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < dcv_conv2d_wgrad_workspace_bytes(d)) return DCV_ERR_WORKSPACE;
     const bool mfma = dcv_mfma_conv2d_supported(d, 2);
     const size_t main_ws = dcv_align_up(mfma ? dcv_mfma_conv2d_ws(d, 2) : dcv_direct_conv2d_wgrad_ws(d), 256);
+    bool db_done = false;
     int rc = mfma ? dcv_mfma_conv2d_wgrad(d, x, dy, dw, ws, main_ws, dcv_stream(stream))
-                  : dcv_direct_conv2d_wgrad(d, x, dy, dw, ws, main_ws, dcv_stream(stream));
+                  : dcv_direct_conv2d_wgrad(d, x, dy, dw, db, &db_done, ws, main_ws, dcv_stream(stream));
     if (rc != DCV_OK) return rc;
-    if (db) rc = dcv_channel_sum(dy, db, (size_t)d->n * d->ho * d->wo, d->cout, reinterpret_cast<char*>(ws) + main_ws, db_ws(d), stream);
+    if (db && !db_done) rc = dcv_channel_sum(dy, db, (size_t)d->n * d->ho * d->wo, d->cout, reinterpret_cast<char*>(ws) + main_ws, db_ws(d), stream);
     return rc;
 }
 

@@ -443,20 +443,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_partial_kernel(WgradArgs a, co
 
 // dw[i] = sum over chunks of partial[chunk][i]: block = 32 consecutive weights x 32 chunk lanes (coalesced 128-B rows, chunks/32 serial loads per
 // thread), merged through LDS in a fixed order
-__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int chunks, size_t wtotal) {
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int chunks, size_t wtotal,
+                                                             float* __restrict__ db = nullptr, size_t slab = 0) {
+    // slabs hold `wtotal` weight-gradient entries followed (when db != nullptr) by the Cout bias-gradient entries; slab = entries per slab
     __shared__ float red[32][33];
     const int wl = threadIdx.x & 31, cl = threadIdx.x >> 5;
+    if (slab == 0) slab = wtotal;
     const size_t wi = (size_t)blockIdx.x * 32 + wl;
     float s = 0.f;
-    if (wi < wtotal)
-        for (int c = cl; c < chunks; c += 32) s += partial[(size_t)c * wtotal + wi];
+    if (wi < slab)
+        for (int c = cl; c < chunks; c += 32) s += partial[(size_t)c * slab + wi];
     red[cl][wl] = s;
     __syncthreads();
-    if (cl == 0 && wi < wtotal) {
+    if (cl == 0 && wi < slab) {
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 32; ++k) t += red[k][wl];
-        dw[wi] = t;
+        if (wi < wtotal) dw[wi] = t; else db[wi - wtotal] = t;
     }
 }
 
@@ -613,7 +616,8 @@ struct WgSlideArgs {
     int red_rs;                    // row stride of the merge buffer
     int tiles_per_img, total_tiles;
     int nt;                        // threads per block
-    size_t wtotal;
+    int fuse_db;                   // also accumulate the bias gradient (column sums of dy) into slab entries [wtotal, wtotal + Cout)
+    size_t wtotal, slab;           // weight-gradient entries, entries per partial slab (wtotal [+ Cout])
 };
 
 __device__ __forceinline__ void dcv_divmod(int j, int d, int shift, int& q, int& r) {
@@ -640,6 +644,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_slide_kernel(WgSlideArgs a, co
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int v = 0; v < VEC; ++v) acc[s][j][v] = 0.f;
+    float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool db_owner = a.fuse_db && ul < a.cogb;               // the (r = 0, first input-channel vector) unit of each output-channel group
 
     for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
         const int n = tile / a.tiles_per_img, ho0 = (tile % a.tiles_per_img) * a.TH;
@@ -761,6 +767,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_slide_kernel(WgSlideArgs a, co
                 }
 #pragma unroll
                 for (int p = 0; p < SEG; ++p) g[p] = *reinterpret_cast<const float4*>(gp + p * tcob);
+                if (db_owner) {
+#pragma unroll
+                    for (int p = 0; p < SEG; ++p) { dbacc.x += g[p].x; dbacc.y += g[p].y; dbacc.z += g[p].z; dbacc.w += g[p].w; }
+                }
 #pragma unroll
                 for (int p = 0; p < SEG; ++p)
 #pragma unroll
@@ -780,8 +790,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_slide_kernel(WgSlideArgs a, co
     // ---- merge the sub-streams in a fixed order, one filter column s at a time, through red[4 * VEC][red_rs]: thread (sub, unit) sums element
     //      e = sub, sub + nsub, ... of ITS unit over all sub-streams (no index arithmetic: the unit's coordinates are already in registers)
     float* red = reinterpret_cast<float*>(smem);
-    float* dst = partial + (size_t)blockIdx.x * a.wtotal;
+    float* dst = partial + (size_t)blockIdx.x * a.slab;
     constexpr int E = 4 * VEC;
+    if (a.fuse_db) {                                                  // bias gradient: same ordered merge, 4 entries per owner unit
+        __syncthreads();
+        if (active) { red[0 * a.red_rs + t] = dbacc.x; red[1 * a.red_rs + t] = dbacc.y; red[2 * a.red_rs + t] = dbacc.z; red[3 * a.red_rs + t] = dbacc.w; }
+        __syncthreads();
+        if (active && ul < a.cogb) {
+            for (int e = sub; e < 4; e += a.nsub) {
+                const float* q = red + e * a.red_rs + ul;
+                float sum = 0.f;
+#pragma unroll 8
+                for (int k = 0; k < a.nsub; ++k) { sum += *q; q += a.units; }
+                const int co = co_base + 4 * cog + e;
+                if (co < a.Cout) dst[a.wtotal + co] = sum;
+            }
+        }
+    }
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         __syncthreads();
@@ -1035,7 +1060,7 @@ bool wgrad_tiled_plan(const dcv_conv2d_desc* d, WgTiledArgs* a, int* tco, int* v
 }
 
 // Plans the sliding-window weight gradient; false when the layer does not fit it (strided / dilated columns, unusual filter width, too many units).
-bool wgrad_slide_plan(const dcv_conv2d_desc* d, WgSlideArgs* a, int* vec, int* seg, int* blocks, int* ygrid, size_t* smem) {
+bool wgrad_slide_plan(const dcv_conv2d_desc* d, bool fuse_db, WgSlideArgs* a, int* vec, int* seg, int* blocks, int* ygrid, size_t* smem) {
     static int enabled = -1;
     if (enabled < 0) { const char* e = getenv("DCV_WGRAD_SLIDE"); enabled = e ? atoi(e) : 1; }
     if (!enabled) return false;
@@ -1083,8 +1108,10 @@ bool wgrad_slide_plan(const dcv_conv2d_desc* d, WgSlideArgs* a, int* vec, int* s
     a->tiles_per_img = (d->ho + th - 1) / th;
     a->total_tiles = d->n * a->tiles_per_img;
     a->wtotal = (size_t)d->cout * d->cin * d->r * d->s;
+    a->fuse_db = fuse_db ? 1 : 0;
+    a->slab = a->wtotal + (fuse_db ? (size_t)d->cout : 0);
     int nb = a->total_tiles < target_blocks ? a->total_tiles : target_blocks;
-    const size_t max_by_bytes = ((size_t)64 << 20) / (a->wtotal * sizeof(float));
+    const size_t max_by_bytes = ((size_t)64 << 20) / (a->slab * sizeof(float));
     if ((size_t)nb > max_by_bytes) nb = (int)(max_by_bytes > 0 ? max_by_bytes : 1);
     *vec = v; *seg = sg; *blocks = nb; *ygrid = (cogs + cogb - 1) / cogb; *smem = bytes;
     return true;
@@ -1114,24 +1141,32 @@ void launch_wgrad_tiled(int tco, dim3 grid, size_t smem, hipStream_t st, const W
 size_t dcv_direct_conv2d_wgrad_ws(const dcv_conv2d_desc* d) {
     WgTiledArgs ta{}; int tco, tvec, blocks; size_t smem;
     { WgSlideArgs sa{}; int sv, sseg, sb, sy; size_t ssm;
-      if (wgrad_slide_plan(d, &sa, &sv, &sseg, &sb, &sy, &ssm)) return dcv_align_up((size_t)sb * sa.wtotal * sizeof(float), 256); }
+      if (wgrad_slide_plan(d, true, &sa, &sv, &sseg, &sb, &sy, &ssm)) return dcv_align_up((size_t)sb * sa.slab * sizeof(float), 256); }
     if (wgrad_tiled_plan(d, &ta, &tco, &tvec, &blocks, &smem)) return dcv_align_up((size_t)blocks * ta.wtotal * sizeof(float), 256);
     WgradArgs a{}; int chunks, ub, vec;
     wgrad_plan(d, &a, &chunks, &ub, &vec);
     return dcv_align_up((size_t)chunks * a.wtotal * sizeof(float), 256);
 }
 
-int dcv_direct_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
+bool dcv_direct_conv2d_wgrad_fuses_bias(const dcv_conv2d_desc* d) {
+    WgSlideArgs sa{}; int sv, sseg, sb, sy; size_t ssm;
+    return wgrad_slide_plan(d, true, &sa, &sv, &sseg, &sb, &sy, &ssm);
+}
+
+// `db` (nullable): bias gradient; *db_done tells the caller whether this back-end produced it
+int dcv_direct_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, float* db, bool* db_done, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (db_done) *db_done = false;
     float* partial = reinterpret_cast<float*>(ws);
     WgTiledArgs ta{}; int tco, tvec, blocks; size_t smem;
     {
         WgSlideArgs sa{}; int sv, sseg, sb, sy; size_t ssm;
-        if (wgrad_slide_plan(d, &sa, &sv, &sseg, &sb, &sy, &ssm) && (sv == 1 || (reinterpret_cast<uintptr_t>(x) & 15) == 0) && (reinterpret_cast<uintptr_t>(dy) & 15) == 0) {
-            if (!ws || ws_bytes < (size_t)sb * sa.wtotal * sizeof(float)) return DCV_ERR_WORKSPACE;
+        if (wgrad_slide_plan(d, db != nullptr, &sa, &sv, &sseg, &sb, &sy, &ssm) && (sv == 1 || (reinterpret_cast<uintptr_t>(x) & 15) == 0) && (reinterpret_cast<uintptr_t>(dy) & 15) == 0) {
+            if (!ws || ws_bytes < (size_t)sb * sa.slab * sizeof(float)) return DCV_ERR_WORKSPACE;
             dim3 grid((unsigned)sb, (unsigned)sy);
             if (sv == 4) launch_wgrad_slide<4>(d->s, grid, ssm, st, sa, x, dy, partial);
             else launch_wgrad_slide<1>(d->s, grid, ssm, st, sa, x, dy, partial);
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)dcv_ceil_div(sa.wtotal, 32)), dim3(1024), 0, st, partial, dw, sb, sa.wtotal);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)dcv_ceil_div(sa.slab, 32)), dim3(1024), 0, st, partial, dw, sb, sa.wtotal, db, sa.slab);
+            if (db_done) *db_done = db != nullptr;
             return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
         }
     }

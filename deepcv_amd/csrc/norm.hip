@@ -494,6 +494,16 @@ __global__ __launch_bounds__(DCV_CR_THREADS) void nf_bn_apply_act_bwd_kernel(NfA
     dcv_colreduce_block<1, VEC>(ld, r0 < rows ? r0 : rows, r1, C, scratch, partial + (size_t)blockIdx.x * C);
 }
 
+// backward (3) without bias gradient (the convolution's weight-gradient kernel sums dz itself): plain streaming kernel
+template <int VEC>
+__global__ __launch_bounds__(256) void nf_bn_apply_act_bwd_ew_kernel(NfApplyActLoader ld, size_t numel_v, int C) {
+    const int CV = C / VEC;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel_v; i += (size_t)gridDim.x * blockDim.x) {
+        float q[1][VEC];
+        ld.template load<VEC>(i * VEC, (int)(i % CV) * VEC, q);
+    }
+}
+
 inline size_t bn_ws_partial_bytes(size_t rows, int C) { return dcv_align_up((size_t)dcv_colreduce_blocks(rows, C) * 2 * C * sizeof(double), 256); }
 
 }  // namespace
@@ -686,9 +696,15 @@ int dcv_bn_gn_act_bwd(const float* dout, const float* x, float* dz, int n, int h
         hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((unsigned)C), dim3(64), 0, st, partial, (int)nb, rows, C, bn_gamma, bn_save_rstd, d_bn_gamma, d_bn_beta, coef);
     }
     NfApplyActLoader ld{dv, x, dz, bn_save_mean, bn_save_rstd, coef, C, act, slope};
-    if (vec == 4) hipLaunchKernelGGL((nf_bn_apply_act_bwd_kernel<4>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
-    else hipLaunchKernelGGL((nf_bn_apply_act_bwd_kernel<1>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
-    if (d_bias) hipLaunchKernelGGL(nf_sum_partials_kernel, dim3((unsigned)C), dim3(64), 0, st, partial, (int)nb, C, d_bias);
+    if (d_bias) {
+        if (vec == 4) hipLaunchKernelGGL((nf_bn_apply_act_bwd_kernel<4>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
+        else hipLaunchKernelGGL((nf_bn_apply_act_bwd_kernel<1>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
+        hipLaunchKernelGGL(nf_sum_partials_kernel, dim3((unsigned)C), dim3(64), 0, st, partial, (int)nb, C, d_bias);
+    } else {
+        const size_t nv = rows * (size_t)C / vec;
+        if (vec == 4) hipLaunchKernelGGL((nf_bn_apply_act_bwd_ew_kernel<4>), dim3(dcv_stream_grid(nv, 256)), dim3(256), 0, st, ld, nv, C);
+        else hipLaunchKernelGGL((nf_bn_apply_act_bwd_ew_kernel<1>), dim3(dcv_stream_grid(nv, 256)), dim3(256), 0, st, ld, nv, C);
+    }
     DCV_RETURN_LAUNCH();
 }
 

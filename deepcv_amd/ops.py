@@ -330,6 +330,7 @@ class _ConvNormLayerFn(torch.autograd.Function):
         new = lambda: torch.empty(c, dtype=torch.float32, device=dev)
         need = ctx.needs_input_grad
         db = new() if (bias is not None and need[2]) else None
+        db_from_wgrad = db is not None and need[1] and bool(lib.dcv_conv2d_wgrad_fuses_bias(d))   # summed from the dz tiles the wgrad kernel stages anyway
         d_bn_w = new() if (bn_w is not None and need[3]) else None
         d_bn_b = new() if (bn_b is not None and need[4]) else None
         d_gn_w = new() if (gn_w is not None and need[8]) else None
@@ -338,7 +339,7 @@ class _ConvNormLayerFn(torch.autograd.Function):
         ws = _ws(lib.dcv_norm_chain_workspace_bytes(d.n, hw, c), dev)
         nat.check(lib.dcv_bn_gn_act_bwd(dout.data_ptr(), y.data_ptr(), dz.data_ptr(), d.n, hw, c, nat.ptr(bn_w), nat.ptr(bn_b), bn_mean.data_ptr(), bn_rstd.data_ptr(),
                                         groups, nat.ptr(gn_w), nat.ptr(gn_mean), nat.ptr(gn_rstd), act, slope,
-                                        nat.ptr(d_bn_w), nat.ptr(d_bn_b), nat.ptr(d_gn_w), nat.ptr(d_gn_b), nat.ptr(db),
+                                        nat.ptr(d_bn_w), nat.ptr(d_bn_b), nat.ptr(d_gn_w), nat.ptr(d_gn_b), None if db_from_wgrad else nat.ptr(db),
                                         ws.data_ptr(), ws.numel(), st), 'dcv_bn_gn_act_bwd')
         dx = dw = None
         if need[0]:
@@ -350,7 +351,8 @@ class _ConvNormLayerFn(torch.autograd.Function):
         if need[1]:
             dw = torch.empty_like(weight)
             ws = _ws(lib.dcv_conv2d_wgrad_workspace_bytes(d), dev)
-            nat.check(lib.dcv_conv2d_wgrad(d, x.data_ptr(), dz.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), ws.numel(), st), 'dcv_conv2d_wgrad')
+            nat.check(lib.dcv_conv2d_wgrad(d, x.data_ptr(), dz.data_ptr(), dw.data_ptr(), nat.ptr(db) if db_from_wgrad else None, ws.data_ptr(), ws.numel(), st),
+                      'dcv_conv2d_wgrad')
         return dx, dw, db, d_bn_w, d_bn_b, None, None, None, d_gn_w, d_gn_b, None
 
 

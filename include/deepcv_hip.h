@@ -82,6 +82,9 @@ int dcv_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, 
 /* dw[Cout,Cin,R,S] = x (*) dy ; db[Cout] = sum dy (db may be NULL).  x honours d->x_layout. */
 int dcv_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, float* db,
                      void* ws, size_t ws_bytes, void* stream);
+/* 1 when dcv_conv2d_wgrad produces db from the dy tiles it already stages (no extra pass over dy, no extra launch): callers which can get the bias
+ * gradient elsewhere too (dcv_bn_gn_act_bwd, dcv_act_bwd) use this to pick the cheaper source. */
+int dcv_conv2d_wgrad_fuses_bias(const dcv_conv2d_desc* d);
 
 /* ---------------------------------------------------------------------------------------------------
  * K4  elementwise activation (standalone; conv/linear fuse it into their epilogue)
