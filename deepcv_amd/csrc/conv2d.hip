@@ -18,6 +18,17 @@ inline bool desc_ok(const dcv_conv2d_desc* d) {
     return true;
 }
 
+// ONE launch re-laying out up to DCV_PREP_MAX filters (blockIdx.y = filter)
+__global__ __launch_bounds__(256) void prep_multi_kernel(dcv_prep_list l) {
+    const dcv_prep_entry& e = l.e[blockIdx.y];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < e.total; i += gridDim.x * blockDim.x) e.dst[i] = dcv_prep_element(e, i);
+}
+
+inline bool prep_entry(const dcv_conv2d_desc* d, int op, dcv_prep_entry* e) {
+    if (op == 1 && d->x_layout != DCV_LAYOUT_NHWC) return false;
+    return dcv_mfma_conv2d_supported(d, op) ? dcv_mfma_conv2d_prep_entry(d, op, e) : dcv_direct_conv2d_prep_entry(d, op, e);
+}
+
 inline size_t db_ws(const dcv_conv2d_desc* d) { return dcv_act_bwd_workspace_bytes((size_t)d->n * d->ho * d->wo, d->cout); }
 
 }  // namespace
@@ -53,6 +64,57 @@ int dcv_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, 
     if (d->x_layout != DCV_LAYOUT_NHWC) return DCV_ERR_UNSUPPORTED;   // dx is always produced NHWC
     if (dcv_mfma_conv2d_supported(d, 1)) return dcv_mfma_conv2d_dgrad(d, dy, w, dx, ws, ws_bytes, dcv_stream(stream));
     return dcv_direct_conv2d_dgrad(d, dy, w, dx, ws, ws_bytes, dcv_stream(stream));
+}
+
+size_t dcv_conv2d_filter_bytes(const dcv_conv2d_desc* d, int op) {
+    if (!desc_ok(d) || d->groups != 1 || (op != 0 && op != 1)) return 0;
+    dcv_prep_entry e{};
+    if (!prep_entry(d, op, &e)) return 0;
+    return op == 0 ? dcv_conv2d_fwd_workspace_bytes(d) : dcv_conv2d_dgrad_workspace_bytes(d);
+}
+
+int dcv_conv2d_prepare_filters(int count, const dcv_conv2d_desc* const* descs, const int* ops, const float* const* w, void* const* filters, void* stream) {
+    DCV_CHECK_ARG(count >= 0 && (count == 0 || (descs && ops && w && filters)));
+    dcv_prep_list l{};
+    int max_total = 0;
+    auto flush = [&]() {
+        if (l.count == 0) return;
+        int gx = (max_total + 255) / 256; if (gx > 64) gx = 64; if (gx < 1) gx = 1;
+        hipLaunchKernelGGL(prep_multi_kernel, dim3((unsigned)gx, (unsigned)l.count), dim3(256), 0, dcv_stream(stream), l);
+        l.count = 0; max_total = 0;
+    };
+    for (int k = 0; k < count; ++k) {
+        DCV_CHECK_ARG(desc_ok(descs[k]) && w[k] && (ops[k] == 0 || ops[k] == 1));
+        dcv_prep_entry e{};
+        if (!prep_entry(descs[k], ops[k], &e)) continue;          // this (layer, op) reads the OIHW filter directly
+        DCV_CHECK_ARG(filters[k] != nullptr);
+        e.w = w[k]; e.dst = reinterpret_cast<float*>(filters[k]);
+        l.e[l.count++] = e;
+        if (e.total > max_total) max_total = e.total;
+        if (l.count == DCV_PREP_MAX) flush();
+    }
+    flush();
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_conv2d_fwd_prepared(const dcv_conv2d_desc* d, const float* x, const float* w, const void* filter, const float* bias, float* y, void* stream) {
+    DCV_CHECK_ARG(desc_ok(d) && x && w && y);
+    if (d->groups != 1) return DCV_ERR_UNSUPPORTED;
+    const size_t fb = dcv_conv2d_filter_bytes(d, 0);
+    if (fb == 0) return dcv_direct_conv2d_fwd(d, x, w, bias, y, nullptr, 0, dcv_stream(stream));
+    DCV_CHECK_ARG(filter != nullptr);
+    if (dcv_mfma_conv2d_supported(d, 0)) return dcv_mfma_conv2d_fwd(d, x, w, bias, y, const_cast<void*>(filter), fb, dcv_stream(stream), true);
+    return dcv_direct_conv2d_fwd(d, x, w, bias, y, const_cast<void*>(filter), fb, dcv_stream(stream), true);
+}
+
+int dcv_conv2d_dgrad_prepared(const dcv_conv2d_desc* d, const float* dy, const float* w, const void* filter, float* dx, void* stream) {
+    DCV_CHECK_ARG(desc_ok(d) && dy && w && dx);
+    if (d->groups != 1 || d->x_layout != DCV_LAYOUT_NHWC) return DCV_ERR_UNSUPPORTED;
+    const size_t fb = dcv_conv2d_filter_bytes(d, 1);
+    if (fb == 0) return dcv_direct_conv2d_dgrad(d, dy, w, dx, nullptr, 0, dcv_stream(stream));
+    DCV_CHECK_ARG(filter != nullptr);
+    if (dcv_mfma_conv2d_supported(d, 1)) return dcv_mfma_conv2d_dgrad(d, dy, w, dx, const_cast<void*>(filter), fb, dcv_stream(stream), true);
+    return dcv_direct_conv2d_dgrad(d, dy, w, dx, const_cast<void*>(filter), fb, dcv_stream(stream), true);
 }
 
 int dcv_conv2d_wgrad_fuses_bias(const dcv_conv2d_desc* d) {

@@ -14,7 +14,7 @@
 //
 // Algorithmic bytes per launch (roofline "hbm"): 4 B * (N*H*W*Cin + Cout*Cin*R*S + N*Ho*Wo*Cout)   (SURVEY.md §8d).
 // Replaces torch.nn.Conv2d forward (reference src/deepcv/meta/submodule_creators.py:251) and its autograd (ignite_training.py:253).
-#include "common.h"
+#include "conv2d_internal.h"
 #include <stdlib.h>
 
 namespace {
@@ -929,7 +929,7 @@ bool tile_plan(const DirectArgs& a, TileArgs* t, int* tco_out, int* ppt_out) {
     return true;
 }
 
-int run_direct(DirectArgs a, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st) {
+int run_direct(DirectArgs a, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st, bool prepared) {
     TileArgs t{}; int tco, ppt;
     if (tile_plan(a, &t, &tco, &ppt)) {
         const int tiles = (int)dcv_ceil_div(a.Cout, tco);
@@ -938,7 +938,7 @@ int run_direct(DirectArgs a, const float* x, const float* w, const float* bias, 
         float* wt = reinterpret_cast<float*>(ws);
         const int total = tiles * a.R * a.S * t.cin_pad * tco;
         const int pblocks = (total + 255) / 256 > 128 ? 128 : (total + 255) / 256;
-        hipLaunchKernelGGL(prep_weights_kernel, dim3((unsigned)pblocks), dim3(256), 0, st, a, w, wt, tco, tiles, t.cin_pad, 1);
+        if (!prepared) hipLaunchKernelGGL(prep_weights_kernel, dim3((unsigned)pblocks), dim3(256), 0, st, a, w, wt, tco, tiles, t.cin_pad, 1);
         dim3 grid((unsigned)dcv_ceil_div(t.total_subtiles, t.nsub), (unsigned)tiles);
         const size_t smem = (size_t)t.nsub * t.XH * t.XW * t.CC * sizeof(float);
 #define DCV_TILE_LAUNCH(TCO_, ST_, PPT_) hipLaunchKernelGGL((conv_tile_kernel<TCO_, ST_, PPT_>), grid, dim3(256), smem, st, t, x, wt, bias, y)
@@ -1001,15 +1001,15 @@ inline void wgrad_plan(const dcv_conv2d_desc* d, WgradArgs* a, int* chunks, int*
 size_t dcv_direct_conv2d_fwd_ws(const dcv_conv2d_desc* d) { return dcv_align_up((size_t)d->r * d->s * dcv_align_up(d->cin, 4) * dcv_align_up(d->cout, 16) * sizeof(float), 256); }
 size_t dcv_direct_conv2d_dgrad_ws(const dcv_conv2d_desc* d) { return dcv_align_up((size_t)d->r * d->s * dcv_align_up(d->cout, 4) * dcv_align_up(d->cin, 16) * sizeof(float), 256); }
 
-int dcv_direct_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st) {
+namespace {
+inline DirectArgs fwd_args(const dcv_conv2d_desc* d) {
     DirectArgs a{};
     a.N = d->n; a.Hin = d->h; a.Win = d->w; a.Cin = d->cin; a.Hout = d->ho; a.Wout = d->wo; a.Cout = d->cout;
     a.R = d->r; a.S = d->s; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
     a.w_cout = d->cout; a.w_cin = d->cin; a.dgrad = 0; a.act = d->act; a.slope = d->act_slope; a.in_nchw = d->x_layout == DCV_LAYOUT_NCHW;
-    return run_direct(a, x, w, bias, y, ws, ws_bytes, st);
+    return a;
 }
-
-int dcv_direct_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t st) {
+inline DirectArgs dgrad_args(const dcv_conv2d_desc* d) {
     DirectArgs a{};
     a.N = d->n; a.Hin = d->ho; a.Win = d->wo; a.Cin = d->cout; a.Hout = d->h; a.Wout = d->w; a.Cout = d->cin;
     a.R = d->r; a.S = d->s; a.dh = d->dil_h; a.dw = d->dil_w;
@@ -1022,7 +1022,26 @@ int dcv_direct_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const flo
         a.dgrad = 2;
         a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w;
     }
-    return run_direct(a, dy, w, nullptr, dx, ws, ws_bytes, st);
+    return a;
+}
+}  // namespace
+
+int dcv_direct_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st, bool prepared) {
+    return run_direct(fwd_args(d), x, w, bias, y, ws, ws_bytes, st, prepared);
+}
+
+int dcv_direct_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t st, bool prepared) {
+    return run_direct(dgrad_args(d), dy, w, nullptr, dx, ws, ws_bytes, st, prepared);
+}
+
+bool dcv_direct_conv2d_prep_entry(const dcv_conv2d_desc* d, int op, dcv_prep_entry* e) {
+    const DirectArgs a = op == 0 ? fwd_args(d) : dgrad_args(d);
+    TileArgs t{}; int tco, ppt;
+    if (!tile_plan(a, &t, &tco, &ppt)) return false;              // generic kernel: stages the OIHW filter itself
+    e->kind = 0; e->kcout = a.Cout; e->kcin = a.Cin; e->R = a.R; e->S = a.S; e->w_cin = a.w_cin; e->dgrad = a.dgrad ? 1 : 0;
+    e->tco = tco; e->tiles = (int)dcv_ceil_div(a.Cout, tco); e->cin_pad = t.cin_pad;
+    e->total = e->tiles * a.R * a.S * t.cin_pad * tco;
+    return true;
 }
 
 namespace {

@@ -5,8 +5,9 @@
 // direct (register-blocked, LDS-resident filter) back-end: any shape, tuned for the small-channel stock layers
 size_t dcv_direct_conv2d_fwd_ws(const dcv_conv2d_desc* d);
 size_t dcv_direct_conv2d_dgrad_ws(const dcv_conv2d_desc* d);
-int dcv_direct_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st);
-int dcv_direct_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t st);
+// `prepared`: ws already holds the prepared filter of this (d, op) (dcv_conv2d_prepare_filters); otherwise it is scratch and the filter is prepared first
+int dcv_direct_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st, bool prepared = false);
+int dcv_direct_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t st, bool prepared = false);
 size_t dcv_direct_conv2d_wgrad_ws(const dcv_conv2d_desc* d);
 bool dcv_direct_conv2d_wgrad_fuses_bias(const dcv_conv2d_desc* d);
 int dcv_direct_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, float* db, bool* db_done, void* ws, size_t ws_bytes, hipStream_t st);
@@ -14,9 +15,44 @@ int dcv_direct_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const floa
 // MFMA implicit-GEMM back-end (fp32 inputs, v_mfma_f32_16x16x4_f32): wide layers (conv2d_mfma.hip)
 bool dcv_mfma_conv2d_supported(const dcv_conv2d_desc* d, int op /*0 fwd, 1 dgrad, 2 wgrad*/);
 size_t dcv_mfma_conv2d_ws(const dcv_conv2d_desc* d, int op);
-int dcv_mfma_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st);
-int dcv_mfma_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t st);
+int dcv_mfma_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st, bool prepared = false);
+int dcv_mfma_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t st, bool prepared = false);
 int dcv_mfma_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
+
+// Prepared filters: one entry describes the re-layout of one OIHW filter for the kernel which will consume it (see dcv_conv2d_prepare_filters).
+struct dcv_prep_entry {
+    const float* w; float* dst;
+    int kind;                      // 0: direct tiled kernel  wt[cout tile][R][S][cin_pad][tco]      1: MFMA kernel  wb[cout][tap][cin]
+    int kcout, kcin;               // kernel-view channel counts (data gradient: kcout = original Cin, kcin = original Cout)
+    int R, S, w_cin;               // taps, OIHW row length (original Cin)
+    int dgrad;                     // 0: forward filter, 1: transposed + flipped filter of the stride-1 data gradient
+    int tco, tiles, cin_pad;       // kind 0 only
+    int total;                     // elements of dst
+};
+#define DCV_PREP_MAX 24
+struct dcv_prep_list { int count; dcv_prep_entry e[DCV_PREP_MAX]; };
+
+// value of element i of the prepared filter described by e
+static __device__ __forceinline__ float dcv_prep_element(const dcv_prep_entry& e, int i) {
+    if (e.kind == 0) {
+        const int co = i % e.tco; int t = i / e.tco;
+        const int ci = t % e.cin_pad; t /= e.cin_pad;
+        const int s = t % e.S; t /= e.S;
+        const int r = t % e.R; const int tile = t / e.R;
+        const int cog = tile * e.tco + co;
+        if (cog >= e.kcout || ci >= e.kcin) return 0.f;
+        if (!e.dgrad) return e.w[(((size_t)cog * e.w_cin + ci) * e.R + r) * e.S + s];
+        return e.w[(((size_t)ci * e.w_cin + cog) * e.R + (e.R - 1 - r)) * e.S + (e.S - 1 - s)];
+    }
+    const int ci = i % e.kcin; int t = i / e.kcin;
+    const int s = t % e.S; t /= e.S;
+    const int r = t % e.R; const int co = t / e.R;
+    if (!e.dgrad) return e.w[(((size_t)co * e.w_cin + ci) * e.R + r) * e.S + s];
+    return e.w[(((size_t)ci * e.w_cin + co) * e.R + (e.R - 1 - r)) * e.S + (e.S - 1 - s)];
+}
+// false when the kernel serving (d, op) reads the OIHW filter directly (nothing to prepare); op: 0 forward, 1 data gradient
+bool dcv_direct_conv2d_prep_entry(const dcv_conv2d_desc* d, int op, dcv_prep_entry* e);
+bool dcv_mfma_conv2d_prep_entry(const dcv_conv2d_desc* d, int op, dcv_prep_entry* e);
 
 // shared with elementwise.hip
 extern "C" size_t dcv_act_bwd_workspace_bytes(size_t rows, int channels);

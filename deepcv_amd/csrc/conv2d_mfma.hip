@@ -304,12 +304,12 @@ static int run_mfma(const MfmaArgs& a, const float* x, const float* wb, const fl
     return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
 }
 
-int dcv_mfma_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st) {
+int dcv_mfma_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st, bool prepared) {
     if (!ws || ws_bytes < dcv_mfma_conv2d_ws(d, 0)) return DCV_ERR_WORKSPACE;
     if (!aligned16(x) || !aligned16(ws)) return DCV_ERR_INVALID_ARG;
     float* wb = reinterpret_cast<float*>(ws);
     const int total = d->cout * d->cin * d->r * d->s;
-    hipLaunchKernelGGL(mfma_prep_weights_kernel, dim3((unsigned)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256)), dim3(256), 0, st, w, wb, d->cout, d->cin, d->r, d->s, d->cin, 0);
+    if (!prepared) hipLaunchKernelGGL(mfma_prep_weights_kernel, dim3((unsigned)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256)), dim3(256), 0, st, w, wb, d->cout, d->cin, d->r, d->s, d->cin, 0);
     MfmaArgs a{};
     a.N = d->n; a.Hin = d->h; a.Win = d->w; a.Cin = d->cin; a.Hout = d->ho; a.Wout = d->wo; a.Cout = d->cout;
     a.R = d->r; a.S = d->s; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
@@ -317,18 +317,25 @@ int dcv_mfma_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w
     return run_mfma(a, x, wb, bias, y, st);
 }
 
-int dcv_mfma_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t st) {
+int dcv_mfma_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t st, bool prepared) {
     if (!ws || ws_bytes < dcv_mfma_conv2d_ws(d, 1)) return DCV_ERR_WORKSPACE;
     if (!aligned16(dy) || !aligned16(ws)) return DCV_ERR_INVALID_ARG;
     float* wb = reinterpret_cast<float*>(ws);
     const int total = d->cout * d->cin * d->r * d->s;
     // kernel view: reads dy (Cin' = Cout), writes dx (Cout' = Cin), filter flipped + transposed, pad' = dil*(R-1) - pad
-    hipLaunchKernelGGL(mfma_prep_weights_kernel, dim3((unsigned)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256)), dim3(256), 0, st, w, wb, d->cin, d->cout, d->r, d->s, d->cin, 1);
+    if (!prepared) hipLaunchKernelGGL(mfma_prep_weights_kernel, dim3((unsigned)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256)), dim3(256), 0, st, w, wb, d->cin, d->cout, d->r, d->s, d->cin, 1);
     MfmaArgs a{};
     a.N = d->n; a.Hin = d->ho; a.Win = d->wo; a.Cin = d->cout; a.Hout = d->h; a.Wout = d->w; a.Cout = d->cin;
     a.R = d->r; a.S = d->s; a.sh = 1; a.sw = 1; a.ph = d->dil_h * (d->r - 1) - d->pad_h; a.pw = d->dil_w * (d->s - 1) - d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
     a.act = DCV_ACT_NONE; a.slope = 0.f; a.M = (long)d->n * d->h * d->w;
     return run_mfma(a, dy, wb, nullptr, dx, st);
+}
+
+bool dcv_mfma_conv2d_prep_entry(const dcv_conv2d_desc* d, int op, dcv_prep_entry* e) {
+    e->kind = 1; e->R = d->r; e->S = d->s; e->w_cin = d->cin; e->dgrad = op ? 1 : 0; e->tco = e->tiles = e->cin_pad = 0;
+    e->kcout = op ? d->cin : d->cout; e->kcin = op ? d->cout : d->cin;
+    e->total = d->cout * d->cin * d->r * d->s;
+    return true;
 }
 
 int dcv_mfma_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {

@@ -1,0 +1,122 @@
+""" Prepared-filter cache of the convolution layers (C-ABI `dcv_conv2d_filter_bytes / prepare_filters / fwd_prepared / dgrad_prepared`).
+
+The forward / data-gradient kernels read the OIHW filter re-laid out for the kernel serving the layer.  The reference re-reads `Conv2d.weight` on every
+forward (`src/deepcv/meta/submodule_creators.py:251`); doing the re-layout on every call costs one ~4.5 us launch per layer and direction on the stock
+model, whose whole step is launch-bound.  Weights only change in `optimizer.step()`, so the re-laid filters are kept here, keyed by the weight
+`Parameter` and the convolution descriptor, and ALL of them are refreshed by ONE launch at the end of `deepcv_amd.optim.*.step()` (which updates the
+weights through raw pointers, i.e. without touching `Tensor._version`).  Every other way of changing a weight is detected and falls back to a lazy,
+per-layer re-preparation: in-place torch ops bump `_version`; `.to()` / `.data = ...` change `data_ptr()`; code writing through `.data` (e.g. the
+data-parallel broadcast) calls `invalidate_all()`. """
+import ctypes
+import weakref
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import torch
+
+from . import _native as nat
+from ._native import lib
+
+__all__ = ['get', 'refresh', 'invalidate_all', 'generation']
+
+_cache: Dict[int, Tuple['weakref.ref', Dict[tuple, '_Entry']]] = {}   # id(weight) -> (weak reference, {key: entry}); tensors compare elementwise, so no WeakKeyDictionary
+_epoch = 0
+_generation = 0          # bumped whenever an entry is (re)created: optimizers rebuild their refresh tables then
+_NO_FILTER = object()    # the kernel serving this (descriptor, op) reads OIHW directly
+
+
+class _Entry:
+    __slots__ = ('desc', 'op', 'buf', 'version', 'epoch', 'data_ptr')
+
+
+def _key(d: nat.Conv2dDesc, op: int) -> tuple:
+    return (op, d.n, d.h, d.w, d.cin, d.cout, d.r, d.s, d.stride_h, d.stride_w, d.pad_h, d.pad_w, d.dil_h, d.dil_w, d.x_layout)
+
+
+def _entries_of(weight: torch.Tensor, create: bool = False) -> Optional[Dict[tuple, '_Entry']]:
+    wid = id(weight)
+    slot = _cache.get(wid)
+    if slot is not None and slot[0]() is weight:
+        return slot[1]
+    if not create:
+        return None
+    per_w: Dict[tuple, _Entry] = {}
+    _cache[wid] = (weakref.ref(weight, lambda _r, wid=wid: _cache.pop(wid, None)), per_w)
+    return per_w
+
+
+def generation() -> int:
+    return _generation
+
+
+def invalidate_all():
+    """ To be called by code which changes weights behind autograd's and the optimizers' back (writes through `.data`, raw pointers). """
+    global _epoch
+    _epoch += 1
+
+
+def _prepare(entries: List[Tuple[torch.Tensor, '_Entry']], stream):
+    n = len(entries)
+    descs = (ctypes.POINTER(nat.Conv2dDesc) * n)(*[ctypes.pointer(e.desc) for _, e in entries])
+    ops_ = (ctypes.c_int * n)(*[e.op for _, e in entries])
+    ws = (ctypes.c_void_p * n)(*[w.data_ptr() for w, _ in entries])
+    bufs = (ctypes.c_void_p * n)(*[e.buf.data_ptr() for _, e in entries])
+    nat.check(lib.dcv_conv2d_prepare_filters(n, descs, ops_, ws, bufs, stream), 'dcv_conv2d_prepare_filters')
+    return descs, ops_, ws, bufs          # keep-alive / reusable call table
+
+
+def get(weight: torch.Tensor, d: nat.Conv2dDesc, op: int) -> Optional[torch.Tensor]:
+    """ The filter of `weight` prepared for (descriptor, op) — op 0 forward, 1 data gradient — (re)prepared now if missing or stale; None when that
+    kernel needs none (or `weight` is not a plain contiguous device tensor: the regular entry points are used then). """
+    global _generation
+    if not (weight.is_cuda and weight.is_contiguous()):
+        return None
+    per_w = _entries_of(weight, create=True)
+    k = _key(d, op)
+    e = per_w.get(k)
+    if e is _NO_FILTER:
+        return None
+    if e is not None and e.version == weight._version and e.epoch == _epoch and e.data_ptr == weight.data_ptr():
+        return e.buf
+    if e is None:
+        nbytes = int(lib.dcv_conv2d_filter_bytes(d, op))
+        if nbytes == 0:
+            per_w[k] = _NO_FILTER
+            return None
+        e = _Entry()
+        e.desc, e.op = nat.Conv2dDesc.from_buffer_copy(d), op
+        e.buf = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+        per_w[k] = e
+    _prepare([(weight, e)], nat.current_stream(weight.device))
+    e.version, e.epoch, e.data_ptr = weight._version, _epoch, weight.data_ptr()
+    _generation += 1
+    return e.buf
+
+
+class RefreshTable:
+    """ Call table of `dcv_conv2d_prepare_filters` for every cached filter of a set of parameters; rebuilt when the cache changed. """
+
+    def __init__(self, params: Iterable[torch.Tensor]):
+        self.params = [p for p in params]
+        self.gen = -1
+        self.table = None
+        self.entries: List[Tuple[torch.Tensor, _Entry]] = []
+
+    def refresh(self, stream):
+        if self.gen != _generation or self.table is None:
+            self.entries = []
+            for w in self.params:
+                for e in (_entries_of(w) or {}).values():
+                    if e is not _NO_FILTER and e.epoch == _epoch and e.data_ptr == w.data_ptr() and e.version == w._version:
+                        self.entries.append((w, e))
+            self.gen = _generation
+            if not self.entries:
+                self.table = None
+                return
+            self.table = _prepare(self.entries, stream)
+            return
+        descs, ops_, ws, bufs = self.table
+        nat.check(lib.dcv_conv2d_prepare_filters(len(self.entries), descs, ops_, ws, bufs, stream), 'dcv_conv2d_prepare_filters')
+
+
+def refresh(table: RefreshTable, stream):
+    table.refresh(stream)

@@ -9,6 +9,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _native as nat
+from . import filters
 from ._native import lib
 
 __all__ = ['conv2d', 'conv_norm_layer', 'activation', 'batch_norm', 'group_norm', 'pool2d', 'interpolate_bilinear', 'concat_channels', 'add_tensors', 'flatten_nchw_order',
@@ -82,6 +83,25 @@ def _conv_desc(x_shape, w_shape, stride, padding, dilation, x_layout, act, slope
                           x_layout, act, slope)
 
 
+def _conv_fwd_launch(d, x, weight, bias, y, st):
+    """ Forward convolution; through the prepared-filter cache when `weight` is a plain parameter (see `deepcv_amd/filters.py`). """
+    f = filters.get(weight, d, 0)
+    if f is not None:
+        nat.check(lib.dcv_conv2d_fwd_prepared(d, x.data_ptr(), weight.data_ptr(), f.data_ptr(), nat.ptr(bias), y.data_ptr(), st), 'dcv_conv2d_fwd_prepared')
+        return
+    ws = _ws(lib.dcv_conv2d_fwd_workspace_bytes(d), x.device)
+    nat.check(lib.dcv_conv2d_fwd(d, x.data_ptr(), weight.data_ptr(), nat.ptr(bias), y.data_ptr(), ws.data_ptr(), ws.numel(), st), 'dcv_conv2d_fwd')
+
+
+def _conv_dgrad_launch(dd, dz, weight, dx, st):
+    f = filters.get(weight, dd, 1)
+    if f is not None:
+        nat.check(lib.dcv_conv2d_dgrad_prepared(dd, dz.data_ptr(), weight.data_ptr(), f.data_ptr(), dx.data_ptr(), st), 'dcv_conv2d_dgrad_prepared')
+        return
+    ws = _ws(lib.dcv_conv2d_dgrad_workspace_bytes(dd), dz.device)
+    nat.check(lib.dcv_conv2d_dgrad(dd, dz.data_ptr(), weight.data_ptr(), dx.data_ptr(), ws.data_ptr(), ws.numel(), st), 'dcv_conv2d_dgrad')
+
+
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, dilation, act, slope):
@@ -95,9 +115,7 @@ class _Conv2dFn(torch.autograd.Function):
         weight = weight.contiguous()
         d = _conv_desc(x.shape, weight.shape, stride, padding, dilation, layout, act, slope)
         y = torch.empty((d.n, d.cout, d.ho, d.wo), dtype=x.dtype, device=x.device, memory_format=_CL)
-        ws = _ws(lib.dcv_conv2d_fwd_workspace_bytes(d), x.device)
-        nat.check(lib.dcv_conv2d_fwd(d, x.data_ptr(), weight.data_ptr(), nat.ptr(bias), y.data_ptr(), ws.data_ptr(), ws.numel(),
-                                     nat.current_stream(x.device)), 'dcv_conv2d_fwd')
+        _conv_fwd_launch(d, x, weight, bias, y, nat.current_stream(x.device))
         ctx.desc, ctx.has_bias = d, bias is not None
         ctx.save_for_backward(x, weight, y if act != nat.ACT_NONE else None)
         return y
@@ -126,8 +144,7 @@ class _Conv2dFn(torch.autograd.Function):
             dd = nat.Conv2dDesc.from_buffer_copy(d)
             dd.x_layout = nat.LAYOUT_NHWC
             dx = torch.empty((d.n, d.cin, d.h, d.w), dtype=dy.dtype, device=dev, memory_format=_CL)
-            ws = _ws(lib.dcv_conv2d_dgrad_workspace_bytes(dd), dev)
-            nat.check(lib.dcv_conv2d_dgrad(dd, dz.data_ptr(), weight.data_ptr(), dx.data_ptr(), ws.data_ptr(), ws.numel(), st), 'dcv_conv2d_dgrad')
+            _conv_dgrad_launch(dd, dz, weight, dx, st)
         if ctx.needs_input_grad[1] or (db is not None and not db_done):
             dw = torch.empty_like(weight)
             ws = _ws(lib.dcv_conv2d_wgrad_workspace_bytes(d), dev)
@@ -303,8 +320,7 @@ class _ConvNormLayerFn(torch.autograd.Function):
         d = _conv_desc(x.shape, weight.shape, stride, padding, dilation, layout, act, slope)
         dev, st = x.device, nat.current_stream(x.device)
         y = torch.empty((d.n, d.cout, d.ho, d.wo), dtype=x.dtype, device=dev, memory_format=_CL)
-        ws = _ws(lib.dcv_conv2d_fwd_workspace_bytes(d), dev)
-        nat.check(lib.dcv_conv2d_fwd(d, x.data_ptr(), weight.data_ptr(), nat.ptr(bias), y.data_ptr(), ws.data_ptr(), ws.numel(), st), 'dcv_conv2d_fwd')
+        _conv_fwd_launch(d, x, weight, bias, y, st)
         out = torch.empty_like(y)
         c, hw = d.cout, d.ho * d.wo
         bn_mean = torch.empty(c, dtype=torch.float32, device=dev)
@@ -346,8 +362,7 @@ class _ConvNormLayerFn(torch.autograd.Function):
             dd = nat.Conv2dDesc.from_buffer_copy(d)
             dd.x_layout = nat.LAYOUT_NHWC
             dx = torch.empty((d.n, d.cin, d.h, d.w), dtype=dz.dtype, device=dev, memory_format=_CL)
-            ws = _ws(lib.dcv_conv2d_dgrad_workspace_bytes(dd), dev)
-            nat.check(lib.dcv_conv2d_dgrad(dd, dz.data_ptr(), weight.data_ptr(), dx.data_ptr(), ws.data_ptr(), ws.numel(), st), 'dcv_conv2d_dgrad')
+            _conv_dgrad_launch(dd, dz, weight, dx, st)
         if need[1]:
             dw = torch.empty_like(weight)
             ws = _ws(lib.dcv_conv2d_wgrad_workspace_bytes(d), dev)

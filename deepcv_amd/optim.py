@@ -13,6 +13,7 @@ from typing import Any, Dict, Iterable, List, Optional, Tuple
 import torch
 
 from . import _native as nat
+from . import filters
 from ._native import lib
 
 __all__ = ['AdamW', 'SGD']
@@ -25,6 +26,7 @@ class _NativeOptimizer(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self._dev: Dict[int, Dict[str, Any]] = {}     # per param-group device-side buffers
         self._lists: Dict[int, Tuple[tuple, List[nat.TensorList], List[list]]] = {}
+        self._filter_tables: Dict[int, filters.RefreshTable] = {}
 
     # -- per-group device buffers ----------------------------------------------------------------------
     def _group_buffers(self, gi: int, device: torch.device) -> Dict[str, Any]:
@@ -123,6 +125,11 @@ class _NativeOptimizer(torch.optim.Optimizer):
             nat.check(lib.dcv_optim_prepare(buf['hyper'].data_ptr(), buf['step'].data_ptr(), stream), 'dcv_optim_prepare')
             for tl in lists:
                 self._launch(tl, buf['hyper'].data_ptr(), group, stream)
+            # the weights just changed behind `Tensor._version`: refresh every prepared convolution filter of this group in one launch
+            table = self._filter_tables.get(gi)
+            if table is None:
+                table = self._filter_tables[gi] = filters.RefreshTable(group['params'])
+            table.refresh(stream)
         return loss
 
     # -- checkpoint compatibility with torch.optim state_dicts ------------------------------------------

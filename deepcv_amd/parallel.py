@@ -19,6 +19,7 @@ import torch
 import torch.distributed as dist
 
 from . import _native as nat
+from . import filters
 
 __all__ = ['GradientAllReducer', 'broadcast_module_state', 'DataParallelModel']
 
@@ -28,6 +29,7 @@ def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None):
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src=src, group=group)
+    filters.invalidate_all()      # weights were rewritten through `.data`: prepared convolution filters are stale
 
 
 class _Bucket:

@@ -86,6 +86,18 @@ int dcv_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, 
  * gradient elsewhere too (dcv_bn_gn_act_bwd, dcv_act_bwd) use this to pick the cheaper source. */
 int dcv_conv2d_wgrad_fuses_bias(const dcv_conv2d_desc* d);
 
+/* Prepared filters.  The forward / data-gradient kernels read the OIHW filter re-laid out for the kernel which serves the layer (scalar-cache tiles for the
+ * direct kernels, K-contiguous rows for the MFMA kernels); dcv_conv2d_fwd / dcv_conv2d_dgrad do that re-layout on every call.  A training loop whose
+ * weights change once per optimisation step keeps the re-laid filters instead and refreshes ALL of them with one launch after the optimizer step
+ * (the reference re-reads `Conv2d.weight` on every forward, submodule_creators.py:251; here that read is paid once per step).
+ *   dcv_conv2d_filter_bytes     size of the prepared filter of (d, op), op 0 = forward, 1 = data gradient; 0 when that kernel reads OIHW directly
+ *   dcv_conv2d_prepare_filters  re-lays out `count` filters (entries whose size is 0 are skipped; filters[k] may then be NULL)
+ *   dcv_conv2d_*_prepared       as dcv_conv2d_fwd / dcv_conv2d_dgrad with the filter prepared for exactly this descriptor (w still required: fallback paths) */
+size_t dcv_conv2d_filter_bytes(const dcv_conv2d_desc* d, int op);
+int dcv_conv2d_prepare_filters(int count, const dcv_conv2d_desc* const* descs, const int* ops, const float* const* w, void* const* filters, void* stream);
+int dcv_conv2d_fwd_prepared(const dcv_conv2d_desc* d, const float* x, const float* w, const void* filter, const float* bias, float* y, void* stream);
+int dcv_conv2d_dgrad_prepared(const dcv_conv2d_desc* d, const float* dy, const float* w, const void* filter, float* dx, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * K4  elementwise activation (standalone; conv/linear fuse it into their epilogue)
  * replaces `act_fn()` modules of nn.py:553 (ReLU parameters.yml:9, LeakyReLU :80, Sigmoid :88)

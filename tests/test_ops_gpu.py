@@ -378,3 +378,41 @@ def test_conv_norm_layer_fused(device, case):
         assert bd.grad.abs().max().item() <= gauge
     else:
         _check(f'{name}.db', bd.grad, ref['db'], 1e-3)
+
+
+def test_prepared_filter_cache_tracks_weight_changes(device):
+    """ `deepcv_amd/filters.py`: the re-laid filters kept between steps must follow every way a weight can change — in-place torch ops (`_version`), the
+    native optimizers (raw-pointer update + one refresh launch), `.data` writes announced with `invalidate_all()` — for the forward AND the data gradient. """
+    from deepcv_amd import filters, ops, optim
+    g = torch.Generator().manual_seed(99)
+    x = _cl(torch.randn(4, 4, 12, 12, generator=g).to(device)).requires_grad_(True)
+    w = torch.nn.Parameter((torch.randn(8, 4, 3, 3, generator=g) * 0.3).to(device))
+    dy = _cl(torch.randn(4, 8, 12, 12, generator=g).to(device))
+
+    def run():
+        x.grad = None
+        y = ops.conv2d(x, w, None, 1, 1, 1)
+        y.backward(dy)
+        return y.detach().clone(), x.grad.detach().clone()
+
+    def ref():
+        xr = x.detach().cpu().double().requires_grad_(True)
+        yr = torch.nn.functional.conv2d(xr, w.detach().cpu().double(), None, 1, 1)
+        yr.backward(dy.cpu().double())
+        return yr.detach().float(), xr.grad.float()
+
+    def same():
+        (y, dx), (yr, dxr) = run(), ref()
+        _check('filters.y', y, yr, 1e-4); _check('filters.dx', dx, dxr, 3e-4)
+
+    same(); same()                                   # second call: served from the cache
+    with torch.no_grad():
+        w.mul_(-1.7)                                 # in-place torch op: Tensor._version changes
+    same()
+    opt = optim.SGD([w], lr=0.5)
+    w.grad = torch.ones_like(w)
+    opt.step()                                       # raw-pointer update, refreshed by the optimizer's single launch
+    same()
+    w.data.add_(0.25)                                # invisible to autograd's version counter
+    filters.invalidate_all()
+    same()
