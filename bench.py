@@ -61,7 +61,7 @@ def cpu_baseline(params, budget_s: float = 20.0):
     for i in range(2):
         O.process_step(model, opt, *batches[i % 4])
     t0, steps = time.perf_counter(), 0
-    while steps < 200 and (time.perf_counter() - t0) < budget_s:
+    while steps < 400 and (time.perf_counter() - t0) < budget_s:
         O.process_step(model, opt, *batches[steps % 4])
         steps += 1
     dt = time.perf_counter() - t0
@@ -71,7 +71,10 @@ def cpu_baseline(params, budget_s: float = 20.0):
 
 def dominant_kernel_roofline(device, launches: int = 200):
     """ Times `conv_tile_kernel<4,5,2>` (N=512, 32x32, 4 -> 4 channels, 5x5, pad 2, fused bias + ReLU: layers 2-3 forward and, with the flipped filter,
-    their data gradients) through the C-ABI with HIP events recorded on the stream the kernel is launched on (torch's current stream). """
+    their data gradients) through the C-ABI exactly as the training step launches it (`dcv_conv2d_fwd_prepared`: the filter was re-laid out once, so a
+    launch is that one kernel), with HIP events recorded on the stream the kernel is launched on (torch's current stream).
+    `traffic` is the HBM traffic per launch measured with the PMC counters in separate rocprofv3 passes (profiles/r01_pmc_conv_tile_traffic.json). """
+    import ctypes
     from deepcv_amd import _native as nat
     n, c, h, w, k = BATCH_PER_GPU, 4, 32, 32, 5
     x = torch.randn(n, c, h, w, device=device).contiguous(memory_format=torch.channels_last)
@@ -80,10 +83,12 @@ def dominant_kernel_roofline(device, launches: int = 200):
     y = torch.empty_like(x)
     d = nat.Conv2dDesc(n, h, w, c, c, k, k, 1, 1, 2, 2, 1, 1, 1, h, w, nat.LAYOUT_NHWC, nat.ACT_RELU, 0.)
     st = nat.current_stream(device)
-    ws = torch.empty(max(16, nat.lib.dcv_conv2d_fwd_workspace_bytes(d)), dtype=torch.uint8, device=device)
+    filt = torch.empty(max(16, nat.lib.dcv_conv2d_filter_bytes(d, 0)), dtype=torch.uint8, device=device)
+    nat.check(nat.lib.dcv_conv2d_prepare_filters(1, (ctypes.POINTER(nat.Conv2dDesc) * 1)(ctypes.pointer(d)), (ctypes.c_int * 1)(0),
+                                                 (ctypes.c_void_p * 1)(wt.data_ptr()), (ctypes.c_void_p * 1)(filt.data_ptr()), st), 'dcv_conv2d_prepare_filters')
 
     def launch():
-        nat.check(nat.lib.dcv_conv2d_fwd(d, x.data_ptr(), wt.data_ptr(), b.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(), st), 'dcv_conv2d_fwd')
+        nat.check(nat.lib.dcv_conv2d_fwd_prepared(d, x.data_ptr(), wt.data_ptr(), filt.data_ptr(), b.data_ptr(), y.data_ptr(), st), 'dcv_conv2d_fwd_prepared')
     for _ in range(20):
         launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -96,8 +101,13 @@ def dominant_kernel_roofline(device, launches: int = 200):
     us = e0.elapsed_time(e1) * 1e3 / launches
     algo_bytes = 4 * (n * h * w * c + c * c * k * k + n * h * w * c)
     achieved = algo_bytes / (us * 1e-6) / 1e9
-    return {'bound': 'hbm', 'kernel': 'conv_tile_kernel<4,5,2> (dcv_conv2d_fwd, 512x32x32x4 -> 4, 5x5)', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None, 'avg_launch_us': round(us, 2), 'algorithmic_bytes_per_launch': algo_bytes}
+    traffic = None
+    pmc = ROOT / 'profiles' / 'r01_pmc_conv_tile_traffic.json'
+    if pmc.exists():
+        traffic = json.loads(pmc.read_text()).get('traffic_bytes_per_launch')
+    return {'bound': 'hbm', 'kernel': 'conv_tile_kernel<4,5,2> (dcv_conv2d_fwd_prepared, 512x32x32x4 -> 4, 5x5)', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE)',
+            'avg_launch_us': round(us, 2), 'algorithmic_bytes_per_launch': algo_bytes}
 
 
 def main():
