@@ -99,6 +99,24 @@ __global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restr
     }
 }
 
+// concat (to_wide = 1: parts -> wide rows) or split (to_wide = 0: wide rows -> parts) of up to DCV_MAX_CONCAT channel blocks in ONE launch; blockIdx.y = part
+struct ConcatTable { float* part[DCV_MAX_CONCAT]; int c[DCV_MAX_CONCAT]; int off[DCV_MAX_CONCAT]; int count; };
+
+template <int VEC>
+__global__ __launch_bounds__(256) void concat_split_kernel(ConcatTable t, float* __restrict__ wide, int wide_c, size_t rows, int to_wide) {
+    const int k = blockIdx.y;
+    float* __restrict__ part = t.part[k];
+    const int pc = t.c[k], off = t.off[k];
+    const int cv = pc / VEC;
+    const size_t total = rows * (size_t)cv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / cv; const int c = (int)(i % cv) * VEC;
+        float* pw = wide + r * wide_c + off + c; float* pp = part + r * pc + c;
+        if constexpr (VEC == 4) { if (to_wide) *reinterpret_cast<float4*>(pw) = *reinterpret_cast<const float4*>(pp); else *reinterpret_cast<float4*>(pp) = *reinterpret_cast<const float4*>(pw); }
+        else { if (to_wide) *pw = *pp; else *pp = *pw; }
+    }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t nv) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
@@ -308,6 +326,36 @@ int dcv_copy_channels(const float* src, int src_c, int src_off, float* dst, int 
     if (v4) hipLaunchKernelGGL((copy_channels_kernel<4>), dim3(dcv_stream_grid(rows * (size_t)(copy_c / 4), 256)), dim3(256), 0, st, src, src_c, src_off, dst, dst_c, dst_off, copy_c, rows);
     else hipLaunchKernelGGL((copy_channels_kernel<1>), dim3(dcv_stream_grid(rows * (size_t)copy_c, 256)), dim3(256), 0, st, src, src_c, src_off, dst, dst_c, dst_off, copy_c, rows);
     DCV_RETURN_LAUNCH();
+}
+
+static int concat_split(int count, float* const* parts, const int* cs, float* wide, size_t rows, int to_wide, void* stream) {
+    DCV_CHECK_ARG(count > 0 && count <= DCV_MAX_CONCAT && parts && cs && wide && rows > 0);
+    ConcatTable t{}; t.count = count;
+    int off = 0, maxc = 0; bool v4 = aligned16(wide);
+    for (int k = 0; k < count; ++k) {
+        DCV_CHECK_ARG(cs[k] > 0 && (parts[k] != nullptr || !to_wide));
+        t.part[k] = parts[k]; t.c[k] = cs[k]; t.off[k] = off;
+        v4 = v4 && (cs[k] % 4 == 0) && (off % 4 == 0) && (parts[k] == nullptr || aligned16(parts[k]));
+        if (cs[k] > maxc) maxc = cs[k];
+        off += cs[k];
+    }
+    v4 = v4 && (off % 4 == 0);
+    // split: a NULL part means "gradient not needed": launch only the others (compact the table)
+    int n = 0;
+    for (int k = 0; k < count; ++k) if (t.part[k]) { t.part[n] = t.part[k]; t.c[n] = t.c[k]; t.off[n] = t.off[k]; ++n; }
+    if (n == 0) return DCV_OK;
+    hipStream_t st = dcv_stream(stream);
+    if (v4) hipLaunchKernelGGL((concat_split_kernel<4>), dim3(dcv_stream_grid(rows * (size_t)(maxc / 4), 256), (unsigned)n), dim3(256), 0, st, t, wide, off, rows, to_wide);
+    else hipLaunchKernelGGL((concat_split_kernel<1>), dim3(dcv_stream_grid(rows * (size_t)maxc, 256), (unsigned)n), dim3(256), 0, st, t, wide, off, rows, to_wide);
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_concat_channels(int count, const float* const* srcs, const int* channels, float* dst, size_t rows, void* stream) {
+    return concat_split(count, const_cast<float* const*>(reinterpret_cast<const float* const*>(srcs)), channels, dst, rows, 1, stream);
+}
+
+int dcv_split_channels(int count, float* const* dsts, const int* channels, const float* src, size_t rows, void* stream) {
+    return concat_split(count, dsts, channels, const_cast<float*>(src), rows, 0, stream);
 }
 
 int dcv_add(const float* a, const float* b, float* out, size_t numel, void* stream) {

@@ -9,15 +9,61 @@
 
 namespace {
 
-// one wave per sample row; lanes stride over K; one shuffle-reduction per output feature
+// one wave per sample row; lanes stride over K.  The row of x is read ONCE into registers (up to XR vectors per lane) and 8 output features are
+// accumulated together, so that the loads of 8 weight rows are in flight at once and the 8 wave reductions are independent (a per-feature loop
+// re-reading x was a chain of 10 dependent global-memory latencies for the 10-class head).
 template <int VEC>
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                           float* __restrict__ y, int N, int K, int O, int act, float slope) {
+    constexpr int XR = 8, OB = 8;
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (n >= N) return;
     const float* xr = x + (size_t)n * K;
     const int KV = K / VEC;
+    const int iters = (KV + 63) / 64;
+    if (iters <= XR) {
+        float xv[XR][VEC];
+#pragma unroll
+        for (int i = 0; i < XR; ++i) {
+            const int k = lane + 64 * i;
+            if (i < iters && k < KV) {
+                if constexpr (VEC == 4) { const float4 a = reinterpret_cast<const float4*>(xr)[k]; xv[i][0] = a.x; xv[i][1] = a.y; xv[i][2] = a.z; xv[i][3] = a.w; }
+                else xv[i][0] = xr[k];
+            } else {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) xv[i][v] = 0.f;
+            }
+        }
+        for (int o0 = 0; o0 < O; o0 += OB) {
+            float acc[OB];
+#pragma unroll
+            for (int j = 0; j < OB; ++j) acc[j] = 0.f;
+#pragma unroll
+            for (int i = 0; i < XR; ++i) {
+                if (i < iters) {
+                    const int k = lane + 64 * i;
+                    const int kc = k < KV ? k : KV - 1;                // clamped: xv is zero there
+#pragma unroll
+                    for (int j = 0; j < OB; ++j) {
+                        const int o = (o0 + j < O) ? o0 + j : O - 1;
+                        if constexpr (VEC == 4) {
+                            const float4 b = reinterpret_cast<const float4*>(w + (size_t)o * K)[kc];
+                            acc[j] += xv[i][0] * b.x + xv[i][1] * b.y + xv[i][2] * b.z + xv[i][3] * b.w;
+                        } else acc[j] += xv[i][0] * w[(size_t)o * K + kc];
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < OB; ++j) acc[j] = dcv_wave_sum(acc[j]);
+            if (lane == 0) {
+#pragma unroll
+                for (int j = 0; j < OB; ++j)
+                    if (o0 + j < O) y[(size_t)n * O + o0 + j] = dcv_act_apply(acc[j] + (bias ? bias[o0 + j] : 0.f), act, slope);
+            }
+        }
+        return;
+    }
     for (int o = 0; o < O; ++o) {
         const float* wr = w + (size_t)o * K;
         float acc = 0.f;

@@ -4,6 +4,7 @@ PyTorch is plumbing here (device memory from the caching allocator, the current 
 arithmetic op of the hot path — K1..K11 of SURVEY.md §2.3 — runs in a hand-written gfx950 kernel.  Activations are 4-D tensors
 with logical NCHW shape (what the reference's modules expose, `src/deepcv/meta/base_module.py:80`) and `torch.channels_last`
 strides, i.e. NHWC in memory, which is the layout the kernels are written for.  There is no CPU / eager fallback. """
+import ctypes
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -453,10 +454,18 @@ class _ConcatFn(torch.autograd.Function):
         chans = [t.shape[1] for t in tensors]
         ctot = sum(chans)
         out = torch.empty((n, ctot, h, w), dtype=tensors[0].dtype, device=tensors[0].device, memory_format=_CL)
-        st, rows, off = nat.current_stream(out.device), n * h * w, 0
-        for t, c in zip(tensors, chans):
-            nat.check(lib.dcv_copy_channels(t.data_ptr(), c, 0, out.data_ptr(), ctot, off, c, rows, st), 'dcv_copy_channels')
-            off += c
+        st, rows = nat.current_stream(out.device), n * h * w
+        for i in range(0, len(tensors), nat.MAX_CONCAT):          # one launch per 8 sources
+            part, cs = tensors[i:i + nat.MAX_CONCAT], chans[i:i + nat.MAX_CONCAT]
+            if len(tensors) <= nat.MAX_CONCAT:
+                k = len(part)
+                nat.check(lib.dcv_concat_channels(k, (ctypes.c_void_p * k)(*[t.data_ptr() for t in part]), (ctypes.c_int * k)(*cs), out.data_ptr(), rows, st),
+                          'dcv_concat_channels')
+            else:
+                off = sum(chans[:i])
+                for t, c in zip(part, cs):
+                    nat.check(lib.dcv_copy_channels(t.data_ptr(), c, 0, out.data_ptr(), ctot, off, c, rows, st), 'dcv_copy_channels')
+                    off += c
         ctx.chans, ctx.geom = chans, (n, h, w)
         return out
 
@@ -465,15 +474,17 @@ class _ConcatFn(torch.autograd.Function):
         n, h, w = ctx.geom
         dy = to_nhwc(dy)
         ctot, rows, st, off = sum(ctx.chans), n * h * w, nat.current_stream(dy.device), 0
-        grads = []
-        for i, c in enumerate(ctx.chans):
-            if ctx.needs_input_grad[i]:
-                g = torch.empty((n, c, h, w), dtype=dy.dtype, device=dy.device, memory_format=_CL)
-                nat.check(lib.dcv_copy_channels(dy.data_ptr(), ctot, off, g.data_ptr(), c, 0, c, rows, st), 'dcv_copy_channels')
-                grads.append(g)
-            else:
-                grads.append(None)
-            off += c
+        grads = [torch.empty((n, c, h, w), dtype=dy.dtype, device=dy.device, memory_format=_CL) if ctx.needs_input_grad[i] else None
+                 for i, c in enumerate(ctx.chans)]
+        k = len(grads)
+        if k <= nat.MAX_CONCAT:
+            nat.check(lib.dcv_split_channels(k, (ctypes.c_void_p * k)(*[nat.ptr(g) for g in grads]), (ctypes.c_int * k)(*ctx.chans), dy.data_ptr(), rows, st),
+                      'dcv_split_channels')
+        else:
+            for g, c in zip(grads, ctx.chans):
+                if g is not None:
+                    nat.check(lib.dcv_copy_channels(dy.data_ptr(), ctot, off, g.data_ptr(), c, 0, c, rows, st), 'dcv_copy_channels')
+                off += c
         return tuple(grads)
 
 

@@ -192,6 +192,10 @@ int dcv_interp_bilinear_fwd(const float* x, float* y, int n, int h, int w, int c
 int dcv_interp_bilinear_bwd(const float* dy, float* dx, int n, int h, int w, int c, int ho, int wo, int align_corners, void* stream);
 /* dst[row][dst_off : dst_off+copy_c] = src[row][src_off : src_off+copy_c] for [rows][dst_c] / [rows][src_c] views */
 int dcv_copy_channels(const float* src, int src_c, int src_off, float* dst, int dst_c, int dst_off, int copy_c, size_t rows, void* stream);
+/* dst[row] = srcs[0][row] | srcs[1][row] | ... (channel concatenation of `count` <= DCV_MAX_CONCAT [rows][channels[k]] blocks) in ONE launch, and its
+ * adjoint (a NULL dsts[k] skips that block): what torch.cat(dim=1) / its backward do for the dense links (submodule_creators.py:309-327) */
+int dcv_concat_channels(int count, const float* const* srcs, const int* channels, float* dst, size_t rows, void* stream);
+int dcv_split_channels(int count, float* const* dsts, const int* channels, const float* src, size_t rows, void* stream);
 /* out = a + b (elementwise; out may alias a) */
 int dcv_add(const float* a, const float* b, float* out, size_t numel, void* stream);
 /* out = alpha * a */
@@ -233,6 +237,7 @@ int dcv_cross_entropy_bwd(const float* logits, const int64_t* target, const floa
  * current learning rate: the host refreshes `hyper` with one small async H2D copy per step.
  * ------------------------------------------------------------------------------------------------- */
 #define DCV_MAX_TENSORS 64
+#define DCV_MAX_CONCAT 8
 typedef struct {
     int count;                               /* number of tensors in this launch (<= DCV_MAX_TENSORS)     */
     float* param[DCV_MAX_TENSORS];
