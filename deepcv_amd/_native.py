@@ -26,6 +26,7 @@ POOL_AVG, POOL_MAX = 0, 1
 LAYOUT_NHWC, LAYOUT_NCHW = 0, 1
 MAX_TENSORS = 64
 MAX_CONCAT = 8
+MAX_COPY_JOBS = 8
 HYP_COUNT = 16
 HYP = {'lr': 0, 'beta1': 1, 'beta2': 2, 'eps': 3, 'weight_decay': 4, 'grad_scale': 5, 'bias_corr1': 6, 'bias_corr2': 7, 'first_step': 8}
 
@@ -89,6 +90,7 @@ _SIGNATURES = {
     'dcv_copy_channels': (_c_int, [_P, _c_int, _c_int, _P, _c_int, _c_int, _c_int, _c_size_t, _P]),
     'dcv_concat_channels': (_c_int, [_c_int, ctypes.POINTER(_P), ctypes.POINTER(_c_int), _P, _c_size_t, _P]),
     'dcv_split_channels': (_c_int, [_c_int, ctypes.POINTER(_P), ctypes.POINTER(_c_int), _P, _c_size_t, _P]),
+    'dcv_indirect_copy': (_c_int, [_P, _P]),
     'dcv_add': (_c_int, [_P, _P, _P, _c_size_t, _P]),
     'dcv_scale': (_c_int, [_P, _c_float, _P, _c_size_t, _P]),
     'dcv_transpose_inner': (_c_int, [_P, _P, _c_int, _c_int, _c_int, _P]),

@@ -117,6 +117,22 @@ __global__ __launch_bounds__(256) void concat_split_kernel(ConcatTable t, float*
     }
 }
 
+// copies described by a mailbox read at run time (see dcv_indirect_copy); 16-B vectors when all three of src, dst, bytes allow it
+__global__ __launch_bounds__(256) void indirect_copy_kernel(const dcv_copy_jobs* __restrict__ jobs) {
+    const int count = jobs->count < DCV_MAX_COPY_JOBS ? jobs->count : DCV_MAX_COPY_JOBS;
+    const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gstride = (size_t)gridDim.x * blockDim.x;
+    for (int j = 0; j < count; ++j) {
+        const char* src = reinterpret_cast<const char*>(jobs->src[j]);
+        char* dst = reinterpret_cast<char*>(jobs->dst[j]);
+        const size_t bytes = (size_t)jobs->bytes[j];
+        if (!src || !dst || bytes == 0) continue;
+        const bool vec = (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0);
+        const size_t n16 = vec ? bytes / 16 : 0;
+        for (size_t i = gtid; i < n16; i += gstride) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+        for (size_t i = n16 * 16 + gtid; i < bytes; i += gstride) dst[i] = src[i];
+    }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t nv) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
@@ -356,6 +372,13 @@ int dcv_concat_channels(int count, const float* const* srcs, const int* channels
 
 int dcv_split_channels(int count, float* const* dsts, const int* channels, const float* src, size_t rows, void* stream) {
     return concat_split(count, dsts, channels, const_cast<float*>(src), rows, 0, stream);
+}
+
+int dcv_indirect_copy(const dcv_copy_jobs* jobs, void* stream) {
+    DCV_CHECK_ARG(jobs != nullptr);
+    // the grid cannot depend on sizes only known at run time: 4 blocks per CU stream any batch at HBM speed and cost nothing for tiny ones
+    hipLaunchKernelGGL(indirect_copy_kernel, dim3(DCV_NUM_CU * 4), dim3(256), 0, dcv_stream(stream), jobs);
+    DCV_RETURN_LAUNCH();
 }
 
 int dcv_add(const float* a, const float* b, float* out, size_t numel, void* stream) {

@@ -196,9 +196,51 @@ class GraphedTrainStep:
         cur.wait_stream(self.stream)
         return out
 
+    # -- mailbox: batch pointers + optimizer scalars read by the graph's first kernel at run time (`dcv_indirect_copy`) ----------------------
+    _MB_PAYLOAD = 256                                              # byte offset of the scalar payload inside the mailbox
+
+    def _mailbox_init(self, dev):
+        from .. import _native as nat
+        self._nat = nat
+        self.mailbox = torch.zeros(1024, dtype=torch.uint8).pin_memory()
+        self._mb = self.mailbox.numpy()                            # shares the pinned memory: plain CPU stores, no API call
+        self._consumed: Optional[torch.cuda.Event] = None
+        self._held = None
+
+    def _direct(self, src, dst) -> bool:
+        """ Can `src` be fetched by the staging kernel (same dtype / shape / strides as the static buffer, device or pinned-host memory)? """
+        return (isinstance(src, torch.Tensor) and src.dtype == dst.dtype and src.shape == dst.shape and src.stride() == dst.stride()
+                and (src.is_cuda and src.device == dst.device or (not src.is_cuda and src.is_pinned())))
+
+    def _mailbox_write(self, x, y):
+        import struct
+        if self._consumed is not None:
+            self._consumed.synchronize()                           # the previous replay has read its mailbox (a no-op after the loss read-back)
+        src, dst, nbytes = [], [], []
+        for s_, d_ in ((x, self.static_x), (y, self.static_y)):
+            if not isinstance(d_, torch.Tensor):
+                continue
+            if self._direct(s_, d_):
+                src.append(s_.data_ptr()); dst.append(d_.data_ptr()); nbytes.append(d_.numel() * d_.element_size())
+            else:
+                d_.copy_(s_, non_blocking=True)                    # foreign layout / pageable host memory: ordinary copy
+        off = self._MB_PAYLOAD
+        if hasattr(self.optimizer, 'hyper_jobs'):
+            for vals, dev_buf in self.optimizer.hyper_jobs():
+                struct.pack_into(f'<{len(vals)}f', self._mb, off, *vals)
+                src.append(self.mailbox.data_ptr() + off); dst.append(dev_buf.data_ptr()); nbytes.append(4 * len(vals))
+                off += 64
+        n = len(src)
+        assert n <= self._nat.MAX_COPY_JOBS and off <= self.mailbox.numel()
+        pad = [0] * (self._nat.MAX_COPY_JOBS - n)
+        struct.pack_into('<8Q8Q8Qii', self._mb, 0, *(src + pad), *(dst + pad), *(nbytes + pad), n, 0)
+        self._held = (x, y)                                        # sources stay alive until the next mailbox write
+
     def _capture(self, x, y):
         dev = x.device
         self.static_x, self.static_y = x.clone(), (y.clone() if isinstance(y, torch.Tensor) else y)
+        self._mailbox_init(dev)
+        self._mailbox_write(x, y)
         self.model.train()
         self.optimizer.zero_grad(set_to_none=True)
         hooks_were = None
@@ -207,6 +249,7 @@ class GraphedTrainStep:
         torch.cuda.synchronize(dev)
         self.graph_fb = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_fb, stream=self.stream):
+            self._nat.check(self._nat.lib.dcv_indirect_copy(self.mailbox.data_ptr(), self._nat.current_stream(dev)), 'dcv_indirect_copy')
             self.static_pred = self.model(self.static_x)
             self.static_losses = _batch_losses(self.losses, self.weights, self.static_pred, self.static_y)
             self.static_losses[MAIN_TRAINING_LOSS_NAME].backward()
@@ -222,12 +265,11 @@ class GraphedTrainStep:
         torch.cuda.synchronize(dev)
 
     def _replay(self, x, y):
-        self.static_x.copy_(x, non_blocking=True)
-        if isinstance(y, torch.Tensor):
-            self.static_y.copy_(y, non_blocking=True)
-        if hasattr(self.optimizer, 'sync_hyper'):
-            self.optimizer.sync_hyper()
+        self._mailbox_write(x, y)
         self.graph_fb.replay()
+        if self._consumed is None:
+            self._consumed = torch.cuda.Event()
+        self._consumed.record()
         if self.reducer is not None:
             for p, g in zip(self.reducer.params, self._static_grads):
                 p.grad = g

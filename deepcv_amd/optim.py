@@ -64,6 +64,19 @@ class _NativeOptimizer(torch.optim.Optimizer):
                 buf['hyper'][:len(vals)].copy_(h[:len(vals)], non_blocking=True)
                 buf['last'] = list(vals)
 
+    def hyper_jobs(self) -> List[Tuple[List[float], torch.Tensor]]:
+        """ (host scalars, device hyper buffer) per param group, for callers which deliver the scalars themselves (the hipGraph mailbox of
+        `GraphedTrainStep`: they ride in the batch-staging kernel instead of a separate H2D copy).  Invalidates `sync_hyper`'s change detection. """
+        jobs = []
+        for gi, group in enumerate(self.param_groups):
+            p0 = next((p for p in group['params']), None)
+            if p0 is None:
+                continue
+            buf = self._group_buffers(gi, p0.device)
+            jobs.append((self._hyper_values(group) + [float(group.get('grad_scale', 1.0))], buf['hyper']))
+            buf['last'] = None
+        return jobs
+
     # -- tensor tables ---------------------------------------------------------------------------------
     def _tensor_lists(self, gi: int, group: Dict[str, Any]) -> List[nat.TensorList]:
         params = [p for p in group['params'] if p.grad is not None]

@@ -202,6 +202,23 @@ int dcv_add(const float* a, const float* b, float* out, size_t numel, void* stre
 int dcv_scale(const float* a, float alpha, float* out, size_t numel, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Indirect batch staging: up to DCV_MAX_COPY_JOBS (src, dst, bytes) copies whose descriptors are READ BY THE KERNEL AT RUN TIME from `jobs`, a block
+ * of device-visible (pinned host or device) memory.  Captured as the first node of the training-step hipGraph it lets every replay fetch a NEW batch
+ * (and the optimizer's scalar hyper-parameters) although the graph's kernel arguments are frozen: the host only rewrites the mailbox before
+ * `hipGraphLaunch` — no hipMemcpyAsync calls (each ~20 us of host latency on the critical path of a 0.6 ms step).
+ * replaces the H2D / D2D batch copies of process_function (ignite_training.py:235-242).  Sources may be pinned host memory (zero-copy read).
+ * ------------------------------------------------------------------------------------------------- */
+#define DCV_MAX_COPY_JOBS 8
+typedef struct {
+    const void* src[DCV_MAX_COPY_JOBS];
+    void* dst[DCV_MAX_COPY_JOBS];
+    unsigned long long bytes[DCV_MAX_COPY_JOBS];
+    int count;
+    int reserved;
+} dcv_copy_jobs;
+int dcv_indirect_copy(const dcv_copy_jobs* jobs, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * K9  layout change + Linear
  * replaces torch.nn.Flatten (parameters.yml:87) on NHWC activations and torch.nn.Linear (submodule_creators.py:268-269)
  * ------------------------------------------------------------------------------------------------- */
