@@ -162,8 +162,11 @@ def main():
     def one_step(i):
         sched(None)                                   # ITERATION_STARTED: LR for this iteration
         x, y = batches[i % POOL]
-        out, _ = step_fn._on_side_stream(step_fn._eager, x, y) if args.eager else step_fn(x, y)
-        return out['main_loss'].item()                # the reference reads the loss back every step (ignite_training.py:255)
+        if args.eager:
+            out, _ = step_fn._on_side_stream(step_fn._eager, x, y)
+            return out['main_loss'].item()
+        step_fn(x, y)
+        return step_fn.loss_values()['main_loss']     # the reference reads the loss back every step (ignite_training.py:255)
 
     it = 0
     for _ in range(4):                                # eager first step + capture + first replays: never timed

@@ -133,6 +133,15 @@ __global__ __launch_bounds__(256) void indirect_copy_kernel(const dcv_copy_jobs*
     }
 }
 
+struct ScalarPtrs { const float* p[DCV_MAX_COPY_JOBS]; };
+__global__ __launch_bounds__(64) void publish_scalars_kernel(const dcv_copy_jobs* __restrict__ mailbox, ScalarPtrs srcs, int n, float* host_vals, int* host_seq) {
+    const int t = threadIdx.x;
+    if (t < n) host_vals[t] = *srcs.p[t];
+    __threadfence_system();                                  // the values are in host memory before the sequence number is
+    __syncthreads();
+    if (t == 0) { *reinterpret_cast<volatile int*>(host_seq) = mailbox->seq; __threadfence_system(); }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t nv) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
@@ -378,6 +387,14 @@ int dcv_indirect_copy(const dcv_copy_jobs* jobs, void* stream) {
     DCV_CHECK_ARG(jobs != nullptr);
     // the grid cannot depend on sizes only known at run time: 4 blocks per CU stream any batch at HBM speed and cost nothing for tiny ones
     hipLaunchKernelGGL(indirect_copy_kernel, dim3(DCV_NUM_CU * 4), dim3(256), 0, dcv_stream(stream), jobs);
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_publish_scalars(const dcv_copy_jobs* mailbox, const float* const* srcs, int n, float* host_vals, int* host_seq, void* stream) {
+    DCV_CHECK_ARG(mailbox && srcs && n > 0 && n <= DCV_MAX_COPY_JOBS && host_vals && host_seq);
+    ScalarPtrs sp{};
+    for (int k = 0; k < n; ++k) { DCV_CHECK_ARG(srcs[k] != nullptr); sp.p[k] = srcs[k]; }
+    hipLaunchKernelGGL(publish_scalars_kernel, dim3(1), dim3(64), 0, dcv_stream(stream), mailbox, sp, n, host_vals, host_seq);
     DCV_RETURN_LAUNCH();
 }
 

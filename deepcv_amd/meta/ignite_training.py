@@ -169,6 +169,11 @@ class GraphedTrainStep:
         self.static_losses: Optional['OrderedDict[str, torch.Tensor]'] = None
         self.static_pred = None
         self.stream: Optional[torch.cuda.Stream] = None
+        self._publishes = False
+        self._launched_seq: Optional[int] = None
+        self._seq_seen = 0
+        self._last_eager = True
+        self._last_losses = None
 
     def _eager(self, x, y):
         self.model.train()
@@ -198,14 +203,19 @@ class GraphedTrainStep:
 
     # -- mailbox: batch pointers + optimizer scalars read by the graph's first kernel at run time (`dcv_indirect_copy`) ----------------------
     _MB_PAYLOAD = 256                                              # byte offset of the scalar payload inside the mailbox
+    _PUB_VALS, _PUB_SEQ = 768, 832                                 # byte offsets of the published loss values / their sequence number
 
     def _mailbox_init(self, dev):
         from .. import _native as nat
         self._nat = nat
         self.mailbox = torch.zeros(1024, dtype=torch.uint8).pin_memory()
         self._mb = self.mailbox.numpy()                            # shares the pinned memory: plain CPU stores, no API call
-        self._consumed: Optional[torch.cuda.Event] = None
         self._held = None
+        # early loss read-back (`dcv_publish_scalars`): values at _PUB_VALS, sequence number at _PUB_SEQ of the same pinned block
+        self._seq = 0                                              # sequence number of the last mailbox written
+        self._seq_seen = 0                                         # ... of the last published loss the host has observed
+        self._pub_vals = self._mb[self._PUB_VALS:self._PUB_VALS + 32].view('<f4')
+        self._pub_seq = self._mb[self._PUB_SEQ:self._PUB_SEQ + 4].view('<i4')
 
     def _direct(self, src, dst) -> bool:
         """ Can `src` be fetched by the staging kernel (same dtype / shape / strides as the static buffer, device or pinned-host memory)? """
@@ -214,8 +224,7 @@ class GraphedTrainStep:
 
     def _mailbox_write(self, x, y):
         import struct
-        if self._consumed is not None:
-            self._consumed.synchronize()                           # the previous replay has read its mailbox (a no-op after the loss read-back)
+        self._wait_published()                                     # the previous replay has read its mailbox (a no-op after the loss read-back)
         src, dst, nbytes = [], [], []
         for s_, d_ in ((x, self.static_x), (y, self.static_y)):
             if not isinstance(d_, torch.Tensor):
@@ -233,8 +242,30 @@ class GraphedTrainStep:
         n = len(src)
         assert n <= self._nat.MAX_COPY_JOBS and off <= self.mailbox.numel()
         pad = [0] * (self._nat.MAX_COPY_JOBS - n)
-        struct.pack_into('<8Q8Q8Qii', self._mb, 0, *(src + pad), *(dst + pad), *(nbytes + pad), n, 0)
+        self._seq = (self._seq + 1) & 0x3fffffff
+        struct.pack_into('<8Q8Q8Qii', self._mb, 0, *(src + pad), *(dst + pad), *(nbytes + pad), n, self._seq)
         self._held = (x, y)                                        # sources stay alive until the next mailbox write
+
+    def _wait_published(self):
+        """ Blocks until the loss of the last launched replay has been published, i.e. its forward pass is done (its staging kernel has consumed the
+        mailbox long before).  Polls pinned memory; yields the GIL between polls so that loader threads keep running. """
+        if self._launched_seq is None or self._launched_seq == self._seq_seen:
+            return
+        import time
+        spins = 0
+        while int(self._pub_seq[0]) != self._launched_seq:
+            spins += 1
+            if spins > 64:
+                time.sleep(0)
+        self._seq_seen = self._launched_seq
+
+    def loss_values(self) -> 'OrderedDict[str, float]':
+        """ Host values of the loss terms of the last step.  After a replay they come from the early read-back (no device synchronisation: the backward
+        pass and the optimizer of that step may still be running); after an eager step, from the loss tensors. """
+        if self._launched_seq is None or self._last_eager:
+            return OrderedDict((n, v.item()) for n, v in self._last_losses.items())
+        self._wait_published()
+        return OrderedDict((n, float(self._pub_vals[i])) for i, n in enumerate(self.static_losses.keys()))
 
     def _capture(self, x, y):
         dev = x.device
@@ -252,6 +283,13 @@ class GraphedTrainStep:
             self._nat.check(self._nat.lib.dcv_indirect_copy(self.mailbox.data_ptr(), self._nat.current_stream(dev)), 'dcv_indirect_copy')
             self.static_pred = self.model(self.static_x)
             self.static_losses = _batch_losses(self.losses, self.weights, self.static_pred, self.static_y)
+            terms = [v.reshape(1) if v.dim() == 0 else v for v in self.static_losses.values()]
+            if 0 < len(terms) <= self._nat.MAX_COPY_JOBS and all(t.numel() == 1 and t.dtype == torch.float32 for t in terms):
+                import ctypes
+                ptrs = (ctypes.c_void_p * len(terms))(*[t.data_ptr() for t in terms])
+                self._nat.check(self._nat.lib.dcv_publish_scalars(self.mailbox.data_ptr(), ptrs, len(terms), self.mailbox.data_ptr() + self._PUB_VALS,
+                                                                  self.mailbox.data_ptr() + self._PUB_SEQ, self._nat.current_stream(dev)), 'dcv_publish_scalars')
+                self._publishes = True
             self.static_losses[MAIN_TRAINING_LOSS_NAME].backward()
             if self.reducer is None:
                 self.optimizer.step()
@@ -267,9 +305,9 @@ class GraphedTrainStep:
     def _replay(self, x, y):
         self._mailbox_write(x, y)
         self.graph_fb.replay()
-        if self._consumed is None:
-            self._consumed = torch.cuda.Event()
-        self._consumed.record()
+        self._launched_seq = self._seq if self._publishes else None
+        if not self._publishes:
+            torch.cuda.current_stream(x.device).synchronize()      # no early read-back: the mailbox may only be rewritten once this replay is done
         if self.reducer is not None:
             for p, g in zip(self.reducer.params, self._static_grads):
                 p.grad = g
@@ -279,15 +317,21 @@ class GraphedTrainStep:
 
     def __call__(self, x, y):
         self.calls += 1
-        if self.calls == 1:
-            return self._on_side_stream(self._eager, x, y)
-        if self.graph_fb is None:
+        eager = self.calls == 1
+        if not eager and self.graph_fb is None:
             if self.stream is None:
                 self._on_side_stream(lambda: None)
             self._capture(x, y)
-        if x.shape != self.static_x.shape or (isinstance(y, torch.Tensor) and y.shape != self.static_y.shape):
-            return self._on_side_stream(self._eager, x, y)
-        return self._replay(x, y)
+        if not eager and (x.shape != self.static_x.shape or (isinstance(y, torch.Tensor) and y.shape != self.static_y.shape)):
+            eager = True
+        if eager:
+            if self._launched_seq is not None:
+                self._wait_published()
+            out = self._on_side_stream(self._eager, x, y)
+        else:
+            out = self._replay(x, y)
+        self._last_eager, self._last_losses = eager, out[0]
+        return out
 
 
 def train(hp: HYPERPARAMS_T, model: torch.nn.Module, losses: LOSS_FN_TERMS_T = None, datasets: Union[Dict[str, Dataset], Tuple[Dataset, ...]] = None,
@@ -394,6 +438,8 @@ def train(hp: HYPERPARAMS_T, model: torch.nn.Module, losses: LOSS_FN_TERMS_T = N
             if reducer is not None:
                 reducer.finish()
             optimizer.step()
+        if graphed_step is not None:
+            return dict(graphed_step.loss_values())               # per-step host read-back like the reference (`:255`), published right after the forward pass
         return {n: v.item() for n, v in batch_losses.items()}   # device -> host sync every step, like the reference (`:255`)
 
     trainer = Engine(process_function)

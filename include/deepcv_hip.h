@@ -214,9 +214,13 @@ typedef struct {
     void* dst[DCV_MAX_COPY_JOBS];
     unsigned long long bytes[DCV_MAX_COPY_JOBS];
     int count;
-    int reserved;
+    int seq;                        /* sequence number of this mailbox content, echoed by dcv_publish_scalars */
 } dcv_copy_jobs;
 int dcv_indirect_copy(const dcv_copy_jobs* jobs, void* stream);
+/* Early read-back: copies `n` <= DCV_MAX_COPY_JOBS device scalars (the loss terms) to host-visible memory `host_vals`, then (system-scope fence) stores the
+ * mailbox's `seq` to `host_seq`.  Placed right after the loss kernels of the step graph it lets the host fetch the per-step loss of process_function
+ * (ignite_training.py:255) by polling pinned memory while the backward pass is still running, and launch the next step's graph without a device sync. */
+int dcv_publish_scalars(const dcv_copy_jobs* mailbox, const float* const* srcs, int n, float* host_vals, int* host_seq, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K9  layout change + Linear
