@@ -87,8 +87,11 @@ def dominant_kernel_roofline(device, launches: int = 200):
     nat.check(nat.lib.dcv_conv2d_prepare_filters(1, (ctypes.POINTER(nat.Conv2dDesc) * 1)(ctypes.pointer(d)), (ctypes.c_int * 1)(0),
                                                  (ctypes.c_void_p * 1)(wt.data_ptr()), (ctypes.c_void_p * 1)(filt.data_ptr()), st), 'dcv_conv2d_prepare_filters')
 
+    # as in the training step, the epilogue also emits the BatchNorm statistics partials of its output tile
+    stats = torch.empty((max(1, nat.lib.dcv_conv2d_fwd_stats_rows(d)), 2, c), dtype=torch.float64, device=device)
+
     def launch():
-        nat.check(nat.lib.dcv_conv2d_fwd_prepared(d, x.data_ptr(), wt.data_ptr(), filt.data_ptr(), b.data_ptr(), y.data_ptr(), st), 'dcv_conv2d_fwd_prepared')
+        nat.check(nat.lib.dcv_conv2d_fwd_prepared(d, x.data_ptr(), wt.data_ptr(), filt.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), st), 'dcv_conv2d_fwd_prepared')
     for _ in range(20):
         launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -67,7 +67,8 @@ _SIGNATURES = {
     'dcv_conv2d_wgrad_fuses_bias': (_c_int, [ctypes.POINTER(Conv2dDesc)]),
     'dcv_conv2d_filter_bytes': (_c_size_t, [ctypes.POINTER(Conv2dDesc), _c_int]),
     'dcv_conv2d_prepare_filters': (_c_int, [_c_int, ctypes.POINTER(ctypes.POINTER(Conv2dDesc)), ctypes.POINTER(_c_int), ctypes.POINTER(_P), ctypes.POINTER(_P), _P]),
-    'dcv_conv2d_fwd_prepared': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _P, _P]),
+    'dcv_conv2d_fwd_stats_rows': (_c_int, [ctypes.POINTER(Conv2dDesc)]),
+    'dcv_conv2d_fwd_prepared': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _P, _P, _P]),
     'dcv_conv2d_dgrad_prepared': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _P]),
     'dcv_act_fwd': (_c_int, [_P, _P, _c_size_t, _c_int, _c_float, _P]),
     'dcv_act_bwd_workspace_bytes': (_c_size_t, [_c_size_t, _c_int]),
@@ -81,7 +82,7 @@ _SIGNATURES = {
     'dcv_groupnorm_fwd': (_c_int, [_P, _P, _c_int, _c_int, _c_int, _c_int, _P, _P, _c_float, _P, _P, _P]),
     'dcv_groupnorm_bwd': (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _P, _c_size_t, _P]),
     'dcv_norm_chain_workspace_bytes': (_c_size_t, [_c_int, _c_int, _c_int]),
-    'dcv_bn_gn_fwd_train': (_c_int, [_P, _P, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _c_float, _c_float, _P, _P, _c_int, _P, _P, _c_float, _P, _P, _P, _c_size_t, _P]),
+    'dcv_bn_gn_fwd_train': (_c_int, [_P, _P, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _c_float, _c_float, _P, _P, _c_int, _P, _P, _c_float, _P, _P, _P, _c_int, _P, _c_size_t, _P]),
     'dcv_bn_gn_act_bwd': (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _P, _P, _P, _P, _c_int, _P, _P, _P, _c_int, _c_float, _P, _P, _P, _P, _P, _P, _c_size_t, _P]),
     'dcv_pool2d_fwd': (_c_int, [ctypes.POINTER(Pool2dDesc), _P, _P, _P, _P]),
     'dcv_pool2d_bwd': (_c_int, [ctypes.POINTER(Pool2dDesc), _P, _P, _P, _P]),

@@ -97,14 +97,19 @@ int dcv_conv2d_prepare_filters(int count, const dcv_conv2d_desc* const* descs, c
     DCV_RETURN_LAUNCH();
 }
 
-int dcv_conv2d_fwd_prepared(const dcv_conv2d_desc* d, const float* x, const float* w, const void* filter, const float* bias, float* y, void* stream) {
+int dcv_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d) {
+    if (!desc_ok(d) || d->groups != 1 || dcv_conv2d_filter_bytes(d, 0) == 0) return 0;
+    return dcv_mfma_conv2d_supported(d, 0) ? dcv_mfma_conv2d_fwd_stats_rows(d) : dcv_direct_conv2d_fwd_stats_rows(d);
+}
+
+int dcv_conv2d_fwd_prepared(const dcv_conv2d_desc* d, const float* x, const float* w, const void* filter, const float* bias, float* y, double* stats, void* stream) {
     DCV_CHECK_ARG(desc_ok(d) && x && w && y);
     if (d->groups != 1) return DCV_ERR_UNSUPPORTED;
     const size_t fb = dcv_conv2d_filter_bytes(d, 0);
-    if (fb == 0) return dcv_direct_conv2d_fwd(d, x, w, bias, y, nullptr, 0, dcv_stream(stream));
+    if (fb == 0) return stats ? DCV_ERR_UNSUPPORTED : dcv_direct_conv2d_fwd(d, x, w, bias, y, nullptr, 0, dcv_stream(stream));
     DCV_CHECK_ARG(filter != nullptr);
-    if (dcv_mfma_conv2d_supported(d, 0)) return dcv_mfma_conv2d_fwd(d, x, w, bias, y, const_cast<void*>(filter), fb, dcv_stream(stream), true);
-    return dcv_direct_conv2d_fwd(d, x, w, bias, y, const_cast<void*>(filter), fb, dcv_stream(stream), true);
+    if (dcv_mfma_conv2d_supported(d, 0)) return dcv_mfma_conv2d_fwd(d, x, w, bias, y, const_cast<void*>(filter), fb, dcv_stream(stream), true, stats);
+    return dcv_direct_conv2d_fwd(d, x, w, bias, y, const_cast<void*>(filter), fb, dcv_stream(stream), true, stats);
 }
 
 int dcv_conv2d_dgrad_prepared(const dcv_conv2d_desc* d, const float* dy, const float* w, const void* filter, float* dx, void* stream) {

@@ -99,7 +99,7 @@ struct TileArgs {
 // the loop overhead are amortised over PPT independent FMA streams.
 template <int TCO, int ST, int PPT>
 __global__ __launch_bounds__(256) void conv_tile_kernel(TileArgs a, const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
-                                                         float* __restrict__ y) {
+                                                         float* __restrict__ y, double* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* xs = reinterpret_cast<float4*>(smem);            // [CC/4][nsub][XH][XW]
     const int t = threadIdx.x;
@@ -271,24 +271,43 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TileArgs a, const float*
 #pragma unroll
     for (int c = 0; c < TCO; ++c) bv[c] = (bias != nullptr && co0 + c < a.Cout) ? bias[co0 + c] : 0.f;
     const bool vec_store = (a.Cout & 3) == 0;
+    float ssum[TCO], ssq[TCO];                                // per-thread sums of the activated outputs (BatchNorm statistics partials)
+#pragma unroll
+    for (int c = 0; c < TCO; ++c) { ssum[c] = 0.f; ssq[c] = 0.f; }
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         if (!active[k]) continue;
         float* yp = y + out_off[k];
+        float o[TCO];
+#pragma unroll
+        for (int c = 0; c < TCO; ++c) { o[c] = dcv_act_apply(acc[k][c] + bv[c], a.act, a.slope); ssum[c] += o[c]; ssq[c] += o[c] * o[c]; }
         if (vec_store) {
 #pragma unroll
-            for (int c = 0; c < TCO; c += 4) {
-                if (co0 + c < a.Cout) {
-                    float4 o;
-                    o.x = dcv_act_apply(acc[k][c] + bv[c], a.act, a.slope); o.y = dcv_act_apply(acc[k][c + 1] + bv[c + 1], a.act, a.slope);
-                    o.z = dcv_act_apply(acc[k][c + 2] + bv[c + 2], a.act, a.slope); o.w = dcv_act_apply(acc[k][c + 3] + bv[c + 3], a.act, a.slope);
-                    *reinterpret_cast<float4*>(yp + c) = o;
-                }
-            }
+            for (int c = 0; c < TCO; c += 4)
+                if (co0 + c < a.Cout) *reinterpret_cast<float4*>(yp + c) = make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]);
         } else {
 #pragma unroll
             for (int c = 0; c < TCO; ++c)
-                if (co0 + c < a.Cout) yp[c] = dcv_act_apply(acc[k][c] + bv[c], a.act, a.slope);
+                if (co0 + c < a.Cout) yp[c] = o[c];
+        }
+    }
+    if (stats != nullptr) {
+        // block sums of y and y^2 per output channel -> stats[blockIdx.x][2][Cout] (fixed order: butterfly, then waves 0..3)
+        double* red = reinterpret_cast<double*>(smem);            // [4 waves][2 * TCO]; the input tile is dead
+        const int lane = t & 63, wave = t >> 6;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < TCO; ++c) {
+            const float s1 = dcv_wave_sum(ssum[c]), s2 = dcv_wave_sum(ssq[c]);     // 64 * PPT values per wave in fp32 (butterfly), fp64 from here on
+            if (lane == 0) { red[wave * 2 * TCO + c] = (double)s1; red[wave * 2 * TCO + TCO + c] = (double)s2; }
+        }
+        __syncthreads();
+        if (t < 2 * TCO) {
+            const int q = t / TCO, c = t - q * TCO;
+            if (co0 + c < a.Cout) {
+                const double v = ((red[t] + red[2 * TCO + t]) + red[4 * TCO + t]) + red[6 * TCO + t];
+                stats[((size_t)blockIdx.x * 2 + q) * a.Cout + co0 + c] = v;
+            }
         }
     }
 }
@@ -929,7 +948,7 @@ bool tile_plan(const DirectArgs& a, TileArgs* t, int* tco_out, int* ppt_out) {
     return true;
 }
 
-int run_direct(DirectArgs a, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st, bool prepared) {
+int run_direct(DirectArgs a, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st, bool prepared, double* stats = nullptr) {
     TileArgs t{}; int tco, ppt;
     if (tile_plan(a, &t, &tco, &ppt)) {
         const int tiles = (int)dcv_ceil_div(a.Cout, tco);
@@ -940,8 +959,9 @@ int run_direct(DirectArgs a, const float* x, const float* w, const float* bias, 
         const int pblocks = (total + 255) / 256 > 128 ? 128 : (total + 255) / 256;
         if (!prepared) hipLaunchKernelGGL(prep_weights_kernel, dim3((unsigned)pblocks), dim3(256), 0, st, a, w, wt, tco, tiles, t.cin_pad, 1);
         dim3 grid((unsigned)dcv_ceil_div(t.total_subtiles, t.nsub), (unsigned)tiles);
-        const size_t smem = (size_t)t.nsub * t.XH * t.XW * t.CC * sizeof(float);
-#define DCV_TILE_LAUNCH(TCO_, ST_, PPT_) hipLaunchKernelGGL((conv_tile_kernel<TCO_, ST_, PPT_>), grid, dim3(256), smem, st, t, x, wt, bias, y)
+        size_t smem = (size_t)t.nsub * t.XH * t.XW * t.CC * sizeof(float);
+        if (smem < 1024) smem = 1024;                             // the statistics epilogue reuses the tile buffer: 4 waves x 2 x TCO doubles
+#define DCV_TILE_LAUNCH(TCO_, ST_, PPT_) hipLaunchKernelGGL((conv_tile_kernel<TCO_, ST_, PPT_>), grid, dim3(256), smem, st, t, x, wt, bias, y, stats)
 #define DCV_TILE_PPT(TCO_, ST_) switch (ppt) { case 4: DCV_TILE_LAUNCH(TCO_, ST_, 4); break; case 2: DCV_TILE_LAUNCH(TCO_, ST_, 2); break; default: DCV_TILE_LAUNCH(TCO_, ST_, 1); break; }
 #define DCV_TILE_SWITCH(TCO_) switch (a.S) { case 1: DCV_TILE_PPT(TCO_, 1); break; case 3: DCV_TILE_PPT(TCO_, 3); break; case 5: DCV_TILE_PPT(TCO_, 5); break; \
                                              case 7: DCV_TILE_PPT(TCO_, 7); break; default: DCV_TILE_PPT(TCO_, 0); break; }
@@ -956,6 +976,7 @@ int run_direct(DirectArgs a, const float* x, const float* w, const float* bias, 
         return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
     }
     // generic kernel: LDS-resident filter slice, one output pixel per thread (strided dgrad gather, very wide rows)
+    if (stats != nullptr) return DCV_ERR_UNSUPPORTED;             // callers ask dcv_direct_conv2d_fwd_stats_rows first
     if (a.dgrad == 2) a.dgrad = 1;
     const int in_mode = a.in_nchw ? 2 : ((a.Cin % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) ? 0 : 1);
     const int vec = in_mode == 0 ? 4 : 1;
@@ -1026,8 +1047,15 @@ inline DirectArgs dgrad_args(const dcv_conv2d_desc* d) {
 }
 }  // namespace
 
-int dcv_direct_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st, bool prepared) {
-    return run_direct(fwd_args(d), x, w, bias, y, ws, ws_bytes, st, prepared);
+int dcv_direct_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st, bool prepared, double* stats) {
+    return run_direct(fwd_args(d), x, w, bias, y, ws, ws_bytes, st, prepared, stats);
+}
+
+int dcv_direct_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d) {
+    const DirectArgs a = fwd_args(d);
+    TileArgs t{}; int tco, ppt;
+    if (!tile_plan(a, &t, &tco, &ppt)) return 0;
+    return (int)dcv_ceil_div(t.total_subtiles, t.nsub);
 }
 
 int dcv_direct_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t st, bool prepared) {

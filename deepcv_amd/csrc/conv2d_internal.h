@@ -6,7 +6,9 @@
 size_t dcv_direct_conv2d_fwd_ws(const dcv_conv2d_desc* d);
 size_t dcv_direct_conv2d_dgrad_ws(const dcv_conv2d_desc* d);
 // `prepared`: ws already holds the prepared filter of this (d, op) (dcv_conv2d_prepare_filters); otherwise it is scratch and the filter is prepared first
-int dcv_direct_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st, bool prepared = false);
+// `stats` (nullable): per-block sums of y and y^2 per output channel, [rows][2][Cout] doubles with rows = dcv_*_conv2d_fwd_stats_rows(d) (0: unsupported)
+int dcv_direct_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st, bool prepared = false, double* stats = nullptr);
+int dcv_direct_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d);
 int dcv_direct_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t st, bool prepared = false);
 size_t dcv_direct_conv2d_wgrad_ws(const dcv_conv2d_desc* d);
 bool dcv_direct_conv2d_wgrad_fuses_bias(const dcv_conv2d_desc* d);
@@ -15,7 +17,8 @@ int dcv_direct_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const floa
 // MFMA implicit-GEMM back-end (fp32 inputs, v_mfma_f32_16x16x4_f32): wide layers (conv2d_mfma.hip)
 bool dcv_mfma_conv2d_supported(const dcv_conv2d_desc* d, int op /*0 fwd, 1 dgrad, 2 wgrad*/);
 size_t dcv_mfma_conv2d_ws(const dcv_conv2d_desc* d, int op);
-int dcv_mfma_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st, bool prepared = false);
+int dcv_mfma_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st, bool prepared = false, double* stats = nullptr);
+int dcv_mfma_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d);
 int dcv_mfma_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t st, bool prepared = false);
 int dcv_mfma_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
 

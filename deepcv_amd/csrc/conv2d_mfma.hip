@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void mfma_prep_weights_kernel(const float* __r
 
 template <int BN>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaArgs a, const float* __restrict__ x, const float* __restrict__ wb, const float* __restrict__ bias,
-                                                         float* __restrict__ y) {
+                                                         float* __restrict__ y, double* __restrict__ stats) {
     constexpr int NT = BN / 16;                                   // accumulator tiles along N per wave
     __shared__ __attribute__((aligned(16))) float As[2][MF_BM * MF_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * MF_LD];
@@ -136,17 +136,40 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaArgs a, const float*
     }
 
     // ---- epilogue: acc[i][j][reg] -> pixel m0 + wave*32 + i*16 + 4*lg + reg, channel n0 + j*16 + li
+    float ssum[NT], ssq[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int co = n0 + j * 16 + li;
         const float bv = bias ? bias[co] : 0.f;
+        ssum[j] = 0.f; ssq[j] = 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const long m = m0 + wave * 32 + i * 16 + 4 * lg + reg;
-                if (m < a.M) y[(size_t)m * a.Cout + co] = dcv_act_apply(acc[i][j][reg] + bv, a.act, a.slope);
+                if (m < a.M) {
+                    const float o = dcv_act_apply(acc[i][j][reg] + bv, a.act, a.slope);
+                    y[(size_t)m * a.Cout + co] = o;
+                    ssum[j] += o; ssq[j] += o * o;
+                }
             }
+    }
+    if (stats != nullptr) {
+        // BatchNorm statistics partials of this 128-pixel tile: lanes li, li+16, li+32, li+48 hold the same channel (fixed-order xor butterfly), then waves 0..3
+        double* red = reinterpret_cast<double*>(&As[0][0]);      // [4 waves][2][BN]; the staging buffers are dead (last loop iteration ended with a barrier)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float s1 = ssum[j], s2 = ssq[j];
+            s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (lg == 0) { red[(wave * 2 + 0) * BN + j * 16 + li] = (double)s1; red[(wave * 2 + 1) * BN + j * 16 + li] = (double)s2; }
+        }
+        __syncthreads();
+        if (t < 2 * BN) {
+            const int q = t / BN, c = t - q * BN;
+            const double v = ((red[(0 * 2 + q) * BN + c] + red[(1 * 2 + q) * BN + c]) + red[(2 * 2 + q) * BN + c]) + red[(3 * 2 + q) * BN + c];
+            stats[((size_t)blockIdx.x * 2 + q) * a.Cout + n0 + c] = v;
+        }
     }
 }
 
@@ -293,18 +316,20 @@ size_t dcv_mfma_conv2d_ws(const dcv_conv2d_desc* d, int op) {
     return dcv_align_up((size_t)d->cout * d->cin * d->r * d->s * sizeof(float), 256);
 }
 
-static int run_mfma(const MfmaArgs& a, const float* x, const float* wb, const float* bias, float* y, hipStream_t st) {
+static int run_mfma(const MfmaArgs& a, const float* x, const float* wb, const float* bias, float* y, hipStream_t st, double* stats = nullptr) {
     const int bn = pick_bn(a.Cout);
     dim3 grid((unsigned)dcv_ceil_div((size_t)a.M, MF_BM), (unsigned)(a.Cout / bn));
     switch (bn) {
-        case 64: hipLaunchKernelGGL((conv_mfma_kernel<64>), grid, dim3(256), 0, st, a, x, wb, bias, y); break;
-        case 32: hipLaunchKernelGGL((conv_mfma_kernel<32>), grid, dim3(256), 0, st, a, x, wb, bias, y); break;
-        default: hipLaunchKernelGGL((conv_mfma_kernel<16>), grid, dim3(256), 0, st, a, x, wb, bias, y); break;
+        case 64: hipLaunchKernelGGL((conv_mfma_kernel<64>), grid, dim3(256), 0, st, a, x, wb, bias, y, stats); break;
+        case 32: hipLaunchKernelGGL((conv_mfma_kernel<32>), grid, dim3(256), 0, st, a, x, wb, bias, y, stats); break;
+        default: hipLaunchKernelGGL((conv_mfma_kernel<16>), grid, dim3(256), 0, st, a, x, wb, bias, y, stats); break;
     }
     return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
 }
 
-int dcv_mfma_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st, bool prepared) {
+int dcv_mfma_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d) { return (int)dcv_ceil_div((size_t)d->n * d->ho * d->wo, MF_BM); }
+
+int dcv_mfma_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st, bool prepared, double* stats) {
     if (!ws || ws_bytes < dcv_mfma_conv2d_ws(d, 0)) return DCV_ERR_WORKSPACE;
     if (!aligned16(x) || !aligned16(ws)) return DCV_ERR_INVALID_ARG;
     float* wb = reinterpret_cast<float*>(ws);
@@ -314,7 +339,7 @@ int dcv_mfma_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w
     a.N = d->n; a.Hin = d->h; a.Win = d->w; a.Cin = d->cin; a.Hout = d->ho; a.Wout = d->wo; a.Cout = d->cout;
     a.R = d->r; a.S = d->s; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
     a.act = d->act; a.slope = d->act_slope; a.M = (long)d->n * d->ho * d->wo;
-    return run_mfma(a, x, wb, bias, y, st);
+    return run_mfma(a, x, wb, bias, y, st, stats);
 }
 
 int dcv_mfma_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t st, bool prepared) {

@@ -633,8 +633,8 @@ int dcv_bn_gn_fwd_train(const float* x, float* y, int n, int hw, int C,
                         const float* bn_gamma, const float* bn_beta, float* running_mean, float* running_var, int64_t* nbt, float momentum, float bn_eps,
                         float* bn_save_mean, float* bn_save_rstd,
                         int G, const float* gn_gamma, const float* gn_beta, float gn_eps, float* gn_save_mean, float* gn_save_rstd,
-                        void* ws, size_t ws_bytes, void* stream) {
-    DCV_CHECK_ARG(x && y && bn_save_mean && bn_save_rstd && ws && n > 0 && hw > 0 && C > 0 && G >= 0);
+                        const double* stats, int stats_rows, void* ws, size_t ws_bytes, void* stream) {
+    DCV_CHECK_ARG(x && y && bn_save_mean && bn_save_rstd && ws && n > 0 && hw > 0 && C > 0 && G >= 0 && (stats == nullptr || stats_rows > 0));
     DCV_CHECK_ARG(G == 0 || (C % G == 0 && gn_save_mean && gn_save_rstd));
     if (ws_bytes < dcv_norm_chain_workspace_bytes(n, hw, C)) return DCV_ERR_WORKSPACE;
     hipStream_t st = dcv_stream(stream);
@@ -643,10 +643,12 @@ int dcv_bn_gn_fwd_train(const float* x, float* y, int n, int hw, int C,
     float* scale_shift = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + nf_partial_bytes(n, hw, C));
     const unsigned nb = dcv_colreduce_blocks(rows, C);
     const int vec = (C % 4 == 0) ? 4 : 1;
-    SumSqLoader ld{x};
-    if (vec == 4) hipLaunchKernelGGL((colreduce2_kernel<4, SumSqLoader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
-    else hipLaunchKernelGGL((colreduce2_kernel<1, SumSqLoader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((unsigned)C), dim3(64), 0, st, partial, (int)nb, rows, C, bn_gamma, bn_beta,
+    if (stats == nullptr) {
+        SumSqLoader ld{x};
+        if (vec == 4) hipLaunchKernelGGL((colreduce2_kernel<4, SumSqLoader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
+        else hipLaunchKernelGGL((colreduce2_kernel<1, SumSqLoader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
+    }
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((unsigned)C), dim3(64), 0, st, stats ? stats : partial, stats ? stats_rows : (int)nb, rows, C, bn_gamma, bn_beta,
                        running_mean, running_var, nbt, momentum, bn_eps, bn_save_mean, bn_save_rstd, scale_shift);
     if (G > 0) {
         const size_t smem = 2 * (size_t)C * sizeof(double) + (size_t)4 * C * sizeof(float) + (size_t)2 * DCV_CR_THREADS * vec * sizeof(float);

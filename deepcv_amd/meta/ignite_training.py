@@ -277,6 +277,7 @@ class GraphedTrainStep:
         hooks_were = None
         if self.reducer is not None:
             hooks_were, self.reducer.enabled = self.reducer.enabled, False     # no collectives inside the captured backward
+        self._seed = torch.ones((), dtype=torch.float32, device=dev)
         torch.cuda.synchronize(dev)
         self.graph_fb = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_fb, stream=self.stream):
@@ -290,7 +291,8 @@ class GraphedTrainStep:
                 self._nat.check(self._nat.lib.dcv_publish_scalars(self.mailbox.data_ptr(), ptrs, len(terms), self.mailbox.data_ptr() + self._PUB_VALS,
                                                                   self.mailbox.data_ptr() + self._PUB_SEQ, self._nat.current_stream(dev)), 'dcv_publish_scalars')
                 self._publishes = True
-            self.static_losses[MAIN_TRAINING_LOSS_NAME].backward()
+            main = self.static_losses[MAIN_TRAINING_LOSS_NAME]
+            main.backward(gradient=self._seed if main.shape == self._seed.shape else None)   # preallocated seed: no ones-fill kernel per replay
             if self.reducer is None:
                 self.optimizer.step()
         if self.reducer is not None:

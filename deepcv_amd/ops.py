@@ -84,14 +84,22 @@ def _conv_desc(x_shape, w_shape, stride, padding, dilation, x_layout, act, slope
                           x_layout, act, slope)
 
 
-def _conv_fwd_launch(d, x, weight, bias, y, st):
-    """ Forward convolution; through the prepared-filter cache when `weight` is a plain parameter (see `deepcv_amd/filters.py`). """
+def _conv_fwd_launch(d, x, weight, bias, y, st, want_stats: bool = False):
+    """ Forward convolution; through the prepared-filter cache when `weight` is a plain parameter (see `deepcv_amd/filters.py`).  With `want_stats`
+    returns the [rows][2][Cout] fp64 BatchNorm statistics partials emitted by the kernel's epilogue (None when that kernel cannot). """
     f = filters.get(weight, d, 0)
     if f is not None:
-        nat.check(lib.dcv_conv2d_fwd_prepared(d, x.data_ptr(), weight.data_ptr(), f.data_ptr(), nat.ptr(bias), y.data_ptr(), st), 'dcv_conv2d_fwd_prepared')
-        return
+        stats = None
+        if want_stats:
+            rows = int(lib.dcv_conv2d_fwd_stats_rows(d))
+            if rows > 0:
+                stats = torch.empty((rows, 2, d.cout), dtype=torch.float64, device=x.device)
+        nat.check(lib.dcv_conv2d_fwd_prepared(d, x.data_ptr(), weight.data_ptr(), f.data_ptr(), nat.ptr(bias), y.data_ptr(), nat.ptr(stats), st),
+                  'dcv_conv2d_fwd_prepared')
+        return stats
     ws = _ws(lib.dcv_conv2d_fwd_workspace_bytes(d), x.device)
     nat.check(lib.dcv_conv2d_fwd(d, x.data_ptr(), weight.data_ptr(), nat.ptr(bias), y.data_ptr(), ws.data_ptr(), ws.numel(), st), 'dcv_conv2d_fwd')
+    return None
 
 
 def _conv_dgrad_launch(dd, dz, weight, dx, st):
@@ -321,7 +329,7 @@ class _ConvNormLayerFn(torch.autograd.Function):
         d = _conv_desc(x.shape, weight.shape, stride, padding, dilation, layout, act, slope)
         dev, st = x.device, nat.current_stream(x.device)
         y = torch.empty((d.n, d.cout, d.ho, d.wo), dtype=x.dtype, device=dev, memory_format=_CL)
-        _conv_fwd_launch(d, x, weight, bias, y, st)
+        stats = _conv_fwd_launch(d, x, weight, bias, y, st, want_stats=True)
         out = torch.empty_like(y)
         c, hw = d.cout, d.ho * d.wo
         bn_mean = torch.empty(c, dtype=torch.float32, device=dev)
@@ -331,7 +339,8 @@ class _ConvNormLayerFn(torch.autograd.Function):
         ws = _ws(lib.dcv_norm_chain_workspace_bytes(d.n, hw, c), dev)
         nat.check(lib.dcv_bn_gn_fwd_train(y.data_ptr(), out.data_ptr(), d.n, hw, c, nat.ptr(bn_w), nat.ptr(bn_b), nat.ptr(running_mean), nat.ptr(running_var),
                                           nat.ptr(nbt), momentum, bn_eps, bn_mean.data_ptr(), bn_rstd.data_ptr(), groups, nat.ptr(gn_w), nat.ptr(gn_b), gn_eps,
-                                          nat.ptr(gn_mean), nat.ptr(gn_rstd), ws.data_ptr(), ws.numel(), st), 'dcv_bn_gn_fwd_train')
+                                          nat.ptr(gn_mean), nat.ptr(gn_rstd), nat.ptr(stats), 0 if stats is None else stats.shape[0],
+                                          ws.data_ptr(), ws.numel(), st), 'dcv_bn_gn_fwd_train')
         ctx.desc, ctx.cfg = d, cfg
         ctx.save_for_backward(x, weight, bias, y, bn_w, bn_b, bn_mean, bn_rstd, gn_w, gn_mean, gn_rstd)
         return out

@@ -60,6 +60,7 @@ class GradientAllReducer:
         self.enabled = True
         self.overlap = overlap
         self.force_collective = False     # rehearsal switch: run the collective even in a group of one
+        self._in_backward = False
         cap = max(1, int(bucket_cap_mb * 1024 * 1024 / 4))
         self.buckets: List[_Bucket] = []
         cur, cur_n = [], 0
@@ -109,13 +110,15 @@ class GradientAllReducer:
     def _launch(self, b: _Bucket):
         self._pack(b)
         if self.world_size > 1 or self.force_collective:
-            if self.comm_stream is not None:
+            if self.comm_stream is not None and self._in_backward:
+                # launched from an autograd hook: the collective goes to the communication stream so that it overlaps the rest of the backward pass
                 self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))   # bucket must be packed before the collective reads it
                 with torch.cuda.stream(self.comm_stream):
                     self._all_reduce_mean(b)
                     b.event = torch.cuda.Event()
                     b.event.record(self.comm_stream)
             else:
+                # launched from finish() (nothing left to overlap with): stay on the compute stream, two cross-stream hops less per step
                 self._all_reduce_mean(b)
         b.launched = True
 
@@ -133,7 +136,11 @@ class GradientAllReducer:
         b = self._bucket_of[p]
         b.pending.discard(p)
         if not b.pending and not b.launched:
-            self._launch(b)
+            self._in_backward = True
+            try:
+                self._launch(b)
+            finally:
+                self._in_backward = False
 
     def finish(self):
         """ Completes the exchange: launches buckets the hooks did not (unused parameters, hooks disabled), makes the compute stream wait for the
