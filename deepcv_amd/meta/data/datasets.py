@@ -10,7 +10,7 @@ from typing import Any, Iterable, Optional, Sequence, Tuple, Union
 import torch
 from torch.utils.data import DataLoader, Dataset
 
-__all__ = ['dataloader_prefetch_batches', 'PrefetchedLoader', 'SyntheticImageDataset']
+__all__ = ['dataloader_prefetch_batches', 'PrefetchedLoader', 'SyntheticImageDataset', 'SyntheticUint8ImageDataset', 'DeviceNormalize']
 
 
 def _to_device(batch, device, non_blocking=True):
@@ -35,14 +35,43 @@ def _record_stream(batch, stream):
             _record_stream(b, stream)
 
 
+class DeviceNormalize:
+    """ `ToTensor()` + `Normalize(mean, std)` of the reference's preprocessing recipe (`conf/base/parameters.yml:196-201`) applied ON THE DEVICE to a batch
+    of raw `[N, H, W, C]` uint8 images (`dcv_images_u8_normalize`): the loader ships a quarter of the bytes over PCIe and no CPU worker converts pixels.
+    Returns `[N, C, H, W]` fp32 (NCHW memory, what the first convolution reads in place). """
+
+    def __init__(self, mean: Sequence[float], std: Sequence[float]):
+        self.mean, self.std = [float(m) for m in mean], [float(s) for s in std]
+        self._dev = {}
+
+    def __call__(self, images_u8: torch.Tensor) -> torch.Tensor:
+        from ... import _native as nat
+        if images_u8.dtype != torch.uint8 or images_u8.dim() != 4:
+            raise TypeError(f'DeviceNormalize expects a [N, H, W, C] uint8 batch, got {images_u8.dtype} {tuple(images_u8.shape)}')
+        nat.require_device(images_u8, 'DeviceNormalize input')
+        n, h, w, c = images_u8.shape
+        if c != len(self.mean):
+            raise ValueError(f'DeviceNormalize: {c} channels but {len(self.mean)} mean values')
+        images_u8 = images_u8.contiguous()
+        dev = images_u8.device
+        if dev not in self._dev:
+            self._dev[dev] = (torch.tensor(self.mean, dtype=torch.float32, device=dev), torch.tensor([1.0 / s for s in self.std], dtype=torch.float32, device=dev))
+        mean, inv_std = self._dev[dev]
+        out = torch.empty((n, c, h, w), dtype=torch.float32, device=dev)
+        nat.check(nat.lib.dcv_images_u8_normalize(images_u8.data_ptr(), out.data_ptr(), n, h, w, c, nat.LAYOUT_NCHW, mean.data_ptr(), inv_std.data_ptr(),
+                                                  nat.current_stream(dev)), 'dcv_images_u8_normalize')
+        return out
+
+
 class PrefetchedLoader:
     """ Iterates `dataloader`, keeping one batch in flight to `device` on a side stream.  Exposes `batch_size`, `dataset`, `sampler`, `__len__` of the
     wrapped loader; iterators carry the `_prefetched_batch` attribute the reference's `process_function` probes (`ignite_training.py:235`). """
 
-    def __init__(self, dataloader: DataLoader, device: Union[str, torch.device]):
+    def __init__(self, dataloader: DataLoader, device: Union[str, torch.device], device_transform=None):
         self.dataloader = dataloader
         self.device = torch.device(device)
         self.copy_stream = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
+        self.device_transform = device_transform     # e.g. `DeviceNormalize`: applied to the first element of every batch on the copy stream
 
     def __len__(self):
         return len(self.dataloader)
@@ -51,12 +80,12 @@ class PrefetchedLoader:
         return getattr(self.dataloader, name)
 
     def __iter__(self):
-        return _PrefetchIterator(iter(self.dataloader), self.device, self.copy_stream)
+        return _PrefetchIterator(iter(self.dataloader), self.device, self.copy_stream, self.device_transform)
 
 
 class _PrefetchIterator:
-    def __init__(self, it, device, copy_stream):
-        self._it, self._device, self._stream = it, device, copy_stream
+    def __init__(self, it, device, copy_stream, device_transform=None):
+        self._it, self._device, self._stream, self._transform = it, device, copy_stream, device_transform
         self._prefetched_batch = None
         self._event = None
         self._fetch()
@@ -69,11 +98,18 @@ class _PrefetchIterator:
             return
         if self._stream is not None:
             with torch.cuda.stream(self._stream):
-                self._prefetched_batch = _to_device(batch, self._device, non_blocking=True)
+                self._prefetched_batch = self._apply(_to_device(batch, self._device, non_blocking=True))
                 self._event = torch.cuda.Event()
                 self._event.record(self._stream)
         else:
-            self._prefetched_batch = _to_device(batch, self._device)
+            self._prefetched_batch = self._apply(_to_device(batch, self._device))
+
+    def _apply(self, batch):
+        if self._transform is None:
+            return batch
+        if isinstance(batch, (list, tuple)):
+            return type(batch)((self._transform(batch[0]), *batch[1:]))
+        return self._transform(batch)
 
     def __iter__(self):
         return self
@@ -90,7 +126,7 @@ class _PrefetchIterator:
         return batch
 
 
-def dataloader_prefetch_batches(dataloader: DataLoader, device: Union[None, str, torch.device] = None) -> Union[DataLoader, PrefetchedLoader]:
+def dataloader_prefetch_batches(dataloader: DataLoader, device: Union[None, str, torch.device] = None, device_transform=None) -> Union[DataLoader, PrefetchedLoader]:
     """ Returns a loader which prefetches the next batch to `device` during compute (reference `datasets.py:76-115`).  Like the reference, nothing is
     patched (the loader is returned as is) when `device` is `None` / CPU; the device is resolved lazily (SURVEY.md Appendix A #37). """
     if device is None:
@@ -100,7 +136,7 @@ def dataloader_prefetch_batches(dataloader: DataLoader, device: Union[None, str,
         return dataloader
     if not getattr(dataloader, 'pin_memory', False):
         logging.warning(f'Warning: `pin_memory=False`: batches of `{type(dataloader).__name__}` are prefetched through pageable memory (slower H2D copies)')
-    return PrefetchedLoader(dataloader, device)
+    return PrefetchedLoader(dataloader, device, device_transform)
 
 
 class SyntheticImageDataset(Dataset):
@@ -110,6 +146,24 @@ class SyntheticImageDataset(Dataset):
     def __init__(self, size: int, image_shape: Sequence[int] = (3, 32, 32), num_classes: int = 10, seed: int = 434546):
         g = torch.Generator().manual_seed(seed)
         self.images = torch.randn(size, *image_shape, generator=g)
+        self.targets = torch.randint(0, num_classes, (size,), generator=g, dtype=torch.int64)
+        self.classes = list(range(num_classes))
+
+    def __len__(self):
+        return self.images.shape[0]
+
+    def __getitem__(self, idx) -> Tuple[torch.Tensor, torch.Tensor]:
+        return self.images[idx], self.targets[idx]
+
+
+class SyntheticUint8ImageDataset(Dataset):
+    """ Raw-pixel twin of `SyntheticImageDataset`: `[H, W, C]` uint8 images (the storage format of CIFAR / ImageNet decoders) to be normalised on the
+    device by `DeviceNormalize`. """
+
+    def __init__(self, size: int, image_shape: Sequence[int] = (3, 32, 32), num_classes: int = 10, seed: int = 434546):
+        g = torch.Generator().manual_seed(seed)
+        c, h, w = image_shape
+        self.images = torch.randint(0, 256, (size, h, w, c), generator=g, dtype=torch.uint8)
         self.targets = torch.randint(0, num_classes, (size,), generator=g, dtype=torch.int64)
         self.classes = list(range(num_classes))
 

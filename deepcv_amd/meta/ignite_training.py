@@ -343,7 +343,8 @@ def train(hp: HYPERPARAMS_T, model: torch.nn.Module, losses: LOSS_FN_TERMS_T = N
 
     Args:
         - hp: hyper-parameters; required: `optimizer_opts`, `epochs`, `batch_size`; optional: see `TRAINING_HP_DEFAULTS` below (reference `:201-203`), plus
-          `hip_graph` (None = auto: capture the step into a hipGraph when the model has fewer than 5M parameters), `num_workers`, `bucket_cap_mb`.
+          `hip_graph` (None = auto: capture the step into a hipGraph when the model has fewer than 5M parameters), `num_workers`, `bucket_cap_mb`,
+          `device_transform` (callable applied on the device to the images of every prefetched batch, e.g. `DeviceNormalize` for raw uint8 pixels).
         - model: `torch.nn.Module` to train (e.g. a `DeepcvModule`)
         - losses (alias `loss`, Appendix A #24): a loss callable/module, a sequence, or a mapping name -> loss; see `loss_weights`
         - datasets: `{'trainset': ..., 'validset': ...[, 'testset': ...]}` (or a 2/3-tuple in that order) of `torch.utils.data.Dataset`s (Appendix A #29)
@@ -357,7 +358,7 @@ def train(hp: HYPERPARAMS_T, model: torch.nn.Module, losses: LOSS_FN_TERMS_T = N
     TRAINING_HP_DEFAULTS = {'optimizer_opts': ..., 'epochs': ..., 'batch_size': ..., 'scheduler': None, 'output_path': Path.cwd() / 'data/04_training/',
                             'log_output_dir_to_mlflow': True, 'validate_every_epochs': 1, 'save_every_iters': 1000, 'log_grads_every_iters': -1,
                             'log_progress_every_iters': 100, 'seed': None, 'prefetch_batches': True, 'resume_from': '', 'crash_iteration': -1,
-                            'deterministic_cudnn': False, 'use_sync_batch_norm': False, 'hip_graph': None, 'num_workers': None, 'bucket_cap_mb': 32.}
+                            'deterministic_cudnn': False, 'use_sync_batch_norm': False, 'hip_graph': None, 'num_workers': None, 'bucket_cap_mb': 32., 'device_transform': None}
     losses = losses if losses is not None else loss
     backend_conf = backend_conf if backend_conf is not None else BackendConfig()
     metrics = dict(metrics) if metrics else {}
@@ -398,7 +399,7 @@ def train(hp: HYPERPARAMS_T, model: torch.nn.Module, losses: LOSS_FN_TERMS_T = N
             train_sampler = sampler = torch.utils.data.distributed.DistributedSampler(ds, seed=hp['seed'] or 0)   # sampler over the DATASET (Appendix A #31)
         dl = DataLoader(ds, batch_size=hp['batch_size'] if is_train else hp['batch_size'] * 32, shuffle=(is_train and sampler is None), sampler=sampler,
                         num_workers=num_workers, pin_memory=backend_conf.is_cuda, persistent_workers=num_workers > 0)   # pin for GPU training (Appendix A #30)
-        dataloaders[n] = dataloader_prefetch_batches(dl, device=device) if (hp['prefetch_batches'] and backend_conf.is_cuda) else dl
+        dataloaders[n] = dataloader_prefetch_batches(dl, device=device, device_transform=hp['device_transform']) if (hp['prefetch_batches'] and backend_conf.is_cuda) else dl
     trainset = dataloaders['trainset']
     validset = dataloaders.get('validset', None)
 

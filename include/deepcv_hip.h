@@ -206,6 +206,16 @@ int dcv_add(const float* a, const float* b, float* out, size_t numel, void* stre
 int dcv_scale(const float* a, float alpha, float* out, size_t numel, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Input side: uint8 images -> normalised fp32 activations on the device, fusing torchvision's ToTensor (HWC u8 -> CHW f32 / 255)
+ * and Normalize ((x - mean[c]) / std[c]) of the reference's preprocessing recipe (conf/base/parameters.yml:196-201) with the layout change:
+ *   src: [N][H][W][C] uint8 (how image datasets store pixels; a quarter of the fp32 bytes over PCIe)
+ *   dst: fp32, DCV_LAYOUT_NCHW (what `DeepcvModule.forward` is fed, base_module.py:113) or DCV_LAYOUT_NHWC
+ * mean / inv_std: device arrays of C floats.
+ * ------------------------------------------------------------------------------------------------- */
+int dcv_images_u8_normalize(const unsigned char* src, float* dst, int n, int h, int w, int c, int dst_layout,
+                            const float* mean, const float* inv_std, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Indirect batch staging: up to DCV_MAX_COPY_JOBS (src, dst, bytes) copies whose descriptors are READ BY THE KERNEL AT RUN TIME from `jobs`, a block
  * of device-visible (pinned host or device) memory.  Captured as the first node of the training-step hipGraph it lets every replay fetch a NEW batch
  * (and the optimizer's scalar hyper-parameters) although the graph's kernel arguments are frozen: the host only rewrites the mailbox before

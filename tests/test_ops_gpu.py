@@ -416,3 +416,33 @@ def test_prepared_filter_cache_tracks_weight_changes(device):
     w.data.add_(0.25)                                # invisible to autograd's version counter
     filters.invalidate_all()
     same()
+
+
+@pytest.mark.parametrize('shape', [(8, 32, 32, 3), (3, 17, 9, 1), (2, 224, 224, 3), (5, 8, 8, 4)], ids=str)
+def test_device_normalize_u8(device, shape):
+    """ `DeviceNormalize` (dcv_images_u8_normalize) == torchvision's ToTensor + Normalize on raw HWC uint8 pixels (reference parameters.yml:196-201). """
+    from deepcv_amd.meta.data.datasets import DeviceNormalize
+    g = torch.Generator().manual_seed(5)
+    img = torch.randint(0, 256, shape, generator=g, dtype=torch.uint8)
+    c = shape[-1]
+    mean, std = [0.491, 0.482, 0.447, 0.5][:c], [0.247, 0.243, 0.262, 0.25][:c]
+    ref = (img.permute(0, 3, 1, 2).double() / 255.0 - torch.tensor(mean, dtype=torch.float64).view(1, c, 1, 1)) / torch.tensor(std, dtype=torch.float64).view(1, c, 1, 1)
+    out = DeviceNormalize(mean, std)(img.to(device))
+    assert out.shape == ref.shape and out.is_contiguous()
+    _check(f'u8norm{shape}', out, ref.float(), 1e-6)
+
+
+def test_prefetched_loader_with_device_transform(device):
+    from torch.utils.data import DataLoader
+    from deepcv_amd.meta.data.datasets import DeviceNormalize, SyntheticUint8ImageDataset, dataloader_prefetch_batches
+    ds = SyntheticUint8ImageDataset(40, (3, 32, 32), 10, seed=3)
+    tf = DeviceNormalize([0.5, 0.5, 0.5], [0.25, 0.25, 0.25])
+    loader = dataloader_prefetch_batches(DataLoader(ds, batch_size=16, pin_memory=True), device=device, device_transform=tf)
+    seen = 0
+    for x, y in loader:
+        assert x.is_cuda and x.dtype == torch.float32 and x.shape[1:] == (3, 32, 32) and y.is_cuda
+        ref = (ds.images[seen:seen + x.shape[0]].permute(0, 3, 1, 2).float() / 255.0 - 0.5) / 0.25
+        torch.cuda.synchronize()
+        assert torch.allclose(x.cpu(), ref, atol=1e-6)
+        seen += x.shape[0]
+    assert seen == 40
