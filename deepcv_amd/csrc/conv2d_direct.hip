@@ -615,7 +615,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tiled_kernel(WgTiledArgs a, co
     }
 }
 
-// ------------------------------------------------------------------------------------------------ sliding-window weight gradient (stride_w = dil_w = 1)
+// ------------------------------------------------------------------------------------------------ sliding-window weight gradient (stride_w in {1, 2}, dil_w = 1)
 // Same tiling as above (zero-padded x halo tile + dy tile of TH output rows in LDS, one partial slab per block, ordered second stage), but a thread owns
 // a unit = (VEC input channels, filter ROW r, 4 output channels) with ALL S taps of that row, and walks SEG consecutive output pixels of one image row at
 // a time: the SEG+S-1 input pixels under the window and the SEG dy vectors are fetched with one ds_read each and feed SEG*S*4*VEC FMAs from registers
@@ -643,7 +643,7 @@ __device__ __forceinline__ void dcv_divmod(int j, int d, int shift, int& q, int&
     if (shift >= 0) { q = j >> shift; r = j & (d - 1); } else { q = j / d; r = j - q * d; }
 }
 
-template <int S, int VEC, int SEG>
+template <int S, int VEC, int SEG, int SW>
 __global__ __launch_bounds__(256) void conv_wgrad_slide_kernel(WgSlideArgs a, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xs = reinterpret_cast<float*>(smem);                       // [XH][xrs]   (pixel-major, channel fastest)
@@ -771,12 +771,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_slide_kernel(WgSlideArgs a, co
             const int dsg = a.nsub / th, dhl = a.nsub - dsg * th;
             for (int seg = sub; seg < nsegs; seg += a.nsub) {
                 const int w0 = sg * SEG;
-                const float* xp = xs + (size_t)(hl * a.sh + r * a.dh) * a.xrs + w0 * a.Cin + ci0;
+                const float* xp = xs + (size_t)(hl * a.sh + r * a.dh) * a.xrs + w0 * SW * a.Cin + ci0;
                 const float* gp = dys + (size_t)hl * a.drs + w0 * tcob + 4 * cog;
-                float xw[SEG + S - 1][VEC];
+                constexpr int XWN = (SEG - 1) * SW + S;                // input pixels under the window of SEG outputs
+                float xw[XWN][VEC];
                 float4 g[SEG];
 #pragma unroll
-                for (int k = 0; k < SEG + S - 1; ++k) {
+                for (int k = 0; k < XWN; ++k) {
                     if constexpr (VEC == 4) {
                         const float4 v = *reinterpret_cast<const float4*>(xp + k * a.Cin);
                         xw[k][0] = v.x; xw[k][1] = v.y; xw[k][2] = v.z; xw[k][3] = v.w;
@@ -796,10 +797,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_slide_kernel(WgSlideArgs a, co
                     for (int s = 0; s < S; ++s)
 #pragma unroll
                         for (int v = 0; v < VEC; ++v) {
-                            acc[s][0][v] = fmaf(g[p].x, xw[p + s][v], acc[s][0][v]);
-                            acc[s][1][v] = fmaf(g[p].y, xw[p + s][v], acc[s][1][v]);
-                            acc[s][2][v] = fmaf(g[p].z, xw[p + s][v], acc[s][2][v]);
-                            acc[s][3][v] = fmaf(g[p].w, xw[p + s][v], acc[s][3][v]);
+                            acc[s][0][v] = fmaf(g[p].x, xw[p * SW + s][v], acc[s][0][v]);
+                            acc[s][1][v] = fmaf(g[p].y, xw[p * SW + s][v], acc[s][1][v]);
+                            acc[s][2][v] = fmaf(g[p].z, xw[p * SW + s][v], acc[s][2][v]);
+                            acc[s][3][v] = fmaf(g[p].w, xw[p * SW + s][v], acc[s][3][v]);
                         }
                 sg += dsg; hl += dhl;
                 if (hl >= th) { hl -= th; ++sg; }
@@ -1111,7 +1112,7 @@ bool wgrad_slide_plan(const dcv_conv2d_desc* d, bool fuse_db, WgSlideArgs* a, in
     static int enabled = -1;
     if (enabled < 0) { const char* e = getenv("DCV_WGRAD_SLIDE"); enabled = e ? atoi(e) : 1; }
     if (!enabled) return false;
-    if (d->stride_w != 1 || d->dil_w != 1) return false;
+    if ((d->stride_w != 1 && d->stride_w != 2) || d->dil_w != 1) return false;
     if (!(d->s == 1 || d->s == 3 || d->s == 5 || d->s == 7)) return false;
     const int v = (d->x_layout == DCV_LAYOUT_NHWC && d->cin % 4 == 0) ? 4 : 1;
     const int civ = d->cin / v;
@@ -1126,7 +1127,7 @@ bool wgrad_slide_plan(const dcv_conv2d_desc* d, bool fuse_db, WgSlideArgs* a, in
     a->sh = d->stride_h; a->ph = d->pad_h; a->pw = d->pad_w; a->dh = d->dil_h;
     a->x_nchw = d->x_layout == DCV_LAYOUT_NCHW;
     a->WoP = (d->wo + sg - 1) / sg * sg;
-    a->XW = a->WoP + d->s - 1;
+    a->XW = (a->WoP - 1) * d->stride_w + d->s;
     a->spr = a->WoP / sg;
     a->civ = civ; a->cogb = cogb; a->units = civ * d->r * cogb; a->nsub = nt / a->units;
     auto log2_or_neg = [](int n) { int sft = 0; while ((1 << sft) < n) ++sft; return (1 << sft) == n ? sft : -1; };
@@ -1164,13 +1165,13 @@ bool wgrad_slide_plan(const dcv_conv2d_desc* d, bool fuse_db, WgSlideArgs* a, in
     return true;
 }
 
-template <int VEC>
+template <int VEC, int SW>
 void launch_wgrad_slide(int s, dim3 grid, size_t smem, hipStream_t st, const WgSlideArgs& a, const float* x, const float* dy, float* partial) {
     switch (s) {
-        case 1: hipLaunchKernelGGL((conv_wgrad_slide_kernel<1, VEC, 4>), grid, dim3(a.nt), smem, st, a, x, dy, partial); break;
-        case 3: hipLaunchKernelGGL((conv_wgrad_slide_kernel<3, VEC, 4>), grid, dim3(a.nt), smem, st, a, x, dy, partial); break;
-        case 5: hipLaunchKernelGGL((conv_wgrad_slide_kernel<5, VEC, 4>), grid, dim3(a.nt), smem, st, a, x, dy, partial); break;
-        default: hipLaunchKernelGGL((conv_wgrad_slide_kernel<7, VEC, (VEC == 4 ? 2 : 4)>), grid, dim3(a.nt), smem, st, a, x, dy, partial); break;
+        case 1: hipLaunchKernelGGL((conv_wgrad_slide_kernel<1, VEC, 4, SW>), grid, dim3(a.nt), smem, st, a, x, dy, partial); break;
+        case 3: hipLaunchKernelGGL((conv_wgrad_slide_kernel<3, VEC, 4, SW>), grid, dim3(a.nt), smem, st, a, x, dy, partial); break;
+        case 5: hipLaunchKernelGGL((conv_wgrad_slide_kernel<5, VEC, 4, SW>), grid, dim3(a.nt), smem, st, a, x, dy, partial); break;
+        default: hipLaunchKernelGGL((conv_wgrad_slide_kernel<7, VEC, (VEC == 4 ? 2 : 4), SW>), grid, dim3(a.nt), smem, st, a, x, dy, partial); break;
     }
 }
 
@@ -1210,8 +1211,10 @@ int dcv_direct_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const floa
         if (wgrad_slide_plan(d, db != nullptr, &sa, &sv, &sseg, &sb, &sy, &ssm) && (sv == 1 || (reinterpret_cast<uintptr_t>(x) & 15) == 0) && (reinterpret_cast<uintptr_t>(dy) & 15) == 0) {
             if (!ws || ws_bytes < (size_t)sb * sa.slab * sizeof(float)) return DCV_ERR_WORKSPACE;
             dim3 grid((unsigned)sb, (unsigned)sy);
-            if (sv == 4) launch_wgrad_slide<4>(d->s, grid, ssm, st, sa, x, dy, partial);
-            else launch_wgrad_slide<1>(d->s, grid, ssm, st, sa, x, dy, partial);
+            if (sv == 4 && d->stride_w == 1) launch_wgrad_slide<4, 1>(d->s, grid, ssm, st, sa, x, dy, partial);
+            else if (sv == 4) launch_wgrad_slide<4, 2>(d->s, grid, ssm, st, sa, x, dy, partial);
+            else if (d->stride_w == 1) launch_wgrad_slide<1, 1>(d->s, grid, ssm, st, sa, x, dy, partial);
+            else launch_wgrad_slide<1, 2>(d->s, grid, ssm, st, sa, x, dy, partial);
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)dcv_ceil_div(sa.slab, 32)), dim3(1024), 0, st, partial, dw, sb, sa.wtotal, db, sa.slab);
             if (db_done) *db_done = db != nullptr;
             return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;

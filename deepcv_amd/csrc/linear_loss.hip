@@ -9,6 +9,7 @@
 
 namespace {
 
+#define LIN_OCHUNK 64
 // one wave per sample row; lanes stride over K.  The row of x is read ONCE into registers (up to XR vectors per lane) and 8 output features are
 // accumulated together, so that the loads of 8 weight rows are in flight at once and the 8 wave reductions are independent (a per-feature loop
 // re-reading x was a chain of 10 dependent global-memory latencies for the 10-class head).
@@ -35,7 +36,9 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
                 for (int v = 0; v < VEC; ++v) xv[i][v] = 0.f;
             }
         }
-        for (int o0 = 0; o0 < O; o0 += OB) {
+        // blockIdx.y selects a chunk of LIN_OCHUNK output features (wide heads: 1000 classes -> 16 chunks of waves instead of one serial loop)
+        const int o_begin = blockIdx.y * LIN_OCHUNK, o_end = (o_begin + LIN_OCHUNK < O) ? o_begin + LIN_OCHUNK : O;
+        for (int o0 = o_begin; o0 < o_end; o0 += OB) {
             float acc[OB];
 #pragma unroll
             for (int j = 0; j < OB; ++j) acc[j] = 0.f;
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
         }
         return;
     }
-    for (int o = 0; o < O; ++o) {
+    for (int o = blockIdx.y * LIN_OCHUNK; o < O && o < (int)(blockIdx.y + 1) * LIN_OCHUNK; ++o) {
         const float* wr = w + (size_t)o * K;
         float acc = 0.f;
         for (int k = lane; k < KV; k += 64) {
@@ -210,9 +213,9 @@ extern "C" {
 int dcv_linear_fwd(const float* x, const float* w, const float* bias, float* y, int n, int K, int O, int act, float slope, void* stream) {
     DCV_CHECK_ARG(x && w && y && n > 0 && K > 0 && O > 0 && act >= DCV_ACT_NONE && act <= DCV_ACT_TANH);
     hipStream_t st = dcv_stream(stream);
-    const unsigned grid = (unsigned)dcv_ceil_div(n, 4);
-    if (K % 4 == 0 && aligned16(x) && aligned16(w)) hipLaunchKernelGGL((linear_fwd_kernel<4>), dim3(grid), dim3(256), 0, st, x, w, bias, y, n, K, O, act, slope);
-    else hipLaunchKernelGGL((linear_fwd_kernel<1>), dim3(grid), dim3(256), 0, st, x, w, bias, y, n, K, O, act, slope);
+    const dim3 grid((unsigned)dcv_ceil_div(n, 4), (unsigned)dcv_ceil_div(O, LIN_OCHUNK));
+    if (K % 4 == 0 && aligned16(x) && aligned16(w)) hipLaunchKernelGGL((linear_fwd_kernel<4>), grid, dim3(256), 0, st, x, w, bias, y, n, K, O, act, slope);
+    else hipLaunchKernelGGL((linear_fwd_kernel<1>), grid, dim3(256), 0, st, x, w, bias, y, n, K, O, act, slope);
     DCV_RETURN_LAUNCH();
 }
 

@@ -1,0 +1,34 @@
+"""Throughput of the build-authored wide specs (BASELINE.json configs 3 / 5) on one GPU: fwd + CE + bwd + SGD-momentum step, fp32.  usage: wide_bench.py <spec> <N> [steps] [graph]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from deepcv_amd import modules, optim
+from deepcv_amd.classification.image import create_model
+from deepcv_amd.meta.data.datasets import SyntheticImageDataset
+from deepcv_amd.meta.ignite_training import GraphedTrainStep, _setup_losses
+from deepcv_amd.utils import load_parameters
+spec = sys.argv[1] if len(sys.argv) > 1 else 'cifar100_deep_model'
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+graph = len(sys.argv) > 4 and sys.argv[4] == 'graph'
+shape, nc = ((3, 224, 224), 1000) if 'resnet' in spec else ((3, 32, 32), 100)
+dev = torch.device('cuda:0')
+P = load_parameters()
+torch.manual_seed(563454)
+model = create_model({'trainset': SyntheticImageDataset(2, shape, nc)}, P[spec]).to(dev)
+print(spec, 'params', sum(p.numel() for p in model.parameters()))
+opt = optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4)
+losses, weights = _setup_losses(modules.CrossEntropyLoss(), None, dev)
+step = GraphedTrainStep(model, opt, losses, weights)
+g = torch.Generator().manual_seed(1)
+batches = [(torch.randn(n, *shape, generator=g).to(dev), torch.randint(0, nc, (n,), generator=g).to(dev)) for _ in range(4)]
+def one(i):
+    x, y = batches[i % 4]
+    if graph:
+        step(x, y); return step.loss_values()['main_loss']
+    out, _ = step._on_side_stream(step._eager, x, y); return out['main_loss'].item()
+for i in range(4): one(i)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for i in range(steps): last = one(i)
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print(f'{spec} N={n} {"graph" if graph else "eager"}: {dt / steps * 1e3:.2f} ms/step, {n * steps / dt:.0f} img/s, loss {last:.4f}')
