@@ -186,9 +186,11 @@ struct MfmaWgArgs {
 #define WG_T 64                    // tile of output channels (rows) and of input channels (columns) per block
 #define WG_LD 68                   // padded row length of the [16 pixels][64 channels] LDS tiles
 
+#define WG_PS 32                   // pixels per pipeline step (one barrier per step: 32 MFMAs per wave between barriers)
+
 __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(MfmaWgArgs a, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial) {
-    __shared__ __attribute__((aligned(16))) float Gs[2][16 * WG_LD];     // dy tile  [pixel][co]
-    __shared__ __attribute__((aligned(16))) float Xs[2][16 * WG_LD];     // x  tile  [pixel][ci]
+    __shared__ __attribute__((aligned(16))) float Gs[2][WG_PS * WG_LD];     // dy tile  [pixel][co]
+    __shared__ __attribute__((aligned(16))) float Xs[2][WG_PS * WG_LD];     // x  tile  [pixel][ci]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 15, lg = lane >> 4;
     const int ci_tiles = a.Cin / WG_T;
@@ -198,24 +200,30 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(MfmaWgArgs a, cons
     const long mb = (long)blockIdx.x * a.m_per_chunk;
     long me = mb + a.m_per_chunk; if (me > a.M) me = a.M;
 
-    // staging role: thread loads pixel row (t >> 4) (0..15), float4 column (t & 15) of both tiles
+    // staging role: thread loads pixel rows (t >> 4) and (t >> 4) + 16 of the step, float4 column (t & 15), of both tiles
     const int prow = t >> 4, pc4 = t & 15;
-    auto load_tiles = [&](long mbase, float4& g, float4& xv) {
-        const long m = mbase + prow;
-        const bool ok = m < me;
-        const long mm = ok ? m : mb;
-        const int wo = (int)(mm % a.Wo); const long r1 = mm / a.Wo; const int ho = (int)(r1 % a.Ho); const int n = (int)(r1 / a.Ho);
-        const float4 gg = *reinterpret_cast<const float4*>(dy + (size_t)mm * a.Cout + co0 + 4 * pc4);
-        const int hi = ho * a.sh - a.ph + r * a.dh, wi = wo * a.sw - a.pw + s * a.dw;
-        const bool xok = ok && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-        const int hic = hi < 0 ? 0 : (hi >= a.H ? a.H - 1 : hi), wic = wi < 0 ? 0 : (wi >= a.W ? a.W - 1 : wi);
-        const float4 xx = *reinterpret_cast<const float4*>(x + (((size_t)n * a.H + hic) * a.W + wic) * a.Cin + ci0 + 4 * pc4);
-        g = ok ? gg : make_float4(0.f, 0.f, 0.f, 0.f);
-        xv = xok ? xx : make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_tiles = [&](long mbase, float4 (&g)[2], float4 (&xv)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long m = mbase + prow + 16 * h;
+            const bool ok = m < me;
+            const long mm = ok ? m : mb;
+            const int wo = (int)(mm % a.Wo); const long r1 = mm / a.Wo; const int ho = (int)(r1 % a.Ho); const int n = (int)(r1 / a.Ho);
+            const float4 gg = *reinterpret_cast<const float4*>(dy + (size_t)mm * a.Cout + co0 + 4 * pc4);
+            const int hi = ho * a.sh - a.ph + r * a.dh, wi = wo * a.sw - a.pw + s * a.dw;
+            const bool xok = ok && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+            const int hic = hi < 0 ? 0 : (hi >= a.H ? a.H - 1 : hi), wic = wi < 0 ? 0 : (wi >= a.W ? a.W - 1 : wi);
+            const float4 xx = *reinterpret_cast<const float4*>(x + (((size_t)n * a.H + hic) * a.W + wic) * a.Cin + ci0 + 4 * pc4);
+            g[h] = ok ? gg : make_float4(0.f, 0.f, 0.f, 0.f);
+            xv[h] = xok ? xx : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     };
-    auto store_tiles = [&](int buf, const float4& g, const float4& xv) {
-        *reinterpret_cast<float4*>(&Gs[buf][prow * WG_LD + 4 * pc4]) = g;
-        *reinterpret_cast<float4*>(&Xs[buf][prow * WG_LD + 4 * pc4]) = xv;
+    auto store_tiles = [&](int buf, const float4 (&g)[2], const float4 (&xv)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            *reinterpret_cast<float4*>(&Gs[buf][(prow + 16 * h) * WG_LD + 4 * pc4]) = g[h];
+            *reinterpret_cast<float4*>(&Xs[buf][(prow + 16 * h) * WG_LD + 4 * pc4]) = xv[h];
+        }
     };
 
     // wave w owns output-channel rows [16w, 16w+16) x all 64 input-channel columns: 4 accumulator tiles
@@ -223,21 +231,22 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(MfmaWgArgs a, cons
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float4 g, xv;
+    float4 g[2], xv[2];
     load_tiles(mb, g, xv);
     store_tiles(0, g, xv);
     __syncthreads();
     int it = 0;
-    for (long m = mb; m < me; m += 16, ++it) {
+    for (long m = mb; m < me; m += WG_PS, ++it) {
         const int buf = it & 1;
-        const bool has_next = (m + 16) < me;
-        if (has_next) load_tiles(m + 16, g, xv);
+        const bool has_next = (m + WG_PS) < me;
+        if (has_next) load_tiles(m + WG_PS, g, xv);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const float av = Gs[buf][(4 * lg + kk) * WG_LD + wave * 16 + li];               // A'[i = co][k = pixel 4g+kk]
+        for (int kk = 0; kk < WG_PS / 4; ++kk) {
+            const int prw = (kk >> 2) * 16 + 4 * lg + (kk & 3);                             // k permutation: lane group g, step kk -> pixel row of the step
+            const float av = Gs[buf][prw * WG_LD + wave * 16 + li];                        // A'[i = co][k = pixel]
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float bvv = Xs[buf][(4 * lg + kk) * WG_LD + j * 16 + li];             // B'[k][j = ci]
+                const float bvv = Xs[buf][prw * WG_LD + j * 16 + li];                      // B'[k][j = ci]
                 acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bvv, acc[j], 0, 0, 0);
             }
         }
@@ -290,7 +299,7 @@ inline void wg_plan(const dcv_conv2d_desc* d, MfmaWgArgs* a, int* chunks) {
     if (ch > max_by_bytes) ch = max_by_bytes;
     if (ch < 1) ch = 1;
     long mpc = (a->M + ch - 1) / ch;
-    mpc = (mpc + 15) / 16 * 16;
+    mpc = (mpc + WG_PS - 1) / WG_PS * WG_PS;
     a->m_per_chunk = mpc;
     *chunks = (int)((a->M + mpc - 1) / mpc);
 }
