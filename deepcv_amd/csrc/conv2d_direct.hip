@@ -292,22 +292,19 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TileArgs a, const float*
         }
     }
     if (stats != nullptr) {
-        // block sums of y and y^2 per output channel -> stats[blockIdx.x][2][Cout] (fixed order: butterfly, then waves 0..3)
-        double* red = reinterpret_cast<double*>(smem);            // [4 waves][2 * TCO]; the input tile is dead
+        // block sums of y and y^2 per output channel -> stats[blockIdx.x][2][Cout].  All 2*TCO per-thread sums go through LDS ([quantity][256], conflict
+        // free); quantity q is then summed by wave q % 4: 4 values per lane + one butterfly, instead of 2*TCO butterflies per wave (fixed order throughout).
+        float* redf = reinterpret_cast<float*>(smem);              // [2 * TCO][256]; the input tile is dead
         const int lane = t & 63, wave = t >> 6;
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < TCO; ++c) {
-            const float s1 = dcv_wave_sum(ssum[c]), s2 = dcv_wave_sum(ssq[c]);     // 64 * PPT values per wave in fp32 (butterfly), fp64 from here on
-            if (lane == 0) { red[wave * 2 * TCO + c] = (double)s1; red[wave * 2 * TCO + TCO + c] = (double)s2; }
-        }
+        for (int c = 0; c < TCO; ++c) { redf[c * 256 + t] = ssum[c]; redf[(TCO + c) * 256 + t] = ssq[c]; }
         __syncthreads();
-        if (t < 2 * TCO) {
-            const int q = t / TCO, c = t - q * TCO;
-            if (co0 + c < a.Cout) {
-                const double v = ((red[t] + red[2 * TCO + t]) + red[4 * TCO + t]) + red[6 * TCO + t];
-                stats[((size_t)blockIdx.x * 2 + q) * a.Cout + co0 + c] = v;
-            }
+        for (int q = wave; q < 2 * TCO; q += 4) {
+            const float* rq = redf + q * 256 + lane;
+            const float v = dcv_wave_sum((rq[0] + rq[64]) + (rq[128] + rq[192]));
+            const int c = q < TCO ? q : q - TCO;
+            if (lane == 0 && co0 + c < a.Cout) stats[((size_t)blockIdx.x * 2 + (q < TCO ? 0 : 1)) * a.Cout + co0 + c] = (double)v;
         }
     }
 }
@@ -961,7 +958,7 @@ int run_direct(DirectArgs a, const float* x, const float* w, const float* bias, 
         if (!prepared) hipLaunchKernelGGL(prep_weights_kernel, dim3((unsigned)pblocks), dim3(256), 0, st, a, w, wt, tco, tiles, t.cin_pad, 1);
         dim3 grid((unsigned)dcv_ceil_div(t.total_subtiles, t.nsub), (unsigned)tiles);
         size_t smem = (size_t)t.nsub * t.XH * t.XW * t.CC * sizeof(float);
-        if (smem < 1024) smem = 1024;                             // the statistics epilogue reuses the tile buffer: 4 waves x 2 x TCO doubles
+        if (smem < (size_t)2 * tco * 1024) smem = (size_t)2 * tco * 1024;   // the statistics epilogue reuses the tile buffer: [2 * TCO][256] floats
 #define DCV_TILE_LAUNCH(TCO_, ST_, PPT_) hipLaunchKernelGGL((conv_tile_kernel<TCO_, ST_, PPT_>), grid, dim3(256), smem, st, t, x, wt, bias, y, stats)
 #define DCV_TILE_PPT(TCO_, ST_) switch (ppt) { case 4: DCV_TILE_LAUNCH(TCO_, ST_, 4); break; case 2: DCV_TILE_LAUNCH(TCO_, ST_, 2); break; default: DCV_TILE_LAUNCH(TCO_, ST_, 1); break; }
 #define DCV_TILE_SWITCH(TCO_) switch (a.S) { case 1: DCV_TILE_PPT(TCO_, 1); break; case 3: DCV_TILE_PPT(TCO_, 3); break; case 5: DCV_TILE_PPT(TCO_, 5); break; \
