@@ -49,21 +49,23 @@ __global__ __launch_bounds__(256) void mfma_prep_weights_kernel(const float* __r
     }
 }
 
-template <int BN>
+// BMR: A rows staged per thread = accumulator tiles along M per wave; block tile = (64 * BMR) pixels x BN channels
+template <int BN, int BMR>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaArgs a, const float* __restrict__ x, const float* __restrict__ wb, const float* __restrict__ bias,
                                                          float* __restrict__ y, double* __restrict__ stats) {
     constexpr int NT = BN / 16;                                   // accumulator tiles along N per wave
-    __shared__ __attribute__((aligned(16))) float As[2][MF_BM * MF_LD];
+    constexpr int BM = 64 * BMR;
+    __shared__ __attribute__((aligned(16))) float As[2][BM * MF_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * MF_LD];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const long m0 = (long)blockIdx.x * MF_BM;
+    const long m0 = (long)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
 
     // ---- staging roles: thread stages A rows (t >> 2) and (t >> 2) + 64, channel quad q = t & 3; B row (t >> 2) when < BN
     const int q = t & 3;
-    int an[2], aho[2], awo[2]; bool arow_ok[2];
+    int an[BMR], aho[BMR], awo[BMR]; bool arow_ok[BMR];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < BMR; ++j) {
         const long m = m0 + (t >> 2) + 64 * j;
         arow_ok[j] = m < a.M;
         const long mm = arow_ok[j] ? m : 0;
@@ -74,9 +76,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaArgs a, const float*
     const int taps = a.R * a.S;
     const size_t wb_row = (size_t)taps * a.Cin;                   // floats per output channel in wb
 
-    auto load_a = [&](int r, int s, int ci0, float4 (&v)[2]) {
+    auto load_a = [&](int r, int s, int ci0, float4 (&v)[BMR]) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < BMR; ++j) {
             const int hi = aho[j] * a.sh - a.ph + r * a.dh, wi = awo[j] * a.sw - a.pw + s * a.dw;
             const bool ok = arow_ok[j] && hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win;
             const int hic = hi < 0 ? 0 : (hi >= a.Hin ? a.Hin - 1 : hi), wic = wi < 0 ? 0 : (wi >= a.Win ? a.Win - 1 : wi);
@@ -88,21 +90,21 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaArgs a, const float*
         if (!b_active) return make_float4(0.f, 0.f, 0.f, 0.f);
         return *reinterpret_cast<const float4*>(wb + (size_t)(n0 + brow) * wb_row + (size_t)tap * a.Cin + ci0 + 4 * q);
     };
-    auto store_stage = [&](int buf, const float4 (&va)[2], const float4& vb) {
+    auto store_stage = [&](int buf, const float4 (&va)[BMR], const float4& vb) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(&As[buf][((t >> 2) + 64 * j) * MF_LD + 4 * q]) = va[j];
+        for (int j = 0; j < BMR; ++j) *reinterpret_cast<float4*>(&As[buf][((t >> 2) + 64 * j) * MF_LD + 4 * q]) = va[j];
         if (b_active) *reinterpret_cast<float4*>(&Bs[buf][brow * MF_LD + 4 * q]) = vb;
     };
 
-    f32x4 acc[2][NT];
+    f32x4 acc[BMR][NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < BMR; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int cchunks = a.Cin / MF_BK;
     const int nchunks = taps * cchunks;
-    float4 va[2]; float4 vb;
+    float4 va[BMR]; float4 vb;
     load_a(0, 0, 0, va); vb = load_b(0, 0);
     store_stage(0, va, vb);
     __syncthreads();
@@ -118,15 +120,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaArgs a, const float*
         if (has_next) { load_a(nr, ns, ncc * MF_BK, va); vb = load_b(nr * a.S + ns, ncc * MF_BK); }
 
         // ---- MFMAs on buffer `buf`
-        f32x4 af[2], bf[NT];
+        f32x4 af[BMR], bf[NT];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f32x4*>(&As[buf][(wave * 32 + i * 16 + li) * MF_LD + 4 * lg]);
+        for (int i = 0; i < BMR; ++i) af[i] = *reinterpret_cast<const f32x4*>(&As[buf][(wave * 16 * BMR + i * 16 + li) * MF_LD + 4 * lg]);
 #pragma unroll
         for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(&Bs[buf][(j * 16 + li) * MF_LD + 4 * lg]);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < BMR; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
 
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaArgs a, const float*
         r = nr; s = ns; cc = ncc;
     }
 
-    // ---- epilogue: acc[i][j][reg] -> pixel m0 + wave*32 + i*16 + 4*lg + reg, channel n0 + j*16 + li
+    // ---- epilogue: acc[i][j][reg] -> pixel m0 + wave*16*BMR + i*16 + 4*lg + reg, channel n0 + j*16 + li
     float ssum[NT], ssq[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -143,10 +145,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaArgs a, const float*
         const float bv = bias ? bias[co] : 0.f;
         ssum[j] = 0.f; ssq[j] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < BMR; ++i)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const long m = m0 + wave * 32 + i * 16 + 4 * lg + reg;
+                const long m = m0 + wave * 16 * BMR + i * 16 + 4 * lg + reg;
                 if (m < a.M) {
                     const float o = dcv_act_apply(acc[i][j][reg] + bv, a.act, a.slope);
                     y[(size_t)m * a.Cout + co] = o;
@@ -325,18 +327,33 @@ size_t dcv_mfma_conv2d_ws(const dcv_conv2d_desc* d, int op) {
     return dcv_align_up((size_t)d->cout * d->cin * d->r * d->s * sizeof(float), 256);
 }
 
+// 256-pixel tiles (BMR = 4) raise the FLOPs per staged byte by a quarter (the kernel is cache-bandwidth bound at ~60 % of the MFMA peak); used when the
+// launch still has more than ~3 blocks per CU
+inline int pick_bmr(long M, int cout, int bn) {
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("DCV_MFMA_BMR"); forced = e ? atoi(e) : 0; }
+    if (forced == 2 || forced == 4) return forced;
+    const long blocks256 = ((M + 255) / 256) * (cout / bn);
+    return (bn == 64 && blocks256 >= 3 * DCV_NUM_CU) ? 4 : 2;
+}
+
 static int run_mfma(const MfmaArgs& a, const float* x, const float* wb, const float* bias, float* y, hipStream_t st, double* stats = nullptr) {
     const int bn = pick_bn(a.Cout);
-    dim3 grid((unsigned)dcv_ceil_div((size_t)a.M, MF_BM), (unsigned)(a.Cout / bn));
-    switch (bn) {
-        case 64: hipLaunchKernelGGL((conv_mfma_kernel<64>), grid, dim3(256), 0, st, a, x, wb, bias, y, stats); break;
-        case 32: hipLaunchKernelGGL((conv_mfma_kernel<32>), grid, dim3(256), 0, st, a, x, wb, bias, y, stats); break;
-        default: hipLaunchKernelGGL((conv_mfma_kernel<16>), grid, dim3(256), 0, st, a, x, wb, bias, y, stats); break;
+    const int bmr = pick_bmr(a.M, a.Cout, bn);
+    dim3 grid((unsigned)dcv_ceil_div((size_t)a.M, (size_t)64 * bmr), (unsigned)(a.Cout / bn));
+    if (bmr == 4) hipLaunchKernelGGL((conv_mfma_kernel<64, 4>), grid, dim3(256), 0, st, a, x, wb, bias, y, stats);
+    else switch (bn) {
+        case 64: hipLaunchKernelGGL((conv_mfma_kernel<64, 2>), grid, dim3(256), 0, st, a, x, wb, bias, y, stats); break;
+        case 32: hipLaunchKernelGGL((conv_mfma_kernel<32, 2>), grid, dim3(256), 0, st, a, x, wb, bias, y, stats); break;
+        default: hipLaunchKernelGGL((conv_mfma_kernel<16, 2>), grid, dim3(256), 0, st, a, x, wb, bias, y, stats); break;
     }
     return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
 }
 
-int dcv_mfma_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d) { return (int)dcv_ceil_div((size_t)d->n * d->ho * d->wo, MF_BM); }
+int dcv_mfma_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d) {
+    const long M = (long)d->n * d->ho * d->wo;
+    return (int)dcv_ceil_div((size_t)M, (size_t)64 * pick_bmr(M, d->cout, pick_bn(d->cout)));
+}
 
 int dcv_mfma_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st, bool prepared, double* stats) {
     if (!ws || ws_bytes < dcv_mfma_conv2d_ws(d, 0)) return DCV_ERR_WORKSPACE;
