@@ -78,6 +78,10 @@ _SIGNATURES = {
     'dcv_batchnorm_fwd_train': (_c_int, [_P, _P, _c_size_t, _c_int, _P, _P, _P, _P, _P, _c_float, _c_float, _P, _P, _P, _c_size_t, _P]),
     'dcv_batchnorm_fwd_eval': (_c_int, [_P, _P, _c_size_t, _c_int, _P, _P, _P, _P, _c_float, _P, _c_size_t, _P]),
     'dcv_batchnorm_bwd': (_c_int, [_P, _P, _P, _c_size_t, _c_int, _P, _P, _P, _P, _P, _P, _c_size_t, _P]),
+    'dcv_batchnorm_stats': (_c_int, [_P, _c_size_t, _c_int, _P, _P, _c_size_t, _P]),
+    'dcv_batchnorm_fwd_from_sums': (_c_int, [_P, _P, _c_size_t, _c_int, _P, ctypes.c_double, _P, _P, _P, _P, _P, _c_float, _c_float, _P, _P, _P, _c_size_t, _P]),
+    'dcv_batchnorm_bwd_stats': (_c_int, [_P, _P, _c_size_t, _c_int, _P, _P, _P, _P, _c_size_t, _P]),
+    'dcv_batchnorm_bwd_from_sums': (_c_int, [_P, _P, _P, _c_size_t, _c_int, _P, _P, _P, _P, ctypes.c_double, _P, _c_size_t, _P]),
     'dcv_groupnorm_workspace_bytes': (_c_size_t, [_c_int, _c_int]),
     'dcv_groupnorm_fwd': (_c_int, [_P, _P, _c_int, _c_int, _c_int, _c_int, _P, _P, _c_float, _P, _P, _P]),
     'dcv_groupnorm_bwd': (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _P, _c_size_t, _P]),

@@ -504,6 +504,55 @@ __global__ __launch_bounds__(256) void nf_bn_apply_act_bwd_ew_kernel(NfApplyActL
     }
 }
 
+// ================================================================================================ split-phase BatchNorm (cross-GPU statistics)
+// `use_sync_batch_norm` (reference ignite_training.py:386-388, torch.nn.SyncBatchNorm): every reduction over the batch is cut in two so that the caller
+// can all-reduce the per-channel sums between the phases (collective C4 of SURVEY.md §2.3, 2 * C doubles).
+//   forward : (1) sums[2][C] = sum x, sum x^2 of the local rows   ->  all-reduce  ->  (2) statistics over `total_rows`, running stats, y
+//   backward: (1) sums[2][C] = sum dy, sum dy * xhat (local; also the local d_beta, d_gamma, which the gradient all-reduce averages like any parameter
+//             gradient)                                            ->  all-reduce  ->  (2) dx with the GLOBAL means of those sums
+__global__ void reduce_partials_kernel(const double* __restrict__ partial, int nb, int Q, int C, double* __restrict__ sums) {
+    // one wave per (quantity, channel); lanes stride over the partial rows, fixed-order butterfly
+    const int qc = blockIdx.x, lane = threadIdx.x;
+    double s = 0.0;
+    for (int b = lane; b < nb; b += DCV_WAVE) s += partial[(size_t)b * Q * C + qc];
+    s = dcv_wave_sum(s);
+    if (lane == 0) sums[qc] = s;
+}
+
+__global__ void bn_finalize_from_sums_kernel(const double* __restrict__ sums, double total_rows, int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                             float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps,
+                                             float* __restrict__ save_mean, float* __restrict__ save_rstd, float* __restrict__ scale_shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) nbt[0] += 1;
+    if (c >= C) return;
+    const double n = total_rows;
+    const double mean = sums[c] / n;
+    double var = sums[C + c] / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    save_mean[c] = (float)mean;
+    save_rstd[c] = rstd;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) {
+        const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * rstd;
+    scale_shift[c] = sc;
+    scale_shift[C + c] = b - (float)mean * sc;
+}
+
+__global__ void bn_coef_from_sums_kernel(const double* __restrict__ sums, double total_rows, int C, const float* __restrict__ gamma, const float* __restrict__ rstd,
+                                         float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float g = gamma ? gamma[c] : 1.f;
+    coef[c] = g * rstd[c];
+    coef[C + c] = (float)(sums[c] / total_rows);
+    coef[2 * C + c] = (float)(sums[C + c] / total_rows);
+}
+
 inline size_t bn_ws_partial_bytes(size_t rows, int C) { return dcv_align_up((size_t)dcv_colreduce_blocks(rows, C) * 2 * C * sizeof(double), 256); }
 
 }  // namespace
@@ -706,6 +755,71 @@ int dcv_bn_gn_act_bwd(const float* dout, const float* x, float* dz, int n, int h
         const size_t nv = rows * (size_t)C / vec;
         if (vec == 4) hipLaunchKernelGGL((nf_bn_apply_act_bwd_ew_kernel<4>), dim3(dcv_stream_grid(nv, 256)), dim3(256), 0, st, ld, nv, C);
         else hipLaunchKernelGGL((nf_bn_apply_act_bwd_ew_kernel<1>), dim3(dcv_stream_grid(nv, 256)), dim3(256), 0, st, ld, nv, C);
+    }
+    DCV_RETURN_LAUNCH();
+}
+
+
+// ------------------------------------------------------------------------------------------------ split-phase BatchNorm entry points
+int dcv_batchnorm_stats(const float* x, size_t rows, int C, double* sums, void* ws, size_t ws_bytes, void* stream) {
+    DCV_CHECK_ARG(x && sums && ws && rows > 0 && C > 0);
+    if (ws_bytes < dcv_batchnorm_workspace_bytes(rows, C)) return DCV_ERR_WORKSPACE;
+    hipStream_t st = dcv_stream(stream);
+    double* partial = reinterpret_cast<double*>(ws);
+    const unsigned nb = dcv_colreduce_blocks(rows, C);
+    SumSqLoader ld{x};
+    if (C % 4 == 0) hipLaunchKernelGGL((colreduce2_kernel<4, SumSqLoader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
+    else hipLaunchKernelGGL((colreduce2_kernel<1, SumSqLoader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(2 * C)), dim3(64), 0, st, partial, (int)nb, 2, C, sums);
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_batchnorm_fwd_from_sums(const float* x, float* y, size_t rows, int C, const double* sums, double total_rows, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps,
+                                float* save_mean, float* save_rstd, void* ws, size_t ws_bytes, void* stream) {
+    DCV_CHECK_ARG(x && y && sums && save_mean && save_rstd && ws && rows > 0 && C > 0 && total_rows >= (double)rows);
+    if (ws_bytes < dcv_batchnorm_workspace_bytes(rows, C)) return DCV_ERR_WORKSPACE;
+    hipStream_t st = dcv_stream(stream);
+    float* scale_shift = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + bn_ws_partial_bytes(rows, C));
+    hipLaunchKernelGGL(bn_finalize_from_sums_kernel, dim3((unsigned)dcv_ceil_div(C, 64)), dim3(64), 0, st, sums, total_rows, C, gamma, beta, running_mean, running_var, nbt,
+                       momentum, eps, save_mean, save_rstd, scale_shift);
+    if (C % 4 == 0) {
+        const size_t nv = rows * (size_t)C / 4;
+        hipLaunchKernelGGL((affine_apply_kernel<4>), dim3(dcv_stream_grid(nv, 256)), dim3(256), 0, st, x, y, nv, C, scale_shift);
+    } else {
+        const size_t nv = rows * (size_t)C;
+        hipLaunchKernelGGL((affine_apply_kernel<1>), dim3(dcv_stream_grid(nv, 256)), dim3(256), 0, st, x, y, nv, C, scale_shift);
+    }
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_batchnorm_bwd_stats(const float* dy, const float* x, size_t rows, int C, const float* save_mean, const float* save_rstd, double* sums,
+                            void* ws, size_t ws_bytes, void* stream) {
+    DCV_CHECK_ARG(dy && x && save_mean && save_rstd && sums && ws && rows > 0 && C > 0);
+    if (ws_bytes < dcv_batchnorm_workspace_bytes(rows, C)) return DCV_ERR_WORKSPACE;
+    hipStream_t st = dcv_stream(stream);
+    double* partial = reinterpret_cast<double*>(ws);
+    const unsigned nb = dcv_colreduce_blocks(rows, C);
+    BnBwdLoader ld{dy, x, save_mean, save_rstd};
+    if (C % 4 == 0) hipLaunchKernelGGL((colreduce2_kernel<4, BnBwdLoader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
+    else hipLaunchKernelGGL((colreduce2_kernel<1, BnBwdLoader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)(2 * C)), dim3(64), 0, st, partial, (int)nb, 2, C, sums);
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_batchnorm_bwd_from_sums(const float* dy, const float* x, float* dx, size_t rows, int C, const float* gamma, const float* save_mean, const float* save_rstd,
+                                const double* sums, double total_rows, void* ws, size_t ws_bytes, void* stream) {
+    DCV_CHECK_ARG(dy && x && dx && save_mean && save_rstd && sums && ws && rows > 0 && C > 0 && total_rows >= (double)rows);
+    if (ws_bytes < dcv_batchnorm_workspace_bytes(rows, C)) return DCV_ERR_WORKSPACE;
+    hipStream_t st = dcv_stream(stream);
+    float* coef = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + bn_ws_partial_bytes(rows, C));
+    hipLaunchKernelGGL(bn_coef_from_sums_kernel, dim3((unsigned)dcv_ceil_div(C, 64)), dim3(64), 0, st, sums, total_rows, C, gamma, save_rstd, coef);
+    if (C % 4 == 0) {
+        const size_t nv = rows * (size_t)C / 4;
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(dcv_stream_grid(nv, 256)), dim3(256), 0, st, dy, x, dx, nv, C, save_mean, save_rstd, coef);
+    } else {
+        const size_t nv = rows * (size_t)C;
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(dcv_stream_grid(nv, 256)), dim3(256), 0, st, dy, x, dx, nv, C, save_mean, save_rstd, coef);
     }
     DCV_RETURN_LAUNCH();
 }

@@ -416,6 +416,8 @@ def train(hp: HYPERPARAMS_T, model: torch.nn.Module, losses: LOSS_FN_TERMS_T = N
     use_graph = hp['hip_graph']
     if use_graph is None:
         use_graph = backend_conf.is_cuda and sum(p.numel() for p in model.parameters()) < 5_000_000
+    if hp['use_sync_batch_norm'] and backend_conf.distributed:
+        use_graph = False    # SyncBatchNorm all-reduces statistics inside forward and backward: collectives are not captured into the step graph
     graphed_step = GraphedTrainStep(model, optimizer, losses, weights, reducer=reducer) if (use_graph and backend_conf.is_cuda) else None
     if graphed_step is not None and reducer is not None:
         reducer.remove_hooks()   # the captured backward cannot launch collectives; finish() reduces everything after the replay
@@ -561,8 +563,9 @@ def _setup_distributed_training(device, backend_conf: BackendConfig, model: torc
     backend_conf._refresh_from_process_group()
     if backend_conf.is_cuda:
         torch.cuda.set_device(backend_conf.device)
-    if use_sync_batch_norm and any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in model.modules()):
-        raise NotImplementedError('`use_sync_batch_norm` (collective C4, SURVEY.md §2.3) is not implemented yet: BatchNorm statistics stay per GPU (the reference default)')
+    if use_sync_batch_norm:
+        from .. import modules as native
+        native.SyncBatchNorm2d.convert(model)      # statistics over all ranks (collective C4); such layers run op by op, not through the fused layer chain
     wrapped = DataParallelModel(model, bucket_cap_mb=bucket_cap_mb, overlap=True)
     return wrapped, wrapped.reducer
 

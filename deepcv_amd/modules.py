@@ -17,7 +17,7 @@ import torch.nn
 from . import _native as nat
 from . import ops
 
-__all__ = ['shape_inference', 'in_shape_inference', 'Conv2d', 'Linear', 'BatchNorm1d', 'BatchNorm2d', 'GroupNorm', 'AvgPool2d', 'MaxPool2d', 'Flatten',
+__all__ = ['shape_inference', 'in_shape_inference', 'Conv2d', 'Linear', 'BatchNorm1d', 'BatchNorm2d', 'SyncBatchNorm2d', 'GroupNorm', 'AvgPool2d', 'MaxPool2d', 'Flatten',
            'ReLU', 'LeakyReLU', 'Sigmoid', 'Tanh', 'CrossEntropyLoss', 'NATIVE_MODULE_TYPES', 'native_type', 'native_activation', 'is_native']
 
 _state = threading.local()
@@ -106,6 +106,28 @@ class _NativeBatchNorm(torch.nn.modules.batchnorm._BatchNorm):
 
 class BatchNorm2d(_NativeBatchNorm, torch.nn.BatchNorm2d):
     pass
+
+
+class SyncBatchNorm2d(BatchNorm2d):
+    """ `BatchNorm2d` whose training statistics span the process group (`torch.nn.SyncBatchNorm`, reference `ignite_training.py:386-388`); same
+    parameters, buffers and `state_dict` keys.  Evaluation mode is plain BatchNorm on the running statistics. """
+    process_group = None
+
+    @classmethod
+    def convert(cls, module: torch.nn.Module, process_group=None) -> torch.nn.Module:
+        """ In-place analogue of `torch.nn.SyncBatchNorm.convert_sync_batchnorm` for native modules. """
+        for m in module.modules():
+            if type(m) is BatchNorm2d:
+                m.__class__ = cls
+                m.process_group = process_group
+        return module
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not self.training or _shape_only(x) or not self.track_running_stats or self.momentum is None:
+            return super().forward(x)
+        self._check_input_dim(x)
+        return ops.sync_batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, self.num_batches_tracked, self.momentum, self.eps,
+                                   self.process_group)
 
 
 class BatchNorm1d(_NativeBatchNorm, torch.nn.BatchNorm1d):

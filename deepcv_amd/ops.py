@@ -13,7 +13,7 @@ from . import _native as nat
 from . import filters
 from ._native import lib
 
-__all__ = ['conv2d', 'conv_norm_layer', 'activation', 'batch_norm', 'group_norm', 'pool2d', 'interpolate_bilinear', 'concat_channels', 'add_tensors', 'flatten_nchw_order',
+__all__ = ['conv2d', 'conv_norm_layer', 'activation', 'batch_norm', 'sync_batch_norm', 'group_norm', 'pool2d', 'interpolate_bilinear', 'concat_channels', 'add_tensors', 'flatten_nchw_order',
            'linear', 'cross_entropy', 'act_code', 'to_nhwc', 'nchw_to_nhwc']
 
 _CL = torch.channels_last
@@ -266,6 +266,63 @@ def batch_norm(x, gamma, beta, running_mean, running_var, num_batches_tracked, t
     nat.check(lib.dcv_batchnorm_fwd_eval(x.data_ptr(), y.data_ptr(), rows, c, nat.ptr(gamma), nat.ptr(beta), running_mean.data_ptr(), running_var.data_ptr(),
                                          float(eps), ws.data_ptr(), ws.numel(), nat.current_stream(x.device)), 'dcv_batchnorm_fwd_eval')
     return y
+
+
+class _SyncBatchNormFn(torch.autograd.Function):
+    """ BatchNorm with statistics over every rank of `group` (`torch.nn.SyncBatchNorm` semantics, reference `ignite_training.py:386-388`): the two
+    per-channel reductions of each direction are all-reduced between the split-phase kernels (collective C4: 2*C + 1 doubles). """
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, group, all_reduce):
+        _require_f32(x, gamma, beta, running_mean, running_var)
+        x, rows, c = _rows_channels(x)
+        dev, st = x.device, nat.current_stream(x.device)
+        y = torch.empty_like(x)
+        save_mean = torch.empty(c, dtype=torch.float32, device=dev)
+        save_rstd = torch.empty(c, dtype=torch.float32, device=dev)
+        sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)      # [sum x | sum x^2 | local row count]
+        ws = _ws(lib.dcv_batchnorm_workspace_bytes(rows, c), dev)
+        nat.check(lib.dcv_batchnorm_stats(x.data_ptr(), rows, c, sums.data_ptr(), ws.data_ptr(), ws.numel(), st), 'dcv_batchnorm_stats')
+        sums[2 * c] = float(rows)
+        all_reduce(sums, group)
+        total_rows = float(sums[2 * c].item())
+        nat.check(lib.dcv_batchnorm_fwd_from_sums(x.data_ptr(), y.data_ptr(), rows, c, sums.data_ptr(), total_rows, nat.ptr(gamma), nat.ptr(beta),
+                                                  nat.ptr(running_mean), nat.ptr(running_var), nat.ptr(num_batches_tracked), momentum, eps,
+                                                  save_mean.data_ptr(), save_rstd.data_ptr(), ws.data_ptr(), ws.numel(), st), 'dcv_batchnorm_fwd_from_sums')
+        ctx.rows, ctx.c, ctx.total_rows, ctx.group, ctx.all_reduce = rows, c, total_rows, group, all_reduce
+        ctx.save_for_backward(x, gamma, save_mean, save_rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, save_mean, save_rstd = ctx.saved_tensors
+        dev, st, c = dy.device, nat.current_stream(dy.device), ctx.c
+        dy = to_nhwc(dy) if dy.dim() == 4 else dy.contiguous()
+        dx = torch.empty_like(x)
+        sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
+        ws = _ws(lib.dcv_batchnorm_workspace_bytes(ctx.rows, c), dev)
+        nat.check(lib.dcv_batchnorm_bwd_stats(dy.data_ptr(), x.data_ptr(), ctx.rows, c, save_mean.data_ptr(), save_rstd.data_ptr(), sums.data_ptr(),
+                                              ws.data_ptr(), ws.numel(), st), 'dcv_batchnorm_bwd_stats')
+        # local parameter gradients (the gradient all-reduce averages them like every other parameter gradient)
+        dbeta = sums[:c].float() if gamma is not None else None
+        dgamma = sums[c:].float() if gamma is not None else None
+        ctx.all_reduce(sums, ctx.group)
+        nat.check(lib.dcv_batchnorm_bwd_from_sums(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), ctx.rows, c, nat.ptr(gamma), save_mean.data_ptr(), save_rstd.data_ptr(),
+                                                  sums.data_ptr(), ctx.total_rows, ws.data_ptr(), ws.numel(), st), 'dcv_batchnorm_bwd_from_sums')
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+def _dist_all_reduce_sum(t: torch.Tensor, group):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+def sync_batch_norm(x, gamma, beta, running_mean, running_var, num_batches_tracked, momentum: float, eps: float, group=None,
+                    all_reduce=_dist_all_reduce_sum) -> torch.Tensor:
+    """ Training-mode BatchNorm whose batch statistics span every rank of `group`.  `all_reduce(tensor, group)` sums a small fp64 tensor in place
+    over the ranks (injectable for tests). """
+    return _SyncBatchNormFn.apply(x, gamma, beta, running_mean, running_var, num_batches_tracked, float(momentum), float(eps), group, all_reduce)
 
 
 # ------------------------------------------------------------------------------------------------ group norm

@@ -150,6 +150,22 @@ int dcv_groupnorm_bwd(const float* dy, const float* x, float* dx, int n, int hw,
                       void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * K5 split in two phases for cross-GPU statistics (`use_sync_batch_norm`, ignite_training.py:203,386-388 -> torch.nn.SyncBatchNorm; collective C4):
+ * the caller all-reduces `sums` ([2][channels] doubles) over the process group between the phases and passes the global row count.
+ *   forward : dcv_batchnorm_stats (sum x, sum x^2 of the local rows)            -> all-reduce -> dcv_batchnorm_fwd_from_sums
+ *   backward: dcv_batchnorm_bwd_stats (sum dy, sum dy*xhat: the LOCAL d_beta, d_gamma) -> all-reduce -> dcv_batchnorm_bwd_from_sums
+ * workspace: dcv_batchnorm_workspace_bytes(rows, channels).
+ * ------------------------------------------------------------------------------------------------- */
+int dcv_batchnorm_stats(const float* x, size_t rows, int channels, double* sums, void* ws, size_t ws_bytes, void* stream);
+int dcv_batchnorm_fwd_from_sums(const float* x, float* y, size_t rows, int channels, const double* sums, double total_rows, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                                float* save_mean, float* save_rstd, void* ws, size_t ws_bytes, void* stream);
+int dcv_batchnorm_bwd_stats(const float* dy, const float* x, size_t rows, int channels, const float* save_mean, const float* save_rstd, double* sums,
+                            void* ws, size_t ws_bytes, void* stream);
+int dcv_batchnorm_bwd_from_sums(const float* dy, const float* x, float* dx, size_t rows, int channels, const float* gamma, const float* save_mean,
+                                const float* save_rstd, const double* sums, double total_rows, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * K5+K6 fused: the normalisation chain of one reference layer, Conv -> act -> BatchNorm [-> GroupNorm] (op order of layer(), nn.py:553; norm stack
  * of normalization_techniques(), nn.py:448-516), two launches per direction.  x is the activated convolution output, groups == 0 means "no GroupNorm".
  *   forward : y = GN(BN(x)); batch statistics -> bn_save_mean / bn_save_rstd [C] and running stats; GroupNorm statistics -> gn_save_* [N][groups];

@@ -446,3 +446,82 @@ def test_prefetched_loader_with_device_transform(device):
         assert torch.allclose(x.cpu(), ref, atol=1e-6)
         seen += x.shape[0]
     assert seen == 40
+
+
+def test_sync_batch_norm_two_virtual_ranks(device):
+    """ `ops.sync_batch_norm` (split-phase kernels dcv_batchnorm_stats / fwd_from_sums / bwd_stats / bwd_from_sums): the two halves of a batch are
+    processed as two ranks whose small fp64 sums are exchanged by an injected all-reduce; outputs, running statistics and gradients must equal plain
+    BatchNorm over the full batch (what torch.nn.SyncBatchNorm guarantees; the reference enables it at ignite_training.py:386-388).
+    The exchange emulation runs both "ranks" phase by phase in one process: rank B's first-phase sums are obtained by a dry run. """
+    from deepcv_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(77)
+    n, c, h, w = 12, 8, 9, 7
+    x = torch.randn(n, c, h, w, generator=g) * 1.5 + 0.3
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    rm, rv = torch.randn(c, generator=g), torch.rand(c, generator=g) + 0.5
+    dy = torch.randn(n, c, h, w, generator=g)
+    mom, eps = 0.07359778246238029, 1e-5
+    ref = ops_ref.batch_norm_train(x, gamma, beta, rm, rv, mom, eps, dy)
+    halves = [(slice(0, 5), slice(5, 12)), (slice(5, 12), slice(0, 5))]       # uneven split: 5 + 7 samples
+
+    def other_sums(xo, dyo, stats):
+        """ the peer's contribution to each all-reduce, computed with the same kernels: forward sums, then backward sums given the GLOBAL statistics """
+        peer = {}
+        def capture_fwd(t, group):
+            peer['fwd'] = t.clone()
+        xo_d = _cl(xo.to(device)).requires_grad_(True)
+        ops.sync_batch_norm(xo_d, None, None, None, None, None, mom, eps, None, capture_fwd)
+        return peer['fwd']
+
+    outs, dxs, dgs, dbs, rms, rvs = {}, {}, {}, {}, {}, {}
+    for rank, (mine, theirs) in enumerate(halves):
+        xm, xt = x[mine], x[theirs]
+        peer_fwd = other_sums(xt, dy[theirs], None)
+        # backward sums of the peer need the global statistics: run the peer fully with MY forward sums injected, capturing its backward sums
+        my_fwd = other_sums(xm, dy[mine], None)
+        peer_bwd = {}
+        def peer_ar(t, group, my_fwd=my_fwd, peer_bwd=peer_bwd):
+            if t.numel() == 2 * c + 1:
+                t += my_fwd
+            else:
+                peer_bwd['v'] = t.clone()
+        xt_d = _cl(xt.to(device)).requires_grad_(True)
+        yt = ops.sync_batch_norm(xt_d, gamma.to(device).requires_grad_(True), beta.to(device).requires_grad_(True), None, None, None, mom, eps, None, peer_ar)
+        yt.backward(_cl(dy[theirs].to(device)))
+        def my_ar(t, group, peer_fwd=peer_fwd, peer_bwd=peer_bwd):
+            t += peer_fwd if t.numel() == 2 * c + 1 else peer_bwd['v']
+        xm_d = _cl(xm.to(device)).requires_grad_(True)
+        gd, bd = gamma.to(device).requires_grad_(True), beta.to(device).requires_grad_(True)
+        rmd, rvd, nbt = rm.to(device), rv.to(device), torch.zeros((), dtype=torch.int64, device=device)
+        ym = ops.sync_batch_norm(xm_d, gd, bd, rmd, rvd, nbt, mom, eps, None, my_ar)
+        ym.backward(_cl(dy[mine].to(device)))
+        torch.cuda.synchronize()
+        outs[rank], dxs[rank], dgs[rank], dbs[rank], rms[rank], rvs[rank] = ym, xm_d.grad, gd.grad, bd.grad, rmd, rvd
+        assert int(nbt) == 1
+    a, b = 0, 1
+    _check('syncbn.y', torch.cat([outs[a].detach().cpu(), outs[b].detach().cpu()]), ref['y'], 1e-4)
+    _check('syncbn.dx', torch.cat([dxs[a].cpu(), dxs[b].cpu()]), ref['dx'], 3e-4)
+    _check('syncbn.dgamma', dgs[a] + dgs[b], ref['dgamma'], 3e-4)          # local parameter gradients add up to the full-batch ones
+    _check('syncbn.dbeta', dbs[a] + dbs[b], ref['dbeta'], 3e-4)
+    for k in (a, b):
+        _check('syncbn.running_mean', rms[k], ref['running_mean'], 1e-5)
+        _check('syncbn.running_var', rvs[k], ref['running_var'], 1e-5)
+
+
+def test_sync_batch_norm_module_conversion(device):
+    """ `SyncBatchNorm2d.convert` keeps parameters / buffers / state_dict keys; with no process group (world of one) it equals BatchNorm2d. """
+    from deepcv_amd import modules as nm
+    g = torch.Generator().manual_seed(3)
+    seq = torch.nn.Sequential(nm.Conv2d(3, 8, 3, padding=1), nm.BatchNorm2d(8)).to(device)
+    ref = torch.nn.Sequential(nm.Conv2d(3, 8, 3, padding=1), nm.BatchNorm2d(8)).to(device)
+    ref.load_state_dict(seq.state_dict())
+    keys = list(seq.state_dict().keys())
+    nm.SyncBatchNorm2d.convert(seq)
+    assert type(seq[1]) is nm.SyncBatchNorm2d and list(seq.state_dict().keys()) == keys
+    x = torch.randn(4, 3, 10, 10, generator=g).to(device)
+    ya, yb = seq(x), ref(x)
+    ya.sum().backward(); yb.sum().backward()
+    torch.cuda.synchronize()
+    assert torch.allclose(ya, yb, atol=1e-5) and torch.allclose(seq[1].running_var, ref[1].running_var, atol=1e-6)
+    assert torch.allclose(seq[0].weight.grad, ref[0].weight.grad, atol=1e-4)
