@@ -232,6 +232,32 @@ int dcv_images_u8_normalize(const unsigned char* src, float* dst, int n, int h, 
                             const float* mean, const float* inv_std, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * GPU augmentation: AugMix-style chains of the reference's PIL operations (src/deepcv/meta/data/augmentation.py:73-124,165-203)
+ * applied per sample ON THE DEVICE and fused with ToTensor + Normalize:
+ *     out = normalize( (1 - m) * x + m * sum_i w_i * chain_i(x) ),   chain_i = up to DCV_AUG_MAX_OPS ops applied in order
+ * ops (codes DCV_AUG_*, integer parameter p): POSTERIZE keeps the p high bits; SOLARIZE inverts pixels >= p; TRANSLATE_X / _Y shift by p pixels with
+ * zero fill (PIL AFFINE (1,0,p,0,1,0): out(x, y) = in(x + p, y)); BRIGHTNESS multiplies by p / 256 and truncates like PIL's blend (p in 1/256 steps).
+ * The random draws (which ops, which parameters, mixing weights) are made on the host by the caller (`deepcv_amd.meta.data.augmentation`), which keeps
+ * them reproducible from a seed; this entry point is deterministic.  src: [N][H][W][C] uint8; dst: fp32 NCHW or NHWC.
+ * ------------------------------------------------------------------------------------------------- */
+#define DCV_AUG_MAX_CHAINS 3
+#define DCV_AUG_MAX_OPS 3
+#define DCV_AUG_NONE 0
+#define DCV_AUG_POSTERIZE 1
+#define DCV_AUG_SOLARIZE 2
+#define DCV_AUG_TRANSLATE_X 3
+#define DCV_AUG_TRANSLATE_Y 4
+#define DCV_AUG_BRIGHTNESS 5
+typedef struct {
+    int op[DCV_AUG_MAX_CHAINS][DCV_AUG_MAX_OPS];      /* DCV_AUG_* (DCV_AUG_NONE = identity) */
+    int param[DCV_AUG_MAX_CHAINS][DCV_AUG_MAX_OPS];
+    float weight[DCV_AUG_MAX_CHAINS];                 /* w_i (unused chains: 0) */
+    float mix;                                        /* m in [0, 1]; 0 = original image */
+} dcv_aug_sample;
+int dcv_images_u8_augment_normalize(const unsigned char* src, float* dst, int n, int h, int w, int c, int dst_layout,
+                                    const dcv_aug_sample* samples /* device, [n] */, const float* mean, const float* inv_std, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Indirect batch staging: up to DCV_MAX_COPY_JOBS (src, dst, bytes) copies whose descriptors are READ BY THE KERNEL AT RUN TIME from `jobs`, a block
  * of device-visible (pinned host or device) memory.  Captured as the first node of the training-step hipGraph it lets every replay fetch a NEW batch
  * (and the optimizer's scalar hyper-parameters) although the graph's kernel arguments are frozen: the host only rewrites the mailbox before
