@@ -24,6 +24,7 @@ CSRC_DIR = _PKG_DIR / 'csrc'
 ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
 POOL_AVG, POOL_MAX = 0, 1
 LAYOUT_NHWC, LAYOUT_NCHW = 0, 1
+MATH_FP32, MATH_BF16 = 0, 1
 MAX_TENSORS = 64
 MAX_CONCAT = 8
 MAX_COPY_JOBS = 8
@@ -37,7 +38,7 @@ class Conv2dDesc(ctypes.Structure):
     """ `dcv_conv2d_desc` """
     _fields_ = [('n', _c_int), ('h', _c_int), ('w', _c_int), ('cin', _c_int), ('cout', _c_int), ('r', _c_int), ('s', _c_int),
                 ('stride_h', _c_int), ('stride_w', _c_int), ('pad_h', _c_int), ('pad_w', _c_int), ('dil_h', _c_int), ('dil_w', _c_int),
-                ('groups', _c_int), ('ho', _c_int), ('wo', _c_int), ('x_layout', _c_int), ('act', _c_int), ('act_slope', _c_float)]
+                ('groups', _c_int), ('ho', _c_int), ('wo', _c_int), ('x_layout', _c_int), ('act', _c_int), ('act_slope', _c_float), ('math', _c_int)]
 
 
 class Pool2dDesc(ctypes.Structure):

@@ -15,6 +15,7 @@ inline bool desc_ok(const dcv_conv2d_desc* d) {
     if (ho != d->ho || wo != d->wo || ho <= 0 || wo <= 0) return false;
     if (d->act < DCV_ACT_NONE || d->act > DCV_ACT_TANH) return false;
     if (d->x_layout != DCV_LAYOUT_NHWC && d->x_layout != DCV_LAYOUT_NCHW) return false;
+    if (d->math != DCV_MATH_FP32 && d->math != DCV_MATH_BF16) return false;
     return true;
 }
 

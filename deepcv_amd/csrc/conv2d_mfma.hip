@@ -22,6 +22,11 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// four consecutive K elements of a lane -> the bf16 operand of v_mfma_f32_16x16x16_bf16 (round to nearest even: v_cvt_pk_bf16_f32)
+__device__ __forceinline__ bf16x4 pack_bf16(const f32x4& v) { return (bf16x4){(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]}; }
+__device__ __forceinline__ bf16x4 pack_bf16(float a, float b, float c, float d) { return (bf16x4){(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d}; }
 
 #define MF_BM 128
 #define MF_BK 16
@@ -50,7 +55,8 @@ __global__ __launch_bounds__(256) void mfma_prep_weights_kernel(const float* __r
 }
 
 // BMR: A rows staged per thread = accumulator tiles along M per wave; block tile = (64 * BMR) pixels x BN channels
-template <int BN, int BMR>
+// BF16: the four fp32 K steps of a chunk become ONE v_mfma_f32_16x16x16_bf16 (operands rounded to bf16 in registers, fp32 accumulate)
+template <int BN, int BMR, bool BF16>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaArgs a, const float* __restrict__ x, const float* __restrict__ wb, const float* __restrict__ bias,
                                                          float* __restrict__ y, double* __restrict__ stats) {
     constexpr int NT = BN / 16;                                   // accumulator tiles along N per wave
@@ -125,12 +131,24 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaArgs a, const float*
         for (int i = 0; i < BMR; ++i) af[i] = *reinterpret_cast<const f32x4*>(&As[buf][(wave * 16 * BMR + i * 16 + li) * MF_LD + 4 * lg]);
 #pragma unroll
         for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(&Bs[buf][(j * 16 + li) * MF_LD + 4 * lg]);
+        if constexpr (BF16) {
+            bf16x4 ah[BMR], bh[NT];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+            for (int i = 0; i < BMR; ++i) ah[i] = pack_bf16(af[i]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bh[j] = pack_bf16(bf[j]);
 #pragma unroll
             for (int i = 0; i < BMR; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < BMR; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+        }
 
         if (has_next) store_stage(buf ^ 1, va, vb);
         __syncthreads();
@@ -190,6 +208,7 @@ struct MfmaWgArgs {
 
 #define WG_PS 32                   // pixels per pipeline step (one barrier per step: 32 MFMAs per wave between barriers)
 
+template <bool BF16>
 __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(MfmaWgArgs a, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) float Gs[2][WG_PS * WG_LD];     // dy tile  [pixel][co]
     __shared__ __attribute__((aligned(16))) float Xs[2][WG_PS * WG_LD];     // x  tile  [pixel][ci]
@@ -242,14 +261,28 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(MfmaWgArgs a, cons
         const int buf = it & 1;
         const bool has_next = (m + WG_PS) < me;
         if (has_next) load_tiles(m + WG_PS, g, xv);
+        if constexpr (BF16) {
 #pragma unroll
-        for (int kk = 0; kk < WG_PS / 4; ++kk) {
-            const int prw = (kk >> 2) * 16 + 4 * lg + (kk & 3);                             // k permutation: lane group g, step kk -> pixel row of the step
-            const float av = Gs[buf][prw * WG_LD + wave * 16 + li];                        // A'[i = co][k = pixel]
+            for (int hh = 0; hh < WG_PS / 16; ++hh) {                                       // 16 pixels per bf16 MFMA: lane group g supplies pixels 4g..4g+3
+                const int p0 = hh * 16 + 4 * lg;
+                const float* gp = &Gs[buf][p0 * WG_LD + wave * 16 + li];
+                const bf16x4 ah = pack_bf16(gp[0], gp[WG_LD], gp[2 * WG_LD], gp[3 * WG_LD]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float bvv = Xs[buf][prw * WG_LD + j * 16 + li];                      // B'[k][j = ci]
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bvv, acc[j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    const float* xp = &Xs[buf][p0 * WG_LD + j * 16 + li];
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, pack_bf16(xp[0], xp[WG_LD], xp[2 * WG_LD], xp[3 * WG_LD]), acc[j], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < WG_PS / 4; ++kk) {
+                const int prw = (kk >> 2) * 16 + 4 * lg + (kk & 3);                         // k permutation: lane group g, step kk -> pixel row of the step
+                const float av = Gs[buf][prw * WG_LD + wave * 16 + li];                    // A'[i = co][k = pixel]
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float bvv = Xs[buf][prw * WG_LD + j * 16 + li];                  // B'[k][j = ci]
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bvv, acc[j], 0, 0, 0);
+                }
             }
         }
         if (has_next) store_tiles(buf ^ 1, g, xv);
@@ -337,16 +370,22 @@ inline int pick_bmr(long M, int cout, int bn) {
     return (bn == 64 && blocks256 >= 3 * DCV_NUM_CU) ? 4 : 2;
 }
 
-static int run_mfma(const MfmaArgs& a, const float* x, const float* wb, const float* bias, float* y, hipStream_t st, double* stats = nullptr) {
+template <bool BF16>
+static void launch_mfma(int bn, int bmr, dim3 grid, hipStream_t st, const MfmaArgs& a, const float* x, const float* wb, const float* bias, float* y, double* stats) {
+    if (bmr == 4) hipLaunchKernelGGL((conv_mfma_kernel<64, 4, BF16>), grid, dim3(256), 0, st, a, x, wb, bias, y, stats);
+    else switch (bn) {
+        case 64: hipLaunchKernelGGL((conv_mfma_kernel<64, 2, BF16>), grid, dim3(256), 0, st, a, x, wb, bias, y, stats); break;
+        case 32: hipLaunchKernelGGL((conv_mfma_kernel<32, 2, BF16>), grid, dim3(256), 0, st, a, x, wb, bias, y, stats); break;
+        default: hipLaunchKernelGGL((conv_mfma_kernel<16, 2, BF16>), grid, dim3(256), 0, st, a, x, wb, bias, y, stats); break;
+    }
+}
+
+static int run_mfma(const MfmaArgs& a, const float* x, const float* wb, const float* bias, float* y, hipStream_t st, double* stats = nullptr, int math = DCV_MATH_FP32) {
     const int bn = pick_bn(a.Cout);
     const int bmr = pick_bmr(a.M, a.Cout, bn);
     dim3 grid((unsigned)dcv_ceil_div((size_t)a.M, (size_t)64 * bmr), (unsigned)(a.Cout / bn));
-    if (bmr == 4) hipLaunchKernelGGL((conv_mfma_kernel<64, 4>), grid, dim3(256), 0, st, a, x, wb, bias, y, stats);
-    else switch (bn) {
-        case 64: hipLaunchKernelGGL((conv_mfma_kernel<64, 2>), grid, dim3(256), 0, st, a, x, wb, bias, y, stats); break;
-        case 32: hipLaunchKernelGGL((conv_mfma_kernel<32, 2>), grid, dim3(256), 0, st, a, x, wb, bias, y, stats); break;
-        default: hipLaunchKernelGGL((conv_mfma_kernel<16, 2>), grid, dim3(256), 0, st, a, x, wb, bias, y, stats); break;
-    }
+    if (math == DCV_MATH_BF16) launch_mfma<true>(bn, bmr, grid, st, a, x, wb, bias, y, stats);
+    else launch_mfma<false>(bn, bmr, grid, st, a, x, wb, bias, y, stats);
     return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
 }
 
@@ -365,7 +404,7 @@ int dcv_mfma_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w
     a.N = d->n; a.Hin = d->h; a.Win = d->w; a.Cin = d->cin; a.Hout = d->ho; a.Wout = d->wo; a.Cout = d->cout;
     a.R = d->r; a.S = d->s; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
     a.act = d->act; a.slope = d->act_slope; a.M = (long)d->n * d->ho * d->wo;
-    return run_mfma(a, x, wb, bias, y, st, stats);
+    return run_mfma(a, x, wb, bias, y, st, stats, d->math);
 }
 
 int dcv_mfma_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t st, bool prepared) {
@@ -379,7 +418,7 @@ int dcv_mfma_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float
     a.N = d->n; a.Hin = d->ho; a.Win = d->wo; a.Cin = d->cout; a.Hout = d->h; a.Wout = d->w; a.Cout = d->cin;
     a.R = d->r; a.S = d->s; a.sh = 1; a.sw = 1; a.ph = d->dil_h * (d->r - 1) - d->pad_h; a.pw = d->dil_w * (d->s - 1) - d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
     a.act = DCV_ACT_NONE; a.slope = 0.f; a.M = (long)d->n * d->h * d->w;
-    return run_mfma(a, dy, wb, nullptr, dx, st);
+    return run_mfma(a, dy, wb, nullptr, dx, st, nullptr, d->math);
 }
 
 bool dcv_mfma_conv2d_prep_entry(const dcv_conv2d_desc* d, int op, dcv_prep_entry* e) {
@@ -397,7 +436,8 @@ int dcv_mfma_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float*
     float* partial = reinterpret_cast<float*>(ws);
     dim3 grid((unsigned)chunks, (unsigned)(d->r * d->s * (d->cin / WG_T)), (unsigned)(d->cout / WG_T));
     if (grid.y > 65535 || grid.z > 65535) return DCV_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(conv_mfma_wgrad_kernel, grid, dim3(256), 0, st, a, x, dy, partial);
+    if (d->math == DCV_MATH_BF16) hipLaunchKernelGGL((conv_mfma_wgrad_kernel<true>), grid, dim3(256), 0, st, a, x, dy, partial);
+    else hipLaunchKernelGGL((conv_mfma_wgrad_kernel<false>), grid, dim3(256), 0, st, a, x, dy, partial);
     hipLaunchKernelGGL(mfma_wgrad_reduce_kernel, dim3((unsigned)dcv_ceil_div(a.wtotal, 32)), dim3(1024), 0, st, partial, dw, chunks, a.wtotal);
     return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
 }

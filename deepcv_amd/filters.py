@@ -29,7 +29,7 @@ class _Entry:
 
 
 def _key(d: nat.Conv2dDesc, op: int) -> tuple:
-    return (op, d.n, d.h, d.w, d.cin, d.cout, d.r, d.s, d.stride_h, d.stride_w, d.pad_h, d.pad_w, d.dil_h, d.dil_w, d.x_layout)
+    return (op, d.n, d.h, d.w, d.cin, d.cout, d.r, d.s, d.stride_h, d.stride_w, d.pad_h, d.pad_w, d.dil_h, d.dil_w, d.x_layout, d.math)
 
 
 def _entries_of(weight: torch.Tensor, create: bool = False) -> Optional[Dict[tuple, '_Entry']]:

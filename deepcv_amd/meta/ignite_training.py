@@ -344,7 +344,8 @@ def train(hp: HYPERPARAMS_T, model: torch.nn.Module, losses: LOSS_FN_TERMS_T = N
     Args:
         - hp: hyper-parameters; required: `optimizer_opts`, `epochs`, `batch_size`; optional: see `TRAINING_HP_DEFAULTS` below (reference `:201-203`), plus
           `hip_graph` (None = auto: capture the step into a hipGraph when the model has fewer than 5M parameters), `num_workers`, `bucket_cap_mb`,
-          `device_transform` (callable applied on the device to the images of every prefetched batch, e.g. `DeviceNormalize` for raw uint8 pixels).
+          `device_transform` (callable applied on the device to the images of every prefetched batch, e.g. `DeviceNormalize` for raw uint8 pixels),
+          `conv_math` ('fp32' | 'bf16': arithmetic of the MFMA convolution kernels, see `deepcv_amd.ops.set_conv_math`).
         - model: `torch.nn.Module` to train (e.g. a `DeepcvModule`)
         - losses (alias `loss`, Appendix A #24): a loss callable/module, a sequence, or a mapping name -> loss; see `loss_weights`
         - datasets: `{'trainset': ..., 'validset': ...[, 'testset': ...]}` (or a 2/3-tuple in that order) of `torch.utils.data.Dataset`s (Appendix A #29)
@@ -358,7 +359,7 @@ def train(hp: HYPERPARAMS_T, model: torch.nn.Module, losses: LOSS_FN_TERMS_T = N
     TRAINING_HP_DEFAULTS = {'optimizer_opts': ..., 'epochs': ..., 'batch_size': ..., 'scheduler': None, 'output_path': Path.cwd() / 'data/04_training/',
                             'log_output_dir_to_mlflow': True, 'validate_every_epochs': 1, 'save_every_iters': 1000, 'log_grads_every_iters': -1,
                             'log_progress_every_iters': 100, 'seed': None, 'prefetch_batches': True, 'resume_from': '', 'crash_iteration': -1,
-                            'deterministic_cudnn': False, 'use_sync_batch_norm': False, 'hip_graph': None, 'num_workers': None, 'bucket_cap_mb': 32., 'device_transform': None}
+                            'deterministic_cudnn': False, 'use_sync_batch_norm': False, 'hip_graph': None, 'num_workers': None, 'bucket_cap_mb': 32., 'device_transform': None, 'conv_math': None}
     losses = losses if losses is not None else loss
     backend_conf = backend_conf if backend_conf is not None else BackendConfig()
     metrics = dict(metrics) if metrics else {}
@@ -372,6 +373,9 @@ def train(hp: HYPERPARAMS_T, model: torch.nn.Module, losses: LOSS_FN_TERMS_T = N
     if 'deterministic' in hp and 'deterministic_cudnn' not in hp:
         hp['deterministic_cudnn'] = hp['deterministic']   # both spellings accepted (Appendix A #28)
     hp, _ = to_hyperparameters(hp, TRAINING_HP_DEFAULTS, raise_if_missing=True)
+    if hp['conv_math'] is not None:
+        from .. import ops as _native_ops
+        _native_ops.set_conv_math(hp['conv_math'])    # 'bf16': MFMA convolutions round their operands to bf16 (fp32 accumulate, fp32 master weights)
     device = backend_conf.device
     if hp['seed'] is not None:
         utils.setup_cudnn(deterministic=hp['deterministic_cudnn'], seed=backend_conf.rank + hp['seed'])   # different seed per worker (`:208`)

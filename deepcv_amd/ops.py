@@ -13,7 +13,7 @@ from . import _native as nat
 from . import filters
 from ._native import lib
 
-__all__ = ['conv2d', 'conv_norm_layer', 'activation', 'batch_norm', 'sync_batch_norm', 'group_norm', 'pool2d', 'interpolate_bilinear', 'concat_channels', 'add_tensors', 'flatten_nchw_order',
+__all__ = ['conv2d', 'set_conv_math', 'conv_norm_layer', 'activation', 'batch_norm', 'sync_batch_norm', 'group_norm', 'pool2d', 'interpolate_bilinear', 'concat_channels', 'add_tensors', 'flatten_nchw_order',
            'linear', 'cross_entropy', 'act_code', 'to_nhwc', 'nchw_to_nhwc']
 
 _CL = torch.channels_last
@@ -71,6 +71,21 @@ def act_code(act_fn) -> Tuple[int, float]:
 
 # ------------------------------------------------------------------------------------------------ conv2d (+ fused bias / activation)
 
+_conv_math = nat.MATH_FP32
+
+
+def set_conv_math(mode: str) -> str:
+    """ Arithmetic of the MFMA convolution kernels: 'fp32' (default: fp32 matrix cores, the parity configuration) or 'bf16' (BASELINE configs 3 / 5:
+    x, dy and the filter are rounded to bf16 in registers and fed to v_mfma_f32_16x16x16_bf16 with fp32 accumulation; tensors stay fp32 in memory and
+    the fp32 weights remain the master copy).  Layers served by the direct kernels are unaffected.  Returns the previous mode. """
+    global _conv_math
+    prev = 'bf16' if _conv_math == nat.MATH_BF16 else 'fp32'
+    if mode not in ('fp32', 'bf16'):
+        raise ValueError(f'deepcv_amd.set_conv_math: unknown mode "{mode}" (fp32 | bf16)')
+    _conv_math = nat.MATH_BF16 if mode == 'bf16' else nat.MATH_FP32
+    return prev
+
+
 def _conv_desc(x_shape, w_shape, stride, padding, dilation, x_layout, act, slope) -> nat.Conv2dDesc:
     n, cin, h, w = x_shape
     cout, cin_w, r, s = w_shape
@@ -81,7 +96,7 @@ def _conv_desc(x_shape, w_shape, stride, padding, dilation, x_layout, act, slope
     if ho <= 0 or wo <= 0:
         raise ValueError(f'deepcv_amd.conv2d: empty output for input {tuple(x_shape)} and kernel {(r, s)}')
     return nat.Conv2dDesc(n, h, w, cin, cout, r, s, stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1], 1, ho, wo,
-                          x_layout, act, slope)
+                          x_layout, act, slope, _conv_math)
 
 
 def _conv_fwd_launch(d, x, weight, bias, y, st, want_stats: bool = False):

@@ -57,6 +57,8 @@ int dcv_device_info(int device, int* cu_count, int* wave_size, char* arch, int a
  * K1-K3  conv2d forward / data-gradient / weight-gradient
  * replaces torch.nn.Conv2d created at submodule_creators.py:251 (fwd) and its autograd (ignite_training.py:253)
  * ------------------------------------------------------------------------------------------------- */
+#define DCV_MATH_FP32 0
+#define DCV_MATH_BF16 1
 typedef struct {
     int n, h, w, cin;            /* input  N x H x W x Cin                                     */
     int cout, r, s;              /* filter Cout x Cin x R x S (OIHW)                           */
@@ -68,6 +70,8 @@ typedef struct {
     int x_layout;                /* DCV_LAYOUT_NHWC, or DCV_LAYOUT_NCHW for the forward input  */
     int act;                     /* forward: fused activation applied after bias (DCV_ACT_*)   */
     float act_slope;             /* negative slope for DCV_ACT_LEAKY_RELU                      */
+    int math;                    /* DCV_MATH_FP32 (default), or DCV_MATH_BF16: the MFMA kernels round x / dy / w to bf16 on the fly and accumulate in fp32
+                                    (BASELINE configs 3 and 5; tensors stay fp32 in memory; layers not served by an MFMA kernel ignore it) */
 } dcv_conv2d_desc;
 
 size_t dcv_conv2d_fwd_workspace_bytes(const dcv_conv2d_desc* d);

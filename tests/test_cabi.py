@@ -42,7 +42,7 @@ def test_python_binding_covers_the_header():
 
 def test_struct_layouts_match_the_header():
     from deepcv_amd import _native
-    assert ctypes.sizeof(_native.Conv2dDesc) == 19 * 4
+    assert ctypes.sizeof(_native.Conv2dDesc) == 20 * 4
     assert ctypes.sizeof(_native.Pool2dDesc) == 13 * 4
     assert ctypes.sizeof(_native.TensorList) == 8 + 6 * 8 * _native.MAX_TENSORS
     text = (ROOT / 'include' / 'deepcv_hip.h').read_text()

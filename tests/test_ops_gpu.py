@@ -550,3 +550,41 @@ def test_device_augmentation_matches_oracle(device, shape, severity):
     # reproducible from the seed
     out2 = DeviceAugmentNormalize(mean, std, severity=severity, seed=123)(img.to(device))
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize('case', [(4, 64, 16, 16, 64, 3, 1, 1), (2, 128, 8, 8, 64, 3, 1, 1), (2, 64, 16, 16, 128, 3, 2, 1), (3, 32, 9, 11, 64, 3, 1, 1)], ids=str)
+def test_conv2d_bf16_math(device, case):
+    """ `set_conv_math('bf16')` (BASELINE configs 3 / 5): MFMA convolutions round x, dy and w to bf16 and accumulate in fp32.  Against the fp64 reference the
+    error is that of bf16 operands (2^-9 relative per product, averaged over K >= 288 products): bounded at 1e-2 of the output range; and it must differ
+    from the fp32 result (the mode is really taken). """
+    from deepcv_amd import ops
+    from oracle import ops_ref
+    n, cin, h, w, cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(21 + sum(case))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * 0.1
+    b = torch.randn(cout, generator=g)
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    dy = torch.randn(n, cout, ho, wo, generator=g)
+    # no activation: a ReLU mask computed from a bf16-accurate output flips wherever |pre-activation| < ~1e-2, which is a property of the precision,
+    # not of the kernels checked here
+    ref = ops_ref.conv2d_act(x, wt, b, stride, pad, 1, 0, 0., dy)
+
+    def run():
+        xd = _cl(x.to(device)).requires_grad_(True)
+        wd, bd = wt.to(device).requires_grad_(True), b.to(device).requires_grad_(True)
+        y = ops.conv2d(xd, wd, bd, stride, pad, 1, 0, 0.)
+        y.backward(_cl(dy.to(device)))
+        torch.cuda.synchronize()
+        return y.detach(), xd.grad, wd.grad
+
+    prev = ops.set_conv_math('bf16')
+    try:
+        y16, dx16, dw16 = run()
+    finally:
+        ops.set_conv_math(prev)
+    y32, _, _ = run()
+    _check(f'bf16conv{case}.y', y16, ref['y'], 1e-2)
+    _check(f'bf16conv{case}.dx', dx16, ref['dx'], 1e-2)
+    _check(f'bf16conv{case}.dw', dw16, ref['dw'], 1e-2)
+    assert (y16 - y32).abs().max().item() > 1e-5 * ref['y'].abs().max().item(), 'bf16 mode produced the fp32 result: mode not taken'

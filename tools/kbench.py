@@ -14,7 +14,7 @@ def conv_case(n, cin, h, w, cout, k, pad):
     b = torch.zeros(cout, device=dev)
     y = torch.empty(n, cout, h, w, device=dev).contiguous(memory_format=cl)
     dy = torch.randn(n, cout, h, w, device=dev).contiguous(memory_format=cl)
-    d = nat.Conv2dDesc(n, h, w, cin, cout, k, k, 1, 1, pad, pad, 1, 1, 1, h, w, nat.LAYOUT_NHWC, nat.ACT_RELU, 0.)
+    d = nat.Conv2dDesc(n, h, w, cin, cout, k, k, 1, 1, pad, pad, 1, 1, 1, h, w, nat.LAYOUT_NHWC, nat.ACT_RELU, 0., int(__import__('os').environ.get('DCV_KBENCH_MATH', '0')))
     return x, wt, b, y, dy, d
 st = nat.current_stream(dev)
 CONVS = {'conv350': (NB, 3, 32, 32, 4, 5, 2), 'conv450': (NB, 4, 32, 32, 4, 5, 2), 'conv1630': (NB, 16, 16, 16, 16, 3, 1), 'conv430': (NB, 4, 16, 16, 16, 3, 1), 'conv6430': (NB, 64, 32, 32, 64, 3, 1),

@@ -10,7 +10,10 @@ from deepcv_amd.utils import load_parameters
 spec = sys.argv[1] if len(sys.argv) > 1 else 'cifar100_deep_model'
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
-graph = len(sys.argv) > 4 and sys.argv[4] == 'graph'
+graph = len(sys.argv) > 4 and 'graph' in sys.argv[4]
+if len(sys.argv) > 4 and 'bf16' in sys.argv[4]:
+    from deepcv_amd import ops as _ops
+    _ops.set_conv_math('bf16')
 shape, nc = ((3, 224, 224), 1000) if 'resnet' in spec else ((3, 32, 32), 100)
 dev = torch.device('cuda:0')
 P = load_parameters()
