@@ -25,9 +25,9 @@ __global__ __launch_bounds__(256) void prep_multi_kernel(dcv_prep_list l) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < e.total; i += gridDim.x * blockDim.x) e.dst[i] = dcv_prep_element(e, i);
 }
 
-inline bool prep_entry(const dcv_conv2d_desc* d, int op, dcv_prep_entry* e) {
-    if (op == 1 && d->x_layout != DCV_LAYOUT_NHWC) return false;
-    return dcv_mfma_conv2d_supported(d, op) ? dcv_mfma_conv2d_prep_entry(d, op, e) : dcv_direct_conv2d_prep_entry(d, op, e);
+inline int prep_entries(const dcv_conv2d_desc* d, int op, dcv_prep_entry* out) {
+    if (op == 1 && d->x_layout != DCV_LAYOUT_NHWC) return 0;
+    return dcv_mfma_conv2d_supported(d, op) ? dcv_mfma_conv2d_prep_entries(d, op, out) : dcv_direct_conv2d_prep_entries(d, op, out);
 }
 
 inline size_t db_ws(const dcv_conv2d_desc* d) { return dcv_act_bwd_workspace_bytes((size_t)d->n * d->ho * d->wo, d->cout); }
@@ -69,8 +69,8 @@ int dcv_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, 
 
 size_t dcv_conv2d_filter_bytes(const dcv_conv2d_desc* d, int op) {
     if (!desc_ok(d) || d->groups != 1 || (op != 0 && op != 1)) return 0;
-    dcv_prep_entry e{};
-    if (!prep_entry(d, op, &e)) return 0;
+    dcv_prep_entry e[DCV_PREP_PIECES];
+    if (prep_entries(d, op, e) == 0) return 0;
     return op == 0 ? dcv_conv2d_fwd_workspace_bytes(d) : dcv_conv2d_dgrad_workspace_bytes(d);
 }
 
@@ -86,13 +86,18 @@ int dcv_conv2d_prepare_filters(int count, const dcv_conv2d_desc* const* descs, c
     };
     for (int k = 0; k < count; ++k) {
         DCV_CHECK_ARG(desc_ok(descs[k]) && w[k] && (ops[k] == 0 || ops[k] == 1));
-        dcv_prep_entry e{};
-        if (!prep_entry(descs[k], ops[k], &e)) continue;          // this (layer, op) reads the OIHW filter directly
+        dcv_prep_entry pieces[DCV_PREP_PIECES];
+        const int np = prep_entries(descs[k], ops[k], pieces);
+        if (np == 0) continue;                                    // this (layer, op) reads the OIHW filter directly
         DCV_CHECK_ARG(filters[k] != nullptr);
-        e.w = w[k]; e.dst = reinterpret_cast<float*>(filters[k]);
-        l.e[l.count++] = e;
-        if (e.total > max_total) max_total = e.total;
-        if (l.count == DCV_PREP_MAX) flush();
+        for (int q = 0; q < np; ++q) {
+            dcv_prep_entry e = pieces[q];
+            if (e.total == 0) continue;
+            e.w = w[k]; e.dst = reinterpret_cast<float*>(filters[k]) + e.dst_off;
+            l.e[l.count++] = e;
+            if (e.total > max_total) max_total = e.total;
+            if (l.count == DCV_PREP_MAX) flush();
+        }
     }
     flush();
     DCV_RETURN_LAUNCH();

@@ -1060,14 +1060,15 @@ int dcv_direct_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const flo
     return run_direct(dgrad_args(d), dy, w, nullptr, dx, ws, ws_bytes, st, prepared);
 }
 
-bool dcv_direct_conv2d_prep_entry(const dcv_conv2d_desc* d, int op, dcv_prep_entry* e) {
+int dcv_direct_conv2d_prep_entries(const dcv_conv2d_desc* d, int op, dcv_prep_entry* e) {
     const DirectArgs a = op == 0 ? fwd_args(d) : dgrad_args(d);
     TileArgs t{}; int tco, ppt;
-    if (!tile_plan(a, &t, &tco, &ppt)) return false;              // generic kernel: stages the OIHW filter itself
+    if (!tile_plan(a, &t, &tco, &ppt)) return 0;                  // generic kernel: stages the OIHW filter itself
+    *e = dcv_prep_entry{};
     e->kind = 0; e->kcout = a.Cout; e->kcin = a.Cin; e->R = a.R; e->S = a.S; e->w_cin = a.w_cin; e->dgrad = a.dgrad ? 1 : 0;
     e->tco = tco; e->tiles = (int)dcv_ceil_div(a.Cout, tco); e->cin_pad = t.cin_pad;
     e->total = e->tiles * a.R * a.S * t.cin_pad * tco;
-    return true;
+    return 1;
 }
 
 namespace {

@@ -30,6 +30,8 @@ struct dcv_prep_entry {
     int R, S, w_cin;               // taps, OIHW row length (original Cin)
     int dgrad;                     // 0: forward filter, 1: transposed + flipped filter of the stride-1 data gradient
     int tco, tiles, cin_pad;       // kind 0 only
+    int r0, rstep, Rw, s0, sstep, Sw;   // kind 1 data gradient: tap (r, s) of this (phase) filter is tap (r0 + rstep*(R-1-r), s0 + sstep*(S-1-s)) of the Rw x Sw filter
+    int dst_off;                   // element offset of this entry inside the layer's prepared-filter buffer
     int total;                     // elements of dst
 };
 #define DCV_PREP_MAX 24
@@ -51,11 +53,13 @@ static __device__ __forceinline__ float dcv_prep_element(const dcv_prep_entry& e
     const int s = t % e.S; t /= e.S;
     const int r = t % e.R; const int co = t / e.R;
     if (!e.dgrad) return e.w[(((size_t)co * e.w_cin + ci) * e.R + r) * e.S + s];
-    return e.w[(((size_t)ci * e.w_cin + co) * e.R + (e.R - 1 - r)) * e.S + (e.S - 1 - s)];
+    return e.w[(((size_t)ci * e.w_cin + co) * e.Rw + (e.r0 + e.rstep * (e.R - 1 - r))) * e.Sw + (e.s0 + e.sstep * (e.S - 1 - s))];
 }
-// false when the kernel serving (d, op) reads the OIHW filter directly (nothing to prepare); op: 0 forward, 1 data gradient
-bool dcv_direct_conv2d_prep_entry(const dcv_conv2d_desc* d, int op, dcv_prep_entry* e);
-bool dcv_mfma_conv2d_prep_entry(const dcv_conv2d_desc* d, int op, dcv_prep_entry* e);
+// number of prepared-filter pieces of (d, op) written to out[] (<= DCV_PREP_PIECES); 0 when the kernel serving it reads the OIHW filter directly.
+// op: 0 forward, 1 data gradient (a strided data gradient on the MFMA kernels has one piece per output phase)
+#define DCV_PREP_PIECES 16
+int dcv_direct_conv2d_prep_entries(const dcv_conv2d_desc* d, int op, dcv_prep_entry* out);
+int dcv_mfma_conv2d_prep_entries(const dcv_conv2d_desc* d, int op, dcv_prep_entry* out);
 
 // shared with elementwise.hip
 extern "C" size_t dcv_act_bwd_workspace_bytes(size_t rows, int channels);

@@ -37,7 +37,9 @@ struct MfmaArgs {
     int Hout, Wout, Cout;          // tensor written
     int R, S, sh, sw, ph, pw, dh, dw;
     int act; float slope;
-    long M;                        // N * Hout * Wout
+    long M;                        // N * Hout * Wout  (Hout x Wout: the grid of pixels this launch computes)
+    // strided data gradient: this launch computes phase (oh_off, ow_off) of the full gradient, written at rows oh_mul*i + oh_off, columns ow_mul*j + ow_off
+    int phase, oh_mul, ow_mul, oh_off, ow_off, Hfull, Wfull;
 };
 
 // wb[co][tap][ci] (fwd: w[co][ci][r][s]; dgrad: kernel-cout = original cin, kernel-cin = original cout, taps flipped)
@@ -55,6 +57,12 @@ __global__ __launch_bounds__(256) void mfma_prep_weights_kernel(const float* __r
 }
 
 // BMR: A rows staged per thread = accumulator tiles along M per wave; block tile = (64 * BMR) pixels x BN channels
+// re-lays out one prepared-filter piece (conv2d_internal.h: dcv_prep_element)
+__global__ __launch_bounds__(256) void mfma_prep_piece_kernel(dcv_prep_entry e, const float* __restrict__ w, float* __restrict__ dst) {
+    e.w = w;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < e.total; i += gridDim.x * blockDim.x) dst[i] = dcv_prep_element(e, i);
+}
+
 // BF16: the four fp32 K steps of a chunk become ONE v_mfma_f32_16x16x16_bf16 (operands rounded to bf16 in registers, fp32 accumulate)
 template <int BN, int BMR, bool BF16>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaArgs a, const float* __restrict__ x, const float* __restrict__ wb, const float* __restrict__ bias,
@@ -169,7 +177,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaArgs a, const float*
                 const long m = m0 + wave * 16 * BMR + i * 16 + 4 * lg + reg;
                 if (m < a.M) {
                     const float o = dcv_act_apply(acc[i][j][reg] + bv, a.act, a.slope);
-                    y[(size_t)m * a.Cout + co] = o;
+                    size_t off = (size_t)m;
+                    if (a.phase) {                                 // (n, i, j) of the phase grid -> position in the full tensor
+                        const int jj = (int)(m % a.Wout); const long r1 = m / a.Wout; const int ii = (int)(r1 % a.Hout); const long nn = r1 / a.Hout;
+                        off = ((size_t)nn * a.Hfull + (size_t)ii * a.oh_mul + a.oh_off) * a.Wfull + (size_t)jj * a.ow_mul + a.ow_off;
+                    }
+                    y[off * a.Cout + co] = o;
                     ssum[j] += o; ssq[j] += o * o;
                 }
             }
@@ -344,9 +357,16 @@ inline void wg_plan(const dcv_conv2d_desc* d, MfmaWgArgs* a, int* chunks) {
 bool dcv_mfma_conv2d_supported(const dcv_conv2d_desc* d, int op) {
     if (d->groups != 1 || d->x_layout != DCV_LAYOUT_NHWC) return false;
     if (d->cin % 16 != 0 || d->cout % 16 != 0) return false;
-    if (op == 1) {   // data gradient through the forward kernel: stride 1 and non-negative transposed padding only
-        if (d->stride_h != 1 || d->stride_w != 1) return false;
-        if (d->dil_h * (d->r - 1) < d->pad_h || d->dil_w * (d->s - 1) < d->pad_w) return false;
+    if (op == 1) {   // data gradient through the forward kernel
+        if (d->stride_h == 1 && d->stride_w == 1) {
+            if (d->dil_h * (d->r - 1) < d->pad_h || d->dil_w * (d->s - 1) < d->pad_w) return false;   // non-negative transposed padding only
+        } else {
+            // strided: one stride-1 launch per output phase (hi % stride_h, wi % stride_w) with the sub-filter of matching parity
+            if (d->dil_h != 1 || d->dil_w != 1 || d->stride_h > 4 || d->stride_w > 4) return false;
+            static int strided = -1;
+            if (strided < 0) { const char* e = getenv("DCV_MFMA_STRIDED_DGRAD"); strided = e ? atoi(e) : 1; }
+            if (!strided) return false;
+        }
     }
     if (op == 2 && (d->cin % WG_T != 0 || d->cout % WG_T != 0)) return false;
     // measured on MI355X: from 16 channels on either side the MFMA kernel already beats the direct one (16->16 3x3 @16x16, N=512: 18.7 vs 29.5 us)
@@ -407,25 +427,84 @@ int dcv_mfma_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w
     return run_mfma(a, x, wb, bias, y, st, stats, d->math);
 }
 
+namespace {
+// Phase a (= output row index mod stride) of a strided data gradient along one axis: dx[stride*i + a] = sum_{r'} dy[i + oa - r'] * w[r0 + stride*r'].
+struct PhaseAxis { int r0, taps, pad, count; };      // first matching tap, number of taps, transposed padding of the stride-1 problem, outputs in this phase
+inline PhaseAxis phase_axis(int a, int size, int R, int stride, int pad) {
+    PhaseAxis p{};
+    p.r0 = (a + pad) % stride;
+    p.taps = p.r0 < R ? (R - p.r0 + stride - 1) / stride : 0;
+    const int oa = (a + pad - p.r0) / stride;
+    p.pad = p.taps - 1 - oa;
+    p.count = a < size ? (size - a + stride - 1) / stride : 0;
+    return p;
+}
+}  // namespace
+
+int dcv_mfma_conv2d_prep_entries(const dcv_conv2d_desc* d, int op, dcv_prep_entry* out) {
+    dcv_prep_entry e{};
+    e.kind = 1; e.w_cin = d->cin; e.dgrad = op ? 1 : 0;
+    e.kcout = op ? d->cin : d->cout; e.kcin = op ? d->cout : d->cin;
+    e.Rw = d->r; e.Sw = d->s;
+    if (op == 0 || (d->stride_h == 1 && d->stride_w == 1)) {
+        e.R = d->r; e.S = d->s; e.r0 = e.s0 = 0; e.rstep = e.sstep = 1; e.dst_off = 0;
+        e.total = d->cout * d->cin * d->r * d->s;
+        out[0] = e;
+        return 1;
+    }
+    int n = 0, off = 0;
+    for (int a = 0; a < d->stride_h; ++a)
+        for (int b = 0; b < d->stride_w; ++b) {
+            const PhaseAxis ph = phase_axis(a, d->h, d->r, d->stride_h, d->pad_h), pw = phase_axis(b, d->w, d->s, d->stride_w, d->pad_w);
+            dcv_prep_entry q = e;
+            q.R = ph.taps; q.S = pw.taps; q.r0 = ph.r0; q.s0 = pw.r0; q.rstep = d->stride_h; q.sstep = d->stride_w;
+            q.dst_off = off; q.total = d->cout * d->cin * ph.taps * pw.taps;
+            off += q.total;
+            out[n++] = q;
+        }
+    return n;
+}
+
 int dcv_mfma_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t st, bool prepared) {
     if (!ws || ws_bytes < dcv_mfma_conv2d_ws(d, 1)) return DCV_ERR_WORKSPACE;
     if (!aligned16(dy) || !aligned16(ws)) return DCV_ERR_INVALID_ARG;
     float* wb = reinterpret_cast<float*>(ws);
-    const int total = d->cout * d->cin * d->r * d->s;
-    // kernel view: reads dy (Cin' = Cout), writes dx (Cout' = Cin), filter flipped + transposed, pad' = dil*(R-1) - pad
-    if (!prepared) hipLaunchKernelGGL(mfma_prep_weights_kernel, dim3((unsigned)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256)), dim3(256), 0, st, w, wb, d->cin, d->cout, d->r, d->s, d->cin, 1);
+    dcv_prep_entry pieces[DCV_PREP_PIECES];
+    const int np = dcv_mfma_conv2d_prep_entries(d, 1, pieces);
+    if (!prepared) {
+        for (int q = 0; q < np; ++q) {
+            if (pieces[q].total == 0) continue;
+            const dcv_prep_entry& e = pieces[q];
+            // same element mapping as the one-launch multi-filter kernel of conv2d.hip (dcv_prep_element), one launch per piece here
+            hipLaunchKernelGGL(mfma_prep_piece_kernel, dim3((unsigned)((e.total + 255) / 256 > 1024 ? 1024 : (e.total + 255) / 256)), dim3(256), 0, st, e, w, wb + e.dst_off);
+        }
+    }
+    // kernel view: reads dy (Cin' = Cout), writes dx (Cout' = Cin)
     MfmaArgs a{};
-    a.N = d->n; a.Hin = d->ho; a.Win = d->wo; a.Cin = d->cout; a.Hout = d->h; a.Wout = d->w; a.Cout = d->cin;
-    a.R = d->r; a.S = d->s; a.sh = 1; a.sw = 1; a.ph = d->dil_h * (d->r - 1) - d->pad_h; a.pw = d->dil_w * (d->s - 1) - d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
-    a.act = DCV_ACT_NONE; a.slope = 0.f; a.M = (long)d->n * d->h * d->w;
-    return run_mfma(a, dy, wb, nullptr, dx, st, nullptr, d->math);
-}
-
-bool dcv_mfma_conv2d_prep_entry(const dcv_conv2d_desc* d, int op, dcv_prep_entry* e) {
-    e->kind = 1; e->R = d->r; e->S = d->s; e->w_cin = d->cin; e->dgrad = op ? 1 : 0; e->tco = e->tiles = e->cin_pad = 0;
-    e->kcout = op ? d->cin : d->cout; e->kcin = op ? d->cout : d->cin;
-    e->total = d->cout * d->cin * d->r * d->s;
-    return true;
+    a.N = d->n; a.Hin = d->ho; a.Win = d->wo; a.Cin = d->cout; a.Cout = d->cin;
+    a.sh = 1; a.sw = 1; a.dh = d->dil_h; a.dw = d->dil_w; a.act = DCV_ACT_NONE; a.slope = 0.f;
+    if (d->stride_h == 1 && d->stride_w == 1) {
+        // filter flipped + transposed, pad' = dil*(R-1) - pad
+        a.Hout = d->h; a.Wout = d->w; a.R = d->r; a.S = d->s;
+        a.ph = d->dil_h * (d->r - 1) - d->pad_h; a.pw = d->dil_w * (d->s - 1) - d->pad_w; a.M = (long)d->n * d->h * d->w;
+        return run_mfma(a, dy, wb, nullptr, dx, st, nullptr, d->math);
+    }
+    bool any_empty = false;
+    for (int q = 0; q < np; ++q) any_empty = any_empty || pieces[q].total == 0;
+    if (any_empty && hipMemsetAsync(dx, 0, (size_t)d->n * d->h * d->w * d->cin * sizeof(float), st) != hipSuccess) return DCV_ERR_LAUNCH;
+    int q = 0;
+    for (int pa = 0; pa < d->stride_h; ++pa)
+        for (int pb = 0; pb < d->stride_w; ++pb, ++q) {
+            const PhaseAxis ph = phase_axis(pa, d->h, d->r, d->stride_h, d->pad_h), pw = phase_axis(pb, d->w, d->s, d->stride_w, d->pad_w);
+            if (ph.taps == 0 || pw.taps == 0 || ph.count == 0 || pw.count == 0) continue;
+            MfmaArgs p = a;
+            p.Hout = ph.count; p.Wout = pw.count; p.R = ph.taps; p.S = pw.taps; p.ph = ph.pad; p.pw = pw.pad; p.dh = p.dw = 1;
+            p.M = (long)d->n * ph.count * pw.count;
+            p.phase = 1; p.oh_mul = d->stride_h; p.ow_mul = d->stride_w; p.oh_off = pa; p.ow_off = pb; p.Hfull = d->h; p.Wfull = d->w;
+            const int rc = run_mfma(p, dy, wb + pieces[q].dst_off, nullptr, dx, st, nullptr, d->math);
+            if (rc != DCV_OK) return rc;
+        }
+    return DCV_OK;
 }
 
 int dcv_mfma_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
