@@ -129,14 +129,20 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit('bench.py --gpus N > 1 must be launched through `python -m torch.distributed.run --nproc-per-node N ...`')
     assert torch.cuda.is_available(), 'bench.py needs a HIP device'
-    device = torch.device('cuda', local_rank)
+    # one GPU per rank; DCV_BENCH_SHARE_GPU=1 (rehearsal on a 1-GPU box, with DCV_BENCH_BACKEND=gloo) lets several ranks share the visible devices
+    share = os.environ.get('DCV_BENCH_SHARE_GPU') == '1'
+    device = torch.device('cuda', local_rank % torch.cuda.device_count() if share else local_rank)
     torch.cuda.set_device(device)
     use_dp = world > 1 or args.force_dp
     if use_dp:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl', device_id=device)   # "nccl" is RCCL on ROCm
+        backend = os.environ.get('DCV_BENCH_BACKEND', 'nccl')            # "nccl" is RCCL on ROCm
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from deepcv_amd import modules, optim
     from deepcv_amd.classification.image import create_model
