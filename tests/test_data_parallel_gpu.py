@@ -33,3 +33,19 @@ def test_rccl_path_world_size_one_matches_single_process(device):
     assert graphed['config']['final_loss'] == single['config']['final_loss'] == eager['config']['final_loss']
     for r in (single, graphed, eager):
         assert r['n_gpus'] == 1 and r['value'] > 0 and set(r['roofline']) >= {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'}
+
+
+def test_two_ranks_sharing_the_gpu_over_gloo(device):
+    """ Multi-process control flow of `bench.py --gpus 2` on real GPU processes (two ranks sharing this box's single GPU, collectives over gloo): process
+    group, rank-0 parameter broadcast, forward+backward graph per rank, bucket all-reduce (SUM / world size), optimizer graph, barriers, max-over-ranks
+    timing and the rank-0 JSON line.  RCCL itself needs one GPU per rank and is exercised by the driver's multi-GPU runs. """
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', DCV_BENCH_SHARE_GPU='1', DCV_BENCH_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', '29553',
+           str(ROOT / 'bench.py'), '--gpus', '2', '--steps', '10', '--warmup', '3']
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, 'exactly one JSON line (rank 0)'
+    r = json.loads(lines[0])
+    assert r['n_gpus'] == 2 and r['config']['parallelism'] == 'dp2' and r['config']['global_batch'] == 1024 and r['value'] > 0
+    assert 0.0 < r['config']['final_loss'] < 10.0 and 'cpu_baseline' not in r
