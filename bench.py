@@ -88,7 +88,7 @@ def dominant_kernel_roofline(device, launches: int = 200):
                                                  (ctypes.c_void_p * 1)(wt.data_ptr()), (ctypes.c_void_p * 1)(filt.data_ptr()), st), 'dcv_conv2d_prepare_filters')
 
     # as in the training step, the epilogue also emits the BatchNorm statistics partials of its output tile
-    stats = torch.empty((max(1, nat.lib.dcv_conv2d_fwd_stats_rows(d)), 2, c), dtype=torch.float64, device=device)
+    stats = torch.empty((2, c, max(1, nat.lib.dcv_conv2d_fwd_stats_rows(d))), dtype=torch.float64, device=device)
 
     def launch():
         nat.check(nat.lib.dcv_conv2d_fwd_prepared(d, x.data_ptr(), wt.data_ptr(), filt.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), st), 'dcv_conv2d_fwd_prepared')

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TileArgs a, const float*
         }
     }
     if (stats != nullptr) {
-        // block sums of y and y^2 per output channel -> stats[blockIdx.x][2][Cout].  All 2*TCO per-thread sums go through LDS ([quantity][256], conflict
+        // block sums of y and y^2 per output channel -> stats[2][Cout][gridDim.x].  All 2*TCO per-thread sums go through LDS ([quantity][256], conflict
         // free); quantity q is then summed by wave q % 4: 4 values per lane + one butterfly, instead of 2*TCO butterflies per wave (fixed order throughout).
         float* redf = reinterpret_cast<float*>(smem);              // [2 * TCO][256]; the input tile is dead
         const int lane = t & 63, wave = t >> 6;
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TileArgs a, const float*
             const float* rq = redf + q * 256 + lane;
             const float v = dcv_wave_sum((rq[0] + rq[64]) + (rq[128] + rq[192]));
             const int c = q < TCO ? q : q - TCO;
-            if (lane == 0 && co0 + c < a.Cout) stats[((size_t)blockIdx.x * 2 + (q < TCO ? 0 : 1)) * a.Cout + co0 + c] = (double)v;
+            if (lane == 0 && co0 + c < a.Cout) stats[((size_t)(q < TCO ? 0 : 1) * a.Cout + co0 + c) * gridDim.x + blockIdx.x] = (double)v;   // [2][Cout][rows]
         }
     }
 }

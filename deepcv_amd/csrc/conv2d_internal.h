@@ -6,7 +6,7 @@
 size_t dcv_direct_conv2d_fwd_ws(const dcv_conv2d_desc* d);
 size_t dcv_direct_conv2d_dgrad_ws(const dcv_conv2d_desc* d);
 // `prepared`: ws already holds the prepared filter of this (d, op) (dcv_conv2d_prepare_filters); otherwise it is scratch and the filter is prepared first
-// `stats` (nullable): per-block sums of y and y^2 per output channel, [rows][2][Cout] doubles with rows = dcv_*_conv2d_fwd_stats_rows(d) (0: unsupported)
+// `stats` (nullable): per-block sums of y and y^2 per output channel, [2][Cout][rows] doubles with rows = dcv_*_conv2d_fwd_stats_rows(d) (0: unsupported)
 int dcv_direct_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st, bool prepared = false, double* stats = nullptr);
 int dcv_direct_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d);
 int dcv_direct_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t st, bool prepared = false);

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaArgs a, const float*
         if (t < 2 * BN) {
             const int q = t / BN, c = t - q * BN;
             const double v = ((red[(0 * 2 + q) * BN + c] + red[(1 * 2 + q) * BN + c]) + red[(2 * 2 + q) * BN + c]) + red[(3 * 2 + q) * BN + c];
-            stats[((size_t)blockIdx.x * 2 + q) * a.Cout + n0 + c] = v;
+            stats[((size_t)q * a.Cout + n0 + c) * gridDim.x + blockIdx.x] = v;                 // [2][Cout][rows]
         }
     }
 }

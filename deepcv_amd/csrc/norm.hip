@@ -74,12 +74,17 @@ __global__ __launch_bounds__(DCV_CR_THREADS) void colreduce2_kernel(Loader ld, s
 __global__ void bn_finalize_fwd_kernel(const double* __restrict__ partial, int nb, size_t rows, int C,
                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                        float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps,
-                                       float* __restrict__ save_mean, float* __restrict__ save_rstd, float* __restrict__ scale_shift) {
+                                       float* __restrict__ save_mean, float* __restrict__ save_rstd, float* __restrict__ scale_shift, int transposed = 0) {
     // one wave per channel; lanes stride over the per-block partials, fixed-order butterfly merge
     const int c = blockIdx.x, lane = threadIdx.x;
     if (c == 0 && lane == 0 && nbt) nbt[0] += 1;
     double s = 0.0, ss = 0.0;
-    for (int b = lane; b < nb; b += DCV_WAVE) { s += partial[((size_t)b * 2 + 0) * C + c]; ss += partial[((size_t)b * 2 + 1) * C + c]; }
+    if (transposed) {        // [2][C][nb]: the rows of one (quantity, channel) are contiguous -> coalesced 8-B reads (convolution-epilogue statistics)
+        const double* p0 = partial + (size_t)c * nb; const double* p1 = partial + ((size_t)C + c) * nb;
+        for (int b = lane; b < nb; b += DCV_WAVE) { s += p0[b]; ss += p1[b]; }
+    } else {
+        for (int b = lane; b < nb; b += DCV_WAVE) { s += partial[((size_t)b * 2 + 0) * C + c]; ss += partial[((size_t)b * 2 + 1) * C + c]; }
+    }
     s = dcv_wave_sum(s); ss = dcv_wave_sum(ss);
     if (lane != 0) return;
     const double n = (double)rows;
@@ -351,16 +356,15 @@ __global__ __launch_bounds__(DCV_CR_THREADS) void nf_bn_gn_apply_kernel(const fl
     }
 }
 
-// finalize of the fused backward: one wave per channel, lanes stride over the per-sample partials [N][4][C] (S1, S2, T1, T2), fixed-order butterfly
+// finalize of the fused backward: one wave per channel, lanes stride over the per-sample partials [4][C][N] (S1, S2, T1, T2), fixed-order butterfly
 __global__ void nf_gn_bn_finalize_kernel(const double* __restrict__ partial, int N, size_t rows, int C, const float* __restrict__ bn_gamma,
                                          const float* __restrict__ bn_rstd, float* __restrict__ d_bn_gamma, float* __restrict__ d_bn_beta,
                                          float* __restrict__ d_gn_gamma, float* __restrict__ d_gn_beta, float* __restrict__ coef) {
     const int c = blockIdx.x, lane = threadIdx.x;
     double s1 = 0.0, s2 = 0.0, t1 = 0.0, t2 = 0.0;
-    for (int n = lane; n < N; n += DCV_WAVE) {
-        const double* pp = partial + (size_t)n * 4 * C + c;
-        s1 += pp[0]; s2 += pp[C]; t1 += pp[2 * (size_t)C]; t2 += pp[3 * (size_t)C];
-    }
+    const double* p0 = partial + (size_t)c * N; const double* p1 = partial + ((size_t)C + c) * N;
+    const double* p2 = partial + (2 * (size_t)C + c) * N; const double* p3 = partial + (3 * (size_t)C + c) * N;
+    for (int n = lane; n < N; n += DCV_WAVE) { s1 += p0[n]; s2 += p1[n]; t1 += p2[n]; t2 += p3[n]; }
     s1 = dcv_wave_sum(s1); s2 = dcv_wave_sum(s2); t1 = dcv_wave_sum(t1); t2 = dcv_wave_sum(t2);
     if (lane != 0) return;
     if (d_gn_beta) d_gn_beta[c] = (float)s1;
@@ -422,7 +426,7 @@ struct NfGnBwdLoaderB {         // pass B: dv = ca * dout - cb - w * cd  (stored
 };
 
 // backward (1), BN + GN: one block per sample.  GroupNorm backward on the recomputed BN output -> dv (gradient w.r.t. the BN output, written to `dv_out`),
-// per-sample sums S1 = sum dout, S2 = sum dout*w (GN parameter gradients), T1 = sum dv, T2 = sum dv*u (BN terms) -> partial [N][4][C].
+// per-sample sums S1 = sum dout, S2 = sum dout*w (GN parameter gradients), T1 = sum dv, T2 = sum dv*u (BN terms) -> partial [4][C][N].
 template <int VEC>
 __global__ __launch_bounds__(DCV_CR_THREADS) void nf_gn_bn_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ x, float* __restrict__ dv_out,
                                                                        int HW, int C, int G, const float* __restrict__ bn_gamma, const float* __restrict__ bn_beta,
@@ -462,7 +466,7 @@ __global__ __launch_bounds__(DCV_CR_THREADS) void nf_gn_bn_bwd_kernel(const floa
     __syncthreads();
     NfGnBwdLoaderB lb{dout + base, x + base, dv_out + base, bsc, bsh, gmc, grc, ca, cb, cd, bm, br};
     dcv_colreduce_block<2, VEC>(lb, 0, (size_t)HW, C, scratch, chan + 2 * (size_t)C);
-    for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) partial[(size_t)n * 4 * C + i] = chan[i];
+    for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) partial[(size_t)i * gridDim.x + n] = chan[i];     // [4][C][N]: the finalize reads sample-contiguous
 }
 
 struct NfApplyActLoader {       // dz = act'(x) * a * (dv - b - u * d), stored to dz;  q0 = dz  (bias gradient)
@@ -698,7 +702,7 @@ int dcv_bn_gn_fwd_train(const float* x, float* y, int n, int hw, int C,
         else hipLaunchKernelGGL((colreduce2_kernel<1, SumSqLoader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
     }
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((unsigned)C), dim3(64), 0, st, stats ? stats : partial, stats ? stats_rows : (int)nb, rows, C, bn_gamma, bn_beta,
-                       running_mean, running_var, nbt, momentum, bn_eps, bn_save_mean, bn_save_rstd, scale_shift);
+                       running_mean, running_var, nbt, momentum, bn_eps, bn_save_mean, bn_save_rstd, scale_shift, stats ? 1 : 0);
     if (G > 0) {
         const size_t smem = 2 * (size_t)C * sizeof(double) + (size_t)4 * C * sizeof(float) + (size_t)2 * DCV_CR_THREADS * vec * sizeof(float);
         if (smem > 64 * 1024) return DCV_ERR_UNSUPPORTED;

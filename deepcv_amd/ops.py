@@ -101,14 +101,14 @@ def _conv_desc(x_shape, w_shape, stride, padding, dilation, x_layout, act, slope
 
 def _conv_fwd_launch(d, x, weight, bias, y, st, want_stats: bool = False):
     """ Forward convolution; through the prepared-filter cache when `weight` is a plain parameter (see `deepcv_amd/filters.py`).  With `want_stats`
-    returns the [rows][2][Cout] fp64 BatchNorm statistics partials emitted by the kernel's epilogue (None when that kernel cannot). """
+    returns the [2][Cout][rows] fp64 BatchNorm statistics partials emitted by the kernel's epilogue (None when that kernel cannot). """
     f = filters.get(weight, d, 0)
     if f is not None:
         stats = None
         if want_stats:
             rows = int(lib.dcv_conv2d_fwd_stats_rows(d))
             if rows > 0:
-                stats = torch.empty((rows, 2, d.cout), dtype=torch.float64, device=x.device)
+                stats = torch.empty((2, d.cout, rows), dtype=torch.float64, device=x.device)
         nat.check(lib.dcv_conv2d_fwd_prepared(d, x.data_ptr(), weight.data_ptr(), f.data_ptr(), nat.ptr(bias), y.data_ptr(), nat.ptr(stats), st),
                   'dcv_conv2d_fwd_prepared')
         return stats
@@ -411,7 +411,7 @@ class _ConvNormLayerFn(torch.autograd.Function):
         ws = _ws(lib.dcv_norm_chain_workspace_bytes(d.n, hw, c), dev)
         nat.check(lib.dcv_bn_gn_fwd_train(y.data_ptr(), out.data_ptr(), d.n, hw, c, nat.ptr(bn_w), nat.ptr(bn_b), nat.ptr(running_mean), nat.ptr(running_var),
                                           nat.ptr(nbt), momentum, bn_eps, bn_mean.data_ptr(), bn_rstd.data_ptr(), groups, nat.ptr(gn_w), nat.ptr(gn_b), gn_eps,
-                                          nat.ptr(gn_mean), nat.ptr(gn_rstd), nat.ptr(stats), 0 if stats is None else stats.shape[0],
+                                          nat.ptr(gn_mean), nat.ptr(gn_rstd), nat.ptr(stats), 0 if stats is None else stats.shape[2],
                                           ws.data_ptr(), ws.numel(), st), 'dcv_bn_gn_fwd_train')
         ctx.desc, ctx.cfg = d, cfg
         ctx.save_for_backward(x, weight, bias, y, bn_w, bn_b, bn_mean, bn_rstd, gn_w, gn_mean, gn_rstd)

@@ -99,7 +99,7 @@ int dcv_conv2d_wgrad_fuses_bias(const dcv_conv2d_desc* d);
  *   dcv_conv2d_*_prepared       as dcv_conv2d_fwd / dcv_conv2d_dgrad with the filter prepared for exactly this descriptor (w still required: fallback paths) */
 size_t dcv_conv2d_filter_bytes(const dcv_conv2d_desc* d, int op);
 int dcv_conv2d_prepare_filters(int count, const dcv_conv2d_desc* const* descs, const int* ops, const float* const* w, void* const* filters, void* stream);
-/* `stats` (nullable): the kernel's epilogue also emits per-block sums of y and y^2 per output channel, [rows][2][Cout] doubles with
+/* `stats` (nullable): the kernel's epilogue also emits per-block sums of y and y^2 per output channel, [2][Cout][rows] doubles with
  * rows = dcv_conv2d_fwd_stats_rows(d) (0: this kernel cannot, pass NULL) — the BatchNorm statistics partials of dcv_bn_gn_fwd_train for free */
 int dcv_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d);
 int dcv_conv2d_fwd_prepared(const dcv_conv2d_desc* d, const float* x, const float* w, const void* filter, const float* bias, float* y, double* stats, void* stream);
@@ -184,7 +184,7 @@ int dcv_bn_gn_fwd_train(const float* x, float* y, int n, int hw, int channels,
                         const float* bn_gamma, const float* bn_beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                         float momentum, float bn_eps, float* bn_save_mean, float* bn_save_rstd,
                         int groups, const float* gn_gamma, const float* gn_beta, float gn_eps, float* gn_save_mean, float* gn_save_rstd,
-                        const double* stats /* nullable: [stats_rows][2][channels] partial sums of x, x^2 from the producer's epilogue */, int stats_rows,
+                        const double* stats /* nullable: [2][channels][stats_rows] partial sums of x, x^2 from the producer's epilogue */, int stats_rows,
                         void* ws, size_t ws_bytes, void* stream);
 int dcv_bn_gn_act_bwd(const float* dout, const float* x, float* dz, int n, int hw, int channels,
                       const float* bn_gamma, const float* bn_beta, const float* bn_save_mean, const float* bn_save_rstd,
