@@ -8,6 +8,8 @@
 
 namespace {
 
+#define FIN_THREADS 256           // threads per channel of the finalize kernels
+
 // ---------------------------------------------------------------- load functors for dcv_colreduce_block
 struct SumSqLoader {            // q0 = x, q1 = x^2
     const float* x;
@@ -75,17 +77,18 @@ __global__ void bn_finalize_fwd_kernel(const double* __restrict__ partial, int n
                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                        float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps,
                                        float* __restrict__ save_mean, float* __restrict__ save_rstd, float* __restrict__ scale_shift, int transposed = 0) {
-    // one wave per channel; lanes stride over the per-block partials, fixed-order butterfly merge
+    // one block (FIN_THREADS) per channel; threads stride over the per-block partials (short load chains), fixed-order merge (butterfly, then waves)
+    __shared__ double fred[FIN_THREADS / 64];
     const int c = blockIdx.x, lane = threadIdx.x;
     if (c == 0 && lane == 0 && nbt) nbt[0] += 1;
     double s = 0.0, ss = 0.0;
     if (transposed) {        // [2][C][nb]: the rows of one (quantity, channel) are contiguous -> coalesced 8-B reads (convolution-epilogue statistics)
         const double* p0 = partial + (size_t)c * nb; const double* p1 = partial + ((size_t)C + c) * nb;
-        for (int b = lane; b < nb; b += DCV_WAVE) { s += p0[b]; ss += p1[b]; }
+        for (int b = lane; b < nb; b += FIN_THREADS) { s += p0[b]; ss += p1[b]; }
     } else {
-        for (int b = lane; b < nb; b += DCV_WAVE) { s += partial[((size_t)b * 2 + 0) * C + c]; ss += partial[((size_t)b * 2 + 1) * C + c]; }
+        for (int b = lane; b < nb; b += FIN_THREADS) { s += partial[((size_t)b * 2 + 0) * C + c]; ss += partial[((size_t)b * 2 + 1) * C + c]; }
     }
-    s = dcv_wave_sum(s); ss = dcv_wave_sum(ss);
+    s = dcv_block_sum(s, fred); ss = dcv_block_sum(ss, fred);
     if (lane != 0) return;
     const double n = (double)rows;
     const double mean = s / n;
@@ -138,10 +141,11 @@ __global__ __launch_bounds__(256) void affine_apply_kernel(const float* __restri
 // coef layout (float [3][C]): a = gamma*rstd, b = sum(dy)/rows, d = sum(dy*xhat)/rows   ->  dx = a * (dy - b - xhat * d)
 __global__ void bn_finalize_bwd_kernel(const double* __restrict__ partial, int nb, size_t rows, int C, const float* __restrict__ gamma,
                                        const float* __restrict__ rstd, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
+    __shared__ double fred[FIN_THREADS / 64];
     const int c = blockIdx.x, lane = threadIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = lane; b < nb; b += DCV_WAVE) { s1 += partial[((size_t)b * 2 + 0) * C + c]; s2 += partial[((size_t)b * 2 + 1) * C + c]; }
-    s1 = dcv_wave_sum(s1); s2 = dcv_wave_sum(s2);
+    for (int b = lane; b < nb; b += FIN_THREADS) { s1 += partial[((size_t)b * 2 + 0) * C + c]; s2 += partial[((size_t)b * 2 + 1) * C + c]; }
+    s1 = dcv_block_sum(s1, fred); s2 = dcv_block_sum(s2, fred);
     if (lane != 0) return;
     if (dbeta) dbeta[c] = (float)s1;
     if (dgamma) dgamma[c] = (float)s2;
@@ -360,12 +364,13 @@ __global__ __launch_bounds__(DCV_CR_THREADS) void nf_bn_gn_apply_kernel(const fl
 __global__ void nf_gn_bn_finalize_kernel(const double* __restrict__ partial, int N, size_t rows, int C, const float* __restrict__ bn_gamma,
                                          const float* __restrict__ bn_rstd, float* __restrict__ d_bn_gamma, float* __restrict__ d_bn_beta,
                                          float* __restrict__ d_gn_gamma, float* __restrict__ d_gn_beta, float* __restrict__ coef) {
+    __shared__ double fred[FIN_THREADS / 64];
     const int c = blockIdx.x, lane = threadIdx.x;
     double s1 = 0.0, s2 = 0.0, t1 = 0.0, t2 = 0.0;
     const double* p0 = partial + (size_t)c * N; const double* p1 = partial + ((size_t)C + c) * N;
     const double* p2 = partial + (2 * (size_t)C + c) * N; const double* p3 = partial + (3 * (size_t)C + c) * N;
-    for (int n = lane; n < N; n += DCV_WAVE) { s1 += p0[n]; s2 += p1[n]; t1 += p2[n]; t2 += p3[n]; }
-    s1 = dcv_wave_sum(s1); s2 = dcv_wave_sum(s2); t1 = dcv_wave_sum(t1); t2 = dcv_wave_sum(t2);
+    for (int n = lane; n < N; n += FIN_THREADS) { s1 += p0[n]; s2 += p1[n]; t1 += p2[n]; t2 += p3[n]; }
+    s1 = dcv_block_sum(s1, fred); s2 = dcv_block_sum(s2, fred); t1 = dcv_block_sum(t1, fred); t2 = dcv_block_sum(t2, fred);
     if (lane != 0) return;
     if (d_gn_beta) d_gn_beta[c] = (float)s1;
     if (d_gn_gamma) d_gn_gamma[c] = (float)s2;
@@ -580,7 +585,7 @@ int dcv_batchnorm_fwd_train(const float* x, float* y, size_t rows, int C, const 
     SumSqLoader ld{x};
     if (C % 4 == 0) hipLaunchKernelGGL((colreduce2_kernel<4, SumSqLoader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
     else hipLaunchKernelGGL((colreduce2_kernel<1, SumSqLoader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((unsigned)C), dim3(64), 0, st, partial, (int)nb, rows, C, gamma, beta,
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((unsigned)C), dim3(FIN_THREADS), 0, st, partial, (int)nb, rows, C, gamma, beta,
                        running_mean, running_var, nbt, momentum, eps, save_mean, save_rstd, scale_shift);
     if (C % 4 == 0) {
         const size_t nv = rows * (size_t)C / 4;
@@ -620,7 +625,7 @@ int dcv_batchnorm_bwd(const float* dy, const float* x, float* dx, size_t rows, i
     BnBwdLoader ld{dy, x, save_mean, save_rstd};
     if (C % 4 == 0) hipLaunchKernelGGL((colreduce2_kernel<4, BnBwdLoader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
     else hipLaunchKernelGGL((colreduce2_kernel<1, BnBwdLoader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((unsigned)C), dim3(64), 0, st, partial, (int)nb, rows, C, gamma, save_rstd, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((unsigned)C), dim3(FIN_THREADS), 0, st, partial, (int)nb, rows, C, gamma, save_rstd, dgamma, dbeta, coef);
     if (C % 4 == 0) {
         const size_t nv = rows * (size_t)C / 4;
         hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(dcv_stream_grid(nv, 256)), dim3(256), 0, st, dy, x, dx, nv, C, save_mean, save_rstd, coef);
@@ -701,7 +706,7 @@ int dcv_bn_gn_fwd_train(const float* x, float* y, int n, int hw, int C,
         if (vec == 4) hipLaunchKernelGGL((colreduce2_kernel<4, SumSqLoader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
         else hipLaunchKernelGGL((colreduce2_kernel<1, SumSqLoader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
     }
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((unsigned)C), dim3(64), 0, st, stats ? stats : partial, stats ? stats_rows : (int)nb, rows, C, bn_gamma, bn_beta,
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((unsigned)C), dim3(FIN_THREADS), 0, st, stats ? stats : partial, stats ? stats_rows : (int)nb, rows, C, bn_gamma, bn_beta,
                        running_mean, running_var, nbt, momentum, bn_eps, bn_save_mean, bn_save_rstd, scale_shift, stats ? 1 : 0);
     if (G > 0) {
         const size_t smem = 2 * (size_t)C * sizeof(double) + (size_t)4 * C * sizeof(float) + (size_t)2 * DCV_CR_THREADS * vec * sizeof(float);
@@ -741,14 +746,14 @@ int dcv_bn_gn_act_bwd(const float* dout, const float* x, float* dz, int n, int h
                                          gn_gamma, gn_save_mean, gn_save_rstd, partial);
         else hipLaunchKernelGGL((nf_gn_bn_bwd_kernel<1>), dim3(n), dim3(DCV_CR_THREADS), smem, st, dout, x, dz, hw, C, G, bn_gamma, bn_beta, bn_save_mean, bn_save_rstd,
                                 gn_gamma, gn_save_mean, gn_save_rstd, partial);
-        hipLaunchKernelGGL(nf_gn_bn_finalize_kernel, dim3((unsigned)C), dim3(64), 0, st, partial, n, rows, C, bn_gamma, bn_save_rstd,
+        hipLaunchKernelGGL(nf_gn_bn_finalize_kernel, dim3((unsigned)C), dim3(FIN_THREADS), 0, st, partial, n, rows, C, bn_gamma, bn_save_rstd,
                            d_bn_gamma, d_bn_beta, d_gn_gamma, d_gn_beta, coef);
         dv = dz;                                             // the apply pass runs in place on dz
     } else {
         BnBwdLoader ld{dout, x, bn_save_mean, bn_save_rstd};
         if (vec == 4) hipLaunchKernelGGL((colreduce2_kernel<4, BnBwdLoader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
         else hipLaunchKernelGGL((colreduce2_kernel<1, BnBwdLoader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
-        hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((unsigned)C), dim3(64), 0, st, partial, (int)nb, rows, C, bn_gamma, bn_save_rstd, d_bn_gamma, d_bn_beta, coef);
+        hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((unsigned)C), dim3(FIN_THREADS), 0, st, partial, (int)nb, rows, C, bn_gamma, bn_save_rstd, d_bn_gamma, d_bn_beta, coef);
     }
     NfApplyActLoader ld{dv, x, dz, bn_save_mean, bn_save_rstd, coef, C, act, slope};
     if (d_bias) {
