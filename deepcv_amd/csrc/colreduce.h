@@ -13,29 +13,13 @@
 // Reduces rows [row_begin, row_end) for all channels; on return (after an internal __syncthreads) `out[q * C + c]` (LDS or global,
 // double) holds the block's sum for quantity q / channel c.  `scratch` must hold NQ * DCV_CR_THREADS * VEC floats of LDS.
 // Must be called by all DCV_CR_THREADS threads of the block.
-template <int NQ, int VEC, typename F>
-__device__ __forceinline__ void dcv_colreduce_block(const F& f, size_t row_begin, size_t row_end, int C, float* scratch, double* out) {
+// Second half of dcv_colreduce_block for CV <= DCV_CR_THREADS: merges the per-thread partial sums acc[q][v] of thread (rsub = t / CV, cv = t % CV) over
+// the row sub-streams in a fixed order; `out[q * C + c]` (LDS or global, double) receives the block's sums.  Must be called by all threads.
+template <int NQ, int VEC>
+__device__ __forceinline__ void dcv_colreduce_merge(const float (&acc)[NQ][VEC], int C, float* scratch, double* out) {
     const int t = threadIdx.x;
-    const int CV = C / VEC;                       // channel-vectors per row (C % VEC == 0 guaranteed by the caller)
-    if (CV <= DCV_CR_THREADS) {
-        const int rows_per_iter = DCV_CR_THREADS / CV;
-        const int active = rows_per_iter * CV;
-        const int cv = t % CV, rsub = t / CV;
-        float acc[NQ][VEC];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) acc[q][v] = 0.f;
-        if (t < active) {
-            for (size_t r = row_begin + rsub; r < row_end; r += rows_per_iter) {
-                float qv[NQ][VEC];
-                f.template load<VEC>(r * (size_t)C + (size_t)cv * VEC, cv * VEC, qv);
-#pragma unroll
-                for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) acc[q][v] += qv[q][v];
-            }
-        }
+    const int CV = C / VEC;
+    const int rows_per_iter = DCV_CR_THREADS / CV;
         __syncthreads();                          // scratch may still be in use by a previous call
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
@@ -77,6 +61,32 @@ __device__ __forceinline__ void dcv_colreduce_block(const F& f, size_t row_begin
             }
         }
         __syncthreads();
+}
+
+template <int NQ, int VEC, typename F>
+__device__ __forceinline__ void dcv_colreduce_block(const F& f, size_t row_begin, size_t row_end, int C, float* scratch, double* out) {
+    const int t = threadIdx.x;
+    const int CV = C / VEC;                       // channel-vectors per row (C % VEC == 0 guaranteed by the caller)
+    if (CV <= DCV_CR_THREADS) {
+        const int rows_per_iter = DCV_CR_THREADS / CV;
+        const int active = rows_per_iter * CV;
+        const int cv = t % CV, rsub = t / CV;
+        float acc[NQ][VEC];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[q][v] = 0.f;
+        if (t < active) {
+            for (size_t r = row_begin + rsub; r < row_end; r += rows_per_iter) {
+                float qv[NQ][VEC];
+                f.template load<VEC>(r * (size_t)C + (size_t)cv * VEC, cv * VEC, qv);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[q][v] += qv[q][v];
+            }
+        }
+        dcv_colreduce_merge<NQ, VEC>(acc, C, scratch, out);
     } else {
         // wide rows: each thread owns channel-vectors cv = t, t + 256, ... and walks every row of the range
         for (int cv = t; cv < CV; cv += DCV_CR_THREADS) {

@@ -5,6 +5,7 @@
 //
 // Replaces torch.nn.BatchNorm2d (reference src/deepcv/meta/nn.py:418,487-491,501) and torch.nn.GroupNorm (nn.py:494-495,501).
 #include "colreduce.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -311,7 +312,16 @@ struct AffineSumSqLoader {      // v = x * scale[c] + shift[c];  q0 = v, q1 = v^
 };
 
 // forward (2): out = GroupNorm(x * bn_scale + bn_shift), one block per sample; the BN output only exists in registers.
-template <int VEC>
+#define NF_NR 4                   // rows of a sample a thread keeps in registers in the CACHED variants (HW <= NF_NR * 256 / (C / VEC))
+
+__device__ __forceinline__ void nf_load_vec4(const float* p, float (&v)[4]) { const float4 q = *reinterpret_cast<const float4*>(p); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+__device__ __forceinline__ void nf_load_vec4(const float* p, float (&v)[1]) { v[0] = p[0]; }
+__device__ __forceinline__ void nf_store_vec4(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void nf_store_vec4(float* p, const float (&v)[1]) { p[0] = v[0]; }
+
+// CACHED: the sample is small enough for every thread to keep its rows in registers between the statistics pass and the apply pass: each element is
+// read from memory once.
+template <int VEC, bool CACHED>
 __global__ __launch_bounds__(DCV_CR_THREADS) void nf_bn_gn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, int HW, int C, int G,
                                                                          const float* __restrict__ bn_scale_shift, const float* __restrict__ gamma,
                                                                          const float* __restrict__ beta, float eps,
@@ -327,8 +337,30 @@ __global__ __launch_bounds__(DCV_CR_THREADS) void nf_bn_gn_apply_kernel(const fl
     const size_t base = (size_t)n * HW * C;
     for (int c = threadIdx.x; c < C; c += blockDim.x) { bsc[c] = bn_scale_shift[c]; bsh[c] = bn_scale_shift[C + c]; }
     __syncthreads();
-    AffineSumSqLoader ld{x + base, bsc, bsh};
-    dcv_colreduce_block<2, VEC>(ld, 0, (size_t)HW, C, scratch, chan);
+    const int CV = C / VEC;
+    const int rpi = CACHED ? DCV_CR_THREADS / CV : 1, cv0 = (threadIdx.x % CV) * VEC, rsub = threadIdx.x / CV;
+    const bool row_thread = CACHED && (int)threadIdx.x < rpi * CV;
+    float xc[NF_NR][VEC];
+    if constexpr (CACHED) {
+        float acc[2][VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { acc[0][v] = 0.f; acc[1][v] = 0.f; }
+        if (row_thread) {
+#pragma unroll
+            for (int k = 0; k < NF_NR; ++k) {
+                const int r = rsub + k * rpi;
+                if (r < HW) {
+                    nf_load_vec4(x + base + (size_t)r * C + cv0, xc[k]);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) { const float u = xc[k][v] * bsc[cv0 + v] + bsh[cv0 + v]; acc[0][v] += u; acc[1][v] += u * u; }
+                }
+            }
+        }
+        dcv_colreduce_merge<2, VEC>(acc, C, scratch, chan);
+    } else {
+        AffineSumSqLoader ld{x + base, bsc, bsh};
+        dcv_colreduce_block<2, VEC>(ld, 0, (size_t)HW, C, scratch, chan);
+    }
     const int cpg = C / G;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const int g = c / cpg;
@@ -345,7 +377,21 @@ __global__ __launch_bounds__(DCV_CR_THREADS) void nf_bn_gn_apply_kernel(const fl
         shift[c] = (bsh[c] - (float)mean) * rstd * gm + bt;
     }
     __syncthreads();
-    const int CV = C / VEC;
+    if constexpr (CACHED) {
+        if (row_thread) {
+#pragma unroll
+            for (int k = 0; k < NF_NR; ++k) {
+                const int r = rsub + k * rpi;
+                if (r < HW) {
+                    float o[VEC];
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) o[v] = xc[k][v] * scale[cv0 + v] + shift[cv0 + v];
+                    nf_store_vec4(y + base + (size_t)r * C + cv0, o);
+                }
+            }
+        }
+        return;
+    }
     const size_t nv = (size_t)HW * CV;
     for (size_t i = threadIdx.x; i < nv; i += blockDim.x) {
         const int c = (int)(i % CV) * VEC;
@@ -432,7 +478,7 @@ struct NfGnBwdLoaderB {         // pass B: dv = ca * dout - cb - w * cd  (stored
 
 // backward (1), BN + GN: one block per sample.  GroupNorm backward on the recomputed BN output -> dv (gradient w.r.t. the BN output, written to `dv_out`),
 // per-sample sums S1 = sum dout, S2 = sum dout*w (GN parameter gradients), T1 = sum dv, T2 = sum dv*u (BN terms) -> partial [4][C][N].
-template <int VEC>
+template <int VEC, bool CACHED>
 __global__ __launch_bounds__(DCV_CR_THREADS) void nf_gn_bn_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ x, float* __restrict__ dv_out,
                                                                        int HW, int C, int G, const float* __restrict__ bn_gamma, const float* __restrict__ bn_beta,
                                                                        const float* __restrict__ bn_mean, const float* __restrict__ bn_rstd,
@@ -456,8 +502,35 @@ __global__ __launch_bounds__(DCV_CR_THREADS) void nf_gn_bn_bwd_kernel(const floa
         gmc[c] = mean[c / cpg]; grc[c] = rstd[c / cpg];
     }
     __syncthreads();
-    NfGnBwdLoaderA la{dout + base, x + base, bsc, bsh, gmc, grc};
-    dcv_colreduce_block<2, VEC>(la, 0, (size_t)HW, C, scratch, chan);
+    const int CV = C / VEC;
+    const int rpi = CACHED ? DCV_CR_THREADS / CV : 1, cv0 = (threadIdx.x % CV) * VEC, rsub = threadIdx.x / CV;
+    const bool row_thread = CACHED && (int)threadIdx.x < rpi * CV;
+    float xc[NF_NR][VEC], dc[NF_NR][VEC];                               // CACHED: this thread's rows of x and dout, read from memory once
+    if constexpr (CACHED) {
+        float acc[2][VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { acc[0][v] = 0.f; acc[1][v] = 0.f; }
+        if (row_thread) {
+#pragma unroll
+            for (int k = 0; k < NF_NR; ++k) {
+                const int r = rsub + k * rpi;
+                if (r < HW) {
+                    nf_load_vec4(x + base + (size_t)r * C + cv0, xc[k]);
+                    nf_load_vec4(dout + base + (size_t)r * C + cv0, dc[k]);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const int c = cv0 + v;
+                        const float w = (xc[k][v] * bsc[c] + bsh[c] - gmc[c]) * grc[c];
+                        acc[0][v] += dc[k][v]; acc[1][v] += dc[k][v] * w;
+                    }
+                }
+            }
+        }
+        dcv_colreduce_merge<2, VEC>(acc, C, scratch, chan);
+    } else {
+        NfGnBwdLoaderA la{dout + base, x + base, bsc, bsh, gmc, grc};
+        dcv_colreduce_block<2, VEC>(la, 0, (size_t)HW, C, scratch, chan);
+    }
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const int g = c / cpg;
         double A = 0.0, B = 0.0;
@@ -469,8 +542,32 @@ __global__ __launch_bounds__(DCV_CR_THREADS) void nf_gn_bn_bwd_kernel(const floa
         cd[c] = (float)(B / m) * rstd[g];
     }
     __syncthreads();
-    NfGnBwdLoaderB lb{dout + base, x + base, dv_out + base, bsc, bsh, gmc, grc, ca, cb, cd, bm, br};
-    dcv_colreduce_block<2, VEC>(lb, 0, (size_t)HW, C, scratch, chan + 2 * (size_t)C);
+    if constexpr (CACHED) {
+        float acc[2][VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { acc[0][v] = 0.f; acc[1][v] = 0.f; }
+        if (row_thread) {
+#pragma unroll
+            for (int k = 0; k < NF_NR; ++k) {
+                const int r = rsub + k * rpi;
+                if (r < HW) {
+                    float dvv[VEC];
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const int c = cv0 + v;
+                        const float w = (xc[k][v] * bsc[c] + bsh[c] - gmc[c]) * grc[c];
+                        dvv[v] = ca[c] * dc[k][v] - cb[c] - w * cd[c];
+                        acc[0][v] += dvv[v]; acc[1][v] += dvv[v] * ((xc[k][v] - bm[c]) * br[c]);
+                    }
+                    nf_store_vec4(dv_out + base + (size_t)r * C + cv0, dvv);
+                }
+            }
+        }
+        dcv_colreduce_merge<2, VEC>(acc, C, scratch, chan + 2 * (size_t)C);
+    } else {
+        NfGnBwdLoaderB lb{dout + base, x + base, dv_out + base, bsc, bsh, gmc, grc, ca, cb, cd, bm, br};
+        dcv_colreduce_block<2, VEC>(lb, 0, (size_t)HW, C, scratch, chan + 2 * (size_t)C);
+    }
     for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) partial[(size_t)i * gridDim.x + n] = chan[i];     // [4][C][N]: the finalize reads sample-contiguous
 }
 
@@ -676,6 +773,15 @@ int dcv_groupnorm_bwd(const float* dy, const float* x, float* dx, int n, int hw,
 
 
 // ------------------------------------------------------------------------------------------------ fused chain entry points
+static inline bool nf_sample_fits_registers(int hw, int C, int vec) {
+    static int enabled = -1;
+    if (enabled < 0) { const char* e = getenv("DCV_NORM_CACHED"); enabled = e ? atoi(e) : 1; }
+    const int cv = C / vec;
+    if (!enabled || cv > DCV_CR_THREADS) return false;
+    const int rpi = DCV_CR_THREADS / cv;
+    return (hw + rpi - 1) / rpi <= NF_NR;
+}
+
 static inline size_t nf_partial_bytes(int n, int hw, int C) {
     const size_t rows = (size_t)n * hw;
     size_t a = (size_t)dcv_colreduce_blocks(rows, C) * 2 * C, b = (size_t)n * 4 * C;
@@ -711,8 +817,11 @@ int dcv_bn_gn_fwd_train(const float* x, float* y, int n, int hw, int C,
     if (G > 0) {
         const size_t smem = 2 * (size_t)C * sizeof(double) + (size_t)4 * C * sizeof(float) + (size_t)2 * DCV_CR_THREADS * vec * sizeof(float);
         if (smem > 64 * 1024) return DCV_ERR_UNSUPPORTED;
-        if (vec == 4) hipLaunchKernelGGL((nf_bn_gn_apply_kernel<4>), dim3(n), dim3(DCV_CR_THREADS), smem, st, x, y, hw, C, G, scale_shift, gn_gamma, gn_beta, gn_eps, gn_save_mean, gn_save_rstd);
-        else hipLaunchKernelGGL((nf_bn_gn_apply_kernel<1>), dim3(n), dim3(DCV_CR_THREADS), smem, st, x, y, hw, C, G, scale_shift, gn_gamma, gn_beta, gn_eps, gn_save_mean, gn_save_rstd);
+        const bool cached = nf_sample_fits_registers(hw, C, vec);
+        if (vec == 4 && cached) hipLaunchKernelGGL((nf_bn_gn_apply_kernel<4, true>), dim3(n), dim3(DCV_CR_THREADS), smem, st, x, y, hw, C, G, scale_shift, gn_gamma, gn_beta, gn_eps, gn_save_mean, gn_save_rstd);
+        else if (vec == 4) hipLaunchKernelGGL((nf_bn_gn_apply_kernel<4, false>), dim3(n), dim3(DCV_CR_THREADS), smem, st, x, y, hw, C, G, scale_shift, gn_gamma, gn_beta, gn_eps, gn_save_mean, gn_save_rstd);
+        else if (cached) hipLaunchKernelGGL((nf_bn_gn_apply_kernel<1, true>), dim3(n), dim3(DCV_CR_THREADS), smem, st, x, y, hw, C, G, scale_shift, gn_gamma, gn_beta, gn_eps, gn_save_mean, gn_save_rstd);
+        else hipLaunchKernelGGL((nf_bn_gn_apply_kernel<1, false>), dim3(n), dim3(DCV_CR_THREADS), smem, st, x, y, hw, C, G, scale_shift, gn_gamma, gn_beta, gn_eps, gn_save_mean, gn_save_rstd);
     } else if (vec == 4) {
         const size_t nv = rows * (size_t)C / 4;
         hipLaunchKernelGGL((affine_apply_kernel<4>), dim3(dcv_stream_grid(nv, 256)), dim3(256), 0, st, x, y, nv, C, scale_shift);
@@ -742,10 +851,11 @@ int dcv_bn_gn_act_bwd(const float* dout, const float* x, float* dz, int n, int h
     if (G > 0) {
         const size_t smem = 4 * (size_t)C * sizeof(double) + (size_t)9 * C * sizeof(float) + (size_t)2 * DCV_CR_THREADS * vec * sizeof(float);
         if (smem > 64 * 1024) return DCV_ERR_UNSUPPORTED;
-        if (vec == 4) hipLaunchKernelGGL((nf_gn_bn_bwd_kernel<4>), dim3(n), dim3(DCV_CR_THREADS), smem, st, dout, x, dz, hw, C, G, bn_gamma, bn_beta, bn_save_mean, bn_save_rstd,
-                                         gn_gamma, gn_save_mean, gn_save_rstd, partial);
-        else hipLaunchKernelGGL((nf_gn_bn_bwd_kernel<1>), dim3(n), dim3(DCV_CR_THREADS), smem, st, dout, x, dz, hw, C, G, bn_gamma, bn_beta, bn_save_mean, bn_save_rstd,
-                                gn_gamma, gn_save_mean, gn_save_rstd, partial);
+#define NF_BWD_LAUNCH(V_, C_) hipLaunchKernelGGL((nf_gn_bn_bwd_kernel<V_, C_>), dim3(n), dim3(DCV_CR_THREADS), smem, st, dout, x, dz, hw, C, G, bn_gamma, bn_beta, \
+                                                 bn_save_mean, bn_save_rstd, gn_gamma, gn_save_mean, gn_save_rstd, partial)
+        const bool cached = nf_sample_fits_registers(hw, C, vec);
+        if (vec == 4 && cached) NF_BWD_LAUNCH(4, true); else if (vec == 4) NF_BWD_LAUNCH(4, false); else if (cached) NF_BWD_LAUNCH(1, true); else NF_BWD_LAUNCH(1, false);
+#undef NF_BWD_LAUNCH
         hipLaunchKernelGGL(nf_gn_bn_finalize_kernel, dim3((unsigned)C), dim3(FIN_THREADS), 0, st, partial, n, rows, C, bn_gamma, bn_save_rstd,
                            d_bn_gamma, d_bn_beta, d_gn_gamma, d_gn_beta, coef);
         dv = dz;                                             // the apply pass runs in place on dz
