@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void linear_wgrad_partial_kernel(const float* 
     float acc[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
-    for (int n = n0; n < n1; ++n) {
+#pragma unroll 8
+    for (int n = n0; n < n1; ++n) {                    // unrolled: 8 rows of x in flight per thread
         const float g = dy[(size_t)n * O + o];
         if constexpr (VEC == 4) {
             const float4 a = reinterpret_cast<const float4*>(x + (size_t)n * K)[k];
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_partial_kernel(const float* 
 __global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int chunks, size_t ok) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ok; i += (size_t)gridDim.x * blockDim.x) {
         float s = 0.f;
+#pragma unroll 8
         for (int c = 0; c < chunks; ++c) s += partial[(size_t)c * ok + i];
         dw[i] = s;
     }
@@ -184,12 +186,16 @@ __global__ __launch_bounds__(CE_THREADS) void ce_fwd_partial_kernel(const float*
     }
 }
 
-__global__ void ce_fwd_final_kernel(const double* __restrict__ part_loss, const int* __restrict__ part_correct, int nb, int N, float* __restrict__ loss, int32_t* __restrict__ correct) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(64) void ce_fwd_final_kernel(const double* __restrict__ part_loss, const int* __restrict__ part_correct, int nb, int N, float* __restrict__ loss, int32_t* __restrict__ correct) {
+    // one wave: lanes stride over the block partials (a single thread walking them was a chain of nb dependent loads), fixed-order butterfly
+    const int lane = threadIdx.x;
     double s = 0.0; int k = 0;
-    for (int i = 0; i < nb; ++i) { s += part_loss[i]; k += part_correct[i]; }
-    loss[0] = (float)(s / (double)N);
-    if (correct) correct[0] = k;
+    for (int i = lane; i < nb; i += 64) { s += part_loss[i]; k += part_correct[i]; }
+    s = dcv_wave_sum(s); k = dcv_wave_sum(k);
+    if (lane == 0) {
+        loss[0] = (float)(s / (double)N);
+        if (correct) correct[0] = k;
+    }
 }
 
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ z, const int64_t* __restrict__ target, const float* __restrict__ lse,
