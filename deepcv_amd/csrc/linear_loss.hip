@@ -147,6 +147,76 @@ __global__ __launch_bounds__(64) void linear_bias_grad_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------- cross entropy
+// ---- fused backward of y = act(x W^T + b): the activation derivative is applied on the fly by every consumer of dz (no dz tensor, no separate pass),
+// the bias gradient rides in the weight-gradient slabs
+template <int VEC>
+__global__ __launch_bounds__(256) void linear_dgrad_act_kernel(const float* __restrict__ dy, const float* __restrict__ y, int act, float slope, const float* __restrict__ w,
+                                                                float* __restrict__ dx, int N, int K, int O) {
+    const int KV = K / VEC;
+    const size_t total = (size_t)N * KV;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / KV), k = (int)(i % KV);
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+#pragma unroll 4
+        for (int o = 0; o < O; ++o) {
+            const float g = dy[(size_t)n * O + o] * (y ? dcv_act_grad_from_out(y[(size_t)n * O + o], act, slope) : 1.f);
+            if constexpr (VEC == 4) {
+                const float4 b = reinterpret_cast<const float4*>(w + (size_t)o * K)[k];
+                acc[0] += g * b.x; acc[1] += g * b.y; acc[2] += g * b.z; acc[3] += g * b.w;
+            } else acc[0] += g * w[(size_t)o * K + k];
+        }
+        if constexpr (VEC == 4) { float4 o4; o4.x = acc[0]; o4.y = acc[1]; o4.z = acc[2]; o4.w = acc[3]; reinterpret_cast<float4*>(dx + (size_t)n * K)[k] = o4; }
+        else dx[(size_t)n * K + k] = acc[0];
+    }
+}
+
+// grid (k-vector tiles, O, chunks): partial[chunk][o][k] = sum_{n in chunk} dz[n][o] * x[n][k];  partial_b[chunk][o] = sum_{n in chunk} dz[n][o]
+template <int VEC>
+__global__ __launch_bounds__(256) void linear_wgrad_act_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y, int act, float slope,
+                                                                        float* __restrict__ partial, float* __restrict__ partial_b, int N, int K, int O) {
+    const int KV = K / VEC;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= KV) return;
+    const int o = blockIdx.y, chunk = blockIdx.z;
+    const int n0 = chunk * LIN_WG_CHUNK;
+    int n1 = n0 + LIN_WG_CHUNK; if (n1 > N) n1 = N;
+    float acc[VEC], gsum = 0.f;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+#pragma unroll 8
+    for (int n = n0; n < n1; ++n) {
+        const float g = dy[(size_t)n * O + o] * (y ? dcv_act_grad_from_out(y[(size_t)n * O + o], act, slope) : 1.f);
+        gsum += g;
+        if constexpr (VEC == 4) {
+            const float4 a = reinterpret_cast<const float4*>(x + (size_t)n * K)[k];
+            acc[0] += g * a.x; acc[1] += g * a.y; acc[2] += g * a.z; acc[3] += g * a.w;
+        } else acc[0] += g * x[(size_t)n * K + k];
+    }
+    float* dst = partial + ((size_t)chunk * O + o) * K;
+    if constexpr (VEC == 4) { float4 o4; o4.x = acc[0]; o4.y = acc[1]; o4.z = acc[2]; o4.w = acc[3]; reinterpret_cast<float4*>(dst)[k] = o4; }
+    else dst[k] = acc[0];
+    if (k == 0 && partial_b) partial_b[(size_t)chunk * O + o] = gsum;
+}
+
+__global__ __launch_bounds__(256) void linear_wgrad_bias_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ partial_b, float* __restrict__ dw,
+                                                                        float* __restrict__ db, int chunks, size_t ok, int O) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ok + (db ? O : 0); i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        if (i < ok) {
+#pragma unroll 8
+            for (int c = 0; c < chunks; ++c) s += partial[(size_t)c * ok + i];
+            if (dw) dw[i] = s;
+        } else {
+            const size_t o = i - ok;
+#pragma unroll 8
+            for (int c = 0; c < chunks; ++c) s += partial_b[(size_t)c * O + o];
+            db[o] = s;
+        }
+    }
+}
+
 #define CE_THREADS 256           // 4 waves per block, one sample per wave per iteration
 // stage 1: per-block partial loss sum (double) and correct count
 __global__ __launch_bounds__(CE_THREADS) void ce_fwd_partial_kernel(const float* __restrict__ z, const int64_t* __restrict__ target, float* __restrict__ lse_out,
@@ -281,6 +351,41 @@ int dcv_cross_entropy_bwd(const float* logits, const int64_t* target, const floa
     DCV_CHECK_ARG(logits && target && lse && dloss && dlogits && n > 0 && classes > 0);
     hipStream_t st = dcv_stream(stream);
     hipLaunchKernelGGL(ce_bwd_kernel, dim3(dcv_stream_grid((size_t)n * classes, 256)), dim3(256), 0, st, logits, target, lse, dloss, dlogits, n, classes);
+    DCV_RETURN_LAUNCH();
+}
+
+
+size_t dcv_linear_bwd_workspace_bytes(int n, int K, int O) {
+    if (n <= 0 || K <= 0 || O <= 0) return 0;
+    return dcv_align_up(dcv_ceil_div(n, LIN_WG_CHUNK) * ((size_t)O * K + O) * sizeof(float), 256);
+}
+
+int dcv_linear_bwd(const float* dy, const float* y, int act, float slope, const float* x, const float* w, float* dx, float* dw, float* db,
+                   int n, int K, int O, void* ws, size_t ws_bytes, void* stream) {
+    DCV_CHECK_ARG(dy && x && w && n > 0 && K > 0 && O > 0 && O <= 65535 && act >= DCV_ACT_NONE && act <= DCV_ACT_TANH && (act == DCV_ACT_NONE || y));
+    hipStream_t st = dcv_stream(stream);
+    const float* yy = act == DCV_ACT_NONE ? nullptr : y;
+    const bool v4 = K % 4 == 0 && aligned16(x) && aligned16(w) && (!dx || aligned16(dx));
+    if (dx) {
+        if (v4) hipLaunchKernelGGL((linear_dgrad_act_kernel<4>), dim3(dcv_stream_grid((size_t)n * (K / 4), 256)), dim3(256), 0, st, dy, yy, act, slope, w, dx, n, K, O);
+        else hipLaunchKernelGGL((linear_dgrad_act_kernel<1>), dim3(dcv_stream_grid((size_t)n * K, 256)), dim3(256), 0, st, dy, yy, act, slope, w, dx, n, K, O);
+    }
+    if (dw || db) {
+        if (!ws || ws_bytes < dcv_linear_bwd_workspace_bytes(n, K, O)) return DCV_ERR_WORKSPACE;
+        const int chunks = (int)dcv_ceil_div(n, LIN_WG_CHUNK);
+        DCV_CHECK_ARG(chunks <= 65535);
+        float* partial = reinterpret_cast<float*>(ws);
+        float* partial_b = partial + (size_t)chunks * O * K;
+        if (v4) {
+            dim3 grid((unsigned)dcv_ceil_div(K / 4, 256), (unsigned)O, (unsigned)chunks);
+            hipLaunchKernelGGL((linear_wgrad_act_partial_kernel<4>), grid, dim3(256), 0, st, x, dy, yy, act, slope, partial, partial_b, n, K, O);
+        } else {
+            dim3 grid((unsigned)dcv_ceil_div(K, 256), (unsigned)O, (unsigned)chunks);
+            hipLaunchKernelGGL((linear_wgrad_act_partial_kernel<1>), grid, dim3(256), 0, st, x, dy, yy, act, slope, partial, partial_b, n, K, O);
+        }
+        const size_t ok = (size_t)O * K;
+        hipLaunchKernelGGL(linear_wgrad_bias_reduce_kernel, dim3(dcv_stream_grid(ok + O, 256)), dim3(256), 0, st, partial, partial_b, dw, db, chunks, ok, O);
+    }
     DCV_RETURN_LAUNCH();
 }
 

@@ -672,20 +672,13 @@ class _LinearFn(torch.autograd.Function):
         o = weight.shape[0]
         dev, st = dy.device, nat.current_stream(dy.device)
         dy = dy.contiguous()
-        if ctx.act != nat.ACT_NONE:
-            dz = torch.empty_like(dy)
-            nat.check(lib.dcv_act_bwd(dy.data_ptr(), y.data_ptr(), dz.data_ptr(), n, o, ctx.act, ctx.slope, None, None, 0, st), 'dcv_act_bwd')
-        else:
-            dz = dy
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            nat.check(lib.dcv_linear_dgrad(dz.data_ptr(), weight.data_ptr(), dx.data_ptr(), n, k, o, st), 'dcv_linear_dgrad')
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw = torch.empty_like(weight)
-            db = torch.empty(o, dtype=dy.dtype, device=dev) if ctx.has_bias else None
-            ws = _ws(lib.dcv_linear_wgrad_workspace_bytes(n, k, o), dev)
-            nat.check(lib.dcv_linear_wgrad(x.data_ptr(), dz.data_ptr(), dw.data_ptr(), nat.ptr(db), n, k, o, ws.data_ptr(), ws.numel(), st), 'dcv_linear_wgrad')
+        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(weight) if need_w else None
+        db = torch.empty(o, dtype=dy.dtype, device=dev) if (need_w and ctx.has_bias) else None
+        ws = _ws(lib.dcv_linear_bwd_workspace_bytes(n, k, o), dev)
+        nat.check(lib.dcv_linear_bwd(dy.data_ptr(), nat.ptr(y), ctx.act, ctx.slope, x.data_ptr(), weight.data_ptr(), nat.ptr(dx), nat.ptr(dw), nat.ptr(db),
+                                     n, k, o, ws.data_ptr(), ws.numel(), st), 'dcv_linear_bwd')
         return dx, dw, db, None, None
 
 

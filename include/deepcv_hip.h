@@ -288,6 +288,12 @@ int dcv_publish_scalars(const dcv_copy_jobs* mailbox, const float* const* srcs, 
  * ------------------------------------------------------------------------------------------------- */
 /* [N][A][B] -> [N][B][A]  (NHWC->NCHW flatten order: A=HW, B=C;  NCHW->NHWC: A=C, B=HW) */
 int dcv_transpose_inner(const float* x, float* y, int n, int a, int b, void* stream);
+/* whole backward of y = act(x W^T + b) in three launches: dx = dz W, dw = dz^T x, db = sum dz with dz = dy * act'(y) evaluated on the fly by every
+ * consumer (no dz tensor, no separate activation-backward pass; the bias gradient rides in the weight-gradient slabs).  y may be NULL when act is
+ * DCV_ACT_NONE; dx / dw / db are nullable. */
+size_t dcv_linear_bwd_workspace_bytes(int n, int in_features, int out_features);
+int dcv_linear_bwd(const float* dy, const float* y, int act, float act_slope, const float* x, const float* w, float* dx, float* dw, float* db,
+                   int n, int in_features, int out_features, void* ws, size_t ws_bytes, void* stream);
 size_t dcv_linear_wgrad_workspace_bytes(int n, int in_features, int out_features);
 /* y[N][O] = act(x[N][K] . w[O][K]^T + bias) */
 int dcv_linear_fwd(const float* x, const float* w, const float* bias, float* y, int n, int in_features, int out_features,
