@@ -13,10 +13,10 @@ namespace {
 // one wave per sample row; lanes stride over K.  The row of x is read ONCE into registers (up to XR vectors per lane) and 8 output features are
 // accumulated together, so that the loads of 8 weight rows are in flight at once and the 8 wave reductions are independent (a per-feature loop
 // re-reading x was a chain of 10 dependent global-memory latencies for the 10-class head).
-template <int VEC>
+template <int VEC, int OB>
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                           float* __restrict__ y, int N, int K, int O, int act, float slope) {
-    constexpr int XR = 8, OB = 8;
+    constexpr int XR = 8;                                      // OB: output features accumulated together (10 for the 10-class head: one pass, no idle slots)
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (n >= N) return;
@@ -290,8 +290,10 @@ int dcv_linear_fwd(const float* x, const float* w, const float* bias, float* y, 
     DCV_CHECK_ARG(x && w && y && n > 0 && K > 0 && O > 0 && act >= DCV_ACT_NONE && act <= DCV_ACT_TANH);
     hipStream_t st = dcv_stream(stream);
     const dim3 grid((unsigned)dcv_ceil_div(n, 4), (unsigned)dcv_ceil_div(O, LIN_OCHUNK));
-    if (K % 4 == 0 && aligned16(x) && aligned16(w)) hipLaunchKernelGGL((linear_fwd_kernel<4>), grid, dim3(256), 0, st, x, w, bias, y, n, K, O, act, slope);
-    else hipLaunchKernelGGL((linear_fwd_kernel<1>), grid, dim3(256), 0, st, x, w, bias, y, n, K, O, act, slope);
+    const bool v4 = K % 4 == 0 && aligned16(x) && aligned16(w);
+    if (v4 && O <= 10 && O > 8) hipLaunchKernelGGL((linear_fwd_kernel<4, 10>), grid, dim3(256), 0, st, x, w, bias, y, n, K, O, act, slope);
+    else if (v4) hipLaunchKernelGGL((linear_fwd_kernel<4, 8>), grid, dim3(256), 0, st, x, w, bias, y, n, K, O, act, slope);
+    else hipLaunchKernelGGL((linear_fwd_kernel<1, 8>), grid, dim3(256), 0, st, x, w, bias, y, n, K, O, act, slope);
     DCV_RETURN_LAUNCH();
 }
 
