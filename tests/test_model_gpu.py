@@ -266,3 +266,18 @@ def test_train_api_config3_bf16_onecycle(device, params, tmp_path):
     finally:
         ops.set_conv_math(prev)
     assert state.iteration == 12 and 'valid_main_loss' in metrics and metrics['valid_main_loss'] == metrics['valid_main_loss']   # finite
+
+
+def test_train_api_ragged_last_batch(device, params, tmp_path):
+    """ 80 samples at batch size 32: every epoch ends with a 16-sample batch, which cannot be served by the captured step graph (static shapes) and runs
+    eagerly between replays; the early loss read-back, the mailbox protocol and the optimizer state must survive the interleaving. """
+    from deepcv_amd.classification import image
+    from deepcv_amd.meta.data.datasets import SyntheticImageDataset
+    ds = {'trainset': SyntheticImageDataset(80, seed=1), 'validset': SyntheticImageDataset(40, seed=2)}
+    torch.manual_seed(SEED)
+    model = image.create_model(ds, params['image_classifier_model'])
+    hp = dict(params['train_image_classifier'])
+    hp.update(epochs=3, batch_size=32, output_path=tmp_path, save_every_iters=1000, num_workers=0, log_progress_every_iters=1, backend_conf={'device_or_id': 'cuda:0'})
+    metrics, state, _ = image.train(ds, model, hp)
+    assert state.iteration == 9 and state.epoch == 3
+    assert metrics['valid_main_loss'] == metrics['valid_main_loss'] and 0. <= metrics['valid_accuracy'] <= 1.
