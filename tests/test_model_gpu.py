@@ -281,3 +281,43 @@ def test_train_api_ragged_last_batch(device, params, tmp_path):
     metrics, state, _ = image.train(ds, model, hp)
     assert state.iteration == 9 and state.epoch == 3
     assert metrics['valid_main_loss'] == metrics['valid_main_loss'] and 0. <= metrics['valid_accuracy'] <= 1.
+
+
+def test_crash_and_resume_on_the_hip_path(device, params, tmp_path):
+    """ `crash_iteration` / `resume_from` (reference `ignite_training.py:325,393-399`) with the native model, optimizer (device-resident step counter),
+    scheduler and the replayed step graph: the resumed run continues at the checkpointed iteration, re-captures its graph on the restored weights
+    (prepared filters re-laid out: `load_state_dict` bumps the weight versions) and reaches the same final iteration count. """
+    from deepcv_amd.classification import image
+    from deepcv_amd.meta.data.datasets import SyntheticImageDataset
+    from deepcv_amd.meta.ignite_training import BackendConfig, train
+    ds = {'trainset': SyntheticImageDataset(64, seed=5), 'validset': SyntheticImageDataset(16, seed=6)}
+
+    def model():
+        torch.manual_seed(SEED)
+        return image.create_model(ds, params['image_classifier_model'])
+
+    def hp(path, **over):
+        h = dict(params['train_image_classifier'])
+        h.update(epochs=2, batch_size=16, output_path=path, num_workers=0, save_every_iters=3, log_progress_every_iters=2)
+        h.update(over)
+        return h
+
+    with pytest.raises(RuntimeError, match='STOP at iteration: 6'):
+        train(hp(tmp_path / 'a', crash_iteration=6), model(), loss=torch.nn.CrossEntropyLoss(), datasets=ds, opt=torch.optim.AdamW, backend_conf=BackendConfig('cuda:0'))
+    ckpts = sorted((tmp_path / 'a').rglob('training_checkpoint_*.pt'))
+    assert [p.name for p in ckpts] == ['training_checkpoint_3.pt']
+    ckpt = torch.load(ckpts[0], weights_only=False)
+    assert ckpt['trainer']['iteration'] == 3 and ckpt['scheduler'] == {'event_index': 3}
+    its = []
+
+    class Spy:
+        def fire(self, event, **kw):
+            if event == 'ON_ITERATION_STARTED':
+                its.append(kw['engine'].state.iteration)
+    resumed = model()
+    _, state = train(hp(tmp_path / 'b', resume_from=str(ckpts[0])), resumed, losses=torch.nn.CrossEntropyLoss(), datasets=ds, opt=torch.optim.AdamW,
+                     backend_conf=BackendConfig('cuda:0'), callbacks_handler=Spy())
+    assert its == [4, 5, 6, 7, 8] and state.iteration == 8 and state.epoch == 2
+    restored = {k: v.cpu() for k, v in ckpt['model'].items()}
+    moved = [k for k, v in resumed.state_dict().items() if v.dtype.is_floating_point and not torch.equal(v.cpu(), restored[k])]
+    assert len(moved) > 10, 'the resumed run must keep training the restored weights'
