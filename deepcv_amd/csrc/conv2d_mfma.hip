@@ -90,19 +90,35 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaArgs a, const float*
     const int taps = a.R * a.S;
     const size_t wb_row = (size_t)taps * a.Cin;                   // floats per output channel in wb
 
-    auto load_a = [&](int r, int s, int ci0, float4 (&v)[BMR]) {
+    // ---- load stream.  MFMAs and ordinary vector instructions share the SIMD's issue port, so every VALU instruction spent on addressing is time the
+    // matrix pipe idles (measured: time = MFMA time + VALU time, nothing overlaps).  The per-pixel address arithmetic (tap offset, clamping, validity)
+    // is therefore done ONCE PER TAP; inside a tap consecutive chunks only advance the pointers by 16 channels.
+    const float* aptr[BMR]; float aokf[BMR];                      // validity as a 0 / 1 factor: a select on the loaded value would be turned into a guarded (branchy) load
+    const float* bptr = wb + (size_t)(n0 + (b_active ? brow : 0)) * wb_row + 4 * q;      // wb[co][tap][ci]: chunks are consecutive across taps
+    int lr = 0, ls = 0, lcc = 0;                                  // position of the next chunk to LOAD
+    auto set_tap = [&](int r, int s) {
 #pragma unroll
         for (int j = 0; j < BMR; ++j) {
             const int hi = aho[j] * a.sh - a.ph + r * a.dh, wi = awo[j] * a.sw - a.pw + s * a.dw;
-            const bool ok = arow_ok[j] && hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win;
+            aokf[j] = (arow_ok[j] && hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win) ? 1.f : 0.f;
             const int hic = hi < 0 ? 0 : (hi >= a.Hin ? a.Hin - 1 : hi), wic = wi < 0 ? 0 : (wi >= a.Win ? a.Win - 1 : wi);
-            const float4 g = *reinterpret_cast<const float4*>(x + (((size_t)an[j] * a.Hin + hic) * a.Win + wic) * a.Cin + ci0 + 4 * q);   // unconditional, clamped
-            v[j] = ok ? g : make_float4(0.f, 0.f, 0.f, 0.f);
+            aptr[j] = x + (((size_t)an[j] * a.Hin + hic) * a.Win + wic) * a.Cin + 4 * q;            // clamped: always a valid address
         }
     };
-    auto load_b = [&](int tap, int ci0) -> float4 {
-        if (!b_active) return make_float4(0.f, 0.f, 0.f, 0.f);
-        return *reinterpret_cast<const float4*>(wb + (size_t)(n0 + brow) * wb_row + (size_t)tap * a.Cin + ci0 + 4 * q);
+    auto load_next = [&](float4 (&v)[BMR], float4& vbv) {
+#pragma unroll
+        for (int j = 0; j < BMR; ++j) {
+            const float4 g = *reinterpret_cast<const float4*>(aptr[j]);                             // unconditional (clamped address: finite data)
+            v[j] = aokf[j] != 0.f ? g : make_float4(0.f, 0.f, 0.f, 0.f);
+            aptr[j] += MF_BK;
+        }
+        vbv = *reinterpret_cast<const float4*>(bptr);                                              // rows beyond BN are never stored to LDS
+        bptr += MF_BK;
+        if (++lcc == a.Cin / MF_BK) {                                                               // next tap (wave-uniform)
+            lcc = 0;
+            if (++ls == a.S) { ls = 0; ++lr; }
+            if (lr < a.R) set_tap(lr, ls);
+        }
     };
     auto store_stage = [&](int buf, const float4 (&va)[BMR], const float4& vb) {
 #pragma unroll
@@ -119,19 +135,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaArgs a, const float*
     const int cchunks = a.Cin / MF_BK;
     const int nchunks = taps * cchunks;
     float4 va[BMR]; float4 vb;
-    load_a(0, 0, 0, va); vb = load_b(0, 0);
+    set_tap(0, 0);
+    load_next(va, vb);
     store_stage(0, va, vb);
     __syncthreads();
 
-    int r = 0, s = 0, cc = 0;                                     // position of the chunk being COMPUTED
     const int li = lane & 15, lg = lane >> 4;
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
-        // next chunk position
-        int nr = r, ns = s, ncc = cc + 1;
-        if (ncc == cchunks) { ncc = 0; ++ns; if (ns == a.S) { ns = 0; ++nr; } }
         const bool has_next = (c + 1) < nchunks;
-        if (has_next) { load_a(nr, ns, ncc * MF_BK, va); vb = load_b(nr * a.S + ns, ncc * MF_BK); }
+        if (has_next) load_next(va, vb);
 
         // ---- MFMAs on buffer `buf`
         f32x4 af[BMR], bf[NT];
@@ -160,7 +173,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaArgs a, const float*
 
         if (has_next) store_stage(buf ^ 1, va, vb);
         __syncthreads();
-        r = nr; s = ns; cc = ncc;
     }
 
     // ---- epilogue: acc[i][j][reg] -> pixel m0 + wave*16*BMR + i*16 + 4*lg + reg, channel n0 + j*16 + li
@@ -212,6 +224,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaArgs a, const float*
 // reads the four pixels 4g..4g+3 of its column with four ds_read_b32 (k permutation as in the forward kernel).
 struct MfmaWgArgs {
     int N, H, W, Cin, Ho, Wo, Cout, R, S, sh, sw, ph, pw, dh, dw;
+    int step_w, step_h;            // WG_PS % Wo, WG_PS / Wo
     long M, m_per_chunk;           // output pixels, pixels per split-K chunk (multiple of 16)
     size_t wtotal;
 };
@@ -236,20 +249,32 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(MfmaWgArgs a, cons
 
     // staging role: thread loads pixel rows (t >> 4) and (t >> 4) + 16 of the step, float4 column (t & 15), of both tiles
     const int prow = t >> 4, pc4 = t & 15;
-    auto load_tiles = [&](long mbase, float4 (&g)[2], float4 (&xv)[2]) {
+    // Pixel coordinates of this thread's two rows are advanced incrementally (WG_PS pixels per step): a 64-bit divide per row and step cost more
+    // vector-ALU time than the 32 MFMAs of the step (MFMAs and VALU instructions share the issue port).
+    long mrow[2]; int pwo[2], pho[2], pn[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        mrow[h] = mb + prow + 16 * h;
+        const long mm = mrow[h] < a.M ? mrow[h] : a.M - 1;
+        pwo[h] = (int)(mm % a.Wo); const long r1 = mm / a.Wo; pho[h] = (int)(r1 % a.Ho); pn[h] = (int)(r1 / a.Ho);
+    }
+    auto load_tiles = [&](float4 (&g)[2], float4 (&xv)[2]) {          // loads the rows at (mrow, pwo, pho, pn), then advances them by WG_PS pixels
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const long m = mbase + prow + 16 * h;
-            const bool ok = m < me;
-            const long mm = ok ? m : mb;
-            const int wo = (int)(mm % a.Wo); const long r1 = mm / a.Wo; const int ho = (int)(r1 % a.Ho); const int n = (int)(r1 / a.Ho);
+            const bool ok = mrow[h] < me;
+            const int n = pn[h] < a.N ? pn[h] : a.N - 1;             // positions past the end stay addressable (their values are zeroed)
+            const long mm = ok ? mrow[h] : mb;
             const float4 gg = *reinterpret_cast<const float4*>(dy + (size_t)mm * a.Cout + co0 + 4 * pc4);
-            const int hi = ho * a.sh - a.ph + r * a.dh, wi = wo * a.sw - a.pw + s * a.dw;
+            const int hi = pho[h] * a.sh - a.ph + r * a.dh, wi = pwo[h] * a.sw - a.pw + s * a.dw;
             const bool xok = ok && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
             const int hic = hi < 0 ? 0 : (hi >= a.H ? a.H - 1 : hi), wic = wi < 0 ? 0 : (wi >= a.W ? a.W - 1 : wi);
             const float4 xx = *reinterpret_cast<const float4*>(x + (((size_t)n * a.H + hic) * a.W + wic) * a.Cin + ci0 + 4 * pc4);
             g[h] = ok ? gg : make_float4(0.f, 0.f, 0.f, 0.f);
             xv[h] = xok ? xx : make_float4(0.f, 0.f, 0.f, 0.f);
+            mrow[h] += WG_PS;
+            pwo[h] += a.step_w; pho[h] += a.step_h;
+            if (pwo[h] >= a.Wo) { pwo[h] -= a.Wo; ++pho[h]; }
+            while (pho[h] >= a.Ho) { pho[h] -= a.Ho; ++pn[h]; }
         }
     };
     auto store_tiles = [&](int buf, const float4 (&g)[2], const float4 (&xv)[2]) {
@@ -266,14 +291,14 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(MfmaWgArgs a, cons
     for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     float4 g[2], xv[2];
-    load_tiles(mb, g, xv);
+    load_tiles(g, xv);
     store_tiles(0, g, xv);
     __syncthreads();
     int it = 0;
     for (long m = mb; m < me; m += WG_PS, ++it) {
         const int buf = it & 1;
         const bool has_next = (m + WG_PS) < me;
-        if (has_next) load_tiles(m + WG_PS, g, xv);
+        if (has_next) load_tiles(g, xv);
         if constexpr (BF16) {
 #pragma unroll
             for (int hh = 0; hh < WG_PS / 16; ++hh) {                                       // 16 pixels per bf16 MFMA: lane group g supplies pixels 4g..4g+3
@@ -337,6 +362,7 @@ inline void wg_plan(const dcv_conv2d_desc* d, MfmaWgArgs* a, int* chunks) {
     a->N = d->n; a->H = d->h; a->W = d->w; a->Cin = d->cin; a->Ho = d->ho; a->Wo = d->wo; a->Cout = d->cout; a->R = d->r; a->S = d->s;
     a->sh = d->stride_h; a->sw = d->stride_w; a->ph = d->pad_h; a->pw = d->pad_w; a->dh = d->dil_h; a->dw = d->dil_w;
     a->M = (long)d->n * d->ho * d->wo;
+    a->step_w = WG_PS % d->wo; a->step_h = WG_PS / d->wo;
     a->wtotal = (size_t)d->cout * d->cin * d->r * d->s;
     // enough blocks to fill the chip (>= ~2048) but partial slabs bounded to 256 MiB
     const long blocks_per_chunk = (long)d->r * d->s * (d->cin / WG_T) * (d->cout / WG_T);
@@ -380,14 +406,13 @@ size_t dcv_mfma_conv2d_ws(const dcv_conv2d_desc* d, int op) {
     return dcv_align_up((size_t)d->cout * d->cin * d->r * d->s * sizeof(float), 256);
 }
 
-// 256-pixel tiles (BMR = 4) raise the FLOPs per staged byte by a quarter (the kernel is cache-bandwidth bound at ~60 % of the MFMA peak); used when the
-// launch still has more than ~3 blocks per CU
-inline int pick_bmr(long M, int cout, int bn) {
+// 256-pixel tiles (BMR = 4) halve the non-MFMA instructions per MFMA (fragment reads, stores, loop) at the price of fewer resident waves
+inline int pick_bmr(long M, int cin, int cout, int bn) {
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("DCV_MFMA_BMR"); forced = e ? atoi(e) : 0; }
     if (forced == 2 || forced == 4) return forced;
     const long blocks256 = ((M + 255) / 256) * (cout / bn);
-    return (bn == 64 && blocks256 >= 3 * DCV_NUM_CU) ? 4 : 2;
+    return (bn == 64 && cin >= 256 && blocks256 >= 2 * DCV_NUM_CU) ? 4 : 2;      // measured: 256-pixel tiles pay off from 256 input channels (110 vs 104 TF), lose below (86 vs 97)
 }
 
 template <bool BF16>
@@ -402,7 +427,7 @@ static void launch_mfma(int bn, int bmr, dim3 grid, hipStream_t st, const MfmaAr
 
 static int run_mfma(const MfmaArgs& a, const float* x, const float* wb, const float* bias, float* y, hipStream_t st, double* stats = nullptr, int math = DCV_MATH_FP32) {
     const int bn = pick_bn(a.Cout);
-    const int bmr = pick_bmr(a.M, a.Cout, bn);
+    const int bmr = pick_bmr(a.M, a.Cin, a.Cout, bn);
     dim3 grid((unsigned)dcv_ceil_div((size_t)a.M, (size_t)64 * bmr), (unsigned)(a.Cout / bn));
     if (math == DCV_MATH_BF16) launch_mfma<true>(bn, bmr, grid, st, a, x, wb, bias, y, stats);
     else launch_mfma<false>(bn, bmr, grid, st, a, x, wb, bias, y, stats);
@@ -411,7 +436,7 @@ static int run_mfma(const MfmaArgs& a, const float* x, const float* wb, const fl
 
 int dcv_mfma_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d) {
     const long M = (long)d->n * d->ho * d->wo;
-    return (int)dcv_ceil_div((size_t)M, (size_t)64 * pick_bmr(M, d->cout, pick_bn(d->cout)));
+    return (int)dcv_ceil_div((size_t)M, (size_t)64 * pick_bmr(M, d->cin, d->cout, pick_bn(d->cout)));
 }
 
 int dcv_mfma_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st, bool prepared, double* stats) {
