@@ -225,6 +225,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaArgs a, const float*
 struct MfmaWgArgs {
     int N, H, W, Cin, Ho, Wo, Cout, R, S, sh, sw, ph, pw, dh, dw;
     int step_w, step_h;            // WG_PS % Wo, WG_PS / Wo
+    int idx32;                     // x and dy both have fewer than 2^31 elements
     long M, m_per_chunk;           // output pixels, pixels per split-K chunk (multiple of 16)
     size_t wtotal;
 };
@@ -264,11 +265,17 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(MfmaWgArgs a, cons
             const bool ok = mrow[h] < me;
             const int n = pn[h] < a.N ? pn[h] : a.N - 1;             // positions past the end stay addressable (their values are zeroed)
             const long mm = ok ? mrow[h] : mb;
-            const float4 gg = *reinterpret_cast<const float4*>(dy + (size_t)mm * a.Cout + co0 + 4 * pc4);
             const int hi = pho[h] * a.sh - a.ph + r * a.dh, wi = pwo[h] * a.sw - a.pw + s * a.dw;
             const bool xok = ok && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
             const int hic = hi < 0 ? 0 : (hi >= a.H ? a.H - 1 : hi), wic = wi < 0 ? 0 : (wi >= a.W ? a.W - 1 : wi);
-            const float4 xx = *reinterpret_cast<const float4*>(x + (((size_t)n * a.H + hic) * a.W + wic) * a.Cin + ci0 + 4 * pc4);
+            float4 gg, xx;
+            if (a.idx32) {       // both tensors have fewer than 2^31 elements: 32-bit index arithmetic (half the vector-ALU work of the 64-bit form)
+                gg = *reinterpret_cast<const float4*>(dy + ((unsigned)mm * (unsigned)a.Cout + (unsigned)(co0 + 4 * pc4)));
+                xx = *reinterpret_cast<const float4*>(x + ((((unsigned)n * (unsigned)a.H + (unsigned)hic) * (unsigned)a.W + (unsigned)wic) * (unsigned)a.Cin + (unsigned)(ci0 + 4 * pc4)));
+            } else {
+                gg = *reinterpret_cast<const float4*>(dy + (size_t)mm * a.Cout + co0 + 4 * pc4);
+                xx = *reinterpret_cast<const float4*>(x + (((size_t)n * a.H + hic) * a.W + wic) * a.Cin + ci0 + 4 * pc4);
+            }
             g[h] = ok ? gg : make_float4(0.f, 0.f, 0.f, 0.f);
             xv[h] = xok ? xx : make_float4(0.f, 0.f, 0.f, 0.f);
             mrow[h] += WG_PS;
@@ -363,6 +370,7 @@ inline void wg_plan(const dcv_conv2d_desc* d, MfmaWgArgs* a, int* chunks) {
     a->sh = d->stride_h; a->sw = d->stride_w; a->ph = d->pad_h; a->pw = d->pad_w; a->dh = d->dil_h; a->dw = d->dil_w;
     a->M = (long)d->n * d->ho * d->wo;
     a->step_w = WG_PS % d->wo; a->step_h = WG_PS / d->wo;
+    a->idx32 = ((size_t)d->n * d->h * d->w * d->cin < ((size_t)1 << 31) && (size_t)d->n * d->ho * d->wo * d->cout < ((size_t)1 << 31)) ? 1 : 0;
     a->wtotal = (size_t)d->cout * d->cin * d->r * d->s;
     // enough blocks to fill the chip (>= ~2048) but partial slabs bounded to 256 MiB
     const long blocks_per_chunk = (long)d->r * d->s * (d->cin / WG_T) * (d->cout / WG_T);
