@@ -13,7 +13,7 @@ from typing import Optional
 
 import torch
 
-__all__ = ['lib', 'load', 'is_available', 'check', 'current_stream', 'Conv2dDesc', 'Pool2dDesc', 'TensorList', 'LIB_PATH', 'build',
+__all__ = ['lib', 'load', 'is_available', 'check', 'current_stream', 'Conv2dDesc', 'SlabSegment', 'Pool2dDesc', 'TensorList', 'LIB_PATH', 'build',
            'ACT_NONE', 'ACT_RELU', 'ACT_LEAKY_RELU', 'ACT_SIGMOID', 'ACT_TANH', 'POOL_AVG', 'POOL_MAX', 'LAYOUT_NHWC', 'LAYOUT_NCHW',
            'MAX_TENSORS', 'HYP_COUNT', 'HYP']
 
@@ -41,6 +41,11 @@ class Conv2dDesc(ctypes.Structure):
                 ('groups', _c_int), ('ho', _c_int), ('wo', _c_int), ('x_layout', _c_int), ('act', _c_int), ('act_slope', _c_float), ('math', _c_int)]
 
 
+class SlabSegment(ctypes.Structure):
+    """ `dcv_slab_segment` """
+    _fields_ = [('src', _c_void_p), ('dst', _c_void_p), ('count', ctypes.c_ulonglong), ('stride', ctypes.c_ulonglong), ('chunks', _c_int), ('reserved', _c_int)]
+
+
 class Pool2dDesc(ctypes.Structure):
     """ `dcv_pool2d_desc` """
     _fields_ = [('n', _c_int), ('h', _c_int), ('w', _c_int), ('c', _c_int), ('kh', _c_int), ('kw', _c_int), ('stride_h', _c_int),
@@ -65,6 +70,8 @@ _SIGNATURES = {
     'dcv_conv2d_fwd': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _P, _c_size_t, _P]),
     'dcv_conv2d_dgrad': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _c_size_t, _P]),
     'dcv_conv2d_wgrad': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _P, _c_size_t, _P]),
+    'dcv_conv2d_wgrad_deferred': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _P, _c_size_t, ctypes.POINTER(SlabSegment), ctypes.POINTER(_c_int), _P]),
+    'dcv_slab_reduce': (_c_int, [_c_int, ctypes.POINTER(SlabSegment), _P]),
     'dcv_conv2d_wgrad_fuses_bias': (_c_int, [ctypes.POINTER(Conv2dDesc)]),
     'dcv_conv2d_filter_bytes': (_c_size_t, [ctypes.POINTER(Conv2dDesc), _c_int]),
     'dcv_conv2d_prepare_filters': (_c_int, [_c_int, ctypes.POINTER(ctypes.POINTER(Conv2dDesc)), ctypes.POINTER(_c_int), ctypes.POINTER(_P), ctypes.POINTER(_P), _P]),
@@ -105,6 +112,8 @@ _SIGNATURES = {
     'dcv_transpose_inner': (_c_int, [_P, _P, _c_int, _c_int, _c_int, _P]),
     'dcv_linear_bwd_workspace_bytes': (_c_size_t, [_c_int, _c_int, _c_int]),
     'dcv_linear_bwd': (_c_int, [_P, _P, _c_int, _c_float, _P, _P, _P, _P, _P, _c_int, _c_int, _c_int, _P, _c_size_t, _P]),
+    'dcv_linear_bwd_deferred': (_c_int, [_P, _P, _c_int, _c_float, _P, _P, _P, _P, _P, _c_int, _c_int, _c_int, _P, _c_size_t,
+                                         ctypes.POINTER(SlabSegment), ctypes.POINTER(_c_int), _P]),
     'dcv_linear_wgrad_workspace_bytes': (_c_size_t, [_c_int, _c_int, _c_int]),
     'dcv_linear_fwd': (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _c_float, _P]),
     'dcv_linear_dgrad': (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _P]),

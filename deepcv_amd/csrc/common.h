@@ -15,6 +15,9 @@ static inline hipStream_t dcv_stream(void* s) { return reinterpret_cast<hipStrea
 static inline size_t dcv_ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
 static inline size_t dcv_align_up(size_t a, size_t b) { return dcv_ceil_div(a, b) * b; }
 
+// Ordered sums of partial slabs (slab_reduce in elementwise.hip): the second stage of every weight-gradient kernel, immediate or deferred.
+int dcv_launch_slab_reduce(int n, const dcv_slab_segment* segments, hipStream_t st);
+
 // Grid size for a bandwidth-bound grid-stride kernel: enough blocks to fill 256 CUs x 8 blocks, never more than the work.
 static inline unsigned dcv_stream_grid(size_t work_items, unsigned block) {
     size_t blocks = dcv_ceil_div(work_items, block);

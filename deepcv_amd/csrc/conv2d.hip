@@ -133,7 +133,8 @@ int dcv_conv2d_wgrad_fuses_bias(const dcv_conv2d_desc* d) {
     return dcv_direct_conv2d_wgrad_fuses_bias(d) ? 1 : 0;
 }
 
-int dcv_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, void* stream) {
+static int conv2d_wgrad_impl(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, void* stream,
+                             dcv_slab_segment* defer, int* ndefer) {
     DCV_CHECK_ARG(desc_ok(d) && x && dy && dw);
     if (d->groups != 1) return DCV_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < dcv_conv2d_wgrad_workspace_bytes(d)) return DCV_ERR_WORKSPACE;
@@ -141,10 +142,21 @@ int dcv_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, 
     const size_t main_ws = dcv_align_up(mfma ? dcv_mfma_conv2d_ws(d, 2) : dcv_direct_conv2d_wgrad_ws(d), 256);
     bool db_done = false;
     int rc = mfma ? dcv_mfma_conv2d_wgrad(d, x, dy, dw, ws, main_ws, dcv_stream(stream))
-                  : dcv_direct_conv2d_wgrad(d, x, dy, dw, db, &db_done, ws, main_ws, dcv_stream(stream));
+                  : dcv_direct_conv2d_wgrad(d, x, dy, dw, db, &db_done, ws, main_ws, dcv_stream(stream), defer, ndefer);
     if (rc != DCV_OK) return rc;
     if (db && !db_done) rc = dcv_channel_sum(dy, db, (size_t)d->n * d->ho * d->wo, d->cout, reinterpret_cast<char*>(ws) + main_ws, db_ws(d), stream);
     return rc;
+}
+
+int dcv_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes, void* stream) {
+    return conv2d_wgrad_impl(d, x, dy, dw, db, ws, ws_bytes, stream, nullptr, nullptr);
+}
+
+int dcv_conv2d_wgrad_deferred(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes,
+                              dcv_slab_segment* segments, int* n_segments, void* stream) {
+    DCV_CHECK_ARG(segments && n_segments);
+    *n_segments = 0;
+    return conv2d_wgrad_impl(d, x, dy, dw, db, ws, ws_bytes, stream, segments, n_segments);
 }
 
 }  // extern "C"

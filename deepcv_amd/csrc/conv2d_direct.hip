@@ -457,32 +457,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_partial_kernel(WgradArgs a, co
     }
 }
 
-// dw[i] = sum over chunks of partial[chunk][i]: block = 32 consecutive weights x 32 chunk lanes (coalesced 128-B rows, chunks/32 serial loads per
-// thread), merged through LDS in a fixed order
-#define WGR_W 8                    // slab entries per block of wgrad_reduce_kernel
-__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int chunks, size_t wtotal,
-                                                             float* __restrict__ db = nullptr, size_t slab = 0) {
-    // slabs hold `wtotal` weight-gradient entries followed (when db != nullptr) by the Cout bias-gradient entries; slab = entries per slab.
-    // Block = 8 entries x 128 slab lanes: a thread adds chunks / 128 slabs (a short load chain: this kernel is pure latency), the 8 slab lanes of a
-    // wave are merged by a fixed xor butterfly, the 16 waves in order through LDS -> deterministic.
-    __shared__ float red[16][WGR_W];
-    const int wl = threadIdx.x & (WGR_W - 1), cl = threadIdx.x >> 3, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (slab == 0) slab = wtotal;
-    const size_t wi = (size_t)blockIdx.x * WGR_W + wl;
-    float s = 0.f;
-    if (wi < slab)
-        for (int c = cl; c < chunks; c += 128) s += partial[(size_t)c * slab + wi];
-    s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-    if (lane < WGR_W) red[wave][lane] = s;
-    __syncthreads();
-    if (threadIdx.x < WGR_W && wi < slab) {
-        float t = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
-        if (wi < wtotal) dw[wi] = t; else db[wi - wtotal] = t;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ LDS-tiled weight gradient
 // One block walks tiles of TH output rows x Wo columns of one image: the zero-padded input halo tile [XH][XW][Cin] and the dy tile [TH*Wo][TCO]
 // are staged in LDS with coalesced 16-B loads (padding resolved while staging: no bounds checks in the inner loop), then every thread owns one
@@ -1204,8 +1178,18 @@ bool dcv_direct_conv2d_wgrad_fuses_bias(const dcv_conv2d_desc* d) {
 }
 
 // `db` (nullable): bias gradient; *db_done tells the caller whether this back-end produced it
-int dcv_direct_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, float* db, bool* db_done, void* ws, size_t ws_bytes, hipStream_t st) {
+// second stage: immediate (one launch of the shared slab reducer) or handed back to the caller as segments (`defer` != nullptr)
+static int wgrad_second_stage(const float* partial, float* dw, float* db, int chunks, size_t wtotal, size_t slab, int cout, dcv_slab_segment* defer, int* ndefer, hipStream_t st) {
+    dcv_slab_segment seg[2] = {{partial, dw, wtotal, slab, chunks, 0}, {partial + wtotal, db, (unsigned long long)(db ? cout : 0), slab, chunks, 0}};
+    const int n = db ? 2 : 1;
+    if (defer) { for (int i = 0; i < n; ++i) defer[i] = seg[i]; *ndefer = n; return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH; }
+    return dcv_launch_slab_reduce(n, seg, st);
+}
+
+int dcv_direct_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, float* db, bool* db_done, void* ws, size_t ws_bytes, hipStream_t st,
+                            dcv_slab_segment* defer, int* ndefer) {
     if (db_done) *db_done = false;
+    if (ndefer) *ndefer = 0;
     float* partial = reinterpret_cast<float*>(ws);
     WgTiledArgs ta{}; int tco, tvec, blocks; size_t smem;
     {
@@ -1217,9 +1201,8 @@ int dcv_direct_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const floa
             else if (sv == 4) launch_wgrad_slide<4, 2>(d->s, grid, ssm, st, sa, x, dy, partial);
             else if (d->stride_w == 1) launch_wgrad_slide<1, 1>(d->s, grid, ssm, st, sa, x, dy, partial);
             else launch_wgrad_slide<1, 2>(d->s, grid, ssm, st, sa, x, dy, partial);
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)dcv_ceil_div(sa.slab, WGR_W)), dim3(1024), 0, st, partial, dw, sb, sa.wtotal, db, sa.slab);
             if (db_done) *db_done = db != nullptr;
-            return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
+            return wgrad_second_stage(partial, dw, db, sb, sa.wtotal, sa.slab, d->cout, defer, ndefer, st);
         }
     }
     if (wgrad_tiled_plan(d, &ta, &tco, &tvec, &blocks, &smem) && (tvec == 1 || (reinterpret_cast<uintptr_t>(x) & 15) == 0)) {
@@ -1227,8 +1210,7 @@ int dcv_direct_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const floa
         dim3 grid((unsigned)blocks, (unsigned)dcv_ceil_div(d->cout, tco));
         if (tvec == 4) launch_wgrad_tiled<4>(tco, grid, smem, st, ta, x, dy, partial);
         else launch_wgrad_tiled<1>(tco, grid, smem, st, ta, x, dy, partial);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)dcv_ceil_div(ta.wtotal, WGR_W)), dim3(1024), 0, st, partial, dw, blocks, ta.wtotal);
-        return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
+        return wgrad_second_stage(partial, dw, nullptr, blocks, ta.wtotal, ta.wtotal, d->cout, defer, ndefer, st);
     }
     WgradArgs a{}; int chunks, ubatches, vec;
     wgrad_plan(d, &a, &chunks, &ubatches, &vec);
@@ -1238,6 +1220,5 @@ int dcv_direct_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const floa
     if (vec == 4 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) hipLaunchKernelGGL((conv_wgrad_partial_kernel<4>), grid, dim3(256), 0, st, a, x, dy, partial);
     else if (vec == 4) return DCV_ERR_INVALID_ARG;   // NHWC activations are always 16-B aligned (torch allocator); anything else is a caller bug
     else hipLaunchKernelGGL((conv_wgrad_partial_kernel<1>), grid, dim3(256), 0, st, a, x, dy, partial);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)dcv_ceil_div(a.wtotal, WGR_W)), dim3(1024), 0, st, partial, dw, chunks, a.wtotal);
-    return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
+    return wgrad_second_stage(partial, dw, nullptr, chunks, a.wtotal, a.wtotal, d->cout, defer, ndefer, st);
 }

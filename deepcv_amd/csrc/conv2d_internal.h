@@ -12,7 +12,8 @@ int dcv_direct_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d);
 int dcv_direct_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t st, bool prepared = false);
 size_t dcv_direct_conv2d_wgrad_ws(const dcv_conv2d_desc* d);
 bool dcv_direct_conv2d_wgrad_fuses_bias(const dcv_conv2d_desc* d);
-int dcv_direct_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, float* db, bool* db_done, void* ws, size_t ws_bytes, hipStream_t st);
+int dcv_direct_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, float* db, bool* db_done, void* ws, size_t ws_bytes, hipStream_t st,
+                            dcv_slab_segment* defer = nullptr, int* ndefer = nullptr);
 
 // MFMA implicit-GEMM back-end (fp32 inputs, v_mfma_f32_16x16x4_f32): wide layers (conv2d_mfma.hip)
 bool dcv_mfma_conv2d_supported(const dcv_conv2d_desc* d, int op /*0 fwd, 1 dgrad, 2 wgrad*/);

@@ -336,9 +336,67 @@ inline float interp_scale(int in_size, int out_size, int align) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+
+// ------------------------------------------------------------------------------------------------ ordered sums of partial slabs
+// dst[i] = sum over k < chunks of src[k * stride + i] for up to DCV_MAX_SLAB_SEGMENTS independent segments in one launch (second stage of the weight
+// gradients).  Block = 8 entries x 128 slab lanes: a thread adds chunks / 128 slabs (a short load chain: this kernel is pure latency), the 8 slab lanes
+// of a wave are merged by a fixed xor butterfly, the 16 waves in order through LDS -> the result only depends on (chunks, entry), not on the launch shape.
+#define SLAB_W 8
+struct SlabTable {
+    int count;
+    int block_start[DCV_MAX_SLAB_SEGMENTS + 1];
+    dcv_slab_segment seg[DCV_MAX_SLAB_SEGMENTS];
+};
+
+__global__ __launch_bounds__(1024) void slab_reduce_kernel(SlabTable t) {
+    __shared__ float red[16][SLAB_W];
+    int si = 0;
+    while (si + 1 < t.count && (int)blockIdx.x >= t.block_start[si + 1]) ++si;          // wave-uniform: scalar loop
+    const dcv_slab_segment& g = t.seg[si];
+    const int wl = threadIdx.x & (SLAB_W - 1), cl = threadIdx.x >> 3, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t wi = (size_t)((int)blockIdx.x - t.block_start[si]) * SLAB_W + wl;
+    const float* __restrict__ src = g.src;
+    float s = 0.f;
+    if (wi < g.count)
+        for (int c = cl; c < g.chunks; c += 128) s += src[(size_t)c * g.stride + wi];
+    s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+    if (lane < SLAB_W) red[wave][lane] = s;
+    __syncthreads();
+    if (threadIdx.x < SLAB_W && wi < g.count) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[k][threadIdx.x];
+        g.dst[wi] = v;
+    }
+}
+
 }  // namespace
 
+int dcv_launch_slab_reduce(int n, const dcv_slab_segment* segments, hipStream_t st) {
+    for (int i0 = 0; i0 < n; i0 += DCV_MAX_SLAB_SEGMENTS) {
+        SlabTable t{};
+        int blocks = 0;
+        for (int i = i0; i < n && i < i0 + DCV_MAX_SLAB_SEGMENTS; ++i) {
+            const dcv_slab_segment& g = segments[i];
+            if (!g.src || !g.dst || g.chunks < 1 || g.stride < g.count) return DCV_ERR_INVALID_ARG;
+            if (g.count == 0) continue;
+            t.block_start[t.count] = blocks;
+            t.seg[t.count++] = g;
+            blocks += (int)dcv_ceil_div((size_t)g.count, SLAB_W);
+        }
+        t.block_start[t.count] = blocks;
+        if (blocks > 0) hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, t);
+    }
+    DCV_RETURN_LAUNCH();
+}
+
 extern "C" {
+
+int dcv_slab_reduce(int n, const dcv_slab_segment* segments, void* stream) {
+    DCV_CHECK_ARG(n >= 0 && (n == 0 || segments));
+    return dcv_launch_slab_reduce(n, segments, dcv_stream(stream));
+}
+
 
 const char* dcv_strerror(int code) {
     switch (code) {

@@ -200,23 +200,6 @@ __global__ __launch_bounds__(256) void linear_wgrad_act_partial_kernel(const flo
     if (k == 0 && partial_b) partial_b[(size_t)chunk * O + o] = gsum;
 }
 
-__global__ __launch_bounds__(256) void linear_wgrad_bias_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ partial_b, float* __restrict__ dw,
-                                                                        float* __restrict__ db, int chunks, size_t ok, int O) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ok + (db ? O : 0); i += (size_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        if (i < ok) {
-#pragma unroll 8
-            for (int c = 0; c < chunks; ++c) s += partial[(size_t)c * ok + i];
-            if (dw) dw[i] = s;
-        } else {
-            const size_t o = i - ok;
-#pragma unroll 8
-            for (int c = 0; c < chunks; ++c) s += partial_b[(size_t)c * O + o];
-            db[o] = s;
-        }
-    }
-}
-
 #define CE_THREADS 256           // 4 waves per block, one sample per wave per iteration
 // stage 1: per-block partial loss sum (double) and correct count
 __global__ __launch_bounds__(CE_THREADS) void ce_fwd_partial_kernel(const float* __restrict__ z, const int64_t* __restrict__ target, float* __restrict__ lse_out,
@@ -362,8 +345,8 @@ size_t dcv_linear_bwd_workspace_bytes(int n, int K, int O) {
     return dcv_align_up(dcv_ceil_div(n, LIN_WG_CHUNK) * ((size_t)O * K + O) * sizeof(float), 256);
 }
 
-int dcv_linear_bwd(const float* dy, const float* y, int act, float slope, const float* x, const float* w, float* dx, float* dw, float* db,
-                   int n, int K, int O, void* ws, size_t ws_bytes, void* stream) {
+static int linear_bwd_impl(const float* dy, const float* y, int act, float slope, const float* x, const float* w, float* dx, float* dw, float* db,
+                           int n, int K, int O, void* ws, size_t ws_bytes, void* stream, dcv_slab_segment* defer, int* ndefer) {
     DCV_CHECK_ARG(dy && x && w && n > 0 && K > 0 && O > 0 && O <= 65535 && act >= DCV_ACT_NONE && act <= DCV_ACT_TANH && (act == DCV_ACT_NONE || y));
     hipStream_t st = dcv_stream(stream);
     const float* yy = act == DCV_ACT_NONE ? nullptr : y;
@@ -386,9 +369,26 @@ int dcv_linear_bwd(const float* dy, const float* y, int act, float slope, const 
             hipLaunchKernelGGL((linear_wgrad_act_partial_kernel<1>), grid, dim3(256), 0, st, x, dy, yy, act, slope, partial, partial_b, n, K, O);
         }
         const size_t ok = (size_t)O * K;
-        hipLaunchKernelGGL(linear_wgrad_bias_reduce_kernel, dim3(dcv_stream_grid(ok + O, 256)), dim3(256), 0, st, partial, partial_b, dw, db, chunks, ok, O);
+        dcv_slab_segment seg[2]; int ns = 0;
+        if (dw) seg[ns++] = dcv_slab_segment{partial, dw, ok, ok, chunks, 0};
+        if (db) seg[ns++] = dcv_slab_segment{partial_b, db, (unsigned long long)O, (unsigned long long)O, chunks, 0};
+        if (defer) { for (int i = 0; i < ns; ++i) defer[i] = seg[i]; *ndefer = ns; }
+        else return dcv_launch_slab_reduce(ns, seg, st);
     }
     DCV_RETURN_LAUNCH();
 }
+
+int dcv_linear_bwd(const float* dy, const float* y, int act, float slope, const float* x, const float* w, float* dx, float* dw, float* db,
+                   int n, int K, int O, void* ws, size_t ws_bytes, void* stream) {
+    return linear_bwd_impl(dy, y, act, slope, x, w, dx, dw, db, n, K, O, ws, ws_bytes, stream, nullptr, nullptr);
+}
+
+int dcv_linear_bwd_deferred(const float* dy, const float* y, int act, float slope, const float* x, const float* w, float* dx, float* dw, float* db,
+                            int n, int K, int O, void* ws, size_t ws_bytes, dcv_slab_segment* segments, int* n_segments, void* stream) {
+    DCV_CHECK_ARG(segments && n_segments);
+    *n_segments = 0;
+    return linear_bwd_impl(dy, y, act, slope, x, w, dx, dw, db, n, K, O, ws, ws_bytes, stream, segments, n_segments);
+}
+
 
 }  // extern "C"

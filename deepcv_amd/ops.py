@@ -11,6 +11,7 @@ import torch
 
 from . import _native as nat
 from . import filters
+from . import slabs
 from ._native import lib
 
 __all__ = ['conv2d', 'set_conv_math', 'conv_norm_layer', 'activation', 'batch_norm', 'sync_batch_norm', 'group_norm', 'pool2d', 'interpolate_bilinear', 'concat_channels', 'add_tensors', 'flatten_nchw_order',
@@ -29,6 +30,20 @@ def _require_f32(*tensors):
 
 def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def _conv_wgrad_launch(d, x, dz, weight, bias, dw, db, st):
+    """ Weight (+ bias) gradient of one convolution; the ordered sum of its partial slabs is left to `slabs.flush()` whenever nothing can read the
+    gradients before the end of the backward pass. """
+    dev = dz.device
+    ws = _ws(lib.dcv_conv2d_wgrad_workspace_bytes(d), dev)
+    if slabs.may_defer(weight, bias):
+        segs, n = (nat.SlabSegment * 2)(), ctypes.c_int(0)
+        nat.check(lib.dcv_conv2d_wgrad_deferred(d, x.data_ptr(), dz.data_ptr(), dw.data_ptr(), nat.ptr(db), ws.data_ptr(), ws.numel(), segs, ctypes.byref(n), st),
+                  'dcv_conv2d_wgrad_deferred')
+        slabs.defer(dev, st, segs, n.value, ws)
+    else:
+        nat.check(lib.dcv_conv2d_wgrad(d, x.data_ptr(), dz.data_ptr(), dw.data_ptr(), nat.ptr(db), ws.data_ptr(), ws.numel(), st), 'dcv_conv2d_wgrad')
 
 
 def _is_nhwc(t: torch.Tensor) -> bool:
@@ -136,6 +151,8 @@ class _Conv2dFn(torch.autograd.Function):
             layout = nat.LAYOUT_NCHW          # e.g. the dataloader's NCHW batch feeding the first layer: read in place, no copy
         else:
             x, layout = to_nhwc(x), nat.LAYOUT_NHWC
+        ctx.weight_ref, ctx.bias_ref = weight, bias
+        slabs.note_use(weight if ctx.needs_input_grad[1] else None, bias if ctx.needs_input_grad[2] else None)
         weight = weight.contiguous()
         d = _conv_desc(x.shape, weight.shape, stride, padding, dilation, layout, act, slope)
         y = torch.empty((d.n, d.cout, d.ho, d.wo), dtype=x.dtype, device=x.device, memory_format=_CL)
@@ -171,9 +188,7 @@ class _Conv2dFn(torch.autograd.Function):
             _conv_dgrad_launch(dd, dz, weight, dx, st)
         if ctx.needs_input_grad[1] or (db is not None and not db_done):
             dw = torch.empty_like(weight)
-            ws = _ws(lib.dcv_conv2d_wgrad_workspace_bytes(d), dev)
-            nat.check(lib.dcv_conv2d_wgrad(d, x.data_ptr(), dz.data_ptr(), dw.data_ptr(), None if db_done else nat.ptr(db),
-                                           ws.data_ptr(), ws.numel(), st), 'dcv_conv2d_wgrad')
+            _conv_wgrad_launch(d, x, dz, ctx.weight_ref, ctx.bias_ref, dw, None if db_done else db, st)
         return dx, dw, db, None, None, None, None, None
 
 
@@ -397,6 +412,8 @@ class _ConvNormLayerFn(torch.autograd.Function):
             layout = nat.LAYOUT_NCHW
         else:
             x, layout = to_nhwc(x), nat.LAYOUT_NHWC
+        ctx.weight_ref, ctx.bias_ref = weight, bias
+        slabs.note_use(weight if ctx.needs_input_grad[1] else None, bias if ctx.needs_input_grad[2] else None)
         weight = weight.contiguous()
         d = _conv_desc(x.shape, weight.shape, stride, padding, dilation, layout, act, slope)
         dev, st = x.device, nat.current_stream(x.device)
@@ -447,9 +464,7 @@ class _ConvNormLayerFn(torch.autograd.Function):
             _conv_dgrad_launch(dd, dz, weight, dx, st)
         if need[1]:
             dw = torch.empty_like(weight)
-            ws = _ws(lib.dcv_conv2d_wgrad_workspace_bytes(d), dev)
-            nat.check(lib.dcv_conv2d_wgrad(d, x.data_ptr(), dz.data_ptr(), dw.data_ptr(), nat.ptr(db) if db_from_wgrad else None, ws.data_ptr(), ws.numel(), st),
-                      'dcv_conv2d_wgrad')
+            _conv_wgrad_launch(d, x, dz, ctx.weight_ref, ctx.bias_ref, dw, db if db_from_wgrad else None, st)
         return dx, dw, db, d_bn_w, d_bn_b, None, None, None, d_gn_w, d_gn_b, None
 
 
@@ -654,6 +669,8 @@ class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, act, slope):
         _require_f32(x, weight, bias)
+        ctx.weight_ref, ctx.bias_ref = weight, bias
+        slabs.note_use(weight if ctx.needs_input_grad[1] else None, bias if ctx.needs_input_grad[2] else None)
         x, weight = x.contiguous(), weight.contiguous()
         n, k = x.shape
         o = weight.shape[0]
@@ -677,8 +694,14 @@ class _LinearFn(torch.autograd.Function):
         dw = torch.empty_like(weight) if need_w else None
         db = torch.empty(o, dtype=dy.dtype, device=dev) if (need_w and ctx.has_bias) else None
         ws = _ws(lib.dcv_linear_bwd_workspace_bytes(n, k, o), dev)
-        nat.check(lib.dcv_linear_bwd(dy.data_ptr(), nat.ptr(y), ctx.act, ctx.slope, x.data_ptr(), weight.data_ptr(), nat.ptr(dx), nat.ptr(dw), nat.ptr(db),
-                                     n, k, o, ws.data_ptr(), ws.numel(), st), 'dcv_linear_bwd')
+        if need_w and slabs.may_defer(ctx.weight_ref, ctx.bias_ref):
+            segs, ns = (nat.SlabSegment * 2)(), ctypes.c_int(0)
+            nat.check(lib.dcv_linear_bwd_deferred(dy.data_ptr(), nat.ptr(y), ctx.act, ctx.slope, x.data_ptr(), weight.data_ptr(), nat.ptr(dx), nat.ptr(dw), nat.ptr(db),
+                                                  n, k, o, ws.data_ptr(), ws.numel(), segs, ctypes.byref(ns), st), 'dcv_linear_bwd_deferred')
+            slabs.defer(dev, st, segs, ns.value, ws)
+        else:
+            nat.check(lib.dcv_linear_bwd(dy.data_ptr(), nat.ptr(y), ctx.act, ctx.slope, x.data_ptr(), weight.data_ptr(), nat.ptr(dx), nat.ptr(dw), nat.ptr(db),
+                                         n, k, o, ws.data_ptr(), ws.numel(), st), 'dcv_linear_bwd')
         return dx, dw, db, None, None
 
 

@@ -14,6 +14,7 @@ import torch
 
 from . import _native as nat
 from . import filters
+from . import slabs
 from ._native import lib
 
 __all__ = ['AdamW', 'SGD']
@@ -126,6 +127,8 @@ class _NativeOptimizer(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+        slabs.flush()
+        slabs.reset_uses()
         if not capturing:
             self.sync_hyper()
         for gi, group in enumerate(self.param_groups):

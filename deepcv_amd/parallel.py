@@ -20,6 +20,7 @@ import torch.distributed as dist
 
 from . import _native as nat
 from . import filters
+from . import slabs
 
 __all__ = ['GradientAllReducer', 'broadcast_module_state', 'DataParallelModel']
 
@@ -89,6 +90,7 @@ class GradientAllReducer:
 
     # -- per-bucket pack + collective ----------------------------------------------------------------
     def _pack(self, b: _Bucket):
+        slabs.flush()        # weight gradients whose ordered slab sum is still pending (deepcv_amd/slabs.py) must be final before they are packed
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b.params]
         if self.device.type == 'cuda':
             grads = [g if g.is_contiguous() else g.contiguous() for g in grads]

@@ -86,6 +86,24 @@ int dcv_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, 
 /* dw[Cout,Cin,R,S] = x (*) dy ; db[Cout] = sum dy (db may be NULL).  x honours d->x_layout. */
 int dcv_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, float* db,
                      void* ws, size_t ws_bytes, void* stream);
+/* Deferred second stage.  Weight gradients are produced in two stages: per-block partial slabs, then an ordered sum of the slabs.  On small layers the second
+ * stage is a ~5 us launch whose result nobody reads before the optimizer (or the gradient all-reduce), so a training step may postpone it and sum the slabs
+ * of ALL its layers in ONE launch: the *_deferred variants run stage one only and describe the pending sums as up to two segments (weights, bias);
+ * dcv_slab_reduce executes any number of segments in one launch (dst[i] = sum over k < chunks of src[k * stride + i], fixed order: bit-identical to
+ * the immediate entry points).  `*n_segments == 0` on return: the back-end summed immediately (nothing is pending).  Until the segments have been
+ * reduced the workspace `ws` must stay untouched. */
+typedef struct dcv_slab_segment {
+    const float* src;
+    float* dst;
+    unsigned long long count;      /* entries of dst */
+    unsigned long long stride;     /* entries between consecutive slabs of src */
+    int chunks;                    /* slabs */
+    int reserved;
+} dcv_slab_segment;
+#define DCV_MAX_SLAB_SEGMENTS 32   /* per launch; dcv_slab_reduce splits longer lists */
+int dcv_conv2d_wgrad_deferred(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, float* db,
+                              void* ws, size_t ws_bytes, dcv_slab_segment* segments /* [2] */, int* n_segments, void* stream);
+int dcv_slab_reduce(int n, const dcv_slab_segment* segments, void* stream);
 /* 1 when dcv_conv2d_wgrad produces db from the dy tiles it already stages (no extra pass over dy, no extra launch): callers which can get the bias
  * gradient elsewhere too (dcv_bn_gn_act_bwd, dcv_act_bwd) use this to pick the cheaper source. */
 int dcv_conv2d_wgrad_fuses_bias(const dcv_conv2d_desc* d);
@@ -294,6 +312,10 @@ int dcv_transpose_inner(const float* x, float* y, int n, int a, int b, void* str
 size_t dcv_linear_bwd_workspace_bytes(int n, int in_features, int out_features);
 int dcv_linear_bwd(const float* dy, const float* y, int act, float act_slope, const float* x, const float* w, float* dx, float* dw, float* db,
                    int n, int in_features, int out_features, void* ws, size_t ws_bytes, void* stream);
+/* as dcv_linear_bwd, with the ordered sum of the weight / bias gradient slabs left to dcv_slab_reduce (see dcv_conv2d_wgrad_deferred) */
+int dcv_linear_bwd_deferred(const float* dy, const float* y, int act, float act_slope, const float* x, const float* w, float* dx, float* dw, float* db,
+                            int n, int in_features, int out_features, void* ws, size_t ws_bytes,
+                            dcv_slab_segment* segments /* [2] */, int* n_segments, void* stream);
 size_t dcv_linear_wgrad_workspace_bytes(int n, int in_features, int out_features);
 /* y[N][O] = act(x[N][K] . w[O][K]^T + bias) */
 int dcv_linear_fwd(const float* x, const float* w, const float* bias, float* y, int n, int in_features, int out_features,

@@ -588,3 +588,73 @@ def test_conv2d_bf16_math(device, case):
     _check(f'bf16conv{case}.dx', dx16, ref['dx'], 1e-2)
     _check(f'bf16conv{case}.dw', dw16, ref['dw'], 1e-2)
     assert (y16 - y32).abs().max().item() > 1e-5 * ref['y'].abs().max().item(), 'bf16 mode produced the fp32 result: mode not taken'
+
+
+def test_slab_reduce_matches_ordered_sum(device):
+    """ `dcv_slab_reduce`: many segments of different shapes in one call (more than DCV_MAX_SLAB_SEGMENTS -> several launches) vs an fp64 sum. """
+    import ctypes
+    from deepcv_amd import _native as nat
+    torch.manual_seed(5)
+    shapes = [(1, 7, 7), (3, 100, 128), (130, 9, 9), (512, 404, 404), (257, 33, 40)] + [(5 + i, 3 + i, 8 + i) for i in range(34)]
+    srcs = [torch.randn(chunks, stride, device=device) for chunks, _, stride in shapes]
+    dsts = [torch.full((count,), float('nan'), device=device) for _, count, _ in shapes]
+    segs = (nat.SlabSegment * len(shapes))()
+    for i, (chunks, count, stride) in enumerate(shapes):
+        segs[i].src, segs[i].dst, segs[i].count, segs[i].stride, segs[i].chunks = srcs[i].data_ptr(), dsts[i].data_ptr(), count, stride, chunks
+    nat.check(nat.lib.dcv_slab_reduce(len(shapes), segs, nat.current_stream(device)), 'dcv_slab_reduce')
+    for i, (chunks, count, stride) in enumerate(shapes):
+        _check(f'slab_reduce[{i}]', dsts[i], srcs[i][:, :count].double().sum(0), 1e-5)
+    bad = (nat.SlabSegment * 1)()
+    bad[0].src, bad[0].dst, bad[0].count, bad[0].stride, bad[0].chunks = srcs[0].data_ptr(), dsts[0].data_ptr(), 8, 4, 1      # stride < count
+    assert nat.lib.dcv_slab_reduce(1, bad, nat.current_stream(device)) != 0
+
+
+def test_deferred_weight_gradient_sums(device):
+    """ The ordered sum of the weight-gradient slabs is postponed to one launch at the end of the backward pass (`deepcv_amd/slabs.py`): gradients must be
+    bit-identical to the immediate path, and the cases in which the engine reads a gradient before the flush (existing `.grad`, parameter used twice)
+    must not be deferred. """
+    from deepcv_amd import ops, slabs, _native as nat
+    torch.manual_seed(11)
+    x = _cl(torch.randn(8, 4, 16, 16, device=device))
+    w1 = torch.nn.Parameter(torch.randn(4, 4, 5, 5, device=device) * 0.1); b1 = torch.nn.Parameter(torch.randn(4, device=device) * 0.1)
+    w2 = torch.nn.Parameter(torch.randn(8, 4, 3, 3, device=device) * 0.1); b2 = torch.nn.Parameter(torch.randn(8, device=device) * 0.1)
+    wl = torch.nn.Parameter(torch.randn(10, 8 * 16 * 16, device=device) * 0.02); bl = torch.nn.Parameter(torch.randn(10, device=device) * 0.1)
+    params = [w1, b1, w2, b2, wl, bl]
+
+    def run(shared: bool):
+        h = ops.conv2d(x, w1, b1, padding=2, act=nat.ACT_RELU)
+        if shared:
+            h = ops.conv2d(h, w1, b1, padding=2, act=nat.ACT_RELU)           # the same parameters a second time
+        h = ops.conv2d(h, w2, b2, padding=1, act=nat.ACT_TANH)
+        out = ops.linear(ops.flatten_nchw_order(h), wl, bl)
+        return (out * out).sum()
+
+    def grads(shared, enabled, accumulate=False):
+        prev = slabs.set_enabled(enabled)
+        try:
+            for p in params:
+                p.grad = None
+            run(shared).backward()
+            if accumulate:
+                run(shared).backward()
+            assert slabs.pending() == 0
+            torch.cuda.synchronize()
+            return [p.grad.clone() for p in params]
+        finally:
+            slabs.set_enabled(prev)
+
+    for shared in (False, True):
+        for accumulate in (False, True):
+            ref = grads(shared, False, accumulate)
+            got = grads(shared, True, accumulate)
+            for r, g, name in zip(ref, got, ('w1', 'b1', 'w2', 'b2', 'wl', 'bl')):
+                assert torch.equal(r, g), f'{name} differs (shared={shared}, accumulate={accumulate}): {(r - g).abs().max().item():.3e}'
+    # the deferred path was really taken in the plain case: segments are pending between the backward functions and the engine's final callback
+    seen = []
+    for p in params:
+        p.grad = None
+    loss = run(False)
+    h = w2.register_hook(lambda g: seen.append(slabs.pending()))
+    loss.backward()
+    h.remove()
+    assert seen and seen[0] > 0 and slabs.pending() == 0

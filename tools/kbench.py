@@ -25,6 +25,17 @@ if case == 'conv350n':     # first layer: NCHW input read in place
     x = x.contiguous(); d.x_layout = nat.LAYOUT_NCHW
     wsf = torch.empty(max(16, nat.lib.dcv_conv2d_fwd_workspace_bytes(d)), dtype=torch.uint8, device=dev)
     fn = lambda: nat.check(nat.lib.dcv_conv2d_fwd(d, x.data_ptr(), wt.data_ptr(), b.data_ptr(), y.data_ptr(), wsf.data_ptr(), wsf.numel(), st))
+elif case.endswith('p') and case[:-1] in CONVS:   # as the training step launches it: prepared filter + BatchNorm statistics epilogue
+    import ctypes
+    cfg = CONVS[case[:-1]]
+    x, wt, b, y, dy, d = conv_case(*cfg)
+    filt = torch.empty(max(16, nat.lib.dcv_conv2d_filter_bytes(d, 0)), dtype=torch.uint8, device=dev)
+    nat.check(nat.lib.dcv_conv2d_prepare_filters(1, (ctypes.POINTER(nat.Conv2dDesc) * 1)(ctypes.pointer(d)), (ctypes.c_int * 1)(0),
+                                                 (ctypes.c_void_p * 1)(wt.data_ptr()), (ctypes.c_void_p * 1)(filt.data_ptr()), st))
+    rows = nat.lib.dcv_conv2d_fwd_stats_rows(d)
+    stats = torch.empty((2, cfg[4], max(1, rows)), dtype=torch.float64, device=dev)
+    sp = stats.data_ptr() if rows > 0 else None
+    fn = lambda: nat.check(nat.lib.dcv_conv2d_fwd_prepared(d, x.data_ptr(), wt.data_ptr(), filt.data_ptr(), b.data_ptr(), y.data_ptr(), sp, st))
 elif case in CONVS:
     cfg = CONVS[case]
     x, wt, b, y, dy, d = conv_case(*cfg)
