@@ -782,44 +782,53 @@ __global__ __launch_bounds__(256) void conv_wgrad_slide_kernel(WgSlideArgs a, co
             }
         }
     }
-    // ---- merge the sub-streams in a fixed order, one filter column s at a time, through red[4 * VEC][red_rs]: thread (sub, unit) sums element
-    //      e = sub, sub + nsub, ... of ITS unit over all sub-streams (no index arithmetic: the unit's coordinates are already in registers)
+    // ---- merge the sub-streams in a fixed order through red[rows][red_rs], SG filter columns (SG * 4 * VEC rows) per pass plus, in the last pass, the 4
+    //      bias-gradient rows: thread (sub, unit) sums rows e = sub, sub + nsub, ... of ITS unit over all sub-streams (no index arithmetic: the unit's
+    //      coordinates are already in registers).  With few units (4->4 5x5: 5 units, 51 sub-streams) every thread owns at most one row per pass; the
+    //      sub-stream sum runs as four interleaved chains so that its LDS reads are in flight together (the merge used to cost more than the FMA loop).
     float* red = reinterpret_cast<float*>(smem);
     float* dst = partial + (size_t)blockIdx.x * a.slab;
     constexpr int E = 4 * VEC;
-    if (a.fuse_db) {                                                  // bias gradient: same ordered merge, 4 entries per owner unit
+    constexpr int SG = (VEC == 4) ? (S < 3 ? S : 3) : S;                  // filter columns per pass (rows <= 52: see wgrad_slide_plan's LDS size)
+    constexpr int PASSES = (S + SG - 1) / SG;
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+        const int s0 = ps * SG;
+        const int ns = (S - s0 < SG) ? (S - s0) : SG;
+        const int rows_w = ns * E;
+        const bool with_db = a.fuse_db && ps == PASSES - 1;
+        const int rows = rows_w + (with_db ? 4 : 0);
         __syncthreads();
-        if (active) { red[0 * a.red_rs + t] = dbacc.x; red[1 * a.red_rs + t] = dbacc.y; red[2 * a.red_rs + t] = dbacc.z; red[3 * a.red_rs + t] = dbacc.w; }
-        __syncthreads();
-        if (active && ul < a.cogb) {
-            for (int e = sub; e < 4; e += a.nsub) {
-                const float* q = red + e * a.red_rs + ul;
-                float sum = 0.f;
-#pragma unroll 8
-                for (int k = 0; k < a.nsub; ++k) { sum += *q; q += a.units; }
-                const int co = co_base + 4 * cog + e;
-                if (co < a.Cout) dst[a.wtotal + co] = sum;
+        if (active) {
+#pragma unroll
+            for (int sl = 0; sl < SG; ++sl) {
+                if (s0 + sl < S) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) red[(sl * E + j * VEC + v) * a.red_rs + t] = acc[(s0 + sl) < S ? (s0 + sl) : 0][j][v];
+                }
             }
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        __syncthreads();
-        if (active) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) red[(j * VEC + v) * a.red_rs + t] = acc[s][j][v];
+            if (with_db) { red[(rows_w + 0) * a.red_rs + t] = dbacc.x; red[(rows_w + 1) * a.red_rs + t] = dbacc.y; red[(rows_w + 2) * a.red_rs + t] = dbacc.z; red[(rows_w + 3) * a.red_rs + t] = dbacc.w; }
         }
         __syncthreads();
         if (active) {
-            for (int e = sub; e < E; e += a.nsub) {
-                const float* q = red + e * a.red_rs + ul;             // bank(e * red_rs + ul) = (e * units + ul) mod 32: conflict-free across lanes
-                float sum = 0.f;
-#pragma unroll 8
-                for (int k = 0; k < a.nsub; ++k) { sum += *q; q += a.units; }
-                const int co = co_base + 4 * cog + e / VEC, ci = ci0 + e % VEC;
-                if (co < a.Cout) dst[(((size_t)co * a.Cin + ci) * a.R + r) * S + s] = sum;
+            for (int e = sub; e < rows; e += a.nsub) {
+                if (e >= rows_w && ul >= a.cogb) continue;                // bias rows: only the owner units hold column sums of dy
+                const float* q = red + e * a.red_rs + ul;                 // bank(e * red_rs + ul) = (e * units + ul) mod 32: conflict-free across lanes
+                float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+                int k = 0;
+                for (; k + 3 < a.nsub; k += 4) { p0 += q[0]; p1 += q[a.units]; p2 += q[2 * a.units]; p3 += q[3 * a.units]; q += 4 * a.units; }
+                for (; k < a.nsub; ++k) { p0 += *q; q += a.units; }
+                const float sum = (p0 + p1) + (p2 + p3);
+                if (e < rows_w) {
+                    const int sl = e / E, rem = e - sl * E;
+                    const int co = co_base + 4 * cog + rem / VEC, ci = ci0 + rem % VEC;
+                    if (co < a.Cout) dst[(((size_t)co * a.Cin + ci) * a.R + r) * S + s0 + sl] = sum;
+                } else {
+                    const int co = co_base + 4 * cog + (e - rows_w);
+                    if (co < a.Cout) dst[a.wtotal + co] = sum;
+                }
             }
         }
     }
@@ -1127,7 +1136,8 @@ bool wgrad_slide_plan(const dcv_conv2d_desc* d, bool fuse_db, WgSlideArgs* a, in
         th = (th + 1) / 2;
     }
     if (bytes > 64 * 1024) return false;
-    const size_t red_bytes = (size_t)4 * v * a->red_rs * sizeof(float);
+    const int sgrp = (v == 4) ? (d->s < 3 ? d->s : 3) : d->s;             // filter columns merged per pass (SG of the kernel)
+    const size_t red_bytes = ((size_t)sgrp * 4 * v + 4) * a->red_rs * sizeof(float);
     if (bytes < red_bytes) bytes = red_bytes;
     a->tiles_per_img = (d->ho + th - 1) / th;
     a->total_tiles = d->n * a->tiles_per_img;

@@ -200,6 +200,82 @@ __global__ __launch_bounds__(256) void linear_wgrad_act_partial_kernel(const flo
     if (k == 0 && partial_b) partial_b[(size_t)chunk * O + o] = gsum;
 }
 
+// Narrow heads (O <= 16: the 10-class classifier): one BLOCK per sample row, its four waves split K.  Every lane issues its x vector and the OB weight
+// vectors of the same k together (one global round trip instead of K / 256 dependent ones per wave), the waves' sums meet in LDS in a fixed order.
+template <int OB>
+__global__ __launch_bounds__(256) void linear_fwd_row_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                              float* __restrict__ y, int K, int O, int act, float slope) {
+    __shared__ float part[4][OB];
+    const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float4* __restrict__ xr = reinterpret_cast<const float4*>(x + (size_t)n * K);
+    const int KV = K / 4;
+    for (int o0 = 0; o0 < O; o0 += OB) {
+        float acc[OB];
+#pragma unroll
+        for (int j = 0; j < OB; ++j) acc[j] = 0.f;
+#pragma unroll 2
+        for (int k = threadIdx.x; k < KV; k += 256) {
+            const float4 a = xr[k];
+#pragma unroll
+            for (int j = 0; j < OB; ++j) {
+                const int o = (o0 + j < O) ? o0 + j : O - 1;
+                const float4 b = reinterpret_cast<const float4*>(w + (size_t)o * K)[k];
+                acc[j] += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < OB; ++j) acc[j] = dcv_wave_sum(acc[j]);
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < OB; ++j) part[wave][j] = acc[j];
+        }
+        __syncthreads();
+        if (threadIdx.x < OB && o0 + (int)threadIdx.x < O) {
+            const int j = threadIdx.x;
+            const float v = (part[0][j] + part[1][j]) + (part[2][j] + part[3][j]);
+            y[(size_t)n * O + o0 + j] = dcv_act_apply(v + (bias ? bias[o0 + j] : 0.f), act, slope);
+        }
+    }
+}
+
+// Small batches of few classes (N <= 1024, C <= 16: the stock classifier's 512 x 10 logits): the whole loss in ONE launch of one block, a thread per
+// sample (its logits in registers: one global round trip), fixed-order block sum in fp64.
+__global__ __launch_bounds__(1024) void ce_fwd_single_kernel(const float* __restrict__ z, const int64_t* __restrict__ target, float* __restrict__ lse_out,
+                                                              float* __restrict__ loss, int32_t* __restrict__ correct, int N, int C) {
+    constexpr int CMAX = 16;
+    __shared__ double wl[16];
+    __shared__ int wc[16];
+    const int n = threadIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    double l = 0.0; int ok = 0;
+    if (n < N) {
+        const float* zr = z + (size_t)n * C;
+        float v[CMAX];
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) v[c] = c < C ? zr[c] : -INFINITY;
+        const int64_t t = target[n];
+        float m = -INFINITY; int mi = 0x7fffffff;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) if (c < C && (v[c] > m || (v[c] != v[c]))) { m = v[c]; mi = c; }     // first maximum wins (NaN: last NaN, as the wave kernel)
+        float sexp = 0.f, zt = 0.f;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) if (c < C) { sexp += expf(v[c] - m); if ((int64_t)c == t) zt = v[c]; }
+        const float lse = m + logf(sexp);
+        lse_out[n] = lse;
+        l = (double)(lse - zt);
+        ok = (mi == (int)t) ? 1 : 0;
+    }
+    l = dcv_wave_sum(l); ok = dcv_wave_sum(ok);
+    if (lane == 0) { wl[wid] = l; wc[wid] = ok; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0; int k = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { s += wl[i]; k += wc[i]; }
+        loss[0] = (float)(s / (double)N);
+        if (correct) correct[0] = k;
+    }
+}
+
 #define CE_THREADS 256           // 4 waves per block, one sample per wave per iteration
 // stage 1: per-block partial loss sum (double) and correct count
 __global__ __launch_bounds__(CE_THREADS) void ce_fwd_partial_kernel(const float* __restrict__ z, const int64_t* __restrict__ target, float* __restrict__ lse_out,
@@ -274,7 +350,12 @@ int dcv_linear_fwd(const float* x, const float* w, const float* bias, float* y, 
     hipStream_t st = dcv_stream(stream);
     const dim3 grid((unsigned)dcv_ceil_div(n, 4), (unsigned)dcv_ceil_div(O, LIN_OCHUNK));
     const bool v4 = K % 4 == 0 && aligned16(x) && aligned16(w);
-    if (v4 && O <= 10 && O > 8) hipLaunchKernelGGL((linear_fwd_kernel<4, 10>), grid, dim3(256), 0, st, x, w, bias, y, n, K, O, act, slope);
+    if (v4 && O <= 16 && K >= 512) {
+        if (O <= 8) hipLaunchKernelGGL((linear_fwd_row_kernel<8>), dim3((unsigned)n), dim3(256), 0, st, x, w, bias, y, K, O, act, slope);
+        else if (O <= 10) hipLaunchKernelGGL((linear_fwd_row_kernel<10>), dim3((unsigned)n), dim3(256), 0, st, x, w, bias, y, K, O, act, slope);
+        else hipLaunchKernelGGL((linear_fwd_row_kernel<16>), dim3((unsigned)n), dim3(256), 0, st, x, w, bias, y, K, O, act, slope);
+    }
+    else if (v4 && O <= 10 && O > 8) hipLaunchKernelGGL((linear_fwd_kernel<4, 10>), grid, dim3(256), 0, st, x, w, bias, y, n, K, O, act, slope);
     else if (v4) hipLaunchKernelGGL((linear_fwd_kernel<4, 8>), grid, dim3(256), 0, st, x, w, bias, y, n, K, O, act, slope);
     else hipLaunchKernelGGL((linear_fwd_kernel<1, 8>), grid, dim3(256), 0, st, x, w, bias, y, n, K, O, act, slope);
     DCV_RETURN_LAUNCH();
@@ -325,6 +406,10 @@ int dcv_cross_entropy_fwd(const float* logits, const int64_t* target, float* los
     hipStream_t st = dcv_stream(stream);
     double* part_loss = reinterpret_cast<double*>(ws);
     int* part_correct = reinterpret_cast<int*>(part_loss + CE_MAX_BLOCKS);
+    if (n <= 1024 && classes <= 16) {
+        hipLaunchKernelGGL(ce_fwd_single_kernel, dim3(1), dim3((unsigned)dcv_align_up(n, 64)), 0, st, logits, target, lse, loss, correct, n, classes);
+        DCV_RETURN_LAUNCH();
+    }
     unsigned nb = (unsigned)dcv_ceil_div(n, CE_THREADS / 64);
     if (nb > CE_MAX_BLOCKS) nb = CE_MAX_BLOCKS;
     hipLaunchKernelGGL(ce_fwd_partial_kernel, dim3(nb), dim3(CE_THREADS), 0, st, logits, target, lse, part_loss, part_correct, n, classes);

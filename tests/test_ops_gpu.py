@@ -238,7 +238,7 @@ def test_concat_add_flatten(device):
     _check('nchw_to_nhwc', ops.nchw_to_nhwc(x.to(device)), x, 0.)
 
 
-@pytest.mark.parametrize('n,k,o,act', [(8, 1280, 10, 3), (64, 512, 100, 0), (5, 37, 7, 1), (4, 64, 3, 4)], ids=str)
+@pytest.mark.parametrize('n,k,o,act', [(8, 1280, 10, 3), (64, 512, 100, 0), (5, 37, 7, 1), (4, 64, 3, 4), (16, 2048, 16, 0), (4, 516, 5, 1)], ids=str)
 def test_linear(device, n, k, o, act):
     from deepcv_amd import ops
     from oracle import ops_ref
@@ -255,7 +255,7 @@ def test_linear(device, n, k, o, act):
     _check(name + '.db', bd.grad, ref['db'], 3e-4)
 
 
-@pytest.mark.parametrize('n,c', [(8, 10), (512, 10), (64, 100), (7, 1000), (1500, 3)], ids=str)
+@pytest.mark.parametrize('n,c', [(8, 10), (512, 10), (64, 100), (7, 1000), (1500, 3), (1000, 16), (65, 1)], ids=str)
 def test_cross_entropy(device, n, c):
     from deepcv_amd import ops
     from oracle import ops_ref
