@@ -13,7 +13,7 @@ from typing import Optional
 
 import torch
 
-__all__ = ['lib', 'load', 'is_available', 'check', 'current_stream', 'Conv2dDesc', 'SlabSegment', 'Pool2dDesc', 'TensorList', 'LIB_PATH', 'build',
+__all__ = ['lib', 'load', 'is_available', 'check', 'current_stream', 'Conv2dDesc', 'SlabSegment', 'WgradJob', 'Pool2dDesc', 'TensorList', 'LIB_PATH', 'build',
            'ACT_NONE', 'ACT_RELU', 'ACT_LEAKY_RELU', 'ACT_SIGMOID', 'ACT_TANH', 'POOL_AVG', 'POOL_MAX', 'LAYOUT_NHWC', 'LAYOUT_NCHW',
            'MAX_TENSORS', 'HYP_COUNT', 'HYP']
 
@@ -46,6 +46,11 @@ class SlabSegment(ctypes.Structure):
     _fields_ = [('src', _c_void_p), ('dst', _c_void_p), ('count', ctypes.c_ulonglong), ('stride', ctypes.c_ulonglong), ('chunks', _c_int), ('reserved', _c_int)]
 
 
+class WgradJob(ctypes.Structure):
+    """ `dcv_wgrad_job` """
+    _fields_ = [('desc', Conv2dDesc), ('x', _c_void_p), ('dy', _c_void_p), ('dw', _c_void_p), ('db', _c_void_p), ('ws', _c_void_p), ('ws_bytes', _c_size_t)]
+
+
 class Pool2dDesc(ctypes.Structure):
     """ `dcv_pool2d_desc` """
     _fields_ = [('n', _c_int), ('h', _c_int), ('w', _c_int), ('c', _c_int), ('kh', _c_int), ('kw', _c_int), ('stride_h', _c_int),
@@ -72,6 +77,7 @@ _SIGNATURES = {
     'dcv_conv2d_wgrad': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _P, _c_size_t, _P]),
     'dcv_conv2d_wgrad_deferred': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _P, _c_size_t, ctypes.POINTER(SlabSegment), ctypes.POINTER(_c_int), _P]),
     'dcv_slab_reduce': (_c_int, [_c_int, ctypes.POINTER(SlabSegment), _P]),
+    'dcv_conv2d_wgrad_batch': (_c_int, [_c_int, ctypes.POINTER(WgradJob), ctypes.POINTER(SlabSegment), ctypes.POINTER(_c_int), _P]),
     'dcv_conv2d_wgrad_fuses_bias': (_c_int, [ctypes.POINTER(Conv2dDesc)]),
     'dcv_conv2d_filter_bytes': (_c_size_t, [ctypes.POINTER(Conv2dDesc), _c_int]),
     'dcv_conv2d_prepare_filters': (_c_int, [_c_int, ctypes.POINTER(ctypes.POINTER(Conv2dDesc)), ctypes.POINTER(_c_int), ctypes.POINTER(_P), ctypes.POINTER(_P), _P]),

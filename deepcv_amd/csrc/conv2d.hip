@@ -152,6 +152,34 @@ int dcv_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, 
     return conv2d_wgrad_impl(d, x, dy, dw, db, ws, ws_bytes, stream, nullptr, nullptr);
 }
 
+int dcv_conv2d_wgrad_batch(int count, const dcv_wgrad_job* jobs, dcv_slab_segment* segments, int* n_segments, void* stream) {
+    DCV_CHECK_ARG(count >= 0 && (count == 0 || (jobs && segments)) && n_segments);
+    if (count > 64) {                                                     // bounded stack tables below
+        for (int i0 = 0; i0 < count; i0 += 64) {
+            const int rc = dcv_conv2d_wgrad_batch(count - i0 < 64 ? count - i0 : 64, jobs + i0, segments, n_segments, stream);
+            if (rc != DCV_OK) return rc;
+        }
+        return DCV_OK;
+    }
+    bool eligible[64], taken[64];
+    for (int i = 0; i < count; ++i) {
+        const dcv_wgrad_job& j = jobs[i];
+        DCV_CHECK_ARG(desc_ok(&j.desc) && j.x && j.dy && j.dw);
+        if (j.desc.groups != 1) return DCV_ERR_UNSUPPORTED;
+        if (!j.ws || j.ws_bytes < dcv_conv2d_wgrad_workspace_bytes(&j.desc)) return DCV_ERR_WORKSPACE;
+        eligible[i] = !dcv_mfma_conv2d_supported(&j.desc, 2);
+    }
+    int rc = dcv_direct_conv2d_wgrad_multi(count, jobs, eligible, taken, segments, n_segments, dcv_stream(stream));
+    for (int i = 0; i < count && rc == DCV_OK; ++i) {
+        if (taken[i]) continue;
+        const dcv_wgrad_job& j = jobs[i];
+        int n = 0;
+        rc = conv2d_wgrad_impl(&j.desc, j.x, j.dy, j.dw, j.db, j.ws, j.ws_bytes, stream, segments + *n_segments, &n);
+        *n_segments += n;
+    }
+    return rc;
+}
+
 int dcv_conv2d_wgrad_deferred(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes,
                               dcv_slab_segment* segments, int* n_segments, void* stream) {
     DCV_CHECK_ARG(segments && n_segments);

@@ -618,9 +618,10 @@ __device__ __forceinline__ void dcv_divmod(int j, int d, int shift, int& q, int&
     if (shift >= 0) { q = j >> shift; r = j & (d - 1); } else { q = j / d; r = j - q * d; }
 }
 
+// `bx`, `by`, `nbx`: the block's coordinates inside ITS problem (blockIdx / gridDim of a single-problem launch; a range of a multi-problem launch)
 template <int S, int VEC, int SEG, int SW>
-__global__ __launch_bounds__(256) void conv_wgrad_slide_kernel(WgSlideArgs a, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void conv_wgrad_slide_body(const WgSlideArgs& a, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
+                                                      const int bx, const int by, const int nbx, char* smem) {
     float* xs = reinterpret_cast<float*>(smem);                       // [XH][xrs]   (pixel-major, channel fastest)
     float* dys = xs + a.xs_floats;                                    // [TH][drs]   (pixel-major, 4 * cogb channels)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
@@ -629,7 +630,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_slide_kernel(WgSlideArgs a, co
     const int cog = ul % a.cogb, r = (ul / a.cogb) % a.R, civ = ul / (a.cogb * a.R);   // cog fastest: neighbouring lanes share the x address (broadcast)
     const int ci0 = civ * VEC;
     const int tcob = 4 * a.cogb;
-    const int co_base = blockIdx.y * tcob;
+    const int co_base = by * tcob;
 
     float acc[S][4][VEC];
 #pragma unroll
@@ -641,7 +642,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_slide_kernel(WgSlideArgs a, co
     float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool db_owner = a.fuse_db && ul < a.cogb;               // the (r = 0, first input-channel vector) unit of each output-channel group
 
-    for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+    for (int tile = bx; tile < a.total_tiles; tile += nbx) {
         const int n = tile / a.tiles_per_img, ho0 = (tile % a.tiles_per_img) * a.TH;
         const int th = (a.Ho - ho0 < a.TH) ? (a.Ho - ho0) : a.TH;
         const int hi0 = ho0 * a.sh - a.ph, wi0 = -a.pw;
@@ -787,7 +788,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_slide_kernel(WgSlideArgs a, co
     //      coordinates are already in registers).  With few units (4->4 5x5: 5 units, 51 sub-streams) every thread owns at most one row per pass; the
     //      sub-stream sum runs as four interleaved chains so that its LDS reads are in flight together (the merge used to cost more than the FMA loop).
     float* red = reinterpret_cast<float*>(smem);
-    float* dst = partial + (size_t)blockIdx.x * a.slab;
+    float* dst = partial + (size_t)bx * a.slab;
     constexpr int E = 4 * VEC;
     constexpr int SG = (VEC == 4) ? (S < 3 ? S : 3) : S;                  // filter columns per pass (rows <= 52: see wgrad_slide_plan's LDS size)
     constexpr int PASSES = (S + SG - 1) / SG;
@@ -831,6 +832,42 @@ __global__ __launch_bounds__(256) void conv_wgrad_slide_kernel(WgSlideArgs a, co
                 }
             }
         }
+    }
+}
+
+template <int S, int VEC, int SEG, int SW>
+__global__ __launch_bounds__(256) void conv_wgrad_slide_kernel(WgSlideArgs a, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    conv_wgrad_slide_body<S, VEC, SEG, SW>(a, x, dy, partial, blockIdx.x, blockIdx.y, gridDim.x, smem);
+}
+
+// Several layers' weight gradients in ONE launch (the training step defers them to the end of its backward pass, deepcv_amd/slabs.py): block ranges
+// [start[i], start[i + 1]) run problem i.  One launch floor instead of one per layer, and the staging / FMA / merge phases of different layers' blocks
+// overlap on the CUs.  Variants: stride-1 kernels of 3 and 5 taps (the reference's stock layers), NHWC vector or scalar input.
+#define WG_MULTI_MAX 8
+struct WgMultiTable {
+    int count;
+    int start[WG_MULTI_MAX + 1];
+    int gx[WG_MULTI_MAX];
+    int variant[WG_MULTI_MAX];     // 0: <3, 4>, 1: <5, 4>, 2: <3, 1>, 3: <5, 1>
+    const float* x[WG_MULTI_MAX];
+    const float* dy[WG_MULTI_MAX];
+    float* partial[WG_MULTI_MAX];
+    WgSlideArgs a[WG_MULTI_MAX];
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_slide_multi_kernel(WgMultiTable t) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int i = 0;
+    while (i + 1 < t.count && (int)blockIdx.x >= t.start[i + 1]) ++i;                  // block-uniform: scalar loop
+    const int local = blockIdx.x - t.start[i];
+    const int gx = t.gx[i], by = local / gx, bx = local - by * gx;
+    const WgSlideArgs& a = t.a[i];
+    switch (t.variant[i]) {
+        case 0: conv_wgrad_slide_body<3, 4, 4, 1>(a, t.x[i], t.dy[i], t.partial[i], bx, by, gx, smem); break;
+        case 1: conv_wgrad_slide_body<5, 4, 4, 1>(a, t.x[i], t.dy[i], t.partial[i], bx, by, gx, smem); break;
+        case 2: conv_wgrad_slide_body<3, 1, 4, 1>(a, t.x[i], t.dy[i], t.partial[i], bx, by, gx, smem); break;
+        default: conv_wgrad_slide_body<5, 1, 4, 1>(a, t.x[i], t.dy[i], t.partial[i], bx, by, gx, smem); break;
     }
 }
 
@@ -1188,6 +1225,45 @@ bool dcv_direct_conv2d_wgrad_fuses_bias(const dcv_conv2d_desc* d) {
 }
 
 // `db` (nullable): bias gradient; *db_done tells the caller whether this back-end produced it
+// Stage one of every job the multi-problem slide kernel serves (taken[i] = true), WG_MULTI_MAX problems per launch; their pending sums are appended to
+// `segs` (the caller reduces them, dcv_slab_reduce).  Jobs it leaves (taken[i] = false) go through dcv_direct_conv2d_wgrad one by one.
+int dcv_direct_conv2d_wgrad_multi(int count, const dcv_wgrad_job* jobs, const bool* eligible, bool* taken, dcv_slab_segment* segs, int* nsegs, hipStream_t st) {
+    static int enabled = -1;
+    if (enabled < 0) { const char* e = getenv("DCV_WGRAD_MULTI"); enabled = e ? atoi(e) : 1; }
+    WgMultiTable t{};
+    size_t smem_max = 0;
+    int blocks = 0;
+    auto launch = [&]() {
+        if (t.count == 0) return;
+        t.start[t.count] = blocks;
+        hipLaunchKernelGGL(conv_wgrad_slide_multi_kernel, dim3((unsigned)blocks), dim3(256), smem_max, st, t);
+        t = WgMultiTable{}; smem_max = 0; blocks = 0;
+    };
+    for (int i = 0; i < count; ++i) {
+        taken[i] = false;
+        if (!enabled || !eligible[i]) continue;
+        const dcv_wgrad_job& j = jobs[i];
+        const dcv_conv2d_desc* d = &j.desc;
+        WgSlideArgs sa{}; int sv, sseg, sb, sy; size_t ssm;
+        if (!wgrad_slide_plan(d, j.db != nullptr, &sa, &sv, &sseg, &sb, &sy, &ssm)) continue;
+        if (d->stride_w != 1 || (d->s != 3 && d->s != 5) || sa.nt != 256 || sseg != 4) continue;
+        if ((sv == 4 && (reinterpret_cast<uintptr_t>(j.x) & 15) != 0) || (reinterpret_cast<uintptr_t>(j.dy) & 15) != 0) continue;
+        if (!j.ws || j.ws_bytes < (size_t)sb * sa.slab * sizeof(float)) return DCV_ERR_WORKSPACE;
+        if (t.count == WG_MULTI_MAX) launch();
+        const int k = t.count++;
+        t.start[k] = blocks; t.gx[k] = sb; t.variant[k] = (sv == 4 ? 0 : 2) + (d->s == 5 ? 1 : 0);
+        t.x[k] = j.x; t.dy[k] = j.dy; t.partial[k] = reinterpret_cast<float*>(j.ws); t.a[k] = sa;
+        blocks += sb * sy;
+        if (ssm > smem_max) smem_max = ssm;
+        float* partial = reinterpret_cast<float*>(j.ws);
+        segs[(*nsegs)++] = dcv_slab_segment{partial, j.dw, sa.wtotal, sa.slab, sb, 0};
+        if (j.db) segs[(*nsegs)++] = dcv_slab_segment{partial + sa.wtotal, j.db, (unsigned long long)d->cout, sa.slab, sb, 0};
+        taken[i] = true;
+    }
+    launch();
+    return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
+}
+
 // second stage: immediate (one launch of the shared slab reducer) or handed back to the caller as segments (`defer` != nullptr)
 static int wgrad_second_stage(const float* partial, float* dw, float* db, int chunks, size_t wtotal, size_t slab, int cout, dcv_slab_segment* defer, int* ndefer, hipStream_t st) {
     dcv_slab_segment seg[2] = {{partial, dw, wtotal, slab, chunks, 0}, {partial + wtotal, db, (unsigned long long)(db ? cout : 0), slab, chunks, 0}};

@@ -12,6 +12,7 @@ int dcv_direct_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d);
 int dcv_direct_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t st, bool prepared = false);
 size_t dcv_direct_conv2d_wgrad_ws(const dcv_conv2d_desc* d);
 bool dcv_direct_conv2d_wgrad_fuses_bias(const dcv_conv2d_desc* d);
+int dcv_direct_conv2d_wgrad_multi(int count, const dcv_wgrad_job* jobs, const bool* eligible, bool* taken, dcv_slab_segment* segs, int* nsegs, hipStream_t st);
 int dcv_direct_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, float* db, bool* db_done, void* ws, size_t ws_bytes, hipStream_t st,
                             dcv_slab_segment* defer = nullptr, int* ndefer = nullptr);
 

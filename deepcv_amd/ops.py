@@ -33,15 +33,12 @@ def _ws(nbytes: int, device) -> torch.Tensor:
 
 
 def _conv_wgrad_launch(d, x, dz, weight, bias, dw, db, st):
-    """ Weight (+ bias) gradient of one convolution; the ordered sum of its partial slabs is left to `slabs.flush()` whenever nothing can read the
-    gradients before the end of the backward pass. """
+    """ Weight (+ bias) gradient of one convolution; left to `slabs.flush()` (one multi-layer launch + one ordered slab sum for the whole backward pass)
+    whenever nothing can read the gradients before the end of the backward pass. """
     dev = dz.device
     ws = _ws(lib.dcv_conv2d_wgrad_workspace_bytes(d), dev)
     if slabs.may_defer(weight, bias):
-        segs, n = (nat.SlabSegment * 2)(), ctypes.c_int(0)
-        nat.check(lib.dcv_conv2d_wgrad_deferred(d, x.data_ptr(), dz.data_ptr(), dw.data_ptr(), nat.ptr(db), ws.data_ptr(), ws.numel(), segs, ctypes.byref(n), st),
-                  'dcv_conv2d_wgrad_deferred')
-        slabs.defer(dev, st, segs, n.value, ws)
+        slabs.defer_wgrad(dev, st, d, x, dz, dw.data_ptr(), nat.ptr(db), ws)       # both stages at the end of the backward pass, with the other layers'
     else:
         nat.check(lib.dcv_conv2d_wgrad(d, x.data_ptr(), dz.data_ptr(), dw.data_ptr(), nat.ptr(db), ws.data_ptr(), ws.numel(), st), 'dcv_conv2d_wgrad')
 

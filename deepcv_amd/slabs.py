@@ -1,10 +1,14 @@
-""" Deferred second stage of the weight gradients.
+""" Deferred weight gradients.
 
-Every weight-gradient kernel of the hot path writes per-block partial slabs which an ordered sum turns into `dw` (and `db`).  On the reference's stock
+(1) Deferred second stage.  Every weight-gradient kernel of the hot path writes per-block partial slabs which an ordered sum turns into `dw` (and `db`).  On the reference's stock
 classifier (`conf/base/parameters.yml:61-107`) that sum is a ~5 us launch per layer whose result nobody reads before the optimizer step, and the
 step is bound by its number of launches: the backward functions of `deepcv_amd/ops.py` therefore only run stage one, queue the pending sums here, and
 ONE `dcv_slab_reduce` launch executes all of them when the autograd engine finishes the backward pass (`queue_callback`, the hook DistributedDataParallel
 uses for the same purpose).  Inside a hipGraph capture the callback is captured like any other launch.
+
+(2) Deferred first stage.  The weight gradient of a convolution depends on nothing but the layer's input and dz, and nothing in the backward pass depends on
+it: `defer_wgrad` queues the whole problem, and the flush hands all of them to `dcv_conv2d_wgrad_batch`, which runs the stock layers' kernels as block
+ranges of ONE multi-problem launch (one launch floor instead of five, and the staging / FMA / merge phases of different layers overlap on the CUs).
 
 The result is bit-identical to the immediate entry points (same kernel, the sum order only depends on the slab count).  A gradient is only deferred when
 nothing can read it before the flush: plain first-order backward, the parameter's `.grad` is empty (the engine then adopts the tensor instead of adding
@@ -18,11 +22,12 @@ import torch
 from . import _native as nat
 from ._native import lib
 
-__all__ = ['enabled', 'set_enabled', 'note_use', 'may_defer', 'reset_uses', 'defer', 'flush', 'pending']
+__all__ = ['enabled', 'set_enabled', 'note_use', 'may_defer', 'reset_uses', 'defer', 'defer_wgrad', 'flush', 'pending']
 
 _enabled = True
 _lock = threading.Lock()
 _pending: List[Tuple[torch.device, int, List[nat.SlabSegment], torch.Tensor]] = []   # (device, stream handle, segments, workspace kept alive)
+_wgrads: List[Tuple[torch.device, int, 'nat.WgradJob', tuple]] = []                  # (device, stream handle, job, tensors kept alive: x, dz, workspace)
 _callback_queued = False
 _uses: Dict[int, List[int]] = {}      # id(parameter) -> [forward uses whose backward has not run yet, peak of that count]
 
@@ -74,18 +79,9 @@ def reset_uses():
         _uses.clear()
 
 
-def defer(device: torch.device, stream: int, segments, n: int, ws: torch.Tensor):
-    """ Queues `n` segments produced by a `*_deferred` entry point; `ws` (their slabs) stays alive until the flush. """
+def _queue_flush():
     global _callback_queued
-    if n <= 0:
-        return
-    segs = []
-    for i in range(n):
-        g = nat.SlabSegment()
-        ctypes.pointer(g)[0] = segments[i]
-        segs.append(g)
     with _lock:
-        _pending.append((device, stream, segs, ws))
         queue = not _callback_queued
         _callback_queued = True
     if queue:
@@ -95,9 +91,34 @@ def defer(device: torch.device, stream: int, segments, n: int, ws: torch.Tensor)
             flush()
 
 
+def defer(device: torch.device, stream: int, segments, n: int, ws: torch.Tensor):
+    """ Queues `n` segments produced by a `*_deferred` entry point; `ws` (their slabs) stays alive until the flush. """
+    if n <= 0:
+        return
+    segs = []
+    for i in range(n):
+        g = nat.SlabSegment()
+        ctypes.pointer(g)[0] = segments[i]
+        segs.append(g)
+    with _lock:
+        _pending.append((device, stream, segs, ws))
+    _queue_flush()
+
+
+def defer_wgrad(device: torch.device, stream: int, desc, x: torch.Tensor, dz: torch.Tensor, dw_ptr: int, db_ptr, ws: torch.Tensor):
+    """ Queues a whole convolution weight gradient (both stages).  `x`, `dz` and the workspace stay alive until the flush; `dw` / `db` are only known by
+    address: the autograd engine must find itself their sole owner to adopt them as `.grad` instead of copying them. """
+    job = nat.WgradJob()
+    ctypes.pointer(job.desc)[0] = desc
+    job.x, job.dy, job.dw, job.db, job.ws, job.ws_bytes = x.data_ptr(), dz.data_ptr(), dw_ptr, db_ptr, ws.data_ptr(), ws.numel()
+    with _lock:
+        _wgrads.append((device, stream, job, (x, dz, ws)))
+    _queue_flush()
+
+
 def pending() -> int:
     with _lock:
-        return sum(len(p[2]) for p in _pending)
+        return sum(len(p[2]) for p in _pending) + len(_wgrads)
 
 
 def flush():
@@ -106,19 +127,36 @@ def flush():
     global _callback_queued
     with _lock:
         jobs = list(_pending)
+        wjobs = list(_wgrads)
         _pending.clear()
+        _wgrads.clear()
         _callback_queued = False
-    groups: Dict[Tuple[torch.device, int], List] = {}
+    groups: Dict[Tuple[torch.device, int], Dict[str, List]] = {}
     for dev, st, segs, ws in jobs:
-        groups.setdefault((dev, st), []).append((segs, ws))
-    for (dev, st), items in groups.items():
-        segs = [g for s, _ in items for g in s]
-        arr = (nat.SlabSegment * len(segs))(*segs)
+        groups.setdefault((dev, st), {'segs': [], 'keep': [], 'wgrads': []})['segs'].extend(segs)
+        groups[(dev, st)]['keep'].append(ws)
+    for dev, st, job, keep in wjobs:
+        g = groups.setdefault((dev, st), {'segs': [], 'keep': [], 'wgrads': []})
+        g['wgrads'].append(job)
+        g['keep'].extend(keep)
+    for (dev, st), g in groups.items():
         cur = nat.current_stream(dev)
         if cur != st:
             # the engine ran the backward ops on the stream of their forward ops; the gradients are consumed on the caller's stream
             torch.cuda.current_stream(dev).wait_stream(torch.cuda.ExternalStream(st, device=dev))
-        nat.check(lib.dcv_slab_reduce(len(segs), arr, cur), 'dcv_slab_reduce')
+        segs = list(g['segs'])
+        if g['wgrads']:
+            n = len(g['wgrads'])
+            jarr = (nat.WgradJob * n)(*g['wgrads'])
+            sarr, ns = (nat.SlabSegment * (2 * n))(), ctypes.c_int(0)
+            nat.check(lib.dcv_conv2d_wgrad_batch(n, jarr, sarr, ctypes.byref(ns), cur), 'dcv_conv2d_wgrad_batch')
+            for i in range(ns.value):
+                s = nat.SlabSegment()
+                ctypes.pointer(s)[0] = sarr[i]
+                segs.append(s)
+        if segs:
+            arr = (nat.SlabSegment * len(segs))(*segs)
+            nat.check(lib.dcv_slab_reduce(len(segs), arr, cur), 'dcv_slab_reduce')
         if cur != st:
-            for _, ws in items:
-                ws.record_stream(torch.cuda.current_stream(dev))
+            for t in g['keep']:
+                t.record_stream(torch.cuda.current_stream(dev))

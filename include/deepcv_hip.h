@@ -104,6 +104,19 @@ typedef struct dcv_slab_segment {
 int dcv_conv2d_wgrad_deferred(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, float* db,
                               void* ws, size_t ws_bytes, dcv_slab_segment* segments /* [2] */, int* n_segments, void* stream);
 int dcv_slab_reduce(int n, const dcv_slab_segment* segments, void* stream);
+/* Stage one of SEVERAL weight gradients (the layers of one backward pass, collected by the caller) in as few launches as possible: the stock layers'
+ * kernels run as block ranges of one multi-problem launch.  Appends every pending sum to `segments` (capacity 2 * count, *n_segments is the running
+ * count); gradients of jobs whose back-end sums immediately are complete on return.  Each job needs its own workspace. */
+typedef struct dcv_wgrad_job {
+    dcv_conv2d_desc desc;
+    const float* x;
+    const float* dy;
+    float* dw;
+    float* db;                     /* nullable */
+    void* ws;
+    size_t ws_bytes;               /* >= dcv_conv2d_wgrad_workspace_bytes(&desc) */
+} dcv_wgrad_job;
+int dcv_conv2d_wgrad_batch(int count, const dcv_wgrad_job* jobs, dcv_slab_segment* segments, int* n_segments, void* stream);
 /* 1 when dcv_conv2d_wgrad produces db from the dy tiles it already stages (no extra pass over dy, no extra launch): callers which can get the bias
  * gradient elsewhere too (dcv_bn_gn_act_bwd, dcv_act_bwd) use this to pick the cheaper source. */
 int dcv_conv2d_wgrad_fuses_bias(const dcv_conv2d_desc* d);
