@@ -102,6 +102,10 @@ _SIGNATURES = {
     'dcv_norm_chain_workspace_bytes': (_c_size_t, [_c_int, _c_int, _c_int]),
     'dcv_bn_gn_fwd_train': (_c_int, [_P, _P, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _c_float, _c_float, _P, _P, _c_int, _P, _P, _c_float, _P, _P, _P, _c_int, _P, _c_size_t, _P]),
     'dcv_bn_gn_act_bwd': (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _P, _P, _P, _P, _c_int, _P, _P, _P, _c_int, _c_float, _P, _P, _P, _P, _P, _P, _c_size_t, _P]),
+    'dcv_bn_gn_pool_fwd_train': (_c_int, [_P, _P, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _c_float, _c_float, _P, _P, _c_int, _P, _P, _c_float, _P, _P, _P, _c_int,
+                                          _c_int, _c_int, _P, _c_size_t, _P]),
+    'dcv_bn_gn_pool_act_bwd': (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _P, _P, _P, _P, _c_int, _P, _P, _P, _c_int, _c_float, _P, _P, _P, _P, _P,
+                                        _c_int, _c_int, _P, _c_size_t, _P]),
     'dcv_pool2d_fwd': (_c_int, [ctypes.POINTER(Pool2dDesc), _P, _P, _P, _P]),
     'dcv_pool2d_bwd': (_c_int, [ctypes.POINTER(Pool2dDesc), _P, _P, _P, _P]),
     'dcv_interp_bilinear_fwd': (_c_int, [_P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _P]),

@@ -325,7 +325,7 @@ template <int VEC, bool CACHED>
 __global__ __launch_bounds__(DCV_CR_THREADS) void nf_bn_gn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, int HW, int C, int G,
                                                                          const float* __restrict__ bn_scale_shift, const float* __restrict__ gamma,
                                                                          const float* __restrict__ beta, float eps,
-                                                                         float* __restrict__ save_mean, float* __restrict__ save_rstd) {
+                                                                         float* __restrict__ save_mean, float* __restrict__ save_rstd, int W, int pk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* chan = reinterpret_cast<double*>(smem);                      // [2][C]
     float* bsc = reinterpret_cast<float*>(chan + 2 * (size_t)C);         // [C] BN scale
@@ -377,6 +377,32 @@ __global__ __launch_bounds__(DCV_CR_THREADS) void nf_bn_gn_apply_kernel(const fl
         shift[c] = (bsh[c] - (float)mean) * rstd * gm + bt;
     }
     __syncthreads();
+    if (pk > 0) {
+        // fused average pooling (pk x pk windows, stride pk): the mean of the affine is the affine of the mean; only the pooled tensor is written.
+        // The sample's pixels were read a moment ago (L2 / vector cache hits); one thread per pooled (pixel, channel vector).
+        const int H = HW / W, Wo = W / pk, HoWo = (H / pk) * Wo;
+        const float inv = 1.f / (float)(pk * pk);
+        float* yp = y + (size_t)n * HoWo * C;
+        for (int i = threadIdx.x; i < HoWo * CV; i += blockDim.x) {
+            const int po = i / CV, c = (i - po * CV) * VEC;
+            const int ho = po / Wo, wo = po - ho * Wo;
+            float acc[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+            for (int kh = 0; kh < pk; ++kh)
+                for (int kw = 0; kw < pk; ++kw) {
+                    float xv[VEC];
+                    nf_load_vec4(x + base + ((size_t)(ho * pk + kh) * W + wo * pk + kw) * C + c, xv);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[v] += xv[v] * scale[c + v] + shift[c + v];     // same per-element rounding as the unfused affine
+                }
+            float o[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) o[v] = acc[v] * inv;
+            nf_store_vec4(yp + (size_t)po * C + c, o);
+        }
+        return;
+    }
     if constexpr (CACHED) {
         if (row_thread) {
 #pragma unroll
@@ -436,17 +462,32 @@ __global__ __launch_bounds__(64) void nf_sum_partials_kernel(const double* __res
     if (lane == 0) out[c] = (float)s;
 }
 
+// Gradient w.r.t. the chain's output at element `idx` (= pixel * C + c) of one sample.  With fused average pooling (pk > 0) `dout` is the gradient of the
+// POOLED tensor: every pixel of a window receives 1 / pk^2 of it.
+struct NfPoolMap {
+    int C, W, Wo, pk; float inv;
+    __device__ __forceinline__ size_t src(size_t idx, int c) const {
+        const int pix = (int)(idx / C);
+        const int h = pix / W, w = pix - h * W;
+        return ((size_t)(h / pk) * Wo + w / pk) * C + c;
+    }
+};
+template <int VEC>
+__device__ __forceinline__ void nf_load_dout(const float* dout, const NfPoolMap& pm, size_t idx, int c, float (&d)[VEC]) {
+    if (pm.pk > 0) {
+        nf_load_vec4(dout + pm.src(idx, c), d);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) d[v] *= pm.inv;
+    } else nf_load_vec4(dout + idx, d);
+}
+
 struct NfGnBwdLoaderA {         // pass A: q0 = dout, q1 = dout * w,  w = (x * bsc + bsh - mean_g) * rstd_g   (mean / rstd expanded per CHANNEL in LDS)
-    const float* dout; const float* x; const float* bsc; const float* bsh; const float* mean; const float* rstd;
+    const float* dout; const float* x; const float* bsc; const float* bsh; const float* mean; const float* rstd; NfPoolMap pm;
     template <int VEC>
     __device__ __forceinline__ void load(size_t idx, int c, float (&q)[2][VEC]) const {
         float xv[VEC];
-        if constexpr (VEC == 4) {
-            const float4 d = *reinterpret_cast<const float4*>(dout + idx);
-            const float4 v = *reinterpret_cast<const float4*>(x + idx);
-            q[0][0] = d.x; q[0][1] = d.y; q[0][2] = d.z; q[0][3] = d.w;
-            xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w;
-        } else { q[0][0] = dout[idx]; xv[0] = x[idx]; }
+        nf_load_dout<VEC>(dout, pm, idx, c, q[0]);
+        nf_load_vec4(x + idx, xv);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) q[1][i] = q[0][i] * ((xv[i] * bsc[c + i] + bsh[c + i] - mean[c + i]) * rstd[c + i]);
     }
@@ -454,16 +495,12 @@ struct NfGnBwdLoaderA {         // pass A: q0 = dout, q1 = dout * w,  w = (x * b
 
 struct NfGnBwdLoaderB {         // pass B: dv = ca * dout - cb - w * cd  (stored to dv_out);  q0 = dv, q1 = dv * u,  u = (x - bn_mean) * bn_rstd
     const float* dout; const float* x; float* dv_out; const float* bsc; const float* bsh; const float* mean; const float* rstd;
-    const float* ca; const float* cb; const float* cd; const float* bmean; const float* brstd;
+    const float* ca; const float* cb; const float* cd; const float* bmean; const float* brstd; NfPoolMap pm;
     template <int VEC>
     __device__ __forceinline__ void load(size_t idx, int c, float (&q)[2][VEC]) const {
         float xv[VEC], dv[VEC];
-        if constexpr (VEC == 4) {
-            const float4 d = *reinterpret_cast<const float4*>(dout + idx);
-            const float4 v = *reinterpret_cast<const float4*>(x + idx);
-            dv[0] = d.x; dv[1] = d.y; dv[2] = d.z; dv[3] = d.w;
-            xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w;
-        } else { dv[0] = dout[idx]; xv[0] = x[idx]; }
+        nf_load_dout<VEC>(dout, pm, idx, c, dv);
+        nf_load_vec4(x + idx, xv);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             const float w = (xv[i] * bsc[c + i] + bsh[c + i] - mean[c + i]) * rstd[c + i];
@@ -483,7 +520,7 @@ __global__ __launch_bounds__(DCV_CR_THREADS) void nf_gn_bn_bwd_kernel(const floa
                                                                        int HW, int C, int G, const float* __restrict__ bn_gamma, const float* __restrict__ bn_beta,
                                                                        const float* __restrict__ bn_mean, const float* __restrict__ bn_rstd,
                                                                        const float* __restrict__ gn_gamma, const float* __restrict__ gn_mean,
-                                                                       const float* __restrict__ gn_rstd, double* __restrict__ partial) {
+                                                                       const float* __restrict__ gn_rstd, double* __restrict__ partial, NfPoolMap pm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* chan = reinterpret_cast<double*>(smem);                      // [4][C]
     float* bsc = reinterpret_cast<float*>(chan + 4 * (size_t)C);         // [C] each:
@@ -492,6 +529,7 @@ __global__ __launch_bounds__(DCV_CR_THREADS) void nf_gn_bn_bwd_kernel(const floa
     float* scratch = grc + C;                                            // [2 * 256 * VEC]
     const int n = blockIdx.x;
     const size_t base = (size_t)n * HW * C;
+    const size_t dbase = pm.pk > 0 ? (size_t)n * (HW / (pm.pk * pm.pk)) * C : base;      // this sample inside dout (the pooled gradient when pooling is fused)
     const int cpg = C / G;
     const float* mean = gn_mean + (size_t)n * G;
     const float* rstd = gn_rstd + (size_t)n * G;
@@ -516,7 +554,7 @@ __global__ __launch_bounds__(DCV_CR_THREADS) void nf_gn_bn_bwd_kernel(const floa
                 const int r = rsub + k * rpi;
                 if (r < HW) {
                     nf_load_vec4(x + base + (size_t)r * C + cv0, xc[k]);
-                    nf_load_vec4(dout + base + (size_t)r * C + cv0, dc[k]);
+                    nf_load_dout<VEC>(dout + dbase, pm, (size_t)r * C + cv0, cv0, dc[k]);
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
                         const int c = cv0 + v;
@@ -528,7 +566,7 @@ __global__ __launch_bounds__(DCV_CR_THREADS) void nf_gn_bn_bwd_kernel(const floa
         }
         dcv_colreduce_merge<2, VEC>(acc, C, scratch, chan);
     } else {
-        NfGnBwdLoaderA la{dout + base, x + base, bsc, bsh, gmc, grc};
+        NfGnBwdLoaderA la{dout + dbase, x + base, bsc, bsh, gmc, grc, pm};
         dcv_colreduce_block<2, VEC>(la, 0, (size_t)HW, C, scratch, chan);
     }
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -565,7 +603,7 @@ __global__ __launch_bounds__(DCV_CR_THREADS) void nf_gn_bn_bwd_kernel(const floa
         }
         dcv_colreduce_merge<2, VEC>(acc, C, scratch, chan + 2 * (size_t)C);
     } else {
-        NfGnBwdLoaderB lb{dout + base, x + base, dv_out + base, bsc, bsh, gmc, grc, ca, cb, cd, bm, br};
+        NfGnBwdLoaderB lb{dout + dbase, x + base, dv_out + base, bsc, bsh, gmc, grc, ca, cb, cd, bm, br, pm};
         dcv_colreduce_block<2, VEC>(lb, 0, (size_t)HW, C, scratch, chan + 2 * (size_t)C);
     }
     for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) partial[(size_t)i * gridDim.x + n] = chan[i];     // [4][C][N]: the finalize reads sample-contiguous
@@ -798,7 +836,17 @@ int dcv_bn_gn_fwd_train(const float* x, float* y, int n, int hw, int C,
                         float* bn_save_mean, float* bn_save_rstd,
                         int G, const float* gn_gamma, const float* gn_beta, float gn_eps, float* gn_save_mean, float* gn_save_rstd,
                         const double* stats, int stats_rows, void* ws, size_t ws_bytes, void* stream) {
+    return dcv_bn_gn_pool_fwd_train(x, y, n, hw, C, bn_gamma, bn_beta, running_mean, running_var, nbt, momentum, bn_eps, bn_save_mean, bn_save_rstd,
+                                    G, gn_gamma, gn_beta, gn_eps, gn_save_mean, gn_save_rstd, stats, stats_rows, 0, 0, ws, ws_bytes, stream);
+}
+
+int dcv_bn_gn_pool_fwd_train(const float* x, float* y, int n, int hw, int C,
+                             const float* bn_gamma, const float* bn_beta, float* running_mean, float* running_var, int64_t* nbt, float momentum, float bn_eps,
+                             float* bn_save_mean, float* bn_save_rstd,
+                             int G, const float* gn_gamma, const float* gn_beta, float gn_eps, float* gn_save_mean, float* gn_save_rstd,
+                             const double* stats, int stats_rows, int width, int pool, void* ws, size_t ws_bytes, void* stream) {
     DCV_CHECK_ARG(x && y && bn_save_mean && bn_save_rstd && ws && n > 0 && hw > 0 && C > 0 && G >= 0 && (stats == nullptr || stats_rows > 0));
+    DCV_CHECK_ARG(pool >= 0 && (pool == 0 || (G > 0 && width > 0 && hw % width == 0 && width % pool == 0 && (hw / width) % pool == 0)));
     DCV_CHECK_ARG(G == 0 || (C % G == 0 && gn_save_mean && gn_save_rstd));
     if (ws_bytes < dcv_norm_chain_workspace_bytes(n, hw, C)) return DCV_ERR_WORKSPACE;
     hipStream_t st = dcv_stream(stream);
@@ -818,10 +866,10 @@ int dcv_bn_gn_fwd_train(const float* x, float* y, int n, int hw, int C,
         const size_t smem = 2 * (size_t)C * sizeof(double) + (size_t)4 * C * sizeof(float) + (size_t)2 * DCV_CR_THREADS * vec * sizeof(float);
         if (smem > 64 * 1024) return DCV_ERR_UNSUPPORTED;
         const bool cached = nf_sample_fits_registers(hw, C, vec);
-        if (vec == 4 && cached) hipLaunchKernelGGL((nf_bn_gn_apply_kernel<4, true>), dim3(n), dim3(DCV_CR_THREADS), smem, st, x, y, hw, C, G, scale_shift, gn_gamma, gn_beta, gn_eps, gn_save_mean, gn_save_rstd);
-        else if (vec == 4) hipLaunchKernelGGL((nf_bn_gn_apply_kernel<4, false>), dim3(n), dim3(DCV_CR_THREADS), smem, st, x, y, hw, C, G, scale_shift, gn_gamma, gn_beta, gn_eps, gn_save_mean, gn_save_rstd);
-        else if (cached) hipLaunchKernelGGL((nf_bn_gn_apply_kernel<1, true>), dim3(n), dim3(DCV_CR_THREADS), smem, st, x, y, hw, C, G, scale_shift, gn_gamma, gn_beta, gn_eps, gn_save_mean, gn_save_rstd);
-        else hipLaunchKernelGGL((nf_bn_gn_apply_kernel<1, false>), dim3(n), dim3(DCV_CR_THREADS), smem, st, x, y, hw, C, G, scale_shift, gn_gamma, gn_beta, gn_eps, gn_save_mean, gn_save_rstd);
+        if (vec == 4 && cached) hipLaunchKernelGGL((nf_bn_gn_apply_kernel<4, true>), dim3(n), dim3(DCV_CR_THREADS), smem, st, x, y, hw, C, G, scale_shift, gn_gamma, gn_beta, gn_eps, gn_save_mean, gn_save_rstd, width, pool);
+        else if (vec == 4) hipLaunchKernelGGL((nf_bn_gn_apply_kernel<4, false>), dim3(n), dim3(DCV_CR_THREADS), smem, st, x, y, hw, C, G, scale_shift, gn_gamma, gn_beta, gn_eps, gn_save_mean, gn_save_rstd, width, pool);
+        else if (cached) hipLaunchKernelGGL((nf_bn_gn_apply_kernel<1, true>), dim3(n), dim3(DCV_CR_THREADS), smem, st, x, y, hw, C, G, scale_shift, gn_gamma, gn_beta, gn_eps, gn_save_mean, gn_save_rstd, width, pool);
+        else hipLaunchKernelGGL((nf_bn_gn_apply_kernel<1, false>), dim3(n), dim3(DCV_CR_THREADS), smem, st, x, y, hw, C, G, scale_shift, gn_gamma, gn_beta, gn_eps, gn_save_mean, gn_save_rstd, width, pool);
     } else if (vec == 4) {
         const size_t nv = rows * (size_t)C / 4;
         hipLaunchKernelGGL((affine_apply_kernel<4>), dim3(dcv_stream_grid(nv, 256)), dim3(256), 0, st, x, y, nv, C, scale_shift);
@@ -838,7 +886,19 @@ int dcv_bn_gn_act_bwd(const float* dout, const float* x, float* dz, int n, int h
                       int act, float slope,
                       float* d_bn_gamma, float* d_bn_beta, float* d_gn_gamma, float* d_gn_beta, float* d_bias,
                       void* ws, size_t ws_bytes, void* stream) {
+    return dcv_bn_gn_pool_act_bwd(dout, x, dz, n, hw, C, bn_gamma, bn_beta, bn_save_mean, bn_save_rstd, G, gn_gamma, gn_save_mean, gn_save_rstd, act, slope,
+                                  d_bn_gamma, d_bn_beta, d_gn_gamma, d_gn_beta, d_bias, 0, 0, ws, ws_bytes, stream);
+}
+
+int dcv_bn_gn_pool_act_bwd(const float* dout, const float* x, float* dz, int n, int hw, int C,
+                           const float* bn_gamma, const float* bn_beta, const float* bn_save_mean, const float* bn_save_rstd,
+                           int G, const float* gn_gamma, const float* gn_save_mean, const float* gn_save_rstd,
+                           int act, float slope,
+                           float* d_bn_gamma, float* d_bn_beta, float* d_gn_gamma, float* d_gn_beta, float* d_bias,
+                           int width, int pool, void* ws, size_t ws_bytes, void* stream) {
     DCV_CHECK_ARG(dout && x && dz && bn_save_mean && bn_save_rstd && ws && n > 0 && hw > 0 && C > 0 && G >= 0);
+    DCV_CHECK_ARG(pool >= 0 && (pool == 0 || (G > 0 && width > 0 && hw % width == 0 && width % pool == 0 && (hw / width) % pool == 0)));
+    const NfPoolMap pm{C, width > 0 ? width : 1, pool > 0 ? width / pool : 1, pool, pool > 0 ? 1.f / (float)(pool * pool) : 1.f};
     DCV_CHECK_ARG(G == 0 || (C % G == 0 && gn_save_mean && gn_save_rstd));
     if (ws_bytes < dcv_norm_chain_workspace_bytes(n, hw, C)) return DCV_ERR_WORKSPACE;
     hipStream_t st = dcv_stream(stream);
@@ -852,7 +912,7 @@ int dcv_bn_gn_act_bwd(const float* dout, const float* x, float* dz, int n, int h
         const size_t smem = 4 * (size_t)C * sizeof(double) + (size_t)9 * C * sizeof(float) + (size_t)2 * DCV_CR_THREADS * vec * sizeof(float);
         if (smem > 64 * 1024) return DCV_ERR_UNSUPPORTED;
 #define NF_BWD_LAUNCH(V_, C_) hipLaunchKernelGGL((nf_gn_bn_bwd_kernel<V_, C_>), dim3(n), dim3(DCV_CR_THREADS), smem, st, dout, x, dz, hw, C, G, bn_gamma, bn_beta, \
-                                                 bn_save_mean, bn_save_rstd, gn_gamma, gn_save_mean, gn_save_rstd, partial)
+                                                 bn_save_mean, bn_save_rstd, gn_gamma, gn_save_mean, gn_save_rstd, partial, pm)
         const bool cached = nf_sample_fits_registers(hw, C, vec);
         if (vec == 4 && cached) NF_BWD_LAUNCH(4, true); else if (vec == 4) NF_BWD_LAUNCH(4, false); else if (cached) NF_BWD_LAUNCH(1, true); else NF_BWD_LAUNCH(1, false);
 #undef NF_BWD_LAUNCH

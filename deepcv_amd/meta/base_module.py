@@ -75,12 +75,23 @@ class DeepcvModule(torch.nn.Module):
                 raise ValueError(f'Error: No enought input tensors in "{type(self).__name__}", was expecting {1 if self._single_input_shape else len(self._input_shape)} '
                                  f'tensor(s) but got {len(x)}.')
         if self.is_sequential_nn():
-            return self._child_modules(x)
+            children = list(self._child_modules.children())
+            i = 0
+            while i < len(children):
+                fused = self._layer_with_pool(children[i], children[i + 1] if i + 1 < len(children) else None, x)
+                if fused is not None:
+                    x, i = fused, i + 2
+                else:
+                    x, i = children[i](x), i + 1
+            return x
 
         # Output tensor reference(s) (`_from`) need specific handling: stash referenced outputs until their last referrer consumed them
         referenced_output_features: Dict[str, TENSOR_OR_SEQ_OF_TENSORS_T] = {}
         remaining_refs = dict(self._submodule_references)
-        for name, subm in self._child_modules.items():
+        items = list(self._child_modules.items())
+        i = 0
+        while i < len(items):
+            name, subm = items[i]
             refs = getattr(subm, 'referenced_submodules', None)
             if refs:
                 current = OrderedDict((ref, referenced_output_features[ref]) for ref in refs)
@@ -90,10 +101,26 @@ class DeepcvModule(torch.nn.Module):
                         del referenced_output_features[ref]   # no remaining referrer: release the stashed tensor
                 x = subm(x, referenced_submodules_out=current)
             else:
-                x = subm(x)
+                fused = None
+                if i + 1 < len(items) and not any(name in r for r in remaining_refs.values()) and not getattr(items[i + 1][1], 'referenced_submodules', None):
+                    fused = self._layer_with_pool(subm, items[i + 1][1], x)
+                if fused is not None:                             # `subm` + the pooling sub-module which follows it, in one go: its output is the pooling's
+                    i += 1
+                    name, x = items[i][0], fused
+                else:
+                    x = subm(x)
             if any(name in r for r in remaining_refs.values()):
                 referenced_output_features[name] = x
+            i += 1
         return x
+
+    @staticmethod
+    def _layer_with_pool(subm, nxt, x):
+        """ Output of the layer `subm` followed by the average pooling `nxt` when the fused training kernels cover the pair (HIP device, training mode,
+        `Conv - act - BatchNorm - GroupNorm` layer, non-overlapping windows), else None.  Same arithmetic, two launches and two activation round trips less. """
+        if nxt is None or not isinstance(subm, deepcv_nn.LayerSequential) or not isinstance(x, torch.Tensor) or not x.is_cuda:
+            return None
+        return subm.forward_with_pool(x, nxt)
 
     def __str__(self) -> str:
         return str(self.describe())

@@ -252,18 +252,42 @@ class LayerSequential(torch.nn.Sequential):
             gn, i = mods[i], i + 1
         return mods[0], act, bn, gn, i
 
+    def _run_fused_layer(self, x: torch.Tensor, plan, pool: int = 0) -> torch.Tensor:
+        conv, act, bn, gn, _ = plan
+        conv._check()
+        code, slope = ops.act_code(act)
+        return ops.conv_norm_layer(x, conv.weight, conv.bias, conv.stride, conv._padding_pair(), conv.dilation, code, slope,
+                                   bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum, bn.eps,
+                                   gn.num_groups if gn is not None else 0, gn.weight if gn is not None else None, gn.bias if gn is not None else None,
+                                   gn.eps if gn is not None else 1e-5, pool=pool)
+
+    def forward_with_pool(self, x, pool: torch.nn.Module) -> Optional[torch.Tensor]:
+        """ This layer followed by the non-overlapping average pooling `pool` (the next sub-module of the architecture, reference
+        `submodule_creators.py:168`) through the fused training kernels: the pooling rides in the normalisation kernels of both directions.
+        None when the pair is not covered (the caller then applies the two modules one after the other). """
+        if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4 and type(pool) is native.AvgPool2d):
+            return None
+        mods = list(self._modules.values())
+        plan = self._fused_layer_plan(mods)
+        if plan is None or plan[3] is None or plan[4] != len(mods):
+            return None
+        try:
+            k, s, p = pool._geom()
+        except NotImplementedError:
+            return None
+        if k[0] != k[1] or tuple(s) != tuple(k) or tuple(p) != (0, 0) or k[0] < 2:
+            return None
+        out_shape = plan[0].out_shape(x.shape)
+        if out_shape[-2] % k[0] or out_shape[-1] % k[0]:
+            return None
+        return self._run_fused_layer(x, plan, pool=k[0])
+
     def _forward_one(self, x: torch.Tensor) -> torch.Tensor:
         mods = list(self._modules.values())
         i, n = 0, len(mods)
         plan = self._fused_layer_plan(mods) if (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4) else None
         if plan is not None:
-            conv, act, bn, gn, i = plan
-            conv._check()
-            code, slope = ops.act_code(act)
-            x = ops.conv_norm_layer(x, conv.weight, conv.bias, conv.stride, conv._padding_pair(), conv.dilation, code, slope,
-                                    bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum, bn.eps,
-                                    gn.num_groups if gn is not None else 0, gn.weight if gn is not None else None, gn.bias if gn is not None else None,
-                                    gn.eps if gn is not None else 1e-5)
+            x, i = self._run_fused_layer(x, plan), plan[4]
         while i < n:
             m = mods[i]
             if isinstance(m, (native.Conv2d, native.Linear)) and i + 1 < n and isinstance(mods[i + 1], native._NativeAct) and not native.in_shape_inference():

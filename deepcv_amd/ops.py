@@ -401,7 +401,7 @@ class _ConvNormLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, bn_w, bn_b, running_mean, running_var, nbt, gn_w, gn_b, cfg):
-        stride, padding, dilation, act, slope, momentum, bn_eps, groups, gn_eps = cfg
+        stride, padding, dilation, act, slope, momentum, bn_eps, groups, gn_eps, pool = cfg
         _require_f32(x, weight, bias, bn_w, bn_b, running_mean, running_var, gn_w, gn_b)
         if _is_nhwc(x):
             layout = nat.LAYOUT_NHWC
@@ -416,17 +416,18 @@ class _ConvNormLayerFn(torch.autograd.Function):
         dev, st = x.device, nat.current_stream(x.device)
         y = torch.empty((d.n, d.cout, d.ho, d.wo), dtype=x.dtype, device=dev, memory_format=_CL)
         stats = _conv_fwd_launch(d, x, weight, bias, y, st, want_stats=True)
-        out = torch.empty_like(y)
+        # `pool` > 0: the layer is followed by a non-overlapping average pooling, applied by the same kernel (only the pooled tensor is written)
+        out = torch.empty_like(y) if not pool else torch.empty((d.n, d.cout, d.ho // pool, d.wo // pool), dtype=x.dtype, device=dev, memory_format=_CL)
         c, hw = d.cout, d.ho * d.wo
         bn_mean = torch.empty(c, dtype=torch.float32, device=dev)
         bn_rstd = torch.empty(c, dtype=torch.float32, device=dev)
         gn_mean = torch.empty(d.n * groups, dtype=torch.float32, device=dev) if groups else None
         gn_rstd = torch.empty(d.n * groups, dtype=torch.float32, device=dev) if groups else None
         ws = _ws(lib.dcv_norm_chain_workspace_bytes(d.n, hw, c), dev)
-        nat.check(lib.dcv_bn_gn_fwd_train(y.data_ptr(), out.data_ptr(), d.n, hw, c, nat.ptr(bn_w), nat.ptr(bn_b), nat.ptr(running_mean), nat.ptr(running_var),
-                                          nat.ptr(nbt), momentum, bn_eps, bn_mean.data_ptr(), bn_rstd.data_ptr(), groups, nat.ptr(gn_w), nat.ptr(gn_b), gn_eps,
-                                          nat.ptr(gn_mean), nat.ptr(gn_rstd), nat.ptr(stats), 0 if stats is None else stats.shape[2],
-                                          ws.data_ptr(), ws.numel(), st), 'dcv_bn_gn_fwd_train')
+        nat.check(lib.dcv_bn_gn_pool_fwd_train(y.data_ptr(), out.data_ptr(), d.n, hw, c, nat.ptr(bn_w), nat.ptr(bn_b), nat.ptr(running_mean), nat.ptr(running_var),
+                                               nat.ptr(nbt), momentum, bn_eps, bn_mean.data_ptr(), bn_rstd.data_ptr(), groups, nat.ptr(gn_w), nat.ptr(gn_b), gn_eps,
+                                               nat.ptr(gn_mean), nat.ptr(gn_rstd), nat.ptr(stats), 0 if stats is None else stats.shape[2],
+                                               d.wo, pool, ws.data_ptr(), ws.numel(), st), 'dcv_bn_gn_pool_fwd_train')
         ctx.desc, ctx.cfg = d, cfg
         ctx.save_for_backward(x, weight, bias, y, bn_w, bn_b, bn_mean, bn_rstd, gn_w, gn_mean, gn_rstd)
         return out
@@ -435,7 +436,7 @@ class _ConvNormLayerFn(torch.autograd.Function):
     def backward(ctx, dout):
         x, weight, bias, y, bn_w, bn_b, bn_mean, bn_rstd, gn_w, gn_mean, gn_rstd = ctx.saved_tensors
         d = ctx.desc
-        stride, padding, dilation, act, slope, momentum, bn_eps, groups, gn_eps = ctx.cfg
+        stride, padding, dilation, act, slope, momentum, bn_eps, groups, gn_eps, pool = ctx.cfg
         dev, st = dout.device, nat.current_stream(dout.device)
         dout = to_nhwc(dout)
         c, hw = d.cout, d.ho * d.wo
@@ -449,10 +450,10 @@ class _ConvNormLayerFn(torch.autograd.Function):
         d_gn_b = new() if (groups and need[9]) else None
         dz = torch.empty_like(y)
         ws = _ws(lib.dcv_norm_chain_workspace_bytes(d.n, hw, c), dev)
-        nat.check(lib.dcv_bn_gn_act_bwd(dout.data_ptr(), y.data_ptr(), dz.data_ptr(), d.n, hw, c, nat.ptr(bn_w), nat.ptr(bn_b), bn_mean.data_ptr(), bn_rstd.data_ptr(),
-                                        groups, nat.ptr(gn_w), nat.ptr(gn_mean), nat.ptr(gn_rstd), act, slope,
-                                        nat.ptr(d_bn_w), nat.ptr(d_bn_b), nat.ptr(d_gn_w), nat.ptr(d_gn_b), None if db_from_wgrad else nat.ptr(db),
-                                        ws.data_ptr(), ws.numel(), st), 'dcv_bn_gn_act_bwd')
+        nat.check(lib.dcv_bn_gn_pool_act_bwd(dout.data_ptr(), y.data_ptr(), dz.data_ptr(), d.n, hw, c, nat.ptr(bn_w), nat.ptr(bn_b), bn_mean.data_ptr(), bn_rstd.data_ptr(),
+                                             groups, nat.ptr(gn_w), nat.ptr(gn_mean), nat.ptr(gn_rstd), act, slope,
+                                             nat.ptr(d_bn_w), nat.ptr(d_bn_b), nat.ptr(d_gn_w), nat.ptr(d_gn_b), None if db_from_wgrad else nat.ptr(db),
+                                             d.wo, pool, ws.data_ptr(), ws.numel(), st), 'dcv_bn_gn_pool_act_bwd')
         dx = dw = None
         if need[0]:
             dd = nat.Conv2dDesc.from_buffer_copy(d)
@@ -466,9 +467,13 @@ class _ConvNormLayerFn(torch.autograd.Function):
 
 
 def conv_norm_layer(x, weight, bias, stride, padding, dilation, act: int, slope: float, bn_w, bn_b, running_mean, running_var, num_batches_tracked,
-                    momentum: float, bn_eps: float, gn_groups: int = 0, gn_w=None, gn_b=None, gn_eps: float = 1e-5) -> torch.Tensor:
-    """ Training-mode `GroupNorm?(BatchNorm(act(conv2d(x))))` with batch statistics and running-stat update, fused (see `_ConvNormLayerFn`). """
-    cfg = (_pair(stride), _pair(padding), _pair(dilation), int(act), float(slope), float(momentum), float(bn_eps), int(gn_groups), float(gn_eps))
+                    momentum: float, bn_eps: float, gn_groups: int = 0, gn_w=None, gn_b=None, gn_eps: float = 1e-5, pool: int = 0) -> torch.Tensor:
+    """ Training-mode `GroupNorm?(BatchNorm(act(conv2d(x))))` with batch statistics and running-stat update, fused (see `_ConvNormLayerFn`).
+    `pool` > 0 appends `avg_pool2d(kernel_size=pool, stride=pool)` (output sizes must be multiples of `pool`): same kernels, the unpooled output is
+    never written. """
+    if pool and (not gn_groups or pool < 0):
+        raise ValueError('deepcv_amd.conv_norm_layer: fused average pooling needs the GroupNorm stage')
+    cfg = (_pair(stride), _pair(padding), _pair(dilation), int(act), float(slope), float(momentum), float(bn_eps), int(gn_groups), float(gn_eps), int(pool))
     return _ConvNormLayerFn.apply(x, weight, bias, bn_w, bn_b, running_mean, running_var, num_batches_tracked, gn_w, gn_b, cfg)
 
 

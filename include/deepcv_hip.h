@@ -224,6 +224,22 @@ int dcv_bn_gn_act_bwd(const float* dout, const float* x, float* dz, int n, int h
                       float* d_bn_gamma, float* d_bn_beta, float* d_gn_gamma, float* d_gn_beta, float* d_bias /* all nullable */,
                       void* ws, size_t ws_bytes, void* stream);
 
+/* The same chain followed by a non-overlapping average pooling (pool x pool windows, stride pool, no padding; torch.nn.AvgPool2d at submodule_creators.py:168
+ * right after the layer, as in the reference's stock architecture): y / dout are the POOLED tensors [N][H/pool][W/pool][C]; the chain's full-size output is
+ * never written, and the pooling launches of both directions disappear.  groups > 0 required when pool > 0; width = W of x (hw = H * W); pool == 0 is the
+ * plain chain. */
+int dcv_bn_gn_pool_fwd_train(const float* x, float* y, int n, int hw, int channels,
+                             const float* bn_gamma, const float* bn_beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                             float momentum, float bn_eps, float* bn_save_mean, float* bn_save_rstd,
+                             int groups, const float* gn_gamma, const float* gn_beta, float gn_eps, float* gn_save_mean, float* gn_save_rstd,
+                             const double* stats, int stats_rows, int width, int pool, void* ws, size_t ws_bytes, void* stream);
+int dcv_bn_gn_pool_act_bwd(const float* dout, const float* x, float* dz, int n, int hw, int channels,
+                           const float* bn_gamma, const float* bn_beta, const float* bn_save_mean, const float* bn_save_rstd,
+                           int groups, const float* gn_gamma, const float* gn_save_mean, const float* gn_save_rstd,
+                           int act, float act_slope,
+                           float* d_bn_gamma, float* d_bn_beta, float* d_gn_gamma, float* d_gn_beta, float* d_bias /* all nullable */,
+                           int width, int pool, void* ws, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * K7 / K7'  2-D average / max pooling, NHWC
  * replaces torch.nn.AvgPool2d (submodule_creators.py:168 -> nn.py:416) and torch.nn.MaxPool2d (nn_spec.py:158-169)

@@ -658,3 +658,75 @@ def test_deferred_weight_gradient_sums(device):
     loss.backward()
     h.remove()
     assert seen and seen[0] > 0 and slabs.pending() == 0
+
+
+@pytest.mark.parametrize('case', [(8, 4, 32, 32, 4, 5, 2, 2, 1), (4, 8, 16, 16, 16, 3, 1, 4, 2), (2, 4, 64, 64, 8, 3, 1, 2, 2), (3, 3, 12, 12, 6, 3, 1, 3, 4), (2, 4, 16, 24, 4, 3, 1, 1, 2)],
+                         ids=str)
+def test_conv_norm_layer_with_fused_average_pooling(device, case):
+    """ `conv_norm_layer(..., pool=k)` (pooling inside the normalisation kernels, `dcv_bn_gn_pool_*`) against the same layer followed by the standalone
+    pooling op: outputs and every gradient (cached and streaming variants of the kernels, vector and scalar channel counts, pool 2 and 4). """
+    from deepcv_amd import ops, _native as nat
+    n, cin, h, w, cout, k, pad, groups, act = case
+    pool = 4 if (h % 4 == 0 and w % 4 == 0 and cout == 6) else 2
+    torch.manual_seed(sum(case))
+    x0 = _cl(torch.randn(n, cin, h, w, device=device))
+    prm = dict(w=torch.randn(cout, cin, k, k, device=device) * 0.2, b=torch.randn(cout, device=device) * 0.1, bw=torch.rand(cout, device=device) + 0.5,
+               bb=torch.randn(cout, device=device) * 0.1, gw=torch.rand(cout, device=device) + 0.5, gb=torch.randn(cout, device=device) * 0.1)
+    g_out = None
+    results = []
+    for fused in (False, True):
+        x = x0.clone().requires_grad_(True)
+        p = {name: t.clone().requires_grad_(True) for name, t in prm.items()}
+        rm, rv, nbt = torch.zeros(cout, device=device), torch.ones(cout, device=device), torch.zeros(1, dtype=torch.int64, device=device)
+        args = (x, p['w'], p['b'], 1, pad, 1, act, 0.1, p['bw'], p['bb'], rm, rv, nbt, 0.1, 1e-5, groups, p['gw'], p['gb'], 1e-5)
+        if fused:
+            out = ops.conv_norm_layer(*args, pool=pool)
+        else:
+            out = ops.pool2d(ops.conv_norm_layer(*args), pool, pool, 0, nat.POOL_AVG)
+        if g_out is None:
+            g_out = torch.randn_like(out)
+        out.backward(g_out)
+        torch.cuda.synchronize()
+        results.append((out.detach(), x.grad, {name: t.grad for name, t in p.items()}, rm, rv))
+    (o0, dx0, g0, rm0, rv0), (o1, dx1, g1, rm1, rv1) = results
+    assert o1.shape == (n, cout, h // pool, w // pool)
+    _check(f'layer+pool{case} out', o1, o0, 1e-5)
+    _check(f'layer+pool{case} dx', dx1, dx0, 2e-4)
+    for name in g0:
+        _check(f'layer+pool{case} d{name}', g1[name], g0[name], 3e-4)
+    assert torch.equal(rm0, rm1) and torch.equal(rv0, rv1)
+
+
+def test_model_fuses_layer_and_pooling(device):
+    """ `DeepcvModule.forward` hands a layer followed by an `AvgPool2d` sub-module to the fused kernels (stock architecture: two such pairs), referenced
+    pooled outputs (`_from` links) keep working, and the result matches the unfused module sequence. """
+    from deepcv_amd import modules
+    from deepcv_amd.classification.image import create_model
+    from deepcv_amd.meta import base_module
+    from deepcv_amd.meta.data.datasets import SyntheticImageDataset
+    from deepcv_amd.utils import load_parameters
+    params = load_parameters()
+    torch.manual_seed(3)
+    model = create_model({'trainset': SyntheticImageDataset(2, (3, 32, 32), 10)}, params['image_classifier_model']).to(device).train()
+    x = torch.randn(16, 3, 32, 32, device=device)
+    calls = []
+    orig = base_module.DeepcvModule._layer_with_pool
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+
+    def spy(subm, nxt, xx):
+        r = orig(subm, nxt, xx)
+        calls.append(r is not None)
+        return r
+    base_module.DeepcvModule._layer_with_pool = staticmethod(spy)
+    try:
+        fused = model(x)
+    finally:
+        base_module.DeepcvModule._layer_with_pool = orig
+    assert sum(calls) == 2, calls
+    model.load_state_dict(state)                                   # running statistics back to where they were
+    base_module.DeepcvModule._layer_with_pool = staticmethod(lambda subm, nxt, xx: None)
+    try:
+        plain = model(x)
+    finally:
+        base_module.DeepcvModule._layer_with_pool = orig
+    _check('model fused pooling', fused, plain, 1e-5)
