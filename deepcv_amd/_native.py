@@ -43,7 +43,8 @@ class Conv2dDesc(ctypes.Structure):
 
 class SlabSegment(ctypes.Structure):
     """ `dcv_slab_segment` """
-    _fields_ = [('src', _c_void_p), ('dst', _c_void_p), ('count', ctypes.c_ulonglong), ('stride', ctypes.c_ulonglong), ('chunks', _c_int), ('reserved', _c_int)]
+    _fields_ = [('src', _c_void_p), ('dst', _c_void_p), ('count', ctypes.c_ulonglong), ('stride', ctypes.c_ulonglong), ('chunks', _c_int),
+                ('tr_a', _c_int), ('tr_b', _c_int), ('reserved', _c_int)]
 
 
 class WgradJob(ctypes.Structure):

@@ -25,7 +25,22 @@ __global__ __launch_bounds__(256) void prep_multi_kernel(dcv_prep_list l) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < e.total; i += gridDim.x * blockDim.x) e.dst[i] = dcv_prep_element(e, i);
 }
 
+// op 2: the weight [O][C * H * W] of a Linear which follows a Flatten of [N][C][H][W] activations, re-laid as [O][H * W][C] so that the Linear reads the
+// NHWC activations in place (no NHWC -> NCHW transposition of the batch in either direction).  Descriptor: h, w, cin of the activations, cout = O,
+// r = h, s = w, no padding (the Linear seen as a full-image convolution); same element mapping as the MFMA kernels' K-major filter rows.
+inline bool linear_desc(const dcv_conv2d_desc* d) {
+    return d->r == d->h && d->s == d->w && d->pad_h == 0 && d->pad_w == 0 && d->stride_h == 1 && d->stride_w == 1 && d->dil_h == 1 && d->dil_w == 1;
+}
+
 inline int prep_entries(const dcv_conv2d_desc* d, int op, dcv_prep_entry* out) {
+    if (op == 2) {
+        if (!linear_desc(d)) return 0;
+        dcv_prep_entry e{};
+        e.kind = 1; e.kcout = d->cout; e.kcin = d->cin; e.R = d->r; e.S = d->s; e.w_cin = d->cin; e.dgrad = 0;
+        e.dst_off = 0; e.total = d->cout * d->cin * d->r * d->s;
+        out[0] = e;
+        return 1;
+    }
     if (op == 1 && d->x_layout != DCV_LAYOUT_NHWC) return 0;
     return dcv_mfma_conv2d_supported(d, op) ? dcv_mfma_conv2d_prep_entries(d, op, out) : dcv_direct_conv2d_prep_entries(d, op, out);
 }
@@ -68,9 +83,10 @@ int dcv_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, 
 }
 
 size_t dcv_conv2d_filter_bytes(const dcv_conv2d_desc* d, int op) {
-    if (!desc_ok(d) || d->groups != 1 || (op != 0 && op != 1)) return 0;
+    if (!desc_ok(d) || d->groups != 1 || (op != 0 && op != 1 && op != 2)) return 0;
     dcv_prep_entry e[DCV_PREP_PIECES];
     if (prep_entries(d, op, e) == 0) return 0;
+    if (op == 2) return dcv_align_up((size_t)e[0].total * sizeof(float), 256);
     return op == 0 ? dcv_conv2d_fwd_workspace_bytes(d) : dcv_conv2d_dgrad_workspace_bytes(d);
 }
 
@@ -85,7 +101,7 @@ int dcv_conv2d_prepare_filters(int count, const dcv_conv2d_desc* const* descs, c
         l.count = 0; max_total = 0;
     };
     for (int k = 0; k < count; ++k) {
-        DCV_CHECK_ARG(desc_ok(descs[k]) && w[k] && (ops[k] == 0 || ops[k] == 1));
+        DCV_CHECK_ARG(desc_ok(descs[k]) && w[k] && (ops[k] == 0 || ops[k] == 1 || ops[k] == 2));
         dcv_prep_entry pieces[DCV_PREP_PIECES];
         const int np = prep_entries(descs[k], ops[k], pieces);
         if (np == 0) continue;                                    // this (layer, op) reads the OIHW filter directly

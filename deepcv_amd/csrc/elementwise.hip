@@ -366,7 +366,13 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel(SlabTable t) {
         float v = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) v += red[k][threadIdx.x];
-        g.dst[wi] = v;
+        size_t di = wi;
+        if (g.tr_a > 0) {                                                                // [o][tr_a][tr_b] -> [o][tr_b][tr_a]
+            const size_t ab = (size_t)g.tr_a * g.tr_b, o = wi / ab, rem = wi - o * ab;
+            const size_t pp = rem / g.tr_b, c = rem - pp * g.tr_b;
+            di = o * ab + c * g.tr_a + pp;
+        }
+        g.dst[di] = v;
     }
 }
 
@@ -379,6 +385,7 @@ int dcv_launch_slab_reduce(int n, const dcv_slab_segment* segments, hipStream_t 
         for (int i = i0; i < n && i < i0 + DCV_MAX_SLAB_SEGMENTS; ++i) {
             const dcv_slab_segment& g = segments[i];
             if (!g.src || !g.dst || g.chunks < 1 || g.stride < g.count) return DCV_ERR_INVALID_ARG;
+            if (g.tr_a < 0 || g.tr_b < 0 || ((g.tr_a > 0) != (g.tr_b > 0)) || (g.tr_a > 0 && g.count % ((unsigned long long)g.tr_a * g.tr_b) != 0)) return DCV_ERR_INVALID_ARG;
             if (g.count == 0) continue;
             t.block_start[t.count] = blocks;
             t.seg[t.count++] = g;

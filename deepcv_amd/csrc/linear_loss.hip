@@ -455,8 +455,8 @@ static int linear_bwd_impl(const float* dy, const float* y, int act, float slope
         }
         const size_t ok = (size_t)O * K;
         dcv_slab_segment seg[2]; int ns = 0;
-        if (dw) seg[ns++] = dcv_slab_segment{partial, dw, ok, ok, chunks, 0};
-        if (db) seg[ns++] = dcv_slab_segment{partial_b, db, (unsigned long long)O, (unsigned long long)O, chunks, 0};
+        if (dw) seg[ns++] = dcv_slab_segment{partial, dw, ok, ok, chunks, 0, 0, 0};
+        if (db) seg[ns++] = dcv_slab_segment{partial_b, db, (unsigned long long)O, (unsigned long long)O, chunks, 0, 0, 0};
         if (defer) { for (int i = 0; i < ns; ++i) defer[i] = seg[i]; *ndefer = ns; }
         else return dcv_launch_slab_reduce(ns, seg, st);
     }

@@ -78,7 +78,7 @@ class DeepcvModule(torch.nn.Module):
             children = list(self._child_modules.children())
             i = 0
             while i < len(children):
-                fused = self._layer_with_pool(children[i], children[i + 1] if i + 1 < len(children) else None, x)
+                fused = self._fused_pair(children[i], children[i + 1] if i + 1 < len(children) else None, x)
                 if fused is not None:
                     x, i = fused, i + 2
                 else:
@@ -103,8 +103,8 @@ class DeepcvModule(torch.nn.Module):
             else:
                 fused = None
                 if i + 1 < len(items) and not any(name in r for r in remaining_refs.values()) and not getattr(items[i + 1][1], 'referenced_submodules', None):
-                    fused = self._layer_with_pool(subm, items[i + 1][1], x)
-                if fused is not None:                             # `subm` + the pooling sub-module which follows it, in one go: its output is the pooling's
+                    fused = self._fused_pair(subm, items[i + 1][1], x)
+                if fused is not None:                             # `subm` + the sub-module which follows it, in one go: its output is the second one's
                     i += 1
                     name, x = items[i][0], fused
                 else:
@@ -113,6 +113,17 @@ class DeepcvModule(torch.nn.Module):
                 referenced_output_features[name] = x
             i += 1
         return x
+
+    @staticmethod
+    def _fused_pair(subm, nxt, x):
+        """ Output of `nxt(subm(x))` through one fused path when the pair is `layer - AvgPool2d` or `Flatten - fully connected layer` on a HIP device
+        (same arithmetic, fewer launches and activation round trips), else None. """
+        if nxt is None or not isinstance(x, torch.Tensor) or not x.is_cuda:
+            return None
+        fused = DeepcvModule._layer_with_pool(subm, nxt, x)
+        if fused is None and isinstance(nxt, deepcv_nn.LayerSequential):
+            fused = nxt.forward_after_flatten(x, subm)
+        return fused
 
     @staticmethod
     def _layer_with_pool(subm, nxt, x):

@@ -282,6 +282,25 @@ class LayerSequential(torch.nn.Sequential):
             return None
         return self._run_fused_layer(x, plan, pool=k[0])
 
+    def forward_after_flatten(self, x, flatten: torch.nn.Module) -> Optional[torch.Tensor]:
+        """ `self(flatten(x))` for a `Flatten` sub-module followed by this fully connected layer (reference `parameters.yml:87-88`): the `Linear` reads the
+        NHWC activations in place through a re-laid copy of its weight instead of a transposed copy of the batch.  None when not covered. """
+        mods = list(self._modules.values())
+        if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4 and type(flatten) is native.Flatten and flatten.start_dim == 1
+                and flatten.end_dim in (-1, 3) and mods and type(mods[0]) is native.Linear and not native.in_shape_inference()):
+            return None
+        lin = mods[0]
+        if lin.in_features != x.shape[1] * x.shape[2] * x.shape[3] or not (lin.weight.is_cuda and lin.weight.is_contiguous()):
+            return None
+        i = 1
+        if len(mods) > 1 and isinstance(mods[1], native._NativeAct):
+            x, i = lin.forward_flattened(x, fused_act=ops.act_code(mods[1])), 2
+        else:
+            x = lin.forward_flattened(x)
+        for m in mods[i:]:
+            x = m(x)
+        return x
+
     def _forward_one(self, x: torch.Tensor) -> torch.Tensor:
         mods = list(self._modules.values())
         i, n = 0, len(mods)

@@ -89,6 +89,10 @@ class Linear(torch.nn.Linear):
         y = ops.linear(x, self.weight, self.bias, fused_act[0], fused_act[1])
         return y if len(lead) == 1 else y.reshape(*lead, self.out_features)
 
+    def forward_flattened(self, x: torch.Tensor, fused_act: Tuple[int, float] = (nat.ACT_NONE, 0.)) -> torch.Tensor:
+        """ `self(torch.flatten(x, 1))` for 4-D activations, without materialising the flattened (C-major) copy: `ops.linear_nhwc`. """
+        return ops.linear_nhwc(x, self.weight, self.bias, fused_act[0], fused_act[1])
+
 
 class _NativeBatchNorm(torch.nn.modules.batchnorm._BatchNorm):
     def forward(self, x: torch.Tensor) -> torch.Tensor:

@@ -15,7 +15,7 @@ from . import slabs
 from ._native import lib
 
 __all__ = ['conv2d', 'set_conv_math', 'conv_norm_layer', 'activation', 'batch_norm', 'sync_batch_norm', 'group_norm', 'pool2d', 'interpolate_bilinear', 'concat_channels', 'add_tensors', 'flatten_nchw_order',
-           'linear', 'cross_entropy', 'act_code', 'to_nhwc', 'nchw_to_nhwc']
+           'linear', 'linear_nhwc', 'cross_entropy', 'act_code', 'to_nhwc', 'nchw_to_nhwc']
 
 _CL = torch.channels_last
 
@@ -705,6 +705,63 @@ class _LinearFn(torch.autograd.Function):
             nat.check(lib.dcv_linear_bwd(dy.data_ptr(), nat.ptr(y), ctx.act, ctx.slope, x.data_ptr(), weight.data_ptr(), nat.ptr(dx), nat.ptr(dw), nat.ptr(db),
                                          n, k, o, ws.data_ptr(), ws.numel(), st), 'dcv_linear_bwd')
         return dx, dw, db, None, None
+
+
+class _LinearNhwcFn(torch.autograd.Function):
+    """ `linear(flatten(x), weight, bias)` for 4-D activations (NHWC in memory) WITHOUT transposing them to the reference's C-major feature order: the
+    weight is re-laid as [O][H*W][C] instead (51 KB against 2.6 MB on the stock head; kept in the prepared-filter cache, refreshed by the optimizer's one
+    launch), the data gradient comes out NHWC, and the weight gradient is written back in [O][C*H*W] order by the ordered slab sum. """
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, slope):
+        _require_f32(x, weight, bias)
+        n, c, h, w = x.shape
+        k, o = c * h * w, weight.shape[0]
+        d = _conv_desc(x.shape, (o, c, h, w), (1, 1), (0, 0), (1, 1), nat.LAYOUT_NHWC, nat.ACT_NONE, 0.)
+        wp = filters.get(weight, d, 2)
+        if wp is None:
+            raise RuntimeError('deepcv_amd.linear_nhwc: the weight must be a contiguous device tensor')
+        ctx.weight_ref, ctx.bias_ref = weight, bias
+        slabs.note_use(weight if ctx.needs_input_grad[1] else None, bias if ctx.needs_input_grad[2] else None)
+        y = torch.empty((n, o), dtype=x.dtype, device=x.device)
+        nat.check(lib.dcv_linear_fwd(x.data_ptr(), wp.data_ptr(), nat.ptr(bias), y.data_ptr(), n, k, o, act, slope, nat.current_stream(x.device)), 'dcv_linear_fwd')
+        ctx.act, ctx.slope, ctx.has_bias, ctx.desc = act, slope, bias is not None, d
+        ctx.save_for_backward(x, weight, y if act != nat.ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        n, c, h, w = x.shape
+        k, o = c * h * w, weight.shape[0]
+        dev, st = dy.device, nat.current_stream(dy.device)
+        dy = dy.contiguous()
+        wp = filters.get(weight, ctx.desc, 2)
+        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None            # channels_last like x: the gradient of the NHWC activations, in place
+        dw = torch.empty_like(weight) if need_w else None
+        db = torch.empty(o, dtype=dy.dtype, device=dev) if (need_w and ctx.has_bias) else None
+        ws = _ws(lib.dcv_linear_bwd_workspace_bytes(n, k, o), dev)
+        if need_w and slabs.may_defer(ctx.weight_ref, ctx.bias_ref):
+            segs, ns = (nat.SlabSegment * 2)(), ctypes.c_int(0)
+            nat.check(lib.dcv_linear_bwd_deferred(dy.data_ptr(), nat.ptr(y), ctx.act, ctx.slope, x.data_ptr(), wp.data_ptr(), nat.ptr(dx), nat.ptr(dw), nat.ptr(db),
+                                                  n, k, o, ws.data_ptr(), ws.numel(), segs, ctypes.byref(ns), st), 'dcv_linear_bwd_deferred')
+            segs[0].tr_a, segs[0].tr_b = h * w, c                                  # [O][H*W][C] sums -> dw [O][C][H*W]
+            slabs.defer(dev, st, segs, ns.value, ws)
+        else:
+            dwp = torch.empty_like(weight) if need_w else None
+            nat.check(lib.dcv_linear_bwd(dy.data_ptr(), nat.ptr(y), ctx.act, ctx.slope, x.data_ptr(), wp.data_ptr(), nat.ptr(dx), nat.ptr(dwp), nat.ptr(db),
+                                         n, k, o, ws.data_ptr(), ws.numel(), st), 'dcv_linear_bwd')
+            if need_w:
+                nat.check(lib.dcv_transpose_inner(dwp.data_ptr(), dw.data_ptr(), o, h * w, c, st), 'dcv_transpose_inner')
+        return dx, dw, db, None, None
+
+
+def linear_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = nat.ACT_NONE, slope: float = 0.) -> torch.Tensor:
+    """ `linear(torch.flatten(x, 1), weight, bias)` for `[N,C,H,W]` activations with channels_last strides (see `_LinearNhwcFn`). """
+    if x.dim() != 4 or weight.shape[1] != x.shape[1] * x.shape[2] * x.shape[3]:
+        raise ValueError(f'deepcv_amd.linear_nhwc: weight {tuple(weight.shape)} does not match activations {tuple(x.shape)}')
+    return _LinearNhwcFn.apply(to_nhwc(x), weight, bias, act, slope)
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = nat.ACT_NONE, slope: float = 0.) -> torch.Tensor:

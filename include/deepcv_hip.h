@@ -98,6 +98,8 @@ typedef struct dcv_slab_segment {
     unsigned long long count;      /* entries of dst */
     unsigned long long stride;     /* entries between consecutive slabs of src */
     int chunks;                    /* slabs */
+    int tr_a, tr_b;                /* 0, 0: dst[i] = sum.  Else the sums are [..][tr_a][tr_b] matrices written transposed: element ((o * tr_a + p) * tr_b + c) goes to
+                                    * dst[(o * tr_b + c) * tr_a + p] (weight gradient of a Linear fed with NHWC-flattened activations, see dcv_linear_bwd_deferred) */
     int reserved;
 } dcv_slab_segment;
 #define DCV_MAX_SLAB_SEGMENTS 32   /* per launch; dcv_slab_reduce splits longer lists */
@@ -125,7 +127,11 @@ int dcv_conv2d_wgrad_fuses_bias(const dcv_conv2d_desc* d);
  * direct kernels, K-contiguous rows for the MFMA kernels); dcv_conv2d_fwd / dcv_conv2d_dgrad do that re-layout on every call.  A training loop whose
  * weights change once per optimisation step keeps the re-laid filters instead and refreshes ALL of them with one launch after the optimizer step
  * (the reference re-reads `Conv2d.weight` on every forward, submodule_creators.py:251; here that read is paid once per step).
- *   dcv_conv2d_filter_bytes     size of the prepared filter of (d, op), op 0 = forward, 1 = data gradient; 0 when that kernel reads OIHW directly
+ *   dcv_conv2d_filter_bytes     size of the prepared filter of (d, op), op 0 = forward, 1 = data gradient; 0 when that kernel reads OIHW directly.
+ *                               op 2 = the weight [O][C*H*W] of a Linear behind Flatten (classification head, submodule_creators.py:268-269 after
+ *                               parameters.yml:87) re-laid as [O][H*W][C]: the dcv_linear_* entry points then read the NHWC activations in place instead
+ *                               of a transposed copy (descriptor: h, w, cin of the activations, cout = O, r = h, s = w, stride 1, no padding; the weight
+ *                               gradient comes back in [O][C*H*W] order through dcv_slab_segment.tr_a / tr_b)
  *   dcv_conv2d_prepare_filters  re-lays out `count` filters (entries whose size is 0 are skipped; filters[k] may then be NULL)
  *   dcv_conv2d_*_prepared       as dcv_conv2d_fwd / dcv_conv2d_dgrad with the filter prepared for exactly this descriptor (w still required: fallback paths) */
 size_t dcv_conv2d_filter_bytes(const dcv_conv2d_desc* d, int op);

@@ -730,3 +730,44 @@ def test_model_fuses_layer_and_pooling(device):
     finally:
         base_module.DeepcvModule._layer_with_pool = orig
     _check('model fused pooling', fused, plain, 1e-5)
+
+
+@pytest.mark.parametrize('shape,o,act', [((8, 20, 8, 8), 10, 3), ((3, 6, 5, 7), 4, 0), ((16, 4, 4, 4), 33, 1)], ids=str)
+def test_linear_on_nhwc_activations(device, shape, o, act):
+    """ `ops.linear_nhwc` (weight re-laid as [O][H*W][C], activations read in place, weight gradient transposed back by the slab sum) against
+    `linear(flatten_nchw_order(x))`; deferred and immediate weight-gradient sums; the prepared weight follows the optimizer. """
+    from deepcv_amd import ops, optim, slabs
+    torch.manual_seed(o)
+    n, c, h, w = shape
+    x0 = _cl(torch.randn(*shape, device=device))
+    w0 = torch.randn(o, c * h * w, device=device) * 0.05
+    b0 = torch.randn(o, device=device) * 0.1
+    g = torch.randn(n, o, device=device)
+
+    def run(fused, deferred=True):
+        prev = slabs.set_enabled(deferred)
+        try:
+            x = x0.clone().requires_grad_(True)
+            wt, b = torch.nn.Parameter(w0.clone()), torch.nn.Parameter(b0.clone())
+            y = ops.linear_nhwc(x, wt, b, act, 0.1) if fused else ops.linear(ops.flatten_nchw_order(x), wt, b, act, 0.1)
+            y.backward(g)
+            torch.cuda.synchronize()
+            return y.detach(), x.grad, wt.grad, b.grad, wt, b
+        finally:
+            slabs.set_enabled(prev)
+
+    ref = run(False)
+    for deferred in (True, False):
+        got = run(True, deferred)
+        for name, a, r, tol in zip(('y', 'dx', 'dw', 'db'), got[:4], ref[:4], (1e-5, 1e-4, 2e-4, 2e-4)):
+            _check(f'linear_nhwc{shape} deferred={deferred} {name}', a, r, tol)
+    assert got[1].is_contiguous(memory_format=torch.channels_last)
+    # the re-laid weight is refreshed by the native optimizer's step
+    wt, b = got[4], got[5]
+    opt = optim.SGD([wt, b], lr=0.5)
+    opt.step()
+    y2 = ops.linear_nhwc(x0, wt, b, act, 0.1)
+    _check(f'linear_nhwc{shape} after optimizer step', y2, ops.linear(ops.flatten_nchw_order(x0), wt, b, act, 0.1), 1e-5)
+    with torch.no_grad():
+        wt.mul_(0.5)                                               # in-place torch op: detected through Tensor._version
+    _check(f'linear_nhwc{shape} after in-place update', ops.linear_nhwc(x0, wt, b, act, 0.1), ops.linear(ops.flatten_nchw_order(x0), wt, b, act, 0.1), 1e-5)
