@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void linear_fwd_row_kernel(const float* __rest
 // Small batches of few classes (N <= 1024, C <= 16: the stock classifier's 512 x 10 logits): the whole loss in ONE launch of one block, a thread per
 // sample (its logits in registers: one global round trip), fixed-order block sum in fp64.
 __global__ __launch_bounds__(1024) void ce_fwd_single_kernel(const float* __restrict__ z, const int64_t* __restrict__ target, float* __restrict__ lse_out,
-                                                              float* __restrict__ loss, int32_t* __restrict__ correct, int N, int C) {
+                                                              float* __restrict__ loss, int32_t* __restrict__ correct, float* __restrict__ dz_unit, int N, int C) {
     constexpr int CMAX = 16;
     __shared__ double wl[16];
     __shared__ int wc[16];
@@ -262,6 +262,11 @@ __global__ __launch_bounds__(1024) void ce_fwd_single_kernel(const float* __rest
         for (int c = 0; c < CMAX; ++c) if (c < C) { sexp += expf(v[c] - m); if ((int64_t)c == t) zt = v[c]; }
         const float lse = m + logf(sexp);
         lse_out[n] = lse;
+        if (dz_unit != nullptr) {                                        // d loss / d logits for an upstream gradient of 1 (same expression as ce_bwd_kernel)
+            const float g = 1.f / (float)N;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) if (c < C) dz_unit[(size_t)n * C + c] = (expf(v[c] - lse) - ((int64_t)c == t ? 1.f : 0.f)) * g;
+        }
         l = (double)(lse - zt);
         ok = (mi == (int)t) ? 1 : 0;
     }
@@ -401,13 +406,20 @@ size_t dcv_cross_entropy_workspace_bytes(int n) {
 
 int dcv_cross_entropy_fwd(const float* logits, const int64_t* target, float* loss, float* lse, int32_t* correct, int n, int classes,
                           void* ws, size_t ws_bytes, void* stream) {
-    DCV_CHECK_ARG(logits && target && loss && lse && n > 0 && classes > 0);
+    return dcv_cross_entropy_fwd_grad(logits, target, loss, lse, correct, nullptr, nullptr, n, classes, ws, ws_bytes, stream);
+}
+
+int dcv_cross_entropy_fwd_grad(const float* logits, const int64_t* target, float* loss, float* lse, int32_t* correct, float* dlogits_unit, int* produced,
+                               int n, int classes, void* ws, size_t ws_bytes, void* stream) {
+    DCV_CHECK_ARG(logits && target && loss && lse && n > 0 && classes > 0 && (dlogits_unit == nullptr || produced != nullptr));
+    if (produced) *produced = 0;
     if (!ws || ws_bytes < dcv_cross_entropy_workspace_bytes(n)) return DCV_ERR_WORKSPACE;
     hipStream_t st = dcv_stream(stream);
     double* part_loss = reinterpret_cast<double*>(ws);
     int* part_correct = reinterpret_cast<int*>(part_loss + CE_MAX_BLOCKS);
     if (n <= 1024 && classes <= 16) {
-        hipLaunchKernelGGL(ce_fwd_single_kernel, dim3(1), dim3((unsigned)dcv_align_up(n, 64)), 0, st, logits, target, lse, loss, correct, n, classes);
+        hipLaunchKernelGGL(ce_fwd_single_kernel, dim3(1), dim3((unsigned)dcv_align_up(n, 64)), 0, st, logits, target, lse, loss, correct, dlogits_unit, n, classes);
+        if (produced && dlogits_unit) *produced = 1;
         DCV_RETURN_LAUNCH();
     }
     unsigned nb = (unsigned)dcv_ceil_div(n, CE_THREADS / 64);

@@ -278,6 +278,8 @@ class GraphedTrainStep:
         if self.reducer is not None:
             hooks_were, self.reducer.enabled = self.reducer.enabled, False     # no collectives inside the captured backward
         self._seed = torch.ones((), dtype=torch.float32, device=dev)
+        from .. import ops as _ops
+        _ops.register_unit_gradient(self._seed)                    # loss ops may return the gradient their forward launch already computed
         torch.cuda.synchronize(dev)
         self.graph_fb = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_fb, stream=self.stream):

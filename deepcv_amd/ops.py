@@ -5,6 +5,7 @@ arithmetic op of the hot path — K1..K11 of SURVEY.md §2.3 — runs in a hand-
 with logical NCHW shape (what the reference's modules expose, `src/deepcv/meta/base_module.py:80`) and `torch.channels_last`
 strides, i.e. NHWC in memory, which is the layout the kernels are written for.  There is no CPU / eager fallback. """
 import ctypes
+import weakref
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -772,6 +773,21 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
 
 # ------------------------------------------------------------------------------------------------ softmax cross-entropy
 
+_unit_seeds: List['weakref.ref'] = []
+
+
+def register_unit_gradient(seed: torch.Tensor):
+    """ Declares `seed` (a scalar device tensor holding 1.0, never modified) as the root gradient training loops pass to `loss.backward(gradient=seed)`.
+    A loss op whose backward receives exactly this tensor knows the upstream gradient is 1 without reading it, and returns the gradient it already
+    computed during its forward launch (`dcv_cross_entropy_fwd_grad`) instead of launching a backward kernel. """
+    _unit_seeds[:] = [r for r in _unit_seeds if r() is not None]
+    _unit_seeds.append(weakref.ref(seed))
+
+
+def _is_unit_gradient(t: torch.Tensor) -> bool:
+    return any(r() is not None and r() is t for r in _unit_seeds)
+
+
 class _CrossEntropyFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target, correct_out):
@@ -785,8 +801,12 @@ class _CrossEntropyFn(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=dev)
         lse = torch.empty(n, dtype=torch.float32, device=dev)
         ws = _ws(lib.dcv_cross_entropy_workspace_bytes(n), dev)
-        nat.check(lib.dcv_cross_entropy_fwd(logits.data_ptr(), target.data_ptr(), loss.data_ptr(), lse.data_ptr(), nat.ptr(correct_out), n, c,
-                                            ws.data_ptr(), ws.numel(), nat.current_stream(dev)), 'dcv_cross_entropy_fwd')
+        # when a unit root gradient is registered (hipGraph training step) the forward launch also leaves d loss / d logits for an upstream gradient of 1
+        dz_unit = torch.empty_like(logits) if (_unit_seeds and ctx.needs_input_grad[0]) else None
+        produced = ctypes.c_int(0)
+        nat.check(lib.dcv_cross_entropy_fwd_grad(logits.data_ptr(), target.data_ptr(), loss.data_ptr(), lse.data_ptr(), nat.ptr(correct_out), nat.ptr(dz_unit),
+                                                 ctypes.byref(produced), n, c, ws.data_ptr(), ws.numel(), nat.current_stream(dev)), 'dcv_cross_entropy_fwd_grad')
+        ctx.dz_unit = dz_unit if produced.value else None
         ctx.save_for_backward(logits, target, lse)
         return loss
 
@@ -794,6 +814,8 @@ class _CrossEntropyFn(torch.autograd.Function):
     def backward(ctx, dloss):
         logits, target, lse = ctx.saved_tensors
         n, c = logits.shape
+        if ctx.dz_unit is not None and _is_unit_gradient(dloss):
+            return ctx.dz_unit, None, None
         dloss = dloss.contiguous().to(torch.float32)
         dz = torch.empty_like(logits)
         nat.check(lib.dcv_cross_entropy_bwd(logits.data_ptr(), target.data_ptr(), lse.data_ptr(), dloss.data_ptr(), dz.data_ptr(), n, c,

@@ -371,6 +371,11 @@ size_t dcv_cross_entropy_workspace_bytes(int n);
 int dcv_cross_entropy_fwd(const float* logits, const int64_t* target, float* loss, float* lse, int32_t* correct,
                           int n, int classes, void* ws, size_t ws_bytes, void* stream);
 /* dlogits[n][c] = (exp(z - lse_n) - [c == t_n]) * dloss[0] / N */
+/* as dcv_cross_entropy_fwd; small batches of few classes (one launch computes the whole loss) can also write d loss / d logits for an upstream gradient of
+ * exactly 1 into `dlogits_unit` [N][classes] (nullable) — *produced tells whether they did: a training step whose loss is the root of the backward
+ * pass (ignite_training.py:253, loss.backward()) then needs no dcv_cross_entropy_bwd launch. */
+int dcv_cross_entropy_fwd_grad(const float* logits, const int64_t* target, float* loss, float* lse, int32_t* correct, float* dlogits_unit, int* produced,
+                               int n, int classes, void* ws, size_t ws_bytes, void* stream);
 int dcv_cross_entropy_bwd(const float* logits, const int64_t* target, const float* lse, const float* dloss, float* dlogits,
                           int n, int classes, void* stream);
 

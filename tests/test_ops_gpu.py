@@ -771,3 +771,32 @@ def test_linear_on_nhwc_activations(device, shape, o, act):
     with torch.no_grad():
         wt.mul_(0.5)                                               # in-place torch op: detected through Tensor._version
     _check(f'linear_nhwc{shape} after in-place update', ops.linear_nhwc(x0, wt, b, act, 0.1), ops.linear(ops.flatten_nchw_order(x0), wt, b, act, 0.1), 1e-5)
+
+
+def test_cross_entropy_unit_gradient_shortcut(device):
+    """ With a registered unit root gradient (`ops.register_unit_gradient`, what `GraphedTrainStep` does) the cross-entropy forward launch also leaves
+    d loss / d logits, and `backward(gradient=seed)` returns it without a backward kernel; any other upstream gradient takes the regular kernel. """
+    from deepcv_amd import ops
+    torch.manual_seed(2)
+    z0 = torch.randn(512, 10, device=device)
+    t = torch.randint(0, 10, (512,), device=device)
+    seed = torch.ones((), device=device)
+
+    def grad(gradient, registered):
+        ops._unit_seeds.clear()
+        if registered:
+            ops.register_unit_gradient(seed)
+        z = z0.clone().requires_grad_(True)
+        ops.cross_entropy(z, t).backward(gradient=gradient)
+        return z.grad
+
+    try:
+        ref = grad(None, False)
+        _check('ce unit shortcut', grad(seed, True), ref, 1e-6)
+        _check('ce registered, other gradient tensor', grad(torch.ones((), device=device), True), ref, 1e-6)
+        _check('ce registered, scaled gradient', grad(torch.full((), 0.5, device=device), True), ref * 0.5, 1e-6)
+        zr = z0.clone().requires_grad_(True)
+        torch.nn.functional.cross_entropy(zr, t).backward()
+        _check('ce unit shortcut vs torch', grad(seed, True), zr.grad, 1e-5)
+    finally:
+        ops._unit_seeds.clear()
