@@ -114,6 +114,10 @@ _SIGNATURES = {
     'dcv_copy_channels': (_c_int, [_P, _c_int, _c_int, _P, _c_int, _c_int, _c_int, _c_size_t, _P]),
     'dcv_concat_channels': (_c_int, [_c_int, ctypes.POINTER(_P), ctypes.POINTER(_c_int), _P, _c_size_t, _P]),
     'dcv_split_channels': (_c_int, [_c_int, ctypes.POINTER(_P), ctypes.POINTER(_c_int), _P, _c_size_t, _P]),
+    'dcv_resize_concat_channels': (_c_int, [_c_int, ctypes.POINTER(_P), ctypes.POINTER(_c_int), ctypes.POINTER(_c_int), ctypes.POINTER(_c_int), _P,
+                                            _c_int, _c_int, _c_int, _c_int, _P]),
+    'dcv_resize_split_channels': (_c_int, [_c_int, ctypes.POINTER(_P), ctypes.POINTER(_c_int), ctypes.POINTER(_c_int), ctypes.POINTER(_c_int), _P,
+                                           _c_int, _c_int, _c_int, _c_int, _P]),
     'dcv_images_u8_normalize': (_c_int, [_P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _P, _P, _P]),
     'dcv_images_u8_augment_normalize': (_c_int, [_P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P]),
     'dcv_indirect_copy': (_c_int, [_P, _P]),

@@ -336,6 +336,81 @@ inline float interp_scale(int in_size, int out_size, int align) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// Channel concatenation whose parts may have another spatial size than the result (dense links with `allow_scaling`, reference submodule_creators.py:272-327:
+// F.interpolate of the referenced features, then torch.cat): blockIdx.y = part; a part of the result's size is copied, any other one is resampled
+// bilinearly on the fly (to_wide = 1, the body of interp_fwd_kernel writing into its channel range of the wide rows) or receives the gather form of the
+// bilinear backward read straight from its channel range of the wide gradient (to_wide = 0, the body of interp_bwd_kernel) — one launch per direction
+// instead of one per resized part plus the concat / split.
+struct ResizeConcatTable { float* part[DCV_MAX_CONCAT]; int c[DCV_MAX_CONCAT]; int off[DCV_MAX_CONCAT]; int h[DCV_MAX_CONCAT]; int w[DCV_MAX_CONCAT];
+                           float sh[DCV_MAX_CONCAT]; float sw[DCV_MAX_CONCAT]; int count; };
+
+template <int VEC>
+__global__ __launch_bounds__(256) void resize_concat_kernel(ResizeConcatTable t, float* __restrict__ wide, int wide_c, int N, int Ho, int Wo, int align, int to_wide) {
+    const int k = blockIdx.y;
+    float* __restrict__ part = t.part[k];
+    const int C = t.c[k], off = t.off[k], H = t.h[k], W = t.w[k];
+    const int CV = C / VEC;
+    const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gstride = (size_t)gridDim.x * blockDim.x;
+    if (H == Ho && W == Wo) {
+        const size_t total = (size_t)N * Ho * Wo * CV;
+        for (size_t i = gtid; i < total; i += gstride) {
+            const size_t r = i / CV; const int c = (int)(i % CV) * VEC;
+            float* pw = wide + r * wide_c + off + c; float* pp = part + r * C + c;
+            if constexpr (VEC == 4) { if (to_wide) *reinterpret_cast<float4*>(pw) = *reinterpret_cast<const float4*>(pp); else *reinterpret_cast<float4*>(pp) = *reinterpret_cast<const float4*>(pw); }
+            else { if (to_wide) *pw = *pp; else *pp = *pw; }
+        }
+        return;
+    }
+    const float sh = t.sh[k], sw = t.sw[k];
+    if (to_wide) {
+        const size_t total = (size_t)N * Ho * Wo * CV;
+        for (size_t i = gtid; i < total; i += gstride) {
+            const int c = (int)(i % CV) * VEC; size_t p = i / CV;
+            const int wo = (int)(p % Wo); p /= Wo; const int ho = (int)(p % Ho); const int n = (int)(p / Ho);
+            int h0, h1, w0, w1; float lh, lw;
+            bilinear_taps(sh, ho, H, align, h0, h1, lh); bilinear_taps(sw, wo, W, align, w0, w1, lw);
+            const float* xs = part + (size_t)n * H * W * C;
+            const float c00 = (1.f - lh) * (1.f - lw), c01 = (1.f - lh) * lw, c10 = lh * (1.f - lw), c11 = lh * lw;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                const float v = c00 * xs[((size_t)h0 * W + w0) * C + c + q] + c01 * xs[((size_t)h0 * W + w1) * C + c + q]
+                              + c10 * xs[((size_t)h1 * W + w0) * C + c + q] + c11 * xs[((size_t)h1 * W + w1) * C + c + q];
+                wide[(((size_t)n * Ho + ho) * Wo + wo) * wide_c + off + c + q] = v;
+            }
+        }
+        return;
+    }
+    const size_t total = (size_t)N * H * W * CV;
+    for (size_t i = gtid; i < total; i += gstride) {
+        const int c = (int)(i % CV) * VEC; size_t p = i / CV;
+        const int w = (int)(p % W); p /= W; const int h = (int)(p % H); const int n = (int)(p / H);
+        int holo, hohi, wolo, wohi;
+        cand_range(sh, h, Ho, holo, hohi); cand_range(sw, w, Wo, wolo, wohi);
+        float acc[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
+        const float* dys = wide + (size_t)n * Ho * Wo * wide_c + off;
+        for (int ho = holo; ho <= hohi; ++ho) {
+            int h0, h1; float lh; bilinear_taps(sh, ho, H, align, h0, h1, lh);
+            float wh = 0.f;
+            if (h0 == h) wh += 1.f - lh;
+            if (h1 == h) wh += lh;
+            if (wh == 0.f) continue;
+            for (int wo = wolo; wo <= wohi; ++wo) {
+                int w0, w1; float lw; bilinear_taps(sw, wo, W, align, w0, w1, lw);
+                float ww = 0.f;
+                if (w0 == w) ww += 1.f - lw;
+                if (w1 == w) ww += lw;
+                if (ww == 0.f) continue;
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) acc[q] += wh * ww * dys[((size_t)ho * Wo + wo) * wide_c + c + q];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) part[(((size_t)n * H + h) * W + w) * C + c + q] = acc[q];
+    }
+}
+
 
 // ------------------------------------------------------------------------------------------------ ordered sums of partial slabs
 // dst[i] = sum over k < chunks of src[k * stride + i] for up to DCV_MAX_SLAB_SEGMENTS independent segments in one launch (second stage of the weight
@@ -502,6 +577,42 @@ static int concat_split(int count, float* const* parts, const int* cs, float* wi
     if (v4) hipLaunchKernelGGL((concat_split_kernel<4>), dim3(dcv_stream_grid(rows * (size_t)(maxc / 4), 256), (unsigned)n), dim3(256), 0, st, t, wide, off, rows, to_wide);
     else hipLaunchKernelGGL((concat_split_kernel<1>), dim3(dcv_stream_grid(rows * (size_t)maxc, 256), (unsigned)n), dim3(256), 0, st, t, wide, off, rows, to_wide);
     DCV_RETURN_LAUNCH();
+}
+
+static int resize_concat(int count, float* const* parts, const int* cs, const int* hs, const int* ws, float* wide, int n, int ho, int wo, int align, int to_wide, void* stream) {
+    DCV_CHECK_ARG(count > 0 && count <= DCV_MAX_CONCAT && parts && cs && hs && ws && wide && n > 0 && ho > 0 && wo > 0);
+    ResizeConcatTable t{}; t.count = count;
+    int off = 0; bool v4 = aligned16(wide);
+    size_t maxwork = 0;
+    for (int k = 0; k < count; ++k) {
+        DCV_CHECK_ARG(cs[k] > 0 && hs[k] > 0 && ws[k] > 0 && (parts[k] != nullptr || !to_wide));
+        t.part[k] = parts[k]; t.c[k] = cs[k]; t.off[k] = off; t.h[k] = hs[k]; t.w[k] = ws[k];
+        t.sh[k] = interp_scale(hs[k], ho, align); t.sw[k] = interp_scale(ws[k], wo, align);
+        v4 = v4 && (cs[k] % 4 == 0) && (off % 4 == 0) && (parts[k] == nullptr || aligned16(parts[k]));
+        const bool same = hs[k] == ho && ws[k] == wo;
+        const size_t work = (size_t)n * ((to_wide || same) ? (size_t)ho * wo : (size_t)hs[k] * ws[k]) * cs[k];
+        if (work > maxwork) maxwork = work;
+        off += cs[k];
+    }
+    v4 = v4 && (off % 4 == 0);
+    int m = 0;                                                            // split: a NULL part means "gradient not needed"
+    for (int k = 0; k < count; ++k) if (t.part[k]) {
+        t.part[m] = t.part[k]; t.c[m] = t.c[k]; t.off[m] = t.off[k]; t.h[m] = t.h[k]; t.w[m] = t.w[k]; t.sh[m] = t.sh[k]; t.sw[m] = t.sw[k]; ++m; }
+    if (m == 0) return DCV_OK;
+    hipStream_t st = dcv_stream(stream);
+    if (v4) hipLaunchKernelGGL((resize_concat_kernel<4>), dim3(dcv_stream_grid(maxwork / 4, 256), (unsigned)m), dim3(256), 0, st, t, wide, off, n, ho, wo, align, to_wide);
+    else hipLaunchKernelGGL((resize_concat_kernel<1>), dim3(dcv_stream_grid(maxwork, 256), (unsigned)m), dim3(256), 0, st, t, wide, off, n, ho, wo, align, to_wide);
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_resize_concat_channels(int count, const float* const* srcs, const int* channels, const int* heights, const int* widths, float* dst,
+                               int n, int ho, int wo, int align_corners, void* stream) {
+    return resize_concat(count, const_cast<float* const*>(reinterpret_cast<const float* const*>(srcs)), channels, heights, widths, dst, n, ho, wo, align_corners ? 1 : 0, 1, stream);
+}
+
+int dcv_resize_split_channels(int count, float* const* dsts, const int* channels, const int* heights, const int* widths, const float* src,
+                              int n, int ho, int wo, int align_corners, void* stream) {
+    return resize_concat(count, dsts, channels, heights, widths, const_cast<float*>(src), n, ho, wo, align_corners ? 1 : 0, 0, stream);
 }
 
 int dcv_concat_channels(int count, const float* const* srcs, const int* channels, float* dst, size_t rows, void* stream) {

@@ -240,6 +240,11 @@ def add_residual_dense_link_creator(is_residual: bool, creator_name: str, submod
         @deepcv_nn.forward_call_convention_dec(apply_parallel_forward=apply_in_parallel, in_tensors_count_similar_to_refs=apply_in_parallel)
         def _forward_callback(x: TENSOR_OR_SEQ_OF_TENSORS_T, referenced_submodules_out: List[TENSOR_OR_SEQ_OF_TENSORS_T]) -> TENSOR_OR_SEQ_OF_TENSORS_T:
             out = [x, ] if deepcv_nn.is_torch_obj(x) else list(x)
+            flat_refs = [y for refs in referenced_submodules_out for y in ([refs, ] if deepcv_nn.is_torch_obj(refs) else list(refs))]
+            if (reduction == 'concat' and allow_scaling and channel_dim == 1 and scaling_mode in (None, 'bilinear') and len(out) + len(flat_refs) <= ops.nat.MAX_CONCAT
+                    and all(deepcv_nn.is_torch_obj(t) and t.is_cuda and t.dim() == 4 for t in out + flat_refs)
+                    and all(t.shape[2:] == out[0].shape[2:] for t in out) and any(y.shape[2:] != out[0].shape[2:] for y in flat_refs)):
+                return ops.resize_concat(out + flat_refs, align_corners=scaling_align_corners)   # resize + concat in one launch (and one for the backward)
             for refs in referenced_submodules_out:
                 for y in ([refs, ] if deepcv_nn.is_torch_obj(refs) else list(refs)):
                     if out[0].shape[channel_dim + 1:] != y.shape[channel_dim + 1:]:

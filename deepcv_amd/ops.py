@@ -15,7 +15,7 @@ from . import filters
 from . import slabs
 from ._native import lib
 
-__all__ = ['conv2d', 'set_conv_math', 'conv_norm_layer', 'activation', 'batch_norm', 'sync_batch_norm', 'group_norm', 'pool2d', 'interpolate_bilinear', 'concat_channels', 'add_tensors', 'flatten_nchw_order',
+__all__ = ['conv2d', 'set_conv_math', 'conv_norm_layer', 'activation', 'batch_norm', 'sync_batch_norm', 'group_norm', 'pool2d', 'interpolate_bilinear', 'concat_channels', 'resize_concat', 'add_tensors', 'flatten_nchw_order',
            'linear', 'linear_nhwc', 'cross_entropy', 'act_code', 'to_nhwc', 'nchw_to_nhwc']
 
 _CL = torch.channels_last
@@ -585,6 +585,48 @@ class _ConcatFn(torch.autograd.Function):
                     nat.check(lib.dcv_copy_channels(dy.data_ptr(), ctot, off, g.data_ptr(), c, 0, c, rows, st), 'dcv_copy_channels')
                 off += c
         return tuple(grads)
+
+
+class _ResizeConcatFn(torch.autograd.Function):
+    """ `torch.cat([t0, interpolate(t1, size of t0), ...], dim=1)`: channel concatenation at the first tensor's spatial size, the other tensors resized
+    bilinearly on the fly where needed (`dcv_resize_concat_channels` / `dcv_resize_split_channels`: one launch per direction). """
+
+    @staticmethod
+    def forward(ctx, align_corners, *tensors):
+        _require_f32(*tensors)
+        tensors = [to_nhwc(t) for t in tensors]
+        n, _, ho, wo = tensors[0].shape
+        k = len(tensors)
+        chans, hs, ws = [t.shape[1] for t in tensors], [t.shape[2] for t in tensors], [t.shape[3] for t in tensors]
+        if any(t.shape[0] != n for t in tensors) or k > nat.MAX_CONCAT:
+            raise RuntimeError(f'deepcv_amd.resize_concat: unsupported inputs {[tuple(t.shape) for t in tensors]}')
+        out = torch.empty((n, sum(chans), ho, wo), dtype=tensors[0].dtype, device=tensors[0].device, memory_format=_CL)
+        ia = lambda v: (ctypes.c_int * k)(*v)
+        nat.check(lib.dcv_resize_concat_channels(k, (ctypes.c_void_p * k)(*[t.data_ptr() for t in tensors]), ia(chans), ia(hs), ia(ws), out.data_ptr(),
+                                                 n, ho, wo, int(align_corners), nat.current_stream(out.device)), 'dcv_resize_concat_channels')
+        ctx.geom = (n, ho, wo, chans, hs, ws, int(align_corners))
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, ho, wo, chans, hs, ws, align = ctx.geom
+        dy = to_nhwc(dy)
+        k = len(chans)
+        grads = [torch.empty((n, c, h, w), dtype=dy.dtype, device=dy.device, memory_format=_CL) if ctx.needs_input_grad[i + 1] else None
+                 for i, (c, h, w) in enumerate(zip(chans, hs, ws))]
+        ia = lambda v: (ctypes.c_int * k)(*v)
+        nat.check(lib.dcv_resize_split_channels(k, (ctypes.c_void_p * k)(*[nat.ptr(g) for g in grads]), ia(chans), ia(hs), ia(ws), dy.data_ptr(),
+                                                n, ho, wo, align, nat.current_stream(dy.device)), 'dcv_resize_split_channels')
+        return (None, *grads)
+
+
+def resize_concat(tensors: Sequence[torch.Tensor], align_corners: bool = False) -> torch.Tensor:
+    """ Channel concatenation of 4-D tensors at the spatial size of the first one; the others are resized bilinearly (as `interpolate_bilinear`) in the
+    same launch. """
+    tensors = list(tensors)
+    if len(tensors) == 1:
+        return tensors[0]
+    return _ResizeConcatFn.apply(bool(align_corners), *tensors)
 
 
 def concat_channels(tensors: Sequence[torch.Tensor]) -> torch.Tensor:

@@ -273,6 +273,13 @@ int dcv_copy_channels(const float* src, int src_c, int src_off, float* dst, int 
  * adjoint (a NULL dsts[k] skips that block): what torch.cat(dim=1) / its backward do for the dense links (submodule_creators.py:309-327) */
 int dcv_concat_channels(int count, const float* const* srcs, const int* channels, float* dst, size_t rows, void* stream);
 int dcv_split_channels(int count, float* const* dsts, const int* channels, const float* src, size_t rows, void* stream);
+/* The same with parts of any spatial size: part k is [n][heights[k]][widths[k]][channels[k]]; parts whose size differs from the result's [n][ho][wo] are
+ * resized bilinearly on the fly (F.interpolate(mode='bilinear', align_corners) of the dense / residual links with allow_scaling, submodule_creators.py:272-327,
+ * followed by torch.cat) — and, for the split, receive the bilinear backward of their channel range of the wide gradient.  One launch per direction. */
+int dcv_resize_concat_channels(int count, const float* const* srcs, const int* channels, const int* heights, const int* widths, float* dst,
+                               int n, int ho, int wo, int align_corners, void* stream);
+int dcv_resize_split_channels(int count, float* const* dsts, const int* channels, const int* heights, const int* widths, const float* src,
+                              int n, int ho, int wo, int align_corners, void* stream);
 /* out = a + b (elementwise; out may alias a) */
 int dcv_add(const float* a, const float* b, float* out, size_t numel, void* stream);
 /* out = alpha * a */

@@ -800,3 +800,28 @@ def test_cross_entropy_unit_gradient_shortcut(device):
         _check('ce unit shortcut vs torch', grad(seed, True), zr.grad, 1e-5)
     finally:
         ops._unit_seeds.clear()
+
+
+@pytest.mark.parametrize('align', [False, True], ids=['half_pixel', 'align_corners'])
+def test_resize_concat_matches_interpolate_then_concat(device, align):
+    """ `ops.resize_concat` (one launch per direction) against `concat_channels([t0, interpolate_bilinear(t1), ...])`: up- and down-scaled parts, vector and
+    scalar channel counts, a part which needs no gradient. """
+    from deepcv_amd import ops
+    torch.manual_seed(17)
+    for shapes in ([(4, 16, 8, 8), (4, 4, 16, 16)], [(3, 8, 10, 6), (3, 4, 5, 3), (3, 12, 10, 6), (3, 4, 20, 13)], [(2, 3, 7, 7), (2, 5, 14, 14)]):
+        base = [_cl(torch.randn(*s, device=device)) for s in shapes]
+        outs = []
+        for fused in (False, True):
+            ts = [t.clone().requires_grad_(i != 2) for i, t in enumerate(base)]
+            if fused:
+                y = ops.resize_concat(ts, align_corners=align)
+            else:
+                y = ops.concat_channels([ts[0]] + [ops.interpolate_bilinear(t, ts[0].shape[2:], align_corners=align) if t.shape[2:] != ts[0].shape[2:] else t for t in ts[1:]])
+            g = torch.randn(y.shape, device=device, generator=None) if not outs else outs[0][2]
+            y.backward(g)
+            outs.append((y.detach(), [t.grad for t in ts], g))
+        _check(f'resize_concat{shapes} out', outs[1][0], outs[0][0], 1e-6)
+        for i, (a, b) in enumerate(zip(outs[1][1], outs[0][1])):
+            assert (a is None) == (b is None)
+            if a is not None:
+                _check(f'resize_concat{shapes} grad{i}', a, b, 1e-5)
