@@ -598,6 +598,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_tiled_kernel(WgTiledArgs a, co
 // Units fewer than 256 are replicated over `nsub` segment sub-streams; consecutive sub-streams work on consecutive tile ROWS and both tiles have a row
 // stride of an odd number of 16-B slots, so the ds_read_b128 of neighbouring lanes fall into different banks.  Sub-streams are merged through LDS in a
 // fixed order (row stride congruent to `units` mod 32: conflict-free for the writers and for the readers) -> deterministic.
+// filter columns merged per pass of the sub-stream merge: 2 -> 36 rows (37.6 KB of LDS, three resident blocks per CU); 3 -> 52 rows, one pass less but only
+// two resident blocks (measured: 0.4388 vs 0.4524 ms per stock step)
+#ifndef DCV_SLIDE_SG
+#define DCV_SLIDE_SG 2
+#endif
 struct WgSlideArgs {
     int N, H, W, Cin, Ho, Wo, Cout, R, sh, ph, pw, dh;
     int x_nchw;
@@ -790,7 +795,7 @@ __device__ __forceinline__ void conv_wgrad_slide_body(const WgSlideArgs& a, cons
     float* red = reinterpret_cast<float*>(smem);
     float* dst = partial + (size_t)bx * a.slab;
     constexpr int E = 4 * VEC;
-    constexpr int SG = (VEC == 4) ? (S < 3 ? S : 3) : S;                  // filter columns per pass (rows <= 52: see wgrad_slide_plan's LDS size)
+    constexpr int SG = (VEC == 4) ? (S < DCV_SLIDE_SG ? S : DCV_SLIDE_SG) : S;   // filter columns per pass (rows <= 16 * DCV_SLIDE_SG + 4: see wgrad_slide_plan's LDS size)
     constexpr int PASSES = (S + SG - 1) / SG;
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
@@ -1173,7 +1178,7 @@ bool wgrad_slide_plan(const dcv_conv2d_desc* d, bool fuse_db, WgSlideArgs* a, in
         th = (th + 1) / 2;
     }
     if (bytes > 64 * 1024) return false;
-    const int sgrp = (v == 4) ? (d->s < 3 ? d->s : 3) : d->s;             // filter columns merged per pass (SG of the kernel)
+    const int sgrp = (v == 4) ? (d->s < DCV_SLIDE_SG ? d->s : DCV_SLIDE_SG) : d->s;             // filter columns merged per pass (SG of the kernel)
     const size_t red_bytes = ((size_t)sgrp * 4 * v + 4) * a->red_rs * sizeof(float);
     if (bytes < red_bytes) bytes = red_bytes;
     a->tiles_per_img = (d->ho + th - 1) / th;
