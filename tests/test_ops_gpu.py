@@ -56,6 +56,10 @@ CONV_CASES = [
     (1, 128, 6, 6, 8, 3, 1, 1, 1, 0, False),       # > 256 wgrad units: un-tiled weight-gradient fallback
     (3, 4, 40, 24, 4, 3, 1, 1, 1, 1, False),       # several row tiles per image, ragged last tile (tiled weight gradient)
     (2, 3, 37, 29, 5, 5, 2, 2, 1, 0, True),        # strided + NCHW input + ragged tiles
+    # narrow MFMA weight gradient (channels multiples of 16 below the wide kernel's 64): 25 taps, 1x1, ragged widths / row tiles, several channel tiles
+    (3, 32, 7, 10, 16, 5, 1, 2, 1, 1, False),
+    (2, 16, 9, 9, 48, 1, 1, 0, 1, 0, False),
+    (5, 48, 40, 22, 32, 3, 1, 1, 1, 4, False),
     # wide layers: MFMA implicit-GEMM back-end (fwd / stride-1 dgrad / wgrad when both channel counts are multiples of 64)
     (2, 64, 16, 16, 64, 3, 1, 1, 1, 1, False),
     (3, 32, 9, 11, 64, 3, 1, 1, 1, 2, False),      # ragged pixel count (not a multiple of the 128-pixel tile), wgrad on the direct fallback
