@@ -29,6 +29,7 @@ _lock = threading.Lock()
 _pending: List[Tuple[torch.device, int, List[nat.SlabSegment], torch.Tensor]] = []   # (device, stream handle, segments, workspace kept alive)
 _wgrads: List[Tuple[torch.device, int, 'nat.WgradJob', tuple]] = []                  # (device, stream handle, job, tensors kept alive: x, dz, workspace)
 _callback_queued = False
+_pass_id = None                       # autograd graph-task id of the backward pass the pending work belongs to
 _uses: Dict[int, List[int]] = {}      # id(parameter) -> [forward uses whose backward has not run yet, peak of that count]
 
 
@@ -79,6 +80,25 @@ def reset_uses():
         _uses.clear()
 
 
+def _current_pass():
+    get = getattr(torch._C, '_current_graph_task_id', None)
+    return get() if get is not None else None
+
+
+def _enter_pass():
+    """ Called before queueing work: whatever a backward pass which died half-way (exception inside a backward function: its final callback never ran) left
+    behind is dropped — those gradients were never delivered, and their buffers may be gone. """
+    global _callback_queued, _pass_id
+    pid = _current_pass()
+    with _lock:
+        if pid != _pass_id:
+            if _callback_queued:
+                _pending.clear()
+                _wgrads.clear()
+                _callback_queued = False
+            _pass_id = pid
+
+
 def _queue_flush():
     global _callback_queued
     with _lock:
@@ -95,6 +115,7 @@ def defer(device: torch.device, stream: int, segments, n: int, ws: torch.Tensor)
     """ Queues `n` segments produced by a `*_deferred` entry point; `ws` (their slabs) stays alive until the flush. """
     if n <= 0:
         return
+    _enter_pass()
     segs = []
     for i in range(n):
         g = nat.SlabSegment()
@@ -108,6 +129,7 @@ def defer(device: torch.device, stream: int, segments, n: int, ws: torch.Tensor)
 def defer_wgrad(device: torch.device, stream: int, desc, x: torch.Tensor, dz: torch.Tensor, dw_ptr: int, db_ptr, ws: torch.Tensor):
     """ Queues a whole convolution weight gradient (both stages).  `x`, `dz` and the workspace stay alive until the flush; `dw` / `db` are only known by
     address: the autograd engine must find itself their sole owner to adopt them as `.grad` instead of copying them. """
+    _enter_pass()
     job = nat.WgradJob()
     ctypes.pointer(job.desc)[0] = desc
     job.x, job.dy, job.dw, job.db, job.ws, job.ws_bytes = x.data_ptr(), dz.data_ptr(), dw_ptr, db_ptr, ws.data_ptr(), ws.numel()
@@ -125,9 +147,10 @@ def flush():
     """ Runs every pending sum (one launch per device and stream, normally one in total).  Idempotent; also called by code which must read the gradients
     before the end of the backward pass (the bucket pack of `deepcv_amd.parallel.GradientAllReducer`). """
     global _callback_queued
+    stale = _current_pass() != _pass_id          # queued by a backward pass which is not the running one: it died before its final callback
     with _lock:
-        jobs = list(_pending)
-        wjobs = list(_wgrads)
+        jobs = [] if stale else list(_pending)
+        wjobs = [] if stale else list(_wgrads)
         _pending.clear()
         _wgrads.clear()
         _callback_queued = False

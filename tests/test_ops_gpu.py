@@ -829,3 +829,44 @@ def test_resize_concat_matches_interpolate_then_concat(device, align):
             assert (a is None) == (b is None)
             if a is not None:
                 _check(f'resize_concat{shapes} grad{i}', a, b, 1e-5)
+
+
+def test_deferred_gradients_survive_a_failed_backward_pass(device):
+    """ A backward pass which raises half-way never runs its final callback: the work it had queued must be dropped by the next pass, not executed
+    against buffers which no longer exist — and the next pass must still flush its own work. """
+    from deepcv_amd import ops, slabs, _native as nat
+    torch.manual_seed(4)
+    x = _cl(torch.randn(4, 4, 16, 16, device=device))
+    w = torch.nn.Parameter(torch.randn(4, 4, 3, 3, device=device) * 0.1)
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError('boom')
+
+    y = ops.conv2d(Boom.apply(ops.conv2d(x, w, None, padding=1)), w.detach().clone().requires_grad_(True), None, padding=1)
+    with pytest.raises(RuntimeError, match='boom'):
+        y.sum().backward()                                         # the second convolution's weight gradient was queued, then the pass died
+    assert slabs.pending() > 0
+    slabs.flush()                                                  # e.g. the optimizer's: drops the dead pass's work instead of running it
+    slabs.reset_uses()
+    assert slabs.pending() == 0
+    w.grad = None
+    out = ops.conv2d(x, w, None, padding=1)
+    seen = []
+    h = w.register_hook(lambda g: seen.append(slabs.pending()))
+    out.sum().backward()
+    h.remove()
+    assert seen == [1] and slabs.pending() == 0                    # deferred again, and flushed by this pass's own callback
+    ref = torch.nn.Parameter(w.detach().clone())
+    prev = slabs.set_enabled(False)
+    try:
+        ops.conv2d(x, ref, None, padding=1).sum().backward()
+    finally:
+        slabs.set_enabled(prev)
+    torch.cuda.synchronize()
+    assert torch.equal(w.grad, ref.grad)
