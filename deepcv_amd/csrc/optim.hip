@@ -88,13 +88,17 @@ __global__ __launch_bounds__(OPT_BLOCK) void pack_kernel(dcv_tensor_list tl, flo
     const int64_t n = tl.numel[t];
     const int64_t base = (int64_t)blockIdx.x * OPT_ELEMS_PER_BLOCK;
     if (base >= n) return;
-    int64_t off = 0;
-    for (int k = 0; k < t; ++k) off += tl.numel[k];
+    float* __restrict__ out = tl.param[t];                        // explicit destination (bucket slices with alignment padding) ...
+    if (out == nullptr) {                                         // ... or the tensors back to back in `dst`
+        int64_t off = 0;
+        for (int k = 0; k < t; ++k) off += tl.numel[k];
+        out = dst + off;
+    }
     const float* __restrict__ g = tl.grad[t];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int64_t i = base + (int64_t)k * OPT_BLOCK + threadIdx.x;
-        if (i < n) dst[off + i] = g[i];
+        if (i < n) out[i] = g[i];
     }
 }
 

@@ -12,6 +12,7 @@ import torch
 
 from . import _native as nat
 from . import filters
+from . import grads
 from . import slabs
 from ._native import lib
 
@@ -31,6 +32,15 @@ def _require_f32(*tensors):
 
 def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def _grad_buffer(param: Optional[torch.Tensor], like: Optional[torch.Tensor] = None, n: int = 0, device=None) -> torch.Tensor:
+    """ Buffer for the gradient of `param`: its slice of the data-parallel all-reduce bucket when there is one (`deepcv_amd/grads.py`), else a new tensor
+    shaped like `like` / of `n` floats. """
+    g = grads.buffer_for(param)
+    if g is not None:
+        return g
+    return torch.empty_like(like) if like is not None else torch.empty(n, dtype=torch.float32, device=device)
 
 
 def _conv_wgrad_launch(d, x, dz, weight, bias, dw, db, st):
@@ -167,7 +177,7 @@ class _Conv2dFn(torch.autograd.Function):
         st = nat.current_stream(dev)
         dy = to_nhwc(dy)
         rows = d.n * d.ho * d.wo
-        db = torch.empty(d.cout, dtype=dy.dtype, device=dev) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        db = _grad_buffer(ctx.bias_ref, n=d.cout, device=dev) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         db_done = False
         if d.act != nat.ACT_NONE:
             # dz = dy * act'(y), fused with the bias-gradient reduction
@@ -185,7 +195,7 @@ class _Conv2dFn(torch.autograd.Function):
             dx = torch.empty((d.n, d.cin, d.h, d.w), dtype=dy.dtype, device=dev, memory_format=_CL)
             _conv_dgrad_launch(dd, dz, weight, dx, st)
         if ctx.needs_input_grad[1] or (db is not None and not db_done):
-            dw = torch.empty_like(weight)
+            dw = _grad_buffer(ctx.weight_ref, like=weight)
             _conv_wgrad_launch(d, x, dz, ctx.weight_ref, ctx.bias_ref, dw, None if db_done else db, st)
         return dx, dw, db, None, None, None, None, None
 
@@ -410,7 +420,7 @@ class _ConvNormLayerFn(torch.autograd.Function):
             layout = nat.LAYOUT_NCHW
         else:
             x, layout = to_nhwc(x), nat.LAYOUT_NHWC
-        ctx.weight_ref, ctx.bias_ref = weight, bias
+        ctx.weight_ref, ctx.bias_ref, ctx.norm_refs = weight, bias, (bn_w, bn_b, gn_w, gn_b)
         slabs.note_use(weight if ctx.needs_input_grad[1] else None, bias if ctx.needs_input_grad[2] else None)
         weight = weight.contiguous()
         d = _conv_desc(x.shape, weight.shape, stride, padding, dilation, layout, act, slope)
@@ -441,14 +451,15 @@ class _ConvNormLayerFn(torch.autograd.Function):
         dev, st = dout.device, nat.current_stream(dout.device)
         dout = to_nhwc(dout)
         c, hw = d.cout, d.ho * d.wo
-        new = lambda: torch.empty(c, dtype=torch.float32, device=dev)
+        new = lambda ref: _grad_buffer(ref, n=c, device=dev)
         need = ctx.needs_input_grad
-        db = new() if (bias is not None and need[2]) else None
+        r_bn_w, r_bn_b, r_gn_w, r_gn_b = ctx.norm_refs
+        db = new(ctx.bias_ref) if (bias is not None and need[2]) else None
         db_from_wgrad = db is not None and need[1] and bool(lib.dcv_conv2d_wgrad_fuses_bias(d))   # summed from the dz tiles the wgrad kernel stages anyway
-        d_bn_w = new() if (bn_w is not None and need[3]) else None
-        d_bn_b = new() if (bn_b is not None and need[4]) else None
-        d_gn_w = new() if (gn_w is not None and need[8]) else None
-        d_gn_b = new() if (groups and need[9]) else None
+        d_bn_w = new(r_bn_w) if (bn_w is not None and need[3]) else None
+        d_bn_b = new(r_bn_b) if (bn_b is not None and need[4]) else None
+        d_gn_w = new(r_gn_w) if (gn_w is not None and need[8]) else None
+        d_gn_b = new(r_gn_b) if (groups and need[9]) else None
         dz = torch.empty_like(y)
         ws = _ws(lib.dcv_norm_chain_workspace_bytes(d.n, hw, c), dev)
         nat.check(lib.dcv_bn_gn_pool_act_bwd(dout.data_ptr(), y.data_ptr(), dz.data_ptr(), d.n, hw, c, nat.ptr(bn_w), nat.ptr(bn_b), bn_mean.data_ptr(), bn_rstd.data_ptr(),
@@ -462,7 +473,7 @@ class _ConvNormLayerFn(torch.autograd.Function):
             dx = torch.empty((d.n, d.cin, d.h, d.w), dtype=dz.dtype, device=dev, memory_format=_CL)
             _conv_dgrad_launch(dd, dz, weight, dx, st)
         if need[1]:
-            dw = torch.empty_like(weight)
+            dw = _grad_buffer(ctx.weight_ref, like=weight)
             _conv_wgrad_launch(d, x, dz, ctx.weight_ref, ctx.bias_ref, dw, db if db_from_wgrad else None, st)
         return dx, dw, db, d_bn_w, d_bn_b, None, None, None, d_gn_w, d_gn_b, None
 
@@ -736,8 +747,8 @@ class _LinearFn(torch.autograd.Function):
         dy = dy.contiguous()
         need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw = torch.empty_like(weight) if need_w else None
-        db = torch.empty(o, dtype=dy.dtype, device=dev) if (need_w and ctx.has_bias) else None
+        dw = _grad_buffer(ctx.weight_ref, like=weight) if need_w else None
+        db = _grad_buffer(ctx.bias_ref, n=o, device=dev) if (need_w and ctx.has_bias) else None
         ws = _ws(lib.dcv_linear_bwd_workspace_bytes(n, k, o), dev)
         if need_w and slabs.may_defer(ctx.weight_ref, ctx.bias_ref):
             segs, ns = (nat.SlabSegment * 2)(), ctypes.c_int(0)
@@ -782,8 +793,8 @@ class _LinearNhwcFn(torch.autograd.Function):
         wp = filters.get(weight, ctx.desc, 2)
         need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None            # channels_last like x: the gradient of the NHWC activations, in place
-        dw = torch.empty_like(weight) if need_w else None
-        db = torch.empty(o, dtype=dy.dtype, device=dev) if (need_w and ctx.has_bias) else None
+        dw = _grad_buffer(ctx.weight_ref, like=weight) if need_w else None
+        db = _grad_buffer(ctx.bias_ref, n=o, device=dev) if (need_w and ctx.has_bias) else None
         ws = _ws(lib.dcv_linear_bwd_workspace_bytes(n, k, o), dev)
         if need_w and slabs.may_defer(ctx.weight_ref, ctx.bias_ref):
             segs, ns = (nat.SlabSegment * 2)(), ctypes.c_int(0)

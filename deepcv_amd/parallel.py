@@ -20,6 +20,7 @@ import torch.distributed as dist
 
 from . import _native as nat
 from . import filters
+from . import grads
 from . import slabs
 
 __all__ = ['GradientAllReducer', 'broadcast_module_state', 'DataParallelModel']
@@ -37,12 +38,14 @@ class _Bucket:
     def __init__(self, params: List[torch.nn.Parameter]):
         self.params = params
         self.numels = [p.numel() for p in params]
-        self.total = sum(self.numels)
+        # slices start on 16-B boundaries: the backward kernels write gradients straight into them (deepcv_amd/grads.py), like into any fresh tensor
+        self.offsets, off = [], 0
+        for n in self.numels:
+            self.offsets.append(off)
+            off += (n + 3) // 4 * 4
+        self.total = off
         self.flat = torch.zeros(self.total, dtype=params[0].dtype, device=params[0].device)
-        self.views, off = [], 0
-        for p, n in zip(params, self.numels):
-            self.views.append(self.flat[off:off + n].view_as(p))
-            off += n
+        self.views = [self.flat[o:o + n].view_as(p) for p, n, o in zip(params, self.numels, self.offsets)]
         self.pending = set()
         self.work = None
         self.event = None
@@ -77,6 +80,8 @@ class GradientAllReducer:
         dev = self.params[0].device if self.params else torch.device('cpu')
         self.device = dev
         self.comm_stream = torch.cuda.Stream(device=dev) if dev.type == 'cuda' else None
+        for b in self.buckets:              # backward functions write gradients straight into the bucket slices (deepcv_amd/grads.py)
+            grads.register(b.params, b.views)
         self._hooks = []
         if overlap:
             for p in self.params:
@@ -91,23 +96,25 @@ class GradientAllReducer:
     # -- per-bucket pack + collective ----------------------------------------------------------------
     def _pack(self, b: _Bucket):
         slabs.flush()        # weight gradients whose ordered slab sum is still pending (deepcv_amd/slabs.py) must be final before they are packed
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b.params]
+        if all(grads.in_place(p) for p in b.params):
+            return           # every gradient of the bucket was produced in its slice: nothing to copy
+        gl = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b.params]
         if self.device.type == 'cuda':
-            grads = [g if g.is_contiguous() else g.contiguous() for g in grads]
-            stream, off = nat.current_stream(self.device), 0
-            for i in range(0, len(grads), nat.MAX_TENSORS):
+            gl = [g if g.is_contiguous() else g.contiguous() for g in gl]
+            stream = nat.current_stream(self.device)
+            for i in range(0, len(gl), nat.MAX_TENSORS):
                 tl = nat.TensorList()
-                chunk = grads[i:i + nat.MAX_TENSORS]
+                chunk = gl[i:i + nat.MAX_TENSORS]
                 tl.count = len(chunk)
                 for j, g in enumerate(chunk):
                     tl.grad[j] = g.data_ptr()
+                    tl.param[j] = b.views[i + j].data_ptr()          # explicit destination: the (padded) bucket slice
                     tl.numel[j] = g.numel()
-                dst = b.flat.data_ptr() + off * 4
-                nat.check(nat.lib.dcv_pack_grads(ctypes.byref(tl), dst, stream), 'dcv_pack_grads')
-                off += sum(g.numel() for g in chunk)
-            b._keepalive = grads
+                nat.check(nat.lib.dcv_pack_grads(ctypes.byref(tl), b.flat.data_ptr(), stream), 'dcv_pack_grads')
+            b._keepalive = gl
         else:
-            torch.cat([g.reshape(-1) for g in grads], out=b.flat)   # CPU / gloo twin of the pack kernel (tests only)
+            for g, v in zip(gl, b.views):                           # CPU / gloo twin of the pack kernel (tests only)
+                v.copy_(g)
 
     def _launch(self, b: _Bucket):
         self._pack(b)

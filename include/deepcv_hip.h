@@ -423,7 +423,8 @@ int dcv_sgd_step(const dcv_tensor_list* tl, const float* hyper, int nesterov, vo
 /* ---------------------------------------------------------------------------------------------------
  * C1 helper  gradient bucket pack for the data-parallel all-reduce (RCCL over xGMI is driven from Python through
  * torch.distributed; the bucket is what gets reduced).  replaces DDP's bucket copy (ignite_training.py:380)
- * dst_flat[offset_i : offset_i + numel_i] = grad_i  (offsets = running sum of numel in list order)
+ * dst_flat[offset_i : offset_i + numel_i] = grad_i  (offsets = running sum of numel in list order); a tensor whose tl->param[i] is set is copied there
+ * instead (bucket slices padded to 16-B boundaries).  Gradients which the backward kernels already wrote into their slice need no pack at all.
  * ------------------------------------------------------------------------------------------------- */
 int dcv_pack_grads(const dcv_tensor_list* tl, float* dst_flat, void* stream);
 

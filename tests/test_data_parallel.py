@@ -93,4 +93,4 @@ def test_reducer_world_size_one_is_identity():
     red.finish()
     for p, g in zip(lin.parameters(), g0):
         assert torch.equal(p.grad, g) and p.grad.data_ptr() != g.data_ptr()   # now views of the flat bucket
-    assert red.buckets[0].flat.numel() == 15
+    assert red.buckets[0].flat.numel() == 16    # bias 3 (+1: slices start on 16-B boundaries) + weight 12

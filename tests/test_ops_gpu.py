@@ -870,3 +870,45 @@ def test_deferred_gradients_survive_a_failed_backward_pass(device):
         slabs.set_enabled(prev)
     torch.cuda.synchronize()
     assert torch.equal(w.grad, ref.grad)
+
+
+def test_gradients_written_into_the_all_reduce_bucket(device):
+    """ With a `GradientAllReducer` the backward kernels write parameter gradients straight into their (16-B aligned) bucket slices
+    (`deepcv_amd/grads.py`): after `backward()` every `.grad` aliases the bucket, `finish()` launches no pack, and the values equal a run without reducer.
+    An existing `.grad` (gradient accumulation) and parameters outside the registry take the regular path. """
+    from deepcv_amd import grads, ops, _native as nat
+    from deepcv_amd.parallel import GradientAllReducer
+    torch.manual_seed(23)
+    x = _cl(torch.randn(8, 4, 16, 16, device=device))
+    mk = lambda *s, k=0.1: torch.nn.Parameter(torch.randn(*s, device=device) * k)
+    names = ('w', 'b', 'bw', 'bb', 'gw', 'gb', 'lw', 'lb')
+    base = dict(w=mk(4, 4, 5, 5), b=mk(4), bw=mk(4, k=1.), bb=mk(4), gw=mk(4, k=1.), gb=mk(4), lw=mk(10, 4 * 8 * 8, k=0.05), lb=mk(10))
+
+    def loss(p):
+        rm, rv, nbt = torch.zeros(4, device=device), torch.ones(4, device=device), torch.zeros(1, dtype=torch.int64, device=device)
+        h = ops.conv_norm_layer(x, p['w'], p['b'], 1, 2, 1, nat.ACT_RELU, 0., p['bw'], p['bb'], rm, rv, nbt, 0.1, 1e-5, 2, p['gw'], p['gb'], 1e-5, pool=2)
+        return (ops.linear_nhwc(h, p['lw'], p['lb'], nat.ACT_SIGMOID, 0.) ** 2).sum()
+
+    ref = {n: torch.nn.Parameter(t.detach().clone()) for n, t in base.items()}
+    loss(ref).backward()
+    p = {n: torch.nn.Parameter(t.detach().clone()) for n, t in base.items()}
+    red = GradientAllReducer([p[n] for n in names], overlap=False)
+    try:
+        loss(p).backward()
+        torch.cuda.synchronize()
+        for n in names:
+            assert grads.in_place(p[n]), f'{n} was not produced in its bucket slice'
+            assert p[n].grad.data_ptr() % 16 == 0
+            assert torch.equal(p[n].grad, ref[n].grad), n
+        flat_before = red.buckets[0].flat.clone()
+        red.finish()                                               # world size 1: no collective; and nothing to pack
+        assert torch.equal(red.buckets[0].flat, flat_before)
+        for n in names:
+            assert torch.equal(p[n].grad, ref[n].grad)
+        # second backward without zeroing: gradients accumulate (fresh buffers + the engine's add), they do not alias the bucket twice
+        loss(p).backward()
+        torch.cuda.synchronize()
+        for n in names:
+            _check(f'arena accumulate {n}', p[n].grad, 2 * ref[n].grad, 1e-5)
+    finally:
+        grads.unregister(p.values())
