@@ -167,9 +167,11 @@ class GradientAllReducer:
         self._reset()
 
     def remove_hooks(self):
+        """ Detaches the reducer from the parameters: autograd hooks and gradient-arena registrations. """
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        grads.unregister(self.params)
 
 
 class DataParallelModel(torch.nn.Module):
