@@ -423,6 +423,147 @@ inline int pick_bmr(long M, int cin, int cout, int bn) {
     return (bn == 64 && cin >= 256 && blocks256 >= 2 * DCV_NUM_CU) ? 4 : 2;      // measured: 256-pixel tiles pay off from 256 input channels (110 vs 104 TF), lose below (86 vs 97)
 }
 
+// ------------------------------------------------------------------------------------------------ narrow layers: halo tile in LDS
+// For 16 / 32 input channels the implicit-GEMM kernel above is a chain of latencies: every tap gathers a 128 x 16 operand tile from global memory for
+// only 8 MFMAs per wave.  Here the zero-padded input tile of TH output rows of one image is staged ONCE (pixel-major, pixel stride Cin + 4 words: the 16
+// pixels x 4 channels of an A operand fall into 64 different banks), the filter slice of the block's 16 output channels lives in registers as B
+// fragments (taps * Cin / 4 VGPRs, read once from the K-major prepared filter), and every wave walks 16-pixel row segments: taps * Cin / 4 MFMAs per
+// segment, each fed by one ds_read_b32.  Same epilogue (bias, activation, BatchNorm statistics partials [2][Cout][tiles]) and the same filter layout as
+// the wide kernel, so it serves the forward pass and the stride-1 data gradient alike.
+struct HaloArgs {
+    int N, Hin, Win, Cin, Hout, Wout, Cout, R, S, ph, pw, act; float slope;
+    int TH, XH, XW, PS;            // output rows per tile, halo rows / columns, pixel stride in LDS (words)
+    int tiles_per_img, total_tiles;
+};
+
+template <int CIN, int TAPS>
+__global__ __launch_bounds__(256) void conv_mfma_halo_kernel(HaloArgs a, const float* __restrict__ x, const float* __restrict__ wb, const float* __restrict__ bias,
+                                                              float* __restrict__ y, double* __restrict__ stats) {
+    constexpr int KC = CIN / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = reinterpret_cast<float*>(smem);                   // [XH][XW][PS]
+    const int t = threadIdx.x, lane = t & 63, lg = lane >> 4, li = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int co0 = blockIdx.y * 16;
+    // B'[k = ci][j = co]: lane (lg, li) holds w[co0 + li][tap][4 * kc + lg].  The 16 filter rows of the block are contiguous in the K-major prepared filter:
+    // coalesced 16-B loads into LDS (row stride + 4 words: conflict-free fragment reads), then TAPS * KC ds_read_b32 per lane — gathering the fragments
+    // straight from global memory (16 cache lines per load instruction) cost 5.5 us per launch.
+    constexpr int WROW = TAPS * CIN, WRS = WROW + 4;
+    {
+        const float* wsrc = wb + (size_t)co0 * WROW;
+        for (int i = t; i < 16 * WROW / 4; i += 256) {
+            const int row = i / (WROW / 4), c4 = i - row * (WROW / 4);
+            *reinterpret_cast<float4*>(xs + row * WRS + c4 * 4) = *reinterpret_cast<const float4*>(wsrc + (size_t)row * WROW + c4 * 4);
+        }
+    }
+    __syncthreads();
+    float bf[TAPS][KC];
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) bf[tap][kc] = xs[li * WRS + tap * CIN + 4 * kc + lg];
+    const float bv = bias != nullptr ? bias[co0 + li] : 0.f;
+    __syncthreads();                                              // the filter slice is in registers: the buffer becomes the input tile
+    const int tile = blockIdx.x;
+    const int n = tile / a.tiles_per_img, ho0 = (tile - n * a.tiles_per_img) * a.TH;
+    const int th = (a.Hout - ho0 < a.TH) ? (a.Hout - ho0) : a.TH;
+    // staging: four 16-B loads in flight per thread before the first LDS store
+    const int nx = a.XH * a.XW * KC;
+    for (int i0 = t; i0 < nx; i0 += 4 * 256) {
+        float4 v[4]; bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * 256 < nx ? i0 + u * 256 : t;
+            const int c4 = i % KC, p = i / KC;
+            const int xr = p / a.XW, xc = p - xr * a.XW;
+            const int hi = ho0 - a.ph + xr, wi = xc - a.pw;
+            ok[u] = hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win;
+            const int hic = hi < 0 ? 0 : (hi >= a.Hin ? a.Hin - 1 : hi), wic = wi < 0 ? 0 : (wi >= a.Win ? a.Win - 1 : wi);
+            v[u] = *reinterpret_cast<const float4*>(x + (((size_t)n * a.Hin + hic) * a.Win + wic) * CIN + c4 * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * 256;
+            if (i < nx) *reinterpret_cast<float4*>(xs + (size_t)(i / KC) * a.PS + (i % KC) * 4) = ok[u] ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __syncthreads();
+    const int spr = a.Wout >> 4;                                  // 16-pixel segments per output row
+    const int nseg = th * spr;
+    float ssum = 0.f, ssq = 0.f;                                  // this lane's channel (li) over its pixels: BatchNorm statistics partials
+    for (int sg = wave; sg < nseg; sg += 4) {
+        const int hl = sg / spr, w0 = (sg - hl * spr) << 4;
+        const float* ap = xs + ((size_t)hl * a.XW + w0 + li) * a.PS + lg;     // A'[i = pixel][k = ci]
+        // all A operands of the segment are read from LDS before the first MFMA (an MFMA waiting on its own ds_read is a chain of LDS latencies), and
+        // two accumulators alternate so that consecutive MFMAs do not depend on each other
+        float av[TAPS][KC];
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int toff = ((tap / a.S) * a.XW + tap % a.S) * a.PS;
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) av[tap][kc] = ap[toff + 4 * kc];
+        }
+        __builtin_amdgcn_sched_barrier(0);                         // keep the reads up here: the scheduler otherwise sinks each one next to its MFMA
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                if ((tap * KC + kc) & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tap][kc], bf[tap][kc], acc2, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tap][kc], bf[tap][kc], acc, 0, 0, 0);
+            }
+        acc += acc2;
+        float* yp = y + (((size_t)n * a.Hout + ho0 + hl) * a.Wout + w0 + 4 * lg) * a.Cout + co0 + li;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const float v = dcv_act_apply(acc[reg] + bv, a.act, a.slope);
+            yp[(size_t)reg * a.Cout] = v;
+            ssum += v; ssq += v * v;
+        }
+    }
+    if (stats != nullptr) {
+        __shared__ float red[4][2][16];
+        ssum += __shfl_xor(ssum, 16, 64); ssum += __shfl_xor(ssum, 32, 64);
+        ssq += __shfl_xor(ssq, 16, 64); ssq += __shfl_xor(ssq, 32, 64);
+        if (lg == 0) { red[wave][0][li] = ssum; red[wave][1][li] = ssq; }
+        __syncthreads();
+        if (t < 32) {
+            const int q = t >> 4, c = t & 15;
+            const float v = (red[0][q][c] + red[1][q][c]) + (red[2][q][c] + red[3][q][c]);
+            stats[((size_t)q * a.Cout + co0 + c) * gridDim.x + blockIdx.x] = (double)v;
+        }
+    }
+}
+
+static bool halo_plan(const MfmaArgs& m, int math, HaloArgs* h, size_t* smem) {
+    static int enabled = -1;
+    if (enabled < 0) { const char* e = getenv("DCV_MFMA_HALO"); enabled = e ? atoi(e) : 1; }
+    if (!enabled || math != DCV_MATH_FP32 || m.phase) return false;
+    if (m.sh != 1 || m.sw != 1 || m.dh != 1 || m.dw != 1) return false;
+    if ((m.Cin != 16 && m.Cin != 32) || m.Cout % 16 != 0 || m.Wout % 16 != 0) return false;
+    const int taps = m.R * m.S;
+    if (!(taps == 9 || taps == 1 || (taps == 25 && m.Cin == 16))) return false;
+    h->N = m.N; h->Hin = m.Hin; h->Win = m.Win; h->Cin = m.Cin; h->Hout = m.Hout; h->Wout = m.Wout; h->Cout = m.Cout; h->R = m.R; h->S = m.S;
+    h->ph = m.ph; h->pw = m.pw; h->act = m.act; h->slope = m.slope;
+    h->PS = m.Cin + 4;
+    h->XW = m.Wout + m.S - 1;
+    int th = m.Hout;
+    size_t bytes;
+    for (;;) {
+        h->TH = th; h->XH = th + m.R - 1;
+        bytes = (size_t)h->XH * h->XW * h->PS * sizeof(float);
+        if (th == 1 || bytes <= 48 * 1024) break;
+        th = (th + 1) / 2;
+    }
+    if (bytes > 64 * 1024) return false;
+    const size_t wbytes = (size_t)16 * (taps * m.Cin + 4) * sizeof(float);     // the buffer first holds the block's filter slice
+    if (bytes < wbytes) bytes = wbytes;
+    h->tiles_per_img = (m.Hout + th - 1) / th;
+    h->total_tiles = m.N * h->tiles_per_img;
+    *smem = bytes;
+    return true;
+}
+
 template <bool BF16>
 static void launch_mfma(int bn, int bmr, dim3 grid, hipStream_t st, const MfmaArgs& a, const float* x, const float* wb, const float* bias, float* y, double* stats) {
     if (bmr == 4) hipLaunchKernelGGL((conv_mfma_kernel<64, 4, BF16>), grid, dim3(256), 0, st, a, x, wb, bias, y, stats);
@@ -434,6 +575,16 @@ static void launch_mfma(int bn, int bmr, dim3 grid, hipStream_t st, const MfmaAr
 }
 
 static int run_mfma(const MfmaArgs& a, const float* x, const float* wb, const float* bias, float* y, hipStream_t st, double* stats = nullptr, int math = DCV_MATH_FP32) {
+    HaloArgs h{}; size_t hsm;
+    if (halo_plan(a, math, &h, &hsm)) {
+        dim3 grid((unsigned)h.total_tiles, (unsigned)(a.Cout / 16));
+        const int taps = a.R * a.S;
+#define DCV_HALO(C_, T_) hipLaunchKernelGGL((conv_mfma_halo_kernel<C_, T_>), grid, dim3(256), hsm, st, h, x, wb, bias, y, stats)
+        if (a.Cin == 16) { if (taps == 9) DCV_HALO(16, 9); else if (taps == 25) DCV_HALO(16, 25); else DCV_HALO(16, 1); }
+        else { if (taps == 9) DCV_HALO(32, 9); else DCV_HALO(32, 1); }
+#undef DCV_HALO
+        return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
+    }
     const int bn = pick_bn(a.Cout);
     const int bmr = pick_bmr(a.M, a.Cin, a.Cout, bn);
     dim3 grid((unsigned)dcv_ceil_div((size_t)a.M, (size_t)64 * bmr), (unsigned)(a.Cout / bn));
@@ -443,6 +594,13 @@ static int run_mfma(const MfmaArgs& a, const float* x, const float* wb, const fl
 }
 
 int dcv_mfma_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d) {
+    {   // the halo kernel emits one row of partials per tile
+        MfmaArgs a{};
+        a.N = d->n; a.Hin = d->h; a.Win = d->w; a.Cin = d->cin; a.Hout = d->ho; a.Wout = d->wo; a.Cout = d->cout;
+        a.R = d->r; a.S = d->s; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
+        HaloArgs h{}; size_t hsm;
+        if (halo_plan(a, d->math, &h, &hsm)) return h.total_tiles;
+    }
     const long M = (long)d->n * d->ho * d->wo;
     return (int)dcv_ceil_div((size_t)M, (size_t)64 * pick_bmr(M, d->cin, d->cout, pick_bn(d->cout)));
 }

@@ -56,6 +56,12 @@ CONV_CASES = [
     (1, 128, 6, 6, 8, 3, 1, 1, 1, 0, False),       # > 256 wgrad units: un-tiled weight-gradient fallback
     (3, 4, 40, 24, 4, 3, 1, 1, 1, 1, False),       # several row tiles per image, ragged last tile (tiled weight gradient)
     (2, 3, 37, 29, 5, 5, 2, 2, 1, 0, True),        # strided + NCHW input + ragged tiles
+    # narrow MFMA forward / data gradient with the halo tile in LDS (16 / 32 input channels, widths multiples of 16): several output-channel tiles, row
+    # tiles, 32 input channels, 25 taps, 1x1
+    (4, 16, 32, 32, 32, 3, 1, 1, 1, 1, False),
+    (2, 32, 16, 16, 16, 3, 1, 1, 1, 2, False),
+    (2, 16, 48, 16, 16, 5, 1, 2, 1, 0, False),
+    (3, 16, 16, 16, 48, 1, 1, 0, 1, 4, False),
     # narrow MFMA weight gradient (channels multiples of 16 below the wide kernel's 64): 25 taps, 1x1, ragged widths / row tiles, several channel tiles
     (3, 32, 7, 10, 16, 5, 1, 2, 1, 1, False),
     (2, 16, 9, 9, 48, 1, 1, 0, 1, 0, False),
@@ -333,6 +339,7 @@ LAYER_CASES = [
     (8, 3, 32, 32, 4, 5, 1, 2, 1, 4, True),        # stock layer 1 (parameters.yml:12): BN + GN(4 groups), NCHW batch read in place
     (8, 4, 16, 16, 16, 3, 1, 1, 2, 4, False),      # stock layer 4, LeakyReLU epilogue
     (6, 16, 16, 16, 16, 3, 1, 1, 1, 0, False),     # BN only (image_classifier_bn_only_model), MFMA convolution
+    (5, 16, 32, 16, 32, 3, 1, 1, 1, 4, False),     # halo-tile MFMA convolution with statistics partials per tile, two output-channel tiles, BN + GN
     (3, 5, 9, 11, 6, 3, 1, 1, 3, 2, False),        # ragged sizes, C % 4 != 0 (scalar paths), sigmoid, 2 groups
     (2, 8, 12, 12, 12, 3, 2, 1, 4, 3, False),      # stride 2, tanh, 3 groups
     (70, 4, 8, 8, 8, 3, 1, 1, 0, 8, False),        # no activation; more samples than one wave of partials; one channel per group
