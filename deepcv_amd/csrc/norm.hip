@@ -648,6 +648,112 @@ __global__ __launch_bounds__(256) void nf_bn_apply_act_bwd_ew_kernel(NfApplyActL
     }
 }
 
+// ---- single-pass backward of the chain (samples which fit the threads' registers, no bias gradient wanted).  The two-pass kernel above forms dv, the
+// gradient w.r.t. the BatchNorm output, only to sum it: T1 = sum dv, T2 = sum dv * u.  With u = (x - bn_mean) * bn_rstd the GroupNorm input is affine in u
+// (v = bn_gamma * u + bn_beta, w = (v - mean_g) * rstd_g = alpha * u + beta'), so every sum of the chain follows from four moments per (sample, channel):
+// M0 = sum dout, M1 = sum dout * u, U1 = sum u, U2 = sum u^2 — one pass, one merge, no dv tensor (its 8 MB store was 3.7 of the kernel's 10.9 us).  The
+// block then does the per-sample algebra itself: the same per-sample partials S1, S2, T1, T2 as the two-pass kernel (-> the same finalize), plus three
+// coefficients per (sample, channel) with which the apply pass evaluates dz = act'(x) * (P * dout + (Q0 - a * d) * u + (R0 - a * b)) straight from dout
+// and x (a, b, d: the finalize's per-channel BatchNorm-backward terms).
+template <int VEC>
+__global__ __launch_bounds__(DCV_CR_THREADS) void nf_moments_kernel(const float* __restrict__ dout, const float* __restrict__ x, int HW, int C, int G,
+                                                                     const float* __restrict__ bn_gamma, const float* __restrict__ bn_beta,
+                                                                     const float* __restrict__ bn_mean, const float* __restrict__ bn_rstd,
+                                                                     const float* __restrict__ gn_gamma, const float* __restrict__ gn_mean, const float* __restrict__ gn_rstd,
+                                                                     double* __restrict__ partial, float* __restrict__ pre, NfPoolMap pm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* chan = reinterpret_cast<double*>(smem);                      // [4][C]
+    float* bm = reinterpret_cast<float*>(chan + 4 * (size_t)C);          // [C] BatchNorm mean, rstd
+    float* br = bm + C;
+    float* scratch = br + C;                                             // [4 * 256 * VEC]
+    const int n = blockIdx.x;
+    const size_t base = (size_t)n * HW * C;
+    const size_t dbase = pm.pk > 0 ? (size_t)n * (HW / (pm.pk * pm.pk)) * C : base;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) { bm[c] = bn_mean[c]; br[c] = bn_rstd[c]; }
+    __syncthreads();
+    const int CV = C / VEC;
+    const int rpi = DCV_CR_THREADS / CV, cv0 = (threadIdx.x % CV) * VEC, rsub = threadIdx.x / CV;
+    float acc[4][VEC];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[q][v] = 0.f;
+    if ((int)threadIdx.x < rpi * CV) {
+#pragma unroll
+        for (int k = 0; k < NF_NR; ++k) {
+            const int r = rsub + k * rpi;
+            if (r < HW) {
+                float xv[VEC], dv[VEC];
+                nf_load_vec4(x + base + (size_t)r * C + cv0, xv);
+                nf_load_dout<VEC>(dout + dbase, pm, (size_t)r * C + cv0, cv0, dv);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const float u = (xv[v] - bm[cv0 + v]) * br[cv0 + v];
+                    acc[0][v] += dv[v]; acc[1][v] += dv[v] * u; acc[2][v] += u; acc[3][v] += u * u;
+                }
+            }
+        }
+    }
+    dcv_colreduce_merge<4, VEC>(acc, C, scratch, chan);                  // M0, M1, U1, U2 of this sample; ends with a barrier
+    const int cpg = C / G;
+    const double hw = (double)HW, m = (double)cpg * hw;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / cpg;
+        const double gr = (double)gn_rstd[(size_t)n * G + g], gmean = (double)gn_mean[(size_t)n * G + g];
+        double A = 0.0, B = 0.0;                                          // group sums of gamma * S1, gamma * S2
+        for (int k = g * cpg; k < (g + 1) * cpg; ++k) {
+            const double gmk = gn_gamma ? (double)gn_gamma[k] : 1.0;
+            const double al = (bn_gamma ? (double)bn_gamma[k] : 1.0) * gr, be = ((bn_beta ? (double)bn_beta[k] : 0.0) - gmean) * gr;
+            A += gmk * chan[k]; B += gmk * (al * chan[C + k] + be * chan[k]);
+        }
+        const double gbc = bn_gamma ? (double)bn_gamma[c] : 1.0;
+        const double al = gbc * gr, be = ((bn_beta ? (double)bn_beta[c] : 0.0) - gmean) * gr;
+        const double ca = (gn_gamma ? (double)gn_gamma[c] : 1.0) * gr, cb = (A / m) * gr, cd = (B / m) * gr;
+        const double m0 = chan[c], m1 = chan[C + c], u1 = chan[2 * C + c], u2 = chan[3 * C + c];
+        const size_t N = gridDim.x;
+        partial[(size_t)c * N + n] = m0;                                                         // S1 = sum dout
+        partial[((size_t)C + c) * N + n] = al * m1 + be * m0;                                    // S2 = sum dout * w
+        partial[(2 * (size_t)C + c) * N + n] = ca * m0 - cb * hw - cd * (al * u1 + be * hw);     // T1 = sum dv
+        partial[(3 * (size_t)C + c) * N + n] = ca * m1 - cb * u1 - cd * (al * u2 + be * u1);     // T2 = sum dv * u
+        const double a = gbc * (double)br[c];
+        float* pf = pre + (size_t)n * 3 * C;
+        pf[c] = (float)(a * ca); pf[C + c] = (float)(-a * al * cd); pf[2 * C + c] = (float)(-a * (cb + be * cd));
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void nf_moments_apply_kernel(const float* __restrict__ dout, const float* __restrict__ x, float* __restrict__ dz, int HW, int C,
+                                                                const float* __restrict__ pre, const float* __restrict__ coef /* a, b, d [C] each */,
+                                                                const float* __restrict__ bn_mean, const float* __restrict__ bn_rstd,
+                                                                int act, float slope, NfPoolMap pm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* cf = reinterpret_cast<float*>(smem);                          // [3][C]: P, Q, R of this sample, then BatchNorm mean, rstd [C] each
+    float* bm = cf + 3 * C; float* br = bm + C;
+    const int n = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float* pf = pre + (size_t)n * 3 * C;
+        const float a = coef[c], b = coef[C + c], d = coef[2 * C + c];
+        cf[c] = pf[c]; cf[C + c] = pf[C + c] - a * d; cf[2 * C + c] = pf[2 * C + c] - a * b;
+        bm[c] = bn_mean[c]; br[c] = bn_rstd[c];
+    }
+    __syncthreads();
+    const size_t base = (size_t)n * HW * C;
+    const size_t dbase = pm.pk > 0 ? (size_t)n * (HW / (pm.pk * pm.pk)) * C : base;
+    const int CV = C / VEC, nv = HW * CV;
+    for (int i = threadIdx.x; i < nv; i += blockDim.x) {
+        const int c = (i % CV) * VEC;
+        float xv[VEC], dv[VEC], o[VEC];
+        nf_load_vec4(x + base + (size_t)i * VEC, xv);
+        nf_load_dout<VEC>(dout + dbase, pm, (size_t)i * VEC, c, dv);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const float u = (xv[v] - bm[c + v]) * br[c + v];
+            o[v] = (cf[c + v] * dv[v] + cf[C + c + v] * u + cf[2 * C + c + v]) * dcv_act_grad_from_out(xv[v], act, slope);
+        }
+        nf_store_vec4(dz + base + (size_t)i * VEC, o);
+    }
+}
+
 // ================================================================================================ split-phase BatchNorm (cross-GPU statistics)
 // `use_sync_batch_norm` (reference ignite_training.py:386-388, torch.nn.SyncBatchNorm): every reduction over the batch is cut in two so that the caller
 // can all-reduce the per-channel sums between the phases (collective C4 of SURVEY.md §2.3, 2 * C doubles).
@@ -828,7 +934,7 @@ static inline size_t nf_partial_bytes(int n, int hw, int C) {
 
 size_t dcv_norm_chain_workspace_bytes(int n, int hw, int channels) {
     if (n <= 0 || hw <= 0 || channels <= 0) return 0;
-    return nf_partial_bytes(n, hw, channels) + dcv_align_up((size_t)3 * channels * sizeof(float), 256);
+    return nf_partial_bytes(n, hw, channels) + dcv_align_up((size_t)3 * channels * sizeof(float), 256) + dcv_align_up((size_t)n * 3 * channels * sizeof(float), 256);
 }
 
 int dcv_bn_gn_fwd_train(const float* x, float* y, int n, int hw, int C,
@@ -911,6 +1017,25 @@ int dcv_bn_gn_pool_act_bwd(const float* dout, const float* x, float* dz, int n, 
     if (G > 0) {
         const size_t smem = 4 * (size_t)C * sizeof(double) + (size_t)9 * C * sizeof(float) + (size_t)2 * DCV_CR_THREADS * vec * sizeof(float);
         if (smem > 64 * 1024) return DCV_ERR_UNSUPPORTED;
+        static int moments = -1;
+        if (moments < 0) { const char* e = getenv("DCV_NORM_MOMENTS"); moments = e ? atoi(e) : 1; }
+        if (moments && !d_bias && nf_sample_fits_registers(hw, C, vec)) {
+            // single-pass variant: moments + per-sample algebra -> the regular finalize (parameter gradients, a / b / d) -> apply from dout and x
+            float* pre = coef + dcv_align_up((size_t)3 * C * sizeof(float), 256) / sizeof(float);              // [N][3][C]
+            const size_t msm = 4 * (size_t)C * sizeof(double) + (size_t)2 * C * sizeof(float) + (size_t)4 * DCV_CR_THREADS * vec * sizeof(float);
+            if (msm > 64 * 1024) return DCV_ERR_UNSUPPORTED;
+            if (vec == 4) hipLaunchKernelGGL((nf_moments_kernel<4>), dim3(n), dim3(DCV_CR_THREADS), msm, st, dout, x, hw, C, G, bn_gamma, bn_beta, bn_save_mean, bn_save_rstd,
+                                             gn_gamma, gn_save_mean, gn_save_rstd, partial, pre, pm);
+            else hipLaunchKernelGGL((nf_moments_kernel<1>), dim3(n), dim3(DCV_CR_THREADS), msm, st, dout, x, hw, C, G, bn_gamma, bn_beta, bn_save_mean, bn_save_rstd,
+                                    gn_gamma, gn_save_mean, gn_save_rstd, partial, pre, pm);
+            hipLaunchKernelGGL(nf_gn_bn_finalize_kernel, dim3((unsigned)C), dim3(FIN_THREADS), 0, st, partial, n, rows, C, bn_gamma, bn_save_rstd,
+                               d_bn_gamma, d_bn_beta, d_gn_gamma, d_gn_beta, coef);
+            if (vec == 4) hipLaunchKernelGGL((nf_moments_apply_kernel<4>), dim3(n), dim3(256), (size_t)5 * C * sizeof(float), st, dout, x, dz, hw, C, pre, coef,
+                                             bn_save_mean, bn_save_rstd, act, slope, pm);
+            else hipLaunchKernelGGL((nf_moments_apply_kernel<1>), dim3(n), dim3(256), (size_t)5 * C * sizeof(float), st, dout, x, dz, hw, C, pre, coef,
+                                    bn_save_mean, bn_save_rstd, act, slope, pm);
+            DCV_RETURN_LAUNCH();
+        }
 #define NF_BWD_LAUNCH(V_, C_) hipLaunchKernelGGL((nf_gn_bn_bwd_kernel<V_, C_>), dim3(n), dim3(DCV_CR_THREADS), smem, st, dout, x, dz, hw, C, G, bn_gamma, bn_beta, \
                                                  bn_save_mean, bn_save_rstd, gn_gamma, gn_save_mean, gn_save_rstd, partial, pm)
         const bool cached = nf_sample_fits_registers(hw, C, vec);

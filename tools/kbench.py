@@ -36,6 +36,25 @@ elif case.endswith('p') and case[:-1] in CONVS:   # as the training step launche
     stats = torch.empty((2, cfg[4], max(1, rows)), dtype=torch.float64, device=dev)
     sp = stats.data_ptr() if rows > 0 else None
     fn = lambda: nat.check(nat.lib.dcv_conv2d_fwd_prepared(d, x.data_ptr(), wt.data_ptr(), filt.data_ptr(), b.data_ptr(), y.data_ptr(), sp, st))
+elif case in ('normbwd4', 'normbwd16', 'normfwd4'):     # fused norm chain of the stock layers: [512, 32, 32, 4] / [512, 16, 16, 16], 4 groups
+    c, hw = (4, 32 * 32) if case.endswith('4') else (16, 16 * 16)
+    cfg = (NB, c, 1, 1, 1, 1, 0)
+    xx = torch.randn(NB, hw, c, device=dev); dout = torch.randn(NB, hw, c, device=dev); dz = torch.empty_like(xx); yy = torch.empty_like(xx)
+    vec = lambda: torch.rand(c, device=dev) + 0.5
+    bw, bb, gw, gb, bm, br = vec(), vec(), vec(), vec(), vec(), vec()
+    G = 4 if c >= 4 else 1
+    gm, gr = torch.rand(NB * G, device=dev), torch.rand(NB * G, device=dev) + 0.5
+    grads = [torch.empty(c, device=dev) for _ in range(4)]
+    rm, rv, nbt = torch.zeros(c, device=dev), torch.ones(c, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)
+    ws = torch.empty(nat.lib.dcv_norm_chain_workspace_bytes(NB, hw, c), dtype=torch.uint8, device=dev)
+    if case.startswith('normbwd'):
+        fn = lambda: nat.check(nat.lib.dcv_bn_gn_act_bwd(dout.data_ptr(), xx.data_ptr(), dz.data_ptr(), NB, hw, c, bw.data_ptr(), bb.data_ptr(), bm.data_ptr(), br.data_ptr(),
+                                                         G, gw.data_ptr(), gm.data_ptr(), gr.data_ptr(), nat.ACT_RELU, 0., grads[0].data_ptr(), grads[1].data_ptr(),
+                                                         grads[2].data_ptr(), grads[3].data_ptr(), None, ws.data_ptr(), ws.numel(), st))
+    else:
+        fn = lambda: nat.check(nat.lib.dcv_bn_gn_fwd_train(xx.data_ptr(), yy.data_ptr(), NB, hw, c, bw.data_ptr(), bb.data_ptr(), rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(), 0.1, 1e-5,
+                                                           bm.data_ptr(), br.data_ptr(), G, gw.data_ptr(), gb.data_ptr(), 1e-5, gm.data_ptr(), gr.data_ptr(), None, 0,
+                                                           ws.data_ptr(), ws.numel(), st))
 elif case in CONVS:
     cfg = CONVS[case]
     x, wt, b, y, dy, d = conv_case(*cfg)
