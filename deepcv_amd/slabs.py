@@ -15,6 +15,7 @@ nothing can read it before the flush: plain first-order backward, the parameter'
 it to an existing one) and the parameter was used by a single forward op since the last flush (otherwise the engine sums the contributions itself). """
 import ctypes
 import threading
+import weakref
 from typing import Dict, List, Tuple
 
 import torch
@@ -30,7 +31,7 @@ _pending: List[Tuple[torch.device, int, List[nat.SlabSegment], torch.Tensor]] = 
 _wgrads: List[Tuple[torch.device, int, 'nat.WgradJob', tuple]] = []                  # (device, stream handle, job, tensors kept alive: x, dz, workspace)
 _callback_queued = False
 _pass_id = None                       # autograd graph-task id of the backward pass the pending work belongs to
-_uses: Dict[int, List[int]] = {}      # id(parameter) -> [forward uses whose backward has not run yet, peak of that count]
+_uses: Dict[int, list] = {}           # id(parameter) -> [forward uses whose backward has not run yet, peak of that count, weak reference]
 
 
 def enabled() -> bool:
@@ -53,7 +54,9 @@ def note_use(*params):
         with _lock:
             for p in params:
                 if p is not None:
-                    u = _uses.setdefault(id(p), [0, 0])
+                    u = _uses.get(id(p))
+                    if u is None or u[2]() is not p:          # ids are reused: an entry left by a dead tensor must not count for a new one
+                        u = _uses[id(p)] = [0, 0, weakref.ref(p)]
                     u[0] += 1
                     u[1] = max(u[1], u[0])
 
@@ -64,6 +67,9 @@ def may_defer(*params) -> bool:
         single = True
         for p in params:
             u = _uses.get(id(p)) if p is not None else None
+            if u is not None and u[2]() is not p:
+                del _uses[id(p)]
+                u = None
             if u is not None:
                 single = single and u[1] <= 1
                 u[0] -= 1
