@@ -415,29 +415,37 @@ __global__ __launch_bounds__(256) void resize_concat_kernel(ResizeConcatTable t,
 // ------------------------------------------------------------------------------------------------ ordered sums of partial slabs
 // dst[i] = sum over k < chunks of src[k * stride + i] for up to DCV_MAX_SLAB_SEGMENTS independent segments in one launch (second stage of the weight
 // gradients).  Block = 8 entries x 128 slab lanes: a thread adds chunks / 128 slabs (a short load chain: this kernel is pure latency), the 8 slab lanes
-// of a wave are merged by a fixed xor butterfly, the 16 waves in order through LDS -> the result only depends on (chunks, entry), not on the launch shape.
+// of a wave are merged by a fixed xor butterfly, the 16 waves in order through LDS -> the result only depends on (segment shape, entry), not on the launch.
+// Long segments (>= SLAB_WIDE_COUNT entries: the linear layer's 12.8 k, a 16->16 3x3 filter's 2.3 k) use blocks of 32 entries x 32 slab lanes instead:
+// 128-B runs per slab row instead of 32-B ones (8.5 of this kernel's 9.5 MB on the stock step).
 #define SLAB_W 8
+#define SLAB_WIDE 32
+#define SLAB_WIDE_COUNT 1024
 struct SlabTable {
     int count;
+    int wshift[DCV_MAX_SLAB_SEGMENTS];      // log2 of the segment's entries per block (3 or 5)
     int block_start[DCV_MAX_SLAB_SEGMENTS + 1];
     dcv_slab_segment seg[DCV_MAX_SLAB_SEGMENTS];
 };
 
 __global__ __launch_bounds__(1024) void slab_reduce_kernel(SlabTable t) {
-    __shared__ float red[16][SLAB_W];
+    __shared__ float red[16][SLAB_WIDE];
     int si = 0;
     while (si + 1 < t.count && (int)blockIdx.x >= t.block_start[si + 1]) ++si;          // wave-uniform: scalar loop
     const dcv_slab_segment& g = t.seg[si];
-    const int wl = threadIdx.x & (SLAB_W - 1), cl = threadIdx.x >> 3, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const size_t wi = (size_t)((int)blockIdx.x - t.block_start[si]) * SLAB_W + wl;
+    const int ws = t.wshift[si], W = 1 << ws, lanes = 1024 >> ws;
+    const int wl = threadIdx.x & (W - 1), cl = threadIdx.x >> ws, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t wi = ((size_t)((int)blockIdx.x - t.block_start[si]) << ws) + wl;
     const float* __restrict__ src = g.src;
     float s = 0.f;
-    if (wi < g.count)
-        for (int c = cl; c < g.chunks; c += 128) s += src[(size_t)c * g.stride + wi];
-    s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-    if (lane < SLAB_W) red[wave][lane] = s;
+    if (wi < g.count) {
+#pragma unroll 4
+        for (int c = cl; c < g.chunks; c += lanes) s += src[(size_t)c * g.stride + wi];
+    }
+    for (int off = W; off < 64; off <<= 1) s += __shfl_xor(s, off, 64);
+    if (lane < W) red[wave][lane] = s;
     __syncthreads();
-    if (threadIdx.x < SLAB_W && wi < g.count) {
+    if ((int)threadIdx.x < W && wi < g.count) {
         float v = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) v += red[k][threadIdx.x];
@@ -462,9 +470,11 @@ int dcv_launch_slab_reduce(int n, const dcv_slab_segment* segments, hipStream_t 
             if (!g.src || !g.dst || g.chunks < 1 || g.stride < g.count) return DCV_ERR_INVALID_ARG;
             if (g.tr_a < 0 || g.tr_b < 0 || ((g.tr_a > 0) != (g.tr_b > 0)) || (g.tr_a > 0 && g.count % ((unsigned long long)g.tr_a * g.tr_b) != 0)) return DCV_ERR_INVALID_ARG;
             if (g.count == 0) continue;
+            const int ws = g.count >= SLAB_WIDE_COUNT ? 5 : 3;
             t.block_start[t.count] = blocks;
+            t.wshift[t.count] = ws;
             t.seg[t.count++] = g;
-            blocks += (int)dcv_ceil_div((size_t)g.count, SLAB_W);
+            blocks += (int)dcv_ceil_div((size_t)g.count, (size_t)1 << ws);
         }
         t.block_start[t.count] = blocks;
         if (blocks > 0) hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, t);
