@@ -10,7 +10,8 @@ uses for the same purpose).  Inside a hipGraph capture the callback is captured 
 it: `defer_wgrad` queues the whole problem, and the flush hands all of them to `dcv_conv2d_wgrad_batch`, which runs the stock layers' kernels as block
 ranges of ONE multi-problem launch (one launch floor instead of five, and the staging / FMA / merge phases of different layers overlap on the CUs).
 
-The result is bit-identical to the immediate entry points (same kernel, the sum order only depends on the slab count).  A gradient is only deferred when
+The arithmetic is that of the immediate entry points (same kernels, fixed summation orders which only depend on the number of partial slabs; layers
+sharing a multi-layer launch use half as many, longer blocks than a layer launched alone, so large layers differ from the immediate path in the last bits).  A gradient is only deferred when
 nothing can read it before the flush: plain first-order backward, the parameter's `.grad` is empty (the engine then adopts the tensor instead of adding
 it to an existing one) and the parameter was used by a single forward op since the last flush (otherwise the engine sums the contributions itself). """
 import ctypes

@@ -89,7 +89,7 @@ int dcv_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, 
 /* Deferred second stage.  Weight gradients are produced in two stages: per-block partial slabs, then an ordered sum of the slabs.  On small layers the second
  * stage is a ~5 us launch whose result nobody reads before the optimizer (or the gradient all-reduce), so a training step may postpone it and sum the slabs
  * of ALL its layers in ONE launch: the *_deferred variants run stage one only and describe the pending sums as up to two segments (weights, bias);
- * dcv_slab_reduce executes any number of segments in one launch (dst[i] = sum over k < chunks of src[k * stride + i], fixed order: bit-identical to
+ * dcv_slab_reduce executes any number of segments in one launch (dst[i] = sum over k < chunks of src[k * stride + i], fixed order: the arithmetic of
  * the immediate entry points).  `*n_segments == 0` on return: the back-end summed immediately (nothing is pending).  Until the segments have been
  * reduced the workspace `ws` must stay untouched. */
 typedef struct dcv_slab_segment {
