@@ -919,3 +919,35 @@ def test_gradients_written_into_the_all_reduce_bucket(device):
             _check(f'arena accumulate {n}', p[n].grad, 2 * ref[n].grad, 1e-5)
     finally:
         grads.unregister(p.values())
+
+
+def test_weight_gradient_batch_with_many_mixed_layers(device):
+    """ One backward pass with more layers than a multi-problem launch holds (WG_MULTI_MAX = 8) and with layers the shared slide launch does not take
+    (stride 2, 7x7, 1x1, a 64-channel MFMA layer, an NCHW first layer): `dcv_conv2d_wgrad_batch` must split / route them and every gradient must equal
+    the immediate per-layer path. """
+    from deepcv_amd import ops, slabs, _native as nat
+    torch.manual_seed(31)
+    specs = [(3, 8, 5, 1, 2, True), (8, 8, 3, 1, 1, False), (8, 8, 3, 1, 1, False), (8, 16, 3, 2, 1, False), (16, 16, 3, 1, 1, False), (16, 16, 1, 1, 0, False),
+             (16, 64, 3, 1, 1, False), (64, 64, 3, 1, 1, False), (64, 8, 3, 1, 1, False), (8, 8, 7, 1, 3, False), (8, 4, 5, 1, 2, False), (4, 4, 5, 1, 2, False),
+             (4, 4, 3, 1, 1, False)]
+    base = [(torch.randn(co, ci, k, k, device=device) * (0.5 / (ci * k * k) ** 0.5), torch.randn(co, device=device) * 0.1) for ci, co, k, _, _, _ in specs]
+    x0 = torch.randn(4, 3, 32, 32, device=device)                  # NCHW batch: the first layer reads it in place
+
+    def run(enabled):
+        prev = slabs.set_enabled(enabled)
+        try:
+            ps = [(torch.nn.Parameter(w.clone()), torch.nn.Parameter(b.clone())) for w, b in base]
+            h = x0
+            for (w, b), (_, _, _, stride, pad, _) in zip(ps, specs):
+                h = ops.conv2d(h, w, b, stride=stride, padding=pad, act=nat.ACT_TANH)
+            (h * h).sum().backward()
+            assert slabs.pending() == 0
+            torch.cuda.synchronize()
+            return [(w.grad, b.grad) for w, b in ps]
+        finally:
+            slabs.set_enabled(prev)
+
+    ref, got = run(False), run(True)
+    for i, ((rw, rb), (gw, gb)) in enumerate(zip(ref, got)):
+        _check(f'batch wgrad layer {i} {specs[i]} dw', gw, rw, 1e-5)
+        _check(f'batch wgrad layer {i} {specs[i]} db', gb, rb, 1e-5)
