@@ -951,3 +951,39 @@ def test_weight_gradient_batch_with_many_mixed_layers(device):
     for i, ((rw, rb), (gw, gb)) in enumerate(zip(ref, got)):
         _check(f'batch wgrad layer {i} {specs[i]} dw', gw, rw, 1e-5)
         _check(f'batch wgrad layer {i} {specs[i]} db', gb, rb, 1e-5)
+
+
+def test_fused_pairs_in_eval_mode(device):
+    """ Evaluation mode: no layer + pooling fusion (the fused kernels are training kernels), the `Flatten` + fully connected pair still reads the NHWC
+    activations in place; outputs equal the module-by-module forward, and running statistics are not touched. """
+    from deepcv_amd.classification.image import create_model
+    from deepcv_amd.meta import base_module
+    from deepcv_amd.meta.data.datasets import SyntheticImageDataset
+    from deepcv_amd.utils import load_parameters
+    torch.manual_seed(9)
+    model = create_model({'trainset': SyntheticImageDataset(2, (3, 32, 32), 10)}, load_parameters()['image_classifier_model']).to(device).eval()
+    x = torch.randn(8, 3, 32, 32, device=device)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    calls = []
+    orig = base_module.DeepcvModule._fused_pair
+
+    def spy(subm, nxt, xx):
+        r = orig(subm, nxt, xx)
+        calls.append((type(subm).__name__, r is not None))
+        return r
+    base_module.DeepcvModule._fused_pair = staticmethod(spy)
+    try:
+        with torch.no_grad():
+            fused = model(x)
+    finally:
+        base_module.DeepcvModule._fused_pair = orig
+    assert [c for c in calls if c[1]] == [('Flatten', True)], calls
+    base_module.DeepcvModule._fused_pair = staticmethod(lambda subm, nxt, xx: None)
+    try:
+        with torch.no_grad():
+            plain = model(x)
+    finally:
+        base_module.DeepcvModule._fused_pair = orig
+    _check('eval fused pairs', fused, plain, 1e-6)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, state[k]), k
