@@ -10,7 +10,11 @@ all-reduce (N > 1) and AdamW update with the stock piecewise-linear LR schedule,
 Rank 0 prints ONE JSON line.  Besides the whole-job throughput it carries
   * `roofline`: the dominant kernel (direct 5x5 4->4 convolution, `conv_tile_kernel<4,5,2>`, 4 launches per step: 2 forward + 2 data-gradient), timed
     live with HIP events on the launch stream; achieved = algorithmic bytes per launch (SURVEY.md §8d) / average launch duration, against 8 TB/s HBM;
-  * `cpu_baseline`: the PyTorch-CPU oracle restatement of the same step on the host cores of this box, on a bounded sample (rank 0, N = 1 only). """
+  * `cpu_baseline`: the PyTorch-CPU oracle restatement of the same step on the host cores of this box, on a bounded sample (rank 0, N = 1 only);
+  * `parity`: the losses of the first PARITY_STEPS steps of THIS run (same seeds, batches and schedule) against the CPU oracle, outside the timed region;
+    at N = 1 a relative loss error above 1e-4 (BASELINE.json `north_star`) makes the run exit non-zero;
+  * `secondary` (N = 1): the wide-channel MFMA convolution kernels (fwd / dgrad / wgrad, fraction of the 157.3 TFLOP/s fp32 matrix peak) and the
+    whole-step throughput of the two build-authored wide specs (BASELINE.json configs 3 / 5) — reported beside the headline, never instead of it. """
 import argparse
 import json
 import os
@@ -33,6 +37,10 @@ MODEL_SEED = 563454     # conf/base/parameters.yml:119
 DATA_SEED = 434546      # conf/base/parameters.yml:183
 POOL = 16
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
+PARITY_STEPS = 6
+PARITY_BAR = 1e-4
 
 
 def _make_batches(n, bs, seed, device=None):
@@ -105,12 +113,136 @@ def dominant_kernel_roofline(device, launches: int = 200):
     algo_bytes = 4 * (n * h * w * c + c * c * k * k + n * h * w * c)
     achieved = algo_bytes / (us * 1e-6) / 1e9
     traffic = None
-    pmc = ROOT / 'profiles' / 'r01_pmc_conv_tile_traffic.json'
-    if pmc.exists():
-        traffic = json.loads(pmc.read_text()).get('traffic_bytes_per_launch')
+    traffic_src = None
+    for pmc in sorted((ROOT / 'profiles').glob('r*_pmc_conv_tile_traffic.json'), reverse=True):      # the latest round's PMC passes (tools/pmc_traffic.py)
+        rec = json.loads(pmc.read_text())
+        traffic, traffic_src = rec.get('traffic_bytes_per_launch'), f'{pmc.name} @ {rec.get("commit", "?")}'
+        break
     return {'bound': 'hbm', 'kernel': 'conv_tile_kernel<4,5,2> (dcv_conv2d_fwd_prepared, 512x32x32x4 -> 4, 5x5)', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
             'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE)',
+            'traffic_source': traffic_src,
             'avg_launch_us': round(us, 2), 'algorithmic_bytes_per_launch': algo_bytes}
+
+
+def _milestones(total_iters: int, lr: float):
+    return [[0, 0.0], [int(0.2 * total_iters), lr], [total_iters, 0.0]]
+
+
+def parity_check(params, got_losses, total_iters: int, world: int):
+    """ The first steps of this run replayed by the CPU oracle: same model seed, same batches (rank r draws its pool from DATA_SEED + r), same optimizer
+    options and LR schedule.  With several ranks the oracle emulates DistributedDataParallel (per-shard BatchNorm statistics, mean of the rank gradients);
+    the loss compared is rank 0's.  Returns the `parity` object of the JSON line. """
+    from oracle import deepcv_oracle as O
+    steps = len(got_losses)
+    hp = dict(params['train_image_classifier'])
+    torch.manual_seed(MODEL_SEED)
+    model = O.create_model(IMAGE_SHAPE, params['image_classifier_model'], NUM_CLASSES)
+    ms = _milestones(total_iters, hp['optimizer_opts']['lr'])
+    per_rank = [_make_batches(steps, BATCH_PER_GPU, DATA_SEED + r) for r in range(world)]
+    if world == 1:
+        ref = O.train_steps(model, per_rank[0], hp, steps, lr_fn=lambda t: O.piecewise_linear(ms, t))
+    else:
+        # global batch whose rows r::world are rank r's batch (the sharding `train_steps_data_parallel` applies)
+        glob = []
+        for t in range(steps):
+            x = torch.stack([per_rank[r][t][0] for r in range(world)], 1).reshape(world * BATCH_PER_GPU, *IMAGE_SHAPE)
+            y = torch.stack([per_rank[r][t][1] for r in range(world)], 1).reshape(world * BATCH_PER_GPU)
+            glob.append((x, y))
+        hp_dp = dict(hp, epochs=1)
+        ref = [l[0] for l in O.train_steps_data_parallel(model, glob, hp_dp, steps, world, iterations_per_epoch=total_iters, lr_fn=lambda t: O.piecewise_linear(ms, t))]
+    errs = [abs(a - b) / abs(b) for a, b in zip(got_losses, ref)]
+    return {'steps': steps, 'max_rel_loss_err': float(f'{max(errs):.3e}'), 'bar': PARITY_BAR, 'pass': bool(max(errs) <= PARITY_BAR),
+            'losses': [round(v, 6) for v in got_losses], 'oracle_losses': [round(v, 6) for v in ref],
+            'against': 'oracle/deepcv_oracle.py (PyTorch-CPU restatement; parity unpinned by the reference, DESIGN.md §2)'}
+
+
+def _time_launches(fn, launches: int, warm: int = 5) -> float:
+    """ Average duration in us of `fn()` (one kernel launch on torch's current stream), HIP events on that stream. """
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(launches):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / launches
+
+
+def secondary_measurements(device, params, launches: int = 20):
+    """ North-star MFMA target on the record (never the headline): per-kernel TFLOP/s of the wide 3x3 convolutions of `cifar100_deep` at N = 512 through the
+    C-ABI (fp32 MFMA; fraction of 157.3 TFLOP/s) and whole-step images/s of the two wide specs (fwd + CE + bwd + SGD-momentum, fp32 and bf16 MFMA math). """
+    from deepcv_amd import _native as nat
+    out = []
+    st = nat.current_stream(device)
+    cl = torch.channels_last
+    for cin, hw in ((64, 32), (128, 16), (512, 4)):
+        n, k = BATCH_PER_GPU, 3
+        x = torch.randn(n, cin, hw, hw, device=device).contiguous(memory_format=cl)
+        dy = torch.randn(n, cin, hw, hw, device=device).contiguous(memory_format=cl)
+        y, dx = torch.empty_like(x), torch.empty_like(x)
+        wt = torch.randn(cin, cin, k, k, device=device) * 0.05
+        b, dw = torch.zeros(cin, device=device), torch.empty_like(wt)
+        flops = 2.0 * n * hw * hw * cin * cin * k * k
+        for math, peak in ((nat.MATH_FP32, MFMA_F32_PEAK_TF), (nat.MATH_BF16, MFMA_BF16_PEAK_TF)):
+            d = nat.Conv2dDesc(n, hw, hw, cin, cin, k, k, 1, 1, 1, 1, 1, 1, 1, hw, hw, nat.LAYOUT_NHWC, nat.ACT_RELU, 0., math)
+            dd = nat.Conv2dDesc.from_buffer_copy(d)
+            ws = torch.empty(max(16, nat.lib.dcv_conv2d_fwd_workspace_bytes(d), nat.lib.dcv_conv2d_dgrad_workspace_bytes(dd), nat.lib.dcv_conv2d_wgrad_workspace_bytes(d)),
+                             dtype=torch.uint8, device=device)
+            runs = {
+                'fwd': lambda: nat.check(nat.lib.dcv_conv2d_fwd(d, x.data_ptr(), wt.data_ptr(), b.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(), st), 'dcv_conv2d_fwd'),
+                'dgrad': lambda: nat.check(nat.lib.dcv_conv2d_dgrad(dd, dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), ws.data_ptr(), ws.numel(), st), 'dcv_conv2d_dgrad'),
+                'wgrad': lambda: nat.check(nat.lib.dcv_conv2d_wgrad(d, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), None, ws.data_ptr(), ws.numel(), st), 'dcv_conv2d_wgrad'),
+            }
+            for op, fn in runs.items():
+                us = _time_launches(fn, launches)
+                tf = flops / us / 1e6
+                out.append({'kind': 'kernel', 'op': f'conv3x3 {cin}->{cin} @{hw}x{hw} N={n} {op}', 'math': 'f32' if math == nat.MATH_FP32 else 'bf16-operands',
+                            'avg_launch_us': round(us, 1), 'achieved': round(tf, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(tf / peak, 4),
+                            'note': 'dcv_conv2d_%s incl. its filter re-layout / split-K reduction launches' % op})
+        del x, dy, y, dx
+    out.extend(_wide_model_steps(device, params))
+    return out
+
+
+def _wide_model_steps(device, params):
+    from deepcv_amd import modules, ops, optim
+    from deepcv_amd.classification.image import create_model
+    from deepcv_amd.meta.data.datasets import SyntheticImageDataset
+    from deepcv_amd.meta.ignite_training import GraphedTrainStep, _setup_losses
+    res = []
+    for spec, shape, nc, bs in (('cifar100_deep_model', (3, 32, 32), 100, 512), ('resnet18_style_model', (3, 224, 224), 1000, 64)):
+        for math in ('fp32', 'bf16'):
+            prev = ops.set_conv_math(math)
+            try:
+                torch.manual_seed(MODEL_SEED)
+                model = create_model({'trainset': SyntheticImageDataset(2, shape, nc)}, params[spec]).to(device)
+                opt = optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=5e-4)
+                losses, weights = _setup_losses(modules.CrossEntropyLoss(), None, device)
+                step = GraphedTrainStep(model, opt, losses, weights)
+                g = torch.Generator().manual_seed(DATA_SEED)
+                batches = [(torch.randn(bs, *shape, generator=g).to(device), torch.randint(0, nc, (bs,), generator=g).to(device)) for _ in range(2)]
+
+                def one(i):
+                    out, _ = step._on_side_stream(step._eager, *batches[i % 2])
+                    return out['main_loss'].item()
+                for i in range(3):
+                    one(i)
+                torch.cuda.synchronize()
+                t0, k = time.perf_counter(), 8
+                for i in range(k):
+                    last = one(i)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                res.append({'kind': 'model', 'workload': f'{spec} {shape[0]}x{shape[1]}x{shape[2]} bs={bs}: fwd + CE + bwd + SGD-momentum, eager launches, per-step loss read-back',
+                            'math': 'f32' if math == 'fp32' else 'bf16-operands (fp32 accumulate / storage / master weights)',
+                            'value': round(bs * k / dt, 1), 'unit': 'images/sec', 'ms_per_step': round(dt / k * 1e3, 3), 'final_loss': round(last, 4)})
+                del model, opt, step, batches
+            finally:
+                ops.set_conv_math(prev)
+            torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -121,6 +253,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true', help='do not capture the step into a hipGraph')
     ap.add_argument('--force-dp', action='store_true', help='rehearsal: take the data-parallel code path (process group, buckets, RCCL all-reduce) even at world size 1')
+    ap.add_argument('--graph-collective', action='store_true', help='capture the RCCL all-reduce inside the step graph (one graph per step)')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the wide-kernel / wide-model secondary measurements')
+    ap.add_argument('--no-parity', action='store_true', help='skip the oracle replay of the first steps')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -147,7 +282,7 @@ def main():
     from deepcv_amd import modules, optim
     from deepcv_amd.classification.image import create_model
     from deepcv_amd.meta.data.datasets import SyntheticImageDataset
-    from deepcv_amd.meta.ignite_training import GraphedTrainStep, _setup_losses
+    from deepcv_amd.meta.ignite_training import GraphedTrainStep, _setup_losses, graphed_train_step
     from deepcv_amd.meta.schedulers import PiecewiseLinear
     from deepcv_amd.parallel import DataParallelModel
     from deepcv_amd.utils import load_parameters
@@ -158,14 +293,17 @@ def main():
     model = create_model({'trainset': SyntheticImageDataset(2, IMAGE_SHAPE, NUM_CLASSES)}, params['image_classifier_model']).to(device)
     reducer = None
     if use_dp:
-        wrapped = DataParallelModel(model, overlap=args.eager)   # autograd hooks only serve the eager path; the graph path reduces after the replay
+        wrapped = DataParallelModel(model, overlap=True)         # as `train()` builds it (`_setup_distributed_training`)
         reducer = wrapped.reducer
         reducer.force_collective = args.force_dp
     opt = optim.AdamW(model.parameters(), **hp['optimizer_opts'])
     total_iters = args.warmup + args.steps + 4
-    sched = PiecewiseLinear(opt, 'lr', [[0, 0.0], [int(0.2 * total_iters), hp['optimizer_opts']['lr']], [total_iters, 0.0]])
+    sched = PiecewiseLinear(opt, 'lr', _milestones(total_iters, hp['optimizer_opts']['lr']))
     losses, weights = _setup_losses(modules.CrossEntropyLoss(), None, device)
-    step_fn = GraphedTrainStep(model, opt, losses, weights, reducer=reducer)
+    if args.eager:
+        step_fn = GraphedTrainStep(model, opt, losses, weights, reducer=reducer)      # only its eager step is used: autograd hooks stay
+    else:
+        step_fn = graphed_train_step(model, opt, losses, weights, reducer, graph_collective=args.graph_collective or None)   # the same call `train()` makes
     batches = _make_batches(POOL, BATCH_PER_GPU, DATA_SEED + rank, device)
 
     def one_step(i):
@@ -178,10 +316,11 @@ def main():
         return step_fn.loss_values()['main_loss']     # the reference reads the loss back every step (ignite_training.py:255)
 
     it = 0
+    first_losses = []
     for _ in range(4):                                # eager first step + capture + first replays: never timed
-        one_step(it); it += 1
+        first_losses.append(one_step(it)); it += 1
     for _ in range(args.warmup):
-        one_step(it); it += 1
+        first_losses.append(one_step(it)); it += 1
     torch.cuda.synchronize(device)
     if use_dp:
         dist.barrier()
@@ -200,7 +339,9 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    parity_failed = False
     if rank == 0:
+        first_losses = first_losses[:min(PARITY_STEPS, POOL)]
         roof = dominant_kernel_roofline(device)
         result = {
             'metric': 'images/sec training, CIFAR-10 DeepcvModule bs=512/GPU', 'value': round(world * BATCH_PER_GPU * args.steps / dt, 1), 'unit': 'images/sec',
@@ -213,10 +354,18 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(params)
+        if not args.no_parity:
+            result['parity'] = parity_check(params, first_losses, total_iters, world)
+        if world == 1 and not args.no_secondary and not args.force_dp:
+            result['secondary'] = secondary_measurements(device, params)
         print(json.dumps(result), flush=True)
+        if world == 1 and not args.no_parity and not result['parity']['pass']:
+            parity_failed = True
     if use_dp:
         dist.barrier()
         dist.destroy_process_group()
+    if parity_failed:
+        raise SystemExit(f'bench.py: parity FAILED: loss of the first {PARITY_STEPS} steps deviates from the CPU oracle by more than {PARITY_BAR}')
 
 
 if __name__ == '__main__':

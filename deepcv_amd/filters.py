@@ -6,8 +6,16 @@ model, whose whole step is launch-bound.  Weights only change in `optimizer.step
 `Parameter` and the convolution descriptor, and ALL of them are refreshed by ONE launch at the end of `deepcv_amd.optim.*.step()` (which updates the
 weights through raw pointers, i.e. without touching `Tensor._version`).  Every other way of changing a weight is detected and falls back to a lazy,
 per-layer re-preparation: in-place torch ops bump `_version`; `.to()` / `.data = ...` change `data_ptr()`; code writing through `.data` (e.g. the
-data-parallel broadcast) calls `invalidate_all()`. """
+data-parallel broadcast) calls `invalidate_all()`.
+
+Freshness against the optimizers' raw-pointer updates does not depend on which launch happened to refresh an entry: every `RefreshTable` (one per
+optimizer parameter group) owns an update counter (`clock`) bumped by each weight update of its parameters — eager `optimizer.step()` calls and replays
+of a captured step graph alike (`RefreshTable.replayed()`).  An entry remembers the counter value of its last refresh (`fresh_at`), or, when it belongs
+to the call table a graph capture froze, shares that capture's mark (`cap`), which each replay moves to the new counter value with one host store.  An
+entry created after the capture (another batch size: the ragged last batch of an epoch, the evaluation batches) is in no replayed table; `get()` sees
+its counter behind and re-prepares it. """
 import ctypes
+import itertools
 import weakref
 from typing import Dict, Iterable, List, Optional, Tuple
 
@@ -22,10 +30,12 @@ _cache: Dict[int, Tuple['weakref.ref', Dict[tuple, '_Entry']]] = {}   # id(weigh
 _epoch = 0
 _generation = 0          # bumped whenever an entry is (re)created: optimizers rebuild their refresh tables then
 _NO_FILTER = object()    # the kernel serving this (descriptor, op) reads OIHW directly
+_owner: Dict[int, Tuple['weakref.ref', List[int]]] = {}   # id(weight) -> (weak reference, update counter of the optimizer group which owns it)
+_tick = itertools.count(1)   # counter values are unique across tables: a mark left by a discarded optimizer / graph can never equal a live counter
 
 
 class _Entry:
-    __slots__ = ('desc', 'op', 'buf', 'version', 'epoch', 'data_ptr')
+    __slots__ = ('desc', 'op', 'buf', 'version', 'epoch', 'data_ptr', 'fresh_at', 'cap')
 
 
 def _key(d: nat.Conv2dDesc, op: int) -> tuple:
@@ -46,6 +56,17 @@ def _entries_of(weight: torch.Tensor, create: bool = False) -> Optional[Dict[tup
 
 def generation() -> int:
     return _generation
+
+
+def _clock_of(weight: torch.Tensor) -> Optional[List[int]]:
+    slot = _owner.get(id(weight))
+    return slot[1] if slot is not None and slot[0]() is weight else None
+
+
+def _fresh(weight: torch.Tensor, e: '_Entry') -> bool:
+    """ Was `e` refreshed after the last raw-pointer update of `weight` (always true for weights no native optimizer owns)? """
+    clock = _clock_of(weight)
+    return clock is None or e.fresh_at == clock[0] or (e.cap is not None and e.cap[0] == clock[0])
 
 
 def invalidate_all():
@@ -75,7 +96,7 @@ def get(weight: torch.Tensor, d: nat.Conv2dDesc, op: int) -> Optional[torch.Tens
     e = per_w.get(k)
     if e is _NO_FILTER:
         return None
-    if e is not None and e.version == weight._version and e.epoch == _epoch and e.data_ptr == weight.data_ptr():
+    if e is not None and e.version == weight._version and e.epoch == _epoch and e.data_ptr == weight.data_ptr() and _fresh(weight, e):
         return e.buf
     if e is None:
         nbytes = int(lib.dcv_conv2d_filter_bytes(d, op))
@@ -85,37 +106,57 @@ def get(weight: torch.Tensor, d: nat.Conv2dDesc, op: int) -> Optional[torch.Tens
         e = _Entry()
         e.desc, e.op = nat.Conv2dDesc.from_buffer_copy(d), op
         e.buf = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+        e.cap = None
         per_w[k] = e
     _prepare([(weight, e)], nat.current_stream(weight.device))
-    e.version, e.epoch, e.data_ptr = weight._version, _epoch, weight.data_ptr()
+    clock = _clock_of(weight)
+    e.version, e.epoch, e.data_ptr, e.fresh_at = weight._version, _epoch, weight.data_ptr(), (clock[0] if clock is not None else 0)
     _generation += 1
     return e.buf
 
 
 class RefreshTable:
-    """ Call table of `dcv_conv2d_prepare_filters` for every cached filter of a set of parameters; rebuilt when the cache changed. """
+    """ Call table of `dcv_conv2d_prepare_filters` for every cached filter of a set of parameters (one optimizer parameter group); rebuilt when the cache
+    changed.  Owns the update counter of those parameters: `refresh()` = "the weights were just updated through raw pointers, re-lay every filter". """
 
     def __init__(self, params: Iterable[torch.Tensor]):
         self.params = [p for p in params]
         self.gen = -1
         self.table = None
         self.entries: List[Tuple[torch.Tensor, _Entry]] = []
+        self.clock: List[int] = [0]
+        self.cap: Optional[List[int]] = None          # mark shared by the entries of the call table frozen into a captured graph
+        for w in self.params:
+            _owner[id(w)] = (weakref.ref(w, lambda _r, k=id(w): _owner.pop(k, None)), self.clock)
 
-    def refresh(self, stream):
-        if self.gen != _generation or self.table is None:
+    def refresh(self, stream, capturing: bool = False):
+        """ Counts one weight update and re-lays every cached filter of the group in ONE launch.  `capturing`: the launch is being recorded into a graph;
+        the entries of this call table are the ones every replay refreshes (`replayed()`). """
+        self.clock[0] = next(_tick)
+        if self.gen != _generation or self.table is None or capturing:
             self.entries = []
             for w in self.params:
                 for e in (_entries_of(w) or {}).values():
                     if e is not _NO_FILTER and e.epoch == _epoch and e.data_ptr == w.data_ptr() and e.version == w._version:
                         self.entries.append((w, e))
             self.gen = _generation
-            if not self.entries:
-                self.table = None
-                return
-            self.table = _prepare(self.entries, stream)
-            return
-        descs, ops_, ws, bufs = self.table
-        nat.check(lib.dcv_conv2d_prepare_filters(len(self.entries), descs, ops_, ws, bufs, stream), 'dcv_conv2d_prepare_filters')
+            self.table = _prepare(self.entries, stream) if self.entries else None
+        else:
+            descs, ops_, ws, bufs = self.table
+            nat.check(lib.dcv_conv2d_prepare_filters(len(self.entries), descs, ops_, ws, bufs, stream), 'dcv_conv2d_prepare_filters')
+        now = self.clock[0]
+        if capturing:
+            self.cap = [now]
+            for _, e in self.entries:
+                e.cap = self.cap
+        for _, e in self.entries:
+            e.fresh_at = now
+
+    def replayed(self):
+        """ A captured graph holding this group's update + refresh launches was replayed: the weights changed, the captured table's entries are fresh. """
+        self.clock[0] = next(_tick)
+        if self.cap is not None:
+            self.cap[0] = self.clock[0]
 
 
 def refresh(table: RefreshTable, stream):

@@ -11,9 +11,10 @@ from typing import Dict, Iterable, Optional, Tuple
 
 import torch
 
-__all__ = ['register', 'unregister', 'buffer_for', 'in_place']
+__all__ = ['register', 'unregister', 'buffer_for', 'in_place', 'new_pass']
 
 _arena: Dict[int, Tuple['weakref.ref', torch.Tensor]] = {}
+_handed: set = set()      # ids of the parameters whose slice was handed out since the last `new_pass()`
 
 
 def register(params: Iterable[torch.nn.Parameter], views: Iterable[torch.Tensor]):
@@ -25,15 +26,25 @@ def register(params: Iterable[torch.nn.Parameter], views: Iterable[torch.Tensor]
 def unregister(params: Iterable[torch.nn.Parameter]):
     for p in params:
         _arena.pop(id(p), None)
+        _handed.discard(id(p))
+
+
+def new_pass():
+    """ A reduction finished (`GradientAllReducer.finish()`): the slices may be handed out again. """
+    _handed.clear()
 
 
 def buffer_for(param: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
-    """ A fresh alias of `param`'s bucket slice (sole owner: the engine's AccumulateGrad adopts it as `.grad`), or None. """
+    """ A fresh alias of `param`'s bucket slice (sole owner: the engine's AccumulateGrad adopts it as `.grad`), or None.  A slice is handed out ONCE per
+    reduction: a parameter used by two forward ops (a module called twice) gets two gradient contributions in one backward pass, which the engine sums —
+    the second one must not be computed into the buffer holding the first (it gets a fresh tensor; the engine adds it to the slice in place). """
     if param is None or not _arena:
         return None
-    slot = _arena.get(id(param))
-    if slot is None or slot[0]() is not param or param.grad is not None or torch.is_grad_enabled():
+    key = id(param)
+    slot = _arena.get(key)
+    if slot is None or slot[0]() is not param or param.grad is not None or torch.is_grad_enabled() or key in _handed:
         return None
+    _handed.add(key)
     return slot[1].detach()
 
 

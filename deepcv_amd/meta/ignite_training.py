@@ -36,7 +36,7 @@ from .engine import Accuracy, Engine, Events, Loss, Metric, RunningAverage, Stat
 from .hyperparams import to_hyperparameters
 from .types_aliases import *
 
-__all__ = ['MAIN_TRAINING_LOSS_NAME', 'BackendConfig', 'TRAINING_EVENTS', 'train', 'add_training_output_dir', 'GraphedTrainStep']
+__all__ = ['MAIN_TRAINING_LOSS_NAME', 'BackendConfig', 'TRAINING_EVENTS', 'train', 'add_training_output_dir', 'GraphedTrainStep', 'graphed_train_step']
 
 MAIN_TRAINING_LOSS_NAME = 'main_loss'
 
@@ -156,13 +156,17 @@ def _native_optimizer_type(opt: Type[torch.optim.Optimizer], device: torch.devic
 class GraphedTrainStep:
     """ One optimisation step captured into hipGraph(s) and replayed: forward, losses, backward and optimizer kernels become a handful of graph launches
     instead of ~100 host-side launches (the stock model's step is launch-latency bound).
-    Without data parallelism the whole step is ONE graph.  With a `GradientAllReducer`, forward+backward is one graph, the bucket pack + RCCL all-reduce
-    run eagerly in between, and the optimizer step is a second graph reading the reduced gradients from the bucket.
+    Without data parallelism the whole step is ONE graph.  With a `GradientAllReducer`, forward+backward is one graph, the RCCL all-reduce of the buckets
+    (the backward kernels wrote the gradients straight into them, `deepcv_amd/grads.py`) runs eagerly in between, and the optimizer step is a second graph
+    reading the reduced gradients from the bucket; with `graph_collective` (RCCL only) the collective is captured too and the step is one graph again.
     The first call runs eagerly (it creates the lazily allocated optimizer state), the second call captures, later calls replay.  Batches whose shape
     differs from the captured one (last, smaller batch of an epoch) run eagerly. """
 
-    def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, losses, weights, reducer=None):
+    def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, losses, weights, reducer=None, graph_collective: Optional[bool] = None):
         self.model, self.optimizer, self.losses, self.weights, self.reducer = model, optimizer, losses, weights, reducer
+        import os
+        # capture the RCCL all-reduce INSIDE the step graph (one graph per step, no eager gap): off by default until validated on a multi-GPU node
+        self.graph_collective = (os.environ.get('DCV_GRAPH_COLLECTIVE') == '1') if graph_collective is None else bool(graph_collective)
         self.calls = 0
         self.graph_fb = self.graph_opt = None
         self.static_x = self.static_y = None
@@ -174,6 +178,9 @@ class GraphedTrainStep:
         self._seq_seen = 0
         self._last_eager = True
         self._last_losses = None
+        self._launch_stream: Optional[torch.cuda.Stream] = None
+        import os
+        self.publish_timeout_s = float(os.environ.get('DCV_PUBLISH_TIMEOUT_S', '30'))
 
     def _eager(self, x, y):
         self.model.train()
@@ -248,15 +255,28 @@ class GraphedTrainStep:
 
     def _wait_published(self):
         """ Blocks until the loss of the last launched replay has been published, i.e. its forward pass is done (its staging kernel has consumed the
-        mailbox long before).  Polls pinned memory; yields the GIL between polls so that loader threads keep running. """
+        mailbox long before).  Polls pinned memory; yields the GIL between polls so that loader threads keep running.  The wait is bounded: every few
+        thousand polls the launch stream is queried (a device fault surfaces as the HIP error it is), a stream which drained without the sequence number
+        arriving, or `publish_timeout_s` seconds (`DCV_PUBLISH_TIMEOUT_S`, default 30) without it, raise instead of spinning forever. """
         if self._launched_seq is None or self._launched_seq == self._seq_seen:
             return
         import time
-        spins = 0
+        spins, t0 = 0, None
         while int(self._pub_seq[0]) != self._launched_seq:
             spins += 1
             if spins > 64:
                 time.sleep(0)
+            if spins % 4096 == 0:
+                now = time.monotonic()
+                t0 = now if t0 is None else t0
+                drained = self._launch_stream.query() if self._launch_stream is not None else False     # raises on an asynchronous HIP error
+                seen = int(self._pub_seq[0])
+                if seen == self._launched_seq:
+                    break
+                if drained or now - t0 > self.publish_timeout_s:
+                    why = 'its stream drained without publishing' if drained else f'nothing published after {now - t0:.1f} s'
+                    raise RuntimeError(f'deepcv_amd: replay #{self._launched_seq} of the captured training step never published its loss ({why}); '
+                                       f'last sequence number seen in pinned memory: {seen}')
         self._seq_seen = self._launched_seq
 
     def loss_values(self) -> 'OrderedDict[str, float]':
@@ -295,9 +315,14 @@ class GraphedTrainStep:
                 self._publishes = True
             main = self.static_losses[MAIN_TRAINING_LOSS_NAME]
             main.backward(gradient=self._seed if main.shape == self._seed.shape else None)   # preallocated seed: no ones-fill kernel per replay
+            in_graph = self.reducer is not None and self.graph_collective and self.reducer.capturable()
             if self.reducer is None:
                 self.optimizer.step()
-        if self.reducer is not None:
+            elif in_graph:
+                self.reducer.enabled = hooks_were
+                self.reducer.finish()                                        # all-reduce captured on the capture stream; p.grad -> bucket views
+                self.optimizer.step()
+        if self.reducer is not None and not in_graph:
             self.reducer.enabled = hooks_were
             self._static_grads = [p.grad for p in self.reducer.params]       # graph-pool gradient tensors written by every replay
             self.reducer.finish()                                            # p.grad -> bucket views (static addresses)
@@ -308,15 +333,18 @@ class GraphedTrainStep:
 
     def _replay(self, x, y):
         self._mailbox_write(x, y)
+        self._launch_stream = torch.cuda.current_stream(x.device)
         self.graph_fb.replay()
         self._launched_seq = self._seq if self._publishes else None
         if not self._publishes:
-            torch.cuda.current_stream(x.device).synchronize()      # no early read-back: the mailbox may only be rewritten once this replay is done
-        if self.reducer is not None:
+            self._launch_stream.synchronize()                      # no early read-back: the mailbox may only be rewritten once this replay is done
+        if self.graph_opt is not None:
             for p, g in zip(self.reducer.params, self._static_grads):
                 p.grad = g
             self.reducer.finish()
             self.graph_opt.replay()
+        if hasattr(self.optimizer, 'note_replayed'):
+            self.optimizer.note_replayed()                         # weights changed behind the prepared-filter cache's back (deepcv_amd/filters.py)
         return self.static_losses, self.static_pred
 
     def __call__(self, x, y):
@@ -338,6 +366,16 @@ class GraphedTrainStep:
         return out
 
 
+def graphed_train_step(model, optimizer, losses, weights, reducer=None, graph_collective: Optional[bool] = None) -> GraphedTrainStep:
+    """ The replayed training step as `train()` configures it (`bench.py` builds its step through this same function): with a data-parallel reducer the
+    autograd hooks go (a captured backward cannot launch collectives; `finish()` reduces the buckets after the replay) while the gradient arena stays, so
+    the captured backward kernels write the gradients straight into the all-reduce buckets and no pack launch runs. """
+    step = GraphedTrainStep(model, optimizer, losses, weights, reducer=reducer, graph_collective=graph_collective)
+    if reducer is not None:
+        reducer.remove_hooks()
+    return step
+
+
 def train(hp: HYPERPARAMS_T, model: torch.nn.Module, losses: LOSS_FN_TERMS_T = None, datasets: Union[Dict[str, Dataset], Tuple[Dataset, ...]] = None,
           opt: Type[torch.optim.Optimizer] = None, backend_conf: BackendConfig = None, loss_weights: Sequence[FLOAT_OR_FLOAT_TENSOR_T] = None,
           metrics: Dict[str, METRIC_FN_T] = None, callbacks_handler=None, nni_compression_pruner=None, loss: LOSS_FN_TERMS_T = None) -> Tuple[METRICS_DICT_T, State]:
@@ -345,7 +383,8 @@ def train(hp: HYPERPARAMS_T, model: torch.nn.Module, losses: LOSS_FN_TERMS_T = N
 
     Args:
         - hp: hyper-parameters; required: `optimizer_opts`, `epochs`, `batch_size`; optional: see `TRAINING_HP_DEFAULTS` below (reference `:201-203`), plus
-          `hip_graph` (None = auto: capture the step into a hipGraph when the model has fewer than 5M parameters), `num_workers`, `bucket_cap_mb`,
+          `hip_graph` (None = auto: capture the step into a hipGraph when the model has fewer than 5M parameters), `graph_collective` (capture the
+          RCCL gradient all-reduce inside that graph; None = `DCV_GRAPH_COLLECTIVE`, off by default), `num_workers`, `bucket_cap_mb`,
           `device_transform` (callable applied on the device to the images of every prefetched batch, e.g. `DeviceNormalize` for raw uint8 pixels),
           `conv_math` ('fp32' | 'bf16': arithmetic of the MFMA convolution kernels, see `deepcv_amd.ops.set_conv_math`).
         - model: `torch.nn.Module` to train (e.g. a `DeepcvModule`)
@@ -361,7 +400,7 @@ def train(hp: HYPERPARAMS_T, model: torch.nn.Module, losses: LOSS_FN_TERMS_T = N
     TRAINING_HP_DEFAULTS = {'optimizer_opts': ..., 'epochs': ..., 'batch_size': ..., 'scheduler': None, 'output_path': Path.cwd() / 'data/04_training/',
                             'log_output_dir_to_mlflow': True, 'validate_every_epochs': 1, 'save_every_iters': 1000, 'log_grads_every_iters': -1,
                             'log_progress_every_iters': 100, 'seed': None, 'prefetch_batches': True, 'resume_from': '', 'crash_iteration': -1,
-                            'deterministic_cudnn': False, 'use_sync_batch_norm': False, 'hip_graph': None, 'num_workers': None, 'bucket_cap_mb': 32., 'device_transform': None, 'conv_math': None}
+                            'deterministic_cudnn': False, 'use_sync_batch_norm': False, 'hip_graph': None, 'graph_collective': None, 'num_workers': None, 'bucket_cap_mb': 32., 'device_transform': None, 'conv_math': None}
     losses = losses if losses is not None else loss
     backend_conf = backend_conf if backend_conf is not None else BackendConfig()
     metrics = dict(metrics) if metrics else {}
@@ -424,9 +463,7 @@ def train(hp: HYPERPARAMS_T, model: torch.nn.Module, losses: LOSS_FN_TERMS_T = N
         use_graph = backend_conf.is_cuda and sum(p.numel() for p in model.parameters()) < 5_000_000
     if hp['use_sync_batch_norm'] and backend_conf.distributed:
         use_graph = False    # SyncBatchNorm all-reduces statistics inside forward and backward: collectives are not captured into the step graph
-    graphed_step = GraphedTrainStep(model, optimizer, losses, weights, reducer=reducer) if (use_graph and backend_conf.is_cuda) else None
-    if graphed_step is not None and reducer is not None:
-        reducer.remove_hooks()   # the captured backward cannot launch collectives; finish() reduces everything after the replay
+    graphed_step = graphed_train_step(model, optimizer, losses, weights, reducer, graph_collective=hp['graph_collective']) if (use_graph and backend_conf.is_cuda) else None
 
     def _split_batch(batch):
         x, *y = batch

@@ -145,8 +145,14 @@ class _NativeOptimizer(torch.optim.Optimizer):
             table = self._filter_tables.get(gi)
             if table is None:
                 table = self._filter_tables[gi] = filters.RefreshTable(group['params'])
-            table.refresh(stream)
+            table.refresh(stream, capturing=capturing)
         return loss
+
+    def note_replayed(self):
+        """ To be called after each replay of a graph which captured `step()`: the weights were updated (and the filters prepared at capture time
+        refreshed) without this object seeing it; filters prepared since then are stale and get re-laid on their next use (`deepcv_amd/filters.py`). """
+        for table in self._filter_tables.values():
+            table.replayed()
 
     # -- checkpoint compatibility with torch.optim state_dicts ------------------------------------------
     def state_dict(self):

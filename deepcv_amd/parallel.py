@@ -89,6 +89,7 @@ class GradientAllReducer:
         self._reset()
 
     def _reset(self):
+        grads.new_pass()
         for b in self.buckets:
             b.pending = set(b.params)
             b.work, b.event, b.launched = None, None, False
@@ -167,11 +168,21 @@ class GradientAllReducer:
         self._reset()
 
     def remove_hooks(self):
-        """ Detaches the reducer from the parameters: autograd hooks and gradient-arena registrations. """
+        """ Removes the autograd hooks (nothing launches collectives during backward any more: `finish()` reduces every bucket); the gradient arena stays,
+        so the backward kernels keep writing the gradients straight into the buckets. """
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        self.overlap = False
+
+    def detach(self):
+        """ Detaches the reducer from the parameters altogether: autograd hooks and gradient-arena registrations. """
+        self.remove_hooks()
         grads.unregister(self.params)
+
+    def capturable(self) -> bool:
+        """ Can the collective be recorded into a hipGraph (RCCL on device buckets)? """
+        return self.device.type == 'cuda' and dist.is_initialized() and dist.get_backend(self.group) == 'nccl'
 
 
 class DataParallelModel(torch.nn.Module):

@@ -388,7 +388,7 @@ def train_steps(model: torch.nn.Module, batches: Sequence[Tuple[torch.Tensor, to
 
 def train_steps_data_parallel(model: torch.nn.Module, batches: Sequence[Tuple[torch.Tensor, torch.Tensor]], hp: Dict[str, Any], steps: int,
                               world_size: int, opt: Type[torch.optim.Optimizer] = torch.optim.AdamW,
-                              iterations_per_epoch: Optional[int] = None) -> List[List[float]]:
+                              iterations_per_epoch: Optional[int] = None, lr_fn: Optional[Callable[[int], float]] = None) -> List[List[float]]:
     """ Single-process emulation of `DistributedDataParallel` (ignite_training.py:380):
     each rank runs fwd/bwd on its shard with per-shard BatchNorm statistics and its own buffers, gradients are
     averaged over ranks (DDP mean all-reduce), every replica applies the same optimizer step.
@@ -400,7 +400,7 @@ def train_steps_data_parallel(model: torch.nn.Module, batches: Sequence[Tuple[to
     loss_fn = torch.nn.CrossEntropyLoss()
     out = []
     for t in range(steps):
-        lr = piecewise_linear(ms, t)
+        lr = lr_fn(t) if lr_fn is not None else piecewise_linear(ms, t)
         x, y = batches[t % len(batches)]
         step_losses = []
         for r, (m, o) in enumerate(zip(replicas, optims)):

@@ -80,6 +80,12 @@ CONV_CASES = [
     (8, 256, 14, 14, 512, 3, 2, 1, 1, 1, False),
     (8, 64, 56, 56, 128, 3, 2, 1, 1, 1, False),
     (2, 3, 224, 224, 64, 7, 2, 3, 1, 1, True),     # stem
+    # the five stock layers at the BENCH batch size (BASELINE.json configs[1], N = 512): `tile_plan` picks its pixels-per-thread variant from the grid size,
+    # so these are the instantiations bench.py times (conv_tile_kernel<4,5,2>, <4,3,2>, the halo-tile MFMA kernel with 512 samples, 512-block weight gradients)
+    (512, 3, 32, 32, 4, 5, 1, 2, 1, 1, True),
+    (512, 4, 32, 32, 4, 5, 1, 2, 1, 1, False),
+    (512, 4, 16, 16, 16, 3, 1, 1, 1, 1, False),
+    (512, 16, 16, 16, 16, 3, 1, 1, 1, 1, False),
 ]
 
 
@@ -344,6 +350,12 @@ LAYER_CASES = [
     (2, 8, 12, 12, 12, 3, 2, 1, 4, 3, False),      # stride 2, tanh, 3 groups
     (70, 4, 8, 8, 8, 3, 1, 1, 0, 8, False),        # no activation; more samples than one wave of partials; one channel per group
     (2, 64, 14, 14, 64, 3, 1, 1, 1, 0, False),     # wide BN-only layer (resnet18_style shapes)
+    # the stock layers at the bench batch size (N = 512): convolution with the statistics epilogue as the training step launches it, the norm chain's
+    # register-resident per-sample path (nf_moments_kernel<4> / nf_bn_gn_apply_kernel at 512 samples), data gradient of the PPT = 2 / 4 tile variants
+    (512, 3, 32, 32, 4, 5, 1, 2, 1, 4, True),
+    (512, 4, 32, 32, 4, 5, 1, 2, 1, 4, False),
+    (512, 4, 16, 16, 16, 3, 1, 1, 1, 4, False),
+    (512, 16, 16, 16, 16, 3, 1, 1, 1, 4, False),
 ]
 
 
@@ -919,6 +931,40 @@ def test_gradients_written_into_the_all_reduce_bucket(device):
             _check(f'arena accumulate {n}', p[n].grad, 2 * ref[n].grad, 1e-5)
     finally:
         grads.unregister(p.values())
+
+
+def test_shared_weight_with_a_registered_gradient_arena(device):
+    """ A parameter used by TWO forward ops (the same convolution applied twice) under a `GradientAllReducer`: both backward functions ask the arena for the
+    gradient buffer before the engine has accumulated anything; the bucket slice may be handed out once only, or the second kernel overwrites the first
+    contribution and the engine sums two aliases of one buffer (2 * g_last instead of g_a + g_b). """
+    from deepcv_amd import grads, ops, _native as nat
+    from deepcv_amd.parallel import GradientAllReducer
+    torch.manual_seed(29)
+    x = _cl(torch.randn(4, 8, 12, 12, device=device))
+    w0, b0 = torch.randn(8, 8, 3, 3, device=device) * 0.2, torch.randn(8, device=device) * 0.1
+
+    def loss(w, b):
+        h = ops.conv2d(x, w, b, 1, 1, 1, nat.ACT_TANH)
+        h = ops.conv2d(h, w, b, 1, 1, 1, nat.ACT_TANH)          # same weight and bias again
+        return (h * h).sum()
+
+    xr, wr, br = x.detach().cpu().double(), w0.cpu().double().requires_grad_(True), b0.cpu().double().requires_grad_(True)
+    hr = torch.tanh(torch.nn.functional.conv2d(torch.tanh(torch.nn.functional.conv2d(xr, wr, br, 1, 1)), wr, br, 1, 1))
+    (hr * hr).sum().backward()
+
+    w, b = torch.nn.Parameter(w0.clone()), torch.nn.Parameter(b0.clone())
+    red = GradientAllReducer([w, b], overlap=False)
+    try:
+        for _ in range(2):                                       # second pass: the slices are handed out again after finish()
+            w.grad = b.grad = None
+            loss(w, b).backward()
+            red.finish()
+            torch.cuda.synchronize()
+            _check('shared weight dw', w.grad, wr.grad, 1e-4)
+            _check('shared weight db', b.grad, br.grad, 1e-4)
+            assert grads.in_place(w) and grads.in_place(b)       # finish() leaves the (reduced) gradients in the bucket
+    finally:
+        red.detach()
 
 
 def test_weight_gradient_batch_with_many_mixed_layers(device):

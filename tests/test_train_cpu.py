@@ -129,3 +129,35 @@ def test_train_argument_validation(params, tmp_path):
     with pytest.raises(ValueError, match='Missing mandatory'):
         train(hp, _model(params), losses=torch.nn.CrossEntropyLoss(), datasets={'trainset': SyntheticImageDataset(4), 'validset': SyntheticImageDataset(4)}, opt=torch.optim.AdamW,
               backend_conf=BackendConfig('cpu'))
+
+
+def test_published_loss_wait_is_bounded():
+    """ `GraphedTrainStep._wait_published` polls pinned memory for the sequence number the replayed graph publishes.  A replay which faults, or whose write
+    never lands, must surface as an exception naming the expected and the seen sequence numbers — not as a host thread spinning forever. """
+    import numpy as np
+    from deepcv_amd.meta.ignite_training import GraphedTrainStep
+
+    class _Stream:
+        def __init__(self, drained, fail=False):
+            self.drained, self.fail, self.queries = drained, fail, 0
+
+        def query(self):
+            self.queries += 1
+            if self.fail:
+                raise RuntimeError('HIP error: an illegal memory access was encountered')
+            return self.drained
+
+    def step(pub, launched, stream, timeout=30.):
+        s = GraphedTrainStep(model=None, optimizer=None, losses=None, weights=None)
+        s._pub_seq, s._launched_seq, s._seq_seen, s._launch_stream, s.publish_timeout_s = np.array([pub], dtype='<i4'), launched, 0, stream, timeout
+        return s
+
+    s = step(7, 7, _Stream(False))                      # already published: returns without querying anything
+    s._wait_published()
+    assert s._seq_seen == 7 and s._launch_stream.queries == 0
+    with pytest.raises(RuntimeError, match=r'replay #8 .* drained without publishing.* seen in pinned memory: 7'):
+        step(7, 8, _Stream(True))._wait_published()     # the stream is idle and the number never arrived: lost write
+    with pytest.raises(RuntimeError, match=r'replay #8 .*nothing published after .* seen in pinned memory: 3'):
+        step(3, 8, _Stream(False), timeout=0.05)._wait_published()
+    with pytest.raises(RuntimeError, match='illegal memory access'):
+        step(3, 8, _Stream(False, fail=True))._wait_published()   # an asynchronous device error surfaces through the stream query
