@@ -257,6 +257,9 @@ def main():
     ap.add_argument('--no-secondary', action='store_true', help='skip the wide-kernel / wide-model secondary measurements')
     ap.add_argument('--no-parity', action='store_true', help='skip the oracle replay of the first steps')
     args = ap.parse_args()
+    if os.environ.get('DCV_BENCH_WATCHDOG_S'):            # diagnostics: dump every thread's stack and exit if the run is still alive after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ['DCV_BENCH_WATCHDOG_S']), exit=True)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))

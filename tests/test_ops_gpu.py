@@ -81,11 +81,12 @@ CONV_CASES = [
     (8, 64, 56, 56, 128, 3, 2, 1, 1, 1, False),
     (2, 3, 224, 224, 64, 7, 2, 3, 1, 1, True),     # stem
     # the five stock layers at the BENCH batch size (BASELINE.json configs[1], N = 512): `tile_plan` picks its pixels-per-thread variant from the grid size,
-    # so these are the instantiations bench.py times (conv_tile_kernel<4,5,2>, <4,3,2>, the halo-tile MFMA kernel with 512 samples, 512-block weight gradients)
-    (512, 3, 32, 32, 4, 5, 1, 2, 1, 1, True),
-    (512, 4, 32, 32, 4, 5, 1, 2, 1, 1, False),
-    (512, 4, 16, 16, 16, 3, 1, 1, 1, 1, False),
-    (512, 16, 16, 16, 16, 3, 1, 1, 1, 1, False),
+    # so these are the instantiations bench.py times (conv_tile_kernel<4,5,2>, <4,3,2>, the halo-tile MFMA kernel with 512 samples, 512-block weight gradients).
+    # tanh epilogue: with 2e6 outputs per layer a ReLU output lands within fp32 rounding of 0 about once, and one flipped act'(y) moves dx by ~1e-2 of its range
+    (512, 3, 32, 32, 4, 5, 1, 2, 1, 4, True),
+    (512, 4, 32, 32, 4, 5, 1, 2, 1, 4, False),
+    (512, 4, 16, 16, 16, 3, 1, 1, 1, 4, False),
+    (512, 16, 16, 16, 16, 3, 1, 1, 1, 4, False),
 ]
 
 
@@ -351,11 +352,12 @@ LAYER_CASES = [
     (70, 4, 8, 8, 8, 3, 1, 1, 0, 8, False),        # no activation; more samples than one wave of partials; one channel per group
     (2, 64, 14, 14, 64, 3, 1, 1, 1, 0, False),     # wide BN-only layer (resnet18_style shapes)
     # the stock layers at the bench batch size (N = 512): convolution with the statistics epilogue as the training step launches it, the norm chain's
-    # register-resident per-sample path (nf_moments_kernel<4> / nf_bn_gn_apply_kernel at 512 samples), data gradient of the PPT = 2 / 4 tile variants
-    (512, 3, 32, 32, 4, 5, 1, 2, 1, 4, True),
-    (512, 4, 32, 32, 4, 5, 1, 2, 1, 4, False),
-    (512, 4, 16, 16, 16, 3, 1, 1, 1, 4, False),
-    (512, 16, 16, 16, 16, 3, 1, 1, 1, 4, False),
+    # register-resident per-sample path (nf_moments_kernel<4> / nf_bn_gn_apply_kernel at 512 samples), data gradient of the PPT = 2 / 4 tile variants;
+    # tanh instead of ReLU: no kink for a rounding difference to flip (see CONV_CASES)
+    (512, 3, 32, 32, 4, 5, 1, 2, 4, 4, True),
+    (512, 4, 32, 32, 4, 5, 1, 2, 4, 4, False),
+    (512, 4, 16, 16, 16, 3, 1, 1, 4, 4, False),
+    (512, 16, 16, 16, 16, 3, 1, 1, 4, 4, False),
 ]
 
 
@@ -393,8 +395,10 @@ def test_conv_norm_layer_fused(device, case):
     gauge = 1e-4 * ref['dw'].abs().max().item() + 1e-6
     for key, got in (('dx', xd.grad), ('dw', wd.grad), ('d_bn_gamma', g1.grad), ('d_bn_beta', b1.grad)) + ((('d_gn_gamma', g2.grad), ('d_gn_beta', b2.grad)) if groups else ()):
         if key.startswith('d_bn_') and groups == cout:
-            # one channel per group: the BatchNorm affine pair is undone by the GroupNorm that follows, its exact gradient is 0 (gauge direction)
-            assert got.abs().max().item() <= gauge, f'{name}.{key}: {got.abs().max().item():.3e}'
+            # one channel per group: the BatchNorm affine pair is undone by the GroupNorm that follows (up to the eps inside the GroupNorm variance): its
+            # exact gradient is ~0 against the sums it is the difference of (gauge direction) -> absolute comparison
+            err = (got.detach().cpu().double() - ref[key].double()).abs().max().item()
+            assert err <= gauge, f'{name}.{key}: |got - ref| = {err:.3e} > {gauge:.3e}'
         else:
             _check(f'{name}.{key}', got, ref[key], 1e-3)
     if act == 0:   # a bias feeding BatchNorm directly is a gauge direction too
