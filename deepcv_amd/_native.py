@@ -13,7 +13,7 @@ from typing import Optional
 
 import torch
 
-__all__ = ['lib', 'load', 'is_available', 'check', 'current_stream', 'Conv2dDesc', 'SlabSegment', 'WgradJob', 'Pool2dDesc', 'TensorList', 'LIB_PATH', 'build',
+__all__ = ['lib', 'load', 'is_available', 'check', 'current_stream', 'Conv2dDesc', 'SlabSegment', 'WgradJob', 'Pool2dDesc', 'TensorList', 'NormChainDesc', 'LIB_PATH', 'build',
            'ACT_NONE', 'ACT_RELU', 'ACT_LEAKY_RELU', 'ACT_SIGMOID', 'ACT_TANH', 'POOL_AVG', 'POOL_MAX', 'LAYOUT_NHWC', 'LAYOUT_NCHW',
            'MAX_TENSORS', 'HYP_COUNT', 'HYP']
 
@@ -58,6 +58,15 @@ class Pool2dDesc(ctypes.Structure):
                 ('stride_w', _c_int), ('pad_h', _c_int), ('pad_w', _c_int), ('ho', _c_int), ('wo', _c_int), ('mode', _c_int)]
 
 
+class NormChainDesc(ctypes.Structure):
+    """ `dcv_norm_chain_desc` """
+    _fields_ = [('n', _c_int), ('hw', _c_int), ('channels', _c_int), ('width', _c_int), ('pool', _c_int),
+                ('bn_gamma', _c_void_p), ('bn_beta', _c_void_p), ('running_mean', _c_void_p), ('running_var', _c_void_p), ('num_batches_tracked', _c_void_p),
+                ('momentum', _c_float), ('bn_eps', _c_float), ('bn_mean', _c_void_p), ('bn_rstd', _c_void_p),
+                ('groups', _c_int), ('gn_gamma', _c_void_p), ('gn_beta', _c_void_p), ('gn_eps', _c_float), ('gn_mean', _c_void_p), ('gn_rstd', _c_void_p),
+                ('coef', _c_void_p), ('act', _c_int), ('act_slope', _c_float)]
+
+
 class TensorList(ctypes.Structure):
     """ `dcv_tensor_list` """
     _fields_ = [('count', _c_int), ('param', _c_void_p * MAX_TENSORS), ('grad', _c_void_p * MAX_TENSORS), ('state1', _c_void_p * MAX_TENSORS),
@@ -83,6 +92,12 @@ _SIGNATURES = {
     'dcv_conv2d_filter_bytes': (_c_size_t, [ctypes.POINTER(Conv2dDesc), _c_int]),
     'dcv_conv2d_prepare_filters': (_c_int, [_c_int, ctypes.POINTER(ctypes.POINTER(Conv2dDesc)), ctypes.POINTER(_c_int), ctypes.POINTER(_P), ctypes.POINTER(_P), _P]),
     'dcv_conv2d_fwd_stats_rows': (_c_int, [ctypes.POINTER(Conv2dDesc)]),
+    'dcv_conv2d_fwd_stats_layout': (_c_int, [ctypes.POINTER(Conv2dDesc), ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
+    'dcv_norm_chain_supported': (_c_int, [ctypes.POINTER(NormChainDesc)]),
+    'dcv_norm_chain_coef_floats': (_c_size_t, [ctypes.POINTER(NormChainDesc)]),
+    'dcv_norm_chain_ws_bytes': (_c_size_t, [ctypes.POINTER(NormChainDesc)]),
+    'dcv_norm_chain_fwd': (_c_int, [ctypes.POINTER(NormChainDesc), _P, _P, _P, _c_int, _c_int, _P, _c_size_t, _P]),
+    'dcv_norm_chain_bwd': (_c_int, [ctypes.POINTER(NormChainDesc), _P, _P, _P, _P, _P, _P, _P, _P, _c_size_t, _P]),
     'dcv_conv2d_fwd_prepared': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _P, _P, _P]),
     'dcv_conv2d_dgrad_prepared': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _P]),
     'dcv_act_fwd': (_c_int, [_P, _P, _c_size_t, _c_int, _c_float, _P]),

@@ -124,6 +124,15 @@ int dcv_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d) {
     return dcv_mfma_conv2d_supported(d, 0) ? dcv_mfma_conv2d_fwd_stats_rows(d) : dcv_direct_conv2d_fwd_stats_rows(d);
 }
 
+int dcv_conv2d_fwd_stats_layout(const dcv_conv2d_desc* d, int* rows, int* rows_per_sample) {
+    DCV_CHECK_ARG(rows && rows_per_sample);
+    *rows = 0; *rows_per_sample = 0;
+    if (!desc_ok(d) || d->groups != 1 || dcv_conv2d_filter_bytes(d, 0) == 0) return DCV_OK;
+    *rows = dcv_mfma_conv2d_supported(d, 0) ? dcv_mfma_conv2d_fwd_stats_rows(d, rows_per_sample) : dcv_direct_conv2d_fwd_stats_rows(d, rows_per_sample);
+    if (*rows_per_sample > 0 && *rows != d->n * *rows_per_sample) *rows_per_sample = 0;
+    return DCV_OK;
+}
+
 int dcv_conv2d_fwd_prepared(const dcv_conv2d_desc* d, const float* x, const float* w, const void* filter, const float* bias, float* y, double* stats, void* stream) {
     DCV_CHECK_ARG(desc_ok(d) && x && w && y);
     if (d->groups != 1) return DCV_ERR_UNSUPPORTED;

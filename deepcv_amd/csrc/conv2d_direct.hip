@@ -92,7 +92,11 @@ struct TileArgs {
     int TH, XH, XW;                // output rows per sub-tile, halo tile rows / cols
     int nsub;                      // sub-tiles (image row bands) per block
     int tiles_per_img, total_subtiles;
+    int stat_per_sub;              // statistics epilogue: one row of partials per SUB-TILE (whole images sharing a block: per-sample sums) instead of per block
 };
+
+// Can the statistics epilogue keep the sums of the PPT pixel slots of a thread apart (one sub-tile = one whole image per slot)?  Register budget: PPT * TCO * 2.
+#define DCV_TILE_PERK(PPT_, TCO_) ((PPT_) > 1 && (PPT_) * (TCO_) <= 16)
 
 // ST: compile-time filter width (the taps of one filter row are unrolled so that their LDS / scalar loads are issued together), 0 = runtime.
 // PPT: output pixels per thread (lane l owns pixels l, l+256, ... of the block's PPT*256-pixel tile): the per-thread setup, the scalar weight loads and
@@ -271,16 +275,21 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TileArgs a, const float*
 #pragma unroll
     for (int c = 0; c < TCO; ++c) bv[c] = (bias != nullptr && co0 + c < a.Cout) ? bias[co0 + c] : 0.f;
     const bool vec_store = (a.Cout & 3) == 0;
-    float ssum[TCO], ssq[TCO];                                // per-thread sums of the activated outputs (BatchNorm statistics partials)
+    // per-thread sums of the activated outputs (BatchNorm statistics partials), kept per pixel slot where slots may belong to different images
+    constexpr bool PERK = DCV_TILE_PERK(PPT, TCO);
+    constexpr int NS = PERK ? PPT : 1;
+    float ssum[NS][TCO], ssq[NS][TCO];
 #pragma unroll
-    for (int c = 0; c < TCO; ++c) { ssum[c] = 0.f; ssq[c] = 0.f; }
+    for (int j = 0; j < NS; ++j)
+#pragma unroll
+        for (int c = 0; c < TCO; ++c) { ssum[j][c] = 0.f; ssq[j][c] = 0.f; }
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         if (!active[k]) continue;
         float* yp = y + out_off[k];
         float o[TCO];
 #pragma unroll
-        for (int c = 0; c < TCO; ++c) { o[c] = dcv_act_apply(acc[k][c] + bv[c], a.act, a.slope); ssum[c] += o[c]; ssq[c] += o[c] * o[c]; }
+        for (int c = 0; c < TCO; ++c) { o[c] = dcv_act_apply(acc[k][c] + bv[c], a.act, a.slope); ssum[PERK ? k : 0][c] += o[c]; ssq[PERK ? k : 0][c] += o[c] * o[c]; }
         if (vec_store) {
 #pragma unroll
             for (int c = 0; c < TCO; c += 4)
@@ -292,19 +301,35 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TileArgs a, const float*
         }
     }
     if (stats != nullptr) {
-        // block sums of y and y^2 per output channel -> stats[2][Cout][gridDim.x].  All 2*TCO per-thread sums go through LDS ([quantity][256], conflict
-        // free); quantity q is then summed by wave q % 4: 4 values per lane + one butterfly, instead of 2*TCO butterflies per wave (fixed order throughout).
-        float* redf = reinterpret_cast<float*>(smem);              // [2 * TCO][256]; the input tile is dead
+        // sums of y and y^2 per output channel -> stats[2][Cout][rows], one row per block (rows = gridDim.x) or, with stat_per_sub (every pixel slot of a
+        // thread is a different whole image), one row per sub-tile (rows = total_subtiles: per-sample sums).  All per-thread sums go through LDS
+        // ([quantity][256], conflict free); quantity q is then summed by wave q % 4: 4 values per lane + one butterfly (fixed order throughout).
+        float* redf = reinterpret_cast<float*>(smem);              // [sets * 2 * TCO][256]; the input tile is dead
         const int lane = t & 63, wave = t >> 6;
+        const bool per_sub = PERK && a.stat_per_sub;
+        if (PERK && !per_sub) {
+#pragma unroll
+            for (int j = 1; j < NS; ++j)
+#pragma unroll
+                for (int c = 0; c < TCO; ++c) { ssum[0][c] += ssum[j][c]; ssq[0][c] += ssq[j][c]; }
+        }
+        const int sets = per_sub ? NS : 1;
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < TCO; ++c) { redf[c * 256 + t] = ssum[c]; redf[(TCO + c) * 256 + t] = ssq[c]; }
+        for (int j = 0; j < NS; ++j)
+            if (j < sets) {
+#pragma unroll
+                for (int c = 0; c < TCO; ++c) { redf[((j * 2) * TCO + c) * 256 + t] = ssum[j][c]; redf[((j * 2 + 1) * TCO + c) * 256 + t] = ssq[j][c]; }
+            }
         __syncthreads();
-        for (int q = wave; q < 2 * TCO; q += 4) {
+        const int rows = per_sub ? a.total_subtiles : (int)gridDim.x;
+        for (int q = wave; q < sets * 2 * TCO; q += 4) {
             const float* rq = redf + q * 256 + lane;
             const float v = dcv_wave_sum((rq[0] + rq[64]) + (rq[128] + rq[192]));
-            const int c = q < TCO ? q : q - TCO;
-            if (lane == 0 && co0 + c < a.Cout) stats[((size_t)(q < TCO ? 0 : 1) * a.Cout + co0 + c) * gridDim.x + blockIdx.x] = (double)v;   // [2][Cout][rows]
+            const int j = q / (2 * TCO), qq = q - j * 2 * TCO;
+            const int c = qq < TCO ? qq : qq - TCO;
+            const int row = per_sub ? (int)blockIdx.x * a.nsub + j : (int)blockIdx.x;
+            if (lane == 0 && co0 + c < a.Cout && row < rows) stats[((size_t)(qq < TCO ? 0 : 1) * a.Cout + co0 + c) * rows + row] = (double)v;   // [2][Cout][rows]
         }
     }
 }
@@ -972,6 +997,8 @@ bool tile_plan(const DirectArgs& a, TileArgs* t, int* tco_out, int* ppt_out) {
     }
     if (best < 0) return false;
     *t = bt; *tco_out = cand[best][1]; *ppt_out = cand[best][0];
+    // several whole images per block, one per pixel slot of a thread: the statistics epilogue can emit one row per image
+    t->stat_per_sub = (t->nsub > 1 && t->nsub == *ppt_out && t->tiles_per_img == 1 && DCV_TILE_PERK(*ppt_out, *tco_out)) ? 1 : 0;
     return true;
 }
 
@@ -987,7 +1014,8 @@ int run_direct(DirectArgs a, const float* x, const float* w, const float* bias, 
         if (!prepared) hipLaunchKernelGGL(prep_weights_kernel, dim3((unsigned)pblocks), dim3(256), 0, st, a, w, wt, tco, tiles, t.cin_pad, 1);
         dim3 grid((unsigned)dcv_ceil_div(t.total_subtiles, t.nsub), (unsigned)tiles);
         size_t smem = (size_t)t.nsub * t.XH * t.XW * t.CC * sizeof(float);
-        if (smem < (size_t)2 * tco * 1024) smem = (size_t)2 * tco * 1024;   // the statistics epilogue reuses the tile buffer: [2 * TCO][256] floats
+        const size_t stat_smem = (size_t)(t.stat_per_sub ? ppt : 1) * 2 * tco * 1024;
+        if (smem < stat_smem) smem = stat_smem;                        // the statistics epilogue reuses the tile buffer: [sets * 2 * TCO][256] floats
 #define DCV_TILE_LAUNCH(TCO_, ST_, PPT_) hipLaunchKernelGGL((conv_tile_kernel<TCO_, ST_, PPT_>), grid, dim3(256), smem, st, t, x, wt, bias, y, stats)
 #define DCV_TILE_PPT(TCO_, ST_) switch (ppt) { case 4: DCV_TILE_LAUNCH(TCO_, ST_, 4); break; case 2: DCV_TILE_LAUNCH(TCO_, ST_, 2); break; default: DCV_TILE_LAUNCH(TCO_, ST_, 1); break; }
 #define DCV_TILE_SWITCH(TCO_) switch (a.S) { case 1: DCV_TILE_PPT(TCO_, 1); break; case 3: DCV_TILE_PPT(TCO_, 3); break; case 5: DCV_TILE_PPT(TCO_, 5); break; \
@@ -1078,10 +1106,13 @@ int dcv_direct_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float*
     return run_direct(fwd_args(d), x, w, bias, y, ws, ws_bytes, st, prepared, stats);
 }
 
-int dcv_direct_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d) {
+int dcv_direct_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d, int* rows_per_sample) {
     const DirectArgs a = fwd_args(d);
     TileArgs t{}; int tco, ppt;
+    if (rows_per_sample) *rows_per_sample = 0;
     if (!tile_plan(a, &t, &tco, &ppt)) return 0;
+    if (t.stat_per_sub) { if (rows_per_sample) *rows_per_sample = 1; return t.total_subtiles; }
+    if (t.nsub == 1 && rows_per_sample) *rows_per_sample = t.tiles_per_img;     // blocks never straddle images
     return (int)dcv_ceil_div(t.total_subtiles, t.nsub);
 }
 

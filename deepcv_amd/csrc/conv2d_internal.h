@@ -6,9 +6,10 @@
 size_t dcv_direct_conv2d_fwd_ws(const dcv_conv2d_desc* d);
 size_t dcv_direct_conv2d_dgrad_ws(const dcv_conv2d_desc* d);
 // `prepared`: ws already holds the prepared filter of this (d, op) (dcv_conv2d_prepare_filters); otherwise it is scratch and the filter is prepared first
-// `stats` (nullable): per-block sums of y and y^2 per output channel, [2][Cout][rows] doubles with rows = dcv_*_conv2d_fwd_stats_rows(d) (0: unsupported)
+// `stats` (nullable): per-block sums of y and y^2 per output channel, [2][Cout][rows] doubles with rows = dcv_*_conv2d_fwd_stats_rows(d) (0: unsupported);
+// *rows_per_sample (nullable) > 0: no row mixes samples, sample n owns rows [n * rps, (n + 1) * rps)
 int dcv_direct_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st, bool prepared = false, double* stats = nullptr);
-int dcv_direct_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d);
+int dcv_direct_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d, int* rows_per_sample = nullptr);
 int dcv_direct_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t st, bool prepared = false);
 size_t dcv_direct_conv2d_wgrad_ws(const dcv_conv2d_desc* d);
 bool dcv_direct_conv2d_wgrad_fuses_bias(const dcv_conv2d_desc* d);
@@ -20,7 +21,7 @@ int dcv_direct_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const floa
 bool dcv_mfma_conv2d_supported(const dcv_conv2d_desc* d, int op /*0 fwd, 1 dgrad, 2 wgrad*/);
 size_t dcv_mfma_conv2d_ws(const dcv_conv2d_desc* d, int op);
 int dcv_mfma_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st, bool prepared = false, double* stats = nullptr);
-int dcv_mfma_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d);
+int dcv_mfma_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d, int* rows_per_sample = nullptr);
 int dcv_mfma_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t st, bool prepared = false);
 int dcv_mfma_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
 

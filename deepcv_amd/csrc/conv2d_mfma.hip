@@ -593,16 +593,19 @@ static int run_mfma(const MfmaArgs& a, const float* x, const float* wb, const fl
     return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
 }
 
-int dcv_mfma_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d) {
-    {   // the halo kernel emits one row of partials per tile
+int dcv_mfma_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d, int* rows_per_sample) {
+    if (rows_per_sample) *rows_per_sample = 0;
+    {   // the halo kernel emits one row of partials per tile (a tile = rows of ONE image)
         MfmaArgs a{};
         a.N = d->n; a.Hin = d->h; a.Win = d->w; a.Cin = d->cin; a.Hout = d->ho; a.Wout = d->wo; a.Cout = d->cout;
         a.R = d->r; a.S = d->s; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
         HaloArgs h{}; size_t hsm;
-        if (halo_plan(a, d->math, &h, &hsm)) return h.total_tiles;
+        if (halo_plan(a, d->math, &h, &hsm)) { if (rows_per_sample) *rows_per_sample = h.tiles_per_img; return h.total_tiles; }
     }
     const long M = (long)d->n * d->ho * d->wo;
-    return (int)dcv_ceil_div((size_t)M, (size_t)64 * pick_bmr(M, d->cin, d->cout, pick_bn(d->cout)));
+    const int tile = 64 * pick_bmr(M, d->cin, d->cout, pick_bn(d->cout));
+    if (rows_per_sample && (d->ho * d->wo) % tile == 0) *rows_per_sample = d->ho * d->wo / tile;    // pixel tiles which never straddle images
+    return (int)dcv_ceil_div((size_t)M, (size_t)tile);
 }
 
 int dcv_mfma_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st, bool prepared, double* stats) {

@@ -16,7 +16,7 @@ from . import grads
 from . import slabs
 from ._native import lib
 
-__all__ = ['conv2d', 'set_conv_math', 'conv_norm_layer', 'activation', 'batch_norm', 'sync_batch_norm', 'group_norm', 'pool2d', 'interpolate_bilinear', 'concat_channels', 'resize_concat', 'add_tensors', 'flatten_nchw_order',
+__all__ = ['conv2d', 'set_conv_math', 'set_norm_streaming', 'conv_norm_layer', 'activation', 'batch_norm', 'sync_batch_norm', 'group_norm', 'pool2d', 'interpolate_bilinear', 'concat_channels', 'resize_concat', 'add_tensors', 'flatten_nchw_order',
            'linear', 'linear_nhwc', 'cross_entropy', 'act_code', 'to_nhwc', 'nchw_to_nhwc']
 
 _CL = torch.channels_last
@@ -405,10 +405,28 @@ def group_norm(x, gamma, beta, groups: int, eps: float) -> torch.Tensor:
 
 # ------------------------------------------------------------------------------------------------ fused layer: conv + act + BatchNorm [+ GroupNorm]
 
+_norm_streaming = True
+
+
+def set_norm_streaming(enabled: bool) -> bool:
+    """ Which kernels serve the fused layer's normalisation chain: the streaming chain of norm_chain.hip (default, where it covers the shape) or the
+    per-sample block kernels of norm.hip (`dcv_bn_gn_pool_*`, the fallback for the other shapes).  Returns the previous setting. """
+    global _norm_streaming
+    prev, _norm_streaming = _norm_streaming, bool(enabled)
+    return prev
+
+
+def _norm_chain_desc(d, cfg, bn_w, bn_b, running_mean, running_var, nbt, bn_mean, bn_rstd, gn_w, gn_b, gn_mean, gn_rstd) -> nat.NormChainDesc:
+    stride, padding, dilation, act, slope, momentum, bn_eps, groups, gn_eps, pool = cfg
+    return nat.NormChainDesc(d.n, d.ho * d.wo, d.cout, d.wo, pool, nat.ptr(bn_w), nat.ptr(bn_b), nat.ptr(running_mean), nat.ptr(running_var), nat.ptr(nbt), momentum, bn_eps,
+                             nat.ptr(bn_mean), nat.ptr(bn_rstd), groups, nat.ptr(gn_w), nat.ptr(gn_b), gn_eps, nat.ptr(gn_mean), nat.ptr(gn_rstd), None, act, slope)
+
+
 class _ConvNormLayerFn(torch.autograd.Function):
     """ One reference layer in training mode, Conv2d -> act -> BatchNorm2d [-> GroupNorm] (`layer()`, reference `nn.py:553`), as ONE autograd node:
-    forward = convolution (+ bias + activation epilogue) and `dcv_bn_gn_fwd_train`; backward = `dcv_bn_gn_act_bwd` (GroupNorm / BatchNorm / activation
-    backward + every parameter gradient of the chain + the bias gradient in two launches), then the convolution's data and weight gradients. """
+    forward = convolution (+ bias + activation + statistics epilogue) and the normalisation chain (`dcv_norm_chain_fwd`: finalize + streaming apply; shapes it
+    does not cover: `dcv_bn_gn_pool_fwd_train`); backward = `dcv_norm_chain_bwd` (moments, finalize with every parameter gradient of the chain, streaming
+    apply -> dz), then the convolution's data and weight gradients (the bias gradient comes out of the weight-gradient kernel's dz tiles). """
 
     @staticmethod
     def forward(ctx, x, weight, bias, bn_w, bn_b, running_mean, running_var, nbt, gn_w, gn_b, cfg):
@@ -434,11 +452,22 @@ class _ConvNormLayerFn(torch.autograd.Function):
         bn_rstd = torch.empty(c, dtype=torch.float32, device=dev)
         gn_mean = torch.empty(d.n * groups, dtype=torch.float32, device=dev) if groups else None
         gn_rstd = torch.empty(d.n * groups, dtype=torch.float32, device=dev) if groups else None
-        ws = _ws(lib.dcv_norm_chain_workspace_bytes(d.n, hw, c), dev)
-        nat.check(lib.dcv_bn_gn_pool_fwd_train(y.data_ptr(), out.data_ptr(), d.n, hw, c, nat.ptr(bn_w), nat.ptr(bn_b), nat.ptr(running_mean), nat.ptr(running_var),
-                                               nat.ptr(nbt), momentum, bn_eps, bn_mean.data_ptr(), bn_rstd.data_ptr(), groups, nat.ptr(gn_w), nat.ptr(gn_b), gn_eps,
-                                               nat.ptr(gn_mean), nat.ptr(gn_rstd), nat.ptr(stats), 0 if stats is None else stats.shape[2],
-                                               d.wo, pool, ws.data_ptr(), ws.numel(), st), 'dcv_bn_gn_pool_fwd_train')
+        nc = _norm_chain_desc(d, cfg, bn_w, bn_b, running_mean, running_var, nbt, bn_mean, bn_rstd, gn_w, gn_b, gn_mean, gn_rstd)
+        ctx.streaming = _norm_streaming and bool(lib.dcv_norm_chain_supported(nc))
+        if ctx.streaming:
+            rows, rps = ctypes.c_int(0), ctypes.c_int(0)
+            if stats is not None:
+                nat.check(lib.dcv_conv2d_fwd_stats_layout(d, ctypes.byref(rows), ctypes.byref(rps)), 'dcv_conv2d_fwd_stats_layout')
+            coef = torch.empty(int(lib.dcv_norm_chain_coef_floats(nc)), dtype=torch.float32, device=dev)
+            nc.coef = coef.data_ptr()
+            ws = _ws(lib.dcv_norm_chain_ws_bytes(nc), dev)
+            nat.check(lib.dcv_norm_chain_fwd(nc, y.data_ptr(), out.data_ptr(), nat.ptr(stats), rows.value, rps.value, ws.data_ptr(), ws.numel(), st), 'dcv_norm_chain_fwd')
+        else:
+            ws = _ws(lib.dcv_norm_chain_workspace_bytes(d.n, hw, c), dev)
+            nat.check(lib.dcv_bn_gn_pool_fwd_train(y.data_ptr(), out.data_ptr(), d.n, hw, c, nat.ptr(bn_w), nat.ptr(bn_b), nat.ptr(running_mean), nat.ptr(running_var),
+                                                   nat.ptr(nbt), momentum, bn_eps, bn_mean.data_ptr(), bn_rstd.data_ptr(), groups, nat.ptr(gn_w), nat.ptr(gn_b), gn_eps,
+                                                   nat.ptr(gn_mean), nat.ptr(gn_rstd), nat.ptr(stats), 0 if stats is None else stats.shape[2],
+                                                   d.wo, pool, ws.data_ptr(), ws.numel(), st), 'dcv_bn_gn_pool_fwd_train')
         ctx.desc, ctx.cfg = d, cfg
         ctx.save_for_backward(x, weight, bias, y, bn_w, bn_b, bn_mean, bn_rstd, gn_w, gn_mean, gn_rstd)
         return out
@@ -461,11 +490,22 @@ class _ConvNormLayerFn(torch.autograd.Function):
         d_gn_w = new(r_gn_w) if (gn_w is not None and need[8]) else None
         d_gn_b = new(r_gn_b) if (groups and need[9]) else None
         dz = torch.empty_like(y)
-        ws = _ws(lib.dcv_norm_chain_workspace_bytes(d.n, hw, c), dev)
-        nat.check(lib.dcv_bn_gn_pool_act_bwd(dout.data_ptr(), y.data_ptr(), dz.data_ptr(), d.n, hw, c, nat.ptr(bn_w), nat.ptr(bn_b), bn_mean.data_ptr(), bn_rstd.data_ptr(),
-                                             groups, nat.ptr(gn_w), nat.ptr(gn_mean), nat.ptr(gn_rstd), act, slope,
-                                             nat.ptr(d_bn_w), nat.ptr(d_bn_b), nat.ptr(d_gn_w), nat.ptr(d_gn_b), None if db_from_wgrad else nat.ptr(db),
-                                             d.wo, pool, ws.data_ptr(), ws.numel(), st), 'dcv_bn_gn_pool_act_bwd')
+        if ctx.streaming:
+            nc = _norm_chain_desc(d, ctx.cfg, bn_w, bn_b, None, None, None, bn_mean, bn_rstd, gn_w, None, gn_mean, gn_rstd)
+            coef = torch.empty(int(lib.dcv_norm_chain_coef_floats(nc)), dtype=torch.float32, device=dev)
+            nc.coef = coef.data_ptr()
+            ws = _ws(lib.dcv_norm_chain_ws_bytes(nc), dev)
+            nat.check(lib.dcv_norm_chain_bwd(nc, dout.data_ptr(), y.data_ptr(), dz.data_ptr(), nat.ptr(d_bn_w), nat.ptr(d_bn_b), nat.ptr(d_gn_w), nat.ptr(d_gn_b),
+                                             ws.data_ptr(), ws.numel(), st), 'dcv_norm_chain_bwd')
+            if db is not None and not db_from_wgrad:
+                wsb = _ws(lib.dcv_act_bwd_workspace_bytes(d.n * hw, c), dev)
+                nat.check(lib.dcv_channel_sum(dz.data_ptr(), db.data_ptr(), d.n * hw, c, wsb.data_ptr(), wsb.numel(), st), 'dcv_channel_sum')
+        else:
+            ws = _ws(lib.dcv_norm_chain_workspace_bytes(d.n, hw, c), dev)
+            nat.check(lib.dcv_bn_gn_pool_act_bwd(dout.data_ptr(), y.data_ptr(), dz.data_ptr(), d.n, hw, c, nat.ptr(bn_w), nat.ptr(bn_b), bn_mean.data_ptr(), bn_rstd.data_ptr(),
+                                                 groups, nat.ptr(gn_w), nat.ptr(gn_mean), nat.ptr(gn_rstd), act, slope,
+                                                 nat.ptr(d_bn_w), nat.ptr(d_bn_b), nat.ptr(d_gn_w), nat.ptr(d_gn_b), None if db_from_wgrad else nat.ptr(db),
+                                                 d.wo, pool, ws.data_ptr(), ws.numel(), st), 'dcv_bn_gn_pool_act_bwd')
         dx = dw = None
         if need[0]:
             dd = nat.Conv2dDesc.from_buffer_copy(d)

@@ -139,6 +139,9 @@ int dcv_conv2d_prepare_filters(int count, const dcv_conv2d_desc* const* descs, c
 /* `stats` (nullable): the kernel's epilogue also emits per-block sums of y and y^2 per output channel, [2][Cout][rows] doubles with
  * rows = dcv_conv2d_fwd_stats_rows(d) (0: this kernel cannot, pass NULL) — the BatchNorm statistics partials of dcv_bn_gn_fwd_train for free */
 int dcv_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d);
+/* The same query with the alignment of the rows to samples: *rows_per_sample > 0 means no row mixes samples and sample n owns rows
+ * [n * rows_per_sample, (n + 1) * rows_per_sample) — per-(sample, channel) sums, what the GroupNorm statistics of dcv_norm_chain_fwd are computed from. */
+int dcv_conv2d_fwd_stats_layout(const dcv_conv2d_desc* d, int* rows, int* rows_per_sample);
 int dcv_conv2d_fwd_prepared(const dcv_conv2d_desc* d, const float* x, const float* w, const void* filter, const float* bias, float* y, double* stats, void* stream);
 int dcv_conv2d_dgrad_prepared(const dcv_conv2d_desc* d, const float* dy, const float* w, const void* filter, float* dx, void* stream);
 
@@ -245,6 +248,41 @@ int dcv_bn_gn_pool_act_bwd(const float* dout, const float* x, float* dz, int n, 
                            int act, float act_slope,
                            float* d_bn_gamma, float* d_bn_beta, float* d_gn_gamma, float* d_gn_beta, float* d_bias /* all nullable */,
                            int width, int pool, void* ws, size_t ws_bytes, void* stream);
+
+/* The same chain (with or without GroupNorm, with or without fused pooling) as STREAMING kernels around tiny finalize kernels (norm_chain.hip): per sample,
+ * GroupNorm(BatchNorm(x)) is an affine function of x, out = S[n][c] * x + T[n][c], and S / T follow from per-(sample, channel) sums of x and x^2 — which the
+ * convolution epilogue already emits (dcv_conv2d_fwd_stats_layout).  Forward = [sums from the producer, else one streaming pass] + finalize (batch statistics,
+ * running statistics) + apply (its prologue turns the block's sample sums into GroupNorm statistics, S, T); backward = four moments per (sample, channel) of
+ * (dout, u = (x - mean) * rstd) with the sample's algebra in the same block + finalize (every parameter gradient) + apply dz = act'(x) * (P * dout + Q * u + R).
+ * Every apply kernel moves each byte once.
+ *   dcv_norm_chain_supported   1 when these kernels cover the shape (channel vectors per pixel a power of two <= 256; with GroupNorm: a power of two of
+ *                              channels per group and samples of at most 8192 channel vectors, one block each); otherwise use dcv_bn_gn_pool_fwd_train /
+ *                              dcv_bn_gn_pool_act_bwd, which read and write the same saved statistics
+ *   dcv_norm_chain_coef_floats size of `coef` (scratch of one call: the forward keeps S, T there, the backward P, Q, R)
+ *   stats / stats_rows / stats_rows_per_sample: [2][channels][stats_rows] sums of x, x^2 left by the producer (nullable); with groups > 0 they are only used
+ *                              when aligned to samples (stats_rows == n * stats_rows_per_sample)
+ * The convolution bias gradient is not produced here: dcv_conv2d_wgrad sums dz (dcv_conv2d_wgrad_fuses_bias) or dcv_channel_sum does. */
+typedef struct dcv_norm_chain_desc {
+    int n, hw, channels;           /* x: [n][hw][channels] fp32 NHWC, the activated convolution output */
+    int width, pool;               /* pool > 0: out / dout are the pooled tensors [n][hw / pool^2][channels]; width = W of x */
+    const float* bn_gamma; const float* bn_beta;           /* nullable (affine = False) */
+    float* running_mean; float* running_var; int64_t* num_batches_tracked;   /* nullable; updated by the forward */
+    float momentum, bn_eps;
+    float* bn_mean; float* bn_rstd;                        /* [channels]: written by the forward, read by the backward */
+    int groups;                                            /* 0: no GroupNorm */
+    const float* gn_gamma; const float* gn_beta; float gn_eps;
+    float* gn_mean; float* gn_rstd;                        /* [n][groups]: written by the forward, read by the backward */
+    float* coef;                                           /* dcv_norm_chain_coef_floats(d) floats */
+    int act; float act_slope;                              /* activation which produced x (its derivative is taken from x) */
+} dcv_norm_chain_desc;
+int dcv_norm_chain_supported(const dcv_norm_chain_desc* d);
+size_t dcv_norm_chain_coef_floats(const dcv_norm_chain_desc* d);
+size_t dcv_norm_chain_ws_bytes(const dcv_norm_chain_desc* d);
+int dcv_norm_chain_fwd(const dcv_norm_chain_desc* d, const float* x, float* out, const double* stats, int stats_rows, int stats_rows_per_sample,
+                       void* ws, size_t ws_bytes, void* stream);
+int dcv_norm_chain_bwd(const dcv_norm_chain_desc* d, const float* dout, const float* x, float* dz,
+                       float* d_bn_gamma, float* d_bn_beta, float* d_gn_gamma, float* d_gn_beta /* all nullable */, void* ws, size_t ws_bytes, void* stream);
+
 
 /* ---------------------------------------------------------------------------------------------------
  * K7 / K7'  2-D average / max pooling, NHWC

@@ -361,10 +361,25 @@ LAYER_CASES = [
 ]
 
 
-@pytest.mark.parametrize('case', LAYER_CASES, ids=lambda c: 'x'.join(str(v) for v in c))
-def test_conv_norm_layer_fused(device, case):
-    """ `ops.conv_norm_layer` (dcv_conv2d_* + dcv_bn_gn_fwd_train / dcv_bn_gn_act_bwd: last-block finalize, BN output never materialised) against the
-    fp64 composition conv2d -> act -> batch_norm -> group_norm. """
+@pytest.fixture(params=['streaming', 'block'])
+def norm_kernels(request):
+    """ Both kernel families of the fused layer's normalisation chain: norm_chain.hip (streaming; the default where it covers the shape) and norm.hip's
+    per-sample block kernels (the fallback). """
+    from deepcv_amd import ops
+    prev = ops.set_norm_streaming(request.param == 'streaming')
+    yield request.param
+    ops.set_norm_streaming(prev)
+
+
+@pytest.mark.parametrize('case', LAYER_CASES + [
+    (6, 8, 12, 12, 32, 3, 1, 1, 1, 4, False),      # 8 channels per group
+    (3, 8, 10, 10, 64, 3, 1, 1, 4, 32, False),     # 2 channels per group, 16 channel vectors per pixel
+    (2, 4, 72, 72, 8, 3, 1, 1, 1, 2, False),       # samples larger than one block's share (several blocks per sample in the streaming kernels)
+    (9, 4, 16, 16, 64, 3, 1, 1, 4, 0, False),      # BatchNorm only on the streaming chain, wide
+], ids=lambda c: 'x'.join(str(v) for v in c))
+def test_conv_norm_layer_fused(device, case, norm_kernels):
+    """ `ops.conv_norm_layer` (dcv_conv2d_* + the normalisation chain: dcv_norm_chain_fwd / _bwd or dcv_bn_gn_pool_fwd_train / _act_bwd; the BN output is
+    never materialised) against the fp64 composition conv2d -> act -> batch_norm -> group_norm. """
     from deepcv_amd import ops
     from oracle import ops_ref
     n, cin, h, w, cout, k, stride, pad, act, groups, nchw = case
@@ -689,7 +704,7 @@ def test_deferred_weight_gradient_sums(device):
 
 @pytest.mark.parametrize('case', [(8, 4, 32, 32, 4, 5, 2, 2, 1), (4, 8, 16, 16, 16, 3, 1, 4, 2), (2, 4, 64, 64, 8, 3, 1, 2, 2), (3, 3, 12, 12, 6, 3, 1, 3, 4), (2, 4, 16, 24, 4, 3, 1, 1, 2)],
                          ids=str)
-def test_conv_norm_layer_with_fused_average_pooling(device, case):
+def test_conv_norm_layer_with_fused_average_pooling(device, case, norm_kernels):
     """ `conv_norm_layer(..., pool=k)` (pooling inside the normalisation kernels, `dcv_bn_gn_pool_*`) against the same layer followed by the standalone
     pooling op: outputs and every gradient (cached and streaming variants of the kernels, vector and scalar channel counts, pool 2 and 4). """
     from deepcv_amd import ops, _native as nat
