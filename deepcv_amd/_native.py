@@ -22,6 +22,7 @@ LIB_PATH = _PKG_DIR / 'lib' / 'libdeepcv_hip.so'
 CSRC_DIR = _PKG_DIR / 'csrc'
 
 ACT_NONE, ACT_RELU, ACT_LEAKY_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
+ERR_UNSUPPORTED = -2
 POOL_AVG, POOL_MAX = 0, 1
 LAYOUT_NHWC, LAYOUT_NCHW = 0, 1
 MATH_FP32, MATH_BF16 = 0, 1
@@ -100,6 +101,7 @@ _SIGNATURES = {
     'dcv_norm_chain_bwd': (_c_int, [ctypes.POINTER(NormChainDesc), _P, _P, _P, _P, _P, _P, _P, _P, _c_size_t, _P]),
     'dcv_conv2d_fwd_prepared': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _P, _P, _P]),
     'dcv_conv2d_dgrad_prepared': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _P]),
+    'dcv_conv2d_dgrad_prepared_add': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _P, _P]),
     'dcv_act_fwd': (_c_int, [_P, _P, _c_size_t, _c_int, _c_float, _P]),
     'dcv_act_bwd_workspace_bytes': (_c_size_t, [_c_size_t, _c_int]),
     'dcv_act_bwd': (_c_int, [_P, _P, _P, _c_size_t, _c_int, _c_int, _c_float, _P, _P, _c_size_t, _P]),

@@ -153,6 +153,15 @@ int dcv_conv2d_dgrad_prepared(const dcv_conv2d_desc* d, const float* dy, const f
     return dcv_direct_conv2d_dgrad(d, dy, w, dx, const_cast<void*>(filter), fb, dcv_stream(stream), true);
 }
 
+int dcv_conv2d_dgrad_prepared_add(const dcv_conv2d_desc* d, const float* dy, const float* w, const void* filter, const float* addend, float* dx, void* stream) {
+    DCV_CHECK_ARG(desc_ok(d) && dy && w && dx && addend);
+    if (d->groups != 1 || d->x_layout != DCV_LAYOUT_NHWC || dcv_mfma_conv2d_supported(d, 1)) return DCV_ERR_UNSUPPORTED;
+    const size_t fb = dcv_conv2d_filter_bytes(d, 1);
+    if (fb == 0) return DCV_ERR_UNSUPPORTED;
+    DCV_CHECK_ARG(filter != nullptr);
+    return dcv_direct_conv2d_dgrad(d, dy, w, dx, const_cast<void*>(filter), fb, dcv_stream(stream), true, addend);
+}
+
 int dcv_conv2d_wgrad_fuses_bias(const dcv_conv2d_desc* d) {
     if (!desc_ok(d) || d->groups != 1 || dcv_mfma_conv2d_supported(d, 2)) return 0;
     return dcv_direct_conv2d_wgrad_fuses_bias(d) ? 1 : 0;

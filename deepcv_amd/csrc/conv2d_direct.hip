@@ -103,7 +103,7 @@ struct TileArgs {
 // the loop overhead are amortised over PPT independent FMA streams.
 template <int TCO, int ST, int PPT>
 __global__ __launch_bounds__(256) void conv_tile_kernel(TileArgs a, const float* __restrict__ x, const float* __restrict__ wt, const float* __restrict__ bias,
-                                                         float* __restrict__ y, double* __restrict__ stats) {
+                                                         float* __restrict__ y, double* __restrict__ stats, const float* __restrict__ addend) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* xs = reinterpret_cast<float4*>(smem);            // [CC/4][nsub][XH][XW]
     const int t = threadIdx.x;
@@ -289,7 +289,15 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(TileArgs a, const float*
         float* yp = y + out_off[k];
         float o[TCO];
 #pragma unroll
-        for (int c = 0; c < TCO; ++c) { o[c] = dcv_act_apply(acc[k][c] + bv[c], a.act, a.slope); ssum[PERK ? k : 0][c] += o[c]; ssq[PERK ? k : 0][c] += o[c] * o[c]; }
+        for (int c = 0; c < TCO; ++c) o[c] = dcv_act_apply(acc[k][c] + bv[c], a.act, a.slope);
+        if (addend != nullptr) {                                   // y = conv + addend (same layout as y): a gradient arriving over another edge of the graph
+            const float* ap = addend + out_off[k];
+#pragma unroll
+            for (int c = 0; c < TCO; ++c)
+                if (co0 + c < a.Cout) o[c] += ap[c];
+        }
+#pragma unroll
+        for (int c = 0; c < TCO; ++c) { ssum[PERK ? k : 0][c] += o[c]; ssq[PERK ? k : 0][c] += o[c] * o[c]; }
         if (vec_store) {
 #pragma unroll
             for (int c = 0; c < TCO; c += 4)
@@ -1002,7 +1010,8 @@ bool tile_plan(const DirectArgs& a, TileArgs* t, int* tco_out, int* ppt_out) {
     return true;
 }
 
-int run_direct(DirectArgs a, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st, bool prepared, double* stats = nullptr) {
+int run_direct(DirectArgs a, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st, bool prepared, double* stats = nullptr,
+               const float* addend = nullptr) {
     TileArgs t{}; int tco, ppt;
     if (tile_plan(a, &t, &tco, &ppt)) {
         const int tiles = (int)dcv_ceil_div(a.Cout, tco);
@@ -1016,7 +1025,7 @@ int run_direct(DirectArgs a, const float* x, const float* w, const float* bias, 
         size_t smem = (size_t)t.nsub * t.XH * t.XW * t.CC * sizeof(float);
         const size_t stat_smem = (size_t)(t.stat_per_sub ? ppt : 1) * 2 * tco * 1024;
         if (smem < stat_smem) smem = stat_smem;                        // the statistics epilogue reuses the tile buffer: [sets * 2 * TCO][256] floats
-#define DCV_TILE_LAUNCH(TCO_, ST_, PPT_) hipLaunchKernelGGL((conv_tile_kernel<TCO_, ST_, PPT_>), grid, dim3(256), smem, st, t, x, wt, bias, y, stats)
+#define DCV_TILE_LAUNCH(TCO_, ST_, PPT_) hipLaunchKernelGGL((conv_tile_kernel<TCO_, ST_, PPT_>), grid, dim3(256), smem, st, t, x, wt, bias, y, stats, addend)
 #define DCV_TILE_PPT(TCO_, ST_) switch (ppt) { case 4: DCV_TILE_LAUNCH(TCO_, ST_, 4); break; case 2: DCV_TILE_LAUNCH(TCO_, ST_, 2); break; default: DCV_TILE_LAUNCH(TCO_, ST_, 1); break; }
 #define DCV_TILE_SWITCH(TCO_) switch (a.S) { case 1: DCV_TILE_PPT(TCO_, 1); break; case 3: DCV_TILE_PPT(TCO_, 3); break; case 5: DCV_TILE_PPT(TCO_, 5); break; \
                                              case 7: DCV_TILE_PPT(TCO_, 7); break; default: DCV_TILE_PPT(TCO_, 0); break; }
@@ -1031,7 +1040,7 @@ int run_direct(DirectArgs a, const float* x, const float* w, const float* bias, 
         return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
     }
     // generic kernel: LDS-resident filter slice, one output pixel per thread (strided dgrad gather, very wide rows)
-    if (stats != nullptr) return DCV_ERR_UNSUPPORTED;             // callers ask dcv_direct_conv2d_fwd_stats_rows first
+    if (stats != nullptr || addend != nullptr) return DCV_ERR_UNSUPPORTED;   // callers ask dcv_direct_conv2d_fwd_stats_rows / fall back to a separate addition
     if (a.dgrad == 2) a.dgrad = 1;
     const int in_mode = a.in_nchw ? 2 : ((a.Cin % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) ? 0 : 1);
     const int vec = in_mode == 0 ? 4 : 1;
@@ -1116,8 +1125,8 @@ int dcv_direct_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d, int* rows_per_sam
     return (int)dcv_ceil_div(t.total_subtiles, t.nsub);
 }
 
-int dcv_direct_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t st, bool prepared) {
-    return run_direct(dgrad_args(d), dy, w, nullptr, dx, ws, ws_bytes, st, prepared);
+int dcv_direct_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t st, bool prepared, const float* addend) {
+    return run_direct(dgrad_args(d), dy, w, nullptr, dx, ws, ws_bytes, st, prepared, nullptr, addend);
 }
 
 int dcv_direct_conv2d_prep_entries(const dcv_conv2d_desc* d, int op, dcv_prep_entry* e) {

@@ -10,7 +10,9 @@ size_t dcv_direct_conv2d_dgrad_ws(const dcv_conv2d_desc* d);
 // *rows_per_sample (nullable) > 0: no row mixes samples, sample n owns rows [n * rps, (n + 1) * rps)
 int dcv_direct_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w, const float* bias, float* y, void* ws, size_t ws_bytes, hipStream_t st, bool prepared = false, double* stats = nullptr);
 int dcv_direct_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d, int* rows_per_sample = nullptr);
-int dcv_direct_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t st, bool prepared = false);
+// `addend` (nullable): dx = data gradient + addend (a tensor shaped like dx); DCV_ERR_UNSUPPORTED when the kernel serving the layer cannot (nothing is launched then)
+int dcv_direct_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t st, bool prepared = false,
+                            const float* addend = nullptr);
 size_t dcv_direct_conv2d_wgrad_ws(const dcv_conv2d_desc* d);
 bool dcv_direct_conv2d_wgrad_fuses_bias(const dcv_conv2d_desc* d);
 int dcv_direct_conv2d_wgrad_multi(int count, const dcv_wgrad_job* jobs, const bool* eligible, bool* taken, dcv_slab_segment* segs, int* nsegs, hipStream_t st);

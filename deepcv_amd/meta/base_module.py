@@ -18,6 +18,7 @@ import torch.nn
 
 from ..utils import NL, NUMBER_T, human_readable_size
 from . import nn as deepcv_nn
+from .. import ops as native_ops
 from . import nn_spec
 from .submodule_creators import ForwardCallbackSubmodule
 from .types_aliases import *
@@ -87,6 +88,7 @@ class DeepcvModule(torch.nn.Module):
 
         # Output tensor reference(s) (`_from`) need specific handling: stash referenced outputs until their last referrer consumed them
         referenced_output_features: Dict[str, TENSOR_OR_SEQ_OF_TENSORS_T] = {}
+        fan_slots: Dict[str, Any] = {}
         remaining_refs = dict(self._submodule_references)
         items = list(self._child_modules.items())
         i = 0
@@ -94,7 +96,12 @@ class DeepcvModule(torch.nn.Module):
             name, subm = items[i]
             refs = getattr(subm, 'referenced_submodules', None)
             if refs:
-                current = OrderedDict((ref, referenced_output_features[ref]) for ref in refs)
+                current = OrderedDict()
+                for ref in refs:
+                    t = referenced_output_features[ref]
+                    if ref in fan_slots:                          # the tap node is created now: younger than the main path, its backward runs before it
+                        t = native_ops.ref_tap(t, fan_slots.pop(ref))
+                    current[ref] = t
                 del remaining_refs[name]
                 for ref in refs:
                     if not any(ref in r for r in remaining_refs.values()):
@@ -109,8 +116,15 @@ class DeepcvModule(torch.nn.Module):
                     name, x = items[i][0], fused
                 else:
                     x = subm(x)
-            if any(name in r for r in remaining_refs.values()):
-                referenced_output_features[name] = x
+            referrers = sum(1 for r in remaining_refs.values() if name in r)
+            if referrers:
+                if (referrers == 1 and isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4 and x.requires_grad and torch.is_grad_enabled()
+                        and i + 1 < len(items) and not getattr(items[i + 1][1], 'referenced_submodules', None)):
+                    # ONE later referrer and a regular consumer next: the referrer's gradient can be added by the consumer's data-gradient kernel
+                    x, ref, fan_slots[name] = native_ops.fan_out(x)
+                    referenced_output_features[name] = ref
+                else:
+                    referenced_output_features[name] = x
             i += 1
         return x
 

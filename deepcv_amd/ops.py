@@ -16,7 +16,7 @@ from . import grads
 from . import slabs
 from ._native import lib
 
-__all__ = ['conv2d', 'set_conv_math', 'set_norm_streaming', 'conv_norm_layer', 'activation', 'batch_norm', 'sync_batch_norm', 'group_norm', 'pool2d', 'interpolate_bilinear', 'concat_channels', 'resize_concat', 'add_tensors', 'flatten_nchw_order',
+__all__ = ['conv2d', 'set_conv_math', 'set_norm_streaming', 'conv_norm_layer', 'fan_out', 'ref_tap', 'activation', 'batch_norm', 'sync_batch_norm', 'group_norm', 'pool2d', 'interpolate_bilinear', 'concat_channels', 'resize_concat', 'add_tensors', 'flatten_nchw_order',
            'linear', 'linear_nhwc', 'cross_entropy', 'act_code', 'to_nhwc', 'nchw_to_nhwc']
 
 _CL = torch.channels_last
@@ -140,13 +140,89 @@ def _conv_fwd_launch(d, x, weight, bias, y, st, want_stats: bool = False):
     return None
 
 
-def _conv_dgrad_launch(dd, dz, weight, dx, st):
+def _conv_dgrad_launch(dd, dz, weight, dx, st, addend: Optional[torch.Tensor] = None) -> bool:
+    """ Data gradient of a convolution into `dx`.  With `addend` (shaped and laid out like dx) tries dx = gradient + addend in the kernel's epilogue; returns
+    whether the addend was taken (kernels without that epilogue compute the plain gradient). """
     f = filters.get(weight, dd, 1)
     if f is not None:
+        if addend is not None:
+            rc = lib.dcv_conv2d_dgrad_prepared_add(dd, dz.data_ptr(), weight.data_ptr(), f.data_ptr(), addend.data_ptr(), dx.data_ptr(), st)
+            if rc != nat.ERR_UNSUPPORTED:
+                nat.check(rc, 'dcv_conv2d_dgrad_prepared_add')
+                return True
         nat.check(lib.dcv_conv2d_dgrad_prepared(dd, dz.data_ptr(), weight.data_ptr(), f.data_ptr(), dx.data_ptr(), st), 'dcv_conv2d_dgrad_prepared')
-        return
+        return False
     ws = _ws(lib.dcv_conv2d_dgrad_workspace_bytes(dd), dz.device)
     nat.check(lib.dcv_conv2d_dgrad(dd, dz.data_ptr(), weight.data_ptr(), dx.data_ptr(), ws.data_ptr(), ws.numel(), st), 'dcv_conv2d_dgrad')
+    return False
+
+
+# ------------------------------------------------------------------------------------------------ fan-out of a referenced tensor (`_from` links)
+# A sub-module output referenced by a later link (reference `nn_spec.py:218-243`, `submodule_creators.py:272-327`) feeds two consumers; autograd sums their two
+# gradients with a separate elementwise kernel.  `fan_out` + `ref_tap` route the link's gradient through a slot instead, so that the data-gradient kernel of
+# the main consumer (which runs later in the backward pass) adds it in its epilogue (`dcv_conv2d_dgrad_prepared_add`); whatever is not fused that way is added
+# by `_FanOutFn.backward` with the native addition kernel.
+
+class _FanSlot:
+    __slots__ = ('grad', 'consumed')
+
+    def __init__(self):
+        self.grad, self.consumed = None, False
+
+
+class _FanOutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, slot):
+        ctx.slot = slot
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g_main, g_ref):
+        slot = ctx.slot
+        pending = None if slot.consumed else slot.grad          # the link's gradient, unless the main consumer's data-gradient kernel already added it
+        slot.grad, slot.consumed = None, False
+        parts = [g for g in (g_main, g_ref, pending) if g is not None]
+        if not parts:
+            return None, None
+        total = parts[0]
+        for g in parts[1:]:
+            a, b = to_nhwc(total) if total.dim() == 4 else total.contiguous(), to_nhwc(g) if g.dim() == 4 else g.contiguous()
+            out = torch.empty_like(a)
+            nat.check(lib.dcv_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), out.numel(), nat.current_stream(out.device)), 'dcv_add')
+            total = out
+        return total, None
+
+
+class _RefTapFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, slot):
+        ctx.slot = slot
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.slot.grad = g                                       # picked up by the main consumer's data gradient, or by _FanOutFn.backward
+        return None, None
+
+
+def fan_out(x: torch.Tensor):
+    """ (main, ref, slot): two aliases of `x` for its regular consumer and for ONE later `_from` referrer; `ref` must go through `ref_tap(ref, slot)` when the
+    referrer consumes it (that node is then younger than every node of the main path, so its backward runs first). """
+    slot = _FanSlot()
+    main, ref = _FanOutFn.apply(x, slot)
+    main._dcv_fan_slot = slot
+    return main, ref, slot
+
+
+def ref_tap(ref: torch.Tensor, slot) -> torch.Tensor:
+    return _RefTapFn.apply(ref, slot)
+
+
+def _fan_addend(slot, like_shape) -> Optional[torch.Tensor]:
+    if slot is None or slot.consumed or slot.grad is None or tuple(slot.grad.shape) != tuple(like_shape):
+        return None
+    return to_nhwc(slot.grad)
 
 
 class _Conv2dFn(torch.autograd.Function):
@@ -439,6 +515,7 @@ class _ConvNormLayerFn(torch.autograd.Function):
         else:
             x, layout = to_nhwc(x), nat.LAYOUT_NHWC
         ctx.weight_ref, ctx.bias_ref, ctx.norm_refs = weight, bias, (bn_w, bn_b, gn_w, gn_b)
+        ctx.fan_slot = getattr(x, '_dcv_fan_slot', None)          # x is also referenced by a later link: its gradient may ride in our data gradient
         slabs.note_use(weight if ctx.needs_input_grad[1] else None, bias if ctx.needs_input_grad[2] else None)
         weight = weight.contiguous()
         d = _conv_desc(x.shape, weight.shape, stride, padding, dilation, layout, act, slope)
@@ -511,7 +588,9 @@ class _ConvNormLayerFn(torch.autograd.Function):
             dd = nat.Conv2dDesc.from_buffer_copy(d)
             dd.x_layout = nat.LAYOUT_NHWC
             dx = torch.empty((d.n, d.cin, d.h, d.w), dtype=dz.dtype, device=dev, memory_format=_CL)
-            _conv_dgrad_launch(dd, dz, weight, dx, st)
+            addend = _fan_addend(ctx.fan_slot, dx.shape)
+            if _conv_dgrad_launch(dd, dz, weight, dx, st, addend):
+                ctx.fan_slot.consumed = True
         if need[1]:
             dw = _grad_buffer(ctx.weight_ref, like=weight)
             _conv_wgrad_launch(d, x, dz, ctx.weight_ref, ctx.bias_ref, dw, db if db_from_wgrad else None, st)

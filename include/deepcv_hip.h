@@ -144,6 +144,10 @@ int dcv_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d);
 int dcv_conv2d_fwd_stats_layout(const dcv_conv2d_desc* d, int* rows, int* rows_per_sample);
 int dcv_conv2d_fwd_prepared(const dcv_conv2d_desc* d, const float* x, const float* w, const void* filter, const float* bias, float* y, double* stats, void* stream);
 int dcv_conv2d_dgrad_prepared(const dcv_conv2d_desc* d, const float* dy, const float* w, const void* filter, float* dx, void* stream);
+/* dx = data gradient + addend, in the data-gradient kernel's epilogue: `addend` ([N][H][W][Cin] like dx) is the gradient which reaches the layer's input over
+ * another edge of the graph (a `_from` link of the reference's architecture grammar, nn_spec.py:218-243), so that autograd's separate accumulation kernel
+ * disappears.  DCV_ERR_UNSUPPORTED (nothing launched) when the kernel serving this layer has no such epilogue: add separately then. */
+int dcv_conv2d_dgrad_prepared_add(const dcv_conv2d_desc* d, const float* dy, const float* w, const void* filter, const float* addend, float* dx, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K4  elementwise activation (standalone; conv/linear fuse it into their epilogue)

@@ -310,6 +310,50 @@ def test_train_api_ragged_last_batch(device, params, tmp_path):
     assert metrics['valid_main_loss'] == metrics['valid_main_loss'] and 0. <= metrics['valid_accuracy'] <= 1.
 
 
+def test_link_gradient_rides_in_the_data_gradient_kernel(device, params):
+    """ Stock backbone: `pooling1` feeds the fourth layer AND the dense link (`_from: pooling1`, reference parameters.yml:19).  The link's gradient is routed
+    through a slot (`ops.fan_out` / `ops.ref_tap`) and added by the fourth layer's data-gradient kernel (`dcv_conv2d_dgrad_prepared_add`) instead of by a
+    separate accumulation kernel of the autograd engine; gradients must equal those of the plain path (same kernels + torch's add), up to the order of
+    one addition. """
+    from deepcv_amd import modules as native_modules, ops
+    from deepcv_amd.classification.image import create_model
+    from deepcv_amd.meta.data.datasets import SyntheticImageDataset
+    (x, y), = _batches(1, 16)
+    x, y = x.to(device), y.to(device)
+
+    def run(fused: bool):
+        torch.manual_seed(SEED)
+        model = create_model({'trainset': SyntheticImageDataset(8)}, params['image_classifier_model']).to(device).train()
+        taken = []
+        orig_launch, orig_fan = ops._conv_dgrad_launch, ops.fan_out
+
+        def spy(dd, dz, weight, dx, st, addend=None):
+            r = orig_launch(dd, dz, weight, dx, st, addend)
+            taken.append((addend is not None, r))
+            return r
+        ops._conv_dgrad_launch = spy
+        if not fused:
+            ops.fan_out = lambda t: (t, t, None)                  # plain path: both consumers hold the tensor itself, the engine sums the gradients
+            orig_tap, ops.ref_tap = ops.ref_tap, (lambda t, slot: t)
+        try:
+            loss = native_modules.CrossEntropyLoss()(model(x), y)
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            ops._conv_dgrad_launch, ops.fan_out = orig_launch, orig_fan
+            if not fused:
+                ops.ref_tap = orig_tap
+        return loss.item(), {n: p.grad.detach().clone() for n, p in model.named_parameters()}, taken
+
+    (l1, g1, t1), (l0, g0, t0) = run(True), run(False)
+    assert [t for t in t1 if t[0]] == [(True, True)], f'exactly one data-gradient launch must take the link gradient: {t1}'
+    assert not any(t[0] for t in t0)
+    assert l1 == l0
+    gscale = max(g.abs().max().item() for g in g0.values())
+    for n in g0:
+        assert (g1[n] - g0[n]).abs().max().item() <= 1e-6 * gscale + 1e-5 * g0[n].abs().max().item(), n
+
+
 def test_replayed_step_keeps_late_prepared_filters_fresh(device, params):
     """ Three "epochs" of [32, 32, 16]-sample batches through `GraphedTrainStep`: the 16-sample batches run eagerly between replays, and their prepared
     filters (forward + data gradient, keyed by batch size) are created AFTER the capture, so no replayed launch refreshes them.  From the second epoch on

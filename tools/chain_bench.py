@@ -66,9 +66,80 @@ def norm_case(n, h, w, c, G, pool, old, bwd):
     return (bwdf if bwd else fwd), keep + [ws]
 
 
+# the stock convolution layers at N = 512: (Cin, H, Cout, k, pad, nchw input)
+CONVS = [(3, 32, 4, 5, 2, True), (4, 32, 4, 5, 2, False), (4, 16, 16, 3, 1, False), (16, 16, 16, 3, 1, False)]
+
+
+def conv_case(cin, h, cout, k, pad, nchw, op):
+    n = 512
+    cl = torch.channels_last
+    x = torch.randn(n, cin, h, h, device=dev)
+    x = x.contiguous() if nchw else x.contiguous(memory_format=cl)
+    wt = torch.randn(cout, cin, k, k, device=dev) * 0.1
+    b = torch.zeros(cout, device=dev)
+    y = torch.empty(n, cout, h, h, device=dev).contiguous(memory_format=cl)
+    dy = torch.randn(n, cout, h, h, device=dev).contiguous(memory_format=cl)
+    dx = torch.empty(n, cin, h, h, device=dev).contiguous(memory_format=cl)
+    d = nat.Conv2dDesc(n, h, h, cin, cout, k, k, 1, 1, pad, pad, 1, 1, 1, h, h, nat.LAYOUT_NCHW if nchw else nat.LAYOUT_NHWC, nat.ACT_RELU, 0., 0)
+    dd = nat.Conv2dDesc.from_buffer_copy(d); dd.x_layout = nat.LAYOUT_NHWC
+    keep = [x, wt, b, y, dy, dx]
+    st0 = nat.current_stream(dev)
+
+    def prepared(desc, o):
+        f = torch.empty(max(16, lib.dcv_conv2d_filter_bytes(desc, o)), dtype=torch.uint8, device=dev)
+        nat.check(lib.dcv_conv2d_prepare_filters(1, (ctypes.POINTER(nat.Conv2dDesc) * 1)(ctypes.pointer(desc)), (ctypes.c_int * 1)(o), (ctypes.c_void_p * 1)(wt.data_ptr()),
+                                                 (ctypes.c_void_p * 1)(f.data_ptr()), st0))
+        keep.append(f)
+        return f
+    if op == 'fwd':
+        f = prepared(d, 0)
+        rows = lib.dcv_conv2d_fwd_stats_rows(d)
+        stats = torch.empty((2, cout, max(1, rows)), dtype=torch.float64, device=dev); keep.append(stats)
+        sp = stats.data_ptr() if rows > 0 else None
+        return (lambda st: nat.check(lib.dcv_conv2d_fwd_prepared(d, x.data_ptr(), wt.data_ptr(), f.data_ptr(), b.data_ptr(), y.data_ptr(), sp, st))), keep
+    if op == 'dgrad':
+        f = prepared(dd, 1)
+        return (lambda st: nat.check(lib.dcv_conv2d_dgrad_prepared(dd, dy.data_ptr(), wt.data_ptr(), f.data_ptr(), dx.data_ptr(), st))), keep
+    dw, db = torch.empty_like(wt), torch.empty_like(b)
+    ws = torch.empty(lib.dcv_conv2d_wgrad_workspace_bytes(d), dtype=torch.uint8, device=dev); keep += [dw, db, ws]
+    return (lambda st: nat.check(lib.dcv_conv2d_wgrad(d, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(), st))), keep
+
+
+def wgrad_batch_case():
+    """ the five stock layers' weight gradients as the training step runs them: one multi-layer launch + one ordered slab sum """
+    jobs, keep = [], []
+    for cin, h, cout, k, pad, nchw in [CONVS[0], CONVS[1], CONVS[1], CONVS[2], CONVS[3]]:
+        n = 512
+        x = torch.randn(n, cin, h, h, device=dev); x = x.contiguous() if nchw else x.contiguous(memory_format=torch.channels_last)
+        dy = torch.randn(n, cout, h, h, device=dev).contiguous(memory_format=torch.channels_last)
+        dw, db = torch.empty(cout, cin, k, k, device=dev), torch.empty(cout, device=dev)
+        d = nat.Conv2dDesc(n, h, h, cin, cout, k, k, 1, 1, pad, pad, 1, 1, 1, h, h, nat.LAYOUT_NCHW if nchw else nat.LAYOUT_NHWC, nat.ACT_RELU, 0., 0)
+        ws = torch.empty(lib.dcv_conv2d_wgrad_workspace_bytes(d), dtype=torch.uint8, device=dev)
+        j = nat.WgradJob(); ctypes.pointer(j.desc)[0] = d
+        j.x, j.dy, j.dw, j.db, j.ws, j.ws_bytes = x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel()
+        jobs.append(j); keep += [x, dy, dw, db, ws]
+    jarr = (nat.WgradJob * len(jobs))(*jobs)
+
+    def fn(st):
+        segs, ns = (nat.SlabSegment * (2 * len(jobs)))(), ctypes.c_int(0)
+        nat.check(lib.dcv_conv2d_wgrad_batch(len(jobs), jarr, segs, ctypes.byref(ns), st))
+        if ns.value:
+            nat.check(lib.dcv_slab_reduce(ns.value, segs, st))
+    return fn, keep + [jarr]
+
+
 cases = sys.argv[1:] or ['norm_fwd_old', 'norm_fwd', 'norm_bwd_old', 'norm_bwd']
 for case in cases:
     if case.startswith('norm'):
         for shp in SHAPES:
             fn, keep = norm_case(*shp, old=case.endswith('_old'), bwd='bwd' in case)
             print(f'{case:14s} N,H,W,C,G,pool={shp}: {chain_us(fn):7.2f} us per call', flush=True)
+    elif case in ('conv_fwd', 'conv_dgrad', 'conv_wgrad'):
+        for cv in CONVS:
+            if case == 'conv_dgrad' and cv[5]:
+                continue
+            fn, keep = conv_case(*cv, op=case[5:])
+            print(f'{case:14s} Cin,H,Cout,k,pad,nchw={cv}: {chain_us(fn):7.2f} us per call', flush=True)
+    elif case == 'wgrad_batch':
+        fn, keep = wgrad_batch_case()
+        print(f'{case:14s} five stock layers, multi-layer launch + slab sum: {chain_us(fn):7.2f} us per call', flush=True)
