@@ -49,3 +49,114 @@ def test_two_ranks_sharing_the_gpu_over_gloo(device):
     r = json.loads(lines[0])
     assert r['n_gpus'] == 2 and r['config']['parallelism'] == 'dp2' and r['config']['global_batch'] == 1024 and r['value'] > 0
     assert 0.0 < r['config']['final_loss'] < 10.0 and 'cpu_baseline' not in r
+
+
+# ------------------------------------------------------------------------------------------------ multi-rank HIP runs against the oracle's DDP emulation
+WORLD, SEED, DP_STEPS = 2, 563454, 4
+
+
+def _dp_global_batches():
+    import torch
+    g = torch.Generator().manual_seed(434546)
+    return [(torch.randn(16, 3, 32, 32, generator=g), torch.randint(0, 10, (16,), generator=g)) for _ in range(DP_STEPS)]
+
+
+def _hip_dp_worker(rank, port, out_dir, backend, spec, graph):
+    """ One rank of a data-parallel run on the HIP path, built the way `train()` builds it: native model, `DataParallelModel` (rank-0 broadcast, gradient arena),
+    native AdamW, `graphed_train_step` (or the eager step with autograd hooks).  `gloo`: both ranks share GPU 0; `nccl` (RCCL): one GPU per rank. """
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, str(ROOT))
+    from deepcv_amd import modules, optim
+    from deepcv_amd.classification.image import create_model
+    from deepcv_amd.meta.data.datasets import SyntheticImageDataset
+    from deepcv_amd.meta.ignite_training import GraphedTrainStep, _setup_losses, graphed_train_step
+    from deepcv_amd.meta.schedulers import PiecewiseLinear
+    from deepcv_amd.parallel import DataParallelModel
+    from deepcv_amd.utils import load_parameters
+    from oracle import deepcv_oracle as O
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    device = torch.device('cuda', rank if backend == 'nccl' else 0)
+    torch.cuda.set_device(device)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=WORLD, device_id=device)
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    params = load_parameters()
+    torch.manual_seed(SEED + rank)            # different init per rank: the wrapper's broadcast must make the replicas identical
+    model = create_model({'trainset': SyntheticImageDataset(8)}, params[spec]).to(device)
+    dp = DataParallelModel(model, overlap=True)
+    hp = dict(params['train_image_classifier']); hp['epochs'] = 1
+    opt = optim.AdamW(dp.module.parameters(), **hp['optimizer_opts'])
+    sched = PiecewiseLinear(opt, 'lr', O.stock_milestones(hp, DP_STEPS))
+    losses, weights = _setup_losses(modules.CrossEntropyLoss(), None, device)
+    if graph:
+        step = graphed_train_step(dp, opt, losses, weights, dp.reducer)
+    else:
+        step = GraphedTrainStep(dp, opt, losses, weights, reducer=dp.reducer)
+    got = []
+    for x, y in _dp_global_batches():
+        sched(None)
+        xr, yr = x[rank::WORLD].contiguous().to(device), y[rank::WORLD].contiguous().to(device)
+        if graph:
+            step(xr, yr)
+            got.append(step.loss_values()['main_loss'])
+        else:
+            out, _ = step._on_side_stream(step._eager, xr, yr)
+            got.append(out['main_loss'].item())
+    torch.cuda.synchronize()
+    torch.save({'losses': got, 'params': [p.detach().cpu().clone() for p in dp.module.parameters()],
+                'graph_replays': step.calls - 2 if graph else 0}, Path(out_dir) / f'rank{rank}.pt')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_hip_dp(backend, spec, graph, params):
+    import socket
+    import tempfile
+    import torch
+    import torch.multiprocessing as mp
+    from oracle import deepcv_oracle as O
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_hip_dp_worker, args=(port, d, backend, spec, graph), nprocs=WORLD, join=True)
+        r = [torch.load(Path(d) / f'rank{k}.pt', weights_only=False) for k in range(WORLD)]
+    for a, b in zip(r[0]['params'], r[1]['params']):
+        assert torch.equal(a, b), 'replicas must stay bit-identical'
+    torch.manual_seed(SEED)                   # the replicas start from rank 0's weights
+    ref_model = O.create_model((3, 32, 32), params[spec], 10)
+    hp = dict(params['train_image_classifier']); hp['epochs'] = 1
+    ref = O.train_steps_data_parallel(ref_model, _dp_global_batches(), hp, DP_STEPS, WORLD, iterations_per_epoch=DP_STEPS)
+    for t in range(DP_STEPS):
+        for k in range(WORLD):
+            assert abs(r[k]['losses'][t] - ref[t][k]) <= 1e-4 * abs(ref[t][k]), f'step {t} rank {k}: {r[k]["losses"][t]} vs oracle {ref[t][k]}'
+    gscale = max(p.grad.abs().max().item() for p in ref_model.parameters())
+    compared = 0
+    for p_n, p_o in zip(r[0]['params'], ref_model.parameters()):
+        if p_o.grad.abs().max().item() < 1e-4 * gscale:
+            continue                          # gauge directions, see tests/test_model_gpu.py
+        compared += 1
+        assert (p_n - p_o.detach()).abs().max().item() <= 1e-4 * p_o.detach().abs().max().item() + 2e-5
+    assert compared >= 6
+    return r
+
+
+@pytest.mark.parametrize('graph', [True, False], ids=['hipgraph', 'eager-hooks'])
+@pytest.mark.parametrize('spec', ['image_classifier_bn_only_model', 'image_classifier_model'])
+def test_two_hip_ranks_over_gloo_match_oracle_ddp_emulation(device, params, spec, graph):
+    """ Reference DDP (`ignite_training.py:373-390`, sampler `:260`) on the HIP path with REAL multi-rank arithmetic: two processes share this box's GPU,
+    the gradient buckets are averaged over gloo; per-rank losses of every step and the final weights must follow the oracle's DDP emulation (per-shard
+    BatchNorm statistics, mean of gradients) within 1e-4, as the CPU twin of this test does (tests/test_data_parallel.py). """
+    r = _run_hip_dp('gloo', spec, graph, params)
+    if graph:
+        assert r[0]['graph_replays'] == DP_STEPS - 2
+
+
+def test_two_hip_ranks_over_rccl_match_oracle_ddp_emulation(params):
+    """ The same over RCCL (`nccl` backend), one GPU per rank: runs wherever two GPUs are visible (the driver's multi-GPU node), skips on a 1-GPU box. """
+    import torch
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip('needs two HIP devices')
+    _run_hip_dp('nccl', 'image_classifier_model', True, params)
