@@ -136,7 +136,8 @@ _SIGNATURES = {
     'dcv_resize_split_channels': (_c_int, [_c_int, ctypes.POINTER(_P), ctypes.POINTER(_c_int), ctypes.POINTER(_c_int), ctypes.POINTER(_c_int), _P,
                                            _c_int, _c_int, _c_int, _c_int, _P]),
     'dcv_images_u8_normalize': (_c_int, [_P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _P, _P, _P]),
-    'dcv_images_u8_augment_normalize': (_c_int, [_P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P]),
+    'dcv_images_u8_augment_scratch_bytes': (_c_size_t, [_c_int, _c_int, _c_int, _c_int]),
+    'dcv_images_u8_augment_normalize': (_c_int, [_P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _c_size_t, _P]),
     'dcv_indirect_copy': (_c_int, [_P, _P]),
     'dcv_publish_scalars': (_c_int, [_P, ctypes.POINTER(_P), _c_int, _P, _P, _P]),
     'dcv_add': (_c_int, [_P, _P, _P, _c_size_t, _P]),

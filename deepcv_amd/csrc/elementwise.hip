@@ -148,55 +148,6 @@ __global__ __launch_bounds__(256) void images_u8_normalize_kernel(const unsigned
     }
 }
 
-// AugMix-style augmentation fused with normalisation: one thread per output pixel.  For every chain the source position is found by walking the chain's
-// translations BACKWARDS (a position leaving the image at any translate stage yields the zero fill, which every later op maps to zero), then the
-// pointwise ops are applied forwards to the fetched bytes.
-__device__ __forceinline__ int aug_pointwise(int v, int op, int p) {
-    switch (op) {
-        case DCV_AUG_POSTERIZE: return v & ~((1 << (8 - p)) - 1);
-        case DCV_AUG_SOLARIZE: return v < p ? v : 255 - v;
-        case DCV_AUG_BRIGHTNESS: { const int t = (v * p) >> 8; return t > 255 ? 255 : t; }
-        default: return v;
-    }
-}
-
-template <int DST_NCHW>
-__global__ __launch_bounds__(256) void images_u8_augment_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst, int N, int H, int W, int C,
-                                                                 const dcv_aug_sample* __restrict__ samples, const float* __restrict__ mean, const float* __restrict__ inv_std) {
-    const int hw = H * W;
-    const size_t pixels = (size_t)N * hw;
-    for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < pixels; pix += (size_t)gridDim.x * blockDim.x) {
-        const int n = (int)(pix / hw), q = (int)(pix - (size_t)n * hw);
-        const int y = q / W, x = q - y * W;
-        const dcv_aug_sample& sp = samples[n];
-        const unsigned char* img = src + (size_t)n * hw * C;
-        float mixv[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int ch = 0; ch < DCV_AUG_MAX_CHAINS; ++ch) {
-            const float wgt = sp.weight[ch];
-            if (wgt == 0.f) continue;
-            int sx = x, sy = y; bool inside = true;
-            for (int k = DCV_AUG_MAX_OPS - 1; k >= 0; --k) {
-                const int op = sp.op[ch][k], p = sp.param[ch][k];
-                if (op == DCV_AUG_TRANSLATE_X) sx += p; else if (op == DCV_AUG_TRANSLATE_Y) sy += p; else continue;
-                inside = inside && sx >= 0 && sx < W && sy >= 0 && sy < H;
-            }
-            if (!inside) continue;                                // zero fill stays zero through posterize / solarize / brightness
-            const unsigned char* pp = img + ((size_t)sy * W + sx) * C;
-            for (int c = 0; c < C && c < 4; ++c) {
-                int v = pp[c];
-                for (int k = 0; k < DCV_AUG_MAX_OPS; ++k) v = aug_pointwise(v, sp.op[ch][k], sp.param[ch][k]);
-                mixv[c] += wgt * (float)v;
-            }
-        }
-        const unsigned char* po = img + (size_t)q * C;
-        for (int c = 0; c < C && c < 4; ++c) {
-            const float v = (1.f - sp.mix) * (float)po[c] + sp.mix * mixv[c];
-            const float o = (v * (1.f / 255.f) - mean[c]) * inv_std[c];
-            if (DST_NCHW) dst[((size_t)n * C + c) * hw + q] = o; else dst[pix * C + c] = o;
-        }
-    }
-}
-
 struct ScalarPtrs { const float* p[DCV_MAX_COPY_JOBS]; };
 __global__ __launch_bounds__(64) void publish_scalars_kernel(const dcv_copy_jobs* __restrict__ mailbox, ScalarPtrs srcs, int n, float* host_vals, int* host_seq) {
     const int t = threadIdx.x;
@@ -646,16 +597,6 @@ int dcv_images_u8_normalize(const unsigned char* src, float* dst, int n, int h, 
     hipStream_t st = dcv_stream(stream);
     if (dst_layout == DCV_LAYOUT_NCHW) hipLaunchKernelGGL((images_u8_normalize_kernel<1>), dim3(dcv_stream_grid(pixels, 256)), dim3(256), 0, st, src, dst, pixels, h * w, c, mean, inv_std);
     else hipLaunchKernelGGL((images_u8_normalize_kernel<0>), dim3(dcv_stream_grid(pixels, 256)), dim3(256), 0, st, src, dst, pixels, h * w, c, mean, inv_std);
-    DCV_RETURN_LAUNCH();
-}
-
-int dcv_images_u8_augment_normalize(const unsigned char* src, float* dst, int n, int h, int w, int c, int dst_layout, const dcv_aug_sample* samples,
-                                    const float* mean, const float* inv_std, void* stream) {
-    DCV_CHECK_ARG(src && dst && samples && mean && inv_std && n > 0 && h > 0 && w > 0 && c > 0 && c <= 4 && (dst_layout == DCV_LAYOUT_NCHW || dst_layout == DCV_LAYOUT_NHWC));
-    const size_t pixels = (size_t)n * h * w;
-    hipStream_t st = dcv_stream(stream);
-    if (dst_layout == DCV_LAYOUT_NCHW) hipLaunchKernelGGL((images_u8_augment_kernel<1>), dim3(dcv_stream_grid(pixels, 256)), dim3(256), 0, st, src, dst, n, h, w, c, samples, mean, inv_std);
-    else hipLaunchKernelGGL((images_u8_augment_kernel<0>), dim3(dcv_stream_grid(pixels, 256)), dim3(256), 0, st, src, dst, n, h, w, c, samples, mean, inv_std);
     DCV_RETURN_LAUNCH();
 }
 

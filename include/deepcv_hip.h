@@ -338,13 +338,18 @@ int dcv_images_u8_normalize(const unsigned char* src, float* dst, int n, int h, 
                             const float* mean, const float* inv_std, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
- * GPU augmentation: AugMix-style chains of the reference's PIL operations (src/deepcv/meta/data/augmentation.py:73-124,165-203)
- * applied per sample ON THE DEVICE and fused with ToTensor + Normalize:
+ * GPU augmentation: AugMix-style chains of the reference's 13 image operations (src/deepcv/meta/data/augmentation.py:65-132, mixed like
+ * augment_and_mix, :165-203) applied per sample ON THE DEVICE and fused with ToTensor + Normalize:
  *     out = normalize( (1 - m) * x + m * sum_i w_i * chain_i(x) ),   chain_i = up to DCV_AUG_MAX_OPS ops applied in order
- * ops (codes DCV_AUG_*, integer parameter p): POSTERIZE keeps the p high bits; SOLARIZE inverts pixels >= p; TRANSLATE_X / _Y shift by p pixels with
- * zero fill (PIL AFFINE (1,0,p,0,1,0): out(x, y) = in(x + p, y)); BRIGHTNESS multiplies by p / 256 and truncates like PIL's blend (p in 1/256 steps).
- * The random draws (which ops, which parameters, mixing weights) are made on the host by the caller (`deepcv_amd.meta.data.augmentation`), which keeps
- * them reproducible from a seed; this entry point is deterministic.  src: [N][H][W][C] uint8; dst: fp32 NCHW or NHWC.
+ * Every operation reproduces Pillow's arithmetic bit for bit on the uint8 images (the reference calls ImageOps / Image.rotate / Image.transform / ImageEnhance):
+ *   POSTERIZE keeps the `ip` high bits; SOLARIZE inverts pixels >= `ip`; AUTOCONTRAST / EQUALIZE: per-band histogram tables;
+ *   TRANSLATE_X / _Y, ROTATE, SHEAR_X / _Y: Image.transform(size, AFFINE, m, resample=BILINEAR) with zero fill, `m` = the six coefficients Pillow derives from
+ *   the pixel offset / angle / shear factor (computed by the caller like Image.rotate does);
+ *   COLOR / CONTRAST / BRIGHTNESS / SHARPNESS: ImageEnhance.*(img).enhance(fp) = Image.blend(degenerate, img, fp) in float32.
+ * The random draws (which ops, parameters, mixing weights) are made on the host by the caller (`deepcv_amd.meta.data.augmentation`), reproducible from a seed;
+ * this entry point is deterministic.  src: [N][H][W][C] uint8, C = 1 (grey levels) or 3 (RGB); dst: fp32 NCHW or NHWC.  scratch: the two uint8 working images
+ * of every (sample, chain), dcv_images_u8_augment_scratch_bytes(n, h, w, c) bytes; on return buffer 0 of (sample i, chain j), at offset
+ * ((i * DCV_AUG_MAX_CHAINS + j) * 2) * h * w * c, holds the image that chain ended with.
  * ------------------------------------------------------------------------------------------------- */
 #define DCV_AUG_MAX_CHAINS 3
 #define DCV_AUG_MAX_OPS 3
@@ -354,14 +359,27 @@ int dcv_images_u8_normalize(const unsigned char* src, float* dst, int n, int h, 
 #define DCV_AUG_TRANSLATE_X 3
 #define DCV_AUG_TRANSLATE_Y 4
 #define DCV_AUG_BRIGHTNESS 5
+#define DCV_AUG_AUTOCONTRAST 6
+#define DCV_AUG_EQUALIZE 7
+#define DCV_AUG_ROTATE 8
+#define DCV_AUG_SHEAR_X 9
+#define DCV_AUG_SHEAR_Y 10
+#define DCV_AUG_COLOR 11
+#define DCV_AUG_CONTRAST 12
+#define DCV_AUG_SHARPNESS 13
 typedef struct {
     int op[DCV_AUG_MAX_CHAINS][DCV_AUG_MAX_OPS];      /* DCV_AUG_* (DCV_AUG_NONE = identity) */
-    int param[DCV_AUG_MAX_CHAINS][DCV_AUG_MAX_OPS];
+    int ip[DCV_AUG_MAX_CHAINS][DCV_AUG_MAX_OPS];      /* integer parameter: bits, threshold */
+    float fp[DCV_AUG_MAX_CHAINS][DCV_AUG_MAX_OPS];    /* enhancement factor */
     float weight[DCV_AUG_MAX_CHAINS];                 /* w_i (unused chains: 0) */
     float mix;                                        /* m in [0, 1]; 0 = original image */
-} dcv_aug_sample;
+    int reserved;
+    double m[DCV_AUG_MAX_CHAINS][DCV_AUG_MAX_OPS][6]; /* AFFINE coefficients of the geometric ops (offset 128) */
+} dcv_augmix_recipe;                                   /* 560 bytes */
+size_t dcv_images_u8_augment_scratch_bytes(int n, int h, int w, int c);
 int dcv_images_u8_augment_normalize(const unsigned char* src, float* dst, int n, int h, int w, int c, int dst_layout,
-                                    const dcv_aug_sample* samples /* device, [n] */, const float* mean, const float* inv_std, void* stream);
+                                    const dcv_augmix_recipe* recipes /* device, [n] */, const float* mean, const float* inv_std,
+                                    void* scratch, size_t scratch_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Indirect batch staging: up to DCV_MAX_COPY_JOBS (src, dst, bytes) copies whose descriptors are READ BY THE KERNEL AT RUN TIME from `jobs`, a block

@@ -569,29 +569,62 @@ def test_sync_batch_norm_module_conversion(device):
     assert torch.allclose(seq[0].weight.grad, ref[0].weight.grad, atol=1e-4)
 
 
-@pytest.mark.parametrize('shape,severity', [((16, 32, 32, 3), 0.3), ((5, 17, 23, 1), 1.0), ((3, 64, 48, 4), 0.6)], ids=str)
+@pytest.mark.parametrize('shape,severity', [((16, 32, 32, 3), 0.3), ((5, 17, 23, 1), 1.0), ((3, 64, 48, 3), 0.6), ((2, 224, 224, 3), 0.5)], ids=str)
 def test_device_augmentation_matches_oracle(device, shape, severity):
-    """ `DeviceAugmentNormalize` (dcv_images_u8_augment_normalize: fused AugMix-style chains + ToTensor + Normalize) against the whole-image numpy
-    restatement `oracle/augment_ref.py` replaying the same seeded recipes. """
+    """ `DeviceAugmentNormalize` (dcv_images_u8_augment_normalize: AugMix-style chains of the reference's 13 operations + ToTensor + Normalize) against the numpy
+    restatement `oracle/augment_ref.py` (itself pinned against Pillow, tests/test_augment_cpu.py) replaying the same seeded recipes: the uint8 image every chain
+    ends with must match BIT FOR BIT, the mixed + normalised output within float rounding. """
     import numpy as np
-    from deepcv_amd.meta.data.augmentation import DeviceAugmentNormalize
+    from deepcv_amd.meta.data.augmentation import AUG_OPS, DeviceAugmentNormalize
     from oracle import augment_ref
     g = torch.Generator().manual_seed(8)
     img = torch.randint(0, 256, shape, generator=g, dtype=torch.uint8)
     c = shape[-1]
-    mean, std = [0.491, 0.482, 0.447, 0.5][:c], [0.247, 0.243, 0.261, 0.25][:c]
+    mean, std = [0.491, 0.482, 0.447][:c], [0.247, 0.243, 0.261][:c]
     aug = DeviceAugmentNormalize(mean, std, severity=severity, seed=123)
     out = aug(img.to(device))
     rec = aug.last_recipes
     assert (rec['op'] != 0).any() and (rec['mix'] > 0).any()
-    ref = augment_ref.augment_normalize(img.numpy(), rec, mean, std)
     torch.cuda.synchronize()
-    err = (out.cpu().numpy() - ref).__abs__().max()
-    _report(f'augment{shape}: max abs err {err:.3e}')
-    assert out.shape == (shape[0], c, shape[1], shape[2]) and err <= 2e-5
-    # reproducible from the seed
-    out2 = DeviceAugmentNormalize(mean, std, severity=severity, seed=123)(img.to(device))
-    assert torch.equal(out, out2)
+    chains = aug.last_chains.cpu().numpy()
+    ref_chains = augment_ref.chain_images(img.numpy(), rec)
+    used = rec['weight'] > 0
+    for i in range(shape[0]):
+        for ch in range(chains.shape[1]):
+            if used[i, ch]:
+                d = np.abs(chains[i, ch].astype(int) - ref_chains[i, ch].astype(int))
+                assert d.max() == 0, f'sample {i} chain {ch} ops {rec["op"][i, ch].tolist()}: {int((d > 0).sum())} pixels differ (max {d.max()} grey levels)'
+    ref = augment_ref.augment_normalize(img.numpy(), rec, mean, std)
+    err = np.abs(out.cpu().numpy() - ref).max()
+    _report(f'augment{shape}: chains bit-exact, normalised output max abs err {err:.3e}; ops used {sorted(set(rec["op"][rec["op"] > 0].tolist()))}')
+    assert err <= 2e-5
+
+
+@pytest.mark.parametrize('name', ['autocontrast', 'equalize', 'posterize', 'rotate', 'solarize', 'shear_x', 'shear_y', 'translate_x', 'translate_y', 'color', 'contrast',
+                                  'brightness', 'sharpness'])
+def test_device_augmentation_single_operations(device, name):
+    """ Each of the reference's 13 operations alone (one chain of depth one, weight 1, mix 1), several parameter values, RGB and grey-level images, including
+    reduced-range and constant images (degenerate histograms): bit-exact against the Pillow-pinned oracle. """
+    import numpy as np
+    from deepcv_amd.meta.data.augmentation import AUGMIX_RECIPE_DTYPE, DeviceAugmentNormalize, make_op
+    from oracle import augment_ref
+    rs = np.random.RandomState(31)
+    values = {'posterize': [1, 2, 5, 8], 'solarize': [0, 50, 171, 255], 'rotate': [12.3, -29.75, 0.4, 90.0], 'shear_x': [0.21, -0.3, 0.0, 0.05], 'shear_y': [0.17, -0.09, 0.3, -0.3],
+              'translate_x': [3, -5, 0, 40], 'translate_y': [2, -4, 1, -40], 'color': [0.3, 1.0, 1.37, 1.8], 'contrast': [0.3, 0.55, 1.0, 1.8], 'brightness': [0.3, 0.99, 1.0, 1.71],
+              'sharpness': [0.3, 0.42, 1.0, 1.66]}.get(name, [None] * 4)
+    for (h, w, c) in [(32, 32, 3), (19, 27, 1), (2, 5, 3)]:
+        imgs = np.stack([rs.randint(0, 256, (h, w, c)), rs.randint(60, 190, (h, w, c)), np.full((h, w, c), 77), rs.randint(0, 2, (h, w, c)) * 255]).astype(np.uint8)
+        rec = np.zeros(4, dtype=AUGMIX_RECIPE_DTYPE)
+        for i, v in enumerate(values):
+            code, ip, fp, m = make_op(name, h, w, v)
+            rec['op'][i, 0, 0], rec['ip'][i, 0, 0], rec['fp'][i, 0, 0], rec['m'][i, 0, 0] = code, ip, fp, m
+            rec['weight'][i, 0], rec['mix'][i] = 1.0, 1.0
+        aug = DeviceAugmentNormalize([0.5] * c, [0.25] * c)
+        aug(torch.from_numpy(imgs).to(device), recipes=rec)
+        torch.cuda.synchronize()
+        got, ref = aug.last_chains.cpu().numpy()[:, 0], augment_ref.chain_images(imgs, rec)[:, 0]
+        d = np.abs(got.astype(int) - ref.astype(int))
+        assert d.max() == 0, f'{name} on {(h, w, c)}: images {sorted(set(np.nonzero(d)[0].tolist()))} differ, max {d.max()} grey levels'
 
 
 @pytest.mark.parametrize('case', [(4, 64, 16, 16, 64, 3, 1, 1), (2, 128, 8, 8, 64, 3, 1, 1), (2, 64, 16, 16, 128, 3, 2, 1), (3, 32, 9, 11, 64, 3, 1, 1)], ids=str)
