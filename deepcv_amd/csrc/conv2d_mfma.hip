@@ -344,6 +344,212 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(MfmaWgArgs a, cons
         }
 }
 
+
+// ------------------------------------------------------------------------------------------------ weight gradient, all nine taps per block
+// 3x3 / stride 1 / pad 1 layers (every wide layer of the BASELINE specs).  The kernel above gives one tap to each block, so x and dy are fetched nine times
+// through L2 and a 32-pixel step feeds only 32 MFMAs per wave between two barriers: its global loads and their address arithmetic were 27 % of its time.
+// Here a block owns a (pixel chunk, 64 input channels, 64 output channels) problem with ALL nine taps: per step of PS pixels of one image it stages the dy tile
+// [PS][64] once and the flat window of x it touches — pixels [p0 - W - 1, p0 + PS + W + 1) of the image, zero outside the image — as [PS + 2W + 2][64]; tap
+// (r, s) of pixel p reads window row p + r * W + s.  Rows above / below the image are the window's zero fill; a window row which wrapped around the left / right
+// edge is cancelled by zeroing the dy operand of the border pixels for s = 0 / s = 2 (one ds_read of a per-pixel column mask + two selects per A operand).
+// Per step and wave: 9 * PS MFMAs (v_mfma_f32_16x16x4_f32) on 36 accumulator tiles, one LDS read per MFMA, one barrier.
+struct Wg9Args {
+    int N, H, W, Cin, Cout;
+    int XR;                         // window rows: PS + 2 * W + 2
+    int HWp;                        // pixels per image rounded up to a multiple of PS: a step never straddles images, the padding pixels contribute zeros
+    long M, m_per_chunk;            // N * HWp; (padded) pixels per split-K chunk (multiple of PS)
+    size_t wtotal;
+};
+#define W9_LDX 10                   // float4 loads of the x window per thread and step (XR * 16 <= 256 * W9_LDX)
+
+template <int PS, bool BF16, bool PIPE>
+__global__ __launch_bounds__(256, PIPE ? 1 : 2) void conv_mfma_wgrad9_kernel(Wg9Args a, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float smem9[];
+    const int XR = a.XR;
+    float* Gs = smem9;                                           // [2][PS * WG_LD]   dy tile [pixel][co]
+    float* Xs = Gs + 2 * PS * WG_LD;                             // [2][XR * WG_LD]   x window [row][ci]
+    int* Cm = reinterpret_cast<int*>(Xs + 2 * XR * WG_LD);       // [2][PS]           bit 0: w > 0, bit 1: w < W - 1
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int ci0 = blockIdx.y * WG_T, co0 = blockIdx.z * WG_T;
+    const long mb = (long)blockIdx.x * a.m_per_chunk;
+    long me = mb + a.m_per_chunk; if (me > a.M) me = a.M;
+    const int HW = a.H * a.W;
+
+    const int prow = t >> 4, pc4 = t & 15;
+    float4 g[PS / 16], xv[W9_LDX];
+    auto load_step = [&](long m0) {
+        const long n = m0 / a.HWp; const int p0 = (int)(m0 - n * a.HWp);                 // a step never straddles images (PS divides HWp)
+#pragma unroll
+        for (int h = 0; h < PS / 16; ++h) {
+            const int p = p0 + prow + 16 * h;
+            const bool ok = p < HW;
+            const float4 v = *reinterpret_cast<const float4*>(dy + ((size_t)n * HW + (ok ? p : 0)) * a.Cout + co0 + 4 * pc4);
+            g[h] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float* xi = x + (size_t)n * HW * a.Cin + ci0 + 4 * pc4;
+        const int q0 = p0 - a.W - 1;
+#pragma unroll
+        for (int u = 0; u < W9_LDX; ++u) {
+            const int row = prow + 16 * u, q = q0 + row;
+            const bool ok = row < XR && q >= 0 && q < HW;
+            const float4 v = *reinterpret_cast<const float4*>(xi + (size_t)(ok ? q : 0) * a.Cin);       // clamped address, value selected below
+            xv[u] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_step = [&](int buf, long m0) {
+#pragma unroll
+        for (int h = 0; h < PS / 16; ++h) *reinterpret_cast<float4*>(&Gs[(buf * PS + prow + 16 * h) * WG_LD + 4 * pc4]) = g[h];
+#pragma unroll
+        for (int u = 0; u < W9_LDX; ++u) {
+            const int row = prow + 16 * u;
+            if (row < XR) *reinterpret_cast<float4*>(&Xs[((size_t)buf * XR + row) * WG_LD + 4 * pc4]) = xv[u];
+        }
+        if (t < PS) { const int w = (int)((m0 % a.HWp + t) % a.W); Cm[buf * PS + t] = (w > 0 ? 1 : 0) | (w < a.W - 1 ? 2 : 0); }
+    };
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[k][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    load_step(mb);
+    store_step(0, mb);
+    __syncthreads();
+    int it = 0;
+    for (long m = mb; m < me; m += PS, ++it) {
+        const int buf = it & 1;
+        const bool has_next = (m + PS) < me;
+        if (has_next) load_step(m + PS);
+        const float* gs = Gs + buf * PS * WG_LD;
+        const float* xs = Xs + (size_t)buf * XR * WG_LD;
+        const int* cm = Cm + buf * PS;
+        if constexpr (BF16) {
+#pragma unroll
+            for (int hh = 0; hh < PS / 16; ++hh) {
+                const int p0q = hh * 16 + 4 * lg;
+                float av[4]; int mk[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { av[u] = gs[(p0q + u) * WG_LD + wave * 16 + li]; mk[u] = cm[p0q + u]; }
+                const bf16x4 ah1 = pack_bf16(av[0], av[1], av[2], av[3]);
+                const bf16x4 ah0 = pack_bf16((mk[0] & 1) ? av[0] : 0.f, (mk[1] & 1) ? av[1] : 0.f, (mk[2] & 1) ? av[2] : 0.f, (mk[3] & 1) ? av[3] : 0.f);
+                const bf16x4 ah2 = pack_bf16((mk[0] & 2) ? av[0] : 0.f, (mk[1] & 2) ? av[1] : 0.f, (mk[2] & 2) ? av[2] : 0.f, (mk[3] & 2) ? av[3] : 0.f);
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int sx = 0; sx < 3; ++sx) {
+                        const bf16x4 ah = sx == 0 ? ah0 : (sx == 1 ? ah1 : ah2);
+                        const float* xp = xs + (size_t)(p0q + r * a.W + sx) * WG_LD + li;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[r * 3 + sx][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, pack_bf16(xp[j * 16], xp[WG_LD + j * 16], xp[2 * WG_LD + j * 16], xp[3 * WG_LD + j * 16]),
+                                                                                           acc[r * 3 + sx][j], 0, 0, 0);
+                    }
+            }
+        } else if constexpr (!PIPE) {
+            // two waves per SIMD: the other block's wave covers this wave's LDS round trips
+#pragma unroll 2
+            for (int kk = 0; kk < PS / 4; ++kk) {
+                const int prw = (kk >> 2) * 16 + 4 * lg + (kk & 3);
+                const float av = gs[prw * WG_LD + wave * 16 + li];
+                const int mk = cm[prw];
+                const float av0 = (mk & 1) ? av : 0.f, av2 = (mk & 2) ? av : 0.f;
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int sx = 0; sx < 3; ++sx) {
+                        const float as = sx == 0 ? av0 : (sx == 1 ? av : av2);
+                        const float* xp = xs + (size_t)(prw + r * a.W + sx) * WG_LD + li;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[r * 3 + sx][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(as, xp[j * 16], acc[r * 3 + sx][j], 0, 0, 0);
+                    }
+            }
+        } else {
+            // One wave per SIMD (the 36 accumulator tiles + a double-buffered operand set need more than 256 registers): nothing but this wave's own
+            // instruction stream hides the LDS latency, so the 36 B operands (+ A and the column mask) of pixel quad kk + 1 are read while the 36 MFMAs of
+            // quad kk issue (with the reads placed next to their MFMAs the wave stalled for an LDS round trip every second MFMA).
+            float bq[2][9][4], aq[2]; int mq[2];
+            auto read_quad = [&](int kk, float (&b)[9][4], float& av, int& mk) {
+                const int prw = (kk >> 2) * 16 + 4 * lg + (kk & 3);                         // k permutation of the 16x16x4 MFMA: lane group g, step kk -> pixel of the step
+                av = gs[prw * WG_LD + wave * 16 + li];                                      // A'[i = co][k = pixel]
+                mk = cm[prw];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int sx = 0; sx < 3; ++sx) {
+                        const float* xp = xs + (size_t)(prw + r * a.W + sx) * WG_LD + li;  // B'[k = pixel shifted by the tap][j = ci]
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) b[r * 3 + sx][j] = xp[j * 16];
+                    }
+            };
+            read_quad(0, bq[0], aq[0], mq[0]);
+#pragma unroll
+            for (int kk = 0; kk < PS / 4; ++kk) {
+                const int cur = kk & 1;
+                if (kk + 1 < PS / 4) read_quad(kk + 1, bq[cur ^ 1], aq[cur ^ 1], mq[cur ^ 1]);
+                const float av = aq[cur];
+                const float av0 = (mq[cur] & 1) ? av : 0.f, av2 = (mq[cur] & 2) ? av : 0.f;
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int sx = 0; sx < 3; ++sx) {
+                        const float as = sx == 0 ? av0 : (sx == 1 ? av : av2);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[r * 3 + sx][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(as, bq[cur][r * 3 + sx][j], acc[r * 3 + sx][j], 0, 0, 0);
+                    }
+                // issue order of this quad: the LDS reads of the NEXT quad spread between this quad's MFMAs (a burst of 20 reads in front of them leaves the
+                // matrix pipe without work for ~100 cycles per quad; reads sunk next to their own MFMAs stall the wave for an LDS round trip)
+                if (kk + 1 < PS / 4) {
+#pragma unroll
+                    for (int q = 0; q < 18; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (has_next) store_step(buf ^ 1, m + PS);
+        __syncthreads();
+    }
+    // partial[chunk][tap][co][ci]: the accumulator layout as it stands (16 lanes = 64 contiguous bytes of one row); OIHW order (taps fastest) would make every
+    // store instruction 64 scattered dwords, 36 B apart.  mfma_wgrad9_reduce_kernel sums the slabs and writes dw in OIHW order.
+    float* dst = partial + (size_t)blockIdx.x * a.wtotal;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int co = co0 + wave * 16 + 4 * lg + reg, ci = ci0 + j * 16 + li;
+                dst[((size_t)k * a.Cout + co) * a.Cin + ci] = acc[k][j][reg];
+            }
+}
+
+// dw[co][ci][tap] = sum over chunks of partial[chunk][tap][co][ci], chunks in order (deterministic).  Block = 8 float4 columns x 32 chunk lanes: a wave
+// reads 128 contiguous bytes of 8 slabs per instruction; the 32 chunk lanes are combined through LDS in a fixed order.
+__global__ __launch_bounds__(256) void mfma_wgrad9_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int chunks, int Cout, int Cin) {
+    __shared__ float4 red[32][8];
+    const int v4 = threadIdx.x & 7, cl = threadIdx.x >> 3;
+    const size_t wtotal = (size_t)9 * Cout * Cin;
+    const size_t e4 = (size_t)blockIdx.x * 8 + v4;                   // float4 index inside a slab ([tap][co][ci / 4])
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e4 * 4 < wtotal)
+        for (int c = cl; c < chunks; c += 32) {
+            const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)c * wtotal + e4 * 4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    red[cl][v4] = s;
+    __syncthreads();
+    if (cl == 0 && e4 * 4 < wtotal) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 32; ++k) { const float4 v = red[k][v4]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        const size_t e = e4 * 4;
+        const int ci = (int)(e % Cin); const size_t r1 = e / Cin; const int co = (int)(r1 % Cout), tap = (int)(r1 / Cout);
+        float* d = dw + ((size_t)co * Cin + ci) * 9 + tap;
+        d[0] = t.x; d[9] = t.y; d[18] = t.z; d[27] = t.w;
+    }
+}
+
 __global__ __launch_bounds__(1024) void mfma_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int chunks, size_t wtotal) {
     __shared__ float red[32][33];
     const int wl = threadIdx.x & 31, cl = threadIdx.x >> 5;
@@ -386,6 +592,49 @@ inline void wg_plan(const dcv_conv2d_desc* d, MfmaWgArgs* a, int* chunks) {
     *chunks = (int)((a->M + mpc - 1) / mpc);
 }
 
+
+inline int wg9_mode() {               // 1: one wave per SIMD with an explicit operand pipeline, 2: two waves per SIMD
+    static int m = -1;
+    if (m < 0) { const char* e = getenv("DCV_MFMA_WGRAD9_MODE"); m = e ? atoi(e) : 2; }
+    return m;
+}
+
+// all-taps weight-gradient kernel: 3x3, stride 1, pad 1, no dilation, 64-aligned channel counts, images whose pixel count is a multiple of the step
+inline bool wg9_plan(const dcv_conv2d_desc* d, Wg9Args* a, int* ps, int* chunks, size_t* smem) {
+    static int enabled = -1;
+    if (enabled < 0) { const char* e = getenv("DCV_MFMA_WGRAD9"); enabled = e ? atoi(e) : 1; }
+    if (!enabled) return false;
+    if (d->r != 3 || d->s != 3 || d->stride_h != 1 || d->stride_w != 1 || d->pad_h != 1 || d->pad_w != 1 || d->dil_h != 1 || d->dil_w != 1) return false;
+    if (d->cin % WG_T != 0 || d->cout % WG_T != 0 || d->ho != d->h || d->wo != d->w) return false;
+    const int hw = d->h * d->w;
+    // step size: the one wasting fewer padding pixels per image, 32 on a tie; 16 when the 32-pixel window does not fit the LDS budget of two blocks per CU
+    auto smem_of = [&](int ps) { return ((size_t)2 * ps * WG_LD + (size_t)2 * (ps + 2 * d->w + 2) * WG_LD) * sizeof(float) + (size_t)2 * ps * sizeof(int); };
+    auto fits = [&](int ps) { return (ps + 2 * d->w + 2) * 16 <= 256 * W9_LDX && smem_of(ps) <= (size_t)80 * 1024; };
+    const int pad32 = (hw + 31) / 32 * 32, pad16 = (hw + 15) / 16 * 16;
+    int PS = (pad32 <= pad16 && fits(32)) ? 32 : 16;
+    if (!fits(PS)) return false;
+    const int XR = PS + 2 * d->w + 2;
+    *smem = smem_of(PS);
+    a->N = d->n; a->H = d->h; a->W = d->w; a->Cin = d->cin; a->Cout = d->cout; a->XR = XR;
+    a->HWp = PS == 32 ? pad32 : pad16;
+    a->M = (long)d->n * a->HWp;
+    a->wtotal = (size_t)d->cout * d->cin * 9;
+    const long blocks_per_chunk = (long)(d->cin / WG_T) * (d->cout / WG_T);
+    const long per_cu = wg9_mode() == 1 ? 1 : 2;                                     // resident blocks per CU (the kernel's register budget): one round
+    long ch = (per_cu * DCV_NUM_CU + blocks_per_chunk - 1) / blocks_per_chunk;
+    const long max_by_m = a->M / (4 * PS) > 0 ? a->M / (4 * PS) : 1;                 // at least four steps per chunk
+    if (ch > max_by_m) ch = max_by_m;
+    const long max_by_bytes = (long)(((size_t)256 << 20) / (a->wtotal * sizeof(float)));
+    if (ch > max_by_bytes) ch = max_by_bytes;
+    if (ch < 1) ch = 1;
+    long mpc = (a->M + ch - 1) / ch;
+    mpc = (mpc + PS - 1) / PS * PS;
+    a->m_per_chunk = mpc;
+    *chunks = (int)((a->M + mpc - 1) / mpc);
+    *ps = PS;
+    return true;
+}
+
 }  // namespace
 
 bool dcv_mfma_conv2d_supported(const dcv_conv2d_desc* d, int op) {
@@ -410,7 +659,11 @@ bool dcv_mfma_conv2d_supported(const dcv_conv2d_desc* d, int op) {
 }
 
 size_t dcv_mfma_conv2d_ws(const dcv_conv2d_desc* d, int op) {
-    if (op == 2) { MfmaWgArgs a{}; int chunks; wg_plan(d, &a, &chunks); return dcv_align_up((size_t)chunks * a.wtotal * sizeof(float), 256); }
+    if (op == 2) {
+        Wg9Args a9{}; int ps9, chunks9; size_t sm9;
+        if (wg9_plan(d, &a9, &ps9, &chunks9, &sm9)) return dcv_align_up((size_t)chunks9 * a9.wtotal * sizeof(float), 256);
+        MfmaWgArgs a{}; int chunks; wg_plan(d, &a, &chunks); return dcv_align_up((size_t)chunks * a.wtotal * sizeof(float), 256);
+    }
     return dcv_align_up((size_t)d->cout * d->cin * d->r * d->s * sizeof(float), 256);
 }
 
@@ -701,7 +954,36 @@ int dcv_mfma_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float
     return DCV_OK;
 }
 
+template <int PS, bool BF16, bool PIPE>
+static int launch_wgrad9(const Wg9Args& a, dim3 grid, size_t smem, hipStream_t st, const float* x, const float* dy, float* partial) {
+    static bool configured = false;            // dynamic LDS above 64 KiB needs the attribute once per instantiation
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_wgrad9_kernel<PS, BF16, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return DCV_ERR_LAUNCH;
+        configured = true;
+    }
+    hipLaunchKernelGGL((conv_mfma_wgrad9_kernel<PS, BF16, PIPE>), grid, dim3(256), smem, st, a, x, dy, partial);
+    return DCV_OK;
+}
+
 int dcv_mfma_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
+    {
+        Wg9Args a9{}; int ps9, chunks9; size_t sm9;
+        if (wg9_plan(d, &a9, &ps9, &chunks9, &sm9)) {
+            if (!ws || ws_bytes < (size_t)chunks9 * a9.wtotal * sizeof(float)) return DCV_ERR_WORKSPACE;
+            if (!aligned16(x) || !aligned16(dy)) return DCV_ERR_INVALID_ARG;
+            float* partial = reinterpret_cast<float*>(ws);
+            dim3 grid((unsigned)chunks9, (unsigned)(d->cin / WG_T), (unsigned)(d->cout / WG_T));
+            if (grid.y > 65535 || grid.z > 65535) return DCV_ERR_UNSUPPORTED;
+            const bool bf = d->math == DCV_MATH_BF16;
+            int rc;
+            const bool pipe = wg9_mode() == 1 && !bf;
+            if (ps9 == 32) rc = bf ? launch_wgrad9<32, true, false>(a9, grid, sm9, st, x, dy, partial) : (pipe ? launch_wgrad9<32, false, true>(a9, grid, sm9, st, x, dy, partial) : launch_wgrad9<32, false, false>(a9, grid, sm9, st, x, dy, partial));
+            else rc = bf ? launch_wgrad9<16, true, false>(a9, grid, sm9, st, x, dy, partial) : (pipe ? launch_wgrad9<16, false, true>(a9, grid, sm9, st, x, dy, partial) : launch_wgrad9<16, false, false>(a9, grid, sm9, st, x, dy, partial));
+            if (rc != DCV_OK) return rc;
+            hipLaunchKernelGGL(mfma_wgrad9_reduce_kernel, dim3((unsigned)dcv_ceil_div(a9.wtotal / 4, 8)), dim3(256), 0, st, partial, dw, chunks9, d->cout, d->cin);
+            return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
+        }
+    }
     MfmaWgArgs a{}; int chunks;
     wg_plan(d, &a, &chunks);
     if (!ws || ws_bytes < (size_t)chunks * a.wtotal * sizeof(float)) return DCV_ERR_WORKSPACE;
