@@ -502,10 +502,15 @@ def train(hp: HYPERPARAMS_T, model: torch.nn.Module, losses: LOSS_FN_TERMS_T = N
     for n in metric_names:
         RunningAverage(output_transform=lambda out, n=n: out[n]).attach(trainer, n)
     to_save = {'trainer': trainer, 'model': model, 'optimizer': optimizer, **({} if scheduler is None else {'scheduler': scheduler})}   # Appendix A #32
+    saved_checkpoints: List[Path] = []
     if hp['save_every_iters'] and hp['save_every_iters'] > 0 and backend_conf.rank == 0:
         @trainer.on(Events.ITERATION_COMPLETED(every=int(hp['save_every_iters'])))
         def _save_checkpoint(engine: Engine):
-            _save_objects(to_save, output_path / f'training_checkpoint_{engine.state.iteration}.pt')
+            fp = output_path / f'training_checkpoint_{engine.state.iteration}.pt'
+            _save_objects(to_save, fp)
+            for old in saved_checkpoints:     # ignite's `Checkpoint(n_saved=1)`, the default of `setup_common_training_handlers`: keep the newest only
+                old.unlink(missing_ok=True)
+            saved_checkpoints[:] = [fp]
     if backend_conf.rank == 0 and hp['log_progress_every_iters']:
         @trainer.on(Events.ITERATION_COMPLETED(every=int(hp['log_progress_every_iters'])))
         def _log_progress(engine: Engine):

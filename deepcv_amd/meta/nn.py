@@ -147,12 +147,25 @@ def get_padding_from_kernel(kernel_size: SIZE_N_T, warn_on_uneven_kernel: bool =
     return padding if is_sequence else padding[0]
 
 
+_WARNED_NON_NATIVE = set()
+
+
+def _warn_if_not_native(module: Any) -> Any:
+    """ Modules this package has no HIP kernels for (1-D / 3-D operators, LayerNorm, InstanceNorm, LocalResponseNorm: none is on a BASELINE config) run on
+    torch's own ATen / MIOpen kernels; say so once per type instead of silently mixing back-ends (native 2-D modules raise on CPU tensors, these do not). """
+    cls = type(module)
+    if isinstance(module, torch.nn.Module) and cls.__module__.startswith('torch.nn') and cls not in _WARNED_NON_NATIVE:
+        _WARNED_NON_NATIVE.add(cls)
+        logging.warning(f'deepcv_amd: `{cls.__name__}` has no hand-written HIP kernel here; it runs on torch\'s own (ATen / MIOpen) kernels')
+    return module
+
+
 def nd_support(_nd_types: Dict[int, Union[Callable, Type]], dims: int, *args, _name: str = None, **kwargs) -> Any:
     """ N-D dispatch helper (reference `nn.py:402-408`, Appendix A #5). """
     if dims not in _nd_types:
         available_ops = ', '.join(f'{dim}D: {getattr(op, "__name__", str(op))}' for dim, op in _nd_types.items())
         raise ValueError(f'Error: {"This operator/module" if _name is None else _name} doesnt support operations on {dims}D features maps, available ops are: "{available_ops}"')
-    return _nd_types[dims](*args, **kwargs)
+    return _warn_if_not_native(_nd_types[dims](*args, **kwargs))
 
 
 # 2-D entries are the native HIP-backed modules; 1-D / 3-D keep torch's (not on the image-classification hot path)
@@ -209,7 +222,7 @@ def normalization_techniques_impl(norm_type, norm_kwargs, input_shape: torch.Siz
                 kwargs['input_shape'] = input_shape
         if norm_t not in supported_norm_ops:
             raise ValueError(f'Error: "{norm_t}" is an unkown or forbiden normalization technique: It isn\'t specified in `supported_norm_ops="{supported_norm_ops}"`')
-        norm_ops.append(supported_norm_ops[norm_t](**kwargs))
+        norm_ops.append(_warn_if_not_native(supported_norm_ops[norm_t](**kwargs)))
     return norm_ops
 
 

@@ -201,3 +201,17 @@ def test_state_dict_roundtrip_with_reference_modules(params):
     o2.load_state_dict(m.state_dict())
     for (k, a), (_, b) in zip(o.state_dict().items(), o2.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_modules_without_hip_kernels_say_so_once(caplog):
+    """ LayerNorm / InstanceNorm / LocalResponseNorm and 1-D / 3-D operators stay on torch's kernels (outside every BASELINE config): warned, not silent. """
+    import logging
+    from deepcv_amd.meta import nn as dnn
+    dnn._WARNED_NON_NATIVE.clear()
+    with caplog.at_level(logging.WARNING):
+        mods = dnn.normalization_techniques(input_shape=torch.Size((8, 4, 4)), layer_norm={'eps': 1e-5}, instance_norm={'eps': 1e-5})
+        dnn.normalization_techniques(input_shape=torch.Size((8, 4, 4)), layer_norm={'eps': 1e-5})
+        dnn.conv_nd(1, 3, 4, 3)
+    assert [type(m).__name__ for m in mods] == ['LayerNorm', 'InstanceNorm2d']
+    msgs = [r.getMessage() for r in caplog.records if 'no hand-written HIP kernel' in r.getMessage()]
+    assert len(msgs) == 3 and any('LayerNorm' in m for m in msgs) and any('InstanceNorm2d' in m for m in msgs) and any('Conv1d' in m for m in msgs)

@@ -268,7 +268,7 @@ def test_train_api_end_to_end(device, params, tmp_path):
     assert state.iteration == 16 and state.epoch == 2
     assert 'valid_accuracy' in metrics and 'valid_main_loss' in metrics
     assert 0. <= metrics['valid_accuracy'] <= 1.
-    assert list(tmp_path.rglob('training_checkpoint_15.pt')), 'periodic checkpoint missing'
+    assert [p.name for p in tmp_path.rglob('training_checkpoint_*.pt')] == ['training_checkpoint_15.pt'], 'only the newest periodic checkpoint is kept (ignite n_saved=1)'
     ckpt = torch.load(next(tmp_path.rglob('training_checkpoint_15.pt')), weights_only=False)
     assert set(ckpt.keys()) == {'trainer', 'model', 'optimizer', 'scheduler'}
 
