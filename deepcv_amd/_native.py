@@ -26,6 +26,7 @@ ERR_UNSUPPORTED = -2
 POOL_AVG, POOL_MAX = 0, 1
 LAYOUT_NHWC, LAYOUT_NCHW = 0, 1
 MATH_FP32, MATH_BF16 = 0, 1
+DTYPE_F32, DTYPE_BF16 = 0, 1
 MAX_TENSORS = 64
 MAX_CONCAT = 8
 MAX_COPY_JOBS = 8
@@ -102,6 +103,16 @@ _SIGNATURES = {
     'dcv_conv2d_fwd_prepared': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _P, _P, _P]),
     'dcv_conv2d_dgrad_prepared': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _P]),
     'dcv_conv2d_dgrad_prepared_add': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _P, _P]),
+    'dcv_conv2d_bf16_supported': (_c_int, [ctypes.POINTER(Conv2dDesc), _c_int]),
+    'dcv_conv2d_bf16_filter_bytes': (_c_size_t, [ctypes.POINTER(Conv2dDesc), _c_int]),
+    'dcv_conv2d_bf16_prepare_filters': (_c_int, [_c_int, ctypes.POINTER(ctypes.POINTER(Conv2dDesc)), ctypes.POINTER(_c_int), ctypes.POINTER(_P), ctypes.POINTER(_P), _P]),
+    'dcv_conv2d_bf16_fwd_stats_layout': (_c_int, [ctypes.POINTER(Conv2dDesc), ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
+    'dcv_conv2d_bf16_fwd': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _c_int, _P, _P]),
+    'dcv_conv2d_bf16_dgrad': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _c_int, _P]),
+    'dcv_conv2d_bf16_wgrad_workspace_bytes': (_c_size_t, [ctypes.POINTER(Conv2dDesc)]),
+    'dcv_conv2d_bf16_wgrad': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _c_size_t, _P]),
+    'dcv_cast_f32_to_bf16': (_c_int, [_P, _P, _c_size_t, _P]),
+    'dcv_cast_bf16_to_f32': (_c_int, [_P, _P, _c_size_t, _P]),
     'dcv_act_fwd': (_c_int, [_P, _P, _c_size_t, _c_int, _c_float, _P]),
     'dcv_act_bwd_workspace_bytes': (_c_size_t, [_c_size_t, _c_int]),
     'dcv_act_bwd': (_c_int, [_P, _P, _P, _c_size_t, _c_int, _c_int, _c_float, _P, _P, _c_size_t, _P]),

@@ -1,0 +1,462 @@
+// conv2d_bf16.hip — convolution with bf16 STORAGE: activations and prepared filters are bf16 in HBM and in LDS, the matrix cores run
+// `v_mfma_f32_16x16x32_bf16` (gfx950: K = 32 per instruction, 16 cycles), accumulation / bias / statistics are fp32 / fp64, master weights stay fp32.
+// This is the "bf16 MFMA conv" of BASELINE configs 3 / 5; the fp32 kernels (conv2d_mfma.hip) remain the parity mode.
+//
+// Forward as implicit GEMM:  D[m][n] = sum_k A[m][k] B[k][n],  m = output pixel (n, ho, wo), n = output channel, k = (tap, ci), ci fastest.
+//   * block = 256 threads = 4 waves = WM x WN, tile = 128 pixels x (64 WN) channels, K step = 64 input channels of one filter tap;
+//   * both operands go global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, 16 B per lane, no VGPR round trip, no `ds_write`): a row of the A image is
+//     the 128 B (64 channels) of one input pixel of the tap, a row of the B image the 128 B of one output channel of the prepared filter [tap][co][ci].
+//     An LDS-DMA image is lane-linear, so the bank swizzle is applied on the SOURCE side: LDS 16-B slot s' of row r holds logical slot s' ^ ((r >> 1) & 7);
+//     with that image the four 16-lane groups of a `ds_read_b128` fragment read (rows 16i + li, logical slot 4 ks + lg) touch 16 distinct 16-B bank groups.
+//   * padding and tile tails cost nothing: an out-of-image pixel gets a buffer offset beyond `num_records`, for which the hardware delivers zeros;
+//     per row the validity of all taps is one 64-bit mask computed once, per K step the address work is a shift, a select and an add per 16-B piece;
+//   * two LDS stages: the DMA of K step c + 1 is in flight while the MFMAs of step c run; one barrier per step; two blocks per CU hide each other's waits;
+//   * output channels are permuted between the B image and the accumulator tiles (tile j, column c <-> channel 4 c + j), so a lane ends up with FOUR
+//     CONSECUTIVE channels of a pixel: 8-B (bf16) or 16-B (fp32) stores, 128 B / 256 B contiguous per pixel across 16 lanes;
+//   * epilogue: bias + activation + (optionally) per-block sums of y and y^2 per channel in fp64 ([2][Cout][rows], the layout of the fp32 kernels).
+// Data gradient (stride 1) = the same kernel on dy with the transposed + flipped filter; strided data gradients run one launch per output phase.
+// Weight gradient: conv2d_mfma.hip's all-taps kernel reading bf16 operands (see dcv_conv2d_bf16_wgrad below).
+//
+// Roofline: bf16 MFMA (~2.5 PFLOP/s dense).  FLOPs per launch = 2 * N*Ho*Wo * Cout * Cin*R*S.
+// Replaces torch.nn.Conv2d forward / backward under autocast-style bf16 (reference src/deepcv/meta/submodule_creators.py:251, ignite_training.py:253).
+#include "conv2d_internal.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+#define BF_BM 128                // pixels per block tile
+#define BF_BK 64                 // input channels per K step (128-B LDS rows)
+#define BF_OOB 0x80000000u       // buffer offset beyond any num_records: the load delivers zeros
+
+struct Bf16Args {
+    int N, Hin, Win, Cin;          // tensor read (fwd: x, dgrad: dy)
+    int Hout, Wout, Cout;          // tensor written
+    int R, S, sh, sw, ph, pw, dh, dw;
+    int act; float slope;
+    long M;                        // N * Hout * Wout
+    unsigned x_bytes, w_bytes;     // buffer sizes (num_records)
+    int phase, oh_mul, ow_mul, oh_off, ow_off, Hfull, Wfull;      // strided data gradient: this launch writes phase (oh_off, ow_off) of the full tensor
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds_wave_base, 16, (int)voffset, 0, 0, 0);
+}
+
+// WM x WN waves; wave tile = (16 TI) pixels x 64 channels; BM = 16 TI WM = 128
+template <int WM, int WN, bool OUT_BF16>
+__global__ __launch_bounds__(256, 2) void conv_bf16_kernel(Bf16Args a, const u16* __restrict__ x, const u16* __restrict__ wb, const float* __restrict__ bias,
+                                                            void* __restrict__ yv, double* __restrict__ stats) {
+    constexpr int TI = BF_BM / (16 * WM);
+    constexpr int BN = 64 * WN;
+    constexpr int PA = BF_BM / 32, PB = BN / 32;                  // 16-B pieces per thread and stage
+    constexpr int A_BYTES = BF_BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 15, lg = lane >> 4;
+    const long m0 = (long)blockIdx.x * BF_BM;
+    const int n0 = blockIdx.y * BN;
+
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)a.x_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, (int)a.w_bytes, 0x00020000);
+
+    // ---- staging roles: piece p of this thread = LDS row 32 p + (t >> 3), LDS slot t & 7, which holds logical slot (t & 7) ^ ((t >> 4) & 7)
+    const int lslot = (t & 7) ^ ((t >> 4) & 7);
+    int offa[PA]; unsigned long long maska[PA];
+    const int taps = a.R * a.S;
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+        const long m = m0 + 32 * p + (t >> 3);
+        const bool ok = m < a.M;
+        const long mm = ok ? m : 0;
+        const int wo = (int)(mm % a.Wout); const long r1 = mm / a.Wout; const int ho = (int)(r1 % a.Hout); const int n = (int)(r1 / a.Hout);
+        const int hi0 = ho * a.sh - a.ph, wi0 = wo * a.sw - a.pw;
+        offa[p] = (((n * a.Hin + hi0) * a.Win + wi0) * a.Cin) * 2 + lslot * 16;      // may be negative for border pixels: only used under its validity bit
+        unsigned long long mk = 0;
+        if (ok)
+            for (int r = 0; r < a.R; ++r) {
+                const int hi = hi0 + r * a.dh;
+                for (int s = 0; s < a.S; ++s) {
+                    const int wi = wi0 + s * a.dw;
+                    if (hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win) mk |= 1ull << (r * a.S + s);
+                }
+            }
+        maska[p] = mk;
+    }
+    int offb[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        const int rho = 32 * p + (t >> 3);                        // LDS row of the B image: 64 wn' + 16 j + c  <-  channel n0 + 64 wn' + 4 c + j
+        const int co = n0 + (rho & ~63) + 4 * (rho & 15) + ((rho >> 4) & 3);
+        offb[p] = (co * a.Cin) * 2 + lslot * 16;
+    }
+
+    const int cchunks = a.Cin / BF_BK;
+    const int nk = taps * cchunks;
+    // position of the next K step to LOAD (scalar state)
+    int l_tap = 0, l_chunk = 0, l_r = 0, l_s = 0;
+    auto stage = [&](int buf) {
+        char* base = lds + buf * STAGE;
+        const int ua = ((l_r * a.dh) * a.Win + l_s * a.dw) * a.Cin * 2 + l_chunk * 128;
+        const int ub = (l_tap * a.Cout) * a.Cin * 2 + l_chunk * 128;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const bool v = (maska[p] >> l_tap) & 1ull;
+            dma16(rx, base + (p * 256 + (t & ~63)) * 16, v ? (unsigned)(offa[p] + ua) : BF_OOB);
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) dma16(rw, base + A_BYTES + (p * 256 + (t & ~63)) * 16, (unsigned)(offb[p] + ub));
+        if (++l_chunk == cchunks) { l_chunk = 0; ++l_tap; if (++l_s == a.S) { l_s = 0; ++l_r; } }
+    };
+
+    f32x4 acc[TI][4];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment addresses: row stride 128 B, slot (4 ks + lg) ^ ((row >> 1) & 7); rows 16 i + li of the wave's range -> swizzle term (li >> 1) & 7
+    const int swz = (li >> 1) & 7;
+    const int a_row0 = (16 * TI * wm + li) * 128, b_row0 = A_BYTES + (64 * wn + li) * 128;
+    const int s0 = ((0 + lg) ^ swz) * 16, s1 = ((4 + lg) ^ swz) * 16;
+
+    stage(0);
+    for (int c = 0; c < nk; ++c) {
+        const int buf = c & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's pieces of step c have landed ...
+        __syncthreads();                                           // ... and everybody's; every wave is also done reading the other stage
+        if (c + 1 < nk) stage(buf ^ 1);
+        const char* sb = lds + buf * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int so = ks ? s1 : s0;
+            bf16x8 af[TI], bf[4];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sb + a_row0 + i * 2048 + so);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(sb + b_row0 + j * 2048 + so);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: acc[i][j][reg] -> pixel m0 + 16 TI wm + 16 i + 4 lg + reg, channel n0 + 64 wn + 4 li + j
+    const int cbase = n0 + 64 * wn + 4 * li;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) { const float4 b4 = *reinterpret_cast<const float4*>(bias + cbase); bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w; }
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const long m = m0 + 16 * TI * wm + 16 * i + 4 * lg + reg;
+            if (m < a.M) {
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[j] = dcv_act_apply(acc[i][j][reg] + bv[j], a.act, a.slope);
+                    ssum[j] += o[j]; ssq[j] += o[j] * o[j];
+                }
+                size_t off = (size_t)m;
+                if (a.phase) {
+                    const int jj = (int)(m % a.Wout); const long r1 = m / a.Wout; const int ii = (int)(r1 % a.Hout); const long nn = r1 / a.Hout;
+                    off = ((size_t)nn * a.Hfull + (size_t)ii * a.oh_mul + a.oh_off) * a.Wfull + (size_t)jj * a.ow_mul + a.ow_off;
+                }
+                if constexpr (OUT_BF16) {
+                    const bf16x4 h = (bf16x4){(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<u16*>(yv) + off * a.Cout + cbase) = h;
+                } else {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(yv) + off * a.Cout + cbase) = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
+    if (stats != nullptr) {
+        // per-block partial sums: lanes li, li + 16, li + 32, li + 48 hold the same four channels (fixed-order butterfly), then the WM waves of a column
+        __syncthreads();                                           // the last K step's fragment reads are done: the stages are free
+        double* red = reinterpret_cast<double*>(lds);              // [4 waves][2][64]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s1v = ssum[j], s2v = ssq[j];
+            s1v += __shfl_xor(s1v, 16, 64); s2v += __shfl_xor(s2v, 16, 64);
+            s1v += __shfl_xor(s1v, 32, 64); s2v += __shfl_xor(s2v, 32, 64);
+            if (lg == 0) { red[(wave * 2 + 0) * 64 + 4 * li + j] = (double)s1v; red[(wave * 2 + 1) * 64 + 4 * li + j] = (double)s2v; }
+        }
+        __syncthreads();
+        if (t < 2 * BN) {
+            const int q = t / BN, c = t - q * BN;                  // channel c of the block: column group wn' = c / 64, waves wm' * WN + wn'
+            const int wnn = c >> 6, cc = c & 63;
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) v += red[((w * WN + wnn) * 2 + q) * 64 + cc];
+            stats[((size_t)q * a.Cout + n0 + c) * gridDim.x + blockIdx.x] = v;                     // [2][Cout][rows]
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ prepared filters, casts
+// dst[tap][kcout][kcin] bf16 from the fp32 OIHW master filter (fwd), or its transposed + flipped (sub-)filter (data gradient; conv2d_internal.h)
+struct Bf16Prep { const float* w; u16* dst; int kcout, kcin, R, S, w_cin, dgrad, r0, rstep, Rw, s0, sstep, Sw, total; };
+#define BF_PREP_MAX 24
+struct Bf16PrepList { int count; Bf16Prep e[BF_PREP_MAX]; };
+
+__device__ __forceinline__ u16 f32_to_bf16_bits(float v) { const __bf16 h = (__bf16)v; return *reinterpret_cast<const u16*>(&h); }
+
+__global__ __launch_bounds__(256) void prep_bf16_kernel(Bf16PrepList l) {
+    const Bf16Prep& e = l.e[blockIdx.y];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < e.total; i += gridDim.x * blockDim.x) {
+        const int ci = i % e.kcin; int q = i / e.kcin;
+        const int co = q % e.kcout; const int tap = q / e.kcout;
+        const int r = tap / e.S, s = tap - r * e.S;
+        float v;
+        if (!e.dgrad) v = e.w[(((size_t)co * e.w_cin + ci) * e.Rw + r) * e.Sw + s];
+        else v = e.w[(((size_t)ci * e.w_cin + co) * e.Rw + (e.r0 + e.rstep * (e.R - 1 - r))) * e.Sw + (e.s0 + e.sstep * (e.S - 1 - s))];
+        e.dst[i] = f32_to_bf16_bits(v);
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float4* __restrict__ x, bf16x4* __restrict__ y, size_t n4, const float* __restrict__ xt, u16* __restrict__ yt, int tail) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = x[i];
+        y[i] = (bf16x4){(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail) yt[threadIdx.x] = f32_to_bf16_bits(xt[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const uint2* __restrict__ x, float4* __restrict__ y, size_t n4, const u16* __restrict__ xt, float* __restrict__ yt, int tail) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const uint2 v = x[i];
+        y[i] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail) yt[threadIdx.x] = __uint_as_float((unsigned)xt[threadIdx.x] << 16);
+}
+
+struct PhaseAxis { int r0, taps, pad, count; };
+inline PhaseAxis phase_axis(int a, int size, int R, int stride, int pad) {
+    PhaseAxis p{};
+    p.r0 = (a + pad) % stride;
+    p.taps = p.r0 < R ? (R - p.r0 + stride - 1) / stride : 0;
+    const int oa = (a + pad - p.r0) / stride;
+    p.pad = p.taps - 1 - oa;
+    p.count = a < size ? (size - a + stride - 1) / stride : 0;
+    return p;
+}
+
+inline bool desc_ok(const dcv_conv2d_desc* d) {
+    if (!d) return false;
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cin <= 0 || d->cout <= 0 || d->r <= 0 || d->s <= 0) return false;
+    if (d->stride_h <= 0 || d->stride_w <= 0 || d->pad_h < 0 || d->pad_w < 0 || d->dil_h <= 0 || d->dil_w <= 0) return false;
+    const int ho = (d->h + 2 * d->pad_h - d->dil_h * (d->r - 1) - 1) / d->stride_h + 1;
+    const int wo = (d->w + 2 * d->pad_w - d->dil_w * (d->s - 1) - 1) / d->stride_w + 1;
+    if (ho != d->ho || wo != d->wo || ho <= 0 || wo <= 0) return false;
+    if (d->act < DCV_ACT_NONE || d->act > DCV_ACT_TANH) return false;
+    return true;
+}
+
+// number of (phase) filter pieces of (d, op) and their element offsets inside the prepared buffer
+inline int prep_pieces(const dcv_conv2d_desc* d, int op, Bf16Prep* out, int* offs) {
+    Bf16Prep e{};
+    e.w_cin = d->cin; e.dgrad = op ? 1 : 0;
+    e.kcout = op ? d->cin : d->cout; e.kcin = op ? d->cout : d->cin;
+    e.Rw = d->r; e.Sw = d->s;
+    if (op == 0 || (d->stride_h == 1 && d->stride_w == 1)) {
+        e.R = d->r; e.S = d->s; e.r0 = e.s0 = 0; e.rstep = e.sstep = 1;
+        e.total = d->cout * d->cin * d->r * d->s;
+        out[0] = e; offs[0] = 0;
+        return 1;
+    }
+    int n = 0, off = 0;
+    for (int pa = 0; pa < d->stride_h; ++pa)
+        for (int pb = 0; pb < d->stride_w; ++pb) {
+            const PhaseAxis ph = phase_axis(pa, d->h, d->r, d->stride_h, d->pad_h), pw = phase_axis(pb, d->w, d->s, d->stride_w, d->pad_w);
+            Bf16Prep q = e;
+            q.R = ph.taps; q.S = pw.taps; q.r0 = ph.r0; q.s0 = pw.r0; q.rstep = d->stride_h; q.sstep = d->stride_w;
+            q.total = d->cout * d->cin * ph.taps * pw.taps;
+            out[n] = q; offs[n] = off; off += q.total; ++n;
+        }
+    return n;
+}
+
+inline bool supported(const dcv_conv2d_desc* d, int op) {
+    if (!desc_ok(d) || d->groups != 1 || d->x_layout != DCV_LAYOUT_NHWC) return false;
+    if (d->r * d->s > 64) return false;                                               // tap validity is a 64-bit mask
+    const int kcin = op == 1 ? d->cout : d->cin, kcout = op == 1 ? d->cin : d->cout;
+    if (kcin % BF_BK != 0 || kcout % 64 != 0) return false;
+    // 32-bit buffer offsets with headroom for the out-of-range marker
+    const size_t xin = (size_t)d->n * (op == 1 ? (size_t)d->ho * d->wo * d->cout : (size_t)d->h * d->w * d->cin) * 2;
+    const size_t wbytes = (size_t)d->cout * d->cin * d->r * d->s * 2;
+    if (xin >= ((size_t)1 << 31) || wbytes >= ((size_t)1 << 31)) return false;
+    if (op == 1) {
+        if (d->stride_h == 1 && d->stride_w == 1) {
+            if (d->dil_h * (d->r - 1) < d->pad_h || d->dil_w * (d->s - 1) < d->pad_w) return false;
+        } else if (d->dil_h != 1 || d->dil_w != 1 || d->stride_h > 4 || d->stride_w > 4) return false;
+    }
+    return true;
+}
+
+template <bool OUT_BF16>
+int launch(const Bf16Args& a, const u16* x, const u16* wb, const float* bias, void* y, double* stats, hipStream_t st) {
+    static bool configured[2] = {false, false};
+    const bool wide = a.Cout % 128 == 0;
+    const size_t smem = wide ? (size_t)2 * (BF_BM + 128) * 128 : (size_t)2 * (BF_BM + 64) * 128;
+    dim3 grid((unsigned)dcv_ceil_div((size_t)a.M, BF_BM), (unsigned)(a.Cout / (wide ? 128 : 64)));
+    if (grid.y > 65535) return DCV_ERR_UNSUPPORTED;
+    if (wide) {
+        if (!configured[0]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<2, 2, OUT_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return DCV_ERR_LAUNCH;
+            configured[0] = true;
+        }
+        hipLaunchKernelGGL((conv_bf16_kernel<2, 2, OUT_BF16>), grid, dim3(256), smem, st, a, x, wb, bias, y, stats);
+    } else {
+        if (!configured[1]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_kernel<4, 1, OUT_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return DCV_ERR_LAUNCH;
+            configured[1] = true;
+        }
+        hipLaunchKernelGGL((conv_bf16_kernel<4, 1, OUT_BF16>), grid, dim3(256), smem, st, a, x, wb, bias, y, stats);
+    }
+    return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int dcv_conv2d_bf16_supported(const dcv_conv2d_desc* d, int op) {
+    if (op == 2) return (desc_ok(d) && dcv_mfma_conv2d_wgrad_in16_supported(d)) ? 1 : 0;
+    return (op == 0 || op == 1) && supported(d, op) ? 1 : 0;
+}
+
+size_t dcv_conv2d_bf16_wgrad_workspace_bytes(const dcv_conv2d_desc* d) {
+    if (!desc_ok(d) || !dcv_mfma_conv2d_wgrad_in16_supported(d)) return 0;
+    return dcv_mfma_conv2d_ws(d, 2);
+}
+
+int dcv_conv2d_bf16_wgrad(const dcv_conv2d_desc* d, const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, void* stream) {
+    DCV_CHECK_ARG(desc_ok(d) && x && dy && dw);
+    if (!dcv_mfma_conv2d_wgrad_in16_supported(d)) return DCV_ERR_UNSUPPORTED;
+    return dcv_mfma_conv2d_wgrad_in16(d, x, dy, dw, ws, ws_bytes, dcv_stream(stream));
+}
+
+size_t dcv_conv2d_bf16_filter_bytes(const dcv_conv2d_desc* d, int op) {
+    if ((op != 0 && op != 1) || !supported(d, op)) return 0;
+    return dcv_align_up((size_t)d->cout * d->cin * d->r * d->s * 2, 256);
+}
+
+int dcv_conv2d_bf16_prepare_filters(int count, const dcv_conv2d_desc* const* descs, const int* ops, const float* const* w, void* const* filters, void* stream) {
+    DCV_CHECK_ARG(count >= 0 && (count == 0 || (descs && ops && w && filters)));
+    Bf16PrepList l{};
+    int max_total = 0;
+    auto flush = [&]() {
+        if (l.count == 0) return;
+        int gx = (max_total + 255) / 256; if (gx > 256) gx = 256; if (gx < 1) gx = 1;
+        hipLaunchKernelGGL(prep_bf16_kernel, dim3((unsigned)gx, (unsigned)l.count), dim3(256), 0, dcv_stream(stream), l);
+        l.count = 0; max_total = 0;
+    };
+    for (int k = 0; k < count; ++k) {
+        DCV_CHECK_ARG((ops[k] == 0 || ops[k] == 1) && w[k] && filters[k]);
+        if (!supported(descs[k], ops[k])) return DCV_ERR_UNSUPPORTED;
+        Bf16Prep pieces[DCV_PREP_PIECES]; int offs[DCV_PREP_PIECES];
+        const int np = prep_pieces(descs[k], ops[k], pieces, offs);
+        for (int q = 0; q < np; ++q) {
+            Bf16Prep e = pieces[q];
+            if (e.total == 0) continue;
+            e.w = w[k]; e.dst = reinterpret_cast<u16*>(filters[k]) + offs[q];
+            l.e[l.count++] = e;
+            if (e.total > max_total) max_total = e.total;
+            if (l.count == BF_PREP_MAX) flush();
+        }
+    }
+    flush();
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_conv2d_bf16_fwd_stats_layout(const dcv_conv2d_desc* d, int* rows, int* rows_per_sample) {
+    DCV_CHECK_ARG(rows && rows_per_sample);
+    *rows = 0; *rows_per_sample = 0;
+    if (!supported(d, 0)) return DCV_OK;
+    const long M = (long)d->n * d->ho * d->wo;
+    *rows = (int)dcv_ceil_div((size_t)M, BF_BM);
+    if ((d->ho * d->wo) % BF_BM == 0) *rows_per_sample = d->ho * d->wo / BF_BM;
+    return DCV_OK;
+}
+
+int dcv_conv2d_bf16_fwd(const dcv_conv2d_desc* d, const void* x, const void* filter, const float* bias, void* y, int y_dtype, double* stats, void* stream) {
+    DCV_CHECK_ARG(desc_ok(d) && x && filter && y && (y_dtype == DCV_DTYPE_F32 || y_dtype == DCV_DTYPE_BF16));
+    if (!supported(d, 0)) return DCV_ERR_UNSUPPORTED;
+    DCV_CHECK_ARG(aligned16(x) && aligned16(filter) && aligned16(y) && (!bias || aligned16(bias)));
+    Bf16Args a{};
+    a.N = d->n; a.Hin = d->h; a.Win = d->w; a.Cin = d->cin; a.Hout = d->ho; a.Wout = d->wo; a.Cout = d->cout;
+    a.R = d->r; a.S = d->s; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
+    a.act = d->act; a.slope = d->act_slope; a.M = (long)d->n * d->ho * d->wo;
+    a.x_bytes = (unsigned)((size_t)d->n * d->h * d->w * d->cin * 2); a.w_bytes = (unsigned)((size_t)d->cout * d->cin * d->r * d->s * 2);
+    const u16* xs = reinterpret_cast<const u16*>(x); const u16* ws = reinterpret_cast<const u16*>(filter);
+    return y_dtype == DCV_DTYPE_BF16 ? launch<true>(a, xs, ws, bias, y, stats, dcv_stream(stream)) : launch<false>(a, xs, ws, bias, y, stats, dcv_stream(stream));
+}
+
+int dcv_conv2d_bf16_dgrad(const dcv_conv2d_desc* d, const void* dy, const void* filter, void* dx, int dx_dtype, void* stream) {
+    DCV_CHECK_ARG(desc_ok(d) && dy && filter && dx && (dx_dtype == DCV_DTYPE_F32 || dx_dtype == DCV_DTYPE_BF16));
+    if (!supported(d, 1)) return DCV_ERR_UNSUPPORTED;
+    DCV_CHECK_ARG(aligned16(dy) && aligned16(filter) && aligned16(dx));
+    hipStream_t st = dcv_stream(stream);
+    const u16* dys = reinterpret_cast<const u16*>(dy); const u16* ws = reinterpret_cast<const u16*>(filter);
+    Bf16Args a{};
+    a.N = d->n; a.Hin = d->ho; a.Win = d->wo; a.Cin = d->cout; a.Cout = d->cin;
+    a.sh = 1; a.sw = 1; a.dh = d->dil_h; a.dw = d->dil_w; a.act = DCV_ACT_NONE; a.slope = 0.f;
+    a.x_bytes = (unsigned)((size_t)d->n * d->ho * d->wo * d->cout * 2);
+    if (d->stride_h == 1 && d->stride_w == 1) {
+        a.Hout = d->h; a.Wout = d->w; a.R = d->r; a.S = d->s;
+        a.ph = d->dil_h * (d->r - 1) - d->pad_h; a.pw = d->dil_w * (d->s - 1) - d->pad_w; a.M = (long)d->n * d->h * d->w;
+        a.w_bytes = (unsigned)((size_t)d->cout * d->cin * d->r * d->s * 2);
+        return dx_dtype == DCV_DTYPE_BF16 ? launch<true>(a, dys, ws, nullptr, dx, nullptr, st) : launch<false>(a, dys, ws, nullptr, dx, nullptr, st);
+    }
+    Bf16Prep pieces[DCV_PREP_PIECES]; int offs[DCV_PREP_PIECES];
+    const int np = prep_pieces(d, 1, pieces, offs);
+    bool any_empty = false;
+    for (int q = 0; q < np; ++q) any_empty = any_empty || pieces[q].total == 0;
+    const size_t esz = dx_dtype == DCV_DTYPE_BF16 ? 2 : 4;
+    if (any_empty && hipMemsetAsync(dx, 0, (size_t)d->n * d->h * d->w * d->cin * esz, st) != hipSuccess) return DCV_ERR_LAUNCH;
+    int q = 0;
+    for (int pa = 0; pa < d->stride_h; ++pa)
+        for (int pb = 0; pb < d->stride_w; ++pb, ++q) {
+            const PhaseAxis ph = phase_axis(pa, d->h, d->r, d->stride_h, d->pad_h), pw = phase_axis(pb, d->w, d->s, d->stride_w, d->pad_w);
+            if (ph.taps == 0 || pw.taps == 0 || ph.count == 0 || pw.count == 0) continue;
+            Bf16Args p = a;
+            p.Hout = ph.count; p.Wout = pw.count; p.R = ph.taps; p.S = pw.taps; p.ph = ph.pad; p.pw = pw.pad; p.dh = p.dw = 1;
+            p.M = (long)d->n * ph.count * pw.count;
+            p.phase = 1; p.oh_mul = d->stride_h; p.ow_mul = d->stride_w; p.oh_off = pa; p.ow_off = pb; p.Hfull = d->h; p.Wfull = d->w;
+            p.w_bytes = (unsigned)((size_t)pieces[q].total * 2);
+            const int rc = dx_dtype == DCV_DTYPE_BF16 ? launch<true>(p, dys, ws + offs[q], nullptr, dx, nullptr, st) : launch<false>(p, dys, ws + offs[q], nullptr, dx, nullptr, st);
+            if (rc != DCV_OK) return rc;
+        }
+    return DCV_OK;
+}
+
+int dcv_cast_f32_to_bf16(const float* x, void* y, size_t n, void* stream) {
+    DCV_CHECK_ARG(x && y && aligned16(x) && (reinterpret_cast<uintptr_t>(y) & 7) == 0);
+    if (n == 0) return DCV_OK;
+    const size_t n4 = n / 4; const int tail = (int)(n - 4 * n4);
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(dcv_stream_grid(n4 ? n4 : 1, 256)), dim3(256), 0, dcv_stream(stream), reinterpret_cast<const float4*>(x), reinterpret_cast<bf16x4*>(y), n4,
+                       x + 4 * n4, reinterpret_cast<u16*>(y) + 4 * n4, tail);
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_cast_bf16_to_f32(const void* x, float* y, size_t n, void* stream) {
+    DCV_CHECK_ARG(x && y && aligned16(y) && (reinterpret_cast<uintptr_t>(x) & 7) == 0);
+    if (n == 0) return DCV_OK;
+    const size_t n4 = n / 4; const int tail = (int)(n - 4 * n4);
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(dcv_stream_grid(n4 ? n4 : 1, 256)), dim3(256), 0, dcv_stream(stream), reinterpret_cast<const uint2*>(x), reinterpret_cast<float4*>(y), n4,
+                       reinterpret_cast<const u16*>(x) + 4 * n4, y + 4 * n4, tail);
+    DCV_RETURN_LAUNCH();
+}
+
+}  // extern "C"

@@ -26,6 +26,9 @@ int dcv_mfma_conv2d_fwd(const dcv_conv2d_desc* d, const float* x, const float* w
 int dcv_mfma_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d, int* rows_per_sample = nullptr);
 int dcv_mfma_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t st, bool prepared = false);
 int dcv_mfma_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
+// bf16 x / dy (bf16 storage path): the all-taps kernel only; workspace = dcv_mfma_conv2d_ws(d, 2)
+bool dcv_mfma_conv2d_wgrad_in16_supported(const dcv_conv2d_desc* d);
+int dcv_mfma_conv2d_wgrad_in16(const dcv_conv2d_desc* d, const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
 
 // Prepared filters: one entry describes the re-layout of one OIHW filter for the kernel which will consume it (see dcv_conv2d_prepare_filters).
 struct dcv_prep_entry {

@@ -362,7 +362,19 @@ struct Wg9Args {
 };
 #define W9_LDX 10                   // float4 loads of the x window per thread and step (XR * 16 <= 256 * W9_LDX)
 
-template <int PS, bool BF16, bool PIPE>
+// four consecutive channels at element index `idx` of an fp32 or (IN16) bf16 tensor, as fp32
+template <bool IN16>
+__device__ __forceinline__ float4 w9_load4(const float* base, size_t idx) {
+    if constexpr (IN16) {
+        const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + idx);
+        return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+    } else {
+        return *reinterpret_cast<const float4*>(base + idx);
+    }
+}
+
+// IN16: x and dy are bf16 tensors (the bf16 storage path, conv2d_bf16.hip); they are widened while staged, everything downstream is unchanged
+template <int PS, bool BF16, bool PIPE, bool IN16 = false>
 __global__ __launch_bounds__(256, PIPE ? 1 : 2) void conv_mfma_wgrad9_kernel(Wg9Args a, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float smem9[];
     const int XR = a.XR;
@@ -384,16 +396,16 @@ __global__ __launch_bounds__(256, PIPE ? 1 : 2) void conv_mfma_wgrad9_kernel(Wg9
         for (int h = 0; h < PS / 16; ++h) {
             const int p = p0 + prow + 16 * h;
             const bool ok = p < HW;
-            const float4 v = *reinterpret_cast<const float4*>(dy + ((size_t)n * HW + (ok ? p : 0)) * a.Cout + co0 + 4 * pc4);
+            const float4 v = w9_load4<IN16>(dy, ((size_t)n * HW + (ok ? p : 0)) * a.Cout + co0 + 4 * pc4);
             g[h] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        const float* xi = x + (size_t)n * HW * a.Cin + ci0 + 4 * pc4;
+        const size_t xi = (size_t)n * HW * a.Cin + ci0 + 4 * pc4;
         const int q0 = p0 - a.W - 1;
 #pragma unroll
         for (int u = 0; u < W9_LDX; ++u) {
             const int row = prow + 16 * u, q = q0 + row;
             const bool ok = row < XR && q >= 0 && q < HW;
-            const float4 v = *reinterpret_cast<const float4*>(xi + (size_t)(ok ? q : 0) * a.Cin);       // clamped address, value selected below
+            const float4 v = w9_load4<IN16>(x, xi + (size_t)(ok ? q : 0) * a.Cin);                       // clamped address, value selected below
             xv[u] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
@@ -954,15 +966,36 @@ int dcv_mfma_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float
     return DCV_OK;
 }
 
-template <int PS, bool BF16, bool PIPE>
+template <int PS, bool BF16, bool PIPE, bool IN16 = false>
 static int launch_wgrad9(const Wg9Args& a, dim3 grid, size_t smem, hipStream_t st, const float* x, const float* dy, float* partial) {
     static bool configured = false;            // dynamic LDS above 64 KiB needs the attribute once per instantiation
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_wgrad9_kernel<PS, BF16, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return DCV_ERR_LAUNCH;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_wgrad9_kernel<PS, BF16, PIPE, IN16>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return DCV_ERR_LAUNCH;
         configured = true;
     }
-    hipLaunchKernelGGL((conv_mfma_wgrad9_kernel<PS, BF16, PIPE>), grid, dim3(256), smem, st, a, x, dy, partial);
+    hipLaunchKernelGGL((conv_mfma_wgrad9_kernel<PS, BF16, PIPE, IN16>), grid, dim3(256), smem, st, a, x, dy, partial);
     return DCV_OK;
+}
+
+// bf16 storage path: x and dy are bf16 tensors; only the layers the all-taps kernel plans (3x3, stride 1, pad 1, 64-aligned channels)
+bool dcv_mfma_conv2d_wgrad_in16_supported(const dcv_conv2d_desc* d) {
+    Wg9Args a9{}; int ps9, chunks9; size_t sm9;
+    return d->groups == 1 && d->x_layout == DCV_LAYOUT_NHWC && wg9_plan(d, &a9, &ps9, &chunks9, &sm9);
+}
+
+int dcv_mfma_conv2d_wgrad_in16(const dcv_conv2d_desc* d, const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
+    Wg9Args a9{}; int ps9, chunks9; size_t sm9;
+    if (!wg9_plan(d, &a9, &ps9, &chunks9, &sm9)) return DCV_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < (size_t)chunks9 * a9.wtotal * sizeof(float)) return DCV_ERR_WORKSPACE;
+    if ((reinterpret_cast<uintptr_t>(x) & 7) || (reinterpret_cast<uintptr_t>(dy) & 7)) return DCV_ERR_INVALID_ARG;
+    float* partial = reinterpret_cast<float*>(ws);
+    dim3 grid((unsigned)chunks9, (unsigned)(d->cin / WG_T), (unsigned)(d->cout / WG_T));
+    if (grid.y > 65535 || grid.z > 65535) return DCV_ERR_UNSUPPORTED;
+    const float* xf = reinterpret_cast<const float*>(x); const float* dyf = reinterpret_cast<const float*>(dy);
+    const int rc = ps9 == 32 ? launch_wgrad9<32, true, false, true>(a9, grid, sm9, st, xf, dyf, partial) : launch_wgrad9<16, true, false, true>(a9, grid, sm9, st, xf, dyf, partial);
+    if (rc != DCV_OK) return rc;
+    hipLaunchKernelGGL(mfma_wgrad9_reduce_kernel, dim3((unsigned)dcv_ceil_div(a9.wtotal / 4, 8)), dim3(256), 0, st, partial, dw, chunks9, d->cout, d->cin);
+    return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
 }
 
 int dcv_mfma_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {

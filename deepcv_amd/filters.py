@@ -35,11 +35,11 @@ _tick = itertools.count(1)   # counter values are unique across tables: a mark l
 
 
 class _Entry:
-    __slots__ = ('desc', 'op', 'buf', 'version', 'epoch', 'data_ptr', 'fresh_at', 'cap')
+    __slots__ = ('desc', 'op', 'buf', 'version', 'epoch', 'data_ptr', 'fresh_at', 'cap', 'bf16')
 
 
-def _key(d: nat.Conv2dDesc, op: int) -> tuple:
-    return (op, d.n, d.h, d.w, d.cin, d.cout, d.r, d.s, d.stride_h, d.stride_w, d.pad_h, d.pad_w, d.dil_h, d.dil_w, d.x_layout, d.math)
+def _key(d: nat.Conv2dDesc, op: int, bf16: bool = False) -> tuple:
+    return (op, d.n, d.h, d.w, d.cin, d.cout, d.r, d.s, d.stride_h, d.stride_w, d.pad_h, d.pad_w, d.dil_h, d.dil_w, d.x_layout, d.math, bf16)
 
 
 def _entries_of(weight: torch.Tensor, create: bool = False) -> Optional[Dict[tuple, '_Entry']]:
@@ -75,36 +75,51 @@ def invalidate_all():
     _epoch += 1
 
 
-def _prepare(entries: List[Tuple[torch.Tensor, '_Entry']], stream):
+def _call_table(entries: List[Tuple[torch.Tensor, '_Entry']]):
     n = len(entries)
     descs = (ctypes.POINTER(nat.Conv2dDesc) * n)(*[ctypes.pointer(e.desc) for _, e in entries])
     ops_ = (ctypes.c_int * n)(*[e.op for _, e in entries])
     ws = (ctypes.c_void_p * n)(*[w.data_ptr() for w, _ in entries])
     bufs = (ctypes.c_void_p * n)(*[e.buf.data_ptr() for _, e in entries])
-    nat.check(lib.dcv_conv2d_prepare_filters(n, descs, ops_, ws, bufs, stream), 'dcv_conv2d_prepare_filters')
-    return descs, ops_, ws, bufs          # keep-alive / reusable call table
+    return n, descs, ops_, ws, bufs
 
 
-def get(weight: torch.Tensor, d: nat.Conv2dDesc, op: int) -> Optional[torch.Tensor]:
+def _launch(table, stream):
+    """ `table`: the call tables of the fp32-layout entries and of the bf16 ones (the bf16 storage path, `dcv_conv2d_bf16_prepare_filters`). """
+    t32, t16 = table
+    if t32[0]:
+        nat.check(lib.dcv_conv2d_prepare_filters(*t32, stream), 'dcv_conv2d_prepare_filters')
+    if t16[0]:
+        nat.check(lib.dcv_conv2d_bf16_prepare_filters(*t16, stream), 'dcv_conv2d_bf16_prepare_filters')
+
+
+def _prepare(entries: List[Tuple[torch.Tensor, '_Entry']], stream):
+    table = (_call_table([we for we in entries if not we[1].bf16]), _call_table([we for we in entries if we[1].bf16]))
+    _launch(table, stream)
+    return table          # keep-alive / reusable call tables
+
+
+def get(weight: torch.Tensor, d: nat.Conv2dDesc, op: int, bf16: bool = False) -> Optional[torch.Tensor]:
     """ The filter of `weight` prepared for (descriptor, op) — op 0 forward, 1 data gradient — (re)prepared now if missing or stale; None when that
-    kernel needs none (or `weight` is not a plain contiguous device tensor: the regular entry points are used then). """
+    kernel needs none (or `weight` is not a plain contiguous device tensor: the regular entry points are used then).  `bf16`: the bf16 [tap][cout][cin]
+    filter of the bf16 storage kernels (`dcv_conv2d_bf16_*`; None when they do not serve this layer). """
     global _generation
     if not (weight.is_cuda and weight.is_contiguous()):
         return None
     per_w = _entries_of(weight, create=True)
-    k = _key(d, op)
+    k = _key(d, op, bf16)
     e = per_w.get(k)
     if e is _NO_FILTER:
         return None
     if e is not None and e.version == weight._version and e.epoch == _epoch and e.data_ptr == weight.data_ptr() and _fresh(weight, e):
         return e.buf
     if e is None:
-        nbytes = int(lib.dcv_conv2d_filter_bytes(d, op))
+        nbytes = int(lib.dcv_conv2d_bf16_filter_bytes(d, op) if bf16 else lib.dcv_conv2d_filter_bytes(d, op))
         if nbytes == 0:
             per_w[k] = _NO_FILTER
             return None
         e = _Entry()
-        e.desc, e.op = nat.Conv2dDesc.from_buffer_copy(d), op
+        e.desc, e.op, e.bf16 = nat.Conv2dDesc.from_buffer_copy(d), op, bf16
         e.buf = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
         e.cap = None
         per_w[k] = e
@@ -142,8 +157,7 @@ class RefreshTable:
             self.gen = _generation
             self.table = _prepare(self.entries, stream) if self.entries else None
         else:
-            descs, ops_, ws, bufs = self.table
-            nat.check(lib.dcv_conv2d_prepare_filters(len(self.entries), descs, ops_, ws, bufs, stream), 'dcv_conv2d_prepare_filters')
+            _launch(self.table, stream)
         now = self.clock[0]
         if capturing:
             self.cap = [now]

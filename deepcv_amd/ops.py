@@ -16,7 +16,7 @@ from . import grads
 from . import slabs
 from ._native import lib
 
-__all__ = ['conv2d', 'set_conv_math', 'set_norm_streaming', 'conv_norm_layer', 'fan_out', 'ref_tap', 'activation', 'batch_norm', 'sync_batch_norm', 'group_norm', 'pool2d', 'interpolate_bilinear', 'concat_channels', 'resize_concat', 'add_tensors', 'flatten_nchw_order',
+__all__ = ['conv2d', 'set_conv_math', 'set_bf16_storage', 'set_norm_streaming', 'conv_norm_layer', 'fan_out', 'ref_tap', 'activation', 'batch_norm', 'sync_batch_norm', 'group_norm', 'pool2d', 'interpolate_bilinear', 'concat_channels', 'resize_concat', 'add_tensors', 'flatten_nchw_order',
            'linear', 'linear_nhwc', 'cross_entropy', 'act_code', 'to_nhwc', 'nchw_to_nhwc']
 
 _CL = torch.channels_last
@@ -107,6 +107,68 @@ def set_conv_math(mode: str) -> str:
         raise ValueError(f'deepcv_amd.set_conv_math: unknown mode "{mode}" (fp32 | bf16)')
     _conv_math = nat.MATH_BF16 if mode == 'bf16' else nat.MATH_FP32
     return prev
+
+
+_bf16_storage = True
+
+
+def set_bf16_storage(enabled: bool) -> bool:
+    """ In 'bf16' convolution math: whether layers the bf16 STORAGE kernels serve (`dcv_conv2d_bf16_*`: bf16 activations and prepared filters in HBM and
+    LDS, v_mfma_f32_16x16x32_bf16) run on them (default) or on the fp32-storage kernels with operands rounded in registers.  Returns the previous setting. """
+    global _bf16_storage
+    prev, _bf16_storage = _bf16_storage, bool(enabled)
+    return prev
+
+
+def _to_bf16(t: torch.Tensor, st) -> torch.Tensor:
+    """ bf16 copy of an fp32 NHWC tensor (`dcv_cast_f32_to_bf16`); bf16 tensors pass through. """
+    if t.dtype == torch.bfloat16:
+        return t
+    out = torch.empty_like(t, dtype=torch.bfloat16)
+    nat.check(lib.dcv_cast_f32_to_bf16(t.data_ptr(), out.data_ptr(), t.numel(), st), 'dcv_cast_f32_to_bf16')
+    return out
+
+
+def _use_bf16_storage(d, layout) -> bool:
+    return _conv_math == nat.MATH_BF16 and _bf16_storage and layout == nat.LAYOUT_NHWC and bool(lib.dcv_conv2d_bf16_supported(d, 0))
+
+
+def _conv_fwd16_launch(d, x16, weight, bias, y, st, want_stats: bool = False):
+    """ Forward convolution on the bf16 storage kernel; returns (statistics partials or None, rows, rows per sample). """
+    f = filters.get(weight, d, 0, bf16=True)
+    stats, rows, rps = None, ctypes.c_int(0), ctypes.c_int(0)
+    if want_stats:
+        nat.check(lib.dcv_conv2d_bf16_fwd_stats_layout(d, ctypes.byref(rows), ctypes.byref(rps)), 'dcv_conv2d_bf16_fwd_stats_layout')
+        stats = torch.empty((2, d.cout, rows.value), dtype=torch.float64, device=y.device)
+    ydt = nat.DTYPE_BF16 if y.dtype == torch.bfloat16 else nat.DTYPE_F32
+    nat.check(lib.dcv_conv2d_bf16_fwd(d, x16.data_ptr(), f.data_ptr(), nat.ptr(bias), y.data_ptr(), ydt, nat.ptr(stats), st), 'dcv_conv2d_bf16_fwd')
+    return stats, rows.value, rps.value
+
+
+def _conv_bwd16_launch(ctx, d, x_saved, dz, weight, dx_needed: bool, dw, st):
+    """ Data and weight gradients of a layer whose forward ran on the bf16 storage kernels: dz is rounded to bf16 once and feeds both.  `x_saved` is the
+    bf16 input when the bf16 weight-gradient kernel serves the layer (`ctx.wgrad16`), else the fp32 one.  Returns dx (or None). """
+    dev = dz.device
+    dz16 = None
+    dx = None
+    if dx_needed:
+        dd = nat.Conv2dDesc.from_buffer_copy(d)
+        dd.x_layout = nat.LAYOUT_NHWC
+        dx = torch.empty((d.n, d.cin, d.h, d.w), dtype=torch.float32, device=dev, memory_format=_CL)
+        if lib.dcv_conv2d_bf16_supported(dd, 1):
+            dz16 = _to_bf16(dz, st)
+            f = filters.get(weight, dd, 1, bf16=True)
+            nat.check(lib.dcv_conv2d_bf16_dgrad(dd, dz16.data_ptr(), f.data_ptr(), dx.data_ptr(), nat.DTYPE_F32, st), 'dcv_conv2d_bf16_dgrad')
+        else:
+            _conv_dgrad_launch(dd, dz, weight, dx, st)
+    if dw is not None:
+        if ctx.wgrad16:
+            dz16 = _to_bf16(dz, st) if dz16 is None else dz16
+            ws = _ws(lib.dcv_conv2d_bf16_wgrad_workspace_bytes(d), dev)
+            nat.check(lib.dcv_conv2d_bf16_wgrad(d, x_saved.data_ptr(), dz16.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), st), 'dcv_conv2d_bf16_wgrad')
+        else:
+            _conv_wgrad_launch(d, x_saved, dz, ctx.weight_ref, ctx.bias_ref, dw, None, st)
+    return dx
 
 
 def _conv_desc(x_shape, w_shape, stride, padding, dilation, x_layout, act, slope) -> nat.Conv2dDesc:
@@ -240,7 +302,16 @@ class _Conv2dFn(torch.autograd.Function):
         weight = weight.contiguous()
         d = _conv_desc(x.shape, weight.shape, stride, padding, dilation, layout, act, slope)
         y = torch.empty((d.n, d.cout, d.ho, d.wo), dtype=x.dtype, device=x.device, memory_format=_CL)
-        _conv_fwd_launch(d, x, weight, bias, y, nat.current_stream(x.device))
+        ctx.use16 = _use_bf16_storage(d, layout)
+        if ctx.use16:
+            st = nat.current_stream(x.device)
+            x16 = _to_bf16(x, st)
+            _conv_fwd16_launch(d, x16, weight, bias, y, st)
+            ctx.wgrad16 = bool(lib.dcv_conv2d_bf16_supported(d, 2))
+            if ctx.wgrad16:
+                x = x16                       # the weight gradient reads the bf16 copy: half the saved bytes
+        else:
+            _conv_fwd_launch(d, x, weight, bias, y, nat.current_stream(x.device))
         ctx.desc, ctx.has_bias = d, bias is not None
         ctx.save_for_backward(x, weight, y if act != nat.ACT_NONE else None)
         return y
@@ -265,6 +336,13 @@ class _Conv2dFn(torch.autograd.Function):
         else:
             dz = dy
         dx = dw = None
+        if ctx.use16:
+            if db is not None and not db_done:
+                wsb = _ws(lib.dcv_act_bwd_workspace_bytes(rows, d.cout), dev)
+                nat.check(lib.dcv_channel_sum(dz.data_ptr(), db.data_ptr(), rows, d.cout, wsb.data_ptr(), wsb.numel(), st), 'dcv_channel_sum')
+            dw = _grad_buffer(ctx.weight_ref, like=weight) if ctx.needs_input_grad[1] else None
+            dx = _conv_bwd16_launch(ctx, d, x, dz, weight, ctx.needs_input_grad[0], dw, st)
+            return dx, dw, db, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             dd = nat.Conv2dDesc.from_buffer_copy(d)
             dd.x_layout = nat.LAYOUT_NHWC
@@ -521,7 +599,15 @@ class _ConvNormLayerFn(torch.autograd.Function):
         d = _conv_desc(x.shape, weight.shape, stride, padding, dilation, layout, act, slope)
         dev, st = x.device, nat.current_stream(x.device)
         y = torch.empty((d.n, d.cout, d.ho, d.wo), dtype=x.dtype, device=dev, memory_format=_CL)
-        stats = _conv_fwd_launch(d, x, weight, bias, y, st, want_stats=True)
+        ctx.use16 = _use_bf16_storage(d, layout)
+        if ctx.use16:
+            x16 = _to_bf16(x, st)
+            stats, rows16, rps16 = _conv_fwd16_launch(d, x16, weight, bias, y, st, want_stats=True)
+            ctx.wgrad16 = bool(lib.dcv_conv2d_bf16_supported(d, 2))
+            if ctx.wgrad16:
+                x = x16
+        else:
+            stats = _conv_fwd_launch(d, x, weight, bias, y, st, want_stats=True)
         # `pool` > 0: the layer is followed by a non-overlapping average pooling, applied by the same kernel (only the pooled tensor is written)
         out = torch.empty_like(y) if not pool else torch.empty((d.n, d.cout, d.ho // pool, d.wo // pool), dtype=x.dtype, device=dev, memory_format=_CL)
         c, hw = d.cout, d.ho * d.wo
@@ -533,7 +619,9 @@ class _ConvNormLayerFn(torch.autograd.Function):
         ctx.streaming = _norm_streaming and bool(lib.dcv_norm_chain_supported(nc))
         if ctx.streaming:
             rows, rps = ctypes.c_int(0), ctypes.c_int(0)
-            if stats is not None:
+            if stats is not None and ctx.use16:
+                rows, rps = ctypes.c_int(rows16), ctypes.c_int(rps16)
+            elif stats is not None:
                 nat.check(lib.dcv_conv2d_fwd_stats_layout(d, ctypes.byref(rows), ctypes.byref(rps)), 'dcv_conv2d_fwd_stats_layout')
             coef = torch.empty(int(lib.dcv_norm_chain_coef_floats(nc)), dtype=torch.float32, device=dev)
             nc.coef = coef.data_ptr()
@@ -561,7 +649,7 @@ class _ConvNormLayerFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         r_bn_w, r_bn_b, r_gn_w, r_gn_b = ctx.norm_refs
         db = new(ctx.bias_ref) if (bias is not None and need[2]) else None
-        db_from_wgrad = db is not None and need[1] and bool(lib.dcv_conv2d_wgrad_fuses_bias(d))   # summed from the dz tiles the wgrad kernel stages anyway
+        db_from_wgrad = db is not None and need[1] and not ctx.use16 and bool(lib.dcv_conv2d_wgrad_fuses_bias(d))   # summed from the dz tiles the wgrad kernel stages anyway
         d_bn_w = new(r_bn_w) if (bn_w is not None and need[3]) else None
         d_bn_b = new(r_bn_b) if (bn_b is not None and need[4]) else None
         d_gn_w = new(r_gn_w) if (gn_w is not None and need[8]) else None
@@ -584,6 +672,10 @@ class _ConvNormLayerFn(torch.autograd.Function):
                                                  nat.ptr(d_bn_w), nat.ptr(d_bn_b), nat.ptr(d_gn_w), nat.ptr(d_gn_b), None if db_from_wgrad else nat.ptr(db),
                                                  d.wo, pool, ws.data_ptr(), ws.numel(), st), 'dcv_bn_gn_pool_act_bwd')
         dx = dw = None
+        if ctx.use16:
+            dw = _grad_buffer(ctx.weight_ref, like=weight) if need[1] else None
+            dx = _conv_bwd16_launch(ctx, d, x, dz, weight, need[0], dw, st)
+            return dx, dw, db, d_bn_w, d_bn_b, None, None, None, d_gn_w, d_gn_b, None
         if need[0]:
             dd = nat.Conv2dDesc.from_buffer_copy(d)
             dd.x_layout = nat.LAYOUT_NHWC

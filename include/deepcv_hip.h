@@ -149,6 +149,28 @@ int dcv_conv2d_dgrad_prepared(const dcv_conv2d_desc* d, const float* dy, const f
  * disappears.  DCV_ERR_UNSUPPORTED (nothing launched) when the kernel serving this layer has no such epilogue: add separately then. */
 int dcv_conv2d_dgrad_prepared_add(const dcv_conv2d_desc* d, const float* dy, const float* w, const void* filter, const float* addend, float* dx, void* stream);
 
+/* ---- bf16 STORAGE path ("bf16 MFMA conv" of BASELINE.json configs 3 / 5; replaces torch.nn.Conv2d under bf16 autocast, submodule_creators.py:251) ----
+ * Activations (x, y, dy, dx) are bf16 NHWC tensors in HBM, the prepared filter is bf16 [tap][cout][cin]; LDS holds bf16, the matrix cores run
+ * v_mfma_f32_16x16x32_bf16 with fp32 accumulation; master weights, bias, statistics (fp64 partials) and weight gradients stay fp32.
+ * Shapes: NHWC, groups 1, input channels of the kernel a multiple of 64, output channels a multiple of 64, tensors below 2 GiB; op 0 forward (any
+ * stride / padding / dilation), op 1 data gradient (stride <= 4), op 2 weight gradient (3x3, stride 1, pad 1).  Otherwise DCV_ERR_UNSUPPORTED: cast with
+ * dcv_cast_* and use the fp32 entry points (math DCV_MATH_BF16 keeps bf16 operand rounding there).
+ * `y_dtype` / `dx_dtype`: element type of the tensor written. */
+#define DCV_DTYPE_F32 0
+#define DCV_DTYPE_BF16 1
+int dcv_conv2d_bf16_supported(const dcv_conv2d_desc* d, int op);
+size_t dcv_conv2d_bf16_filter_bytes(const dcv_conv2d_desc* d, int op);                        /* op 0 / 1 */
+/* ONE launch (per 24 pieces) rounding and re-laying out `count` fp32 OIHW master filters into their bf16 prepared forms */
+int dcv_conv2d_bf16_prepare_filters(int count, const dcv_conv2d_desc* const* descs, const int* ops, const float* const* w, void* const* filters, void* stream);
+int dcv_conv2d_bf16_fwd_stats_layout(const dcv_conv2d_desc* d, int* rows, int* rows_per_sample);   /* as dcv_conv2d_fwd_stats_layout, for the kernel below */
+int dcv_conv2d_bf16_fwd(const dcv_conv2d_desc* d, const void* x_bf16, const void* filter, const float* bias, void* y, int y_dtype, double* stats, void* stream);
+int dcv_conv2d_bf16_dgrad(const dcv_conv2d_desc* d, const void* dy_bf16, const void* filter, void* dx, int dx_dtype, void* stream);
+size_t dcv_conv2d_bf16_wgrad_workspace_bytes(const dcv_conv2d_desc* d);
+int dcv_conv2d_bf16_wgrad(const dcv_conv2d_desc* d, const void* x_bf16, const void* dy_bf16, float* dw, void* ws, size_t ws_bytes, void* stream);
+/* element type conversion (round to nearest even, NaN stays NaN); n elements, x 16-B (fp32) / 8-B (bf16) aligned */
+int dcv_cast_f32_to_bf16(const float* x, void* y_bf16, size_t n, void* stream);
+int dcv_cast_bf16_to_f32(const void* x_bf16, float* y, size_t n, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * K4  elementwise activation (standalone; conv/linear fuse it into their epilogue)
  * replaces `act_fn()` modules of nn.py:553 (ReLU parameters.yml:9, LeakyReLU :80, Sigmoid :88)

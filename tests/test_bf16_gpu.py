@@ -1,0 +1,147 @@
+""" GPU tests of the bf16 STORAGE convolution path (`deepcv_amd/csrc/conv2d_bf16.hip`, C-ABI `dcv_conv2d_bf16_*`, `dcv_cast_*`): bf16 activations and
+prepared filters in HBM / LDS, v_mfma_f32_16x16x32_bf16, fp32 accumulation.
+
+Reference = fp64 torch convolution of the SAME bf16-rounded operands (what the kernel computes, up to the order of its fp32 accumulation): the stated
+tolerance for fp32 outputs is 2e-5 of the output's range (K <= 4608 products of bf16 values accumulated in fp32); a bf16 output adds one rounding to
+8 significant bits (2^-8 relative, asserted as 4.5e-3 of the range). """
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # (N, Cin, H, W, Cout, k, stride, pad, dil, act, bias)
+    (8, 64, 16, 16, 64, 3, 1, 1, 1, 1, True),        # 64-wide tile kernel (4 x 1 waves), relu
+    (4, 64, 16, 16, 128, 3, 1, 1, 1, 0, True),       # 128-wide tile kernel (2 x 2 waves)
+    (2, 128, 16, 16, 256, 3, 1, 1, 1, 2, False),     # two K chunks per tap, leaky relu, no bias
+    (3, 64, 10, 10, 64, 3, 1, 1, 1, 0, True),        # 300 pixels: ragged last tile, tiles straddling images
+    (2, 128, 16, 16, 128, 3, 2, 1, 1, 1, True),      # stride 2 (strided data gradient: four phases)
+    (2, 64, 16, 16, 128, 1, 2, 0, 1, 0, False),      # 1x1 stride 2 (ResNet downsample)
+    (2, 64, 12, 12, 64, 5, 1, 2, 1, 4, True),        # 5x5, tanh
+    (2, 64, 14, 14, 64, 3, 1, 2, 2, 0, True),        # dilation 2
+    (1, 256, 8, 8, 256, 3, 1, 1, 1, 1, True),        # four K chunks per tap
+]
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+def _desc(nat, n, cin, h, w, cout, k, stride, pad, dil, act):
+    ho = (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    wo = (w + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    return nat.Conv2dDesc(n, h, w, cin, cout, k, k, stride, stride, pad, pad, dil, dil, 1, ho, wo, nat.LAYOUT_NHWC, act, 0.1, nat.MATH_BF16)
+
+
+def _act(y, act):
+    return {0: lambda v: v, 1: torch.relu, 2: lambda v: F.leaky_relu(v, 0.1), 3: torch.sigmoid, 4: torch.tanh}[act](y)
+
+
+def _rel(got, ref):
+    return ((got.double().cpu() - ref.double().cpu()).abs().max() / (ref.abs().max() + 1e-30)).item()
+
+
+def _prepared(nat, lib, d, op, w, st):
+    nbytes = int(lib.dcv_conv2d_bf16_filter_bytes(d, op))
+    assert nbytes > 0
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    descs = (ctypes.POINTER(nat.Conv2dDesc) * 1)(ctypes.pointer(d))
+    ops_ = (ctypes.c_int * 1)(op)
+    ws = (ctypes.c_void_p * 1)(w.data_ptr())
+    bufs = (ctypes.c_void_p * 1)(buf.data_ptr())
+    nat.check(lib.dcv_conv2d_bf16_prepare_filters(1, descs, ops_, ws, bufs, st), 'prepare')
+    return buf
+
+
+def test_cast_kernels_match_torch(device):
+    from deepcv_amd import _native as nat
+    lib = nat.lib
+    st = nat.current_stream(device)
+    torch.manual_seed(0)
+    for n in (4096, 4099, 7):
+        x = torch.randn(n, device=device) * 3
+        x[0] = float('nan') if n > 100 else x[0]
+        y = torch.empty(n, dtype=torch.bfloat16, device=device)
+        nat.check(lib.dcv_cast_f32_to_bf16(x.data_ptr(), y.data_ptr(), n, st), 'cast')
+        ref = x.to(torch.bfloat16)
+        assert torch.equal(y.view(torch.int16)[1:], ref.view(torch.int16)[1:])
+        assert torch.isnan(y[0]) == torch.isnan(ref[0])
+        z = torch.empty(n, device=device)
+        nat.check(lib.dcv_cast_bf16_to_f32(ref.data_ptr(), z.data_ptr(), n, st), 'cast back')
+        assert torch.equal(z[1:], ref.float()[1:])
+
+
+@pytest.mark.parametrize('case', CASES, ids=lambda c: 'x'.join(str(v) for v in c))
+@pytest.mark.parametrize('out_bf16', [False, True], ids=['f32out', 'bf16out'])
+def test_bf16_forward_and_statistics(device, case, out_bf16):
+    from deepcv_amd import _native as nat
+    lib = nat.lib
+    n, cin, h, w, cout, k, stride, pad, dil, act, has_bias = case
+    torch.manual_seed(sum(case))
+    st = nat.current_stream(device)
+    d = _desc(nat, n, cin, h, w, cout, k, stride, pad, dil, act)
+    assert lib.dcv_conv2d_bf16_supported(d, 0)
+    x = _bf(torch.randn(n, cin, h, w)).contiguous(memory_format=torch.channels_last)
+    wt = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
+    b = torch.randn(cout) if has_bias else None
+    ref = _act(F.conv2d(x.double(), _bf(wt).double(), None if b is None else b.double(), stride, pad, dil), act)
+    xd, wd = x.to(device), wt.to(device)
+    bd = None if b is None else b.to(device)
+    f = _prepared(nat, lib, d, 0, wd, st)
+    y = torch.empty((n, cout, d.ho, d.wo), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=device).contiguous(memory_format=torch.channels_last)
+    rows, rps = ctypes.c_int(0), ctypes.c_int(0)
+    nat.check(lib.dcv_conv2d_bf16_fwd_stats_layout(d, ctypes.byref(rows), ctypes.byref(rps)), 'layout')
+    assert rows.value == (n * d.ho * d.wo + 127) // 128
+    stats = torch.full((2, cout, rows.value), float('nan'), dtype=torch.float64, device=device)
+    nat.check(lib.dcv_conv2d_bf16_fwd(d, xd.data_ptr(), f.data_ptr(), nat.ptr(bd), y.data_ptr(), nat.DTYPE_BF16 if out_bf16 else nat.DTYPE_F32, stats.data_ptr(), st), 'fwd')
+    torch.cuda.synchronize()
+    err = _rel(y, ref)
+    assert err <= (4.5e-3 if out_bf16 else 2e-5), f'forward error {err:.3e}'
+    # statistics: per-channel sums of y and y^2 (of the fp32 values before any output rounding), summed over the per-block rows
+    s = stats.sum(dim=2).cpu()
+    m = ref.permute(1, 0, 2, 3).reshape(cout, -1)
+    assert _rel(s[0], m.sum(1)) <= 2e-5 and _rel(s[1], (m * m).sum(1)) <= 2e-5
+    if rps.value:
+        per_sample = stats.view(2, cout, n, rps.value).sum(3)[0].cpu()
+        assert _rel(per_sample, ref.sum(dim=(2, 3)).t()) <= 2e-5
+
+
+@pytest.mark.parametrize('case', CASES, ids=lambda c: 'x'.join(str(v) for v in c))
+def test_bf16_data_and_weight_gradients(device, case):
+    from deepcv_amd import _native as nat
+    lib = nat.lib
+    n, cin, h, w, cout, k, stride, pad, dil, act, has_bias = case
+    torch.manual_seed(sum(case) + 1)
+    st = nat.current_stream(device)
+    d = _desc(nat, n, cin, h, w, cout, k, stride, pad, dil, 0)
+    x = _bf(torch.randn(n, cin, h, w)).contiguous(memory_format=torch.channels_last)
+    wt = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
+    dy = _bf(torch.randn(n, cout, d.ho, d.wo)).contiguous(memory_format=torch.channels_last)
+    xr = x.double().requires_grad_(True)
+    wr = _bf(wt).double().requires_grad_(True)
+    F.conv2d(xr, wr, None, stride, pad, dil).backward(dy.double())
+    wx = x.double()
+    wr2 = wt.double().requires_grad_(True)          # the weight gradient does not involve the (rounded) filter
+    F.conv2d(wx, wr2, None, stride, pad, dil).backward(dy.double())
+    xd, wd, dyd = x.to(device), wt.to(device), dy.to(device)
+    if lib.dcv_conv2d_bf16_supported(d, 1):
+        f = _prepared(nat, lib, d, 1, wd, st)
+        for dt, tol in ((torch.float32, 2e-5), (torch.bfloat16, 4.5e-3)):
+            dx = torch.full((n, cin, h, w), float('nan'), dtype=dt, device=device).contiguous(memory_format=torch.channels_last)
+            nat.check(lib.dcv_conv2d_bf16_dgrad(d, dyd.data_ptr(), f.data_ptr(), dx.data_ptr(), nat.DTYPE_BF16 if dt == torch.bfloat16 else nat.DTYPE_F32, st), 'dgrad')
+            torch.cuda.synchronize()
+            err = _rel(dx, xr.grad)
+            assert err <= tol, f'data gradient error {err:.3e} ({dt})'
+    else:
+        assert dil != 1 and stride != 1
+    if lib.dcv_conv2d_bf16_supported(d, 2):
+        assert k == 3 and stride == 1 and pad == 1 and dil == 1
+        ws = torch.empty(int(lib.dcv_conv2d_bf16_wgrad_workspace_bytes(d)), dtype=torch.uint8, device=device)
+        dw = torch.full((cout, cin, k, k), float('nan'), device=device)
+        nat.check(lib.dcv_conv2d_bf16_wgrad(d, xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), st), 'wgrad')
+        torch.cuda.synchronize()
+        err = _rel(dw, wr2.grad)
+        assert err <= 2e-5, f'weight gradient error {err:.3e}'

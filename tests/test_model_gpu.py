@@ -215,25 +215,29 @@ def test_wide_models_match_oracle(device, params, spec, nc, shape, n):
     assert med <= 3e-2 and max(errs.values()) <= 0.5, f'gradient rel err: median {med:.3e}, worst {max(errs.values()):.3e} at {max(errs, key=errs.get)}'
 
 
-def test_cifar100_deep_bf16_math_tracks_fp32(device, params):
-    """ BASELINE.json config 3 ("bf16 MFMA conv"): with `set_conv_math('bf16')` the wide convolutions run on v_mfma_f32_16x16x16_bf16 (operands rounded to
-    bf16 in registers, fp32 accumulation, fp32 tensors and master weights).  Against the fp32 CPU oracle the logits / loss then carry bf16 operand error
-    (2^-9 per product): asserted at 3e-2 of the logit range and 1e-2 of the loss, on the smooth (tanh) twin so that no ReLU kink amplifies it. """
+@pytest.mark.parametrize('spec,nc,shape,n', [('cifar100_deep_model', 100, (3, 32, 32), 4), ('resnet18_style_model', 1000, (3, 224, 224), 2)], ids=['cifar100_deep', 'resnet18_style'])
+@pytest.mark.parametrize('storage', [True, False], ids=['bf16_storage', 'bf16_operands'])
+def test_wide_models_bf16_math_track_fp32(device, params, spec, nc, shape, n, storage):
+    """ BASELINE.json configs 3 / 5 ("bf16 MFMA conv"): with `set_conv_math('bf16')` the wide convolutions run on the bf16 STORAGE kernels
+    (`dcv_conv2d_bf16_*`: bf16 activations and filters in HBM / LDS, v_mfma_f32_16x16x32_bf16) or, with `set_bf16_storage(False)` and for the layers those
+    kernels do not serve, on the fp32-storage kernels with operands rounded in registers; fp32 accumulation and master weights either way.  Against the fp32
+    CPU oracle the logits / loss then carry bf16 operand error (2^-9 per product): asserted at 3e-2 of the logit range and 1e-2 of the loss, on the smooth
+    (tanh) twin so that no ReLU kink amplifies it. """
     import copy
     from deepcv_amd import ops
-    spec, nc, shape, n = 'cifar100_deep_model', 100, (3, 32, 32), 4
     g = torch.Generator().manual_seed(DATA_SEED)
     x, y = torch.randn(n, *shape, generator=g), torch.randint(0, nc, (n,), generator=g)
     smooth = dict(copy.deepcopy(dict(params[spec])))
     smooth['act_fn'] = torch.nn.Tanh
     native, oracle = _build({'smooth': smooth}, 'smooth', nc, image_shape=shape)
-    prev = ops.set_conv_math('bf16')
+    prev, prev_st = ops.set_conv_math('bf16'), ops.set_bf16_storage(storage)
     try:
         e_logits, e_loss = _fwd_bwd_pair(native.to(device), oracle, x, y, device)
     finally:
         ops.set_conv_math(prev)
+        ops.set_bf16_storage(prev_st)
     errs = _grad_rel_errors(native, oracle)
-    _report(f'{spec}[bf16 math, tanh twin]: logits rel err {e_logits:.3e}, loss rel err {e_loss:.3e}, worst grad rel err {max(errs.values()):.3e}')
+    _report(f'{spec}[bf16 math, storage={storage}, tanh twin]: logits rel err {e_logits:.3e}, loss rel err {e_loss:.3e}, worst grad rel err {max(errs.values()):.3e}')
     assert 1e-5 < e_logits <= 3e-2 and e_loss <= 1e-2          # > 1e-5: the bf16 kernels really ran
     assert max(errs.values()) <= 0.15
 
