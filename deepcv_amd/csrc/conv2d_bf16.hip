@@ -202,6 +202,224 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(Bf16Args a, const u16
     }
 }
 
+// ------------------------------------------------------------------------------------------------ weight gradient, all nine taps per block, bf16 operands
+// dW[tap][co][ci] = sum over pixels of dz[p][co] * x[p (+) tap][ci] for 3x3 / stride 1 / pad 1 layers: GEMM with M = co, N = ci, K = pixels.  Both operands
+// are K-strided in memory ([pixel][channel] rows), so the LDS images keep the natural layout and the fragments are read TRANSPOSED (`ds_read_b64_tr_b16`:
+// a 16-lane group fetches a 4-pixel x 16-channel block and every lane receives the four pixels of its channel).  Structure as conv2d_mfma.hip's all-taps
+// kernel: a block owns (pixel chunk, 64 ci, 64 co); per step of 32 pixels of one image it stages the dz tile [32][64] and the flat x window
+// [32 + 2W + 2][64] (zero outside the image) once for all nine taps; tap (r, s) of pixel p reads window row p + r W + s; window rows which wrapped around the
+// left / right edge are cancelled by zeroing the dz operand of border pixels for s = 0 / s = 2 (two mask words per pixel pair, applied with v_and).
+//   * wave w owns input-channel tile w (16 ci) and ALL four output-channel tiles: per step 4 x 2 transposed reads of dz + 9 x 2 of x feed 36 MFMAs
+//     (v_mfma_f32_16x16x32_bf16), a third of the LDS traffic of one-co-tile-per-wave; 36 accumulator tiles = 144 VGPRs, two waves per SIMD.
+//   * K order inside a step: lane group g takes pixels 4g..4g+3 and 16+4g..16+4g+3, the same for both operands (any common permutation of K is valid), so a
+//     32-lane half always reads 8 CONSECUTIVE rows; with 160-B rows (128 B + 32 B pad: 40 r mod 64 visits every multiple of 8) those reads are conflict-free
+//     at every tap offset.
+//   * partial[chunk][tap][co][ci] fp32 slabs + conv2d_mfma.hip's ordered reduce (deterministic).
+struct W16Args {
+    int N, H, W, Cin, Cout;
+    int XR;                         // window rows: 32 + 2 W + 2
+    int HWp;                        // pixels per image rounded up to a multiple of 32
+    long M, m_per_chunk;            // N * HWp; padded pixels per split-K chunk (multiple of 32)
+    size_t wtotal;
+};
+#define W16_PS 32
+#define W16_LD 160                  // LDS row stride in bytes
+#define W16_XP 8                    // 16-B pieces of the x window per thread and step (XR * 8 <= 256 * W16_XP)
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+__device__ __forceinline__ s16x4 tr_read(const char* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p); }
+
+// GROUPS: wave groups of 256 threads splitting the block's pixel range; their accumulators are summed through LDS at the end (group 1's 36 tiles = 144 KB,
+// the staging buffers are dead by then), which halves the number of fp32 partial slabs the ordered reduce has to read for the same number of resident waves.
+template <int GROUPS>
+__global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9_kernel(W16Args a, const u16* __restrict__ x, const u16* __restrict__ dy, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem16[];
+    const int XR = a.XR;
+    const int G_BYTES = W16_PS * W16_LD, X_BYTES = XR * W16_LD;
+    const int GROUP_BYTES = 2 * G_BYTES + 2 * X_BYTES + 2 * 16 * 2 * (int)sizeof(unsigned);
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), t = threadIdx.x & 255, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    char* Gs = smem16 + grp * GROUP_BYTES;                       // [2][32 rows]   dz tile [pixel][co]
+    char* Xs = Gs + 2 * G_BYTES;                                 // [2][XR rows]   x window [row][ci]
+    unsigned* Cm = reinterpret_cast<unsigned*>(Xs + 2 * X_BYTES);   // [2][16 pixel pairs][2]: and-masks of the pair's two bf16 for s = 0 (w > 0) and s = 2 (w < W - 1)
+    const int li = lane & 15, lg = lane >> 4;
+    const int ci0 = blockIdx.y * 64, co0 = blockIdx.z * 64;
+    // pixel counts fit 32 bits (tensors are below 2 GiB); all of this is wave-uniform (scalar registers)
+    const int per_group = (int)(a.m_per_chunk / GROUPS);         // multiple of 32
+    const int mb = (int)blockIdx.x * (int)a.m_per_chunk + grp * per_group;
+    int me = mb + per_group; if (me > (int)a.M) me = (int)a.M;
+    const int nsteps = per_group / W16_PS;                       // the same for every group: they share the barriers
+    int l_n = mb / a.HWp, l_p0 = mb - l_n * a.HWp;               // image and first pixel of the next step to LOAD (a step never straddles images: 32 | HWp)
+    int s_p0 = 0;                                                // first pixel of the step whose tiles sit in registers
+    const int HW = a.H * a.W;
+
+    const int prow = t >> 3, piece = t & 7;
+    const int nxp = (XR + 31) / 32;                               // passes over the x window (block-uniform)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    // Buffer loads: an out-of-range offset delivers zeros, so rows outside the image need no select on the loaded value (hipcc turns `ok ? load : 0` into a
+    // branch and a full vmcnt(0) drain per load) and no clamped address.
+    __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((size_t)a.N * HW * a.Cout * 2), 0x00020000);
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((size_t)a.N * HW * a.Cin * 2), 0x00020000);
+    u32x4 g, xv[W16_XP];
+    auto load_step = [&]() {
+        const int n = l_n, p0 = l_p0;
+        s_p0 = p0;
+        l_p0 += W16_PS; if (l_p0 >= a.HWp) { l_p0 = 0; ++l_n; }
+        {
+            const int p = p0 + prow;
+            const unsigned off = (unsigned)(((n * HW + p) * a.Cout + co0 + 8 * piece) * 2);
+            g = __builtin_amdgcn_raw_buffer_load_b128(rdy, (int)(p < HW ? off : BF_OOB), 0, 0);
+        }
+        const int xbase = ((n * HW) * a.Cin + ci0 + 8 * piece) * 2;
+        const int q0 = p0 - a.W - 1;
+#pragma unroll
+        for (int u = 0; u < W16_XP; ++u)
+            if (u < nxp) {
+                const int row = prow + 32 * u, q = q0 + row;
+                const bool ok = row < XR && q >= 0 && q < HW;
+                xv[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(ok ? (unsigned)(xbase + q * a.Cin * 2) : BF_OOB), 0, 0);
+            }
+    };
+    auto store_step = [&](int buf) {
+        *reinterpret_cast<u32x4*>(Gs + buf * G_BYTES + prow * W16_LD + piece * 16) = g;
+#pragma unroll
+        for (int u = 0; u < W16_XP; ++u)
+            if (u < nxp) {
+                const int row = prow + 32 * u;
+                if (row < XR) *reinterpret_cast<u32x4*>(Xs + (size_t)buf * X_BYTES + row * W16_LD + piece * 16) = xv[u];
+            }
+        if (t < 16) {
+            const int pw = s_p0 + 2 * t;
+            const int w0 = pw % a.W, w1 = (pw + 1) % a.W;
+            Cm[(buf * 16 + t) * 2 + 0] = (w0 > 0 ? 0x0000ffffu : 0u) | (w1 > 0 ? 0xffff0000u : 0u);
+            Cm[(buf * 16 + t) * 2 + 1] = (w0 < a.W - 1 ? 0x0000ffffu : 0u) | (w1 < a.W - 1 ? 0xffff0000u : 0u);
+        }
+    };
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[k][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // transposed-read addresses of this lane: row q = li >> 2 of a 4-pixel block, channels 4 (li & 3) .. + 3 of a 16-channel tile
+    const int tr_row = 4 * lg + (li >> 2), tr_col = (li & 3) * 8;
+    const int a_off = tr_row * W16_LD + tr_col;                  // + 32 t for output-channel tile t, + 16 rows for the second half of K
+    const int b_off = tr_row * W16_LD + wave * 32 + tr_col;      // + (r W + s) rows for tap (r, s)
+
+    if (mb < me) { load_step(); store_step(0); }                 // (group-uniform)
+    __syncthreads();
+    for (int it = 0; it < nsteps; ++it) {
+        const int m = mb + it * W16_PS;
+        const int buf = it & 1;
+        const bool active = m < me, has_next = (m + W16_PS) < me;    // group-uniform: a group whose range ended early only keeps the barriers
+        if (has_next) load_step();
+        if (active) {
+            const char* gs = Gs + buf * G_BYTES;
+            const char* xs = Xs + (size_t)buf * X_BYTES;
+            // masks of this lane's eight pixels (pairs 2g, 2g+1 and 8+2g, 8+2g+1): {left01, right01, left23, right23}
+            const uint4 mk0 = *reinterpret_cast<const uint4*>(Cm + (buf * 16 + 2 * lg) * 2);
+            const uint4 mk1 = *reinterpret_cast<const uint4*>(Cm + (buf * 16 + 8 + 2 * lg) * 2);
+            union Frag { bf16x8 v; s16x4 h[2]; unsigned u[4]; };
+            Frag af[4];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) { af[tt].h[0] = tr_read(gs + a_off + tt * 32); af[tt].h[1] = tr_read(gs + a_off + tt * 32 + 16 * W16_LD); }
+#pragma unroll
+            for (int sx = 0; sx < 3; ++sx) {
+                Frag av[4];
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    if (sx == 1) av[tt] = af[tt];
+                    else {
+                        av[tt].u[0] = af[tt].u[0] & (sx == 0 ? mk0.x : mk0.y); av[tt].u[1] = af[tt].u[1] & (sx == 0 ? mk0.z : mk0.w);
+                        av[tt].u[2] = af[tt].u[2] & (sx == 0 ? mk1.x : mk1.y); av[tt].u[3] = af[tt].u[3] & (sx == 0 ? mk1.z : mk1.w);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    Frag bfr;
+                    const char* bp = xs + b_off + (r * a.W + sx) * W16_LD;
+                    bfr.h[0] = tr_read(bp); bfr.h[1] = tr_read(bp + 16 * W16_LD);
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) acc[r * 3 + sx][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[tt].v, bfr.v, acc[r * 3 + sx][tt], 0, 0, 0);
+                }
+            }
+        }
+        if (has_next) store_step(buf ^ 1);
+        __syncthreads();
+    }
+    if constexpr (GROUPS == 2) {
+        // acc of group 1 -> LDS -> added by group 0 (fixed order: group 0 + group 1)
+        f32x4* red = reinterpret_cast<f32x4*>(smem16);
+        if (grp == 1) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) red[(k * 4 + tt) * 256 + t] = acc[k][tt];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) acc[k][tt] += red[(k * 4 + tt) * 256 + t];
+    }
+    // acc[tap][tt][reg]: co = co0 + 16 tt + 4 lg + reg, ci = ci0 + 16 wave + li
+    float* dst = partial + (size_t)blockIdx.x * a.wtotal;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int co = co0 + tt * 16 + 4 * lg + reg, ci = ci0 + wave * 16 + li;
+                dst[((size_t)k * a.Cout + co) * a.Cin + ci] = acc[k][tt][reg];
+            }
+}
+
+inline int w16_groups() {              // wave groups per block (2: in-block sum of two pixel halves, half the partial slabs).  Measured at N = 512: a tie on
+    static int gr = -1;                // 64- and 256-channel layers (71.7 vs 72.3 us, 209.9 vs 209.2 us), 206 vs 195 us on 512 -> 512 @8x8: one group by default
+    if (gr < 0) { const char* e = getenv("DCV_BF16_WGRAD9_GROUPS"); gr = e ? atoi(e) : 1; if (gr != 2) gr = 1; }
+    return gr;
+}
+
+inline bool w16_plan(const dcv_conv2d_desc* d, W16Args* a, int* chunks, size_t* smem, int* groups) {
+    static int enabled = -1;
+    if (enabled < 0) { const char* e = getenv("DCV_BF16_WGRAD9"); enabled = e ? atoi(e) : 1; }
+    if (!enabled) return false;
+    if (d->groups != 1 || d->x_layout != DCV_LAYOUT_NHWC) return false;
+    if (d->r != 3 || d->s != 3 || d->stride_h != 1 || d->stride_w != 1 || d->pad_h != 1 || d->pad_w != 1 || d->dil_h != 1 || d->dil_w != 1) return false;
+    if (d->cin % 64 != 0 || d->cout % 64 != 0 || d->ho != d->h || d->wo != d->w) return false;
+    const int hw = d->h * d->w, XR = W16_PS + 2 * d->w + 2;
+    if (XR * 8 > 256 * W16_XP) return false;
+    const int hwp = (hw + W16_PS - 1) / W16_PS * W16_PS;
+    if (hwp * 3 > hw * 4) return false;                                                // more than a third of padding pixels: the fp32-staged kernel steps by 16
+    const size_t group_bytes = (size_t)2 * W16_PS * W16_LD + (size_t)2 * XR * W16_LD + (size_t)2 * 16 * 2 * sizeof(unsigned);
+    int gr = w16_groups();
+    if (gr == 2 && 2 * group_bytes > (size_t)150 * 1024) gr = 1;
+    if (group_bytes > (size_t)80 * 1024) return false;
+    *smem = gr == 2 ? (2 * group_bytes > (size_t)36 * 256 * 16 ? 2 * group_bytes : (size_t)36 * 256 * 16) : group_bytes;
+    *groups = gr;
+    a->N = d->n; a->H = d->h; a->W = d->w; a->Cin = d->cin; a->Cout = d->cout; a->XR = XR; a->HWp = hwp;
+    a->M = (long)d->n * hwp;
+    a->wtotal = (size_t)d->cout * d->cin * 9;
+    const long blocks_per_chunk = (long)(d->cin / 64) * (d->cout / 64);
+    const long resident = gr == 2 ? DCV_NUM_CU : 2 * DCV_NUM_CU;                       // blocks resident at once (two waves per SIMD either way): one round
+    long ch = (resident + blocks_per_chunk - 1) / blocks_per_chunk;
+    const long unit = (long)gr * W16_PS;
+    const long max_by_m = a->M / (4 * unit) > 0 ? a->M / (4 * unit) : 1;              // at least four steps per group
+    if (ch > max_by_m) ch = max_by_m;
+    const long max_by_bytes = (long)(((size_t)256 << 20) / (a->wtotal * sizeof(float)));
+    if (ch > max_by_bytes) ch = max_by_bytes;
+    if (ch < 1) ch = 1;
+    long mpc = (a->M + ch - 1) / ch;
+    mpc = (mpc + unit - 1) / unit * unit;
+    a->m_per_chunk = mpc;
+    *chunks = (int)((a->M + mpc - 1) / mpc);
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------ prepared filters, casts
 // dst[tap][kcout][kcin] bf16 from the fp32 OIHW master filter (fwd), or its transposed + flipped (sub-)filter (data gradient; conv2d_internal.h)
 struct Bf16Prep { const float* w; u16* dst; int kcout, kcin, R, S, w_cin, dgrad, r0, rstep, Rw, s0, sstep, Sw, total; };
@@ -338,12 +556,34 @@ int dcv_conv2d_bf16_supported(const dcv_conv2d_desc* d, int op) {
 
 size_t dcv_conv2d_bf16_wgrad_workspace_bytes(const dcv_conv2d_desc* d) {
     if (!desc_ok(d) || !dcv_mfma_conv2d_wgrad_in16_supported(d)) return 0;
-    return dcv_mfma_conv2d_ws(d, 2);
+    size_t need = dcv_mfma_conv2d_ws(d, 2);
+    W16Args a{}; int chunks, groups; size_t smem;
+    if (w16_plan(d, &a, &chunks, &smem, &groups)) { const size_t n16 = dcv_align_up((size_t)chunks * a.wtotal * sizeof(float), 256); if (n16 > need) need = n16; }
+    return need;
 }
 
 int dcv_conv2d_bf16_wgrad(const dcv_conv2d_desc* d, const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, void* stream) {
     DCV_CHECK_ARG(desc_ok(d) && x && dy && dw);
     if (!dcv_mfma_conv2d_wgrad_in16_supported(d)) return DCV_ERR_UNSUPPORTED;
+    W16Args a{}; int chunks, groups; size_t smem;
+    if (w16_plan(d, &a, &chunks, &smem, &groups)) {
+        if (!ws || ws_bytes < (size_t)chunks * a.wtotal * sizeof(float)) return DCV_ERR_WORKSPACE;
+        DCV_CHECK_ARG(aligned16(x) && aligned16(dy) && aligned16(ws));
+        dim3 grid((unsigned)chunks, (unsigned)(d->cin / 64), (unsigned)(d->cout / 64));
+        if (grid.y > 65535 || grid.z > 65535) return DCV_ERR_UNSUPPORTED;
+        static bool configured = false;
+        if (!configured) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_wgrad9_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_wgrad9_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DCV_ERR_LAUNCH;
+            configured = true;
+        }
+        float* partial = reinterpret_cast<float*>(ws);
+        const u16* xs = reinterpret_cast<const u16*>(x); const u16* dys = reinterpret_cast<const u16*>(dy);
+        if (groups == 2) hipLaunchKernelGGL(conv_bf16_wgrad9_kernel<2>, grid, dim3(512), smem, dcv_stream(stream), a, xs, dys, partial);
+        else hipLaunchKernelGGL(conv_bf16_wgrad9_kernel<1>, grid, dim3(256), smem, dcv_stream(stream), a, xs, dys, partial);
+        if (hipGetLastError() != hipSuccess) return DCV_ERR_LAUNCH;
+        return dcv_mfma_wgrad9_reduce(partial, dw, chunks, d->cout, d->cin, dcv_stream(stream));
+    }
     return dcv_mfma_conv2d_wgrad_in16(d, x, dy, dw, ws, ws_bytes, dcv_stream(stream));
 }
 

@@ -29,6 +29,8 @@ int dcv_mfma_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float*
 // bf16 x / dy (bf16 storage path): the all-taps kernel only; workspace = dcv_mfma_conv2d_ws(d, 2)
 bool dcv_mfma_conv2d_wgrad_in16_supported(const dcv_conv2d_desc* d);
 int dcv_mfma_conv2d_wgrad_in16(const dcv_conv2d_desc* d, const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
+// dw[co][ci][tap] = ordered sum over chunks of partial[chunk][tap][co][ci] (3x3 filters)
+int dcv_mfma_wgrad9_reduce(const float* partial, float* dw, int chunks, int cout, int cin, hipStream_t st);
 
 // Prepared filters: one entry describes the re-layout of one OIHW filter for the kernel which will consume it (see dcv_conv2d_prepare_filters).
 struct dcv_prep_entry {

@@ -544,11 +544,22 @@ __global__ __launch_bounds__(256) void mfma_wgrad9_reduce_kernel(const float* __
     const size_t wtotal = (size_t)9 * Cout * Cin;
     const size_t e4 = (size_t)blockIdx.x * 8 + v4;                   // float4 index inside a slab ([tap][co][ci / 4])
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e4 * 4 < wtotal)
-        for (int c = cl; c < chunks; c += 32) {
-            const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)c * wtotal + e4 * 4);
+    if (e4 * 4 < wtotal) {
+        const float* src = partial + e4 * 4;
+        int c = cl;
+        for (; c + 96 < chunks; c += 128) {                          // four slabs in flight per thread (same summation order as the plain loop)
+            const float4 v0 = *reinterpret_cast<const float4*>(src + (size_t)c * wtotal), v1 = *reinterpret_cast<const float4*>(src + (size_t)(c + 32) * wtotal);
+            const float4 v2 = *reinterpret_cast<const float4*>(src + (size_t)(c + 64) * wtotal), v3 = *reinterpret_cast<const float4*>(src + (size_t)(c + 96) * wtotal);
+            s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+            s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+            s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+            s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+        }
+        for (; c < chunks; c += 32) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)c * wtotal);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
+    }
     red[cl][v4] = s;
     __syncthreads();
     if (cl == 0 && e4 * 4 < wtotal) {
@@ -560,6 +571,30 @@ __global__ __launch_bounds__(256) void mfma_wgrad9_reduce_kernel(const float* __
         float* d = dw + ((size_t)co * Cin + ci) * 9 + tap;
         d[0] = t.x; d[9] = t.y; d[18] = t.z; d[27] = t.w;
     }
+}
+
+// The same sum for FEW slabs (<= 16: wide layers, where one chunk already holds many blocks): with 32 chunk lanes most threads of the kernel above idle and its
+// output goes out as 4-B stores 36 B apart.  Here a thread sums all slabs of one (tap, 4 input channels) item itself (every load independent), the block
+// gathers the nine taps of (one output channel, CB input channels) in LDS and writes them as one contiguous run of dw.
+template <int CB>
+__global__ __launch_bounds__(256) void mfma_wgrad9_reduce_few_kernel(const float* __restrict__ partial, float* __restrict__ dw, int chunks, int Cout, int Cin) {
+    __shared__ __attribute__((aligned(16))) float out[CB * 9];
+    const int co = blockIdx.y, ci0 = blockIdx.x * CB;
+    const size_t wtotal = (size_t)9 * Cout * Cin;
+    for (int i = threadIdx.x; i < 9 * (CB / 4); i += 256) {
+        const int tap = i / (CB / 4), v4 = i - tap * (CB / 4);
+        const float* src = partial + ((size_t)tap * Cout + co) * Cin + ci0 + 4 * v4;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+        for (int c = 0; c < chunks; ++c) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)c * wtotal);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        out[(4 * v4 + 0) * 9 + tap] = s.x; out[(4 * v4 + 1) * 9 + tap] = s.y; out[(4 * v4 + 2) * 9 + tap] = s.z; out[(4 * v4 + 3) * 9 + tap] = s.w;
+    }
+    __syncthreads();
+    float4* dst = reinterpret_cast<float4*>(dw + ((size_t)co * Cin + ci0) * 9);
+    for (int i = threadIdx.x; i < CB * 9 / 4; i += 256) dst[i] = reinterpret_cast<const float4*>(out)[i];
 }
 
 __global__ __launch_bounds__(1024) void mfma_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int chunks, size_t wtotal) {
@@ -977,6 +1012,16 @@ static int launch_wgrad9(const Wg9Args& a, dim3 grid, size_t smem, hipStream_t s
     return DCV_OK;
 }
 
+int dcv_mfma_wgrad9_reduce(const float* partial, float* dw, int chunks, int cout, int cin, hipStream_t st) {
+    if (chunks <= 16 && cin % 64 == 0 && cout <= 65535 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0) {
+        if (cin % 128 == 0) hipLaunchKernelGGL(mfma_wgrad9_reduce_few_kernel<128>, dim3((unsigned)(cin / 128), (unsigned)cout), dim3(256), 0, st, partial, dw, chunks, cout, cin);
+        else hipLaunchKernelGGL(mfma_wgrad9_reduce_few_kernel<64>, dim3((unsigned)(cin / 64), (unsigned)cout), dim3(256), 0, st, partial, dw, chunks, cout, cin);
+        return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(mfma_wgrad9_reduce_kernel, dim3((unsigned)dcv_ceil_div((size_t)9 * cout * cin / 4, 8)), dim3(256), 0, st, partial, dw, chunks, cout, cin);
+    return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
+}
+
 // bf16 storage path: x and dy are bf16 tensors; only the layers the all-taps kernel plans (3x3, stride 1, pad 1, 64-aligned channels)
 bool dcv_mfma_conv2d_wgrad_in16_supported(const dcv_conv2d_desc* d) {
     Wg9Args a9{}; int ps9, chunks9; size_t sm9;
@@ -994,8 +1039,7 @@ int dcv_mfma_conv2d_wgrad_in16(const dcv_conv2d_desc* d, const void* x, const vo
     const float* xf = reinterpret_cast<const float*>(x); const float* dyf = reinterpret_cast<const float*>(dy);
     const int rc = ps9 == 32 ? launch_wgrad9<32, true, false, true>(a9, grid, sm9, st, xf, dyf, partial) : launch_wgrad9<16, true, false, true>(a9, grid, sm9, st, xf, dyf, partial);
     if (rc != DCV_OK) return rc;
-    hipLaunchKernelGGL(mfma_wgrad9_reduce_kernel, dim3((unsigned)dcv_ceil_div(a9.wtotal / 4, 8)), dim3(256), 0, st, partial, dw, chunks9, d->cout, d->cin);
-    return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
+    return dcv_mfma_wgrad9_reduce(partial, dw, chunks9, d->cout, d->cin, st);
 }
 
 int dcv_mfma_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -1013,8 +1057,7 @@ int dcv_mfma_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float*
             if (ps9 == 32) rc = bf ? launch_wgrad9<32, true, false>(a9, grid, sm9, st, x, dy, partial) : (pipe ? launch_wgrad9<32, false, true>(a9, grid, sm9, st, x, dy, partial) : launch_wgrad9<32, false, false>(a9, grid, sm9, st, x, dy, partial));
             else rc = bf ? launch_wgrad9<16, true, false>(a9, grid, sm9, st, x, dy, partial) : (pipe ? launch_wgrad9<16, false, true>(a9, grid, sm9, st, x, dy, partial) : launch_wgrad9<16, false, false>(a9, grid, sm9, st, x, dy, partial));
             if (rc != DCV_OK) return rc;
-            hipLaunchKernelGGL(mfma_wgrad9_reduce_kernel, dim3((unsigned)dcv_ceil_div(a9.wtotal / 4, 8)), dim3(256), 0, st, partial, dw, chunks9, d->cout, d->cin);
-            return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
+            return dcv_mfma_wgrad9_reduce(partial, dw, chunks9, d->cout, d->cin, st);
         }
     }
     MfmaWgArgs a{}; int chunks;

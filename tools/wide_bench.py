@@ -14,6 +14,7 @@ graph = len(sys.argv) > 4 and 'graph' in sys.argv[4]
 if len(sys.argv) > 4 and 'bf16' in sys.argv[4]:
     from deepcv_amd import ops as _ops
     _ops.set_conv_math('bf16')
+    _ops.set_bf16_storage('operands' not in sys.argv[4])
 shape, nc = ((3, 224, 224), 1000) if 'resnet' in spec else ((3, 32, 32), 100)
 dev = torch.device('cuda:0')
 P = load_parameters()
