@@ -66,7 +66,7 @@ class NormChainDesc(ctypes.Structure):
                 ('bn_gamma', _c_void_p), ('bn_beta', _c_void_p), ('running_mean', _c_void_p), ('running_var', _c_void_p), ('num_batches_tracked', _c_void_p),
                 ('momentum', _c_float), ('bn_eps', _c_float), ('bn_mean', _c_void_p), ('bn_rstd', _c_void_p),
                 ('groups', _c_int), ('gn_gamma', _c_void_p), ('gn_beta', _c_void_p), ('gn_eps', _c_float), ('gn_mean', _c_void_p), ('gn_rstd', _c_void_p),
-                ('coef', _c_void_p), ('act', _c_int), ('act_slope', _c_float)]
+                ('coef', _c_void_p), ('act', _c_int), ('act_slope', _c_float), ('io_dtype', _c_int)]
 
 
 class TensorList(ctypes.Structure):
@@ -117,6 +117,7 @@ _SIGNATURES = {
     'dcv_act_bwd_workspace_bytes': (_c_size_t, [_c_size_t, _c_int]),
     'dcv_act_bwd': (_c_int, [_P, _P, _P, _c_size_t, _c_int, _c_int, _c_float, _P, _P, _c_size_t, _P]),
     'dcv_channel_sum': (_c_int, [_P, _P, _c_size_t, _c_int, _P, _c_size_t, _P]),
+    'dcv_channel_sum_bf16': (_c_int, [_P, _P, _c_size_t, _c_int, _P, _c_size_t, _P]),
     'dcv_batchnorm_workspace_bytes': (_c_size_t, [_c_size_t, _c_int]),
     'dcv_batchnorm_fwd_train': (_c_int, [_P, _P, _c_size_t, _c_int, _P, _P, _P, _P, _P, _c_float, _c_float, _P, _P, _P, _c_size_t, _P]),
     'dcv_batchnorm_fwd_eval': (_c_int, [_P, _P, _c_size_t, _c_int, _P, _P, _P, _P, _c_float, _P, _c_size_t, _P]),

@@ -394,7 +394,7 @@ inline bool w16_plan(const dcv_conv2d_desc* d, W16Args* a, int* chunks, size_t* 
     const int hw = d->h * d->w, XR = W16_PS + 2 * d->w + 2;
     if (XR * 8 > 256 * W16_XP) return false;
     const int hwp = (hw + W16_PS - 1) / W16_PS * W16_PS;
-    if (hwp * 3 > hw * 4) return false;                                                // more than a third of padding pixels: the fp32-staged kernel steps by 16
+    if (hwp > 2 * hw) return false;                                                    // more than half of the steps' pixels would be padding (4x4 images: exactly half, still 2x the 16-pixel-step kernel)
     const size_t group_bytes = (size_t)2 * W16_PS * W16_LD + (size_t)2 * XR * W16_LD + (size_t)2 * 16 * 2 * sizeof(unsigned);
     int gr = w16_groups();
     if (gr == 2 && 2 * group_bytes > (size_t)150 * 1024) gr = 1;
@@ -430,6 +430,17 @@ __device__ __forceinline__ u16 f32_to_bf16_bits(float v) { const __bf16 h = (__b
 
 __global__ __launch_bounds__(256) void prep_bf16_kernel(Bf16PrepList l) {
     const Bf16Prep& e = l.e[blockIdx.y];
+    if (e.rstep == 1 && e.sstep == 1 && e.R == e.Rw && e.S == e.Sw) {
+        // whole filter: a thread owns one (kernel-cout, kernel-cin) pair, reads its R*S taps (contiguous in OIHW) and writes one element of every tap plane:
+        // reads are 4 R S-byte runs, writes of consecutive threads are consecutive bf16 of a plane (the element-wise form below gathers with stride R*S)
+        const int pairs = e.kcout * e.kcin, taps = e.R * e.S;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += gridDim.x * blockDim.x) {
+            const int ci = i % e.kcin, co = i / e.kcin;
+            const float* src = e.dgrad ? e.w + ((size_t)ci * e.w_cin + co) * taps : e.w + ((size_t)co * e.w_cin + ci) * taps;
+            for (int tp = 0; tp < taps; ++tp) e.dst[((size_t)tp * e.kcout + co) * e.kcin + ci] = f32_to_bf16_bits(src[e.dgrad ? taps - 1 - tp : tp]);
+        }
+        return;
+    }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < e.total; i += gridDim.x * blockDim.x) {
         const int ci = i % e.kcin; int q = i / e.kcin;
         const int co = q % e.kcout; const int tap = q / e.kcout;

@@ -78,8 +78,19 @@ struct PlainLoader {
     }
 };
 
-template <int VEC>
-__global__ __launch_bounds__(DCV_CR_THREADS) void channel_sum_kernel(PlainLoader ld, size_t rows, int C, double* __restrict__ partial) {
+struct Bf16Loader {                // bf16 rows (the bf16 storage path's dz), widened on load
+    const unsigned short* x;
+    template <int VEC>
+    __device__ __forceinline__ void load(size_t idx, int, float (&q)[1][VEC]) const {
+        if constexpr (VEC == 4) {
+            const uint2 v = *reinterpret_cast<const uint2*>(x + idx);
+            q[0][0] = __uint_as_float(v.x << 16); q[0][1] = __uint_as_float(v.x & 0xffff0000u); q[0][2] = __uint_as_float(v.y << 16); q[0][3] = __uint_as_float(v.y & 0xffff0000u);
+        } else q[0][0] = __uint_as_float((unsigned)x[idx] << 16);
+    }
+};
+
+template <int VEC, typename Loader = PlainLoader>
+__global__ __launch_bounds__(DCV_CR_THREADS) void channel_sum_kernel(Loader ld, size_t rows, int C, double* __restrict__ partial) {
     __shared__ float scratch[DCV_CR_THREADS * VEC];
     const size_t rpb = (rows + gridDim.x - 1) / gridDim.x;
     const size_t r0 = (size_t)blockIdx.x * rpb;
@@ -505,6 +516,19 @@ int dcv_channel_sum(const float* x, float* out, size_t rows, int C, void* ws, si
     PlainLoader ld{x};
     if (C % 4 == 0 && aligned16(x)) hipLaunchKernelGGL((channel_sum_kernel<4>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
     else hipLaunchKernelGGL((channel_sum_kernel<1>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)C), dim3(64), 0, st, partial, (int)nb, C, out);
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_channel_sum_bf16(const void* x, float* out, size_t rows, int C, void* ws, size_t ws_bytes, void* stream) {
+    DCV_CHECK_ARG(x && out && rows > 0 && C > 0);
+    if (!ws || ws_bytes < dcv_act_bwd_workspace_bytes(rows, C)) return DCV_ERR_WORKSPACE;
+    hipStream_t st = dcv_stream(stream);
+    double* partial = reinterpret_cast<double*>(ws);
+    const unsigned nb = dcv_colreduce_blocks(rows, C);
+    Bf16Loader ld{reinterpret_cast<const unsigned short*>(x)};
+    if (C % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0) hipLaunchKernelGGL((channel_sum_kernel<4, Bf16Loader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
+    else hipLaunchKernelGGL((channel_sum_kernel<1, Bf16Loader>), dim3(nb), dim3(DCV_CR_THREADS), 0, st, ld, rows, C, partial);
     hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)C), dim3(64), 0, st, partial, (int)nb, C, out);
     DCV_RETURN_LAUNCH();
 }

@@ -38,6 +38,21 @@ template <int VEC> __device__ __forceinline__ void nc_store(float* p, const NcVe
     if constexpr (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
     else p[0] = r.v[0];
 }
+// bf16 activations (io_dtype DCV_DTYPE_BF16: the layers of the bf16 storage convolution path): widened on load, rounded to nearest even on store
+typedef unsigned short nc_bf16;
+template <int VEC> __device__ __forceinline__ NcVec<VEC> nc_load(const nc_bf16* p) {
+    NcVec<VEC> r;
+    if constexpr (VEC == 4) {
+        const uint2 q = *reinterpret_cast<const uint2*>(p);
+        r.v[0] = __uint_as_float(q.x << 16); r.v[1] = __uint_as_float(q.x & 0xffff0000u); r.v[2] = __uint_as_float(q.y << 16); r.v[3] = __uint_as_float(q.y & 0xffff0000u);
+    } else r.v[0] = __uint_as_float((unsigned)p[0] << 16);
+    return r;
+}
+template <int VEC> __device__ __forceinline__ void nc_store(nc_bf16* p, const NcVec<VEC>& r) {
+    typedef __bf16 nc_bf16x4 __attribute__((ext_vector_type(4)));
+    if constexpr (VEC == 4) *reinterpret_cast<nc_bf16x4*>(p) = (nc_bf16x4){(__bf16)r.v[0], (__bf16)r.v[1], (__bf16)r.v[2], (__bf16)r.v[3]};
+    else { const __bf16 h = (__bf16)r.v[0]; p[0] = *reinterpret_cast<const nc_bf16*>(&h); }
+}
 
 // Block (x = chunk, y = sample) handles vectors [chunk * per, ...) of the sample; `per` is a multiple of NC_THREADS and CV (vectors per pixel) a power of
 // two <= NC_THREADS, so a thread's channel vector (t % CV) never changes and its pixel advances by NC_THREADS / CV per iteration.  No integer division.
@@ -106,15 +121,15 @@ struct NcGn {
 // per-sample coefficients P, Q0, R0 of dz = act'(x) * (P d + (Q0 - a dd) u + (R0 - a b)) -> pre[N][3][C]  (a dd, a b: batch-level terms, nc_param_finalize).
 struct NcBwdCtx { const float* bn_gamma; const float* bn_beta; const float* bn_rstd; NcGn gn; float* pre; };
 
-template <int VEC, bool DOTS>
-__global__ __launch_bounds__(NC_THREADS) void nc_sample_sums_kernel(const float* __restrict__ x, const float* __restrict__ dout, int HW, int C, int per,
+template <int VEC, bool DOTS, typename AT = float>
+__global__ __launch_bounds__(NC_THREADS) void nc_sample_sums_kernel(const AT* __restrict__ x, const AT* __restrict__ dout, int HW, int C, int per,
                                                                      const float* __restrict__ mean, const float* __restrict__ rstd, NcPool pm,
                                                                      double* __restrict__ part, int rows, NcBwdCtx bc) {
     constexpr int NQ = DOTS ? 4 : 2;
     __shared__ float sm[NQ * VEC][NC_THREADS];
     const int CV = C / VEC, nv = HW * CV;
     const NcChunk ck = nc_chunk(nv, CV, per);
-    const float* xs = x + (size_t)ck.n * HW * C;
+    const AT* xs = x + (size_t)ck.n * HW * C;
     float acc[NQ][VEC];
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
@@ -146,7 +161,7 @@ __global__ __launch_bounds__(NC_THREADS) void nc_sample_sums_kernel(const float*
             }
         }
     } else if (pm.pk == 0) {
-        const float* ds = dout + (size_t)ck.n * HW * C;
+        const AT* ds = dout + (size_t)ck.n * HW * C;
         for (int i = ck.i0; i < ck.i1; i += B * NC_THREADS) {
             NcVec<VEC> xv[B], dv[B];
 #pragma unroll
@@ -166,7 +181,7 @@ __global__ __launch_bounds__(NC_THREADS) void nc_sample_sums_kernel(const float*
         }
     } else {
         const int H = HW / pm.W;
-        const float* ds = dout + (size_t)ck.n * (H / pm.pk) * pm.Wo * C + ck.cv * VEC;
+        const AT* ds = dout + (size_t)ck.n * (H / pm.pk) * pm.Wo * C + ck.cv * VEC;
         int h = ck.pix / pm.W, w = ck.pix - h * pm.W;                      // one division per thread; the loop only adds
         const int hstep = ck.pstep / pm.W, wstep = ck.pstep - hstep * pm.W;
         for (int i = ck.i0; i < ck.i1; i += B * NC_THREADS) {
@@ -283,14 +298,14 @@ __global__ __launch_bounds__(NC_THREADS) void nc_bn_fwd_finalize_kernel(const do
 // out = S x + T.  Prologue (GroupNorm): the block's sample -> statistics of v = a x + b over each group from the sample's sums of x, x^2 (`part`, rps rows per
 // sample), S = a * rstd_g * gn_gamma, T = (b - mean_g) * rstd_g * gn_gamma + gn_beta, shared through LDS; the first loads of x are already in flight.
 // Pooled: one thread per pooled (pixel, channel vector), the mean of the affine over its window (same per-element rounding as affine + AvgPool2d).
-template <int VEC>
-__global__ __launch_bounds__(NC_THREADS) void nc_apply_kernel(const float* __restrict__ x, float* __restrict__ out, int HW, int C, int per,
+template <int VEC, typename AT = float>
+__global__ __launch_bounds__(NC_THREADS) void nc_apply_kernel(const AT* __restrict__ x, AT* __restrict__ out, int HW, int C, int per,
                                                                const float* __restrict__ ab, const double* __restrict__ part, int rows, int rps, NcGn gn, NcPool pm) {
     __shared__ float sS[NC_THREADS], sT[NC_THREADS];           // GroupNorm chains: C <= NC_THREADS
     const int CV = C / VEC;
     const int n = blockIdx.y;
     constexpr int PF = 4;                                       // vectors per thread requested before the prologue
-    const float* xs = x + (size_t)n * HW * C;
+    const AT* xs = x + (size_t)n * HW * C;
     NcVec<VEC> pre[PF];
     NcChunk ck;
     if (pm.pk == 0) {
@@ -337,7 +352,7 @@ __global__ __launch_bounds__(NC_THREADS) void nc_apply_kernel(const float* __res
         S = nc_load<VEC>(ab + cv * VEC); T = nc_load<VEC>(ab + C + cv * VEC);
     }
     if (pm.pk == 0) {
-        float* os = out + (size_t)n * HW * C;
+        AT* os = out + (size_t)n * HW * C;
 #pragma unroll
         for (int k = 0; k < PF; ++k) {
             const int i = ck.i0 + k * NC_THREADS;
@@ -364,7 +379,7 @@ __global__ __launch_bounds__(NC_THREADS) void nc_apply_kernel(const float* __res
     }
     const int H = HW / pm.W, HoWo = (H / pm.pk) * pm.Wo;
     ck = nc_chunk(HoWo * CV, CV, per);
-    const float* xc = xs + ck.cv * VEC; float* os = out + (size_t)n * HoWo * C;
+    const AT* xc = xs + ck.cv * VEC; AT* os = out + (size_t)n * HoWo * C;
     int ho = ck.pix / pm.Wo, wo = ck.pix - ho * pm.Wo;
     const int hstep = ck.pstep / pm.Wo, wstep = ck.pstep - hstep * pm.Wo;
     for (int i = ck.i0; i < ck.i1; i += NC_THREADS) {
@@ -413,8 +428,8 @@ __global__ __launch_bounds__(NC_THREADS) void nc_param_finalize_kernel(const dou
     else { coef[c] = a; coef[C + c] = -ad; coef[2 * C + c] = -ab; chan[c] = 0.f; chan[C + c] = 0.f; }
 }
 
-template <int VEC>
-__global__ __launch_bounds__(NC_THREADS) void nc_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ x, float* __restrict__ dz, int HW, int C,
+template <int VEC, typename AT = float>
+__global__ __launch_bounds__(NC_THREADS) void nc_bwd_apply_kernel(const AT* __restrict__ dout, const AT* __restrict__ x, AT* __restrict__ dz, int HW, int C,
                                                                    int per, const float* __restrict__ coef, int coef_stride, const float* __restrict__ chan,
                                                                    const float* __restrict__ mean, const float* __restrict__ rstd, NcAct act, NcPool pm) {
     const int CV = C / VEC;
@@ -429,10 +444,10 @@ __global__ __launch_bounds__(NC_THREADS) void nc_bwd_apply_kernel(const float* _
 #pragma unroll
         for (int v = 0; v < VEC; ++v) { Q.v[v] -= ad.v[v]; R.v[v] -= ab.v[v]; }
     }
-    const float* xs = x + (size_t)ck.n * HW * C; float* zs = dz + (size_t)ck.n * HW * C;
+    const AT* xs = x + (size_t)ck.n * HW * C; AT* zs = dz + (size_t)ck.n * HW * C;
     constexpr int B = 4;                                        // vectors per thread in flight: all loads of a batch are issued before the first use
     if (pm.pk == 0) {
-        const float* ds = dout + (size_t)ck.n * HW * C;
+        const AT* ds = dout + (size_t)ck.n * HW * C;
         for (int i = ck.i0; i < ck.i1; i += B * NC_THREADS) {
             NcVec<VEC> xv[B], dv[B];
 #pragma unroll
@@ -454,7 +469,7 @@ __global__ __launch_bounds__(NC_THREADS) void nc_bwd_apply_kernel(const float* _
         return;
     }
     const int H = HW / pm.W;
-    const float* ds = dout + (size_t)ck.n * (H / pm.pk) * pm.Wo * C + ck.cv * VEC;
+    const AT* ds = dout + (size_t)ck.n * (H / pm.pk) * pm.Wo * C + ck.cv * VEC;
     int h = ck.pix / pm.W, w = ck.pix - h * pm.W;
     const int hstep = ck.pstep / pm.W, wstep = ck.pstep - hstep * pm.W;
     for (int i = ck.i0; i < ck.i1; i += B * NC_THREADS) {
@@ -559,8 +574,10 @@ size_t dcv_norm_chain_ws_bytes(const dcv_norm_chain_desc* d) {
     return nc_part_bytes(d) + nc_chan_bytes(d);
 }
 
-int dcv_norm_chain_fwd(const dcv_norm_chain_desc* d, const float* x, float* out, const double* stats, int stats_rows, int stats_rows_per_sample,
+int dcv_norm_chain_fwd(const dcv_norm_chain_desc* d, const void* xv, void* outv, const double* stats, int stats_rows, int stats_rows_per_sample,
                        void* ws, size_t ws_bytes, void* stream) {
+    const float* x = reinterpret_cast<const float*>(xv); float* out = reinterpret_cast<float*>(outv);
+    const nc_bf16* x16 = reinterpret_cast<const nc_bf16*>(xv); nc_bf16* out16 = reinterpret_cast<nc_bf16*>(outv);
     DCV_CHECK_ARG(nc_shape_ok(d) && x && out && d->bn_mean && d->bn_rstd && d->coef && ws && (stats == nullptr || stats_rows > 0));
     DCV_CHECK_ARG(d->groups == 0 || (d->gn_mean && d->gn_rstd));
     if (ws_bytes < nc_part_bytes(d) + nc_chan_bytes(d)) return DCV_ERR_WORKSPACE;
@@ -569,6 +586,7 @@ int dcv_norm_chain_fwd(const dcv_norm_chain_desc* d, const float* x, float* out,
     int bps, per; nc_split(d->hw * CV, G > 0, &bps, &per);
     const NcPool pm = nc_pool(d);
     const NcGn gn = nc_gn(d);
+    const bool io16 = d->io_dtype == DCV_DTYPE_BF16;
     float* ab = d->coef;                                          // [2][C]: the BatchNorm affine
     const double* part = stats; int rows = stats_rows, rps = stats_rows_per_sample;
     if (part == nullptr || (G > 0 && (rps <= 0 || rows != d->n * rps))) {
@@ -577,8 +595,11 @@ int dcv_norm_chain_fwd(const dcv_norm_chain_desc* d, const float* x, float* out,
         rows = d->n * bps; rps = bps;
         const dim3 sgrid((unsigned)bps, (unsigned)d->n);
         const NcBwdCtx none{};
-        if (vec == 4) hipLaunchKernelGGL((nc_sample_sums_kernel<4, false>), sgrid, dim3(NC_THREADS), 0, st, x, nullptr, d->hw, C, per, nullptr, nullptr, pm, pw, rows, none);
-        else hipLaunchKernelGGL((nc_sample_sums_kernel<1, false>), sgrid, dim3(NC_THREADS), 0, st, x, nullptr, d->hw, C, per, nullptr, nullptr, pm, pw, rows, none);
+        const nc_bf16* no16 = nullptr; const float* no32 = nullptr;
+        if (io16 && vec == 4) hipLaunchKernelGGL((nc_sample_sums_kernel<4, false, nc_bf16>), sgrid, dim3(NC_THREADS), 0, st, x16, no16, d->hw, C, per, nullptr, nullptr, pm, pw, rows, none);
+        else if (io16) hipLaunchKernelGGL((nc_sample_sums_kernel<1, false, nc_bf16>), sgrid, dim3(NC_THREADS), 0, st, x16, no16, d->hw, C, per, nullptr, nullptr, pm, pw, rows, none);
+        else if (vec == 4) hipLaunchKernelGGL((nc_sample_sums_kernel<4, false>), sgrid, dim3(NC_THREADS), 0, st, x, no32, d->hw, C, per, nullptr, nullptr, pm, pw, rows, none);
+        else hipLaunchKernelGGL((nc_sample_sums_kernel<1, false>), sgrid, dim3(NC_THREADS), 0, st, x, no32, d->hw, C, per, nullptr, nullptr, pm, pw, rows, none);
         part = pw;
     }
     if (!(nc_skip() & 2)) hipLaunchKernelGGL(nc_bn_fwd_finalize_kernel, dim3((unsigned)C), dim3(NC_THREADS), 0, st, part, rows, (double)d->n * (double)d->hw, C, d->bn_gamma, d->bn_beta,
@@ -587,13 +608,18 @@ int dcv_norm_chain_fwd(const dcv_norm_chain_desc* d, const float* x, float* out,
     if (d->pool > 0) nc_split((d->hw / (d->pool * d->pool)) * CV, true, &abps, &aper);
     const dim3 agrid((unsigned)abps, (unsigned)d->n);
     if (nc_skip() & 4) DCV_RETURN_LAUNCH();
-    if (vec == 4) hipLaunchKernelGGL((nc_apply_kernel<4>), agrid, dim3(NC_THREADS), 0, st, x, out, d->hw, C, aper, ab, part, rows, rps, gn, pm);
+    if (io16 && vec == 4) hipLaunchKernelGGL((nc_apply_kernel<4, nc_bf16>), agrid, dim3(NC_THREADS), 0, st, x16, out16, d->hw, C, aper, ab, part, rows, rps, gn, pm);
+    else if (io16) hipLaunchKernelGGL((nc_apply_kernel<1, nc_bf16>), agrid, dim3(NC_THREADS), 0, st, x16, out16, d->hw, C, aper, ab, part, rows, rps, gn, pm);
+    else if (vec == 4) hipLaunchKernelGGL((nc_apply_kernel<4>), agrid, dim3(NC_THREADS), 0, st, x, out, d->hw, C, aper, ab, part, rows, rps, gn, pm);
     else hipLaunchKernelGGL((nc_apply_kernel<1>), agrid, dim3(NC_THREADS), 0, st, x, out, d->hw, C, aper, ab, part, rows, rps, gn, pm);
     DCV_RETURN_LAUNCH();
 }
 
-int dcv_norm_chain_bwd(const dcv_norm_chain_desc* d, const float* dout, const float* x, float* dz,
+int dcv_norm_chain_bwd(const dcv_norm_chain_desc* d, const void* doutv, const void* xv, void* dzv,
                        float* d_bn_gamma, float* d_bn_beta, float* d_gn_gamma, float* d_gn_beta, void* ws, size_t ws_bytes, void* stream) {
+    const float* dout = reinterpret_cast<const float*>(doutv); const float* x = reinterpret_cast<const float*>(xv); float* dz = reinterpret_cast<float*>(dzv);
+    const nc_bf16* dout16 = reinterpret_cast<const nc_bf16*>(doutv); const nc_bf16* x16 = reinterpret_cast<const nc_bf16*>(xv); nc_bf16* dz16 = reinterpret_cast<nc_bf16*>(dzv);
+    const bool io16 = d && d->io_dtype == DCV_DTYPE_BF16;
     DCV_CHECK_ARG(nc_shape_ok(d) && dout && x && dz && d->bn_mean && d->bn_rstd && d->coef && ws);
     DCV_CHECK_ARG(d->groups == 0 || (d->gn_mean && d->gn_rstd));
     if (ws_bytes < nc_part_bytes(d) + nc_chan_bytes(d)) return DCV_ERR_WORKSPACE;
@@ -607,6 +633,8 @@ int dcv_norm_chain_bwd(const dcv_norm_chain_desc* d, const float* dout, const fl
     const dim3 sgrid((unsigned)bps, (unsigned)d->n);
     const NcBwdCtx bc{d->bn_gamma, d->bn_beta, d->bn_rstd, nc_gn(d), d->coef};
     if (nc_skip() & 1) {}
+    else if (io16 && vec == 4) hipLaunchKernelGGL((nc_sample_sums_kernel<4, true, nc_bf16>), sgrid, dim3(NC_THREADS), 0, st, x16, dout16, d->hw, C, per, d->bn_mean, d->bn_rstd, pm, part, rows, bc);
+    else if (io16) hipLaunchKernelGGL((nc_sample_sums_kernel<1, true, nc_bf16>), sgrid, dim3(NC_THREADS), 0, st, x16, dout16, d->hw, C, per, d->bn_mean, d->bn_rstd, pm, part, rows, bc);
     else if (vec == 4) hipLaunchKernelGGL((nc_sample_sums_kernel<4, true>), sgrid, dim3(NC_THREADS), 0, st, x, dout, d->hw, C, per, d->bn_mean, d->bn_rstd, pm, part, rows, bc);
     else hipLaunchKernelGGL((nc_sample_sums_kernel<1, true>), sgrid, dim3(NC_THREADS), 0, st, x, dout, d->hw, C, per, d->bn_mean, d->bn_rstd, pm, part, rows, bc);
     if (!(nc_skip() & 2)) hipLaunchKernelGGL(nc_param_finalize_kernel, dim3((unsigned)C), dim3(NC_THREADS), 0, st, part, rows, (double)d->n * (double)d->hw, C, G > 0 ? 1 : 0, d->bn_gamma, d->bn_rstd,
@@ -614,7 +642,9 @@ int dcv_norm_chain_bwd(const dcv_norm_chain_desc* d, const float* dout, const fl
     const int cstride = G > 0 ? 3 * C : 0;
     const float* ch = chan;
     if (nc_skip() & 4) DCV_RETURN_LAUNCH();
-    if (vec == 4) hipLaunchKernelGGL((nc_bwd_apply_kernel<4>), sgrid, dim3(NC_THREADS), 0, st, dout, x, dz, d->hw, C, per, d->coef, cstride, ch, d->bn_mean, d->bn_rstd, nc_act(d->act, d->act_slope), pm);
+    if (io16 && vec == 4) hipLaunchKernelGGL((nc_bwd_apply_kernel<4, nc_bf16>), sgrid, dim3(NC_THREADS), 0, st, dout16, x16, dz16, d->hw, C, per, d->coef, cstride, ch, d->bn_mean, d->bn_rstd, nc_act(d->act, d->act_slope), pm);
+    else if (io16) hipLaunchKernelGGL((nc_bwd_apply_kernel<1, nc_bf16>), sgrid, dim3(NC_THREADS), 0, st, dout16, x16, dz16, d->hw, C, per, d->coef, cstride, ch, d->bn_mean, d->bn_rstd, nc_act(d->act, d->act_slope), pm);
+    else if (vec == 4) hipLaunchKernelGGL((nc_bwd_apply_kernel<4>), sgrid, dim3(NC_THREADS), 0, st, dout, x, dz, d->hw, C, per, d->coef, cstride, ch, d->bn_mean, d->bn_rstd, nc_act(d->act, d->act_slope), pm);
     else hipLaunchKernelGGL((nc_bwd_apply_kernel<1>), sgrid, dim3(NC_THREADS), 0, st, dout, x, dz, d->hw, C, per, d->coef, cstride, ch, d->bn_mean, d->bn_rstd, nc_act(d->act, d->act_slope), pm);
     DCV_RETURN_LAUNCH();
 }

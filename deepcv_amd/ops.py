@@ -62,7 +62,7 @@ def to_nhwc(t: torch.Tensor) -> torch.Tensor:
     """ Returns `t` with channels-last strides; uses the native transpose kernel when a real layout change is needed. """
     if _is_nhwc(t):
         return t
-    if t.dim() == 4 and t.is_contiguous():
+    if t.dim() == 4 and t.is_contiguous() and t.dtype == torch.float32:
         return nchw_to_nhwc(t)
     return t.contiguous(memory_format=_CL)   # exotic strides coming from foreign torch ops: let torch normalise them
 
@@ -129,6 +129,36 @@ def _to_bf16(t: torch.Tensor, st) -> torch.Tensor:
     return out
 
 
+def _to_f32(t: torch.Tensor, st) -> torch.Tensor:
+    """ fp32 copy of a bf16 tensor (`dcv_cast_bf16_to_f32`), same strides; fp32 tensors pass through. """
+    if t.dtype != torch.bfloat16:
+        return t
+    out = torch.empty_like(t, dtype=torch.float32)
+    nat.check(lib.dcv_cast_bf16_to_f32(t.data_ptr(), out.data_ptr(), t.numel(), st), 'dcv_cast_bf16_to_f32')
+    return out
+
+
+class _WidenFn(torch.autograd.Function):
+    """ bf16 -> fp32 at the entry of an operator without bf16 kernels; the gradient goes back as bf16 (what the producing layer's backward reads). """
+
+    @staticmethod
+    def forward(ctx, x):
+        return _to_f32(x if x.is_contiguous() or _is_nhwc(x) else x.contiguous(), nat.current_stream(x.device))
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g if g.is_contiguous() or _is_nhwc(g) else g.contiguous()
+        return _to_bf16(g, nat.current_stream(g.device))
+
+
+def _f32(x):
+    """ Activations entering an fp32-only operator: bf16 tensors (outputs of layers on the bf16 storage path) are widened, with autograd. """
+    if isinstance(x, torch.Tensor) and x.dtype == torch.bfloat16:
+        nat.require_device(x)
+        return _WidenFn.apply(x)
+    return x
+
+
 def _use_bf16_storage(d, layout) -> bool:
     return _conv_math == nat.MATH_BF16 and _bf16_storage and layout == nat.LAYOUT_NHWC and bool(lib.dcv_conv2d_bf16_supported(d, 0))
 
@@ -146,29 +176,40 @@ def _conv_fwd16_launch(d, x16, weight, bias, y, st, want_stats: bool = False):
 
 
 def _conv_bwd16_launch(ctx, d, x_saved, dz, weight, dx_needed: bool, dw, st):
-    """ Data and weight gradients of a layer whose forward ran on the bf16 storage kernels: dz is rounded to bf16 once and feeds both.  `x_saved` is the
-    bf16 input when the bf16 weight-gradient kernel serves the layer (`ctx.wgrad16`), else the fp32 one.  Returns dx (or None). """
+    """ Data and weight gradients of a layer whose forward ran on the bf16 storage kernels.  `dz` is bf16 (or fp32: rounded once, the copy feeds both
+    kernels); `x_saved` is the bf16 input when the bf16 weight-gradient kernel serves the layer (`ctx.wgrad16`), else the fp32 one; dx has the element type
+    the layer's input had (`ctx.x_dtype`).  Returns dx (or None). """
     dev = dz.device
-    dz16 = None
+    dz16 = dz if dz.dtype == torch.bfloat16 else None
     dx = None
     if dx_needed:
         dd = nat.Conv2dDesc.from_buffer_copy(d)
         dd.x_layout = nat.LAYOUT_NHWC
-        dx = torch.empty((d.n, d.cin, d.h, d.w), dtype=torch.float32, device=dev, memory_format=_CL)
+        dx = torch.empty((d.n, d.cin, d.h, d.w), dtype=ctx.x_dtype, device=dev, memory_format=_CL)
         if lib.dcv_conv2d_bf16_supported(dd, 1):
-            dz16 = _to_bf16(dz, st)
+            dz16 = _to_bf16(dz, st) if dz16 is None else dz16
             f = filters.get(weight, dd, 1, bf16=True)
-            nat.check(lib.dcv_conv2d_bf16_dgrad(dd, dz16.data_ptr(), f.data_ptr(), dx.data_ptr(), nat.DTYPE_F32, st), 'dcv_conv2d_bf16_dgrad')
+            nat.check(lib.dcv_conv2d_bf16_dgrad(dd, dz16.data_ptr(), f.data_ptr(), dx.data_ptr(), nat.DTYPE_BF16 if dx.dtype == torch.bfloat16 else nat.DTYPE_F32, st),
+                      'dcv_conv2d_bf16_dgrad')
         else:
-            _conv_dgrad_launch(dd, dz, weight, dx, st)
+            dx32 = dx if dx.dtype == torch.float32 else torch.empty_like(dx, dtype=torch.float32)
+            _conv_dgrad_launch(dd, _to_f32(dz, st), weight, dx32, st)
+            dx = dx32 if dx32 is dx else _to_bf16(dx32, st)
     if dw is not None:
         if ctx.wgrad16:
             dz16 = _to_bf16(dz, st) if dz16 is None else dz16
             ws = _ws(lib.dcv_conv2d_bf16_wgrad_workspace_bytes(d), dev)
             nat.check(lib.dcv_conv2d_bf16_wgrad(d, x_saved.data_ptr(), dz16.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), st), 'dcv_conv2d_bf16_wgrad')
         else:
-            _conv_wgrad_launch(d, x_saved, dz, ctx.weight_ref, ctx.bias_ref, dw, None, st)
+            _conv_wgrad_launch(d, x_saved, _to_f32(dz, st), ctx.weight_ref, ctx.bias_ref, dw, None, st)
     return dx
+
+
+def _channel_sum(t: torch.Tensor, out: torch.Tensor, rows: int, c: int, st):
+    """ out[c] = sum over rows of t[rows][c] (fp32 or bf16 rows): the convolution bias gradient. """
+    ws = _ws(lib.dcv_act_bwd_workspace_bytes(rows, c), t.device)
+    fn, name = (lib.dcv_channel_sum_bf16, 'dcv_channel_sum_bf16') if t.dtype == torch.bfloat16 else (lib.dcv_channel_sum, 'dcv_channel_sum')
+    nat.check(fn(t.data_ptr(), out.data_ptr(), rows, c, ws.data_ptr(), ws.numel(), st), name)
 
 
 def _conv_desc(x_shape, w_shape, stride, padding, dilation, x_layout, act, slope) -> nat.Conv2dDesc:
@@ -290,28 +331,34 @@ def _fan_addend(slot, like_shape) -> Optional[torch.Tensor]:
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, dilation, act, slope):
-        _require_f32(x, weight, bias)
+        _require_f32(weight, bias)
+        nat.require_device(x)
+        ctx.x_dtype = x.dtype
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError(f'deepcv_amd: fp32 (or bf16) activations expected, got {x.dtype}')
         if _is_nhwc(x):
             layout = nat.LAYOUT_NHWC
-        elif x.is_contiguous():
+        elif x.is_contiguous() and x.dtype == torch.float32:
             layout = nat.LAYOUT_NCHW          # e.g. the dataloader's NCHW batch feeding the first layer: read in place, no copy
         else:
-            x, layout = to_nhwc(x), nat.LAYOUT_NHWC
+            x, layout = to_nhwc(_to_f32(x.contiguous(), nat.current_stream(x.device)) if x.dtype == torch.bfloat16 else x), nat.LAYOUT_NHWC
         ctx.weight_ref, ctx.bias_ref = weight, bias
         slabs.note_use(weight if ctx.needs_input_grad[1] else None, bias if ctx.needs_input_grad[2] else None)
         weight = weight.contiguous()
         d = _conv_desc(x.shape, weight.shape, stride, padding, dilation, layout, act, slope)
-        y = torch.empty((d.n, d.cout, d.ho, d.wo), dtype=x.dtype, device=x.device, memory_format=_CL)
+        st = nat.current_stream(x.device)
         ctx.use16 = _use_bf16_storage(d, layout)
         if ctx.use16:
-            st = nat.current_stream(x.device)
+            # bf16 storage path: bf16 in, bf16 out (consumers without bf16 kernels widen on entry: `_f32`)
+            y = torch.empty((d.n, d.cout, d.ho, d.wo), dtype=torch.bfloat16, device=x.device, memory_format=_CL)
             x16 = _to_bf16(x, st)
             _conv_fwd16_launch(d, x16, weight, bias, y, st)
             ctx.wgrad16 = bool(lib.dcv_conv2d_bf16_supported(d, 2))
-            if ctx.wgrad16:
-                x = x16                       # the weight gradient reads the bf16 copy: half the saved bytes
+            x = x16 if ctx.wgrad16 else _to_f32(x, st)      # the weight gradient reads the bf16 copy (half the saved bytes) where its bf16 kernel serves the layer
         else:
-            _conv_fwd_launch(d, x, weight, bias, y, nat.current_stream(x.device))
+            x = _to_f32(x, st)
+            y = torch.empty((d.n, d.cout, d.ho, d.wo), dtype=torch.float32, device=x.device, memory_format=_CL)
+            _conv_fwd_launch(d, x, weight, bias, y, st)
         ctx.desc, ctx.has_bias = d, bias is not None
         ctx.save_for_backward(x, weight, y if act != nat.ACT_NONE else None)
         return y
@@ -327,10 +374,11 @@ class _Conv2dFn(torch.autograd.Function):
         db = _grad_buffer(ctx.bias_ref, n=d.cout, device=dev) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         db_done = False
         if d.act != nat.ACT_NONE:
-            # dz = dy * act'(y), fused with the bias-gradient reduction
-            dz = torch.empty_like(dy)
+            # dz = dy * act'(y), fused with the bias-gradient reduction (fp32 kernel: bf16 tensors are widened for it)
+            dy32, y32 = _to_f32(dy, st), _to_f32(y, st)
+            dz = torch.empty_like(dy32)
             ws = _ws(lib.dcv_act_bwd_workspace_bytes(rows, d.cout), dev)
-            nat.check(lib.dcv_act_bwd(dy.data_ptr(), y.data_ptr(), dz.data_ptr(), rows, d.cout, d.act, d.act_slope, nat.ptr(db),
+            nat.check(lib.dcv_act_bwd(dy32.data_ptr(), y32.data_ptr(), dz.data_ptr(), rows, d.cout, d.act, d.act_slope, nat.ptr(db),
                                       ws.data_ptr(), ws.numel(), st), 'dcv_act_bwd')
             db_done = True
         else:
@@ -338,16 +386,18 @@ class _Conv2dFn(torch.autograd.Function):
         dx = dw = None
         if ctx.use16:
             if db is not None and not db_done:
-                wsb = _ws(lib.dcv_act_bwd_workspace_bytes(rows, d.cout), dev)
-                nat.check(lib.dcv_channel_sum(dz.data_ptr(), db.data_ptr(), rows, d.cout, wsb.data_ptr(), wsb.numel(), st), 'dcv_channel_sum')
+                _channel_sum(dz, db, rows, d.cout, st)
             dw = _grad_buffer(ctx.weight_ref, like=weight) if ctx.needs_input_grad[1] else None
             dx = _conv_bwd16_launch(ctx, d, x, dz, weight, ctx.needs_input_grad[0], dw, st)
             return dx, dw, db, None, None, None, None, None
+        dz = _to_f32(dz, st)
         if ctx.needs_input_grad[0]:
             dd = nat.Conv2dDesc.from_buffer_copy(d)
             dd.x_layout = nat.LAYOUT_NHWC
-            dx = torch.empty((d.n, d.cin, d.h, d.w), dtype=dy.dtype, device=dev, memory_format=_CL)
+            dx = torch.empty((d.n, d.cin, d.h, d.w), dtype=torch.float32, device=dev, memory_format=_CL)
             _conv_dgrad_launch(dd, dz, weight, dx, st)
+            if ctx.x_dtype == torch.bfloat16:
+                dx = _to_bf16(dx, st)
         if ctx.needs_input_grad[1] or (db is not None and not db_done):
             dw = _grad_buffer(ctx.weight_ref, like=weight)
             _conv_wgrad_launch(d, x, dz, ctx.weight_ref, ctx.bias_ref, dw, None if db_done else db, st)
@@ -393,6 +443,7 @@ class _ActFn(torch.autograd.Function):
 
 
 def activation(x: torch.Tensor, act: int, slope: float = 0.) -> torch.Tensor:
+    x = _f32(x)
     if act == nat.ACT_NONE:
         return x
     return _ActFn.apply(x, int(act), float(slope))
@@ -445,6 +496,7 @@ class _BatchNormTrainFn(torch.autograd.Function):
 def batch_norm(x, gamma, beta, running_mean, running_var, num_batches_tracked, training: bool, momentum: float, eps: float) -> torch.Tensor:
     """ BatchNorm over all dims but the channel dim (dim 1).  Training: batch statistics + running-stat EMA (`dcv_batchnorm_fwd_train`);
     inference: running statistics (`dcv_batchnorm_fwd_eval`, not differentiable w.r.t. its input in this build). """
+    x = _f32(x)
     use_batch_stats = training or running_mean is None
     if use_batch_stats:
         return _BatchNormTrainFn.apply(x, gamma, beta, running_mean if training else None, running_var if training else None,
@@ -514,7 +566,7 @@ def sync_batch_norm(x, gamma, beta, running_mean, running_var, num_batches_track
                     all_reduce=_dist_all_reduce_sum) -> torch.Tensor:
     """ Training-mode BatchNorm whose batch statistics span every rank of `group`.  `all_reduce(tensor, group)` sums a small fp64 tensor in place
     over the ranks (injectable for tests). """
-    return _SyncBatchNormFn.apply(x, gamma, beta, running_mean, running_var, num_batches_tracked, float(momentum), float(eps), group, all_reduce)
+    return _SyncBatchNormFn.apply(_f32(x), gamma, beta, running_mean, running_var, num_batches_tracked, float(momentum), float(eps), group, all_reduce)
 
 
 # ------------------------------------------------------------------------------------------------ group norm
@@ -554,6 +606,7 @@ class _GroupNormFn(torch.autograd.Function):
 
 
 def group_norm(x, gamma, beta, groups: int, eps: float) -> torch.Tensor:
+    x = _f32(x)
     return _GroupNormFn.apply(x, gamma, beta, int(groups), float(eps))
 
 
@@ -585,31 +638,23 @@ class _ConvNormLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, bn_w, bn_b, running_mean, running_var, nbt, gn_w, gn_b, cfg):
         stride, padding, dilation, act, slope, momentum, bn_eps, groups, gn_eps, pool = cfg
-        _require_f32(x, weight, bias, bn_w, bn_b, running_mean, running_var, gn_w, gn_b)
+        _require_f32(weight, bias, bn_w, bn_b, running_mean, running_var, gn_w, gn_b)
+        nat.require_device(x)
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError(f'deepcv_amd: fp32 (or bf16) activations expected, got {x.dtype}')
+        ctx.x_dtype = x.dtype
+        dev, st = x.device, nat.current_stream(x.device)
         if _is_nhwc(x):
             layout = nat.LAYOUT_NHWC
-        elif x.is_contiguous():
+        elif x.is_contiguous() and x.dtype == torch.float32:
             layout = nat.LAYOUT_NCHW
         else:
-            x, layout = to_nhwc(x), nat.LAYOUT_NHWC
+            x, layout = to_nhwc(_to_f32(x.contiguous(), st) if x.dtype == torch.bfloat16 else x), nat.LAYOUT_NHWC
         ctx.weight_ref, ctx.bias_ref, ctx.norm_refs = weight, bias, (bn_w, bn_b, gn_w, gn_b)
         ctx.fan_slot = getattr(x, '_dcv_fan_slot', None)          # x is also referenced by a later link: its gradient may ride in our data gradient
         slabs.note_use(weight if ctx.needs_input_grad[1] else None, bias if ctx.needs_input_grad[2] else None)
         weight = weight.contiguous()
         d = _conv_desc(x.shape, weight.shape, stride, padding, dilation, layout, act, slope)
-        dev, st = x.device, nat.current_stream(x.device)
-        y = torch.empty((d.n, d.cout, d.ho, d.wo), dtype=x.dtype, device=dev, memory_format=_CL)
-        ctx.use16 = _use_bf16_storage(d, layout)
-        if ctx.use16:
-            x16 = _to_bf16(x, st)
-            stats, rows16, rps16 = _conv_fwd16_launch(d, x16, weight, bias, y, st, want_stats=True)
-            ctx.wgrad16 = bool(lib.dcv_conv2d_bf16_supported(d, 2))
-            if ctx.wgrad16:
-                x = x16
-        else:
-            stats = _conv_fwd_launch(d, x, weight, bias, y, st, want_stats=True)
-        # `pool` > 0: the layer is followed by a non-overlapping average pooling, applied by the same kernel (only the pooled tensor is written)
-        out = torch.empty_like(y) if not pool else torch.empty((d.n, d.cout, d.ho // pool, d.wo // pool), dtype=x.dtype, device=dev, memory_format=_CL)
         c, hw = d.cout, d.ho * d.wo
         bn_mean = torch.empty(c, dtype=torch.float32, device=dev)
         bn_rstd = torch.empty(c, dtype=torch.float32, device=dev)
@@ -617,6 +662,21 @@ class _ConvNormLayerFn(torch.autograd.Function):
         gn_rstd = torch.empty(d.n * groups, dtype=torch.float32, device=dev) if groups else None
         nc = _norm_chain_desc(d, cfg, bn_w, bn_b, running_mean, running_var, nbt, bn_mean, bn_rstd, gn_w, gn_b, gn_mean, gn_rstd)
         ctx.streaming = _norm_streaming and bool(lib.dcv_norm_chain_supported(nc))
+        ctx.use16 = _use_bf16_storage(d, layout)
+        # bf16 storage path: the convolution output, the layer output and (backward) their gradients are bf16 tensors when the streaming chain serves the layer
+        ctx.io16 = ctx.use16 and ctx.streaming
+        adt = torch.bfloat16 if ctx.io16 else torch.float32
+        y = torch.empty((d.n, d.cout, d.ho, d.wo), dtype=adt, device=dev, memory_format=_CL)
+        if ctx.use16:
+            x16 = _to_bf16(x, st)
+            stats, rows16, rps16 = _conv_fwd16_launch(d, x16, weight, bias, y, st, want_stats=True)
+            ctx.wgrad16 = bool(lib.dcv_conv2d_bf16_supported(d, 2))
+            x = x16 if ctx.wgrad16 else _to_f32(x, st)
+        else:
+            x = _to_f32(x, st)
+            stats = _conv_fwd_launch(d, x, weight, bias, y, st, want_stats=True)
+        # `pool` > 0: the layer is followed by a non-overlapping average pooling, applied by the same kernel (only the pooled tensor is written)
+        out = torch.empty_like(y) if not pool else torch.empty((d.n, d.cout, d.ho // pool, d.wo // pool), dtype=adt, device=dev, memory_format=_CL)
         if ctx.streaming:
             rows, rps = ctypes.c_int(0), ctypes.c_int(0)
             if stats is not None and ctx.use16:
@@ -625,6 +685,7 @@ class _ConvNormLayerFn(torch.autograd.Function):
                 nat.check(lib.dcv_conv2d_fwd_stats_layout(d, ctypes.byref(rows), ctypes.byref(rps)), 'dcv_conv2d_fwd_stats_layout')
             coef = torch.empty(int(lib.dcv_norm_chain_coef_floats(nc)), dtype=torch.float32, device=dev)
             nc.coef = coef.data_ptr()
+            nc.io_dtype = nat.DTYPE_BF16 if ctx.io16 else nat.DTYPE_F32
             ws = _ws(lib.dcv_norm_chain_ws_bytes(nc), dev)
             nat.check(lib.dcv_norm_chain_fwd(nc, y.data_ptr(), out.data_ptr(), nat.ptr(stats), rows.value, rps.value, ws.data_ptr(), ws.numel(), st), 'dcv_norm_chain_fwd')
         else:
@@ -644,6 +705,7 @@ class _ConvNormLayerFn(torch.autograd.Function):
         stride, padding, dilation, act, slope, momentum, bn_eps, groups, gn_eps, pool = ctx.cfg
         dev, st = dout.device, nat.current_stream(dout.device)
         dout = to_nhwc(dout)
+        dout = _to_bf16(dout, st) if ctx.io16 else _to_f32(dout, st)      # (autograd hands over the output's element type: no-ops)
         c, hw = d.cout, d.ho * d.wo
         new = lambda ref: _grad_buffer(ref, n=c, device=dev)
         need = ctx.needs_input_grad
@@ -659,12 +721,12 @@ class _ConvNormLayerFn(torch.autograd.Function):
             nc = _norm_chain_desc(d, ctx.cfg, bn_w, bn_b, None, None, None, bn_mean, bn_rstd, gn_w, None, gn_mean, gn_rstd)
             coef = torch.empty(int(lib.dcv_norm_chain_coef_floats(nc)), dtype=torch.float32, device=dev)
             nc.coef = coef.data_ptr()
+            nc.io_dtype = nat.DTYPE_BF16 if ctx.io16 else nat.DTYPE_F32
             ws = _ws(lib.dcv_norm_chain_ws_bytes(nc), dev)
             nat.check(lib.dcv_norm_chain_bwd(nc, dout.data_ptr(), y.data_ptr(), dz.data_ptr(), nat.ptr(d_bn_w), nat.ptr(d_bn_b), nat.ptr(d_gn_w), nat.ptr(d_gn_b),
                                              ws.data_ptr(), ws.numel(), st), 'dcv_norm_chain_bwd')
             if db is not None and not db_from_wgrad:
-                wsb = _ws(lib.dcv_act_bwd_workspace_bytes(d.n * hw, c), dev)
-                nat.check(lib.dcv_channel_sum(dz.data_ptr(), db.data_ptr(), d.n * hw, c, wsb.data_ptr(), wsb.numel(), st), 'dcv_channel_sum')
+                _channel_sum(dz, db, d.n * hw, c, st)
         else:
             ws = _ws(lib.dcv_norm_chain_workspace_bytes(d.n, hw, c), dev)
             nat.check(lib.dcv_bn_gn_pool_act_bwd(dout.data_ptr(), y.data_ptr(), dz.data_ptr(), d.n, hw, c, nat.ptr(bn_w), nat.ptr(bn_b), bn_mean.data_ptr(), bn_rstd.data_ptr(),
@@ -680,9 +742,11 @@ class _ConvNormLayerFn(torch.autograd.Function):
             dd = nat.Conv2dDesc.from_buffer_copy(d)
             dd.x_layout = nat.LAYOUT_NHWC
             dx = torch.empty((d.n, d.cin, d.h, d.w), dtype=dz.dtype, device=dev, memory_format=_CL)
-            addend = _fan_addend(ctx.fan_slot, dx.shape)
+            addend = _fan_addend(ctx.fan_slot, dx.shape) if ctx.x_dtype == torch.float32 else None
             if _conv_dgrad_launch(dd, dz, weight, dx, st, addend):
                 ctx.fan_slot.consumed = True
+            if ctx.x_dtype == torch.bfloat16:
+                dx = _to_bf16(dx, st)
         if need[1]:
             dw = _grad_buffer(ctx.weight_ref, like=weight)
             _conv_wgrad_launch(d, x, dz, ctx.weight_ref, ctx.bias_ref, dw, db if db_from_wgrad else None, st)
@@ -731,6 +795,7 @@ class _Pool2dFn(torch.autograd.Function):
 
 
 def pool2d(x: torch.Tensor, kernel_size, stride=None, padding=0, mode: int = nat.POOL_AVG) -> torch.Tensor:
+    x = _f32(x)
     k = _pair(kernel_size)
     s = _pair(stride) if stride is not None else k
     return _Pool2dFn.apply(x, k, s, _pair(padding), int(mode))
@@ -760,6 +825,7 @@ class _InterpFn(torch.autograd.Function):
 
 
 def interpolate_bilinear(x: torch.Tensor, out_hw: Sequence[int], align_corners: bool = False) -> torch.Tensor:
+    x = _f32(x)
     return _InterpFn.apply(x, (int(out_hw[0]), int(out_hw[1])), bool(align_corners))
 
 
@@ -845,6 +911,7 @@ class _ResizeConcatFn(torch.autograd.Function):
 def resize_concat(tensors: Sequence[torch.Tensor], align_corners: bool = False) -> torch.Tensor:
     """ Channel concatenation of 4-D tensors at the spatial size of the first one; the others are resized bilinearly (as `interpolate_bilinear`) in the
     same launch. """
+    tensors = [_f32(t) for t in tensors]
     tensors = list(tensors)
     if len(tensors) == 1:
         return tensors[0]
@@ -852,6 +919,7 @@ def resize_concat(tensors: Sequence[torch.Tensor], align_corners: bool = False) 
 
 
 def concat_channels(tensors: Sequence[torch.Tensor]) -> torch.Tensor:
+    tensors = [_f32(t) for t in tensors]
     tensors = list(tensors)
     return tensors[0] if len(tensors) == 1 else _ConcatFn.apply(*tensors)
 
@@ -888,6 +956,7 @@ class _AddFn(torch.autograd.Function):
 
 def add_tensors(tensors: Sequence[torch.Tensor], mean: bool = False) -> torch.Tensor:
     """ Elementwise sum (or mean) of same-shape tensors: the 'sum' / 'mean' link reductions (SURVEY Appendix A #14). """
+    tensors = [_f32(t) for t in tensors]
     tensors = list(tensors)
     if len(tensors) == 1:
         return tensors[0]
@@ -923,6 +992,7 @@ class _FlattenFn(torch.autograd.Function):
 def flatten_nchw_order(x: torch.Tensor) -> torch.Tensor:
     """ `[N,C,H,W]` (NHWC memory) -> `[N, C*H*W]` in the reference's C-major feature order (what `torch.nn.Flatten` yields on NCHW data),
     so that the stored FC weight keeps the reference layout. """
+    x = _f32(x)
     if x.dim() == 2:
         return x
     if x.dim() != 4:
@@ -1024,12 +1094,14 @@ class _LinearNhwcFn(torch.autograd.Function):
 
 def linear_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = nat.ACT_NONE, slope: float = 0.) -> torch.Tensor:
     """ `linear(torch.flatten(x, 1), weight, bias)` for `[N,C,H,W]` activations with channels_last strides (see `_LinearNhwcFn`). """
+    x = _f32(x)
     if x.dim() != 4 or weight.shape[1] != x.shape[1] * x.shape[2] * x.shape[3]:
         raise ValueError(f'deepcv_amd.linear_nhwc: weight {tuple(weight.shape)} does not match activations {tuple(x.shape)}')
     return _LinearNhwcFn.apply(to_nhwc(x), weight, bias, act, slope)
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = nat.ACT_NONE, slope: float = 0.) -> torch.Tensor:
+    x = _f32(x)
     if x.dim() != 2:
         x = x.reshape(-1, x.shape[-1]) if x.dim() > 2 else x.unsqueeze(0)
     return _LinearFn.apply(x, weight, bias, int(act), float(slope))
@@ -1090,4 +1162,4 @@ class _CrossEntropyFn(torch.autograd.Function):
 def cross_entropy(logits: torch.Tensor, target: torch.Tensor, correct_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """ Mean softmax cross-entropy over the batch (`torch.nn.CrossEntropyLoss()` defaults).  If `correct_out` (int32[1], device) is given,
     the kernel also writes the number of samples whose arg-max equals the target (accuracy numerator). """
-    return _CrossEntropyFn.apply(logits, target, correct_out)
+    return _CrossEntropyFn.apply(_f32(logits), target, correct_out)

@@ -186,6 +186,7 @@ int dcv_act_bwd(const float* dy, const float* y, float* dx, size_t rows, int cha
 /* out[c] = sum over rows of x[rows][channels] (ordered two-stage reduction; ws of dcv_act_bwd_workspace_bytes) — the bias
  * gradient of a conv / linear layer without fused activation. */
 int dcv_channel_sum(const float* x, float* out, size_t rows, int channels, void* ws, size_t ws_bytes, void* stream);
+int dcv_channel_sum_bf16(const void* x_bf16, float* out, size_t rows, int channels, void* ws, size_t ws_bytes, void* stream);   /* bf16 rows, fp32 sums */
 
 /* ---------------------------------------------------------------------------------------------------
  * K5  BatchNorm (training + inference), NHWC view [rows = N*H*W][C]
@@ -300,13 +301,14 @@ typedef struct dcv_norm_chain_desc {
     float* gn_mean; float* gn_rstd;                        /* [n][groups]: written by the forward, read by the backward */
     float* coef;                                           /* dcv_norm_chain_coef_floats(d) floats */
     int act; float act_slope;                              /* activation which produced x (its derivative is taken from x) */
+    int io_dtype;                                          /* element type of x / out / dout / dz: DCV_DTYPE_F32 (0, default) or DCV_DTYPE_BF16 (bf16 storage path) */
 } dcv_norm_chain_desc;
 int dcv_norm_chain_supported(const dcv_norm_chain_desc* d);
 size_t dcv_norm_chain_coef_floats(const dcv_norm_chain_desc* d);
 size_t dcv_norm_chain_ws_bytes(const dcv_norm_chain_desc* d);
-int dcv_norm_chain_fwd(const dcv_norm_chain_desc* d, const float* x, float* out, const double* stats, int stats_rows, int stats_rows_per_sample,
+int dcv_norm_chain_fwd(const dcv_norm_chain_desc* d, const void* x, void* out, const double* stats, int stats_rows, int stats_rows_per_sample,
                        void* ws, size_t ws_bytes, void* stream);
-int dcv_norm_chain_bwd(const dcv_norm_chain_desc* d, const float* dout, const float* x, float* dz,
+int dcv_norm_chain_bwd(const dcv_norm_chain_desc* d, const void* dout, const void* x, void* dz,
                        float* d_bn_gamma, float* d_bn_beta, float* d_gn_gamma, float* d_gn_beta /* all nullable */, void* ws, size_t ws_bytes, void* stream);
 
 

@@ -145,3 +145,52 @@ def test_bf16_data_and_weight_gradients(device, case):
         torch.cuda.synchronize()
         err = _rel(dw, wr2.grad)
         assert err <= 2e-5, f'weight gradient error {err:.3e}'
+
+
+@pytest.mark.parametrize('groups,pool', [(0, 0), (4, 0), (4, 2)], ids=['bn', 'bn_gn', 'bn_gn_pool'])
+def test_fused_layer_with_bf16_activations(device, groups, pool):
+    """ `ops.conv_norm_layer` on the bf16 storage path (bf16 x, conv output, layer output and their gradients; fp32 statistics and parameters) against a
+    double-precision torch graph fed the same bf16-rounded x and filter: the output within two bf16 roundings (conv output and layer output: 8e-3 of its range),
+    gradients within 2e-2 of theirs (dout, dz and dx are rounded to bf16 on the way). """
+    from deepcv_amd import ops
+    n, cin, h, cout = 8, 64, 16, 64
+    torch.manual_seed(5 + groups + pool)
+    x = _bf(torch.randn(n, cin, h, h)).float()
+    wt = _bf(torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5).float()
+    b = torch.randn(cout) * 0.1
+    bn_w, bn_b = torch.rand(cout) + 0.5, torch.randn(cout) * 0.1
+    gn_w, gn_b = (torch.rand(cout) + 0.5, torch.randn(cout) * 0.1) if groups else (None, None)
+    dout = _bf(torch.randn(n, cout, h // (pool or 1), h // (pool or 1))).float()
+
+    ref_in = [t.double().requires_grad_(True) for t in (x, wt, b, bn_w, bn_b)] + ([t.double().requires_grad_(True) for t in (gn_w, gn_b)] if groups else [])
+    z = torch.tanh(F.conv2d(ref_in[0], ref_in[1], ref_in[2], 1, 1))
+    o = F.batch_norm(z, None, None, ref_in[3], ref_in[4], True, 0.1, 1e-5)
+    if groups:
+        o = F.group_norm(o, groups, ref_in[5], ref_in[6], 1e-5)
+    if pool:
+        o = F.avg_pool2d(o, pool)
+    o.backward(dout.double())
+
+    dev_in = [t.to(device).requires_grad_(True) for t in (x, wt, b, bn_w, bn_b)] + ([t.to(device).requires_grad_(True) for t in (gn_w, gn_b)] if groups else [None, None])
+    xd = dev_in[0].to(torch.bfloat16).contiguous(memory_format=torch.channels_last)      # a bf16 activation, as a preceding bf16 layer hands it over
+    rm, rv, nbt = torch.zeros(cout, device=device), torch.ones(cout, device=device), torch.zeros(1, dtype=torch.int64, device=device)
+    prev, prev_st = ops.set_conv_math('bf16'), ops.set_bf16_storage(True)
+    try:
+        out = ops.conv_norm_layer(xd, dev_in[1], dev_in[2], 1, 1, 1, 4, 0., dev_in[3], dev_in[4], rm, rv, nbt, 0.1, 1e-5, groups, dev_in[5], dev_in[6], 1e-5, pool)
+        assert out.dtype == torch.bfloat16
+        out.backward(dout.to(device).to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
+    finally:
+        ops.set_conv_math(prev)
+        ops.set_bf16_storage(prev_st)
+    torch.cuda.synchronize()
+    assert _rel(out.float(), o.detach()) <= 8e-3
+    names = ['x', 'weight', 'bias', 'bn_weight', 'bn_bias', 'gn_weight', 'gn_bias']
+    for k, r in enumerate(ref_in):
+        got = dev_in[k].grad
+        if k in (2,) or (k in (3, 4) and groups):
+            # gauge directions (bias before BatchNorm behind tanh is not one, but BatchNorm's affine pair followed by per-channel GroupNorm is): absolute scale
+            scale = max(ri.grad.abs().max().item() for ri in ref_in[1:])
+            assert (got.double().cpu() - r.grad).abs().max().item() <= 2e-2 * scale, names[k]
+        else:
+            assert _rel(got, r.grad) <= 2e-2, f'{names[k]}: {_rel(got, r.grad):.3e}'
+    assert (nbt.item() == 1) and _rel(rm, 0.1 * z.detach().mean(dim=(0, 2, 3))) <= 1e-2

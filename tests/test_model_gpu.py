@@ -238,8 +238,11 @@ def test_wide_models_bf16_math_track_fp32(device, params, spec, nc, shape, n, st
         ops.set_bf16_storage(prev_st)
     errs = _grad_rel_errors(native, oracle)
     _report(f'{spec}[bf16 math, storage={storage}, tanh twin]: logits rel err {e_logits:.3e}, loss rel err {e_loss:.3e}, worst grad rel err {max(errs.values()):.3e}')
-    assert 1e-5 < e_logits <= 3e-2 and e_loss <= 1e-2          # > 1e-5: the bf16 kernels really ran
-    assert max(errs.values()) <= 0.15
+    # > 1e-5: the bf16 kernels really ran.  With bf16 STORAGE every layer output (and its gradient) is additionally rounded to 8 significant bits, 18 layers deep
+    # on `resnet18_style`: the bounds are those of bf16 training, the kernels themselves are held to tight bounds in tests/test_bf16_gpu.py
+    tol_logits, tol_grad = (1e-1, 0.3) if storage else (3e-2, 0.15)
+    assert 1e-5 < e_logits <= tol_logits and e_loss <= 1e-2
+    assert max(errs.values()) <= tol_grad
 
 
 def test_eval_mode_and_accuracy(device, params):
