@@ -16,6 +16,7 @@ Rank 0 prints ONE JSON line.  Besides the whole-job throughput it carries
   * `secondary` (N = 1): the wide-channel MFMA convolution kernels (fwd / dgrad / wgrad, fraction of the 157.3 TFLOP/s fp32 matrix peak) and the
     whole-step throughput of the two build-authored wide specs (BASELINE.json configs 3 / 5) — reported beside the headline, never instead of it. """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -202,7 +203,50 @@ def secondary_measurements(device, params, launches: int = 20):
                             'avg_launch_us': round(us, 1), 'achieved': round(tf, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(tf / peak, 4),
                             'note': 'dcv_conv2d_%s incl. its filter re-layout / split-K reduction launches' % op})
         del x, dy, y, dx
+    out.extend(_bf16_storage_kernels(device, launches))
     out.extend(_wide_model_steps(device, params))
+    return out
+
+
+def _bf16_storage_kernels(device, launches: int):
+    """ The bf16 STORAGE convolution kernels (BASELINE configs 3 / 5: bf16 activations and prepared filters in HBM and LDS, v_mfma_f32_16x16x32_bf16, fp32
+    accumulation) through their C-ABI entry points `dcv_conv2d_bf16_fwd / _dgrad / _wgrad`; filters prepared once outside the timed launches, as in the
+    training step (one re-layout launch per optimizer step).  Fraction of the 2.5 PFLOP/s dense bf16 MFMA peak. """
+    from deepcv_amd import _native as nat
+    lib, st, cl, out = nat.lib, nat.current_stream(device), torch.channels_last, []
+    for cin, hw in ((64, 32), (128, 16), (256, 16), (512, 8)):
+        n = BATCH_PER_GPU
+        d = nat.Conv2dDesc(n, hw, hw, cin, cin, 3, 3, 1, 1, 1, 1, 1, 1, 1, hw, hw, nat.LAYOUT_NHWC, nat.ACT_RELU, 0., nat.MATH_BF16)
+        if not lib.dcv_conv2d_bf16_supported(d, 0):
+            continue
+        x = torch.randn(n, cin, hw, hw, device=device).to(torch.bfloat16).contiguous(memory_format=cl)
+        dy = torch.randn(n, cin, hw, hw, device=device).to(torch.bfloat16).contiguous(memory_format=cl)
+        y, dx = torch.empty_like(x), torch.empty_like(x)
+        wt = torch.randn(cin, cin, 3, 3, device=device) * 0.05
+        b, dw = torch.zeros(cin, device=device), torch.empty_like(wt)
+        flops = 2.0 * n * hw * hw * cin * cin * 9
+        filt = []
+        for op in (0, 1):
+            f = torch.empty(int(lib.dcv_conv2d_bf16_filter_bytes(d, op)), dtype=torch.uint8, device=device)
+            nat.check(lib.dcv_conv2d_bf16_prepare_filters(1, (ctypes.POINTER(nat.Conv2dDesc) * 1)(ctypes.pointer(d)), (ctypes.c_int * 1)(op),
+                                                          (ctypes.c_void_p * 1)(wt.data_ptr()), (ctypes.c_void_p * 1)(f.data_ptr()), st), 'dcv_conv2d_bf16_prepare_filters')
+            filt.append(f)
+        rows, rps = ctypes.c_int(0), ctypes.c_int(0)
+        nat.check(lib.dcv_conv2d_bf16_fwd_stats_layout(d, ctypes.byref(rows), ctypes.byref(rps)), 'dcv_conv2d_bf16_fwd_stats_layout')
+        stats = torch.empty((2, cin, max(1, rows.value)), dtype=torch.float64, device=device)
+        runs = {'fwd': lambda: nat.check(lib.dcv_conv2d_bf16_fwd(d, x.data_ptr(), filt[0].data_ptr(), b.data_ptr(), y.data_ptr(), nat.DTYPE_BF16, stats.data_ptr(), st), 'dcv_conv2d_bf16_fwd'),
+                'dgrad': lambda: nat.check(lib.dcv_conv2d_bf16_dgrad(d, dy.data_ptr(), filt[1].data_ptr(), dx.data_ptr(), nat.DTYPE_BF16, st), 'dcv_conv2d_bf16_dgrad')}
+        if lib.dcv_conv2d_bf16_supported(d, 2):
+            ws = torch.empty(int(lib.dcv_conv2d_bf16_wgrad_workspace_bytes(d)), dtype=torch.uint8, device=device)
+            runs['wgrad'] = lambda: nat.check(lib.dcv_conv2d_bf16_wgrad(d, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), st), 'dcv_conv2d_bf16_wgrad')
+        for op, fn in runs.items():
+            us = _time_launches(fn, launches)
+            tf = flops / us / 1e6
+            out.append({'kind': 'kernel', 'op': f'conv3x3 {cin}->{cin} @{hw}x{hw} N={n} {op}', 'math': 'bf16-storage', 'avg_launch_us': round(us, 1), 'achieved': round(tf, 1),
+                        'peak': MFMA_BF16_PEAK_TF, 'unit': 'TFLOP/s', 'frac': round(tf / MFMA_BF16_PEAK_TF, 4),
+                        'note': 'dcv_conv2d_bf16_%s: bf16 tensors in HBM / LDS, fp32 accumulate%s' % (op, ' (statistics epilogue on)' if op == 'fwd' else
+                                                                                                   ' incl. the ordered slab sum' if op == 'wgrad' else '')})
+        del x, dy, y, dx
     return out
 
 
@@ -236,7 +280,7 @@ def _wide_model_steps(device, params):
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
                 res.append({'kind': 'model', 'workload': f'{spec} {shape[0]}x{shape[1]}x{shape[2]} bs={bs}: fwd + CE + bwd + SGD-momentum, eager launches, per-step loss read-back',
-                            'math': 'f32' if math == 'fp32' else 'bf16-operands (fp32 accumulate / storage / master weights)',
+                            'math': 'f32' if math == 'fp32' else 'bf16-storage (bf16 activations / gradients / prepared filters in HBM, fp32 accumulate, statistics and master weights)',
                             'value': round(bs * k / dt, 1), 'unit': 'images/sec', 'ms_per_step': round(dt / k * 1e3, 3), 'final_loss': round(last, 4)})
                 del model, opt, step, batches
             finally:

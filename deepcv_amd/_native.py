@@ -13,7 +13,7 @@ from typing import Optional
 
 import torch
 
-__all__ = ['lib', 'load', 'is_available', 'check', 'current_stream', 'Conv2dDesc', 'SlabSegment', 'WgradJob', 'Pool2dDesc', 'TensorList', 'NormChainDesc', 'LIB_PATH', 'build',
+__all__ = ['lib', 'load', 'is_available', 'check', 'current_stream', 'Conv2dDesc', 'SlabSegment', 'WgradJob', 'Pool2dDesc', 'TensorList', 'NormChainDesc', 'ResidentOp', 'ResidentProgram', 'LIB_PATH', 'build',
            'ACT_NONE', 'ACT_RELU', 'ACT_LEAKY_RELU', 'ACT_SIGMOID', 'ACT_TANH', 'POOL_AVG', 'POOL_MAX', 'LAYOUT_NHWC', 'LAYOUT_NCHW',
            'MAX_TENSORS', 'HYP_COUNT', 'HYP']
 
@@ -67,6 +67,25 @@ class NormChainDesc(ctypes.Structure):
                 ('momentum', _c_float), ('bn_eps', _c_float), ('bn_mean', _c_void_p), ('bn_rstd', _c_void_p),
                 ('groups', _c_int), ('gn_gamma', _c_void_p), ('gn_beta', _c_void_p), ('gn_eps', _c_float), ('gn_mean', _c_void_p), ('gn_rstd', _c_void_p),
                 ('coef', _c_void_p), ('act', _c_int), ('act_slope', _c_float), ('io_dtype', _c_int)]
+
+
+RESIDENT_MAX_OPS = 10
+RES_LAYER, RES_LINK, RES_FC = 1, 2, 3
+
+
+class ResidentOp(ctypes.Structure):
+    """ `dcv_resident_op` """
+    _fields_ = [('kind', _c_int), ('cin', _c_int), ('cout', _c_int), ('k', _c_int), ('h', _c_int), ('w', _c_int), ('act', _c_int), ('slope', _c_float),
+                ('bn', _c_int), ('groups', _c_int), ('pool', _c_int), ('momentum', _c_float), ('bn_eps', _c_float), ('gn_eps', _c_float), ('x_nchw', _c_int),
+                ('ref_c', _c_int), ('ref_h', _c_int), ('ref_w', _c_int), ('align_corners', _c_int),
+                ('x', _c_void_p), ('filt', _c_void_p), ('bias', _c_void_p), ('bn_gamma', _c_void_p), ('bn_beta', _c_void_p), ('running_mean', _c_void_p),
+                ('running_var', _c_void_p), ('num_batches_tracked', _c_void_p), ('gn_gamma', _c_void_p), ('gn_beta', _c_void_p), ('y', _c_void_p), ('out', _c_void_p),
+                ('bn_mean', _c_void_p), ('bn_rstd', _c_void_p), ('gn_mean', _c_void_p), ('gn_rstd', _c_void_p), ('ref', _c_void_p)]
+
+
+class ResidentProgram(ctypes.Structure):
+    """ `dcv_resident_program` """
+    _fields_ = [('n', _c_int), ('count', _c_int), ('op', ResidentOp * RESIDENT_MAX_OPS)]
 
 
 class TensorList(ctypes.Structure):
@@ -171,6 +190,10 @@ _SIGNATURES = {
     'dcv_adamw_step': (_c_int, [ctypes.POINTER(TensorList), _P, _c_int, _P]),
     'dcv_sgd_step': (_c_int, [ctypes.POINTER(TensorList), _P, _c_int, _P]),
     'dcv_pack_grads': (_c_int, [ctypes.POINTER(TensorList), _P, _P]),
+    'dcv_resident_supported': (_c_int, [ctypes.POINTER(ResidentProgram)]),
+    'dcv_resident_ws_bytes': (_c_size_t, []),
+    'dcv_resident_forward': (_c_int, [ctypes.POINTER(ResidentProgram), _P, _c_size_t, _P]),
+    'dcv_resident_status': (_c_int, [_P, _P, ctypes.POINTER(_c_int)]),
 }
 
 _lib: Optional[ctypes.CDLL] = None

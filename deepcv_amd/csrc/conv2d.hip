@@ -41,6 +41,16 @@ inline int prep_entries(const dcv_conv2d_desc* d, int op, dcv_prep_entry* out) {
         out[0] = e;
         return 1;
     }
+    if (op == 3) {
+        // the LDS-resident network's forward filter (resident.hip): [R][S][cin rounded up to 4][cout], the direct kernels' layout with ONE tile of all
+        // output channels (wave-uniform scalar loads of 4 x cout weights per tap)
+        dcv_prep_entry e{};
+        e.kind = 0; e.kcout = d->cout; e.kcin = d->cin; e.R = d->r; e.S = d->s; e.w_cin = d->cin; e.dgrad = 0;
+        e.tco = d->cout; e.tiles = 1; e.cin_pad = (d->cin + 3) & ~3;
+        e.dst_off = 0; e.total = d->r * d->s * e.cin_pad * e.tco;
+        out[0] = e;
+        return 1;
+    }
     if (op == 1 && d->x_layout != DCV_LAYOUT_NHWC) return 0;
     return dcv_mfma_conv2d_supported(d, op) ? dcv_mfma_conv2d_prep_entries(d, op, out) : dcv_direct_conv2d_prep_entries(d, op, out);
 }
@@ -83,10 +93,10 @@ int dcv_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, 
 }
 
 size_t dcv_conv2d_filter_bytes(const dcv_conv2d_desc* d, int op) {
-    if (!desc_ok(d) || d->groups != 1 || (op != 0 && op != 1 && op != 2)) return 0;
+    if (!desc_ok(d) || d->groups != 1 || op < 0 || op > 3) return 0;
     dcv_prep_entry e[DCV_PREP_PIECES];
     if (prep_entries(d, op, e) == 0) return 0;
-    if (op == 2) return dcv_align_up((size_t)e[0].total * sizeof(float), 256);
+    if (op == 2 || op == 3) return dcv_align_up((size_t)e[0].total * sizeof(float), 256);
     return op == 0 ? dcv_conv2d_fwd_workspace_bytes(d) : dcv_conv2d_dgrad_workspace_bytes(d);
 }
 
@@ -101,7 +111,7 @@ int dcv_conv2d_prepare_filters(int count, const dcv_conv2d_desc* const* descs, c
         l.count = 0; max_total = 0;
     };
     for (int k = 0; k < count; ++k) {
-        DCV_CHECK_ARG(desc_ok(descs[k]) && w[k] && (ops[k] == 0 || ops[k] == 1 || ops[k] == 2));
+        DCV_CHECK_ARG(desc_ok(descs[k]) && w[k] && ops[k] >= 0 && ops[k] <= 3);
         dcv_prep_entry pieces[DCV_PREP_PIECES];
         const int np = prep_entries(descs[k], ops[k], pieces);
         if (np == 0) continue;                                    // this (layer, op) reads the OIHW filter directly

@@ -1,0 +1,539 @@
+// resident.hip — the LDS-resident network: the training forward of a small-channel DeepcvModule (reference src/deepcv/meta/base_module.py:113-155 over
+// `layer()` stacks, src/deepcv/meta/nn.py:519-554) as ONE persistent launch.
+//
+// Why: the stock CIFAR-10 classifier is five Conv -> act -> BatchNorm -> GroupNorm layers of 4 / 16 channels on 32x32 / 16x16 maps.  A sample's
+// activations are 16 KB per layer, so the per-layer kernels spend their time on everything except arithmetic: a launch boundary per kernel (1.6 us), a fill
+// and drain of the chip per kernel, an 8 MB write + read of every intermediate tensor.  Here a block of 1024 threads owns TWO samples and keeps them in
+// LDS from the input image to the logits (256 blocks = 512 samples, one block per CU); HBM only sees what the backward pass needs later (y, the layer
+// outputs, the saved statistics: write-only streams) and the filters (scalar cache).  The one thing a sample needs from the rest of the batch is the
+// BatchNorm statistics: per layer each block publishes its 2 * C sums as 8-byte {epoch, value} granules (one agent-scope store each: the tag travels
+// with the data, no fence) and gathers all blocks' granules with agent-scope loads until every tag shows the epoch (bounded spin); the sums are then
+// reduced in a fixed order in fp64 by every block, so all blocks derive bit-identical statistics.  tools/probes/resident_probe.hip measured a 4 -> 4 5x5
+// layer at 12.9 us this way (conv 6.4 + gather 5.1 + HBM stores 1.4) against 21.7 us for its two per-layer launches.
+//
+// Convolution variants (all read the zero-padded input tile from LDS, filters never touch LDS):
+//   c4 -> 4   (stock layers 1-3): two vertically adjacent output pixels per thread, input rows rotate through registers (5 ds_read_b128 per 80
+//             v_pk_fma_f32), one filter row (80 scalars) at a time from the scalar cache.
+//   c4 -> 8/16 (layer 4): one pixel x 8 output channels per thread, one tap (32 scalars) at a time.
+//   16 -> 16  (layer 5): v_mfma_f32_16x16x4_f32, M = the 16 pixels of an image row, N = 16 output channels, K = 4 input channels; the planar LDS layout
+//             [channel vector][row][col] makes ONE ds_read_b128 per tap the A operand of four MFMAs; the B fragments are 36 registers loaded straight
+//             from the OIHW weight (each lane's 36 values are contiguous there).
+// Roofline: VALU / MFMA fp32 (157.3 TF) for the convolutions; the gathers are latency (about 5 us each).
+#include "common.h"
+#include "conv2d_internal.h"
+
+namespace {
+
+constexpr int RS_T = 1024;          // threads per block: 16 waves, 4 per SIMD (<= 128 VGPRs)
+constexpr int RS_SPB = 2;           // samples per block
+constexpr int RS_XIN = 1296;        // float4 per sample of the padded input tile: (32 + 4)^2, or 4 planes of (16 + 2)^2
+constexpr int RS_Y = 4096;          // floats per sample of a layer's activated convolution output
+constexpr int RS_MAXC = 16;         // channels of a resident layer
+constexpr int RS_MAXQ = 2 * RS_MAXC;
+constexpr int RS_MAXG = 256;        // blocks
+constexpr int RS_SPINS = 1 << 16;   // gather polls before giving up (each at least a memory round trip: tens of milliseconds)
+constexpr size_t RS_CTL_BYTES = 256;
+
+typedef unsigned long long rs_u64;
+typedef __attribute__((address_space(1))) rs_u64 rs_gu64;
+typedef __attribute__((address_space(1))) unsigned rs_gu32;
+typedef __attribute__((address_space(4))) const float rs_cfloat;       // constant address space: wave-uniform loads go through the scalar cache
+#define RS_CONST(p) ((rs_cfloat*)(unsigned long long)(p))
+
+// LDS map (dynamic): xin [RS_SPB][RS_XIN] float4 | yt [RS_SPB][RS_Y] float.  While xin is dead (between a layer's convolution and its apply step) it holds
+// the gathered sums `arr` [RS_MAXQ][RS_MAXG] float (32 KB), the fp64 partials (4 KB) and the per-wave sums (2 KB).
+constexpr size_t RS_XIN_BYTES = (size_t)RS_SPB * RS_XIN * 16, RS_Y_BYTES = (size_t)RS_SPB * RS_Y * 4, RS_SMEM = RS_XIN_BYTES + RS_Y_BYTES;
+constexpr size_t RS_ARR_OFF = 0, RS_PART_OFF = (size_t)RS_MAXQ * RS_MAXG * 4, RS_WP_OFF = RS_PART_OFF + (size_t)RS_MAXQ * 16 * 8;
+static_assert(RS_WP_OFF + 16 * 2 * RS_MAXC * 4 <= RS_XIN_BYTES, "gather scratch must fit the input tile");
+
+__device__ __forceinline__ int rs_variant(int cin, int cout, int k) {
+    if (cin <= 4 && cout == 4 && (k == 3 || k == 5)) return 1;
+    if (cin <= 4 && (cout == 8 || cout == 16) && (k == 1 || k == 3)) return 2;
+    if (cin == 16 && cout == 16 && k == 3) return 3;
+    return 0;
+}
+
+__device__ __forceinline__ double rs_rsqrt(double v) {                   // as norm_chain.hip: fp32 estimate + two Newton steps in fp64
+    double r = (double)__frsqrt_rn((float)v);
+    r = r * (1.5 - 0.5 * v * r * r);
+    return r * (1.5 - 0.5 * v * r * r);
+}
+
+// ------------------------------------------------------------------------------------------------ convolutions (LDS -> LDS)
+// Input tile of sample s: plane cv of [XH][XW] float4 at xin + s * RS_XIN + cv * XH * XW.  Output: yt[s * RS_Y + (r * W + c) * Cout + co].
+
+template <int K>
+__device__ __forceinline__ void rs_conv_c4_co4(const dcv_resident_op& o, const float4* xin, float* yt) {
+    const int H = o.h, W = o.w, pad = K / 2, XW = W + 2 * pad, XH = H + 2 * pad;
+    const int per = (H >> 1) * W;                                                    // pixel pairs per sample
+    rs_cfloat* wl = RS_CONST(o.filt);                                                // [K][K][4][4]
+    float b[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) b[c] = o.bias ? RS_CONST(o.bias)[c] : 0.f;
+    for (int it = threadIdx.x; it < RS_SPB * per; it += RS_T) {
+        const int s = it >= per ? 1 : 0, p = it - s * per, rp = p / W, col = p - rp * W;
+        const float4* xs = xin + s * RS_XIN + (rp * 2) * XW + col;
+        float acc[2][4];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[k][c] = 0.f;
+        float4 old[K], nw[K];
+#pragma unroll
+        for (int sx = 0; sx < K; ++sx) old[sx] = xs[sx];
+#pragma unroll 1
+        for (int ky = 0; ky < K; ++ky) {                                             // rolled: one filter row of scalar operands live at a time
+#pragma unroll
+            for (int sx = 0; sx < K; ++sx) nw[sx] = xs[(ky + 1) * XW + sx];
+            rs_cfloat* wr = wl + ky * K * 16;
+#pragma unroll
+            for (int sx = 0; sx < K; ++sx) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    acc[0][c] = fmaf(old[sx].x, wr[sx * 16 + c], acc[0][c]);
+                    acc[0][c] = fmaf(old[sx].y, wr[sx * 16 + 4 + c], acc[0][c]);
+                    acc[0][c] = fmaf(old[sx].z, wr[sx * 16 + 8 + c], acc[0][c]);
+                    acc[0][c] = fmaf(old[sx].w, wr[sx * 16 + 12 + c], acc[0][c]);
+                    acc[1][c] = fmaf(nw[sx].x, wr[sx * 16 + c], acc[1][c]);
+                    acc[1][c] = fmaf(nw[sx].y, wr[sx * 16 + 4 + c], acc[1][c]);
+                    acc[1][c] = fmaf(nw[sx].z, wr[sx * 16 + 8 + c], acc[1][c]);
+                    acc[1][c] = fmaf(nw[sx].w, wr[sx * 16 + 12 + c], acc[1][c]);
+                }
+            }
+#pragma unroll
+            for (int sx = 0; sx < K; ++sx) old[sx] = nw[sx];
+        }
+        (void)XH;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = dcv_act_apply(acc[k][c] + b[c], o.act, o.slope);
+            reinterpret_cast<float4*>(yt + s * RS_Y)[(rp * 2 + k) * W + col] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// one pixel x 8 output channels per item; items of a wave share (sample, channel half): H * W is a multiple of 64
+template <int K>
+__device__ __forceinline__ void rs_conv_c4_wide(const dcv_resident_op& o, const float4* xin, float* yt) {
+    const int H = o.h, W = o.w, pad = K / 2, XW = W + 2 * pad, HW = H * W, CO = o.cout, nh = CO >> 3;
+    const int per = HW * nh;
+    for (int it = threadIdx.x; it < RS_SPB * per; it += RS_T) {
+        const int s = __builtin_amdgcn_readfirstlane(it >= per ? 1 : 0), rem = it - s * per;
+        const int half = __builtin_amdgcn_readfirstlane(rem / HW), px = rem - half * HW, r = px / W, col = px - r * W;
+        const float4* xs = xin + s * RS_XIN + r * XW + col;
+        rs_cfloat* wl = RS_CONST(o.filt) + half * 8;                                 // [K][K][4][CO]
+        float acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+#pragma unroll 1
+        for (int tap = 0; tap < K * K; ++tap) {
+            const int ky = tap / K, kx = tap - ky * K;
+            const float4 xv = xs[ky * XW + kx];
+            rs_cfloat* wt = wl + tap * 4 * CO;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                acc[c] = fmaf(xv.x, wt[c], acc[c]);
+                acc[c] = fmaf(xv.y, wt[CO + c], acc[c]);
+                acc[c] = fmaf(xv.z, wt[2 * CO + c], acc[c]);
+                acc[c] = fmaf(xv.w, wt[3 * CO + c], acc[c]);
+            }
+        }
+        float* yp = yt + s * RS_Y + px * CO + half * 8;
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = dcv_act_apply(acc[c] + (o.bias ? RS_CONST(o.bias)[half * 8 + c] : 0.f), o.act, o.slope);
+        reinterpret_cast<float4*>(yp)[0] = make_float4(v[0], v[1], v[2], v[3]);
+        reinterpret_cast<float4*>(yp)[1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
+typedef float rs_f4 __attribute__((ext_vector_type(4)));
+
+// 16 -> 16 channels, 3x3, W == 16: a wave owns image rows; per tap one ds_read_b128 (plane k = lane / 16: channels 4k .. 4k + 3 of pixel lane % 16)
+// feeds four v_mfma_f32_16x16x4_f32 (MFMA j contracts channels {j, 4 + j, 8 + j, 12 + j}).
+__device__ __forceinline__ void rs_conv_c16_mfma(const dcv_resident_op& o, const float4* xin, float* yt) {
+    const int H = o.h, XW = 18, XH = H + 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4;
+    // B fragments: lane (n = co = lane % 16, k = lane / 16) needs w[co][4k + j][tap], j < 4, tap < 9: 36 contiguous floats of the OIHW filter
+    float breg[36];
+    {
+        const float4* wp = reinterpret_cast<const float4*>(o.filt + ((size_t)m * 16 + 4 * kq) * 9);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { const float4 v = wp[q]; breg[4 * q] = v.x; breg[4 * q + 1] = v.y; breg[4 * q + 2] = v.z; breg[4 * q + 3] = v.w; }
+    }
+    const float bias = o.bias ? o.bias[m] : 0.f;
+    for (int row = wave; row < RS_SPB * H; row += 16) {
+        const int s = row >= H ? 1 : 0, r = row - s * H;
+        const float4* xs = xin + s * RS_XIN + (kq * XH + r) * XW + m;
+        rs_f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float4 a = xs[ky * XW + kx];
+                const int tap = ky * 3 + kx;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, breg[tap], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, breg[9 + tap], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, breg[18 + tap], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, breg[27 + tap], acc, 0, 0, 0);
+            }
+        // D: lane holds pixels 4 * (lane / 16) + i, output channel lane % 16
+        float* yp = yt + s * RS_Y + (r * 16 + 4 * kq) * 16 + m;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) yp[i * 16] = dcv_act_apply(acc[i] + bias, o.act, o.slope);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ the kernel
+
+__global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program p, unsigned* ctl, rs_u64* gran) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* xin = reinterpret_cast<float4*>(smem);
+    float* xinf = reinterpret_cast<float*>(smem);
+    float* yt = reinterpret_cast<float*>(smem + RS_XIN_BYTES);
+    float* arr = reinterpret_cast<float*>(smem + RS_ARR_OFF);
+    double* part = reinterpret_cast<double*>(smem + RS_PART_OFF);                    // [RS_MAXQ][16]
+    float* wpart = reinterpret_cast<float*>(smem + RS_WP_OFF);                       // [16 waves][2][RS_MAXC]
+    __shared__ float s_samp[RS_SPB][2][RS_MAXC];                                     // per-sample sums of y, y^2
+    __shared__ float s_ab[2][RS_MAXC];                                               // BatchNorm: v = a y + b
+    __shared__ float s_S[RS_SPB][RS_MAXC], s_T[RS_SPB][RS_MAXC];                      // layer output = S y + T
+    __shared__ double s_grp[RS_SPB][2][RS_MAXC];
+    __shared__ unsigned s_gen;
+    __shared__ int s_fail;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int s_of_t = t >> 9, tt = t & 511;                                         // sample-major split of the block for the per-sample passes
+    const int N = p.n, G = (int)gridDim.x;
+    const bool valid0 = (int)blockIdx.x * RS_SPB < N, valid1 = (int)blockIdx.x * RS_SPB + 1 < N;
+    if (t == 0) { s_gen = __hip_atomic_load((rs_gu32*)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_fail = 0; }
+    for (int i = t; i < RS_SPB * RS_XIN; i += RS_T) xin[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    const unsigned gen = s_gen;
+    {   // stage the two samples into the first layer's padded tile
+        const dcv_resident_op& o = p.op[0];
+        const int pad = o.k / 2, XW = o.w + 2 * pad, XH = o.h + 2 * pad, HW = o.h * o.w, C = o.cin;
+        const int n = (int)blockIdx.x * RS_SPB + s_of_t;
+        if (n < N) {
+            float* dst = xinf + (size_t)s_of_t * RS_XIN * 4;
+            if (!o.x_nchw && (C & 3) == 0) {
+                const float4* src = reinterpret_cast<const float4*>(o.x) + (size_t)n * HW * (C >> 2);
+                for (int e = tt; e < HW * (C >> 2); e += 512) {
+                    const int px = e / (C >> 2), cv = e - px * (C >> 2), r = px / o.w, col = px - r * o.w;
+                    reinterpret_cast<float4*>(dst)[(cv * XH + r + pad) * XW + col + pad] = src[e];
+                }
+            } else {
+                const float* src = o.x + (size_t)n * HW * C;
+                for (int e = tt; e < HW * C; e += 512) {
+                    int c, px;
+                    if (o.x_nchw) { c = e / HW; px = e - c * HW; } else { px = e / C; c = e - px * C; }
+                    const int r = px / o.w, col = px - r * o.w;
+                    dst[(((c >> 2) * XH + r + pad) * XW + col + pad) * 4 + (c & 3)] = src[e];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    int fc_from_y = 0;                                                               // the FC input is the wide tensor a LINK left in yt
+    for (int oi = 0; oi < p.count; ++oi) {
+        const dcv_resident_op& o = p.op[oi];
+        if (o.kind == DCV_RES_LAYER) {
+            const int C = o.cout, CV = C >> 2, H = o.h, W = o.w, HW = H * W;
+            // ---- convolution + bias + activation: xin -> yt
+            const int var = rs_variant(o.cin, o.cout, o.k);
+            if (var == 1) { if (o.k == 5) rs_conv_c4_co4<5>(o, xin, yt); else rs_conv_c4_co4<3>(o, xin, yt); }
+            else if (var == 2) { if (o.k == 3) rs_conv_c4_wide<3>(o, xin, yt); else rs_conv_c4_wide<1>(o, xin, yt); }
+            else rs_conv_c16_mfma(o, xin, yt);
+            __syncthreads();
+            // ---- y -> HBM (saved for the backward pass) and the per-sample sums of y, y^2: thread = fixed channel vector (512 % CV == 0)
+            {
+                const int n = (int)blockIdx.x * RS_SPB + s_of_t;
+                const float4* ys = reinterpret_cast<const float4*>(yt + s_of_t * RS_Y);
+                float4* yg = reinterpret_cast<float4*>(o.y) + (size_t)n * HW * CV;
+                float sum[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int i = tt; i < HW * CV; i += 512) {
+                    const float4 v = ys[i];
+                    if (n < N) yg[i] = v;
+                    sum[0] += v.x; sum[1] += v.y; sum[2] += v.z; sum[3] += v.w;
+                    sq[0] += v.x * v.x; sq[1] += v.y * v.y; sq[2] += v.z * v.z; sq[3] += v.w * v.w;
+                }
+                if (o.bn || o.groups) {
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1)
+                        if (off >= CV) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { sum[j] += __shfl_xor(sum[j], off, 64); sq[j] += __shfl_xor(sq[j], off, 64); }
+                        }
+                    if (lane < CV) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { wpart[(wave * 2) * RS_MAXC + lane * 4 + j] = sum[j]; wpart[(wave * 2 + 1) * RS_MAXC + lane * 4 + j] = sq[j]; }
+                    }
+                }
+            }
+            __syncthreads();
+            if (o.bn || o.groups) {
+                if (t < RS_SPB * 2 * C) {
+                    const int ss = t / (2 * C), r = t - ss * 2 * C, q = r / C, c = r - q * C;
+                    float v = 0.f;
+                    for (int w8 = 0; w8 < 8; ++w8) v += wpart[((ss * 8 + w8) * 2 + q) * RS_MAXC + c];
+                    s_samp[ss][q][c] = v;
+                }
+                __syncthreads();
+            }
+            if (o.bn) {
+                // ---- batch statistics: publish this block's 2C sums, gather every block's
+                const unsigned epoch = gen * DCV_RESIDENT_MAX_OPS + (unsigned)oi + 1u;
+                rs_u64* go = gran + (size_t)oi * RS_MAXQ * RS_MAXG;
+                if (t < 2 * C) {
+                    const int q = t / C, c = t - q * C;
+                    const float tot = (valid0 ? s_samp[0][q][c] : 0.f) + (valid1 ? s_samp[1][q][c] : 0.f);
+                    __hip_atomic_store((rs_gu64*)(go + (size_t)t * RS_MAXG + blockIdx.x), ((rs_u64)epoch << 32) | (rs_u64)__float_as_uint(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                const int total = 2 * C * G;
+                bool ok = true;
+                for (int i0 = 0; i0 < total; i0 += RS_T * 4) {                       // <= 4 granules per thread and sweep
+                    int idx[4]; float gv[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { const int i = i0 + k * RS_T + t; const int q = i / G; idx[k] = i < total ? q * RS_MAXG + (i - q * G) : -1; }
+                    bool got = false;
+                    for (int spins = 0; spins < RS_SPINS; ++spins) {
+                        got = true;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (idx[k] >= 0) {
+                                const rs_u64 g = __hip_atomic_load((rs_gu64*)(go + idx[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                gv[k] = __uint_as_float((unsigned)g);
+                                got &= (unsigned)(g >> 32) == epoch;
+                            }
+                        }
+                        if (__all(got)) break;
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    ok &= (bool)__all(got);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (idx[k] >= 0) arr[idx[k]] = gv[k];
+                }
+                if (!ok && lane == 0) s_fail = 1;
+                __syncthreads();
+                if (s_fail) {                                                        // a block of this grid is not resident: report, poison the logits, leave
+                    if (t == 0) { __hip_atomic_store((rs_gu32*)(ctl + 1), (unsigned)oi + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                    for (int k = 0; k < p.count; ++k)
+                        if (p.op[k].kind == DCV_RES_FC)
+                            for (int e = t; e < RS_SPB * p.op[k].cout; e += RS_T) {
+                                const int n = (int)blockIdx.x * RS_SPB + e / p.op[k].cout;
+                                if (n < N) p.op[k].out[(size_t)n * p.op[k].cout + e % p.op[k].cout] = __builtin_nanf("");
+                            }
+                    return;
+                }
+                // fixed-order fp64 sums: 16 partial sums of <= 16 blocks per quantity, then the 16 partials
+                if (t < 2 * C * 16) {
+                    const int q = t >> 4, j = t & 15;
+                    double v = 0.0;
+                    for (int i = j * 16; i < j * 16 + 16 && i < G; ++i) v += (double)arr[q * RS_MAXG + i];
+                    part[q * 16 + j] = v;
+                }
+                __syncthreads();
+                if (t < C) {
+                    double s1 = 0.0, s2 = 0.0;
+                    for (int j = 0; j < 16; ++j) { s1 += part[t * 16 + j]; s2 += part[(C + t) * 16 + j]; }
+                    const double count = (double)N * (double)HW, mean = s1 / count;
+                    double varc = s2 / count - mean * mean; if (varc < 0.0) varc = 0.0;
+                    const float rstd = (float)rs_rsqrt(varc + (double)o.bn_eps);
+                    const float g = o.bn_gamma ? o.bn_gamma[t] : 1.f, b = o.bn_beta ? o.bn_beta[t] : 0.f;
+                    const float sc = g * rstd;
+                    s_ab[0][t] = sc; s_ab[1][t] = b - (float)mean * sc;
+                    if (blockIdx.x == 0) {                                           // saved / running statistics: written once
+                        o.bn_mean[t] = (float)mean; o.bn_rstd[t] = rstd;
+                        if (o.running_mean) o.running_mean[t] = (1.f - o.momentum) * o.running_mean[t] + o.momentum * (float)mean;
+                        if (o.running_var) { const double unb = count > 1.0 ? varc * count / (count - 1.0) : varc; o.running_var[t] = (1.f - o.momentum) * o.running_var[t] + o.momentum * (float)unb; }
+                        if (t == 0 && o.num_batches_tracked) o.num_batches_tracked[0] += 1;
+                    }
+                }
+            } else if (t < C) { s_ab[0][t] = 1.f; s_ab[1][t] = 0.f; }
+            __syncthreads();
+            // ---- per-sample affine of the layer output: GroupNorm of the BatchNorm output (norm_chain.hip, nc_apply_kernel's prologue)
+            if (o.groups > 0) {
+                const int cpg = C / o.groups;
+                const int ss = t / C, c = t - ss * C;
+                const bool own = t < RS_SPB * C;
+                float a = 0.f, b = 0.f;
+                if (own) {
+                    a = s_ab[0][c]; b = s_ab[1][c];
+                    const double hw = (double)HW, ad = (double)a, bd = (double)b, s1 = (double)s_samp[ss][0][c], s2 = (double)s_samp[ss][1][c];
+                    s_grp[ss][0][c] = ad * s1 + hw * bd;
+                    s_grp[ss][1][c] = ad * ad * s2 + 2.0 * ad * bd * s1 + hw * bd * bd;
+                }
+                __syncthreads();
+                if (own) {
+                    const int g = c / cpg, g0 = g * cpg;
+                    double sv = 0.0, svv = 0.0;
+                    for (int k = g0; k < g0 + cpg; ++k) { sv += s_grp[ss][0][k]; svv += s_grp[ss][1][k]; }
+                    const double inv_m = 1.0 / ((double)cpg * (double)HW), mean = sv * inv_m;
+                    double varc = svv * inv_m - mean * mean; if (varc < 0.0) varc = 0.0;
+                    const float rstd = (float)rs_rsqrt(varc + (double)o.gn_eps);
+                    const int n = (int)blockIdx.x * RS_SPB + ss;
+                    if (c == g0 && n < N) { o.gn_mean[(size_t)n * o.groups + g] = (float)mean; o.gn_rstd[(size_t)n * o.groups + g] = rstd; }
+                    const float gg = o.gn_gamma ? o.gn_gamma[c] : 1.f, gb = o.gn_beta ? o.gn_beta[c] : 0.f;
+                    s_S[ss][c] = a * rstd * gg;
+                    s_T[ss][c] = (b - (float)mean) * rstd * gg + gb;
+                }
+            } else if (t < RS_SPB * C) { const int ss = t / C, c = t - ss * C; s_S[ss][c] = s_ab[0][c]; s_T[ss][c] = s_ab[1][c]; }
+            // ---- apply: out = S y + T [averaged over pool windows] -> HBM and the next op's input tile
+            for (int i = t; i < RS_SPB * RS_XIN; i += RS_T) xin[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            __syncthreads();
+            {
+                const int pk = o.pool > 0 ? o.pool : 1, Ho = H / pk, Wo = W / pk;
+                const bool nxt_layer = oi + 1 < p.count && p.op[oi + 1].kind == DCV_RES_LAYER;
+                const int npad = nxt_layer ? p.op[oi + 1].k / 2 : 0, XWn = Wo + 2 * npad, XHn = Ho + 2 * npad;
+                const float inv = 1.f / (float)(pk * pk);
+                const int per = Ho * Wo * CV;
+                for (int it = t; it < RS_SPB * per; it += RS_T) {
+                    const int ss = it >= per ? 1 : 0, e = it - ss * per, px = e / CV, cv = e - px * CV, ho = px / Wo, wo = px - ho * Wo;
+                    const float* S = s_S[ss] + cv * 4; const float* T = s_T[ss] + cv * 4;
+                    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                    for (int kh = 0; kh < pk; ++kh)
+                        for (int kw = 0; kw < pk; ++kw) {
+                            const float4 v = reinterpret_cast<const float4*>(yt + ss * RS_Y)[((ho * pk + kh) * W + wo * pk + kw) * CV + cv];
+                            acc[0] += v.x * S[0] + T[0]; acc[1] += v.y * S[1] + T[1]; acc[2] += v.z * S[2] + T[2]; acc[3] += v.w * S[3] + T[3];
+                        }
+                    float4 r4;
+                    if (o.pool > 0) r4 = make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv); else r4 = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                    const int n = (int)blockIdx.x * RS_SPB + ss;
+                    if (n < N) {
+                        reinterpret_cast<float4*>(o.out)[((size_t)n * Ho * Wo + px) * CV + cv] = r4;
+                        if (nxt_layer) xin[ss * RS_XIN + (cv * XHn + ho + npad) * XWn + wo + npad] = r4;
+                        else reinterpret_cast<float4*>(xinf + (size_t)ss * RS_XIN * 4)[px * CV + cv] = r4;       // flat NHWC for a LINK / FC
+                    }
+                }
+            }
+            __syncthreads();
+            fc_from_y = 0;
+        } else if (o.kind == DCV_RES_LINK) {
+            // wide[px][0 .. cin) = current (flat NHWC in xin), wide[px][cin ..) = bilinear resize of ref to (h, w): -> HBM and yt (flat NHWC)
+            const int Cc = o.cin, Cr = o.ref_c, Cw = Cc + Cr, HW = o.h * o.w;
+            const float sh = o.align_corners ? (o.h > 1 ? (float)(o.ref_h - 1) / (float)(o.h - 1) : 0.f) : (float)o.ref_h / (float)o.h;
+            const float sw = o.align_corners ? (o.w > 1 ? (float)(o.ref_w - 1) / (float)(o.w - 1) : 0.f) : (float)o.ref_w / (float)o.w;
+            const int per = HW * Cw;
+            for (int it = t; it < RS_SPB * per; it += RS_T) {
+                const int ss = it >= per ? 1 : 0, e = it - ss * per, px = e / Cw, c = e - px * Cw;
+                const int n = (int)blockIdx.x * RS_SPB + ss;
+                if (n >= N) continue;
+                float v;
+                if (c < Cc) v = xinf[(size_t)ss * RS_XIN * 4 + px * Cc + c];
+                else {
+                    const int ho = px / o.w, wo = px - ho * o.w, cr = c - Cc;
+                    float fs = o.align_corners ? sh * ho : sh * (ho + 0.5f) - 0.5f; if (fs < 0.f) fs = 0.f;
+                    int h0 = (int)fs; if (h0 > o.ref_h - 1) h0 = o.ref_h - 1;
+                    const int h1 = h0 + (h0 < o.ref_h - 1 ? 1 : 0); const float lh = fs - (float)h0;
+                    float fw = o.align_corners ? sw * wo : sw * (wo + 0.5f) - 0.5f; if (fw < 0.f) fw = 0.f;
+                    int w0 = (int)fw; if (w0 > o.ref_w - 1) w0 = o.ref_w - 1;
+                    const int w1 = w0 + (w0 < o.ref_w - 1 ? 1 : 0); const float lw = fw - (float)w0;
+                    // `ref` was stored by this block earlier in this launch (its own samples): agent-scope loads, never the CU's L1
+                    const float* rs = o.ref + (size_t)n * o.ref_h * o.ref_w * Cr + cr;
+                    auto ld = [&](int hh, int ww) { return __uint_as_float(__hip_atomic_load((rs_gu32*)(rs + ((size_t)hh * o.ref_w + ww) * Cr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
+                    const float c00 = (1.f - lh) * (1.f - lw), c01 = (1.f - lh) * lw, c10 = lh * (1.f - lw), c11 = lh * lw;
+                    v = c00 * ld(h0, w0) + c01 * ld(h0, w1) + c10 * ld(h1, w0) + c11 * ld(h1, w1);
+                }
+                yt[ss * RS_Y + e] = v;
+                o.out[(size_t)n * per + e] = v;
+            }
+            __syncthreads();
+            fc_from_y = 1;
+        } else if (o.kind == DCV_RES_FC) {
+            // logits[n][j] = act(bias[j] + sum_k x[n][k] w[j][k]), K = h * w * cin floats of the sample's flat NHWC activations; 32 lanes per (sample, j)
+            const int K4 = (o.h * o.w * o.cin) >> 2, O = o.cout;
+            const float4* xs = fc_from_y ? reinterpret_cast<const float4*>(yt + s_of_t * RS_Y) : reinterpret_cast<const float4*>(xinf + (size_t)s_of_t * RS_XIN * 4);
+            const int j = tt >> 5, l32 = tt & 31, n = (int)blockIdx.x * RS_SPB + s_of_t;
+            float acc = 0.f;
+            if (j < O) {
+                const float4* wr = reinterpret_cast<const float4*>(o.filt) + (size_t)j * K4;
+                for (int k = l32; k < K4; k += 32) { const float4 a = xs[k], b = wr[k]; acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+            }
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+            if (j < O && l32 == 0 && n < N) o.out[(size_t)n * O + j] = dcv_act_apply(acc + (o.bias ? o.bias[j] : 0.f), o.act, o.slope);
+            __syncthreads();
+        }
+    }
+    // every block read `gen` before its first publication and block 0 only gets here after it has gathered everybody's: the next launch is stream-ordered
+    if (blockIdx.x == 0 && t == 0) __hip_atomic_store((rs_gu32*)ctl, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+inline bool rs_layer_ok(const dcv_resident_op& o, bool first) {
+    const int var = (o.cin <= 4 && o.cout == 4 && (o.k == 3 || o.k == 5)) ? 1 : (o.cin <= 4 && (o.cout == 8 || o.cout == 16) && (o.k == 1 || o.k == 3)) ? 2
+                    : (o.cin == 16 && o.cout == 16 && o.k == 3) ? 3 : 0;
+    if (var == 0 || o.h <= 0 || o.w <= 0 || o.cin <= 0) return false;
+    const int pad = o.k / 2, cvin = (o.cin + 3) / 4;
+    if (cvin * (o.h + 2 * pad) * (o.w + 2 * pad) > RS_XIN || o.h * o.w * o.cout > RS_Y) return false;
+    if (var == 1 && (o.h & 1)) return false;
+    if (var == 2 && (o.h * o.w) % 64 != 0) return false;
+    if (var == 3 && o.w != 16) return false;
+    if (!first && (o.cin & 3)) return false;                      // only the staged model input may have a partial channel vector
+    if (o.act < DCV_ACT_NONE || o.act > DCV_ACT_TANH || !o.filt || !o.y || !o.out) return false;
+    if (o.bn && !(o.bn_mean && o.bn_rstd)) return false;
+    if (o.groups < 0 || (o.groups > 0 && (o.cout % o.groups != 0 || !o.gn_mean || !o.gn_rstd))) return false;
+    if (o.pool < 0 || o.pool == 1 || (o.pool > 0 && (o.h % o.pool != 0 || o.w % o.pool != 0))) return false;
+    return true;
+}
+
+inline bool rs_program_ok(const dcv_resident_program* p) {
+    if (!p || p->n <= 0 || p->n > RS_SPB * RS_MAXG || p->count <= 0 || p->count > DCV_RESIDENT_MAX_OPS) return false;
+    if (p->op[0].kind != DCV_RES_LAYER || !p->op[0].x) return false;
+    int c = 0, h = 0, w = 0;                                      // the current tensor
+    for (int i = 0; i < p->count; ++i) {
+        const dcv_resident_op& o = p->op[i];
+        if (o.kind == DCV_RES_LAYER) {
+            if (!rs_layer_ok(o, i == 0)) return false;
+            if (i > 0 && (p->op[i - 1].kind != DCV_RES_LAYER || o.cin != c || o.h != h || o.w != w)) return false;
+            const int pk = o.pool > 0 ? o.pool : 1;
+            c = o.cout; h = o.h / pk; w = o.w / pk;
+        } else if (o.kind == DCV_RES_LINK) {
+            if (i == 0 || p->op[i - 1].kind != DCV_RES_LAYER || o.cin != c || o.h != h || o.w != w || !o.ref || !o.out || o.ref_c <= 0 || o.ref_h <= 0 || o.ref_w <= 0) return false;
+            if (i + 1 < p->count && p->op[i + 1].kind != DCV_RES_FC) return false;
+            bool found = false;                                   // ref must be an earlier layer's output (this block wrote its samples' part)
+            for (int k = 0; k < i; ++k) if (p->op[k].kind == DCV_RES_LAYER && p->op[k].out == o.ref) found = true;
+            if (!found || h * w * (c + o.ref_c) > RS_Y) return false;
+            c += o.ref_c;
+        } else if (o.kind == DCV_RES_FC) {
+            if (i == 0 || o.cin != c || o.h != h || o.w != w || !o.filt || !o.out || o.cout <= 0 || o.cout > 16 || ((c * h * w) & 3) || c * h * w > RS_Y) return false;
+            if (p->op[i - 1].kind == DCV_RES_LAYER && (size_t)c * h * w > (size_t)RS_XIN * 4) return false;
+            if (i + 1 != p->count) return false;
+            if (o.act < DCV_ACT_NONE || o.act > DCV_ACT_TANH) return false;
+        } else return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dcv_resident_supported(const dcv_resident_program* p) { return rs_program_ok(p) ? 1 : 0; }
+
+size_t dcv_resident_ws_bytes(void) { return RS_CTL_BYTES + (size_t)DCV_RESIDENT_MAX_OPS * RS_MAXQ * RS_MAXG * sizeof(rs_u64); }
+
+int dcv_resident_forward(const dcv_resident_program* p, void* ws, size_t ws_bytes, void* stream) {
+    DCV_CHECK_ARG(p && ws);
+    if (!rs_program_ok(p)) return DCV_ERR_UNSUPPORTED;
+    if (ws_bytes < dcv_resident_ws_bytes()) return DCV_ERR_WORKSPACE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(resident_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RS_SMEM) != hipSuccess) return DCV_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const unsigned grid = (unsigned)((p->n + RS_SPB - 1) / RS_SPB);
+    hipLaunchKernelGGL(resident_fwd_kernel, dim3(grid), dim3(RS_T), RS_SMEM, dcv_stream(stream), *p, reinterpret_cast<unsigned*>(ws),
+                       reinterpret_cast<rs_u64*>(reinterpret_cast<char*>(ws) + RS_CTL_BYTES));
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_resident_status(const void* ws, void* stream, int* err) {
+    DCV_CHECK_ARG(ws && err);
+    unsigned ctl[2] = {0, 0};
+    if (hipMemcpyAsync(ctl, ws, sizeof(ctl), hipMemcpyDeviceToHost, dcv_stream(stream)) != hipSuccess) return DCV_ERR_LAUNCH;
+    if (hipStreamSynchronize(dcv_stream(stream)) != hipSuccess) return DCV_ERR_LAUNCH;
+    *err = (int)ctl[1];
+    return DCV_OK;
+}
+
+}  // extern "C"

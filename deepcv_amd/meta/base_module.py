@@ -19,6 +19,7 @@ import torch.nn
 from ..utils import NL, NUMBER_T, human_readable_size
 from . import nn as deepcv_nn
 from .. import ops as native_ops
+from .. import resident as native_resident
 from . import nn_spec
 from .submodule_creators import ForwardCallbackSubmodule
 from .types_aliases import *
@@ -68,7 +69,20 @@ class DeepcvModule(torch.nn.Module):
                                       'to the container module which has no `weight` parameter (SURVEY.md Appendix A #22).')
 
     def forward(self, x: TENSOR_OR_SEQ_OF_TENSORS_T) -> torch.Tensor:
-        """ Reference `base_module.py:113-155` (intended semantics, SURVEY.md Appendix A #19). """
+        """ Reference `base_module.py:113-155` (intended semantics, SURVEY.md Appendix A #19).  In training mode on a HIP device the outermost module first
+        tries to RECORD the walk below for one persistent launch (`deepcv_amd.resident`: small-channel chains whose activations stay in LDS); a model the
+        resident kernel does not cover runs the same walk on the per-layer kernels. """
+        if native_resident.wanted(self, x):
+            try:
+                with native_resident.Recorder(x) as rec:
+                    out = self._forward_walk(x)
+                    rec.finish(out)
+                return out
+            except native_resident.Ineligible as e:
+                native_resident.mark_ineligible(self, x, str(e))
+        return self._forward_walk(x)
+
+    def _forward_walk(self, x: TENSOR_OR_SEQ_OF_TENSORS_T) -> torch.Tensor:
         if not isinstance(x, torch.Tensor) and (self._single_input_shape or len(x) < len(self._input_shape)):
             if self._single_input_shape and len(x) == 1:
                 x = x[0]

@@ -13,6 +13,7 @@ import torch
 from . import _native as nat
 from . import filters
 from . import grads
+from . import resident
 from . import slabs
 from ._native import lib
 
@@ -62,6 +63,7 @@ def to_nhwc(t: torch.Tensor) -> torch.Tensor:
     """ Returns `t` with channels-last strides; uses the native transpose kernel when a real layout change is needed. """
     if _is_nhwc(t):
         return t
+    resident.forbid('a layout conversion')
     if t.dim() == 4 and t.is_contiguous() and t.dtype == torch.float32:
         return nchw_to_nhwc(t)
     return t.contiguous(memory_format=_CL)   # exotic strides coming from foreign torch ops: let torch normalise them
@@ -415,6 +417,7 @@ def _pair(v) -> Tuple[int, int]:
 def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stride=1, padding=0, dilation=1, act: int = nat.ACT_NONE,
            slope: float = 0.) -> torch.Tensor:
     """ y = act(conv2d(x, weight) + bias) — HIP kernels `dcv_conv2d_fwd/dgrad/wgrad` (+ `dcv_act_bwd` for the fused epilogue). """
+    resident.forbid('conv2d')
     return _Conv2dFn.apply(x, weight, bias, _pair(stride), _pair(padding), _pair(dilation), int(act), float(slope))
 
 
@@ -443,6 +446,7 @@ class _ActFn(torch.autograd.Function):
 
 
 def activation(x: torch.Tensor, act: int, slope: float = 0.) -> torch.Tensor:
+    resident.forbid('a standalone activation')
     x = _f32(x)
     if act == nat.ACT_NONE:
         return x
@@ -496,6 +500,7 @@ class _BatchNormTrainFn(torch.autograd.Function):
 def batch_norm(x, gamma, beta, running_mean, running_var, num_batches_tracked, training: bool, momentum: float, eps: float) -> torch.Tensor:
     """ BatchNorm over all dims but the channel dim (dim 1).  Training: batch statistics + running-stat EMA (`dcv_batchnorm_fwd_train`);
     inference: running statistics (`dcv_batchnorm_fwd_eval`, not differentiable w.r.t. its input in this build). """
+    resident.forbid('a standalone batch_norm')
     x = _f32(x)
     use_batch_stats = training or running_mean is None
     if use_batch_stats:
@@ -566,6 +571,7 @@ def sync_batch_norm(x, gamma, beta, running_mean, running_var, num_batches_track
                     all_reduce=_dist_all_reduce_sum) -> torch.Tensor:
     """ Training-mode BatchNorm whose batch statistics span every rank of `group`.  `all_reduce(tensor, group)` sums a small fp64 tensor in place
     over the ranks (injectable for tests). """
+    resident.forbid('sync_batch_norm')
     return _SyncBatchNormFn.apply(_f32(x), gamma, beta, running_mean, running_var, num_batches_tracked, float(momentum), float(eps), group, all_reduce)
 
 
@@ -606,6 +612,7 @@ class _GroupNormFn(torch.autograd.Function):
 
 
 def group_norm(x, gamma, beta, groups: int, eps: float) -> torch.Tensor:
+    resident.forbid('a standalone group_norm')
     x = _f32(x)
     return _GroupNormFn.apply(x, gamma, beta, int(groups), float(eps))
 
@@ -644,17 +651,24 @@ class _ConvNormLayerFn(torch.autograd.Function):
             raise TypeError(f'deepcv_amd: fp32 (or bf16) activations expected, got {x.dtype}')
         ctx.x_dtype = x.dtype
         dev, st = x.device, nat.current_stream(x.device)
+        rec = resident.recorder()                   # not None: the forward is being recorded for ONE persistent launch (deepcv_amd/resident.py)
         if _is_nhwc(x):
             layout = nat.LAYOUT_NHWC
         elif x.is_contiguous() and x.dtype == torch.float32:
             layout = nat.LAYOUT_NCHW
         else:
+            resident.forbid('a layout conversion')
             x, layout = to_nhwc(_to_f32(x.contiguous(), st) if x.dtype == torch.bfloat16 else x), nat.LAYOUT_NHWC
         ctx.weight_ref, ctx.bias_ref, ctx.norm_refs = weight, bias, (bn_w, bn_b, gn_w, gn_b)
         ctx.fan_slot = getattr(x, '_dcv_fan_slot', None)          # x is also referenced by a later link: its gradient may ride in our data gradient
+        d = _conv_desc(x.shape, weight.shape, stride, padding, dilation, layout, act, slope)
+        if rec is not None:
+            if x.dtype != torch.float32 or not weight.is_contiguous():
+                raise resident.Ineligible('layer: element type / weight layout')
+            rec.check_layer(x, d, cfg, layout)
+            rec.note(weight if ctx.needs_input_grad[1] else None, bias if ctx.needs_input_grad[2] else None)
         slabs.note_use(weight if ctx.needs_input_grad[1] else None, bias if ctx.needs_input_grad[2] else None)
         weight = weight.contiguous()
-        d = _conv_desc(x.shape, weight.shape, stride, padding, dilation, layout, act, slope)
         c, hw = d.cout, d.ho * d.wo
         bn_mean = torch.empty(c, dtype=torch.float32, device=dev)
         bn_rstd = torch.empty(c, dtype=torch.float32, device=dev)
@@ -662,6 +676,20 @@ class _ConvNormLayerFn(torch.autograd.Function):
         gn_rstd = torch.empty(d.n * groups, dtype=torch.float32, device=dev) if groups else None
         nc = _norm_chain_desc(d, cfg, bn_w, bn_b, running_mean, running_var, nbt, bn_mean, bn_rstd, gn_w, gn_b, gn_mean, gn_rstd)
         ctx.streaming = _norm_streaming and bool(lib.dcv_norm_chain_supported(nc))
+        if rec is not None:
+            # recorded: same outputs, saved tensors and autograd node, no launch here (the backward pass below is the per-layer one, unchanged)
+            if not ctx.streaming:
+                raise resident.Ineligible('layer: the streaming norm chain does not cover its backward')
+            ctx.use16 = ctx.io16 = False
+            filt = weight if (d.cin == 16 and d.cout == 16) else filters.get(weight, d, 3)
+            if filt is None:
+                raise resident.Ineligible('layer: no resident filter layout')
+            y = torch.empty((d.n, d.cout, d.ho, d.wo), dtype=torch.float32, device=dev, memory_format=_CL)
+            out = torch.empty_like(y) if not pool else torch.empty((d.n, d.cout, d.ho // pool, d.wo // pool), dtype=torch.float32, device=dev, memory_format=_CL)
+            rec.add_layer(x, d, cfg, layout, weight, filt, bias, bn_w, bn_b, running_mean, running_var, nbt, gn_w, gn_b, y, out, bn_mean, bn_rstd, gn_mean, gn_rstd)
+            ctx.desc, ctx.cfg = d, cfg
+            ctx.save_for_backward(x, weight, bias, y, bn_w, bn_b, bn_mean, bn_rstd, gn_w, gn_mean, gn_rstd)
+            return out
         ctx.use16 = _use_bf16_storage(d, layout)
         # bf16 storage path: the convolution output, the layer output and (backward) their gradients are bf16 tensors when the streaming chain serves the layer
         ctx.io16 = ctx.use16 and ctx.streaming
@@ -795,6 +823,7 @@ class _Pool2dFn(torch.autograd.Function):
 
 
 def pool2d(x: torch.Tensor, kernel_size, stride=None, padding=0, mode: int = nat.POOL_AVG) -> torch.Tensor:
+    resident.forbid('a standalone pooling')
     x = _f32(x)
     k = _pair(kernel_size)
     s = _pair(stride) if stride is not None else k
@@ -825,6 +854,7 @@ class _InterpFn(torch.autograd.Function):
 
 
 def interpolate_bilinear(x: torch.Tensor, out_hw: Sequence[int], align_corners: bool = False) -> torch.Tensor:
+    resident.forbid('interpolate')
     x = _f32(x)
     return _InterpFn.apply(x, (int(out_hw[0]), int(out_hw[1])), bool(align_corners))
 
@@ -882,6 +912,11 @@ class _ResizeConcatFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, align_corners, *tensors):
         _require_f32(*tensors)
+        rec = resident.recorder()
+        if rec is not None:
+            if not all(_is_nhwc(t) for t in tensors):
+                raise resident.Ineligible('link: NCHW tensors')
+            rec.check_link(tensors, align_corners)
         tensors = [to_nhwc(t) for t in tensors]
         n, _, ho, wo = tensors[0].shape
         k = len(tensors)
@@ -889,6 +924,10 @@ class _ResizeConcatFn(torch.autograd.Function):
         if any(t.shape[0] != n for t in tensors) or k > nat.MAX_CONCAT:
             raise RuntimeError(f'deepcv_amd.resize_concat: unsupported inputs {[tuple(t.shape) for t in tensors]}')
         out = torch.empty((n, sum(chans), ho, wo), dtype=tensors[0].dtype, device=tensors[0].device, memory_format=_CL)
+        if rec is not None:
+            rec.add_link(tensors, align_corners, out)
+            ctx.geom = (n, ho, wo, chans, hs, ws, int(align_corners))
+            return out
         ia = lambda v: (ctypes.c_int * k)(*v)
         nat.check(lib.dcv_resize_concat_channels(k, (ctypes.c_void_p * k)(*[t.data_ptr() for t in tensors]), ia(chans), ia(hs), ia(ws), out.data_ptr(),
                                                  n, ho, wo, int(align_corners), nat.current_stream(out.device)), 'dcv_resize_concat_channels')
@@ -919,6 +958,7 @@ def resize_concat(tensors: Sequence[torch.Tensor], align_corners: bool = False) 
 
 
 def concat_channels(tensors: Sequence[torch.Tensor]) -> torch.Tensor:
+    resident.forbid('concat_channels')
     tensors = [_f32(t) for t in tensors]
     tensors = list(tensors)
     return tensors[0] if len(tensors) == 1 else _ConcatFn.apply(*tensors)
@@ -956,6 +996,7 @@ class _AddFn(torch.autograd.Function):
 
 def add_tensors(tensors: Sequence[torch.Tensor], mean: bool = False) -> torch.Tensor:
     """ Elementwise sum (or mean) of same-shape tensors: the 'sum' / 'mean' link reductions (SURVEY Appendix A #14). """
+    resident.forbid('add_tensors')
     tensors = [_f32(t) for t in tensors]
     tensors = list(tensors)
     if len(tensors) == 1:
@@ -992,6 +1033,7 @@ class _FlattenFn(torch.autograd.Function):
 def flatten_nchw_order(x: torch.Tensor) -> torch.Tensor:
     """ `[N,C,H,W]` (NHWC memory) -> `[N, C*H*W]` in the reference's C-major feature order (what `torch.nn.Flatten` yields on NCHW data),
     so that the stored FC weight keeps the reference layout. """
+    resident.forbid('flatten')
     x = _f32(x)
     if x.dim() == 2:
         return x
@@ -1053,13 +1095,21 @@ class _LinearNhwcFn(torch.autograd.Function):
         n, c, h, w = x.shape
         k, o = c * h * w, weight.shape[0]
         d = _conv_desc(x.shape, (o, c, h, w), (1, 1), (0, 0), (1, 1), nat.LAYOUT_NHWC, nat.ACT_NONE, 0.)
+        rec = resident.recorder()
+        if rec is not None:
+            rec.check_fc(x, o)
         wp = filters.get(weight, d, 2)
         if wp is None:
             raise RuntimeError('deepcv_amd.linear_nhwc: the weight must be a contiguous device tensor')
         ctx.weight_ref, ctx.bias_ref = weight, bias
+        if rec is not None:
+            rec.note(weight if ctx.needs_input_grad[1] else None, bias if ctx.needs_input_grad[2] else None)
         slabs.note_use(weight if ctx.needs_input_grad[1] else None, bias if ctx.needs_input_grad[2] else None)
         y = torch.empty((n, o), dtype=x.dtype, device=x.device)
-        nat.check(lib.dcv_linear_fwd(x.data_ptr(), wp.data_ptr(), nat.ptr(bias), y.data_ptr(), n, k, o, act, slope, nat.current_stream(x.device)), 'dcv_linear_fwd')
+        if rec is not None:
+            rec.add_fc(x, wp, bias, act, slope, y)
+        else:
+            nat.check(lib.dcv_linear_fwd(x.data_ptr(), wp.data_ptr(), nat.ptr(bias), y.data_ptr(), n, k, o, act, slope, nat.current_stream(x.device)), 'dcv_linear_fwd')
         ctx.act, ctx.slope, ctx.has_bias, ctx.desc = act, slope, bias is not None, d
         ctx.save_for_backward(x, weight, y if act != nat.ACT_NONE else None)
         return y
@@ -1101,6 +1151,7 @@ def linear_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = nat.ACT_NONE, slope: float = 0.) -> torch.Tensor:
+    resident.forbid('a linear layer on flattened activations')
     x = _f32(x)
     if x.dim() != 2:
         x = x.reshape(-1, x.shape[-1]) if x.dim() > 2 else x.unsqueeze(0)

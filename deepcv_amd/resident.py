@@ -1,0 +1,242 @@
+""" LDS-resident forward of small-channel models (`dcv_resident_forward`, `deepcv_amd/csrc/resident.hip`).
+
+`DeepcvModule.forward` (reference `src/deepcv/meta/base_module.py:113-155`) walks the sub-modules one by one; on the stock classifier that is ~20 kernel
+launches for five tiny layers.  When the whole model is a chain the resident kernel covers — `layer()` stacks `Conv2d -> act -> BatchNorm2d [-> GroupNorm]`
+(`src/deepcv/meta/nn.py:519-554`) with optional fused average pooling, one dense link with `allow_scaling`, `Flatten` + fully connected head — the forward
+is RECORDED instead of launched: the autograd functions of `deepcv_amd.ops` run as usual (they allocate their outputs and saved tensors and create the same
+autograd nodes, so the backward pass is untouched) but append a `dcv_resident_op` to the active `Recorder` instead of launching their kernels; when the
+outermost `DeepcvModule.forward` returns, ONE persistent launch fills every tensor.  Nothing on the host reads those tensors in between, and everything
+else on the stream is ordered after the launch, so deferring the arithmetic to the end of the walk is invisible.
+
+Recording is transactional: an op the kernel does not cover raises `Ineligible` BEFORE launching anything (every entry point of `deepcv_amd.ops` calls
+`forbid()`), nothing recorded so far has touched a parameter, a buffer or a running statistic, and the forward simply runs again on the per-layer kernels;
+the verdict is cached per (module, input shape, mode).  `DCV_RESIDENT=0` (or `set_enabled(False)`) turns the path off. """
+import ctypes
+import os
+import weakref
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _native as nat
+from ._native import lib
+
+__all__ = ['Ineligible', 'Recorder', 'recorder', 'forbid', 'enabled', 'set_enabled', 'wanted', 'mark_ineligible', 'check_status', 'launches']
+
+_enabled = os.environ.get('DCV_RESIDENT', '1') not in ('0', 'false', 'False', '')
+_active: Optional['Recorder'] = None
+_verdicts: Dict[int, Tuple['weakref.ref', Dict[tuple, str]]] = {}   # id(module) -> (weak reference, {(input shape, training): reason it is not eligible})
+_ws: Dict[torch.device, torch.Tensor] = {}                          # persistent control words + granules per device (zeroed once)
+_launches = 0
+
+
+class Ineligible(Exception):
+    """ The model (or this call of it) is not covered by the resident kernel: the caller re-runs the forward on the per-layer kernels. """
+
+
+def enabled() -> bool:
+    return _enabled
+
+
+def set_enabled(value: bool) -> bool:
+    global _enabled
+    prev, _enabled = _enabled, bool(value)
+    return prev
+
+
+def launches() -> int:
+    """ Number of resident launches recorded so far (tests: did the path actually run?). """
+    return _launches
+
+
+def recorder() -> Optional['Recorder']:
+    return _active
+
+
+def forbid(what: str):
+    """ Called at the top of every op of `deepcv_amd.ops` the resident kernel does not cover. """
+    if _active is not None:
+        raise Ineligible(f'{what} inside the forward')
+
+
+def _verdict_slot(module) -> Dict[tuple, str]:
+    slot = _verdicts.get(id(module))
+    if slot is None or slot[0]() is not module:
+        slot = _verdicts[id(module)] = (weakref.ref(module, lambda _r, k=id(module): _verdicts.pop(k, None)), {})
+    return slot[1]
+
+
+def wanted(module, x) -> bool:
+    """ Should the outermost `DeepcvModule.forward` try to record this call? """
+    if not _enabled or _active is not None or not isinstance(x, torch.Tensor):
+        return False
+    if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and module.training and torch.is_grad_enabled()):
+        return False
+    if torch.is_autocast_enabled():
+        return False
+    from . import ops
+    if ops._conv_math != nat.MATH_FP32 or not ops._norm_streaming:
+        return False
+    return (tuple(x.shape), True) not in _verdict_slot(module)
+
+
+def mark_ineligible(module, x, reason: str):
+    _verdict_slot(module)[(tuple(x.shape), True)] = reason
+
+
+def why_not(module, x) -> Optional[str]:
+    return _verdict_slot(module).get((tuple(x.shape), True))
+
+
+def _workspace(device: torch.device) -> torch.Tensor:
+    ws = _ws.get(device)
+    if ws is None:
+        ws = _ws[device] = torch.zeros(int(lib.dcv_resident_ws_bytes()), dtype=torch.uint8, device=device)
+    return ws
+
+
+def check_status(device=None):
+    """ Raises if a resident launch on `device` gave up waiting for the other blocks of its grid (a grid which is not fully resident: e.g. three processes
+    sharing the GPU).  Synchronises the current stream: call it where the host waits anyway. """
+    for dev, ws in list(_ws.items()):
+        if device is not None and dev != torch.device(device):
+            continue
+        err = ctypes.c_int(0)
+        nat.check(lib.dcv_resident_status(ws.data_ptr(), nat.current_stream(dev), ctypes.byref(err)), 'dcv_resident_status')
+        if err.value:
+            ws[4:8].zero_()
+            raise RuntimeError(f'deepcv_amd.resident: the gather of op {err.value - 1} timed out (the blocks of the persistent launch were not all resident); '
+                               'outputs of that step are invalid. Set DCV_RESIDENT=0 when more than two processes share the GPU.')
+
+
+class Recorder:
+    """ One recorded forward.  `cur` is the tensor the next op must consume (the chain the kernel executes is linear). """
+
+    def __init__(self, x: torch.Tensor):
+        self.x = x
+        self.device = x.device
+        self.n = x.shape[0]
+        self.ops: List[nat.ResidentOp] = []
+        self.keep: List[torch.Tensor] = []
+        self.cur: Optional[torch.Tensor] = x
+        self.noted: List[Optional[torch.Tensor]] = []
+        self.layer_outs: Dict[int, Tuple[int, int, int]] = {}     # data_ptr of a recorded layer output -> (c, h, w)
+
+    # ---- context
+    def __enter__(self):
+        global _active
+        if _active is not None:
+            raise RuntimeError('deepcv_amd.resident: recordings do not nest')
+        _active = self
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _active
+        _active = None
+        if et is not None:                     # aborted: give back the forward uses the recorded ops noted (deepcv_amd.slabs)
+            from . import slabs
+            slabs.unnote_use(*self.noted)
+        return False
+
+    # ---- checks shared by the ops
+    def _consume(self, x: torch.Tensor, what: str):
+        cur = self.cur
+        if cur is None or x.data_ptr() != cur.data_ptr() or tuple(x.shape) != tuple(cur.shape):
+            raise Ineligible(f'{what}: its input is not the previous recorded output (the model is not a chain the resident kernel executes)')
+        if len(self.ops) >= nat.RESIDENT_MAX_OPS:
+            raise Ineligible('more ops than a resident program holds')
+
+    def note(self, *params):
+        self.noted.extend(params)
+
+    def check_layer(self, x: torch.Tensor, d: nat.Conv2dDesc, cfg, layout: int):
+        """ Raises `Ineligible` unless the layer is one the kernel covers; called before the op allocates anything. """
+        stride, padding, dilation, act, slope, momentum, bn_eps, groups, gn_eps, pool = cfg
+        self._consume(x, 'layer')
+        k = d.r
+        if not (d.r == d.s and k % 2 == 1 and tuple(stride) == (1, 1) and tuple(dilation) == (1, 1) and tuple(padding) == (k // 2, k // 2) and d.groups == 1):
+            raise Ineligible(f'layer: convolution geometry {d.r}x{d.s} stride {tuple(stride)} padding {tuple(padding)} dilation {tuple(dilation)}')
+        first = not self.ops
+        if not first and layout != nat.LAYOUT_NHWC:
+            raise Ineligible('layer: NCHW input inside the chain')
+        op = nat.ResidentOp()
+        op.kind, op.cin, op.cout, op.k, op.h, op.w, op.act, op.slope = nat.RES_LAYER, d.cin, d.cout, k, d.h, d.w, act, slope
+        op.bn, op.groups, op.pool = 1, groups, pool
+        probe = nat.ResidentProgram()
+        probe.n, probe.count = self.n, 1
+        probe.op[0] = op
+        for field in ('x', 'filt', 'y', 'out', 'bn_mean', 'bn_rstd', 'gn_mean', 'gn_rstd'):     # shape probe: any non-NULL address
+            setattr(probe.op[0], field, 16)
+        if not first and d.cin % 4:                        # only the staged model input may have a partial channel vector
+            raise Ineligible('layer: channels of an inner layer are not a multiple of 4')
+        if not lib.dcv_resident_supported(probe):
+            raise Ineligible(f'layer: {d.cin}->{d.cout} {k}x{k} @{d.h}x{d.w} groups {groups} pool {pool} is not covered')
+
+    def add_layer(self, x, d: nat.Conv2dDesc, cfg, layout: int, weight, filt, bias, bn_w, bn_b, running_mean, running_var, nbt, gn_w, gn_b,
+                  y, out, bn_mean, bn_rstd, gn_mean, gn_rstd):
+        stride, padding, dilation, act, slope, momentum, bn_eps, groups, gn_eps, pool = cfg
+        op = nat.ResidentOp()
+        op.kind, op.cin, op.cout, op.k, op.h, op.w, op.act, op.slope = nat.RES_LAYER, d.cin, d.cout, d.r, d.h, d.w, act, slope
+        op.bn, op.groups, op.pool, op.momentum, op.bn_eps, op.gn_eps = 1, groups, pool, momentum, bn_eps, gn_eps
+        op.x_nchw = 1 if layout == nat.LAYOUT_NCHW else 0
+        op.x = x.data_ptr() if not self.ops else None
+        op.filt, op.bias = filt.data_ptr(), nat.ptr(bias)
+        op.bn_gamma, op.bn_beta, op.running_mean, op.running_var, op.num_batches_tracked = nat.ptr(bn_w), nat.ptr(bn_b), nat.ptr(running_mean), nat.ptr(running_var), nat.ptr(nbt)
+        op.gn_gamma, op.gn_beta = nat.ptr(gn_w), nat.ptr(gn_b)
+        op.y, op.out, op.bn_mean, op.bn_rstd, op.gn_mean, op.gn_rstd = y.data_ptr(), out.data_ptr(), bn_mean.data_ptr(), bn_rstd.data_ptr(), nat.ptr(gn_mean), nat.ptr(gn_rstd)
+        self.ops.append(op)
+        self.keep.extend(t for t in (x, weight, filt, bias, bn_w, bn_b, running_mean, running_var, nbt, gn_w, gn_b, y, out, bn_mean, bn_rstd, gn_mean, gn_rstd) if t is not None)
+        self.cur = out
+        self.layer_outs[out.data_ptr()] = (out.shape[1], out.shape[2], out.shape[3])
+
+    def check_link(self, tensors, align_corners: bool):
+        if len(tensors) != 2:
+            raise Ineligible('link: more than one referenced tensor')
+        cur, ref = tensors
+        self._consume(cur, 'link')
+        if ref.data_ptr() not in self.layer_outs or self.layer_outs[ref.data_ptr()] != (ref.shape[1], ref.shape[2], ref.shape[3]):
+            raise Ineligible('link: the referenced tensor is not the output of a recorded layer')
+        if cur.shape[1] % 4 or cur.shape[2] * cur.shape[3] * (cur.shape[1] + ref.shape[1]) > 4096:
+            raise Ineligible('link: shape not covered')
+
+    def add_link(self, tensors, align_corners: bool, out: torch.Tensor):
+        cur, ref = tensors
+        op = nat.ResidentOp()
+        op.kind, op.cin, op.h, op.w = nat.RES_LINK, cur.shape[1], cur.shape[2], cur.shape[3]
+        op.ref_c, op.ref_h, op.ref_w, op.align_corners = ref.shape[1], ref.shape[2], ref.shape[3], int(bool(align_corners))
+        op.ref, op.out = ref.data_ptr(), out.data_ptr()
+        self.ops.append(op)
+        self.keep.extend((cur, ref, out))
+        self.cur = out
+
+    def check_fc(self, x: torch.Tensor, out_features: int):
+        self._consume(x, 'fully connected head')
+        if out_features > 16 or (x.shape[1] * x.shape[2] * x.shape[3]) % 4:
+            raise Ineligible('fully connected head: shape not covered')
+
+    def add_fc(self, x, wp, bias, act: int, slope: float, y: torch.Tensor):
+        op = nat.ResidentOp()
+        op.kind, op.cin, op.h, op.w, op.cout, op.act, op.slope = nat.RES_FC, x.shape[1], x.shape[2], x.shape[3], y.shape[1], act, slope
+        op.filt, op.bias, op.out = wp.data_ptr(), nat.ptr(bias), y.data_ptr()
+        self.ops.append(op)
+        self.keep.extend(t for t in (x, wp, bias, y) if t is not None)
+        self.cur = y
+
+    # ---- the launch
+    def finish(self, result):
+        """ `result`: what the model returns; it must be the last recorded output.  Launches the kernel on the current stream. """
+        global _launches
+        if not self.ops:
+            raise Ineligible('nothing was recorded')
+        if not isinstance(result, torch.Tensor) or self.cur is None or result.data_ptr() != self.cur.data_ptr():
+            raise Ineligible('the model output is not the last recorded output')
+        prog = nat.ResidentProgram()
+        prog.n, prog.count = self.n, len(self.ops)
+        for i, op in enumerate(self.ops):
+            prog.op[i] = op
+        if not lib.dcv_resident_supported(prog):
+            raise Ineligible('the recorded program is not covered by the resident kernel')
+        ws = _workspace(self.device)
+        nat.check(lib.dcv_resident_forward(prog, ws.data_ptr(), ws.numel(), nat.current_stream(self.device)), 'dcv_resident_forward')
+        _launches += 1
+        self.keep.clear()

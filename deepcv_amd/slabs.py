@@ -24,7 +24,7 @@ import torch
 from . import _native as nat
 from ._native import lib
 
-__all__ = ['enabled', 'set_enabled', 'note_use', 'may_defer', 'reset_uses', 'defer', 'defer_wgrad', 'flush', 'pending']
+__all__ = ['enabled', 'set_enabled', 'note_use', 'unnote_use', 'may_defer', 'reset_uses', 'defer', 'defer_wgrad', 'flush', 'pending']
 
 _enabled = True
 _lock = threading.Lock()
@@ -60,6 +60,20 @@ def note_use(*params):
                         u = _uses[id(p)] = [0, 0, weakref.ref(p)]
                     u[0] += 1
                     u[1] = max(u[1], u[0])
+
+
+def unnote_use(*params):
+    """ Takes back `note_use` calls of forward ops whose autograd nodes were discarded before any backward (an aborted recording of
+    `deepcv_amd.resident`). """
+    with _lock:
+        for p in params:
+            u = _uses.get(id(p)) if p is not None else None
+            if u is not None and u[2]() is p:
+                u[0] -= 1
+                if u[0] <= 0:
+                    del _uses[id(p)]
+                else:
+                    u[1] = max(1, u[1] - 1)
 
 
 def may_defer(*params) -> bool:

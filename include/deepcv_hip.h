@@ -132,6 +132,7 @@ int dcv_conv2d_wgrad_fuses_bias(const dcv_conv2d_desc* d);
  *                               parameters.yml:87) re-laid as [O][H*W][C]: the dcv_linear_* entry points then read the NHWC activations in place instead
  *                               of a transposed copy (descriptor: h, w, cin of the activations, cout = O, r = h, s = w, stride 1, no padding; the weight
  *                               gradient comes back in [O][C*H*W] order through dcv_slab_segment.tr_a / tr_b)
+ *                               op 3 = the forward filter of a layer of the LDS-resident network (dcv_resident_forward): [R][S][cin rounded up to 4][cout]
  *   dcv_conv2d_prepare_filters  re-lays out `count` filters (entries whose size is 0 are skipped; filters[k] may then be NULL)
  *   dcv_conv2d_*_prepared       as dcv_conv2d_fwd / dcv_conv2d_dgrad with the filter prepared for exactly this descriptor (w still required: fallback paths) */
 size_t dcv_conv2d_filter_bytes(const dcv_conv2d_desc* d, int op);
@@ -511,6 +512,53 @@ int dcv_sgd_step(const dcv_tensor_list* tl, const float* hyper, int nesterov, vo
  * instead (bucket slices padded to 16-B boundaries).  Gradients which the backward kernels already wrote into their slice need no pack at all.
  * ------------------------------------------------------------------------------------------------- */
 int dcv_pack_grads(const dcv_tensor_list* tl, float* dst_flat, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * LDS-resident network (resident.hip): the training forward of a small-channel DeepcvModule as ONE persistent launch.
+ * replaces the per-sub-module dispatch of DeepcvModule.forward (src/deepcv/meta/base_module.py:113-155) over `layer()` stacks
+ * (src/deepcv/meta/nn.py:519-554: Conv2d -> act -> BatchNorm2d [-> GroupNorm]), avg_pooling (submodule_creators.py:163-176), dense links
+ * (submodule_creators.py:272-332) and the Flatten + fully connected head (parameters.yml:87-88), for models whose per-sample activations fit the LDS.
+ * One block of 1024 threads keeps TWO samples resident in LDS from the input image to the logits; grid = ceil(n / 2) <= 256 blocks, all co-resident
+ * (<= 80 KB of LDS per block: two such grids fit the chip).  The only traffic between blocks is the BatchNorm batch statistics: per layer every block
+ * publishes its sums of y and y^2 as 8-byte {epoch, value} granules and gathers everybody's (agent-scope stores / loads, no fence, bounded spin);
+ * GroupNorm, pooling, the link and the head are per-sample and stay inside the block.  Every tensor the per-layer backward kernels read (y, the layer
+ * outputs, the saved statistics) is written to HBM exactly as the per-layer forward writes it.
+ *   program     ops in execution order; each op consumes the previous op's output (the first one the model input `x`)
+ *   LAYER       conv (stride 1, padding k / 2) + bias + act [+ BatchNorm, batch statistics + running statistics] [+ GroupNorm] [+ avg pool `pool` x `pool`]
+ *               `filt`: the filter prepared with dcv_conv2d_prepare_filters op 3 ([k][k][cin rounded up to 4][cout]); 16 -> 16 channels: the OIHW weight
+ *   LINK        channel concatenation [current, bilinear resize of `ref` to the current size] (dense link with allow_scaling); `ref` must be the `out`
+ *               of an earlier LAYER of this program; must be followed by FC or end the program
+ *   FC          Flatten + Linear (+ act) on the NHWC activations: `filt` = the [O][H*W][C] weight (dcv_conv2d_prepare_filters op 2), `out` = logits
+ *   ws          persistent, zero-initialised once by the caller (dcv_resident_ws_bytes): launch generation, error word, granules.  After a launch whose
+ *               gather timed out (a block not resident: another grid holds the CUs) err != 0 and the logits are NaN: dcv_resident_status reads it.
+ * ------------------------------------------------------------------------------------------------- */
+#define DCV_RESIDENT_MAX_OPS 10
+#define DCV_RES_LAYER 1
+#define DCV_RES_LINK 2
+#define DCV_RES_FC 3
+typedef struct dcv_resident_op {
+    int kind;
+    int cin, cout, k, h, w;            /* LAYER: convolution geometry (h, w: input = output size); LINK: cin, h, w of the current tensor; FC: cin, h, w of its input, cout = out features */
+    int act; float slope;              /* LAYER, FC */
+    int bn, groups, pool;              /* LAYER: BatchNorm present, GroupNorm groups (0: none), average pooling window (0: none) */
+    float momentum, bn_eps, gn_eps;
+    int x_nchw;                        /* first op: the model input is NCHW (else NHWC) */
+    int ref_c, ref_h, ref_w, align_corners;   /* LINK */
+    const float* x;                    /* first op: the model input */
+    const float* filt; const float* bias;
+    const float* bn_gamma; const float* bn_beta; float* running_mean; float* running_var; int64_t* num_batches_tracked;
+    const float* gn_gamma; const float* gn_beta;
+    float* y;                          /* LAYER: [n][h][w][cout] activated convolution output (saved for the backward pass) */
+    float* out;                        /* LAYER: layer output [n][h/pool][w/pool][cout]; LINK: the wide tensor; FC: logits [n][cout] */
+    float* bn_mean; float* bn_rstd; float* gn_mean; float* gn_rstd;   /* saved statistics, as dcv_norm_chain_desc */
+    const float* ref;                  /* LINK: [n][ref_h][ref_w][ref_c] */
+} dcv_resident_op;
+typedef struct dcv_resident_program { int n; int count; dcv_resident_op op[DCV_RESIDENT_MAX_OPS]; } dcv_resident_program;
+int dcv_resident_supported(const dcv_resident_program* p);           /* 1 when the resident kernel covers every op of the program */
+size_t dcv_resident_ws_bytes(void);
+int dcv_resident_forward(const dcv_resident_program* p, void* ws, size_t ws_bytes, void* stream);
+/* host read of the error word of `ws` (synchronises the stream): 0, or 1 + index of the op whose gather timed out */
+int dcv_resident_status(const void* ws, void* stream, int* err);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,123 @@
+""" The LDS-resident forward (`dcv_resident_forward`, deepcv_amd/resident.py) against the per-layer kernels and the CPU oracle: same model, same seed, same
+batch.  The per-layer path is itself oracle-checked (tests/test_model_gpu.py), so agreement to rounding here pins the resident kernel; the oracle comparison
+at the bench batch size is repeated directly. """
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SEED, DATA_SEED = 563454, 434546
+
+
+def _model(params, spec, device):
+    from deepcv_amd.classification.image import create_model
+    from deepcv_amd.meta.data.datasets import SyntheticImageDataset
+    torch.manual_seed(SEED)
+    return create_model({'trainset': SyntheticImageDataset(8)}, params[spec]).to(device)
+
+
+def _run(model, x, y, resident_on):
+    from deepcv_amd import modules, resident
+    prev = resident.set_enabled(resident_on)
+    try:
+        before = resident.launches()
+        model.train()
+        logits = model(x)
+        loss = modules.CrossEntropyLoss()(logits, y)
+        loss.backward()
+        torch.cuda.synchronize()
+        resident.check_status()
+        return logits.detach().clone(), loss.item(), resident.launches() - before
+    finally:
+        resident.set_enabled(prev)
+
+
+@pytest.mark.parametrize('bs', [2, 7, 64, 511, 512])
+def test_resident_forward_matches_per_layer_kernels(device, params, bs):
+    """ Logits, loss, every parameter gradient (the backward pass reads the tensors the resident launch saved: y, layer outputs, BatchNorm / GroupNorm
+    statistics) and the running statistics, against the per-layer path.  Odd batch sizes leave a block with one sample. """
+    from deepcv_amd import resident
+    g = torch.Generator().manual_seed(DATA_SEED)
+    x, y = torch.randn(bs, 3, 32, 32, generator=g).to(device), torch.randint(0, 10, (bs,), generator=g).to(device)
+    a, b = _model(params, 'image_classifier_model', device), _model(params, 'image_classifier_model', device)
+    la, loss_a, n_a = _run(a, x, y, True)
+    lb, loss_b, n_b = _run(b, x, y, False)
+    assert n_a == 1, f'the resident path did not run: {resident.why_not(a, x)}'
+    assert n_b == 0
+    scale = lb.abs().max().item()
+    assert (la - lb).abs().max().item() <= 2e-6 * max(scale, 1.0), (la - lb).abs().max().item()
+    assert abs(loss_a - loss_b) <= 1e-6 * abs(loss_b)
+    # large batches: the two forwards differ in the last bit of the BatchNorm sums, 2e6 pre-activations per layer put about one ReLU within that distance of
+    # its kink, and one flipped pixel moves a weight gradient (a sum of 5e5 terms of random sign) by ~1e-3 of its size (tests/test_model_gpu.py)
+    rel = 2e-4 if bs <= 64 else 1e-2
+    gscale = max(p.grad.abs().max().item() for p in b.parameters())
+    for (name, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        err = (pa.grad - pb.grad).abs().max().item()
+        assert err <= rel * pb.grad.abs().max().item() + 2e-6 * gscale, f'{name}: {err:.3e} (max {pb.grad.abs().max().item():.3e})'
+    for (name, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
+        assert torch.allclose(ba.float(), bb.float(), rtol=1e-5, atol=1e-7), name
+
+
+def test_resident_forward_matches_oracle_at_the_bench_batch(device, params):
+    """ BASELINE.json bars on the resident path itself: logits rtol 1e-3, loss rtol 1e-4 against the CPU oracle at bs 512. """
+    from deepcv_amd import resident
+    from oracle import deepcv_oracle as O
+    g = torch.Generator().manual_seed(DATA_SEED)
+    x, y = torch.randn(512, 3, 32, 32, generator=g), torch.randint(0, 10, (512,), generator=g)
+    model = _model(params, 'image_classifier_model', device)
+    torch.manual_seed(SEED)
+    oracle = O.create_model((3, 32, 32), params['image_classifier_model'], 10)
+    oracle.train()
+    lo = oracle(x)
+    loss_o = torch.nn.functional.cross_entropy(lo, y).item()
+    ln, loss_n, n = _run(model, x.to(device), y.to(device), True)
+    assert n == 1, resident.why_not(model, x.to(device))
+    rel = ((ln.cpu() - lo.detach()).abs().max() / lo.detach().abs().max()).item()
+    assert rel <= 1e-3 and abs(loss_n - loss_o) <= 1e-4 * abs(loss_o), (rel, loss_n, loss_o)
+
+
+def test_models_the_kernel_does_not_cover_fall_back(device, params):
+    """ A wide spec is not a resident program: the recording aborts before anything is launched, the verdict is cached, the per-layer kernels serve it. """
+    from deepcv_amd import modules, resident
+    from deepcv_amd.classification.image import create_model
+    from deepcv_amd.meta.data.datasets import SyntheticImageDataset
+    torch.manual_seed(SEED)
+    model = create_model({'trainset': SyntheticImageDataset(4, num_classes=100)}, params['cifar100_deep_model']).to(device)
+    x, y = torch.randn(4, 3, 32, 32, device=device), torch.randint(0, 100, (4,), device=device)
+    before = resident.launches()
+    model.train()
+    rm0 = [b.clone() for b in model.buffers()]
+    loss = modules.CrossEntropyLoss()(model(x), y)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert resident.launches() == before and resident.why_not(model, x) is not None
+    assert torch.isfinite(loss).item() and all(p.grad is not None for p in model.parameters())
+    # the aborted recording touched no running statistic: exactly ONE update happened
+    nbt = [b for n, b in model.named_buffers() if n.endswith('num_batches_tracked')]
+    assert all(int(b) == 1 for b in nbt)
+    assert not resident.wanted(model, x)          # cached verdict: no second recording attempt
+    del rm0
+
+
+def test_replayed_graph_on_the_resident_path_tracks_eager(device, params):
+    """ The persistent launch inside a captured step: 4 replays against 4 eager steps, bit for bit (the launch generation lives in device memory). """
+    from deepcv_amd import modules, optim, resident
+    from deepcv_amd.meta.ignite_training import GraphedTrainStep, _setup_losses
+    g = torch.Generator().manual_seed(DATA_SEED)
+    batches = [(torch.randn(64, 3, 32, 32, generator=g).to(device), torch.randint(0, 10, (64,), generator=g).to(device)) for _ in range(6)]
+    curves = []
+    for graph in (True, False):
+        model = _model(params, 'image_classifier_model', device)
+        opt = optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-2)
+        losses, weights = _setup_losses(modules.CrossEntropyLoss(), None, device)
+        step = GraphedTrainStep(model, opt, losses, weights)
+        before = resident.launches()
+        got = []
+        for xb, yb in batches:
+            out, _ = step(xb, yb) if graph else step._eager(xb, yb)
+            got.append(out['main_loss'].item())
+        torch.cuda.synchronize()
+        resident.check_status()
+        assert resident.launches() > before
+        curves.append(got)
+    assert curves[0] == curves[1], curves
