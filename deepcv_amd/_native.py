@@ -77,6 +77,7 @@ class ResidentOp(ctypes.Structure):
     """ `dcv_resident_op` """
     _fields_ = [('kind', _c_int), ('cin', _c_int), ('cout', _c_int), ('k', _c_int), ('h', _c_int), ('w', _c_int), ('act', _c_int), ('slope', _c_float),
                 ('bn', _c_int), ('groups', _c_int), ('pool', _c_int), ('momentum', _c_float), ('bn_eps', _c_float), ('gn_eps', _c_float), ('x_nchw', _c_int),
+                ('reserved', _c_int), ('inv_count', ctypes.c_double), ('unbias', ctypes.c_double), ('inv_group', ctypes.c_double),
                 ('ref_c', _c_int), ('ref_h', _c_int), ('ref_w', _c_int), ('align_corners', _c_int),
                 ('x', _c_void_p), ('filt', _c_void_p), ('bias', _c_void_p), ('bn_gamma', _c_void_p), ('bn_beta', _c_void_p), ('running_mean', _c_void_p),
                 ('running_var', _c_void_p), ('num_batches_tracked', _c_void_p), ('gn_gamma', _c_void_p), ('gn_beta', _c_void_p), ('y', _c_void_p), ('out', _c_void_p),

@@ -32,7 +32,8 @@ constexpr int RS_MAXC = 16;         // channels of a resident layer
 constexpr int RS_MAXQ = 2 * RS_MAXC;
 constexpr int RS_MAXG = 256;        // blocks
 constexpr int RS_SPINS = 1 << 16;   // gather polls before giving up (each at least a memory round trip: tens of milliseconds)
-constexpr size_t RS_CTL_BYTES = 256;
+constexpr size_t RS_CTL_BYTES = 1024;  // [0] launch generation, [1] error word, [4..): time stamps of block 0 (64-bit, 100 MHz): tools/resident_stamps.py
+constexpr int RS_MAX_STAMPS = 120;
 
 typedef unsigned long long rs_u64;
 typedef __attribute__((address_space(1))) rs_u64 rs_gu64;
@@ -46,11 +47,35 @@ constexpr size_t RS_XIN_BYTES = (size_t)RS_SPB * RS_XIN * 16, RS_Y_BYTES = (size
 constexpr size_t RS_ARR_OFF = 0, RS_PART_OFF = (size_t)RS_MAXQ * RS_MAXG * 4, RS_WP_OFF = RS_PART_OFF + (size_t)RS_MAXQ * 16 * 8;
 static_assert(RS_WP_OFF + 16 * 2 * RS_MAXC * 4 <= RS_XIN_BYTES, "gather scratch must fit the input tile");
 
-__device__ __forceinline__ int rs_variant(int cin, int cout, int k) {
+// Workgroup barrier which only drains the LDS / scalar counter.  `__syncthreads()` also waits for every outstanding global STORE of the wave (vmcnt(0)):
+// with 32 KB of y / layer-output stores in flight per phase that wait was 2 us per barrier, although nothing in this launch reads those bytes back
+// (the one exception, the link's referenced tensor, sits behind a full __syncthreads()).  Loads are tracked by the compiler per register as usual.
+__device__ __forceinline__ void rs_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+typedef float rs_f4 __attribute__((ext_vector_type(4)));
+
+// 1: cin <= 4 -> 4 (VALU, row pairs)   4: cin <= 4 -> 16 on rows of 16 pixels (MFMA, K = 4)   2: cin <= 4 -> 8 / 16 otherwise (VALU)   3: 16 -> 16 (MFMA)
+__host__ __device__ __forceinline__ int rs_variant(int cin, int cout, int k, int w) {
     if (cin <= 4 && cout == 4 && (k == 3 || k == 5)) return 1;
+    if (cin <= 4 && cout == 16 && (k == 1 || k == 3) && w == 16) return 4;
     if (cin <= 4 && (cout == 8 || cout == 16) && (k == 1 || k == 3)) return 2;
-    if (cin == 16 && cout == 16 && k == 3) return 3;
+    if (cin == 16 && cout == 16 && k == 3 && w == 16) return 3;
     return 0;
+}
+
+// Sum over the 64 lanes without the LDS crossbar (`__shfl_xor` is ds_bpermute_b32: sixteen waves reducing eight values each kept the LDS pipe busy for
+// 1.5 us per layer): four DPP steps inside each row of 16 lanes, then the four row sums through v_readlane.  Result on every lane (wave-uniform).
+template <int CTRL> __device__ __forceinline__ float rs_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float rs_wave_sum(float v) {
+    v += rs_dpp<0xB1>(v);                       // quad_perm [1, 0, 3, 2]
+    v += rs_dpp<0x4E>(v);                       // quad_perm [2, 3, 0, 1]
+    v += rs_dpp<0x141>(v);                      // row_half_mirror
+    v += rs_dpp<0x140>(v);                      // row_mirror
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 __device__ __forceinline__ double rs_rsqrt(double v) {                   // as norm_chain.hip: fp32 estimate + two Newton steps in fp64
@@ -114,55 +139,92 @@ __device__ __forceinline__ void rs_conv_c4_co4(const dcv_resident_op& o, const f
     }
 }
 
-// one pixel x 8 output channels per item; items of a wave share (sample, channel half): H * W is a multiple of 64
+// cin <= 4 -> 8 / 16 channels: one pixel x 4 output channels per item, one filter row (K taps x 4 x 4 scalars) at a time; the items of a wave share
+// (sample, channel quarter): H * W is a multiple of 64
 template <int K>
 __device__ __forceinline__ void rs_conv_c4_wide(const dcv_resident_op& o, const float4* xin, float* yt) {
-    const int H = o.h, W = o.w, pad = K / 2, XW = W + 2 * pad, HW = H * W, CO = o.cout, nh = CO >> 3;
-    const int per = HW * nh;
+    const int H = o.h, W = o.w, pad = K / 2, XW = W + 2 * pad, HW = H * W, CO = o.cout, nq = CO >> 2;
+    const int per = HW * nq;
     for (int it = threadIdx.x; it < RS_SPB * per; it += RS_T) {
         const int s = __builtin_amdgcn_readfirstlane(it >= per ? 1 : 0), rem = it - s * per;
-        const int half = __builtin_amdgcn_readfirstlane(rem / HW), px = rem - half * HW, r = px / W, col = px - r * W;
+        const int qt = __builtin_amdgcn_readfirstlane(rem / HW), px = rem - qt * HW, r = px / W, col = px - r * W;
         const float4* xs = xin + s * RS_XIN + r * XW + col;
-        rs_cfloat* wl = RS_CONST(o.filt) + half * 8;                                 // [K][K][4][CO]
-        float acc[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+        rs_cfloat* wl = RS_CONST(o.filt) + qt * 4;                                   // [K][K][4][CO]
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-        for (int tap = 0; tap < K * K; ++tap) {
-            const int ky = tap / K, kx = tap - ky * K;
-            const float4 xv = xs[ky * XW + kx];
-            rs_cfloat* wt = wl + tap * 4 * CO;
+        for (int ky = 0; ky < K; ++ky) {
+            float4 xv[K];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                acc[c] = fmaf(xv.x, wt[c], acc[c]);
-                acc[c] = fmaf(xv.y, wt[CO + c], acc[c]);
-                acc[c] = fmaf(xv.z, wt[2 * CO + c], acc[c]);
-                acc[c] = fmaf(xv.w, wt[3 * CO + c], acc[c]);
+            for (int kx = 0; kx < K; ++kx) xv[kx] = xs[ky * XW + kx];
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                rs_cfloat* wt = wl + (ky * K + kx) * 4 * CO;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    acc[c] = fmaf(xv[kx].x, wt[c], acc[c]);
+                    acc[c] = fmaf(xv[kx].y, wt[CO + c], acc[c]);
+                    acc[c] = fmaf(xv[kx].z, wt[2 * CO + c], acc[c]);
+                    acc[c] = fmaf(xv[kx].w, wt[3 * CO + c], acc[c]);
+                }
             }
         }
-        float* yp = yt + s * RS_Y + px * CO + half * 8;
-        float v[8];
+        float v[4];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] = dcv_act_apply(acc[c] + (o.bias ? RS_CONST(o.bias)[half * 8 + c] : 0.f), o.act, o.slope);
-        reinterpret_cast<float4*>(yp)[0] = make_float4(v[0], v[1], v[2], v[3]);
-        reinterpret_cast<float4*>(yp)[1] = make_float4(v[4], v[5], v[6], v[7]);
+        for (int c = 0; c < 4; ++c) v[c] = dcv_act_apply(acc[c] + (o.bias ? RS_CONST(o.bias)[qt * 4 + c] : 0.f), o.act, o.slope);
+        reinterpret_cast<float4*>(yt + s * RS_Y + px * CO + qt * 4)[0] = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
-typedef float rs_f4 __attribute__((ext_vector_type(4)));
-
 // 16 -> 16 channels, 3x3, W == 16: a wave owns image rows; per tap one ds_read_b128 (plane k = lane / 16: channels 4k .. 4k + 3 of pixel lane % 16)
 // feeds four v_mfma_f32_16x16x4_f32 (MFMA j contracts channels {j, 4 + j, 8 + j, 12 + j}).
-__device__ __forceinline__ void rs_conv_c16_mfma(const dcv_resident_op& o, const float4* xin, float* yt) {
+// cin <= 4 -> 16 channels on rows of 16 pixels: ONE v_mfma_f32_16x16x4_f32 per tap (K = the 4 input channels of the pixel's float4).  A: lane (pixel
+// m = lane % 16, channel k = lane / 16) reads one float of the tile; B: w[co = lane % 16][ci = lane / 16][tap] straight from the OIHW filter (zero for
+// ci >= cin).  Two image rows per wave on the stock 16x16 maps: 18 MFMAs.
+template <int K>
+__device__ __forceinline__ void rs_conv_c4_mfma(const dcv_resident_op& o, const float4* xin, float* yt) {
+    const int H = o.h, pad = K / 2, XW = 16 + 2 * pad;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4;
+    float breg[K * K];
+    {
+        const float* wp = o.filt + ((size_t)m * o.cin + (kq < o.cin ? kq : 0)) * (K * K);
+#pragma unroll
+        for (int q = 0; q < K * K; ++q) breg[q] = wp[q];
+        if (kq >= o.cin) {
+#pragma unroll
+            for (int q = 0; q < K * K; ++q) breg[q] = 0.f;
+        }
+    }
+    const float bias = o.bias ? o.bias[m] : 0.f;
+    const float* xf = reinterpret_cast<const float*>(xin);
+    for (int row = wave; row < RS_SPB * H; row += 16) {
+        const int s = row >= H ? 1 : 0, r = row - s * H;
+        const float* xs = xf + ((size_t)s * RS_XIN + r * XW + m) * 4 + kq;
+        rs_f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[(ky * XW + kx) * 4], breg[ky * K + kx], acc, 0, 0, 0);
+        float* yp = yt + s * RS_Y + (r * 16 + 4 * kq) * 16 + m;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) yp[i * 16] = dcv_act_apply(acc[i] + bias, o.act, o.slope);
+    }
+}
+
+// B fragments: lane (n = co = lane % 16, k = lane / 16) needs w[co][4k + j][tap], j < 4, tap < 9: 36 contiguous floats of the OIHW filter.  Requested by
+// the PREVIOUS layer's apply step (a global round trip, 1 - 2 us, which nothing there waits for).
+__device__ __forceinline__ void rs_load_bfrag(const float* w, float4 (&b4)[9]) {
+    const int lane = threadIdx.x & 63, m = lane & 15, kq = lane >> 4;
+    const float4* wp = reinterpret_cast<const float4*>(w + ((size_t)m * 16 + 4 * kq) * 9);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) b4[q] = wp[q];
+}
+
+__device__ __forceinline__ void rs_conv_c16_mfma(const dcv_resident_op& o, const float4* xin, float* yt, const float4 (&b4)[9]) {
     const int H = o.h, XW = 18, XH = H + 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4;
-    // B fragments: lane (n = co = lane % 16, k = lane / 16) needs w[co][4k + j][tap], j < 4, tap < 9: 36 contiguous floats of the OIHW filter
     float breg[36];
-    {
-        const float4* wp = reinterpret_cast<const float4*>(o.filt + ((size_t)m * 16 + 4 * kq) * 9);
 #pragma unroll
-        for (int q = 0; q < 9; ++q) { const float4 v = wp[q]; breg[4 * q] = v.x; breg[4 * q + 1] = v.y; breg[4 * q + 2] = v.z; breg[4 * q + 3] = v.w; }
-    }
+    for (int q = 0; q < 9; ++q) { breg[4 * q] = b4[q].x; breg[4 * q + 1] = b4[q].y; breg[4 * q + 2] = b4[q].z; breg[4 * q + 3] = b4[q].w; }
     const float bias = o.bias ? o.bias[m] : 0.f;
     for (int row = wave; row < RS_SPB * H; row += 16) {
         const int s = row >= H ? 1 : 0, r = row - s * H;
@@ -206,80 +268,126 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
     const int s_of_t = t >> 9, tt = t & 511;                                         // sample-major split of the block for the per-sample passes
     const int N = p.n, G = (int)gridDim.x;
     const bool valid0 = (int)blockIdx.x * RS_SPB < N, valid1 = (int)blockIdx.x * RS_SPB + 1 < N;
+    __shared__ float s_par[DCV_RESIDENT_MAX_OPS][6][RS_MAXC];                        // per-channel parameters of every layer: bn gamma, beta, running mean, var, gn gamma, beta
     if (t == 0) { s_gen = __hip_atomic_load((rs_gu32*)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_fail = 0; }
-    for (int i = t; i < RS_SPB * RS_XIN; i += RS_T) xin[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
-    const unsigned gen = s_gen;
-    {   // stage the two samples into the first layer's padded tile
+    int n_stamp = 0;
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(ctl + 4);
+    auto stamp = [&]() { if (blockIdx.x == 0 && t == 0 && n_stamp < RS_MAX_STAMPS) stamps[1 + n_stamp] = wall_clock64(); ++n_stamp; };
+    stamp();
+    {   // ONE global round trip: every layer's per-channel parameters -> LDS (the coefficient phases never wait for memory), the two samples -> the first
+        // layer's padded tile (loads issued before the tile is zeroed)
+        float pv = 0.f; int pslot = -1;
+        if (t < p.count * 6 * RS_MAXC) {
+            const int oi = t / (6 * RS_MAXC), r = t - oi * 6 * RS_MAXC, f = r / RS_MAXC, c = r - f * RS_MAXC;
+            const dcv_resident_op& o = p.op[oi];
+            if (o.kind == DCV_RES_LAYER && c < o.cout) {
+                const float* src = f == 0 ? o.bn_gamma : f == 1 ? o.bn_beta : f == 2 ? o.running_mean : f == 3 ? o.running_var : f == 4 ? o.gn_gamma : o.gn_beta;
+                pslot = t;
+                pv = (f == 0 || f == 4) ? 1.f : 0.f;
+                if (src != nullptr) pv = src[c];
+            }
+        }
+        // ... and one float of every 64-B line of every filter: the scalar loads of the convolutions then find them in L2 instead of HBM
+        {
+            const int oi = t >> 6, line = t & 63;
+            if (oi < p.count && p.op[oi].kind == DCV_RES_LAYER) {
+                const dcv_resident_op& w = p.op[oi];
+                const int floats = w.k * w.k * ((w.cin + 3) & ~3) * w.cout;
+                for (int f = line * 16; f < floats; f += 64 * 16) { const float v = w.filt[f]; asm volatile("" :: "v"(v)); }
+            }
+        }
         const dcv_resident_op& o = p.op[0];
         const int pad = o.k / 2, XW = o.w + 2 * pad, XH = o.h + 2 * pad, HW = o.h * o.w, C = o.cin;
         const int n = (int)blockIdx.x * RS_SPB + s_of_t;
-        if (n < N) {
-            float* dst = xinf + (size_t)s_of_t * RS_XIN * 4;
-            if (!o.x_nchw && (C & 3) == 0) {
-                const float4* src = reinterpret_cast<const float4*>(o.x) + (size_t)n * HW * (C >> 2);
-                for (int e = tt; e < HW * (C >> 2); e += 512) {
-                    const int px = e / (C >> 2), cv = e - px * (C >> 2), r = px / o.w, col = px - r * o.w;
-                    reinterpret_cast<float4*>(dst)[(cv * XH + r + pad) * XW + col + pad] = src[e];
+        constexpr int SB = 8;                                                        // elements per thread in flight
+        const bool vec = !o.x_nchw && (C & 3) == 0;
+        const int total = vec ? HW * (C >> 2) : HW * C;
+        float4 v4[SB]; float v1[SB];
+        const float* src = o.x + (size_t)(n < N ? n : 0) * HW * C;
+        if (vec) {
+#pragma unroll
+            for (int k = 0; k < SB; ++k) { const int e = tt + k * 512; v4[k] = reinterpret_cast<const float4*>(src)[e < total ? e : 0]; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < SB; ++k) { const int e = tt + k * 512; v1[k] = src[e < total ? e : 0]; }
+        }
+        for (int i = t; i < RS_SPB * RS_XIN; i += RS_T) xin[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        rs_barrier();
+        if (pslot >= 0) (&s_par[0][0][0])[pslot] = pv;
+        float* dst = xinf + (size_t)s_of_t * RS_XIN * 4;
+        for (int e0 = 0; e0 < total; e0 += SB * 512) {
+            if (e0 > 0) {                                                            // samples larger than SB * 512 elements: further batches
+#pragma unroll
+                for (int k = 0; k < SB; ++k) {
+                    const int e = e0 + tt + k * 512;
+                    if (vec) v4[k] = reinterpret_cast<const float4*>(src)[e < total ? e : 0]; else v1[k] = src[e < total ? e : 0];
                 }
-            } else {
-                const float* src = o.x + (size_t)n * HW * C;
-                for (int e = tt; e < HW * C; e += 512) {
-                    int c, px;
-                    if (o.x_nchw) { c = e / HW; px = e - c * HW; } else { px = e / C; c = e - px * C; }
-                    const int r = px / o.w, col = px - r * o.w;
-                    dst[(((c >> 2) * XH + r + pad) * XW + col + pad) * 4 + (c & 3)] = src[e];
+            }
+#pragma unroll
+            for (int k = 0; k < SB; ++k) {
+                const int e = e0 + tt + k * 512;
+                if (e < total && n < N) {
+                    if (vec) {
+                        const int px = e / (C >> 2), cv = e - px * (C >> 2), r = px / o.w, col = px - r * o.w;
+                        reinterpret_cast<float4*>(dst)[(cv * XH + r + pad) * XW + col + pad] = v4[k];
+                    } else {
+                        int c, px;
+                        if (o.x_nchw) { c = e / HW; px = e - c * HW; } else { px = e / C; c = e - px * C; }
+                        const int r = px / o.w, col = px - r * o.w;
+                        dst[(((c >> 2) * XH + r + pad) * XW + col + pad) * 4 + (c & 3)] = v1[k];
+                    }
                 }
             }
         }
     }
-    __syncthreads();
+    rs_barrier();
+    const unsigned gen = s_gen;
+    stamp();
+    bool conv_done = false;                                                          // this layer's convolution already ran (behind the previous apply step)
     int fc_from_y = 0;                                                               // the FC input is the wide tensor a LINK left in yt
     for (int oi = 0; oi < p.count; ++oi) {
         const dcv_resident_op& o = p.op[oi];
         if (o.kind == DCV_RES_LAYER) {
             const int C = o.cout, CV = C >> 2, H = o.h, W = o.w, HW = H * W;
             // ---- convolution + bias + activation: xin -> yt
-            const int var = rs_variant(o.cin, o.cout, o.k);
-            if (var == 1) { if (o.k == 5) rs_conv_c4_co4<5>(o, xin, yt); else rs_conv_c4_co4<3>(o, xin, yt); }
-            else if (var == 2) { if (o.k == 3) rs_conv_c4_wide<3>(o, xin, yt); else rs_conv_c4_wide<1>(o, xin, yt); }
-            else rs_conv_c16_mfma(o, xin, yt);
-            __syncthreads();
-            // ---- y -> HBM (saved for the backward pass) and the per-sample sums of y, y^2: thread = fixed channel vector (512 % CV == 0)
-            {
-                const int n = (int)blockIdx.x * RS_SPB + s_of_t;
+            const int var = rs_variant(o.cin, o.cout, o.k, o.w);
+            if (!conv_done) {
+                if (var == 1) { if (o.k == 5) rs_conv_c4_co4<5>(o, xin, yt); else rs_conv_c4_co4<3>(o, xin, yt); }
+                else if (var == 2) { if (o.k == 3) rs_conv_c4_wide<3>(o, xin, yt); else rs_conv_c4_wide<1>(o, xin, yt); }
+                else if (var == 4) { if (o.k == 3) rs_conv_c4_mfma<3>(o, xin, yt); else rs_conv_c4_mfma<1>(o, xin, yt); }
+                else { float4 b4[9]; rs_load_bfrag(o.filt, b4); rs_conv_c16_mfma(o, xin, yt, b4); }
+                rs_barrier();
+            }
+            conv_done = false;
+            stamp();
+            // ---- per-sample sums of y, y^2.  Wave w8 of the sample (8 waves) owns channel vector w8 % CV and every (8 / CV)-th stripe of 64 pixels, so one
+            // full-wave sum per quantity finishes its part (CV is 1, 2 or 4).  (y goes to HBM in the apply step: a global store here would sit in front of
+            // the gather's loads in the wave's in-order memory counter.)
+            if (o.bn || o.groups) {
+                const int w8 = wave & 7, cv = w8 & (CV - 1), stripes = 8 / CV, st0 = w8 / CV;
                 const float4* ys = reinterpret_cast<const float4*>(yt + s_of_t * RS_Y);
-                float4* yg = reinterpret_cast<float4*>(o.y) + (size_t)n * HW * CV;
                 float sum[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
-                for (int i = tt; i < HW * CV; i += 512) {
-                    const float4 v = ys[i];
-                    if (n < N) yg[i] = v;
+                for (int px = st0 * 64 + lane; px < HW; px += stripes * 64) {
+                    const float4 v = ys[px * CV + cv];
                     sum[0] += v.x; sum[1] += v.y; sum[2] += v.z; sum[3] += v.w;
                     sq[0] += v.x * v.x; sq[1] += v.y * v.y; sq[2] += v.z * v.z; sq[3] += v.w * v.w;
                 }
-                if (o.bn || o.groups) {
 #pragma unroll
-                    for (int off = 32; off > 0; off >>= 1)
-                        if (off >= CV) {
+                for (int j = 0; j < 4; ++j) { sum[j] = rs_wave_sum(sum[j]); sq[j] = rs_wave_sum(sq[j]); }
+                if (lane == 0) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) { sum[j] += __shfl_xor(sum[j], off, 64); sq[j] += __shfl_xor(sq[j], off, 64); }
-                        }
-                    if (lane < CV) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) { wpart[(wave * 2) * RS_MAXC + lane * 4 + j] = sum[j]; wpart[(wave * 2 + 1) * RS_MAXC + lane * 4 + j] = sq[j]; }
-                    }
+                    for (int j = 0; j < 4; ++j) { wpart[(wave * 2) * RS_MAXC + j] = sum[j]; wpart[(wave * 2 + 1) * RS_MAXC + j] = sq[j]; }       // [wave][q][j]
                 }
-            }
-            __syncthreads();
-            if (o.bn || o.groups) {
+                rs_barrier();
                 if (t < RS_SPB * 2 * C) {
-                    const int ss = t / (2 * C), r = t - ss * 2 * C, q = r / C, c = r - q * C;
+                    const int ss = t / (2 * C), r = t - ss * 2 * C, q = r / C, c = r - q * C, ccv = c >> 2, j = c & 3;
                     float v = 0.f;
-                    for (int w8 = 0; w8 < 8; ++w8) v += wpart[((ss * 8 + w8) * 2 + q) * RS_MAXC + c];
+                    for (int k = 0; k < stripes; ++k) v += wpart[((ss * 8 + k * CV + ccv) * 2 + q) * RS_MAXC + j];
                     s_samp[ss][q][c] = v;
                 }
-                __syncthreads();
+                rs_barrier();
             }
+            stamp();
             if (o.bn) {
                 // ---- batch statistics: publish this block's 2C sums, gather every block's
                 const unsigned epoch = gen * DCV_RESIDENT_MAX_OPS + (unsigned)oi + 1u;
@@ -291,15 +399,16 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                 }
                 const int total = 2 * C * G;
                 bool ok = true;
-                for (int i0 = 0; i0 < total; i0 += RS_T * 4) {                       // <= 4 granules per thread and sweep
-                    int idx[4]; float gv[4];
+                constexpr int GP = RS_MAXQ * RS_MAXG / RS_T;                         // granules per thread: all of a sweep's loads are in flight together
+                for (int i0 = 0; i0 < total; i0 += RS_T * GP) {
+                    int idx[GP]; float gv[GP];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) { const int i = i0 + k * RS_T + t; const int q = i / G; idx[k] = i < total ? q * RS_MAXG + (i - q * G) : -1; }
+                    for (int k = 0; k < GP; ++k) { const int i = i0 + k * RS_T + t; const int q = i / G; idx[k] = i < total ? q * RS_MAXG + (i - q * G) : -1; }
                     bool got = false;
                     for (int spins = 0; spins < RS_SPINS; ++spins) {
                         got = true;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
+                        for (int k = 0; k < GP; ++k) {
                             if (idx[k] >= 0) {
                                 const rs_u64 g = __hip_atomic_load((rs_gu64*)(go + idx[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 gv[k] = __uint_as_float((unsigned)g);
@@ -311,10 +420,10 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                     }
                     ok &= (bool)__all(got);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) if (idx[k] >= 0) arr[idx[k]] = gv[k];
+                    for (int k = 0; k < GP; ++k) if (idx[k] >= 0) arr[idx[k]] = gv[k];
                 }
                 if (!ok && lane == 0) s_fail = 1;
-                __syncthreads();
+                rs_barrier();
                 if (s_fail) {                                                        // a block of this grid is not resident: report, poison the logits, leave
                     if (t == 0) { __hip_atomic_store((rs_gu32*)(ctl + 1), (unsigned)oi + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                     for (int k = 0; k < p.count; ++k)
@@ -325,6 +434,7 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                             }
                     return;
                 }
+                stamp();
                 // fixed-order fp64 sums: 16 partial sums of <= 16 blocks per quantity, then the 16 partials
                 if (t < 2 * C * 16) {
                     const int q = t >> 4, j = t & 15;
@@ -332,25 +442,25 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                     for (int i = j * 16; i < j * 16 + 16 && i < G; ++i) v += (double)arr[q * RS_MAXG + i];
                     part[q * 16 + j] = v;
                 }
-                __syncthreads();
+                rs_barrier();
                 if (t < C) {
                     double s1 = 0.0, s2 = 0.0;
                     for (int j = 0; j < 16; ++j) { s1 += part[t * 16 + j]; s2 += part[(C + t) * 16 + j]; }
-                    const double count = (double)N * (double)HW, mean = s1 / count;
-                    double varc = s2 / count - mean * mean; if (varc < 0.0) varc = 0.0;
+                    const double mean = s1 * o.inv_count;
+                    double varc = s2 * o.inv_count - mean * mean; if (varc < 0.0) varc = 0.0;
                     const float rstd = (float)rs_rsqrt(varc + (double)o.bn_eps);
-                    const float g = o.bn_gamma ? o.bn_gamma[t] : 1.f, b = o.bn_beta ? o.bn_beta[t] : 0.f;
+                    const float g = s_par[oi][0][t], b = s_par[oi][1][t];
                     const float sc = g * rstd;
                     s_ab[0][t] = sc; s_ab[1][t] = b - (float)mean * sc;
                     if (blockIdx.x == 0) {                                           // saved / running statistics: written once
                         o.bn_mean[t] = (float)mean; o.bn_rstd[t] = rstd;
-                        if (o.running_mean) o.running_mean[t] = (1.f - o.momentum) * o.running_mean[t] + o.momentum * (float)mean;
-                        if (o.running_var) { const double unb = count > 1.0 ? varc * count / (count - 1.0) : varc; o.running_var[t] = (1.f - o.momentum) * o.running_var[t] + o.momentum * (float)unb; }
+                        if (o.running_mean) o.running_mean[t] = (1.f - o.momentum) * s_par[oi][2][t] + o.momentum * (float)mean;
+                        if (o.running_var) { const double unb = varc * o.unbias; o.running_var[t] = (1.f - o.momentum) * s_par[oi][3][t] + o.momentum * (float)unb; }
                         if (t == 0 && o.num_batches_tracked) o.num_batches_tracked[0] += 1;
                     }
                 }
             } else if (t < C) { s_ab[0][t] = 1.f; s_ab[1][t] = 0.f; }
-            __syncthreads();
+            rs_barrier();
             // ---- per-sample affine of the layer output: GroupNorm of the BatchNorm output (norm_chain.hip, nc_apply_kernel's prologue)
             if (o.groups > 0) {
                 const int cpg = C / o.groups;
@@ -363,25 +473,40 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                     s_grp[ss][0][c] = ad * s1 + hw * bd;
                     s_grp[ss][1][c] = ad * ad * s2 + 2.0 * ad * bd * s1 + hw * bd * bd;
                 }
-                __syncthreads();
+                rs_barrier();
                 if (own) {
                     const int g = c / cpg, g0 = g * cpg;
                     double sv = 0.0, svv = 0.0;
                     for (int k = g0; k < g0 + cpg; ++k) { sv += s_grp[ss][0][k]; svv += s_grp[ss][1][k]; }
-                    const double inv_m = 1.0 / ((double)cpg * (double)HW), mean = sv * inv_m;
+                    const double inv_m = o.inv_group, mean = sv * inv_m;
                     double varc = svv * inv_m - mean * mean; if (varc < 0.0) varc = 0.0;
                     const float rstd = (float)rs_rsqrt(varc + (double)o.gn_eps);
                     const int n = (int)blockIdx.x * RS_SPB + ss;
                     if (c == g0 && n < N) { o.gn_mean[(size_t)n * o.groups + g] = (float)mean; o.gn_rstd[(size_t)n * o.groups + g] = rstd; }
-                    const float gg = o.gn_gamma ? o.gn_gamma[c] : 1.f, gb = o.gn_beta ? o.gn_beta[c] : 0.f;
+                    const float gg = s_par[oi][4][c], gb = s_par[oi][5][c];
                     s_S[ss][c] = a * rstd * gg;
                     s_T[ss][c] = (b - (float)mean) * rstd * gg + gb;
                 }
             } else if (t < RS_SPB * C) { const int ss = t / C, c = t - ss * C; s_S[ss][c] = s_ab[0][c]; s_T[ss][c] = s_ab[1][c]; }
+            stamp();
             // ---- apply: out = S y + T [averaged over pool windows] -> HBM and the next op's input tile
-            for (int i = t; i < RS_SPB * RS_XIN; i += RS_T) xin[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            __syncthreads();
-            {
+            {   // the gather scratch lived in the input tile: re-zero the halo of the NEXT layer's tile (its interior is rewritten below; flat tiles have none)
+                const bool nl = oi + 1 < p.count && p.op[oi + 1].kind == DCV_RES_LAYER;
+                if (nl) {
+                    const int pk = o.pool > 0 ? o.pool : 1, Ho = H / pk, Wo = W / pk, np = p.op[oi + 1].k / 2, XWn = Wo + 2 * np, XHn = Ho + 2 * np;
+                    const int rows_part = 2 * np * XWn, halo = rows_part + Ho * 2 * np, planes = RS_SPB * CV;
+                    for (int i = t; i < planes * halo; i += RS_T) {
+                        const int pl = i / halo, e = i - pl * halo;
+                        int r, c;
+                        if (e < rows_part) { r = e / XWn; c = e - r * XWn; if (r >= np) r += Ho; }
+                        else { const int e2 = e - rows_part; r = e2 / (2 * np); c = e2 - r * 2 * np; r += np; if (c >= np) c += Wo; }
+                        const int ss = pl / CV, cvp = pl - ss * CV;
+                        xin[ss * RS_XIN + (cvp * XHn + r) * XWn + c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+            }
+            rs_barrier();
+            auto apply_step = [&]() {
                 const int pk = o.pool > 0 ? o.pool : 1, Ho = H / pk, Wo = W / pk;
                 const bool nxt_layer = oi + 1 < p.count && p.op[oi + 1].kind == DCV_RES_LAYER;
                 const int npad = nxt_layer ? p.op[oi + 1].k / 2 : 0, XWn = Wo + 2 * npad, XHn = Ho + 2 * npad;
@@ -391,22 +516,39 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                     const int ss = it >= per ? 1 : 0, e = it - ss * per, px = e / CV, cv = e - px * CV, ho = px / Wo, wo = px - ho * Wo;
                     const float* S = s_S[ss] + cv * 4; const float* T = s_T[ss] + cv * 4;
                     float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                    const int n = (int)blockIdx.x * RS_SPB + ss;
+                    float4* yg = reinterpret_cast<float4*>(o.y) + (size_t)(n < N ? n : 0) * HW * CV;
                     for (int kh = 0; kh < pk; ++kh)
                         for (int kw = 0; kw < pk; ++kw) {
-                            const float4 v = reinterpret_cast<const float4*>(yt + ss * RS_Y)[((ho * pk + kh) * W + wo * pk + kw) * CV + cv];
+                            const int yi = ((ho * pk + kh) * W + wo * pk + kw) * CV + cv;
+                            const float4 v = reinterpret_cast<const float4*>(yt + ss * RS_Y)[yi];
+                            if (n < N) yg[yi] = v;                                   // y -> HBM (saved for the backward pass): every element passes here once
                             acc[0] += v.x * S[0] + T[0]; acc[1] += v.y * S[1] + T[1]; acc[2] += v.z * S[2] + T[2]; acc[3] += v.w * S[3] + T[3];
                         }
                     float4 r4;
                     if (o.pool > 0) r4 = make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv); else r4 = make_float4(acc[0], acc[1], acc[2], acc[3]);
-                    const int n = (int)blockIdx.x * RS_SPB + ss;
-                    if (n < N) {
-                        reinterpret_cast<float4*>(o.out)[((size_t)n * Ho * Wo + px) * CV + cv] = r4;
-                        if (nxt_layer) xin[ss * RS_XIN + (cv * XHn + ho + npad) * XWn + wo + npad] = r4;
-                        else reinterpret_cast<float4*>(xinf + (size_t)ss * RS_XIN * 4)[px * CV + cv] = r4;       // flat NHWC for a LINK / FC
-                    }
+                    if (n < N) reinterpret_cast<float4*>(o.out)[((size_t)n * Ho * Wo + px) * CV + cv] = r4;
+                    else r4 = make_float4(0.f, 0.f, 0.f, 0.f);                       // (a block's missing second sample: keep its tile finite)
+                    if (nxt_layer) xin[ss * RS_XIN + (cv * XHn + ho + npad) * XWn + wo + npad] = r4;
+                    else reinterpret_cast<float4*>(xinf + (size_t)ss * RS_XIN * 4)[px * CV + cv] = r4;           // flat NHWC for a LINK / FC
                 }
+            };
+            if (oi + 1 < p.count && p.op[oi + 1].kind == DCV_RES_LAYER && rs_variant(p.op[oi + 1].cin, p.op[oi + 1].cout, p.op[oi + 1].k, p.op[oi + 1].w) == 3) {
+                // the next layer runs on the matrix cores: its B fragments are requested before this step's stores (a global round trip nothing waits
+                // for), and its convolution runs right here so that the 36 registers do not live across the op loop
+                float4 b4[9];
+                rs_load_bfrag(p.op[oi + 1].filt, b4);
+                apply_step();
+                rs_barrier();
+                stamp();
+                rs_conv_c16_mfma(p.op[oi + 1], xin, yt, b4);
+                rs_barrier();
+                conv_done = true;
+            } else {
+                apply_step();
+                rs_barrier();
+                stamp();
             }
-            __syncthreads();
             fc_from_y = 0;
         } else if (o.kind == DCV_RES_LINK) {
             // wide[px][0 .. cin) = current (flat NHWC in xin), wide[px][cin ..) = bilinear resize of ref to (h, w): -> HBM and yt (flat NHWC)
@@ -414,6 +556,7 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
             const float sh = o.align_corners ? (o.h > 1 ? (float)(o.ref_h - 1) / (float)(o.h - 1) : 0.f) : (float)o.ref_h / (float)o.h;
             const float sw = o.align_corners ? (o.w > 1 ? (float)(o.ref_w - 1) / (float)(o.w - 1) : 0.f) : (float)o.ref_w / (float)o.w;
             const int per = HW * Cw;
+            __syncthreads();                                                         // full: every wave's earlier global stores (the referenced tensor) are done
             for (int it = t; it < RS_SPB * per; it += RS_T) {
                 const int ss = it >= per ? 1 : 0, e = it - ss * per, px = e / Cw, c = e - px * Cw;
                 const int n = (int)blockIdx.x * RS_SPB + ss;
@@ -437,7 +580,8 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                 yt[ss * RS_Y + e] = v;
                 o.out[(size_t)n * per + e] = v;
             }
-            __syncthreads();
+            rs_barrier();
+            stamp();
             fc_from_y = 1;
         } else if (o.kind == DCV_RES_FC) {
             // logits[n][j] = act(bias[j] + sum_k x[n][k] w[j][k]), K = h * w * cin floats of the sample's flat NHWC activations; 32 lanes per (sample, j)
@@ -447,27 +591,36 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
             float acc = 0.f;
             if (j < O) {
                 const float4* wr = reinterpret_cast<const float4*>(o.filt) + (size_t)j * K4;
-                for (int k = l32; k < K4; k += 32) { const float4 a = xs[k], b = wr[k]; acc += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+                constexpr int FB = 10;                                               // weight vectors in flight per lane (the stock head: all of them)
+                for (int k0 = l32; k0 < K4; k0 += 32 * FB) {
+                    float4 b[FB];
+#pragma unroll
+                    for (int u = 0; u < FB; ++u) { const int k = k0 + 32 * u; b[u] = wr[k < K4 ? k : 0]; }
+#pragma unroll
+                    for (int u = 0; u < FB; ++u) {
+                        const int k = k0 + 32 * u;
+                        if (k < K4) { const float4 a = xs[k]; acc += a.x * b[u].x + a.y * b[u].y + a.z * b[u].z + a.w * b[u].w; }
+                    }
+                }
             }
 #pragma unroll
             for (int off = 16; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
             if (j < O && l32 == 0 && n < N) o.out[(size_t)n * O + j] = dcv_act_apply(acc + (o.bias ? o.bias[j] : 0.f), o.act, o.slope);
-            __syncthreads();
+            rs_barrier();
+            stamp();
         }
     }
     // every block read `gen` before its first publication and block 0 only gets here after it has gathered everybody's: the next launch is stream-ordered
-    if (blockIdx.x == 0 && t == 0) __hip_atomic_store((rs_gu32*)ctl, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x == 0 && t == 0) { stamps[0] = (unsigned long long)n_stamp; __hip_atomic_store((rs_gu32*)ctl, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
 
 inline bool rs_layer_ok(const dcv_resident_op& o, bool first) {
-    const int var = (o.cin <= 4 && o.cout == 4 && (o.k == 3 || o.k == 5)) ? 1 : (o.cin <= 4 && (o.cout == 8 || o.cout == 16) && (o.k == 1 || o.k == 3)) ? 2
-                    : (o.cin == 16 && o.cout == 16 && o.k == 3) ? 3 : 0;
+    const int var = rs_variant(o.cin, o.cout, o.k, o.w);
     if (var == 0 || o.h <= 0 || o.w <= 0 || o.cin <= 0) return false;
     const int pad = o.k / 2, cvin = (o.cin + 3) / 4;
     if (cvin * (o.h + 2 * pad) * (o.w + 2 * pad) > RS_XIN || o.h * o.w * o.cout > RS_Y) return false;
     if (var == 1 && (o.h & 1)) return false;
     if (var == 2 && (o.h * o.w) % 64 != 0) return false;
-    if (var == 3 && o.w != 16) return false;
     if (!first && (o.cin & 3)) return false;                      // only the staged model input may have a partial channel vector
     if (o.act < DCV_ACT_NONE || o.act > DCV_ACT_TANH || !o.filt || !o.y || !o.out) return false;
     if (o.bn && !(o.bn_mean && o.bn_rstd)) return false;

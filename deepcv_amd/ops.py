@@ -681,7 +681,7 @@ class _ConvNormLayerFn(torch.autograd.Function):
             if not ctx.streaming:
                 raise resident.Ineligible('layer: the streaming norm chain does not cover its backward')
             ctx.use16 = ctx.io16 = False
-            filt = weight if (d.cin == 16 and d.cout == 16) else filters.get(weight, d, 3)
+            filt = weight if resident.reads_oihw(d) else filters.get(weight, d, 3)
             if filt is None:
                 raise resident.Ineligible('layer: no resident filter layout')
             y = torch.empty((d.n, d.cout, d.ho, d.wo), dtype=torch.float32, device=dev, memory_format=_CL)

@@ -59,6 +59,12 @@ def forbid(what: str):
         raise Ineligible(f'{what} inside the forward')
 
 
+def reads_oihw(d: nat.Conv2dDesc) -> bool:
+    """ The matrix-core variants of the resident kernel (16 output channels on rows of 16 pixels) take their B fragments straight from the OIHW weight;
+    the others read the prepared [k][k][cin4][cout] filter (`dcv_conv2d_prepare_filters` op 3) through the scalar cache (`rs_variant`, resident.hip). """
+    return d.cout == 16 and d.w == 16 and ((d.cin == 16 and d.r == 3) or (d.cin <= 4 and d.r in (1, 3)))
+
+
 def _verdict_slot(module) -> Dict[tuple, str]:
     slot = _verdicts.get(id(module))
     if slot is None or slot[0]() is not module:
@@ -179,6 +185,9 @@ class Recorder:
         op.kind, op.cin, op.cout, op.k, op.h, op.w, op.act, op.slope = nat.RES_LAYER, d.cin, d.cout, d.r, d.h, d.w, act, slope
         op.bn, op.groups, op.pool, op.momentum, op.bn_eps, op.gn_eps = 1, groups, pool, momentum, bn_eps, gn_eps
         op.x_nchw = 1 if layout == nat.LAYOUT_NCHW else 0
+        count = float(d.n) * d.h * d.w
+        op.inv_count, op.unbias = 1.0 / count, (count / (count - 1.0) if count > 1.0 else 1.0)
+        op.inv_group = 1.0 / (float(d.h * d.w) * (d.cout // groups)) if groups else 0.0
         op.x = x.data_ptr() if not self.ops else None
         op.filt, op.bias = filt.data_ptr(), nat.ptr(bias)
         op.bn_gamma, op.bn_beta, op.running_mean, op.running_var, op.num_batches_tracked = nat.ptr(bn_w), nat.ptr(bn_b), nat.ptr(running_mean), nat.ptr(running_var), nat.ptr(nbt)

@@ -543,6 +543,9 @@ typedef struct dcv_resident_op {
     int bn, groups, pool;              /* LAYER: BatchNorm present, GroupNorm groups (0: none), average pooling window (0: none) */
     float momentum, bn_eps, gn_eps;
     int x_nchw;                        /* first op: the model input is NCHW (else NHWC) */
+    int reserved;
+    double inv_count, unbias, inv_group;   /* LAYER, filled by the caller: 1 / (n h w), n h w / (n h w - 1) (1 when n h w == 1), 1 / (h w cout / groups): the kernel
+                                          multiplies by them instead of dividing in fp64 on a few lanes */
     int ref_c, ref_h, ref_w, align_corners;   /* LINK */
     const float* x;                    /* first op: the model input */
     const float* filt; const float* bias;

@@ -1,0 +1,42 @@
+"""Phase times of the resident forward launch (block 0's 100 MHz time stamps, `resident.hip`): stock model, bs 512, inside replayed training steps.
+usage: resident_stamps.py [steps]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from deepcv_amd import modules, optim, resident
+from deepcv_amd.classification.image import create_model
+from deepcv_amd.meta.data.datasets import SyntheticImageDataset
+from deepcv_amd.meta.ignite_training import GraphedTrainStep, _setup_losses
+from deepcv_amd.utils import load_parameters
+
+dev = torch.device('cuda:0')
+params = load_parameters()
+torch.manual_seed(1)
+model = create_model({'trainset': SyntheticImageDataset(8)}, params['image_classifier_model']).to(dev)
+opt = optim.AdamW(model.parameters(), lr=1e-3)
+losses, weights = _setup_losses(modules.CrossEntropyLoss(), None, dev)
+step = GraphedTrainStep(model, opt, losses, weights)
+bs = int(os.environ.get('BS', '512'))
+x, y = torch.randn(bs, 3, 32, 32, device=dev), torch.randint(0, 10, (bs,), device=dev)
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+acc = None
+for i in range(steps):
+    step(x, y)
+    torch.cuda.synchronize()
+    ws = resident._ws[dev]
+    st = ws[16:16 + 8 * 121].view(torch.int64).cpu()
+    n = int(st[0])
+    t = st[1:1 + n].double() * 0.01      # us
+    d = t[1:] - t[:-1]
+    if i >= 5:
+        acc = d if acc is None else acc + d
+        cnt = i - 4
+names = ['stage input']
+for l in range(5):
+    names += [f'L{l + 1} conv', f'L{l + 1} sums + y store', f'L{l + 1} gather', f'L{l + 1} coefficients', f'L{l + 1} apply']
+names += ['link', 'fc']
+tot = 0.
+for k, v in enumerate((acc / cnt).tolist()):
+    print(f'{names[k] if k < len(names) else k:28s} {v:7.2f} us')
+    tot += v
+print(f'{"total (block 0)":28s} {tot:7.2f} us')
