@@ -42,10 +42,10 @@ typedef __attribute__((address_space(4))) const float rs_cfloat;       // consta
 #define RS_CONST(p) ((rs_cfloat*)(unsigned long long)(p))
 
 // LDS map (dynamic): xin [RS_SPB][RS_XIN] float4 | yt [RS_SPB][RS_Y] float.  While xin is dead (between a layer's convolution and its apply step) it holds
-// the gathered sums `arr` [RS_MAXQ][RS_MAXG] float (32 KB), the fp64 partials (4 KB) and the per-wave sums (2 KB).
+// the gathered sums `arr` [RS_MAXQ][RS_MAXG] float (32 KB) and their fp64 partials (4 KB).
 constexpr size_t RS_XIN_BYTES = (size_t)RS_SPB * RS_XIN * 16, RS_Y_BYTES = (size_t)RS_SPB * RS_Y * 4, RS_SMEM = RS_XIN_BYTES + RS_Y_BYTES;
-constexpr size_t RS_ARR_OFF = 0, RS_PART_OFF = (size_t)RS_MAXQ * RS_MAXG * 4, RS_WP_OFF = RS_PART_OFF + (size_t)RS_MAXQ * 16 * 8;
-static_assert(RS_WP_OFF + 16 * 2 * RS_MAXC * 4 <= RS_XIN_BYTES, "gather scratch must fit the input tile");
+constexpr size_t RS_ARR_OFF = 0, RS_PART_OFF = (size_t)RS_MAXQ * RS_MAXG * 4;
+static_assert(RS_PART_OFF + (size_t)RS_MAXQ * 16 * 8 <= RS_XIN_BYTES, "gather scratch must fit the input tile");
 
 // Workgroup barrier which only drains the LDS / scalar counter.  `__syncthreads()` also waits for every outstanding global STORE of the wave (vmcnt(0)):
 // with 32 KB of y / layer-output stores in flight per phase that wait was 2 us per barrier, although nothing in this launch reads those bytes back
@@ -84,19 +84,48 @@ __device__ __forceinline__ double rs_rsqrt(double v) {                   // as n
     return r * (1.5 - 0.5 * v * r * r);
 }
 
+// Exact x / d for 0 <= x < 2^20, 0 < d < 2^12 with inv = 1.f / d: the index decodes of the short phases (a 32-bit integer division is ~40 VALU
+// instructions, and with 16 waves on 4 SIMDs every instruction of a phase costs 16 cycles of the block's time)
+__device__ __forceinline__ int rs_fdiv(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
+
+// Sums of the 8 values of every lane over the 64 lanes in ~30 instructions instead of 8 butterflies: each exchange step also halves what a lane keeps
+// (xor 1: half of the values, xor 2: half again), two rotations inside the rows of 16 lanes, two ds_bpermute across the rows.  On return lane l holds,
+// in r[0] and r[1], the totals of values (l & 1) * 4 + ((l >> 1) & 1) * 2 + {0, 1}; lanes 0 - 3 together hold all eight.
+template <int CTRL> __device__ __forceinline__ float rs_dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ void rs_reduce8(const float (&v)[8], float (&r)[2]) {
+    const int lane = threadIdx.x & 63;
+    const bool b0 = lane & 1, b1 = lane & 2;
+    float a[4], b[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float mine = b0 ? v[4 + i] : v[i], send = b0 ? v[i] : v[4 + i]; a[i] = mine + rs_dpp_mov<0xB1>(send); }     // quad_perm [1, 0, 3, 2]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const float mine = b1 ? a[2 + i] : a[i], send = b1 ? a[i] : a[2 + i]; b[i] = mine + rs_dpp_mov<0x4E>(send); }     // quad_perm [2, 3, 0, 1]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        b[i] += rs_dpp_mov<0x124>(b[i]);        // row_ror:4
+        b[i] += rs_dpp_mov<0x128>(b[i]);        // row_ror:8
+        b[i] += __shfl_xor(b[i], 16, 64);
+        b[i] += __shfl_xor(b[i], 32, 64);
+        r[i] = b[i];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ convolutions (LDS -> LDS)
 // Input tile of sample s: plane cv of [XH][XW] float4 at xin + s * RS_XIN + cv * XH * XW.  Output: yt[s * RS_Y + (r * W + c) * Cout + co].
+// Waves 0 - 7 work on the block's first sample, waves 8 - 15 on the second.  Every wave leaves its sums of y and y^2 per output channel in
+// wsum[wave][2][RS_MAXC] (zeros where it had no pixel), except the scalar wide variant (returns false: the caller runs a pass over yt).
 
 template <int K>
-__device__ __forceinline__ void rs_conv_c4_co4(const dcv_resident_op& o, const float4* xin, float* yt) {
-    const int H = o.h, W = o.w, pad = K / 2, XW = W + 2 * pad, XH = H + 2 * pad;
-    const int per = (H >> 1) * W;                                                    // pixel pairs per sample
+__device__ __forceinline__ bool rs_conv_c4_co4(const dcv_resident_op& o, const float4* xin, float* yt, float* wsum) {
+    const int H = o.h, W = o.w, pad = K / 2, XW = W + 2 * pad;
+    const int per = (H >> 1) * W;                                                    // pixel pairs per sample (<= 512)
+    const int t = threadIdx.x, s = t >> 9, p = t & 511, lane = t & 63, wave = t >> 6;
     rs_cfloat* wl = RS_CONST(o.filt);                                                // [K][K][4][4]
-    float b[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) b[c] = o.bias ? RS_CONST(o.bias)[c] : 0.f;
-    for (int it = threadIdx.x; it < RS_SPB * per; it += RS_T) {
-        const int s = it >= per ? 1 : 0, p = it - s * per, rp = p / W, col = p - rp * W;
+    float q8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p < per) {
+        const int rp = rs_fdiv(p, 1.f / (float)W), col = p - rp * W;
         const float4* xs = xin + s * RS_XIN + (rp * 2) * XW + col;
         float acc[2][4];
 #pragma unroll
@@ -128,21 +157,31 @@ __device__ __forceinline__ void rs_conv_c4_co4(const dcv_resident_op& o, const f
 #pragma unroll
             for (int sx = 0; sx < K; ++sx) old[sx] = nw[sx];
         }
-        (void)XH;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             float v[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = dcv_act_apply(acc[k][c] + b[c], o.act, o.slope);
+            for (int c = 0; c < 4; ++c) {
+                v[c] = dcv_act_apply(acc[k][c] + (o.bias ? RS_CONST(o.bias)[c] : 0.f), o.act, o.slope);
+                q8[c] += v[c]; q8[4 + c] += v[c] * v[c];
+            }
             reinterpret_cast<float4*>(yt + s * RS_Y)[(rp * 2 + k) * W + col] = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
+    float r[2];
+    rs_reduce8(q8, r);                                                               // value index = quantity * 4 + channel
+    if (lane < 4) {
+        const int vi = (lane & 1) * 4 + ((lane >> 1) & 1) * 2;                       // r[0], r[1] = values vi, vi + 1
+        wsum[(wave * 2 + (vi >> 2)) * RS_MAXC + (vi & 3)] = r[0];
+        wsum[(wave * 2 + (vi >> 2)) * RS_MAXC + (vi & 3) + 1] = r[1];
+    }
+    return true;
 }
 
-// cin <= 4 -> 8 / 16 channels: one pixel x 4 output channels per item, one filter row (K taps x 4 x 4 scalars) at a time; the items of a wave share
-// (sample, channel quarter): H * W is a multiple of 64
+// cin <= 4 -> 8 / 16 channels, any map: one pixel x 4 output channels per item, one filter row (K taps x 4 x 4 scalars) at a time; the items of a wave
+// share (sample, channel quarter): H * W is a multiple of 64.  (The stock 4 -> 16 layer on 16-pixel rows runs on the matrix cores instead.)
 template <int K>
-__device__ __forceinline__ void rs_conv_c4_wide(const dcv_resident_op& o, const float4* xin, float* yt) {
+__device__ __forceinline__ bool rs_conv_c4_wide(const dcv_resident_op& o, const float4* xin, float* yt, float* wsum) {
     const int H = o.h, W = o.w, pad = K / 2, XW = W + 2 * pad, HW = H * W, CO = o.cout, nq = CO >> 2;
     const int per = HW * nq;
     for (int it = threadIdx.x; it < RS_SPB * per; it += RS_T) {
@@ -173,17 +212,29 @@ __device__ __forceinline__ void rs_conv_c4_wide(const dcv_resident_op& o, const 
         for (int c = 0; c < 4; ++c) v[c] = dcv_act_apply(acc[c] + (o.bias ? RS_CONST(o.bias)[qt * 4 + c] : 0.f), o.act, o.slope);
         reinterpret_cast<float4*>(yt + s * RS_Y + px * CO + qt * 4)[0] = make_float4(v[0], v[1], v[2], v[3]);
     }
+    (void)wsum;
+    return false;
 }
 
-// 16 -> 16 channels, 3x3, W == 16: a wave owns image rows; per tap one ds_read_b128 (plane k = lane / 16: channels 4k .. 4k + 3 of pixel lane % 16)
-// feeds four v_mfma_f32_16x16x4_f32 (MFMA j contracts channels {j, 4 + j, 8 + j, 12 + j}).
+// MFMA epilogue shared by the two matrix-core variants: D holds pixels 4 * (lane / 16) + i of the row, output channel lane % 16
+__device__ __forceinline__ void rs_mfma_store(const dcv_resident_op& o, const rs_f4& acc, float bias, float* yp, float& sum, float& sq) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float v = dcv_act_apply(acc[i] + bias, o.act, o.slope); yp[i * 16] = v; sum += v; sq += v * v; }
+}
+__device__ __forceinline__ void rs_mfma_sums(float sum, float sq, float* wsum) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    sum += __shfl_xor(sum, 16, 64); sq += __shfl_xor(sq, 16, 64);
+    sum += __shfl_xor(sum, 32, 64); sq += __shfl_xor(sq, 32, 64);
+    if (lane < 16) { wsum[(wave * 2) * RS_MAXC + lane] = sum; wsum[(wave * 2 + 1) * RS_MAXC + lane] = sq; }
+}
+
 // cin <= 4 -> 16 channels on rows of 16 pixels: ONE v_mfma_f32_16x16x4_f32 per tap (K = the 4 input channels of the pixel's float4).  A: lane (pixel
 // m = lane % 16, channel k = lane / 16) reads one float of the tile; B: w[co = lane % 16][ci = lane / 16][tap] straight from the OIHW filter (zero for
-// ci >= cin).  Two image rows per wave on the stock 16x16 maps: 18 MFMAs.
+// ci >= cin).  Wave w of a sample owns the rows w, w + 8, ...: 18 MFMAs on the stock 16x16 maps.
 template <int K>
-__device__ __forceinline__ void rs_conv_c4_mfma(const dcv_resident_op& o, const float4* xin, float* yt) {
+__device__ __forceinline__ bool rs_conv_c4_mfma(const dcv_resident_op& o, const float4* xin, float* yt, float* wsum) {
     const int H = o.h, pad = K / 2, XW = 16 + 2 * pad;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4, s = wave >> 3;
     float breg[K * K];
     {
         const float* wp = o.filt + ((size_t)m * o.cin + (kq < o.cin ? kq : 0)) * (K * K);
@@ -196,18 +247,18 @@ __device__ __forceinline__ void rs_conv_c4_mfma(const dcv_resident_op& o, const 
     }
     const float bias = o.bias ? o.bias[m] : 0.f;
     const float* xf = reinterpret_cast<const float*>(xin);
-    for (int row = wave; row < RS_SPB * H; row += 16) {
-        const int s = row >= H ? 1 : 0, r = row - s * H;
+    float sum = 0.f, sq = 0.f;
+    for (int r = wave & 7; r < H; r += 8) {
         const float* xs = xf + ((size_t)s * RS_XIN + r * XW + m) * 4 + kq;
         rs_f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ky = 0; ky < K; ++ky)
 #pragma unroll
             for (int kx = 0; kx < K; ++kx) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[(ky * XW + kx) * 4], breg[ky * K + kx], acc, 0, 0, 0);
-        float* yp = yt + s * RS_Y + (r * 16 + 4 * kq) * 16 + m;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) yp[i * 16] = dcv_act_apply(acc[i] + bias, o.act, o.slope);
+        rs_mfma_store(o, acc, bias, yt + s * RS_Y + (r * 16 + 4 * kq) * 16 + m, sum, sq);
     }
+    rs_mfma_sums(sum, sq, wsum);
+    return true;
 }
 
 // B fragments: lane (n = co = lane % 16, k = lane / 16) needs w[co][4k + j][tap], j < 4, tap < 9: 36 contiguous floats of the OIHW filter.  Requested by
@@ -219,15 +270,17 @@ __device__ __forceinline__ void rs_load_bfrag(const float* w, float4 (&b4)[9]) {
     for (int q = 0; q < 9; ++q) b4[q] = wp[q];
 }
 
-__device__ __forceinline__ void rs_conv_c16_mfma(const dcv_resident_op& o, const float4* xin, float* yt, const float4 (&b4)[9]) {
+// 16 -> 16 channels, 3x3, rows of 16 pixels: per tap one ds_read_b128 (plane k = lane / 16: channels 4k .. 4k + 3 of pixel lane % 16) feeds four
+// v_mfma_f32_16x16x4_f32 (MFMA j contracts channels {j, 4 + j, 8 + j, 12 + j}).
+__device__ __forceinline__ bool rs_conv_c16_mfma(const dcv_resident_op& o, const float4* xin, float* yt, const float4 (&b4)[9], float* wsum) {
     const int H = o.h, XW = 18, XH = H + 2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4, s = wave >> 3;
     float breg[36];
 #pragma unroll
     for (int q = 0; q < 9; ++q) { breg[4 * q] = b4[q].x; breg[4 * q + 1] = b4[q].y; breg[4 * q + 2] = b4[q].z; breg[4 * q + 3] = b4[q].w; }
     const float bias = o.bias ? o.bias[m] : 0.f;
-    for (int row = wave; row < RS_SPB * H; row += 16) {
-        const int s = row >= H ? 1 : 0, r = row - s * H;
+    float sum = 0.f, sq = 0.f;
+    for (int r = wave & 7; r < H; r += 8) {
         const float4* xs = xin + s * RS_XIN + (kq * XH + r) * XW + m;
         rs_f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -241,11 +294,10 @@ __device__ __forceinline__ void rs_conv_c16_mfma(const dcv_resident_op& o, const
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, breg[18 + tap], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, breg[27 + tap], acc, 0, 0, 0);
             }
-        // D: lane holds pixels 4 * (lane / 16) + i, output channel lane % 16
-        float* yp = yt + s * RS_Y + (r * 16 + 4 * kq) * 16 + m;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) yp[i * 16] = dcv_act_apply(acc[i] + bias, o.act, o.slope);
+        rs_mfma_store(o, acc, bias, yt + s * RS_Y + (r * 16 + 4 * kq) * 16 + m, sum, sq);
     }
+    rs_mfma_sums(sum, sq, wsum);
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------ the kernel
@@ -257,18 +309,17 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
     float* yt = reinterpret_cast<float*>(smem + RS_XIN_BYTES);
     float* arr = reinterpret_cast<float*>(smem + RS_ARR_OFF);
     double* part = reinterpret_cast<double*>(smem + RS_PART_OFF);                    // [RS_MAXQ][16]
-    float* wpart = reinterpret_cast<float*>(smem + RS_WP_OFF);                       // [16 waves][2][RS_MAXC]
+    __shared__ float s_wsum[16 * 2 * RS_MAXC];                                       // per-wave sums of y, y^2 left by the convolution epilogues
     __shared__ float s_samp[RS_SPB][2][RS_MAXC];                                     // per-sample sums of y, y^2
-    __shared__ float s_ab[2][RS_MAXC];                                               // BatchNorm: v = a y + b
-    __shared__ float s_S[RS_SPB][RS_MAXC], s_T[RS_SPB][RS_MAXC];                      // layer output = S y + T
-    __shared__ double s_grp[RS_SPB][2][RS_MAXC];
+    __shared__ __attribute__((aligned(16))) float s_S[RS_SPB][RS_MAXC];              // layer output = S y + T
+    __shared__ __attribute__((aligned(16))) float s_T[RS_SPB][RS_MAXC];
+    __shared__ float s_par[DCV_RESIDENT_MAX_OPS][6][RS_MAXC];                        // per-channel parameters of every layer: bn gamma, beta, running mean, var, gn gamma, beta
     __shared__ unsigned s_gen;
     __shared__ int s_fail;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int s_of_t = t >> 9, tt = t & 511;                                         // sample-major split of the block for the per-sample passes
     const int N = p.n, G = (int)gridDim.x;
     const bool valid0 = (int)blockIdx.x * RS_SPB < N, valid1 = (int)blockIdx.x * RS_SPB + 1 < N;
-    __shared__ float s_par[DCV_RESIDENT_MAX_OPS][6][RS_MAXC];                        // per-channel parameters of every layer: bn gamma, beta, running mean, var, gn gamma, beta
     if (t == 0) { s_gen = __hip_atomic_load((rs_gu32*)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_fail = 0; }
     int n_stamp = 0;
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(ctl + 4);
@@ -278,7 +329,7 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
         // layer's padded tile (loads issued before the tile is zeroed)
         float pv = 0.f; int pslot = -1;
         if (t < p.count * 6 * RS_MAXC) {
-            const int oi = t / (6 * RS_MAXC), r = t - oi * 6 * RS_MAXC, f = r / RS_MAXC, c = r - f * RS_MAXC;
+            const int oi = rs_fdiv(t, 1.f / (float)(6 * RS_MAXC)), r = t - oi * 6 * RS_MAXC, f = r >> 4, c = r & 15;
             const dcv_resident_op& o = p.op[oi];
             if (o.kind == DCV_RES_LAYER && c < o.cout) {
                 const float* src = f == 0 ? o.bn_gamma : f == 1 ? o.bn_beta : f == 2 ? o.running_mean : f == 3 ? o.running_var : f == 4 ? o.gn_gamma : o.gn_beta;
@@ -298,6 +349,7 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
         }
         const dcv_resident_op& o = p.op[0];
         const int pad = o.k / 2, XW = o.w + 2 * pad, XH = o.h + 2 * pad, HW = o.h * o.w, C = o.cin;
+        const float inv_hw = 1.f / (float)HW, inv_w = 1.f / (float)o.w, inv_c = 1.f / (float)C, inv_cv = 1.f / (float)((C >> 2) > 0 ? (C >> 2) : 1);
         const int n = (int)blockIdx.x * RS_SPB + s_of_t;
         constexpr int SB = 8;                                                        // elements per thread in flight
         const bool vec = !o.x_nchw && (C & 3) == 0;
@@ -328,12 +380,12 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                 const int e = e0 + tt + k * 512;
                 if (e < total && n < N) {
                     if (vec) {
-                        const int px = e / (C >> 2), cv = e - px * (C >> 2), r = px / o.w, col = px - r * o.w;
+                        const int px = rs_fdiv(e, inv_cv), cv = e - px * (C >> 2), r = rs_fdiv(px, inv_w), col = px - r * o.w;
                         reinterpret_cast<float4*>(dst)[(cv * XH + r + pad) * XW + col + pad] = v4[k];
                     } else {
                         int c, px;
-                        if (o.x_nchw) { c = e / HW; px = e - c * HW; } else { px = e / C; c = e - px * C; }
-                        const int r = px / o.w, col = px - r * o.w;
+                        if (o.x_nchw) { c = rs_fdiv(e, inv_hw); px = e - c * HW; } else { px = rs_fdiv(e, inv_c); c = e - px * C; }
+                        const int r = rs_fdiv(px, inv_w), col = px - r * o.w;
                         dst[(((c >> 2) * XH + r + pad) * XW + col + pad) * 4 + (c & 3)] = v1[k];
                     }
                 }
@@ -344,26 +396,26 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
     const unsigned gen = s_gen;
     stamp();
     bool conv_done = false;                                                          // this layer's convolution already ran (behind the previous apply step)
+    bool sums_done = false;
     int fc_from_y = 0;                                                               // the FC input is the wide tensor a LINK left in yt
     for (int oi = 0; oi < p.count; ++oi) {
         const dcv_resident_op& o = p.op[oi];
         if (o.kind == DCV_RES_LAYER) {
             const int C = o.cout, CV = C >> 2, H = o.h, W = o.w, HW = H * W;
-            // ---- convolution + bias + activation: xin -> yt
-            const int var = rs_variant(o.cin, o.cout, o.k, o.w);
+            // ---- convolution + bias + activation: xin -> yt, per-wave sums of y, y^2 -> s_wsum
             if (!conv_done) {
-                if (var == 1) { if (o.k == 5) rs_conv_c4_co4<5>(o, xin, yt); else rs_conv_c4_co4<3>(o, xin, yt); }
-                else if (var == 2) { if (o.k == 3) rs_conv_c4_wide<3>(o, xin, yt); else rs_conv_c4_wide<1>(o, xin, yt); }
-                else if (var == 4) { if (o.k == 3) rs_conv_c4_mfma<3>(o, xin, yt); else rs_conv_c4_mfma<1>(o, xin, yt); }
-                else { float4 b4[9]; rs_load_bfrag(o.filt, b4); rs_conv_c16_mfma(o, xin, yt, b4); }
+                const int var = rs_variant(o.cin, o.cout, o.k, o.w);
+                if (var == 1) sums_done = o.k == 5 ? rs_conv_c4_co4<5>(o, xin, yt, s_wsum) : rs_conv_c4_co4<3>(o, xin, yt, s_wsum);
+                else if (var == 2) sums_done = o.k == 3 ? rs_conv_c4_wide<3>(o, xin, yt, s_wsum) : rs_conv_c4_wide<1>(o, xin, yt, s_wsum);
+                else if (var == 4) sums_done = o.k == 3 ? rs_conv_c4_mfma<3>(o, xin, yt, s_wsum) : rs_conv_c4_mfma<1>(o, xin, yt, s_wsum);
+                else { float4 b4[9]; rs_load_bfrag(o.filt, b4); sums_done = rs_conv_c16_mfma(o, xin, yt, b4, s_wsum); }
                 rs_barrier();
             }
             conv_done = false;
             stamp();
-            // ---- per-sample sums of y, y^2.  Wave w8 of the sample (8 waves) owns channel vector w8 % CV and every (8 / CV)-th stripe of 64 pixels, so one
-            // full-wave sum per quantity finishes its part (CV is 1, 2 or 4).  (y goes to HBM in the apply step: a global store here would sit in front of
-            // the gather's loads in the wave's in-order memory counter.)
-            if (o.bn || o.groups) {
+            const bool norm = o.bn || o.groups;
+            if (norm && !sums_done) {
+                // (scalar wide variant) a pass over yt: wave w8 of the sample owns channel vector w8 % CV and every (8 / CV)-th stripe of 64 pixels
                 const int w8 = wave & 7, cv = w8 & (CV - 1), stripes = 8 / CV, st0 = w8 / CV;
                 const float4* ys = reinterpret_cast<const float4*>(yt + s_of_t * RS_Y);
                 float sum[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
@@ -372,38 +424,39 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                     sum[0] += v.x; sum[1] += v.y; sum[2] += v.z; sum[3] += v.w;
                     sq[0] += v.x * v.x; sq[1] += v.y * v.y; sq[2] += v.z * v.z; sq[3] += v.w * v.w;
                 }
+                for (int i = lane; i < 2 * RS_MAXC; i += 64) s_wsum[wave * 2 * RS_MAXC + i] = 0.f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { sum[j] = rs_wave_sum(sum[j]); sq[j] = rs_wave_sum(sq[j]); }
                 if (lane == 0) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { wpart[(wave * 2) * RS_MAXC + j] = sum[j]; wpart[(wave * 2 + 1) * RS_MAXC + j] = sq[j]; }       // [wave][q][j]
-                }
-                rs_barrier();
-                if (t < RS_SPB * 2 * C) {
-                    const int ss = t / (2 * C), r = t - ss * 2 * C, q = r / C, c = r - q * C, ccv = c >> 2, j = c & 3;
-                    float v = 0.f;
-                    for (int k = 0; k < stripes; ++k) v += wpart[((ss * 8 + k * CV + ccv) * 2 + q) * RS_MAXC + j];
-                    s_samp[ss][q][c] = v;
+                    for (int j = 0; j < 4; ++j) { s_wsum[(wave * 2) * RS_MAXC + cv * 4 + j] = sum[j]; s_wsum[(wave * 2 + 1) * RS_MAXC + cv * 4 + j] = sq[j]; }
                 }
                 rs_barrier();
             }
-            stamp();
-            if (o.bn) {
-                // ---- batch statistics: publish this block's 2C sums, gather every block's
-                const unsigned epoch = gen * DCV_RESIDENT_MAX_OPS + (unsigned)oi + 1u;
-                rs_u64* go = gran + (size_t)oi * RS_MAXQ * RS_MAXG;
-                if (t < 2 * C) {
-                    const int q = t / C, c = t - q * C;
-                    const float tot = (valid0 ? s_samp[0][q][c] : 0.f) + (valid1 ? s_samp[1][q][c] : 0.f);
+            // ---- per-sample sums (8 waves each); BatchNorm: publish this block's 2C totals, gather every block's
+            const unsigned epoch = gen * DCV_RESIDENT_MAX_OPS + (unsigned)oi + 1u;
+            rs_u64* go = gran + (size_t)oi * RS_MAXQ * RS_MAXG;
+            if (norm && t < 2 * C) {
+                const int q = t >= C ? 1 : 0, c = t - q * C;
+                float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+                for (int w8 = 0; w8 < 8; ++w8) { v0 += s_wsum[(w8 * 2 + q) * RS_MAXC + c]; v1 += s_wsum[((8 + w8) * 2 + q) * RS_MAXC + c]; }
+                s_samp[0][q][c] = v0; s_samp[1][q][c] = v1;
+                if (o.bn) {
+                    const float tot = (valid0 ? v0 : 0.f) + (valid1 ? v1 : 0.f);
                     __hip_atomic_store((rs_gu64*)(go + (size_t)t * RS_MAXG + blockIdx.x), ((rs_u64)epoch << 32) | (rs_u64)__float_as_uint(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+            }
+            stamp();
+            if (o.bn) {
                 const int total = 2 * C * G;
+                const float inv_g = 1.f / (float)G;
                 bool ok = true;
                 constexpr int GP = RS_MAXQ * RS_MAXG / RS_T;                         // granules per thread: all of a sweep's loads are in flight together
                 for (int i0 = 0; i0 < total; i0 += RS_T * GP) {
                     int idx[GP]; float gv[GP];
 #pragma unroll
-                    for (int k = 0; k < GP; ++k) { const int i = i0 + k * RS_T + t; const int q = i / G; idx[k] = i < total ? q * RS_MAXG + (i - q * G) : -1; }
+                    for (int k = 0; k < GP; ++k) { const int i = i0 + k * RS_T + t; const int q = rs_fdiv(i, inv_g); idx[k] = i < total ? q * RS_MAXG + (i - q * G) : -1; }
                     bool got = false;
                     for (int spins = 0; spins < RS_SPINS; ++spins) {
                         got = true;
@@ -435,86 +488,64 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                     return;
                 }
                 stamp();
-                // fixed-order fp64 sums: 16 partial sums of <= 16 blocks per quantity, then the 16 partials
+                // fixed-order fp64 sums, level 1: 16 partial sums of <= 16 blocks per quantity
                 if (t < 2 * C * 16) {
                     const int q = t >> 4, j = t & 15;
                     double v = 0.0;
                     for (int i = j * 16; i < j * 16 + 16 && i < G; ++i) v += (double)arr[q * RS_MAXG + i];
                     part[q * 16 + j] = v;
                 }
-                rs_barrier();
-                if (t < C) {
+            } else stamp();
+            rs_barrier();
+            // ---- coefficients, all in wave 0: thread (sample, channel) sums the 16 partials of its channel, derives the BatchNorm affine v = a y + b, the
+            // GroupNorm statistics of v from the sample's sums (norm_chain.hip, nc_apply_kernel's prologue; group totals by DPP exchanges between the
+            // cpg adjacent lanes) and the layer's affine S y + T
+            if (t < RS_SPB * C) {
+                const int ss = t >= C ? 1 : 0, c = t - ss * C;
+                float a = 1.f, b = 0.f;
+                if (o.bn) {
                     double s1 = 0.0, s2 = 0.0;
-                    for (int j = 0; j < 16; ++j) { s1 += part[t * 16 + j]; s2 += part[(C + t) * 16 + j]; }
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) { s1 += part[c * 16 + j]; s2 += part[(C + c) * 16 + j]; }
                     const double mean = s1 * o.inv_count;
                     double varc = s2 * o.inv_count - mean * mean; if (varc < 0.0) varc = 0.0;
                     const float rstd = (float)rs_rsqrt(varc + (double)o.bn_eps);
-                    const float g = s_par[oi][0][t], b = s_par[oi][1][t];
-                    const float sc = g * rstd;
-                    s_ab[0][t] = sc; s_ab[1][t] = b - (float)mean * sc;
-                    if (blockIdx.x == 0) {                                           // saved / running statistics: written once
-                        o.bn_mean[t] = (float)mean; o.bn_rstd[t] = rstd;
-                        if (o.running_mean) o.running_mean[t] = (1.f - o.momentum) * s_par[oi][2][t] + o.momentum * (float)mean;
-                        if (o.running_var) { const double unb = varc * o.unbias; o.running_var[t] = (1.f - o.momentum) * s_par[oi][3][t] + o.momentum * (float)unb; }
-                        if (t == 0 && o.num_batches_tracked) o.num_batches_tracked[0] += 1;
+                    a = s_par[oi][0][c] * rstd; b = s_par[oi][1][c] - (float)mean * a;
+                    if (blockIdx.x == 0 && ss == 0) {                                // saved / running statistics: written once
+                        o.bn_mean[c] = (float)mean; o.bn_rstd[c] = rstd;
+                        if (o.running_mean) o.running_mean[c] = (1.f - o.momentum) * s_par[oi][2][c] + o.momentum * (float)mean;
+                        if (o.running_var) o.running_var[c] = (1.f - o.momentum) * s_par[oi][3][c] + o.momentum * (float)(varc * o.unbias);
+                        if (c == 0 && o.num_batches_tracked) o.num_batches_tracked[0] += 1;
                     }
                 }
-            } else if (t < C) { s_ab[0][t] = 1.f; s_ab[1][t] = 0.f; }
-            rs_barrier();
-            // ---- per-sample affine of the layer output: GroupNorm of the BatchNorm output (norm_chain.hip, nc_apply_kernel's prologue)
-            if (o.groups > 0) {
-                const int cpg = C / o.groups;
-                const int ss = t / C, c = t - ss * C;
-                const bool own = t < RS_SPB * C;
-                float a = 0.f, b = 0.f;
-                if (own) {
-                    a = s_ab[0][c]; b = s_ab[1][c];
+                float S = a, T = b;
+                if (o.groups > 0) {
+                    const int cpg = C / o.groups;
                     const double hw = (double)HW, ad = (double)a, bd = (double)b, s1 = (double)s_samp[ss][0][c], s2 = (double)s_samp[ss][1][c];
-                    s_grp[ss][0][c] = ad * s1 + hw * bd;
-                    s_grp[ss][1][c] = ad * ad * s2 + 2.0 * ad * bd * s1 + hw * bd * bd;
-                }
-                rs_barrier();
-                if (own) {
-                    const int g = c / cpg, g0 = g * cpg;
-                    double sv = 0.0, svv = 0.0;
-                    for (int k = g0; k < g0 + cpg; ++k) { sv += s_grp[ss][0][k]; svv += s_grp[ss][1][k]; }
-                    const double inv_m = o.inv_group, mean = sv * inv_m;
-                    double varc = svv * inv_m - mean * mean; if (varc < 0.0) varc = 0.0;
+                    double sv = ad * s1 + hw * bd, svv = ad * ad * s2 + 2.0 * ad * bd * s1 + hw * bd * bd;
+                    for (int off = 1; off < cpg; off <<= 1) { sv += __shfl_xor(sv, off, 64); svv += __shfl_xor(svv, off, 64); }   // cpg: a power of two of adjacent lanes
+                    const double mean = sv * o.inv_group;
+                    double varc = svv * o.inv_group - mean * mean; if (varc < 0.0) varc = 0.0;
                     const float rstd = (float)rs_rsqrt(varc + (double)o.gn_eps);
-                    const int n = (int)blockIdx.x * RS_SPB + ss;
-                    if (c == g0 && n < N) { o.gn_mean[(size_t)n * o.groups + g] = (float)mean; o.gn_rstd[(size_t)n * o.groups + g] = rstd; }
+                    const int n = (int)blockIdx.x * RS_SPB + ss, g = rs_fdiv(c, 1.f / (float)cpg);
+                    if (c == g * cpg && n < N) { o.gn_mean[(size_t)n * o.groups + g] = (float)mean; o.gn_rstd[(size_t)n * o.groups + g] = rstd; }
                     const float gg = s_par[oi][4][c], gb = s_par[oi][5][c];
-                    s_S[ss][c] = a * rstd * gg;
-                    s_T[ss][c] = (b - (float)mean) * rstd * gg + gb;
+                    S = a * rstd * gg; T = (b - (float)mean) * rstd * gg + gb;
                 }
-            } else if (t < RS_SPB * C) { const int ss = t / C, c = t - ss * C; s_S[ss][c] = s_ab[0][c]; s_T[ss][c] = s_ab[1][c]; }
-            stamp();
-            // ---- apply: out = S y + T [averaged over pool windows] -> HBM and the next op's input tile
-            {   // the gather scratch lived in the input tile: re-zero the halo of the NEXT layer's tile (its interior is rewritten below; flat tiles have none)
-                const bool nl = oi + 1 < p.count && p.op[oi + 1].kind == DCV_RES_LAYER;
-                if (nl) {
-                    const int pk = o.pool > 0 ? o.pool : 1, Ho = H / pk, Wo = W / pk, np = p.op[oi + 1].k / 2, XWn = Wo + 2 * np, XHn = Ho + 2 * np;
-                    const int rows_part = 2 * np * XWn, halo = rows_part + Ho * 2 * np, planes = RS_SPB * CV;
-                    for (int i = t; i < planes * halo; i += RS_T) {
-                        const int pl = i / halo, e = i - pl * halo;
-                        int r, c;
-                        if (e < rows_part) { r = e / XWn; c = e - r * XWn; if (r >= np) r += Ho; }
-                        else { const int e2 = e - rows_part; r = e2 / (2 * np); c = e2 - r * 2 * np; r += np; if (c >= np) c += Wo; }
-                        const int ss = pl / CV, cvp = pl - ss * CV;
-                        xin[ss * RS_XIN + (cvp * XHn + r) * XWn + c] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
-                }
+                s_S[ss][c] = S; s_T[ss][c] = T;
             }
             rs_barrier();
+            stamp();
+            // ---- apply: out = S y + T [averaged over pool windows] -> HBM, y -> HBM, the next op's input tile (interior here, its halo below)
             auto apply_step = [&]() {
                 const int pk = o.pool > 0 ? o.pool : 1, Ho = H / pk, Wo = W / pk;
                 const bool nxt_layer = oi + 1 < p.count && p.op[oi + 1].kind == DCV_RES_LAYER;
                 const int npad = nxt_layer ? p.op[oi + 1].k / 2 : 0, XWn = Wo + 2 * npad, XHn = Ho + 2 * npad;
-                const float inv = 1.f / (float)(pk * pk);
+                const float inv = 1.f / (float)(pk * pk), inv_cv = 1.f / (float)CV, inv_wo = 1.f / (float)Wo;
                 const int per = Ho * Wo * CV;
                 for (int it = t; it < RS_SPB * per; it += RS_T) {
-                    const int ss = it >= per ? 1 : 0, e = it - ss * per, px = e / CV, cv = e - px * CV, ho = px / Wo, wo = px - ho * Wo;
-                    const float* S = s_S[ss] + cv * 4; const float* T = s_T[ss] + cv * 4;
+                    const int ss = it >= per ? 1 : 0, e = it - ss * per, px = rs_fdiv(e, inv_cv), cv = e - px * CV, ho = rs_fdiv(px, inv_wo), wo = px - ho * Wo;
+                    const float4 S = *reinterpret_cast<const float4*>(s_S[ss] + cv * 4), T = *reinterpret_cast<const float4*>(s_T[ss] + cv * 4);
                     float acc[4] = {0.f, 0.f, 0.f, 0.f};
                     const int n = (int)blockIdx.x * RS_SPB + ss;
                     float4* yg = reinterpret_cast<float4*>(o.y) + (size_t)(n < N ? n : 0) * HW * CV;
@@ -523,7 +554,7 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                             const int yi = ((ho * pk + kh) * W + wo * pk + kw) * CV + cv;
                             const float4 v = reinterpret_cast<const float4*>(yt + ss * RS_Y)[yi];
                             if (n < N) yg[yi] = v;                                   // y -> HBM (saved for the backward pass): every element passes here once
-                            acc[0] += v.x * S[0] + T[0]; acc[1] += v.y * S[1] + T[1]; acc[2] += v.z * S[2] + T[2]; acc[3] += v.w * S[3] + T[3];
+                            acc[0] += v.x * S.x + T.x; acc[1] += v.y * S.y + T.y; acc[2] += v.z * S.z + T.z; acc[3] += v.w * S.w + T.w;
                         }
                     float4 r4;
                     if (o.pool > 0) r4 = make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv); else r4 = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -531,6 +562,19 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                     else r4 = make_float4(0.f, 0.f, 0.f, 0.f);                       // (a block's missing second sample: keep its tile finite)
                     if (nxt_layer) xin[ss * RS_XIN + (cv * XHn + ho + npad) * XWn + wo + npad] = r4;
                     else reinterpret_cast<float4*>(xinf + (size_t)ss * RS_XIN * 4)[px * CV + cv] = r4;           // flat NHWC for a LINK / FC
+                }
+                if (nxt_layer && npad > 0) {
+                    // the gather scratch lived in the input tile: re-zero the halo of the next layer's tile (disjoint from the interior written above)
+                    const int rows_part = 2 * npad * XWn, halo = rows_part + Ho * 2 * npad, planes = RS_SPB * CV;
+                    const float inv_halo = 1.f / (float)halo, inv_xw = 1.f / (float)XWn, inv_2p = 1.f / (float)(2 * npad);
+                    for (int i = t; i < planes * halo; i += RS_T) {
+                        const int pl = rs_fdiv(i, inv_halo), e = i - pl * halo;
+                        int r, c;
+                        if (e < rows_part) { r = rs_fdiv(e, inv_xw); c = e - r * XWn; if (r >= npad) r += Ho; }
+                        else { const int e2 = e - rows_part; r = rs_fdiv(e2, inv_2p); c = e2 - r * 2 * npad; r += npad; if (c >= npad) c += Wo; }
+                        const int ss = pl >= CV ? 1 : 0, cvp = pl - ss * CV;
+                        xin[ss * RS_XIN + (cvp * XHn + r) * XWn + c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
                 }
             };
             if (oi + 1 < p.count && p.op[oi + 1].kind == DCV_RES_LAYER && rs_variant(p.op[oi + 1].cin, p.op[oi + 1].cout, p.op[oi + 1].k, p.op[oi + 1].w) == 3) {
@@ -541,7 +585,7 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                 apply_step();
                 rs_barrier();
                 stamp();
-                rs_conv_c16_mfma(p.op[oi + 1], xin, yt, b4);
+                sums_done = rs_conv_c16_mfma(p.op[oi + 1], xin, yt, b4, s_wsum);
                 rs_barrier();
                 conv_done = true;
             } else {
@@ -552,19 +596,17 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
             fc_from_y = 0;
         } else if (o.kind == DCV_RES_LINK) {
             // wide[px][0 .. cin) = current (flat NHWC in xin), wide[px][cin ..) = bilinear resize of ref to (h, w): -> HBM and yt (flat NHWC)
-            const int Cc = o.cin, Cr = o.ref_c, Cw = Cc + Cr, HW = o.h * o.w;
+            const int Cc = o.cin, CVc = Cc >> 2, Cr = o.ref_c, Cw = Cc + Cr, HW = o.h * o.w, perw = HW * Cw;
             const float sh = o.align_corners ? (o.h > 1 ? (float)(o.ref_h - 1) / (float)(o.h - 1) : 0.f) : (float)o.ref_h / (float)o.h;
             const float sw = o.align_corners ? (o.w > 1 ? (float)(o.ref_w - 1) / (float)(o.w - 1) : 0.f) : (float)o.ref_w / (float)o.w;
-            const int per = HW * Cw;
             __syncthreads();                                                         // full: every wave's earlier global stores (the referenced tensor) are done
-            for (int it = t; it < RS_SPB * per; it += RS_T) {
-                const int ss = it >= per ? 1 : 0, e = it - ss * per, px = e / Cw, c = e - px * Cw;
-                const int n = (int)blockIdx.x * RS_SPB + ss;
-                if (n >= N) continue;
-                float v;
-                if (c < Cc) v = xinf[(size_t)ss * RS_XIN * 4 + px * Cc + c];
-                else {
-                    const int ho = px / o.w, wo = px - ho * o.w, cr = c - Cc;
+            {   // referenced channels: one item per (sample, pixel, channel); loads first
+                const int per = HW * Cr;
+                const float inv_cr = 1.f / (float)Cr, inv_w = 1.f / (float)o.w;
+                for (int it = t; it < RS_SPB * per; it += RS_T) {
+                    const int ss = it >= per ? 1 : 0, e = it - ss * per, px = rs_fdiv(e, inv_cr), cr = e - px * Cr, ho = rs_fdiv(px, inv_w), wo = px - ho * o.w;
+                    const int n = (int)blockIdx.x * RS_SPB + ss;
+                    if (n >= N) continue;
                     float fs = o.align_corners ? sh * ho : sh * (ho + 0.5f) - 0.5f; if (fs < 0.f) fs = 0.f;
                     int h0 = (int)fs; if (h0 > o.ref_h - 1) h0 = o.ref_h - 1;
                     const int h1 = h0 + (h0 < o.ref_h - 1 ? 1 : 0); const float lh = fs - (float)h0;
@@ -574,11 +616,24 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                     // `ref` was stored by this block earlier in this launch (its own samples): agent-scope loads, never the CU's L1
                     const float* rs = o.ref + (size_t)n * o.ref_h * o.ref_w * Cr + cr;
                     auto ld = [&](int hh, int ww) { return __uint_as_float(__hip_atomic_load((rs_gu32*)(rs + ((size_t)hh * o.ref_w + ww) * Cr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
+                    const float x00 = ld(h0, w0), x01 = ld(h0, w1), x10 = ld(h1, w0), x11 = ld(h1, w1);
                     const float c00 = (1.f - lh) * (1.f - lw), c01 = (1.f - lh) * lw, c10 = lh * (1.f - lw), c11 = lh * lw;
-                    v = c00 * ld(h0, w0) + c01 * ld(h0, w1) + c10 * ld(h1, w0) + c11 * ld(h1, w1);
+                    const float v = c00 * x00 + c01 * x01 + c10 * x10 + c11 * x11;
+                    yt[ss * RS_Y + px * Cw + Cc + cr] = v;
+                    o.out[(size_t)n * perw + px * Cw + Cc + cr] = v;
                 }
-                yt[ss * RS_Y + e] = v;
-                o.out[(size_t)n * per + e] = v;
+            }
+            {   // current channels: float4 copies
+                const int per = HW * CVc;
+                const float inv_cv = 1.f / (float)CVc;
+                for (int it = t; it < RS_SPB * per; it += RS_T) {
+                    const int ss = it >= per ? 1 : 0, e = it - ss * per, px = rs_fdiv(e, inv_cv), cv = e - px * CVc;
+                    const int n = (int)blockIdx.x * RS_SPB + ss;
+                    if (n >= N) continue;
+                    const float4 v = reinterpret_cast<const float4*>(xinf + (size_t)ss * RS_XIN * 4)[e];
+                    *reinterpret_cast<float4*>(yt + ss * RS_Y + px * Cw + cv * 4) = v;
+                    *reinterpret_cast<float4*>(o.out + (size_t)n * perw + px * Cw + cv * 4) = v;
+                }
             }
             rs_barrier();
             stamp();
@@ -619,12 +674,12 @@ inline bool rs_layer_ok(const dcv_resident_op& o, bool first) {
     if (var == 0 || o.h <= 0 || o.w <= 0 || o.cin <= 0) return false;
     const int pad = o.k / 2, cvin = (o.cin + 3) / 4;
     if (cvin * (o.h + 2 * pad) * (o.w + 2 * pad) > RS_XIN || o.h * o.w * o.cout > RS_Y) return false;
-    if (var == 1 && (o.h & 1)) return false;
+    if (var == 1 && ((o.h & 1) || (o.h >> 1) * o.w > 512)) return false;
     if (var == 2 && (o.h * o.w) % 64 != 0) return false;
     if (!first && (o.cin & 3)) return false;                      // only the staged model input may have a partial channel vector
     if (o.act < DCV_ACT_NONE || o.act > DCV_ACT_TANH || !o.filt || !o.y || !o.out) return false;
     if (o.bn && !(o.bn_mean && o.bn_rstd)) return false;
-    if (o.groups < 0 || (o.groups > 0 && (o.cout % o.groups != 0 || !o.gn_mean || !o.gn_rstd))) return false;
+    if (o.groups < 0 || (o.groups > 0 && (o.cout % o.groups != 0 || ((o.cout / o.groups) & (o.cout / o.groups - 1)) || !o.gn_mean || !o.gn_rstd))) return false;   // channels per group: a power of two
     if (o.pool < 0 || o.pool == 1 || (o.pool > 0 && (o.h % o.pool != 0 || o.w % o.pool != 0))) return false;
     return true;
 }
@@ -641,7 +696,7 @@ inline bool rs_program_ok(const dcv_resident_program* p) {
             const int pk = o.pool > 0 ? o.pool : 1;
             c = o.cout; h = o.h / pk; w = o.w / pk;
         } else if (o.kind == DCV_RES_LINK) {
-            if (i == 0 || p->op[i - 1].kind != DCV_RES_LAYER || o.cin != c || o.h != h || o.w != w || !o.ref || !o.out || o.ref_c <= 0 || o.ref_h <= 0 || o.ref_w <= 0) return false;
+            if (i == 0 || p->op[i - 1].kind != DCV_RES_LAYER || o.cin != c || (c & 3) || o.h != h || o.w != w || !o.ref || !o.out || o.ref_c <= 0 || (o.ref_c & 3) || o.ref_h <= 0 || o.ref_w <= 0) return false;
             if (i + 1 < p->count && p->op[i + 1].kind != DCV_RES_FC) return false;
             bool found = false;                                   // ref must be an earlier layer's output (this block wrote its samples' part)
             for (int k = 0; k < i; ++k) if (p->op[k].kind == DCV_RES_LAYER && p->op[k].out == o.ref) found = true;

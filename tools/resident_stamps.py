@@ -33,7 +33,7 @@ for i in range(steps):
         cnt = i - 4
 names = ['stage input']
 for l in range(5):
-    names += [f'L{l + 1} conv', f'L{l + 1} sums + y store', f'L{l + 1} gather', f'L{l + 1} coefficients', f'L{l + 1} apply']
+    names += [f'L{l + 1} conv (+ sums)', f'L{l + 1} combine + publish', f'L{l + 1} gather', f'L{l + 1} fp64 sums + coefficients', f'L{l + 1} apply']
 names += ['link', 'fc']
 tot = 0.
 for k, v in enumerate((acc / cnt).tolist()):
