@@ -315,6 +315,9 @@ def main():
     share = os.environ.get('DCV_BENCH_SHARE_GPU') == '1'
     device = torch.device('cuda', local_rank % torch.cuda.device_count() if share else local_rank)
     torch.cuda.set_device(device)
+    if share and world > 1:
+        from deepcv_amd import resident
+        resident.set_enabled(False)           # the persistent forward launch needs the whole GPU (deepcv_amd/resident.py): ranks sharing one use the per-layer kernels
     use_dp = world > 1 or args.force_dp
     if use_dp:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')

@@ -283,9 +283,15 @@ class GraphedTrainStep:
         """ Host values of the loss terms of the last step.  After a replay they come from the early read-back (no device synchronisation: the backward
         pass and the optimizer of that step may still be running); after an eager step, from the loss tensors. """
         if self._launched_seq is None or self._last_eager:
-            return OrderedDict((n, v.item()) for n, v in self._last_losses.items())
-        self._wait_published()
-        return OrderedDict((n, float(self._pub_vals[i])) for i, n in enumerate(self.static_losses.keys()))
+            vals = OrderedDict((n, v.item()) for n, v in self._last_losses.items())
+        else:
+            self._wait_published()
+            vals = OrderedDict((n, float(self._pub_vals[i])) for i, n in enumerate(self.static_losses.keys()))
+        if any(v != v for v in vals.values()):
+            # a persistent launch which gave up waiting for its own blocks poisons the logits: say so instead of training on NaN (deepcv_amd/resident.py)
+            from .. import resident
+            resident.check_status()
+        return vals
 
     def _capture(self, x, y):
         dev = x.device
@@ -488,7 +494,11 @@ def train(hp: HYPERPARAMS_T, model: torch.nn.Module, losses: LOSS_FN_TERMS_T = N
             optimizer.step()
         if graphed_step is not None:
             return dict(graphed_step.loss_values())               # per-step host read-back like the reference (`:255`), published right after the forward pass
-        return {n: v.item() for n, v in batch_losses.items()}   # device -> host sync every step, like the reference (`:255`)
+        vals = {n: v.item() for n, v in batch_losses.items()}   # device -> host sync every step, like the reference (`:255`)
+        if any(v != v for v in vals.values()):
+            from .. import resident
+            resident.check_status()
+        return vals
 
     trainer = Engine(process_function)
 

@@ -18,6 +18,8 @@ from typing import Dict, Iterable, List, Optional, Sequence
 import torch
 import torch.distributed as dist
 
+from . import resident
+
 from . import _native as nat
 from . import filters
 from . import grads
@@ -193,6 +195,7 @@ class DataParallelModel(torch.nn.Module):
     def __init__(self, module: torch.nn.Module, process_group=None, bucket_cap_mb: float = 32., overlap: bool = True, broadcast: bool = True):
         super().__init__()
         self.module = module
+        resident.disable_if_gpu_shared()
         if broadcast and dist.is_initialized() and dist.get_world_size(process_group) > 1:
             broadcast_module_state(module, src=0, group=process_group)
         self.reducer = GradientAllReducer(module.parameters(), process_group=process_group, bucket_cap_mb=bucket_cap_mb, overlap=overlap)

@@ -21,7 +21,7 @@ import torch
 from . import _native as nat
 from ._native import lib
 
-__all__ = ['Ineligible', 'Recorder', 'recorder', 'forbid', 'enabled', 'set_enabled', 'wanted', 'mark_ineligible', 'check_status', 'launches']
+__all__ = ['Ineligible', 'Recorder', 'recorder', 'forbid', 'enabled', 'set_enabled', 'disable_if_gpu_shared', 'wanted', 'mark_ineligible', 'check_status', 'launches']
 
 _enabled = os.environ.get('DCV_RESIDENT', '1') not in ('0', 'false', 'False', '')
 _active: Optional['Recorder'] = None
@@ -47,6 +47,22 @@ def set_enabled(value: bool) -> bool:
 def launches() -> int:
     """ Number of resident launches recorded so far (tests: did the path actually run?). """
     return _launches
+
+
+def disable_if_gpu_shared() -> bool:
+    """ The persistent launch needs every CU of the GPU: its 256 blocks of 1024 threads x 128 VGPRs only fit one per CU, and two such grids launched at the
+    same time by two processes can each hold half of the chip and wait for the rest (the gather then gives up after its bounded spin and the step's
+    outputs are invalid).  Called where ranks are set up: turns the path off when more ranks of this node than visible GPUs exist (rehearsals of the
+    data-parallel path on a 1-GPU box).  Returns True when it did. """
+    try:
+        import torch.distributed as dist
+        local = int(os.environ.get('LOCAL_WORLD_SIZE', '0')) or (dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1)
+    except (RuntimeError, ValueError):
+        local = 1
+    if torch.cuda.is_available() and local > torch.cuda.device_count():
+        set_enabled(False)
+        return True
+    return False
 
 
 def recorder() -> Optional['Recorder']:

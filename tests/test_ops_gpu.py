@@ -1074,14 +1074,14 @@ def test_fused_pairs_in_eval_mode(device):
         with torch.no_grad():
             fused = model(x)
     finally:
-        base_module.DeepcvModule._fused_pair = orig
+        base_module.DeepcvModule._fused_pair = staticmethod(orig)
     assert [c for c in calls if c[1]] == [('Flatten', True)], calls
     base_module.DeepcvModule._fused_pair = staticmethod(lambda subm, nxt, xx: None)
     try:
         with torch.no_grad():
             plain = model(x)
     finally:
-        base_module.DeepcvModule._fused_pair = orig
+        base_module.DeepcvModule._fused_pair = staticmethod(orig)
     _check('eval fused pairs', fused, plain, 1e-6)
     for k, v in model.state_dict().items():
         assert torch.equal(v, state[k]), k
