@@ -13,7 +13,7 @@ from typing import Optional
 
 import torch
 
-__all__ = ['lib', 'load', 'is_available', 'check', 'current_stream', 'Conv2dDesc', 'SlabSegment', 'WgradJob', 'Pool2dDesc', 'TensorList', 'NormChainDesc', 'ResidentOp', 'ResidentProgram', 'LIB_PATH', 'build',
+__all__ = ['lib', 'load', 'is_available', 'check', 'current_stream', 'Conv2dDesc', 'SlabSegment', 'WgradJob', 'Pool2dDesc', 'TensorList', 'NormChainDesc', 'ResidentOp', 'ResidentProgram', 'ResidentBwdOp', 'ResidentBwdProgram', 'LIB_PATH', 'build',
            'ACT_NONE', 'ACT_RELU', 'ACT_LEAKY_RELU', 'ACT_SIGMOID', 'ACT_TANH', 'POOL_AVG', 'POOL_MAX', 'LAYOUT_NHWC', 'LAYOUT_NCHW',
            'MAX_TENSORS', 'HYP_COUNT', 'HYP']
 
@@ -87,6 +87,23 @@ class ResidentOp(ctypes.Structure):
 class ResidentProgram(ctypes.Structure):
     """ `dcv_resident_program` """
     _fields_ = [('n', _c_int), ('count', _c_int), ('op', ResidentOp * RESIDENT_MAX_OPS)]
+
+
+RESIDENT_BWD_MAX_OPS = 8
+
+
+class ResidentBwdOp(ctypes.Structure):
+    """ `dcv_resident_bwd_op` """
+    _fields_ = [('cin', _c_int), ('cout', _c_int), ('k', _c_int), ('h', _c_int), ('w', _c_int), ('act', _c_int), ('slope', _c_float), ('groups', _c_int), ('pool', _c_int),
+                ('need_dx', _c_int), ('inv_count', ctypes.c_double), ('inv_group', ctypes.c_double),
+                ('y', _c_void_p), ('dout', _c_void_p), ('addend', _c_void_p), ('filt', _c_void_p), ('bn_gamma', _c_void_p), ('bn_beta', _c_void_p), ('bn_mean', _c_void_p),
+                ('bn_rstd', _c_void_p), ('gn_gamma', _c_void_p), ('gn_mean', _c_void_p), ('gn_rstd', _c_void_p), ('dz', _c_void_p), ('dx', _c_void_p),
+                ('d_bn_gamma', _c_void_p), ('d_bn_beta', _c_void_p), ('gn_part', _c_void_p)]
+
+
+class ResidentBwdProgram(ctypes.Structure):
+    """ `dcv_resident_bwd_program` """
+    _fields_ = [('n', _c_int), ('count', _c_int), ('op', ResidentBwdOp * RESIDENT_BWD_MAX_OPS)]
 
 
 class TensorList(ctypes.Structure):
@@ -195,6 +212,8 @@ _SIGNATURES = {
     'dcv_resident_ws_bytes': (_c_size_t, []),
     'dcv_resident_forward': (_c_int, [ctypes.POINTER(ResidentProgram), _P, _c_size_t, _P]),
     'dcv_resident_status': (_c_int, [_P, _P, ctypes.POINTER(_c_int)]),
+    'dcv_resident_bwd_supported': (_c_int, [ctypes.POINTER(ResidentBwdProgram)]),
+    'dcv_resident_backward': (_c_int, [ctypes.POINTER(ResidentBwdProgram), _P, _c_size_t, _P]),
 }
 
 _lib: Optional[ctypes.CDLL] = None

@@ -51,6 +51,22 @@ inline int prep_entries(const dcv_conv2d_desc* d, int op, dcv_prep_entry* out) {
         out[0] = e;
         return 1;
     }
+    if (op == 4) {
+        // the LDS-resident network's data-gradient filter (resident.hip).  16 output channels of the layer on rows of 16 pixels: the matrix-core B fragments
+        // (kind 2); otherwise the direct kernels' transposed + flipped layout with ONE tile [R][S][cout rounded up to 4][cin rounded up to 4]
+        dcv_prep_entry e{};
+        e.R = d->r; e.S = d->s; e.w_cin = d->cin; e.dgrad = 1; e.dst_off = 0;
+        if (d->cout == 16 && d->w == 16 && d->r == 3 && d->s == 3 && d->cin <= 16) {
+            e.kind = 2; e.kcout = d->cin; e.kcin = 16;
+            e.total = 16 * 4 * 4 * 9;
+        } else {
+            e.kind = 0; e.kcout = d->cin; e.kcin = d->cout;
+            e.tco = (d->cin + 3) & ~3; e.tiles = 1; e.cin_pad = (d->cout + 3) & ~3;
+            e.total = d->r * d->s * e.cin_pad * e.tco;
+        }
+        out[0] = e;
+        return 1;
+    }
     if (op == 1 && d->x_layout != DCV_LAYOUT_NHWC) return 0;
     return dcv_mfma_conv2d_supported(d, op) ? dcv_mfma_conv2d_prep_entries(d, op, out) : dcv_direct_conv2d_prep_entries(d, op, out);
 }
@@ -93,10 +109,10 @@ int dcv_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, 
 }
 
 size_t dcv_conv2d_filter_bytes(const dcv_conv2d_desc* d, int op) {
-    if (!desc_ok(d) || d->groups != 1 || op < 0 || op > 3) return 0;
+    if (!desc_ok(d) || d->groups != 1 || op < 0 || op > 4) return 0;
     dcv_prep_entry e[DCV_PREP_PIECES];
     if (prep_entries(d, op, e) == 0) return 0;
-    if (op == 2 || op == 3) return dcv_align_up((size_t)e[0].total * sizeof(float), 256);
+    if (op == 2 || op == 3 || op == 4) return dcv_align_up((size_t)e[0].total * sizeof(float), 256);
     return op == 0 ? dcv_conv2d_fwd_workspace_bytes(d) : dcv_conv2d_dgrad_workspace_bytes(d);
 }
 
@@ -111,7 +127,7 @@ int dcv_conv2d_prepare_filters(int count, const dcv_conv2d_desc* const* descs, c
         l.count = 0; max_total = 0;
     };
     for (int k = 0; k < count; ++k) {
-        DCV_CHECK_ARG(desc_ok(descs[k]) && w[k] && ops[k] >= 0 && ops[k] <= 3);
+        DCV_CHECK_ARG(desc_ok(descs[k]) && w[k] && ops[k] >= 0 && ops[k] <= 4);
         dcv_prep_entry pieces[DCV_PREP_PIECES];
         const int np = prep_entries(descs[k], ops[k], pieces);
         if (np == 0) continue;                                    // this (layer, op) reads the OIHW filter directly

@@ -35,7 +35,7 @@ int dcv_mfma_wgrad9_reduce(const float* partial, float* dw, int chunks, int cout
 // Prepared filters: one entry describes the re-layout of one OIHW filter for the kernel which will consume it (see dcv_conv2d_prepare_filters).
 struct dcv_prep_entry {
     const float* w; float* dst;
-    int kind;                      // 0: direct tiled kernel  wt[cout tile][R][S][cin_pad][tco]      1: MFMA kernel  wb[cout][tap][cin]
+    int kind;                      // 0: direct tiled kernel  wt[cout tile][R][S][cin_pad][tco]      1: MFMA kernel  wb[cout][tap][cin]      2: resident MFMA data gradient
     int kcout, kcin;               // kernel-view channel counts (data gradient: kcout = original Cin, kcin = original Cout)
     int R, S, w_cin;               // taps, OIHW row length (original Cin)
     int dgrad;                     // 0: forward filter, 1: transposed + flipped filter of the stride-1 data gradient
@@ -58,6 +58,17 @@ static __device__ __forceinline__ float dcv_prep_element(const dcv_prep_entry& e
         if (cog >= e.kcout || ci >= e.kcin) return 0.f;
         if (!e.dgrad) return e.w[(((size_t)cog * e.w_cin + ci) * e.R + r) * e.S + s];
         return e.w[(((size_t)ci * e.w_cin + cog) * e.R + (e.R - 1 - r)) * e.S + (e.S - 1 - s)];
+    }
+    if (e.kind == 2) {
+        // B fragments of the LDS-resident network's matrix-core DATA gradient (resident.hip): [n 16][kq 4][j 4][tap R*S], the value lane (n, kq) feeds to the
+        // MFMA which contracts output channels {4 kq + j}: w[co = 4 kq + j][ci = n][flipped tap], zero for n >= Cin (e.kcout = original Cin, e.kcin = 16)
+        const int taps = e.R * e.S;
+        const int tap = i % taps; int t = i / taps;
+        const int j = t & 3; t >>= 2;
+        const int kq = t & 3; const int n = t >> 2;
+        const int co = 4 * kq + j;
+        if (n >= e.kcout || co >= e.kcin) return 0.f;
+        return e.w[((size_t)co * e.w_cin + n) * taps + (taps - 1 - tap)];
     }
     const int ci = i % e.kcin; int t = i / e.kcin;
     const int s = t % e.S; t /= e.S;

@@ -221,6 +221,14 @@ __device__ __forceinline__ void rs_mfma_store(const dcv_resident_op& o, const rs
 #pragma unroll
     for (int i = 0; i < 4; ++i) { const float v = dcv_act_apply(acc[i] + bias, o.act, o.slope); yp[i * 16] = v; sum += v; sq += v * v; }
 }
+// the same tile when only the first `co` (< 16) output channels exist (the data gradient of a 4 -> 16 layer): row base `yrow`, pixel stride `co`
+__device__ __forceinline__ void rs_mfma_store_narrow(const rs_f4& acc, float* yrow, int co) {
+    const int lane = threadIdx.x & 63, m = lane & 15, kq = lane >> 4;
+    if (m < co) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) yrow[(4 * kq + i) * co + m] = acc[i];
+    }
+}
 __device__ __forceinline__ void rs_mfma_sums(float sum, float sq, float* wsum) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     sum += __shfl_xor(sum, 16, 64); sq += __shfl_xor(sq, 16, 64);
@@ -270,8 +278,17 @@ __device__ __forceinline__ void rs_load_bfrag(const float* w, float4 (&b4)[9]) {
     for (int q = 0; q < 9; ++q) b4[q] = wp[q];
 }
 
+// the same fragments from the prepared data-gradient layout [n 16][kq 4][j 4][tap 9] (dcv_conv2d_prepare_filters op 4)
+__device__ __forceinline__ void rs_load_bfrag_prepared(const float* f, float4 (&b4)[9]) {
+    const int lane = threadIdx.x & 63, m = lane & 15, kq = lane >> 4;
+    const float4* wp = reinterpret_cast<const float4*>(f + ((size_t)m * 4 + kq) * 36);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) b4[q] = wp[q];
+}
+
 // 16 -> 16 channels, 3x3, rows of 16 pixels: per tap one ds_read_b128 (plane k = lane / 16: channels 4k .. 4k + 3 of pixel lane % 16) feeds four
 // v_mfma_f32_16x16x4_f32 (MFMA j contracts channels {j, 4 + j, 8 + j, 12 + j}).
+// `o.cout` < 16 (data gradient towards a 4-channel tensor): the B fragments of the missing channels are zero, only `o.cout` channels are stored.
 __device__ __forceinline__ bool rs_conv_c16_mfma(const dcv_resident_op& o, const float4* xin, float* yt, const float4 (&b4)[9], float* wsum) {
     const int H = o.h, XW = 18, XH = H + 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4, s = wave >> 3;
@@ -294,9 +311,10 @@ __device__ __forceinline__ bool rs_conv_c16_mfma(const dcv_resident_op& o, const
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, breg[18 + tap], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, breg[27 + tap], acc, 0, 0, 0);
             }
-        rs_mfma_store(o, acc, bias, yt + s * RS_Y + (r * 16 + 4 * kq) * 16 + m, sum, sq);
+        if (o.cout == 16) rs_mfma_store(o, acc, bias, yt + s * RS_Y + (r * 16 + 4 * kq) * 16 + m, sum, sq);
+        else rs_mfma_store_narrow(acc, yt + s * RS_Y + (size_t)r * 16 * o.cout, o.cout);
     }
-    rs_mfma_sums(sum, sq, wsum);
+    if (o.cout == 16) rs_mfma_sums(sum, sq, wsum);
     return true;
 }
 
@@ -669,6 +687,296 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
     if (blockIdx.x == 0 && t == 0) { stamps[0] = (unsigned long long)n_stamp; __hip_atomic_store((rs_gu32*)ctl, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
 
+// ------------------------------------------------------------------------------------------------ the backward chain
+// LDS map (dynamic): DZ [RS_SPB][RS_XIN] float4 (the zero-padded dz tile the data gradient reads; between a data gradient and the next dz it holds the
+// gather scratch) | Y [RS_SPB][RS_Y] (the layer's saved y) | DO [RS_SPB][RS_Y] (dout of the layer; then its data gradient = the next layer's dout).
+constexpr size_t RB_SMEM = RS_XIN_BYTES + 2 * RS_Y_BYTES;
+
+// data-gradient variant of a layer (forward cin -> cout, k): the forward kernels on the swapped channel counts
+__host__ __device__ __forceinline__ int rb_dgrad_variant(int cin, int cout, int k, int w) {
+    if (cout <= 4 && cin == 4 && (k == 3 || k == 5)) return 1;                       // 4 <- 4: VALU row pairs
+    if (cout == 16 && (cin == 16 || cin == 4) && k == 3 && w == 16) return 3;        // 16 / 4 <- 16: matrix cores
+    return 0;
+}
+
+__device__ __forceinline__ float rb_act_grad(float y, int act, float slope) { return dcv_act_grad_from_out(y, act, slope); }
+
+__global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_program p, unsigned* ctl, rs_u64* gran) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* dzt = reinterpret_cast<float4*>(smem);
+    float* yreg = reinterpret_cast<float*>(smem + RS_XIN_BYTES);
+    float* dor = reinterpret_cast<float*>(smem + RS_XIN_BYTES + RS_Y_BYTES);
+    float* arr = reinterpret_cast<float*>(smem + RS_ARR_OFF);
+    double* part = reinterpret_cast<double*>(smem + RS_PART_OFF);
+    __shared__ float s_wsum[16 * 4 * RS_MAXC];                                       // per-wave moments [wave][4][C]
+    __shared__ __attribute__((aligned(16))) float s_coef[RS_SPB][3][RS_MAXC];        // dz = act'(y) (P d + Q u + R)
+    __shared__ __attribute__((aligned(16))) float s_mr[2][RS_MAXC];                  // BatchNorm mean, rstd of the current layer
+    __shared__ float s_par[DCV_RESIDENT_BWD_MAX_OPS][5][RS_MAXC];                    // bn gamma, beta, mean, rstd, gn gamma of every layer
+    __shared__ float s_dummy[16 * 2 * RS_MAXC];
+    __shared__ unsigned s_gen;
+    __shared__ int s_fail;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int s_of_t = t >> 9, tt = t & 511;
+    const int N = p.n, G = (int)gridDim.x;
+    const bool valid0 = (int)blockIdx.x * RS_SPB < N, valid1 = (int)blockIdx.x * RS_SPB + 1 < N;
+    if (t == 0) { s_gen = __hip_atomic_load((rs_gu32*)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_fail = 0; }
+    int n_stamp = 0;
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(ctl + 4);
+    auto stamp = [&]() { if (blockIdx.x == 0 && t == 0 && n_stamp < RS_MAX_STAMPS) stamps[1 + n_stamp] = wall_clock64(); ++n_stamp; };
+    stamp();
+    // a sample's [HW * C] floats, HBM -> LDS region (flat), 8 float4 per thread in flight
+    auto load_flat = [&](const float* src, float* region, int floats_per_sample) {
+        const int n = (int)blockIdx.x * RS_SPB + s_of_t, v4 = floats_per_sample >> 2;
+        const float4* g = reinterpret_cast<const float4*>(src) + (size_t)(n < N ? n : 0) * v4;
+        float4* d = reinterpret_cast<float4*>(region + s_of_t * RS_Y);
+        for (int i0 = 0; i0 < v4; i0 += 8 * 512) {
+            float4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int i = i0 + tt + k * 512; v[k] = g[i < v4 ? i : 0]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int i = i0 + tt + k * 512; if (i < v4) d[i] = n < N ? v[k] : make_float4(0.f, 0.f, 0.f, 0.f); }
+        }
+    };
+    {   // per-channel parameters of every layer -> LDS; y and dout of the first op (the last layer) -> LDS
+        float pv = 0.f; int pslot = -1;
+        if (t < p.count * 5 * RS_MAXC) {
+            const int oi = rs_fdiv(t, 1.f / (float)(5 * RS_MAXC)), r = t - oi * 5 * RS_MAXC, f = r >> 4, c = r & 15;
+            const dcv_resident_bwd_op& o = p.op[oi];
+            if (c < o.cout) {
+                const float* src = f == 0 ? o.bn_gamma : f == 1 ? o.bn_beta : f == 2 ? o.bn_mean : f == 3 ? o.bn_rstd : o.gn_gamma;
+                pslot = t;
+                pv = (f == 0 || f == 4) ? 1.f : 0.f;
+                if (src != nullptr) pv = src[c];
+            }
+        }
+        const dcv_resident_bwd_op& o = p.op[0];
+        const int pk = o.pool > 0 ? o.pool : 1;
+        load_flat(o.y, yreg, o.h * o.w * o.cout);
+        load_flat(o.dout, dor, (o.h / pk) * (o.w / pk) * o.cout);
+        if (pslot >= 0) (&s_par[0][0][0])[pslot] = pv;
+    }
+    rs_barrier();
+    const unsigned gen = s_gen;
+    stamp();
+    for (int oi = 0; oi < p.count; ++oi) {
+        const dcv_resident_bwd_op& o = p.op[oi];
+        const int C = o.cout, CV = C >> 2, H = o.h, W = o.w, HW = H * W, pk = o.pool > 0 ? o.pool : 1, Wo = W / pk;
+        const float pinv = 1.f / (float)(pk * pk), inv_w = 1.f / (float)W, inv_pk = 1.f / (float)pk;
+        // the (sample, channel) threads of wave 0 request their GroupNorm statistics now; used after the moments
+        const int ac_ss = t >= C ? 1 : 0, ac_c = t - ac_ss * C, ac_n = (int)blockIdx.x * RS_SPB + ac_ss;
+        const int cpg = o.groups > 0 ? C / o.groups : 1;
+        float e_gr = 0.f, e_gm = 0.f;
+        if (t < RS_SPB * C && o.groups > 0 && ac_n < N) {
+            const int g = rs_fdiv(ac_c, 1.f / (float)cpg);
+            e_gr = o.gn_rstd[(size_t)ac_n * o.groups + g]; e_gm = o.gn_mean[(size_t)ac_n * o.groups + g];
+        }
+        if (t < C) { s_mr[0][t] = s_par[oi][2][t]; s_mr[1][t] = s_par[oi][3][t]; }
+        rs_barrier();
+        // ---- four moments per (sample, channel): sum d, sum d u, sum u, sum u^2 with u = (y - mean) rstd, d = dout through the pooling map.  Wave w8 of the
+        // sample owns channel vector w8 % CV and every (8 / CV)-th stripe of 64 pixels.
+        {
+            const int w8 = wave & 7, cv = w8 & (CV - 1), stripes = 8 / CV, st0 = w8 / CV;
+            const float4 mu = *reinterpret_cast<const float4*>(s_mr[0] + cv * 4), rs = *reinterpret_cast<const float4*>(s_mr[1] + cv * 4);
+            const float4* ys = reinterpret_cast<const float4*>(yreg + s_of_t * RS_Y);
+            const float4* ds = reinterpret_cast<const float4*>(dor + s_of_t * RS_Y);
+            float m8a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, m8b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // (d, du) and (u, uu) x 4 channels
+            for (int px = st0 * 64 + lane; px < HW; px += stripes * 64) {
+                const float4 y4 = ys[px * CV + cv];
+                int di = px;
+                if (pk > 1) { const int r = rs_fdiv(px, inv_w), c = px - r * W; di = rs_fdiv(r, inv_pk) * Wo + rs_fdiv(c, inv_pk); }
+                float4 d4 = ds[di * CV + cv];
+                d4.x *= pinv; d4.y *= pinv; d4.z *= pinv; d4.w *= pinv;
+                const float u0 = (y4.x - mu.x) * rs.x, u1 = (y4.y - mu.y) * rs.y, u2 = (y4.z - mu.z) * rs.z, u3 = (y4.w - mu.w) * rs.w;
+                m8a[0] += d4.x; m8a[1] += d4.y; m8a[2] += d4.z; m8a[3] += d4.w;
+                m8a[4] += d4.x * u0; m8a[5] += d4.y * u1; m8a[6] += d4.z * u2; m8a[7] += d4.w * u3;
+                m8b[0] += u0; m8b[1] += u1; m8b[2] += u2; m8b[3] += u3;
+                m8b[4] += u0 * u0; m8b[5] += u1 * u1; m8b[6] += u2 * u2; m8b[7] += u3 * u3;
+            }
+            float ra[2], rb[2];
+            rs_reduce8(m8a, ra); rs_reduce8(m8b, rb);
+            if (lane < 4) {
+                const int vi = (lane & 1) * 4 + ((lane >> 1) & 1) * 2;                // values vi, vi + 1 = (quantity vi / 4, channel vi % 4)
+                float* wr = s_wsum + wave * 4 * RS_MAXC;
+                wr[(vi >> 2) * RS_MAXC + cv * 4 + (vi & 3)] = ra[0]; wr[(vi >> 2) * RS_MAXC + cv * 4 + (vi & 3) + 1] = ra[1];
+                wr[(2 + (vi >> 2)) * RS_MAXC + cv * 4 + (vi & 3)] = rb[0]; wr[(2 + (vi >> 2)) * RS_MAXC + cv * 4 + (vi & 3) + 1] = rb[1];
+            }
+        }
+        rs_barrier();
+        stamp();
+        // ---- the sample's algebra (norm_chain.hip, nc_sample_sums_kernel's epilogue) by thread (sample, channel) of wave 0; publish the block's T1, T2
+        const unsigned epoch = gen * DCV_RESIDENT_MAX_OPS + (unsigned)oi + 1u;
+        rs_u64* go = gran + (size_t)oi * RS_MAXQ * RS_MAXG;
+        float P = 0.f, Q0 = 0.f, R0 = 0.f, a_bn = 0.f;
+        if (t < RS_SPB * C) {
+            const int ss = ac_ss, c = ac_c, ccv = c >> 2, j = c & 3, stripes = 8 / CV;
+            float mq[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < stripes; ++k) {
+                const float* wr = s_wsum + (ss * 8 + k * CV + ccv) * 4 * RS_MAXC + ccv * 4 + j;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) mq[q] += wr[q * RS_MAXC];
+            }
+            const double m0 = (double)mq[0], m1 = (double)mq[1], u1 = (double)mq[2], u2 = (double)mq[3];
+            const float gbn = s_par[oi][0][c], bbn = s_par[oi][1][c], brs = s_par[oi][3][c], ggn = s_par[oi][4][c];
+            a_bn = gbn * brs;
+            double S1 = m0, S2 = m1, T1 = m0, T2 = m1;
+            P = a_bn;
+            if (o.groups > 0) {
+                const double gr = (double)e_gr, al = (double)gbn * gr, be = ((double)bbn - (double)e_gm) * gr;
+                const double s2 = al * m1 + be * m0;
+                double A = (double)ggn * m0, Bs = (double)ggn * s2;
+                for (int off = 1; off < cpg; off <<= 1) { A += __shfl_xor(A, off, 64); Bs += __shfl_xor(Bs, off, 64); }
+                const double hw = (double)HW, ca = (double)ggn * gr, cb = A * o.inv_group * gr, cd = Bs * o.inv_group * gr;
+                S2 = s2;
+                T1 = ca * m0 - cb * hw - cd * (al * u1 + be * hw);
+                T2 = ca * m1 - cb * u1 - cd * (al * u2 + be * u1);
+                const double a = (double)gbn * (double)brs;
+                P = (float)(a * ca); Q0 = (float)(-a * al * cd); R0 = (float)(-a * (cb + be * cd));
+            }
+            const bool v = ss == 0 ? valid0 : valid1;
+            const float fS1 = v ? (float)S1 : 0.f, fS2 = v ? (float)S2 : 0.f, fT1 = v ? (float)T1 : 0.f, fT2 = v ? (float)T2 : 0.f;
+            // the block's totals: the two samples of a channel sit C lanes apart (C: a power of two <= 16)
+            const float bS1 = fS1 + __shfl_xor(fS1, C, 64), bS2 = fS2 + __shfl_xor(fS2, C, 64), bT1 = fT1 + __shfl_xor(fT1, C, 64), bT2 = fT2 + __shfl_xor(fT2, C, 64);
+            if (ss == 0) {
+                __hip_atomic_store((rs_gu64*)(go + (size_t)c * RS_MAXG + blockIdx.x), ((rs_u64)epoch << 32) | (rs_u64)__float_as_uint(bT1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store((rs_gu64*)(go + (size_t)(C + c) * RS_MAXG + blockIdx.x), ((rs_u64)epoch << 32) | (rs_u64)__float_as_uint(bT2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (o.groups > 0 && o.gn_part) { o.gn_part[((size_t)blockIdx.x * 2) * C + c] = bS1; o.gn_part[((size_t)blockIdx.x * 2 + 1) * C + c] = bS2; }
+            }
+        }
+        stamp();
+        // ---- gather every block's T1, T2 (the dz tile of the previous op is dead: the scratch lives there)
+        {
+            const int total = 2 * C * G;
+            const float inv_g = 1.f / (float)G;
+            bool ok = true;
+            constexpr int GP = RS_MAXQ * RS_MAXG / RS_T;
+            for (int i0 = 0; i0 < total; i0 += RS_T * GP) {
+                int idx[GP]; float gv[GP];
+#pragma unroll
+                for (int k = 0; k < GP; ++k) { const int i = i0 + k * RS_T + t; const int q = rs_fdiv(i, inv_g); idx[k] = i < total ? q * RS_MAXG + (i - q * G) : -1; }
+                bool got = false;
+                for (int spins = 0; spins < RS_SPINS; ++spins) {
+                    got = true;
+#pragma unroll
+                    for (int k = 0; k < GP; ++k) {
+                        if (idx[k] >= 0) {
+                            const rs_u64 g = __hip_atomic_load((rs_gu64*)(go + idx[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            gv[k] = __uint_as_float((unsigned)g);
+                            got &= (unsigned)(g >> 32) == epoch;
+                        }
+                    }
+                    if (__all(got)) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                ok &= (bool)__all(got);
+#pragma unroll
+                for (int k = 0; k < GP; ++k) if (idx[k] >= 0) arr[idx[k]] = gv[k];
+            }
+            if (!ok && lane == 0) s_fail = 1;
+            rs_barrier();
+            if (s_fail) {                                                            // a block of this grid is not resident: report, poison the first layer's dz, leave
+                if (t == 0) { __hip_atomic_store((rs_gu32*)(ctl + 1), (unsigned)oi + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                if (blockIdx.x == 0 && t < p.op[p.count - 1].cout) p.op[p.count - 1].dz[t] = __builtin_nanf("");
+                return;
+            }
+            stamp();
+            if (t < 2 * C * 16) {
+                const int q = t >> 4, j = t & 15;
+                double v = 0.0;
+                for (int i = j * 16; i < j * 16 + 16 && i < G; ++i) v += (double)arr[q * RS_MAXG + i];
+                part[q * 16 + j] = v;
+            }
+        }
+        rs_barrier();
+        if (t < RS_SPB * C) {
+            const int ss = ac_ss, c = ac_c;
+            double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { t1 += part[c * 16 + j]; t2 += part[(C + c) * 16 + j]; }
+            const float ad = a_bn * (float)(t2 * o.inv_count), ab = a_bn * (float)(t1 * o.inv_count);     // the batch terms (nc_param_finalize_kernel)
+            s_coef[ss][0][c] = P; s_coef[ss][1][c] = Q0 - ad; s_coef[ss][2][c] = R0 - ab;
+            if (blockIdx.x == 0 && ss == 0) { if (o.d_bn_beta) o.d_bn_beta[c] = (float)t1; if (o.d_bn_gamma) o.d_bn_gamma[c] = (float)t2; }
+        }
+        // the dz tile: zero it (halo; the scratch dirtied it), interior below
+        rs_barrier();
+        for (int i = t; i < RS_SPB * RS_XIN; i += RS_T) dzt[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        rs_barrier();
+        stamp();
+        // ---- dz = act'(y) (P d + Q u + R): -> HBM (what the weight-gradient kernels read) and the padded tile of the data gradient
+        {
+            const int pad = o.k / 2, XW = W + 2 * pad, XH = H + 2 * pad;
+            const float inv_cv = 1.f / (float)CV;
+            const int per = HW * CV;
+            for (int it = t; it < RS_SPB * per; it += RS_T) {
+                const int ss = it >= per ? 1 : 0, e = it - ss * per, px = rs_fdiv(e, inv_cv), cv = e - px * CV, r = rs_fdiv(px, inv_w), c = px - r * W;
+                const float4 y4 = reinterpret_cast<const float4*>(yreg + ss * RS_Y)[e];
+                const int di = pk > 1 ? rs_fdiv(r, inv_pk) * Wo + rs_fdiv(c, inv_pk) : px;
+                float4 d4 = reinterpret_cast<const float4*>(dor + ss * RS_Y)[di * CV + cv];
+                const float4 Pv = *reinterpret_cast<const float4*>(s_coef[ss][0] + cv * 4), Qv = *reinterpret_cast<const float4*>(s_coef[ss][1] + cv * 4);
+                const float4 Rv = *reinterpret_cast<const float4*>(s_coef[ss][2] + cv * 4);
+                const float4 mu = *reinterpret_cast<const float4*>(s_mr[0] + cv * 4), rs = *reinterpret_cast<const float4*>(s_mr[1] + cv * 4);
+                float4 z;
+                z.x = (Pv.x * (d4.x * pinv) + Qv.x * ((y4.x - mu.x) * rs.x) + Rv.x) * rb_act_grad(y4.x, o.act, o.slope);
+                z.y = (Pv.y * (d4.y * pinv) + Qv.y * ((y4.y - mu.y) * rs.y) + Rv.y) * rb_act_grad(y4.y, o.act, o.slope);
+                z.z = (Pv.z * (d4.z * pinv) + Qv.z * ((y4.z - mu.z) * rs.z) + Rv.z) * rb_act_grad(y4.z, o.act, o.slope);
+                z.w = (Pv.w * (d4.w * pinv) + Qv.w * ((y4.w - mu.w) * rs.w) + Rv.w) * rb_act_grad(y4.w, o.act, o.slope);
+                const int n = (int)blockIdx.x * RS_SPB + ss;
+                if (n < N) reinterpret_cast<float4*>(o.dz)[(size_t)n * per + e] = z; else z = make_float4(0.f, 0.f, 0.f, 0.f);
+                dzt[ss * RS_XIN + (cv * XH + r + pad) * XW + c + pad] = z;
+            }
+        }
+        rs_barrier();
+        stamp();
+        // ---- the next op's y -> LDS (this layer's y is dead), then the data gradient: dz tile -> DO = the next op's dout
+        if (oi + 1 < p.count) load_flat(p.op[oi + 1].y, yreg, p.op[oi + 1].h * p.op[oi + 1].w * p.op[oi + 1].cout);
+        if (o.need_dx) {
+            dcv_resident_op cv{};
+            cv.cin = o.cout; cv.cout = o.cin; cv.k = o.k; cv.h = H; cv.w = W; cv.act = DCV_ACT_NONE; cv.filt = o.filt; cv.bias = nullptr;
+            const int var = rb_dgrad_variant(o.cin, o.cout, o.k, o.w);
+            if (var == 1) { if (o.k == 5) rs_conv_c4_co4<5>(cv, dzt, dor, s_dummy); else rs_conv_c4_co4<3>(cv, dzt, dor, s_dummy); }
+            else { float4 b4[9]; rs_load_bfrag_prepared(o.filt, b4); rs_conv_c16_mfma(cv, dzt, dor, b4, s_dummy); }
+            rs_barrier();
+            if (o.addend != nullptr || o.dx != nullptr) {
+                const int v4 = (HW * o.cin) >> 2, n = (int)blockIdx.x * RS_SPB + s_of_t;
+                float4* d = reinterpret_cast<float4*>(dor + s_of_t * RS_Y);
+                for (int i = tt; i < v4 && n < N; i += 512) {
+                    float4 v = d[i];
+                    if (o.addend) { const float4 a = reinterpret_cast<const float4*>(o.addend)[(size_t)n * v4 + i]; v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; d[i] = v; }
+                    if (o.dx) reinterpret_cast<float4*>(o.dx)[(size_t)n * v4 + i] = v;
+                }
+            }
+        }
+        rs_barrier();
+        stamp();
+    }
+    if (blockIdx.x == 0 && t == 0) { stamps[0] = (unsigned long long)n_stamp; __hip_atomic_store((rs_gu32*)ctl, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+}
+
+inline bool rb_program_ok(const dcv_resident_bwd_program* p) {
+    if (!p || p->n <= 0 || p->n > RS_SPB * RS_MAXG || p->count <= 0 || p->count > DCV_RESIDENT_BWD_MAX_OPS || !p->op[0].dout) return false;
+    for (int i = 0; i < p->count; ++i) {
+        const dcv_resident_bwd_op& o = p->op[i];
+        if (o.cout != 4 && o.cout != 8 && o.cout != 16) return false;
+        if (o.h <= 0 || o.w <= 0 || o.h * o.w * o.cout > RS_Y || (o.k & 1) == 0 || o.k > 5) return false;
+        const int pad = o.k / 2;
+        if ((o.cout >> 2) * (o.h + 2 * pad) * (o.w + 2 * pad) > RS_XIN) return false;
+        if (o.groups < 0 || (o.groups > 0 && (o.cout % o.groups != 0 || ((o.cout / o.groups) & (o.cout / o.groups - 1)) || !o.gn_mean || !o.gn_rstd))) return false;
+        if (o.pool < 0 || o.pool == 1 || (o.pool > 0 && (o.h % o.pool != 0 || o.w % o.pool != 0 || o.groups == 0))) return false;
+        if (!o.y || !o.dz || !o.bn_mean || !o.bn_rstd || o.act < DCV_ACT_NONE || o.act > DCV_ACT_TANH) return false;
+        if (o.need_dx) {
+            const int var = rb_dgrad_variant(o.cin, o.cout, o.k, o.w);
+            if (var == 0 || !o.filt) return false;
+            if (var == 1 && ((o.h & 1) || (o.h >> 1) * o.w > 512)) return false;
+            if (o.h * o.w * o.cin > RS_Y || (o.cin & 3)) return false;
+        } else if (i + 1 < p->count) return false;                   // only the last op (the model's first layer) may skip its data gradient
+        if (i + 1 < p->count) {
+            const dcv_resident_bwd_op& nx = p->op[i + 1];
+            const int pk = nx.pool > 0 ? nx.pool : 1;
+            if (nx.cout != o.cin || nx.h / pk != o.h || nx.w / pk != o.w) return false;      // this op's data gradient is the next op's dout
+        }
+    }
+    return true;
+}
+
 inline bool rs_layer_ok(const dcv_resident_op& o, bool first) {
     const int var = rs_variant(o.cin, o.cout, o.k, o.w);
     if (var == 0 || o.h <= 0 || o.w <= 0 || o.cin <= 0) return false;
@@ -731,6 +1039,23 @@ int dcv_resident_forward(const dcv_resident_program* p, void* ws, size_t ws_byte
     }
     const unsigned grid = (unsigned)((p->n + RS_SPB - 1) / RS_SPB);
     hipLaunchKernelGGL(resident_fwd_kernel, dim3(grid), dim3(RS_T), RS_SMEM, dcv_stream(stream), *p, reinterpret_cast<unsigned*>(ws),
+                       reinterpret_cast<rs_u64*>(reinterpret_cast<char*>(ws) + RS_CTL_BYTES));
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_resident_bwd_supported(const dcv_resident_bwd_program* p) { return rb_program_ok(p) ? 1 : 0; }
+
+int dcv_resident_backward(const dcv_resident_bwd_program* p, void* ws, size_t ws_bytes, void* stream) {
+    DCV_CHECK_ARG(p && ws);
+    if (!rb_program_ok(p)) return DCV_ERR_UNSUPPORTED;
+    if (ws_bytes < dcv_resident_ws_bytes()) return DCV_ERR_WORKSPACE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(resident_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RB_SMEM) != hipSuccess) return DCV_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const unsigned grid = (unsigned)((p->n + RS_SPB - 1) / RS_SPB);
+    hipLaunchKernelGGL(resident_bwd_kernel, dim3(grid), dim3(RS_T), RB_SMEM, dcv_stream(stream), *p, reinterpret_cast<unsigned*>(ws),
                        reinterpret_cast<rs_u64*>(reinterpret_cast<char*>(ws) + RS_CTL_BYTES));
     DCV_RETURN_LAUNCH();
 }

@@ -687,6 +687,10 @@ class _ConvNormLayerFn(torch.autograd.Function):
             y = torch.empty((d.n, d.cout, d.ho, d.wo), dtype=torch.float32, device=dev, memory_format=_CL)
             out = torch.empty_like(y) if not pool else torch.empty((d.n, d.cout, d.ho // pool, d.wo // pool), dtype=torch.float32, device=dev, memory_format=_CL)
             rec.add_layer(x, d, cfg, layout, weight, filt, bias, bn_w, bn_b, running_mean, running_var, nbt, gn_w, gn_b, y, out, bn_mean, bn_rstd, gn_mean, gn_rstd)
+            need = ctx.needs_input_grad
+            ctx.res_plan = (rec.plan, rec.plan.add_layer(d, cfg, [weight if need[1] else None, bias if need[2] else None, bn_w if need[3] else None,
+                                                                 bn_b if need[4] else None, gn_w if need[8] else None, gn_b if need[9] else None],
+                                                         need[0], bias is not None and need[2] and not need[1]))
             ctx.desc, ctx.cfg = d, cfg
             ctx.save_for_backward(x, weight, bias, y, bn_w, bn_b, bn_mean, bn_rstd, gn_w, gn_mean, gn_rstd)
             return out
@@ -745,6 +749,53 @@ class _ConvNormLayerFn(torch.autograd.Function):
         d_gn_w = new(r_gn_w) if (gn_w is not None and need[8]) else None
         d_gn_b = new(r_gn_b) if (groups and need[9]) else None
         dz = torch.empty_like(y)
+        plan = getattr(ctx, 'res_plan', None)
+        if plan is not None and not ctx.use16:
+            # the forward of this layer stack was ONE persistent launch: so is the serial chain of its backward pass when the plan allows it
+            plan, index = plan
+            if plan.state is None:
+                plan.decide(index, dout, lambda dd: bool(lib.dcv_conv2d_wgrad_fuses_bias(dd)))
+            if plan.state == 'fused':
+                plan.expect(index, dout)
+                op = nat.ResidentBwdOp()
+                op.cin, op.cout, op.k, op.h, op.w, op.act, op.slope, op.groups, op.pool = d.cin, d.cout, d.r, d.h, d.w, act, slope, groups, pool
+                op.inv_count = 1.0 / (float(d.n) * hw)
+                op.inv_group = 1.0 / (float(hw) * (c // groups)) if groups else 0.0
+                op.y, op.dz = y.data_ptr(), dz.data_ptr()
+                op.dout = dout.data_ptr() if not plan.ops else None
+                op.bn_gamma, op.bn_beta, op.bn_mean, op.bn_rstd = nat.ptr(bn_w), nat.ptr(bn_b), bn_mean.data_ptr(), bn_rstd.data_ptr()
+                op.gn_gamma, op.gn_mean, op.gn_rstd = nat.ptr(gn_w), nat.ptr(gn_mean), nat.ptr(gn_rstd)
+                op.d_bn_gamma, op.d_bn_beta = nat.ptr(d_bn_w), nat.ptr(d_bn_b)
+                # (the parameter-gradient buffers are only passed by address: the engine's AccumulateGrad adopts a gradient as `.grad` when it is its sole
+                # owner and COPIES it otherwise — a copy taken now, before the launch has filled the buffer)
+                keep = [y, dz, dout, bn_w, bn_b, bn_mean, bn_rstd, gn_w, gn_mean, gn_rstd]
+                if groups and (d_gn_w is not None or d_gn_b is not None):
+                    blocks = (d.n + 1) // 2
+                    gn_part = torch.empty(blocks * 2 * c, dtype=torch.float32, device=dev)
+                    op.gn_part = gn_part.data_ptr()
+                    segs, k = (nat.SlabSegment * 2)(), 0
+                    for off, dst in ((0, d_gn_b), (c, d_gn_w)):                    # d_gn_beta = sum S1, d_gn_gamma = sum S2 over the blocks
+                        if dst is not None:
+                            segs[k].src, segs[k].dst, segs[k].count, segs[k].stride, segs[k].chunks = gn_part.data_ptr() + 4 * off, dst.data_ptr(), c, 2 * c, blocks
+                            k += 1
+                    slabs.defer(dev, st, segs, k, gn_part)
+                dx = None
+                if need[0]:
+                    dx = torch.empty((d.n, d.cin, d.h, d.w), dtype=torch.float32, device=dev, memory_format=_CL)
+                    filt = filters.get(weight, d, 4)
+                    addend = _fan_addend(ctx.fan_slot, dx.shape)
+                    op.need_dx, op.filt, op.addend = 1, filt.data_ptr(), nat.ptr(addend)
+                    if addend is not None:
+                        ctx.fan_slot.consumed = True
+                    if index == 0:
+                        op.dx = dx.data_ptr()                                      # nothing consumes it in LDS: the model input's gradient goes to HBM
+                    keep += [dx, filt, addend]
+                plan.add(op, dx, keep, st)
+                dw = None
+                if need[1]:
+                    dw = _grad_buffer(ctx.weight_ref, like=weight)
+                    _conv_wgrad_launch(d, x, dz, ctx.weight_ref, ctx.bias_ref, dw, db, st)      # deferred: runs at the flush, after the launch above
+                return dx, dw, db, d_bn_w, d_bn_b, None, None, None, d_gn_w, d_gn_b, None
         if ctx.streaming:
             nc = _norm_chain_desc(d, ctx.cfg, bn_w, bn_b, None, None, None, bn_mean, bn_rstd, gn_w, None, gn_mean, gn_rstd)
             coef = torch.empty(int(lib.dcv_norm_chain_coef_floats(nc)), dtype=torch.float32, device=dev)

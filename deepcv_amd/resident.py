@@ -24,10 +24,13 @@ from ._native import lib
 __all__ = ['Ineligible', 'Recorder', 'recorder', 'forbid', 'enabled', 'set_enabled', 'disable_if_gpu_shared', 'wanted', 'mark_ineligible', 'check_status', 'launches']
 
 _enabled = os.environ.get('DCV_RESIDENT', '1') not in ('0', 'false', 'False', '')
+_bwd_enabled = os.environ.get('DCV_RESIDENT_BWD', '1') not in ('0', 'false', 'False', '')
 _active: Optional['Recorder'] = None
 _verdicts: Dict[int, Tuple['weakref.ref', Dict[tuple, str]]] = {}   # id(module) -> (weak reference, {(input shape, training): reason it is not eligible})
 _ws: Dict[torch.device, torch.Tensor] = {}                          # persistent control words + granules per device (zeroed once)
 _launches = 0
+_bwd_launches = 0
+_ws_bwd: Dict[torch.device, torch.Tensor] = {}
 
 
 class Ineligible(Exception):
@@ -42,6 +45,17 @@ def set_enabled(value: bool) -> bool:
     global _enabled
     prev, _enabled = _enabled, bool(value)
     return prev
+
+
+def set_backward_enabled(value: bool) -> bool:
+    """ The persistent launch of the backward chain (`dcv_resident_backward`) on / off; the forward launch is governed by `set_enabled`. """
+    global _bwd_enabled
+    prev, _bwd_enabled = _bwd_enabled, bool(value)
+    return prev
+
+
+def backward_launches() -> int:
+    return _bwd_launches
 
 
 def launches() -> int:
@@ -120,7 +134,7 @@ def _workspace(device: torch.device) -> torch.Tensor:
 def check_status(device=None):
     """ Raises if a resident launch on `device` gave up waiting for the other blocks of its grid (a grid which is not fully resident: e.g. three processes
     sharing the GPU).  Synchronises the current stream: call it where the host waits anyway. """
-    for dev, ws in list(_ws.items()):
+    for dev, ws in list(_ws.items()) + list(_ws_bwd.items()):
         if device is not None and dev != torch.device(device):
             continue
         err = ctypes.c_int(0)
@@ -143,6 +157,7 @@ class Recorder:
         self.cur: Optional[torch.Tensor] = x
         self.noted: List[Optional[torch.Tensor]] = []
         self.layer_outs: Dict[int, Tuple[int, int, int]] = {}     # data_ptr of a recorded layer output -> (c, h, w)
+        self.plan = BackwardPlan(self.n, self.device)
 
     # ---- context
     def __enter__(self):
@@ -265,3 +280,99 @@ class Recorder:
         nat.check(lib.dcv_resident_forward(prog, ws.data_ptr(), ws.numel(), nat.current_stream(self.device)), 'dcv_resident_forward')
         _launches += 1
         self.keep.clear()
+
+
+class BackwardPlan:
+    """ The layers of one recorded forward, for the backward pass: when the autograd engine reaches the LAST layer's node the plan decides, for all layers
+    at once, whether the serial chain of the backward pass (normalisation-chain backward + data gradient of every layer) runs as ONE persistent launch
+    (`dcv_resident_backward`); the layers' backward functions (`deepcv_amd.ops._ConvNormLayerFn.backward`) then only allocate their results and describe
+    themselves, and the launch happens at the start of `deepcv_amd.slabs.flush()`, ahead of the weight gradients which read its dz tensors.  Anything the
+    launch would get wrong — gradients the engine would add to existing `.grad`s before they are computed, a second-order pass, shapes the kernel does not
+    cover — is decided BEFORE the first layer records itself: the per-layer kernels then serve the whole pass. """
+
+    def __init__(self, n: int, device: torch.device):
+        self.n, self.device = n, device
+        self.layers: List[dict] = []          # forward order: desc, cfg, grad_params, needs_dx
+        self.state: Optional[str] = None      # None: undecided, 'fused', 'plain'
+        self.next_index = -1
+        self.prev_dx: Optional[torch.Tensor] = None
+        self.ops: List[nat.ResidentBwdOp] = []
+        self.keep: List[torch.Tensor] = []
+        self.stream = 0
+
+    def add_layer(self, d: nat.Conv2dDesc, cfg, grad_params, needs_dx: bool, bias_without_weight: bool) -> int:
+        self.layers.append({'d': nat.Conv2dDesc.from_buffer_copy(d), 'cfg': cfg, 'params': [p for p in grad_params if p is not None], 'needs_dx': bool(needs_dx),
+                            'odd': bool(bias_without_weight)})
+        return len(self.layers) - 1
+
+    def _skeleton(self) -> nat.ResidentBwdProgram:
+        prog = nat.ResidentBwdProgram()
+        prog.n, prog.count = self.n, len(self.layers)
+        for k, layer in enumerate(reversed(self.layers)):
+            d, cfg = layer['d'], layer['cfg']
+            op = prog.op[k]
+            op.cin, op.cout, op.k, op.h, op.w, op.act, op.slope, op.groups, op.pool = d.cin, d.cout, d.r, d.h, d.w, cfg[3], cfg[4], cfg[7], cfg[9]
+            op.need_dx = 1 if layer['needs_dx'] else 0
+            for f in ('y', 'dz', 'bn_mean', 'bn_rstd', 'gn_mean', 'gn_rstd', 'filt'):
+                setattr(op, f, 16)
+            if k == 0:
+                op.dout = 16
+        return prog
+
+    def decide(self, index: int, dout: torch.Tensor, bias_from_wgrad) -> bool:
+        """ Called by the first backward node of the stack to run (it must be the last layer's).  True: the pass is recorded. """
+        from . import slabs
+        self.state = 'plain'
+        if not (_enabled and _bwd_enabled) or index != len(self.layers) - 1 or len(self.layers) > nat.RESIDENT_BWD_MAX_OPS:
+            return False
+        if slabs._current_pass() in (None, -1) or any(layer['odd'] for layer in self.layers):      # not an engine-driven pass: no final callback to launch from
+            return False
+        if torch.is_grad_enabled() or not slabs.enabled() or not (dout.is_cuda and dout.dtype == torch.float32 and dout.dim() == 4 and dout.is_contiguous(memory_format=torch.channels_last)):
+            return False
+        if not all(slabs.would_defer(*layer['params']) for layer in self.layers):
+            return False
+        if not all(bias_from_wgrad(layer['d']) for layer in self.layers):
+            return False
+        if not lib.dcv_resident_bwd_supported(self._skeleton()):
+            return False
+        self.state, self.next_index, self.prev_dx = 'fused', index, None
+        self.ops, self.keep = [], []
+        return True
+
+    def expect(self, index: int, dout: torch.Tensor):
+        if index != self.next_index or (self.prev_dx is not None and (dout.data_ptr() != self.prev_dx.data_ptr() or tuple(dout.shape) != tuple(self.prev_dx.shape))):
+            raise RuntimeError('deepcv_amd.resident: the backward pass left the recorded chain (a gradient of an intermediate tensor was consumed or replaced by '
+                               'something else than the next layer); set DCV_RESIDENT_BWD=0 for this model')
+
+    def add(self, op: nat.ResidentBwdOp, dx: Optional[torch.Tensor], keep, stream: int):
+        from . import slabs
+        if not self.ops:
+            self.stream = stream
+            slabs.before_flush(self.launch)
+        self.ops.append(op)
+        self.keep.extend(t for t in keep if t is not None)
+        self.prev_dx = dx
+        self.next_index -= 1
+
+    def launch(self):
+        global _bwd_launches
+        ops, self.ops = self.ops, []
+        keep, self.keep = self.keep, []
+        self.state, self.prev_dx = None, None
+        if not ops:
+            return
+        prog = nat.ResidentBwdProgram()
+        prog.n, prog.count = self.n, len(ops)
+        for i, op in enumerate(ops):
+            prog.op[i] = op
+        ws = _ws_bwd.get(self.device)
+        if ws is None:
+            ws = _ws_bwd[self.device] = torch.zeros(int(lib.dcv_resident_ws_bytes()), dtype=torch.uint8, device=self.device)
+        cur = nat.current_stream(self.device)
+        if cur != self.stream:               # the engine ran the backward functions on the stream of their forward ops (see slabs.flush)
+            torch.cuda.current_stream(self.device).wait_stream(torch.cuda.ExternalStream(self.stream, device=self.device))
+        nat.check(lib.dcv_resident_backward(prog, ws.data_ptr(), ws.numel(), cur), 'dcv_resident_backward')
+        if cur != self.stream:
+            for t in keep:
+                t.record_stream(torch.cuda.current_stream(self.device))
+        _bwd_launches += 1

@@ -24,7 +24,7 @@ import torch
 from . import _native as nat
 from ._native import lib
 
-__all__ = ['enabled', 'set_enabled', 'note_use', 'unnote_use', 'may_defer', 'reset_uses', 'defer', 'defer_wgrad', 'flush', 'pending']
+__all__ = ['enabled', 'set_enabled', 'note_use', 'unnote_use', 'may_defer', 'would_defer', 'before_flush', 'reset_uses', 'defer', 'defer_wgrad', 'flush', 'pending']
 
 _enabled = True
 _lock = threading.Lock()
@@ -95,6 +95,30 @@ def may_defer(*params) -> bool:
     return single and all(p is None or p.grad is None for p in params)
 
 
+def would_defer(*params) -> bool:
+    """ What `may_defer(*params)` would answer, without consuming the recorded uses (a backward function deciding for several layers at once). """
+    if not _enabled or torch.is_grad_enabled():
+        return False
+    with _lock:
+        for p in params:
+            u = _uses.get(id(p)) if p is not None else None
+            if u is not None and u[2]() is p and u[1] > 1:
+                return False
+    return all(p is None or p.grad is None for p in params)
+
+
+_preflush: List = []
+
+
+def before_flush(fn):
+    """ `fn()` runs once at the start of the next flush, before the queued weight gradients and slab sums (the persistent backward launch of
+    `deepcv_amd.resident`, which produces the dz tensors those weight gradients read).  Makes sure a flush is coming. """
+    _enter_pass()
+    with _lock:
+        _preflush.append(fn)
+    _queue_flush()
+
+
 def reset_uses():
     """ Forgets the recorded forward uses (forward passes whose backward never ran would otherwise keep their parameters on the immediate path). """
     with _lock:
@@ -116,6 +140,7 @@ def _enter_pass():
             if _callback_queued:
                 _pending.clear()
                 _wgrads.clear()
+                _preflush.clear()
                 _callback_queued = False
             _pass_id = pid
 
@@ -172,9 +197,13 @@ def flush():
     with _lock:
         jobs = [] if stale else list(_pending)
         wjobs = [] if stale else list(_wgrads)
+        pre = [] if stale else list(_preflush)
         _pending.clear()
         _wgrads.clear()
+        _preflush.clear()
         _callback_queued = False
+    for fn in pre:
+        fn()
     groups: Dict[Tuple[torch.device, int], Dict[str, List]] = {}
     for dev, st, segs, ws in jobs:
         groups.setdefault((dev, st), {'segs': [], 'keep': [], 'wgrads': []})['segs'].extend(segs)

@@ -133,6 +133,8 @@ int dcv_conv2d_wgrad_fuses_bias(const dcv_conv2d_desc* d);
  *                               of a transposed copy (descriptor: h, w, cin of the activations, cout = O, r = h, s = w, stride 1, no padding; the weight
  *                               gradient comes back in [O][C*H*W] order through dcv_slab_segment.tr_a / tr_b)
  *                               op 3 = the forward filter of a layer of the LDS-resident network (dcv_resident_forward): [R][S][cin rounded up to 4][cout]
+ *                               op 4 = its data-gradient filter (dcv_resident_backward): transposed + flipped [R][S][cout4][cin4], or the matrix-core
+ *                               B fragments [16][4][4][9] for 3x3 layers with 16 output channels on rows of 16 pixels
  *   dcv_conv2d_prepare_filters  re-lays out `count` filters (entries whose size is 0 are skipped; filters[k] may then be NULL)
  *   dcv_conv2d_*_prepared       as dcv_conv2d_fwd / dcv_conv2d_dgrad with the filter prepared for exactly this descriptor (w still required: fallback paths) */
 size_t dcv_conv2d_filter_bytes(const dcv_conv2d_desc* d, int op);
@@ -562,6 +564,36 @@ size_t dcv_resident_ws_bytes(void);
 int dcv_resident_forward(const dcv_resident_program* p, void* ws, size_t ws_bytes, void* stream);
 /* host read of the error word of `ws` (synchronises the stream): 0, or 1 + index of the op whose gather timed out */
 int dcv_resident_status(const void* ws, void* stream, int* err);
+
+/* The serial chain of the BACKWARD pass of the same layer stack as a second persistent launch (same block / sample mapping; its blocks use ~110 KB of LDS:
+ * one per CU): per layer, last to first, the normalisation-chain backward of dcv_norm_chain_bwd (four moments per (sample, channel), the sample's
+ * GroupNorm algebra, the BatchNorm batch terms through ONE gather of the blocks' partial sums, dz = act'(y) (P dout + Q u + R)) and the data gradient
+ * (the forward convolution kernels on the zero-padded dz tile with the transposed + flipped filter, op 4 of dcv_conv2d_prepare_filters), whose result is
+ * the next layer's dout and never leaves LDS.  replaces autograd's walk over the `layer()` stack (src/deepcv/meta/ignite_training.py:253 `loss.backward()`).
+ * Written to HBM: dz of every layer (what the weight-gradient kernels read, dcv_conv2d_wgrad_batch), d_bn_gamma / d_bn_beta (block 0, from the gathered
+ * totals), per-block partial sums of the GroupNorm parameter gradients (`gn_part`, [blocks][2][cout]: d_gn_beta, d_gn_gamma = their sums over the
+ * blocks, dcv_slab_reduce) and, if asked for, dx of the first layer.
+ *   ops          layers in BACKWARD order; op 0 reads its output gradient `dout` from HBM ([n][h/pool][w/pool][cout]), the others from the previous op's
+ *                data gradient; `addend` (nullable, [n][h][w][cin]) is added to an op's data gradient (the gradient of a dense link)
+ *   ws           its own persistent, zero-initialised workspace of dcv_resident_ws_bytes() */
+typedef struct dcv_resident_bwd_op {
+    int cin, cout, k, h, w;            /* forward geometry of the layer */
+    int act; float slope;
+    int groups, pool;                  /* GroupNorm groups (0: none), average pooling window behind the layer (0: none) */
+    int need_dx;                       /* compute the data gradient (0 for the first layer of the model) */
+    double inv_count, inv_group;       /* 1 / (n h w), 1 / (h w cout / groups) */
+    const float* y;                    /* saved activated convolution output */
+    const float* dout; const float* addend;
+    const float* filt;                 /* data-gradient filter (op 4); unused when !need_dx */
+    const float* bn_gamma; const float* bn_beta; const float* bn_mean; const float* bn_rstd;
+    const float* gn_gamma; const float* gn_mean; const float* gn_rstd;
+    float* dz; float* dx;              /* dx: nullable (HBM copy of the last op's data gradient) */
+    float* d_bn_gamma; float* d_bn_beta; float* gn_part;
+} dcv_resident_bwd_op;
+#define DCV_RESIDENT_BWD_MAX_OPS 8
+typedef struct dcv_resident_bwd_program { int n; int count; dcv_resident_bwd_op op[DCV_RESIDENT_BWD_MAX_OPS]; } dcv_resident_bwd_program;
+int dcv_resident_bwd_supported(const dcv_resident_bwd_program* p);
+int dcv_resident_backward(const dcv_resident_bwd_program* p, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

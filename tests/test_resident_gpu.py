@@ -16,31 +16,35 @@ def _model(params, spec, device):
     return create_model({'trainset': SyntheticImageDataset(8)}, params[spec]).to(device)
 
 
-def _run(model, x, y, resident_on):
+def _run(model, x, y, resident_on, backward_on=False):
     from deepcv_amd import modules, resident
-    prev = resident.set_enabled(resident_on)
+    prev, prev_b = resident.set_enabled(resident_on), resident.set_backward_enabled(backward_on)
     try:
-        before = resident.launches()
+        before, before_b = resident.launches(), resident.backward_launches()
         model.train()
         logits = model(x)
         loss = modules.CrossEntropyLoss()(logits, y)
         loss.backward()
         torch.cuda.synchronize()
         resident.check_status()
+        assert resident.backward_launches() - before_b == (1 if (resident_on and backward_on) else 0), 'the persistent backward launch did not run'
         return logits.detach().clone(), loss.item(), resident.launches() - before
     finally:
         resident.set_enabled(prev)
+        resident.set_backward_enabled(prev_b)
 
 
+@pytest.mark.parametrize('backward_on', [False, True], ids=['forward', 'forward+backward'])
 @pytest.mark.parametrize('bs', [2, 7, 64, 511, 512])
-def test_resident_forward_matches_per_layer_kernels(device, params, bs):
+def test_resident_forward_matches_per_layer_kernels(device, params, bs, backward_on):
     """ Logits, loss, every parameter gradient (the backward pass reads the tensors the resident launch saved: y, layer outputs, BatchNorm / GroupNorm
-    statistics) and the running statistics, against the per-layer path.  Odd batch sizes leave a block with one sample. """
+    statistics; with `backward_on` its serial chain is the second persistent launch) and the running statistics, against the per-layer path.  Odd batch
+    sizes leave a block with one sample. """
     from deepcv_amd import resident
     g = torch.Generator().manual_seed(DATA_SEED)
     x, y = torch.randn(bs, 3, 32, 32, generator=g).to(device), torch.randint(0, 10, (bs,), generator=g).to(device)
     a, b = _model(params, 'image_classifier_model', device), _model(params, 'image_classifier_model', device)
-    la, loss_a, n_a = _run(a, x, y, True)
+    la, loss_a, n_a = _run(a, x, y, True, backward_on)
     lb, loss_b, n_b = _run(b, x, y, False)
     assert n_a == 1, f'the resident path did not run: {resident.why_not(a, x)}'
     assert n_b == 0
@@ -70,7 +74,7 @@ def test_resident_forward_matches_oracle_at_the_bench_batch(device, params):
     oracle.train()
     lo = oracle(x)
     loss_o = torch.nn.functional.cross_entropy(lo, y).item()
-    ln, loss_n, n = _run(model, x.to(device), y.to(device), True)
+    ln, loss_n, n = _run(model, x.to(device), y.to(device), True, True)
     assert n == 1, resident.why_not(model, x.to(device))
     rel = ((ln.cpu() - lo.detach()).abs().max() / lo.detach().abs().max()).item()
     assert rel <= 1e-3 and abs(loss_n - loss_o) <= 1e-4 * abs(loss_o), (rel, loss_n, loss_o)

@@ -1,4 +1,4 @@
-"""Phase times of the resident forward launch (block 0's 100 MHz time stamps, `resident.hip`): stock model, bs 512, inside replayed training steps.
+"""Phase times of the two persistent launches (block 0's 100 MHz time stamps, `resident.hip`): stock model, bs 512, inside replayed training steps.
 usage: resident_stamps.py [steps]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,24 +19,33 @@ step = GraphedTrainStep(model, opt, losses, weights)
 bs = int(os.environ.get('BS', '512'))
 x, y = torch.randn(bs, 3, 32, 32, device=dev), torch.randint(0, 10, (bs,), device=dev)
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-acc = None
+acc = {}
 for i in range(steps):
     step(x, y)
     torch.cuda.synchronize()
-    ws = resident._ws[dev]
-    st = ws[16:16 + 8 * 121].view(torch.int64).cpu()
-    n = int(st[0])
-    t = st[1:1 + n].double() * 0.01      # us
-    d = t[1:] - t[:-1]
-    if i >= 5:
-        acc = d if acc is None else acc + d
-        cnt = i - 4
-names = ['stage input']
+    for tag, table in (('forward', resident._ws), ('backward', resident._ws_bwd)):
+        if dev not in table:
+            continue
+        st = table[dev][16:16 + 8 * 121].view(torch.int64).cpu()
+        n = int(st[0])
+        t = st[1:1 + n].double() * 0.01      # us
+        d = t[1:] - t[:-1]
+        if i >= 5:
+            acc[tag] = d if tag not in acc else acc[tag] + d
+cnt = steps - 5
+fwd = ['stage input']
 for l in range(5):
-    names += [f'L{l + 1} conv (+ sums)', f'L{l + 1} combine + publish', f'L{l + 1} gather', f'L{l + 1} fp64 sums + coefficients', f'L{l + 1} apply']
-names += ['link', 'fc']
-tot = 0.
-for k, v in enumerate((acc / cnt).tolist()):
-    print(f'{names[k] if k < len(names) else k:28s} {v:7.2f} us')
-    tot += v
-print(f'{"total (block 0)":28s} {tot:7.2f} us')
+    fwd += [f'L{l + 1} conv (+ sums)', f'L{l + 1} combine + publish', f'L{l + 1} gather', f'L{l + 1} fp64 sums + coefficients', f'L{l + 1} apply']
+fwd += ['link', 'fc']
+bwd = ['load y, dout']
+for l in range(5, 0, -1):
+    bwd += [f'L{l} moments', f'L{l} algebra + publish', f'L{l} gather', f'L{l} fp64 sums, coefficients, zero tile', f'L{l} dz', f'L{l} next y + data gradient']
+for tag, names in (('forward', fwd), ('backward', bwd)):
+    if tag not in acc:
+        continue
+    print(f'--- {tag} launch')
+    tot = 0.
+    for k, v in enumerate((acc[tag] / cnt).tolist()):
+        print(f'{names[k] if k < len(names) else k:40s} {v:7.2f} us')
+        tot += v
+    print(f'{"total (block 0)":40s} {tot:7.2f} us')
