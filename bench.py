@@ -8,8 +8,10 @@ A step = one pass of the hot path over one batch of 512 synthetic 3x32x32 images
 all-reduce (N > 1) and AdamW update with the stock piecewise-linear LR schedule, plus the per-step loss read-back of the reference's `process_function`
 (`src/deepcv/meta/ignite_training.py:233-255`).  Inputs are resident in HBM when the timed region starts (a pool of 16 device batches is cycled).
 Rank 0 prints ONE JSON line.  Besides the whole-job throughput it carries
-  * `roofline`: the dominant kernel (direct 5x5 4->4 convolution, `conv_tile_kernel<4,5,2>`, 4 launches per step: 2 forward + 2 data-gradient), timed
-    live with HIP events on the launch stream; achieved = algorithmic bytes per launch (SURVEY.md §8d) / average launch duration, against 8 TB/s HBM;
+  * `roofline`: the dominant kernel — the slower of the step's two persistent launches (`resident_fwd_kernel`: the whole forward, `resident_bwd_kernel`:
+    the serial chain of the backward pass; together more than half of the step), each re-launched with the step's own program and timed live with HIP
+    events on the launch stream; achieved = algorithmic HBM bytes per launch / average launch duration, against 8 TB/s HBM; when the
+    resident path is off (DCV_RESIDENT=0) the per-layer path's dominant kernel, `conv_tile_kernel<4,5,2>`, is reported instead;
   * `cpu_baseline`: the PyTorch-CPU oracle restatement of the same step on the host cores of this box, on a bounded sample (rank 0, N = 1 only);
   * `parity`: the losses of the first PARITY_STEPS steps of THIS run (same seeds, batches and schedule) against the CPU oracle, outside the timed region;
     at N = 1 a relative loss error above 1e-4 (BASELINE.json `north_star`) makes the run exit non-zero;
@@ -78,11 +80,59 @@ def cpu_baseline(params, budget_s: float = 20.0):
             'sample': f'{steps} training steps of batch {BATCH_PER_GPU} ({dt:.1f} s) of the PyTorch-CPU oracle (oracle/deepcv_oracle.py), AdamW, fp32'}
 
 
-def dominant_kernel_roofline(device, launches: int = 200):
-    """ Times `conv_tile_kernel<4,5,2>` (N=512, 32x32, 4 -> 4 channels, 5x5, pad 2, fused bias + ReLU: layers 2-3 forward and, with the flipped filter,
-    their data gradients) through the C-ABI exactly as the training step launches it (`dcv_conv2d_fwd_prepared`: the filter was re-laid out once, so a
-    launch is that one kernel), with HIP events recorded on the stream the kernel is launched on (torch's current stream).
-    `traffic` is the HBM traffic per launch measured with the PMC counters in separate rocprofv3 passes (profiles/r01_pmc_conv_tile_traffic.json). """
+def dominant_kernel_roofline(device, params, launches: int = 200):
+    """ The two persistent launches which make up most of the step (`resident_fwd_kernel`: the whole forward; `resident_bwd_kernel`: the serial chain of
+    the backward pass: deepcv_amd/csrc/resident.hip) timed live: one eager training step of a scratch copy of the model records the very programs the
+    step launches (`deepcv_amd.resident.capture_programs`), each is then re-launched through the C-ABI (`dcv_resident_forward` / `dcv_resident_backward`)
+    with HIP events recorded on the launch stream.  The slower one is reported as the dominant kernel; `achieved` = its algorithmic HBM bytes per launch
+    (`deepcv_amd.resident.algorithmic_bytes`) / its average duration.  `traffic` = HBM bytes per launch from the PMC counters in separate
+    rocprofv3 passes over this command (tools/pmc_traffic.py -> profiles/rNN_pmc_resident_traffic.json). """
+    from deepcv_amd import _native as nat, modules, resident
+    from deepcv_amd.classification.image import create_model
+    from deepcv_amd.meta.data.datasets import SyntheticImageDataset
+    torch.manual_seed(MODEL_SEED)
+    model = create_model({'trainset': SyntheticImageDataset(BATCH_PER_GPU)}, params['image_classifier_model']).to(device)
+    x, y = torch.randn(BATCH_PER_GPU, *IMAGE_SHAPE, device=device), torch.randint(0, NUM_CLASSES, (BATCH_PER_GPU,), device=device)
+    resident.capture_programs = True
+    try:
+        model.train()
+        loss = modules.CrossEntropyLoss()(model(x), y)
+        loss.backward()
+        torch.cuda.synchronize(device)
+    finally:
+        resident.capture_programs = False
+    if 'forward' not in resident.last_programs:
+        return None
+    st = nat.current_stream(device)
+    rows = []
+    for kind, fn, name in (('forward', nat.lib.dcv_resident_forward, 'resident_fwd_kernel'), ('backward', nat.lib.dcv_resident_backward, 'resident_bwd_kernel')):
+        if kind not in resident.last_programs:
+            continue
+        prog, ws, _keep = resident.last_programs[kind]
+        us = _time_launches(lambda: nat.check(fn(prog, ws.data_ptr(), ws.numel(), st), name), launches, warm=20)
+        rows.append((us, kind, name, resident.algorithmic_bytes(kind, prog)))
+    resident.check_status()
+    resident.last_programs.clear()
+    rows.sort(reverse=True)
+    us, kind, name, algo_bytes = rows[0]
+    achieved = algo_bytes / (us * 1e-6) / 1e9
+    traffic = traffic_src = None
+    for pmc in sorted((ROOT / 'profiles').glob('r*_pmc_resident_traffic.json'), reverse=True):      # the latest round's PMC passes (tools/pmc_traffic.py)
+        rec = json.loads(pmc.read_text())
+        traffic, traffic_src = rec.get(name, {}).get('traffic_bytes_per_launch'), f'{pmc.name} @ {rec.get("commit", "?")}'
+        break
+    return {'bound': 'hbm', 'kernel': f'{name} (dcv_resident_{kind}: the stock model\'s {"training forward" if kind == "forward" else "backward chain"} as one persistent launch, '
+                                      f'{BATCH_PER_GPU} samples, 2 per block)',
+            'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+            'traffic_unit': 'bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE)', 'traffic_source': traffic_src, 'avg_launch_us': round(us, 2),
+            'algorithmic_bytes_per_launch': algo_bytes,
+            'other_kernels': [{'kernel': nm, 'avg_launch_us': round(u, 2), 'algorithmic_bytes_per_launch': ab, 'achieved': round(ab / (u * 1e-6) / 1e9, 1),
+                               'frac': round(ab / (u * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)} for u, _k, nm, ab in rows[1:]]}
+
+
+def conv_tile_roofline(device, launches: int = 200):
+    """ Dominant kernel of the per-layer path (resident path off): `conv_tile_kernel<4,5,2>` (N=512, 32x32, 4 -> 4 channels, 5x5, pad 2, fused bias + ReLU +
+    statistics epilogue) through `dcv_conv2d_fwd_prepared`, HIP events on the launch stream; algorithmic bytes per SURVEY.md §8d. """
     import ctypes
     from deepcv_amd import _native as nat
     n, c, h, w, k = BATCH_PER_GPU, 4, 32, 32, 5
@@ -95,34 +145,14 @@ def dominant_kernel_roofline(device, launches: int = 200):
     filt = torch.empty(max(16, nat.lib.dcv_conv2d_filter_bytes(d, 0)), dtype=torch.uint8, device=device)
     nat.check(nat.lib.dcv_conv2d_prepare_filters(1, (ctypes.POINTER(nat.Conv2dDesc) * 1)(ctypes.pointer(d)), (ctypes.c_int * 1)(0),
                                                  (ctypes.c_void_p * 1)(wt.data_ptr()), (ctypes.c_void_p * 1)(filt.data_ptr()), st), 'dcv_conv2d_prepare_filters')
-
-    # as in the training step, the epilogue also emits the BatchNorm statistics partials of its output tile
     stats = torch.empty((2, c, max(1, nat.lib.dcv_conv2d_fwd_stats_rows(d))), dtype=torch.float64, device=device)
-
-    def launch():
-        nat.check(nat.lib.dcv_conv2d_fwd_prepared(d, x.data_ptr(), wt.data_ptr(), filt.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), st), 'dcv_conv2d_fwd_prepared')
-    for _ in range(20):
-        launch()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(device)
-    e0.record()
-    for _ in range(launches):
-        launch()
-    e1.record()
-    torch.cuda.synchronize(device)
-    us = e0.elapsed_time(e1) * 1e3 / launches
+    us = _time_launches(lambda: nat.check(nat.lib.dcv_conv2d_fwd_prepared(d, x.data_ptr(), wt.data_ptr(), filt.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), st),
+                                          'dcv_conv2d_fwd_prepared'), launches, warm=20)
     algo_bytes = 4 * (n * h * w * c + c * c * k * k + n * h * w * c)
     achieved = algo_bytes / (us * 1e-6) / 1e9
-    traffic = None
-    traffic_src = None
-    for pmc in sorted((ROOT / 'profiles').glob('r*_pmc_conv_tile_traffic.json'), reverse=True):      # the latest round's PMC passes (tools/pmc_traffic.py)
-        rec = json.loads(pmc.read_text())
-        traffic, traffic_src = rec.get('traffic_bytes_per_launch'), f'{pmc.name} @ {rec.get("commit", "?")}'
-        break
-    return {'bound': 'hbm', 'kernel': 'conv_tile_kernel<4,5,2> (dcv_conv2d_fwd_prepared, 512x32x32x4 -> 4, 5x5)', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
-            'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE)',
-            'traffic_source': traffic_src,
-            'avg_launch_us': round(us, 2), 'algorithmic_bytes_per_launch': algo_bytes}
+    return {'bound': 'hbm', 'kernel': 'conv_tile_kernel<4,5,2> (dcv_conv2d_fwd_prepared, 512x32x32x4 -> 4, 5x5; per-layer path, DCV_RESIDENT=0)', 'achieved': round(achieved, 1),
+            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None, 'avg_launch_us': round(us, 2),
+            'algorithmic_bytes_per_launch': algo_bytes}
 
 
 def _milestones(total_iters: int, lr: float):
@@ -392,7 +422,7 @@ def main():
     parity_failed = False
     if rank == 0:
         first_losses = first_losses[:min(PARITY_STEPS, POOL)]
-        roof = dominant_kernel_roofline(device)
+        roof = dominant_kernel_roofline(device, params) or conv_tile_roofline(device)
         result = {
             'metric': 'images/sec training, CIFAR-10 DeepcvModule bs=512/GPU', 'value': round(world * BATCH_PER_GPU * args.steps / dt, 1), 'unit': 'images/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True,

@@ -771,6 +771,18 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
             e_gr = o.gn_rstd[(size_t)ac_n * o.groups + g]; e_gm = o.gn_mean[(size_t)ac_n * o.groups + g];
         }
         if (t < C) { s_mr[0][t] = s_par[oi][2][t]; s_mr[1][t] = s_par[oi][3][t]; }
+        // the next op's y is requested now (two float4 per thread: a sample holds at most RS_Y floats) and lands in LDS after the dz step, when this
+        // layer's y is dead: the HBM round trip hides behind the moments and the gather
+        float4 ypre[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+        int ypre_v4 = 0;
+        if (oi + 1 < p.count) {
+            const dcv_resident_bwd_op& nx = p.op[oi + 1];
+            const int n = (int)blockIdx.x * RS_SPB + s_of_t;
+            ypre_v4 = (nx.h * nx.w * nx.cout) >> 2;
+            const float4* g = reinterpret_cast<const float4*>(nx.y) + (size_t)(n < N ? n : 0) * ypre_v4;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { const int i = tt + k * 512; ypre[k] = g[i < ypre_v4 ? i : 0]; }
+        }
         rs_barrier();
         // ---- four moments per (sample, channel): sum d, sum d u, sum u, sum u^2 with u = (y - mean) rstd, d = dout through the pooling map.  Wave w8 of the
         // sample owns channel vector w8 % CV and every (8 / CV)-th stripe of 64 pixels.
@@ -927,7 +939,12 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         rs_barrier();
         stamp();
         // ---- the next op's y -> LDS (this layer's y is dead), then the data gradient: dz tile -> DO = the next op's dout
-        if (oi + 1 < p.count) load_flat(p.op[oi + 1].y, yreg, p.op[oi + 1].h * p.op[oi + 1].w * p.op[oi + 1].cout);
+        if (oi + 1 < p.count) {
+            const int n = (int)blockIdx.x * RS_SPB + s_of_t;
+            float4* d = reinterpret_cast<float4*>(yreg + s_of_t * RS_Y);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { const int i = tt + k * 512; if (i < ypre_v4) d[i] = n < N ? ypre[k] : make_float4(0.f, 0.f, 0.f, 0.f); }
+        }
         if (o.need_dx) {
             dcv_resident_op cv{};
             cv.cin = o.cout; cv.cout = o.cin; cv.k = o.k; cv.h = H; cv.w = W; cv.act = DCV_ACT_NONE; cv.filt = o.filt; cv.bias = nullptr;

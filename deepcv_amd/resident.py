@@ -29,6 +29,8 @@ _active: Optional['Recorder'] = None
 _verdicts: Dict[int, Tuple['weakref.ref', Dict[tuple, str]]] = {}   # id(module) -> (weak reference, {(input shape, training): reason it is not eligible})
 _ws: Dict[torch.device, torch.Tensor] = {}                          # persistent control words + granules per device (zeroed once)
 _launches = 0
+capture_programs = False      # measurement hook (bench.py, tools): keep the last launched programs, their workspaces and tensors in `last_programs`
+last_programs: Dict[str, tuple] = {}
 _bwd_launches = 0
 _ws_bwd: Dict[torch.device, torch.Tensor] = {}
 
@@ -279,6 +281,8 @@ class Recorder:
         ws = _workspace(self.device)
         nat.check(lib.dcv_resident_forward(prog, ws.data_ptr(), ws.numel(), nat.current_stream(self.device)), 'dcv_resident_forward')
         _launches += 1
+        if capture_programs:
+            last_programs['forward'] = (prog, ws, list(self.keep))
         self.keep.clear()
 
 
@@ -372,7 +376,38 @@ class BackwardPlan:
         if cur != self.stream:               # the engine ran the backward functions on the stream of their forward ops (see slabs.flush)
             torch.cuda.current_stream(self.device).wait_stream(torch.cuda.ExternalStream(self.stream, device=self.device))
         nat.check(lib.dcv_resident_backward(prog, ws.data_ptr(), ws.numel(), cur), 'dcv_resident_backward')
+        if capture_programs:
+            last_programs['backward'] = (prog, ws, list(keep))
         if cur != self.stream:
             for t in keep:
                 t.record_stream(torch.cuda.current_stream(self.device))
         _bwd_launches += 1
+
+
+def algorithmic_bytes(kind: str, prog) -> int:
+    """ HBM bytes a persistent launch has to move by construction: forward = the input batch + every tensor it must leave for the backward
+    pass (y and the output of every layer, the wide tensor of the link, the logits) + filters and per-channel parameters; backward = y and dz of every
+    layer + the first output gradient, the link's addend, the GroupNorm partials and the filters.  fp32. """
+    n, total = prog.n, 0
+    for i in range(prog.count):
+        o = prog.op[i]
+        if kind == 'forward':
+            if o.kind == nat.RES_LAYER:
+                pk = o.pool if o.pool > 0 else 1
+                total += n * o.h * o.w * o.cout + n * (o.h // pk) * (o.w // pk) * o.cout + o.k * o.k * o.cin * o.cout + 8 * o.cout
+                if i == 0:
+                    total += n * o.h * o.w * o.cin
+            elif o.kind == nat.RES_LINK:
+                total += n * o.h * o.w * (o.cin + o.ref_c) + n * o.ref_h * o.ref_w * o.ref_c
+            else:
+                total += o.cout * o.h * o.w * o.cin + n * o.cout
+        else:
+            pk = o.pool if o.pool > 0 else 1
+            total += 2 * n * o.h * o.w * o.cout + o.k * o.k * o.cin * o.cout + 8 * o.cout + ((n + 1) // 2) * 2 * o.cout
+            if i == 0:
+                total += n * (o.h // pk) * (o.w // pk) * o.cout
+            if o.addend:
+                total += n * o.h * o.w * o.cin
+            if o.dx:
+                total += n * o.h * o.w * o.cin
+    return 4 * total

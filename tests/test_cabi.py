@@ -64,3 +64,69 @@ def test_invalid_arguments_are_rejected_on_the_host():
     good = _native.Conv2dDesc(2, 8, 8, 4, 4, 3, 3, 1, 1, 1, 1, 1, 1, 1, 8, 8, 0, 0, 0.)
     assert lib.dcv_conv2d_wgrad_workspace_bytes(good) > 0 and lib.dcv_conv2d_fwd_workspace_bytes(good) > 0
     assert lib.dcv_conv2d_wgrad(good, 1, 1, 1, None, None, 0, None) == -3   # workspace too small
+
+
+def _stock_resident_program(n=512):
+    """ The stock classifier (conf/base/parameters.yml `image_classifier_model`) as a `dcv_resident_program`, with placeholder addresses: only the host-side
+    validation is exercised here (no launch without a GPU). """
+    from deepcv_amd import _native as nat
+    prog = nat.ResidentProgram()
+    prog.n = n
+    layers = [(3, 4, 5, 32, 0), (4, 4, 5, 32, 0), (4, 4, 5, 32, 2), (4, 16, 3, 16, 0), (16, 16, 3, 16, 2)]
+    outs = []
+    for i, (cin, cout, k, hw, pool) in enumerate(layers):
+        op = prog.op[i]
+        op.kind, op.cin, op.cout, op.k, op.h, op.w, op.act, op.bn, op.groups, op.pool = nat.RES_LAYER, cin, cout, k, hw, hw, nat.ACT_RELU, 1, 4, pool
+        for f in ('filt', 'y', 'bn_mean', 'bn_rstd', 'gn_mean', 'gn_rstd'):
+            setattr(op, f, 64)
+        op.out = 4096 * (i + 1)
+        outs.append(op.out)
+    prog.op[0].x, prog.op[0].x_nchw = 64, 1
+    link = prog.op[5]
+    link.kind, link.cin, link.h, link.w, link.ref_c, link.ref_h, link.ref_w, link.ref, link.out = nat.RES_LINK, 16, 8, 8, 4, 16, 16, outs[2], 64
+    fc = prog.op[6]
+    fc.kind, fc.cin, fc.h, fc.w, fc.cout, fc.act, fc.filt, fc.out = nat.RES_FC, 20, 8, 8, 10, nat.ACT_SIGMOID, 64, 64
+    prog.count = 7
+    return prog
+
+
+def test_resident_program_validation_on_the_host():
+    """ `dcv_resident_supported` / `dcv_resident_bwd_supported` accept the stock classifier's programs and refuse what the persistent kernels do not cover
+    (also pins the ctypes mirrors of `dcv_resident_op` / `dcv_resident_bwd_op`: a misplaced field fails the shape checks). """
+    from deepcv_amd import _native as nat
+    lib = _native_lib()
+    assert lib.dcv_resident_supported(_stock_resident_program()) == 1
+    assert lib.dcv_resident_supported(_stock_resident_program(7)) == 1
+    assert lib.dcv_resident_supported(_stock_resident_program(513)) == 0            # more than two samples per block of a 256-block grid
+    p = _stock_resident_program(); p.op[1].cout = 5
+    assert lib.dcv_resident_supported(p) == 0
+    p = _stock_resident_program(); p.op[2].pool = 3
+    assert lib.dcv_resident_supported(p) == 0
+    p = _stock_resident_program(); p.op[5].ref = 12345                              # the link must reference an earlier layer's output
+    assert lib.dcv_resident_supported(p) == 0
+    p = _stock_resident_program(); p.op[0].h = p.op[0].w = 64                       # a sample which does not fit the LDS tiles
+    assert lib.dcv_resident_supported(p) == 0
+    assert lib.dcv_resident_forward(_stock_resident_program(), None, 0, None) == -1 and lib.dcv_resident_ws_bytes() > 0
+
+    def bwd(n=512):
+        prog = nat.ResidentBwdProgram()
+        prog.n, prog.count = n, 5
+        for i, (cin, cout, k, hw, pool) in enumerate([(16, 16, 3, 16, 2), (4, 16, 3, 16, 0), (4, 4, 5, 32, 2), (4, 4, 5, 32, 0), (3, 4, 5, 32, 0)]):
+            op = prog.op[i]
+            op.cin, op.cout, op.k, op.h, op.w, op.act, op.groups, op.pool, op.need_dx = cin, cout, k, hw, hw, nat.ACT_RELU, 4, pool, 0 if i == 4 else 1
+            for f in ('y', 'dz', 'bn_mean', 'bn_rstd', 'gn_mean', 'gn_rstd', 'filt'):
+                setattr(op, f, 64)
+        prog.op[0].dout = 64
+        return prog
+    assert lib.dcv_resident_bwd_supported(bwd()) == 1 and lib.dcv_resident_bwd_supported(bwd(3)) == 1
+    p = bwd(); p.op[2].need_dx = 0                                                  # only the model's first layer may skip its data gradient
+    assert lib.dcv_resident_bwd_supported(p) == 0
+    p = bwd(); p.op[1].h = 8                                                        # its data gradient is not the next op's dout
+    assert lib.dcv_resident_bwd_supported(p) == 0
+    p = bwd(); p.op[0].dout = None
+    assert lib.dcv_resident_bwd_supported(p) == 0
+
+
+def _native_lib():
+    from deepcv_amd import _native
+    return _native.load()
