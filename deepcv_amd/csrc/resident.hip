@@ -31,6 +31,7 @@ constexpr int RS_Y = 4096;          // floats per sample of a layer's activated 
 constexpr int RS_MAXC = 16;         // channels of a resident layer
 constexpr int RS_MAXQ = 2 * RS_MAXC;
 constexpr int RS_MAXG = 256;        // blocks
+constexpr int RS_GRAN_OP = RS_MAXQ * RS_MAXG + 2 * RS_MAXQ;   // granules of one synchronisation: hop-1 partials [RS_MAXQ][RS_MAXG], hop-2 totals [RS_MAXQ][2]
 constexpr int RS_SPINS = 1 << 16;   // gather polls before giving up (each at least a memory round trip: tens of milliseconds)
 constexpr size_t RS_CTL_BYTES = 1024;  // [0] launch generation, [1] error word, [4..): time stamps of block 0 (64-bit, 100 MHz): tools/resident_stamps.py
 constexpr int RS_MAX_STAMPS = 120;
@@ -41,11 +42,8 @@ typedef __attribute__((address_space(1))) unsigned rs_gu32;
 typedef __attribute__((address_space(4))) const float rs_cfloat;       // constant address space: wave-uniform loads go through the scalar cache
 #define RS_CONST(p) ((rs_cfloat*)(unsigned long long)(p))
 
-// LDS map (dynamic): xin [RS_SPB][RS_XIN] float4 | yt [RS_SPB][RS_Y] float.  While xin is dead (between a layer's convolution and its apply step) it holds
-// the gathered sums `arr` [RS_MAXQ][RS_MAXG] float (32 KB) and their fp64 partials (4 KB).
+// LDS map (dynamic): xin [RS_SPB][RS_XIN] float4 | yt [RS_SPB][RS_Y] float.
 constexpr size_t RS_XIN_BYTES = (size_t)RS_SPB * RS_XIN * 16, RS_Y_BYTES = (size_t)RS_SPB * RS_Y * 4, RS_SMEM = RS_XIN_BYTES + RS_Y_BYTES;
-constexpr size_t RS_ARR_OFF = 0, RS_PART_OFF = (size_t)RS_MAXQ * RS_MAXG * 4;
-static_assert(RS_PART_OFF + (size_t)RS_MAXQ * 16 * 8 <= RS_XIN_BYTES, "gather scratch must fit the input tile");
 
 // Workgroup barrier which only drains the LDS / scalar counter.  `__syncthreads()` also waits for every outstanding global STORE of the wave (vmcnt(0)):
 // with 32 KB of y / layer-output stores in flight per phase that wait was 2 us per barrier, although nothing in this launch reads those bytes back
@@ -110,6 +108,78 @@ __device__ __forceinline__ void rs_reduce8(const float (&v)[8], float (&r)[2]) {
         b[i] += __shfl_xor(b[i], 32, 64);
         r[i] = b[i];
     }
+}
+
+// Sum of a double over the 64 lanes: four DPP steps inside the rows of 16 lanes (each moves the two 32-bit halves), the four row sums through
+// v_readlane, combined in a fixed order.  Wave-uniform result.
+template <int CTRL> __device__ __forceinline__ double rs_dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false), hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double rs_wave_sum_f64(double v) {
+    v += rs_dpp_f64<0xB1>(v); v += rs_dpp_f64<0x4E>(v); v += rs_dpp_f64<0x141>(v); v += rs_dpp_f64<0x140>(v);
+    double r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16 * k), __builtin_amdgcn_readlane(__double2loint(v), 16 * k));
+    return (r[0] + r[1]) + (r[2] + r[3]);
+}
+
+// Sums over all blocks of the grid, in two hops of 8-byte {epoch, value} granules (agent-scope stores and loads: the tag travels with the data, no
+// fence; every spin is bounded).  Hop 1: thread q < Q of every block publishes its block's partial of quantity q (fp32) to A[q][block].  Quantity q
+// belongs to block q % G: that block's first four waves poll A[q][0 .. G), sum the G values in fp64 in a fixed order and publish the total as two
+// granules (its low and high word) to B[q].  Hop 2: threads 0 .. 2Q of every block poll B and leave the totals in `totals` (LDS, doubles) — the same
+// bits in every block.  A one-hop version (every block gathering all Q * G partials: 64 KB per block at 16 channels, two million polling loads per
+// sweep on the chip) took 2.5 - 6.5 us per layer.  Returns false when a poll gave up (a block of the grid is not resident).  Block-uniform control flow.
+__device__ __forceinline__ bool rs_allreduce(rs_u64* ga, rs_u64* gb, unsigned epoch, int Q, int G, float mine, double* totals, double* red, unsigned* w32, int* s_fail) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t < Q) __hip_atomic_store((rs_gu64*)(ga + (size_t)t * RS_MAXG + blockIdx.x), ((rs_u64)epoch << 32) | (rs_u64)__float_as_uint(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int q = (int)blockIdx.x; q < Q; q += G) {                                   // the quantities this block owns
+        double d = 0.0;
+        if (t < 256) {
+            bool got = true;
+            float v = 0.f;
+            for (int spins = 0; spins < RS_SPINS; ++spins) {
+                got = true;
+                if (t < G) {
+                    const rs_u64 g = __hip_atomic_load((rs_gu64*)(ga + (size_t)q * RS_MAXG + t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v = __uint_as_float((unsigned)g);
+                    got = (unsigned)(g >> 32) == epoch;
+                }
+                if (__all(got)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (!__all(got) && lane == 0) *s_fail = 1;
+            d = rs_wave_sum_f64(t < G ? (double)v : 0.0);
+            if (lane == 0) red[wave] = d;
+        }
+        rs_barrier();
+        if (t == 0) {
+            const double tot = (red[0] + red[1]) + (red[2] + red[3]);
+            __hip_atomic_store((rs_gu64*)(gb + 2 * q), ((rs_u64)epoch << 32) | (rs_u64)(unsigned)__double2loint(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store((rs_gu64*)(gb + 2 * q + 1), ((rs_u64)epoch << 32) | (rs_u64)(unsigned)__double2hiint(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        rs_barrier();
+    }
+    if (wave == 0) {
+        bool got = true;
+        unsigned v = 0;
+        for (int spins = 0; spins < RS_SPINS; ++spins) {
+            got = true;
+            if (t < 2 * Q) {
+                const rs_u64 g = __hip_atomic_load((rs_gu64*)(gb + t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v = (unsigned)g;
+                got = (unsigned)(g >> 32) == epoch;
+            }
+            if (__all(got)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!__all(got) && lane == 0) *s_fail = 1;
+        if (t < 2 * Q) w32[t] = v;
+    }
+    rs_barrier();
+    if (t < Q) totals[t] = __hiloint2double((int)w32[2 * t + 1], (int)w32[2 * t]);
+    rs_barrier();
+    return *s_fail == 0;
 }
 
 // ------------------------------------------------------------------------------------------------ convolutions (LDS -> LDS)
@@ -325,13 +395,13 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
     float4* xin = reinterpret_cast<float4*>(smem);
     float* xinf = reinterpret_cast<float*>(smem);
     float* yt = reinterpret_cast<float*>(smem + RS_XIN_BYTES);
-    float* arr = reinterpret_cast<float*>(smem + RS_ARR_OFF);
-    double* part = reinterpret_cast<double*>(smem + RS_PART_OFF);                    // [RS_MAXQ][16]
     __shared__ float s_wsum[16 * 2 * RS_MAXC];                                       // per-wave sums of y, y^2 left by the convolution epilogues
     __shared__ float s_samp[RS_SPB][2][RS_MAXC];                                     // per-sample sums of y, y^2
     __shared__ __attribute__((aligned(16))) float s_S[RS_SPB][RS_MAXC];              // layer output = S y + T
     __shared__ __attribute__((aligned(16))) float s_T[RS_SPB][RS_MAXC];
     __shared__ float s_par[DCV_RESIDENT_MAX_OPS][6][RS_MAXC];                        // per-channel parameters of every layer: bn gamma, beta, running mean, var, gn gamma, beta
+    __shared__ double s_tot[RS_MAXQ], s_red[4];                                      // batch totals of the current synchronisation
+    __shared__ unsigned s_w32[2 * RS_MAXQ];
     __shared__ unsigned s_gen;
     __shared__ int s_fail;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -453,49 +523,20 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
             }
             // ---- per-sample sums (8 waves each); BatchNorm: publish this block's 2C totals, gather every block's
             const unsigned epoch = gen * DCV_RESIDENT_MAX_OPS + (unsigned)oi + 1u;
-            rs_u64* go = gran + (size_t)oi * RS_MAXQ * RS_MAXG;
+            rs_u64* go = gran + (size_t)oi * RS_GRAN_OP;
+            float mine = 0.f;
             if (norm && t < 2 * C) {
                 const int q = t >= C ? 1 : 0, c = t - q * C;
                 float v0 = 0.f, v1 = 0.f;
 #pragma unroll
                 for (int w8 = 0; w8 < 8; ++w8) { v0 += s_wsum[(w8 * 2 + q) * RS_MAXC + c]; v1 += s_wsum[((8 + w8) * 2 + q) * RS_MAXC + c]; }
                 s_samp[0][q][c] = v0; s_samp[1][q][c] = v1;
-                if (o.bn) {
-                    const float tot = (valid0 ? v0 : 0.f) + (valid1 ? v1 : 0.f);
-                    __hip_atomic_store((rs_gu64*)(go + (size_t)t * RS_MAXG + blockIdx.x), ((rs_u64)epoch << 32) | (rs_u64)__float_as_uint(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                mine = (valid0 ? v0 : 0.f) + (valid1 ? v1 : 0.f);
             }
             stamp();
             if (o.bn) {
-                const int total = 2 * C * G;
-                const float inv_g = 1.f / (float)G;
-                bool ok = true;
-                constexpr int GP = RS_MAXQ * RS_MAXG / RS_T;                         // granules per thread: all of a sweep's loads are in flight together
-                for (int i0 = 0; i0 < total; i0 += RS_T * GP) {
-                    int idx[GP]; float gv[GP];
-#pragma unroll
-                    for (int k = 0; k < GP; ++k) { const int i = i0 + k * RS_T + t; const int q = rs_fdiv(i, inv_g); idx[k] = i < total ? q * RS_MAXG + (i - q * G) : -1; }
-                    bool got = false;
-                    for (int spins = 0; spins < RS_SPINS; ++spins) {
-                        got = true;
-#pragma unroll
-                        for (int k = 0; k < GP; ++k) {
-                            if (idx[k] >= 0) {
-                                const rs_u64 g = __hip_atomic_load((rs_gu64*)(go + idx[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                gv[k] = __uint_as_float((unsigned)g);
-                                got &= (unsigned)(g >> 32) == epoch;
-                            }
-                        }
-                        if (__all(got)) break;
-                        __builtin_amdgcn_s_sleep(2);
-                    }
-                    ok &= (bool)__all(got);
-#pragma unroll
-                    for (int k = 0; k < GP; ++k) if (idx[k] >= 0) arr[idx[k]] = gv[k];
-                }
-                if (!ok && lane == 0) s_fail = 1;
-                rs_barrier();
-                if (s_fail) {                                                        // a block of this grid is not resident: report, poison the logits, leave
+                if (!rs_allreduce(go, go + RS_MAXQ * RS_MAXG, epoch, 2 * C, G, mine, s_tot, s_red, s_w32, &s_fail)) {
+                    // a block of this grid is not resident: report, poison the logits, leave
                     if (t == 0) { __hip_atomic_store((rs_gu32*)(ctl + 1), (unsigned)oi + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                     for (int k = 0; k < p.count; ++k)
                         if (p.op[k].kind == DCV_RES_FC)
@@ -505,16 +546,8 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                             }
                     return;
                 }
-                stamp();
-                // fixed-order fp64 sums, level 1: 16 partial sums of <= 16 blocks per quantity
-                if (t < 2 * C * 16) {
-                    const int q = t >> 4, j = t & 15;
-                    double v = 0.0;
-                    for (int i = j * 16; i < j * 16 + 16 && i < G; ++i) v += (double)arr[q * RS_MAXG + i];
-                    part[q * 16 + j] = v;
-                }
-            } else stamp();
-            rs_barrier();
+            } else rs_barrier();
+            stamp();
             // ---- coefficients, all in wave 0: thread (sample, channel) sums the 16 partials of its channel, derives the BatchNorm affine v = a y + b, the
             // GroupNorm statistics of v from the sample's sums (norm_chain.hip, nc_apply_kernel's prologue; group totals by DPP exchanges between the
             // cpg adjacent lanes) and the layer's affine S y + T
@@ -522,9 +555,7 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                 const int ss = t >= C ? 1 : 0, c = t - ss * C;
                 float a = 1.f, b = 0.f;
                 if (o.bn) {
-                    double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) { s1 += part[c * 16 + j]; s2 += part[(C + c) * 16 + j]; }
+                    const double s1 = s_tot[c], s2 = s_tot[C + c];
                     const double mean = s1 * o.inv_count;
                     double varc = s2 * o.inv_count - mean * mean; if (varc < 0.0) varc = 0.0;
                     const float rstd = (float)rs_rsqrt(varc + (double)o.bn_eps);
@@ -582,7 +613,7 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                     else reinterpret_cast<float4*>(xinf + (size_t)ss * RS_XIN * 4)[px * CV + cv] = r4;           // flat NHWC for a LINK / FC
                 }
                 if (nxt_layer && npad > 0) {
-                    // the gather scratch lived in the input tile: re-zero the halo of the next layer's tile (disjoint from the interior written above)
+                    // zero the halo of the next layer's tile (disjoint from the interior written above): its geometry may differ from this layer's
                     const int rows_part = 2 * npad * XWn, halo = rows_part + Ho * 2 * npad, planes = RS_SPB * CV;
                     const float inv_halo = 1.f / (float)halo, inv_xw = 1.f / (float)XWn, inv_2p = 1.f / (float)(2 * npad);
                     for (int i = t; i < planes * halo; i += RS_T) {
@@ -706,9 +737,9 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
     float4* dzt = reinterpret_cast<float4*>(smem);
     float* yreg = reinterpret_cast<float*>(smem + RS_XIN_BYTES);
     float* dor = reinterpret_cast<float*>(smem + RS_XIN_BYTES + RS_Y_BYTES);
-    float* arr = reinterpret_cast<float*>(smem + RS_ARR_OFF);
-    double* part = reinterpret_cast<double*>(smem + RS_PART_OFF);
     __shared__ float s_wsum[16 * 4 * RS_MAXC];                                       // per-wave moments [wave][4][C]
+    __shared__ double s_tot[RS_MAXQ], s_red[4];                                      // batch totals of the current synchronisation
+    __shared__ unsigned s_w32[2 * RS_MAXQ];
     __shared__ __attribute__((aligned(16))) float s_coef[RS_SPB][3][RS_MAXC];        // dz = act'(y) (P d + Q u + R)
     __shared__ __attribute__((aligned(16))) float s_mr[2][RS_MAXC];                  // BatchNorm mean, rstd of the current layer
     __shared__ float s_par[DCV_RESIDENT_BWD_MAX_OPS][5][RS_MAXC];                    // bn gamma, beta, mean, rstd, gn gamma of every layer
@@ -817,8 +848,8 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         stamp();
         // ---- the sample's algebra (norm_chain.hip, nc_sample_sums_kernel's epilogue) by thread (sample, channel) of wave 0; publish the block's T1, T2
         const unsigned epoch = gen * DCV_RESIDENT_MAX_OPS + (unsigned)oi + 1u;
-        rs_u64* go = gran + (size_t)oi * RS_MAXQ * RS_MAXG;
-        float P = 0.f, Q0 = 0.f, R0 = 0.f, a_bn = 0.f;
+        rs_u64* go = gran + (size_t)oi * RS_GRAN_OP;
+        float P = 0.f, Q0 = 0.f, R0 = 0.f, a_bn = 0.f, mine = 0.f;
         if (t < RS_SPB * C) {
             const int ss = ac_ss, c = ac_c, ccv = c >> 2, j = c & 3, stripes = 8 / CV;
             float mq[4] = {0.f, 0.f, 0.f, 0.f};
@@ -848,62 +879,21 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
             const float fS1 = v ? (float)S1 : 0.f, fS2 = v ? (float)S2 : 0.f, fT1 = v ? (float)T1 : 0.f, fT2 = v ? (float)T2 : 0.f;
             // the block's totals: the two samples of a channel sit C lanes apart (C: a power of two <= 16)
             const float bS1 = fS1 + __shfl_xor(fS1, C, 64), bS2 = fS2 + __shfl_xor(fS2, C, 64), bT1 = fT1 + __shfl_xor(fT1, C, 64), bT2 = fT2 + __shfl_xor(fT2, C, 64);
-            if (ss == 0) {
-                __hip_atomic_store((rs_gu64*)(go + (size_t)c * RS_MAXG + blockIdx.x), ((rs_u64)epoch << 32) | (rs_u64)__float_as_uint(bT1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store((rs_gu64*)(go + (size_t)(C + c) * RS_MAXG + blockIdx.x), ((rs_u64)epoch << 32) | (rs_u64)__float_as_uint(bT2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (o.groups > 0 && o.gn_part) { o.gn_part[((size_t)blockIdx.x * 2) * C + c] = bS1; o.gn_part[((size_t)blockIdx.x * 2 + 1) * C + c] = bS2; }
-            }
+            mine = ss == 0 ? bT1 : bT2;                                             // quantity t of the synchronisation: T1 of channel t, T2 of channel t - C
+            if (ss == 0 && o.groups > 0 && o.gn_part) { o.gn_part[((size_t)blockIdx.x * 2) * C + c] = bS1; o.gn_part[((size_t)blockIdx.x * 2 + 1) * C + c] = bS2; }
         }
         stamp();
-        // ---- gather every block's T1, T2 (the dz tile of the previous op is dead: the scratch lives there)
-        {
-            const int total = 2 * C * G;
-            const float inv_g = 1.f / (float)G;
-            bool ok = true;
-            constexpr int GP = RS_MAXQ * RS_MAXG / RS_T;
-            for (int i0 = 0; i0 < total; i0 += RS_T * GP) {
-                int idx[GP]; float gv[GP];
-#pragma unroll
-                for (int k = 0; k < GP; ++k) { const int i = i0 + k * RS_T + t; const int q = rs_fdiv(i, inv_g); idx[k] = i < total ? q * RS_MAXG + (i - q * G) : -1; }
-                bool got = false;
-                for (int spins = 0; spins < RS_SPINS; ++spins) {
-                    got = true;
-#pragma unroll
-                    for (int k = 0; k < GP; ++k) {
-                        if (idx[k] >= 0) {
-                            const rs_u64 g = __hip_atomic_load((rs_gu64*)(go + idx[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            gv[k] = __uint_as_float((unsigned)g);
-                            got &= (unsigned)(g >> 32) == epoch;
-                        }
-                    }
-                    if (__all(got)) break;
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                ok &= (bool)__all(got);
-#pragma unroll
-                for (int k = 0; k < GP; ++k) if (idx[k] >= 0) arr[idx[k]] = gv[k];
-            }
-            if (!ok && lane == 0) s_fail = 1;
-            rs_barrier();
-            if (s_fail) {                                                            // a block of this grid is not resident: report, poison the first layer's dz, leave
-                if (t == 0) { __hip_atomic_store((rs_gu32*)(ctl + 1), (unsigned)oi + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                if (blockIdx.x == 0 && t < p.op[p.count - 1].cout) p.op[p.count - 1].dz[t] = __builtin_nanf("");
-                return;
-            }
-            stamp();
-            if (t < 2 * C * 16) {
-                const int q = t >> 4, j = t & 15;
-                double v = 0.0;
-                for (int i = j * 16; i < j * 16 + 16 && i < G; ++i) v += (double)arr[q * RS_MAXG + i];
-                part[q * 16 + j] = v;
-            }
+        // ---- the batch totals of T1, T2
+        if (!rs_allreduce(go, go + RS_MAXQ * RS_MAXG, epoch, 2 * C, G, mine, s_tot, s_red, s_w32, &s_fail)) {
+            // a block of this grid is not resident: report, poison the first layer's dz, leave
+            if (t == 0) { __hip_atomic_store((rs_gu32*)(ctl + 1), (unsigned)oi + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            if (blockIdx.x == 0 && t < p.op[p.count - 1].cout) p.op[p.count - 1].dz[t] = __builtin_nanf("");
+            return;
         }
-        rs_barrier();
+        stamp();
         if (t < RS_SPB * C) {
             const int ss = ac_ss, c = ac_c;
-            double t1 = 0.0, t2 = 0.0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) { t1 += part[c * 16 + j]; t2 += part[(C + c) * 16 + j]; }
+            const double t1 = s_tot[c], t2 = s_tot[C + c];
             const float ad = a_bn * (float)(t2 * o.inv_count), ab = a_bn * (float)(t1 * o.inv_count);     // the batch terms (nc_param_finalize_kernel)
             s_coef[ss][0][c] = P; s_coef[ss][1][c] = Q0 - ad; s_coef[ss][2][c] = R0 - ab;
             if (blockIdx.x == 0 && ss == 0) { if (o.d_bn_beta) o.d_bn_beta[c] = (float)t1; if (o.d_bn_gamma) o.d_bn_gamma[c] = (float)t2; }
@@ -1043,7 +1033,7 @@ extern "C" {
 
 int dcv_resident_supported(const dcv_resident_program* p) { return rs_program_ok(p) ? 1 : 0; }
 
-size_t dcv_resident_ws_bytes(void) { return RS_CTL_BYTES + (size_t)DCV_RESIDENT_MAX_OPS * RS_MAXQ * RS_MAXG * sizeof(rs_u64); }
+size_t dcv_resident_ws_bytes(void) { return RS_CTL_BYTES + (size_t)DCV_RESIDENT_MAX_OPS * RS_GRAN_OP * sizeof(rs_u64); }
 
 int dcv_resident_forward(const dcv_resident_program* p, void* ws, size_t ws_bytes, void* stream) {
     DCV_CHECK_ARG(p && ws);
