@@ -1005,6 +1005,11 @@ def resize_concat(tensors: Sequence[torch.Tensor], align_corners: bool = False) 
     tensors = list(tensors)
     if len(tensors) == 1:
         return tensors[0]
+    rec = resident.recorder()
+    if rec is not None and not all(type(t.grad_fn).__name__.startswith('_RefTapFn') for t in tensors[1:] if t.requires_grad):
+        # a referenced tensor which does not come through `ref_tap`: the engine itself will add the link's gradient to the main consumer's — before the
+        # persistent backward launch has computed either.  The backward pass of this forward stays on the per-layer kernels.
+        rec.plan.fusable = False
     return _ResizeConcatFn.apply(bool(align_corners), *tensors)
 
 

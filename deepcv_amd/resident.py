@@ -296,6 +296,7 @@ class BackwardPlan:
 
     def __init__(self, n: int, device: torch.device):
         self.n, self.device = n, device
+        self.fusable = True                   # cleared by the forward when the engine would have to sum gradients of an intermediate tensor itself
         self.layers: List[dict] = []          # forward order: desc, cfg, grad_params, needs_dx
         self.state: Optional[str] = None      # None: undecided, 'fused', 'plain'
         self.next_index = -1
@@ -327,7 +328,7 @@ class BackwardPlan:
         """ Called by the first backward node of the stack to run (it must be the last layer's).  True: the pass is recorded. """
         from . import slabs
         self.state = 'plain'
-        if not (_enabled and _bwd_enabled) or index != len(self.layers) - 1 or len(self.layers) > nat.RESIDENT_BWD_MAX_OPS:
+        if not (_enabled and _bwd_enabled and self.fusable) or index != len(self.layers) - 1 or len(self.layers) > nat.RESIDENT_BWD_MAX_OPS:
             return False
         if slabs._current_pass() in (None, -1) or any(layer['odd'] for layer in self.layers):      # not an engine-driven pass: no final callback to launch from
             return False

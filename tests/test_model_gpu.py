@@ -328,7 +328,15 @@ def test_link_gradient_rides_in_the_data_gradient_kernel(device, params):
     (x, y), = _batches(1, 16)
     x, y = x.to(device), y.to(device)
 
-    def run(fused: bool):
+    def run(fused: bool, persistent_backward: bool = False):
+        from deepcv_amd import resident
+        prev = resident.set_backward_enabled(persistent_backward)
+        try:
+            return run_(fused)
+        finally:
+            resident.set_backward_enabled(prev)
+
+    def run_(fused: bool):
         torch.manual_seed(SEED)
         model = create_model({'trainset': SyntheticImageDataset(8)}, params['image_classifier_model']).to(device).train()
         taken = []
@@ -359,6 +367,12 @@ def test_link_gradient_rides_in_the_data_gradient_kernel(device, params):
     gscale = max(g.abs().max().item() for g in g0.values())
     for n in g0:
         assert (g1[n] - g0[n]).abs().max().item() <= 1e-6 * gscale + 1e-5 * g0[n].abs().max().item(), n
+    # the same link with the backward chain as ONE persistent launch (`dcv_resident_backward`): the link's gradient is the `addend` of the fourth layer's
+    # data gradient inside that launch, no per-layer data-gradient launch at all
+    l2, g2, t2 = run(True, persistent_backward=True)
+    assert t2 == [] and l2 == l0
+    for n in g0:
+        assert (g2[n] - g0[n]).abs().max().item() <= 1e-6 * gscale + 1e-5 * g0[n].abs().max().item(), n
 
 
 def test_replayed_step_keeps_late_prepared_filters_fresh(device, params):
