@@ -1,5 +1,6 @@
 #!/bin/bash
-# round-2 measurement records: bench line, kernel statistics of the bench command, PMC traffic of the persistent launches
+# measurement records of a round (run through gpurun: `gpurun -- "bash tools/measure_round.sh <commit>"`): bench line, kernel statistics of the bench command,
+# PMC traffic of the persistent launches; results under gpurun_out/r2q/, copied to profiles/ by hand
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2q
 mkdir -p $O
