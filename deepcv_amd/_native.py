@@ -98,7 +98,8 @@ class ResidentBwdOp(ctypes.Structure):
                 ('need_dx', _c_int), ('inv_count', ctypes.c_double), ('inv_group', ctypes.c_double),
                 ('y', _c_void_p), ('dout', _c_void_p), ('addend', _c_void_p), ('filt', _c_void_p), ('bn_gamma', _c_void_p), ('bn_beta', _c_void_p), ('bn_mean', _c_void_p),
                 ('bn_rstd', _c_void_p), ('gn_gamma', _c_void_p), ('gn_mean', _c_void_p), ('gn_rstd', _c_void_p), ('dz', _c_void_p), ('dx', _c_void_p),
-                ('d_bn_gamma', _c_void_p), ('d_bn_beta', _c_void_p), ('gn_part', _c_void_p)]
+                ('d_bn_gamma', _c_void_p), ('d_bn_beta', _c_void_p), ('gn_part', _c_void_p),
+                ('x', _c_void_p), ('dw_part', _c_void_p), ('db_part', _c_void_p), ('x_nchw', _c_int), ('reserved', _c_int)]
 
 
 class ResidentBwdProgram(ctypes.Structure):

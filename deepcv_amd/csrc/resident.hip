@@ -130,9 +130,16 @@ __device__ __forceinline__ double rs_wave_sum_f64(double v) {
 // granules (its low and high word) to B[q].  Hop 2: threads 0 .. 2Q of every block poll B and leave the totals in `totals` (LDS, doubles) — the same
 // bits in every block.  A one-hop version (every block gathering all Q * G partials: 64 KB per block at 16 channels, two million polling loads per
 // sweep on the chip) took 2.5 - 6.5 us per layer.  Returns false when a poll gave up (a block of the grid is not resident).  Block-uniform control flow.
-__device__ __forceinline__ bool rs_allreduce(rs_u64* ga, rs_u64* gb, unsigned epoch, int Q, int G, float mine, double* totals, double* red, unsigned* w32, int* s_fail) {
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+// hop 1 alone: a caller with independent work (the weight gradients of the backward launch) does it between this and rs_allreduce(..., published = true)
+__device__ __forceinline__ void rs_allreduce_publish(rs_u64* ga, unsigned epoch, int Q, float mine) {
+    const int t = threadIdx.x;
     if (t < Q) __hip_atomic_store((rs_gu64*)(ga + (size_t)t * RS_MAXG + blockIdx.x), ((rs_u64)epoch << 32) | (rs_u64)__float_as_uint(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ bool rs_allreduce(rs_u64* ga, rs_u64* gb, unsigned epoch, int Q, int G, float mine, double* totals, double* red, unsigned* w32, int* s_fail,
+                                             bool published = false) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (!published) rs_allreduce_publish(ga, epoch, Q, mine);
     for (int q = (int)blockIdx.x; q < Q; q += G) {                                   // the quantities this block owns
         double d = 0.0;
         if (t < 256) {
@@ -720,14 +727,147 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
 
 // ------------------------------------------------------------------------------------------------ the backward chain
 // LDS map (dynamic): DZ [RS_SPB][RS_XIN] float4 (the zero-padded dz tile the data gradient reads; between a data gradient and the next dz it holds the
-// gather scratch) | Y [RS_SPB][RS_Y] (the layer's saved y) | DO [RS_SPB][RS_Y] (dout of the layer; then its data gradient = the next layer's dout).
-constexpr size_t RB_SMEM = RS_XIN_BYTES + 2 * RS_Y_BYTES;
+// gather scratch) | Y [RS_SPB][RS_Y] (the layer's saved y) | DO [RS_SPB][RS_Y] (dout of the layer; then its data gradient = the next layer's dout)
+// | XT [RS_SPB][RS_XIN] float4 (the layer's zero-padded input x, for its weight gradient).
+constexpr size_t RB_SMEM = 2 * RS_XIN_BYTES + 2 * RS_Y_BYTES;          // + XT: the zero-padded input tile of the layer whose weight gradient is pending
 
 // data-gradient variant of a layer (forward cin -> cout, k): the forward kernels on the swapped channel counts
 __host__ __device__ __forceinline__ int rb_dgrad_variant(int cin, int cout, int k, int w) {
     if (cout <= 4 && cin == 4 && (k == 3 || k == 5)) return 1;                       // 4 <- 4: VALU row pairs
     if (cout == 16 && (cin == 16 || cin == 4) && k == 3 && w == 16) return 3;        // 16 / 4 <- 16: matrix cores
     return 0;
+}
+
+// ---- weight gradients inside the backward launch.  A wave takes whole UNITS = (filter tap or filter row, sample slot) and walks all pixels of the
+// sample for it: nothing is reduced across waves, a unit's result goes straight to its chunk (2 * block + sample slot) of the layer's partial slab, and the
+// step's one dcv_slab_reduce sums the chunks.  xt: the layer's zero-padded input tile (same layout as the forward's), dzt: its zero-padded dz tile.
+__host__ __device__ __forceinline__ int rb_wgrad_variant(int cin, int cout, int k, int w) {
+    if (cin <= 4 && cout == 4 && (k == 3 || k == 5)) return 1;                       // VALU, lanes = pixels
+    if (cin <= 4 && cout == 16 && k == 3 && w == 16) return 2;                       // MFMA, M = (filter column, input channel)
+    if (cin == 16 && cout == 16 && k == 3 && w == 16) return 3;                      // MFMA, M = input channel
+    return 0;
+}
+
+// cin <= 4 -> 4: unit = (tap | bias, sample).  Lanes = pixels (two image rows H / 2 apart per iteration share the index decode): per pixel one ds_read_b128 of
+// x at the tap's offset, one of dz, 16 FMAs into the lane's [ci][co] accumulators; two halving reductions finish the unit.
+template <int K>
+__device__ __forceinline__ void rb_wgrad_c4(const dcv_resident_bwd_op& o, const float4* xt, const float4* dzt) {
+    const int H = o.h, W = o.w, pad = K / 2, XW = W + 2 * pad, T = K * K, half = (H >> 1) * W, wsize = o.cout * o.cin * T;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv_w = 1.f / (float)W;
+    for (int u = wave; u < RS_SPB * (T + 1); u += 16) {
+        const int s = u >= T + 1 ? 1 : 0, tap = u - s * (T + 1);                     // tap == T: the bias gradient (x = 1 on input channel 0)
+        const int ky = tap < T ? tap / K : pad, kx = tap < T ? tap - ky * K : pad;
+        float acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const float4* xs = xt + s * RS_XIN + ky * XW + kx;
+        const float4* ds = dzt + s * RS_XIN + pad * XW + pad;
+        for (int px = lane; px < half; px += 64) {
+            const int r = rs_fdiv(px, inv_w), c = px - r * W, a0 = r * XW + c, a1 = a0 + (H >> 1) * XW;
+            float4 x0 = xs[a0], x1 = xs[a1];
+            const float4 d0 = ds[a0], d1 = ds[a1];
+            if (tap == T) { x0 = make_float4(1.f, 0.f, 0.f, 0.f); x1 = x0; }
+#define RB_ACC(x4, d4) \
+            acc[0] += x4.x * d4.x; acc[1] += x4.x * d4.y; acc[2] += x4.x * d4.z; acc[3] += x4.x * d4.w; \
+            acc[4] += x4.y * d4.x; acc[5] += x4.y * d4.y; acc[6] += x4.y * d4.z; acc[7] += x4.y * d4.w; \
+            acc[8] += x4.z * d4.x; acc[9] += x4.z * d4.y; acc[10] += x4.z * d4.z; acc[11] += x4.z * d4.w; \
+            acc[12] += x4.w * d4.x; acc[13] += x4.w * d4.y; acc[14] += x4.w * d4.z; acc[15] += x4.w * d4.w;
+            RB_ACC(x0, d0)
+            RB_ACC(x1, d1)
+#undef RB_ACC
+        }
+        float lo[8], hi[8], rl[2], rh[2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { lo[i] = acc[i]; hi[i] = acc[8 + i]; }
+        rs_reduce8(lo, rl); rs_reduce8(hi, rh);
+        if (lane < 4) {
+            const int vi = (lane & 1) * 4 + ((lane >> 1) & 1) * 2, chunk = (int)blockIdx.x * RS_SPB + s;
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int v = g * 8 + vi + j, ci = v >> 2, co = v & 3;
+                    const float val = g == 0 ? rl[j] : rh[j];
+                    if (tap < T) { if (ci < o.cin) o.dw_part[(size_t)chunk * wsize + ((co * o.cin + ci) * K + ky) * K + kx] = val; }
+                    else if (ci == 0 && o.db_part) o.db_part[(size_t)chunk * o.cout + co] = val;
+                }
+        }
+    }
+}
+
+// sum of dz per channel (bias gradient) of a 16-channel layer: unit = sample, lanes = pixels x channel vectors
+__device__ __forceinline__ void rb_bias16(const dcv_resident_bwd_op& o, const float4* dzt, int unit_wave0) {
+    const int H = o.h, XW = 18, XH = H + 2, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (!o.db_part) return;
+    for (int s = 0; s < RS_SPB; ++s) {
+        if (wave != ((unit_wave0 + s) & 15)) continue;
+        float acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int px = lane; px < H * 16; px += 64) {
+            const int r = px >> 4, c = px & 15;
+#pragma unroll
+            for (int cv = 0; cv < 4; ++cv) { const float4 d = dzt[s * RS_XIN + (cv * XH + r + 1) * XW + c + 1]; acc[cv * 4] += d.x; acc[cv * 4 + 1] += d.y; acc[cv * 4 + 2] += d.z; acc[cv * 4 + 3] += d.w; }
+        }
+        float lo[8], hi[8], rl[2], rh[2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { lo[i] = acc[i]; hi[i] = acc[8 + i]; }
+        rs_reduce8(lo, rl); rs_reduce8(hi, rh);
+        if (lane < 4) {
+            const int vi = (lane & 1) * 4 + ((lane >> 1) & 1) * 2, chunk = (int)blockIdx.x * RS_SPB + s;
+            o.db_part[(size_t)chunk * 16 + vi] = rl[0]; o.db_part[(size_t)chunk * 16 + vi + 1] = rl[1];
+            o.db_part[(size_t)chunk * 16 + 8 + vi] = rh[0]; o.db_part[(size_t)chunk * 16 + 8 + vi + 1] = rh[1];
+        }
+    }
+}
+
+// 16 -> 16, 3x3, rows of 16 pixels: unit = (tap, sample): D[ci][co] += A[ci][4 pixels] B[4 pixels][co] over the 64 pixel quads of the sample, one
+// v_mfma_f32_16x16x4_f32 each (A: x at the tap's offset, B: dz; one ds_read_b32 per operand and lane).
+__device__ __forceinline__ void rb_wgrad_c16(const dcv_resident_bwd_op& o, const float4* xt, const float4* dzt) {
+    const int H = o.h, XW = 18, XH = H + 2, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4;
+    const float* xf = reinterpret_cast<const float*>(xt); const float* df = reinterpret_cast<const float*>(dzt);
+    for (int u = wave; u < RS_SPB * 9; u += 16) {
+        const int s = u >= 9 ? 1 : 0, tap = u - s * 9, ky = tap / 3, kx = tap - ky * 3;
+        const float* xa = xf + ((size_t)s * RS_XIN + ((m >> 2) * XH + ky) * XW + kx + kq) * 4 + (m & 3);      // lane: input channel m, pixel kq of the quad
+        const float* db = df + ((size_t)s * RS_XIN + ((m >> 2) * XH + 1) * XW + 1 + kq) * 4 + (m & 3);        // lane: output channel m, pixel kq of the quad
+        rs_f4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < H; ++r)
+#pragma unroll
+            for (int c0 = 0; c0 < 16; c0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[(r * XW + c0) * 4], db[(r * XW + c0) * 4], acc, 0, 0, 0);
+        const int chunk = (int)blockIdx.x * RS_SPB + s;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o.dw_part[(size_t)chunk * 2304 + (m * 16 + 4 * kq + i) * 9 + tap] = acc[i];          // D: input channel 4 kq + i, output channel m
+    }
+    rb_bias16(o, dzt, 2);
+}
+
+// cin <= 4 -> 16, 3x3, rows of 16 pixels: unit = (filter row, sample): M = (filter column 0..3, input channel), the fourth column is not a tap (dropped)
+__device__ __forceinline__ void rb_wgrad_c4x16(const dcv_resident_bwd_op& o, const float4* xt, const float4* dzt) {
+    const int H = o.h, XW = 18, XH = H + 2, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4;
+    const float* xf = reinterpret_cast<const float*>(xt); const float* df = reinterpret_cast<const float*>(dzt);
+    for (int u = wave; u < RS_SPB * 3; u += 16) {
+        const int s = u >= 3 ? 1 : 0, ky = u - s * 3;
+        const float* xa = xf + ((size_t)s * RS_XIN + ky * XW + (m >> 2) + kq) * 4 + (m & 3);                    // lane: (column m / 4, input channel m % 4), pixel kq
+        const float* db = df + ((size_t)s * RS_XIN + ((m >> 2) * XH + 1) * XW + 1 + kq) * 4 + (m & 3);
+        rs_f4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < H; ++r)
+#pragma unroll
+            for (int c0 = 0; c0 < 16; c0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[(r * XW + c0) * 4], db[(r * XW + c0) * 4], acc, 0, 0, 0);
+        const int chunk = (int)blockIdx.x * RS_SPB + s, wsize = 16 * o.cin * 9;
+        if (kq < 3) {                                                                // D rows 4 kq + i = (column kq, input channel i), output channel m
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (i < o.cin) o.dw_part[(size_t)chunk * wsize + ((m * o.cin + i) * 3 + ky) * 3 + kq] = acc[i];
+        }
+    }
+    rb_bias16(o, dzt, 6);
+}
+
+__device__ __forceinline__ void rb_wgrad(const dcv_resident_bwd_op& o, const float4* xt, const float4* dzt) {
+    const int var = rb_wgrad_variant(o.cin, o.cout, o.k, o.w);
+    if (var == 1) { if (o.k == 5) rb_wgrad_c4<5>(o, xt, dzt); else rb_wgrad_c4<3>(o, xt, dzt); }
+    else if (var == 2) rb_wgrad_c4x16(o, xt, dzt);
+    else rb_wgrad_c16(o, xt, dzt);
 }
 
 __device__ __forceinline__ float rb_act_grad(float y, int act, float slope) { return dcv_act_grad_from_out(y, act, slope); }
@@ -737,11 +877,13 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
     float4* dzt = reinterpret_cast<float4*>(smem);
     float* yreg = reinterpret_cast<float*>(smem + RS_XIN_BYTES);
     float* dor = reinterpret_cast<float*>(smem + RS_XIN_BYTES + RS_Y_BYTES);
+    float4* xtt = reinterpret_cast<float4*>(smem + RS_XIN_BYTES + 2 * RS_Y_BYTES);
     __shared__ float s_wsum[16 * 4 * RS_MAXC];                                       // per-wave moments [wave][4][C]
     __shared__ double s_tot[RS_MAXQ], s_red[4];                                      // batch totals of the current synchronisation
     __shared__ unsigned s_w32[2 * RS_MAXQ];
     __shared__ __attribute__((aligned(16))) float s_coef[RS_SPB][3][RS_MAXC];        // dz = act'(y) (P d + Q u + R)
     __shared__ __attribute__((aligned(16))) float s_mr[2][RS_MAXC];                  // BatchNorm mean, rstd of the current layer
+    __shared__ float s_abn[RS_SPB][RS_MAXC];                                         // BatchNorm gamma * rstd
     __shared__ float s_par[DCV_RESIDENT_BWD_MAX_OPS][5][RS_MAXC];                    // bn gamma, beta, mean, rstd, gn gamma of every layer
     __shared__ float s_dummy[16 * 2 * RS_MAXC];
     __shared__ unsigned s_gen;
@@ -802,18 +944,6 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
             e_gr = o.gn_rstd[(size_t)ac_n * o.groups + g]; e_gm = o.gn_mean[(size_t)ac_n * o.groups + g];
         }
         if (t < C) { s_mr[0][t] = s_par[oi][2][t]; s_mr[1][t] = s_par[oi][3][t]; }
-        // the next op's y is requested now (two float4 per thread: a sample holds at most RS_Y floats) and lands in LDS after the dz step, when this
-        // layer's y is dead: the HBM round trip hides behind the moments and the gather
-        float4 ypre[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-        int ypre_v4 = 0;
-        if (oi + 1 < p.count) {
-            const dcv_resident_bwd_op& nx = p.op[oi + 1];
-            const int n = (int)blockIdx.x * RS_SPB + s_of_t;
-            ypre_v4 = (nx.h * nx.w * nx.cout) >> 2;
-            const float4* g = reinterpret_cast<const float4*>(nx.y) + (size_t)(n < N ? n : 0) * ypre_v4;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) { const int i = tt + k * 512; ypre[k] = g[i < ypre_v4 ? i : 0]; }
-        }
         rs_barrier();
         // ---- four moments per (sample, channel): sum d, sum d u, sum u, sum u^2 with u = (y - mean) rstd, d = dout through the pooling map.  Wave w8 of the
         // sample owns channel vector w8 % CV and every (8 / CV)-th stripe of 64 pixels.
@@ -849,7 +979,7 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         // ---- the sample's algebra (norm_chain.hip, nc_sample_sums_kernel's epilogue) by thread (sample, channel) of wave 0; publish the block's T1, T2
         const unsigned epoch = gen * DCV_RESIDENT_MAX_OPS + (unsigned)oi + 1u;
         rs_u64* go = gran + (size_t)oi * RS_GRAN_OP;
-        float P = 0.f, Q0 = 0.f, R0 = 0.f, a_bn = 0.f, mine = 0.f;
+        float mine = 0.f;
         if (t < RS_SPB * C) {
             const int ss = ac_ss, c = ac_c, ccv = c >> 2, j = c & 3, stripes = 8 / CV;
             float mq[4] = {0.f, 0.f, 0.f, 0.f};
@@ -860,9 +990,9 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
             }
             const double m0 = (double)mq[0], m1 = (double)mq[1], u1 = (double)mq[2], u2 = (double)mq[3];
             const float gbn = s_par[oi][0][c], bbn = s_par[oi][1][c], brs = s_par[oi][3][c], ggn = s_par[oi][4][c];
-            a_bn = gbn * brs;
+            const float a_bn = gbn * brs;
             double S1 = m0, S2 = m1, T1 = m0, T2 = m1;
-            P = a_bn;
+            float P = a_bn, Q0 = 0.f, R0 = 0.f;
             if (o.groups > 0) {
                 const double gr = (double)e_gr, al = (double)gbn * gr, be = ((double)bbn - (double)e_gm) * gr;
                 const double s2 = al * m1 + be * m0;
@@ -880,11 +1010,39 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
             // the block's totals: the two samples of a channel sit C lanes apart (C: a power of two <= 16)
             const float bS1 = fS1 + __shfl_xor(fS1, C, 64), bS2 = fS2 + __shfl_xor(fS2, C, 64), bT1 = fT1 + __shfl_xor(fT1, C, 64), bT2 = fT2 + __shfl_xor(fT2, C, 64);
             mine = ss == 0 ? bT1 : bT2;                                             // quantity t of the synchronisation: T1 of channel t, T2 of channel t - C
+            s_coef[ss][0][c] = P; s_coef[ss][1][c] = Q0; s_coef[ss][2][c] = R0; s_abn[ss][c] = a_bn;      // parked in LDS across the weight gradient below
             if (ss == 0 && o.groups > 0 && o.gn_part) { o.gn_part[((size_t)blockIdx.x * 2) * C + c] = bS1; o.gn_part[((size_t)blockIdx.x * 2 + 1) * C + c] = bS2; }
         }
         stamp();
-        // ---- the batch totals of T1, T2
-        if (!rs_allreduce(go, go + RS_MAXQ * RS_MAXG, epoch, 2 * C, G, mine, s_tot, s_red, s_w32, &s_fail)) {
+        // ---- the batch totals of T1, T2: publish the block's partials, compute the PREVIOUS op's weight gradient while they travel (its dz and x tiles are
+        // still intact), then reduce / collect
+        rs_allreduce_publish(go, epoch, 2 * C, mine);
+        if (oi > 0 && p.op[oi - 1].dw_part != nullptr) rb_wgrad(p.op[oi - 1], xtt, dzt);
+        rs_barrier();
+        stamp();
+        // the next op's y is requested now (two float4 per thread: a sample holds at most RS_Y floats) and lands in LDS after the dz step, when this
+        // layer's y is dead: the HBM round trip hides behind the all-reduce
+        float4 ypre[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+        int ypre_v4 = 0;
+        if (oi + 1 < p.count) {
+            const dcv_resident_bwd_op& nx = p.op[oi + 1];
+            const int n = (int)blockIdx.x * RS_SPB + s_of_t;
+            ypre_v4 = (nx.h * nx.w * nx.cout) >> 2;
+            const float4* g = reinterpret_cast<const float4*>(nx.y) + (size_t)(n < N ? n : 0) * ypre_v4;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { const int i = tt + k * 512; ypre[k] = g[i < ypre_v4 ? i : 0]; }
+        }
+        // this op's input x (for its weight gradient, which runs during the NEXT op's all-reduce): same scheme, NHWC with whole channel vectors
+        const bool wg = o.dw_part != nullptr;
+        const bool xvec = wg && !o.x_nchw && (o.cin & 3) == 0;
+        float4 xpre[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+        if (xvec) {
+            const int n = (int)blockIdx.x * RS_SPB + s_of_t, v4 = (H * W * o.cin) >> 2;
+            const float4* g = reinterpret_cast<const float4*>(o.x) + (size_t)(n < N ? n : 0) * v4;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { const int i = tt + k * 512; xpre[k] = g[i < v4 ? i : 0]; }
+        }
+        if (!rs_allreduce(go, go + RS_MAXQ * RS_MAXG, epoch, 2 * C, G, mine, s_tot, s_red, s_w32, &s_fail, true)) {
             // a block of this grid is not resident: report, poison the first layer's dz, leave
             if (t == 0) { __hip_atomic_store((rs_gu32*)(ctl + 1), (unsigned)oi + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
             if (blockIdx.x == 0 && t < p.op[p.count - 1].cout) p.op[p.count - 1].dz[t] = __builtin_nanf("");
@@ -894,15 +1052,48 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         if (t < RS_SPB * C) {
             const int ss = ac_ss, c = ac_c;
             const double t1 = s_tot[c], t2 = s_tot[C + c];
-            const float ad = a_bn * (float)(t2 * o.inv_count), ab = a_bn * (float)(t1 * o.inv_count);     // the batch terms (nc_param_finalize_kernel)
-            s_coef[ss][0][c] = P; s_coef[ss][1][c] = Q0 - ad; s_coef[ss][2][c] = R0 - ab;
+            const float abn = s_abn[ss][c];
+            const float ad = abn * (float)(t2 * o.inv_count), ab = abn * (float)(t1 * o.inv_count);       // the batch terms (nc_param_finalize_kernel)
+            s_coef[ss][1][c] -= ad; s_coef[ss][2][c] -= ab;
             if (blockIdx.x == 0 && ss == 0) { if (o.d_bn_beta) o.d_bn_beta[c] = (float)t1; if (o.d_bn_gamma) o.d_bn_gamma[c] = (float)t2; }
         }
         // the dz tile: zero it (halo; the scratch dirtied it), interior below
         rs_barrier();
-        for (int i = t; i < RS_SPB * RS_XIN; i += RS_T) dzt[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = t; i < RS_SPB * RS_XIN; i += RS_T) { dzt[i] = make_float4(0.f, 0.f, 0.f, 0.f); if (wg) xtt[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
         rs_barrier();
         stamp();
+        if (wg) {   // this op's x -> its zero-padded tile
+            const int pad = o.k / 2, XW = W + 2 * pad, XH = H + 2 * pad, n = (int)blockIdx.x * RS_SPB + s_of_t;
+            if (xvec) {
+                const int CVI = o.cin >> 2, v4 = H * W * CVI;
+                const float inv_cvi = 1.f / (float)CVI;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int e = tt + k * 512;
+                    if (e < v4 && n < N) { const int px = rs_fdiv(e, inv_cvi), cv = e - px * CVI, r = rs_fdiv(px, inv_w), c = px - r * W; xtt[s_of_t * RS_XIN + (cv * XH + r + pad) * XW + c + pad] = xpre[k]; }
+                }
+            } else if (n < N) {                                                      // NCHW / partial channel vector (the model input): scalar elements
+                const int total = H * W * o.cin;
+                const float inv_hw = 1.f / (float)HW, inv_ci = 1.f / (float)o.cin;
+                const float* src = o.x + (size_t)n * total;
+                float* dst = reinterpret_cast<float*>(xtt + s_of_t * RS_XIN);
+                for (int e0 = 0; e0 < total; e0 += 8 * 512) {
+                    float v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { const int e = e0 + tt + k * 512; v[k] = src[e < total ? e : 0]; }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int e = e0 + tt + k * 512;
+                        if (e < total) {
+                            int c, px;
+                            if (o.x_nchw) { c = rs_fdiv(e, inv_hw); px = e - c * HW; } else { px = rs_fdiv(e, inv_ci); c = e - px * o.cin; }
+                            const int r = rs_fdiv(px, inv_w), col = px - r * W;
+                            dst[(((c >> 2) * XH + r + pad) * XW + col + pad) * 4 + (c & 3)] = v[k];
+                        }
+                    }
+                }
+            }
+        }
         // ---- dz = act'(y) (P d + Q u + R): -> HBM (what the weight-gradient kernels read) and the padded tile of the data gradient
         {
             const int pad = o.k / 2, XW = W + 2 * pad, XH = H + 2 * pad;
@@ -955,6 +1146,8 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         rs_barrier();
         stamp();
     }
+    if (p.op[p.count - 1].dw_part != nullptr) rb_wgrad(p.op[p.count - 1], xtt, dzt);     // the first layer's: nothing left to hide it behind
+    stamp();
     if (blockIdx.x == 0 && t == 0) { stamps[0] = (unsigned long long)n_stamp; __hip_atomic_store((rs_gu32*)ctl, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
 
@@ -969,6 +1162,11 @@ inline bool rb_program_ok(const dcv_resident_bwd_program* p) {
         if (o.groups < 0 || (o.groups > 0 && (o.cout % o.groups != 0 || ((o.cout / o.groups) & (o.cout / o.groups - 1)) || !o.gn_mean || !o.gn_rstd))) return false;
         if (o.pool < 0 || o.pool == 1 || (o.pool > 0 && (o.h % o.pool != 0 || o.w % o.pool != 0 || o.groups == 0))) return false;
         if (!o.y || !o.dz || !o.bn_mean || !o.bn_rstd || o.act < DCV_ACT_NONE || o.act > DCV_ACT_TANH) return false;
+        if (o.dw_part) {
+            const int wv = rb_wgrad_variant(o.cin, o.cout, o.k, o.w);
+            if (wv == 0 || !o.x || (wv == 1 && (o.h & 1)) || ((o.cin + 3) >> 2) * (o.h + 2 * pad) * (o.w + 2 * pad) > RS_XIN) return false;
+            if (o.x_nchw == 0 && (o.cin & 3) != 0 && o.cin > 4) return false;
+        }
         if (o.need_dx) {
             const int var = rb_dgrad_variant(o.cin, o.cout, o.k, o.w);
             if (var == 0 || !o.filt) return false;

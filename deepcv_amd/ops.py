@@ -790,11 +790,26 @@ class _ConvNormLayerFn(torch.autograd.Function):
                     if index == 0:
                         op.dx = dx.data_ptr()                                      # nothing consumes it in LDS: the model input's gradient goes to HBM
                     keep += [dx, filt, addend]
-                plan.add(op, dx, keep, st)
                 dw = None
                 if need[1]:
                     dw = _grad_buffer(ctx.weight_ref, like=weight)
-                    _conv_wgrad_launch(d, x, dz, ctx.weight_ref, ctx.bias_ref, dw, db, st)      # deferred: runs at the flush, after the launch above
+                    if resident.wgrad_in_launch(d) and slabs.may_defer(ctx.weight_ref, ctx.bias_ref):
+                        # the weight gradient is computed inside the persistent launch (while the blocks wait for the next layer's all-reduce): per-(block,
+                        # sample slot) partial slabs in OIHW order, summed by the step's one dcv_slab_reduce
+                        chunks, wsize = 2 * ((d.n + 1) // 2), weight.numel()
+                        part = torch.empty(chunks * (wsize + (c if db is not None else 0)), dtype=torch.float32, device=dev)
+                        op.x, op.x_nchw, op.dw_part = x.data_ptr(), (1 if d.x_layout == nat.LAYOUT_NCHW else 0), part.data_ptr()
+                        segs, k = (nat.SlabSegment * 2)(), 1
+                        segs[0].src, segs[0].dst, segs[0].count, segs[0].stride, segs[0].chunks = part.data_ptr(), dw.data_ptr(), wsize, wsize, chunks
+                        if db is not None:
+                            op.db_part = part.data_ptr() + 4 * chunks * wsize
+                            segs[1].src, segs[1].dst, segs[1].count, segs[1].stride, segs[1].chunks = op.db_part, db.data_ptr(), c, c, chunks
+                            k = 2
+                        slabs.defer(dev, st, segs, k, part)
+                        keep.append(x)
+                    else:
+                        _conv_wgrad_launch(d, x, dz, ctx.weight_ref, ctx.bias_ref, dw, db, st)  # deferred: runs at the flush, after the launch above
+                plan.add(op, dx, keep, st)
                 return dx, dw, db, d_bn_w, d_bn_b, None, None, None, d_gn_w, d_gn_b, None
         if ctx.streaming:
             nc = _norm_chain_desc(d, ctx.cfg, bn_w, bn_b, None, None, None, bn_mean, bn_rstd, gn_w, None, gn_mean, gn_rstd)

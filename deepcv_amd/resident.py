@@ -97,6 +97,17 @@ def reads_oihw(d: nat.Conv2dDesc) -> bool:
     return d.cout == 16 and d.w == 16 and ((d.cin == 16 and d.r == 3) or (d.cin <= 4 and d.r in (1, 3)))
 
 
+_wgrad_in_launch = os.environ.get('DCV_RESIDENT_WGRAD', '1') not in ('0', 'false', 'False', '')
+
+
+def wgrad_in_launch(d: nat.Conv2dDesc) -> bool:
+    """ Does the persistent backward launch compute this layer's weight gradient itself (`rb_wgrad_variant`, resident.hip)?  `DCV_RESIDENT_WGRAD=0`: never
+    (the multi-layer weight-gradient launch then reads the launch's dz tensors, as for the layers not covered). """
+    if not _wgrad_in_launch or d.r != d.s:
+        return False
+    return (d.cin <= 4 and d.cout == 4 and d.r in (3, 5) and d.h % 2 == 0) or (d.cout == 16 and d.w == 16 and d.r == 3 and (d.cin <= 4 or d.cin == 16))
+
+
 def _verdict_slot(module) -> Dict[tuple, str]:
     slot = _verdicts.get(id(module))
     if slot is None or slot[0]() is not module:
