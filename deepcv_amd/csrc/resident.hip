@@ -136,11 +136,12 @@ __device__ __forceinline__ void rs_allreduce_publish(rs_u64* ga, unsigned epoch,
     if (t < Q) __hip_atomic_store((rs_gu64*)(ga + (size_t)t * RS_MAXG + blockIdx.x), ((rs_u64)epoch << 32) | (rs_u64)__float_as_uint(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ bool rs_allreduce(rs_u64* ga, rs_u64* gb, unsigned epoch, int Q, int G, float mine, double* totals, double* red, unsigned* w32, int* s_fail,
-                                             bool published = false) {
+// the block's share of the reduction: for every quantity it owns, poll the G partials, sum, publish the total (hop 2).  A caller with independent work
+// does it between this and rs_allreduce_collect: the totals are then on their way while every block computes.
+__device__ __forceinline__ void rs_allreduce_reduce_owned(rs_u64* ga, rs_u64* gb, unsigned epoch, int Q, int G, double* red, int* s_fail) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (!published) rs_allreduce_publish(ga, epoch, Q, mine);
     for (int q = (int)blockIdx.x; q < Q; q += G) {                                   // the quantities this block owns
+
         double d = 0.0;
         if (t < 256) {
             bool got = true;
@@ -167,6 +168,10 @@ __device__ __forceinline__ bool rs_allreduce(rs_u64* ga, rs_u64* gb, unsigned ep
         }
         rs_barrier();
     }
+}
+
+__device__ __forceinline__ bool rs_allreduce_collect(rs_u64* gb, unsigned epoch, int Q, double* totals, unsigned* w32, int* s_fail) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (wave == 0) {
         bool got = true;
         unsigned v = 0;
@@ -187,6 +192,13 @@ __device__ __forceinline__ bool rs_allreduce(rs_u64* ga, rs_u64* gb, unsigned ep
     if (t < Q) totals[t] = __hiloint2double((int)w32[2 * t + 1], (int)w32[2 * t]);
     rs_barrier();
     return *s_fail == 0;
+}
+
+__device__ __forceinline__ bool rs_allreduce(rs_u64* ga, rs_u64* gb, unsigned epoch, int Q, int G, float mine, double* totals, double* red, unsigned* w32, int* s_fail,
+                                             bool published = false) {
+    if (!published) rs_allreduce_publish(ga, epoch, Q, mine);
+    rs_allreduce_reduce_owned(ga, gb, epoch, Q, G, red, s_fail);
+    return rs_allreduce_collect(gb, epoch, Q, totals, w32, s_fail);
 }
 
 // ------------------------------------------------------------------------------------------------ convolutions (LDS -> LDS)
@@ -832,7 +844,8 @@ __device__ __forceinline__ void rb_wgrad_c16(const dcv_resident_bwd_op& o, const
         const float* xa = xf + ((size_t)s * RS_XIN + ((m >> 2) * XH + ky) * XW + kx + kq) * 4 + (m & 3);      // lane: input channel m, pixel kq of the quad
         const float* db = df + ((size_t)s * RS_XIN + ((m >> 2) * XH + 1) * XW + 1 + kq) * 4 + (m & 3);        // lane: output channel m, pixel kq of the quad
         rs_f4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int r = 0; r < H; ++r)
+#pragma unroll 4
+        for (int r = 0; r < H; ++r)                                                  // 16 operand loads in flight per iteration of the unrolled loop
 #pragma unroll
             for (int c0 = 0; c0 < 16; c0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[(r * XW + c0) * 4], db[(r * XW + c0) * 4], acc, 0, 0, 0);
         const int chunk = (int)blockIdx.x * RS_SPB + s;
@@ -851,7 +864,8 @@ __device__ __forceinline__ void rb_wgrad_c4x16(const dcv_resident_bwd_op& o, con
         const float* xa = xf + ((size_t)s * RS_XIN + ky * XW + (m >> 2) + kq) * 4 + (m & 3);                    // lane: (column m / 4, input channel m % 4), pixel kq
         const float* db = df + ((size_t)s * RS_XIN + ((m >> 2) * XH + 1) * XW + 1 + kq) * 4 + (m & 3);
         rs_f4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int r = 0; r < H; ++r)
+#pragma unroll 4
+        for (int r = 0; r < H; ++r)                                                  // 16 operand loads in flight per iteration of the unrolled loop
 #pragma unroll
             for (int c0 = 0; c0 < 16; c0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[(r * XW + c0) * 4], db[(r * XW + c0) * 4], acc, 0, 0, 0);
         const int chunk = (int)blockIdx.x * RS_SPB + s, wsize = 16 * o.cin * 9;
@@ -1017,6 +1031,7 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         // ---- the batch totals of T1, T2: publish the block's partials, compute the PREVIOUS op's weight gradient while they travel (its dz and x tiles are
         // still intact), then reduce / collect
         rs_allreduce_publish(go, epoch, 2 * C, mine);
+        rs_allreduce_reduce_owned(go, go + RS_MAXQ * RS_MAXG, epoch, 2 * C, G, s_red, &s_fail);   // the few owner blocks: before their own weight gradient, so that nobody waits for it
         if (oi > 0 && p.op[oi - 1].dw_part != nullptr) rb_wgrad(p.op[oi - 1], xtt, dzt);
         rs_barrier();
         stamp();
@@ -1042,7 +1057,7 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
 #pragma unroll
             for (int k = 0; k < 2; ++k) { const int i = tt + k * 512; xpre[k] = g[i < v4 ? i : 0]; }
         }
-        if (!rs_allreduce(go, go + RS_MAXQ * RS_MAXG, epoch, 2 * C, G, mine, s_tot, s_red, s_w32, &s_fail, true)) {
+        if (!rs_allreduce_collect(go + RS_MAXQ * RS_MAXG, epoch, 2 * C, s_tot, s_w32, &s_fail)) {
             // a block of this grid is not resident: report, poison the first layer's dz, leave
             if (t == 0) { __hip_atomic_store((rs_gu32*)(ctl + 1), (unsigned)oi + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
             if (blockIdx.x == 0 && t < p.op[p.count - 1].cout) p.op[p.count - 1].dz[t] = __builtin_nanf("");
