@@ -834,6 +834,23 @@ __device__ __forceinline__ void rb_bias16(const dcv_resident_bwd_op& o, const fl
     }
 }
 
+// acc += A B over the pixel quads of rows [r0, r1) of a 16-pixel-wide map: the 16 operand words of two rows are requested before their 8 MFMAs (a loop of
+// load, load, MFMA is a chain of LDS latencies: 44 % of the matrix pipe)
+__device__ __forceinline__ void rb_mfma_rows(const float* xa, const float* db, int r0, int r1, int XW, rs_f4& acc) {
+    int r = r0;
+    for (; r + 1 < r1; r += 2) {
+        float a[8], b[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int off = ((r + (k >> 2)) * XW + (k & 3) * 4) * 4; a[k] = xa[off]; b[k] = db[off]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k], b[k], acc, 0, 0, 0);
+    }
+    if (r < r1) {
+#pragma unroll
+        for (int c0 = 0; c0 < 16; c0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[(r * XW + c0) * 4], db[(r * XW + c0) * 4], acc, 0, 0, 0);
+    }
+}
+
 // 16 -> 16, 3x3, rows of 16 pixels: unit = (tap, sample): D[ci][co] += A[ci][4 pixels] B[4 pixels][co] over the 64 pixel quads of the sample, one
 // v_mfma_f32_16x16x4_f32 each (A: x at the tap's offset, B: dz; one ds_read_b32 per operand and lane).
 __device__ __forceinline__ void rb_wgrad_c16(const dcv_resident_bwd_op& o, const float4* xt, const float4* dzt) {
@@ -844,10 +861,7 @@ __device__ __forceinline__ void rb_wgrad_c16(const dcv_resident_bwd_op& o, const
         const float* xa = xf + ((size_t)s * RS_XIN + ((m >> 2) * XH + ky) * XW + kx + kq) * 4 + (m & 3);      // lane: input channel m, pixel kq of the quad
         const float* db = df + ((size_t)s * RS_XIN + ((m >> 2) * XH + 1) * XW + 1 + kq) * 4 + (m & 3);        // lane: output channel m, pixel kq of the quad
         rs_f4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int r = 0; r < H; ++r)                                                  // 16 operand loads in flight per iteration of the unrolled loop
-#pragma unroll
-            for (int c0 = 0; c0 < 16; c0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[(r * XW + c0) * 4], db[(r * XW + c0) * 4], acc, 0, 0, 0);
+        rb_mfma_rows(xa, db, 0, H, XW, acc);
         const int chunk = (int)blockIdx.x * RS_SPB + s;
 #pragma unroll
         for (int i = 0; i < 4; ++i) o.dw_part[(size_t)chunk * 2304 + (m * 16 + 4 * kq + i) * 9 + tap] = acc[i];          // D: input channel 4 kq + i, output channel m
@@ -864,10 +878,7 @@ __device__ __forceinline__ void rb_wgrad_c4x16(const dcv_resident_bwd_op& o, con
         const float* xa = xf + ((size_t)s * RS_XIN + ky * XW + (m >> 2) + kq) * 4 + (m & 3);                    // lane: (column m / 4, input channel m % 4), pixel kq
         const float* db = df + ((size_t)s * RS_XIN + ((m >> 2) * XH + 1) * XW + 1 + kq) * 4 + (m & 3);
         rs_f4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int r = 0; r < H; ++r)                                                  // 16 operand loads in flight per iteration of the unrolled loop
-#pragma unroll
-            for (int c0 = 0; c0 < 16; c0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[(r * XW + c0) * 4], db[(r * XW + c0) * 4], acc, 0, 0, 0);
+        rb_mfma_rows(xa, db, 0, H, XW, acc);
         const int chunk = (int)blockIdx.x * RS_SPB + s, wsize = 16 * o.cin * 9;
         if (kq < 3) {                                                                // D rows 4 kq + i = (column kq, input channel i), output channel m
 #pragma unroll
