@@ -399,7 +399,8 @@ class BackwardPlan:
 def algorithmic_bytes(kind: str, prog) -> int:
     """ HBM bytes a persistent launch has to move by construction: forward = the input batch + every tensor it must leave for the backward
     pass (y and the output of every layer, the wide tensor of the link, the logits) + filters and per-channel parameters; backward = y and dz of every
-    layer + the first output gradient, the link's addend, the GroupNorm partials and the filters.  fp32. """
+    layer + the first output gradient, the link's addend, the GroupNorm partials and the filters, + with the weight gradients inside the launch every
+    layer's input and its partial slabs.  fp32. """
     n, total = prog.n, 0
     for i in range(prog.count):
         o = prog.op[i]
@@ -416,6 +417,8 @@ def algorithmic_bytes(kind: str, prog) -> int:
         else:
             pk = o.pool if o.pool > 0 else 1
             total += 2 * n * o.h * o.w * o.cout + o.k * o.k * o.cin * o.cout + 8 * o.cout + ((n + 1) // 2) * 2 * o.cout
+            if o.dw_part:              # weight gradient inside the launch: the layer's input + the per-(block, sample slot) partial slabs
+                total += n * o.h * o.w * o.cin + 2 * ((n + 1) // 2) * (o.k * o.k * o.cin * o.cout + o.cout)
             if i == 0:
                 total += n * (o.h // pk) * (o.w // pk) * o.cout
             if o.addend:

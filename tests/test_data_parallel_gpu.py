@@ -19,7 +19,7 @@ def _bench(args, launcher=()):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, *launcher, str(ROOT / 'bench.py'), '--steps', '12', '--warmup', '3', '--no-cpu-baseline', *args]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.returncode == 0, out.stderr[-8000:]
     line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
     return json.loads(line)
 

@@ -62,6 +62,24 @@ def test_resident_forward_matches_per_layer_kernels(device, params, bs, backward
         assert torch.allclose(ba.float(), bb.float(), rtol=1e-5, atol=1e-7), name
 
 
+def test_weight_gradients_outside_the_backward_launch(device, params):
+    """ `DCV_RESIDENT_WGRAD=0`: the persistent backward launch leaves the weight gradients to the multi-layer launch, which reads its dz tensors. """
+    from deepcv_amd import resident
+    g = torch.Generator().manual_seed(DATA_SEED)
+    x, y = torch.randn(64, 3, 32, 32, generator=g).to(device), torch.randint(0, 10, (64,), generator=g).to(device)
+    a, b = _model(params, 'image_classifier_model', device), _model(params, 'image_classifier_model', device)
+    prev, resident._wgrad_in_launch = resident._wgrad_in_launch, False
+    try:
+        la, loss_a, _ = _run(a, x, y, True, True)
+    finally:
+        resident._wgrad_in_launch = prev
+    lb, loss_b, _ = _run(b, x, y, True, True)
+    assert loss_a == loss_b
+    gscale = max(p.grad.abs().max().item() for p in b.parameters())
+    for (name, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert (pa.grad - pb.grad).abs().max().item() <= 2e-4 * pb.grad.abs().max().item() + 2e-6 * gscale, name
+
+
 def test_resident_forward_matches_oracle_at_the_bench_batch(device, params):
     """ BASELINE.json bars on the resident path itself: logits rtol 1e-3, loss rtol 1e-4 against the CPU oracle at bs 512. """
     from deepcv_amd import resident
