@@ -760,50 +760,55 @@ __host__ __device__ __forceinline__ int rb_wgrad_variant(int cin, int cout, int 
     return 0;
 }
 
-// cin <= 4 -> 4: unit = (tap | bias, sample).  Lanes = pixels (two image rows H / 2 apart per iteration share the index decode): per pixel one ds_read_b128 of
-// x at the tap's offset, one of dz, 16 FMAs into the lane's [ci][co] accumulators; two halving reductions finish the unit.
+// cin <= 4 -> 4: unit = (filter row ky, output-channel pair, sample) + one bias unit per sample.  Lanes = pixels: per pixel the K input vectors of the row's
+// sliding window and one dz vector feed K * 8 FMAs (K = 5: 40 FMAs per 6 ds_read_b128; a unit per single tap does 16 per 2 and spent as many instructions
+// on reads and index arithmetic as on FMAs: 13 us per 5x5 layer), into the lane's [kx][ci][co of the pair] accumulators; K halving reductions finish it.
 template <int K>
 __device__ __forceinline__ void rb_wgrad_c4(const dcv_resident_bwd_op& o, const float4* xt, const float4* dzt) {
-    const int H = o.h, W = o.w, pad = K / 2, XW = W + 2 * pad, T = K * K, half = (H >> 1) * W, wsize = o.cout * o.cin * T;
+    const int H = o.h, W = o.w, pad = K / 2, XW = W + 2 * pad, HW = H * W, wsize = o.cout * o.cin * K * K;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float inv_w = 1.f / (float)W;
-    for (int u = wave; u < RS_SPB * (T + 1); u += 16) {
-        const int s = u >= T + 1 ? 1 : 0, tap = u - s * (T + 1);                     // tap == T: the bias gradient (x = 1 on input channel 0)
-        const int ky = tap < T ? tap / K : pad, kx = tap < T ? tap - ky * K : pad;
-        float acc[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        const float4* xs = xt + s * RS_XIN + ky * XW + kx;
+    constexpr int UPS = 2 * K + 1;                                                   // units per sample: K filter rows x 2 channel pairs, + the bias
+    for (int u = wave; u < RS_SPB * UPS; u += 16) {
+        const int s = u >= UPS ? 1 : 0, v = u - s * UPS, chunk = (int)blockIdx.x * RS_SPB + s;
         const float4* ds = dzt + s * RS_XIN + pad * XW + pad;
-        for (int px = lane; px < half; px += 64) {
-            const int r = rs_fdiv(px, inv_w), c = px - r * W, a0 = r * XW + c, a1 = a0 + (H >> 1) * XW;
-            float4 x0 = xs[a0], x1 = xs[a1];
-            const float4 d0 = ds[a0], d1 = ds[a1];
-            if (tap == T) { x0 = make_float4(1.f, 0.f, 0.f, 0.f); x1 = x0; }
-#define RB_ACC(x4, d4) \
-            acc[0] += x4.x * d4.x; acc[1] += x4.x * d4.y; acc[2] += x4.x * d4.z; acc[3] += x4.x * d4.w; \
-            acc[4] += x4.y * d4.x; acc[5] += x4.y * d4.y; acc[6] += x4.y * d4.z; acc[7] += x4.y * d4.w; \
-            acc[8] += x4.z * d4.x; acc[9] += x4.z * d4.y; acc[10] += x4.z * d4.z; acc[11] += x4.z * d4.w; \
-            acc[12] += x4.w * d4.x; acc[13] += x4.w * d4.y; acc[14] += x4.w * d4.z; acc[15] += x4.w * d4.w;
-            RB_ACC(x0, d0)
-            RB_ACC(x1, d1)
-#undef RB_ACC
+        if (v == 2 * K) {                                                            // bias gradient: sum of dz per output channel
+            float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rb[2];
+            for (int px = lane; px < HW; px += 64) { const int r = rs_fdiv(px, inv_w), c = px - r * W; const float4 d = ds[r * XW + c]; b8[0] += d.x; b8[1] += d.y; b8[2] += d.z; b8[3] += d.w; }
+            rs_reduce8(b8, rb);
+            if (o.db_part && (lane == 0 || lane == 2)) { o.db_part[(size_t)chunk * o.cout + lane] = rb[0]; o.db_part[(size_t)chunk * o.cout + lane + 1] = rb[1]; }
+            continue;
         }
-        float lo[8], hi[8], rl[2], rh[2];
+        const int ky = v >> 1, h2 = v & 1;
+        const float4* xs = xt + s * RS_XIN + ky * XW;
+        float acc[K][8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { lo[i] = acc[i]; hi[i] = acc[8 + i]; }
-        rs_reduce8(lo, rl); rs_reduce8(hi, rh);
-        if (lane < 4) {
-            const int vi = (lane & 1) * 4 + ((lane >> 1) & 1) * 2, chunk = (int)blockIdx.x * RS_SPB + s;
+        for (int kx = 0; kx < K; ++kx)
 #pragma unroll
-            for (int g = 0; g < 2; ++g)
+            for (int i = 0; i < 8; ++i) acc[kx][i] = 0.f;
+        for (int px = lane; px < HW; px += 64) {
+            const int r = rs_fdiv(px, inv_w), c = px - r * W, a = r * XW + c;
+            const float4 d4 = ds[a];
+            const float d0 = h2 ? d4.z : d4.x, d1 = h2 ? d4.w : d4.y;
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const float4 x4 = xs[a + kx];
+                acc[kx][0] += x4.x * d0; acc[kx][1] += x4.x * d1; acc[kx][2] += x4.y * d0; acc[kx][3] += x4.y * d1;
+                acc[kx][4] += x4.z * d0; acc[kx][5] += x4.z * d1; acc[kx][6] += x4.w * d0; acc[kx][7] += x4.w * d1;
+            }
+        }
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            float r2[2];
+            rs_reduce8(acc[kx], r2);                                                 // value index = ci * 2 + (channel of the pair)
+            if (lane < 4) {
+                const int vi = (lane & 1) * 4 + ((lane >> 1) & 1) * 2;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int v = g * 8 + vi + j, ci = v >> 2, co = v & 3;
-                    const float val = g == 0 ? rl[j] : rh[j];
-                    if (tap < T) { if (ci < o.cin) o.dw_part[(size_t)chunk * wsize + ((co * o.cin + ci) * K + ky) * K + kx] = val; }
-                    else if (ci == 0 && o.db_part) o.db_part[(size_t)chunk * o.cout + co] = val;
+                    const int ci = (vi + j) >> 1, co = 2 * h2 + ((vi + j) & 1);
+                    if (ci < o.cin) o.dw_part[(size_t)chunk * wsize + ((co * o.cin + ci) * K + ky) * K + kx] = r2[j];
                 }
+            }
         }
     }
 }
