@@ -13,7 +13,7 @@ from typing import Optional
 
 import torch
 
-__all__ = ['lib', 'load', 'is_available', 'check', 'current_stream', 'Conv2dDesc', 'SlabSegment', 'WgradJob', 'Pool2dDesc', 'TensorList', 'NormChainDesc', 'ResidentOp', 'ResidentProgram', 'ResidentBwdOp', 'ResidentBwdProgram', 'LIB_PATH', 'build',
+__all__ = ['lib', 'load', 'is_available', 'check', 'current_stream', 'Conv2dDesc', 'SlabSegment', 'WgradJob', 'Pool2dDesc', 'TensorList', 'NormChainDesc', 'ResidentOp', 'ResidentProgram', 'ResidentBwdOp', 'ResidentBwdHead', 'ResidentBwdProgram', 'LIB_PATH', 'build',
            'ACT_NONE', 'ACT_RELU', 'ACT_LEAKY_RELU', 'ACT_SIGMOID', 'ACT_TANH', 'POOL_AVG', 'POOL_MAX', 'LAYOUT_NHWC', 'LAYOUT_NCHW',
            'MAX_TENSORS', 'HYP_COUNT', 'HYP']
 
@@ -102,9 +102,16 @@ class ResidentBwdOp(ctypes.Structure):
                 ('x', _c_void_p), ('dw_part', _c_void_p), ('db_part', _c_void_p), ('x_nchw', _c_int), ('reserved', _c_int)]
 
 
+class ResidentBwdHead(ctypes.Structure):
+    """ `dcv_resident_bwd_head` """
+    _fields_ = [('enabled', _c_int), ('classes', _c_int), ('act', _c_int), ('slope', _c_float), ('h', _c_int), ('w', _c_int), ('cc', _c_int), ('cr', _c_int),
+                ('ref_h', _c_int), ('ref_w', _c_int), ('align_corners', _c_int), ('reserved', _c_int),
+                ('dlogits', _c_void_p), ('logits', _c_void_p), ('wp', _c_void_p), ('dref', _c_void_p)]
+
+
 class ResidentBwdProgram(ctypes.Structure):
     """ `dcv_resident_bwd_program` """
-    _fields_ = [('n', _c_int), ('count', _c_int), ('op', ResidentBwdOp * RESIDENT_BWD_MAX_OPS)]
+    _fields_ = [('n', _c_int), ('count', _c_int), ('op', ResidentBwdOp * RESIDENT_BWD_MAX_OPS), ('head', ResidentBwdHead)]
 
 
 class TensorList(ctypes.Structure):

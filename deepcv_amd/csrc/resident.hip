@@ -955,8 +955,72 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         const dcv_resident_bwd_op& o = p.op[0];
         const int pk = o.pool > 0 ? o.pool : 1;
         load_flat(o.y, yreg, o.h * o.w * o.cout);
-        load_flat(o.dout, dor, (o.h / pk) * (o.w / pk) * o.cout);
+        if (!p.head.enabled) load_flat(o.dout, dor, (o.h / pk) * (o.w / pk) * o.cout);
         if (pslot >= 0) (&s_par[0][0][0])[pslot] = pv;
+    }
+    if (p.head.enabled) {
+        // ---- head of the backward pass: dl = dlogits act'(logits); dwide = dl W; the current tensor's channels -> op 0's dout (LDS), the referenced tensor's
+        // channels -> back through the bilinear resize (gather: each input pixel sums the output pixels whose footprint contains it) -> dref (HBM)
+        const dcv_resident_bwd_head& hd = p.head;
+        const int O = hd.classes, HWo = hd.h * hd.w, Cc = hd.cc, Cr = hd.cr, Cw = Cc + Cr, K = HWo * Cw;
+        float* tmp = reinterpret_cast<float*>(xtt);                                  // [RS_SPB][HWo * Cr]: the referenced channels of dwide (the x tile is still free)
+        if (t < RS_SPB * O) {
+            const int ss = t >= O ? 1 : 0, j = t - ss * O, n = (int)blockIdx.x * RS_SPB + ss;
+            float g = 0.f;
+            if (n < N) { g = hd.dlogits[(size_t)n * O + j]; if (hd.logits) g *= dcv_act_grad_from_out(hd.logits[(size_t)n * O + j], hd.act, hd.slope); }
+            s_wsum[ss * 16 + j] = g;
+        }
+        rs_barrier();
+        {
+            const float inv_cw = 1.f / (float)Cw;
+            for (int k = tt; k < K; k += 512) {
+                float acc = 0.f;
+                for (int j = 0; j < O; ++j) acc += s_wsum[s_of_t * 16 + j] * hd.wp[(size_t)j * K + k];
+                const int px = rs_fdiv(k, inv_cw), c = k - px * Cw;
+                if (c < Cc) dor[s_of_t * RS_Y + px * Cc + c] = acc; else tmp[s_of_t * RS_Y + px * Cr + (c - Cc)] = acc;
+            }
+        }
+        rs_barrier();
+        {
+            const int RH = hd.ref_h, RW = hd.ref_w, per = RH * RW * Cr;
+            const float sh = hd.align_corners ? (hd.h > 1 ? (float)(RH - 1) / (float)(hd.h - 1) : 0.f) : (float)RH / (float)hd.h;
+            const float sw = hd.align_corners ? (hd.w > 1 ? (float)(RW - 1) / (float)(hd.w - 1) : 0.f) : (float)RW / (float)hd.w;
+            const float inv_cr = 1.f / (float)Cr, inv_rw = 1.f / (float)RW;
+            auto taps = [&](float scale, int dst, int in_size, int& i0, int& i1, float& l1) {
+                float fs = hd.align_corners ? scale * dst : scale * (dst + 0.5f) - 0.5f; if (fs < 0.f) fs = 0.f;
+                i0 = (int)fs; if (i0 > in_size - 1) i0 = in_size - 1;
+                i1 = i0 + ((i0 < in_size - 1) ? 1 : 0); l1 = fs - (float)i0;
+            };
+            auto range = [&](float scale, int i, int out_size, int& lo, int& hi) {
+                const float inv = scale > 0.f ? 1.f / scale : 0.f;
+                lo = (int)floorf(((float)i - 1.5f) * inv - 1.5f); hi = (int)ceilf(((float)i + 1.5f) * inv + 1.5f);
+                if (lo < 0) lo = 0;
+                if (hi > out_size - 1) hi = out_size - 1;
+            };
+            for (int e = tt; e < per; e += 512) {
+                const int px = rs_fdiv(e, inv_cr), cr = e - px * Cr, rh = rs_fdiv(px, inv_rw), rw = px - rh * RW;
+                int holo, hohi, wolo, wohi;
+                range(sh, rh, hd.h, holo, hohi); range(sw, rw, hd.w, wolo, wohi);
+                float acc = 0.f;
+                for (int ho = holo; ho <= hohi; ++ho) {
+                    int h0, h1; float lh; taps(sh, ho, RH, h0, h1, lh);
+                    float wh = 0.f;
+                    if (h0 == rh) wh += 1.f - lh;
+                    if (h1 == rh) wh += lh;
+                    if (wh == 0.f) continue;
+                    for (int wo = wolo; wo <= wohi; ++wo) {
+                        int w0, w1; float lw; taps(sw, wo, RW, w0, w1, lw);
+                        float ww = 0.f;
+                        if (w0 == rw) ww += 1.f - lw;
+                        if (w1 == rw) ww += lw;
+                        if (ww == 0.f) continue;
+                        acc += wh * ww * tmp[s_of_t * RS_Y + (ho * hd.w + wo) * Cr + cr];
+                    }
+                }
+                const int n = (int)blockIdx.x * RS_SPB + s_of_t;
+                if (n < N) hd.dref[(size_t)n * per + e] = acc;
+            }
+        }
     }
     rs_barrier();
     const unsigned gen = s_gen;
@@ -1183,7 +1247,15 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
 }
 
 inline bool rb_program_ok(const dcv_resident_bwd_program* p) {
-    if (!p || p->n <= 0 || p->n > RS_SPB * RS_MAXG || p->count <= 0 || p->count > DCV_RESIDENT_BWD_MAX_OPS || !p->op[0].dout) return false;
+    if (!p || p->n <= 0 || p->n > RS_SPB * RS_MAXG || p->count <= 0 || p->count > DCV_RESIDENT_BWD_MAX_OPS) return false;
+    if (p->head.enabled) {
+        const dcv_resident_bwd_head& hd = p->head;
+        const dcv_resident_bwd_op& o = p->op[0];
+        const int pk = o.pool > 0 ? o.pool : 1;
+        if (hd.classes <= 0 || hd.classes > 16 || hd.cc != o.cout || hd.h != o.h / pk || hd.w != o.w / pk || hd.cr <= 0 || hd.ref_h <= 0 || hd.ref_w <= 0) return false;
+        if (hd.h * hd.w * hd.cr > RS_Y || hd.ref_h * hd.ref_w * hd.cr > 16 * RS_Y || !hd.dlogits || !hd.wp || !hd.dref || hd.act < DCV_ACT_NONE || hd.act > DCV_ACT_TANH) return false;
+        if (hd.act != DCV_ACT_NONE && !hd.logits) return false;
+    } else if (!p->op[0].dout) return false;
     for (int i = 0; i < p->count; ++i) {
         const dcv_resident_bwd_op& o = p->op[i];
         if (o.cout != 4 && o.cout != 8 && o.cout != 16) return false;

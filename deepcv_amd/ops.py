@@ -993,6 +993,7 @@ class _ResizeConcatFn(torch.autograd.Function):
         if rec is not None:
             rec.add_link(tensors, align_corners, out)
             ctx.geom = (n, ho, wo, chans, hs, ws, int(align_corners))
+            ctx.res_plan = rec.plan
             return out
         ia = lambda v: (ctypes.c_int * k)(*v)
         nat.check(lib.dcv_resize_concat_channels(k, (ctypes.c_void_p * k)(*[t.data_ptr() for t in tensors]), ia(chans), ia(hs), ia(ws), out.data_ptr(),
@@ -1007,6 +1008,9 @@ class _ResizeConcatFn(torch.autograd.Function):
         k = len(chans)
         grads = [torch.empty((n, c, h, w), dtype=dy.dtype, device=dy.device, memory_format=_CL) if ctx.needs_input_grad[i + 1] else None
                  for i, (c, h, w) in enumerate(zip(chans, hs, ws))]
+        plan = getattr(ctx, 'res_plan', None)
+        if plan is not None and k == 2 and grads[0] is not None and grads[1] is not None and plan.split_link(dy, grads[0], grads[1]):
+            return (None, *grads)       # both parts are produced by the persistent backward launch (its head)
         ia = lambda v: (ctypes.c_int * k)(*v)
         nat.check(lib.dcv_resize_split_channels(k, (ctypes.c_void_p * k)(*[nat.ptr(g) for g in grads]), ia(chans), ia(hs), ia(ws), dy.data_ptr(),
                                                 n, ho, wo, align, nat.current_stream(dy.device)), 'dcv_resize_split_channels')
@@ -1179,6 +1183,7 @@ class _LinearNhwcFn(torch.autograd.Function):
         y = torch.empty((n, o), dtype=x.dtype, device=x.device)
         if rec is not None:
             rec.add_fc(x, wp, bias, act, slope, y)
+            ctx.res_plan = rec.plan
         else:
             nat.check(lib.dcv_linear_fwd(x.data_ptr(), wp.data_ptr(), nat.ptr(bias), y.data_ptr(), n, k, o, act, slope, nat.current_stream(x.device)), 'dcv_linear_fwd')
         ctx.act, ctx.slope, ctx.has_bias, ctx.desc = act, slope, bias is not None, d
@@ -1195,12 +1200,17 @@ class _LinearNhwcFn(torch.autograd.Function):
         wp = filters.get(weight, ctx.desc, 2)
         need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None            # channels_last like x: the gradient of the NHWC activations, in place
+        plan = getattr(ctx, 'res_plan', None)
+        dx_arg = dx
+        if (plan is not None and dx is not None and need_w and slabs.would_defer(ctx.weight_ref, ctx.bias_ref)
+                and plan.decide_head(dy, y, wp, dx, lambda dd: bool(lib.dcv_conv2d_wgrad_fuses_bias(dd)))):
+            dx_arg = None        # the head's data gradient and the link's split are the first thing the persistent backward launch does; dx is never written
         dw = _grad_buffer(ctx.weight_ref, like=weight) if need_w else None
         db = _grad_buffer(ctx.bias_ref, n=o, device=dev) if (need_w and ctx.has_bias) else None
         ws = _ws(lib.dcv_linear_bwd_workspace_bytes(n, k, o), dev)
         if need_w and slabs.may_defer(ctx.weight_ref, ctx.bias_ref):
             segs, ns = (nat.SlabSegment * 2)(), ctypes.c_int(0)
-            nat.check(lib.dcv_linear_bwd_deferred(dy.data_ptr(), nat.ptr(y), ctx.act, ctx.slope, x.data_ptr(), wp.data_ptr(), nat.ptr(dx), nat.ptr(dw), nat.ptr(db),
+            nat.check(lib.dcv_linear_bwd_deferred(dy.data_ptr(), nat.ptr(y), ctx.act, ctx.slope, x.data_ptr(), wp.data_ptr(), nat.ptr(dx_arg), nat.ptr(dw), nat.ptr(db),
                                                   n, k, o, ws.data_ptr(), ws.numel(), segs, ctypes.byref(ns), st), 'dcv_linear_bwd_deferred')
             segs[0].tr_a, segs[0].tr_b = h * w, c                                  # [O][H*W][C] sums -> dw [O][C][H*W]
             slabs.defer(dev, st, segs, ns.value, ws)

@@ -98,6 +98,7 @@ def reads_oihw(d: nat.Conv2dDesc) -> bool:
 
 
 _wgrad_in_launch = os.environ.get('DCV_RESIDENT_WGRAD', '1') not in ('0', 'false', 'False', '')
+_head_in_launch = os.environ.get('DCV_RESIDENT_HEAD', '1') not in ('0', 'false', 'False', '')
 
 
 def wgrad_in_launch(d: nat.Conv2dDesc) -> bool:
@@ -261,6 +262,8 @@ class Recorder:
         self.ops.append(op)
         self.keep.extend((cur, ref, out))
         self.cur = out
+        self.plan.link = {'cc': cur.shape[1], 'h': cur.shape[2], 'w': cur.shape[3], 'cr': ref.shape[1], 'ref_h': ref.shape[2], 'ref_w': ref.shape[3],
+                          'align': int(bool(align_corners)), 'after_layer': len(self.plan.layers) - 1}
 
     def check_fc(self, x: torch.Tensor, out_features: int):
         self._consume(x, 'fully connected head')
@@ -274,6 +277,7 @@ class Recorder:
         self.ops.append(op)
         self.keep.extend(t for t in (x, wp, bias, y) if t is not None)
         self.cur = y
+        self.plan.fc = {'classes': y.shape[1], 'act': act, 'slope': slope, 'follows_link': len(self.ops) >= 2 and self.ops[-2].kind == nat.RES_LINK}
 
     # ---- the launch
     def finish(self, result):
@@ -315,6 +319,10 @@ class BackwardPlan:
         self.ops: List[nat.ResidentBwdOp] = []
         self.keep: List[torch.Tensor] = []
         self.stream = 0
+        self.link: Optional[dict] = None      # the dense link / the fully connected head recorded behind the layers (forward), for the head of the backward launch
+        self.fc: Optional[dict] = None
+        self.head: Optional[nat.ResidentBwdHead] = None
+        self.head_dx: Optional[torch.Tensor] = None
 
     def add_layer(self, d: nat.Conv2dDesc, cfg, grad_params, needs_dx: bool, bias_without_weight: bool) -> int:
         self.layers.append({'d': nat.Conv2dDesc.from_buffer_copy(d), 'cfg': cfg, 'params': [p for p in grad_params if p is not None], 'needs_dx': bool(needs_dx),
@@ -335,24 +343,60 @@ class BackwardPlan:
                 op.dout = 16
         return prog
 
-    def decide(self, index: int, dout: torch.Tensor, bias_from_wgrad) -> bool:
-        """ Called by the first backward node of the stack to run (it must be the last layer's).  True: the pass is recorded. """
+    def _layers_ok(self, bias_from_wgrad) -> bool:
         from . import slabs
-        self.state = 'plain'
-        if not (_enabled and _bwd_enabled and self.fusable) or index != len(self.layers) - 1 or len(self.layers) > nat.RESIDENT_BWD_MAX_OPS:
+        if not (_enabled and _bwd_enabled and self.fusable) or not self.layers or len(self.layers) > nat.RESIDENT_BWD_MAX_OPS:
             return False
         if slabs._current_pass() in (None, -1) or any(layer['odd'] for layer in self.layers):      # not an engine-driven pass: no final callback to launch from
             return False
-        if torch.is_grad_enabled() or not slabs.enabled() or not (dout.is_cuda and dout.dtype == torch.float32 and dout.dim() == 4 and dout.is_contiguous(memory_format=torch.channels_last)):
+        if torch.is_grad_enabled() or not slabs.enabled():
             return False
         if not all(slabs.would_defer(*layer['params']) for layer in self.layers):
             return False
-        if not all(bias_from_wgrad(layer['d']) for layer in self.layers):
+        return all(bias_from_wgrad(layer['d']) for layer in self.layers)
+
+    def decide(self, index: int, dout: torch.Tensor, bias_from_wgrad) -> bool:
+        """ Called by the first backward node of the stack to run (it must be the last layer's).  True: the pass is recorded. """
+        self.state = 'plain'
+        if index != len(self.layers) - 1 or not self._layers_ok(bias_from_wgrad):
+            return False
+        if not (dout.is_cuda and dout.dtype == torch.float32 and dout.dim() == 4 and dout.is_contiguous(memory_format=torch.channels_last)):
             return False
         if not lib.dcv_resident_bwd_supported(self._skeleton()):
             return False
         self.state, self.next_index, self.prev_dx = 'fused', index, None
-        self.ops, self.keep = [], []
+        self.ops, self.keep, self.head = [], [], None
+        return True
+
+    def decide_head(self, dlogits: torch.Tensor, logits: Optional[torch.Tensor], wp: torch.Tensor, dwide: torch.Tensor, bias_from_wgrad) -> bool:
+        """ Called by the fully connected head's backward node — the first node of the whole pass when the stack ends LINK -> Flatten -> FC: the launch then
+        also computes the head's data gradient and the link's split (`dcv_resident_bwd_head`).  `dwide`: the (never materialised) gradient tensor the head
+        hands to the link's node, by which that node recognises the recorded pass.  False: undecided, the layers decide for themselves later. """
+        if not _head_in_launch or self.state is not None or self.link is None or self.fc is None or not self.fc['follows_link'] or self.link['after_layer'] != len(self.layers) - 1:
+            return False
+        if not self._layers_ok(bias_from_wgrad) or not (dlogits.is_cuda and dlogits.dtype == torch.float32 and dlogits.is_contiguous()):
+            return False
+        head = nat.ResidentBwdHead()
+        head.enabled, head.classes, head.act, head.slope = 1, self.fc['classes'], self.fc['act'], self.fc['slope']
+        head.h, head.w, head.cc, head.cr, head.ref_h, head.ref_w, head.align_corners = (self.link[k] for k in ('h', 'w', 'cc', 'cr', 'ref_h', 'ref_w', 'align'))
+        head.dlogits, head.logits, head.wp, head.dref = dlogits.data_ptr(), nat.ptr(logits), wp.data_ptr(), 16
+        prog = self._skeleton()
+        prog.op[0].dout = None
+        prog.head = head
+        if not lib.dcv_resident_bwd_supported(prog):
+            return False
+        self.state, self.next_index, self.prev_dx = 'fused', len(self.layers) - 1, None
+        self.ops, self.keep, self.head, self.head_dx = [], [dlogits, logits, wp], head, dwide
+        return True
+
+    def split_link(self, dwide: torch.Tensor, dcur: torch.Tensor, dref: torch.Tensor) -> bool:
+        """ The link's backward node in a recorded pass with a head: `dcur` (what the last layer's node will receive as dout; it stays in LDS) and `dref`
+        (HBM, written by the launch, added to the data gradient of the layer which consumed the referenced tensor). """
+        if self.state != 'fused' or self.head is None or self.head_dx is None or dwide.data_ptr() != self.head_dx.data_ptr():
+            return False
+        self.head.dref = dref.data_ptr()
+        self.keep.append(dref)
+        self.prev_dx, self.head_dx = dcur, None
         return True
 
     def expect(self, index: int, dout: torch.Tensor):
@@ -381,6 +425,8 @@ class BackwardPlan:
         prog.n, prog.count = self.n, len(ops)
         for i, op in enumerate(ops):
             prog.op[i] = op
+        if self.head is not None:
+            prog.head, self.head = self.head, None
         ws = _ws_bwd.get(self.device)
         if ws is None:
             ws = _ws_bwd[self.device] = torch.zeros(int(lib.dcv_resident_ws_bytes()), dtype=torch.uint8, device=self.device)

@@ -595,7 +595,17 @@ typedef struct dcv_resident_bwd_op {
     const float* x; float* dw_part; float* db_part; int x_nchw; int reserved;
 } dcv_resident_bwd_op;
 #define DCV_RESIDENT_BWD_MAX_OPS 8
-typedef struct dcv_resident_bwd_program { int n; int count; dcv_resident_bwd_op op[DCV_RESIDENT_BWD_MAX_OPS]; } dcv_resident_bwd_program;
+/* Optional head of the backward pass in front of op 0, for a stack which ends LINK -> Flatten -> fully connected layer (dcv_resident_program): the data gradient
+ * of the Linear (dwide = (dlogits * act'(logits)) W, W = the [O][H*W*C] weight of dcv_conv2d_prepare_filters op 2) and the link's split: the current tensor's
+ * channels become op 0's dout (in LDS), the referenced tensor's channels go back through the bilinear resize (gather form) to `dref` in HBM, which the caller
+ * names as `addend` of the op whose input the link referenced.  replaces the autograd nodes of submodule_creators.py:268-269 (Linear) and :272-332 (dense link).
+ * The weight / bias gradient of the Linear stays with dcv_linear_bwd_deferred (dx = NULL). */
+typedef struct dcv_resident_bwd_head {
+    int enabled, classes, act; float slope;
+    int h, w, cc, cr, ref_h, ref_w, align_corners, reserved;   /* wide tensor [n][h][w][cc + cr]; referenced tensor [n][ref_h][ref_w][cr] */
+    const float* dlogits; const float* logits; const float* wp; float* dref;
+} dcv_resident_bwd_head;
+typedef struct dcv_resident_bwd_program { int n; int count; dcv_resident_bwd_op op[DCV_RESIDENT_BWD_MAX_OPS]; dcv_resident_bwd_head head; } dcv_resident_bwd_program;
 int dcv_resident_bwd_supported(const dcv_resident_bwd_program* p);
 int dcv_resident_backward(const dcv_resident_bwd_program* p, void* ws, size_t ws_bytes, void* stream);
 
