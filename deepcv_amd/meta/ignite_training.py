@@ -308,7 +308,11 @@ class GraphedTrainStep:
         _ops.register_unit_gradient(self._seed)                    # loss ops may return the gradient their forward launch already computed
         torch.cuda.synchronize(dev)
         self.graph_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_fb, stream=self.stream):
+        # with a process group alive its watchdog thread queries events while this thread captures: under the default 'global' capture mode such a call from
+        # another thread invalidates the capture (observed once as an abort of the rank process in the data-parallel rehearsal); 'thread_local' confines the
+        # check to the capturing thread
+        capture_mode = 'thread_local' if (self.reducer is not None or (torch.distributed.is_available() and torch.distributed.is_initialized())) else 'global'
+        with torch.cuda.graph(self.graph_fb, stream=self.stream, capture_error_mode=capture_mode):
             self._nat.check(self._nat.lib.dcv_indirect_copy(self.mailbox.data_ptr(), self._nat.current_stream(dev)), 'dcv_indirect_copy')
             self.static_pred = self.model(self.static_x)
             self.static_losses = _batch_losses(self.losses, self.weights, self.static_pred, self.static_y)
@@ -333,7 +337,7 @@ class GraphedTrainStep:
             self._static_grads = [p.grad for p in self.reducer.params]       # graph-pool gradient tensors written by every replay
             self.reducer.finish()                                            # p.grad -> bucket views (static addresses)
             self.graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_opt, stream=self.stream):
+            with torch.cuda.graph(self.graph_opt, stream=self.stream, capture_error_mode=capture_mode):
                 self.optimizer.step()
         torch.cuda.synchronize(dev)
 
