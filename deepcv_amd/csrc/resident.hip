@@ -611,12 +611,13 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                 const int npad = nxt_layer ? p.op[oi + 1].k / 2 : 0, XWn = Wo + 2 * npad, XHn = Ho + 2 * npad;
                 const float inv = 1.f / (float)(pk * pk), inv_cv = 1.f / (float)CV, inv_wo = 1.f / (float)Wo;
                 const int per = Ho * Wo * CV;
-                for (int it = t; it < RS_SPB * per; it += RS_T) {
-                    const int ss = it >= per ? 1 : 0, e = it - ss * per, px = rs_fdiv(e, inv_cv), cv = e - px * CV, ho = rs_fdiv(px, inv_wo), wo = px - ho * Wo;
-                    const float4 S = *reinterpret_cast<const float4*>(s_S[ss] + cv * 4), T = *reinterpret_cast<const float4*>(s_T[ss] + cv * 4);
+                // waves 0 - 7: the first sample, 8 - 15: the second; a thread's channel vector is fixed (512 is a multiple of CV): S, T in registers
+                const int ss = s_of_t, cv = tt & (CV - 1), n = (int)blockIdx.x * RS_SPB + ss;
+                const float4 S = *reinterpret_cast<const float4*>(s_S[ss] + cv * 4), T = *reinterpret_cast<const float4*>(s_T[ss] + cv * 4);
+                float4* yg = reinterpret_cast<float4*>(o.y) + (size_t)(n < N ? n : 0) * HW * CV;
+                for (int e = tt; e < per; e += 512) {
+                    const int px = rs_fdiv(e, inv_cv), ho = rs_fdiv(px, inv_wo), wo = px - ho * Wo;
                     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-                    const int n = (int)blockIdx.x * RS_SPB + ss;
-                    float4* yg = reinterpret_cast<float4*>(o.y) + (size_t)(n < N ? n : 0) * HW * CV;
                     for (int kh = 0; kh < pk; ++kh)
                         for (int kw = 0; kw < pk; ++kw) {
                             const int yi = ((ho * pk + kh) * W + wo * pk + kw) * CV + cv;
@@ -1194,20 +1195,21 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
             const int pad = o.k / 2, XW = W + 2 * pad, XH = H + 2 * pad;
             const float inv_cv = 1.f / (float)CV;
             const int per = HW * CV;
-            for (int it = t; it < RS_SPB * per; it += RS_T) {
-                const int ss = it >= per ? 1 : 0, e = it - ss * per, px = rs_fdiv(e, inv_cv), cv = e - px * CV, r = rs_fdiv(px, inv_w), c = px - r * W;
+            // waves 0 - 7: the first sample, 8 - 15: the second; a thread's channel vector is fixed (512 is a multiple of CV): coefficients in registers
+            const int ss = s_of_t, cv = tt & (CV - 1), n = (int)blockIdx.x * RS_SPB + ss;
+            const float4 Pv = *reinterpret_cast<const float4*>(s_coef[ss][0] + cv * 4), Qv = *reinterpret_cast<const float4*>(s_coef[ss][1] + cv * 4);
+            const float4 Rv = *reinterpret_cast<const float4*>(s_coef[ss][2] + cv * 4);
+            const float4 mu = *reinterpret_cast<const float4*>(s_mr[0] + cv * 4), rs = *reinterpret_cast<const float4*>(s_mr[1] + cv * 4);
+            for (int e = tt; e < per; e += 512) {
+                const int px = rs_fdiv(e, inv_cv), r = rs_fdiv(px, inv_w), c = px - r * W;
                 const float4 y4 = reinterpret_cast<const float4*>(yreg + ss * RS_Y)[e];
                 const int di = pk > 1 ? rs_fdiv(r, inv_pk) * Wo + rs_fdiv(c, inv_pk) : px;
                 float4 d4 = reinterpret_cast<const float4*>(dor + ss * RS_Y)[di * CV + cv];
-                const float4 Pv = *reinterpret_cast<const float4*>(s_coef[ss][0] + cv * 4), Qv = *reinterpret_cast<const float4*>(s_coef[ss][1] + cv * 4);
-                const float4 Rv = *reinterpret_cast<const float4*>(s_coef[ss][2] + cv * 4);
-                const float4 mu = *reinterpret_cast<const float4*>(s_mr[0] + cv * 4), rs = *reinterpret_cast<const float4*>(s_mr[1] + cv * 4);
                 float4 z;
                 z.x = (Pv.x * (d4.x * pinv) + Qv.x * ((y4.x - mu.x) * rs.x) + Rv.x) * rb_act_grad(y4.x, o.act, o.slope);
                 z.y = (Pv.y * (d4.y * pinv) + Qv.y * ((y4.y - mu.y) * rs.y) + Rv.y) * rb_act_grad(y4.y, o.act, o.slope);
                 z.z = (Pv.z * (d4.z * pinv) + Qv.z * ((y4.z - mu.z) * rs.z) + Rv.z) * rb_act_grad(y4.z, o.act, o.slope);
                 z.w = (Pv.w * (d4.w * pinv) + Qv.w * ((y4.w - mu.w) * rs.w) + Rv.w) * rb_act_grad(y4.w, o.act, o.slope);
-                const int n = (int)blockIdx.x * RS_SPB + ss;
                 if (n < N) reinterpret_cast<float4*>(o.dz)[(size_t)n * per + e] = z; else z = make_float4(0.f, 0.f, 0.f, 0.f);
                 dzt[ss * RS_XIN + (cv * XH + r + pad) * XW + c + pad] = z;
             }
