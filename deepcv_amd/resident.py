@@ -1,4 +1,5 @@
-""" LDS-resident forward of small-channel models (`dcv_resident_forward`, `deepcv_amd/csrc/resident.hip`).
+""" LDS-resident execution of small-channel models: their training forward (`dcv_resident_forward`) and the backward pass of their layer stack
+(`dcv_resident_backward`) as two persistent launches (`deepcv_amd/csrc/resident.hip`).
 
 `DeepcvModule.forward` (reference `src/deepcv/meta/base_module.py:113-155`) walks the sub-modules one by one; on the stock classifier that is ~20 kernel
 launches for five tiny layers.  When the whole model is a chain the resident kernel covers — `layer()` stacks `Conv2d -> act -> BatchNorm2d [-> GroupNorm]`
@@ -10,7 +11,14 @@ else on the stream is ordered after the launch, so deferring the arithmetic to t
 
 Recording is transactional: an op the kernel does not cover raises `Ineligible` BEFORE launching anything (every entry point of `deepcv_amd.ops` calls
 `forbid()`), nothing recorded so far has touched a parameter, a buffer or a running statistic, and the forward simply runs again on the per-layer kernels;
-the verdict is cached per (module, input shape, mode).  `DCV_RESIDENT=0` (or `set_enabled(False)`) turns the path off. """
+the verdict is cached per (module, input shape, mode).  `DCV_RESIDENT=0` (or `set_enabled(False)`) turns the path off.
+
+The backward pass follows the same idea through a `BackwardPlan` the forward leaves on the autograd contexts (see its docstring): the first backward node
+of the recorded stack decides for all of them, the nodes then only allocate their results and describe themselves, and ONE `dcv_resident_backward`
+launch — head (fully connected layer's data gradient, link split), per layer the normalisation-chain backward, the data gradient and, inside the
+all-reduce of the next layer, the weight gradient — runs at the start of `deepcv_amd.slabs.flush()`.  `DCV_RESIDENT_BWD=0`, `DCV_RESIDENT_HEAD=0`,
+`DCV_RESIDENT_WGRAD=0` switch the launch, its head, its weight gradients off (the per-layer kernels take over those parts).  Both launches need the
+whole GPU (`disable_if_gpu_shared`); a launch which could not get all its blocks resident reports it (`check_status`). """
 import ctypes
 import os
 import weakref
