@@ -33,7 +33,7 @@ constexpr int RS_MAXQ = 2 * RS_MAXC;
 constexpr int RS_MAXG = 256;        // blocks
 constexpr int RS_GRAN_OP = RS_MAXQ * RS_MAXG + 2 * RS_MAXQ;   // granules of one synchronisation: hop-1 partials [RS_MAXQ][RS_MAXG], hop-2 totals [RS_MAXQ][2]
 constexpr int RS_SPINS = 1 << 16;   // gather polls before giving up (each at least a memory round trip: tens of milliseconds)
-constexpr size_t RS_CTL_BYTES = 1024;  // [0] launch generation, [1] error word, [4..): time stamps of block 0 (64-bit, 100 MHz): tools/resident_stamps.py
+constexpr size_t RS_CTL_BYTES = 1024;  // [0] launch generation, [1] error word, [2] test hook (1 + index of a block which never publishes), [4..): time stamps of block 0 (64-bit, 100 MHz): tools/resident_stamps.py
 constexpr int RS_MAX_STAMPS = 120;
 
 typedef unsigned long long rs_u64;
@@ -131,9 +131,9 @@ __device__ __forceinline__ double rs_wave_sum_f64(double v) {
 // bits in every block.  A one-hop version (every block gathering all Q * G partials: 64 KB per block at 16 channels, two million polling loads per
 // sweep on the chip) took 2.5 - 6.5 us per layer.  Returns false when a poll gave up (a block of the grid is not resident).  Block-uniform control flow.
 // hop 1 alone: a caller with independent work (the weight gradients of the backward launch) does it between this and rs_allreduce(..., published = true)
-__device__ __forceinline__ void rs_allreduce_publish(rs_u64* ga, unsigned epoch, int Q, float mine) {
+__device__ __forceinline__ void rs_allreduce_publish(rs_u64* ga, unsigned epoch, int Q, float mine, bool mute = false) {
     const int t = threadIdx.x;
-    if (t < Q) __hip_atomic_store((rs_gu64*)(ga + (size_t)t * RS_MAXG + blockIdx.x), ((rs_u64)epoch << 32) | (rs_u64)__float_as_uint(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t < Q && !mute) __hip_atomic_store((rs_gu64*)(ga + (size_t)t * RS_MAXG + blockIdx.x), ((rs_u64)epoch << 32) | (rs_u64)__float_as_uint(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // the block's share of the reduction: for every quantity it owns, poll the G partials, sum, publish the total (hop 2).  A caller with independent work
@@ -195,8 +195,8 @@ __device__ __forceinline__ bool rs_allreduce_collect(rs_u64* gb, unsigned epoch,
 }
 
 __device__ __forceinline__ bool rs_allreduce(rs_u64* ga, rs_u64* gb, unsigned epoch, int Q, int G, float mine, double* totals, double* red, unsigned* w32, int* s_fail,
-                                             bool published = false) {
-    if (!published) rs_allreduce_publish(ga, epoch, Q, mine);
+                                             bool published = false, bool mute = false) {
+    if (!published) rs_allreduce_publish(ga, epoch, Q, mine, mute);
     rs_allreduce_reduce_owned(ga, gb, epoch, Q, G, red, s_fail);
     return rs_allreduce_collect(gb, epoch, Q, totals, w32, s_fail);
 }
@@ -428,6 +428,7 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
     const int N = p.n, G = (int)gridDim.x;
     const bool valid0 = (int)blockIdx.x * RS_SPB < N, valid1 = (int)blockIdx.x * RS_SPB + 1 < N;
     if (t == 0) { s_gen = __hip_atomic_load((rs_gu32*)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_fail = 0; }
+    const bool mute = ctl[2] == blockIdx.x + 1u;        // test hook (tests/test_resident_gpu.py): this block never publishes -> every block's bounded spin gives up
     int n_stamp = 0;
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(ctl + 4);
     auto stamp = [&]() { if (blockIdx.x == 0 && t == 0 && n_stamp < RS_MAX_STAMPS) stamps[1 + n_stamp] = wall_clock64(); ++n_stamp; };
@@ -554,7 +555,7 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
             }
             stamp();
             if (o.bn) {
-                if (!rs_allreduce(go, go + RS_MAXQ * RS_MAXG, epoch, 2 * C, G, mine, s_tot, s_red, s_w32, &s_fail)) {
+                if (!rs_allreduce(go, go + RS_MAXQ * RS_MAXG, epoch, 2 * C, G, mine, s_tot, s_red, s_w32, &s_fail, false, mute)) {
                     // a block of this grid is not resident: report, poison the logits, leave
                     if (t == 0) { __hip_atomic_store((rs_gu32*)(ctl + 1), (unsigned)oi + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                     for (int k = 0; k < p.count; ++k)
@@ -924,6 +925,7 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
     const int N = p.n, G = (int)gridDim.x;
     const bool valid0 = (int)blockIdx.x * RS_SPB < N, valid1 = (int)blockIdx.x * RS_SPB + 1 < N;
     if (t == 0) { s_gen = __hip_atomic_load((rs_gu32*)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_fail = 0; }
+    const bool mute = ctl[2] == blockIdx.x + 1u;        // test hook, as in the forward launch
     int n_stamp = 0;
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(ctl + 4);
     auto stamp = [&]() { if (blockIdx.x == 0 && t == 0 && n_stamp < RS_MAX_STAMPS) stamps[1 + n_stamp] = wall_clock64(); ++n_stamp; };
@@ -1111,7 +1113,7 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         stamp();
         // ---- the batch totals of T1, T2: publish the block's partials, compute the PREVIOUS op's weight gradient while they travel (its dz and x tiles are
         // still intact), then reduce / collect
-        rs_allreduce_publish(go, epoch, 2 * C, mine);
+        rs_allreduce_publish(go, epoch, 2 * C, mine, mute);
         rs_allreduce_reduce_owned(go, go + RS_MAXQ * RS_MAXG, epoch, 2 * C, G, s_red, &s_fail);   // the few owner blocks: before their own weight gradient, so that nobody waits for it
         if (oi > 0 && p.op[oi - 1].dw_part != nullptr) rb_wgrad(p.op[oi - 1], xtt, dzt);
         rs_barrier();

@@ -162,7 +162,7 @@ def check_status(device=None):
         err = ctypes.c_int(0)
         nat.check(lib.dcv_resident_status(ws.data_ptr(), nat.current_stream(dev), ctypes.byref(err)), 'dcv_resident_status')
         if err.value:
-            ws[4:8].zero_()
+            ws.zero_()         # launch generation, error word and every granule: the next launch starts from a clean slate (the failed one never advanced the generation)
             raise RuntimeError(f'deepcv_amd.resident: the gather of op {err.value - 1} timed out (the blocks of the persistent launch were not all resident); '
                                'outputs of that step are invalid. Set DCV_RESIDENT=0 when more than two processes share the GPU.')
 

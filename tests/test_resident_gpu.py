@@ -143,3 +143,46 @@ def test_replayed_graph_on_the_resident_path_tracks_eager(device, params):
         assert resident.launches() > before
         curves.append(got)
     assert curves[0] == curves[1], curves
+
+
+@pytest.mark.parametrize('which', ['forward', 'backward'])
+def test_a_block_which_never_arrives_is_reported_not_waited_for(device, params, which):
+    """ The all-reduce's spins are bounded: with one block muted (test hook in the workspace's control words: it takes part in everything but never publishes
+    its partial sums) every block gives up after its poll budget, the launch ends, the error word names the op, the step's loss is NaN and
+    `resident.check_status()` raises — and the next step, with the hook cleared, is an ordinary step again. """
+    from deepcv_amd import modules, resident
+    g = torch.Generator().manual_seed(DATA_SEED)
+    x, y = torch.randn(64, 3, 32, 32, generator=g).to(device), torch.randint(0, 10, (64,), generator=g).to(device)
+    model = _model(params, 'image_classifier_model', device)
+    ref = _model(params, 'image_classifier_model', device)
+    prev, prev_b = resident.set_enabled(True), resident.set_backward_enabled(True)
+    try:
+        model.train()
+        loss = modules.CrossEntropyLoss()(model(x), y)           # creates both workspaces
+        loss.backward()
+        torch.cuda.synchronize()
+        resident.check_status()
+        model.zero_grad(set_to_none=True)
+        ws = (resident._ws if which == 'forward' else resident._ws_bwd)[device]
+        ws[8:12].copy_(torch.tensor([4], dtype=torch.int32).view(torch.uint8).to(device))        # block 3 never publishes
+        loss = modules.CrossEntropyLoss()(model(x), y)
+        loss.backward()
+        torch.cuda.synchronize()
+        if which == 'forward':
+            assert not torch.isfinite(loss).item()
+        with pytest.raises(RuntimeError, match='timed out'):
+            resident.check_status()
+        assert int(ws[8:12].view(torch.int32).item()) == 0      # check_status wiped the workspace (hook included)
+        # recovery: same weights as a fresh model (the failed steps never reached an optimizer), same batch -> same loss and gradients as the reference
+        for m in (model, ref):
+            m.zero_grad(set_to_none=True)
+        for (n1, b1), (_, b2) in zip(model.named_buffers(), ref.named_buffers()):
+            b1.copy_(b2)
+        la, loss_a, _ = _run(model, x, y, True, True)
+        lb, loss_b, _ = _run(ref, x, y, True, True)
+        assert loss_a == loss_b and torch.equal(la, lb)
+        for (name, pa), (_, pb) in zip(model.named_parameters(), ref.named_parameters()):
+            assert torch.equal(pa.grad, pb.grad), name
+    finally:
+        resident.set_enabled(prev)
+        resident.set_backward_enabled(prev_b)
