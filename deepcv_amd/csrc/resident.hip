@@ -206,7 +206,8 @@ __device__ __forceinline__ bool rs_allreduce(rs_u64* ga, rs_u64* gb, unsigned ep
 // Waves 0 - 7 work on the block's first sample, waves 8 - 15 on the second.  Every wave leaves its sums of y and y^2 per output channel in
 // wsum[wave][2][RS_MAXC] (zeros where it had no pixel), except the scalar wide variant (returns false: the caller runs a pass over yt).
 
-template <int K>
+// CI: 4, or 3 (the RGB model input: the fourth lane of the pixel vectors is zero padding, its FMAs — a quarter of the first layer's — are skipped)
+template <int K, int CI = 4>
 __device__ __forceinline__ bool rs_conv_c4_co4(const dcv_resident_op& o, const float4* xin, float* yt, float* wsum) {
     const int H = o.h, W = o.w, pad = K / 2, XW = W + 2 * pad;
     const int per = (H >> 1) * W;                                                    // pixel pairs per sample (<= 512)
@@ -236,11 +237,11 @@ __device__ __forceinline__ bool rs_conv_c4_co4(const dcv_resident_op& o, const f
                     acc[0][c] = fmaf(old[sx].x, wr[sx * 16 + c], acc[0][c]);
                     acc[0][c] = fmaf(old[sx].y, wr[sx * 16 + 4 + c], acc[0][c]);
                     acc[0][c] = fmaf(old[sx].z, wr[sx * 16 + 8 + c], acc[0][c]);
-                    acc[0][c] = fmaf(old[sx].w, wr[sx * 16 + 12 + c], acc[0][c]);
+                    if constexpr (CI > 3) acc[0][c] = fmaf(old[sx].w, wr[sx * 16 + 12 + c], acc[0][c]);
                     acc[1][c] = fmaf(nw[sx].x, wr[sx * 16 + c], acc[1][c]);
                     acc[1][c] = fmaf(nw[sx].y, wr[sx * 16 + 4 + c], acc[1][c]);
                     acc[1][c] = fmaf(nw[sx].z, wr[sx * 16 + 8 + c], acc[1][c]);
-                    acc[1][c] = fmaf(nw[sx].w, wr[sx * 16 + 12 + c], acc[1][c]);
+                    if constexpr (CI > 3) acc[1][c] = fmaf(nw[sx].w, wr[sx * 16 + 12 + c], acc[1][c]);
                 }
             }
 #pragma unroll
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
             // ---- convolution + bias + activation: xin -> yt, per-wave sums of y, y^2 -> s_wsum
             if (!conv_done) {
                 const int var = rs_variant(o.cin, o.cout, o.k, o.w);
-                if (var == 1) sums_done = o.k == 5 ? rs_conv_c4_co4<5>(o, xin, yt, s_wsum) : rs_conv_c4_co4<3>(o, xin, yt, s_wsum);
+                if (var == 1) sums_done = o.k == 5 ? (o.cin == 3 ? rs_conv_c4_co4<5, 3>(o, xin, yt, s_wsum) : rs_conv_c4_co4<5>(o, xin, yt, s_wsum)) : rs_conv_c4_co4<3>(o, xin, yt, s_wsum);
                 else if (var == 2) sums_done = o.k == 3 ? rs_conv_c4_wide<3>(o, xin, yt, s_wsum) : rs_conv_c4_wide<1>(o, xin, yt, s_wsum);
                 else if (var == 4) sums_done = o.k == 3 ? rs_conv_c4_mfma<3>(o, xin, yt, s_wsum) : rs_conv_c4_mfma<1>(o, xin, yt, s_wsum);
                 else { float4 b4[9]; rs_load_bfrag(o.filt, b4); sums_done = rs_conv_c16_mfma(o, xin, yt, b4, s_wsum); }
