@@ -34,7 +34,7 @@ __all__ = ['Ineligible', 'Recorder', 'recorder', 'forbid', 'enabled', 'set_enabl
 _enabled = os.environ.get('DCV_RESIDENT', '1') not in ('0', 'false', 'False', '')
 _bwd_enabled = os.environ.get('DCV_RESIDENT_BWD', '1') not in ('0', 'false', 'False', '')
 _active: Optional['Recorder'] = None
-_verdicts: Dict[int, Tuple['weakref.ref', Dict[tuple, str]]] = {}   # id(module) -> (weak reference, {(input shape, training): reason it is not eligible})
+_verdicts: Dict[int, Tuple['weakref.ref', dict]] = {}   # id(module) -> (weak reference, {(input shape, training): reason it is not eligible; 'modules': foreign leaf or None})
 _ws: Dict[torch.device, torch.Tensor] = {}                          # persistent control words + granules per device (zeroed once)
 _launches = 0
 capture_programs = False      # measurement hook (bench.py, tools): keep the last launched programs, their workspaces and tensors in `last_programs`
@@ -135,7 +135,26 @@ def wanted(module, x) -> bool:
     from . import ops
     if ops._conv_math != nat.MATH_FP32 or not ops._norm_streaming:
         return False
-    return (tuple(x.shape), True) not in _verdict_slot(module)
+    slot = _verdict_slot(module)
+    if 'modules' not in slot:
+        slot['modules'] = _foreign_module(module)
+    if slot['modules'] is not None:
+        return False
+    return (tuple(x.shape), True) not in slot
+
+
+def _foreign_module(module) -> Optional[str]:
+    """ Name of the first leaf sub-module which is not one of the native kinds a resident program is made of, or None.  Such a module (a Dropout, a
+    `torch.nn` normalisation, a user module) computes through its own kernels: a recording would launch it on tensors which are not filled yet — harmless
+    for the data (the forward is then repeated on the per-layer kernels) but not for state it may touch on the way (a random-number generator, running
+    statistics).  Checked once per model, before any recording. """
+    from . import modules as nm
+    from .meta.submodule_creators import ForwardCallbackSubmodule
+    native = (nm.Conv2d, nm.BatchNorm2d, nm.GroupNorm, nm.AvgPool2d, nm.Flatten, nm.Linear, nm._NativeAct, ForwardCallbackSubmodule)
+    for name, m in module.named_modules():
+        if next(m.children(), None) is None and not isinstance(m, native) and type(m) is not torch.nn.Identity:
+            return f'{name} ({type(m).__name__})'
+    return None
 
 
 def mark_ineligible(module, x, reason: str):
@@ -143,7 +162,10 @@ def mark_ineligible(module, x, reason: str):
 
 
 def why_not(module, x) -> Optional[str]:
-    return _verdict_slot(module).get((tuple(x.shape), True))
+    slot = _verdict_slot(module)
+    if slot.get('modules') is not None:
+        return f'sub-module {slot["modules"]} is not part of a resident program'
+    return slot.get((tuple(x.shape), True))
 
 
 def _workspace(device: torch.device) -> torch.Tensor:

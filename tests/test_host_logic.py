@@ -215,3 +215,20 @@ def test_modules_without_hip_kernels_say_so_once(caplog):
     assert [type(m).__name__ for m in mods] == ['LayerNorm', 'InstanceNorm2d']
     msgs = [r.getMessage() for r in caplog.records if 'no hand-written HIP kernel' in r.getMessage()]
     assert len(msgs) == 3 and any('LayerNorm' in m for m in msgs) and any('InstanceNorm2d' in m for m in msgs) and any('Conv1d' in m for m in msgs)
+
+
+def test_resident_recording_is_refused_for_models_with_foreign_leaf_modules(params):
+    """ `deepcv_amd.resident` records a forward only for models made of the native module kinds a resident program consists of: a Dropout (or any other
+    module computing through its own kernels) would run on not-yet-filled tensors during a recording and advance its random-number generator on the way. """
+    import copy
+    from deepcv_amd import resident
+    from deepcv_amd.classification.image import create_model
+    from deepcv_amd.meta.data.datasets import SyntheticImageDataset
+    ds = {'trainset': SyntheticImageDataset(8)}
+    assert resident._foreign_module(create_model(ds, params['image_classifier_model'])) is None
+    assert resident._foreign_module(create_model(ds, params['image_classifier_bn_only_model'])) is None
+    with_dropout = copy.deepcopy(dict(params['image_classifier_model']))
+    with_dropout['dropout_prob'] = 0.3
+    assert 'Dropout' in resident._foreign_module(create_model(ds, with_dropout))
+    wide = create_model({'trainset': SyntheticImageDataset(8, image_shape=(3, 224, 224), num_classes=1000)}, params['resnet18_style_model'])
+    assert 'MaxPool2d' in resident._foreign_module(wide)
