@@ -164,6 +164,8 @@ class GraphedTrainStep:
 
     def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, losses, weights, reducer=None, graph_collective: Optional[bool] = None):
         self.model, self.optimizer, self.losses, self.weights, self.reducer = model, optimizer, losses, weights, reducer
+        if reducer is not None:
+            reducer.isolate = True        # until the capture is done no collective may be recorded on the stream which captures (deepcv_amd/parallel.py)
         import os
         # capture the RCCL all-reduce INSIDE the step graph (one graph per step, no eager gap): off by default until validated on a multi-GPU node
         self.graph_collective = (os.environ.get('DCV_GRAPH_COLLECTIVE') == '1') if graph_collective is None else bool(graph_collective)
@@ -308,9 +310,9 @@ class GraphedTrainStep:
         _ops.register_unit_gradient(self._seed)                    # loss ops may return the gradient their forward launch already computed
         torch.cuda.synchronize(dev)
         self.graph_fb = torch.cuda.CUDAGraph()
-        # with a process group alive its watchdog thread queries events while this thread captures: under the default 'global' capture mode such a call from
-        # another thread invalidates the capture (observed once as an abort of the rank process in the data-parallel rehearsal); 'thread_local' confines the
-        # check to the capturing thread
+        # with a process group alive its watchdog thread queries events while this thread captures: 'thread_local' confines the capture's legality checks to
+        # the capturing thread.  (The abort seen in the data-parallel rehearsal had another cause: the watchdog polling the end event of an eager step's
+        # collective recorded on THIS stream just before the capture began -> `reducer.isolate`, deepcv_amd/parallel.py.)
         capture_mode = 'thread_local' if (self.reducer is not None or (torch.distributed.is_available() and torch.distributed.is_initialized())) else 'global'
         with torch.cuda.graph(self.graph_fb, stream=self.stream, capture_error_mode=capture_mode):
             self._nat.check(self._nat.lib.dcv_indirect_copy(self.mailbox.data_ptr(), self._nat.current_stream(dev)), 'dcv_indirect_copy')
@@ -340,6 +342,8 @@ class GraphedTrainStep:
             with torch.cuda.graph(self.graph_opt, stream=self.stream, capture_error_mode=capture_mode):
                 self.optimizer.step()
         torch.cuda.synchronize(dev)
+        if self.reducer is not None:
+            self.reducer.isolate = False                                     # nothing captures on the callers' streams from here on
 
     def _replay(self, x, y):
         self._mailbox_write(x, y)

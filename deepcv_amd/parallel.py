@@ -66,6 +66,11 @@ class GradientAllReducer:
         self.enabled = True
         self.overlap = overlap
         self.force_collective = False     # rehearsal switch: run the collective even in a group of one
+        # True: collectives never go to the caller's stream, always to `comm_stream`.  The process group's watchdog thread polls the end event of every
+        # collective until it has seen it complete (up to ~100 ms after the fact), and HIP refuses an event query whose stream has meanwhile begun a graph
+        # capture (hipErrorCapturedEvent -> the watchdog throws, the rank aborts).  `GraphedTrainStep` sets this for the eager steps which run on its
+        # capture stream before the capture.
+        self.isolate = False
         self._in_backward = False
         cap = max(1, int(bucket_cap_mb * 1024 * 1024 / 4))
         self.buckets: List[_Bucket] = []
@@ -122,8 +127,9 @@ class GradientAllReducer:
     def _launch(self, b: _Bucket):
         self._pack(b)
         if self.world_size > 1 or self.force_collective:
-            if self.comm_stream is not None and self._in_backward:
+            if self.comm_stream is not None and (self._in_backward or (self.isolate and not torch.cuda.is_current_stream_capturing())):
                 # launched from an autograd hook: the collective goes to the communication stream so that it overlaps the rest of the backward pass
+                # (or `isolate`: the caller's stream is about to capture a graph, see __init__)
                 self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))   # bucket must be packed before the collective reads it
                 with torch.cuda.stream(self.comm_stream):
                     self._all_reduce_mean(b)
