@@ -106,7 +106,8 @@ class ResidentBwdHead(ctypes.Structure):
     """ `dcv_resident_bwd_head` """
     _fields_ = [('enabled', _c_int), ('classes', _c_int), ('act', _c_int), ('slope', _c_float), ('h', _c_int), ('w', _c_int), ('cc', _c_int), ('cr', _c_int),
                 ('ref_h', _c_int), ('ref_w', _c_int), ('align_corners', _c_int), ('reserved', _c_int),
-                ('dlogits', _c_void_p), ('logits', _c_void_p), ('wp', _c_void_p), ('dref', _c_void_p)]
+                ('dlogits', _c_void_p), ('logits', _c_void_p), ('wp', _c_void_p), ('dref', _c_void_p),
+                ('fc_x', _c_void_p), ('fc_dw', _c_void_p), ('fc_db', _c_void_p)]
 
 
 class ResidentBwdProgram(ctypes.Structure):
@@ -221,6 +222,7 @@ _SIGNATURES = {
     'dcv_resident_forward': (_c_int, [ctypes.POINTER(ResidentProgram), _P, _c_size_t, _P]),
     'dcv_resident_status': (_c_int, [_P, _P, ctypes.POINTER(_c_int)]),
     'dcv_resident_bwd_supported': (_c_int, [ctypes.POINTER(ResidentBwdProgram)]),
+    'dcv_resident_head_wgrad_supported': (_c_int, [_c_int, _c_int, _c_int]),
     'dcv_resident_backward': (_c_int, [ctypes.POINTER(ResidentBwdProgram), _P, _c_size_t, _P]),
 }
 

@@ -905,6 +905,75 @@ __device__ __forceinline__ void rb_wgrad(const dcv_resident_bwd_op& o, const flo
 
 __device__ __forceinline__ float rb_act_grad(float y, int act, float slope) { return dcv_act_grad_from_out(y, act, slope); }
 
+// ---- weight / bias gradient of the fully connected head inside the backward launch.  Its operands exist before the launch (the head's saved input x
+// [n][K] in NHWC order, dlogits, the logits), so no grid synchronisation is involved: the first K / 8 blocks each take a GROUP of 8 consecutive input
+// positions (one 32-B sector of every sample's row) and compute their gradient rows for ALL samples, final values straight into dw (the reference's
+// [O][C * H * W] order) — no partial slabs.  The operands are requested at the very start of the launch and parked in the dz tile's LDS region (free
+// until the first layer's dz): dz of all samples [N][O] (coalesced loads) and one float4 of x per thread = (sample, half of the group).  The arithmetic
+// runs while the partials of the first all-reduce travel (that wait has no earlier layer's weight gradient to hide behind): products summed over the 64
+// lanes (rs_reduce8), then over the eight waves of the half through LDS in a fixed order.  Groups are dealt so that the blocks of one XCD (block % 8)
+// read one contiguous eighth of every row: each L2 fetches its part of x once.
+constexpr int RB_FC_MAXO = 12, RB_FC_DZ_SLOTS = (512 * RB_FC_MAXO) / RS_T;          // classes; dz values staged per thread
+static_assert(512 * RB_FC_MAXO * 4 + RS_T * 16 <= RS_SPB * RS_XIN * 16, "the staged operands of the head's weight gradient must fit the dz tile region");
+__host__ __device__ __forceinline__ bool rb_fc_wgrad_ok(int n, int k, int classes) {
+    const int g = (n + RS_SPB - 1) / RS_SPB;
+    return n > 0 && n <= 512 && k > 0 && (k & 7) == 0 && classes > 0 && classes <= RB_FC_MAXO && (k >> 3) <= g;
+}
+// the block's group of input positions, or -1
+__device__ __forceinline__ int rb_fc_group(int K) {
+    const int G = (int)gridDim.x, GA = K >> 3, per = (GA + 7) >> 3;
+    int pg = (int)blockIdx.x;
+    if ((G & 7) == 0 && per * 8 <= G) { const int xcd = pg & 7, i = pg >> 3; pg = i < per ? xcd * per + i : GA; }
+    return pg < GA ? pg : -1;
+}
+struct rb_fc_args { float* fc_dw; float* fc_db; int classes, cw, hwo, n, pg; };
+// (not inlined, arguments by value: inlined, its registers pushed the allocation of the kernel's hot loops into spills — 0.2551 -> 0.2698 ms per step)
+__device__ __attribute__((noinline)) void rb_fc_wgrad(const rb_fc_args hd, const float* staged, float* scratch) {
+    const int O = hd.classes, Cw = hd.cw, HWo = hd.hwo, K = HWo * Cw, N = hd.n, pg = hd.pg;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n = t & 511, half = t >> 9;
+    const float4 x4 = reinterpret_cast<const float4*>(staged + 512 * RB_FC_MAXO)[t];
+    float dz[RB_FC_MAXO];
+#pragma unroll
+    for (int j = 0; j < RB_FC_MAXO; ++j) dz[j] = (n < N && j < O) ? staged[n * O + j] : 0.f;
+    const int vi = (lane & 1) * 4 + ((lane >> 1) & 1) * 2;
+    float r2[2];
+#pragma unroll
+    for (int c = 0; c < RB_FC_MAXO / 2; ++c) {                                       // call c: classes 2c, 2c + 1 x the half's four positions
+        if (2 * c < O) {
+            const float v[8] = {x4.x * dz[2 * c], x4.y * dz[2 * c], x4.z * dz[2 * c], x4.w * dz[2 * c],
+                                x4.x * dz[2 * c + 1], x4.y * dz[2 * c + 1], x4.z * dz[2 * c + 1], x4.w * dz[2 * c + 1]};
+            rs_reduce8(v, r2);
+            if (lane < 4) { scratch[(wave * 8 + c) * 8 + vi] = r2[0]; scratch[(wave * 8 + c) * 8 + vi + 1] = r2[1]; }
+        }
+    }
+    if (pg == 0 && half == 0 && hd.fc_db != nullptr) {                               // the bias gradient: sums of dz over the samples (waves 0 - 7 of group 0)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = 8 * c + i < RB_FC_MAXO ? dz[8 * c + i < RB_FC_MAXO ? 8 * c + i : 0] : 0.f;
+            rs_reduce8(v, r2);
+            if (lane < 4) { scratch[(16 * 8 + wave * 2 + c) * 8 + vi] = r2[0]; scratch[(16 * 8 + wave * 2 + c) * 8 + vi + 1] = r2[1]; }
+        }
+    }
+    rs_barrier();
+    if (t < 128) {
+        const int pos = t >> 4, j = t & 15, hf = pos >> 2, q = pos & 3;
+        if (j < O) {
+            const float* sc = scratch + ((hf * 8) * 8 + (j >> 1)) * 8 + (j & 1) * 4 + q;
+            const float v = ((sc[0] + sc[64]) + (sc[128] + sc[192])) + ((sc[256] + sc[320]) + (sc[384] + sc[448]));      // the half's eight waves, 8 * 8 floats apart
+            const int m = pg * 8 + pos, px = m / Cw, ch = m - px * Cw;
+            hd.fc_dw[(size_t)j * K + (size_t)ch * HWo + px] = v;
+        }
+    } else if (t < 144 && pg == 0 && hd.fc_db != nullptr) {
+        const int j = t - 128;
+        if (j < O) {
+            const float* sc = scratch + (16 * 8 + (j >> 3)) * 8 + (j & 7);
+            hd.fc_db[j] = ((sc[0] + sc[16]) + (sc[32] + sc[48])) + ((sc[64] + sc[80]) + (sc[96] + sc[112]));          // waves 0 - 7, 2 * 8 floats apart
+        }
+    }
+}
+
 __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_program p, unsigned* ctl, rs_u64* gran) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* dzt = reinterpret_cast<float4*>(smem);
@@ -944,6 +1013,16 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
             for (int k = 0; k < 8; ++k) { const int i = i0 + tt + k * 512; if (i < v4) d[i] = n < N ? v[k] : make_float4(0.f, 0.f, 0.f, 0.f); }
         }
     };
+    // the head's weight gradient: its operands are requested first and parked in LDS at the end of this prologue (rb_fc_wgrad)
+    const int fc_pg = (p.head.enabled && p.head.fc_dw != nullptr) ? rb_fc_group(p.head.h * p.head.w * (p.head.cc + p.head.cr)) : -1;
+    float4 fc_x4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float fc_g[RB_FC_DZ_SLOTS], fc_l[RB_FC_DZ_SLOTS];
+    if (fc_pg >= 0) {
+        const int K = p.head.h * p.head.w * (p.head.cc + p.head.cr), total = N * p.head.classes;
+        if (tt < N) fc_x4 = *reinterpret_cast<const float4*>(p.head.fc_x + (size_t)tt * K + fc_pg * 8 + s_of_t * 4);
+#pragma unroll
+        for (int k = 0; k < RB_FC_DZ_SLOTS; ++k) { const int i = t + k * RS_T; fc_g[k] = p.head.dlogits[i < total ? i : 0]; fc_l[k] = p.head.logits ? p.head.logits[i < total ? i : 0] : 0.f; }
+    }
     {   // per-channel parameters of every layer -> LDS; y and dout of the first op (the last layer) -> LDS
         float pv = 0.f; int pslot = -1;
         if (t < p.count * 5 * RS_MAXC) {
@@ -961,6 +1040,16 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         load_flat(o.y, yreg, o.h * o.w * o.cout);
         if (!p.head.enabled) load_flat(o.dout, dor, (o.h / pk) * (o.w / pk) * o.cout);
         if (pslot >= 0) (&s_par[0][0][0])[pslot] = pv;
+    }
+    if (fc_pg >= 0) {
+        float* staged = reinterpret_cast<float*>(dzt);
+        const int total = N * p.head.classes;
+        reinterpret_cast<float4*>(staged + 512 * RB_FC_MAXO)[t] = fc_x4;
+#pragma unroll
+        for (int k = 0; k < RB_FC_DZ_SLOTS; ++k) {
+            const int i = t + k * RS_T;
+            if (i < total) staged[i] = p.head.logits ? fc_g[k] * dcv_act_grad_from_out(fc_l[k], p.head.act, p.head.slope) : fc_g[k];
+        }
     }
     if (p.head.enabled) {
         // ---- head of the backward pass: dl = dlogits act'(logits); dwide = dl W; the current tensor's channels -> op 0's dout (LDS), the referenced tensor's
@@ -1117,6 +1206,10 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         rs_allreduce_publish(go, epoch, 2 * C, mine, mute);
         rs_allreduce_reduce_owned(go, go + RS_MAXQ * RS_MAXG, epoch, 2 * C, G, s_red, &s_fail);   // the few owner blocks: before their own weight gradient, so that nobody waits for it
         if (oi > 0 && p.op[oi - 1].dw_part != nullptr) rb_wgrad(p.op[oi - 1], xtt, dzt);
+        else if (oi == 0 && fc_pg >= 0) {
+            const rb_fc_args fa = {p.head.fc_dw, p.head.fc_db, p.head.classes, p.head.cc + p.head.cr, p.head.h * p.head.w, N, fc_pg};
+            rb_fc_wgrad(fa, reinterpret_cast<const float*>(dzt), reinterpret_cast<float*>(xtt));      // (operands parked in the dz tile's region, the x tile is not in use yet)
+        }
         rs_barrier();
         stamp();
         // the next op's y is requested now (two float4 per thread: a sample holds at most RS_Y floats) and lands in LDS after the dz step, when this
@@ -1260,6 +1353,7 @@ inline bool rb_program_ok(const dcv_resident_bwd_program* p) {
         if (hd.classes <= 0 || hd.classes > 16 || hd.cc != o.cout || hd.h != o.h / pk || hd.w != o.w / pk || hd.cr <= 0 || hd.ref_h <= 0 || hd.ref_w <= 0) return false;
         if (hd.h * hd.w * hd.cr > RS_Y || hd.ref_h * hd.ref_w * hd.cr > 16 * RS_Y || !hd.dlogits || !hd.wp || !hd.dref || hd.act < DCV_ACT_NONE || hd.act > DCV_ACT_TANH) return false;
         if (hd.act != DCV_ACT_NONE && !hd.logits) return false;
+        if (hd.fc_dw && (!hd.fc_x || !rb_fc_wgrad_ok(p->n, hd.h * hd.w * (hd.cc + hd.cr), hd.classes))) return false;
     } else if (!p->op[0].dout) return false;
     for (int i = 0; i < p->count; ++i) {
         const dcv_resident_bwd_op& o = p->op[i];
@@ -1357,6 +1451,8 @@ int dcv_resident_forward(const dcv_resident_program* p, void* ws, size_t ws_byte
 }
 
 int dcv_resident_bwd_supported(const dcv_resident_bwd_program* p) { return rb_program_ok(p) ? 1 : 0; }
+
+int dcv_resident_head_wgrad_supported(int n, int k, int classes) { return rb_fc_wgrad_ok(n, k, classes) ? 1 : 0; }
 
 int dcv_resident_backward(const dcv_resident_bwd_program* p, void* ws, size_t ws_bytes, void* stream) {
     DCV_CHECK_ARG(p && ws);

@@ -1207,8 +1207,11 @@ class _LinearNhwcFn(torch.autograd.Function):
             dx_arg = None        # the head's data gradient and the link's split are the first thing the persistent backward launch does; dx is never written
         dw = _grad_buffer(ctx.weight_ref, like=weight) if need_w else None
         db = _grad_buffer(ctx.bias_ref, n=o, device=dev) if (need_w and ctx.has_bias) else None
+        deferred = need_w and slabs.may_defer(ctx.weight_ref, ctx.bias_ref)
+        if deferred and dx_arg is None and ctx.needs_input_grad[1] and plan.head_wgrad(x, dw, db, n, k, o):
+            return dx, dw, db, None, None    # the launch also computes the final dw / db (buffers passed by address: the engine must stay their sole owner)
         ws = _ws(lib.dcv_linear_bwd_workspace_bytes(n, k, o), dev)
-        if need_w and slabs.may_defer(ctx.weight_ref, ctx.bias_ref):
+        if deferred:
             segs, ns = (nat.SlabSegment * 2)(), ctypes.c_int(0)
             nat.check(lib.dcv_linear_bwd_deferred(dy.data_ptr(), nat.ptr(y), ctx.act, ctx.slope, x.data_ptr(), wp.data_ptr(), nat.ptr(dx_arg), nat.ptr(dw), nat.ptr(db),
                                                   n, k, o, ws.data_ptr(), ws.numel(), segs, ctypes.byref(ns), st), 'dcv_linear_bwd_deferred')

@@ -107,6 +107,7 @@ def reads_oihw(d: nat.Conv2dDesc) -> bool:
 
 _wgrad_in_launch = os.environ.get('DCV_RESIDENT_WGRAD', '1') not in ('0', 'false', 'False', '')
 _head_in_launch = os.environ.get('DCV_RESIDENT_HEAD', '1') not in ('0', 'false', 'False', '')
+_head_wgrad_in_launch = os.environ.get('DCV_RESIDENT_HEAD_WGRAD', '1') not in ('0', 'false', 'False', '')
 
 
 def wgrad_in_launch(d: nat.Conv2dDesc) -> bool:
@@ -419,6 +420,17 @@ class BackwardPlan:
         self.ops, self.keep, self.head, self.head_dx = [], [dlogits, logits, wp], head, dwide
         return True
 
+    def head_wgrad(self, x: torch.Tensor, dw: torch.Tensor, db: Optional[torch.Tensor], n: int, k: int, classes: int) -> bool:
+        """ The head's weight / bias gradient inside the launch (`rb_fc_wgrad`, resident.hip): the blocks split the input positions among themselves and
+        each computes its rows for all samples, which takes batches of at least k / 4 samples.  `DCV_RESIDENT_WGRAD=0`: stays with its own launch. """
+        if self.state != 'fused' or self.head is None or not (_wgrad_in_launch and _head_wgrad_in_launch) or not lib.dcv_resident_head_wgrad_supported(n, k, classes):
+            return False
+        if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last) and dw.is_contiguous()):
+            return False
+        self.head.fc_x, self.head.fc_dw, self.head.fc_db = x.data_ptr(), dw.data_ptr(), (db.data_ptr() if db is not None else None)
+        self.keep.append(x)
+        return True
+
     def split_link(self, dwide: torch.Tensor, dcur: torch.Tensor, dref: torch.Tensor) -> bool:
         """ The link's backward node in a recorded pass with a head: `dcur` (what the last layer's node will receive as dout; it stays in LDS) and `dref`
         (HBM, written by the launch, added to the data gradient of the layer which consumed the referenced tensor). """
@@ -497,6 +509,9 @@ def algorithmic_bytes(kind: str, prog) -> int:
                 total += n * o.h * o.w * o.cin + 2 * ((n + 1) // 2) * (o.k * o.k * o.cin * o.cout + o.cout)
             if i == 0:
                 total += n * (o.h // pk) * (o.w // pk) * o.cout
+                if prog.head.enabled and prog.head.fc_dw:      # the head's weight gradient: its input, the result, dlogits + logits
+                    kf = prog.head.h * prog.head.w * (prog.head.cc + prog.head.cr)
+                    total += n * kf + prog.head.classes * (kf + 1) + 2 * n * prog.head.classes
             if o.addend:
                 total += n * o.h * o.w * o.cin
             if o.dx:

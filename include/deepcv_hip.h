@@ -599,14 +599,19 @@ typedef struct dcv_resident_bwd_op {
  * of the Linear (dwide = (dlogits * act'(logits)) W, W = the [O][H*W*C] weight of dcv_conv2d_prepare_filters op 2) and the link's split: the current tensor's
  * channels become op 0's dout (in LDS), the referenced tensor's channels go back through the bilinear resize (gather form) to `dref` in HBM, which the caller
  * names as `addend` of the op whose input the link referenced.  replaces the autograd nodes of submodule_creators.py:268-269 (Linear) and :272-332 (dense link).
- * The weight / bias gradient of the Linear stays with dcv_linear_bwd_deferred (dx = NULL). */
+ * The weight / bias gradient of the Linear: with fc_dw set (fc_x = the head's input [n][h][w][cc + cr], fc_dw [classes][(cc + cr) * h * w] in the reference's
+ * C-major feature order, fc_db [classes] nullable) every block computes the final gradient rows of its share of the input positions for all samples while
+ * the first all-reduce travels (no partial slabs; dcv_resident_head_wgrad_supported(n, k, classes): 8 positions per block, i.e. n >= k / 4, k % 8 == 0, classes <= 12);
+ * with fc_dw NULL it stays with dcv_linear_bwd_deferred (dx = NULL). */
 typedef struct dcv_resident_bwd_head {
     int enabled, classes, act; float slope;
     int h, w, cc, cr, ref_h, ref_w, align_corners, reserved;   /* wide tensor [n][h][w][cc + cr]; referenced tensor [n][ref_h][ref_w][cr] */
     const float* dlogits; const float* logits; const float* wp; float* dref;
+    const float* fc_x; float* fc_dw; float* fc_db;
 } dcv_resident_bwd_head;
 typedef struct dcv_resident_bwd_program { int n; int count; dcv_resident_bwd_op op[DCV_RESIDENT_BWD_MAX_OPS]; dcv_resident_bwd_head head; } dcv_resident_bwd_program;
 int dcv_resident_bwd_supported(const dcv_resident_bwd_program* p);
+int dcv_resident_head_wgrad_supported(int n, int k, int classes);
 int dcv_resident_backward(const dcv_resident_bwd_program* p, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus

@@ -126,6 +126,21 @@ def test_resident_program_validation_on_the_host():
     p = bwd(); p.op[0].dout = None
     assert lib.dcv_resident_bwd_supported(p) == 0
 
+    def with_head(n, fc):
+        p = bwd(n); p.op[0].dout = None
+        hd = p.head
+        hd.enabled, hd.classes, hd.act, hd.h, hd.w, hd.cc, hd.cr, hd.ref_h, hd.ref_w = 1, 10, nat.ACT_SIGMOID, 8, 8, 16, 4, 32, 32
+        hd.dlogits = hd.logits = hd.wp = hd.dref = 64
+        if fc:
+            hd.fc_x = hd.fc_dw = hd.fc_db = 64
+        return p
+    assert lib.dcv_resident_bwd_supported(with_head(512, False)) == 1 and lib.dcv_resident_bwd_supported(with_head(512, True)) == 1
+    # the head's weight gradient inside the launch: one block per 8 input positions (k = 1280 -> 160 blocks = 320 samples), at most 12 classes
+    assert lib.dcv_resident_bwd_supported(with_head(64, False)) == 1 and lib.dcv_resident_bwd_supported(with_head(64, True)) == 0
+    assert lib.dcv_resident_head_wgrad_supported(512, 1280, 10) == 1 and lib.dcv_resident_head_wgrad_supported(320, 1280, 10) == 1
+    assert lib.dcv_resident_head_wgrad_supported(318, 1280, 10) == 0 and lib.dcv_resident_head_wgrad_supported(512, 1284, 10) == 0
+    assert lib.dcv_resident_head_wgrad_supported(512, 1280, 13) == 0
+
 
 def _native_lib():
     from deepcv_amd import _native

@@ -44,7 +44,15 @@ def test_resident_forward_matches_per_layer_kernels(device, params, bs, backward
     g = torch.Generator().manual_seed(DATA_SEED)
     x, y = torch.randn(bs, 3, 32, 32, generator=g).to(device), torch.randint(0, 10, (bs,), generator=g).to(device)
     a, b = _model(params, 'image_classifier_model', device), _model(params, 'image_classifier_model', device)
-    la, loss_a, n_a = _run(a, x, y, True, backward_on)
+    prev_cap, resident.capture_programs = resident.capture_programs, True
+    try:
+        la, loss_a, n_a = _run(a, x, y, True, backward_on)
+    finally:
+        resident.capture_programs = prev_cap
+    if backward_on:
+        # the head's weight gradient is part of the launch from 320 samples on (one block per 8 of its 1280 input positions), its own launch below
+        head = resident.last_programs['backward'][0].head
+        assert head.enabled == 1 and bool(head.fc_dw) == (bs >= 320)
     lb, loss_b, n_b = _run(b, x, y, False)
     assert n_a == 1, f'the resident path did not run: {resident.why_not(a, x)}'
     assert n_b == 0

@@ -39,7 +39,7 @@ for l in range(5):
 fwd += ['link', 'fc']
 bwd = ['load y, dout']
 for l in range(5, 0, -1):
-    bwd += [f'L{l} moments', f'L{l} algebra + publish', f'L{l} weight gradient of L{l + 1}' if l < 5 else 'L5 (no pending weight gradient)', f'L{l} all-reduce',
+    bwd += [f'L{l} moments', f'L{l} algebra + publish', f'L{l} weight gradient of L{l + 1}' if l < 5 else 'L5 weight gradient of the head', f'L{l} all-reduce',
             f'L{l} coefficients, zero tiles', f'L{l} dz + x tile', f'L{l} next y + data gradient']
 bwd += ['L1 weight gradient']
 for tag, names in (('forward', fwd), ('backward', bwd)):
