@@ -212,6 +212,7 @@ _SIGNATURES = {
     'dcv_cross_entropy_workspace_bytes': (_c_size_t, [_c_int]),
     'dcv_cross_entropy_fwd': (_c_int, [_P, _P, _P, _P, _P, _c_int, _c_int, _P, _c_size_t, _P]),
     'dcv_cross_entropy_fwd_grad': (_c_int, [_P, _P, _P, _P, _P, _P, ctypes.POINTER(_c_int), _c_int, _c_int, _P, _c_size_t, _P]),
+    'dcv_cross_entropy_fwd_grad_publish': (_c_int, [_P, _P, _P, _P, _P, _P, ctypes.POINTER(_c_int), _c_int, _c_int, _P, _c_size_t, _P, _P, _P, _c_int, ctypes.POINTER(_c_int), _P]),
     'dcv_cross_entropy_bwd': (_c_int, [_P, _P, _P, _P, _P, _c_int, _c_int, _P]),
     'dcv_optim_prepare': (_c_int, [_P, _P, _P]),
     'dcv_adamw_step': (_c_int, [ctypes.POINTER(TensorList), _P, _c_int, _P]),

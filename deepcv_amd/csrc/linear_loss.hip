@@ -241,8 +241,9 @@ __global__ __launch_bounds__(256) void linear_fwd_row_kernel(const float* __rest
 
 // Small batches of few classes (N <= 1024, C <= 16: the stock classifier's 512 x 10 logits): the whole loss in ONE launch of one block, a thread per
 // sample (its logits in registers: one global round trip), fixed-order block sum in fp64.
+struct CePublish { const dcv_copy_jobs* mailbox; float* host_vals; int* host_seq; int slots; };
 __global__ __launch_bounds__(1024) void ce_fwd_single_kernel(const float* __restrict__ z, const int64_t* __restrict__ target, float* __restrict__ lse_out,
-                                                              float* __restrict__ loss, int32_t* __restrict__ correct, float* __restrict__ dz_unit, int N, int C) {
+                                                              float* __restrict__ loss, int32_t* __restrict__ correct, float* __restrict__ dz_unit, int N, int C, CePublish pub) {
     constexpr int CMAX = 16;
     __shared__ double wl[16];
     __shared__ int wc[16];
@@ -276,8 +277,15 @@ __global__ __launch_bounds__(1024) void ce_fwd_single_kernel(const float* __rest
     if (threadIdx.x == 0) {
         double s = 0.0; int k = 0;
         for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { s += wl[i]; k += wc[i]; }
-        loss[0] = (float)(s / (double)N);
+        const float value = (float)(s / (double)N);
+        loss[0] = value;
         if (correct) correct[0] = k;
+        if (pub.host_seq != nullptr) {                                   // early read-back of a replayed step (dcv_publish_scalars without its launch)
+            for (int i = 0; i < pub.slots; ++i) pub.host_vals[i] = value;
+            __threadfence_system();                                      // the values are in host memory before the sequence number is
+            *reinterpret_cast<volatile int*>(pub.host_seq) = pub.mailbox->seq;
+            __threadfence_system();
+        }
     }
 }
 
@@ -411,15 +419,25 @@ int dcv_cross_entropy_fwd(const float* logits, const int64_t* target, float* los
 
 int dcv_cross_entropy_fwd_grad(const float* logits, const int64_t* target, float* loss, float* lse, int32_t* correct, float* dlogits_unit, int* produced,
                                int n, int classes, void* ws, size_t ws_bytes, void* stream) {
+    return dcv_cross_entropy_fwd_grad_publish(logits, target, loss, lse, correct, dlogits_unit, produced, n, classes, ws, ws_bytes, nullptr, nullptr, nullptr, 0, nullptr, stream);
+}
+
+int dcv_cross_entropy_fwd_grad_publish(const float* logits, const int64_t* target, float* loss, float* lse, int32_t* correct, float* dlogits_unit, int* produced,
+                                       int n, int classes, void* ws, size_t ws_bytes, const dcv_copy_jobs* mailbox, float* host_vals, int* host_seq, int slots,
+                                       int* published, void* stream) {
     DCV_CHECK_ARG(logits && target && loss && lse && n > 0 && classes > 0 && (dlogits_unit == nullptr || produced != nullptr));
+    DCV_CHECK_ARG(host_seq == nullptr || (mailbox && host_vals && published && slots > 0 && slots <= DCV_MAX_COPY_JOBS));
     if (produced) *produced = 0;
+    if (published) *published = 0;
     if (!ws || ws_bytes < dcv_cross_entropy_workspace_bytes(n)) return DCV_ERR_WORKSPACE;
     hipStream_t st = dcv_stream(stream);
     double* part_loss = reinterpret_cast<double*>(ws);
     int* part_correct = reinterpret_cast<int*>(part_loss + CE_MAX_BLOCKS);
     if (n <= 1024 && classes <= 16) {
-        hipLaunchKernelGGL(ce_fwd_single_kernel, dim3(1), dim3((unsigned)dcv_align_up(n, 64)), 0, st, logits, target, lse, loss, correct, dlogits_unit, n, classes);
+        const CePublish pub{mailbox, host_vals, host_seq, slots};
+        hipLaunchKernelGGL(ce_fwd_single_kernel, dim3(1), dim3((unsigned)dcv_align_up(n, 64)), 0, st, logits, target, lse, loss, correct, dlogits_unit, n, classes, pub);
         if (produced && dlogits_unit) *produced = 1;
+        if (published && host_seq) *published = 1;
         DCV_RETURN_LAUNCH();
     }
     unsigned nb = (unsigned)dcv_ceil_div(n, CE_THREADS / 64);

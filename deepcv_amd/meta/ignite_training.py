@@ -317,9 +317,21 @@ class GraphedTrainStep:
         with torch.cuda.graph(self.graph_fb, stream=self.stream, capture_error_mode=capture_mode):
             self._nat.check(self._nat.lib.dcv_indirect_copy(self.mailbox.data_ptr(), self._nat.current_stream(dev)), 'dcv_indirect_copy')
             self.static_pred = self.model(self.static_x)
-            self.static_losses = _batch_losses(self.losses, self.weights, self.static_pred, self.static_y)
+            # a single cross-entropy term publishes its value from its own launch (both names of `_batch_losses` are that one tensor): no publish launch
+            fold = len(self.losses) == 1 and isinstance(next(iter(self.losses.values())), native.CrossEntropyLoss)
+            if fold:
+                _ops.set_loss_publisher((self.mailbox.data_ptr(), self.mailbox.data_ptr() + self._PUB_VALS, self.mailbox.data_ptr() + self._PUB_SEQ, 2))
+            try:
+                self.static_losses = _batch_losses(self.losses, self.weights, self.static_pred, self.static_y)
+                published = _ops.last_published() if fold else None
+            finally:
+                _ops.set_loss_publisher(None)
             terms = [v.reshape(1) if v.dim() == 0 else v for v in self.static_losses.values()]
-            if 0 < len(terms) <= self._nat.MAX_COPY_JOBS and all(t.numel() == 1 and t.dtype == torch.float32 for t in terms):
+            if published is not None:
+                if len(terms) > 2 or any(t.data_ptr() != published.data_ptr() for t in terms):      # (one name or two for the one tensor: both slots carry it)
+                    raise RuntimeError('deepcv_amd: the loss published by the cross-entropy launch is not the loss of the captured step')
+                self._publishes = True
+            elif 0 < len(terms) <= self._nat.MAX_COPY_JOBS and all(t.numel() == 1 and t.dtype == torch.float32 for t in terms):
                 import ctypes
                 ptrs = (ctypes.c_void_p * len(terms))(*[t.data_ptr() for t in terms])
                 self._nat.check(self._nat.lib.dcv_publish_scalars(self.mailbox.data_ptr(), ptrs, len(terms), self.mailbox.data_ptr() + self._PUB_VALS,

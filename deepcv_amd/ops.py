@@ -1259,6 +1259,22 @@ def _is_unit_gradient(t: torch.Tensor) -> bool:
     return any(r() is not None and r() is t for r in _unit_seeds)
 
 
+_loss_publisher: Optional[tuple] = None       # (mailbox address, host values address, host sequence-number address, slots) while a training step captures its loss
+_last_published: Optional['weakref.ref'] = None
+
+
+def set_loss_publisher(spec: Optional[tuple]):
+    """ `spec = (mailbox, host_vals, host_seq, slots)` (addresses of `GraphedTrainStep`'s pinned mailbox): the next cross-entropy launches also publish their loss
+    value for the host's early read-back, like `dcv_publish_scalars` would in a launch of its own; `None` switches it off.  `last_published()` returns the loss
+    tensor which was published since (or None: the launch in question cannot publish, e.g. more than 1024 samples). """
+    global _loss_publisher, _last_published
+    _loss_publisher, _last_published = spec, None
+
+
+def last_published() -> Optional[torch.Tensor]:
+    return _last_published() if _last_published is not None else None
+
+
 class _CrossEntropyFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target, correct_out):
@@ -1274,9 +1290,14 @@ class _CrossEntropyFn(torch.autograd.Function):
         ws = _ws(lib.dcv_cross_entropy_workspace_bytes(n), dev)
         # when a unit root gradient is registered (hipGraph training step) the forward launch also leaves d loss / d logits for an upstream gradient of 1
         dz_unit = torch.empty_like(logits) if (_unit_seeds and ctx.needs_input_grad[0]) else None
-        produced = ctypes.c_int(0)
-        nat.check(lib.dcv_cross_entropy_fwd_grad(logits.data_ptr(), target.data_ptr(), loss.data_ptr(), lse.data_ptr(), nat.ptr(correct_out), nat.ptr(dz_unit),
-                                                 ctypes.byref(produced), n, c, ws.data_ptr(), ws.numel(), nat.current_stream(dev)), 'dcv_cross_entropy_fwd_grad')
+        produced, published = ctypes.c_int(0), ctypes.c_int(0)
+        pub = _loss_publisher if _loss_publisher is not None else (None, None, None, 0)
+        nat.check(lib.dcv_cross_entropy_fwd_grad_publish(logits.data_ptr(), target.data_ptr(), loss.data_ptr(), lse.data_ptr(), nat.ptr(correct_out), nat.ptr(dz_unit),
+                                                         ctypes.byref(produced), n, c, ws.data_ptr(), ws.numel(), pub[0], pub[1], pub[2], pub[3],
+                                                         ctypes.byref(published), nat.current_stream(dev)), 'dcv_cross_entropy_fwd_grad_publish')
+        if published.value:
+            global _last_published
+            _last_published = weakref.ref(loss)
         ctx.dz_unit = dz_unit if produced.value else None
         ctx.save_for_backward(logits, target, lse)
         return loss

@@ -4,9 +4,11 @@
 `conf/base/parameters.yml:129-134`) and `SGD` mirrors `torch.optim.SGD` (`parameters.yml:136`): same constructor arguments, `param_groups`
 keys (so ignite-style schedulers writing `param_groups[i]['lr'|'momentum'|'betas']` work unchanged) and `state_dict` entry names
 (`step`, `exp_avg`, `exp_avg_sq`, `max_exp_avg_sq`, `momentum_buffer`).  `step()` is ONE fused multi-tensor HIP launch per 64 parameter tensors
-(`dcv_adamw_step` / `dcv_sgd_step`) preceded by a one-thread `dcv_optim_prepare` which advances the device-side step counter and derives the bias
-corrections; the scalars that change over time (lr, momentum, ...) are read by the kernels from a 64-byte device buffer refreshed from pinned host
-memory, so the captured hipGraph of a training step replays with the scheduler's current values. """
+(`dcv_adamw_step` / `dcv_sgd_step`).  The scalars that change over time (lr, momentum, ..., and the per-step bias corrections) are read by the kernels
+from a 64-byte device buffer: an eager step derives the per-step ones on the device (a one-thread `dcv_optim_prepare` in front of the update, which
+advances a device-side step counter); a step captured into a hipGraph has no such launch — the host, which counts the steps (`note_replayed`), hands
+the bias corrections of the coming step to the replay together with the scheduler's current values (`hyper_jobs`: they ride in the batch-staging
+kernel of `GraphedTrainStep`). """
 import ctypes
 from typing import Any, Dict, Iterable, List, Optional, Tuple
 
@@ -39,11 +41,26 @@ class _NativeOptimizer(torch.optim.Optimizer):
                 host = host.pin_memory()
             buf = {'hyper_host': host, 'slot': 0, 'hyper': torch.zeros(nat.HYP_COUNT, dtype=torch.float32, device=device),
                    'step': torch.zeros(1, dtype=torch.int64, device=device), 'last': None}
-            pending = getattr(self, '_pending_steps', {}).pop(gi, None)
-            if pending is not None:
-                buf['step'].fill_(int(pending))
+            buf['dev_step'] = 0          # what the device-side counter holds, as far as the host knows (None: unknown)
             self._dev[gi] = buf
         return buf
+
+    def _completed(self, gi: int) -> int:
+        """ Optimisation steps group `gi` has taken (the host's count: eager steps + replays of a captured step). """
+        return getattr(self, '_steps_done', {}).get(gi, 0)
+
+    def _set_completed(self, gi: int, value: int):
+        if not hasattr(self, '_steps_done'):
+            self._steps_done = {}
+        self._steps_done[gi] = int(value)
+
+    @staticmethod
+    def _step_scalars(vals: List[float], s: int) -> List[float]:
+        """ What `dcv_optim_prepare` derives on the device for step `s` (DCV_HYP_BIAS_CORR1, _BIAS_CORR2, _FIRST_STEP), from the float32 values the
+        device sees. """
+        import struct
+        b1, b2 = struct.unpack('<2f', struct.pack('<2f', vals[1], vals[2]))
+        return [1.0 - b1 ** s, 1.0 - b2 ** s, 1.0 if s == 1 else 0.0]
 
     def _hyper_values(self, group: Dict[str, Any]) -> List[float]:
         raise NotImplementedError
@@ -74,7 +91,8 @@ class _NativeOptimizer(torch.optim.Optimizer):
             if p0 is None:
                 continue
             buf = self._group_buffers(gi, p0.device)
-            jobs.append((self._hyper_values(group) + [float(group.get('grad_scale', 1.0))], buf['hyper']))
+            vals = self._hyper_values(group) + [float(group.get('grad_scale', 1.0))]
+            jobs.append((vals + self._step_scalars(vals, self._completed(gi) + 1), buf['hyper']))      # the replayed step has no prepare launch
             buf['last'] = None
         return jobs
 
@@ -138,7 +156,14 @@ class _NativeOptimizer(torch.optim.Optimizer):
             dev = group['params'][0].device
             buf = self._group_buffers(gi, dev)
             stream = nat.current_stream(dev)
-            nat.check(lib.dcv_optim_prepare(buf['hyper'].data_ptr(), buf['step'].data_ptr(), stream), 'dcv_optim_prepare')
+            if not capturing:
+                done = self._completed(gi)
+                if buf['dev_step'] != done:          # replays advanced the host's count only
+                    buf['step'].fill_(done)
+                nat.check(lib.dcv_optim_prepare(buf['hyper'].data_ptr(), buf['step'].data_ptr(), stream), 'dcv_optim_prepare')
+                self._set_completed(gi, done + 1)
+                buf['dev_step'] = done + 1
+            # (captured: the per-step scalars arrive with `hyper_jobs()` before every replay, `note_replayed()` counts the step)
             for tl in lists:
                 self._launch(tl, buf['hyper'].data_ptr(), group, stream)
             # the weights just changed behind `Tensor._version`: refresh every prepared convolution filter of this group in one launch
@@ -153,12 +178,14 @@ class _NativeOptimizer(torch.optim.Optimizer):
         refreshed) without this object seeing it; filters prepared since then are stale and get re-laid on their next use (`deepcv_amd/filters.py`). """
         for table in self._filter_tables.values():
             table.replayed()
+        for gi, group in enumerate(self.param_groups):
+            if any(p.grad is not None for p in group['params']):
+                self._set_completed(gi, self._completed(gi) + 1)
 
     # -- checkpoint compatibility with torch.optim state_dicts ------------------------------------------
     def state_dict(self):
         for gi, group in enumerate(self.param_groups):
-            buf = self._dev.get(gi)
-            step = int(buf['step'].item()) if buf is not None else 0
+            step = self._completed(gi)
             for p in group['params']:
                 if p in self.state and len(self.state[p]) > 0:
                     self.state[p]['step'] = torch.tensor(float(step))
@@ -167,15 +194,12 @@ class _NativeOptimizer(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._lists.clear()
-        self._pending_steps = {}
         for gi, group in enumerate(self.param_groups):
             steps = [float(self.state[p]['step']) for p in group['params'] if p in self.state and 'step' in self.state[p]]
-            step = int(max(steps)) if steps else 0
+            self._set_completed(gi, int(max(steps)) if steps else 0)
             if gi in self._dev:
-                self._dev[gi]['step'].fill_(step)
+                self._dev[gi]['dev_step'] = None
                 self._dev[gi]['last'] = None
-            else:
-                self._pending_steps[gi] = step
 
 
 class AdamW(_NativeOptimizer):

@@ -470,6 +470,12 @@ int dcv_cross_entropy_fwd(const float* logits, const int64_t* target, float* los
  * pass (ignite_training.py:253, loss.backward()) then needs no dcv_cross_entropy_bwd launch. */
 int dcv_cross_entropy_fwd_grad(const float* logits, const int64_t* target, float* loss, float* lse, int32_t* correct, float* dlogits_unit, int* produced,
                                int n, int classes, void* ws, size_t ws_bytes, void* stream);
+/* as dcv_cross_entropy_fwd_grad; the one-launch case also publishes the loss to pinned host memory the way dcv_publish_scalars does (the value into
+ * host_vals[0 .. slots), then mailbox->seq into *host_seq), sparing a replayed training step that launch — *published tells whether it did; host_seq NULL:
+ * nothing is published. */
+int dcv_cross_entropy_fwd_grad_publish(const float* logits, const int64_t* target, float* loss, float* lse, int32_t* correct, float* dlogits_unit, int* produced,
+                                       int n, int classes, void* ws, size_t ws_bytes, const dcv_copy_jobs* mailbox, float* host_vals, int* host_seq, int slots,
+                                       int* published, void* stream);
 int dcv_cross_entropy_bwd(const float* logits, const int64_t* target, const float* lse, const float* dloss, float* dlogits,
                           int n, int classes, void* stream);
 
