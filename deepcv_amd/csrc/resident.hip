@@ -33,7 +33,7 @@ constexpr int RS_MAXQ = 2 * RS_MAXC;
 constexpr int RS_MAXG = 256;        // blocks
 constexpr int RS_GRAN_OP = RS_MAXQ * RS_MAXG + 2 * RS_MAXQ;   // granules of one synchronisation: hop-1 partials [RS_MAXQ][RS_MAXG], hop-2 totals [RS_MAXQ][2]
 constexpr int RS_SPINS = 1 << 16;   // gather polls before giving up (each at least a memory round trip: tens of milliseconds)
-constexpr size_t RS_CTL_BYTES = 1024;  // [0] launch generation, [1] error word, [2] test hook (1 + index of a block which never publishes), [4..): time stamps of block 0 (64-bit, 100 MHz): tools/resident_stamps.py
+constexpr size_t RS_CTL_BYTES = 1024;  // [0] launch generation, [1] error word, [2] test hook (1 + index of a block which never publishes), [3] the block whose time stamps are recorded, [4..): its time stamps (64-bit, 100 MHz): tools/resident_stamps.py
 constexpr int RS_MAX_STAMPS = 120;
 
 typedef unsigned long long rs_u64;
@@ -432,7 +432,8 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
     const bool mute = ctl[2] == blockIdx.x + 1u;        // test hook (tests/test_resident_gpu.py): this block never publishes -> every block's bounded spin gives up
     int n_stamp = 0;
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(ctl + 4);
-    auto stamp = [&]() { if (blockIdx.x == 0 && t == 0 && n_stamp < RS_MAX_STAMPS) stamps[1 + n_stamp] = wall_clock64(); ++n_stamp; };
+    const unsigned stamp_block = ctl[3];                // diagnostics: the block whose phase times are recorded (tools/resident_stamps.py), 0 by default
+    auto stamp = [&]() { if (blockIdx.x == stamp_block && t == 0 && n_stamp < RS_MAX_STAMPS) stamps[1 + n_stamp] = wall_clock64(); ++n_stamp; };
     stamp();
     {   // ONE global round trip: every layer's per-channel parameters -> LDS (the coefficient phases never wait for memory), the two samples -> the first
         // layer's padded tile (loads issued before the tile is zeroed)
@@ -737,7 +738,8 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
         }
     }
     // every block read `gen` before its first publication and block 0 only gets here after it has gathered everybody's: the next launch is stream-ordered
-    if (blockIdx.x == 0 && t == 0) { stamps[0] = (unsigned long long)n_stamp; __hip_atomic_store((rs_gu32*)ctl, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    if (blockIdx.x == stamp_block && t == 0) stamps[0] = (unsigned long long)n_stamp;
+    if (blockIdx.x == 0 && t == 0) __hip_atomic_store((rs_gu32*)ctl, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------------------ the backward chain
@@ -905,6 +907,22 @@ __device__ __forceinline__ void rb_wgrad(const dcv_resident_bwd_op& o, const flo
 
 __device__ __forceinline__ float rb_act_grad(float y, int act, float slope) { return dcv_act_grad_from_out(y, act, slope); }
 
+// the head's resize gradient keeps, per input row / column of the referenced tensor, the output rows / columns whose two bilinear taps touch it
+constexpr int RB_TAPS = 8;
+inline bool rb_resize_taps_ok(int in_size, int out_size, int align_corners) {
+    if (in_size <= 0 || out_size <= 0 || in_size > 4096 || out_size > 4096) return false;
+    const float scale = align_corners ? (out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f) : (float)in_size / (float)out_size;
+    int count[4096] = {0};
+    for (int dst = 0; dst < out_size; ++dst) {
+        float fs = align_corners ? scale * dst : scale * (dst + 0.5f) - 0.5f; if (fs < 0.f) fs = 0.f;
+        int i0 = (int)fs; if (i0 > in_size - 1) i0 = in_size - 1;
+        const int i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+        if (++count[i0] > RB_TAPS) return false;
+        if (i1 != i0 && ++count[i1] > RB_TAPS) return false;
+    }
+    return true;
+}
+
 // ---- weight / bias gradient of the fully connected head inside the backward launch.  Its operands exist before the launch (the head's saved input x
 // [n][K] in NHWC order, dlogits, the logits), so no grid synchronisation is involved: the first K / 8 blocks each take a GROUP of 8 consecutive input
 // positions (one 32-B sector of every sample's row) and compute their gradient rows for ALL samples, final values straight into dw (the reference's
@@ -998,7 +1016,8 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
     const bool mute = ctl[2] == blockIdx.x + 1u;        // test hook, as in the forward launch
     int n_stamp = 0;
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(ctl + 4);
-    auto stamp = [&]() { if (blockIdx.x == 0 && t == 0 && n_stamp < RS_MAX_STAMPS) stamps[1 + n_stamp] = wall_clock64(); ++n_stamp; };
+    const unsigned stamp_block = ctl[3];                // diagnostics: the block whose phase times are recorded (tools/resident_stamps.py), 0 by default
+    auto stamp = [&]() { if (blockIdx.x == stamp_block && t == 0 && n_stamp < RS_MAX_STAMPS) stamps[1 + n_stamp] = wall_clock64(); ++n_stamp; };
     stamp();
     // a sample's [HW * C] floats, HBM -> LDS region (flat), 8 float4 per thread in flight
     auto load_flat = [&](const float* src, float* region, int floats_per_sample) {
@@ -1017,9 +1036,10 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
     const int fc_pg = (p.head.enabled && p.head.fc_dw != nullptr) ? rb_fc_group(p.head.h * p.head.w * (p.head.cc + p.head.cr)) : -1;
     float4 fc_x4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float fc_g[RB_FC_DZ_SLOTS], fc_l[RB_FC_DZ_SLOTS];
-    if (fc_pg >= 0) {
+    const bool stage_dz = p.head.enabled && p.head.fc_dw != nullptr;               // every block: its own samples' dl (the head's data gradient) comes from there too
+    if (stage_dz) {
         const int K = p.head.h * p.head.w * (p.head.cc + p.head.cr), total = N * p.head.classes;
-        if (tt < N) fc_x4 = *reinterpret_cast<const float4*>(p.head.fc_x + (size_t)tt * K + fc_pg * 8 + s_of_t * 4);
+        if (fc_pg >= 0 && tt < N) fc_x4 = *reinterpret_cast<const float4*>(p.head.fc_x + (size_t)tt * K + fc_pg * 8 + s_of_t * 4);
 #pragma unroll
         for (int k = 0; k < RB_FC_DZ_SLOTS; ++k) { const int i = t + k * RS_T; fc_g[k] = p.head.dlogits[i < total ? i : 0]; fc_l[k] = p.head.logits ? p.head.logits[i < total ? i : 0] : 0.f; }
     }
@@ -1041,7 +1061,7 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         if (!p.head.enabled) load_flat(o.dout, dor, (o.h / pk) * (o.w / pk) * o.cout);
         if (pslot >= 0) (&s_par[0][0][0])[pslot] = pv;
     }
-    if (fc_pg >= 0) {
+    if (stage_dz) {
         float* staged = reinterpret_cast<float*>(dzt);
         const int total = N * p.head.classes;
         reinterpret_cast<float4*>(staged + 512 * RB_FC_MAXO)[t] = fc_x4;
@@ -1051,13 +1071,17 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
             if (i < total) staged[i] = p.head.logits ? fc_g[k] * dcv_act_grad_from_out(fc_l[k], p.head.act, p.head.slope) : fc_g[k];
         }
     }
+    if (stage_dz) rs_barrier();
+    stamp();
     if (p.head.enabled) {
         // ---- head of the backward pass: dl = dlogits act'(logits); dwide = dl W; the current tensor's channels -> op 0's dout (LDS), the referenced tensor's
         // channels -> back through the bilinear resize (gather: each input pixel sums the output pixels whose footprint contains it) -> dref (HBM)
         const dcv_resident_bwd_head& hd = p.head;
         const int O = hd.classes, HWo = hd.h * hd.w, Cc = hd.cc, Cr = hd.cr, Cw = Cc + Cr, K = HWo * Cw;
         float* tmp = reinterpret_cast<float*>(xtt);                                  // [RS_SPB][HWo * Cr]: the referenced channels of dwide (the x tile is still free)
-        if (t < RS_SPB * O) {
+        if (stage_dz) {                                                              // dl of this block's samples: already in LDS with everybody's (the head's weight gradient)
+            if (t < RS_SPB * O) { const int ss = t >= O ? 1 : 0, j = t - ss * O, n = (int)blockIdx.x * RS_SPB + ss; s_wsum[ss * 16 + j] = n < N ? reinterpret_cast<const float*>(dzt)[n * O + j] : 0.f; }
+        } else if (t < RS_SPB * O) {
             const int ss = t >= O ? 1 : 0, j = t - ss * O, n = (int)blockIdx.x * RS_SPB + ss;
             float g = 0.f;
             if (n < N) { g = hd.dlogits[(size_t)n * O + j]; if (hd.logits) g *= dcv_act_grad_from_out(hd.logits[(size_t)n * O + j], hd.act, hd.slope); }
@@ -1066,48 +1090,71 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         rs_barrier();
         {
             const float inv_cw = 1.f / (float)Cw;
-            for (int k = tt; k < K; k += 512) {
-                float acc = 0.f;
-                for (int j = 0; j < O; ++j) acc += s_wsum[s_of_t * 16 + j] * hd.wp[(size_t)j * K + k];
-                const int px = rs_fdiv(k, inv_cw), c = k - px * Cw;
-                if (c < Cc) dor[s_of_t * RS_Y + px * Cc + c] = acc; else tmp[s_of_t * RS_Y + px * Cr + (c - Cc)] = acc;
+            // a thread computes its positions for BOTH samples (every weight is loaded once per block), two positions per pass with all their weights
+            // requested before the first use (a pass per position = a round trip to L2 each)
+            for (int k0 = t; k0 < K; k0 += 2 * RS_T) {
+                float wv[2][16];
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) { const int k = k0 + q * RS_T; wv[q][j] = (j < O && k < K) ? hd.wp[(size_t)j * K + k] : 0.f; }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int k = k0 + q * RS_T;
+                    if (k < K) {
+                        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) if (j < O) { a0 += s_wsum[j] * wv[q][j]; a1 += s_wsum[16 + j] * wv[q][j]; }
+                        const int px = rs_fdiv(k, inv_cw), c = k - px * Cw;
+                        if (c < Cc) { dor[px * Cc + c] = a0; dor[RS_Y + px * Cc + c] = a1; } else { tmp[px * Cr + (c - Cc)] = a0; tmp[RS_Y + px * Cr + (c - Cc)] = a1; }
+                    }
+                }
+            }
+        }
+        {
+            // the resize's weights are separable: per input row (column) the <= RB_TAPS output rows (columns) whose two taps touch it and their weights, once
+            // per block into LDS (behind `tmp` in the x tile's region) — evaluating the tap arithmetic per element and candidate took 5 us of this prologue
+            const int RH = hd.ref_h, RW = hd.ref_w;
+            const float sh = hd.align_corners ? (hd.h > 1 ? (float)(RH - 1) / (float)(hd.h - 1) : 0.f) : (float)RH / (float)hd.h;
+            const float sw = hd.align_corners ? (hd.w > 1 ? (float)(RW - 1) / (float)(hd.w - 1) : 0.f) : (float)RW / (float)hd.w;
+            float* wtab = tmp + RS_SPB * RS_Y;                                       // [RH + RW][RB_TAPS] weights, then the same shape of output indices
+            int* itab = reinterpret_cast<int*>(wtab + (RH + RW) * RB_TAPS);
+            if (t < RH + RW) {
+                const bool row = t < RH;
+                const int i = row ? t : t - RH, in_size = row ? RH : RW, out_size = row ? hd.h : hd.w;
+                const float scale = row ? sh : sw;
+                int n = 0;
+                for (int dst = 0; dst < out_size; ++dst) {
+                    float fs = hd.align_corners ? scale * dst : scale * (dst + 0.5f) - 0.5f; if (fs < 0.f) fs = 0.f;
+                    int i0 = (int)fs; if (i0 > in_size - 1) i0 = in_size - 1;
+                    const int i1 = i0 + ((i0 < in_size - 1) ? 1 : 0); const float l1 = fs - (float)i0;
+                    float wgt = 0.f;
+                    if (i0 == i) wgt += 1.f - l1;
+                    if (i1 == i) wgt += l1;
+                    if (wgt != 0.f && n < RB_TAPS) { wtab[t * RB_TAPS + n] = wgt; itab[t * RB_TAPS + n] = dst; ++n; }
+                }
+                for (; n < RB_TAPS; ++n) { wtab[t * RB_TAPS + n] = 0.f; itab[t * RB_TAPS + n] = 0; }
             }
         }
         rs_barrier();
+        stamp();
         {
             const int RH = hd.ref_h, RW = hd.ref_w, per = RH * RW * Cr;
-            const float sh = hd.align_corners ? (hd.h > 1 ? (float)(RH - 1) / (float)(hd.h - 1) : 0.f) : (float)RH / (float)hd.h;
-            const float sw = hd.align_corners ? (hd.w > 1 ? (float)(RW - 1) / (float)(hd.w - 1) : 0.f) : (float)RW / (float)hd.w;
             const float inv_cr = 1.f / (float)Cr, inv_rw = 1.f / (float)RW;
-            auto taps = [&](float scale, int dst, int in_size, int& i0, int& i1, float& l1) {
-                float fs = hd.align_corners ? scale * dst : scale * (dst + 0.5f) - 0.5f; if (fs < 0.f) fs = 0.f;
-                i0 = (int)fs; if (i0 > in_size - 1) i0 = in_size - 1;
-                i1 = i0 + ((i0 < in_size - 1) ? 1 : 0); l1 = fs - (float)i0;
-            };
-            auto range = [&](float scale, int i, int out_size, int& lo, int& hi) {
-                const float inv = scale > 0.f ? 1.f / scale : 0.f;
-                lo = (int)floorf(((float)i - 1.5f) * inv - 1.5f); hi = (int)ceilf(((float)i + 1.5f) * inv + 1.5f);
-                if (lo < 0) lo = 0;
-                if (hi > out_size - 1) hi = out_size - 1;
-            };
+            const float* wtab = tmp + RS_SPB * RS_Y;
+            const int* itab = reinterpret_cast<const int*>(wtab + (RH + RW) * RB_TAPS);
             for (int e = tt; e < per; e += 512) {
                 const int px = rs_fdiv(e, inv_cr), cr = e - px * Cr, rh = rs_fdiv(px, inv_rw), rw = px - rh * RW;
-                int holo, hohi, wolo, wohi;
-                range(sh, rh, hd.h, holo, hohi); range(sw, rw, hd.w, wolo, wohi);
                 float acc = 0.f;
-                for (int ho = holo; ho <= hohi; ++ho) {
-                    int h0, h1; float lh; taps(sh, ho, RH, h0, h1, lh);
-                    float wh = 0.f;
-                    if (h0 == rh) wh += 1.f - lh;
-                    if (h1 == rh) wh += lh;
+#pragma unroll
+                for (int a = 0; a < RB_TAPS; ++a) {
+                    const float wh = wtab[rh * RB_TAPS + a];
                     if (wh == 0.f) continue;
-                    for (int wo = wolo; wo <= wohi; ++wo) {
-                        int w0, w1; float lw; taps(sw, wo, RW, w0, w1, lw);
-                        float ww = 0.f;
-                        if (w0 == rw) ww += 1.f - lw;
-                        if (w1 == rw) ww += lw;
-                        if (ww == 0.f) continue;
-                        acc += wh * ww * tmp[s_of_t * RS_Y + (ho * hd.w + wo) * Cr + cr];
+                    const int ho = itab[rh * RB_TAPS + a];
+#pragma unroll
+                    for (int c = 0; c < RB_TAPS; ++c) {
+                        const float ww = wtab[(RH + rw) * RB_TAPS + c];
+                        if (ww != 0.f) acc += wh * ww * tmp[s_of_t * RS_Y + (ho * hd.w + itab[(RH + rw) * RB_TAPS + c]) * Cr + cr];
                     }
                 }
                 const int n = (int)blockIdx.x * RS_SPB + s_of_t;
@@ -1341,7 +1388,8 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
     }
     if (p.op[p.count - 1].dw_part != nullptr) rb_wgrad(p.op[p.count - 1], xtt, dzt);     // the first layer's: nothing left to hide it behind
     stamp();
-    if (blockIdx.x == 0 && t == 0) { stamps[0] = (unsigned long long)n_stamp; __hip_atomic_store((rs_gu32*)ctl, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    if (blockIdx.x == stamp_block && t == 0) stamps[0] = (unsigned long long)n_stamp;
+    if (blockIdx.x == 0 && t == 0) __hip_atomic_store((rs_gu32*)ctl, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 inline bool rb_program_ok(const dcv_resident_bwd_program* p) {
@@ -1353,6 +1401,8 @@ inline bool rb_program_ok(const dcv_resident_bwd_program* p) {
         if (hd.classes <= 0 || hd.classes > 16 || hd.cc != o.cout || hd.h != o.h / pk || hd.w != o.w / pk || hd.cr <= 0 || hd.ref_h <= 0 || hd.ref_w <= 0) return false;
         if (hd.h * hd.w * hd.cr > RS_Y || hd.ref_h * hd.ref_w * hd.cr > 16 * RS_Y || !hd.dlogits || !hd.wp || !hd.dref || hd.act < DCV_ACT_NONE || hd.act > DCV_ACT_TANH) return false;
         if (hd.act != DCV_ACT_NONE && !hd.logits) return false;
+        if ((size_t)(hd.ref_h + hd.ref_w) * RB_TAPS * 8 + (size_t)RS_SPB * RS_Y * 4 > (size_t)RS_SPB * RS_XIN * 16 || hd.ref_h + hd.ref_w > RS_T) return false;
+        if (!rb_resize_taps_ok(hd.ref_h, hd.h, hd.align_corners) || !rb_resize_taps_ok(hd.ref_w, hd.w, hd.align_corners)) return false;
         if (hd.fc_dw && (!hd.fc_x || !rb_fc_wgrad_ok(p->n, hd.h * hd.w * (hd.cc + hd.cr), hd.classes))) return false;
     } else if (!p->op[0].dout) return false;
     for (int i = 0; i < p->count; ++i) {

@@ -1,5 +1,5 @@
-"""Phase times of the two persistent launches (block 0's 100 MHz time stamps, `resident.hip`): stock model, bs 512, inside replayed training steps.
-usage: resident_stamps.py [steps]"""
+"""Phase times of the two persistent launches (100 MHz time stamps of block $BLOCK, default 0, `resident.hip`): stock model, bs 512, inside replayed
+training steps.  usage: [BLOCK=b] resident_stamps.py [steps]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -19,10 +19,14 @@ step = GraphedTrainStep(model, opt, losses, weights)
 bs = int(os.environ.get('BS', '512'))
 x, y = torch.randn(bs, 3, 32, 32, device=dev), torch.randint(0, 10, (bs,), device=dev)
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+block = int(os.environ.get('BLOCK', '0'))             # whose time stamps (ctl word 3 of both workspaces)
 acc = {}
 for i in range(steps):
     step(x, y)
     torch.cuda.synchronize()
+    if i == 1 and block:
+        for table in (resident._ws, resident._ws_bwd):
+            table[dev][12:16].copy_(torch.tensor([block], dtype=torch.int32).view(torch.uint8).to(dev))
     for tag, table in (('forward', resident._ws), ('backward', resident._ws_bwd)):
         if dev not in table:
             continue
@@ -37,7 +41,7 @@ fwd = ['stage input']
 for l in range(5):
     fwd += [f'L{l + 1} conv (+ sums)', f'L{l + 1} combine + publish', f'L{l + 1} gather', f'L{l + 1} fp64 sums + coefficients', f'L{l + 1} apply']
 fwd += ['link', 'fc']
-bwd = ['load y, dout']
+bwd = ['parameters, y, head operands -> LDS', 'head: dwide = dl W (+ resize tables)', 'head: resize gradient -> dref']
 for l in range(5, 0, -1):
     bwd += [f'L{l} moments', f'L{l} algebra + publish', f'L{l} weight gradient of L{l + 1}' if l < 5 else 'L5 weight gradient of the head', f'L{l} all-reduce',
             f'L{l} coefficients, zero tiles', f'L{l} dz + x tile', f'L{l} next y + data gradient']
@@ -50,4 +54,4 @@ for tag, names in (('forward', fwd), ('backward', bwd)):
     for k, v in enumerate((acc[tag] / cnt).tolist()):
         print(f'{names[k] if k < len(names) else k:40s} {v:7.2f} us')
         tot += v
-    print(f'{"total (block 0)":40s} {tot:7.2f} us')
+    print(f'{"total (block " + str(block) + ")":40s} {tot:7.2f} us')
