@@ -465,7 +465,12 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
         const bool vec = !o.x_nchw && (C & 3) == 0;
         const int total = vec ? HW * (C >> 2) : HW * C;
         float4 v4[SB]; float v1[SB];
-        const float* src = o.x + (size_t)(n < N ? n : 0) * HW * C;
+        // a replayed step's batch: read through the address the host left in the mailbox for THIS replay, and kept in the static tensor for the backward pass
+        const float* batch = o.x;
+        if (p.mailbox != nullptr) batch = reinterpret_cast<const float*>(p.mailbox->src[p.x_job]);
+        const bool keep = p.mailbox != nullptr && batch != o.x && n < N;
+        const float* src = batch + (size_t)(n < N ? n : 0) * HW * C;
+        float* stat = const_cast<float*>(o.x) + (size_t)(n < N ? n : 0) * HW * C;
         if (vec) {
 #pragma unroll
             for (int k = 0; k < SB; ++k) { const int e = tt + k * 512; v4[k] = reinterpret_cast<const float4*>(src)[e < total ? e : 0]; }
@@ -488,6 +493,7 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
 #pragma unroll
             for (int k = 0; k < SB; ++k) {
                 const int e = e0 + tt + k * 512;
+                if (keep && e < total) { if (vec) reinterpret_cast<float4*>(stat)[e] = v4[k]; else stat[e] = v1[k]; }
                 if (e < total && n < N) {
                     if (vec) {
                         const int px = rs_fdiv(e, inv_cv), cv = e - px * (C >> 2), r = rs_fdiv(px, inv_w), col = px - r * o.w;
@@ -499,6 +505,21 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                         dst[(((c >> 2) * XH + r + pad) * XW + col + pad) * 4 + (c & 3)] = v1[k];
                     }
                 }
+            }
+        }
+        if (p.mailbox != nullptr) {
+            // the mailbox's other jobs (labels, optimizer scalars: a few KB): job j by block j % G
+            const int count = p.mailbox->count < DCV_MAX_COPY_JOBS ? p.mailbox->count : DCV_MAX_COPY_JOBS;
+            for (int j = 0; j < count; ++j) {
+                if (j == p.x_job || j % G != (int)blockIdx.x) continue;
+                const char* js = reinterpret_cast<const char*>(p.mailbox->src[j]);
+                char* jd = reinterpret_cast<char*>(p.mailbox->dst[j]);
+                const size_t bytes = (size_t)p.mailbox->bytes[j];
+                if (!js || !jd || js == jd) continue;
+                const bool v16 = (((reinterpret_cast<uintptr_t>(js) | reinterpret_cast<uintptr_t>(jd)) & 15) == 0);
+                const size_t n16 = v16 ? bytes / 16 : 0;
+                for (size_t i = t; i < n16; i += RS_T) reinterpret_cast<uint4*>(jd)[i] = reinterpret_cast<const uint4*>(js)[i];
+                for (size_t i = n16 * 16 + t; i < bytes; i += RS_T) jd[i] = js[i];
             }
         }
     }
@@ -1452,6 +1473,7 @@ inline bool rs_layer_ok(const dcv_resident_op& o, bool first) {
 inline bool rs_program_ok(const dcv_resident_program* p) {
     if (!p || p->n <= 0 || p->n > RS_SPB * RS_MAXG || p->count <= 0 || p->count > DCV_RESIDENT_MAX_OPS) return false;
     if (p->op[0].kind != DCV_RES_LAYER || !p->op[0].x) return false;
+    if (p->mailbox && (p->x_job < 0 || p->x_job >= DCV_MAX_COPY_JOBS)) return false;
     int c = 0, h = 0, w = 0;                                      // the current tensor
     for (int i = 0; i < p->count; ++i) {
         const dcv_resident_op& o = p->op[i];

@@ -170,6 +170,8 @@ class GraphedTrainStep:
         # capture the RCCL all-reduce INSIDE the step graph (one graph per step, no eager gap): off by default until validated on a multi-GPU node
         self.graph_collective = (os.environ.get('DCV_GRAPH_COLLECTIVE') == '1') if graph_collective is None else bool(graph_collective)
         self.calls = 0
+        # None: the resident forward launch stages the batch when it runs (decided at capture); False (`DCV_STAGE_IN_FORWARD=0`): always dcv_indirect_copy
+        self._stage_in_forward: Optional[bool] = False if os.environ.get('DCV_STAGE_IN_FORWARD', '1') in ('0', 'false', 'False') else None
         self.graph_fb = self.graph_opt = None
         self.static_x = self.static_y = None
         self.static_losses: Optional['OrderedDict[str, torch.Tensor]'] = None
@@ -242,6 +244,9 @@ class GraphedTrainStep:
                 src.append(s_.data_ptr()); dst.append(d_.data_ptr()); nbytes.append(d_.numel() * d_.element_size())
             else:
                 d_.copy_(s_, non_blocking=True)                    # foreign layout / pageable host memory: ordinary copy
+                if d_ is self.static_x and self._stage_in_forward:
+                    # the forward launch reads its batch through job 0 whatever happened: point it at the static tensor the copy above fills
+                    src.append(d_.data_ptr()); dst.append(d_.data_ptr()); nbytes.append(d_.numel() * d_.element_size())
         off = self._MB_PAYLOAD
         if hasattr(self.optimizer, 'hyper_jobs'):
             for vals, dev_buf in self.optimizer.hyper_jobs():
@@ -299,8 +304,15 @@ class GraphedTrainStep:
         dev = x.device
         self.static_x, self.static_y = x.clone(), (y.clone() if isinstance(y, torch.Tensor) else y)
         self._mailbox_init(dev)
-        self._mailbox_write(x, y)
         self.model.train()
+        from .. import resident as _resident
+        from .base_module import DeepcvModule
+        inner = self.model.module if isinstance(self.model, DataParallelModel) else self.model
+        # the LDS-resident forward launch can stage the batch itself (it reads the mailbox: no dcv_indirect_copy launch, 8 us); decided from the verdict the
+        # eager first step left, verified after the captured forward
+        stage_in_forward = (self._stage_in_forward is not False and isinstance(inner, DeepcvModule) and _resident.launches() > 0 and _resident.wanted(inner, self.static_x))
+        self._stage_in_forward = bool(stage_in_forward)
+        self._mailbox_write(x, y)
         self.optimizer.zero_grad(set_to_none=True)
         hooks_were = None
         if self.reducer is not None:
@@ -315,8 +327,18 @@ class GraphedTrainStep:
         # collective recorded on THIS stream just before the capture began -> `reducer.isolate`, deepcv_amd/parallel.py.)
         capture_mode = 'thread_local' if (self.reducer is not None or (torch.distributed.is_available() and torch.distributed.is_initialized())) else 'global'
         with torch.cuda.graph(self.graph_fb, stream=self.stream, capture_error_mode=capture_mode):
-            self._nat.check(self._nat.lib.dcv_indirect_copy(self.mailbox.data_ptr(), self._nat.current_stream(dev)), 'dcv_indirect_copy')
-            self.static_pred = self.model(self.static_x)
+            if stage_in_forward:
+                _resident.set_staging((self.mailbox.data_ptr(), 0, self.static_x.data_ptr()))
+            else:
+                self._nat.check(self._nat.lib.dcv_indirect_copy(self.mailbox.data_ptr(), self._nat.current_stream(dev)), 'dcv_indirect_copy')
+            try:
+                self.static_pred = self.model(self.static_x)
+            finally:
+                staged = _resident.staging_consumed()
+                _resident.set_staging(None)
+            if stage_in_forward and not staged:
+                raise RuntimeError('deepcv_amd: the captured forward pass did not run as the LDS-resident launch which was to stage the batch '
+                                   '(set DCV_STAGE_IN_FORWARD=0)')
             # a single cross-entropy term publishes its value from its own launch (both names of `_batch_losses` are that one tensor): no publish launch
             fold = len(self.losses) == 1 and isinstance(next(iter(self.losses.values())), native.CrossEntropyLoss)
             if fold:

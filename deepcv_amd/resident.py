@@ -125,6 +125,22 @@ def _verdict_slot(module) -> Dict[tuple, str]:
     return slot[1]
 
 
+_staging: Optional[tuple] = None          # (mailbox address, index of the batch's job, address of the static input tensor) while a training step is captured
+_staging_consumed = False
+
+
+def set_staging(spec: Optional[tuple]):
+    """ `spec = (mailbox, x_job, static_x_ptr)` (`GraphedTrainStep`): the next recorded forward whose input IS that static tensor reads the batch through the
+    mailbox itself and copies the mailbox's other jobs (`dcv_resident_program.mailbox`): the step then has no `dcv_indirect_copy` launch.  `None` switches it
+    off; `staging_consumed()` tells whether a launch took the mailbox since the last `set_staging`. """
+    global _staging, _staging_consumed
+    _staging, _staging_consumed = spec, False
+
+
+def staging_consumed() -> bool:
+    return _staging_consumed
+
+
 def wanted(module, x) -> bool:
     """ Should the outermost `DeepcvModule.forward` try to record this call? """
     if not _enabled or _active is not None or not isinstance(x, torch.Tensor):
@@ -324,8 +340,13 @@ class Recorder:
             prog.op[i] = op
         if not lib.dcv_resident_supported(prog):
             raise Ineligible('the recorded program is not covered by the resident kernel')
+        global _staging_consumed
+        if _staging is not None and not _staging_consumed and prog.op[0].x == _staging[2]:
+            prog.mailbox, prog.x_job = _staging[0], _staging[1]          # the launch stages its batch (and the step's labels / scalars) itself
         ws = _workspace(self.device)
         nat.check(lib.dcv_resident_forward(prog, ws.data_ptr(), ws.numel(), nat.current_stream(self.device)), 'dcv_resident_forward')
+        if prog.mailbox:
+            _staging_consumed = True
         _launches += 1
         if capture_programs:
             last_programs['forward'] = (prog, ws, list(self.keep))

@@ -564,7 +564,14 @@ typedef struct dcv_resident_op {
     float* bn_mean; float* bn_rstd; float* gn_mean; float* gn_rstd;   /* saved statistics, as dcv_norm_chain_desc */
     const float* ref;                  /* LINK: [n][ref_h][ref_w][ref_c] */
 } dcv_resident_op;
-typedef struct dcv_resident_program { int n; int count; dcv_resident_op op[DCV_RESIDENT_MAX_OPS]; } dcv_resident_program;
+/* `mailbox` (nullable) folds the batch staging of a replayed training step (dcv_indirect_copy) into the launch: the first op's input is read from
+ * mailbox->src[x_job] — the address the host wrote for THIS replay — instead of op[0].x, and also stored to op[0].x (= mailbox->dst[x_job], the static tensor
+ * the backward pass reads); the mailbox's other jobs (labels, optimizer scalars) are copied by one block each.  Nothing of the launch's own outputs may
+ * alias them. */
+typedef struct dcv_resident_program {
+    int n; int count; dcv_resident_op op[DCV_RESIDENT_MAX_OPS];
+    const dcv_copy_jobs* mailbox; int x_job; int reserved;
+} dcv_resident_program;
 int dcv_resident_supported(const dcv_resident_program* p);           /* 1 when the resident kernel covers every op of the program */
 size_t dcv_resident_ws_bytes(void);
 int dcv_resident_forward(const dcv_resident_program* p, void* ws, size_t ws_bytes, void* stream);

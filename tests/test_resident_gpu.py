@@ -153,6 +153,35 @@ def test_replayed_graph_on_the_resident_path_tracks_eager(device, params):
     assert curves[0] == curves[1], curves
 
 
+def test_forward_launch_stages_the_batch_of_a_replayed_step(device, params):
+    """ A captured step on the resident path has no `dcv_indirect_copy` launch: the forward launch reads the batch through the mailbox (and copies labels and
+    optimizer scalars).  Batches the mailbox cannot point at (another memory layout: ordinary copy into the static tensor, job 0 then names that tensor)
+    and ones it can alternate; with `DCV_STAGE_IN_FORWARD` off the same steps go through the staging kernel: same losses, bit for bit. """
+    from deepcv_amd import modules, optim, resident
+    from deepcv_amd.meta.ignite_training import GraphedTrainStep, _setup_losses
+    g = torch.Generator().manual_seed(DATA_SEED)
+    batches = [(torch.randn(64, 3, 32, 32, generator=g).to(device), torch.randint(0, 10, (64,), generator=g).to(device)) for _ in range(6)]
+    batches[3] = (batches[3][0].to(memory_format=torch.channels_last), batches[3][1])
+    curves, staged = [], []
+    for fold in (None, False):
+        model = _model(params, 'image_classifier_model', device)
+        opt = optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-2)
+        losses, weights = _setup_losses(modules.CrossEntropyLoss(), None, device)
+        step = GraphedTrainStep(model, opt, losses, weights)
+        step._stage_in_forward = fold
+        got = []
+        for xb, yb in batches:
+            out, _ = step(xb, yb)
+            got.append(out['main_loss'].item())
+        torch.cuda.synchronize()
+        resident.check_status()
+        staged.append(step._stage_in_forward)
+        curves.append(got)
+        assert torch.equal(step.static_x, batches[-1][0]) and torch.equal(step.static_y, batches[-1][1])      # the static copies the backward pass reads
+    assert staged == [True, False]
+    assert curves[0] == curves[1], curves
+
+
 @pytest.mark.parametrize('which', ['forward', 'backward'])
 def test_a_block_which_never_arrives_is_reported_not_waited_for(device, params, which):
     """ The all-reduce's spins are bounded: with one block muted (test hook in the workspace's control words: it takes part in everything but never publishes
