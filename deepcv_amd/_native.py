@@ -121,6 +121,19 @@ class TensorList(ctypes.Structure):
                 ('state2', _c_void_p * MAX_TENSORS), ('state3', _c_void_p * MAX_TENSORS), ('numel', _c_int64 * MAX_TENSORS)]
 
 
+OPT_MAX_ITEMS, OPT_MAX_PREPS = 40, 24
+
+
+class OptItem(ctypes.Structure):
+    """ `dcv_opt_item` """
+    _fields_ = [('param', _c_void_p), ('grad', _c_void_p), ('state1', _c_void_p), ('state2', _c_void_p), ('numel', _c_int), ('prep_first', ctypes.c_short), ('prep_count', ctypes.c_short)]
+
+
+class AdamwPrepTable(ctypes.Structure):
+    """ `dcv_adamw_prep_table` """
+    _fields_ = [('items', _c_int), ('preps', _c_int), ('item', OptItem * OPT_MAX_ITEMS), ('prep', ctypes.c_ubyte * (OPT_MAX_PREPS * 88))]
+
+
 _P = _c_void_p
 _SIGNATURES = {
     # name: (restype, argtypes)
@@ -217,6 +230,8 @@ _SIGNATURES = {
     'dcv_optim_prepare': (_c_int, [_P, _P, _P]),
     'dcv_adamw_step': (_c_int, [ctypes.POINTER(TensorList), _P, _c_int, _P]),
     'dcv_sgd_step': (_c_int, [ctypes.POINTER(TensorList), _P, _c_int, _P]),
+    'dcv_adamw_prep_build': (_c_int, [ctypes.POINTER(TensorList), _c_int, _c_int, _P, _P, _P, _P, ctypes.POINTER(AdamwPrepTable)]),
+    'dcv_adamw_step_prep': (_c_int, [ctypes.POINTER(AdamwPrepTable), _P, _P]),
     'dcv_pack_grads': (_c_int, [ctypes.POINTER(TensorList), _P, _P]),
     'dcv_resident_supported': (_c_int, [ctypes.POINTER(ResidentProgram)]),
     'dcv_resident_ws_bytes': (_c_size_t, []),

@@ -3,6 +3,7 @@
 //   * direct convolution (conv2d_direct.hip) otherwise (the stock small-channel layers, and every shape as fallback).
 // Replaces torch.nn.Conv2d (reference src/deepcv/meta/submodule_creators.py:251) forward and autograd backward.
 #include "conv2d_internal.h"
+#include "optim_update.h"
 
 namespace {
 
@@ -23,6 +24,22 @@ inline bool desc_ok(const dcv_conv2d_desc* d) {
 __global__ __launch_bounds__(256) void prep_multi_kernel(dcv_prep_list l) {
     const dcv_prep_entry& e = l.e[blockIdx.y];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < e.total; i += gridDim.x * blockDim.x) e.dst[i] = dcv_prep_element(e, i);
+}
+
+// AdamW update of a whole tensor (or of a group of rows of a Linear weight) by ONE block, then — behind a block barrier — every prepared layout of that
+// tensor gathered from the updated values: dcv_adamw_step + dcv_conv2d_prepare_filters of a small parameter set in one launch.
+static_assert(sizeof(dcv_prep_entry) == 88, "dcv_adamw_prep_table reserves 88 bytes per prepared layout");
+__global__ __launch_bounds__(1024) void adamw_prep_kernel(dcv_adamw_prep_table t, const float* __restrict__ hyper) {
+    const dcv_opt_item& it = t.item[blockIdx.x];
+    const dcv_adamw_scalars sc = dcv_adamw_load_scalars(hyper);
+    for (int i = threadIdx.x; i < it.numel; i += 1024) dcv_adamw_update<false>(sc, it.param, it.grad, it.state1, it.state2, nullptr, i);
+    if (it.prep_count == 0) return;                                                  // block-uniform
+    __syncthreads();                                                                 // the block's stores are visible to its own gathers below
+    const dcv_prep_entry* preps = reinterpret_cast<const dcv_prep_entry*>(t.prep);
+    for (int q = 0; q < it.prep_count; ++q) {
+        const dcv_prep_entry& e = preps[it.prep_first + q];
+        for (int i = threadIdx.x; i < e.total; i += 1024) e.dst[i] = dcv_prep_element(e, i);
+    }
 }
 
 // op 2: the weight [O][C * H * W] of a Linear which follows a Flatten of [N][C][H][W] activations, re-laid as [O][H * W][C] so that the Linear reads the
@@ -142,6 +159,69 @@ int dcv_conv2d_prepare_filters(int count, const dcv_conv2d_desc* const* descs, c
         }
     }
     flush();
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_adamw_prep_build(const dcv_tensor_list* lists, int n_lists, int n_filters, const dcv_conv2d_desc* const* descs, const int* ops,
+                         const float* const* weights, void* const* filters, dcv_adamw_prep_table* out) {
+    DCV_CHECK_ARG(lists && n_lists > 0 && out && n_filters >= 0 && (n_filters == 0 || (descs && ops && weights && filters)));
+    dcv_adamw_prep_table t{};
+    dcv_prep_entry* preps = reinterpret_cast<dcv_prep_entry*>(t.prep);
+    bool used[256] = {false};
+    if (n_filters > 256) return DCV_ERR_UNSUPPORTED;
+    for (int li = 0; li < n_lists; ++li) {
+        const dcv_tensor_list& tl = lists[li];
+        DCV_CHECK_ARG(tl.count > 0 && tl.count <= DCV_MAX_TENSORS);
+        for (int k = 0; k < tl.count; ++k) {
+            DCV_CHECK_ARG(tl.param[k] && tl.grad[k] && tl.state1[k] && tl.state2[k] && tl.numel[k] > 0);
+            if (tl.state3[k]) return DCV_ERR_UNSUPPORTED;                            // amsgrad: the multi-tensor kernel
+            // the prepared layouts of this tensor
+            dcv_prep_entry mine[DCV_OPT_MAX_PREPS]; int nm = 0;
+            for (int f = 0; f < n_filters; ++f) {
+                if (weights[f] != tl.param[k]) continue;
+                DCV_CHECK_ARG(desc_ok(descs[f]) && ops[f] >= 0 && ops[f] <= 4 && filters[f]);
+                used[f] = true;
+                dcv_prep_entry pieces[DCV_PREP_PIECES];
+                const int np = prep_entries(descs[f], ops[f], pieces);
+                for (int q = 0; q < np; ++q) {
+                    if (pieces[q].total == 0) continue;
+                    if (nm == DCV_OPT_MAX_PREPS) return DCV_ERR_UNSUPPORTED;
+                    dcv_prep_entry e = pieces[q];
+                    e.w = tl.param[k]; e.dst = reinterpret_cast<float*>(filters[f]) + e.dst_off;
+                    mine[nm++] = e;
+                }
+            }
+            const long long numel = tl.numel[k];
+            // a Linear weight with its one row-wise layout splits into groups of rows (rows are independent); everything else is one block
+            const bool rows_split = numel > DCV_OPT_MAX_NUMEL && nm == 1 && mine[0].kind == 1 && !mine[0].dgrad && mine[0].kcout > 1 && numel % mine[0].kcout == 0
+                                    && numel / mine[0].kcout <= DCV_OPT_MAX_NUMEL && (long long)mine[0].total == numel;
+            if (numel > DCV_OPT_MAX_NUMEL && !rows_split) return DCV_ERR_UNSUPPORTED;
+            const long long row = rows_split ? numel / mine[0].kcout : numel;
+            const int rows_total = rows_split ? mine[0].kcout : 1, rows_per = rows_split ? (int)(DCV_OPT_MAX_NUMEL / row) : 1;
+            for (int r0 = 0; r0 < rows_total; r0 += rows_per) {
+                const int rows = r0 + rows_per <= rows_total ? rows_per : rows_total - r0;
+                if (t.items == DCV_OPT_MAX_ITEMS || t.preps + nm > DCV_OPT_MAX_PREPS) return DCV_ERR_UNSUPPORTED;
+                dcv_opt_item& it = t.item[t.items++];
+                const long long off = (long long)r0 * row;
+                it.param = tl.param[k] + off; it.grad = tl.grad[k] + off; it.state1 = tl.state1[k] + off; it.state2 = tl.state2[k] + off;
+                it.numel = (int)((long long)rows * row);
+                it.prep_first = (short)t.preps; it.prep_count = (short)nm;
+                for (int q = 0; q < nm; ++q) {
+                    dcv_prep_entry e = mine[q];
+                    if (rows_split) { e.w += off; e.dst += off; e.kcout = rows; e.total = it.numel; }
+                    preps[t.preps++] = e;
+                }
+            }
+        }
+    }
+    for (int f = 0; f < n_filters; ++f) if (!used[f]) return DCV_ERR_UNSUPPORTED;    // a filter of a weight which is not updated here would go stale
+    *out = t;
+    return DCV_OK;
+}
+
+int dcv_adamw_step_prep(const dcv_adamw_prep_table* table, const float* hyper, void* stream) {
+    DCV_CHECK_ARG(table && hyper && table->items > 0 && table->items <= DCV_OPT_MAX_ITEMS && table->preps >= 0 && table->preps <= DCV_OPT_MAX_PREPS);
+    hipLaunchKernelGGL(adamw_prep_kernel, dim3((unsigned)table->items), dim3(1024), 0, dcv_stream(stream), *table, hyper);
     DCV_RETURN_LAUNCH();
 }
 

@@ -8,6 +8,7 @@
 // Replaces torch.optim.AdamW (reference classification/image.py:71; options conf/base/parameters.yml:129-134), torch.optim.SGD
 // (parameters.yml:136) as called at ignite_training.py:254, and DDP's gradient bucketing (ignite_training.py:380).
 #include "common.h"
+#include "optim_update.h"
 
 namespace {
 
@@ -23,36 +24,20 @@ __global__ void optim_prepare_kernel(float* __restrict__ hyper, int64_t* __restr
     hyper[DCV_HYP_FIRST_STEP] = (s == 1) ? 1.f : 0.f;
 }
 
-// torch.optim.AdamW single-tensor semantics:  p *= 1 - lr*wd ; m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ;
-// denom = sqrt(v)/sqrt(bc2) + eps ; p -= (lr/bc1) * m / denom      (amsgrad: denom from max(v_max, v))
+// (the update itself: optim_update.h, shared with the update + filter re-layout kernel of conv2d.hip)
 template <bool AMSGRAD>
 __global__ __launch_bounds__(OPT_BLOCK) void adamw_kernel(dcv_tensor_list tl, const float* __restrict__ hyper) {
     const int t = blockIdx.y;
     const int64_t n = tl.numel[t];
     const int64_t base = (int64_t)blockIdx.x * OPT_ELEMS_PER_BLOCK;
     if (base >= n) return;
-    const float lr = hyper[DCV_HYP_LR], b1 = hyper[DCV_HYP_BETA1], b2 = hyper[DCV_HYP_BETA2], eps = hyper[DCV_HYP_EPS];
-    const float wd = hyper[DCV_HYP_WEIGHT_DECAY], gs = hyper[DCV_HYP_GRAD_SCALE];
-    const float bc1 = hyper[DCV_HYP_BIAS_CORR1], bc2_sqrt = sqrtf(hyper[DCV_HYP_BIAS_CORR2]);
-    const float step_size = lr / bc1;
+    const dcv_adamw_scalars sc = dcv_adamw_load_scalars(hyper);
     float* __restrict__ p = tl.param[t]; const float* __restrict__ g = tl.grad[t];
     float* __restrict__ m = tl.state1[t]; float* __restrict__ v = tl.state2[t]; float* __restrict__ vmax = tl.state3[t];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int64_t i = base + (int64_t)k * OPT_BLOCK + threadIdx.x;
-        if (i < n) {
-            const float gi = g[i] * gs;
-            float pi = p[i] * (1.f - lr * wd);
-            const float m0 = m[i];
-            const float mi = m0 + (1.f - b1) * (gi - m0);      // torch: exp_avg.lerp_(grad, 1 - beta1)
-            const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-            m[i] = mi; v[i] = vi;
-            float vden = vi;
-            if (AMSGRAD) { vden = fmaxf(vmax[i], vi); vmax[i] = vden; }
-            const float denom = sqrtf(vden) / bc2_sqrt + eps;
-            pi -= step_size * (mi / denom);
-            p[i] = pi;
-        }
+        if (i < n) dcv_adamw_update<AMSGRAD>(sc, p, g, m, v, vmax, i);
     }
 }
 

@@ -144,16 +144,25 @@ class RefreshTable:
         for w in self.params:
             _owner[id(w)] = (weakref.ref(w, lambda _r, k=id(w): _owner.pop(k, None)), self.clock)
 
-    def refresh(self, stream, capturing: bool = False):
+    def current_entries(self) -> List[Tuple[torch.Tensor, '_Entry']]:
+        """ The cached filters of this group's parameters which a refresh re-lays now. """
+        entries = []
+        for w in self.params:
+            for e in (_entries_of(w) or {}).values():
+                if e is not _NO_FILTER and e.epoch == _epoch and e.data_ptr == w.data_ptr() and e.version == w._version:
+                    entries.append((w, e))
+        return entries
+
+    def refresh(self, stream, capturing: bool = False, launched_by=None):
         """ Counts one weight update and re-lays every cached filter of the group in ONE launch.  `capturing`: the launch is being recorded into a graph;
-        the entries of this call table are the ones every replay refreshes (`replayed()`). """
+        the entries of this call table are the ones every replay refreshes (`replayed()`).  `launched_by`: the entries another launch has just re-laid
+        (the optimizer's update + re-layout kernel): only the bookkeeping happens here. """
         self.clock[0] = next(_tick)
-        if self.gen != _generation or self.table is None or capturing:
-            self.entries = []
-            for w in self.params:
-                for e in (_entries_of(w) or {}).values():
-                    if e is not _NO_FILTER and e.epoch == _epoch and e.data_ptr == w.data_ptr() and e.version == w._version:
-                        self.entries.append((w, e))
+        if launched_by is not None:
+            self.entries = list(launched_by)
+            self.gen, self.table = _generation, None
+        elif self.gen != _generation or self.table is None or capturing:
+            self.entries = self.current_entries()
             self.gen = _generation
             self.table = _prepare(self.entries, stream) if self.entries else None
         else:

@@ -512,6 +512,20 @@ typedef struct {
 int dcv_optim_prepare(float* hyper, int64_t* step, void* stream);
 int dcv_adamw_step(const dcv_tensor_list* tl, const float* hyper, int amsgrad, void* stream);
 int dcv_sgd_step(const dcv_tensor_list* tl, const float* hyper, int nesterov, void* stream);
+/* AdamW step AND the re-layout of the prepared filters of the updated weights in ONE launch, for small parameter sets (a captured training step of the
+ * stock classifier: 2 launches less).  A block owns a whole tensor (or a group of rows of a Linear weight): update, block barrier, then every prepared
+ * layout of that tensor (dcv_conv2d_prepare_filters ops 0 - 4) gathered from the updated values.  `dcv_adamw_prep_build` (host only) packs the tensors of
+ * `lists` and the filters (descs / ops / weights / filters as for dcv_conv2d_prepare_filters; every weight must be a `param` of the lists) into `out`;
+ * DCV_ERR_UNSUPPORTED when the set does not fit (more than DCV_OPT_MAX_ITEMS blocks, DCV_OPT_MAX_PREPS layouts, a tensor above DCV_OPT_MAX_NUMEL elements
+ * which cannot be split, amsgrad state).  Same arithmetic as dcv_adamw_step + dcv_conv2d_prepare_filters, bit for bit. */
+#define DCV_OPT_MAX_ITEMS 40
+#define DCV_OPT_MAX_PREPS 24
+#define DCV_OPT_MAX_NUMEL 4096
+typedef struct dcv_opt_item { float* param; const float* grad; float* state1; float* state2; int numel; short prep_first; short prep_count; } dcv_opt_item;
+typedef struct dcv_adamw_prep_table { int items; int preps; dcv_opt_item item[DCV_OPT_MAX_ITEMS]; unsigned char prep[DCV_OPT_MAX_PREPS * 88]; } dcv_adamw_prep_table;
+int dcv_adamw_prep_build(const dcv_tensor_list* lists, int n_lists, int n_filters, const dcv_conv2d_desc* const* descs, const int* ops,
+                         const float* const* weights, void* const* filters, dcv_adamw_prep_table* out);
+int dcv_adamw_step_prep(const dcv_adamw_prep_table* table, const float* hyper, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * C1 helper  gradient bucket pack for the data-parallel all-reduce (RCCL over xGMI is driven from Python through

@@ -142,6 +142,39 @@ def test_resident_program_validation_on_the_host():
     assert lib.dcv_resident_head_wgrad_supported(512, 1280, 13) == 0
 
 
+def test_adamw_prep_table_is_built_on_the_host():
+    """ `dcv_adamw_prep_build` packs tensors and prepared-filter layouts into the kernel-argument table of `dcv_adamw_step_prep`: one block per tensor, a
+    Linear weight with its row-wise layout split into groups of rows; sets which do not fit are refused (the caller then launches update and re-layout
+    separately). """
+    import ctypes
+    from deepcv_amd import _native as nat
+    lib = _native_lib()
+    tl = nat.TensorList()
+    tl.count = 3
+    for k, n in enumerate((300, 12800, 10)):
+        tl.param[k], tl.grad[k], tl.state1[k], tl.state2[k], tl.numel[k] = 4096 * (k + 1), 8192 * (k + 1), 16384 * (k + 1), 32768 * (k + 1), n
+    conv = nat.Conv2dDesc(); conv.n, conv.h, conv.w, conv.cin, conv.cout, conv.r, conv.s = 512, 32, 32, 3, 4, 5, 5
+    conv.stride_h = conv.stride_w = conv.dil_h = conv.dil_w = conv.groups = 1; conv.pad_h = conv.pad_w = 2; conv.ho = conv.wo = 32; conv.x_layout = nat.LAYOUT_NCHW
+    fc = nat.Conv2dDesc(); fc.n, fc.h, fc.w, fc.cin, fc.cout, fc.r, fc.s = 512, 8, 8, 20, 10, 8, 8
+    fc.stride_h = fc.stride_w = fc.dil_h = fc.dil_w = fc.groups = 1; fc.ho = fc.wo = 1; fc.x_layout = nat.LAYOUT_NHWC
+    descs = (ctypes.POINTER(nat.Conv2dDesc) * 2)(ctypes.pointer(conv), ctypes.pointer(fc))
+    ops = (ctypes.c_int * 2)(3, 2)
+    ws = (ctypes.c_void_p * 2)(4096, 8192)
+    bufs = (ctypes.c_void_p * 2)(1 << 20, 2 << 20)
+    table = nat.AdamwPrepTable()
+    lists = (nat.TensorList * 1)(tl)
+    assert lib.dcv_adamw_prep_build(lists, 1, 2, descs, ops, ws, bufs, ctypes.byref(table)) == 0
+    # conv weight: 1 block + 1 layout; the Linear weight: 3 rows of 1280 per block -> 4 blocks, each with its slice of the layout; the bias: 1 block
+    assert table.items == 6 and table.preps == 5
+    assert [table.item[i].numel for i in range(6)] == [300, 3840, 3840, 3840, 1280, 10]
+    assert table.item[2].param == 8192 + 4 * 3840 and table.item[2].prep_count == 1 and table.item[5].prep_count == 0
+    ws[1] = 12345                                                                   # a filter of a weight which is not in the lists: refused
+    assert lib.dcv_adamw_prep_build(lists, 1, 2, descs, ops, ws, bufs, ctypes.byref(table)) == nat.ERR_UNSUPPORTED
+    lists[0].numel[0] = 5000                                                        # a tensor above DCV_OPT_MAX_NUMEL which cannot be split
+    ws[1] = 8192
+    assert lib.dcv_adamw_prep_build(lists, 1, 2, descs, ops, ws, bufs, ctypes.byref(table)) == nat.ERR_UNSUPPORTED
+
+
 def _native_lib():
     from deepcv_amd import _native
     return _native.load()
