@@ -214,12 +214,17 @@ class GraphedTrainStep:
 
     # -- mailbox: batch pointers + optimizer scalars read by the graph's first kernel at run time (`dcv_indirect_copy`) ----------------------
     _MB_PAYLOAD = 256                                              # byte offset of the scalar payload inside the mailbox
+    _MB_COUNT_SEQ = 192                                            # ... of dcv_copy_jobs.count / .seq (behind 3 x 8 eight-byte words)
     _PUB_VALS, _PUB_SEQ = 768, 832                                 # byte offsets of the published loss values / their sequence number
 
     def _mailbox_init(self, dev):
         from .. import _native as nat
         self._nat = nat
         self.mailbox = torch.zeros(1024, dtype=torch.uint8).pin_memory()
+        # device shadow of the mailbox's (count, seq) words, filled by a copy job of every replay: the publishing cross-entropy launch reads the sequence
+        # number from there (a PCIe read less on its single block's critical path)
+        self._mb_dev = torch.zeros(256, dtype=torch.uint8, device=dev)
+        self._seq_shadowed = False
         self._mb = self.mailbox.numpy()                            # shares the pinned memory: plain CPU stores, no API call
         self._held = None
         # early loss read-back (`dcv_publish_scalars`): values at _PUB_VALS, sequence number at _PUB_SEQ of the same pinned block
@@ -253,6 +258,11 @@ class GraphedTrainStep:
                 struct.pack_into(f'<{len(vals)}f', self._mb, off, *vals)
                 src.append(self.mailbox.data_ptr() + off); dst.append(dev_buf.data_ptr()); nbytes.append(4 * len(vals))
                 off += 64
+        if len(src) < self._nat.MAX_COPY_JOBS:
+            src.append(self.mailbox.data_ptr() + self._MB_COUNT_SEQ); dst.append(self._mb_dev.data_ptr() + self._MB_COUNT_SEQ); nbytes.append(8)
+            self._seq_shadowed = True
+        else:
+            self._seq_shadowed = False
         n = len(src)
         assert n <= self._nat.MAX_COPY_JOBS and off <= self.mailbox.numel()
         pad = [0] * (self._nat.MAX_COPY_JOBS - n)
@@ -342,7 +352,8 @@ class GraphedTrainStep:
             # a single cross-entropy term publishes its value from its own launch (both names of `_batch_losses` are that one tensor): no publish launch
             fold = len(self.losses) == 1 and isinstance(next(iter(self.losses.values())), native.CrossEntropyLoss)
             if fold:
-                _ops.set_loss_publisher((self.mailbox.data_ptr(), self.mailbox.data_ptr() + self._PUB_VALS, self.mailbox.data_ptr() + self._PUB_SEQ, 2))
+                seq_src = self._mb_dev.data_ptr() if self._seq_shadowed else self.mailbox.data_ptr()
+                _ops.set_loss_publisher((seq_src, self.mailbox.data_ptr() + self._PUB_VALS, self.mailbox.data_ptr() + self._PUB_SEQ, 2))
             try:
                 self.static_losses = _batch_losses(self.losses, self.weights, self.static_pred, self.static_y)
                 published = _ops.last_published() if fold else None
