@@ -73,7 +73,7 @@ inline int prep_entries(const dcv_conv2d_desc* d, int op, dcv_prep_entry* out) {
         // (kind 2); otherwise the direct kernels' transposed + flipped layout with ONE tile [R][S][cout rounded up to 4][cin rounded up to 4]
         dcv_prep_entry e{};
         e.R = d->r; e.S = d->s; e.w_cin = d->cin; e.dgrad = 1; e.dst_off = 0;
-        if (d->cout == 16 && d->w == 16 && d->r == 3 && d->s == 3 && d->cin <= 16) {
+        if (d->cout == 16 && d->w == 16 && d->r == 3 && d->s == 3 && d->cin <= 16 && d->cin != 4) {      // (4 <- 16: the VALU variant reads the direct layout)
             e.kind = 2; e.kcout = d->cin; e.kcin = 16;
             e.total = 16 * 4 * 4 * 9;
         } else {

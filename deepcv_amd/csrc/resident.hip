@@ -772,8 +772,48 @@ constexpr size_t RB_SMEM = 2 * RS_XIN_BYTES + 2 * RS_Y_BYTES;          // + XT: 
 // data-gradient variant of a layer (forward cin -> cout, k): the forward kernels on the swapped channel counts
 __host__ __device__ __forceinline__ int rb_dgrad_variant(int cin, int cout, int k, int w) {
     if (cout <= 4 && cin == 4 && (k == 3 || k == 5)) return 1;                       // 4 <- 4: VALU row pairs
+    if (cout == 16 && cin == 4 && k == 3 && w == 16) return 4;                       // 4 <- 16: VALU, scalar-cache filter (on the matrix cores 3/4 of the MACs multiply zeros)
     if (cout == 16 && (cin == 16 || cin == 4) && k == 3 && w == 16) return 3;        // 16 / 4 <- 16: matrix cores
     return 0;
+}
+
+// 4 <- 16 channels, 3x3, 16 x 16 pixels (the data gradient of a 4 -> 16 layer): thread = (half of the 16 dz channels, sample, pixel); per (tap, channel
+// vector) one ds_read_b128 of dz and 16 wave-uniform filter scalars ([tap][dz channel 16][x channel 4]: dcv_conv2d_prepare_filters op 4, direct
+// layout) feed 16 FMAs; the two halves' partial sums meet in the DO region.  295 k FMAs per block instead of the 1.2 M MACs of the 16 <- 16 matrix-core tile.
+__device__ __forceinline__ void rb_dgrad_c16_co4(const float* filt, const float4* dzt, float* dor) {
+    constexpr int XH = 18, XW = 18;
+    const int t = threadIdx.x, hv = __builtin_amdgcn_readfirstlane(t >> 9), tt = t & 511, ss = __builtin_amdgcn_readfirstlane(tt >> 8), px = tt & 255, r = px >> 4, c = px & 15;
+    rs_cfloat* wl = RS_CONST(filt);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int ky = 0; ky < 3; ++ky) {
+        float4 dv[2][3];
+#pragma unroll
+        for (int cvl = 0; cvl < 2; ++cvl)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) dv[cvl][kx] = dzt[ss * RS_XIN + ((2 * hv + cvl) * XH + r + ky) * XW + c + kx];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int cvl = 0; cvl < 2; ++cvl) {
+                rs_cfloat* wt = wl + ((ky * 3 + kx) * 16 + (2 * hv + cvl) * 4) * 4;
+#pragma unroll
+                for (int co = 0; co < 4; ++co) {
+                    acc[co] = fmaf(dv[cvl][kx].x, wt[co], acc[co]);
+                    acc[co] = fmaf(dv[cvl][kx].y, wt[4 + co], acc[co]);
+                    acc[co] = fmaf(dv[cvl][kx].z, wt[8 + co], acc[co]);
+                    acc[co] = fmaf(dv[cvl][kx].w, wt[12 + co], acc[co]);
+                }
+            }
+    }
+    float4* out = reinterpret_cast<float4*>(dor + ss * RS_Y + hv * 1024);          // half 1: parked behind the sample's 256 x 4 results
+    out[px] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    rs_barrier();
+    if (t < 512) {
+        float4* o4 = reinterpret_cast<float4*>(dor + ss * RS_Y);
+        const float4 a = o4[px], b = o4[256 + px];
+        o4[px] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
 }
 
 // ---- weight gradients inside the backward launch.  A wave takes whole UNITS = (filter tap or filter row, sample slot) and walks all pixels of the
@@ -1392,6 +1432,7 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
             cv.cin = o.cout; cv.cout = o.cin; cv.k = o.k; cv.h = H; cv.w = W; cv.act = DCV_ACT_NONE; cv.filt = o.filt; cv.bias = nullptr;
             const int var = rb_dgrad_variant(o.cin, o.cout, o.k, o.w);
             if (var == 1) { if (o.k == 5) rs_conv_c4_co4<5>(cv, dzt, dor, s_dummy); else rs_conv_c4_co4<3>(cv, dzt, dor, s_dummy); }
+            else if (var == 4) rb_dgrad_c16_co4(o.filt, dzt, dor);
             else { float4 b4[9]; rs_load_bfrag_prepared(o.filt, b4); rs_conv_c16_mfma(cv, dzt, dor, b4, s_dummy); }
             rs_barrier();
             if (o.addend != nullptr || o.dx != nullptr) {
@@ -1444,6 +1485,7 @@ inline bool rb_program_ok(const dcv_resident_bwd_program* p) {
             const int var = rb_dgrad_variant(o.cin, o.cout, o.k, o.w);
             if (var == 0 || !o.filt) return false;
             if (var == 1 && ((o.h & 1) || (o.h >> 1) * o.w > 512)) return false;
+            if (var == 4 && o.h != 16) return false;
             if (o.h * o.w * o.cin > RS_Y || (o.cin & 3)) return false;
         } else if (i + 1 < p->count) return false;                   // only the last op (the model's first layer) may skip its data gradient
         if (i + 1 < p->count) {

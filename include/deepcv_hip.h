@@ -134,7 +134,7 @@ int dcv_conv2d_wgrad_fuses_bias(const dcv_conv2d_desc* d);
  *                               gradient comes back in [O][C*H*W] order through dcv_slab_segment.tr_a / tr_b)
  *                               op 3 = the forward filter of a layer of the LDS-resident network (dcv_resident_forward): [R][S][cin rounded up to 4][cout]
  *                               op 4 = its data-gradient filter (dcv_resident_backward): transposed + flipped [R][S][cout4][cin4], or the matrix-core
- *                               B fragments [16][4][4][9] for 3x3 layers with 16 output channels on rows of 16 pixels
+ *                               B fragments [16][4][4][9] for 3x3 layers with 16 output channels on rows of 16 pixels (and not 4 input channels: 4 <- 16 runs on the VALU from the first layout)
  *   dcv_conv2d_prepare_filters  re-lays out `count` filters (entries whose size is 0 are skipped; filters[k] may then be NULL)
  *   dcv_conv2d_*_prepared       as dcv_conv2d_fwd / dcv_conv2d_dgrad with the filter prepared for exactly this descriptor (w still required: fallback paths) */
 size_t dcv_conv2d_filter_bytes(const dcv_conv2d_desc* d, int op);
