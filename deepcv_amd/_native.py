@@ -275,13 +275,45 @@ def load() -> ctypes.CDLL:
     return _lib
 
 
+class LaunchRecorder:
+    """ Log of the library calls which launch on `stream` (raw handle) while it is active (`record_launches`): what a captured training step consists of,
+    for `GraphedTrainStep`'s launch-list replay.  `calls`: [(function, argument tuple, index of the stream argument)]; the argument objects (ctypes
+    structures passed by reference, arrays) stay alive with the log. """
+
+    def __init__(self, stream: int):
+        self.stream, self.calls = stream, []
+
+    def replay(self, stream: int):
+        for fn, args, k in self.calls:
+            rc = fn(*args[:k], stream, *args[k + 1:])
+            if rc != 0:
+                check(rc, f'replayed {fn.__name__}')
+
+
+_recorder: Optional[LaunchRecorder] = None
+
+
+def record_launches(recorder: Optional[LaunchRecorder]) -> Optional[LaunchRecorder]:
+    """ Switches the launch log on (`recorder`) / off (None); returns the previous one. """
+    global _recorder
+    prev, _recorder = _recorder, recorder
+    return prev
+
+
 class _LazyLib:
-    """ `lib.dcv_xxx(...)` resolves the symbol on first use. """
+    """ `lib.dcv_xxx(...)` resolves the symbol on first use.  Every call passes through a thin wrapper which feeds the active `LaunchRecorder`. """
 
     def __getattr__(self, name):
-        fn = getattr(load(), name)
-        setattr(self, name, fn)
-        return fn
+        raw = getattr(load(), name)
+
+        def call(*args, _raw=raw):
+            rec = _recorder
+            if rec is not None and args and isinstance(args[-1], int) and args[-1] == rec.stream and rec.stream:      # (the stream is every entry point's last argument)
+                rec.calls.append((_raw, args, len(args) - 1))
+            return _raw(*args)
+        call.__name__ = name
+        setattr(self, name, call)
+        return call
 
 
 lib = _LazyLib()

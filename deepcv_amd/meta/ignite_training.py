@@ -172,6 +172,10 @@ class GraphedTrainStep:
         self.calls = 0
         # None: the resident forward launch stages the batch when it runs (decided at capture); False (`DCV_STAGE_IN_FORWARD=0`): always dcv_indirect_copy
         self._stage_in_forward: Optional[bool] = False if os.environ.get('DCV_STAGE_IN_FORWARD', '1') in ('0', 'false', 'False') else None
+        # launch-list replay: on unless `DCV_REPLAY_LIST=0`; verified against the graph on the first replay (`_verify_launch_list`)
+        self._replay_list = os.environ.get('DCV_REPLAY_LIST', '1') not in ('0', 'false', 'False')
+        self._launch_list = None
+        self._list_verified = False
         self.graph_fb = self.graph_opt = None
         self.static_x = self.static_y = None
         self.static_losses: Optional['OrderedDict[str, torch.Tensor]'] = None
@@ -336,6 +340,10 @@ class GraphedTrainStep:
         # the capturing thread.  (The abort seen in the data-parallel rehearsal had another cause: the watchdog polling the end event of an eager step's
         # collective recorded on THIS stream just before the capture began -> `reducer.isolate`, deepcv_amd/parallel.py.)
         capture_mode = 'thread_local' if (self.reducer is not None or (torch.distributed.is_available() and torch.distributed.is_initialized())) else 'global'
+        # launch-list replay (`DCV_REPLAY_LIST=1`): the library calls of the captured step are logged while the graph is captured and re-issued as plain
+        # launches on every replay — the graph's memory pool keeps their buffers alive; a hipGraphLaunch costs ~9 us of idle GPU between two steps
+        recorder = self._nat.LaunchRecorder(self.stream.cuda_stream) if (self._replay_list and self.reducer is None) else None
+        prev_recorder = self._nat.record_launches(recorder)
         with torch.cuda.graph(self.graph_fb, stream=self.stream, capture_error_mode=capture_mode):
             if stage_in_forward:
                 _resident.set_staging((self.mailbox.data_ptr(), 0, self.static_x.data_ptr()))
@@ -379,6 +387,9 @@ class GraphedTrainStep:
                 self.reducer.enabled = hooks_were
                 self.reducer.finish()                                        # all-reduce captured on the capture stream; p.grad -> bucket views
                 self.optimizer.step()
+        self._nat.record_launches(prev_recorder)
+        # (short steps only: the ~9 us a graph launch costs matter to a 0.23 ms step, not to one of a hundred launches — and Python re-issues those slowly)
+        self._launch_list = recorder if (recorder is not None and 0 < len(recorder.calls) <= 32) else None
         if self.reducer is not None and not in_graph:
             self.reducer.enabled = hooks_were
             self._static_grads = [p.grad for p in self.reducer.params]       # graph-pool gradient tensors written by every replay
@@ -390,10 +401,53 @@ class GraphedTrainStep:
         if self.reducer is not None:
             self.reducer.isolate = False                                     # nothing captures on the callers' streams from here on
 
+    def _step_state(self) -> List[torch.Tensor]:
+        """ Every device tensor a replayed step reads AND writes: parameters, buffers, optimizer state, prepared filters. """
+        tensors = [p for p in self.model.parameters()] + [b for b in self.model.buffers()]
+        for st in self.optimizer.state.values():
+            tensors += [v for v in st.values() if isinstance(v, torch.Tensor) and v.is_cuda]
+        for table in getattr(self.optimizer, '_filter_tables', {}).values():
+            tensors += [e.buf for _, e in table.current_entries()]
+        return tensors
+
+    @torch.no_grad()
+    def _verify_launch_list(self, x, y) -> bool:
+        """ The first replay, twice from the same state: through the launch list, then through the graph.  The list only holds this library's launches; a
+        step which also runs other kernels (a loss built from torch operations, a module without a HIP kernel) leaves their outputs unwritten — the list
+        goes FIRST, on the graph pool's never-written buffers, so that nothing an earlier replay left there can stand in for them — and comes out
+        different: the graph then stays the replay mechanism.  Leaves the state of ONE step, computed by the graph. """
+        dev = x.device
+        state = self._step_state()
+        snapshot = [t.clone() for t in state]
+        self._mailbox_write(x, y)
+        self._launch_stream = torch.cuda.current_stream(dev)
+        self._launch_list.replay(self._launch_stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        by_list = [t.clone() for t in state] + [v.clone() for v in self.static_losses.values()]
+        for t, s0 in zip(state, snapshot):
+            t.data.copy_(s0)                                       # (.data: no version bump — the prepared-filter cache keys on the weights' versions)
+        self._mailbox_write(x, y)                                  # same step number, same scalars (nothing counted the first replay yet)
+        self.graph_fb.replay()
+        torch.cuda.synchronize(dev)
+        return all(torch.equal(a, b) for a, b in zip(by_list, state + list(self.static_losses.values())))
+
     def _replay(self, x, y):
+        if self._launch_list is not None and not self._list_verified:
+            self._list_verified = True
+            if not self._verify_launch_list(x, y):
+                logging.getLogger(__name__).info('deepcv_amd: the captured step runs kernels outside libdeepcv_hip: replaying it as a hipGraph')
+                self._launch_list = None
+            # (the verification replayed this very batch: the step is done)
+            self._launched_seq = None
+            if hasattr(self.optimizer, 'note_replayed'):
+                self.optimizer.note_replayed()
+            return OrderedDict((n, v.detach().clone()) for n, v in self.static_losses.items()), self.static_pred
         self._mailbox_write(x, y)
         self._launch_stream = torch.cuda.current_stream(x.device)
-        self.graph_fb.replay()
+        if self._launch_list is not None:
+            self._launch_list.replay(self._launch_stream.cuda_stream)
+        else:
+            self.graph_fb.replay()
         self._launched_seq = self._seq if self._publishes else None
         if not self._publishes:
             self._launch_stream.synchronize()                      # no early read-back: the mailbox may only be rewritten once this replay is done

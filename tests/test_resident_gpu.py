@@ -149,8 +149,37 @@ def test_replayed_graph_on_the_resident_path_tracks_eager(device, params):
         torch.cuda.synchronize()
         resident.check_status()
         assert resident.launches() > before
+        if graph:
+            # the step as a verified list of launches: forward, cross-entropy, the head's weight gradient (its own launch below 320 samples), backward,
+            # slab sums, AdamW + filters
+            assert step._launch_list is not None and len(step._launch_list.calls) == 6
         curves.append(got)
     assert curves[0] == curves[1], curves
+
+
+def test_launch_list_replay_is_dropped_when_the_step_runs_foreign_kernels(device, params):
+    """ A captured step is replayed as a list of this library's launches only after the first replay came out bit-identical through the graph and through
+    the list; a second loss term made of torch operations puts kernels into the graph which the list does not know: the graph stays the replay mechanism,
+    and the losses still track the eager steps. """
+    from deepcv_amd import modules, optim
+    from deepcv_amd.meta.ignite_training import GraphedTrainStep, _setup_losses
+    g = torch.Generator().manual_seed(DATA_SEED)
+    batches = [(torch.randn(64, 3, 32, 32, generator=g).to(device), torch.randint(0, 10, (64,), generator=g).to(device)) for _ in range(5)]
+    curves = []
+    for graph in (True, False):
+        model = _model(params, 'image_classifier_model', device)
+        opt = optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-2)
+        losses, weights = _setup_losses({'ce': modules.CrossEntropyLoss(), 'l2': lambda p, y: (p * p).mean()}, {'ce': 1.0, 'l2': 0.1}, device)
+        step = GraphedTrainStep(model, opt, losses, weights)
+        got = []
+        for xb, yb in batches:
+            out, _ = step(xb, yb) if graph else step._eager(xb, yb)
+            got.append(out['main_loss'].item())
+        torch.cuda.synchronize()
+        if graph:
+            assert step._list_verified and step._launch_list is None
+        curves.append(got)
+    assert all(abs(a - b) <= 1e-6 * abs(b) for a, b in zip(*curves)), curves
 
 
 def test_forward_launch_stages_the_batch_of_a_replayed_step(device, params):
