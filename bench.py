@@ -429,7 +429,8 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'CIFAR-10 stock image_classifier DeepcvModule (17010 params): fwd + CE + bwd + AdamW + piecewise-linear LR, per-step loss read-back',
                        'global_batch': world * BATCH_PER_GPU, 'image_shape': list(IMAGE_SHAPE), 'parallelism': f'dp{world}',
-                       'step_mode': 'eager' if args.eager else 'hipgraph-replay', 'final_loss': last},
+                       'step_mode': 'eager' if args.eager else ('launch-list replay of the captured step (verified against its hipGraph)' if getattr(step_fn, '_launch_list', None) is not None
+                                                                else 'hipgraph-replay'), 'final_loss': last},
             'roofline': roof,
         }
         if world == 1 and not args.no_cpu_baseline:

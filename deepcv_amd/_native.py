@@ -86,7 +86,7 @@ class ResidentOp(ctypes.Structure):
 
 class ResidentProgram(ctypes.Structure):
     """ `dcv_resident_program` """
-    _fields_ = [('n', _c_int), ('count', _c_int), ('op', ResidentOp * RESIDENT_MAX_OPS), ('mailbox', _c_void_p), ('x_job', _c_int), ('reserved', _c_int)]
+    _fields_ = [('n', _c_int), ('count', _c_int), ('op', ResidentOp * RESIDENT_MAX_OPS), ('mailbox', _c_void_p), ('x_job', _c_int), ('reserved', _c_int), ('batch', _c_void_p)]
 
 
 RESIDENT_BWD_MAX_OPS = 8

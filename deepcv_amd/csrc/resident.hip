@@ -467,7 +467,7 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
         float4 v4[SB]; float v1[SB];
         // a replayed step's batch: read through the address the host left in the mailbox for THIS replay, and kept in the static tensor for the backward pass
         const float* batch = o.x;
-        if (p.mailbox != nullptr) batch = reinterpret_cast<const float*>(p.mailbox->src[p.x_job]);
+        if (p.mailbox != nullptr) batch = p.batch != nullptr ? p.batch : reinterpret_cast<const float*>(p.mailbox->src[p.x_job]);
         const bool keep = p.mailbox != nullptr && batch != o.x && n < N;
         const float* src = batch + (size_t)(n < N ? n : 0) * HW * C;
         float* stat = const_cast<float*>(o.x) + (size_t)(n < N ? n : 0) * HW * C;
@@ -505,21 +505,6 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                         dst[(((c >> 2) * XH + r + pad) * XW + col + pad) * 4 + (c & 3)] = v1[k];
                     }
                 }
-            }
-        }
-        if (p.mailbox != nullptr) {
-            // the mailbox's other jobs (labels, optimizer scalars: a few KB): job j by block j % G
-            const int count = p.mailbox->count < DCV_MAX_COPY_JOBS ? p.mailbox->count : DCV_MAX_COPY_JOBS;
-            for (int j = 0; j < count; ++j) {
-                if (j == p.x_job || j % G != (int)blockIdx.x) continue;
-                const char* js = reinterpret_cast<const char*>(p.mailbox->src[j]);
-                char* jd = reinterpret_cast<char*>(p.mailbox->dst[j]);
-                const size_t bytes = (size_t)p.mailbox->bytes[j];
-                if (!js || !jd || js == jd) continue;
-                const bool v16 = (((reinterpret_cast<uintptr_t>(js) | reinterpret_cast<uintptr_t>(jd)) & 15) == 0);
-                const size_t n16 = v16 ? bytes / 16 : 0;
-                for (size_t i = t; i < n16; i += RS_T) reinterpret_cast<uint4*>(jd)[i] = reinterpret_cast<const uint4*>(js)[i];
-                for (size_t i = n16 * 16 + t; i < bytes; i += RS_T) jd[i] = js[i];
             }
         }
     }
@@ -578,7 +563,25 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
             }
             stamp();
             if (o.bn) {
-                if (!rs_allreduce(go, go + RS_MAXQ * RS_MAXG, epoch, 2 * C, G, mine, s_tot, s_red, s_w32, &s_fail, false, mute)) {
+                rs_allreduce_publish(go, epoch, 2 * C, mine, mute);
+                if (oi == 0 && p.mailbox != nullptr) {
+                    // the mailbox's other jobs (labels, optimizer scalars: a few KB) travel while the first layer's partial sums do: job j by a block which
+                    // owns no quantity of the all-reduce (blocks 32 ..: nobody waits for them), or by block j when the grid is that small.  The reads of
+                    // the pinned host block (PCIe) are on nobody's critical path; the next launch of the step is their first consumer.
+                    const int count = p.mailbox->count < DCV_MAX_COPY_JOBS ? p.mailbox->count : DCV_MAX_COPY_JOBS;
+                    for (int j = 0; j < count; ++j) {
+                        if (j == p.x_job || (G >= RS_MAXQ + DCV_MAX_COPY_JOBS ? RS_MAXQ + j : j % G) != (int)blockIdx.x) continue;
+                        const char* js = reinterpret_cast<const char*>(p.mailbox->src[j]);
+                        char* jd = reinterpret_cast<char*>(p.mailbox->dst[j]);
+                        const size_t bytes = (size_t)p.mailbox->bytes[j];
+                        if (!js || !jd || js == jd) continue;
+                        const bool v16 = (((reinterpret_cast<uintptr_t>(js) | reinterpret_cast<uintptr_t>(jd)) & 15) == 0);
+                        const size_t n16 = v16 ? bytes / 16 : 0;
+                        for (size_t i = t; i < n16; i += RS_T) reinterpret_cast<uint4*>(jd)[i] = reinterpret_cast<const uint4*>(js)[i];
+                        for (size_t i = n16 * 16 + t; i < bytes; i += RS_T) jd[i] = js[i];
+                    }
+                }
+                if (!rs_allreduce(go, go + RS_MAXQ * RS_MAXG, epoch, 2 * C, G, mine, s_tot, s_red, s_w32, &s_fail, true, mute)) {
                     // a block of this grid is not resident: report, poison the logits, leave
                     if (t == 0) { __hip_atomic_store((rs_gu32*)(ctl + 1), (unsigned)oi + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                     for (int k = 0; k < p.count; ++k)
@@ -1515,7 +1518,7 @@ inline bool rs_layer_ok(const dcv_resident_op& o, bool first) {
 inline bool rs_program_ok(const dcv_resident_program* p) {
     if (!p || p->n <= 0 || p->n > RS_SPB * RS_MAXG || p->count <= 0 || p->count > DCV_RESIDENT_MAX_OPS) return false;
     if (p->op[0].kind != DCV_RES_LAYER || !p->op[0].x) return false;
-    if (p->mailbox && (p->x_job < 0 || p->x_job >= DCV_MAX_COPY_JOBS)) return false;
+    if (p->mailbox && (p->x_job < 0 || p->x_job >= DCV_MAX_COPY_JOBS || !p->op[0].bn)) return false;      // (the other jobs are copied in the first layer's all-reduce wait)
     int c = 0, h = 0, w = 0;                                      // the current tensor
     for (int i = 0; i < p->count; ++i) {
         const dcv_resident_op& o = p->op[i];

@@ -127,18 +127,25 @@ def _verdict_slot(module) -> Dict[tuple, str]:
 
 _staging: Optional[tuple] = None          # (mailbox address, index of the batch's job, address of the static input tensor) while a training step is captured
 _staging_consumed = False
+_staged_program = None                    # the program of the launch which took the mailbox (kept for launch-list replays: its `batch` field is theirs to set)
 
 
 def set_staging(spec: Optional[tuple]):
     """ `spec = (mailbox, x_job, static_x_ptr)` (`GraphedTrainStep`): the next recorded forward whose input IS that static tensor reads the batch through the
     mailbox itself and copies the mailbox's other jobs (`dcv_resident_program.mailbox`): the step then has no `dcv_indirect_copy` launch.  `None` switches it
     off; `staging_consumed()` tells whether a launch took the mailbox since the last `set_staging`. """
-    global _staging, _staging_consumed
-    _staging, _staging_consumed = spec, False
+    global _staging, _staging_consumed, _staged_program
+    _staging, _staging_consumed, _staged_program = spec, False, None
 
 
 def staging_consumed() -> bool:
     return _staging_consumed
+
+
+def staged_program():
+    """ The `ResidentProgram` (host structure, copied into the kernel arguments at every launch) of the launch which took the mailbox since the last
+    `set_staging`: a caller which re-issues that launch itself may set its `batch` field to the address of the coming batch. """
+    return _staged_program if _staging_consumed else None
 
 
 def wanted(module, x) -> bool:
@@ -341,12 +348,13 @@ class Recorder:
         if not lib.dcv_resident_supported(prog):
             raise Ineligible('the recorded program is not covered by the resident kernel')
         global _staging_consumed
-        if _staging is not None and not _staging_consumed and prog.op[0].x == _staging[2]:
+        if _staging is not None and not _staging_consumed and prog.op[0].x == _staging[2] and prog.op[0].bn:
             prog.mailbox, prog.x_job = _staging[0], _staging[1]          # the launch stages its batch (and the step's labels / scalars) itself
         ws = _workspace(self.device)
         nat.check(lib.dcv_resident_forward(prog, ws.data_ptr(), ws.numel(), nat.current_stream(self.device)), 'dcv_resident_forward')
         if prog.mailbox:
-            _staging_consumed = True
+            global _staged_program
+            _staging_consumed, _staged_program = True, prog
         _launches += 1
         if capture_programs:
             last_programs['forward'] = (prog, ws, list(self.keep))

@@ -580,11 +580,13 @@ typedef struct dcv_resident_op {
 } dcv_resident_op;
 /* `mailbox` (nullable) folds the batch staging of a replayed training step (dcv_indirect_copy) into the launch: the first op's input is read from
  * mailbox->src[x_job] — the address the host wrote for THIS replay — instead of op[0].x, and also stored to op[0].x (= mailbox->dst[x_job], the static tensor
- * the backward pass reads); the mailbox's other jobs (labels, optimizer scalars) are copied by one block each.  Nothing of the launch's own outputs may
- * alias them. */
+ * the backward pass reads); the mailbox's other jobs (labels, optimizer scalars) are copied by one block each while the first layer's batch sums travel (that layer
+ * must have BatchNorm).  Nothing of the launch's own outputs may alias them. */
 typedef struct dcv_resident_program {
     int n; int count; dcv_resident_op op[DCV_RESIDENT_MAX_OPS];
     const dcv_copy_jobs* mailbox; int x_job; int reserved;
+    const float* batch;                /* nullable; with `mailbox`: the batch's address when the host knows it at launch time (a re-issued launch: no read of
+                                          mailbox->src[x_job] over PCIe on every block's critical path) */
 } dcv_resident_program;
 int dcv_resident_supported(const dcv_resident_program* p);           /* 1 when the resident kernel covers every op of the program */
 size_t dcv_resident_ws_bytes(void);
