@@ -674,11 +674,11 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                 }
             };
             if (oi + 1 < p.count && p.op[oi + 1].kind == DCV_RES_LAYER && rs_variant(p.op[oi + 1].cin, p.op[oi + 1].cout, p.op[oi + 1].k, p.op[oi + 1].w) == 3) {
-                // the next layer runs on the matrix cores: its B fragments are requested before this step's stores (a global round trip nothing waits
-                // for), and its convolution runs right here so that the 36 registers do not live across the op loop
-                float4 b4[9];
-                rs_load_bfrag(p.op[oi + 1].filt, b4);
+                // the next layer runs on the matrix cores: its B fragments are requested behind this step, and its convolution runs right here so that the
+                // 36 registers do not live across the op loop
                 apply_step();
+                float4 b4[9];
+                rs_load_bfrag(p.op[oi + 1].filt, b4);       // (requested in FRONT of the apply step, the 36 registers slowed its loops from 2.2 to 5.3 us)
                 rs_barrier();
                 stamp();
                 sums_done = rs_conv_c16_mfma(p.op[oi + 1], xin, yt, b4, s_wsum);
