@@ -107,7 +107,9 @@ class ResidentBwdHead(ctypes.Structure):
     _fields_ = [('enabled', _c_int), ('classes', _c_int), ('act', _c_int), ('slope', _c_float), ('h', _c_int), ('w', _c_int), ('cc', _c_int), ('cr', _c_int),
                 ('ref_h', _c_int), ('ref_w', _c_int), ('align_corners', _c_int), ('reserved', _c_int),
                 ('dlogits', _c_void_p), ('logits', _c_void_p), ('wp', _c_void_p), ('dref', _c_void_p),
-                ('fc_x', _c_void_p), ('fc_dw', _c_void_p), ('fc_db', _c_void_p)]
+                ('fc_x', _c_void_p), ('fc_dw', _c_void_p), ('fc_db', _c_void_p),
+                ('ce_target', _c_void_p), ('ce_loss', _c_void_p), ('ce_lse', _c_void_p), ('ce_correct', _c_void_p),
+                ('pub_mailbox', _c_void_p), ('pub_vals', _c_void_p), ('pub_seq', _c_void_p), ('pub_slots', _c_int), ('reserved2', _c_int)]
 
 
 class ResidentBwdProgram(ctypes.Structure):

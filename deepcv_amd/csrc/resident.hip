@@ -1100,12 +1100,22 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
     const int fc_pg = (p.head.enabled && p.head.fc_dw != nullptr) ? rb_fc_group(p.head.h * p.head.w * (p.head.cc + p.head.cr)) : -1;
     float4 fc_x4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float fc_g[RB_FC_DZ_SLOTS], fc_l[RB_FC_DZ_SLOTS];
-    const bool stage_dz = p.head.enabled && p.head.fc_dw != nullptr;               // every block: its own samples' dl (the head's data gradient) comes from there too
+    const bool ce_here = p.head.enabled && p.head.ce_target != nullptr;            // the step's cross-entropy is computed by this launch (row t by thread t)
+    const bool stage_dz = p.head.enabled && (p.head.fc_dw != nullptr || ce_here);  // every block: its own samples' dl (the head's data gradient) comes from there too
+    long long ce_t = 0;
     if (stage_dz) {
         const int K = p.head.h * p.head.w * (p.head.cc + p.head.cr), total = N * p.head.classes;
         if (fc_pg >= 0 && tt < N) fc_x4 = *reinterpret_cast<const float4*>(p.head.fc_x + (size_t)tt * K + fc_pg * 8 + s_of_t * 4);
+        if (ce_here) {
+            // the sample's logits: slots 0 .. 11 of (fc_g, fc_l)
+            const int O = p.head.classes, row = t < N ? t : 0;
 #pragma unroll
-        for (int k = 0; k < RB_FC_DZ_SLOTS; ++k) { const int i = t + k * RS_T; fc_g[k] = p.head.dlogits[i < total ? i : 0]; fc_l[k] = p.head.logits ? p.head.logits[i < total ? i : 0] : 0.f; }
+            for (int k = 0; k < RB_FC_DZ_SLOTS; ++k) { fc_g[k] = p.head.logits[(size_t)row * O + (k < O ? k : 0)]; fc_l[k] = p.head.logits[(size_t)row * O + (RB_FC_DZ_SLOTS + k < O ? RB_FC_DZ_SLOTS + k : 0)]; }
+            ce_t = p.head.ce_target[row];
+        } else {
+#pragma unroll
+            for (int k = 0; k < RB_FC_DZ_SLOTS; ++k) { const int i = t + k * RS_T; fc_g[k] = p.head.dlogits[i < total ? i : 0]; fc_l[k] = p.head.logits ? p.head.logits[i < total ? i : 0] : 0.f; }
+        }
     }
     {   // per-channel parameters of every layer -> LDS; y and dout of the first op (the last layer) -> LDS
         float pv = 0.f; int pslot = -1;
@@ -1129,10 +1139,56 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         float* staged = reinterpret_cast<float*>(dzt);
         const int total = N * p.head.classes;
         reinterpret_cast<float4*>(staged + 512 * RB_FC_MAXO)[t] = fc_x4;
+        if (ce_here) {
+            // softmax cross-entropy of row t, the arithmetic of ce_fwd_single_kernel (linear_loss.hip) expression by expression: the loss and its gradient
+            // must not depend on which launch computes them
+            const int O = p.head.classes;
+            double l = 0.0; int ok = 0;
+            float lse = 0.f;
+            if (t < N) {
+                float v[2 * RB_FC_DZ_SLOTS];
 #pragma unroll
-        for (int k = 0; k < RB_FC_DZ_SLOTS; ++k) {
-            const int i = t + k * RS_T;
-            if (i < total) staged[i] = p.head.logits ? fc_g[k] * dcv_act_grad_from_out(fc_l[k], p.head.act, p.head.slope) : fc_g[k];
+                for (int k = 0; k < RB_FC_DZ_SLOTS; ++k) { v[k] = k < O ? fc_g[k] : -INFINITY; v[RB_FC_DZ_SLOTS + k] = RB_FC_DZ_SLOTS + k < O ? fc_l[k] : -INFINITY; }
+                float m = -INFINITY; int mi = 0x7fffffff;
+#pragma unroll
+                for (int c = 0; c < 2 * RB_FC_DZ_SLOTS; ++c) if (c < O && (v[c] > m || (v[c] != v[c]))) { m = v[c]; mi = c; }
+                float sexp = 0.f, zt = 0.f;
+#pragma unroll
+                for (int c = 0; c < 2 * RB_FC_DZ_SLOTS; ++c) if (c < O) { sexp += expf(v[c] - m); if ((long long)c == ce_t) zt = v[c]; }
+                lse = m + logf(sexp);
+                const float g = 1.f / (float)N;
+#pragma unroll
+                for (int c = 0; c < 2 * RB_FC_DZ_SLOTS; ++c)
+                    if (c < O) staged[t * O + c] = ((expf(v[c] - lse) - ((long long)c == ce_t ? 1.f : 0.f)) * g) * dcv_act_grad_from_out(v[c], p.head.act, p.head.slope);
+                l = (double)(lse - zt);
+                ok = (mi == (int)ce_t) ? 1 : 0;
+            }
+            l = dcv_wave_sum(l); ok = dcv_wave_sum(ok);
+            if (lane == 0) { s_tot[wave] = l; s_w32[wave] = (unsigned)ok; }
+            rs_barrier();
+            const bool writer = blockIdx.x == (G > RS_MAXQ + DCV_MAX_COPY_JOBS ? (unsigned)(RS_MAXQ + DCV_MAX_COPY_JOBS) : 0u);     // a block which owns no all-reduce quantity
+            if (writer) {
+                if (t < N && p.head.ce_lse != nullptr) p.head.ce_lse[t] = lse;
+                if (t == 0) {
+                    double sum = 0.0; int k = 0;
+                    for (int i = 0; i < 16; ++i) { sum += s_tot[i]; k += (int)s_w32[i]; }
+                    const float value = (float)(sum / (double)N);
+                    p.head.ce_loss[0] = value;
+                    if (p.head.ce_correct != nullptr) p.head.ce_correct[0] = k;
+                    if (p.head.pub_seq != nullptr) {                                 // early read-back, as dcv_cross_entropy_fwd_grad_publish
+                        for (int i = 0; i < p.head.pub_slots; ++i) p.head.pub_vals[i] = value;
+                        __threadfence_system();
+                        *reinterpret_cast<volatile int*>(p.head.pub_seq) = p.head.pub_mailbox->seq;
+                        __threadfence_system();
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < RB_FC_DZ_SLOTS; ++k) {
+                const int i = t + k * RS_T;
+                if (i < total) staged[i] = p.head.logits ? fc_g[k] * dcv_act_grad_from_out(fc_l[k], p.head.act, p.head.slope) : fc_g[k];
+            }
         }
     }
     if (stage_dz) rs_barrier();
@@ -1464,10 +1520,12 @@ inline bool rb_program_ok(const dcv_resident_bwd_program* p) {
         const dcv_resident_bwd_op& o = p->op[0];
         const int pk = o.pool > 0 ? o.pool : 1;
         if (hd.classes <= 0 || hd.classes > 16 || hd.cc != o.cout || hd.h != o.h / pk || hd.w != o.w / pk || hd.cr <= 0 || hd.ref_h <= 0 || hd.ref_w <= 0) return false;
-        if (hd.h * hd.w * hd.cr > RS_Y || hd.ref_h * hd.ref_w * hd.cr > 16 * RS_Y || !hd.dlogits || !hd.wp || !hd.dref || hd.act < DCV_ACT_NONE || hd.act > DCV_ACT_TANH) return false;
+        if (hd.h * hd.w * hd.cr > RS_Y || hd.ref_h * hd.ref_w * hd.cr > 16 * RS_Y || !hd.wp || !hd.dref || hd.act < DCV_ACT_NONE || hd.act > DCV_ACT_TANH) return false;
         if (hd.act != DCV_ACT_NONE && !hd.logits) return false;
         if ((size_t)(hd.ref_h + hd.ref_w) * RB_TAPS * 8 + (size_t)RS_SPB * RS_Y * 4 > (size_t)RS_SPB * RS_XIN * 16 || hd.ref_h + hd.ref_w > RS_T) return false;
         if (!rb_resize_taps_ok(hd.ref_h, hd.h, hd.align_corners) || !rb_resize_taps_ok(hd.ref_w, hd.w, hd.align_corners)) return false;
+        if (hd.ce_target && (!hd.logits || !hd.ce_loss || p->n > 512 || hd.classes > RB_FC_MAXO || (hd.pub_seq && (!hd.pub_mailbox || !hd.pub_vals || hd.pub_slots <= 0 || hd.pub_slots > DCV_MAX_COPY_JOBS)))) return false;
+        if (!hd.ce_target && !hd.dlogits) return false;
         if (hd.fc_dw && (!hd.fc_x || !rb_fc_wgrad_ok(p->n, hd.h * hd.w * (hd.cc + hd.cr), hd.classes))) return false;
     } else if (!p->op[0].dout) return false;
     for (int i = 0; i < p->count; ++i) {

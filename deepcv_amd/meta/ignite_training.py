@@ -366,11 +366,13 @@ class GraphedTrainStep:
             if fold:
                 seq_src = self._mb_dev.data_ptr() if self._seq_shadowed else self.mailbox.data_ptr()
                 _ops.set_loss_publisher((seq_src, self.mailbox.data_ptr() + self._PUB_VALS, self.mailbox.data_ptr() + self._PUB_SEQ, 2))
+            _ops.defer_cross_entropy(fold)                 # ... and, on the LDS-resident path, leaves the loss itself to the backward launch
             try:
                 self.static_losses = _batch_losses(self.losses, self.weights, self.static_pred, self.static_y)
                 published = _ops.last_published() if fold else None
             finally:
                 _ops.set_loss_publisher(None)
+                _ops.defer_cross_entropy(False)
             terms = [v.reshape(1) if v.dim() == 0 else v for v in self.static_losses.values()]
             if published is not None:
                 if len(terms) > 2 or any(t.data_ptr() != published.data_ptr() for t in terms):      # (one name or two for the one tensor: both slots carry it)
@@ -384,6 +386,9 @@ class GraphedTrainStep:
                 self._publishes = True
             main = self.static_losses[MAIN_TRAINING_LOSS_NAME]
             main.backward(gradient=self._seed if main.shape == self._seed.shape else None)   # preallocated seed: no ones-fill kernel per replay
+            pending_plan = getattr(getattr(self.static_pred, 'grad_fn', None), 'res_plan', None)
+            if pending_plan is not None:
+                _ops.flush_deferred_cross_entropy(pending_plan)                # (a deferred loss nobody took: cannot happen behind a backward pass; cheap to be sure)
             in_graph = self.reducer is not None and self.graph_collective and self.reducer.capturable()
             if self.reducer is None:
                 self.optimizer.step()

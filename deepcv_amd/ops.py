@@ -1210,6 +1210,10 @@ class _LinearNhwcFn(torch.autograd.Function):
         deferred = need_w and slabs.may_defer(ctx.weight_ref, ctx.bias_ref)
         if deferred and dx_arg is None and ctx.needs_input_grad[1] and plan.head_wgrad(x, dw, db, n, k, o):
             return dx, dw, db, None, None    # the launch also computes the final dw / db (buffers passed by address: the engine must stay their sole owner)
+        if plan is not None and plan.pending_ce is not None:
+            # a loss deferred to the backward launch, but the kernels below read dy from memory before that launch runs: the loss kernel now, after all
+            plan.drop_head_cross_entropy()
+            flush_deferred_cross_entropy(plan)
         ws = _ws(lib.dcv_linear_bwd_workspace_bytes(n, k, o), dev)
         if deferred:
             segs, ns = (nat.SlabSegment * 2)(), ctypes.c_int(0)
@@ -1275,6 +1279,35 @@ def last_published() -> Optional[torch.Tensor]:
     return _last_published() if _last_published is not None else None
 
 
+_ce_deferral = False                  # set by a training step which captures model + loss + backward in one go: see `defer_cross_entropy`
+
+
+def defer_cross_entropy(on: bool):
+    """ While on, a cross-entropy whose logits are the output of a recorded LDS-resident forward with a fully connected head launches NOTHING: the
+    persistent backward launch computes loss, d loss / d logits and the early read-back itself (`dcv_resident_bwd_head.ce_target`).  The loss tensor is
+    only filled once that launch has run — the caller must run `backward()` right away, with the registered unit gradient (`GraphedTrainStep._capture`);
+    whatever else happens (another upstream gradient, a backward pass which does not take the recorded path, none at all: `flush_deferred_cross_entropy`)
+    launches the loss kernel late but correctly. """
+    global _ce_deferral
+    _ce_deferral = bool(on)
+
+
+def flush_deferred_cross_entropy(plan):
+    """ Launches the cross-entropy a resident plan still holds (nobody took it into the backward launch). """
+    ce = getattr(plan, 'pending_ce', None)
+    if ce is None:
+        return
+    plan.pending_ce = None
+    logits, target, loss, lse, correct, dz, pub = ce['logits'], ce['target'], ce['loss'], ce['lse'], ce['correct'], ce['dz'], ce['pub']
+    n, c = logits.shape
+    ws = _ws(lib.dcv_cross_entropy_workspace_bytes(n), logits.device)
+    produced, published = ctypes.c_int(0), ctypes.c_int(0)
+    pub = pub if pub is not None else (None, None, None, 0)
+    nat.check(lib.dcv_cross_entropy_fwd_grad_publish(logits.data_ptr(), target.data_ptr(), loss.data_ptr(), lse.data_ptr(), nat.ptr(correct), nat.ptr(dz),
+                                                     ctypes.byref(produced), n, c, ws.data_ptr(), ws.numel(), pub[0], pub[1], pub[2], pub[3],
+                                                     ctypes.byref(published), nat.current_stream(logits.device)), 'dcv_cross_entropy_fwd_grad_publish')
+
+
 class _CrossEntropyFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target, correct_out):
@@ -1287,6 +1320,19 @@ class _CrossEntropyFn(torch.autograd.Function):
         dev = logits.device
         loss = torch.empty((), dtype=torch.float32, device=dev)
         lse = torch.empty(n, dtype=torch.float32, device=dev)
+        ctx.deferred = None
+        if _ce_deferral and _unit_seeds and ctx.needs_input_grad[0] and n <= 512 and c <= 12:
+            plan = getattr(logits.grad_fn, 'res_plan', None) if logits.grad_fn is not None else None
+            if plan is not None and plan.can_take_cross_entropy(logits):
+                # nothing is launched: the persistent backward launch computes the loss from these logits (deepcv_amd/resident.py)
+                dz = torch.empty_like(logits)
+                plan.pending_ce = {'logits': logits, 'target': target, 'loss': loss, 'lse': lse, 'correct': correct_out, 'dz': dz, 'pub': _loss_publisher}
+                if _loss_publisher is not None:
+                    global _last_published
+                    _last_published = weakref.ref(loss)
+                ctx.deferred, ctx.dz_unit = plan, dz
+                ctx.save_for_backward(logits, target, lse)
+                return loss
         ws = _ws(lib.dcv_cross_entropy_workspace_bytes(n), dev)
         # when a unit root gradient is registered (hipGraph training step) the forward launch also leaves d loss / d logits for an upstream gradient of 1
         dz_unit = torch.empty_like(logits) if (_unit_seeds and ctx.needs_input_grad[0]) else None
@@ -1296,7 +1342,6 @@ class _CrossEntropyFn(torch.autograd.Function):
                                                          ctypes.byref(produced), n, c, ws.data_ptr(), ws.numel(), pub[0], pub[1], pub[2], pub[3],
                                                          ctypes.byref(published), nat.current_stream(dev)), 'dcv_cross_entropy_fwd_grad_publish')
         if published.value:
-            global _last_published
             _last_published = weakref.ref(loss)
         ctx.dz_unit = dz_unit if produced.value else None
         ctx.save_for_backward(logits, target, lse)
@@ -1306,6 +1351,10 @@ class _CrossEntropyFn(torch.autograd.Function):
     def backward(ctx, dloss):
         logits, target, lse = ctx.saved_tensors
         n, c = logits.shape
+        if ctx.deferred is not None:
+            if _is_unit_gradient(dloss) and ctx.deferred.pending_ce is not None:
+                return ctx.dz_unit, None, None          # unfilled: the head of the persistent backward launch recognises it (or flushes the loss kernel first)
+            flush_deferred_cross_entropy(ctx.deferred)  # another upstream gradient: the loss kernel now, the gradient kernel below
         if ctx.dz_unit is not None and _is_unit_gradient(dloss):
             return ctx.dz_unit, None, None
         dloss = dloss.contiguous().to(torch.float32)

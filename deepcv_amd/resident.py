@@ -108,6 +108,7 @@ def reads_oihw(d: nat.Conv2dDesc) -> bool:
 _wgrad_in_launch = os.environ.get('DCV_RESIDENT_WGRAD', '1') not in ('0', 'false', 'False', '')
 _head_in_launch = os.environ.get('DCV_RESIDENT_HEAD', '1') not in ('0', 'false', 'False', '')
 _head_wgrad_in_launch = os.environ.get('DCV_RESIDENT_HEAD_WGRAD', '1') not in ('0', 'false', 'False', '')
+_ce_in_backward = os.environ.get('DCV_CE_IN_BACKWARD', '1') not in ('0', 'false', 'False', '')
 
 
 def wgrad_in_launch(d: nat.Conv2dDesc) -> bool:
@@ -331,7 +332,8 @@ class Recorder:
         self.ops.append(op)
         self.keep.extend(t for t in (x, wp, bias, y) if t is not None)
         self.cur = y
-        self.plan.fc = {'classes': y.shape[1], 'act': act, 'slope': slope, 'follows_link': len(self.ops) >= 2 and self.ops[-2].kind == nat.RES_LINK}
+        self.plan.fc = {'classes': y.shape[1], 'act': act, 'slope': slope, 'follows_link': len(self.ops) >= 2 and self.ops[-2].kind == nat.RES_LINK,
+                        'out_ptr': y.data_ptr()}
 
     # ---- the launch
     def finish(self, result):
@@ -383,6 +385,7 @@ class BackwardPlan:
         self.fc: Optional[dict] = None
         self.head: Optional[nat.ResidentBwdHead] = None
         self.head_dx: Optional[torch.Tensor] = None
+        self.pending_ce: Optional[dict] = None    # a cross-entropy on the head's output which waits for the backward launch (deepcv_amd.ops.defer_cross_entropy)
 
     def add_layer(self, d: nat.Conv2dDesc, cfg, grad_params, needs_dx: bool, bias_without_weight: bool) -> int:
         self.layers.append({'d': nat.Conv2dDesc.from_buffer_copy(d), 'cfg': cfg, 'params': [p for p in grad_params if p is not None], 'needs_dx': bool(needs_dx),
@@ -428,6 +431,21 @@ class BackwardPlan:
         self.ops, self.keep, self.head = [], [], None
         return True
 
+    def can_take_cross_entropy(self, logits: torch.Tensor) -> bool:
+        """ Could the head of the backward launch compute a cross-entropy on `logits` (the recorded head's output)?  Static conditions only: whether the
+        launch happens is decided by `decide_head`, which flushes the loss kernel when it does not. """
+        return (_ce_in_backward and _head_in_launch and _enabled and _bwd_enabled and self.fusable and self.state is None and self.pending_ce is None
+                and self.link is not None and self.fc is not None and self.fc['follows_link'] and self.fc['out_ptr'] == logits.data_ptr()
+                and logits.is_contiguous() and logits.dtype == torch.float32)
+
+    def drop_head_cross_entropy(self):
+        """ The head keeps its data gradient but not the deferred loss (its weight gradient stays outside the launch and reads dlogits from memory before
+        the launch runs): the caller launches the loss kernel (`ops.flush_deferred_cross_entropy`). """
+        if self.head is not None and self.head.ce_target:
+            self.head.ce_target = self.head.ce_loss = self.head.ce_lse = self.head.ce_correct = None
+            self.head.pub_mailbox = self.head.pub_vals = self.head.pub_seq = None
+            self.head.pub_slots = 0
+
     def decide_head(self, dlogits: torch.Tensor, logits: Optional[torch.Tensor], wp: torch.Tensor, dwide: torch.Tensor, bias_from_wgrad) -> bool:
         """ Called by the fully connected head's backward node — the first node of the whole pass when the stack ends LINK -> Flatten -> FC: the launch then
         also computes the head's data gradient and the link's split (`dcv_resident_bwd_head`).  `dwide`: the (never materialised) gradient tensor the head
@@ -440,6 +458,12 @@ class BackwardPlan:
         head.enabled, head.classes, head.act, head.slope = 1, self.fc['classes'], self.fc['act'], self.fc['slope']
         head.h, head.w, head.cc, head.cr, head.ref_h, head.ref_w, head.align_corners = (self.link[k] for k in ('h', 'w', 'cc', 'cr', 'ref_h', 'ref_w', 'align'))
         head.dlogits, head.logits, head.wp, head.dref = dlogits.data_ptr(), nat.ptr(logits), wp.data_ptr(), 16
+        ce = self.pending_ce
+        if ce is not None and ce['dz'].data_ptr() == dlogits.data_ptr() and logits is not None and ce['logits'].data_ptr() == logits.data_ptr():
+            # the loss on these logits was deferred to this launch: it derives d loss / d logits itself (dlogits stays unwritten)
+            head.ce_target, head.ce_loss, head.ce_lse, head.ce_correct = ce['target'].data_ptr(), ce['loss'].data_ptr(), ce['lse'].data_ptr(), nat.ptr(ce['correct'])
+            if ce['pub'] is not None:
+                head.pub_mailbox, head.pub_vals, head.pub_seq, head.pub_slots = ce['pub']
         prog = self._skeleton()
         prog.op[0].dout = None
         prog.head = head
@@ -447,6 +471,8 @@ class BackwardPlan:
             return False
         self.state, self.next_index, self.prev_dx = 'fused', len(self.layers) - 1, None
         self.ops, self.keep, self.head, self.head_dx = [], [dlogits, logits, wp], head, dwide
+        if head.ce_target:
+            self.keep += [t for t in (ce['target'], ce['loss'], ce['lse'], ce['correct']) if t is not None]      # (committed by head_wgrad: `pending_ce` stays until then)
         return True
 
     def head_wgrad(self, x: torch.Tensor, dw: torch.Tensor, db: Optional[torch.Tensor], n: int, k: int, classes: int) -> bool:
@@ -458,6 +484,8 @@ class BackwardPlan:
             return False
         self.head.fc_x, self.head.fc_dw, self.head.fc_db = x.data_ptr(), dw.data_ptr(), (db.data_ptr() if db is not None else None)
         self.keep.append(x)
+        if self.head.ce_target:
+            self.pending_ce = None      # nothing outside the launch reads dlogits any more: the deferred loss is the launch's
         return True
 
     def split_link(self, dwide: torch.Tensor, dcur: torch.Tensor, dref: torch.Tensor) -> bool:

@@ -637,6 +637,13 @@ typedef struct dcv_resident_bwd_head {
     int h, w, cc, cr, ref_h, ref_w, align_corners, reserved;   /* wide tensor [n][h][w][cc + cr]; referenced tensor [n][ref_h][ref_w][cr] */
     const float* dlogits; const float* logits; const float* wp; float* dref;
     const float* fc_x; float* fc_dw; float* fc_db;
+    /* the softmax cross-entropy of the step inside the launch (nullable ce_target: int64 class indices [n]): `logits` (= the head's output, which the
+     * loss took as its input) are the loss's logits, dlogits is then NOT read: every block derives (softmax - onehot) / n for all samples itself (and the
+     * loss: the same bits in every block), one block writes ce_loss [1], ce_lse [n] (nullable), ce_correct [1] (nullable) and — pub_seq non-NULL —
+     * publishes the loss like dcv_cross_entropy_fwd_grad_publish.  n <= 512, classes <= 12.  replaces the dcv_cross_entropy_fwd_grad launch of a
+     * training step whose loss is the root of the backward pass (ignite_training.py:253). */
+    const long long* ce_target; float* ce_loss; float* ce_lse; int* ce_correct;
+    const dcv_copy_jobs* pub_mailbox; float* pub_vals; int* pub_seq; int pub_slots; int reserved2;
 } dcv_resident_bwd_head;
 typedef struct dcv_resident_bwd_program { int n; int count; dcv_resident_bwd_op op[DCV_RESIDENT_BWD_MAX_OPS]; dcv_resident_bwd_head head; } dcv_resident_bwd_program;
 int dcv_resident_bwd_supported(const dcv_resident_bwd_program* p);

@@ -157,6 +157,41 @@ def test_replayed_graph_on_the_resident_path_tracks_eager(device, params):
     assert curves[0] == curves[1], curves
 
 
+def test_cross_entropy_inside_the_backward_launch(device, params):
+    """ At the bench batch size a captured step is four launches: the loss (value, early read-back, arg-max hits, d loss / d logits) is computed by the
+    head of the persistent backward launch from the forward launch's logits — the same arithmetic as the loss kernel the eager steps run: losses and hit
+    counts equal bit for bit.  `DCV_CE_IN_BACKWARD` off: five launches, the same numbers. """
+    from deepcv_amd import modules, optim, resident
+    from deepcv_amd.meta.ignite_training import GraphedTrainStep, _setup_losses
+    g = torch.Generator().manual_seed(DATA_SEED)
+    batches = [(torch.randn(512, 3, 32, 32, generator=g).to(device), torch.randint(0, 10, (512,), generator=g).to(device)) for _ in range(4)]
+    curves = []
+    for mode in ('in backward', 'own launch', 'eager'):
+        prev, resident._ce_in_backward = resident._ce_in_backward, mode == 'in backward'
+        try:
+            model = _model(params, 'image_classifier_model', device)
+            opt = optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-2)
+            loss_fn = modules.CrossEntropyLoss()
+            losses, weights = _setup_losses(loss_fn, None, device)
+            step = GraphedTrainStep(model, opt, losses, weights)
+            got = []
+            for xb, yb in batches:
+                if mode == 'eager':
+                    out, _ = step._eager(xb, yb)
+                    got.append((out['main_loss'].item(), int(loss_fn.last_correct.item())))
+                else:
+                    step(xb, yb)
+                    got.append((step.loss_values()['main_loss'], int(loss_fn.last_correct.item())))
+            torch.cuda.synchronize()
+            resident.check_status()
+            if mode != 'eager':
+                assert step._launch_list is not None and len(step._launch_list.calls) == (4 if mode == 'in backward' else 5)
+            curves.append(got)
+        finally:
+            resident._ce_in_backward = prev
+    assert curves[0] == curves[1] == curves[2], curves
+
+
 def test_launch_list_replay_is_dropped_when_the_step_runs_foreign_kernels(device, params):
     """ A captured step is replayed as a list of this library's launches only after the first replay came out bit-identical through the graph and through
     the list; a second loss term made of torch operations puts kernels into the graph which the list does not know: the graph stays the replay mechanism,
