@@ -1131,65 +1131,79 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         }
         const dcv_resident_bwd_op& o = p.op[0];
         const int pk = o.pool > 0 ? o.pool : 1;
-        load_flat(o.y, yreg, o.h * o.w * o.cout);
-        if (!p.head.enabled) load_flat(o.dout, dor, (o.h / pk) * (o.w / pk) * o.cout);
-        if (pslot >= 0) (&s_par[0][0][0])[pslot] = pv;
-    }
-    if (stage_dz) {
-        float* staged = reinterpret_cast<float*>(dzt);
-        const int total = N * p.head.classes;
-        reinterpret_cast<float4*>(staged + 512 * RB_FC_MAXO)[t] = fc_x4;
-        if (ce_here) {
-            // softmax cross-entropy of row t, the arithmetic of ce_fwd_single_kernel (linear_loss.hip) expression by expression: the loss and its gradient
-            // must not depend on which launch computes them
-            const int O = p.head.classes;
-            double l = 0.0; int ok = 0;
-            float lse = 0.f;
-            if (t < N) {
-                float v[2 * RB_FC_DZ_SLOTS];
+        // y of the first op: requested now, committed to LDS behind the head's operand staging — the loss arithmetic of a captured step (2 us on half of the
+        // waves) then runs while these loads travel
+        const int yv4 = (o.h * o.w * o.cout) >> 2, yn = (int)blockIdx.x * RS_SPB + s_of_t;
+        const bool y_two = yv4 <= 2 * 512;
+        float4 y2[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+        if (y_two) {
+            const float4* g = reinterpret_cast<const float4*>(o.y) + (size_t)(yn < N ? yn : 0) * yv4;
 #pragma unroll
-                for (int k = 0; k < RB_FC_DZ_SLOTS; ++k) { v[k] = k < O ? fc_g[k] : -INFINITY; v[RB_FC_DZ_SLOTS + k] = RB_FC_DZ_SLOTS + k < O ? fc_l[k] : -INFINITY; }
-                float m = -INFINITY; int mi = 0x7fffffff;
-#pragma unroll
-                for (int c = 0; c < 2 * RB_FC_DZ_SLOTS; ++c) if (c < O && (v[c] > m || (v[c] != v[c]))) { m = v[c]; mi = c; }
-                float sexp = 0.f, zt = 0.f;
-#pragma unroll
-                for (int c = 0; c < 2 * RB_FC_DZ_SLOTS; ++c) if (c < O) { sexp += expf(v[c] - m); if ((long long)c == ce_t) zt = v[c]; }
-                lse = m + logf(sexp);
-                const float g = 1.f / (float)N;
-#pragma unroll
-                for (int c = 0; c < 2 * RB_FC_DZ_SLOTS; ++c)
-                    if (c < O) staged[t * O + c] = ((expf(v[c] - lse) - ((long long)c == ce_t ? 1.f : 0.f)) * g) * dcv_act_grad_from_out(v[c], p.head.act, p.head.slope);
-                l = (double)(lse - zt);
-                ok = (mi == (int)ce_t) ? 1 : 0;
-            }
-            l = dcv_wave_sum(l); ok = dcv_wave_sum(ok);
-            if (lane == 0) { s_tot[wave] = l; s_w32[wave] = (unsigned)ok; }
-            rs_barrier();
-            const bool writer = blockIdx.x == (G > RS_MAXQ + DCV_MAX_COPY_JOBS ? (unsigned)(RS_MAXQ + DCV_MAX_COPY_JOBS) : 0u);     // a block which owns no all-reduce quantity
-            if (writer) {
-                if (t < N && p.head.ce_lse != nullptr) p.head.ce_lse[t] = lse;
-                if (t == 0) {
-                    double sum = 0.0; int k = 0;
-                    for (int i = 0; i < 16; ++i) { sum += s_tot[i]; k += (int)s_w32[i]; }
-                    const float value = (float)(sum / (double)N);
-                    p.head.ce_loss[0] = value;
-                    if (p.head.ce_correct != nullptr) p.head.ce_correct[0] = k;
-                    if (p.head.pub_seq != nullptr) {                                 // early read-back, as dcv_cross_entropy_fwd_grad_publish
-                        for (int i = 0; i < p.head.pub_slots; ++i) p.head.pub_vals[i] = value;
-                        __threadfence_system();
-                        *reinterpret_cast<volatile int*>(p.head.pub_seq) = p.head.pub_mailbox->seq;
-                        __threadfence_system();
+            for (int k = 0; k < 2; ++k) { const int i = tt + k * 512; y2[k] = g[i < yv4 ? i : 0]; }
+        }
+        if (stage_dz) {
+            float* staged = reinterpret_cast<float*>(dzt);
+            const int total = N * p.head.classes;
+            reinterpret_cast<float4*>(staged + 512 * RB_FC_MAXO)[t] = fc_x4;
+            if (ce_here) {
+                // softmax cross-entropy of row t, the arithmetic of ce_fwd_single_kernel (linear_loss.hip) expression by expression: the loss and its gradient
+                // must not depend on which launch computes them
+                const int O = p.head.classes;
+                double l = 0.0; int ok = 0;
+                float lse = 0.f;
+                if (t < N) {
+                    float v[2 * RB_FC_DZ_SLOTS];
+    #pragma unroll
+                    for (int k = 0; k < RB_FC_DZ_SLOTS; ++k) { v[k] = k < O ? fc_g[k] : -INFINITY; v[RB_FC_DZ_SLOTS + k] = RB_FC_DZ_SLOTS + k < O ? fc_l[k] : -INFINITY; }
+                    float m = -INFINITY; int mi = 0x7fffffff;
+    #pragma unroll
+                    for (int c = 0; c < 2 * RB_FC_DZ_SLOTS; ++c) if (c < O && (v[c] > m || (v[c] != v[c]))) { m = v[c]; mi = c; }
+                    float sexp = 0.f, zt = 0.f;
+    #pragma unroll
+                    for (int c = 0; c < 2 * RB_FC_DZ_SLOTS; ++c) if (c < O) { sexp += expf(v[c] - m); if ((long long)c == ce_t) zt = v[c]; }
+                    lse = m + logf(sexp);
+                    const float g = 1.f / (float)N;
+    #pragma unroll
+                    for (int c = 0; c < 2 * RB_FC_DZ_SLOTS; ++c)
+                        if (c < O) staged[t * O + c] = ((expf(v[c] - lse) - ((long long)c == ce_t ? 1.f : 0.f)) * g) * dcv_act_grad_from_out(v[c], p.head.act, p.head.slope);
+                    l = (double)(lse - zt);
+                    ok = (mi == (int)ce_t) ? 1 : 0;
+                }
+                l = dcv_wave_sum(l); ok = dcv_wave_sum(ok);
+                if (lane == 0) { s_tot[wave] = l; s_w32[wave] = (unsigned)ok; }
+                rs_barrier();
+                const bool writer = blockIdx.x == (G > RS_MAXQ + DCV_MAX_COPY_JOBS ? (unsigned)(RS_MAXQ + DCV_MAX_COPY_JOBS) : 0u);     // a block which owns no all-reduce quantity
+                if (writer) {
+                    if (t < N && p.head.ce_lse != nullptr) p.head.ce_lse[t] = lse;
+                    if (t == 0) {
+                        double sum = 0.0; int k = 0;
+                        for (int i = 0; i < 16; ++i) { sum += s_tot[i]; k += (int)s_w32[i]; }
+                        const float value = (float)(sum / (double)N);
+                        p.head.ce_loss[0] = value;
+                        if (p.head.ce_correct != nullptr) p.head.ce_correct[0] = k;
+                        if (p.head.pub_seq != nullptr) {                                 // early read-back, as dcv_cross_entropy_fwd_grad_publish
+                            for (int i = 0; i < p.head.pub_slots; ++i) p.head.pub_vals[i] = value;
+                            __threadfence_system();
+                            *reinterpret_cast<volatile int*>(p.head.pub_seq) = p.head.pub_mailbox->seq;
+                            __threadfence_system();
+                        }
                     }
                 }
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < RB_FC_DZ_SLOTS; ++k) {
-                const int i = t + k * RS_T;
-                if (i < total) staged[i] = p.head.logits ? fc_g[k] * dcv_act_grad_from_out(fc_l[k], p.head.act, p.head.slope) : fc_g[k];
+            } else {
+    #pragma unroll
+                for (int k = 0; k < RB_FC_DZ_SLOTS; ++k) {
+                    const int i = t + k * RS_T;
+                    if (i < total) staged[i] = p.head.logits ? fc_g[k] * dcv_act_grad_from_out(fc_l[k], p.head.act, p.head.slope) : fc_g[k];
+                }
             }
         }
+        if (y_two) {
+            float4* d = reinterpret_cast<float4*>(yreg + s_of_t * RS_Y);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { const int i = tt + k * 512; if (i < yv4) d[i] = yn < N ? y2[k] : make_float4(0.f, 0.f, 0.f, 0.f); }
+        } else load_flat(o.y, yreg, o.h * o.w * o.cout);
+        if (!p.head.enabled) load_flat(o.dout, dor, (o.h / pk) * (o.w / pk) * o.cout);
+        if (pslot >= 0) (&s_par[0][0][0])[pslot] = pv;
     }
     if (stage_dz) rs_barrier();
     stamp();
