@@ -302,6 +302,21 @@ def record_launches(recorder: Optional[LaunchRecorder]) -> Optional[LaunchRecord
     return prev
 
 
+class recording:
+    """ `with recording(recorder): ...` — `record_launches(recorder)` for the duration of the block (None: nothing changes hands). """
+
+    def __init__(self, recorder: Optional[LaunchRecorder]):
+        self.recorder, self.prev = recorder, None
+
+    def __enter__(self):
+        self.prev = record_launches(self.recorder)
+        return self.recorder
+
+    def __exit__(self, *exc):
+        record_launches(self.prev)
+        return False
+
+
 class _LazyLib:
     """ `lib.dcv_xxx(...)` resolves the symbol on first use.  Every call passes through a thin wrapper which feeds the active `LaunchRecorder`. """
 

@@ -346,8 +346,7 @@ class GraphedTrainStep:
         # launch-list replay (`DCV_REPLAY_LIST=1`): the library calls of the captured step are logged while the graph is captured and re-issued as plain
         # launches on every replay — the graph's memory pool keeps their buffers alive; a hipGraphLaunch costs ~9 us of idle GPU between two steps
         recorder = self._nat.LaunchRecorder(self.stream.cuda_stream) if (self._replay_list and self.reducer is None) else None
-        prev_recorder = self._nat.record_launches(recorder)
-        with torch.cuda.graph(self.graph_fb, stream=self.stream, capture_error_mode=capture_mode):
+        with self._nat.recording(recorder), torch.cuda.graph(self.graph_fb, stream=self.stream, capture_error_mode=capture_mode):
             if stage_in_forward:
                 _resident.set_staging((self.mailbox.data_ptr(), 0, self.static_x.data_ptr()))
             else:
@@ -396,7 +395,6 @@ class GraphedTrainStep:
                 self.reducer.enabled = hooks_were
                 self.reducer.finish()                                        # all-reduce captured on the capture stream; p.grad -> bucket views
                 self.optimizer.step()
-        self._nat.record_launches(prev_recorder)
         # (short steps only: the ~9 us a graph launch costs matter to a 0.23 ms step, not to one of a hundred launches — and Python re-issues those slowly)
         self._launch_list = recorder if (recorder is not None and 0 < len(recorder.calls) <= 32) else None
         if self.reducer is not None and not in_graph:

@@ -175,6 +175,28 @@ def test_adamw_prep_table_is_built_on_the_host():
     assert lib.dcv_adamw_prep_build(lists, 1, 2, descs, ops, ws, bufs, ctypes.byref(table)) == nat.ERR_UNSUPPORTED
 
 
+def test_launch_recorder_logs_and_replays_calls_on_its_stream():
+    """ `LaunchRecorder` (the launch-list replay of a captured training step): while it is active, every library call whose LAST argument is its stream
+    handle is logged with its argument objects; `replay(stream)` re-issues the calls with that argument replaced and raises on a non-zero status.  Host-only
+    stand-in: `dcv_resident_head_wgrad_supported(n, k, classes)` returns 1 / 0 depending on its last argument. """
+    import pytest
+    from deepcv_amd import _native as nat
+    rec = nat.LaunchRecorder(10)
+    with nat.recording(rec):
+        assert nat.lib.dcv_resident_head_wgrad_supported(512, 1280, 10) == 1      # last argument == the recorder's "stream": logged
+        assert nat.lib.dcv_resident_head_wgrad_supported(512, 1280, 11) == 1      # not logged
+        nat.lib.dcv_resident_ws_bytes()                                           # no arguments: not logged
+    assert nat.lib.dcv_resident_head_wgrad_supported(512, 1280, 10) == 1          # recorder off again
+    assert len(rec.calls) == 1 and rec.calls[0][1] == (512, 1280, 10) and rec.calls[0][2] == 2
+    with pytest.raises(RuntimeError):
+        rec.replay(12)               # "status" 1 of the re-issued call (12 classes are supported): reported like a failed launch
+    rec.replay(13)                   # 13 classes: the stand-in returns 0 = success
+    zero = nat.LaunchRecorder(0)     # the null stream is never matched (too many integer arguments are 0)
+    with nat.recording(zero):
+        nat.lib.dcv_resident_head_wgrad_supported(512, 1280, 0)
+    assert not zero.calls
+
+
 def _native_lib():
     from deepcv_amd import _native
     return _native.load()
