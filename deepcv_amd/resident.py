@@ -517,6 +517,10 @@ class BackwardPlan:
         global _bwd_launches
         ops, self.ops = self.ops, []
         keep, self.keep = self.keep, []
+        if ops and self.next_index >= 0 and self.prev_dx is not None and not ops[-1].dx:
+            # flushed before every layer had recorded itself (a gradient bucket of the data-parallel reducer filled up mid-pass): the last recorded layer's data
+            # gradient must reach HBM — the remaining layers, which find the plan undecided again, run on the per-layer kernels and read it there
+            ops[-1].dx = self.prev_dx.data_ptr()
         self.state, self.prev_dx = None, None
         if not ops:
             return

@@ -157,6 +157,46 @@ def test_replayed_graph_on_the_resident_path_tracks_eager(device, params):
     assert curves[0] == curves[1], curves
 
 
+def test_backward_launch_flushed_in_the_middle_of_the_pass(device, params):
+    """ Small gradient buckets of the data-parallel reducer fill up while the backward pass is still recording layers: the bucket pack flushes the
+    pending work, i.e. launches the persistent backward launch with the layers recorded so far.  Their last data gradient then has to reach HBM, the
+    remaining layers run on the per-layer kernels: same gradients as without a reducer. """
+    from deepcv_amd import modules, resident
+    from deepcv_amd.parallel import GradientAllReducer
+    g = torch.Generator().manual_seed(DATA_SEED)
+    x, y = torch.randn(64, 3, 32, 32, generator=g).to(device), torch.randint(0, 10, (64,), generator=g).to(device)
+    a, b = _model(params, 'image_classifier_model', device), _model(params, 'image_classifier_model', device)
+    reducer = GradientAllReducer(a.parameters(), bucket_cap_mb=0.002, overlap=True)         # ~500 floats per bucket: most layers get a bucket of their own
+    assert len(reducer.buckets) > 4
+    try:
+        la, loss_a, _ = _run_plain(a, x, y)
+        reducer.finish()
+    finally:
+        reducer.detach()
+    lb, loss_b, _ = _run_plain(b, x, y)
+    assert loss_a == loss_b
+    gscale = max(p.grad.abs().max().item() for p in b.parameters())
+    for (name, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        err = (pa.grad - pb.grad).abs().max().item()
+        assert err <= 2e-4 * pb.grad.abs().max().item() + 2e-6 * gscale, f'{name}: {err:.3e}'
+
+
+def _run_plain(model, x, y):
+    from deepcv_amd import modules, resident
+    prev, prev_b = resident.set_enabled(True), resident.set_backward_enabled(True)
+    try:
+        model.train()
+        logits = model(x)
+        loss = modules.CrossEntropyLoss()(logits, y)
+        loss.backward()
+        torch.cuda.synchronize()
+        resident.check_status()
+        return logits.detach().clone(), loss.item(), 0
+    finally:
+        resident.set_enabled(prev)
+        resident.set_backward_enabled(prev_b)
+
+
 def test_cross_entropy_inside_the_backward_launch(device, params):
     """ At the bench batch size a captured step is four launches: the loss (value, early read-back, arg-max hits, d loss / d logits) is computed by the
     head of the persistent backward launch from the forward launch's logits — the same arithmetic as the loss kernel the eager steps run: losses and hit
