@@ -181,6 +181,32 @@ def test_backward_launch_flushed_in_the_middle_of_the_pass(device, params):
         assert err <= 2e-4 * pb.grad.abs().max().item() + 2e-6 * gscale, f'{name}: {err:.3e}'
 
 
+def test_gradient_accumulation_over_two_backward_passes(device, params):
+    """ A second backward pass onto existing `.grad`s: the engine ADDS what the backward functions return, so nothing may be handed over unfilled — the
+    second pass must leave the recorded path (the plan decides that before its first layer records itself).  Sum of both passes' gradients against the
+    per-layer kernels. """
+    from deepcv_amd import modules, resident
+    g = torch.Generator().manual_seed(DATA_SEED)
+    xs = [torch.randn(64, 3, 32, 32, generator=g).to(device) for _ in range(2)]
+    ys = [torch.randint(0, 10, (64,), generator=g).to(device) for _ in range(2)]
+    a, b = _model(params, 'image_classifier_model', device), _model(params, 'image_classifier_model', device)
+    for model, on in ((a, True), (b, False)):
+        prev, prev_b = resident.set_enabled(on), resident.set_backward_enabled(on)
+        try:
+            model.train()
+            for x, y in zip(xs, ys):
+                modules.CrossEntropyLoss()(model(x), y).backward()        # no zero_grad in between
+            torch.cuda.synchronize()
+            resident.check_status()
+        finally:
+            resident.set_enabled(prev)
+            resident.set_backward_enabled(prev_b)
+    gscale = max(p.grad.abs().max().item() for p in b.parameters())
+    for (name, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        err = (pa.grad - pb.grad).abs().max().item()
+        assert err <= 2e-4 * pb.grad.abs().max().item() + 2e-6 * gscale, f'{name}: {err:.3e}'
+
+
 def _run_plain(model, x, y):
     from deepcv_amd import modules, resident
     prev, prev_b = resident.set_enabled(True), resident.set_backward_enabled(True)
