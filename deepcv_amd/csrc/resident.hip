@@ -875,7 +875,7 @@ __device__ __forceinline__ void rb_wgrad_c4(const dcv_resident_bwd_op& o, const 
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int ci = (vi + j) >> 1, co = 2 * h2 + ((vi + j) & 1);
-                    if (ci < o.cin) o.dw_part[(size_t)chunk * wsize + ((co * o.cin + ci) * K + ky) * K + kx] = r2[j];
+                    if (ci < o.cin) o.dw_part[(size_t)chunk * wsize + (ky * K + kx) * (o.cout * o.cin) + co * o.cin + ci] = r2[j];      // [tap][co][ci]: the four lanes' values are neighbours
                 }
             }
         }
@@ -937,8 +937,7 @@ __device__ __forceinline__ void rb_wgrad_c16(const dcv_resident_bwd_op& o, const
         rs_f4 acc = {0.f, 0.f, 0.f, 0.f};
         rb_mfma_rows(xa, db, 0, H, XW, acc);
         const int chunk = (int)blockIdx.x * RS_SPB + s;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o.dw_part[(size_t)chunk * 2304 + (m * 16 + 4 * kq + i) * 9 + tap] = acc[i];          // D: input channel 4 kq + i, output channel m
+        *reinterpret_cast<float4*>(o.dw_part + (size_t)chunk * 2304 + (tap * 16 + m) * 16 + 4 * kq) = make_float4(acc[0], acc[1], acc[2], acc[3]);     // D: input channels 4 kq .. + 3, output channel m -> [tap][co][ci]: 1 KB per wave, contiguous
     }
     rb_bias16(o, dzt, 2);
 }
@@ -956,7 +955,7 @@ __device__ __forceinline__ void rb_wgrad_c4x16(const dcv_resident_bwd_op& o, con
         const int chunk = (int)blockIdx.x * RS_SPB + s, wsize = 16 * o.cin * 9;
         if (kq < 3) {                                                                // D rows 4 kq + i = (column kq, input channel i), output channel m
 #pragma unroll
-            for (int i = 0; i < 4; ++i) if (i < o.cin) o.dw_part[(size_t)chunk * wsize + ((m * o.cin + i) * 3 + ky) * 3 + kq] = acc[i];
+            for (int i = 0; i < 4; ++i) if (i < o.cin) o.dw_part[(size_t)chunk * wsize + ((ky * 3 + kq) * 16 + m) * o.cin + i] = acc[i];                  // [tap][co][ci]
         }
     }
     rb_bias16(o, dzt, 6);

@@ -795,12 +795,13 @@ class _ConvNormLayerFn(torch.autograd.Function):
                     dw = _grad_buffer(ctx.weight_ref, like=weight)
                     if resident.wgrad_in_launch(d) and slabs.may_defer(ctx.weight_ref, ctx.bias_ref):
                         # the weight gradient is computed inside the persistent launch (while the blocks wait for the next layer's all-reduce): per-(block,
-                        # sample slot) partial slabs in OIHW order, summed by the step's one dcv_slab_reduce
+                        # sample slot) partial slabs in [tap][cout][cin] order (coalesced stores), transposed into OIHW and summed by the step's one dcv_slab_reduce
                         chunks, wsize = 2 * ((d.n + 1) // 2), weight.numel()
                         part = torch.empty(chunks * (wsize + (c if db is not None else 0)), dtype=torch.float32, device=dev)
                         op.x, op.x_nchw, op.dw_part = x.data_ptr(), (1 if d.x_layout == nat.LAYOUT_NCHW else 0), part.data_ptr()
                         segs, k = (nat.SlabSegment * 2)(), 1
                         segs[0].src, segs[0].dst, segs[0].count, segs[0].stride, segs[0].chunks = part.data_ptr(), dw.data_ptr(), wsize, wsize, chunks
+                        segs[0].tr_a, segs[0].tr_b = d.r * d.s, d.cout * d.cin               # chunks are [tap][cout][cin] (coalesced stores): summed into OIHW
                         if db is not None:
                             op.db_part = part.data_ptr() + 4 * chunks * wsize
                             segs[1].src, segs[1].dst, segs[1].count, segs[1].stride, segs[1].chunks = op.db_part, db.data_ptr(), c, c, chunks

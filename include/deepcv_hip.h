@@ -619,8 +619,8 @@ typedef struct dcv_resident_bwd_op {
     float* dz; float* dx;              /* dx: nullable (HBM copy of the last op's data gradient) */
     float* d_bn_gamma; float* d_bn_beta; float* gn_part;
     /* weight gradient inside the launch (nullable: the caller then runs dcv_conv2d_wgrad on dz): x = the layer's input ([n][h][w][cin] NHWC, or NCHW when
-     * x_nchw), dw_part [2 * blocks][cout * cin * k * k] and db_part [2 * blocks][cout] (nullable) = per-(block, sample slot) partial sums in OIHW order;
-     * dw / db = their sums over the 2 * blocks chunks (dcv_slab_reduce).  Computed while the block waits for the next layer's all-reduce. */
+     * x_nchw), dw_part [2 * blocks][k * k][cout][cin] and db_part [2 * blocks][cout] (nullable) = per-(block, sample slot) partial sums, tap-major;
+     * dw (OIHW) / db = their sums over the 2 * blocks chunks (dcv_slab_reduce with tr_a = k * k, tr_b = cout * cin).  Computed while the block waits for the next layer's all-reduce. */
     const float* x; float* dw_part; float* db_part; int x_nchw; int reserved;
 } dcv_resident_bwd_op;
 #define DCV_RESIDENT_BWD_MAX_OPS 8
