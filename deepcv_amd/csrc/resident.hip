@@ -463,7 +463,8 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
         const int n = (int)blockIdx.x * RS_SPB + s_of_t;
         constexpr int SB = 8;                                                        // elements per thread in flight
         const bool vec = !o.x_nchw && (C & 3) == 0;
-        const int total = vec ? HW * (C >> 2) : HW * C;
+        const bool planes = o.x_nchw && C <= 4 && HW <= 2 * 512;                     // the RGB model input: a thread gathers the channels of its two pixels
+        const int total = planes ? 0 : (vec ? HW * (C >> 2) : HW * C);
         float4 v4[SB]; float v1[SB];
         // a replayed step's batch: read through the address the host left in the mailbox for THIS replay, and kept in the static tensor for the backward pass
         const float* batch = o.x;
@@ -471,7 +472,14 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
         const bool keep = p.mailbox != nullptr && batch != o.x && n < N;
         const float* src = batch + (size_t)(n < N ? n : 0) * HW * C;
         float* stat = const_cast<float*>(o.x) + (size_t)(n < N ? n : 0) * HW * C;
-        if (vec) {
+        if (planes) {
+            // v1[4 k + c] = channel c of pixel tt + 512 k: coalesced per plane, and ONE conflict-free float4 per pixel into the tile below (element-wise, the
+            // 4-byte LDS stores of a channel-interleaved tile are 8-way bank conflicts)
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { const int px = tt + k * 512; v1[4 * k + c] = (c < C && px < HW) ? src[c * HW + px] : 0.f; }
+        } else if (vec) {
 #pragma unroll
             for (int k = 0; k < SB; ++k) { const int e = tt + k * 512; v4[k] = reinterpret_cast<const float4*>(src)[e < total ? e : 0]; }
         } else {
@@ -482,6 +490,20 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
         rs_barrier();
         if (pslot >= 0) (&s_par[0][0][0])[pslot] = pv;
         float* dst = xinf + (size_t)s_of_t * RS_XIN * 4;
+        if (planes) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int px = tt + k * 512;
+                if (px < HW && n < N) {
+                    const int r = rs_fdiv(px, inv_w), col = px - r * o.w;
+                    reinterpret_cast<float4*>(dst)[(r + pad) * XW + col + pad] = make_float4(v1[4 * k], v1[4 * k + 1], v1[4 * k + 2], v1[4 * k + 3]);
+                    if (keep) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) if (c < C) stat[c * HW + px] = v1[4 * k + c];
+                    }
+                }
+            }
+        }
         for (int e0 = 0; e0 < total; e0 += SB * 512) {
             if (e0 > 0) {                                                            // samples larger than SB * 512 elements: further batches
 #pragma unroll
