@@ -1430,11 +1430,22 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         const bool wg = o.dw_part != nullptr;
         const bool xvec = wg && !o.x_nchw && (o.cin & 3) == 0;
         float4 xpre[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+        // (the model input, NCHW with <= 4 channels: a thread gathers the channels of its two pixels from the planes — one conflict-free float4 per pixel
+        // into the tile instead of element-wise 4-byte stores, and requested here like the vector case instead of inside the tile phase)
+        const bool xplanes = wg && o.x_nchw && o.cin <= 4 && HW <= 2 * 512;
         if (xvec) {
             const int n = (int)blockIdx.x * RS_SPB + s_of_t, v4 = (H * W * o.cin) >> 2;
             const float4* g = reinterpret_cast<const float4*>(o.x) + (size_t)(n < N ? n : 0) * v4;
 #pragma unroll
             for (int k = 0; k < 2; ++k) { const int i = tt + k * 512; xpre[k] = g[i < v4 ? i : 0]; }
+        } else if (xplanes) {
+            const int n = (int)blockIdx.x * RS_SPB + s_of_t;
+            const float* g = o.x + (size_t)(n < N ? n : 0) * HW * o.cin;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int px = tt + k * 512, q = px < HW ? px : 0;
+                xpre[k].x = g[q]; xpre[k].y = o.cin > 1 ? g[HW + q] : 0.f; xpre[k].z = o.cin > 2 ? g[2 * HW + q] : 0.f; xpre[k].w = o.cin > 3 ? g[3 * HW + q] : 0.f;
+            }
         }
         if (!rs_allreduce_collect(go + RS_MAXQ * RS_MAXG, epoch, 2 * C, s_tot, s_w32, &s_fail)) {
             // a block of this grid is not resident: report, poison the first layer's dz, leave
@@ -1465,6 +1476,12 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
                 for (int k = 0; k < 2; ++k) {
                     const int e = tt + k * 512;
                     if (e < v4 && n < N) { const int px = rs_fdiv(e, inv_cvi), cv = e - px * CVI, r = rs_fdiv(px, inv_w), c = px - r * W; xtt[s_of_t * RS_XIN + (cv * XH + r + pad) * XW + c + pad] = xpre[k]; }
+                }
+            } else if (xplanes) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int px = tt + k * 512;
+                    if (px < HW && n < N) { const int r = rs_fdiv(px, inv_w), c = px - r * W; xtt[s_of_t * RS_XIN + (r + pad) * XW + c + pad] = xpre[k]; }
                 }
             } else if (n < N) {                                                      // NCHW / partial channel vector (the model input): scalar elements
                 const int total = H * W * o.cin;
