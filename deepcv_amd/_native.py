@@ -241,6 +241,7 @@ _SIGNATURES = {
     'dcv_resident_status': (_c_int, [_P, _P, ctypes.POINTER(_c_int)]),
     'dcv_resident_bwd_supported': (_c_int, [ctypes.POINTER(ResidentBwdProgram)]),
     'dcv_resident_head_wgrad_supported': (_c_int, [_c_int, _c_int, _c_int]),
+    'dcv_resident_wgrad_supported': (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int]),
     'dcv_resident_backward': (_c_int, [ctypes.POINTER(ResidentBwdProgram), _P, _c_size_t, _P]),
 }
 

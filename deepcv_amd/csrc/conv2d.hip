@@ -292,15 +292,8 @@ int dcv_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, 
     return conv2d_wgrad_impl(d, x, dy, dw, db, ws, ws_bytes, stream, nullptr, nullptr);
 }
 
-int dcv_conv2d_wgrad_batch(int count, const dcv_wgrad_job* jobs, dcv_slab_segment* segments, int* n_segments, void* stream) {
-    DCV_CHECK_ARG(count >= 0 && (count == 0 || (jobs && segments)) && n_segments);
-    if (count > 64) {                                                     // bounded stack tables below
-        for (int i0 = 0; i0 < count; i0 += 64) {
-            const int rc = dcv_conv2d_wgrad_batch(count - i0 < 64 ? count - i0 : 64, jobs + i0, segments, n_segments, stream);
-            if (rc != DCV_OK) return rc;
-        }
-        return DCV_OK;
-    }
+// at most 64 jobs (bounded stack tables); APPENDS its segments behind the *n_segments already there
+static int wgrad_batch_part(int count, const dcv_wgrad_job* jobs, dcv_slab_segment* segments, int* n_segments, void* stream) {
     bool eligible[64], taken[64];
     for (int i = 0; i < count; ++i) {
         const dcv_wgrad_job& j = jobs[i];
@@ -318,6 +311,18 @@ int dcv_conv2d_wgrad_batch(int count, const dcv_wgrad_job* jobs, dcv_slab_segmen
         *n_segments += n;
     }
     return rc;
+}
+
+// `segments` (room for 2 * count entries) is an OUT array: every call starts it at 0.  (It used to append behind whatever *n_segments held: a caller
+// re-issuing the call with the same objects — a launch list replaying a captured step — wrote past the array, further each time.)
+int dcv_conv2d_wgrad_batch(int count, const dcv_wgrad_job* jobs, dcv_slab_segment* segments, int* n_segments, void* stream) {
+    DCV_CHECK_ARG(count >= 0 && (count == 0 || (jobs && segments)) && n_segments);
+    *n_segments = 0;
+    for (int i0 = 0; i0 < count; i0 += 64) {
+        const int rc = wgrad_batch_part(count - i0 < 64 ? count - i0 : 64, jobs + i0, segments, n_segments, stream);
+        if (rc != DCV_OK) return rc;
+    }
+    return DCV_OK;
 }
 
 int dcv_conv2d_wgrad_deferred(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, float* db, void* ws, size_t ws_bytes,

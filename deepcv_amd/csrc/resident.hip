@@ -50,6 +50,13 @@ constexpr size_t RS_XIN_BYTES = (size_t)RS_SPB * RS_XIN * 16, RS_Y_BYTES = (size
 // (the one exception, the link's referenced tensor, sits behind a full __syncthreads()).  Loads are tracked by the compiler per register as usual.
 __device__ __forceinline__ void rs_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// The thread index as a value the optimiser cannot see through.  Every phase of the persistent kernels derives lane / wave / tile addresses from the thread
+// index; derived from `threadIdx.x` itself those are loop invariants of the op loop, LLVM hoists dozens of them in front of it and — the kernels sit at the
+// 128-VGPR cap of four waves per SIMD — spills them (33 VGPRs = 35 MB of scratch stores per launch, every reload an exposed L2 round trip in the middle of a
+// phase).  A phase that starts from rs_tid() recomputes its few index instructions instead.
+__device__ __forceinline__ int rs_tid() { int t = (int)threadIdx.x; asm volatile("" : "+v"(t)); return t; }
+__device__ __forceinline__ int rs_wave_of(int t) { return __builtin_amdgcn_readfirstlane(t >> 6); }        // the wave index as a scalar (t: a thread index of this wave)
+
 typedef float rs_f4 __attribute__((ext_vector_type(4)));
 
 // 1: cin <= 4 -> 4 (VALU, row pairs)   4: cin <= 4 -> 16 on rows of 16 pixels (MFMA, K = 4)   2: cin <= 4 -> 8 / 16 otherwise (VALU)   3: 16 -> 16 (MFMA)
@@ -93,7 +100,7 @@ template <int CTRL> __device__ __forceinline__ float rs_dpp_mov(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
 }
 __device__ __forceinline__ void rs_reduce8(const float (&v)[8], float (&r)[2]) {
-    const int lane = threadIdx.x & 63;
+    const int lane = rs_tid() & 63;
     const bool b0 = lane & 1, b1 = lane & 2;
     float a[4], b[2];
 #pragma unroll
@@ -132,14 +139,14 @@ __device__ __forceinline__ double rs_wave_sum_f64(double v) {
 // sweep on the chip) took 2.5 - 6.5 us per layer.  Returns false when a poll gave up (a block of the grid is not resident).  Block-uniform control flow.
 // hop 1 alone: a caller with independent work (the weight gradients of the backward launch) does it between this and rs_allreduce(..., published = true)
 __device__ __forceinline__ void rs_allreduce_publish(rs_u64* ga, unsigned epoch, int Q, float mine, bool mute = false) {
-    const int t = threadIdx.x;
+    const int t = rs_tid();
     if (t < Q && !mute) __hip_atomic_store((rs_gu64*)(ga + (size_t)t * RS_MAXG + blockIdx.x), ((rs_u64)epoch << 32) | (rs_u64)__float_as_uint(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // the block's share of the reduction: for every quantity it owns, poll the G partials, sum, publish the total (hop 2).  A caller with independent work
 // does it between this and rs_allreduce_collect: the totals are then on their way while every block computes.
 __device__ __forceinline__ void rs_allreduce_reduce_owned(rs_u64* ga, rs_u64* gb, unsigned epoch, int Q, int G, double* red, int* s_fail) {
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = rs_tid(), lane = t & 63, wave = rs_wave_of(t);
     for (int q = (int)blockIdx.x; q < Q; q += G) {                                   // the quantities this block owns
 
         double d = 0.0;
@@ -171,7 +178,7 @@ __device__ __forceinline__ void rs_allreduce_reduce_owned(rs_u64* ga, rs_u64* gb
 }
 
 __device__ __forceinline__ bool rs_allreduce_collect(rs_u64* gb, unsigned epoch, int Q, double* totals, unsigned* w32, int* s_fail) {
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = rs_tid(), lane = t & 63, wave = rs_wave_of(t);
     if (wave == 0) {
         bool got = true;
         unsigned v = 0;
@@ -206,57 +213,143 @@ __device__ __forceinline__ bool rs_allreduce(rs_u64* ga, rs_u64* gb, unsigned ep
 // Waves 0 - 7 work on the block's first sample, waves 8 - 15 on the second.  Every wave leaves its sums of y and y^2 per output channel in
 // wsum[wave][2][RS_MAXC] (zeros where it had no pixel), except the scalar wide variant (returns false: the caller runs a pass over yt).
 
-// CI: 4, or 3 (the RGB model input: the fourth lane of the pixel vectors is zero padding, its FMAs — a quarter of the first layer's — are skipped)
-template <int K, int CI = 4>
-__device__ __forceinline__ bool rs_conv_c4_co4(const dcv_resident_op& o, const float4* xin, float* yt, float* wsum) {
-    const int H = o.h, W = o.w, pad = K / 2, XW = W + 2 * pad;
-    const int per = (H >> 1) * W;                                                    // pixel pairs per sample (<= 512)
-    const int t = threadIdx.x, s = t >> 9, p = t & 511, lane = t & 63, wave = t >> 6;
-    rs_cfloat* wl = RS_CONST(o.filt);                                                // [K][K][4][4]
+// cin <= 4 -> 4 on the matrix cores: v_mfma_f32_4x4x1_16b_f32 = 16 independent 4 x 4 outer products per wave instruction (K = 1), D_b[i][j] += A_b[i] B_b[j]
+// with A from lane 4 b + i, B from lane 4 b + j and D_b[i][j] in register i of lane 4 b + j (tools/probes/mfma4x4_probe.hip: 8.4 clocks per instruction
+// and SIMD, 97 - 107 MAC / clk / CU with the LDS reads below — the rate of v_pk_fma_f32, but 256 MACs per instruction instead of 128 and none of the
+// instructions which a VALU convolution spends around its FMAs: the VALU version (two pixels per thread, 80 v_pk_fma_f32 per filter row with 5 scalar
+// loads, 5 ds_read_b128 and 15 register moves) took 7.4 - 7.7 us per 5x5 layer, 46 % of the SIMD cycles in VALU issue with every wave in line for it).
+// A wave takes GROUPS of 64 consecutive pixels of its sample: lane l = pixel l of the group, block b = pixels 4 b .. 4 b + 3, j = output channel.  Per
+// (tap, input channel) one MFMA: A = x[pixel + tap][ci] — the pixel's float4 is ONE ds_read_b128 per tap for its four MFMAs —, B = w[tap][ci][co = j],
+// from the filter copy the prologue left in LDS as [tap][co][ci] (one ds_read_b128 per tap, shared by the wave's two groups).  CI = 3 (the RGB model
+// input: the fourth lane of the pixel vectors is zero padding): that MFMA is skipped.  XWC: the tile's row stride when it is known at compile time
+// (32-pixel rows: every tap offset is an immediate of its ds_read), 0: run-time geometry.  Output: lane (b, j) holds channel j of pixels 4 b .. 4 b + 3.
+constexpr int RS_FILT_OPS = 6;                                                       // forward launch: ops [0, RS_FILT_OPS) may be cin <= 4 -> 4 layers (their filters live in LDS)
+constexpr int RB_FILT_SLOTS = 3;                                                     // backward launch (LDS is scarcer there): at most that many 4 <- 4 data gradients
+constexpr int RS_FILT_FLOATS = 5 * 5 * 16;
+
+// the prologue's part: thread t < taps * 16 fetches element t of the [tap][co][ci] copy from the prepared [tap][ci][co] filter
+__device__ __forceinline__ float rs_filt_fetch(const float* filt, int k, int t) {
+    return t < k * k * 16 ? filt[((t >> 4) * 4 + (t & 3)) * 4 + ((t >> 2) & 3)] : 0.f;
+}
+
+template <int K, int CI, int XWC>
+__device__ __forceinline__ bool rs_conv_c4_co4(const dcv_resident_op& o, const float4* xin, float* yt, const float* wl, const float* bias_lds, float* wsum) {
+    constexpr int pad = K / 2;
+    const int t = rs_tid(), lane = t & 63, wave = rs_wave_of(t), s = wave >> 3, w8 = wave & 7;
+    const int H = o.h, W = XWC > 0 ? XWC - 2 * pad : o.w, XW = XWC > 0 ? XWC : W + 2 * pad, HW = H * W, GS = (HW + 63) >> 6;
+    const int j = lane & 3;
+    const float bias = bias_lds ? bias_lds[j] : 0.f;                                 // (from LDS: see rs_conv_c4_co4_32 (c))
+    const int act = o.act; const float slope = o.slope;                              // (requested before the sched_barriers of the tap loop)
+    const rs_f4* wl4 = reinterpret_cast<const rs_f4*>(wl) + j;
+    const rs_f4* xs = reinterpret_cast<const rs_f4*>(xin) + s * RS_XIN;
+    float sum = 0.f, sq = 0.f;
+    for (int g0 = w8; g0 < GS; g0 += 16) {                                           // the wave's groups, two at a time: g0 and g0 + 8 (one weight read serves both)
+        const bool two = g0 + 8 < GS;
+        const int p0 = g0 * 64 + lane, p1 = p0 + 512;
+        const int q0 = p0 < HW ? p0 : 0, q1 = (two && p1 < HW) ? p1 : q0;
+        int r0, c0, r1, c1;
+        if (XWC > 0) { r0 = q0 / W; c0 = q0 - r0 * W; r1 = q1 / W; c1 = q1 - r1 * W; }
+        else { const float inv_w = 1.f / (float)W; r0 = rs_fdiv(q0, inv_w); c0 = q0 - r0 * W; r1 = rs_fdiv(q1, inv_w); c1 = q1 - r1 * W; }
+        const rs_f4* x0 = xs + r0 * XW + c0;
+        const rs_f4* x1 = xs + r1 * XW + c1;
+        rs_f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        // Software pipeline over the taps: the three operand vectors of tap n + 1 are requested BEFORE the eight MFMAs of tap n.  All 16 waves leave the
+        // barrier in front of this phase together, so a loop of "request a filter row's operands, wait, multiply" runs the LDS and the matrix pipe one
+        // after the other for the whole block (5 x (960 + 1340) clocks: 5.5 us measured for 3.2 us of MFMAs).  sched_barrier keeps the compiler from
+        // hoisting every request to the top (75 live vectors: spills).
+        rs_f4 wv[2], a0[2], a1[2];
+        wv[0] = wl4[0]; a0[0] = x0[0]; a1[0] = x1[0];
+#pragma unroll
+        for (int tap = 0; tap < K * K; ++tap) {
+            const int cur = tap & 1, nxt = cur ^ 1;
+            if (tap + 1 < K * K) {
+                const int ky = (tap + 1) / K, kx = (tap + 1) - ky * K;
+                wv[nxt] = wl4[(tap + 1) * 4]; a0[nxt] = x0[ky * XW + kx]; a1[nxt] = x1[ky * XW + kx];
+            }
+            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[cur].x, wv[cur].x, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[cur].x, wv[cur].x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[cur].y, wv[cur].y, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[cur].y, wv[cur].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[cur].z, wv[cur].z, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[cur].z, wv[cur].z, acc1, 0, 0, 0);
+            if constexpr (CI > 3) { acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[cur].w, wv[cur].w, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[cur].w, wv[cur].w, acc1, 0, 0, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // lane (b, j): channel j of pixels 4 b + i of each group
+        float* y0 = yt + s * RS_Y + (g0 * 64 + (lane & ~3)) * 4 + j;
+        const int pb = g0 * 64 + (lane & ~3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (pb + i < HW) { const float v = dcv_act_apply(acc0[i] + bias, act, slope); y0[i * 4] = v; sum += v; sq += v * v; }
+            if (two && pb + 512 + i < HW) { const float v = dcv_act_apply(acc1[i] + bias, act, slope); y0[(512 + i) * 4] = v; sum += v; sq += v * v; }
+        }
+    }
+    // the wave's sums of y, y^2 per channel: lanes j, j + 4, ... hold channel j
+    sum += rs_dpp_mov<0x124>(sum); sq += rs_dpp_mov<0x124>(sq);                      // row_ror:4
+    sum += rs_dpp_mov<0x128>(sum); sq += rs_dpp_mov<0x128>(sq);                      // row_ror:8
+    sum += __shfl_xor(sum, 16, 64); sq += __shfl_xor(sq, 16, 64);
+    sum += __shfl_xor(sum, 32, 64); sq += __shfl_xor(sq, 32, 64);
+    if (lane < 4) { wsum[(wave * 2) * RS_MAXC + lane] = sum; wsum[(wave * 2 + 1) * RS_MAXC + lane] = sq; }
+    return true;
+}
+
+// The same convolution for 32 x 32 maps (the stock 5x5 layers), tuned to what tools/probes/conv4x4_probe.hip measured on the version above: 1.8 us of MFMAs,
+// 2.1 us of x reads (LDS bandwidth: 50 ds_read_b128 per wave), 0.3 us of filter reads, 1.0 us of epilogue (four-way conflicting 4-byte stores), all of it
+// back to back.  Here (a) the wave's two groups are vertically adjacent rows — lanes 0 - 31 rows r0 / r0 + 1, lanes 32 - 63 rows r0 + 2 / r0 + 3 — so the x vector
+// of tile row ry and column kx is group 0's operand for filter row ry and group 1's for filter row ry - 1: 6 x K reads instead of 2 x K x K, and group 1 reuses
+// the K filter vectors group 0 used one row earlier; (b) the roles of the operands are swapped — A = filter (row i = output channel), B = x (column j = pixel) —
+// so register i of a lane is channel i of ITS pixel: the output is one conflict-free ds_write_b128 per pixel and the sums are the VALU kernel's rs_reduce8.
+// (c) the bias comes from LDS (`bias_lds`, four floats left there by the prologue; NULL: none): a scalar load from memory inside this phase shares its
+// counter with the LDS reads (lgkmcnt, and scalar loads return out of order), so the first wait for a tile vector also waited 1 - 1.5 us for the bias; (d) four
+// accumulation chains — per group one for the even and one for the odd input channels — so that no MFMA waits for its predecessor's result (one chain per
+// group: every wave spent 2.6 us after its last MFMA was issued waiting for the chain to drain).
+template <int K, int CI>
+__device__ __forceinline__ bool rs_conv_c4_co4_32(const dcv_resident_op& o, const float4* xin, float* yt, const float* wl, const float* bias_lds, float* wsum) {
+    constexpr int XW = 32 + 2 * (K / 2), NS = (K + 1) * K, DEPTH = 2;
+    const int t = rs_tid(), lane = t & 63, wave = rs_wave_of(t), s = wave >> 3, w8 = wave & 7;
+    const int r0 = w8 * 4 + (lane >> 5) * 2, c = lane & 31;
+    const rs_f4* wl4 = reinterpret_cast<const rs_f4*>(wl) + (lane & 3);
+    const rs_f4* x0 = reinterpret_cast<const rs_f4*>(xin) + s * RS_XIN + r0 * XW + c;
+    // what the epilogue needs from memory is requested here: behind the sched_barriers of the tap loop its scalar loads (kernel argument, then the bias
+    // through the pointer found there) would only be issued when the MFMAs are done — two exposed round trips
+    const int act = o.act; const float slope = o.slope;
+    rs_f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc0b = {0.f, 0.f, 0.f, 0.f}, acc1b = {0.f, 0.f, 0.f, 0.f};
+    rs_f4 a[DEPTH + 1], wq[DEPTH + 1], wprev[K];
+    auto request = [&](int n, int slot) {
+        const int ry = n / K, kx = n - ry * K;
+        a[slot] = x0[ry * XW + kx];
+        if (ry < K) wq[slot] = wl4[(ry * K + kx) * 4];
+    };
+#pragma unroll
+    for (int n = 0; n < DEPTH; ++n) request(n, n % (DEPTH + 1));
+#pragma unroll
+    for (int n = 0; n < NS; ++n) {
+        const int slot = n % (DEPTH + 1), ry = n / K, kx = n - ry * K;
+        if (n + DEPTH < NS) request(n + DEPTH, (n + DEPTH) % (DEPTH + 1));
+        const rs_f4 av = a[slot];
+        const bool g1 = ry >= 1, g0 = ry < K;                                        // group 1 (rows r0 + 1): filter row ry - 1; group 0 (rows r0): filter row ry
+        const rs_f4 w1 = wprev[kx], w0 = g0 ? wq[slot] : wprev[kx];
+        if (g1) acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w1.x, av.x, acc1, 0, 0, 0);
+        if (g0) acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w0.x, av.x, acc0, 0, 0, 0);
+        if (g1) acc1b = __builtin_amdgcn_mfma_f32_4x4x1f32(w1.y, av.y, acc1b, 0, 0, 0);
+        if (g0) acc0b = __builtin_amdgcn_mfma_f32_4x4x1f32(w0.y, av.y, acc0b, 0, 0, 0);
+        if (g1) acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w1.z, av.z, acc1, 0, 0, 0);
+        if (g0) acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w0.z, av.z, acc0, 0, 0, 0);
+        if constexpr (CI > 3) {
+            if (g1) acc1b = __builtin_amdgcn_mfma_f32_4x4x1f32(w1.w, av.w, acc1b, 0, 0, 0);
+            if (g0) acc0b = __builtin_amdgcn_mfma_f32_4x4x1f32(w0.w, av.w, acc0b, 0, 0, 0);
+        }
+        if (g0) wprev[kx] = w0;
+        __builtin_amdgcn_sched_barrier(0);
+    }
     float q8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (p < per) {
-        const int rp = rs_fdiv(p, 1.f / (float)W), col = p - rp * W;
-        const float4* xs = xin + s * RS_XIN + (rp * 2) * XW + col;
-        float acc[2][4];
+    float4* yo = reinterpret_cast<float4*>(yt + s * RS_Y) + r0 * 32 + c;
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
+    for (int g = 0; g < 2; ++g) {
+        float v[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[k][c] = 0.f;
-        float4 old[K], nw[K];
-#pragma unroll
-        for (int sx = 0; sx < K; ++sx) old[sx] = xs[sx];
-#pragma unroll 1
-        for (int ky = 0; ky < K; ++ky) {                                             // rolled: one filter row of scalar operands live at a time
-#pragma unroll
-            for (int sx = 0; sx < K; ++sx) nw[sx] = xs[(ky + 1) * XW + sx];
-            rs_cfloat* wr = wl + ky * K * 16;
-#pragma unroll
-            for (int sx = 0; sx < K; ++sx) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    acc[0][c] = fmaf(old[sx].x, wr[sx * 16 + c], acc[0][c]);
-                    acc[0][c] = fmaf(old[sx].y, wr[sx * 16 + 4 + c], acc[0][c]);
-                    acc[0][c] = fmaf(old[sx].z, wr[sx * 16 + 8 + c], acc[0][c]);
-                    if constexpr (CI > 3) acc[0][c] = fmaf(old[sx].w, wr[sx * 16 + 12 + c], acc[0][c]);
-                    acc[1][c] = fmaf(nw[sx].x, wr[sx * 16 + c], acc[1][c]);
-                    acc[1][c] = fmaf(nw[sx].y, wr[sx * 16 + 4 + c], acc[1][c]);
-                    acc[1][c] = fmaf(nw[sx].z, wr[sx * 16 + 8 + c], acc[1][c]);
-                    if constexpr (CI > 3) acc[1][c] = fmaf(nw[sx].w, wr[sx * 16 + 12 + c], acc[1][c]);
-                }
-            }
-#pragma unroll
-            for (int sx = 0; sx < K; ++sx) old[sx] = nw[sx];
+        for (int i = 0; i < 4; ++i) {
+            v[i] = dcv_act_apply((g ? acc1[i] + acc1b[i] : acc0[i] + acc0b[i]) + (bias_lds ? bias_lds[i] : 0.f), act, slope);
+            q8[i] += v[i]; q8[4 + i] += v[i] * v[i];
         }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            float v[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                v[c] = dcv_act_apply(acc[k][c] + (o.bias ? RS_CONST(o.bias)[c] : 0.f), o.act, o.slope);
-                q8[c] += v[c]; q8[4 + c] += v[c] * v[c];
-            }
-            reinterpret_cast<float4*>(yt + s * RS_Y)[(rp * 2 + k) * W + col] = make_float4(v[0], v[1], v[2], v[3]);
-        }
+        yo[g * 32] = make_float4(v[0], v[1], v[2], v[3]);
     }
     float r[2];
     rs_reduce8(q8, r);                                                               // value index = quantity * 4 + channel
@@ -274,7 +367,7 @@ template <int K>
 __device__ __forceinline__ bool rs_conv_c4_wide(const dcv_resident_op& o, const float4* xin, float* yt, float* wsum) {
     const int H = o.h, W = o.w, pad = K / 2, XW = W + 2 * pad, HW = H * W, CO = o.cout, nq = CO >> 2;
     const int per = HW * nq;
-    for (int it = threadIdx.x; it < RS_SPB * per; it += RS_T) {
+    for (int it = rs_tid(); it < RS_SPB * per; it += RS_T) {
         const int s = __builtin_amdgcn_readfirstlane(it >= per ? 1 : 0), rem = it - s * per;
         const int qt = __builtin_amdgcn_readfirstlane(rem / HW), px = rem - qt * HW, r = px / W, col = px - r * W;
         const float4* xs = xin + s * RS_XIN + r * XW + col;
@@ -313,14 +406,14 @@ __device__ __forceinline__ void rs_mfma_store(const dcv_resident_op& o, const rs
 }
 // the same tile when only the first `co` (< 16) output channels exist (the data gradient of a 4 -> 16 layer): row base `yrow`, pixel stride `co`
 __device__ __forceinline__ void rs_mfma_store_narrow(const rs_f4& acc, float* yrow, int co) {
-    const int lane = threadIdx.x & 63, m = lane & 15, kq = lane >> 4;
+    const int lane = rs_tid() & 63, m = lane & 15, kq = lane >> 4;
     if (m < co) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) yrow[(4 * kq + i) * co + m] = acc[i];
     }
 }
 __device__ __forceinline__ void rs_mfma_sums(float sum, float sq, float* wsum) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = rs_tid(), lane = t & 63, wave = rs_wave_of(t);
     sum += __shfl_xor(sum, 16, 64); sq += __shfl_xor(sq, 16, 64);
     sum += __shfl_xor(sum, 32, 64); sq += __shfl_xor(sq, 32, 64);
     if (lane < 16) { wsum[(wave * 2) * RS_MAXC + lane] = sum; wsum[(wave * 2 + 1) * RS_MAXC + lane] = sq; }
@@ -332,7 +425,7 @@ __device__ __forceinline__ void rs_mfma_sums(float sum, float sq, float* wsum) {
 template <int K>
 __device__ __forceinline__ bool rs_conv_c4_mfma(const dcv_resident_op& o, const float4* xin, float* yt, float* wsum) {
     const int H = o.h, pad = K / 2, XW = 16 + 2 * pad;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4, s = wave >> 3;
+    const int t = rs_tid(), lane = t & 63, wave = rs_wave_of(t), m = lane & 15, kq = lane >> 4, s = wave >> 3;
     float breg[K * K];
     {
         const float* wp = o.filt + ((size_t)m * o.cin + (kq < o.cin ? kq : 0)) * (K * K);
@@ -362,7 +455,7 @@ __device__ __forceinline__ bool rs_conv_c4_mfma(const dcv_resident_op& o, const 
 // B fragments: lane (n = co = lane % 16, k = lane / 16) needs w[co][4k + j][tap], j < 4, tap < 9: 36 contiguous floats of the OIHW filter.  Requested by
 // the PREVIOUS layer's apply step (a global round trip, 1 - 2 us, which nothing there waits for).
 __device__ __forceinline__ void rs_load_bfrag(const float* w, float4 (&b4)[9]) {
-    const int lane = threadIdx.x & 63, m = lane & 15, kq = lane >> 4;
+    const int lane = rs_tid() & 63, m = lane & 15, kq = lane >> 4;
     const float4* wp = reinterpret_cast<const float4*>(w + ((size_t)m * 16 + 4 * kq) * 9);
 #pragma unroll
     for (int q = 0; q < 9; ++q) b4[q] = wp[q];
@@ -370,7 +463,7 @@ __device__ __forceinline__ void rs_load_bfrag(const float* w, float4 (&b4)[9]) {
 
 // the same fragments from the prepared data-gradient layout [n 16][kq 4][j 4][tap 9] (dcv_conv2d_prepare_filters op 4)
 __device__ __forceinline__ void rs_load_bfrag_prepared(const float* f, float4 (&b4)[9]) {
-    const int lane = threadIdx.x & 63, m = lane & 15, kq = lane >> 4;
+    const int lane = rs_tid() & 63, m = lane & 15, kq = lane >> 4;
     const float4* wp = reinterpret_cast<const float4*>(f + ((size_t)m * 4 + kq) * 36);
 #pragma unroll
     for (int q = 0; q < 9; ++q) b4[q] = wp[q];
@@ -381,7 +474,7 @@ __device__ __forceinline__ void rs_load_bfrag_prepared(const float* f, float4 (&
 // `o.cout` < 16 (data gradient towards a 4-channel tensor): the B fragments of the missing channels are zero, only `o.cout` channels are stored.
 __device__ __forceinline__ bool rs_conv_c16_mfma(const dcv_resident_op& o, const float4* xin, float* yt, const float4 (&b4)[9], float* wsum) {
     const int H = o.h, XW = 18, XH = H + 2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4, s = wave >> 3;
+    const int t = rs_tid(), lane = t & 63, wave = rs_wave_of(t), m = lane & 15, kq = lane >> 4, s = wave >> 3;
     float breg[36];
 #pragma unroll
     for (int q = 0; q < 9; ++q) { breg[4 * q] = b4[q].x; breg[4 * q + 1] = b4[q].y; breg[4 * q + 2] = b4[q].z; breg[4 * q + 3] = b4[q].w; }
@@ -419,12 +512,13 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
     __shared__ float s_samp[RS_SPB][2][RS_MAXC];                                     // per-sample sums of y, y^2
     __shared__ __attribute__((aligned(16))) float s_S[RS_SPB][RS_MAXC];              // layer output = S y + T
     __shared__ __attribute__((aligned(16))) float s_T[RS_SPB][RS_MAXC];
-    __shared__ float s_par[DCV_RESIDENT_MAX_OPS][6][RS_MAXC];                        // per-channel parameters of every layer: bn gamma, beta, running mean, var, gn gamma, beta
+    __shared__ __attribute__((aligned(16))) float s_par[DCV_RESIDENT_MAX_OPS][8][RS_MAXC];   // per-channel parameters of every layer: bn gamma, beta, running mean, var, gn gamma, beta, convolution bias
+    __shared__ __attribute__((aligned(16))) float s_filt[RS_FILT_OPS][RS_FILT_FLOATS];  // filters of the cin <= 4 -> 4 layers as [tap][co][ci] (rs_conv_c4_co4)
     __shared__ double s_tot[RS_MAXQ], s_red[4];                                      // batch totals of the current synchronisation
     __shared__ unsigned s_w32[2 * RS_MAXQ];
     __shared__ unsigned s_gen;
     __shared__ int s_fail;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x;
     const int s_of_t = t >> 9, tt = t & 511;                                         // sample-major split of the block for the per-sample passes
     const int N = p.n, G = (int)gridDim.x;
     const bool valid0 = (int)blockIdx.x * RS_SPB < N, valid1 = (int)blockIdx.x * RS_SPB + 1 < N;
@@ -437,16 +531,27 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
     stamp();
     {   // ONE global round trip: every layer's per-channel parameters -> LDS (the coefficient phases never wait for memory), the two samples -> the first
         // layer's padded tile (loads issued before the tile is zeroed)
-        float pv = 0.f; int pslot = -1;
-        if (t < p.count * 6 * RS_MAXC) {
-            const int oi = rs_fdiv(t, 1.f / (float)(6 * RS_MAXC)), r = t - oi * 6 * RS_MAXC, f = r >> 4, c = r & 15;
-            const dcv_resident_op& o = p.op[oi];
-            if (o.kind == DCV_RES_LAYER && c < o.cout) {
-                const float* src = f == 0 ? o.bn_gamma : f == 1 ? o.bn_beta : f == 2 ? o.running_mean : f == 3 ? o.running_var : f == 4 ? o.gn_gamma : o.gn_beta;
-                pslot = t;
-                pv = (f == 0 || f == 4) ? 1.f : 0.f;
-                if (src != nullptr) pv = src[c];
+        float pv[2] = {0.f, 0.f}; int pslot[2] = {-1, -1};                           // (up to 10 ops x 8 rows x 16 channels = 1280 slots: two per thread)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = t + k * RS_T;
+            if (e < p.count * 8 * RS_MAXC) {
+                const int oi = e >> 7, r = e & 127, f = r >> 4, c = r & 15;
+                const dcv_resident_op& o = p.op[oi];
+                if (o.kind == DCV_RES_LAYER && c < o.cout && f < 7) {
+                    const float* src = f == 0 ? o.bn_gamma : f == 1 ? o.bn_beta : f == 2 ? o.running_mean : f == 3 ? o.running_var : f == 4 ? o.gn_gamma : f == 5 ? o.gn_beta : o.bias;
+                    pslot[k] = e;
+                    pv[k] = (f == 0 || f == 4) ? 1.f : 0.f;
+                    if (src != nullptr) pv[k] = src[c];
+                }
             }
+        }
+        // ... the filters of the cin <= 4 -> 4 layers, element t of their [tap][co][ci] copy in LDS
+        float fv[RS_FILT_OPS];
+#pragma unroll
+        for (int k = 0; k < RS_FILT_OPS; ++k) {
+            fv[k] = 0.f;
+            if (k < p.count && p.op[k].kind == DCV_RES_LAYER && rs_variant(p.op[k].cin, p.op[k].cout, p.op[k].k, p.op[k].w) == 1) fv[k] = rs_filt_fetch(p.op[k].filt, p.op[k].k, t);
         }
         // ... and one float of every 64-B line of every filter: the scalar loads of the convolutions then find them in L2 instead of HBM
         {
@@ -466,6 +571,8 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
         const bool planes = o.x_nchw && C <= 4 && HW <= 2 * 512;                     // the RGB model input: a thread gathers the channels of its two pixels
         const int total = planes ? 0 : (vec ? HW * (C >> 2) : HW * C);
         float4 v4[SB]; float v1[SB];
+#pragma unroll
+        for (int k = 0; k < SB; ++k) { v4[k] = make_float4(0.f, 0.f, 0.f, 0.f); v1[k] = 0.f; }
         // a replayed step's batch: read through the address the host left in the mailbox for THIS replay, and kept in the static tensor for the backward pass
         const float* batch = o.x;
         if (p.mailbox != nullptr) batch = p.batch != nullptr ? p.batch : reinterpret_cast<const float*>(p.mailbox->src[p.x_job]);
@@ -488,7 +595,12 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
         }
         for (int i = t; i < RS_SPB * RS_XIN; i += RS_T) xin[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         rs_barrier();
-        if (pslot >= 0) (&s_par[0][0][0])[pslot] = pv;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) if (pslot[k] >= 0) (&s_par[0][0][0])[pslot[k]] = pv[k];
+        if (t < RS_FILT_FLOATS) {
+#pragma unroll
+            for (int k = 0; k < RS_FILT_OPS; ++k) s_filt[k][t] = fv[k];
+        }
         float* dst = xinf + (size_t)s_of_t * RS_XIN * 4;
         if (planes) {
 #pragma unroll
@@ -504,30 +616,36 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                 }
             }
         }
-        for (int e0 = 0; e0 < total; e0 += SB * 512) {
-            if (e0 > 0) {                                                            // samples larger than SB * 512 elements: further batches
-#pragma unroll
-                for (int k = 0; k < SB; ++k) {
-                    const int e = e0 + tt + k * 512;
-                    if (vec) v4[k] = reinterpret_cast<const float4*>(src)[e < total ? e : 0]; else v1[k] = src[e < total ? e : 0];
-                }
-            }
+        // (the first SB * 512 elements of the sample were requested before the tile was zeroed; larger samples: further batches through arrays of their own —
+        // one pair of arrays refilled inside the loop lived in scratch memory)
+        auto commit = [&](int e0, const float4 (&c4)[SB], const float (&c1)[SB]) {
 #pragma unroll
             for (int k = 0; k < SB; ++k) {
                 const int e = e0 + tt + k * 512;
-                if (keep && e < total) { if (vec) reinterpret_cast<float4*>(stat)[e] = v4[k]; else stat[e] = v1[k]; }
+                if (keep && e < total) { if (vec) reinterpret_cast<float4*>(stat)[e] = c4[k]; else stat[e] = c1[k]; }
                 if (e < total && n < N) {
                     if (vec) {
                         const int px = rs_fdiv(e, inv_cv), cv = e - px * (C >> 2), r = rs_fdiv(px, inv_w), col = px - r * o.w;
-                        reinterpret_cast<float4*>(dst)[(cv * XH + r + pad) * XW + col + pad] = v4[k];
+                        reinterpret_cast<float4*>(dst)[(cv * XH + r + pad) * XW + col + pad] = c4[k];
                     } else {
                         int c, px;
                         if (o.x_nchw) { c = rs_fdiv(e, inv_hw); px = e - c * HW; } else { px = rs_fdiv(e, inv_c); c = e - px * C; }
                         const int r = rs_fdiv(px, inv_w), col = px - r * o.w;
-                        dst[(((c >> 2) * XH + r + pad) * XW + col + pad) * 4 + (c & 3)] = v1[k];
+                        dst[(((c >> 2) * XH + r + pad) * XW + col + pad) * 4 + (c & 3)] = c1[k];
                     }
                 }
             }
+        };
+        if (total > 0) commit(0, v4, v1);
+        for (int e0 = SB * 512; e0 < total; e0 += SB * 512) {
+            float4 n4[SB]; float n1[SB];
+#pragma unroll
+            for (int k = 0; k < SB; ++k) {
+                const int e = e0 + tt + k * 512;
+                n4[k] = make_float4(0.f, 0.f, 0.f, 0.f); n1[k] = 0.f;
+                if (vec) n4[k] = reinterpret_cast<const float4*>(src)[e < total ? e : 0]; else n1[k] = src[e < total ? e : 0];
+            }
+            commit(e0, n4, n1);
         }
     }
     rs_barrier();
@@ -538,12 +656,19 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
     int fc_from_y = 0;                                                               // the FC input is the wide tensor a LINK left in yt
     for (int oi = 0; oi < p.count; ++oi) {
         const dcv_resident_op& o = p.op[oi];
+        const int t = rs_tid(), lane = t & 63, wave = rs_wave_of(t), s_of_t = __builtin_amdgcn_readfirstlane(t >> 9), tt = t & 511;     // (per op: see rs_tid)
         if (o.kind == DCV_RES_LAYER) {
             const int C = o.cout, CV = C >> 2, H = o.h, W = o.w, HW = H * W;
             // ---- convolution + bias + activation: xin -> yt, per-wave sums of y, y^2 -> s_wsum
             if (!conv_done) {
                 const int var = rs_variant(o.cin, o.cout, o.k, o.w);
-                if (var == 1) sums_done = o.k == 5 ? (o.cin == 3 ? rs_conv_c4_co4<5, 3>(o, xin, yt, s_wsum) : rs_conv_c4_co4<5>(o, xin, yt, s_wsum)) : rs_conv_c4_co4<3>(o, xin, yt, s_wsum);
+                if (var == 1) {
+                    const float* wl = s_filt[oi < RS_FILT_OPS ? oi : 0];
+                    const float* bl = o.bias ? s_par[oi][6] : nullptr;
+                    if (o.k == 3) sums_done = rs_conv_c4_co4<3, 4, 0>(o, xin, yt, wl, bl, s_wsum);
+                    else if (o.w != 32 || o.h != 32) sums_done = rs_conv_c4_co4<5, 4, 0>(o, xin, yt, wl, bl, s_wsum);
+                    else sums_done = o.cin == 3 ? rs_conv_c4_co4_32<5, 3>(o, xin, yt, wl, bl, s_wsum) : rs_conv_c4_co4_32<5, 4>(o, xin, yt, wl, bl, s_wsum);
+                }
                 else if (var == 2) sums_done = o.k == 3 ? rs_conv_c4_wide<3>(o, xin, yt, s_wsum) : rs_conv_c4_wide<1>(o, xin, yt, s_wsum);
                 else if (var == 4) sums_done = o.k == 3 ? rs_conv_c4_mfma<3>(o, xin, yt, s_wsum) : rs_conv_c4_mfma<1>(o, xin, yt, s_wsum);
                 else { float4 b4[9]; rs_load_bfrag(o.filt, b4); sums_done = rs_conv_c16_mfma(o, xin, yt, b4, s_wsum); }
@@ -612,6 +737,7 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                                 const int n = (int)blockIdx.x * RS_SPB + e / p.op[k].cout;
                                 if (n < N) p.op[k].out[(size_t)n * p.op[k].cout + e % p.op[k].cout] = __builtin_nanf("");
                             }
+                    if (blockIdx.x == 0 && t == 0) __hip_atomic_store((rs_gu32*)ctl, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (a later launch must not take this launch's granules for its own)
                     return;
                 }
             } else rs_barrier();
@@ -807,7 +933,7 @@ __host__ __device__ __forceinline__ int rb_dgrad_variant(int cin, int cout, int 
 // layout) feed 16 FMAs; the two halves' partial sums meet in the DO region.  295 k FMAs per block instead of the 1.2 M MACs of the 16 <- 16 matrix-core tile.
 __device__ __forceinline__ void rb_dgrad_c16_co4(const float* filt, const float4* dzt, float* dor) {
     constexpr int XH = 18, XW = 18;
-    const int t = threadIdx.x, hv = __builtin_amdgcn_readfirstlane(t >> 9), tt = t & 511, ss = __builtin_amdgcn_readfirstlane(tt >> 8), px = tt & 255, r = px >> 4, c = px & 15;
+    const int t = rs_tid(), hv = __builtin_amdgcn_readfirstlane(t >> 9), tt = t & 511, ss = __builtin_amdgcn_readfirstlane(tt >> 8), px = tt & 255, r = px >> 4, c = px & 15;
     rs_cfloat* wl = RS_CONST(filt);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
@@ -845,68 +971,172 @@ __device__ __forceinline__ void rb_dgrad_c16_co4(const float* filt, const float4
 // sample for it: nothing is reduced across waves, a unit's result goes straight to its chunk (2 * block + sample slot) of the layer's partial slab, and the
 // step's one dcv_slab_reduce sums the chunks.  xt: the layer's zero-padded input tile (same layout as the forward's), dzt: its zero-padded dz tile.
 __host__ __device__ __forceinline__ int rb_wgrad_variant(int cin, int cout, int k, int w) {
-    if (cin <= 4 && cout == 4 && (k == 3 || k == 5)) return 1;                       // VALU, lanes = pixels
+    if (cin <= 4 && cout == 4 && (k == 3 || k == 5) && w <= 32) return 1;            // VALU, lanes = image columns (rb_wgrad_c4_rows_ok: the rows)
     if (cin <= 4 && cout == 16 && k == 3 && w == 16) return 2;                       // MFMA, M = (filter column, input channel)
     if (cin == 16 && cout == 16 && k == 3 && w == 16) return 3;                      // MFMA, M = input channel
     return 0;
 }
 
-// cin <= 4 -> 4: unit = (filter row ky, output-channel pair, sample) + one bias unit per sample.  Lanes = pixels: per pixel the K input vectors of the row's
-// sliding window and one dz vector feed K * 8 FMAs (K = 5: 40 FMAs per 6 ds_read_b128; a unit per single tap does 16 per 2 and spent as many instructions
-// on reads and index arithmetic as on FMAs: 13 us per 5x5 layer), into the lane's [kx][ci][co of the pair] accumulators; K halving reductions finish it.
-template <int K>
-__device__ __forceinline__ void rb_wgrad_c4(const dcv_resident_bwd_op& o, const float4* xt, const float4* dzt) {
-    const int H = o.h, W = o.w, pad = K / 2, XW = W + 2 * pad, HW = H * W, wsize = o.cout * o.cin * K * K;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float inv_w = 1.f / (float)W;
-    constexpr int UPS = 2 * K + 1;                                                   // units per sample: K filter rows x 2 channel pairs, + the bias
-    for (int u = wave; u < RS_SPB * UPS; u += 16) {
-        const int s = u >= UPS ? 1 : 0, v = u - s * UPS, chunk = (int)blockIdx.x * RS_SPB + s;
-        const float4* ds = dzt + s * RS_XIN + pad * XW + pad;
-        if (v == 2 * K) {                                                            // bias gradient: sum of dz per output channel
-            float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rb[2];
-            for (int px = lane; px < HW; px += 64) { const int r = rs_fdiv(px, inv_w), c = px - r * W; const float4 d = ds[r * XW + c]; b8[0] += d.x; b8[1] += d.y; b8[2] += d.z; b8[3] += d.w; }
-            rs_reduce8(b8, rb);
-            if (o.db_part && (lane == 0 || lane == 2)) { o.db_part[(size_t)chunk * o.cout + lane] = rb[0]; o.db_part[(size_t)chunk * o.cout + lane + 1] = rb[1]; }
-            continue;
+// rows of the maps rb_wgrad_c4 covers: equal row groups, and for K = 5 row groups which split into four quarters
+__host__ __device__ __forceinline__ bool rb_wgrad_c4_rows_ok(int h, int w, int k) {
+    const int rg = (w > 0 && (w & (w - 1)) == 0) ? 32 / w : 1;
+    return w > 0 && w <= 32 && rg > 0 && h % rg == 0 && (k != 5 || (h / rg) % 4 == 0);
+}
+
+// cin <= 4 -> 4, K x K on maps of at most 32 columns.  UNIT = (filter column kx, output channel co) for BOTH samples of the block: lanes 0 - 31 work on
+// the first sample, lanes 32 - 63 on the second; a lane owns one image column (maps narrower than 32: 32 / W row groups side by side) and walks DOWN its
+// rows.  Walking down, the K input vectors x[r + ky][c + kx] of a step are a sliding window: one new ds_read_b128 of x and one of dz per step feed K * 4
+// FMAs into the lane's [ky][ci] accumulators — a fifth of the LDS traffic of a unit per (filter row, channel pair) (6 ds_read_b128 per 40 FMAs: with 16
+// waves that is 24 LDS-array cycles against 20 VALU cycles per step and SIMD, the phase was LDS-bound), no index arithmetic inside the loop (rows are a
+// constant stride apart), and the window rotates through register NAMES (the loop is unrolled by K), not through moves.  K = 5: the 16 units of the filter
+// columns 0 - 3 go one to each wave; the four units of column 4 are cut into four row ranges each (16 quarter units, one per wave) whose partial sums meet
+// in LDS (`scratch`, 2 * 16 * K * 4 floats) in a fixed order — every wave does 1.25 units, none idles.  K = 3: 12 units, one round.  A unit's totals over
+// its 32 lanes come from rs_reduce8 without the last (cross-sample) exchange.  The units of filter column 0 also sum dz (bias gradient).
+typedef float rs_f2 __attribute__((ext_vector_type(2)));
+template <int CO> __device__ __forceinline__ float rb_comp(const rs_f4& v) { return v[CO]; }
+
+// one unit over rows [0, nrows) relative to xs / ds (xs: x tile at (first row, column + kx); ds: dz tile interior at (first row, column)): whole groups
+// of K rows with the window rotating through register names, the remaining rows one at a time with a shifting window.  XW: the tiles' row stride in
+// float4 — a compile-time constant makes every row offset of a group an immediate of its ds_read (one address register per tile, advanced once per group).
+// Accumulators are explicit pairs (v_pk_fma_f32 with the dz value broadcast): left to the SLP vectoriser, the unrolled group turned into packed
+// multiplies across steps plus separate adds, and 269 spilled registers.
+template <int K, int CI, int CO>
+__device__ __forceinline__ void rb_wg_unit(const rs_f4* xs, const rs_f4* ds, const int XW, int nrows, bool live, rs_f2 (&acc)[K][2], float& bsum) {
+    constexpr int S = K + 1;                                                         // window slots: the K rows of the step + the row requested for the next one
+    rs_f4 w[S];
+#pragma unroll
+    for (int j = 0; j < K; ++j) w[j] = xs[j * XW];
+    rs_f4 dn = ds[0];
+    auto fma_rows = [&](const rs_f4 (&win)[S], int j0, float d) {
+        const rs_f2 d2 = {d, d};
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const rs_f4 xv = win[(j0 + ky) % S];
+            acc[ky][0] = __builtin_elementwise_fma(xv.xy, d2, acc[ky][0]);
+            if constexpr (CI > 3) acc[ky][1] = __builtin_elementwise_fma(xv.zw, d2, acc[ky][1]);
+            else acc[ky][1].x = fmaf(xv.z, d, acc[ky][1].x);
         }
-        const int ky = v >> 1, h2 = v & 1;
-        const float4* xs = xt + s * RS_XIN + ky * XW;
-        float acc[K][8];
+    };
+    int r0 = 0;
+    for (; r0 + S <= nrows; r0 += S) {
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx)
+        for (int j = 0; j < S; ++j) {
+            // both operands of the NEXT step are requested first (its x row goes into the slot of the row which left the window): an LDS round trip later,
+            // when this step's FMAs are done, they have landed
+            const bool more = j + 1 < S || r0 + S < nrows;
+            w[(j + K) % S] = xs[(more ? j + K : j + K - 1) * XW];
+            const rs_f4 dc = dn;
+            dn = ds[(more ? j + 1 : j) * XW];
+            float d = rb_comp<CO>(dc);
+            if (!live) d = 0.f;
+            bsum += d;
+            fma_rows(w, j, d);
+        }
+        xs += S * XW; ds += S * XW;
+    }
+    for (; r0 < nrows; ++r0) {                                                       // at most K rows: rows r0 .. r0 + K - 1 sit in slots 0 .. K - 1
+        const bool more = r0 + 1 < nrows;
+        w[K] = xs[(more ? K : K - 1) * XW];
+        const rs_f4 dc = dn;
+        dn = ds[(more ? 1 : 0) * XW];
+        float d = rb_comp<CO>(dc);
+        if (!live) d = 0.f;
+        bsum += d;
+        fma_rows(w, 0, d);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[kx][i] = 0.f;
-        for (int px = lane; px < HW; px += 64) {
-            const int r = rs_fdiv(px, inv_w), c = px - r * W, a = r * XW + c;
-            const float4 d4 = ds[a];
-            const float d0 = h2 ? d4.z : d4.x, d1 = h2 ? d4.w : d4.y;
+        for (int j = 0; j < K; ++j) w[j] = w[j + 1];
+        xs += XW; ds += XW;
+    }
+}
+
+// rs_reduce8 over the 32 lanes of each half of the wave: lanes 0 - 3 hold the first half's eight totals (as rs_reduce8), lanes 32 - 35 the second half's
+__device__ __forceinline__ void rs_reduce8_half(const float (&v)[8], float (&r)[2]) {
+    const int lane = rs_tid() & 63;
+    const bool b0 = lane & 1, b1 = lane & 2;
+    float a[4], b[2];
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-                const float4 x4 = xs[a + kx];
-                acc[kx][0] += x4.x * d0; acc[kx][1] += x4.x * d1; acc[kx][2] += x4.y * d0; acc[kx][3] += x4.y * d1;
-                acc[kx][4] += x4.z * d0; acc[kx][5] += x4.z * d1; acc[kx][6] += x4.w * d0; acc[kx][7] += x4.w * d1;
+    for (int i = 0; i < 4; ++i) { const float mine = b0 ? v[4 + i] : v[i], send = b0 ? v[i] : v[4 + i]; a[i] = mine + rs_dpp_mov<0xB1>(send); }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const float mine = b1 ? a[2 + i] : a[i], send = b1 ? a[i] : a[2 + i]; b[i] = mine + rs_dpp_mov<0x4E>(send); }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        b[i] += rs_dpp_mov<0x124>(b[i]);        // row_ror:4
+        b[i] += rs_dpp_mov<0x128>(b[i]);        // row_ror:8
+        b[i] += __shfl_xor(b[i], 16, 64);
+        r[i] = b[i];
+    }
+}
+
+// `pass` 0: the wave's own unit (filter column wave / 4, all rows); pass 1 (K = 5): its quarter of the last filter column's unit -> scratch
+template <int K, int CI, int CO, int XWC>
+__device__ __forceinline__ void rb_wgrad_c4_units(const dcv_resident_bwd_op& o, const float4* xt, const float4* dzt, int wave, float* scratch) {
+    constexpr int pad = K / 2, FULL = 4 * K <= 16 ? 4 * K : 16;
+    const int W = XWC > 0 ? XWC - 2 * pad : o.w, XW = XWC > 0 ? XWC : W + 2 * pad, H = o.h;
+    const bool pow2 = (W & (W - 1)) == 0;
+    const int RG = pow2 ? 32 / W : 1, RPG = H / RG;                                  // row groups side by side in a half-wave; rows per group (H % RG == 0)
+    const int chunk0 = (int)blockIdx.x * RS_SPB, wsize = o.cout * o.cin * K * K;
+#pragma unroll 1
+    for (int pass = (wave < FULL ? 0 : 1); pass < (4 * K > 16 ? 2 : 1); ++pass) {
+        const int kx = pass == 0 ? wave >> 2 : K - 1, q = wave >> 2;
+        const int nrows = pass == 0 ? RPG : RPG >> 2, row0 = pass == 0 ? 0 : q * nrows;
+        const int lane = rs_tid() & 63, s = lane >> 5, l32 = lane & 31;
+        const int g = pow2 ? l32 / W : 0, c = l32 - g * W;
+        const bool live = l32 < RG * W;
+        const int first = live ? g * RPG + row0 : 0, col = live ? c : 0;
+        rs_f2 acc[K][2];
+        float bsum = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) { acc[ky][0] = rs_f2{0.f, 0.f}; acc[ky][1] = rs_f2{0.f, 0.f}; }
+        rb_wg_unit<K, CI, CO>(reinterpret_cast<const rs_f4*>(xt) + s * RS_XIN + first * XW + col + kx, reinterpret_cast<const rs_f4*>(dzt) + s * RS_XIN + (first + pad) * XW + col + pad,
+                              XW, nrows, live, acc, bsum);
+        // totals per half-wave; value index of a call = (ky of the pair) * 4 + ci
+        const int vi = (l32 & 1) * 4 + ((l32 >> 1) & 1) * 2;
+#pragma unroll
+        for (int k2 = 0; k2 < (K + 1) / 2; ++k2) {
+            float v[8], r2[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v[i] = acc[2 * k2][i >> 1][i & 1]; v[4 + i] = 2 * k2 + 1 < K ? acc[2 * k2 + 1 < K ? 2 * k2 + 1 : 0][i >> 1][i & 1] : (i == 0 ? bsum : 0.f); }
+            rs_reduce8_half(v, r2);
+            if (l32 < 4) {
+                const int ky = 2 * k2 + (vi >> 2), ci = vi & 3;
+                if (ky < K) {
+                    if (pass == 1) { float* sc = scratch + ((q * RS_SPB + s) * 4 + CO) * (K * 4) + ky * 4 + ci; sc[0] = r2[0]; sc[1] = r2[1]; }
+                    else {
+                        float* dst = o.dw_part + (size_t)(chunk0 + s) * wsize + ((ky * K + kx) * o.cout + CO) * o.cin;      // [tap][co][ci]
+                        if (ci < o.cin) dst[ci] = r2[0];
+                        if (ci + 1 < o.cin) dst[ci + 1] = r2[1];
+                    }
+                } else if (ci == 0 && kx == 0 && pass == 0 && o.db_part) o.db_part[(size_t)(chunk0 + s) * o.cout + CO] = r2[0];   // (odd K: the spare slot of the last pair carries the sum of dz)
             }
         }
-#pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
-            float r2[2];
-            rs_reduce8(acc[kx], r2);                                                 // value index = ci * 2 + (channel of the pair)
-            if (lane < 4) {
-                const int vi = (lane & 1) * 4 + ((lane >> 1) & 1) * 2;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int ci = (vi + j) >> 1, co = 2 * h2 + ((vi + j) & 1);
-                    if (ci < o.cin) o.dw_part[(size_t)chunk * wsize + (ky * K + kx) * (o.cout * o.cin) + co * o.cin + ci] = r2[j];      // [tap][co][ci]: the four lanes' values are neighbours
-                }
-            }
+    }
+}
+
+template <int K, int CI, int XWC>
+__device__ __forceinline__ void rb_wgrad_c4(const dcv_resident_bwd_op& o, const float4* xt, const float4* dzt, float* scratch) {
+    const int t = rs_tid(), wave = rs_wave_of(t), co = wave & 3;
+    if (co == 0) rb_wgrad_c4_units<K, CI, 0, XWC>(o, xt, dzt, wave, scratch);
+    else if (co == 1) rb_wgrad_c4_units<K, CI, 1, XWC>(o, xt, dzt, wave, scratch);
+    else if (co == 2) rb_wgrad_c4_units<K, CI, 2, XWC>(o, xt, dzt, wave, scratch);
+    else rb_wgrad_c4_units<K, CI, 3, XWC>(o, xt, dzt, wave, scratch);
+    if constexpr (4 * K > 16) {
+        static_assert(4 * K == 20, "the split of the last filter column assumes K = 5");
+        rs_barrier();
+        if (t < RS_SPB * 4 * K * 4) {                                              // (sample, co, ky, ci): the four quarters in a fixed order
+            const int ss = t / (4 * K * 4), e = t - ss * (4 * K * 4), c2 = e / (K * 4), f = e - c2 * (K * 4), ky = f >> 2, ci = f & 3;
+            const float* sc = scratch + (ss * 4 + c2) * (K * 4) + f;
+            constexpr int QS = RS_SPB * 4 * K * 4;
+            const float v = (sc[0] + sc[QS]) + (sc[2 * QS] + sc[3 * QS]);
+            const int chunk = (int)blockIdx.x * RS_SPB + ss, wsize = o.cout * o.cin * K * K;
+            if (ci < o.cin) o.dw_part[(size_t)chunk * wsize + ((ky * K + (K - 1)) * o.cout + c2) * o.cin + ci] = v;
         }
     }
 }
 
 // sum of dz per channel (bias gradient) of a 16-channel layer: unit = sample, lanes = pixels x channel vectors
 __device__ __forceinline__ void rb_bias16(const dcv_resident_bwd_op& o, const float4* dzt, int unit_wave0) {
-    const int H = o.h, XW = 18, XH = H + 2, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tb = rs_tid();
+    const int H = o.h, XW = 18, XH = H + 2, lane = tb & 63, wave = rs_wave_of(tb);
     if (!o.db_part) return;
     for (int s = 0; s < RS_SPB; ++s) {
         if (wave != ((unit_wave0 + s) & 15)) continue;
@@ -950,7 +1180,8 @@ __device__ __forceinline__ void rb_mfma_rows(const float* xa, const float* db, i
 // 16 -> 16, 3x3, rows of 16 pixels: unit = (tap, sample): D[ci][co] += A[ci][4 pixels] B[4 pixels][co] over the 64 pixel quads of the sample, one
 // v_mfma_f32_16x16x4_f32 each (A: x at the tap's offset, B: dz; one ds_read_b32 per operand and lane).
 __device__ __forceinline__ void rb_wgrad_c16(const dcv_resident_bwd_op& o, const float4* xt, const float4* dzt) {
-    const int H = o.h, XW = 18, XH = H + 2, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4;
+    const int tw = rs_tid();
+    const int H = o.h, XW = 18, XH = H + 2, lane = tw & 63, wave = rs_wave_of(tw), m = lane & 15, kq = lane >> 4;
     const float* xf = reinterpret_cast<const float*>(xt); const float* df = reinterpret_cast<const float*>(dzt);
     for (int u = wave; u < RS_SPB * 9; u += 16) {
         const int s = u >= 9 ? 1 : 0, tap = u - s * 9, ky = tap / 3, kx = tap - ky * 3;
@@ -966,7 +1197,8 @@ __device__ __forceinline__ void rb_wgrad_c16(const dcv_resident_bwd_op& o, const
 
 // cin <= 4 -> 16, 3x3, rows of 16 pixels: unit = (filter row, sample): M = (filter column 0..3, input channel), the fourth column is not a tap (dropped)
 __device__ __forceinline__ void rb_wgrad_c4x16(const dcv_resident_bwd_op& o, const float4* xt, const float4* dzt) {
-    const int H = o.h, XW = 18, XH = H + 2, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4;
+    const int tw = rs_tid();
+    const int H = o.h, XW = 18, XH = H + 2, lane = tw & 63, wave = rs_wave_of(tw), m = lane & 15, kq = lane >> 4;
     const float* xf = reinterpret_cast<const float*>(xt); const float* df = reinterpret_cast<const float*>(dzt);
     for (int u = wave; u < RS_SPB * 3; u += 16) {
         const int s = u >= 3 ? 1 : 0, ky = u - s * 3;
@@ -983,9 +1215,15 @@ __device__ __forceinline__ void rb_wgrad_c4x16(const dcv_resident_bwd_op& o, con
     rb_bias16(o, dzt, 6);
 }
 
-__device__ __forceinline__ void rb_wgrad(const dcv_resident_bwd_op& o, const float4* xt, const float4* dzt) {
+__device__ __forceinline__ void rb_wgrad(const dcv_resident_bwd_op& o, const float4* xt, const float4* dzt, float* scratch) {
     const int var = rb_wgrad_variant(o.cin, o.cout, o.k, o.w);
-    if (var == 1) { if (o.k == 5) rb_wgrad_c4<5>(o, xt, dzt); else rb_wgrad_c4<3>(o, xt, dzt); }
+    if (var == 1) {
+        if (o.k == 5) {
+            if (o.w != 32) rb_wgrad_c4<5, 4, 0>(o, xt, dzt, scratch);
+            else if (o.cin == 3) rb_wgrad_c4<5, 3, 36>(o, xt, dzt, scratch);
+            else rb_wgrad_c4<5, 4, 36>(o, xt, dzt, scratch);
+        } else rb_wgrad_c4<3, 4, 0>(o, xt, dzt, scratch);
+    }
     else if (var == 2) rb_wgrad_c4x16(o, xt, dzt);
     else rb_wgrad_c16(o, xt, dzt);
 }
@@ -1033,7 +1271,7 @@ struct rb_fc_args { float* fc_dw; float* fc_db; int classes, cw, hwo, n, pg; };
 // (not inlined, arguments by value: inlined, its registers pushed the allocation of the kernel's hot loops into spills — 0.2551 -> 0.2698 ms per step)
 __device__ __attribute__((noinline)) void rb_fc_wgrad(const rb_fc_args hd, const float* staged, float* scratch) {
     const int O = hd.classes, Cw = hd.cw, HWo = hd.hwo, K = HWo * Cw, N = hd.n, pg = hd.pg;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, n = t & 511, half = t >> 9;
+    const int t = rs_tid(), lane = t & 63, wave = rs_wave_of(t), n = t & 511, half = __builtin_amdgcn_readfirstlane(t >> 9);
     const float4 x4 = reinterpret_cast<const float4*>(staged + 512 * RB_FC_MAXO)[t];
     float dz[RB_FC_MAXO];
 #pragma unroll
@@ -1090,7 +1328,10 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
     __shared__ __attribute__((aligned(16))) float s_mr[2][RS_MAXC];                  // BatchNorm mean, rstd of the current layer
     __shared__ float s_abn[RS_SPB][RS_MAXC];                                         // BatchNorm gamma * rstd
     __shared__ float s_par[DCV_RESIDENT_BWD_MAX_OPS][5][RS_MAXC];                    // bn gamma, beta, mean, rstd, gn gamma of every layer
-    __shared__ float s_dummy[16 * 2 * RS_MAXC];
+    __shared__ float s_scratch[4 * RS_SPB * 4 * 5 * 4];                              // data-gradient phases: the convolutions' unused sums; weight-gradient phases: quarter-unit partials (rb_wgrad_c4)
+    float* const s_dummy = s_scratch;
+    float* const s_wgq = s_scratch;
+    __shared__ __attribute__((aligned(16))) float s_filt[RB_FILT_SLOTS][RS_FILT_FLOATS];  // data-gradient filters of the 4 <- 4 layers as [tap][co][ci] (rs_conv_c4_co4)                                  // quarter-unit partials of the 5x5 weight gradient (rb_wgrad_c4)
     __shared__ unsigned s_gen;
     __shared__ int s_fail;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1148,6 +1389,21 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
                 pslot = t;
                 pv = (f == 0 || f == 4) ? 1.f : 0.f;
                 if (src != nullptr) pv = src[c];
+            }
+        }
+        // the filters of the 4 <- 4 data gradients: the n-th such op owns slot n of s_filt (rb_filt_slot)
+        float fv[RB_FILT_SLOTS];
+#pragma unroll
+        for (int sl = 0; sl < RB_FILT_SLOTS; ++sl) fv[sl] = 0.f;
+        {
+            int ns = 0;
+#pragma unroll
+            for (int k = 0; k < DCV_RESIDENT_BWD_MAX_OPS; ++k) {
+                if (k < p.count && p.op[k].need_dx && rb_dgrad_variant(p.op[k].cin, p.op[k].cout, p.op[k].k, p.op[k].w) == 1) {
+#pragma unroll
+                    for (int sl = 0; sl < RB_FILT_SLOTS; ++sl) if (ns == sl) fv[sl] = rs_filt_fetch(p.op[k].filt, p.op[k].k, t);
+                    ++ns;
+                }
             }
         }
         const dcv_resident_bwd_op& o = p.op[0];
@@ -1225,6 +1481,10 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         } else load_flat(o.y, yreg, o.h * o.w * o.cout);
         if (!p.head.enabled) load_flat(o.dout, dor, (o.h / pk) * (o.w / pk) * o.cout);
         if (pslot >= 0) (&s_par[0][0][0])[pslot] = pv;
+        if (t < RS_FILT_FLOATS) {
+#pragma unroll
+            for (int sl = 0; sl < RB_FILT_SLOTS; ++sl) s_filt[sl][t] = fv[sl];
+        }
     }
     if (stage_dz) rs_barrier();
     stamp();
@@ -1320,13 +1580,20 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
     rs_barrier();
     const unsigned gen = s_gen;
     stamp();
-    for (int oi = 0; oi < p.count; ++oi) {
-        const dcv_resident_bwd_op& o = p.op[oi];
+    // One more pass than ops: the last one (`tail`) only computes the first layer's weight gradient, which has no later all-reduce to hide behind — ONE
+    // call site of rb_wgrad in the loop instead of a second copy of all its variants behind it.
+    for (int oi = 0; oi <= p.count; ++oi) {
+        const bool tail = oi == p.count;
+        const dcv_resident_bwd_op& o = p.op[tail ? oi - 1 : oi];
+        const int t = rs_tid(), lane = t & 63, wave = rs_wave_of(t), s_of_t = __builtin_amdgcn_readfirstlane(t >> 9), tt = t & 511;     // (per op: see rs_tid)
         const int C = o.cout, CV = C >> 2, H = o.h, W = o.w, HW = H * W, pk = o.pool > 0 ? o.pool : 1, Wo = W / pk;
         const float pinv = 1.f / (float)(pk * pk), inv_w = 1.f / (float)W, inv_pk = 1.f / (float)pk;
         // the (sample, channel) threads of wave 0 request their GroupNorm statistics now; used after the moments
         const int ac_ss = t >= C ? 1 : 0, ac_c = t - ac_ss * C, ac_n = (int)blockIdx.x * RS_SPB + ac_ss;
         const int cpg = o.groups > 0 ? C / o.groups : 1;
+        const unsigned epoch = gen * DCV_RESIDENT_MAX_OPS + (unsigned)oi + 1u;
+        rs_u64* go = gran + (size_t)(tail ? 0 : oi) * RS_GRAN_OP;
+        if (!tail) {
         float e_gr = 0.f, e_gm = 0.f;
         if (t < RS_SPB * C && o.groups > 0 && ac_n < N) {
             const int g = rs_fdiv(ac_c, 1.f / (float)cpg);
@@ -1366,8 +1633,6 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         rs_barrier();
         stamp();
         // ---- the sample's algebra (norm_chain.hip, nc_sample_sums_kernel's epilogue) by thread (sample, channel) of wave 0; publish the block's T1, T2
-        const unsigned epoch = gen * DCV_RESIDENT_MAX_OPS + (unsigned)oi + 1u;
-        rs_u64* go = gran + (size_t)oi * RS_GRAN_OP;
         float mine = 0.f;
         if (t < RS_SPB * C) {
             const int ss = ac_ss, c = ac_c, ccv = c >> 2, j = c & 3, stripes = 8 / CV;
@@ -1407,11 +1672,13 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         // still intact), then reduce / collect
         rs_allreduce_publish(go, epoch, 2 * C, mine, mute);
         rs_allreduce_reduce_owned(go, go + RS_MAXQ * RS_MAXG, epoch, 2 * C, G, s_red, &s_fail);   // the few owner blocks: before their own weight gradient, so that nobody waits for it
-        if (oi > 0 && p.op[oi - 1].dw_part != nullptr) rb_wgrad(p.op[oi - 1], xtt, dzt);
+        }
+        if (oi > 0 && p.op[oi - 1].dw_part != nullptr) rb_wgrad(p.op[oi - 1], xtt, dzt, s_wgq);
         else if (oi == 0 && fc_pg >= 0) {
             const rb_fc_args fa = {p.head.fc_dw, p.head.fc_db, p.head.classes, p.head.cc + p.head.cr, p.head.h * p.head.w, N, fc_pg};
             rb_fc_wgrad(fa, reinterpret_cast<const float*>(dzt), reinterpret_cast<float*>(xtt));      // (operands parked in the dz tile's region, the x tile is not in use yet)
         }
+        if (tail) break;
         rs_barrier();
         stamp();
         // the next op's y is requested now (two float4 per thread: a sample holds at most RS_Y floats) and lands in LDS after the dz step, when this
@@ -1448,9 +1715,31 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
             }
         }
         if (!rs_allreduce_collect(go + RS_MAXQ * RS_MAXG, epoch, 2 * C, s_tot, s_w32, &s_fail)) {
-            // a block of this grid is not resident: report, poison the first layer's dz, leave
+            // a block of this grid is not resident: report (the error word: resident.check_status) and make the failure visible on the path a training loop
+            // reads anyway — every gradient this launch owes is poisoned with NaN (the block's own chunks of every partial slab, the BatchNorm parameter
+            // gradients, dz / dx where they leave the launch, the head's weight gradient), so the optimizer carries NaN into the weights and the NEXT loss the
+            // host reads is NaN (the loss of this step was published by the head before anything could fail).  The launch generation still advances: a
+            // later launch must not take this launch's granules for its own.
+            const float qnan = __builtin_nanf("");
             if (t == 0) { __hip_atomic_store((rs_gu32*)(ctl + 1), (unsigned)oi + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-            if (blockIdx.x == 0 && t < p.op[p.count - 1].cout) p.op[p.count - 1].dz[t] = __builtin_nanf("");
+            for (int k = 0; k < p.count; ++k) {
+                const dcv_resident_bwd_op& q = p.op[k];
+                const int wsize = q.cout * q.cin * q.k * q.k;
+                if (q.dw_part) for (int e = t; e < RS_SPB * wsize; e += RS_T) q.dw_part[(size_t)blockIdx.x * RS_SPB * wsize + e] = qnan;
+                if (q.db_part && t < RS_SPB * q.cout) q.db_part[(size_t)blockIdx.x * RS_SPB * q.cout + t] = qnan;
+                if (blockIdx.x == 0 && t < q.cout) {
+                    if (q.d_bn_gamma) q.d_bn_gamma[t] = qnan;
+                    if (q.d_bn_beta) q.d_bn_beta[t] = qnan;
+                    if (q.dz) q.dz[t] = qnan;
+                    if (q.dx) q.dx[t] = qnan;
+                    if (q.gn_part) q.gn_part[t] = qnan;
+                }
+            }
+            if (blockIdx.x == 0 && t == 0) {
+                if (p.head.enabled && p.head.fc_dw) p.head.fc_dw[0] = qnan;
+                if (p.head.enabled && p.head.dref) p.head.dref[0] = qnan;
+                __hip_atomic_store((rs_gu32*)ctl, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             return;
         }
         stamp();
@@ -1505,7 +1794,8 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
                 }
             }
         }
-        // ---- dz = act'(y) (P d + Q u + R): -> HBM (what the weight-gradient kernels read) and the padded tile of the data gradient
+        // ---- dz = act'(y) (P d + Q u + R): -> the padded tile of the data gradient (and of this layer's in-launch weight gradient); -> HBM only for a layer
+        // whose weight gradient is a launch of its own (o.dz set)
         {
             const int pad = o.k / 2, XW = W + 2 * pad, XH = H + 2 * pad;
             const float inv_cv = 1.f / (float)CV;
@@ -1525,7 +1815,8 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
                 z.y = (Pv.y * (d4.y * pinv) + Qv.y * ((y4.y - mu.y) * rs.y) + Rv.y) * rb_act_grad(y4.y, o.act, o.slope);
                 z.z = (Pv.z * (d4.z * pinv) + Qv.z * ((y4.z - mu.z) * rs.z) + Rv.z) * rb_act_grad(y4.z, o.act, o.slope);
                 z.w = (Pv.w * (d4.w * pinv) + Qv.w * ((y4.w - mu.w) * rs.w) + Rv.w) * rb_act_grad(y4.w, o.act, o.slope);
-                if (n < N) reinterpret_cast<float4*>(o.dz)[(size_t)n * per + e] = z; else z = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (n >= N) z = make_float4(0.f, 0.f, 0.f, 0.f);
+                else if (o.dz != nullptr) reinterpret_cast<float4*>(o.dz)[(size_t)n * per + e] = z;      // only when a weight-gradient launch will read it (dw_part == NULL)
                 dzt[ss * RS_XIN + (cv * XH + r + pad) * XW + c + pad] = z;
             }
         }
@@ -1542,7 +1833,14 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
             dcv_resident_op cv{};
             cv.cin = o.cout; cv.cout = o.cin; cv.k = o.k; cv.h = H; cv.w = W; cv.act = DCV_ACT_NONE; cv.filt = o.filt; cv.bias = nullptr;
             const int var = rb_dgrad_variant(o.cin, o.cout, o.k, o.w);
-            if (var == 1) { if (o.k == 5) rs_conv_c4_co4<5>(cv, dzt, dor, s_dummy); else rs_conv_c4_co4<3>(cv, dzt, dor, s_dummy); }
+            if (var == 1) {
+                int slot = 0;                                                       // this op's filter: slot = the number of 4 <- 4 data gradients before it
+                for (int k = 0; k < oi; ++k) if (p.op[k].need_dx && rb_dgrad_variant(p.op[k].cin, p.op[k].cout, p.op[k].k, p.op[k].w) == 1) ++slot;
+                const float* wl = s_filt[slot < RB_FILT_SLOTS ? slot : 0];
+                if (o.k == 3) rs_conv_c4_co4<3, 4, 0>(cv, dzt, dor, wl, nullptr, s_dummy);
+                else if (o.w != 32 || o.h != 32) rs_conv_c4_co4<5, 4, 0>(cv, dzt, dor, wl, nullptr, s_dummy);
+                else rs_conv_c4_co4_32<5, 4>(cv, dzt, dor, wl, nullptr, s_dummy);
+            }
             else if (var == 4) rb_dgrad_c16_co4(o.filt, dzt, dor);
             else { float4 b4[9]; rs_load_bfrag_prepared(o.filt, b4); rs_conv_c16_mfma(cv, dzt, dor, b4, s_dummy); }
             rs_barrier();
@@ -1559,7 +1857,6 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         rs_barrier();
         stamp();
     }
-    if (p.op[p.count - 1].dw_part != nullptr) rb_wgrad(p.op[p.count - 1], xtt, dzt);     // the first layer's: nothing left to hide it behind
     stamp();
     if (blockIdx.x == stamp_block && t == 0) stamps[0] = (unsigned long long)n_stamp;
     if (blockIdx.x == 0 && t == 0) __hip_atomic_store((rs_gu32*)ctl, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1580,6 +1877,7 @@ inline bool rb_program_ok(const dcv_resident_bwd_program* p) {
         if (!hd.ce_target && !hd.dlogits) return false;
         if (hd.fc_dw && (!hd.fc_x || !rb_fc_wgrad_ok(p->n, hd.h * hd.w * (hd.cc + hd.cr), hd.classes))) return false;
     } else if (!p->op[0].dout) return false;
+    int c4_dgrads = 0;
     for (int i = 0; i < p->count; ++i) {
         const dcv_resident_bwd_op& o = p->op[i];
         if (o.cout != 4 && o.cout != 8 && o.cout != 16) return false;
@@ -1588,16 +1886,16 @@ inline bool rb_program_ok(const dcv_resident_bwd_program* p) {
         if ((o.cout >> 2) * (o.h + 2 * pad) * (o.w + 2 * pad) > RS_XIN) return false;
         if (o.groups < 0 || (o.groups > 0 && (o.cout % o.groups != 0 || ((o.cout / o.groups) & (o.cout / o.groups - 1)) || !o.gn_mean || !o.gn_rstd))) return false;
         if (o.pool < 0 || o.pool == 1 || (o.pool > 0 && (o.h % o.pool != 0 || o.w % o.pool != 0 || o.groups == 0))) return false;
-        if (!o.y || !o.dz || !o.bn_mean || !o.bn_rstd || o.act < DCV_ACT_NONE || o.act > DCV_ACT_TANH) return false;
+        if (!o.y || (!o.dz && !o.dw_part) || !o.bn_mean || !o.bn_rstd || o.act < DCV_ACT_NONE || o.act > DCV_ACT_TANH) return false;   // dz in HBM: optional with the weight gradient in the launch
         if (o.dw_part) {
             const int wv = rb_wgrad_variant(o.cin, o.cout, o.k, o.w);
-            if (wv == 0 || !o.x || (wv == 1 && (o.h & 1)) || ((o.cin + 3) >> 2) * (o.h + 2 * pad) * (o.w + 2 * pad) > RS_XIN) return false;
+            if (wv == 0 || !o.x || (wv == 1 && !rb_wgrad_c4_rows_ok(o.h, o.w, o.k)) || ((o.cin + 3) >> 2) * (o.h + 2 * pad) * (o.w + 2 * pad) > RS_XIN) return false;
             if (o.x_nchw == 0 && (o.cin & 3) != 0 && o.cin > 4) return false;
         }
         if (o.need_dx) {
             const int var = rb_dgrad_variant(o.cin, o.cout, o.k, o.w);
             if (var == 0 || !o.filt) return false;
-            if (var == 1 && ((o.h & 1) || (o.h >> 1) * o.w > 512)) return false;
+            if (var == 1 && ++c4_dgrads > RB_FILT_SLOTS) return false;                              // (its filter's place in LDS)
             if (var == 4 && o.h != 16) return false;
             if (o.h * o.w * o.cin > RS_Y || (o.cin & 3)) return false;
         } else if (i + 1 < p->count) return false;                   // only the last op (the model's first layer) may skip its data gradient
@@ -1615,7 +1913,6 @@ inline bool rs_layer_ok(const dcv_resident_op& o, bool first) {
     if (var == 0 || o.h <= 0 || o.w <= 0 || o.cin <= 0) return false;
     const int pad = o.k / 2, cvin = (o.cin + 3) / 4;
     if (cvin * (o.h + 2 * pad) * (o.w + 2 * pad) > RS_XIN || o.h * o.w * o.cout > RS_Y) return false;
-    if (var == 1 && ((o.h & 1) || (o.h >> 1) * o.w > 512)) return false;
     if (var == 2 && (o.h * o.w) % 64 != 0) return false;
     if (!first && (o.cin & 3)) return false;                      // only the staged model input may have a partial channel vector
     if (o.act < DCV_ACT_NONE || o.act > DCV_ACT_TANH || !o.filt || !o.y || !o.out) return false;
@@ -1634,6 +1931,7 @@ inline bool rs_program_ok(const dcv_resident_program* p) {
         const dcv_resident_op& o = p->op[i];
         if (o.kind == DCV_RES_LAYER) {
             if (!rs_layer_ok(o, i == 0)) return false;
+            if (rs_variant(o.cin, o.cout, o.k, o.w) == 1 && i >= RS_FILT_OPS) return false;      // (its filter's place in LDS)
             if (i > 0 && (p->op[i - 1].kind != DCV_RES_LAYER || o.cin != c || o.h != h || o.w != w)) return false;
             const int pk = o.pool > 0 ? o.pool : 1;
             c = o.cout; h = o.h / pk; w = o.w / pk;
@@ -1680,6 +1978,11 @@ int dcv_resident_forward(const dcv_resident_program* p, void* ws, size_t ws_byte
 int dcv_resident_bwd_supported(const dcv_resident_bwd_program* p) { return rb_program_ok(p) ? 1 : 0; }
 
 int dcv_resident_head_wgrad_supported(int n, int k, int classes) { return rb_fc_wgrad_ok(n, k, classes) ? 1 : 0; }
+
+int dcv_resident_wgrad_supported(int cin, int cout, int k, int h, int w) {
+    const int wv = rb_wgrad_variant(cin, cout, k, w);
+    return (wv != 0 && (wv != 1 || rb_wgrad_c4_rows_ok(h, w, k))) ? 1 : 0;
+}
 
 int dcv_resident_backward(const dcv_resident_bwd_program* p, void* ws, size_t ws_bytes, void* stream) {
     DCV_CHECK_ARG(p && ws);

@@ -748,7 +748,7 @@ class _ConvNormLayerFn(torch.autograd.Function):
         d_bn_b = new(r_bn_b) if (bn_b is not None and need[4]) else None
         d_gn_w = new(r_gn_w) if (gn_w is not None and need[8]) else None
         d_gn_b = new(r_gn_b) if (groups and need[9]) else None
-        dz = torch.empty_like(y)
+        dz = None       # allocated where a kernel writes it: inside the persistent backward launch dz only reaches HBM for a layer whose weight gradient is a launch of its own
         plan = getattr(ctx, 'res_plan', None)
         if plan is not None and not ctx.use16:
             # the forward of this layer stack was ONE persistent launch: so is the serial chain of its backward pass when the plan allows it
@@ -761,14 +761,14 @@ class _ConvNormLayerFn(torch.autograd.Function):
                 op.cin, op.cout, op.k, op.h, op.w, op.act, op.slope, op.groups, op.pool = d.cin, d.cout, d.r, d.h, d.w, act, slope, groups, pool
                 op.inv_count = 1.0 / (float(d.n) * hw)
                 op.inv_group = 1.0 / (float(hw) * (c // groups)) if groups else 0.0
-                op.y, op.dz = y.data_ptr(), dz.data_ptr()
+                op.y = y.data_ptr()
                 op.dout = dout.data_ptr() if not plan.ops else None
                 op.bn_gamma, op.bn_beta, op.bn_mean, op.bn_rstd = nat.ptr(bn_w), nat.ptr(bn_b), bn_mean.data_ptr(), bn_rstd.data_ptr()
                 op.gn_gamma, op.gn_mean, op.gn_rstd = nat.ptr(gn_w), nat.ptr(gn_mean), nat.ptr(gn_rstd)
                 op.d_bn_gamma, op.d_bn_beta = nat.ptr(d_bn_w), nat.ptr(d_bn_b)
                 # (the parameter-gradient buffers are only passed by address: the engine's AccumulateGrad adopts a gradient as `.grad` when it is its sole
                 # owner and COPIES it otherwise — a copy taken now, before the launch has filled the buffer)
-                keep = [y, dz, dout, bn_w, bn_b, bn_mean, bn_rstd, gn_w, gn_mean, gn_rstd]
+                keep = [y, dout, bn_w, bn_b, bn_mean, bn_rstd, gn_w, gn_mean, gn_rstd]
                 if groups and (d_gn_w is not None or d_gn_b is not None):
                     blocks = (d.n + 1) // 2
                     gn_part = torch.empty(blocks * 2 * c, dtype=torch.float32, device=dev)
@@ -809,9 +809,13 @@ class _ConvNormLayerFn(torch.autograd.Function):
                         slabs.defer(dev, st, segs, k, part)
                         keep.append(x)
                     else:
+                        dz = torch.empty_like(y)
+                        op.dz = dz.data_ptr()
+                        keep.append(dz)
                         _conv_wgrad_launch(d, x, dz, ctx.weight_ref, ctx.bias_ref, dw, db, st)  # deferred: runs at the flush, after the launch above
                 plan.add(op, dx, keep, st)
                 return dx, dw, db, d_bn_w, d_bn_b, None, None, None, d_gn_w, d_gn_b, None
+        dz = torch.empty_like(y)
         if ctx.streaming:
             nc = _norm_chain_desc(d, ctx.cfg, bn_w, bn_b, None, None, None, bn_mean, bn_rstd, gn_w, None, gn_mean, gn_rstd)
             coef = torch.empty(int(lib.dcv_norm_chain_coef_floats(nc)), dtype=torch.float32, device=dev)

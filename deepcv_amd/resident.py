@@ -116,7 +116,7 @@ def wgrad_in_launch(d: nat.Conv2dDesc) -> bool:
     (the multi-layer weight-gradient launch then reads the launch's dz tensors, as for the layers not covered). """
     if not _wgrad_in_launch or d.r != d.s:
         return False
-    return (d.cin <= 4 and d.cout == 4 and d.r in (3, 5) and d.h % 2 == 0) or (d.cout == 16 and d.w == 16 and d.r == 3 and (d.cin <= 4 or d.cin == 16))
+    return bool(lib.dcv_resident_wgrad_supported(d.cin, d.cout, d.r, d.h, d.w))
 
 
 def _verdict_slot(module) -> Dict[tuple, str]:
@@ -400,7 +400,7 @@ class BackwardPlan:
             op = prog.op[k]
             op.cin, op.cout, op.k, op.h, op.w, op.act, op.slope, op.groups, op.pool = d.cin, d.cout, d.r, d.h, d.w, cfg[3], cfg[4], cfg[7], cfg[9]
             op.need_dx = 1 if layer['needs_dx'] else 0
-            for f in ('y', 'dz', 'bn_mean', 'bn_rstd', 'gn_mean', 'gn_rstd', 'filt'):
+            for f in ('y', 'dz', 'bn_mean', 'bn_rstd', 'gn_mean', 'gn_rstd', 'filt'):      # (dz: as if every weight gradient were a launch of its own)
                 setattr(op, f, 16)
             if k == 0:
                 op.dout = 16
@@ -547,8 +547,8 @@ class BackwardPlan:
 
 def algorithmic_bytes(kind: str, prog) -> int:
     """ HBM bytes a persistent launch has to move by construction: forward = the input batch + every tensor it must leave for the backward
-    pass (y and the output of every layer, the wide tensor of the link, the logits) + filters and per-channel parameters; backward = y and dz of every
-    layer + the first output gradient, the link's addend, the GroupNorm partials and the filters, + with the weight gradients inside the launch every
+    pass (y and the output of every layer, the wide tensor of the link, the logits) + filters and per-channel parameters; backward = y of every layer (+ dz
+    where a weight-gradient launch outside will read it) + the first output gradient, the link's addend, the GroupNorm partials and the filters, + with the weight gradients inside the launch every
     layer's input and its partial slabs.  fp32. """
     n, total = prog.n, 0
     for i in range(prog.count):
@@ -565,7 +565,9 @@ def algorithmic_bytes(kind: str, prog) -> int:
                 total += o.cout * o.h * o.w * o.cin + n * o.cout
         else:
             pk = o.pool if o.pool > 0 else 1
-            total += 2 * n * o.h * o.w * o.cout + o.k * o.k * o.cin * o.cout + 8 * o.cout + ((n + 1) // 2) * 2 * o.cout
+            total += n * o.h * o.w * o.cout + o.k * o.k * o.cin * o.cout + 8 * o.cout + ((n + 1) // 2) * 2 * o.cout
+            if o.dz:                   # dz only leaves the launch for a layer whose weight gradient is a launch of its own
+                total += n * o.h * o.w * o.cout
             if o.dw_part:              # weight gradient inside the launch: the layer's input + the per-(block, sample slot) partial slabs
                 total += n * o.h * o.w * o.cin + 2 * ((n + 1) // 2) * (o.k * o.k * o.cin * o.cout + o.cout)
             if i == 0:

@@ -648,6 +648,8 @@ typedef struct dcv_resident_bwd_head {
 typedef struct dcv_resident_bwd_program { int n; int count; dcv_resident_bwd_op op[DCV_RESIDENT_BWD_MAX_OPS]; dcv_resident_bwd_head head; } dcv_resident_bwd_program;
 int dcv_resident_bwd_supported(const dcv_resident_bwd_program* p);
 int dcv_resident_head_wgrad_supported(int n, int k, int classes);
+/* 1 when dcv_resident_backward computes the weight gradient of a (cin -> cout, k x k, stride 1, padding k / 2) layer on h x w maps itself (dw_part may be set for it) */
+int dcv_resident_wgrad_supported(int cin, int cout, int k, int h, int w);
 int dcv_resident_backward(const dcv_resident_bwd_program* p, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
