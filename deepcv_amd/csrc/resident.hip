@@ -709,6 +709,13 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                 mine = (valid0 ? v0 : 0.f) + (valid1 ? v1 : 0.f);
             }
             stamp();
+            auto store_y = [&]() {                                                   // the sample's [HW][C] floats: the same order in LDS and in HBM
+                const int n = (int)blockIdx.x * RS_SPB + s_of_t, v4 = HW * CV;
+                if (n >= N) return;
+                const float4* ys = reinterpret_cast<const float4*>(yt + s_of_t * RS_Y);
+                float4* yg = reinterpret_cast<float4*>(o.y) + (size_t)n * v4;
+                for (int e = tt; e < v4; e += 512) yg[e] = ys[e];
+            };
             if (o.bn) {
                 rs_allreduce_publish(go, epoch, 2 * C, mine, mute);
                 if (oi == 0 && p.mailbox != nullptr) {
@@ -728,7 +735,12 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                         for (size_t i = n16 * 16 + t; i < bytes; i += RS_T) jd[i] = js[i];
                     }
                 }
-                if (!rs_allreduce(go, go + RS_MAXQ * RS_MAXG, epoch, 2 * C, G, mine, s_tot, s_red, s_w32, &s_fail, true, mute)) {
+                // y -> HBM (saved for the backward pass) needs no statistics: it travels while the partial sums do.  Blocks which own a quantity reduce first
+                // (everybody waits for their totals), the others store first.
+                const bool owner = (int)blockIdx.x < 2 * C;
+                if (owner) rs_allreduce_reduce_owned(go, go + RS_MAXQ * RS_MAXG, epoch, 2 * C, G, s_red, &s_fail);
+                store_y();
+                if (!rs_allreduce_collect(go + RS_MAXQ * RS_MAXG, epoch, 2 * C, s_tot, s_w32, &s_fail)) {
                     // a block of this grid is not resident: report, poison the logits, leave
                     if (t == 0) { __hip_atomic_store((rs_gu32*)(ctl + 1), (unsigned)oi + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                     for (int k = 0; k < p.count; ++k)
@@ -740,7 +752,7 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                     if (blockIdx.x == 0 && t == 0) __hip_atomic_store((rs_gu32*)ctl, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (a later launch must not take this launch's granules for its own)
                     return;
                 }
-            } else rs_barrier();
+            } else { store_y(); rs_barrier(); }
             stamp();
             // ---- coefficients, all in wave 0: thread (sample, channel) sums the 16 partials of its channel, derives the BatchNorm affine v = a y + b, the
             // GroupNorm statistics of v from the sample's sums (norm_chain.hip, nc_apply_kernel's prologue; group totals by DPP exchanges between the
@@ -789,7 +801,6 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                 // waves 0 - 7: the first sample, 8 - 15: the second; a thread's channel vector is fixed (512 is a multiple of CV): S, T in registers
                 const int ss = s_of_t, cv = tt & (CV - 1), n = (int)blockIdx.x * RS_SPB + ss;
                 const float4 S = *reinterpret_cast<const float4*>(s_S[ss] + cv * 4), T = *reinterpret_cast<const float4*>(s_T[ss] + cv * 4);
-                float4* yg = reinterpret_cast<float4*>(o.y) + (size_t)(n < N ? n : 0) * HW * CV;
                 for (int e = tt; e < per; e += 512) {
                     const int px = rs_fdiv(e, inv_cv), ho = rs_fdiv(px, inv_wo), wo = px - ho * Wo;
                     float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -797,7 +808,6 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                         for (int kw = 0; kw < pk; ++kw) {
                             const int yi = ((ho * pk + kh) * W + wo * pk + kw) * CV + cv;
                             const float4 v = reinterpret_cast<const float4*>(yt + ss * RS_Y)[yi];
-                            if (n < N) yg[yi] = v;                                   // y -> HBM (saved for the backward pass): every element passes here once
                             acc[0] += v.x * S.x + T.x; acc[1] += v.y * S.y + T.y; acc[2] += v.z * S.z + T.z; acc[3] += v.w * S.w + T.w;
                         }
                     float4 r4;

@@ -419,24 +419,50 @@ class GraphedTrainStep:
 
     @torch.no_grad()
     def _verify_launch_list(self, x, y) -> bool:
-        """ The first replay, twice from the same state: through the launch list, then through the graph.  The list only holds this library's launches; a
-        step which also runs other kernels (a loss built from torch operations, a module without a HIP kernel) leaves their outputs unwritten — the list
-        goes FIRST, on the graph pool's never-written buffers, so that nothing an earlier replay left there can stand in for them — and comes out
-        different: the graph then stays the replay mechanism.  Leaves the state of ONE step, computed by the graph. """
+        """ The first replay: TWO consecutive steps on two different batches (the batch and its mirror image) through the launch list, then the same two steps
+        from the same state through the graph; the list is trusted when parameters, buffers, optimizer state, prepared filters, losses and predictions of BOTH
+        steps agree to the bit.  The list only holds this library's launches: a step which also runs other kernels (a loss built from torch operations, a module
+        without a HIP kernel, a captured memset or zero-fill) leaves their outputs unwritten.  The list goes FIRST, with every visible output of the step (losses,
+        predictions, gradients) filled with NaN beforehand, so neither the zeros of freshly allocated pool memory nor anything an earlier replay left behind can
+        stand in for a missing kernel; and the SECOND list step runs on buffers which hold the first step's data, so a dependence on what the previous replay
+        left in the pool (which one comparison from pristine memory cannot show) comes out as a difference too.  Leaves the state of ONE step on (x, y),
+        computed by the graph. """
         dev = x.device
         state = self._step_state()
         snapshot = [t.clone() for t in state]
-        self._mailbox_write(x, y)
-        self._launch_stream = torch.cuda.current_stream(dev)
-        self._replay_launch_list()
-        torch.cuda.synchronize(dev)
-        by_list = [t.clone() for t in state] + [v.clone() for v in self.static_losses.values()]
+        x2 = torch.empty_like(x)                                   # (same strides as x: the staging kernel fetches it the same way)
+        x2.copy_(x.flip(0))
+        y2 = y
+        if isinstance(y, torch.Tensor):
+            y2 = torch.empty_like(y)
+            y2.copy_(y.flip(0))
+        outputs = list(self.static_losses.values()) + ([self.static_pred] if isinstance(self.static_pred, torch.Tensor) else [])
+        grads = [p.grad for p in self.model.parameters() if p.grad is not None]
+
+        def run(replay):
+            seen = []
+            for xb, yb in ((x, y), (x2, y2)):
+                self._mailbox_write(xb, yb)                        # (same step number and scalars for both mechanisms: nothing counts these replays)
+                self._launch_stream = torch.cuda.current_stream(dev)
+                replay()
+                torch.cuda.synchronize(dev)
+                seen += [t.clone() for t in state] + [v.clone() for v in outputs]
+            return seen
+        for t in outputs + grads:
+            if t.is_floating_point():
+                t.fill_(float('nan'))
+        by_list = run(self._replay_launch_list)
         for t, s0 in zip(state, snapshot):
             t.data.copy_(s0)                                       # (.data: no version bump — the prepared-filter cache keys on the weights' versions)
-        self._mailbox_write(x, y)                                  # same step number, same scalars (nothing counted the first replay yet)
-        self.graph_fb.replay()
+        by_graph = run(self.graph_fb.replay)
+        ok = len(by_list) == len(by_graph) and all(torch.equal(a, b) for a, b in zip(by_list, by_graph))
+        for t, s0 in zip(state, snapshot):
+            t.data.copy_(s0)
+        self._mailbox_write(x, y)
+        self._launch_stream = torch.cuda.current_stream(dev)
+        self.graph_fb.replay()                                     # the one step this call owes its caller
         torch.cuda.synchronize(dev)
-        return all(torch.equal(a, b) for a, b in zip(by_list, state + list(self.static_losses.values())))
+        return ok
 
     def _replay_launch_list(self):
         if self._staged_prog is not None:

@@ -21,6 +21,7 @@ all-reduce of the next layer, the weight gradient — runs at the start of `deep
 whole GPU (`disable_if_gpu_shared`); a launch which could not get all its blocks resident reports it (`check_status`). """
 import ctypes
 import os
+import threading
 import weakref
 from typing import Dict, List, Optional, Tuple
 
@@ -33,7 +34,18 @@ __all__ = ['Ineligible', 'Recorder', 'recorder', 'forbid', 'enabled', 'set_enabl
 
 _enabled = os.environ.get('DCV_RESIDENT', '1') not in ('0', 'false', 'False', '')
 _bwd_enabled = os.environ.get('DCV_RESIDENT_BWD', '1') not in ('0', 'false', 'False', '')
-_active: Optional['Recorder'] = None
+
+
+class _ThreadState(threading.local):
+    """ Recording state of the calling thread.  A forward is recorded by the thread which runs it: an op issued meanwhile by ANOTHER thread (a second model, an
+    evaluation or transform thread) must neither be appended to that program nor trip `forbid()` — it simply runs on the per-layer kernels. """
+    active: Optional['Recorder'] = None
+    staging: Optional[tuple] = None       # (mailbox address, index of the batch's job, address of the static input tensor) while a training step is captured
+    staging_consumed = False
+    staged_program = None                 # the program of the launch which took the mailbox (kept for launch-list replays: its `batch` field is theirs to set)
+
+
+_tls = _ThreadState()
 _verdicts: Dict[int, Tuple['weakref.ref', dict]] = {}   # id(module) -> (weak reference, {(input shape, training): reason it is not eligible; 'modules': foreign leaf or None})
 _ws: Dict[torch.device, torch.Tensor] = {}                          # persistent control words + granules per device (zeroed once)
 _launches = 0
@@ -90,12 +102,12 @@ def disable_if_gpu_shared() -> bool:
 
 
 def recorder() -> Optional['Recorder']:
-    return _active
+    return _tls.active
 
 
 def forbid(what: str):
     """ Called at the top of every op of `deepcv_amd.ops` the resident kernel does not cover. """
-    if _active is not None:
+    if _tls.active is not None:
         raise Ineligible(f'{what} inside the forward')
 
 
@@ -126,32 +138,28 @@ def _verdict_slot(module) -> Dict[tuple, str]:
     return slot[1]
 
 
-_staging: Optional[tuple] = None          # (mailbox address, index of the batch's job, address of the static input tensor) while a training step is captured
-_staging_consumed = False
-_staged_program = None                    # the program of the launch which took the mailbox (kept for launch-list replays: its `batch` field is theirs to set)
 
 
 def set_staging(spec: Optional[tuple]):
     """ `spec = (mailbox, x_job, static_x_ptr)` (`GraphedTrainStep`): the next recorded forward whose input IS that static tensor reads the batch through the
     mailbox itself and copies the mailbox's other jobs (`dcv_resident_program.mailbox`): the step then has no `dcv_indirect_copy` launch.  `None` switches it
     off; `staging_consumed()` tells whether a launch took the mailbox since the last `set_staging`. """
-    global _staging, _staging_consumed, _staged_program
-    _staging, _staging_consumed, _staged_program = spec, False, None
+    _tls.staging, _tls.staging_consumed, _tls.staged_program = spec, False, None
 
 
 def staging_consumed() -> bool:
-    return _staging_consumed
+    return _tls.staging_consumed
 
 
 def staged_program():
     """ The `ResidentProgram` (host structure, copied into the kernel arguments at every launch) of the launch which took the mailbox since the last
     `set_staging`: a caller which re-issues that launch itself may set its `batch` field to the address of the coming batch. """
-    return _staged_program if _staging_consumed else None
+    return _tls.staged_program if _tls.staging_consumed else None
 
 
 def wanted(module, x) -> bool:
     """ Should the outermost `DeepcvModule.forward` try to record this call? """
-    if not _enabled or _active is not None or not isinstance(x, torch.Tensor):
+    if not _enabled or _tls.active is not None or not isinstance(x, torch.Tensor):
         return False
     if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and module.training and torch.is_grad_enabled()):
         return False
@@ -230,15 +238,13 @@ class Recorder:
 
     # ---- context
     def __enter__(self):
-        global _active
-        if _active is not None:
+        if _tls.active is not None:
             raise RuntimeError('deepcv_amd.resident: recordings do not nest')
-        _active = self
+        _tls.active = self
         return self
 
     def __exit__(self, et, ev, tb):
-        global _active
-        _active = None
+        _tls.active = None
         if et is not None:                     # aborted: give back the forward uses the recorded ops noted (deepcv_amd.slabs)
             from . import slabs
             slabs.unnote_use(*self.noted)
@@ -349,14 +355,12 @@ class Recorder:
             prog.op[i] = op
         if not lib.dcv_resident_supported(prog):
             raise Ineligible('the recorded program is not covered by the resident kernel')
-        global _staging_consumed
-        if _staging is not None and not _staging_consumed and prog.op[0].x == _staging[2] and prog.op[0].bn:
-            prog.mailbox, prog.x_job = _staging[0], _staging[1]          # the launch stages its batch (and the step's labels / scalars) itself
+        if _tls.staging is not None and not _tls.staging_consumed and prog.op[0].x == _tls.staging[2] and prog.op[0].bn:
+            prog.mailbox, prog.x_job = _tls.staging[0], _tls.staging[1]          # the launch stages its batch (and the step's labels / scalars) itself
         ws = _workspace(self.device)
         nat.check(lib.dcv_resident_forward(prog, ws.data_ptr(), ws.numel(), nat.current_stream(self.device)), 'dcv_resident_forward')
         if prog.mailbox:
-            global _staged_program
-            _staging_consumed, _staged_program = True, prog
+            _tls.staging_consumed, _tls.staged_program = True, prog
         _launches += 1
         if capture_programs:
             last_programs['forward'] = (prog, ws, list(self.keep))

@@ -26,6 +26,12 @@ CASES = [
 ]
 
 
+# the four shapes bench.py times (`_bf16_storage_kernels`: N = 512 = BATCH_PER_GPU, 3x3, stride 1): the grid-size dependent paths of the kernels (tile
+# counts beyond one wave of blocks, the all-nine-taps weight gradient's chunking over 512 samples) are the ones the bench line reports
+BENCH_CASES = [(512, 64, 32, 32, 64, 3, 1, 1, 1, 1, True), (512, 128, 16, 16, 128, 3, 1, 1, 1, 1, True),
+               (512, 256, 16, 16, 256, 3, 1, 1, 1, 1, True), (512, 512, 8, 8, 512, 3, 1, 1, 1, 1, True)]
+
+
 def _bf(t):
     return t.to(torch.bfloat16)
 
@@ -194,3 +200,53 @@ def test_fused_layer_with_bf16_activations(device, groups, pool):
         else:
             assert _rel(got, r.grad) <= 2e-2, f'{names[k]}: {_rel(got, r.grad):.3e}'
     assert (nbt.item() == 1) and _rel(rm, 0.1 * z.detach().mean(dim=(0, 2, 3))) <= 1e-2
+
+
+@pytest.mark.parametrize('case', BENCH_CASES, ids=lambda c: 'x'.join(str(v) for v in c[:5]))
+def test_bf16_kernels_at_the_bench_shapes(device, case):
+    """ Forward (bf16 output, the dtype bench.py times), data gradient and weight gradient at N = 512 against fp64 torch on the CPU, same tolerances as the
+    small cases.  The forward and the data gradient are per-sample operations: their reference is computed for 6 samples spread over the batch (first, last,
+    tile seams); the weight gradient sums over all samples and is compared whole. """
+    from deepcv_amd import _native as nat
+    lib = nat.lib
+    n, cin, h, w, cout, k, stride, pad, dil, act, has_bias = case
+    torch.manual_seed(cin)
+    st = nat.current_stream(device)
+    d = _desc(nat, n, cin, h, w, cout, k, stride, pad, dil, act)
+    d0 = _desc(nat, n, cin, h, w, cout, k, stride, pad, dil, 0)
+    assert lib.dcv_conv2d_bf16_supported(d, 0) and lib.dcv_conv2d_bf16_supported(d0, 1) and lib.dcv_conv2d_bf16_supported(d0, 2)
+    x = _bf(torch.randn(n, cin, h, w)).contiguous(memory_format=torch.channels_last)
+    wt = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
+    b = torch.randn(cout)
+    dy = _bf(torch.randn(n, cout, h, w)).contiguous(memory_format=torch.channels_last)
+    xd, wd, bd, dyd = x.to(device), wt.to(device), b.to(device), dy.to(device)
+    pick = torch.tensor([0, 1, n // 2 - 1, n // 2, n - 2, n - 1])
+    # forward
+    f = _prepared(nat, lib, d, 0, wd, st)
+    y = torch.empty((n, cout, h, w), dtype=torch.bfloat16, device=device).contiguous(memory_format=torch.channels_last)
+    rows = ctypes.c_int(0); rps = ctypes.c_int(0)
+    nat.check(lib.dcv_conv2d_bf16_fwd_stats_layout(d, ctypes.byref(rows), ctypes.byref(rps)), 'layout')
+    stats = torch.full((2, cout, rows.value), float('nan'), dtype=torch.float64, device=device)
+    nat.check(lib.dcv_conv2d_bf16_fwd(d, xd.data_ptr(), f.data_ptr(), bd.data_ptr(), y.data_ptr(), nat.DTYPE_BF16, stats.data_ptr(), st), 'fwd')
+    torch.cuda.synchronize()
+    ref = _act(F.conv2d(x[pick].double(), _bf(wt).double(), b.double(), stride, pad, dil), act)
+    err = _rel(y[pick.to(device)], ref)
+    assert err <= 4.5e-3, f'forward error {err:.3e}'
+    assert torch.isfinite(stats).all()
+    # data gradient
+    f1 = _prepared(nat, lib, d0, 1, wd, st)
+    dx = torch.full((n, cin, h, w), float('nan'), dtype=torch.float32, device=device).contiguous(memory_format=torch.channels_last)
+    nat.check(lib.dcv_conv2d_bf16_dgrad(d0, dyd.data_ptr(), f1.data_ptr(), dx.data_ptr(), nat.DTYPE_F32, st), 'dgrad')
+    torch.cuda.synchronize()
+    ref_dx = F.conv_transpose2d(dy[pick].double(), _bf(wt).double(), None, stride, pad)
+    err = _rel(dx[pick.to(device)], ref_dx)
+    assert err <= 2e-5, f'data gradient error {err:.3e}'
+    assert torch.isfinite(dx).all()
+    # weight gradient (all samples)
+    ws = torch.empty(int(lib.dcv_conv2d_bf16_wgrad_workspace_bytes(d0)), dtype=torch.uint8, device=device)
+    dw = torch.full((cout, cin, k, k), float('nan'), device=device)
+    nat.check(lib.dcv_conv2d_bf16_wgrad(d0, xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), st), 'wgrad')
+    torch.cuda.synchronize()
+    ref_dw = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, k, k), dy.double(), stride, pad, dil)
+    err = _rel(dw, ref_dw)
+    assert err <= 2e-5, f'weight gradient error {err:.3e}'

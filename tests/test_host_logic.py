@@ -232,3 +232,32 @@ def test_resident_recording_is_refused_for_models_with_foreign_leaf_modules(para
     assert 'Dropout' in resident._foreign_module(create_model(ds, with_dropout))
     wide = create_model({'trainset': SyntheticImageDataset(8, image_shape=(3, 224, 224), num_classes=1000)}, params['resnet18_style_model'])
     assert 'MaxPool2d' in resident._foreign_module(wide)
+
+
+def test_resident_recording_state_is_per_thread():
+    """ A forward is recorded by the thread which runs it (deepcv_amd/resident.py): an op issued meanwhile by another thread must not see the recorder — neither
+    be appended to its program nor raise `Ineligible` outside any `DeepcvModule.forward`. """
+    import threading
+    import torch
+    from deepcv_amd import resident
+    seen = {}
+    with resident.Recorder(torch.zeros(2, 3, 8, 8)) as rec:
+        assert resident.recorder() is rec
+        with pytest.raises(resident.Ineligible):
+            resident.forbid('an op of the recording thread')
+
+        def other():
+            seen['recorder'] = resident.recorder()
+            try:
+                resident.forbid('an op of another thread')
+                seen['raised'] = False
+            except resident.Ineligible:
+                seen['raised'] = True
+            resident.set_staging((1, 0, 2))
+            seen['staging'] = resident.staging_consumed()
+        th = threading.Thread(target=other)
+        th.start()
+        th.join()
+        assert resident.staged_program() is None and not resident.staging_consumed()      # the other thread's staging request is its own
+    assert seen == {'recorder': None, 'raised': False, 'staging': False}
+    assert resident.recorder() is None

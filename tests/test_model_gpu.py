@@ -76,6 +76,7 @@ def test_forward_backward_matches_oracle(device, params, spec, bs, smooth):
     assert all(torch.equal(sd_n[k], sd_o[k]) for k in sd_n), 'initial weights must be bit-identical to the reference recipe'
     native = native.to(device)
     (x, y), = _batches(1, bs)
+    stock = spec == 'image_classifier_model'            # (the bn-only spec has a standalone pooling: not a program of the persistent launches)
     spec = f'{spec}[bs{bs}{" tanh twin" if smooth else ""}]'
 
     oracle.train()
@@ -83,11 +84,19 @@ def test_forward_backward_matches_oracle(device, params, spec, bs, smooth):
     loss_o = torch.nn.CrossEntropyLoss()(logits_o, y)
     loss_o.backward()
 
+    from deepcv_amd import resident
+    launches_before = (resident.launches(), resident.backward_launches())
     native.train()
     logits_n = native(x.to(device))
     loss_n = native_modules.CrossEntropyLoss()(logits_n, y.to(device))
     loss_n.backward()
     torch.cuda.synchronize()
+    resident.check_status()
+    if stock and resident.enabled() and resident._bwd_enabled:
+        # the stock spec (and its tanh twin) is a program of the persistent launches: the bounds below bind resident_fwd_kernel / resident_bwd_kernel, not the
+        # per-layer kernels a silently ineligible model would fall back to
+        assert resident.launches() == launches_before[0] + 1, f'the forward did not run as the persistent launch: {resident.why_not(native, x.to(device))}'
+        assert resident.backward_launches() == launches_before[1] + 1, 'the backward pass did not run as the persistent launch'
 
     e_logits, e_loss = _rel(logits_n, logits_o), abs(loss_n.item() - loss_o.item()) / abs(loss_o.item())
     _report(f'{spec}: logits rel err {e_logits:.3e}, loss rel err {e_loss:.3e} (loss {loss_n.item():.6f} vs {loss_o.item():.6f})')
@@ -261,18 +270,33 @@ def test_eval_mode_and_accuracy(device, params):
     assert int(ce.last_correct) == int((lo.argmax(1) == y).sum())
 
 
-def test_train_api_end_to_end(device, params, tmp_path):
+def _learnable(ds, strength: float = 2.0, seed: int = 77):
+    """ Adds a class prototype to every synthetic image (pure noise with random labels can only be memorised: no loss curve to assert on). """
+    g = torch.Generator().manual_seed(seed)
+    protos = torch.randn(len(ds.classes), *ds.images.shape[1:], generator=g)
+    ds.images += strength * protos[ds.targets]
+    return ds
+
+
+def test_train_api_end_to_end(device, params, tmp_path, caplog):
     """ `classification.image.create_model` + `train` (reference `image.py:40-80`) on synthetic CIFAR-shaped data: runs 2 epochs with checkpoints,
     validation, hipGraph replay and the stock scheduler; the loss must decrease and the returned tuple must have the reference's layout. """
+    import logging
+    import re
     from deepcv_amd.classification import image
     from deepcv_amd.meta.data.datasets import SyntheticImageDataset
-    ds = {'trainset': SyntheticImageDataset(256, seed=1), 'validset': SyntheticImageDataset(64, seed=2)}
+    ds = {'trainset': _learnable(SyntheticImageDataset(256, seed=1)), 'validset': _learnable(SyntheticImageDataset(64, seed=2))}
+    caplog.set_level(logging.INFO)
     torch.manual_seed(SEED)
     model = image.create_model(ds, params['image_classifier_model'])
     hp = dict(params['train_image_classifier'])
     hp.update(epochs=2, batch_size=32, output_path=tmp_path, save_every_iters=5, num_workers=0, log_progress_every_iters=4, backend_conf={'device_or_id': 'cuda:0'})
     metrics, state, _ = image.train(ds, model, hp)
     assert state.iteration == 16 and state.epoch == 2
+    # the running average of the training loss, as `train` logs it every `log_progress_every_iters` iterations (it 4, 8, 12, 16)
+    seen = [float(m.group(1)) for r in caplog.records for m in [re.search(r'it \d+: .*?main_loss=([0-9.]+)', r.getMessage())] if m]
+    assert len(seen) == 4, f'expected four progress lines, got {seen}'
+    assert seen[-1] < seen[0] - 1e-3, f'the training loss did not decrease: {seen}' 
     assert 'valid_accuracy' in metrics and 'valid_main_loss' in metrics
     assert 0. <= metrics['valid_accuracy'] <= 1.
     assert [p.name for p in tmp_path.rglob('training_checkpoint_*.pt')] == ['training_checkpoint_15.pt'], 'only the newest periodic checkpoint is kept (ignite n_saved=1)'
@@ -287,19 +311,29 @@ def test_train_api_config3_bf16_onecycle(device, params, tmp_path):
     from deepcv_amd.classification import image
     from deepcv_amd.meta import ignite_training
     from deepcv_amd.meta.data.datasets import SyntheticImageDataset
-    ds = {'trainset': SyntheticImageDataset(128, (3, 32, 32), 100, seed=1), 'validset': SyntheticImageDataset(32, (3, 32, 32), 100, seed=2)}
+    ds = {'trainset': _learnable(SyntheticImageDataset(128, (3, 32, 32), 100, seed=1)), 'validset': _learnable(SyntheticImageDataset(32, (3, 32, 32), 100, seed=2))}
     torch.manual_seed(SEED)
     model = image.create_model(ds, params['cifar100_deep_model'])
+
+    class _Losses:                       # `callbacks_handler`: the main loss of every iteration (reference events, `ignite_training.py:120-122`)
+        seen = []
+
+        def fire(self, event, **kw):
+            if event == 'ON_ITERATION_COMPLETED':
+                out = kw['engine'].state.output
+                self.seen.append(float(out[ignite_training.MAIN_TRAINING_LOSS_NAME]))
+    probe = _Losses()
     hp = dict(params['train_cifar100_deep'])
     assert hp['conv_math'] == 'bf16'
     hp.update(epochs=3, batch_size=32, output_path=tmp_path, save_every_iters=1000, num_workers=0)
     prev = ops.set_conv_math('fp32')
     try:
         metrics, state = ignite_training.train(hp=hp, model=model, datasets=ds, backend_conf=ignite_training.BackendConfig(device_or_id='cuda:0'),
-                                               loss=torch.nn.CrossEntropyLoss(), opt=torch.optim.SGD)
+                                               loss=torch.nn.CrossEntropyLoss(), opt=torch.optim.SGD, callbacks_handler=probe)
     finally:
         ops.set_conv_math(prev)
     assert state.iteration == 12 and 'valid_main_loss' in metrics and metrics['valid_main_loss'] == metrics['valid_main_loss']   # finite
+    assert len(probe.seen) == 12 and sum(probe.seen[-4:]) < sum(probe.seen[:4]), f'the training loss did not fall: {probe.seen}' 
 
 
 def test_train_api_ragged_last_batch(device, params, tmp_path):

@@ -353,3 +353,105 @@ def test_a_block_which_never_arrives_is_reported_not_waited_for(device, params, 
     finally:
         resident.set_enabled(prev)
         resident.set_backward_enabled(prev_b)
+
+
+def test_persistent_launches_gradients_match_oracle_at_the_bench_batch(device, params):
+    """ Every parameter gradient of the stock spec's smooth (Tanh) twin at bs 512, computed by the two persistent launches, against the CPU oracle at the strict
+    bound of tests/test_model_gpu.py (2e-3 of the tensor's largest gradient + 1e-5 of the model's): pins resident_bwd_kernel directly — weight gradients, head,
+    in-launch cross-entropy path excluded (eager loss) — not through the per-layer kernels. """
+    from test_model_gpu import _build, _batches, _smooth_twin
+    from deepcv_amd import modules, resident
+    native, oracle = _build({'twin': _smooth_twin(params['image_classifier_model'])}, 'twin', 10)
+    native = native.to(device)
+    (x, y), = _batches(1, 512)
+    oracle.train()
+    loss_o = torch.nn.CrossEntropyLoss()(oracle(x), y)
+    loss_o.backward()
+    prev, prev_b = resident.set_enabled(True), resident.set_backward_enabled(True)
+    prev_cap, resident.capture_programs = resident.capture_programs, True
+    try:
+        before = (resident.launches(), resident.backward_launches())
+        native.train()
+        loss_n = modules.CrossEntropyLoss()(native(x.to(device)), y.to(device))
+        loss_n.backward()
+        torch.cuda.synchronize()
+        resident.check_status()
+        assert (resident.launches(), resident.backward_launches()) == (before[0] + 1, before[1] + 1), 'the persistent launches did not run'
+        prog = resident.last_programs['backward'][0]
+        assert prog.count == 5 and all(prog.op[i].dw_part for i in range(5)) and prog.head.enabled and prog.head.fc_dw, 'weight gradients / head are not inside the launch'
+        assert not any(prog.op[i].dz for i in range(5)), 'dz must not leave the launch when nothing reads it'
+    finally:
+        resident.capture_programs = prev_cap
+        resident.set_enabled(prev)
+        resident.set_backward_enabled(prev_b)
+    assert abs(loss_n.item() - loss_o.item()) <= 1e-4 * abs(loss_o.item())
+    gscale = max(p.grad.abs().max().item() for p in oracle.parameters())
+    for (name, p_n), (_, p_o) in zip(native.named_parameters(), oracle.named_parameters()):
+        abs_err = (p_n.grad.detach().cpu() - p_o.grad).abs().max().item()
+        bound = 2e-3 * p_o.grad.abs().max().item() + 1e-5 * gscale
+        assert abs_err <= bound, f'{name}: gradient error {abs_err:.3e} > {bound:.3e}'
+
+
+def test_backward_launch_timeout_is_seen_by_the_training_loop(device, params):
+    """ A backward launch which gives up (one block never publishes) has already published the step's loss: the failure must reach the host on the path a
+    training loop reads anyway.  The launch poisons every gradient it owes with NaN, the optimizer carries it into the weights, and the NEXT loss read through
+    `GraphedTrainStep.loss_values()` is NaN -> `resident.check_status()` -> RuntimeError naming the timed-out launch; nobody calls check_status here. """
+    from deepcv_amd import modules, optim, resident
+    from deepcv_amd.meta.ignite_training import GraphedTrainStep, _setup_losses
+    g = torch.Generator().manual_seed(DATA_SEED)
+    x, y = torch.randn(64, 3, 32, 32, generator=g).to(device), torch.randint(0, 10, (64,), generator=g).to(device)
+    model = _model(params, 'image_classifier_model', device)
+    opt = optim.AdamW(model.parameters(), lr=1e-3)
+    losses, weights = _setup_losses(modules.CrossEntropyLoss(), None, device)
+    step = GraphedTrainStep(model, opt, losses, weights)
+    prev, prev_b = resident.set_enabled(True), resident.set_backward_enabled(True)
+    try:
+        for _ in range(4):                                       # eager, capture, verified replay, replay
+            step(x, y)
+            assert all(v == v for v in step.loss_values().values())
+        ws = resident._ws_bwd[device]
+        ws[8:12].copy_(torch.tensor([4], dtype=torch.int32).view(torch.uint8).to(device))        # block 3 of the backward launch never publishes
+        with pytest.raises(RuntimeError, match='timed out'):
+            for _ in range(3):                                   # the failing step's own loss is still finite; the next one's is not
+                step(x, y)
+                step.loss_values()
+        torch.cuda.synchronize()
+    finally:
+        if device in resident._ws_bwd:
+            resident._ws_bwd[device][8:12].zero_()
+        resident.set_enabled(prev)
+        resident.set_backward_enabled(prev_b)
+
+
+def test_launch_list_with_a_weight_gradient_batch_call_stays_in_bounds(device, params):
+    """ `dcv_conv2d_wgrad_batch` writes a host OUT array (the slab segments of its jobs).  A launch list re-issues the call with the ctypes objects recorded at
+    capture: the segment count must start from zero on every call (it used to append: a host heap overflow growing with every replay), and the replays must
+    reproduce the eager steps bit for bit.  Weight gradients kept outside the persistent launch put the call into the captured step. """
+    from deepcv_amd import modules, optim, resident
+    from deepcv_amd.meta.ignite_training import GraphedTrainStep, _setup_losses
+    g = torch.Generator().manual_seed(DATA_SEED)
+    batches = [(torch.randn(64, 3, 32, 32, generator=g).to(device), torch.randint(0, 10, (64,), generator=g).to(device)) for _ in range(7)]
+    prev, resident._wgrad_in_launch = resident._wgrad_in_launch, False
+    try:
+        curves = []
+        for graph in (True, False):
+            model = _model(params, 'image_classifier_model', device)
+            opt = optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-2)
+            losses, weights = _setup_losses(modules.CrossEntropyLoss(), None, device)
+            step = GraphedTrainStep(model, opt, losses, weights)
+            got = []
+            for xb, yb in batches:
+                out, _ = step(xb, yb) if graph else step._eager(xb, yb)
+                got.append(out['main_loss'].item())
+            torch.cuda.synchronize()
+            if graph:
+                assert step._launch_list is not None, 'the step was expected to replay as a launch list'
+                calls = [(fn, args) for fn, args, _ in step._launch_list.calls if getattr(fn, '__name__', '') == 'dcv_conv2d_wgrad_batch' or 'wgrad_batch' in repr(fn)]
+                assert calls, [getattr(fn, '__name__', repr(fn)) for fn, _, _ in step._launch_list.calls]
+                for _, args in calls:
+                    n_jobs, ns = args[0], args[3]._obj
+                    assert 0 < ns.value <= 2 * n_jobs, f'segment count {ns.value} after {len(batches) - 2} replays of {n_jobs} jobs'
+            curves.append(got)
+        assert curves[0] == curves[1], curves
+    finally:
+        resident._wgrad_in_launch = prev
