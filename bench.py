@@ -328,6 +328,7 @@ def main():
     ap.add_argument('--eager', action='store_true', help='do not capture the step into a hipGraph')
     ap.add_argument('--force-dp', action='store_true', help='rehearsal: take the data-parallel code path (process group, buckets, RCCL all-reduce) even at world size 1')
     ap.add_argument('--graph-collective', action='store_true', help='capture the RCCL all-reduce inside the step graph (one graph per step)')
+    ap.add_argument('--native-allreduce', action='store_true', help="the library's one-shot all-reduce (dcv_allreduce_*) instead of RCCL for the gradient bucket (also DCV_NATIVE_ALLREDUCE=1)")
     ap.add_argument('--no-secondary', action='store_true', help='skip the wide-kernel / wide-model secondary measurements')
     ap.add_argument('--no-parity', action='store_true', help='skip the oracle replay of the first steps')
     args = ap.parse_args()
@@ -373,7 +374,7 @@ def main():
     model = create_model({'trainset': SyntheticImageDataset(2, IMAGE_SHAPE, NUM_CLASSES)}, params['image_classifier_model']).to(device)
     reducer = None
     if use_dp:
-        wrapped = DataParallelModel(model, overlap=True)         # as `train()` builds it (`_setup_distributed_training`)
+        wrapped = DataParallelModel(model, overlap=True, native_allreduce=True if args.native_allreduce else None)         # as `train()` builds it (`_setup_distributed_training`)
         reducer = wrapped.reducer
         reducer.force_collective = args.force_dp
     opt = optim.AdamW(model.parameters(), **hp['optimizer_opts'])
@@ -430,7 +431,8 @@ def main():
             'config': {'workload': 'CIFAR-10 stock image_classifier DeepcvModule (17010 params): fwd + CE + bwd + AdamW + piecewise-linear LR, per-step loss read-back',
                        'global_batch': world * BATCH_PER_GPU, 'image_shape': list(IMAGE_SHAPE), 'parallelism': f'dp{world}',
                        'step_mode': 'eager' if args.eager else ('launch-list replay of the captured step (verified against its hipGraph)' if getattr(step_fn, '_launch_list', None) is not None
-                                                                else 'hipgraph-replay'), 'final_loss': last},
+                                                                else 'hipgraph-replay'), 'final_loss': last,
+                       **({'collective': ('library one-shot all-reduce (dcv_allreduce_oneshot) inside the captured step' if reducer.native_active() else 'RCCL all_reduce(AVG) between the backward and the optimizer launches')} if reducer is not None else {})},
             'roofline': roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -30,6 +30,7 @@ DTYPE_F32, DTYPE_BF16 = 0, 1
 MAX_TENSORS = 64
 MAX_CONCAT = 8
 MAX_COPY_JOBS = 8
+ALLREDUCE_MAX_RANKS, ALLREDUCE_HANDLE_BYTES = 16, 64      # DCV_ALLREDUCE_MAX_RANKS, DCV_ALLREDUCE_HANDLE_BYTES
 HYP_COUNT = 16
 HYP = {'lr': 0, 'beta1': 1, 'beta2': 2, 'eps': 3, 'weight_decay': 4, 'grad_scale': 5, 'bias_corr1': 6, 'bias_corr2': 7, 'first_step': 8}
 
@@ -235,6 +236,14 @@ _SIGNATURES = {
     'dcv_adamw_prep_build': (_c_int, [ctypes.POINTER(TensorList), _c_int, _c_int, _P, _P, _P, _P, ctypes.POINTER(AdamwPrepTable)]),
     'dcv_adamw_step_prep': (_c_int, [ctypes.POINTER(AdamwPrepTable), _P, _P]),
     'dcv_pack_grads': (_c_int, [ctypes.POINTER(TensorList), _P, _P]),
+    'dcv_allreduce_inbox_bytes': (_c_size_t, [_c_int, _c_size_t]),
+    'dcv_allreduce_alloc': (_c_int, [_c_size_t, ctypes.POINTER(_c_void_p)]),
+    'dcv_allreduce_free': (_c_int, [_P]),
+    'dcv_allreduce_export': (_c_int, [_P, ctypes.c_char_p]),
+    'dcv_allreduce_import': (_c_int, [ctypes.c_char_p, ctypes.POINTER(_c_void_p)]),
+    'dcv_allreduce_unmap': (_c_int, [_P]),
+    'dcv_allreduce_oneshot': (_c_int, [_P, _c_size_t, _c_int, _c_int, ctypes.POINTER(_c_void_p), _c_size_t, _P]),
+    'dcv_allreduce_status': (_c_int, [_P, _P, ctypes.POINTER(_c_int)]),
     'dcv_resident_supported': (_c_int, [ctypes.POINTER(ResidentProgram)]),
     'dcv_resident_ws_bytes': (_c_size_t, []),
     'dcv_resident_forward': (_c_int, [ctypes.POINTER(ResidentProgram), _P, _c_size_t, _P]),

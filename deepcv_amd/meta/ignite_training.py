@@ -175,6 +175,7 @@ class GraphedTrainStep:
         # launch-list replay: on unless `DCV_REPLAY_LIST=0`; verified against the graph on the first replay (`_verify_launch_list`)
         self._replay_list = os.environ.get('DCV_REPLAY_LIST', '1') not in ('0', 'false', 'False')
         self._launch_list = None
+        self._launch_list_opt = None         # with a data-parallel reducer whose collective runs between two graphs: the optimizer graph's launches
         self._list_verified = False
         self._staged_prog = None             # the forward program which stages the batch (launch-list replays hand it the batch's address directly)
         self._job0_src = None
@@ -345,7 +346,10 @@ class GraphedTrainStep:
         capture_mode = 'thread_local' if (self.reducer is not None or (torch.distributed.is_available() and torch.distributed.is_initialized())) else 'global'
         # launch-list replay (`DCV_REPLAY_LIST=1`): the library calls of the captured step are logged while the graph is captured and re-issued as plain
         # launches on every replay — the graph's memory pool keeps their buffers alive; a hipGraphLaunch costs ~9 us of idle GPU between two steps
-        recorder = self._nat.LaunchRecorder(self.stream.cuda_stream) if (self._replay_list and self.reducer is None) else None
+        # (not when RCCL's collective is captured inside the graph: its launch is no library call, the list would silently lack it — and the verification
+        # below could not tell whenever the ranks' gradients happen to be equal, e.g. in a group of one)
+        rccl_in_graph = self.reducer is not None and self.graph_collective and self.reducer.capturable() and not self.reducer.native_active()
+        recorder = self._nat.LaunchRecorder(self.stream.cuda_stream) if (self._replay_list and not rccl_in_graph) else None
         with self._nat.recording(recorder), torch.cuda.graph(self.graph_fb, stream=self.stream, capture_error_mode=capture_mode):
             if stage_in_forward:
                 _resident.set_staging((self.mailbox.data_ptr(), 0, self.static_x.data_ptr()))
@@ -388,7 +392,9 @@ class GraphedTrainStep:
             pending_plan = getattr(getattr(self.static_pred, 'grad_fn', None), 'res_plan', None)
             if pending_plan is not None:
                 _ops.flush_deferred_cross_entropy(pending_plan)                # (a deferred loss nobody took: cannot happen behind a backward pass; cheap to be sure)
-            in_graph = self.reducer is not None and self.graph_collective and self.reducer.capturable()
+            # the collective inside the captured step: always when it is the library's own launch (`NativeAllReduce`: one more kernel of the list), on request
+            # (`graph_collective`) when it is RCCL's
+            in_graph = self.reducer is not None and self.reducer.capturable() and (self.graph_collective or self.reducer.native_active())
             if self.reducer is None:
                 self.optimizer.step()
             elif in_graph:
@@ -402,8 +408,13 @@ class GraphedTrainStep:
             self._static_grads = [p.grad for p in self.reducer.params]       # graph-pool gradient tensors written by every replay
             self.reducer.finish()                                            # p.grad -> bucket views (static addresses)
             self.graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_opt, stream=self.stream, capture_error_mode=capture_mode):
+            recorder_opt = self._nat.LaunchRecorder(self.stream.cuda_stream) if self._launch_list is not None else None
+            with self._nat.recording(recorder_opt), torch.cuda.graph(self.graph_opt, stream=self.stream, capture_error_mode=capture_mode):
                 self.optimizer.step()
+            # launch lists on both sides of the eager collective, or graphs on both sides
+            self._launch_list_opt = recorder_opt if (recorder_opt is not None and 0 < len(recorder_opt.calls) <= 32) else None
+            if self._launch_list_opt is None:
+                self._launch_list = None
         torch.cuda.synchronize(dev)
         if self.reducer is not None:
             self.reducer.isolate = False                                     # nothing captures on the callers' streams from here on
@@ -439,30 +450,47 @@ class GraphedTrainStep:
         outputs = list(self.static_losses.values()) + ([self.static_pred] if isinstance(self.static_pred, torch.Tensor) else [])
         grads = [p.grad for p in self.model.parameters() if p.grad is not None]
 
-        def run(replay):
+        def run(use_list: bool):
             seen = []
             for xb, yb in ((x, y), (x2, y2)):
                 self._mailbox_write(xb, yb)                        # (same step number and scalars for both mechanisms: nothing counts these replays)
                 self._launch_stream = torch.cuda.current_stream(dev)
-                replay()
+                self._run_captured(use_list)
                 torch.cuda.synchronize(dev)
                 seen += [t.clone() for t in state] + [v.clone() for v in outputs]
             return seen
         for t in outputs + grads:
             if t.is_floating_point():
                 t.fill_(float('nan'))
-        by_list = run(self._replay_launch_list)
+        by_list = run(True)
         for t, s0 in zip(state, snapshot):
             t.data.copy_(s0)                                       # (.data: no version bump — the prepared-filter cache keys on the weights' versions)
-        by_graph = run(self.graph_fb.replay)
+        by_graph = run(False)
         ok = len(by_list) == len(by_graph) and all(torch.equal(a, b) for a, b in zip(by_list, by_graph))
         for t, s0 in zip(state, snapshot):
             t.data.copy_(s0)
         self._mailbox_write(x, y)
         self._launch_stream = torch.cuda.current_stream(dev)
-        self.graph_fb.replay()                                     # the one step this call owes its caller
+        self._run_captured(False)                                  # the one step this call owes its caller
         torch.cuda.synchronize(dev)
         return ok
+
+    def _run_captured(self, use_list: bool):
+        """ One captured step on the current stream, through the launch lists or through the graphs: forward + backward (+ the collective and the optimizer when they
+        were captured with them), then — a reducer whose collective runs between two captures — the collective, eagerly, and the optimizer's captured part.  With
+        a data-parallel reducer every rank makes the same calls whichever mechanism it uses (one collective per step). """
+        if use_list:
+            self._replay_launch_list()
+        else:
+            self.graph_fb.replay()
+        if self.graph_opt is not None:
+            for p, g in zip(self.reducer.params, self._static_grads):
+                p.grad = g
+            self.reducer.finish()
+            if use_list:
+                self._launch_list_opt.replay(self._launch_stream.cuda_stream)
+            else:
+                self.graph_opt.replay()
 
     def _replay_launch_list(self):
         if self._staged_prog is not None:
@@ -474,7 +502,7 @@ class GraphedTrainStep:
             self._list_verified = True
             if not self._verify_launch_list(x, y):
                 logging.getLogger(__name__).info('deepcv_amd: the captured step runs kernels outside libdeepcv_hip: replaying it as a hipGraph')
-                self._launch_list = None
+                self._launch_list = self._launch_list_opt = None
             # (the verification replayed this very batch: the step is done)
             self._launched_seq = None
             if hasattr(self.optimizer, 'note_replayed'):
@@ -482,18 +510,10 @@ class GraphedTrainStep:
             return OrderedDict((n, v.detach().clone()) for n, v in self.static_losses.items()), self.static_pred
         self._mailbox_write(x, y)
         self._launch_stream = torch.cuda.current_stream(x.device)
-        if self._launch_list is not None:
-            self._replay_launch_list()
-        else:
-            self.graph_fb.replay()
+        self._run_captured(self._launch_list is not None)
         self._launched_seq = self._seq if self._publishes else None
         if not self._publishes:
             self._launch_stream.synchronize()                      # no early read-back: the mailbox may only be rewritten once this replay is done
-        if self.graph_opt is not None:
-            for p, g in zip(self.reducer.params, self._static_grads):
-                p.grad = g
-            self.reducer.finish()
-            self.graph_opt.replay()
         if hasattr(self.optimizer, 'note_replayed'):
             self.optimizer.note_replayed()                         # weights changed behind the prepared-filter cache's back (deepcv_amd/filters.py)
         return self.static_losses, self.static_pred

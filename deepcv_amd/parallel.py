@@ -25,7 +25,102 @@ from . import filters
 from . import grads
 from . import slabs
 
-__all__ = ['GradientAllReducer', 'broadcast_module_state', 'DataParallelModel']
+__all__ = ['GradientAllReducer', 'NativeAllReduce', 'broadcast_module_state', 'DataParallelModel']
+
+
+def _env_flag(name: str, default: str = '0') -> bool:
+    import os
+    return os.environ.get(name, default) not in ('0', 'false', 'False', '')
+
+
+class NativeAllReduce:
+    """ Driver of the library's one-shot all-reduce (`dcv_allreduce_*`, deepcv_amd/csrc/allreduce.hip): every rank allocates an inbox, exports it with hipIpc,
+    the handles travel through the process group (`all_gather_object`: any backend), every rank maps its peers' inboxes.  `reduce(flat)` is then ONE kernel
+    launch on the current stream — capturable into a hipGraph and replayable from a launch list (the epoch lives in device memory) — which leaves the mean
+    over the ranks in `flat`, the same bits on every rank.  Meant for buckets of at most `max_floats` values whose all-reduce cannot overlap anything (the
+    stock classifier's 68 KB); off by default (`DCV_NATIVE_ALLREDUCE=1`, `DataParallelModel(native_allreduce=True)`): RCCL stays the default collective
+    until a multi-GPU run has validated this path (no such run is possible from the build container). """
+
+    def __init__(self, device: torch.device, max_floats: int, group=None):
+        self.device, self.max_floats, self.group = torch.device(device), int(max_floats), group
+        initialised = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if initialised else 0
+        self.world = dist.get_world_size(group) if initialised else 1
+        if self.world > nat.ALLREDUCE_MAX_RANKS:
+            raise ValueError(f'deepcv_amd.NativeAllReduce: at most {nat.ALLREDUCE_MAX_RANKS} ranks')
+        lib = nat.lib
+        with torch.cuda.device(self.device):
+            nbytes = int(lib.dcv_allreduce_inbox_bytes(self.world, self.max_floats))
+            inbox = ctypes.c_void_p()
+            nat.check(lib.dcv_allreduce_alloc(nbytes, ctypes.byref(inbox)), 'dcv_allreduce_alloc')
+            self._own = inbox.value
+            self.inboxes = (ctypes.c_void_p * self.world)()
+            self.inboxes[self.rank] = self._own
+            self._mapped: List[int] = []
+            if self.world > 1:
+                # every rank walks through the same collectives whatever fails locally (a rank which raised early would leave the others waiting)
+                handle = ctypes.create_string_buffer(nat.ALLREDUCE_HANDLE_BYTES)
+                exported = lib.dcv_allreduce_export(self._own, handle) == 0
+                handles: List[Optional[bytes]] = [None] * self.world
+                dist.all_gather_object(handles, bytes(handle.raw) if exported else b'', group=group)
+                mapped_all = all(handles)
+                if mapped_all:
+                    for p, h in enumerate(handles):
+                        if p == self.rank:
+                            continue
+                        peer = ctypes.c_void_p()
+                        if lib.dcv_allreduce_import(ctypes.create_string_buffer(h, nat.ALLREDUCE_HANDLE_BYTES), ctypes.byref(peer)) != 0:
+                            mapped_all = False
+                            break
+                        self.inboxes[p] = peer.value
+                        self._mapped.append(peer.value)
+                verdicts: List[Optional[bool]] = [None] * self.world
+                dist.all_gather_object(verdicts, bool(mapped_all), group=group)     # (also the barrier: every inbox is mapped everywhere before anybody pushes)
+                if not all(verdicts):
+                    self.close()
+                    raise RuntimeError(f'hipIpc could not share the inboxes between the ranks (export / import refused on rank(s) {[r for r, v in enumerate(verdicts) if not v]})')
+
+    def self_test(self) -> bool:
+        """ One all-reduce of known values (rank r contributes r + 1 + i / 8): True when THIS rank received the exact mean.  Collective; used by
+        `GradientAllReducer.enable_native`, which keeps the process group's collective unless every rank passes. """
+        n = min(self.max_floats, 4096)
+        idx = torch.arange(n, dtype=torch.float32, device=self.device) * 0.125
+        flat = idx + float(self.rank + 1)
+        want = idx.clone()
+        for _ in range(2):                                       # both parities
+            cur = flat.clone()
+            self.reduce(cur)
+            torch.cuda.synchronize(self.device)
+            acc = torch.zeros_like(idx)
+            for r in range(self.world):                          # the kernel's arithmetic: sum in rank order, times 1 / world
+                acc = acc + (idx + float(r + 1))
+            want = acc * (1.0 / self.world)
+            if not torch.equal(cur, want):
+                return False
+        err = ctypes.c_int(0)
+        nat.check(nat.lib.dcv_allreduce_status(self._own, nat.current_stream(self.device), ctypes.byref(err)), 'dcv_allreduce_status')
+        return err.value == 0
+
+    def reduce(self, flat: torch.Tensor):
+        assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous() and flat.numel() <= self.max_floats
+        nat.check(nat.lib.dcv_allreduce_oneshot(flat.data_ptr(), flat.numel(), self.rank, self.world, self.inboxes, self.max_floats, nat.current_stream(self.device)),
+                  'dcv_allreduce_oneshot')
+
+    def check_status(self):
+        """ Raises if a launch gave up waiting for a peer (synchronises the current stream). """
+        err = ctypes.c_int(0)
+        nat.check(nat.lib.dcv_allreduce_status(self._own, nat.current_stream(self.device), ctypes.byref(err)), 'dcv_allreduce_status')
+        if err.value:
+            raise RuntimeError(f'deepcv_amd.NativeAllReduce: rank {self.rank} never received the values of rank {err.value - 1} (bounded wait); the gradients of that step are NaN')
+
+    def close(self):
+        lib = nat.lib
+        for peer in self._mapped:
+            lib.dcv_allreduce_unmap(peer)
+        self._mapped = []
+        if self._own:
+            lib.dcv_allreduce_free(self._own)
+            self._own = None
 
 
 def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None):
@@ -66,6 +161,7 @@ class GradientAllReducer:
         self.enabled = True
         self.overlap = overlap
         self.force_collective = False     # rehearsal switch: run the collective even in a group of one
+        self.native: Optional[NativeAllReduce] = None     # the library's one-shot all-reduce instead of the process group's (`enable_native`)
         # True: collectives never go to the caller's stream, always to `comm_stream`.  The process group's watchdog thread polls the end event of every
         # collective until it has seen it complete (up to ~100 ms after the fact), and HIP refuses an event query whose stream has meanwhile begun a graph
         # capture (hipErrorCapturedEvent -> the watchdog throws, the rank aborts).  `GraphedTrainStep` sets this for the eager steps which run on its
@@ -140,7 +236,39 @@ class GradientAllReducer:
                 self._all_reduce_mean(b)
         b.launched = True
 
+    def enable_native(self, max_floats: int = 1 << 18) -> bool:
+        """ Switches the single small bucket of a small model over to `NativeAllReduce` (a kernel launch: it can be captured / replayed with the step).  False
+        (and nothing changes) when the gradients do not fit one bucket of at most `max_floats` values or do not live on a HIP device.  Collective: every rank
+        must call it. """
+        if self.native is not None:
+            return True
+        if self.device.type != 'cuda' or len(self.buckets) != 1 or self.buckets[0].total > max_floats or self.buckets[0].flat.dtype != torch.float32:
+            return False
+        try:
+            native = NativeAllReduce(self.device, max(self.buckets[0].total, 1024), self.group)
+            ok = native.self_test()
+        except RuntimeError as e:                                # hipIpc export / import refused (e.g. no peer access between the devices)
+            import logging
+            logging.getLogger(__name__).warning(f'deepcv_amd: the native all-reduce is not available here ({e}); keeping the process group\'s collective')
+            native, ok = None, False
+        if dist.is_initialized() and self.world_size > 1:        # all ranks or none
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device if dist.get_backend(self.group) == 'nccl' else 'cpu')
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            ok = bool(flag.item())
+        if not ok:
+            if native is not None:
+                native.close()
+            return False
+        self.native = native
+        return True
+
+    def native_active(self) -> bool:
+        return self.native is not None
+
     def _all_reduce_mean(self, b: _Bucket):
+        if self.native is not None:
+            self.native.reduce(b.flat)
+            return
         backend = dist.get_backend(self.group)
         if backend == 'nccl':
             dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.group)    # RCCL averages in the collective: no extra pass
@@ -189,7 +317,9 @@ class GradientAllReducer:
         grads.unregister(self.params)
 
     def capturable(self) -> bool:
-        """ Can the collective be recorded into a hipGraph (RCCL on device buckets)? """
+        """ Can the collective be recorded into a hipGraph (the library's own launch, or RCCL on device buckets)? """
+        if self.native is not None:
+            return True
         return self.device.type == 'cuda' and dist.is_initialized() and dist.get_backend(self.group) == 'nccl'
 
 
@@ -198,13 +328,25 @@ class DataParallelModel(torch.nn.Module):
     (what `Checkpoint` saves for a DDP model at `ignite_training.py:263`).  Owns the `GradientAllReducer`; `train()` calls `reducer.finish()`
     between `backward()` and `optimizer.step()`. """
 
-    def __init__(self, module: torch.nn.Module, process_group=None, bucket_cap_mb: float = 32., overlap: bool = True, broadcast: bool = True):
+    def __init__(self, module: torch.nn.Module, process_group=None, bucket_cap_mb: float = 32., overlap: bool = True, broadcast: bool = True,
+                 native_allreduce: Optional[bool] = None, broadcast_buffers: bool = False):
         super().__init__()
         self.module = module
+        self.group = process_group
         resident.disable_if_gpu_shared()
         if broadcast and dist.is_initialized() and dist.get_world_size(process_group) > 1:
             broadcast_module_state(module, src=0, group=process_group)
         self.reducer = GradientAllReducer(module.parameters(), process_group=process_group, bucket_cap_mb=bucket_cap_mb, overlap=overlap)
+        if native_allreduce if native_allreduce is not None else _env_flag('DCV_NATIVE_ALLREDUCE'):
+            self.reducer.enable_native()
+        # DistributedDataParallel's `broadcast_buffers=True` (the reference's default, ignite_training.py:380): rank 0's buffers (BatchNorm running statistics)
+        # overwrite every other rank's before each training forward.  Off by default here: every rank keeps its own running statistics, checkpoints are
+        # rank 0's either way (DESIGN.md §6).
+        self.broadcast_buffers = bool(broadcast_buffers)
 
     def forward(self, *args, **kwargs):
+        if self.broadcast_buffers and self.training and dist.is_initialized() and dist.get_world_size(self.group) > 1 and not torch.cuda.is_current_stream_capturing():
+            with torch.no_grad():
+                for b in self.module.buffers():
+                    dist.broadcast(b.data, src=0, group=self.group)
         return self.module(*args, **kwargs)

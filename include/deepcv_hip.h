@@ -536,6 +536,31 @@ int dcv_adamw_step_prep(const dcv_adamw_prep_table* table, const float* hyper, v
 int dcv_pack_grads(const dcv_tensor_list* tl, float* dst_flat, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * C1  one-shot mean all-reduce of a small gradient bucket across the GPUs of one node, without a collective library (allreduce.hip).
+ * replaces the bucket all-reduce of DistributedDataParallel (ignite_training.py:373-390) for models whose whole gradient is one bucket which only exists
+ * when the backward pass has ended (the stock classifier: 68 KB): a latency problem.  Every rank owns an INBOX (device memory, one allocation, mapped into
+ * the peer processes with hipIpc); a launch pushes its values as 8-byte {epoch, value} granules into every peer's inbox over xGMI, polls its own inbox for
+ * the others' and adds the `world` values in rank order (the same bits on every rank), then scales by 1 / world, in place.  The epoch lives in the inbox
+ * header and advances with every launch: a replayed launch list / hipGraph re-issues the identical call.  Bounded spins: a rank which never hears from
+ * another sets an error word (dcv_allreduce_status -> 1 + that rank) and writes NaN.
+ *   setup (once per process group):  bytes = dcv_allreduce_inbox_bytes(world, max_floats);  dcv_allreduce_alloc(bytes, &inbox);  dcv_allreduce_export(inbox, handle);
+ *          exchange the handles (any host channel, e.g. torch.distributed.all_gather_object);  dcv_allreduce_import(handle_p, &inboxes[p]) for every p != rank,
+ *          inboxes[rank] = inbox;   teardown: dcv_allreduce_unmap(inboxes[p]), dcv_allreduce_free(inbox)
+ *   per step:  dcv_allreduce_oneshot(bucket, count, rank, world, inboxes, max_floats, stream)   — every rank the same count, the same number of calls
+ * The only entry points of this library which allocate / map device memory (hipIpc exports whole allocations) and synchronise (alloc, status).
+ * ------------------------------------------------------------------------------------------------- */
+#define DCV_ALLREDUCE_MAX_RANKS 16
+#define DCV_ALLREDUCE_HANDLE_BYTES 64
+size_t dcv_allreduce_inbox_bytes(int world, size_t max_floats);
+int dcv_allreduce_alloc(size_t bytes, void** inbox);
+int dcv_allreduce_free(void* inbox);
+int dcv_allreduce_export(void* inbox, unsigned char* handle);
+int dcv_allreduce_import(const unsigned char* handle, void** peer_inbox);
+int dcv_allreduce_unmap(void* peer_inbox);
+int dcv_allreduce_oneshot(float* bucket, size_t count, int rank, int world, void* const* inboxes, size_t max_floats, void* stream);
+int dcv_allreduce_status(const void* inbox, void* stream, int* err);
+
+/* ---------------------------------------------------------------------------------------------------
  * LDS-resident network (resident.hip): the training forward of a small-channel DeepcvModule as ONE persistent launch.
  * replaces the per-sub-module dispatch of DeepcvModule.forward (src/deepcv/meta/base_module.py:113-155) over `layer()` stacks
  * (src/deepcv/meta/nn.py:519-554: Conv2d -> act -> BatchNorm2d [-> GroupNorm]), avg_pooling (submodule_creators.py:163-176), dense links

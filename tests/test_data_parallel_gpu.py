@@ -29,9 +29,14 @@ def test_rccl_path_world_size_one_matches_single_process(device):
     single = _bench([])
     graphed = _bench(['--gpus', '1', '--force-dp'], launcher)
     eager = _bench(['--force-dp', '--eager'])
-    assert graphed['config']['step_mode'] == 'hipgraph-replay' and eager['config']['step_mode'] == 'eager'
-    assert graphed['config']['final_loss'] == single['config']['final_loss'] == eager['config']['final_loss']
-    for r in (single, graphed, eager):
+    one_graph = _bench(['--gpus', '1', '--force-dp', '--graph-collective'], launcher)       # the RCCL collective captured inside the step's graph
+    native = _bench(['--gpus', '1', '--force-dp', '--native-allreduce'], launcher)          # the library's own all-reduce: one more launch of the list
+    # a short captured step replays as launch lists on both sides of the eager collective; RCCL's launch is no library call, so a graph which contains it stays a graph
+    assert graphed['config']['step_mode'].startswith('launch-list') and eager['config']['step_mode'] == 'eager'
+    assert one_graph['config']['step_mode'] == 'hipgraph-replay' and native['config']['step_mode'].startswith('launch-list')
+    assert 'RCCL' in graphed['config']['collective'] and 'dcv_allreduce_oneshot' in native['config']['collective']
+    assert graphed['config']['final_loss'] == single['config']['final_loss'] == eager['config']['final_loss'] == one_graph['config']['final_loss'] == native['config']['final_loss']
+    for r in (single, graphed, eager, one_graph, native):
         assert r['n_gpus'] == 1 and r['value'] > 0 and set(r['roofline']) >= {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'}
 
 
@@ -61,7 +66,7 @@ def _dp_global_batches():
     return [(torch.randn(16, 3, 32, 32, generator=g), torch.randint(0, 10, (16,), generator=g)) for _ in range(DP_STEPS)]
 
 
-def _hip_dp_worker(rank, port, out_dir, backend, spec, graph):
+def _hip_dp_worker(rank, port, out_dir, backend, spec, graph, native=False):
     """ One rank of a data-parallel run on the HIP path, built the way `train()` builds it: native model, `DataParallelModel` (rank-0 broadcast, gradient arena),
     native AdamW, `graphed_train_step` (or the eager step with autograd hooks).  `gloo`: both ranks share GPU 0; `nccl` (RCCL): one GPU per rank. """
     import torch
@@ -85,7 +90,8 @@ def _hip_dp_worker(rank, port, out_dir, backend, spec, graph):
     params = load_parameters()
     torch.manual_seed(SEED + rank)            # different init per rank: the wrapper's broadcast must make the replicas identical
     model = create_model({'trainset': SyntheticImageDataset(8)}, params[spec]).to(device)
-    dp = DataParallelModel(model, overlap=True)
+    dp = DataParallelModel(model, overlap=True, native_allreduce=native)
+    assert dp.reducer.native_active() == bool(native)
     hp = dict(params['train_image_classifier']); hp['epochs'] = 1
     opt = optim.AdamW(dp.module.parameters(), **hp['optimizer_opts'])
     sched = PiecewiseLinear(opt, 'lr', O.stock_milestones(hp, DP_STEPS))
@@ -105,13 +111,16 @@ def _hip_dp_worker(rank, port, out_dir, backend, spec, graph):
             out, _ = step._on_side_stream(step._eager, xr, yr)
             got.append(out['main_loss'].item())
     torch.cuda.synchronize()
+    if native:
+        dp.reducer.native.check_status()
     torch.save({'losses': got, 'params': [p.detach().cpu().clone() for p in dp.module.parameters()],
-                'graph_replays': step.calls - 2 if graph else 0}, Path(out_dir) / f'rank{rank}.pt')
+                'graph_replays': step.calls - 2 if graph else 0, 'one_graph': graph and step.graph_opt is None,
+                'list_replay': graph and step._launch_list is not None}, Path(out_dir) / f'rank{rank}.pt')
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run_hip_dp(backend, spec, graph, params):
+def _run_hip_dp(backend, spec, graph, params, native=False):
     import socket
     import tempfile
     import torch
@@ -121,7 +130,7 @@ def _run_hip_dp(backend, spec, graph, params):
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_hip_dp_worker, args=(port, d, backend, spec, graph), nprocs=WORLD, join=True)
+        mp.spawn(_hip_dp_worker, args=(port, d, backend, spec, graph, native), nprocs=WORLD, join=True)
         r = [torch.load(Path(d) / f'rank{k}.pt', weights_only=False) for k in range(WORLD)]
     for a, b in zip(r[0]['params'], r[1]['params']):
         assert torch.equal(a, b), 'replicas must stay bit-identical'
@@ -154,9 +163,68 @@ def test_two_hip_ranks_over_gloo_match_oracle_ddp_emulation(device, params, spec
         assert r[0]['graph_replays'] == DP_STEPS - 2
 
 
-def test_two_hip_ranks_over_rccl_match_oracle_ddp_emulation(params):
-    """ The same over RCCL (`nccl` backend), one GPU per rank: runs wherever two GPUs are visible (the driver's multi-GPU node), skips on a 1-GPU box. """
+@pytest.mark.parametrize('graph', [True, False], ids=['hipgraph', 'eager-hooks'])
+def test_two_hip_ranks_with_the_native_allreduce_match_oracle_ddp_emulation(device, params, graph):
+    """ The library's one-shot all-reduce (`dcv_allreduce_*`, allreduce.hip) as the gradient collective: two processes share this box's GPU, each maps the other's
+    inbox through hipIpc (handles exchanged over the gloo group), every step's bucket is pushed / polled / summed by ONE kernel launch per rank.  Same bars as the
+    gloo run: per-rank losses of every step and the final weights against the oracle's DDP emulation, replicas bit-identical.  Captured steps carry the collective
+    inside their single graph (no second graph, no eager call between two replays). """
+    r = _run_hip_dp('gloo', 'image_classifier_model', graph, params, native=True)
+    if graph:
+        assert r[0]['graph_replays'] == DP_STEPS - 2 and all(x['one_graph'] for x in r)
+
+
+@pytest.mark.parametrize('native', [False, True], ids=['rccl', 'native-allreduce'])
+def test_two_hip_ranks_over_rccl_match_oracle_ddp_emulation(params, native):
+    """ The same with one GPU per rank (`nccl` = RCCL process group; `native`: the gradient bucket goes through the library's own all-reduce over xGMI instead):
+    runs wherever two GPUs are visible, skips on a 1-GPU box. """
     import torch
     if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
         pytest.skip('needs two HIP devices')
-    _run_hip_dp('nccl', 'image_classifier_model', True, params)
+    _run_hip_dp('nccl', 'image_classifier_model', True, params, native=native)
+
+
+def test_native_allreduce_two_virtual_ranks_in_one_process(device):
+    """ The protocol of `dcv_allreduce_oneshot` without processes: two inboxes in this process, each "rank" launched on its own stream (they wait for each other's
+    pushes, so they must not share a stream).  Mean in rank order: both ranks end with bit-identical (a + b) / 2; five rounds (the epoch advances in device memory,
+    the parities alternate), sizes which are not multiples of the block and larger than one sweep of the grid. """
+    import ctypes
+    import torch
+    from deepcv_amd import _native as nat
+    lib = nat.lib
+    cap = 1 << 17
+    nbytes = int(lib.dcv_allreduce_inbox_bytes(2, cap))
+    assert nbytes == 256 + 2 * 2 * cap * 8 and lib.dcv_allreduce_inbox_bytes(17, cap) == 0
+    boxes = (ctypes.c_void_p * 2)()
+    for k in range(2):
+        p = ctypes.c_void_p()
+        nat.check(lib.dcv_allreduce_alloc(nbytes, ctypes.byref(p)), 'alloc')
+        boxes[k] = p.value
+    streams = [torch.cuda.Stream(device=device) for _ in range(2)]
+    try:
+        g = torch.Generator().manual_seed(5)
+        for n in (17010, 1, 255, 257, 100_003):
+            a, b = torch.randn(n, generator=g).to(device), torch.randn(n, generator=g).to(device)
+            want = (a + b) * 0.5
+            ra, rb = a.clone(), b.clone()
+            torch.cuda.synchronize()
+            for k, buf in enumerate((ra, rb)):
+                with torch.cuda.stream(streams[k]):
+                    nat.check(lib.dcv_allreduce_oneshot(buf.data_ptr(), n, k, 2, boxes, cap, streams[k].cuda_stream), 'oneshot')
+            torch.cuda.synchronize()
+            assert torch.equal(ra, want) and torch.equal(rb, want), f'n = {n}'
+        for k in range(2):
+            err = ctypes.c_int(-1)
+            nat.check(lib.dcv_allreduce_status(boxes[k], nat.current_stream(device), ctypes.byref(err)), 'status')
+            assert err.value == 0
+        # world size 1: the identity (scaled by 1 / 1), no peer
+        solo = (ctypes.c_void_p * 1)(boxes[0])
+        x = torch.randn(1000, generator=g).to(device)
+        y = x.clone()
+        nat.check(lib.dcv_allreduce_oneshot(y.data_ptr(), 1000, 0, 1, solo, cap, nat.current_stream(device)), 'oneshot world 1')
+        torch.cuda.synchronize()
+        assert torch.equal(x, y)
+    finally:
+        torch.cuda.synchronize()
+        for k in range(2):
+            lib.dcv_allreduce_free(boxes[k])
