@@ -557,7 +557,9 @@ def train(hp: HYPERPARAMS_T, model: torch.nn.Module, losses: LOSS_FN_TERMS_T = N
           `hip_graph` (None = auto: capture the step into a hipGraph when the model has fewer than 5M parameters), `graph_collective` (capture the
           RCCL gradient all-reduce inside that graph; None = `DCV_GRAPH_COLLECTIVE`, off by default), `num_workers`, `bucket_cap_mb`,
           `device_transform` (callable applied on the device to the images of every prefetched batch, e.g. `DeviceNormalize` for raw uint8 pixels),
-          `conv_math` ('fp32' | 'bf16': arithmetic of the MFMA convolution kernels, see `deepcv_amd.ops.set_conv_math`).
+          `conv_math` ('fp32' | 'bf16': arithmetic of the MFMA convolution kernels, see `deepcv_amd.ops.set_conv_math`), `native_allreduce` (None =
+          `DCV_NATIVE_ALLREDUCE`: the library's one-shot all-reduce for a single small gradient bucket instead of RCCL's), `broadcast_buffers` (DDP's per-forward
+          broadcast of rank 0's buffers, reference `:380`; off by default: DESIGN.md §6).
         - model: `torch.nn.Module` to train (e.g. a `DeepcvModule`)
         - losses (alias `loss`, Appendix A #24): a loss callable/module, a sequence, or a mapping name -> loss; see `loss_weights`
         - datasets: `{'trainset': ..., 'validset': ...[, 'testset': ...]}` (or a 2/3-tuple in that order) of `torch.utils.data.Dataset`s (Appendix A #29)
@@ -571,7 +573,8 @@ def train(hp: HYPERPARAMS_T, model: torch.nn.Module, losses: LOSS_FN_TERMS_T = N
     TRAINING_HP_DEFAULTS = {'optimizer_opts': ..., 'epochs': ..., 'batch_size': ..., 'scheduler': None, 'output_path': Path.cwd() / 'data/04_training/',
                             'log_output_dir_to_mlflow': True, 'validate_every_epochs': 1, 'save_every_iters': 1000, 'log_grads_every_iters': -1,
                             'log_progress_every_iters': 100, 'seed': None, 'prefetch_batches': True, 'resume_from': '', 'crash_iteration': -1,
-                            'deterministic_cudnn': False, 'use_sync_batch_norm': False, 'hip_graph': None, 'graph_collective': None, 'num_workers': None, 'bucket_cap_mb': 32., 'device_transform': None, 'conv_math': None}
+                            'deterministic_cudnn': False, 'use_sync_batch_norm': False, 'hip_graph': None, 'graph_collective': None, 'num_workers': None, 'bucket_cap_mb': 32., 'device_transform': None, 'conv_math': None,
+                            'native_allreduce': None, 'broadcast_buffers': False}
     losses = losses if losses is not None else loss
     backend_conf = backend_conf if backend_conf is not None else BackendConfig()
     metrics = dict(metrics) if metrics else {}
@@ -599,7 +602,8 @@ def train(hp: HYPERPARAMS_T, model: torch.nn.Module, losses: LOSS_FN_TERMS_T = N
 
     # Distributed setup first: samplers need the process group (`:373-390`, Appendix A #34)
     model = model.to(device, non_blocking=True)
-    model, reducer = _setup_distributed_training(device, backend_conf, model, use_sync_batch_norm=hp['use_sync_batch_norm'], bucket_cap_mb=hp['bucket_cap_mb'])
+    model, reducer = _setup_distributed_training(device, backend_conf, model, use_sync_batch_norm=hp['use_sync_batch_norm'], bucket_cap_mb=hp['bucket_cap_mb'],
+                                                 native_allreduce=hp['native_allreduce'], broadcast_buffers=hp['broadcast_buffers'])
 
     # Dataloaders (`:210-219`); evaluation batches are 32x larger than training ones (`:215`)
     if hp['num_workers'] is not None:
@@ -776,7 +780,8 @@ def _unwrap(model: torch.nn.Module) -> torch.nn.Module:
     return model.module if isinstance(model, DataParallelModel) else model
 
 
-def _setup_distributed_training(device, backend_conf: BackendConfig, model: torch.nn.Module, use_sync_batch_norm: bool = False, bucket_cap_mb: float = 32.):
+def _setup_distributed_training(device, backend_conf: BackendConfig, model: torch.nn.Module, use_sync_batch_norm: bool = False, bucket_cap_mb: float = 32.,
+                                native_allreduce: Optional[bool] = None, broadcast_buffers: bool = False):
     """ Process-group initialisation + data-parallel wrapping (reference `ignite_training.py:373-390`).  The reference asserts CUDA; this build also accepts
     the `gloo` backend on CPU so that the sharding / averaging logic is testable without GPUs.  Returns `(model, reducer | None)`. """
     if not backend_conf.distributed:
@@ -789,7 +794,7 @@ def _setup_distributed_training(device, backend_conf: BackendConfig, model: torc
     if use_sync_batch_norm:
         from .. import modules as native
         native.SyncBatchNorm2d.convert(model)      # statistics over all ranks (collective C4); such layers run op by op, not through the fused layer chain
-    wrapped = DataParallelModel(model, bucket_cap_mb=bucket_cap_mb, overlap=True)
+    wrapped = DataParallelModel(model, bucket_cap_mb=bucket_cap_mb, overlap=True, native_allreduce=native_allreduce, broadcast_buffers=broadcast_buffers)
     return wrapped, wrapped.reducer
 
 

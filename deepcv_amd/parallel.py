@@ -345,7 +345,7 @@ class DataParallelModel(torch.nn.Module):
         self.broadcast_buffers = bool(broadcast_buffers)
 
     def forward(self, *args, **kwargs):
-        if self.broadcast_buffers and self.training and dist.is_initialized() and dist.get_world_size(self.group) > 1 and not torch.cuda.is_current_stream_capturing():
+        if self.broadcast_buffers and self.training and dist.is_initialized() and dist.get_world_size(self.group) > 1 and not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
             with torch.no_grad():
                 for b in self.module.buffers():
                     dist.broadcast(b.data, src=0, group=self.group)

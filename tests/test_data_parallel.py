@@ -94,3 +94,50 @@ def test_reducer_world_size_one_is_identity():
     for p, g in zip(lin.parameters(), g0):
         assert torch.equal(p.grad, g) and p.grad.data_ptr() != g.data_ptr()   # now views of the flat bucket
     assert red.buckets[0].flat.numel() == 16    # bias 3 (+1: slices start on 16-B boundaries) + weight 12
+
+
+def _buffers_worker(rank, port, out_dir, broadcast_buffers):
+    import sys
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    from deepcv_amd.parallel import DataParallelModel
+    from deepcv_amd.utils import load_parameters
+    from oracle import deepcv_oracle as O
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    torch.set_num_threads(2)
+    params = load_parameters()
+    torch.manual_seed(SEED)
+    model = O.create_model((3, 32, 32), params['image_classifier_bn_only_model'], 10)
+    dp = DataParallelModel(model, broadcast_buffers=broadcast_buffers)
+    (x0, _), (x1, _), _ = _global_batches()
+    dp.train()
+    with torch.no_grad():
+        dp(x0[rank::WORLD])                      # each rank's shard moves its own running statistics
+        kept = [b.detach().clone() for b in dp.module.buffers()]
+        dp(x1[rank::WORLD])
+        clean = [b.detach().clone() for b in dp.module.buffers()]
+        for b, k in zip(dp.module.buffers(), kept):
+            b.copy_(k)
+            if rank == 1 and b.is_floating_point():
+                b.add_(123.)                     # rank 1's statistics are off before the second forward
+        dp(x1[rank::WORLD])
+        dirty = [b.detach().clone() for b in dp.module.buffers()]
+    torch.save({'clean': clean, 'dirty': dirty}, Path(out_dir) / f'rank{rank}.pt')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('broadcast_buffers', [False, True], ids=['own-statistics', 'ddp-broadcast-buffers'])
+def test_broadcast_buffers_option_follows_ddp(params, broadcast_buffers):
+    """ DistributedDataParallel(broadcast_buffers=True) (the reference's default, `ignite_training.py:380`) overwrites every rank's buffers with rank 0's before
+    each training forward: whatever rank 1 held in its running statistics does not survive into the forward.  Without the option (this package's default,
+    DESIGN.md §6) every rank keeps its own. """
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_buffers_worker, args=(_free_port(), d, broadcast_buffers), nprocs=WORLD, join=True)
+        r = [torch.load(Path(d) / f'rank{k}.pt', weights_only=False) for k in range(WORLD)]
+    floats = [i for i, b in enumerate(r[1]['clean']) if b.is_floating_point()]
+    assert floats
+    for i in floats:
+        assert torch.equal(r[0]['clean'][i], r[0]['dirty'][i])                   # rank 0 is the source either way
+        survived = not torch.equal(r[1]['clean'][i], r[1]['dirty'][i])
+        assert survived == (not broadcast_buffers), f'buffer {i}: rank 1\'s own statistics {"survived" if survived else "were replaced"}'
