@@ -30,6 +30,7 @@ DTYPE_F32, DTYPE_BF16 = 0, 1
 MAX_TENSORS = 64
 MAX_CONCAT = 8
 MAX_COPY_JOBS = 8
+IM2COL_MAX_K = 256                                         # DCV_IM2COL_MAX_K
 ALLREDUCE_MAX_RANKS, ALLREDUCE_HANDLE_BYTES = 16, 64      # DCV_ALLREDUCE_MAX_RANKS, DCV_ALLREDUCE_HANDLE_BYTES
 HYP_COUNT = 16
 HYP = {'lr': 0, 'beta1': 1, 'beta2': 2, 'eps': 3, 'weight_decay': 4, 'grad_scale': 5, 'bias_corr1': 6, 'bias_corr2': 7, 'first_step': 8}
@@ -174,6 +175,7 @@ _SIGNATURES = {
     'dcv_conv2d_bf16_wgrad_workspace_bytes': (_c_size_t, [ctypes.POINTER(Conv2dDesc)]),
     'dcv_conv2d_bf16_wgrad': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _c_size_t, _P]),
     'dcv_cast_f32_to_bf16': (_c_int, [_P, _P, _c_size_t, _P]),
+    'dcv_im2col_bf16': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _c_int, _P]),
     'dcv_cast_bf16_to_f32': (_c_int, [_P, _P, _c_size_t, _P]),
     'dcv_act_fwd': (_c_int, [_P, _P, _c_size_t, _c_int, _c_float, _P]),
     'dcv_act_bwd_workspace_bytes': (_c_size_t, [_c_size_t, _c_int]),

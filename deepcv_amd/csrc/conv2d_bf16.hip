@@ -233,7 +233,9 @@ __device__ __forceinline__ s16x4 tr_read(const char* p) { return __builtin_amdgc
 
 // GROUPS: wave groups of 256 threads splitting the block's pixel range; their accumulators are summed through LDS at the end (group 1's 36 tiles = 144 KB,
 // the staging buffers are dead by then), which halves the number of fp32 partial slabs the ordered reduce has to read for the same number of resident waves.
-template <int GROUPS>
+// TAPS: 9 (3x3 / pad 1) or 1 (1x1 / pad 0: a plain GEMM dW[co][ci] = sum over pixels — the weight gradient of a first layer rewritten as im2col + 1x1,
+// dcv_im2col_bf16): one tap, the x "window" is the step's 32 pixels themselves, no border masks.
+template <int GROUPS, int TAPS = 9>
 __global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9_kernel(W16Args a, const u16* __restrict__ x, const u16* __restrict__ dy, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem16[];
     const int XR = a.XR;
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9_kernel(W16Ar
             g = __builtin_amdgcn_raw_buffer_load_b128(rdy, (int)(p < HW ? off : BF_OOB), 0, 0);
         }
         const int xbase = ((n * HW) * a.Cin + ci0 + 8 * piece) * 2;
-        const int q0 = p0 - a.W - 1;
+        const int q0 = TAPS == 9 ? p0 - a.W - 1 : p0;
 #pragma unroll
         for (int u = 0; u < W16_XP; ++u)
             if (u < nxp) {
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9_kernel(W16Ar
                 const int row = prow + 32 * u;
                 if (row < XR) *reinterpret_cast<u32x4*>(Xs + (size_t)buf * X_BYTES + row * W16_LD + piece * 16) = xv[u];
             }
-        if (t < 16) {
+        if (TAPS == 9 && t < 16) {
             const int pw = s_p0 + 2 * t;
             const int w0 = pw % a.W, w1 = (pw + 1) % a.W;
             Cm[(buf * 16 + t) * 2 + 0] = (w0 > 0 ? 0x0000ffffu : 0u) | (w1 > 0 ? 0xffff0000u : 0u);
@@ -297,9 +299,9 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9_kernel(W16Ar
         }
     };
 
-    f32x4 acc[9][4];
+    f32x4 acc[TAPS][4];
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
+    for (int k = 0; k < TAPS; ++k)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[k][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -325,6 +327,12 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9_kernel(W16Ar
             Frag af[4];
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) { af[tt].h[0] = tr_read(gs + a_off + tt * 32); af[tt].h[1] = tr_read(gs + a_off + tt * 32 + 16 * W16_LD); }
+            if constexpr (TAPS == 1) {
+                Frag bfr;
+                bfr.h[0] = tr_read(xs + b_off); bfr.h[1] = tr_read(xs + b_off + 16 * W16_LD);
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) acc[0][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tt].v, bfr.v, acc[0][tt], 0, 0, 0);
+            } else
 #pragma unroll
             for (int sx = 0; sx < 3; ++sx) {
                 Frag av[4];
@@ -342,7 +350,7 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9_kernel(W16Ar
                     const char* bp = xs + b_off + (r * a.W + sx) * W16_LD;
                     bfr.h[0] = tr_read(bp); bfr.h[1] = tr_read(bp + 16 * W16_LD);
 #pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) acc[r * 3 + sx][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[tt].v, bfr.v, acc[r * 3 + sx][tt], 0, 0, 0);
+                    for (int tt = 0; tt < 4; ++tt) acc[(r * 3 + sx) % TAPS][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[tt].v, bfr.v, acc[(r * 3 + sx) % TAPS][tt], 0, 0, 0);
                 }
             }
         }
@@ -354,21 +362,21 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9_kernel(W16Ar
         f32x4* red = reinterpret_cast<f32x4*>(smem16);
         if (grp == 1) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k)
+            for (int k = 0; k < TAPS; ++k)
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) red[(k * 4 + tt) * 256 + t] = acc[k][tt];
         }
         __syncthreads();
         if (grp == 1) return;
 #pragma unroll
-        for (int k = 0; k < 9; ++k)
+        for (int k = 0; k < TAPS; ++k)
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) acc[k][tt] += red[(k * 4 + tt) * 256 + t];
     }
     // acc[tap][tt][reg]: co = co0 + 16 tt + 4 lg + reg, ci = ci0 + 16 wave + li
     float* dst = partial + (size_t)blockIdx.x * a.wtotal;
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
+    for (int k = 0; k < TAPS; ++k)
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
@@ -389,9 +397,11 @@ inline bool w16_plan(const dcv_conv2d_desc* d, W16Args* a, int* chunks, size_t* 
     if (enabled < 0) { const char* e = getenv("DCV_BF16_WGRAD9"); enabled = e ? atoi(e) : 1; }
     if (!enabled) return false;
     if (d->groups != 1 || d->x_layout != DCV_LAYOUT_NHWC) return false;
-    if (d->r != 3 || d->s != 3 || d->stride_h != 1 || d->stride_w != 1 || d->pad_h != 1 || d->pad_w != 1 || d->dil_h != 1 || d->dil_w != 1) return false;
+    const bool one = d->r == 1 && d->s == 1 && d->pad_h == 0 && d->pad_w == 0;         // 1x1: the one-tap instance (a plain GEMM over the pixels)
+    if (d->stride_h != 1 || d->stride_w != 1 || d->dil_h != 1 || d->dil_w != 1) return false;
+    if (!one && (d->r != 3 || d->s != 3 || d->pad_h != 1 || d->pad_w != 1)) return false;
     if (d->cin % 64 != 0 || d->cout % 64 != 0 || d->ho != d->h || d->wo != d->w) return false;
-    const int hw = d->h * d->w, XR = W16_PS + 2 * d->w + 2;
+    const int hw = d->h * d->w, XR = one ? W16_PS : W16_PS + 2 * d->w + 2;
     if (XR * 8 > 256 * W16_XP) return false;
     const int hwp = (hw + W16_PS - 1) / W16_PS * W16_PS;
     if (hwp > 2 * hw) return false;                                                    // more than half of the steps' pixels would be padding (4x4 images: exactly half, still 2x the 16-pixel-step kernel)
@@ -403,7 +413,7 @@ inline bool w16_plan(const dcv_conv2d_desc* d, W16Args* a, int* chunks, size_t* 
     *groups = gr;
     a->N = d->n; a->H = d->h; a->W = d->w; a->Cin = d->cin; a->Cout = d->cout; a->XR = XR; a->HWp = hwp;
     a->M = (long)d->n * hwp;
-    a->wtotal = (size_t)d->cout * d->cin * 9;
+    a->wtotal = (size_t)d->cout * d->cin * (one ? 1 : 9);
     const long blocks_per_chunk = (long)(d->cin / 64) * (d->cout / 64);
     const long resident = gr == 2 ? DCV_NUM_CU : 2 * DCV_NUM_CU;                       // blocks resident at once (two waves per SIMD either way): one round
     long ch = (resident + blocks_per_chunk - 1) / blocks_per_chunk;
@@ -558,16 +568,53 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
+struct Im2colArgs { int H, W, Cin, Ho, Wo, R, S, sh, sw, ph, pw, dh, dw, K, kpad, nchw; unsigned M; };
+
+// thread = (pixel, 64 consecutive k): the pixel is decoded once (three 32-bit divisions), (ci, r, s) of the first k once, then they advance by carries; eight
+// 16-byte stores per thread, a pixel's kpad / 64 threads write its row contiguously.  (A first version — one 8-wide piece per thread, the taps' offsets from a
+// 2 KB table in the kernel arguments, 64-bit index arithmetic — took 814 us for the 308 MB of the ResNet stem at bs 64: 15x the time of its stores.)
+__global__ __launch_bounds__(256) void im2col_bf16_kernel(Im2colArgs a, const float* __restrict__ x, u16* __restrict__ out) {
+    const unsigned chunks = (unsigned)a.kpad >> 6, items = a.M * chunks;
+    const int RS = a.R * a.S, HW = a.H * a.W;
+    for (unsigned it = blockIdx.x * 256u + threadIdx.x; it < items; it += gridDim.x * 256u) {
+        const unsigned m = it / chunks, kc = it - m * chunks;
+        const unsigned wo = m % (unsigned)a.Wo, r1 = m / (unsigned)a.Wo, ho = r1 % (unsigned)a.Ho, n = r1 / (unsigned)a.Ho;
+        const int hi0 = (int)ho * a.sh - a.ph, wi0 = (int)wo * a.sw - a.pw;
+        const float* xn = x + (size_t)n * a.Cin * HW;
+        int k = (int)kc * 64;
+        int ci = k / RS, rs = k - ci * RS, r = rs / a.S, sx = rs - r * a.S;
+        u16* dst = out + (size_t)m * a.kpad + k;
+#pragma unroll 1
+        for (int p8 = 0; p8 < 8; ++p8) {
+            union { bf16x8 h; uint4 u; } o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int hi = hi0 + r * a.dh, wi = wi0 + sx * a.dw;
+                const bool ok = k < a.K && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+                const int off = a.nchw ? ci * HW + hi * a.W + wi : (hi * a.W + wi) * a.Cin + ci;
+                const float g = xn[ok ? off : 0];                                    // unconditional (a valid address either way): no branch per element
+                o.h[j] = (__bf16)(ok ? g : 0.f);
+                ++k;
+                if (++sx == a.S) { sx = 0; if (++r == a.R) { r = 0; ++ci; } }
+            }
+            *reinterpret_cast<uint4*>(dst + 8 * p8) = o.u;
+        }
+    }
+}
+
 extern "C" {
 
 int dcv_conv2d_bf16_supported(const dcv_conv2d_desc* d, int op) {
-    if (op == 2) return (desc_ok(d) && dcv_mfma_conv2d_wgrad_in16_supported(d)) ? 1 : 0;
+    if (op == 2) {
+        W16Args a{}; int chunks, groups; size_t smem;
+        return (desc_ok(d) && (dcv_mfma_conv2d_wgrad_in16_supported(d) || w16_plan(d, &a, &chunks, &smem, &groups))) ? 1 : 0;
+    }
     return (op == 0 || op == 1) && supported(d, op) ? 1 : 0;
 }
 
 size_t dcv_conv2d_bf16_wgrad_workspace_bytes(const dcv_conv2d_desc* d) {
-    if (!desc_ok(d) || !dcv_mfma_conv2d_wgrad_in16_supported(d)) return 0;
-    size_t need = dcv_mfma_conv2d_ws(d, 2);
+    if (!dcv_conv2d_bf16_supported(d, 2)) return 0;
+    size_t need = dcv_mfma_conv2d_wgrad_in16_supported(d) ? dcv_mfma_conv2d_ws(d, 2) : 0;
     W16Args a{}; int chunks, groups; size_t smem;
     if (w16_plan(d, &a, &chunks, &smem, &groups)) { const size_t n16 = dcv_align_up((size_t)chunks * a.wtotal * sizeof(float), 256); if (n16 > need) need = n16; }
     return need;
@@ -575,7 +622,7 @@ size_t dcv_conv2d_bf16_wgrad_workspace_bytes(const dcv_conv2d_desc* d) {
 
 int dcv_conv2d_bf16_wgrad(const dcv_conv2d_desc* d, const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, void* stream) {
     DCV_CHECK_ARG(desc_ok(d) && x && dy && dw);
-    if (!dcv_mfma_conv2d_wgrad_in16_supported(d)) return DCV_ERR_UNSUPPORTED;
+    if (!dcv_conv2d_bf16_supported(d, 2)) return DCV_ERR_UNSUPPORTED;
     W16Args a{}; int chunks, groups; size_t smem;
     if (w16_plan(d, &a, &chunks, &smem, &groups)) {
         if (!ws || ws_bytes < (size_t)chunks * a.wtotal * sizeof(float)) return DCV_ERR_WORKSPACE;
@@ -585,14 +632,20 @@ int dcv_conv2d_bf16_wgrad(const dcv_conv2d_desc* d, const void* x, const void* d
         static bool configured = false;
         if (!configured) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_wgrad9_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_wgrad9_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DCV_ERR_LAUNCH;
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_wgrad9_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_wgrad9_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_wgrad9_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DCV_ERR_LAUNCH;
             configured = true;
         }
         float* partial = reinterpret_cast<float*>(ws);
         const u16* xs = reinterpret_cast<const u16*>(x); const u16* dys = reinterpret_cast<const u16*>(dy);
-        if (groups == 2) hipLaunchKernelGGL(conv_bf16_wgrad9_kernel<2>, grid, dim3(512), smem, dcv_stream(stream), a, xs, dys, partial);
-        else hipLaunchKernelGGL(conv_bf16_wgrad9_kernel<1>, grid, dim3(256), smem, dcv_stream(stream), a, xs, dys, partial);
+        const bool one = d->r == 1;
+        if (groups == 2) { if (one) hipLaunchKernelGGL((conv_bf16_wgrad9_kernel<2, 1>), grid, dim3(512), smem, dcv_stream(stream), a, xs, dys, partial);
+                           else hipLaunchKernelGGL((conv_bf16_wgrad9_kernel<2, 9>), grid, dim3(512), smem, dcv_stream(stream), a, xs, dys, partial); }
+        else { if (one) hipLaunchKernelGGL((conv_bf16_wgrad9_kernel<1, 1>), grid, dim3(256), smem, dcv_stream(stream), a, xs, dys, partial);
+               else hipLaunchKernelGGL((conv_bf16_wgrad9_kernel<1, 9>), grid, dim3(256), smem, dcv_stream(stream), a, xs, dys, partial); }
         if (hipGetLastError() != hipSuccess) return DCV_ERR_LAUNCH;
+        if (one) return dcv_mfma_wgrad_reduce_plain(partial, dw, chunks, a.wtotal, dcv_stream(stream));      // slabs [co][ci] = dw's own order
         return dcv_mfma_wgrad9_reduce(partial, dw, chunks, d->cout, d->cin, dcv_stream(stream));
     }
     return dcv_mfma_conv2d_wgrad_in16(d, x, dy, dw, ws, ws_bytes, dcv_stream(stream));
@@ -690,6 +743,23 @@ int dcv_conv2d_bf16_dgrad(const dcv_conv2d_desc* d, const void* dy, const void* 
             if (rc != DCV_OK) return rc;
         }
     return DCV_OK;
+}
+
+// im2col of a small-cin first layer: out[m][k] (bf16, row stride kpad) = x[n][ci][ho sh - ph + r dh][wo sw - pw + s dw] for k = (ci R + r) S + s (the OIHW
+// filter's own flattening), 0 outside the image and for k >= cin R S.  Thread = (pixel, 8 consecutive k): one 16-byte store; the taps' offsets come from a
+// table in the kernel arguments (no division per element).
+int dcv_im2col_bf16(const dcv_conv2d_desc* d, const float* x, void* out, int kpad, void* stream) {
+    DCV_CHECK_ARG(desc_ok(d) && x && out && aligned16(out));
+    const int K = d->cin * d->r * d->s;
+    if (d->groups != 1 || kpad < K || kpad > DCV_IM2COL_MAX_K || kpad % 64 != 0) return DCV_ERR_UNSUPPORTED;
+    const size_t M = (size_t)d->n * d->ho * d->wo;
+    if ((size_t)d->cin * d->h * d->w >= ((size_t)1 << 31) || M * (size_t)kpad >= ((size_t)1 << 31)) return DCV_ERR_UNSUPPORTED;      // 32-bit item and element indices
+    Im2colArgs a{};
+    a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Ho = d->ho; a.Wo = d->wo; a.R = d->r; a.S = d->s; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w;
+    a.dh = d->dil_h; a.dw = d->dil_w; a.K = K; a.kpad = kpad; a.M = (unsigned)M; a.nchw = d->x_layout == DCV_LAYOUT_NCHW ? 1 : 0;
+    const size_t items = M * (size_t)(kpad / 64);
+    hipLaunchKernelGGL(im2col_bf16_kernel, dim3(dcv_stream_grid(items, 256)), dim3(256), 0, dcv_stream(stream), a, x, reinterpret_cast<u16*>(out));
+    DCV_RETURN_LAUNCH();
 }
 
 int dcv_cast_f32_to_bf16(const float* x, void* y, size_t n, void* stream) {

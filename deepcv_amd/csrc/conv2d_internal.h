@@ -27,6 +27,7 @@ int dcv_mfma_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d, int* rows_per_sampl
 int dcv_mfma_conv2d_dgrad(const dcv_conv2d_desc* d, const float* dy, const float* w, float* dx, void* ws, size_t ws_bytes, hipStream_t st, bool prepared = false);
 int dcv_mfma_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
 // bf16 x / dy (bf16 storage path): the all-taps kernel only; workspace = dcv_mfma_conv2d_ws(d, 2)
+int dcv_mfma_wgrad_reduce_plain(const float* partial, float* dw, int chunks, size_t wtotal, hipStream_t st);
 bool dcv_mfma_conv2d_wgrad_in16_supported(const dcv_conv2d_desc* d);
 int dcv_mfma_conv2d_wgrad_in16(const dcv_conv2d_desc* d, const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
 // dw[co][ci][tap] = ordered sum over chunks of partial[chunk][tap][co][ci] (3x3 filters)

@@ -1012,6 +1012,12 @@ static int launch_wgrad9(const Wg9Args& a, dim3 grid, size_t smem, hipStream_t s
     return DCV_OK;
 }
 
+// dw[i] = sum over chunks of partial[chunk][i], chunks in order (slabs whose layout already is dw's: the one-tap weight gradient)
+int dcv_mfma_wgrad_reduce_plain(const float* partial, float* dw, int chunks, size_t wtotal, hipStream_t st) {
+    hipLaunchKernelGGL(mfma_wgrad_reduce_kernel, dim3((unsigned)dcv_ceil_div(wtotal, 32)), dim3(1024), 0, st, partial, dw, chunks, wtotal);
+    return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
+}
+
 int dcv_mfma_wgrad9_reduce(const float* partial, float* dw, int chunks, int cout, int cin, hipStream_t st) {
     if (chunks <= 16 && cin % 64 == 0 && cout <= 65535 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0) {
         if (cin % 128 == 0) hipLaunchKernelGGL(mfma_wgrad9_reduce_few_kernel<128>, dim3((unsigned)(cin / 128), (unsigned)cout), dim3(256), 0, st, partial, dw, chunks, cout, cin);

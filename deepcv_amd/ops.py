@@ -5,6 +5,7 @@ arithmetic op of the hot path — K1..K11 of SURVEY.md §2.3 — runs in a hand-
 with logical NCHW shape (what the reference's modules expose, `src/deepcv/meta/base_module.py:80`) and `torch.channels_last`
 strides, i.e. NHWC in memory, which is the layout the kernels are written for.  There is no CPU / eager fallback. """
 import ctypes
+import os
 import weakref
 from typing import List, Optional, Sequence, Tuple
 
@@ -159,6 +160,43 @@ def _f32(x):
         nat.require_device(x)
         return _WidenFn.apply(x)
     return x
+
+
+_stem_gemm = os.environ.get('DCV_STEM_GEMM', '1') not in ('0', 'false', 'False', '')
+
+
+def _stem_as_gemm(x, weight, stride, padding, dilation):
+    """ A first layer (cin <= 4: the 3x3 layer of a CIFAR spec, the 7x7 / 2 stem of a ResNet) in bf16 storage mode: its K = cin * R * S is far too small for the
+    implicit-GEMM kernels (they step over 64 input channels of one tap) and the direct / sliding-window kernels which served it ran on the VALU (resnet18_style,
+    bs 64: 0.40 ms forward + 0.83 ms weight gradient of a 6.4 ms step).  Rewritten as im2col + 1x1: `dcv_im2col_bf16` expands the input once into a bf16 matrix
+    [n ho wo][kpad], the OIHW filter flattened per output channel and zero-padded to kpad is the 1x1 layer's filter (plain torch ops on the parameter: autograd
+    carries dW back), and the bf16 kernels do the rest — forward as any 1x1 layer, weight gradient on the one-tap instance of the all-taps kernel.  Only for
+    inputs which need no gradient (the model input).  Returns (x_col, w_col) or None. """
+    if not (_stem_gemm and _conv_math == nat.MATH_BF16 and _bf16_storage) or x.dtype != torch.float32 or x.dim() != 4 or x.requires_grad or not x.is_cuda:
+        return None
+    cout, cin, r, s = weight.shape
+    k = cin * r * s
+    if cin > 4 or r * s == 1 or k > nat.IM2COL_MAX_K or cout % 64 != 0 or x.shape[1] != cin:
+        return None
+    kpad = (k + 63) // 64 * 64
+    if _is_nhwc(x):
+        layout = nat.LAYOUT_NHWC
+    elif x.is_contiguous():
+        layout = nat.LAYOUT_NCHW
+    else:
+        return None
+    d = _conv_desc(x.shape, weight.shape, _pair(stride), _pair(padding), _pair(dilation), layout, nat.ACT_NONE, 0.)
+    if d.n * d.ho * d.wo * kpad * 2 >= (1 << 31):          # (the bf16 kernels index their tensors with 32-bit byte offsets)
+        return None
+    d1 = _conv_desc((d.n, kpad, d.ho, d.wo), (cout, kpad, 1, 1), (1, 1), (0, 0), (1, 1), nat.LAYOUT_NHWC, nat.ACT_NONE, 0.)
+    if not (lib.dcv_conv2d_bf16_supported(d1, 0) and lib.dcv_conv2d_bf16_supported(d1, 2)):
+        return None
+    nat.require_device(x)
+    with torch.no_grad():
+        x_col = torch.empty((d.n, kpad, d.ho, d.wo), dtype=torch.bfloat16, device=x.device, memory_format=_CL)
+        nat.check(lib.dcv_im2col_bf16(d, x.data_ptr(), x_col.data_ptr(), kpad, nat.current_stream(x.device)), 'dcv_im2col_bf16')
+    w_col = torch.nn.functional.pad(weight.reshape(cout, k), (0, kpad - k)).reshape(cout, kpad, 1, 1)
+    return x_col, w_col
 
 
 def _use_bf16_storage(d, layout) -> bool:
@@ -418,6 +456,9 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
            slope: float = 0.) -> torch.Tensor:
     """ y = act(conv2d(x, weight) + bias) — HIP kernels `dcv_conv2d_fwd/dgrad/wgrad` (+ `dcv_act_bwd` for the fused epilogue). """
     resident.forbid('conv2d')
+    gemm = _stem_as_gemm(x, weight, stride, padding, dilation)
+    if gemm is not None:
+        (x, weight), stride, padding, dilation = gemm, 1, 0, 1
     return _Conv2dFn.apply(x, weight, bias, _pair(stride), _pair(padding), _pair(dilation), int(act), float(slope))
 
 
@@ -859,6 +900,9 @@ def conv_norm_layer(x, weight, bias, stride, padding, dilation, act: int, slope:
     never written. """
     if pool and (not gn_groups or pool < 0):
         raise ValueError('deepcv_amd.conv_norm_layer: fused average pooling needs the GroupNorm stage')
+    gemm = _stem_as_gemm(x, weight, stride, padding, dilation) if resident.recorder() is None else None
+    if gemm is not None:
+        (x, weight), stride, padding, dilation = gemm, 1, 0, 1
     cfg = (_pair(stride), _pair(padding), _pair(dilation), int(act), float(slope), float(momentum), float(bn_eps), int(gn_groups), float(gn_eps), int(pool))
     return _ConvNormLayerFn.apply(x, weight, bias, bn_w, bn_b, running_mean, running_var, num_batches_tracked, gn_w, gn_b, cfg)
 

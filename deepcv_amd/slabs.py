@@ -92,7 +92,7 @@ def may_defer(*params) -> bool:
                     del _uses[id(p)]
     if not _enabled or torch.is_grad_enabled():      # grad mode on inside backward = create_graph: the engine copies the gradients it is handed
         return False
-    return single and all(p is None or p.grad is None for p in params)
+    return single and all(p is None or (p.is_leaf and p.grad is None) for p in params)      # (a non-leaf's gradient travels on through the graph at once)
 
 
 def would_defer(*params) -> bool:
@@ -104,7 +104,7 @@ def would_defer(*params) -> bool:
             u = _uses.get(id(p)) if p is not None else None
             if u is not None and u[2]() is p and u[1] > 1:
                 return False
-    return all(p is None or p.grad is None for p in params)
+    return all(p is None or (p.is_leaf and p.grad is None) for p in params)
 
 
 _preflush: List = []

@@ -172,6 +172,14 @@ size_t dcv_conv2d_bf16_wgrad_workspace_bytes(const dcv_conv2d_desc* d);
 int dcv_conv2d_bf16_wgrad(const dcv_conv2d_desc* d, const void* x_bf16, const void* dy_bf16, float* dw, void* ws, size_t ws_bytes, void* stream);
 /* element type conversion (round to nearest even, NaN stays NaN); n elements, x 16-B (fp32) / 8-B (bf16) aligned */
 int dcv_cast_f32_to_bf16(const float* x, void* y_bf16, size_t n, void* stream);
+/* A first layer (cin <= 4, any kernel / stride / padding / dilation: the 3x3 layer of a CIFAR spec, the 7x7 / 2 stem of a ResNet) on the matrix cores: its
+ * input is expanded ONCE into the bf16 matrix out[n ho wo][kpad] with out[m][(ci R + r) S + s] = x[n][ci][ho sh - ph + r dh][wo sw - pw + s dw] (zero outside the
+ * image and in the padding columns k >= cin R S; kpad: a multiple of 64, at most DCV_IM2COL_MAX_K), after which the layer is a 1x1 convolution of kpad
+ * channels whose filter is the OIHW filter flattened per output channel and zero-padded to kpad: dcv_conv2d_bf16_fwd / _wgrad serve it (the one-tap weight
+ * gradient), no data gradient is needed.  x: fp32 in d->x_layout (the dataloader's NCHW batch is read in place).  replaces the first Conv2d of a wide spec
+ * in bf16 math mode (submodule_creators.py:251). */
+#define DCV_IM2COL_MAX_K 256
+int dcv_im2col_bf16(const dcv_conv2d_desc* d, const float* x, void* out_bf16, int kpad, void* stream);
 int dcv_cast_bf16_to_f32(const void* x_bf16, float* y, size_t n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------

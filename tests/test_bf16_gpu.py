@@ -250,3 +250,43 @@ def test_bf16_kernels_at_the_bench_shapes(device, case):
     ref_dw = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, k, k), dy.double(), stride, pad, dil)
     err = _rel(dw, ref_dw)
     assert err <= 2e-5, f'weight gradient error {err:.3e}'
+
+
+@pytest.mark.parametrize('case', [(6, 3, 32, 32, 64, 3, 1, 1, 1), (3, 3, 56, 56, 64, 7, 2, 3, 1), (2, 4, 20, 18, 128, 5, 1, 2, 2)], ids=['cifar_first', 'resnet_stem', 'dilated'])
+@pytest.mark.parametrize('nchw', [True, False], ids=['nchw', 'nhwc'])
+def test_first_layer_as_im2col_plus_one_tap_kernels(device, case, nchw):
+    """ `dcv_im2col_bf16` + the 1x1 instances of the bf16 kernels (forward, one-tap weight gradient) = the small-cin first layer: the im2col matrix bit for bit
+    against torch's unfold of the bf16-rounded input, forward and weight gradient against fp64 torch convolutions of the same rounded operands. """
+    from deepcv_amd import _native as nat
+    lib = nat.lib
+    n, cin, h, w, cout, k, stride, pad, dil = case
+    torch.manual_seed(sum(case))
+    st = nat.current_stream(device)
+    d = nat.Conv2dDesc(n, h, w, cin, cout, k, k, stride, stride, pad, pad, dil, dil, 1, (h + 2 * pad - dil * (k - 1) - 1) // stride + 1,
+                       (w + 2 * pad - dil * (k - 1) - 1) // stride + 1, nat.LAYOUT_NCHW if nchw else nat.LAYOUT_NHWC, 0, 0., nat.MATH_BF16)
+    K, kpad = cin * k * k, (cin * k * k + 63) // 64 * 64
+    x = torch.randn(n, cin, h, w)
+    xd = x.to(device) if nchw else x.to(device).contiguous(memory_format=torch.channels_last)
+    col = torch.full((n * d.ho * d.wo, kpad), float('nan'), dtype=torch.bfloat16, device=device)
+    nat.check(lib.dcv_im2col_bf16(d, xd.data_ptr(), col.data_ptr(), kpad, st), 'im2col')
+    torch.cuda.synchronize()
+    ref_col = F.unfold(_bf(x).float(), k, dil, pad, stride).transpose(1, 2).reshape(n * d.ho * d.wo, K)     # [m][(ci, r, s)]
+    assert torch.equal(col[:, :K].float().cpu(), ref_col) and (col[:, K:] == 0).all()
+    # the layer as a 1x1 convolution of kpad channels
+    d1 = _desc(nat, n, kpad, d.ho, d.wo, cout, 1, 1, 0, 1, 0)
+    assert lib.dcv_conv2d_bf16_supported(d1, 0) and lib.dcv_conv2d_bf16_supported(d1, 2)
+    wt = torch.randn(cout, cin, k, k) / K ** 0.5
+    w_col = F.pad(wt.reshape(cout, K), (0, kpad - K)).reshape(cout, kpad, 1, 1).to(device)
+    f = _prepared(nat, lib, d1, 0, w_col, st)
+    y = torch.empty((n, cout, d.ho, d.wo), dtype=torch.float32, device=device).contiguous(memory_format=torch.channels_last)
+    nat.check(lib.dcv_conv2d_bf16_fwd(d1, col.data_ptr(), f.data_ptr(), None, y.data_ptr(), nat.DTYPE_F32, None, st), 'fwd')
+    ref = F.conv2d(_bf(x).double(), _bf(wt).double(), None, stride, pad, dil)
+    torch.cuda.synchronize()
+    assert _rel(y, ref) <= 2e-5
+    dy = _bf(torch.randn(n, cout, d.ho, d.wo)).contiguous(memory_format=torch.channels_last)
+    ws = torch.empty(int(lib.dcv_conv2d_bf16_wgrad_workspace_bytes(d1)), dtype=torch.uint8, device=device)
+    dw = torch.full((cout, kpad), float('nan'), device=device)
+    nat.check(lib.dcv_conv2d_bf16_wgrad(d1, col.data_ptr(), dy.to(device).data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), st), 'wgrad')
+    torch.cuda.synchronize()
+    ref_dw = torch.nn.grad.conv2d_weight(_bf(x).double(), (cout, cin, k, k), dy.double(), stride, pad, dil)
+    assert _rel(dw[:, :K].reshape(cout, cin, k, k), ref_dw) <= 2e-5 and (dw[:, K:] == 0).all()
