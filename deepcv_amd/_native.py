@@ -202,6 +202,8 @@ _SIGNATURES = {
                                         _c_int, _c_int, _P, _c_size_t, _P]),
     'dcv_pool2d_fwd': (_c_int, [ctypes.POINTER(Pool2dDesc), _P, _P, _P, _P]),
     'dcv_pool2d_bwd': (_c_int, [ctypes.POINTER(Pool2dDesc), _P, _P, _P, _P]),
+    'dcv_pool2d_fwd_bf16': (_c_int, [ctypes.POINTER(Pool2dDesc), _P, _P, _P, _P]),
+    'dcv_pool2d_bwd_bf16': (_c_int, [ctypes.POINTER(Pool2dDesc), _P, _P, _P, _P]),
     'dcv_interp_bilinear_fwd': (_c_int, [_P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _P]),
     'dcv_interp_bilinear_bwd': (_c_int, [_P, _P, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _P]),
     'dcv_copy_channels': (_c_int, [_P, _c_int, _c_int, _P, _c_int, _c_int, _c_int, _c_size_t, _P]),
@@ -217,6 +219,7 @@ _SIGNATURES = {
     'dcv_indirect_copy': (_c_int, [_P, _P]),
     'dcv_publish_scalars': (_c_int, [_P, ctypes.POINTER(_P), _c_int, _P, _P, _P]),
     'dcv_add': (_c_int, [_P, _P, _P, _c_size_t, _P]),
+    'dcv_add_bf16': (_c_int, [_P, _P, _P, _c_size_t, _P]),
     'dcv_scale': (_c_int, [_P, _c_float, _P, _c_size_t, _P]),
     'dcv_transpose_inner': (_c_int, [_P, _P, _c_int, _c_int, _c_int, _P]),
     'dcv_linear_bwd_workspace_bytes': (_c_size_t, [_c_int, _c_int, _c_int]),

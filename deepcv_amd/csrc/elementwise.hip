@@ -179,6 +179,25 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, c
     }
 }
 
+// bf16 tensors (the wide specs' residual links on the bf16 storage path): eight values per thread, fp32 sums rounded once
+__global__ __launch_bounds__(256) void add_bf16_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b, uint4* __restrict__ out, size_t n8, const unsigned short* ta,
+                                                       const unsigned short* tb, unsigned short* tout, int tail) {
+    auto add2 = [](unsigned u, unsigned v) {
+        const float lo = __uint_as_float(u << 16) + __uint_as_float(v << 16), hi = __uint_as_float(u & 0xffff0000u) + __uint_as_float(v & 0xffff0000u);
+        const __bf16 l = (__bf16)lo, h = (__bf16)hi;
+        return (unsigned)__builtin_bit_cast(unsigned short, l) | ((unsigned)__builtin_bit_cast(unsigned short, h) << 16);
+    };
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 u = a[i], v = b[i];
+        out[i] = make_uint4(add2(u.x, v.x), add2(u.y, v.y), add2(u.z, v.z), add2(u.w, v.w));
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail) {
+        const float s = __uint_as_float((unsigned)ta[threadIdx.x] << 16) + __uint_as_float((unsigned)tb[threadIdx.x] << 16);
+        const __bf16 h = (__bf16)s;
+        tout[threadIdx.x] = __builtin_bit_cast(unsigned short, h);
+    }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ a, float alpha, float* __restrict__ out, size_t nv) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
@@ -637,6 +656,15 @@ int dcv_add(const float* a, const float* b, float* out, size_t numel, void* stre
     hipStream_t st = dcv_stream(stream);
     if (numel % 4 == 0 && aligned16(a) && aligned16(b) && aligned16(out)) hipLaunchKernelGGL((add_kernel<4>), dim3(dcv_stream_grid(numel / 4, 256)), dim3(256), 0, st, a, b, out, numel / 4);
     else hipLaunchKernelGGL((add_kernel<1>), dim3(dcv_stream_grid(numel, 256)), dim3(256), 0, st, a, b, out, numel);
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_add_bf16(const void* a, const void* b, void* out, size_t numel, void* stream) {
+    DCV_CHECK_ARG(a && b && out && numel > 0 && aligned16(a) && aligned16(b) && aligned16(out));
+    const size_t n8 = numel / 8; const int tail = (int)(numel - 8 * n8);
+    const unsigned short* ta = reinterpret_cast<const unsigned short*>(a) + 8 * n8; const unsigned short* tb = reinterpret_cast<const unsigned short*>(b) + 8 * n8;
+    hipLaunchKernelGGL(add_bf16_kernel, dim3(dcv_stream_grid(n8 ? n8 : 1, 256)), dim3(256), 0, dcv_stream(stream), reinterpret_cast<const uint4*>(a), reinterpret_cast<const uint4*>(b),
+                       reinterpret_cast<uint4*>(out), n8, ta, tb, reinterpret_cast<unsigned short*>(out) + 8 * n8, tail);
     DCV_RETURN_LAUNCH();
 }
 

@@ -10,15 +10,28 @@
 
 namespace {
 
-template <int VEC, int MODE>
-__global__ __launch_bounds__(256) void pool_fwd_kernel(dcv_pool2d_desc d, const float* __restrict__ x, float* __restrict__ y, int32_t* __restrict__ argmax) {
+// element types: float, or bf16 (the bf16 STORAGE path of the wide specs: activations and their gradients are bf16 tensors; arithmetic stays fp32, so the result
+// is exactly the fp32 kernel's rounded once — what the widen / pool / narrow sequence it replaces produced, without the two cast launches and half the bytes)
+typedef unsigned short pl_u16;
+__device__ __forceinline__ float pl_ld(const float* p) { return *p; }
+__device__ __forceinline__ float pl_ld(const pl_u16* p) { return __uint_as_float((unsigned)*p << 16); }
+__device__ __forceinline__ void pl_ld4(const float* p, float (&v)[4]) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+__device__ __forceinline__ void pl_ld4(const pl_u16* p, float (&v)[4]) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u); v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+__device__ __forceinline__ void pl_st(float* p, float v) { *p = v; }
+__device__ __forceinline__ void pl_st(pl_u16* p, float v) { const __bf16 h = (__bf16)v; *p = __builtin_bit_cast(pl_u16, h); }
+
+template <int VEC, int MODE, typename T>
+__global__ __launch_bounds__(256) void pool_fwd_kernel(dcv_pool2d_desc d, const T* __restrict__ x, T* __restrict__ y, int32_t* __restrict__ argmax) {
     const int CV = d.c / VEC;
     const size_t total = (size_t)d.n * d.ho * d.wo * CV;
     const float inv = 1.f / (float)(d.kh * d.kw);                        // count_include_pad=True
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % CV) * VEC; size_t p = i / CV;
         const int wo = (int)(p % d.wo); p /= d.wo; const int ho = (int)(p % d.ho); const int n = (int)(p / d.ho);
-        const float* xs = x + (size_t)n * d.h * d.w * d.c;
+        const T* xs = x + (size_t)n * d.h * d.w * d.c;
         float acc[VEC]; int32_t arg[VEC];
         const int h0 = ho * d.stride_h - d.pad_h, w0 = wo * d.stride_w - d.pad_w;
         const int32_t first = (h0 < 0 ? 0 : h0) * d.w + (w0 < 0 ? 0 : w0);   // torch initialises maxindex to the window's first in-range element
@@ -31,8 +44,8 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(dcv_pool2d_desc d, const 
                 const int w = w0 + s;
                 if (w < 0 || w >= d.w) continue;
                 float v[VEC];
-                if constexpr (VEC == 4) { const float4 t = *reinterpret_cast<const float4*>(xs + ((size_t)h * d.w + w) * d.c + c); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-                else v[0] = xs[((size_t)h * d.w + w) * d.c + c];
+                if constexpr (VEC == 4) pl_ld4(xs + ((size_t)h * d.w + w) * d.c + c, v);
+                else v[0] = pl_ld(xs + ((size_t)h * d.w + w) * d.c + c);
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
                     if (MODE == DCV_POOL_MAX) {
@@ -45,7 +58,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(dcv_pool2d_desc d, const 
         const size_t o = (((size_t)n * d.ho + ho) * d.wo + wo) * d.c + c;
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-            y[o + k] = (MODE == DCV_POOL_MAX) ? acc[k] : acc[k] * inv;
+            pl_st(y + o + k, (MODE == DCV_POOL_MAX) ? acc[k] : acc[k] * inv);
             if (MODE == DCV_POOL_MAX) argmax[o + k] = arg[k];
         }
     }
@@ -59,8 +72,8 @@ __device__ __forceinline__ void window_range(int i, int pad, int k, int stride, 
     lo = u <= 0 ? 0 : (u + stride - 1) / stride;
 }
 
-template <int VEC, int MODE>
-__global__ __launch_bounds__(256) void pool_bwd_kernel(dcv_pool2d_desc d, const float* __restrict__ dy, const int32_t* __restrict__ argmax, float* __restrict__ dx) {
+template <int VEC, int MODE, typename T>
+__global__ __launch_bounds__(256) void pool_bwd_kernel(dcv_pool2d_desc d, const T* __restrict__ dy, const int32_t* __restrict__ argmax, T* __restrict__ dx) {
     const int CV = d.c / VEC;
     const size_t total = (size_t)d.n * d.h * d.w * CV;
     const float inv = 1.f / (float)(d.kh * d.kw);
@@ -79,13 +92,13 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(dcv_pool2d_desc d, const 
                 const size_t o = (((size_t)n * d.ho + ho) * d.wo + wo) * d.c + c;
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
-                    if (MODE == DCV_POOL_MAX) { if (argmax[o + k] == me) acc[k] += dy[o + k]; }
-                    else acc[k] += dy[o + k] * inv;
+                    if (MODE == DCV_POOL_MAX) { if (argmax[o + k] == me) acc[k] += pl_ld(dy + o + k); }
+                    else acc[k] += pl_ld(dy + o + k) * inv;
                 }
             }
         const size_t xi = (((size_t)n * d.h + h) * d.w + w) * d.c + c;
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) dx[xi + k] = acc[k];
+        for (int k = 0; k < VEC; ++k) pl_st(dx + xi + k, acc[k]);
     }
 }
 
@@ -96,38 +109,56 @@ inline bool pool_desc_ok(const dcv_pool2d_desc* d) {
     return ho == d->ho && wo == d->wo && ho > 0 && wo > 0 && (d->mode == DCV_POOL_AVG || d->mode == DCV_POOL_MAX);
 }
 
+template <typename T>
+int pool_fwd_launch(const dcv_pool2d_desc* d, const T* x, T* y, int32_t* argmax, hipStream_t st) {
+    const int vec = d->c % 4 == 0 ? 4 : 1;
+    const unsigned grid = dcv_stream_grid((size_t)d->n * d->ho * d->wo * (d->c / vec), 256);
+    if (d->mode == DCV_POOL_AVG) {
+        if (vec == 4) hipLaunchKernelGGL((pool_fwd_kernel<4, DCV_POOL_AVG, T>), dim3(grid), dim3(256), 0, st, *d, x, y, argmax);
+        else hipLaunchKernelGGL((pool_fwd_kernel<1, DCV_POOL_AVG, T>), dim3(grid), dim3(256), 0, st, *d, x, y, argmax);
+    } else {
+        if (vec == 4) hipLaunchKernelGGL((pool_fwd_kernel<4, DCV_POOL_MAX, T>), dim3(grid), dim3(256), 0, st, *d, x, y, argmax);
+        else hipLaunchKernelGGL((pool_fwd_kernel<1, DCV_POOL_MAX, T>), dim3(grid), dim3(256), 0, st, *d, x, y, argmax);
+    }
+    DCV_RETURN_LAUNCH();
+}
+
+template <typename T>
+int pool_bwd_launch(const dcv_pool2d_desc* d, const T* dy, const int32_t* argmax, T* dx, hipStream_t st) {
+    const int vec = d->c % 4 == 0 ? 4 : 1;
+    const unsigned grid = dcv_stream_grid((size_t)d->n * d->h * d->w * (d->c / vec), 256);
+    if (d->mode == DCV_POOL_AVG) {
+        if (vec == 4) hipLaunchKernelGGL((pool_bwd_kernel<4, DCV_POOL_AVG, T>), dim3(grid), dim3(256), 0, st, *d, dy, argmax, dx);
+        else hipLaunchKernelGGL((pool_bwd_kernel<1, DCV_POOL_AVG, T>), dim3(grid), dim3(256), 0, st, *d, dy, argmax, dx);
+    } else {
+        if (vec == 4) hipLaunchKernelGGL((pool_bwd_kernel<4, DCV_POOL_MAX, T>), dim3(grid), dim3(256), 0, st, *d, dy, argmax, dx);
+        else hipLaunchKernelGGL((pool_bwd_kernel<1, DCV_POOL_MAX, T>), dim3(grid), dim3(256), 0, st, *d, dy, argmax, dx);
+    }
+    DCV_RETURN_LAUNCH();
+}
+
 }  // namespace
 
 extern "C" {
 
 int dcv_pool2d_fwd(const dcv_pool2d_desc* d, const float* x, float* y, int32_t* argmax, void* stream) {
     DCV_CHECK_ARG(pool_desc_ok(d) && x && y && (d->mode == DCV_POOL_AVG || argmax));
-    hipStream_t st = dcv_stream(stream);
-    const int vec = d->c % 4 == 0 ? 4 : 1;
-    const unsigned grid = dcv_stream_grid((size_t)d->n * d->ho * d->wo * (d->c / vec), 256);
-    if (d->mode == DCV_POOL_AVG) {
-        if (vec == 4) hipLaunchKernelGGL((pool_fwd_kernel<4, DCV_POOL_AVG>), dim3(grid), dim3(256), 0, st, *d, x, y, argmax);
-        else hipLaunchKernelGGL((pool_fwd_kernel<1, DCV_POOL_AVG>), dim3(grid), dim3(256), 0, st, *d, x, y, argmax);
-    } else {
-        if (vec == 4) hipLaunchKernelGGL((pool_fwd_kernel<4, DCV_POOL_MAX>), dim3(grid), dim3(256), 0, st, *d, x, y, argmax);
-        else hipLaunchKernelGGL((pool_fwd_kernel<1, DCV_POOL_MAX>), dim3(grid), dim3(256), 0, st, *d, x, y, argmax);
-    }
-    DCV_RETURN_LAUNCH();
+    return pool_fwd_launch<float>(d, x, y, argmax, dcv_stream(stream));
 }
 
 int dcv_pool2d_bwd(const dcv_pool2d_desc* d, const float* dy, const int32_t* argmax, float* dx, void* stream) {
     DCV_CHECK_ARG(pool_desc_ok(d) && dy && dx && (d->mode == DCV_POOL_AVG || argmax));
-    hipStream_t st = dcv_stream(stream);
-    const int vec = d->c % 4 == 0 ? 4 : 1;
-    const unsigned grid = dcv_stream_grid((size_t)d->n * d->h * d->w * (d->c / vec), 256);
-    if (d->mode == DCV_POOL_AVG) {
-        if (vec == 4) hipLaunchKernelGGL((pool_bwd_kernel<4, DCV_POOL_AVG>), dim3(grid), dim3(256), 0, st, *d, dy, argmax, dx);
-        else hipLaunchKernelGGL((pool_bwd_kernel<1, DCV_POOL_AVG>), dim3(grid), dim3(256), 0, st, *d, dy, argmax, dx);
-    } else {
-        if (vec == 4) hipLaunchKernelGGL((pool_bwd_kernel<4, DCV_POOL_MAX>), dim3(grid), dim3(256), 0, st, *d, dy, argmax, dx);
-        else hipLaunchKernelGGL((pool_bwd_kernel<1, DCV_POOL_MAX>), dim3(grid), dim3(256), 0, st, *d, dy, argmax, dx);
-    }
-    DCV_RETURN_LAUNCH();
+    return pool_bwd_launch<float>(d, dy, argmax, dx, dcv_stream(stream));
+}
+
+int dcv_pool2d_fwd_bf16(const dcv_pool2d_desc* d, const void* x, void* y, int32_t* argmax, void* stream) {
+    DCV_CHECK_ARG(pool_desc_ok(d) && x && y && (d->mode == DCV_POOL_AVG || argmax) && (reinterpret_cast<uintptr_t>(x) & 7) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0);
+    return pool_fwd_launch<pl_u16>(d, reinterpret_cast<const pl_u16*>(x), reinterpret_cast<pl_u16*>(y), argmax, dcv_stream(stream));
+}
+
+int dcv_pool2d_bwd_bf16(const dcv_pool2d_desc* d, const void* dy, const int32_t* argmax, void* dx, void* stream) {
+    DCV_CHECK_ARG(pool_desc_ok(d) && dy && dx && (d->mode == DCV_POOL_AVG || argmax) && (reinterpret_cast<uintptr_t>(dy) & 7) == 0 && (reinterpret_cast<uintptr_t>(dx) & 7) == 0);
+    return pool_bwd_launch<pl_u16>(d, reinterpret_cast<const pl_u16*>(dy), argmax, reinterpret_cast<pl_u16*>(dx), dcv_stream(stream));
 }
 
 }  // extern "C"

@@ -912,7 +912,8 @@ def conv_norm_layer(x, weight, bias, stride, padding, dilation, act: int, slope:
 class _Pool2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, kernel, stride, padding, mode):
-        _require_f32(x)
+        if x.dtype != torch.bfloat16:
+            _require_f32(x)
         x = to_nhwc(x)
         n, c, h, w = x.shape
         ho = (h + 2 * padding[0] - kernel[0]) // stride[0] + 1
@@ -922,8 +923,9 @@ class _Pool2dFn(torch.autograd.Function):
         d = nat.Pool2dDesc(n, h, w, c, kernel[0], kernel[1], stride[0], stride[1], padding[0], padding[1], ho, wo, mode)
         y = torch.empty((n, c, ho, wo), dtype=x.dtype, device=x.device, memory_format=_CL)
         argmax = torch.empty((n, c, ho, wo), dtype=torch.int32, device=x.device, memory_format=_CL) if mode == nat.POOL_MAX else None
-        nat.check(lib.dcv_pool2d_fwd(d, x.data_ptr(), y.data_ptr(), nat.ptr(argmax), nat.current_stream(x.device)), 'dcv_pool2d_fwd')
-        ctx.desc = d
+        fwd = lib.dcv_pool2d_fwd_bf16 if x.dtype == torch.bfloat16 else lib.dcv_pool2d_fwd
+        nat.check(fwd(d, x.data_ptr(), y.data_ptr(), nat.ptr(argmax), nat.current_stream(x.device)), 'dcv_pool2d_fwd')
+        ctx.desc, ctx.dtype = d, x.dtype
         ctx.save_for_backward(argmax)
         return y
 
@@ -932,14 +934,18 @@ class _Pool2dFn(torch.autograd.Function):
         (argmax,) = ctx.saved_tensors
         d = ctx.desc
         dy = to_nhwc(dy)
+        st = nat.current_stream(dy.device)
+        dy = _to_bf16(dy, st) if ctx.dtype == torch.bfloat16 else _to_f32(dy, st)       # (autograd hands over the output's element type: no-ops)
         dx = torch.empty((d.n, d.c, d.h, d.w), dtype=dy.dtype, device=dy.device, memory_format=_CL)
-        nat.check(lib.dcv_pool2d_bwd(d, dy.data_ptr(), nat.ptr(argmax), dx.data_ptr(), nat.current_stream(dy.device)), 'dcv_pool2d_bwd')
+        bwd = lib.dcv_pool2d_bwd_bf16 if ctx.dtype == torch.bfloat16 else lib.dcv_pool2d_bwd
+        nat.check(bwd(d, dy.data_ptr(), nat.ptr(argmax), dx.data_ptr(), st), 'dcv_pool2d_bwd')
         return dx, None, None, None, None
 
 
 def pool2d(x: torch.Tensor, kernel_size, stride=None, padding=0, mode: int = nat.POOL_AVG) -> torch.Tensor:
     resident.forbid('a standalone pooling')
-    x = _f32(x)
+    if not (isinstance(x, torch.Tensor) and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] % 4 == 0):      # bf16 activations are pooled as they are
+        x = _f32(x)
     k = _pair(kernel_size)
     s = _pair(stride) if stride is not None else k
     return _Pool2dFn.apply(x, k, s, _pair(padding), int(mode))
@@ -1091,7 +1097,8 @@ def concat_channels(tensors: Sequence[torch.Tensor]) -> torch.Tensor:
 class _AddFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, scale, *tensors):
-        _require_f32(*tensors)
+        if not all(t.dtype == torch.bfloat16 for t in tensors):
+            _require_f32(*tensors)
         ref = tensors[0]
         nhwc = ref.dim() == 4
         tensors = [to_nhwc(t) if nhwc else t.contiguous() for t in tensors]
@@ -1100,9 +1107,10 @@ class _AddFn(torch.autograd.Function):
                 raise RuntimeError(f'deepcv_amd.add_tensors: mismatching shapes {[tuple(t.shape) for t in tensors]}')
         st = nat.current_stream(ref.device)
         out = torch.empty_like(tensors[0])
-        nat.check(lib.dcv_add(tensors[0].data_ptr(), tensors[1].data_ptr(), out.data_ptr(), out.numel(), st), 'dcv_add')
+        add = lib.dcv_add_bf16 if ref.dtype == torch.bfloat16 else lib.dcv_add
+        nat.check(add(tensors[0].data_ptr(), tensors[1].data_ptr(), out.data_ptr(), out.numel(), st), 'dcv_add')
         for t in tensors[2:]:
-            nat.check(lib.dcv_add(out.data_ptr(), t.data_ptr(), out.data_ptr(), out.numel(), st), 'dcv_add')
+            nat.check(add(out.data_ptr(), t.data_ptr(), out.data_ptr(), out.numel(), st), 'dcv_add')
         if scale != 1.:
             nat.check(lib.dcv_scale(out.data_ptr(), scale, out.data_ptr(), out.numel(), st), 'dcv_scale')
         ctx.scale = scale
@@ -1121,8 +1129,11 @@ class _AddFn(torch.autograd.Function):
 def add_tensors(tensors: Sequence[torch.Tensor], mean: bool = False) -> torch.Tensor:
     """ Elementwise sum (or mean) of same-shape tensors: the 'sum' / 'mean' link reductions (SURVEY Appendix A #14). """
     resident.forbid('add_tensors')
-    tensors = [_f32(t) for t in tensors]
     tensors = list(tensors)
+    # a plain sum of bf16 tensors of one memory layout stays bf16 (the residual links of a wide spec on the bf16 storage path)
+    if not (not mean and len(tensors) >= 2 and all(isinstance(t, torch.Tensor) and t.dtype == torch.bfloat16 and t.shape == tensors[0].shape and (_is_nhwc(t) if t.dim() == 4 else t.is_contiguous())
+                                                   for t in tensors)):
+        tensors = [_f32(t) for t in tensors]
     if len(tensors) == 1:
         return tensors[0]
     return _AddFn.apply(1. / len(tensors) if mean else 1., *tensors)

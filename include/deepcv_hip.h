@@ -337,6 +337,10 @@ typedef struct {
 /* argmax: int32 [N,Ho,Wo,C] flat input offset (h*W + w) of the selected element; required for DCV_POOL_MAX, else NULL */
 int dcv_pool2d_fwd(const dcv_pool2d_desc* d, const float* x, float* y, int32_t* argmax, void* stream);
 int dcv_pool2d_bwd(const dcv_pool2d_desc* d, const float* dy, const int32_t* argmax, float* dx, void* stream);
+/* the same on bf16 NHWC tensors (the bf16 storage path of the wide specs): fp32 arithmetic, one rounding of the result — what widening, pooling in fp32 and
+ * narrowing again produced, without the two cast launches and with half the bytes */
+int dcv_pool2d_fwd_bf16(const dcv_pool2d_desc* d, const void* x_bf16, void* y_bf16, int32_t* argmax, void* stream);
+int dcv_pool2d_bwd_bf16(const dcv_pool2d_desc* d, const void* dy_bf16, const int32_t* argmax, void* dx_bf16, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K8  dense / residual link helpers: bilinear resize, channel concat (slice copy), n-ary add
@@ -359,6 +363,7 @@ int dcv_resize_split_channels(int count, float* const* dsts, const int* channels
                               int n, int ho, int wo, int align_corners, void* stream);
 /* out = a + b (elementwise; out may alias a) */
 int dcv_add(const float* a, const float* b, float* out, size_t numel, void* stream);
+int dcv_add_bf16(const void* a_bf16, const void* b_bf16, void* out_bf16, size_t numel, void* stream);   /* bf16 tensors (16-byte aligned), fp32 sum rounded once */
 /* out = alpha * a */
 int dcv_scale(const float* a, float alpha, float* out, size_t numel, void* stream);
 

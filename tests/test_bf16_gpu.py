@@ -290,3 +290,28 @@ def test_first_layer_as_im2col_plus_one_tap_kernels(device, case, nchw):
     torch.cuda.synchronize()
     ref_dw = torch.nn.grad.conv2d_weight(_bf(x).double(), (cout, cin, k, k), dy.double(), stride, pad, dil)
     assert _rel(dw[:, :K].reshape(cout, cin, k, k), ref_dw) <= 2e-5 and (dw[:, K:] == 0).all()
+
+
+@pytest.mark.parametrize('mode,kernel,stride,pad', [('avg', 2, 2, 0), ('max', 3, 2, 1), ('avg', 4, 4, 0)], ids=['avg2', 'max3s2p1', 'avg4'])
+def test_bf16_pooling_and_add_equal_the_widened_fp32_path(device, mode, kernel, stride, pad):
+    """ Pooling and the residual sum on bf16 tensors: fp32 arithmetic rounded once, i.e. bit for bit what widening to fp32, running the fp32 kernel and narrowing
+    the result gives (the sequence the bf16 storage path used before, with two cast launches around every such op). """
+    from deepcv_amd import _native as nat, ops
+    torch.manual_seed(3)
+    x = torch.randn(5, 64, 18, 18, device=device).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    m = nat.POOL_AVG if mode == 'avg' else nat.POOL_MAX
+    x16 = x.clone().requires_grad_(True)
+    x32 = x.float().requires_grad_(True)
+    y16 = ops.pool2d(x16, kernel, stride, pad, m)
+    y32 = ops.pool2d(x32, kernel, stride, pad, m)
+    assert y16.dtype == torch.bfloat16 and torch.equal(y16, y32.to(torch.bfloat16))
+    g = torch.randn_like(y32).to(torch.bfloat16)
+    y16.backward(g)
+    y32.backward(g.float())
+    torch.cuda.synchronize()
+    assert x16.grad.dtype == torch.bfloat16 and torch.equal(x16.grad, x32.grad.to(torch.bfloat16))
+    a, b = x, torch.randn_like(x.float()).to(torch.bfloat16)
+    s16 = ops.add_tensors([a, b])
+    assert s16.dtype == torch.bfloat16 and torch.equal(s16, (a.float() + b.float()).to(torch.bfloat16))
+    odd = torch.randn(1003, device=device).to(torch.bfloat16)
+    assert torch.equal(ops.add_tensors([odd, odd]), (odd.float() * 2).to(torch.bfloat16))
