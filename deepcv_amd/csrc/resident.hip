@@ -1012,7 +1012,9 @@ template <int CO> __device__ __forceinline__ float rb_comp(const rs_f4& v) { ret
 // multiplies across steps plus separate adds, and 269 spilled registers.
 template <int K, int CI, int CO>
 __device__ __forceinline__ void rb_wg_unit(const rs_f4* xs, const rs_f4* ds, const int XW, int nrows, bool live, rs_f2 (&acc)[K][2], float& bsum) {
-    constexpr int S = K + 1;                                                         // window slots: the K rows of the step + the row requested for the next one
+    // window slots: the K rows of the step + the row requested for the next one; K = 5: eight, so that groups of eight steps tile the stock maps' 32 rows and the
+    // 8-row quarter units exactly (the shifting-window tail below costs 20 moves per step)
+    constexpr int S = K == 5 ? 8 : K + 1;
     rs_f4 w[S];
 #pragma unroll
     for (int j = 0; j < K; ++j) w[j] = xs[j * XW];
@@ -1099,25 +1101,26 @@ __device__ __forceinline__ void rb_wgrad_c4_units(const dcv_resident_bwd_op& o, 
         for (int ky = 0; ky < K; ++ky) { acc[ky][0] = rs_f2{0.f, 0.f}; acc[ky][1] = rs_f2{0.f, 0.f}; }
         rb_wg_unit<K, CI, CO>(reinterpret_cast<const rs_f4*>(xt) + s * RS_XIN + first * XW + col + kx, reinterpret_cast<const rs_f4*>(dzt) + s * RS_XIN + (first + pad) * XW + col + pad,
                               XW, nrows, live, acc, bsum);
-        // totals per half-wave; value index of a call = (ky of the pair) * 4 + ci
-        const int vi = (l32 & 1) * 4 + ((l32 >> 1) & 1) * 2;
+        // totals per half-wave; value index of a call = (ky of the pair) * 4 + ci.  Lanes 0 - 3 of each half keep two totals per call: their destinations are
+        // computed ONCE here (the per-call address arithmetic of the first version was a third of this epilogue's instructions)
+        const int vi = (l32 & 1) * 4 + ((l32 >> 1) & 1) * 2, ky0 = vi >> 2, ci = vi & 3;
+        const int cin = o.cin, ky_stride = K * o.cout * cin;                                       // floats between filter rows of the [tap][co][ci] slab
+        float* dst = o.dw_part + (size_t)(chunk0 + s) * wsize + ((ky0 * K + kx) * o.cout + CO) * cin + ci;
+        float* sc = scratch + ((q * RS_SPB + s) * 4 + CO) * (K * 4) + ky0 * 4 + ci;
+        const bool keep = l32 < 4, st0 = keep && ci < cin, st1 = keep && ci + 1 < cin;
 #pragma unroll
         for (int k2 = 0; k2 < (K + 1) / 2; ++k2) {
             float v[8], r2[2];
 #pragma unroll
             for (int i = 0; i < 4; ++i) { v[i] = acc[2 * k2][i >> 1][i & 1]; v[4 + i] = 2 * k2 + 1 < K ? acc[2 * k2 + 1 < K ? 2 * k2 + 1 : 0][i >> 1][i & 1] : (i == 0 ? bsum : 0.f); }
             rs_reduce8_half(v, r2);
-            if (l32 < 4) {
-                const int ky = 2 * k2 + (vi >> 2), ci = vi & 3;
-                if (ky < K) {
-                    if (pass == 1) { float* sc = scratch + ((q * RS_SPB + s) * 4 + CO) * (K * 4) + ky * 4 + ci; sc[0] = r2[0]; sc[1] = r2[1]; }
-                    else {
-                        float* dst = o.dw_part + (size_t)(chunk0 + s) * wsize + ((ky * K + kx) * o.cout + CO) * o.cin;      // [tap][co][ci]
-                        if (ci < o.cin) dst[ci] = r2[0];
-                        if (ci + 1 < o.cin) dst[ci + 1] = r2[1];
-                    }
-                } else if (ci == 0 && kx == 0 && pass == 0 && o.db_part) o.db_part[(size_t)(chunk0 + s) * o.cout + CO] = r2[0];   // (odd K: the spare slot of the last pair carries the sum of dz)
-            }
+            if (2 * k2 + 1 < K || ky0 == 0) {                                                       // (compile time for all but the last pair of an odd K)
+                if (pass == 1) { if (keep) { sc[2 * k2 * 4] = r2[0]; sc[2 * k2 * 4 + 1] = r2[1]; } }
+                else {
+                    if (st0) dst[2 * k2 * ky_stride] = r2[0];
+                    if (st1) dst[2 * k2 * ky_stride + 1] = r2[1];
+                }
+            } else if (keep && ci == 0 && kx == 0 && pass == 0 && o.db_part) o.db_part[(size_t)(chunk0 + s) * o.cout + CO] = r2[0];   // (odd K: the spare slot of the last pair carries the sum of dz)
         }
     }
 }
