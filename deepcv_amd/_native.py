@@ -83,7 +83,7 @@ class ResidentOp(ctypes.Structure):
                 ('ref_c', _c_int), ('ref_h', _c_int), ('ref_w', _c_int), ('align_corners', _c_int),
                 ('x', _c_void_p), ('filt', _c_void_p), ('bias', _c_void_p), ('bn_gamma', _c_void_p), ('bn_beta', _c_void_p), ('running_mean', _c_void_p),
                 ('running_var', _c_void_p), ('num_batches_tracked', _c_void_p), ('gn_gamma', _c_void_p), ('gn_beta', _c_void_p), ('y', _c_void_p), ('out', _c_void_p),
-                ('bn_mean', _c_void_p), ('bn_rstd', _c_void_p), ('gn_mean', _c_void_p), ('gn_rstd', _c_void_p), ('ref', _c_void_p)]
+                ('bn_mean', _c_void_p), ('bn_rstd', _c_void_p), ('gn_mean', _c_void_p), ('gn_rstd', _c_void_p), ('ref', _c_void_p), ('sample_sums', _c_void_p)]
 
 
 class ResidentProgram(ctypes.Structure):
@@ -101,7 +101,7 @@ class ResidentBwdOp(ctypes.Structure):
                 ('y', _c_void_p), ('dout', _c_void_p), ('addend', _c_void_p), ('filt', _c_void_p), ('bn_gamma', _c_void_p), ('bn_beta', _c_void_p), ('bn_mean', _c_void_p),
                 ('bn_rstd', _c_void_p), ('gn_gamma', _c_void_p), ('gn_mean', _c_void_p), ('gn_rstd', _c_void_p), ('dz', _c_void_p), ('dx', _c_void_p),
                 ('d_bn_gamma', _c_void_p), ('d_bn_beta', _c_void_p), ('gn_part', _c_void_p),
-                ('x', _c_void_p), ('dw_part', _c_void_p), ('db_part', _c_void_p), ('x_nchw', _c_int), ('reserved', _c_int)]
+                ('x', _c_void_p), ('dw_part', _c_void_p), ('db_part', _c_void_p), ('x_nchw', _c_int), ('reserved', _c_int), ('sample_sums', _c_void_p)]
 
 
 class ResidentBwdHead(ctypes.Structure):

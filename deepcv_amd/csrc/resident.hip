@@ -707,6 +707,11 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                 for (int w8 = 0; w8 < 8; ++w8) { v0 += s_wsum[(w8 * 2 + q) * RS_MAXC + c]; v1 += s_wsum[((8 + w8) * 2 + q) * RS_MAXC + c]; }
                 s_samp[0][q][c] = v0; s_samp[1][q][c] = v1;
                 mine = (valid0 ? v0 : 0.f) + (valid1 ? v1 : 0.f);
+                if (o.sample_sums != nullptr) {                                      // for the backward launch's GroupNorm algebra (sum u, sum u^2 without a pass over y)
+                    float* dst = o.sample_sums + ((size_t)blockIdx.x * RS_SPB * 2 + q) * C + c;
+                    if (valid0) dst[0] = v0;
+                    if (valid1) dst[2 * C] = v1;
+                }
             }
             stamp();
             auto store_y = [&]() {                                                   // the sample's [HW][C] floats: the same order in LDS and in HBM
@@ -1608,9 +1613,12 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         rs_u64* go = gran + (size_t)(tail ? 0 : oi) * RS_GRAN_OP;
         if (!tail) {
         float e_gr = 0.f, e_gm = 0.f;
+        float e_sy = 0.f, e_syy = 0.f;                                               // the forward's sums of y, y^2 of (sample, channel), when it left them
+        const bool have_sums = o.sample_sums != nullptr;
         if (t < RS_SPB * C && o.groups > 0 && ac_n < N) {
             const int g = rs_fdiv(ac_c, 1.f / (float)cpg);
             e_gr = o.gn_rstd[(size_t)ac_n * o.groups + g]; e_gm = o.gn_mean[(size_t)ac_n * o.groups + g];
+            if (have_sums) { e_sy = o.sample_sums[((size_t)ac_n * 2) * C + ac_c]; e_syy = o.sample_sums[((size_t)ac_n * 2 + 1) * C + ac_c]; }
         }
         if (t < C) { s_mr[0][t] = s_par[oi][2][t]; s_mr[1][t] = s_par[oi][3][t]; }
         rs_barrier();
@@ -1631,11 +1639,14 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
                 const float u0 = (y4.x - mu.x) * rs.x, u1 = (y4.y - mu.y) * rs.y, u2 = (y4.z - mu.z) * rs.z, u3 = (y4.w - mu.w) * rs.w;
                 m8a[0] += d4.x; m8a[1] += d4.y; m8a[2] += d4.z; m8a[3] += d4.w;
                 m8a[4] += d4.x * u0; m8a[5] += d4.y * u1; m8a[6] += d4.z * u2; m8a[7] += d4.w * u3;
-                m8b[0] += u0; m8b[1] += u1; m8b[2] += u2; m8b[3] += u3;
-                m8b[4] += u0 * u0; m8b[5] += u1 * u1; m8b[6] += u2 * u2; m8b[7] += u3 * u3;
+                if (!have_sums) {                                                    // (block-uniform) sum u, sum u^2: derived from the forward's sums of y, y^2 when it left them
+                    m8b[0] += u0; m8b[1] += u1; m8b[2] += u2; m8b[3] += u3;
+                    m8b[4] += u0 * u0; m8b[5] += u1 * u1; m8b[6] += u2 * u2; m8b[7] += u3 * u3;
+                }
             }
-            float ra[2], rb[2];
-            rs_reduce8(m8a, ra); rs_reduce8(m8b, rb);
+            float ra[2], rb[2] = {0.f, 0.f};
+            rs_reduce8(m8a, ra);
+            if (!have_sums) rs_reduce8(m8b, rb);
             if (lane < 4) {
                 const int vi = (lane & 1) * 4 + ((lane >> 1) & 1) * 2;                // values vi, vi + 1 = (quantity vi / 4, channel vi % 4)
                 float* wr = s_wsum + wave * 4 * RS_MAXC;
@@ -1655,8 +1666,14 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
 #pragma unroll
                 for (int q = 0; q < 4; ++q) mq[q] += wr[q * RS_MAXC];
             }
-            const double m0 = (double)mq[0], m1 = (double)mq[1], u1 = (double)mq[2], u2 = (double)mq[3];
             const float gbn = s_par[oi][0][c], bbn = s_par[oi][1][c], brs = s_par[oi][3][c], ggn = s_par[oi][4][c];
+            double u1 = (double)mq[2], u2 = (double)mq[3];
+            if (have_sums) {                                                         // u = (y - mean) rstd: sum u = (sum y - HW mean) rstd, sum u^2 = (sum y^2 - 2 mean sum y + HW mean^2) rstd^2
+                const double mean = (double)s_par[oi][2][c], rstd = (double)brs, hw = (double)HW, sy = (double)e_sy, syy = (double)e_syy;
+                u1 = (sy - hw * mean) * rstd;
+                u2 = (syy - 2.0 * mean * sy + hw * mean * mean) * rstd * rstd;
+            }
+            const double m0 = (double)mq[0], m1 = (double)mq[1];
             const float a_bn = gbn * brs;
             double S1 = m0, S2 = m1, T1 = m0, T2 = m1;
             float P = a_bn, Q0 = 0.f, R0 = 0.f;
@@ -1965,17 +1982,30 @@ inline bool rs_program_ok(const dcv_resident_program* p) {
     return true;
 }
 
+// Both launches put one 1024-thread block on every CU they use and their blocks wait for each other: the grid must be co-resident.  With the current device's
+// CU count known, a program whose grid is larger is refused here (the caller falls back to the per-layer kernels) instead of timing out in its first
+// synchronisation; without a device (the build container) the count is unknown and nothing is refused.
+inline bool rs_grid_fits(int n) {
+    static int cus = -2;
+    if (cus == -2) {
+        int dev = 0, v = 0;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : -1;
+        (void)hipGetLastError();
+    }
+    return cus < 0 || (n + RS_SPB - 1) / RS_SPB <= cus;
+}
+
 }  // namespace
 
 extern "C" {
 
-int dcv_resident_supported(const dcv_resident_program* p) { return rs_program_ok(p) ? 1 : 0; }
+int dcv_resident_supported(const dcv_resident_program* p) { return (rs_program_ok(p) && rs_grid_fits(p->n)) ? 1 : 0; }
 
 size_t dcv_resident_ws_bytes(void) { return RS_CTL_BYTES + (size_t)DCV_RESIDENT_MAX_OPS * RS_GRAN_OP * sizeof(rs_u64); }
 
 int dcv_resident_forward(const dcv_resident_program* p, void* ws, size_t ws_bytes, void* stream) {
     DCV_CHECK_ARG(p && ws);
-    if (!rs_program_ok(p)) return DCV_ERR_UNSUPPORTED;
+    if (!rs_program_ok(p) || !rs_grid_fits(p->n)) return DCV_ERR_UNSUPPORTED;
     if (ws_bytes < dcv_resident_ws_bytes()) return DCV_ERR_WORKSPACE;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1988,7 +2018,7 @@ int dcv_resident_forward(const dcv_resident_program* p, void* ws, size_t ws_byte
     DCV_RETURN_LAUNCH();
 }
 
-int dcv_resident_bwd_supported(const dcv_resident_bwd_program* p) { return rb_program_ok(p) ? 1 : 0; }
+int dcv_resident_bwd_supported(const dcv_resident_bwd_program* p) { return (rb_program_ok(p) && rs_grid_fits(p->n)) ? 1 : 0; }
 
 int dcv_resident_head_wgrad_supported(int n, int k, int classes) { return rb_fc_wgrad_ok(n, k, classes) ? 1 : 0; }
 
@@ -1999,7 +2029,7 @@ int dcv_resident_wgrad_supported(int cin, int cout, int k, int h, int w) {
 
 int dcv_resident_backward(const dcv_resident_bwd_program* p, void* ws, size_t ws_bytes, void* stream) {
     DCV_CHECK_ARG(p && ws);
-    if (!rb_program_ok(p)) return DCV_ERR_UNSUPPORTED;
+    if (!rb_program_ok(p) || !rs_grid_fits(p->n)) return DCV_ERR_UNSUPPORTED;
     if (ws_bytes < dcv_resident_ws_bytes()) return DCV_ERR_WORKSPACE;
     static bool attr_set = false;
     if (!attr_set) {

@@ -727,7 +727,9 @@ class _ConvNormLayerFn(torch.autograd.Function):
                 raise resident.Ineligible('layer: no resident filter layout')
             y = torch.empty((d.n, d.cout, d.ho, d.wo), dtype=torch.float32, device=dev, memory_format=_CL)
             out = torch.empty_like(y) if not pool else torch.empty((d.n, d.cout, d.ho // pool, d.wo // pool), dtype=torch.float32, device=dev, memory_format=_CL)
-            rec.add_layer(x, d, cfg, layout, weight, filt, bias, bn_w, bn_b, running_mean, running_var, nbt, gn_w, gn_b, y, out, bn_mean, bn_rstd, gn_mean, gn_rstd)
+            # per-(sample, channel) sums of y, y^2 from the forward launch's statistics epilogue: the backward launch's GroupNorm algebra takes sum u, sum u^2 from them
+            ctx.res_samp = torch.empty((d.n, 2, d.cout), dtype=torch.float32, device=dev) if groups else None
+            rec.add_layer(x, d, cfg, layout, weight, filt, bias, bn_w, bn_b, running_mean, running_var, nbt, gn_w, gn_b, y, out, bn_mean, bn_rstd, gn_mean, gn_rstd, ctx.res_samp)
             need = ctx.needs_input_grad
             ctx.res_plan = (rec.plan, rec.plan.add_layer(d, cfg, [weight if need[1] else None, bias if need[2] else None, bn_w if need[3] else None,
                                                                  bn_b if need[4] else None, gn_w if need[8] else None, gn_b if need[9] else None],
@@ -803,13 +805,15 @@ class _ConvNormLayerFn(torch.autograd.Function):
                 op.inv_count = 1.0 / (float(d.n) * hw)
                 op.inv_group = 1.0 / (float(hw) * (c // groups)) if groups else 0.0
                 op.y = y.data_ptr()
+                samp = getattr(ctx, 'res_samp', None)
+                op.sample_sums = nat.ptr(samp)
                 op.dout = dout.data_ptr() if not plan.ops else None
                 op.bn_gamma, op.bn_beta, op.bn_mean, op.bn_rstd = nat.ptr(bn_w), nat.ptr(bn_b), bn_mean.data_ptr(), bn_rstd.data_ptr()
                 op.gn_gamma, op.gn_mean, op.gn_rstd = nat.ptr(gn_w), nat.ptr(gn_mean), nat.ptr(gn_rstd)
                 op.d_bn_gamma, op.d_bn_beta = nat.ptr(d_bn_w), nat.ptr(d_bn_b)
                 # (the parameter-gradient buffers are only passed by address: the engine's AccumulateGrad adopts a gradient as `.grad` when it is its sole
                 # owner and COPIES it otherwise — a copy taken now, before the launch has filled the buffer)
-                keep = [y, dout, bn_w, bn_b, bn_mean, bn_rstd, gn_w, gn_mean, gn_rstd]
+                keep = [y, dout, bn_w, bn_b, bn_mean, bn_rstd, gn_w, gn_mean, gn_rstd, samp]
                 if groups and (d_gn_w is not None or d_gn_b is not None):
                     blocks = (d.n + 1) // 2
                     gn_part = torch.empty(blocks * 2 * c, dtype=torch.float32, device=dev)

@@ -285,7 +285,7 @@ class Recorder:
             raise Ineligible(f'layer: {d.cin}->{d.cout} {k}x{k} @{d.h}x{d.w} groups {groups} pool {pool} is not covered')
 
     def add_layer(self, x, d: nat.Conv2dDesc, cfg, layout: int, weight, filt, bias, bn_w, bn_b, running_mean, running_var, nbt, gn_w, gn_b,
-                  y, out, bn_mean, bn_rstd, gn_mean, gn_rstd):
+                  y, out, bn_mean, bn_rstd, gn_mean, gn_rstd, sample_sums=None):
         stride, padding, dilation, act, slope, momentum, bn_eps, groups, gn_eps, pool = cfg
         op = nat.ResidentOp()
         op.kind, op.cin, op.cout, op.k, op.h, op.w, op.act, op.slope = nat.RES_LAYER, d.cin, d.cout, d.r, d.h, d.w, act, slope
@@ -299,8 +299,9 @@ class Recorder:
         op.bn_gamma, op.bn_beta, op.running_mean, op.running_var, op.num_batches_tracked = nat.ptr(bn_w), nat.ptr(bn_b), nat.ptr(running_mean), nat.ptr(running_var), nat.ptr(nbt)
         op.gn_gamma, op.gn_beta = nat.ptr(gn_w), nat.ptr(gn_b)
         op.y, op.out, op.bn_mean, op.bn_rstd, op.gn_mean, op.gn_rstd = y.data_ptr(), out.data_ptr(), bn_mean.data_ptr(), bn_rstd.data_ptr(), nat.ptr(gn_mean), nat.ptr(gn_rstd)
+        op.sample_sums = nat.ptr(sample_sums)
         self.ops.append(op)
-        self.keep.extend(t for t in (x, weight, filt, bias, bn_w, bn_b, running_mean, running_var, nbt, gn_w, gn_b, y, out, bn_mean, bn_rstd, gn_mean, gn_rstd) if t is not None)
+        self.keep.extend(t for t in (x, weight, filt, bias, bn_w, bn_b, running_mean, running_var, nbt, gn_w, gn_b, y, out, bn_mean, bn_rstd, gn_mean, gn_rstd, sample_sums) if t is not None)
         self.cur = out
         self.layer_outs[out.data_ptr()] = (out.shape[1], out.shape[2], out.shape[3])
 

@@ -615,6 +615,8 @@ typedef struct dcv_resident_op {
     float* out;                        /* LAYER: layer output [n][h/pool][w/pool][cout]; LINK: the wide tensor; FC: logits [n][cout] */
     float* bn_mean; float* bn_rstd; float* gn_mean; float* gn_rstd;   /* saved statistics, as dcv_norm_chain_desc */
     const float* ref;                  /* LINK: [n][ref_h][ref_w][ref_c] */
+    float* sample_sums;                /* LAYER, nullable: [n][2][cout] sums of y and y^2 per (sample, channel), as the layer's statistics epilogue computes them; handed to
+                                          dcv_resident_backward (dcv_resident_bwd_op.sample_sums) they spare its moments phase two of its four reductions */
 } dcv_resident_op;
 /* `mailbox` (nullable) folds the batch staging of a replayed training step (dcv_indirect_copy) into the launch: the first op's input is read from
  * mailbox->src[x_job] — the address the host wrote for THIS replay — instead of op[0].x, and also stored to op[0].x (= mailbox->dst[x_job], the static tensor
@@ -660,6 +662,9 @@ typedef struct dcv_resident_bwd_op {
      * x_nchw), dw_part [2 * blocks][k * k][cout][cin] and db_part [2 * blocks][cout] (nullable) = per-(block, sample slot) partial sums, tap-major;
      * dw (OIHW) / db = their sums over the 2 * blocks chunks (dcv_slab_reduce with tr_a = k * k, tr_b = cout * cin).  Computed while the block waits for the next layer's all-reduce. */
     const float* x; float* dw_part; float* db_part; int x_nchw; int reserved;
+    /* nullable: the forward launch's [n][2][cout] sums of y, y^2 per (sample, channel) (dcv_resident_op.sample_sums): sum u and sum u^2 of the GroupNorm algebra
+     * (u = (y - mean) rstd) then come from them in fp64 instead of from two more reductions over the sample */
+    const float* sample_sums;
 } dcv_resident_bwd_op;
 #define DCV_RESIDENT_BWD_MAX_OPS 8
 /* Optional head of the backward pass in front of op 0, for a stack which ends LINK -> Flatten -> fully connected layer (dcv_resident_program): the data gradient
