@@ -23,14 +23,15 @@ __device__ __forceinline__ void pl_ld4(const pl_u16* p, float (&v)[4]) {
 __device__ __forceinline__ void pl_st(float* p, float v) { *p = v; }
 __device__ __forceinline__ void pl_st(pl_u16* p, float v) { const __bf16 h = (__bf16)v; *p = __builtin_bit_cast(pl_u16, h); }
 
-template <int VEC, int MODE, typename T>
+// IDX: unsigned (tensors below 2^32 elements: a 64-bit division is ~100 VALU instructions, and the index decode was most of these kernels' time) or size_t
+template <int VEC, int MODE, typename T, typename IDX>
 __global__ __launch_bounds__(256) void pool_fwd_kernel(dcv_pool2d_desc d, const T* __restrict__ x, T* __restrict__ y, int32_t* __restrict__ argmax) {
-    const int CV = d.c / VEC;
-    const size_t total = (size_t)d.n * d.ho * d.wo * CV;
+    const IDX CV = (IDX)(d.c / VEC);
+    const IDX total = (IDX)d.n * (IDX)d.ho * (IDX)d.wo * CV;
     const float inv = 1.f / (float)(d.kh * d.kw);                        // count_include_pad=True
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % CV) * VEC; size_t p = i / CV;
-        const int wo = (int)(p % d.wo); p /= d.wo; const int ho = (int)(p % d.ho); const int n = (int)(p / d.ho);
+    for (IDX i = (IDX)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (IDX)gridDim.x * blockDim.x) {
+        const int c = (int)(i % CV) * VEC; IDX p = i / CV;
+        const int wo = (int)(p % (IDX)d.wo); p /= (IDX)d.wo; const int ho = (int)(p % (IDX)d.ho); const int n = (int)(p / (IDX)d.ho);
         const T* xs = x + (size_t)n * d.h * d.w * d.c;
         float acc[VEC]; int32_t arg[VEC];
         const int h0 = ho * d.stride_h - d.pad_h, w0 = wo * d.stride_w - d.pad_w;
@@ -72,14 +73,14 @@ __device__ __forceinline__ void window_range(int i, int pad, int k, int stride, 
     lo = u <= 0 ? 0 : (u + stride - 1) / stride;
 }
 
-template <int VEC, int MODE, typename T>
+template <int VEC, int MODE, typename T, typename IDX>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(dcv_pool2d_desc d, const T* __restrict__ dy, const int32_t* __restrict__ argmax, T* __restrict__ dx) {
-    const int CV = d.c / VEC;
-    const size_t total = (size_t)d.n * d.h * d.w * CV;
+    const IDX CV = (IDX)(d.c / VEC);
+    const IDX total = (IDX)d.n * (IDX)d.h * (IDX)d.w * CV;
     const float inv = 1.f / (float)(d.kh * d.kw);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % CV) * VEC; size_t p = i / CV;
-        const int w = (int)(p % d.w); p /= d.w; const int h = (int)(p % d.h); const int n = (int)(p / d.h);
+    for (IDX i = (IDX)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (IDX)gridDim.x * blockDim.x) {
+        const int c = (int)(i % CV) * VEC; IDX p = i / CV;
+        const int w = (int)(p % (IDX)d.w); p /= (IDX)d.w; const int h = (int)(p % (IDX)d.h); const int n = (int)(p / (IDX)d.h);
         int holo, hohi, wolo, wohi;
         window_range(h, d.pad_h, d.kh, d.stride_h, d.ho, holo, hohi);
         window_range(w, d.pad_w, d.kw, d.stride_w, d.wo, wolo, wohi);
@@ -112,14 +113,14 @@ inline bool pool_desc_ok(const dcv_pool2d_desc* d) {
 template <typename T>
 int pool_fwd_launch(const dcv_pool2d_desc* d, const T* x, T* y, int32_t* argmax, hipStream_t st) {
     const int vec = d->c % 4 == 0 ? 4 : 1;
-    const unsigned grid = dcv_stream_grid((size_t)d->n * d->ho * d->wo * (d->c / vec), 256);
-    if (d->mode == DCV_POOL_AVG) {
-        if (vec == 4) hipLaunchKernelGGL((pool_fwd_kernel<4, DCV_POOL_AVG, T>), dim3(grid), dim3(256), 0, st, *d, x, y, argmax);
-        else hipLaunchKernelGGL((pool_fwd_kernel<1, DCV_POOL_AVG, T>), dim3(grid), dim3(256), 0, st, *d, x, y, argmax);
-    } else {
-        if (vec == 4) hipLaunchKernelGGL((pool_fwd_kernel<4, DCV_POOL_MAX, T>), dim3(grid), dim3(256), 0, st, *d, x, y, argmax);
-        else hipLaunchKernelGGL((pool_fwd_kernel<1, DCV_POOL_MAX, T>), dim3(grid), dim3(256), 0, st, *d, x, y, argmax);
-    }
+    const size_t items = (size_t)d->n * d->ho * d->wo * (d->c / vec);
+    const unsigned grid = dcv_stream_grid(items, 256);
+    const bool small = (size_t)d->n * d->h * d->w * d->c < ((size_t)1 << 31);      // every element index fits 32 bits
+#define DCV_POOL_FWD(V, M) do { if (small) hipLaunchKernelGGL((pool_fwd_kernel<V, M, T, unsigned>), dim3(grid), dim3(256), 0, st, *d, x, y, argmax); \
+                                else hipLaunchKernelGGL((pool_fwd_kernel<V, M, T, size_t>), dim3(grid), dim3(256), 0, st, *d, x, y, argmax); } while (0)
+    if (d->mode == DCV_POOL_AVG) { if (vec == 4) DCV_POOL_FWD(4, DCV_POOL_AVG); else DCV_POOL_FWD(1, DCV_POOL_AVG); }
+    else { if (vec == 4) DCV_POOL_FWD(4, DCV_POOL_MAX); else DCV_POOL_FWD(1, DCV_POOL_MAX); }
+#undef DCV_POOL_FWD
     DCV_RETURN_LAUNCH();
 }
 
@@ -127,13 +128,12 @@ template <typename T>
 int pool_bwd_launch(const dcv_pool2d_desc* d, const T* dy, const int32_t* argmax, T* dx, hipStream_t st) {
     const int vec = d->c % 4 == 0 ? 4 : 1;
     const unsigned grid = dcv_stream_grid((size_t)d->n * d->h * d->w * (d->c / vec), 256);
-    if (d->mode == DCV_POOL_AVG) {
-        if (vec == 4) hipLaunchKernelGGL((pool_bwd_kernel<4, DCV_POOL_AVG, T>), dim3(grid), dim3(256), 0, st, *d, dy, argmax, dx);
-        else hipLaunchKernelGGL((pool_bwd_kernel<1, DCV_POOL_AVG, T>), dim3(grid), dim3(256), 0, st, *d, dy, argmax, dx);
-    } else {
-        if (vec == 4) hipLaunchKernelGGL((pool_bwd_kernel<4, DCV_POOL_MAX, T>), dim3(grid), dim3(256), 0, st, *d, dy, argmax, dx);
-        else hipLaunchKernelGGL((pool_bwd_kernel<1, DCV_POOL_MAX, T>), dim3(grid), dim3(256), 0, st, *d, dy, argmax, dx);
-    }
+    const bool small = (size_t)d->n * d->h * d->w * d->c < ((size_t)1 << 31);
+#define DCV_POOL_BWD(V, M) do { if (small) hipLaunchKernelGGL((pool_bwd_kernel<V, M, T, unsigned>), dim3(grid), dim3(256), 0, st, *d, dy, argmax, dx); \
+                                else hipLaunchKernelGGL((pool_bwd_kernel<V, M, T, size_t>), dim3(grid), dim3(256), 0, st, *d, dy, argmax, dx); } while (0)
+    if (d->mode == DCV_POOL_AVG) { if (vec == 4) DCV_POOL_BWD(4, DCV_POOL_AVG); else DCV_POOL_BWD(1, DCV_POOL_AVG); }
+    else { if (vec == 4) DCV_POOL_BWD(4, DCV_POOL_MAX); else DCV_POOL_BWD(1, DCV_POOL_MAX); }
+#undef DCV_POOL_BWD
     DCV_RETURN_LAUNCH();
 }
 
