@@ -202,6 +202,188 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(Bf16Args a, const u16
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3 / stride 1 / pad 1: the input window staged once for all nine taps
+// conv_bf16_kernel above re-stages its 128-pixel x tile for every K step — nine times per pixel for a 3x3 layer — and keeps the matrix pipe busy 20 % of the
+// time on cifar100_deep (profiles/r03_pmc_cifar100_deep_bf16.json): it is bound by the bytes it moves into LDS (24 - 32 KB per K step of 16 - 32 us of MFMAs per
+// SIMD), not by arithmetic.  Here a block of 512 threads (8 waves: one block per CU, the same occupancy as two of the blocks above) owns 256 consecutive output
+// pixels x BN channels.  Per 64-channel chunk the FLAT input window of the tile — rows q = m0 - W - 1 .. m0 + 255 + W + 1 of the [n h w][Cin] tensor, zeros outside
+// it (buffer loads beyond num_records) — is staged ONCE; tap (r, s) of pixel p reads window row p + r W + s.  Window rows which belong to a neighbouring image row
+// / image (the tile ignores image borders) are never read: every lane keeps, per accumulator-tile row and tap, the LDS address of its operand — the window row, or
+// an all-zero row when the tap falls outside the image — computed once per block (36 registers), so the inner loop has no address or border arithmetic at all.
+// Only the filter tile is staged per K step (double buffered), the window of the next chunk lands in a second window buffer during the current chunk.
+// LDS: 2 windows x (256 + 2 W + 2 rows rounded up to 64) x 128 B + a zero row + 2 x BN x 128 B = 122 KB at W = 32, BN = 128.
+// Bytes into LDS per 128 pixels x 128 channels x 256 input channels: 0.38 MB (window 0.09 + filters 0.29) against 1.18 MB above.
+// Same fragment layouts, swizzle (applied on the source side of the LDS-DMA), epilogue and statistics rows (one per 128 pixels: two per block) as above.
+template <int WN, bool OUT_BF16>
+__global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, const u16* __restrict__ x, const u16* __restrict__ wb, const float* __restrict__ bias,
+                                                                 void* __restrict__ yv, double* __restrict__ stats, int win_rows) {
+    constexpr int WM = 8 / WN, BMH = 256, TI = BMH / (16 * WM), BN = 64 * WN, PB = BN / 64;       // PB: 16-B pieces of the filter tile per thread and stage
+    constexpr int B_BYTES = BN * 128;
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 15, lg = lane >> 4;
+    const long m0 = (long)blockIdx.x * BMH;
+    const int n0 = blockIdx.y * BN;
+    const int W = a.Win, H = a.Hin;
+    const int WIN_BYTES = win_rows * 128;                          // win_rows: a multiple of 64 >= 256 + 2 W + 2
+    char* const zrow = lds + 2 * WIN_BYTES;                         // 128 B of zeros
+    char* const bst = zrow + 128;                                   // two filter stages
+
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)a.x_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, (int)a.w_bytes, 0x00020000);
+    if (t < 8) *reinterpret_cast<uint4*>(zrow + t * 16) = make_uint4(0u, 0u, 0u, 0u);
+
+    // ---- staging roles (as above): piece p of this thread = LDS row 64 p + (t >> 3), physical slot t & 7, which holds logical slot (t & 7) ^ ((t >> 4) & 7)
+    const int lslot = (t & 7) ^ ((t >> 4) & 7);
+    const long q0 = m0 - W - 1;                                     // flat pixel index of window row 0
+    const long Mtot = (long)a.N * H * W;
+    const int cchunks = a.Cin / BF_BK;
+    auto stage_window = [&](int wbuf, int chunk) {
+        char* base = lds + wbuf * WIN_BYTES;
+        for (int p = 0; p * 64 < win_rows; ++p) {
+            const long q = q0 + 64 * p + (t >> 3);
+            const bool v = q >= 0 && q < Mtot;
+            dma16(rx, base + (p * 512 + (t & ~63)) * 16, v ? (unsigned)((q * a.Cin) * 2 + chunk * 128 + lslot * 16) : BF_OOB);
+        }
+    };
+    int offb[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        const int rho = 64 * p + (t >> 3);                          // LDS row of the B image: 64 wn' + 16 j + c  <-  channel n0 + 64 wn' + 4 c + j
+        const int co = n0 + (rho & ~63) + 4 * (rho & 15) + ((rho >> 4) & 3);
+        offb[p] = (co * a.Cin) * 2 + lslot * 16;
+    }
+    auto stage_filter = [&](int buf, int chunk, int tap) {
+        char* base = bst + buf * B_BYTES;
+        const int ub = (tap * a.Cout) * a.Cin * 2 + chunk * 128;
+#pragma unroll
+        for (int p = 0; p < PB; ++p) dma16(rw, base + (p * 512 + (t & ~63)) * 16, (unsigned)(offb[p] + ub));
+    };
+
+    // ---- operand addresses: tile row i of this wave = pixel pl = 16 TI wm + 16 i + li of the block; tap (r, s) -> window row pl + r W + s, logical slot lg (K half 0;
+    // the other half is the address ^ 64), or the zero row when the tap leaves the image
+    unsigned aaddr[TI][9];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int pl = 16 * TI * wm + 16 * i + li;
+        const long m = m0 + pl;
+        const bool ok = m < a.M;
+        const long mm = ok ? m : 0;
+        const int wo = (int)(mm % W), ho = (int)((mm / W) % H);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int sx = 0; sx < 3; ++sx) {
+                const int hi = ho + r - 1, wi = wo + sx - 1;
+                const int R = pl + r * W + sx;
+                const bool v = ok && hi >= 0 && hi < H && wi >= 0 && wi < W;
+                aaddr[i][r * 3 + sx] = v ? (unsigned)(R * 128 + ((lg ^ ((R >> 1) & 7)) << 4)) : (unsigned)(2 * WIN_BYTES + lg * 16);
+            }
+    }
+    const int swz = (li >> 1) & 7;
+    const int b_row0 = (64 * wn + li) * 128;
+    const int s0 = ((0 + lg) ^ swz) * 16, s1 = ((4 + lg) ^ swz) * 16;
+
+    f32x4 acc[TI][4];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    stage_window(0, 0);
+    stage_filter(0, 0, 0);
+    int step = 0;
+    for (int chunk = 0; chunk < cchunks; ++chunk) {
+        const char* win = lds + (chunk & 1) * WIN_BYTES;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap, ++step) {
+            const int buf = step & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of this step (and, at tap 0, of this chunk's window) have landed ...
+            __syncthreads();                                       // ... and everybody's; every wave is also done reading the other filter stage
+            if (tap == 0 && chunk + 1 < cchunks) stage_window((chunk + 1) & 1, chunk + 1);          // (the other window buffer: last read in the previous chunk)
+            if (tap + 1 < 9) stage_filter(buf ^ 1, chunk, tap + 1);
+            else if (chunk + 1 < cchunks) stage_filter(buf ^ 1, chunk + 1, 0);
+            const char* sb = bst + buf * B_BYTES;
+            unsigned ad[TI];
+            // (the tap index is a loop variable: select this tap's address per tile row)
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                unsigned v = aaddr[i][0];
+#pragma unroll
+                for (int q = 1; q < 9; ++q) v = tap == q ? aaddr[i][q] : v;
+                ad[i] = v;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int so = ks ? s1 : s0;
+                bf16x8 af[TI], bf[4];
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    const unsigned adr = ks ? (ad[i] ^ 64u) : ad[i];
+                    const char* ap = adr >= (unsigned)(2 * WIN_BYTES) ? lds + adr : win + adr;
+                    af[i] = *reinterpret_cast<const bf16x8*>(ap);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(sb + b_row0 + j * 2048 + so);
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: acc[i][j][reg] -> pixel m0 + 16 TI wm + 16 i + 4 lg + reg, channel n0 + 64 wn + 4 li + j
+    const int cbase = n0 + 64 * wn + 4 * li;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) { const float4 b4 = *reinterpret_cast<const float4*>(bias + cbase); bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w; }
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const long m = m0 + 16 * TI * wm + 16 * i + 4 * lg + reg;
+            if (m < a.M) {
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[j] = dcv_act_apply(acc[i][j][reg] + bv[j], a.act, a.slope);
+                    ssum[j] += o[j]; ssq[j] += o[j] * o[j];
+                }
+                if constexpr (OUT_BF16) {
+                    const bf16x4 h = (bf16x4){(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<u16*>(yv) + (size_t)m * a.Cout + cbase) = h;
+                } else {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(yv) + (size_t)m * a.Cout + cbase) = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
+    if (stats != nullptr) {
+        // statistics rows are per 128 pixels (the layout dcv_conv2d_bf16_fwd_stats_layout promises): the block's two halves = waves wm < WM / 2 and the others
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(lds);              // [8 waves][2][64]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s1v = ssum[j], s2v = ssq[j];
+            s1v += __shfl_xor(s1v, 16, 64); s2v += __shfl_xor(s2v, 16, 64);
+            s1v += __shfl_xor(s1v, 32, 64); s2v += __shfl_xor(s2v, 32, 64);
+            if (lg == 0) { red[(wave * 2 + 0) * 64 + 4 * li + j] = (double)s1v; red[(wave * 2 + 1) * 64 + 4 * li + j] = (double)s2v; }
+        }
+        __syncthreads();
+        const int rows_total = (int)((a.M + 127) / 128);
+        for (int e = t; e < 2 * 2 * BN; e += 512) {
+            const int half = e / (2 * BN), r2 = e - half * 2 * BN, q = r2 / BN, c = r2 - q * BN;
+            const int wnn = c >> 6, cc = c & 63;
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < WM / 2; ++w) v += red[(((half * (WM / 2) + w) * WN + wnn) * 2 + q) * 64 + cc];
+            const int row = 2 * (int)blockIdx.x + half;
+            if (row < rows_total) stats[((size_t)q * a.Cout + n0 + c) * rows_total + row] = v;            // [2][Cout][rows]
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradient, all nine taps per block, bf16 operands
 // dW[tap][co][ci] = sum over pixels of dz[p][co] * x[p (+) tap][ci] for 3x3 / stride 1 / pad 1 layers: GEMM with M = co, N = ci, K = pixels.  Both operands
 // are K-strided in memory ([pixel][channel] rows), so the LDS images keep the natural layout and the fragments are read TRANSPOSED (`ds_read_b64_tr_b16`:
@@ -541,10 +723,45 @@ inline bool supported(const dcv_conv2d_desc* d, int op) {
     return true;
 }
 
+// the window kernel's plan: 3x3 / stride 1 / pad 1 / no dilation on the whole tensor (not a phase of a strided data gradient), enough pixels to give every CU a
+// block, and two windows + two filter stages within the CU's LDS.  DCV_BF16_HALO=0 switches it off, =2 forces it for every shape it can run.
+inline bool halo_plan(const Bf16Args& a, int bn, int* win_rows, size_t* smem) {
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("DCV_BF16_HALO"); mode = e ? atoi(e) : 1; }
+    if (mode == 0 || a.phase || a.R != 3 || a.S != 3 || a.sh != 1 || a.sw != 1 || a.ph != 1 || a.pw != 1 || a.dh != 1 || a.dw != 1) return false;
+    if (a.Hin != a.Hout || a.Win != a.Wout) return false;
+    // measured at N = 512: kernel by kernel (tools/bf16_bench.py) +3 - 4 % on 128 / 256 channels at 16x16 and 8x8, a tie on 512 -> 512 @8x8, -8 % on 64 -> 64 @32x32 and
+    // -19 % on 512 -> 512 @4x4 in isolation; inside the captured training step (tools/gpu_halo_cmp.sh, cifar100_deep bs 512, alternating runs on one box) every
+    // 3x3 layer on this kernel is the fastest setting: 2.99 - 3.01 ms against 3.04 - 3.05 (only >= 128 channels and >= 8 columns) and 3.07 (off).  So only the
+    // pixel count decides (every CU a 256-pixel tile).
+    if (mode != 2 && a.M < 8192) return false;
+    const int rows = (256 + 2 * a.Win + 2 + 63) / 64 * 64;
+    const size_t need = (size_t)2 * rows * 128 + 128 + (size_t)2 * bn * 128;
+    if (need > (size_t)160 * 1024) return false;
+    *win_rows = rows; *smem = need;
+    return true;
+}
+
 template <bool OUT_BF16>
 int launch(const Bf16Args& a, const u16* x, const u16* wb, const float* bias, void* y, double* stats, hipStream_t st) {
     static bool configured[2] = {false, false};
     const bool wide = a.Cout % 128 == 0;
+    {
+        int win_rows = 0; size_t hs = 0;
+        if (halo_plan(a, wide ? 128 : 64, &win_rows, &hs)) {
+            static bool hconf[2] = {false, false};
+            dim3 hgrid((unsigned)dcv_ceil_div((size_t)a.M, 256), (unsigned)(a.Cout / (wide ? 128 : 64)));
+            if (hgrid.y > 65535) return DCV_ERR_UNSUPPORTED;
+            if (wide) {
+                if (!hconf[0]) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_halo_kernel<2, OUT_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DCV_ERR_LAUNCH; hconf[0] = true; }
+                hipLaunchKernelGGL((conv_bf16_halo_kernel<2, OUT_BF16>), hgrid, dim3(512), hs, st, a, x, wb, bias, y, stats, win_rows);
+            } else {
+                if (!hconf[1]) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_halo_kernel<1, OUT_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DCV_ERR_LAUNCH; hconf[1] = true; }
+                hipLaunchKernelGGL((conv_bf16_halo_kernel<1, OUT_BF16>), hgrid, dim3(512), hs, st, a, x, wb, bias, y, stats, win_rows);
+            }
+            return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
+        }
+    }
     const size_t smem = wide ? (size_t)2 * (BF_BM + 128) * 128 : (size_t)2 * (BF_BM + 64) * 128;
     dim3 grid((unsigned)dcv_ceil_div((size_t)a.M, BF_BM), (unsigned)(a.Cout / (wide ? 128 : 64)));
     if (grid.y > 65535) return DCV_ERR_UNSUPPORTED;

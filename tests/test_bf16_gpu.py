@@ -23,6 +23,10 @@ CASES = [
     (2, 64, 12, 12, 64, 5, 1, 2, 1, 4, True),        # 5x5, tanh
     (2, 64, 14, 14, 64, 3, 1, 2, 2, 0, True),        # dilation 2
     (1, 256, 8, 8, 256, 3, 1, 1, 1, 1, True),        # four K chunks per tap
+    # M >= 8192 pixels, >= 128 input channels: the window kernel (conv_bf16_halo_kernel: 256-pixel tiles, the input window staged once for all nine taps)
+    (90, 128, 10, 10, 64, 3, 1, 1, 1, 1, True),      # 9000 pixels: ragged last tile, tiles straddling images and image rows, 64-wide filter tile
+    (40, 128, 16, 16, 128, 3, 1, 1, 1, 0, True),     # two chunks (two window buffers), 128-wide filter tile
+    (9, 192, 40, 24, 64, 3, 1, 1, 1, 2, False),      # three chunks, non-square maps, leaky relu, no bias
 ]
 
 
