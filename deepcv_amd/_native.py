@@ -284,7 +284,8 @@ def load() -> ctypes.CDLL:
             if not LIB_PATH.exists():
                 raise RuntimeError(f'deepcv_amd: native library {LIB_PATH} is missing. Build it with `python -c "import __graft_entry__ as g; g.build()"` '
                                    f'or `make -C {CSRC_DIR}`; there is no CPU / PyTorch fallback for the hot path.')
-            cdll = ctypes.CDLL(str(LIB_PATH))
+            # DCV_LIB: another build of the SAME library (tools/make_variants.py: A/B experiments on the GPU box); never a fallback — it must export every symbol too
+            cdll = ctypes.CDLL(os.environ.get('DCV_LIB') or str(LIB_PATH))
             for name, (restype, argtypes) in _SIGNATURES.items():
                 fn = getattr(cdll, name)   # AttributeError if the library does not export a declared symbol
                 fn.restype, fn.argtypes = restype, argtypes

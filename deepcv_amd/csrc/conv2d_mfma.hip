@@ -218,6 +218,211 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaArgs a, const float*
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3 / stride 1 / pad 1 wide layers: the input window staged once per chunk
+// What the per-block time stamps of conv_mfma_kernel showed on 64 -> 64 @32x32, N = 512 (tools/variants/mfma_fwd_stamps.py, lesson 27 of DESIGN.md): the blocks of a
+// CU start together, run their K loops in lock step at 77 % of the matrix pipe (a barrier and a round of global -> VGPR -> LDS staging per 32 MFMAs of a wave) and
+// then all sit in a 20 us epilogue of 4-byte stores (19 % of a block's life, pipe idle); tools/probes/mfma16_probe.hip reaches 0.92 - 0.96 of the pipe with
+// fragment reads alone.  This kernel serves every wide layer of the BASELINE specs (3x3, stride 1, pad 1: forward and, with the flipped filter, data gradient):
+//   * block = 256 threads, tile = 256 consecutive output pixels x 64 channels, wave = 64 pixels x 64 channels (16 accumulator tiles).
+//   * per 16-channel chunk the FLAT input window of the tile — pixels m0 - W - 1 .. m0 + 255 + W + 1, zeros beyond the tensor — goes to LDS ONCE by LDS-DMA
+//     (buffer_load ... lds, 16 B per lane, no VGPR round trip) as [row][16 + 4 pad] floats (the pad lanes fetch out of range = zeros); tap (r, s) of pixel p reads row
+//     p + r W + s: nine times fewer bytes into LDS than a gather per tap, ONE barrier per nine taps (576 MFMAs per wave), double buffered.
+//   * a tap outside the image reads an all-zero row instead (the row behind the window): per tile row one base address + a 9-bit validity mask, 4 VALU
+//     instructions per fragment read in the shadow of 16 MFMAs.
+//   * filter fragments never touch LDS: every lane fetches its own 16 B of wb[co][tap][ci] (buffer_load_dwordx4, one VGPR of addressing, scalar offsets), one
+//     tap ahead in registers; the four waves fetch the same lines (L1 / L2 hits, 8 B/clk/CU).
+//   * operand roles swapped (A = filter, B = x): a lane holds FOUR CONSECUTIVE CHANNELS of one pixel per accumulator tile -> 16-byte stores, 64-B runs per pixel;
+//     per-channel statistics by DPP row sums over the 16 pixel lanes.
+// Registers: 64 accumulators + ~80 -> three blocks per CU (LDS 2 x (257 + 2 W + 2) x 80 B = 51.7 KB at W = 32).
+struct WinArgs {
+    int N, H, W, Cin, Cout;
+    int act; float slope;
+    int M;                         // N * H * W; x_bytes < 2^31 (32-bit buffer offsets)
+    unsigned x_bytes, w_bytes;
+    int nrows;                     // 256 + 2 W + 2 window rows; row `nrows` is the all-zero row
+    int tiles;                     // ceil(M / 256)
+};
+#define MW_OOB 0x80000000u        // buffer offset beyond any num_records: the load delivers zeros
+#define MW_ROWB 80                // bytes per window row: 16 floats + 4 pad (conflict-free ds_read_b128 over 16 consecutive rows)
+typedef __attribute__((address_space(3))) void* mw_lds_ptr;
+typedef unsigned mw_u32x4 __attribute__((ext_vector_type(4)));
+
+template <int CTRL> __device__ __forceinline__ float mw_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// sum over the 16 lanes of a DPP row (fixed order), result on every lane of the row
+__device__ __forceinline__ float mw_row_sum(float v) {
+    v += mw_dpp<0xB1>(v);                       // quad_perm [1, 0, 3, 2]
+    v += mw_dpp<0x4E>(v);                       // quad_perm [2, 3, 0, 1]
+    v += mw_dpp<0x141>(v);                      // row_half_mirror
+    v += mw_dpp<0x140>(v);                      // row_mirror
+    return v;
+}
+
+// PLAIN_ACT: no activation, ReLU or leaky ReLU as one select + one multiply (the 64 inlined copies of the general activation switch — expf, tanhf — are 8000
+// instructions and 120 VGPRs of epilogue: two waves per SIMD instead of three for the whole kernel)
+template <bool PLAIN_ACT>
+__global__ __launch_bounds__(256, 3) void conv_mfma_win_kernel(WinArgs a, const float* __restrict__ x, const float* __restrict__ wb, const float* __restrict__ bias,
+                                                             float* __restrict__ y, double* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) char mw_lds[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
+    // consecutive block indices go to different XCDs: give every XCD a contiguous range of tiles (neighbouring tiles share their halo rows in that XCD's L2)
+    int tile = blockIdx.x;
+    if ((a.tiles & 7) == 0) tile = (int)(blockIdx.x & 7u) * (a.tiles >> 3) + (int)(blockIdx.x >> 3);
+    const int m0 = tile * 256, n0 = blockIdx.y * 64;
+    const int W = a.W, H = a.H;
+    const int win_bytes = (a.nrows + 1) * MW_ROWB, pieces = (a.nrows + 1) * 5;
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)a.x_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, (int)a.w_bytes, 0x00020000);
+
+    // ---- window staging: 16-B piece g of a buffer = row g / 5, slot g % 5 (slot 4: the pad); window row `row` = flat pixel q0 + row
+    const int q0 = m0 - W - 1;
+    auto stage = [&](int buf, int chunk) {
+        char* base = mw_lds + buf * win_bytes;
+        for (int g0 = 0; g0 < pieces; g0 += 256) {                 // (uniform trip count)
+            const int g = g0 + t;
+            const int row = (g * 52429) >> 18;                     // g / 5 (exact below 2^16)
+            const int slot = g - 5 * row;
+            const int q = q0 + row;
+            const bool v = slot < 4 && row < a.nrows && q >= 0 && q < a.M;
+            const unsigned vo = v ? (unsigned)(q * a.Cin + slot * 4) * 4u : MW_OOB;
+            if (g < pieces) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (mw_lds_ptr)(base + (g0 + (t & ~63)) * 16), 16, (int)vo, chunk * 64, 0, 0);
+        }
+    };
+
+    // ---- operands of tile row i of this wave: pixel pl = 64 wave + 16 i + li of the block; tap (r, s) -> window row pl + r W + s, the lane's four channels at + 16 lg
+    unsigned xbase[4], vmask[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pl = 64 * wave + 16 * i + li;
+        const int m = m0 + pl;
+        const bool ok = m < a.M;
+        const unsigned mm = ok ? (unsigned)m : 0u;
+        const int wo = (int)(mm % (unsigned)W), ho = (int)((mm / (unsigned)W) % (unsigned)H);
+        unsigned mk = 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int hi = ho + r - 1, wi = wo + s - 1;
+                if (ok && hi >= 0 && hi < H && wi >= 0 && wi < W) mk |= 1u << (r * 3 + s);
+            }
+        xbase[i] = (unsigned)(pl * MW_ROWB + lg * 16);
+        vmask[i] = mk;
+    }
+    const unsigned zaddr = (unsigned)(a.nrows * MW_ROWB + lg * 16);
+
+    // ---- filter fragments: lane (li, lg) of tile j, tap, chunk: wb[n0 + 16 j + li][tap][16 chunk + 4 lg ..]
+    const int wvo = ((n0 + li) * 9 * a.Cin + 4 * lg) * 4;
+    auto wload = [&](f32x4 (&w)[4], int chunk, int tap) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, wvo, ((j * 144 + tap) * a.Cin + 16 * chunk) * 4, 0));
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int cchunks = a.Cin / 16;
+    f32x4 wa[4], wb2[4];                                           // filter fragments of the tap in flight and of the next one (register double buffer)
+    stage(0, 0);
+    wload(wa, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int chunk = 0; chunk < cchunks; ++chunk) {
+        // the operand addresses are loop invariants the optimiser would keep in 36 registers (and push the kernel to two waves per SIMD): recompute them per tap
+        const unsigned wino = (unsigned)((chunk & 1) * win_bytes);
+        unsigned xb[4], zb = zaddr + wino;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { xb[i] = xbase[i] + wino; asm volatile("" : "+v"(vmask[i]), "+v"(xb[i])); }
+        asm volatile("" : "+v"(zb));
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            f32x4 (&wc)[4] = (tap & 1) ? wb2 : wa;
+            f32x4 (&wn)[4] = (tap & 1) ? wa : wb2;
+            if (tap < 8) wload(wn, chunk, tap + 1);                // requested a whole tap (64 MFMAs) before their first use
+            else if (chunk + 1 < cchunks) wload(wn, chunk + 1, 0);
+            const unsigned d = (unsigned)(((tap / 3) * W + (tap % 3)) * MW_ROWB);
+            f32x4 xv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned ad = ((vmask[i] >> tap) & 1u) ? xb[i] + d : zb;
+                xv[i] = *reinterpret_cast<const f32x4*>(mw_lds + ad);
+            }
+            __builtin_amdgcn_sched_barrier(0);                     // (the scheduler would sink the loads behind the last use of the registers they overwrite)
+            // the next window goes to the other buffer (last read in the previous chunk, which ended with a barrier); requested behind the first tap's operands:
+            // vmcnt counts in order, so a wait for filter fragments also waits for every DMA issued before them
+            if (tap == 0 && chunk + 1 < cchunks) stage((chunk + 1) & 1, chunk + 1);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[j][kk], xv[i][kk], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wa[j] = wb2[j];                // (nine taps: the fragments of the next chunk's first tap arrived in the second set)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's pieces of the next window have landed ...
+        __syncthreads();                                           // ... and everybody's; every wave is done reading this one
+    }
+
+    // ---- epilogue: acc[i][j][r] -> pixel m0 + 64 wave + 16 i + li, channel n0 + 16 j + 4 lg + r
+    float ssum[4][4], ssq[4][4];
+    float4 bv[4];
+    const float neg = a.act == DCV_ACT_NONE ? 1.f : (a.act == DCV_ACT_RELU ? 0.f : a.slope);       // PLAIN_ACT: factor of the negative side
+    auto actf = [&](float v) { if constexpr (PLAIN_ACT) return v > 0.f ? v : v * neg; else return dcv_act_apply(v, a.act, a.slope); };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        bv[j] = bias ? *reinterpret_cast<const float4*>(bias + n0 + 16 * j + 4 * lg) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ssum[j][r] = 0.f; ssq[j][r] = 0.f; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + 64 * wave + 16 * i + li;
+        if (m < a.M) {
+            float* yp = y + (size_t)m * a.Cout + n0 + 4 * lg;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float4 o;
+                // the accumulators live in AGPRs; read here, one tile at a time (left alone, the register allocator copies all 64 into VGPRs at the loop exit: 120
+                // VGPRs and two waves per SIMD for the whole kernel)
+                float c0, c1, c2, c3;
+                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(c0) : "a"(acc[i][j][0]));
+                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(c1) : "a"(acc[i][j][1]));
+                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(c2) : "a"(acc[i][j][2]));
+                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(c3) : "a"(acc[i][j][3]));
+                o.x = actf(c0 + bv[j].x); o.y = actf(c1 + bv[j].y); o.z = actf(c2 + bv[j].z); o.w = actf(c3 + bv[j].w);
+                *reinterpret_cast<float4*>(yp + 16 * j) = o;
+                ssum[j][0] += o.x; ssq[j][0] += o.x * o.x; ssum[j][1] += o.y; ssq[j][1] += o.y * o.y;
+                ssum[j][2] += o.z; ssq[j][2] += o.z * o.z; ssum[j][3] += o.w; ssq[j][3] += o.w * o.w;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);                         // one tile row at a time: the scheduler would first move all 64 accumulators into VGPRs (120 registers)
+    }
+    if (stats != nullptr) {
+        // BatchNorm statistics partials of this 256-pixel tile: the 16 pixel lanes of a row (DPP, fixed order), then the four waves through LDS (the windows are dead:
+        // the loop ended with a barrier)
+        double* red = reinterpret_cast<double*>(mw_lds);           // [4 waves][2][64]
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s1 = mw_row_sum(ssum[j][r]), s2 = mw_row_sum(ssq[j][r]);
+                if (li == 0) { red[(wave * 2 + 0) * 64 + 16 * j + 4 * lg + r] = (double)s1; red[(wave * 2 + 1) * 64 + 16 * j + 4 * lg + r] = (double)s2; }
+            }
+        __syncthreads();
+        if (t < 128) {
+            const int q = t >> 6, c = t & 63;
+            const double v = ((red[(0 * 2 + q) * 64 + c] + red[(1 * 2 + q) * 64 + c]) + red[(2 * 2 + q) * 64 + c]) + red[(3 * 2 + q) * 64 + c];
+            stats[((size_t)q * a.Cout + n0 + c) * a.tiles + tile] = v;                             // [2][Cout][rows]
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradient
 // dW[co][tap][ci] = sum_m dy[m][co] * x[m (+) tap][ci].  Block = (pixel chunk, tap, 64-channel column tile of ci, 64-row tile of co).
 // MFMA roles: A'[i = co][k = pixel], B'[k = pixel][j = ci].  Pixel tiles of 16 are staged in LDS in their natural [pixel][channel] layouts; lane (i, g)
@@ -864,6 +1069,23 @@ static bool halo_plan(const MfmaArgs& m, int math, HaloArgs* h, size_t* smem) {
     return true;
 }
 
+// the window kernel's plan: fp32 3x3 / stride 1 / pad 1 / no dilation on the whole tensor (not a phase of a strided data gradient), 64-aligned output channels,
+// 32-bit buffer offsets, at least one block per CU.  DCV_MFMA_WIN=0 switches it off, =2 forces it for every shape it can run.
+static bool win_plan(const MfmaArgs& m, int math, WinArgs* w, size_t* smem) {
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("DCV_MFMA_WIN"); mode = e ? atoi(e) : 1; }
+    if (mode == 0 || math != DCV_MATH_FP32 || m.phase || m.R != 3 || m.S != 3 || m.sh != 1 || m.sw != 1 || m.ph != 1 || m.pw != 1 || m.dh != 1 || m.dw != 1) return false;
+    if (m.Hin != m.Hout || m.Win != m.Wout || m.Cout % 64 != 0 || m.Cin % 16 != 0 || m.Win > 256) return false;
+    if ((size_t)m.M * m.Cin * 4 >= ((size_t)1 << 31) || (size_t)m.Cout * 9 * m.Cin * 4 >= ((size_t)1 << 31)) return false;
+    const int tiles = (int)((m.M + 255) / 256);
+    if (mode != 2 && (long)tiles * (m.Cout / 64) < DCV_NUM_CU) return false;
+    w->N = m.N; w->H = m.Hin; w->W = m.Win; w->Cin = m.Cin; w->Cout = m.Cout; w->act = m.act; w->slope = m.slope; w->M = (int)m.M;
+    w->x_bytes = (unsigned)((size_t)m.M * m.Cin * 4); w->w_bytes = (unsigned)((size_t)m.Cout * 9 * m.Cin * 4);
+    w->nrows = 256 + 2 * m.Win + 2; w->tiles = tiles;
+    *smem = (size_t)2 * (w->nrows + 1) * MW_ROWB;
+    return true;
+}
+
 template <bool BF16>
 static void launch_mfma(int bn, int bmr, dim3 grid, hipStream_t st, const MfmaArgs& a, const float* x, const float* wb, const float* bias, float* y, double* stats) {
     if (bmr == 4) hipLaunchKernelGGL((conv_mfma_kernel<64, 4, BF16>), grid, dim3(256), 0, st, a, x, wb, bias, y, stats);
@@ -885,6 +1107,19 @@ static int run_mfma(const MfmaArgs& a, const float* x, const float* wb, const fl
 #undef DCV_HALO
         return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
     }
+    WinArgs wa{}; size_t wsm;
+    if (win_plan(a, math, &wa, &wsm)) {
+        static bool conf = false;
+        if (!conf) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_win_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DCV_ERR_LAUNCH;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_win_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DCV_ERR_LAUNCH;
+            conf = true;
+        }
+        const dim3 wgrid((unsigned)wa.tiles, (unsigned)(a.Cout / 64));
+        if (a.act == DCV_ACT_NONE || a.act == DCV_ACT_RELU || a.act == DCV_ACT_LEAKY_RELU) hipLaunchKernelGGL(conv_mfma_win_kernel<true>, wgrid, dim3(256), wsm, st, wa, x, wb, bias, y, stats);
+        else hipLaunchKernelGGL(conv_mfma_win_kernel<false>, wgrid, dim3(256), wsm, st, wa, x, wb, bias, y, stats);
+        return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
+    }
     const int bn = pick_bn(a.Cout);
     const int bmr = pick_bmr(a.M, a.Cin, a.Cout, bn);
     dim3 grid((unsigned)dcv_ceil_div((size_t)a.M, (size_t)64 * bmr), (unsigned)(a.Cout / bn));
@@ -903,7 +1138,15 @@ int dcv_mfma_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d, int* rows_per_sampl
         if (halo_plan(a, d->math, &h, &hsm)) { if (rows_per_sample) *rows_per_sample = h.tiles_per_img; return h.total_tiles; }
     }
     const long M = (long)d->n * d->ho * d->wo;
-    const int tile = 64 * pick_bmr(M, d->cin, d->cout, pick_bn(d->cout));
+    bool win = false;
+    {   // the window kernel: 256-pixel tiles
+        MfmaArgs a{};
+        a.N = d->n; a.Hin = d->h; a.Win = d->w; a.Cin = d->cin; a.Hout = d->ho; a.Wout = d->wo; a.Cout = d->cout;
+        a.R = d->r; a.S = d->s; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w; a.M = M;
+        WinArgs wa{}; size_t wsm;
+        win = win_plan(a, d->math, &wa, &wsm);
+    }
+    const int tile = win ? 256 : 64 * pick_bmr(M, d->cin, d->cout, pick_bn(d->cout));
     if (rows_per_sample && (d->ho * d->wo) % tile == 0) *rows_per_sample = d->ho * d->wo / tile;    // pixel tiles which never straddle images
     return (int)dcv_ceil_div((size_t)M, (size_t)tile);
 }

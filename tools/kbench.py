@@ -18,7 +18,7 @@ def conv_case(n, cin, h, w, cout, k, pad):
     return x, wt, b, y, dy, d
 st = nat.current_stream(dev)
 CONVS = {'conv350': (NB, 3, 32, 32, 4, 5, 2), 'conv450': (NB, 4, 32, 32, 4, 5, 2), 'conv1630': (NB, 16, 16, 16, 16, 3, 1), 'conv430': (NB, 4, 16, 16, 16, 3, 1), 'conv6430': (NB, 64, 32, 32, 64, 3, 1),
-         'conv12830': (NB, 128, 16, 16, 128, 3, 1), 'conv51230': (NB, 512, 4, 4, 512, 3, 1)}
+         'conv12830': (NB, 128, 16, 16, 128, 3, 1), 'conv25630': (NB, 256, 8, 8, 256, 3, 1), 'conv51230': (NB, 512, 4, 4, 512, 3, 1)}
 if case == 'conv350n':     # first layer: NCHW input read in place
     cfg = CONVS['conv350']
     x, wt, b, y, dy, d = conv_case(*cfg)
@@ -60,6 +60,13 @@ elif case in CONVS:
     x, wt, b, y, dy, d = conv_case(*cfg)
     wsf = torch.empty(max(16, nat.lib.dcv_conv2d_fwd_workspace_bytes(d)), dtype=torch.uint8, device=dev)
     fn = lambda: nat.check(nat.lib.dcv_conv2d_fwd(d, x.data_ptr(), wt.data_ptr(), b.data_ptr(), y.data_ptr(), wsf.data_ptr(), wsf.numel(), st))
+elif case.startswith('dgrad') and ('conv' + case[5:]) in CONVS:
+    cfg = CONVS['conv' + case[5:]]
+    x, wt, b, y, dy, d = conv_case(*cfg)
+    d.act = nat.ACT_NONE
+    dx = torch.empty_like(x)
+    ws = torch.empty(max(16, nat.lib.dcv_conv2d_dgrad_workspace_bytes(d)), dtype=torch.uint8, device=dev)
+    fn = lambda: nat.check(nat.lib.dcv_conv2d_dgrad(d, dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), ws.data_ptr(), ws.numel(), st))
 elif case.startswith('wgrad') and ('conv' + case[5:]) in CONVS:
     cfg = CONVS['conv' + case[5:]]
     x, wt, b, y, dy, d = conv_case(*cfg)
@@ -76,3 +83,14 @@ us = e0.elapsed_time(e1) * 1e3 / launches
 n_, cin_, h_, w_, cout_, k_, _p = cfg
 flops = 2.0 * n_ * h_ * w_ * cout_ * cin_ * k_ * k_
 print(case, 'avg us', round(us, 2), 'TFLOP/s', round(flops / us / 1e6, 2))
+if __import__('os').environ.get('DCV_KBENCH_STAMPS') and case.endswith('p'):     # a tools/variants/*_stamps.py library: per-block time stamps (100 MHz) in the statistics buffer
+    nb = int(__import__('os').environ['DCV_KBENCH_STAMPS'])
+    stats.zero_(); torch.cuda.synchronize(); fn(); torch.cuda.synchronize()
+    s = stats.flatten()[:nb * 4].reshape(nb, 4).cpu().numpy() * 0.01       # us
+    t0 = s[:, 0].min()
+    import numpy as np
+    print('blocks', nb, 'span us', round(float(s[:, 3].max() - t0), 1))
+    print('mean prologue', round(float((s[:, 1] - s[:, 0]).mean()), 2), 'loop', round(float((s[:, 2] - s[:, 1]).mean()), 2), 'epilogue', round(float((s[:, 3] - s[:, 2]).mean()), 2))
+    order = np.argsort(s[:, 0])
+    print('entry times (sorted, every 64th):', np.round(s[order, 0][::64] - t0, 1).tolist())
+    print('exit times of the same blocks   :', np.round(s[order, 3][::64] - t0, 1).tolist())

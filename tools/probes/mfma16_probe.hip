@@ -1,0 +1,110 @@
+// mfma16_probe.hip — what bounds the fp32 implicit-GEMM loop of conv2d_mfma.hip (v_mfma_f32_16x16x4_f32, 256-thread blocks, 256 x 64 tile, K chunks of 16)?
+//   mode 0: 64 MFMAs per iteration on 16 accumulator tiles, operands in registers (the matrix pipe's rate at the clock the chip holds)
+//   mode 1: + the 8 ds_read_b128 fragment reads of a chunk
+//   mode 2: + 5 global float4 loads issued before the MFMAs, 5 ds_write_b128 + one barrier after them (the kernel's loop, addresses advancing by 64 B)
+//   mode 3: mode 2 with the MFMAs interleaved with the other instructions by sched_group_barrier
+// each with 1, 2, 3 resident blocks per CU (dynamic LDS pads the block to 160 KB / B).
+//   hipcc --offload-arch=gfx950 -O3 tools/probes/mfma16_probe.hip -o build/probes/mfma16_probe && build/probes/mfma16_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int ITER = 576;            // chunks per tile in the probe (16 tiles' worth of the 64 -> 64 3x3 layer)
+constexpr int LD = 20;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void loop(const float* __restrict__ x, float* __restrict__ out, size_t xfloats) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* As = lds;                       // [2][256 * LD]
+    float* Bs = lds + 2 * 256 * LD;        // [2][64 * LD]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4, q = t & 3;
+    for (int i = t; i < 2 * 320 * LD; i += 256) lds[i] = 0.001f * (float)(i & 127);
+    __syncthreads();
+    f4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+    f4 af[4], bf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { af[i] = (f4){1.f + lane, 2.f, 3.f, 4.f}; bf[i] = (f4){0.5f, 0.25f * lane, 1.f, 2.f}; }
+    const float* ap[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ap[j] = x + (((size_t)blockIdx.x * 256 + (t >> 2) + 64 * j) * 64 + 4 * q) % (xfloats - 64 * ITER * 16);
+    const float* bp = x + 4 * q + (size_t)(t >> 2) * 576;
+    f4 va[4], vb;
+    for (int c = 0; c < ITER; ++c) {
+        const int buf = c & 1;
+        if (MODE >= 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { va[j] = *reinterpret_cast<const f4*>(ap[j]); ap[j] += 16; }
+            vb = *reinterpret_cast<const f4*>(bp); bp += 16; if ((c & 31) == 31) bp -= 512;
+        }
+        if (MODE >= 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const f4*>(&As[buf * 256 * LD + (wave * 64 + i * 16 + li) * LD + 4 * lg]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f4*>(&Bs[buf * 64 * LD + (j * 16 + li) * LD + 4 * lg]);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+        if (MODE >= 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<f4*>(&As[(buf ^ 1) * 256 * LD + ((t >> 2) + 64 * j) * LD + 4 * q]) = va[j];
+            *reinterpret_cast<f4*>(&Bs[(buf ^ 1) * 64 * LD + (t >> 2) * LD + 4 * q]) = vb;
+            if (MODE == 3) {
+                // per chunk: 64 MFMA, 5 VMEM reads, 8 DS reads, 5 DS writes: spread them
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);      // 8 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // 1 DS write
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // some VALU
+                }
+            }
+            __syncthreads();
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    out[(size_t)blockIdx.x * 256 + t] = s;
+}
+
+template <int MODE>
+int run(const float* x, float* out, size_t xfloats, int per_cu) {
+    const size_t smem = per_cu == 1 ? 150 * 1024 : (per_cu == 2 ? 78 * 1024 : 51200);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(loop<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    const int grid = 256 * per_cu * 4;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(loop<MODE>, dim3(grid), dim3(256), smem, 0, x, out, xfloats);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(loop<MODE>, dim3(grid), dim3(256), smem, 0, x, out, xfloats);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
+    const double flops = (double)grid * 4 * ITER * 64 * 2.0 * 1024;
+    printf("mode %d, %d block(s)/CU: %.1f us, %.1f TF (%.2f of 157.3)\n", MODE, per_cu, ms * 1e3, flops / ms * 1e-9, flops / ms * 1e-9 / 157.3);
+    return 0;
+}
+
+int main() {
+    const size_t xfloats = (size_t)512 * 1024 * 64;     // the 64-channel 32x32 activation of 512 images
+    float *x, *out;
+    CK(hipMalloc(&x, xfloats * 4)); CK(hipMemset(x, 0, xfloats * 4)); CK(hipMalloc(&out, (size_t)256 * 12 * 256 * 4));
+    for (int b = 1; b <= 3; ++b) {
+        if (run<0>(x, out, xfloats, b)) return 1;
+        if (run<1>(x, out, xfloats, b)) return 1;
+        if (run<2>(x, out, xfloats, b)) return 1;
+        if (run<3>(x, out, xfloats, b)) return 1;
+    }
+    return 0;
+}
