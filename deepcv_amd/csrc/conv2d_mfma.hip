@@ -18,6 +18,7 @@
 // Replaces torch.nn.Conv2d forward/backward (reference src/deepcv/meta/submodule_creators.py:251, ignite_training.py:253) for wide layers.
 #include "conv2d_internal.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -219,33 +220,41 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaArgs a, const float*
 }
 
 // ------------------------------------------------------------------------------------------------ 3x3 / stride 1 / pad 1 wide layers: the input window staged once per chunk
-// What the per-block time stamps of conv_mfma_kernel showed on 64 -> 64 @32x32, N = 512 (tools/variants/mfma_fwd_stamps.py, lesson 27 of DESIGN.md): the blocks of a
-// CU start together, run their K loops in lock step at 77 % of the matrix pipe (a barrier and a round of global -> VGPR -> LDS staging per 32 MFMAs of a wave) and
-// then all sit in a 20 us epilogue of 4-byte stores (19 % of a block's life, pipe idle); tools/probes/mfma16_probe.hip reaches 0.92 - 0.96 of the pipe with
-// fragment reads alone.  This kernel serves every wide layer of the BASELINE specs (3x3, stride 1, pad 1: forward and, with the flipped filter, data gradient):
+// What the per-block time stamps of conv_mfma_kernel showed on 64 -> 64 @32x32, N = 512 (tools/variants/mfma_fwd_stamps.py, lessons 27 - 29 of DESIGN.md): the blocks
+// of a CU start together, run their K loops in lock step at 77 % of the matrix pipe (a barrier and a round of global -> VGPR -> LDS staging per 32 MFMAs of a wave)
+// and then all sit in a 20 us epilogue of 4-byte stores (19 % of a block's life, pipe idle).  And tools/probes/mfma16_probe.hip: the matrix pipe and the VALU share
+// the SIMD's issue port ACROSS waves — time = 32 clocks per MFMA + ~4 per VALU instruction of any resident wave — so every address computation anywhere in the
+// kernel is paid in matrix-pipe time.  This kernel serves every wide layer of the BASELINE specs (3x3, stride 1, pad 1: forward and, with the flipped filter, data
+// gradient) with four vector-ALU instructions per 64 MFMAs in its K loop:
 //   * block = 256 threads, tile = 256 consecutive output pixels x 64 channels, wave = 64 pixels x 64 channels (16 accumulator tiles).
 //   * per 16-channel chunk the FLAT input window of the tile — pixels m0 - W - 1 .. m0 + 255 + W + 1, zeros beyond the tensor — goes to LDS ONCE by LDS-DMA
-//     (buffer_load ... lds, 16 B per lane, no VGPR round trip) as [row][16 + 4 pad] floats (the pad lanes fetch out of range = zeros); tap (r, s) of pixel p reads row
-//     p + r W + s: nine times fewer bytes into LDS than a gather per tap, ONE barrier per nine taps (576 MFMAs per wave), double buffered.
-//   * a tap outside the image reads an all-zero row instead (the row behind the window): per tile row one base address + a 9-bit validity mask, 4 VALU
-//     instructions per fragment read in the shadow of 16 MFMAs.
+//     (buffer_load ... lds, 16 B per lane, no VGPR round trip) as [row][16 + 4 pad] floats; tap (r, s) of pixel p reads row p + r W + s: nine times fewer bytes
+//     into LDS than a gather per tap, ONE barrier per nine taps (576 MFMAs per wave), double buffered.  A DMA instruction of a wave covers 12 rows (lane l: row
+//     l / 5, slot l % 5; slot 4 is the pad and fetches out of range = zeros; lanes 60 - 63 repeat the first four pieces of the next instruction's first row), so a
+//     lane's offsets advance by a constant: one add per piece.  Offsets are computed modulo 2^32: pixels in front of the tensor wrap beyond num_records, pixels
+//     behind it exceed it — both read zeros without a compare.
+//   * a tap outside the image reads the buffer's all-zero row instead: every lane keeps the 36 LDS addresses (4 tile rows x 9 taps) it will ever use, computed
+//     once per block (two 16-bit addresses per register: one shift / mask per fragment read is all the vector ALU does in the K loop); the second window buffer
+//     lies a compile-time distance behind the first (BSTRIDE: the ds_read's immediate offset).
 //   * filter fragments never touch LDS: every lane fetches its own 16 B of wb[co][tap][ci] (buffer_load_dwordx4, one VGPR of addressing, scalar offsets), one
 //     tap ahead in registers; the four waves fetch the same lines (L1 / L2 hits, 8 B/clk/CU).
 //   * operand roles swapped (A = filter, B = x): a lane holds FOUR CONSECUTIVE CHANNELS of one pixel per accumulator tile -> 16-byte stores, 64-B runs per pixel;
 //     per-channel statistics by DPP row sums over the 16 pixel lanes.
-// Registers: 64 accumulators + ~80 -> three blocks per CU (LDS 2 x (257 + 2 W + 2) x 80 B = 51.7 KB at W = 32).
+// Registers: __launch_bounds__(256, 3) = a budget of 168 <= 256 registers, which makes the compiler keep the accumulators in VGPRs (v_mfma ... vgprcd) instead of
+// splitting the budget evenly between VGPRs and AGPRs; three blocks per CU (LDS 2 x 26 KB at W <= 32).
 struct WinArgs {
     int N, H, W, Cin, Cout;
     int act; float slope;
     int M;                         // N * H * W; x_bytes < 2^31 (32-bit buffer offsets)
     unsigned x_bytes, w_bytes;
-    int nrows;                     // 256 + 2 W + 2 window rows; row `nrows` is the all-zero row
+    int nrows;                     // 256 + 2 W + 2 window rows
+    int ninstr;                    // DMA wave instructions per window: ceil(nrows / 12)
     int tiles;                     // ceil(M / 256)
+    unsigned magic_w, magic_h;     // floor((2^32 - 1) / d) + 1: n / d = mulhi(n, magic) for n d < 2^32
 };
 #define MW_OOB 0x80000000u        // buffer offset beyond any num_records: the load delivers zeros
 #define MW_ROWB 80                // bytes per window row: 16 floats + 4 pad (conflict-free ds_read_b128 over 16 consecutive rows)
 typedef __attribute__((address_space(3))) void* mw_lds_ptr;
-typedef unsigned mw_u32x4 __attribute__((ext_vector_type(4)));
 
 template <int CTRL> __device__ __forceinline__ float mw_dpp(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
@@ -259,58 +268,59 @@ __device__ __forceinline__ float mw_row_sum(float v) {
     return v;
 }
 
+// window buffer = [zero row][window rows 0 .. 12 ninstr]; buffer 1 starts BSTRIDE bytes behind buffer 0
 // PLAIN_ACT: no activation, ReLU or leaky ReLU as one select + one multiply (the 64 inlined copies of the general activation switch — expf, tanhf — are 8000
-// instructions and 120 VGPRs of epilogue: two waves per SIMD instead of three for the whole kernel)
-template <bool PLAIN_ACT>
+// instructions and 120 VGPRs of epilogue)
+template <bool PLAIN_ACT, int BSTRIDE>
 __global__ __launch_bounds__(256, 3) void conv_mfma_win_kernel(WinArgs a, const float* __restrict__ x, const float* __restrict__ wb, const float* __restrict__ bias,
-                                                             float* __restrict__ y, double* __restrict__ stats) {
+                                                                float* __restrict__ y, double* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char mw_lds[];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), li = lane & 15, lg = lane >> 4;
     // consecutive block indices go to different XCDs: give every XCD a contiguous range of tiles (neighbouring tiles share their halo rows in that XCD's L2)
     int tile = blockIdx.x;
     if ((a.tiles & 7) == 0) tile = (int)(blockIdx.x & 7u) * (a.tiles >> 3) + (int)(blockIdx.x >> 3);
     const int m0 = tile * 256, n0 = blockIdx.y * 64;
     const int W = a.W, H = a.H;
-    const int win_bytes = (a.nrows + 1) * MW_ROWB, pieces = (a.nrows + 1) * 5;
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)a.x_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, (int)a.w_bytes, 0x00020000);
+    if (t < 10) *reinterpret_cast<float4*>(mw_lds + (t >= 5 ? BSTRIDE : 0) + (t % 5) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);       // the two zero rows
 
-    // ---- window staging: 16-B piece g of a buffer = row g / 5, slot g % 5 (slot 4: the pad); window row `row` = flat pixel q0 + row
-    const int q0 = m0 - W - 1;
+    // ---- window staging: DMA instruction idx = 4 k + wave of a buffer covers window rows 12 idx .. 12 idx + 12 (+ 4 pieces); window row R = flat pixel m0 - W - 1 + R
+    const int lrow = (lane * 13) >> 6, lslot = lane - 5 * lrow;                 // lane / 5, lane % 5
+    const unsigned vstep = (unsigned)(48 * a.Cin * 4);                           // four instructions (one per wave) further
+    const unsigned vb0 = lslot < 4 ? (unsigned)((m0 - W - 1 + 12 * wave + lrow) * a.Cin * 4 + lslot * 16) : MW_OOB;       // (mod 2^32, see above)
+    const int kinstr = (a.ninstr + 3) >> 2;
     auto stage = [&](int buf, int chunk) {
-        char* base = mw_lds + buf * win_bytes;
-        for (int g0 = 0; g0 < pieces; g0 += 256) {                 // (uniform trip count)
-            const int g = g0 + t;
-            const int row = (g * 52429) >> 18;                     // g / 5 (exact below 2^16)
-            const int slot = g - 5 * row;
-            const int q = q0 + row;
-            const bool v = slot < 4 && row < a.nrows && q >= 0 && q < a.M;
-            const unsigned vo = v ? (unsigned)(q * a.Cin + slot * 4) * 4u : MW_OOB;
-            if (g < pieces) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (mw_lds_ptr)(base + (g0 + (t & ~63)) * 16), 16, (int)vo, chunk * 64, 0, 0);
+        char* base = mw_lds + buf * BSTRIDE + MW_ROWB + wave * 960;
+        unsigned vo = vb0;
+        for (int k = 0; k < kinstr; ++k) {
+            if (4 * k + wave < a.ninstr) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (mw_lds_ptr)(base + k * 3840), 16, (int)vo, chunk * 64, 0, 0);
+            vo += vstep;
         }
     };
 
-    // ---- operands of tile row i of this wave: pixel pl = 64 wave + 16 i + li of the block; tap (r, s) -> window row pl + r W + s, the lane's four channels at + 16 lg
-    unsigned xbase[4], vmask[4];
+    // ---- operands of tile row i of this wave: pixel pl = 64 wave + 16 i + li of the block; tap (r, s) -> window row pl + r W + s, the lane's four channels at + 16 lg;
+    // a tap outside the image -> the zero row (buffer offset 0)
+    const unsigned wo0 = (unsigned)m0 - __umulhi((unsigned)m0, a.magic_w) * (unsigned)W;               // (uniform: scalar unit)
+    const unsigned r0 = __umulhi((unsigned)m0, a.magic_w), ho0 = r0 - __umulhi(r0, a.magic_h) * (unsigned)H;
+    unsigned xad[4][5];                                            // two 16-bit LDS addresses per register: taps 2 q (low half) and 2 q + 1
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int pl = 64 * wave + 16 * i + li;
-        const int m = m0 + pl;
-        const bool ok = m < a.M;
-        const unsigned mm = ok ? (unsigned)m : 0u;
-        const int wo = (int)(mm % (unsigned)W), ho = (int)((mm / (unsigned)W) % (unsigned)H);
-        unsigned mk = 0;
+        const unsigned u = wo0 + (unsigned)pl, dq = __umulhi(u, a.magic_w), wo = u - dq * (unsigned)W;
+        const unsigned v = ho0 + dq, ho = v - __umulhi(v, a.magic_h) * (unsigned)H;
+        const bool ok = m0 + pl < a.M;
+        const bool rok[3] = {ok && ho > 0, ok, ok && ho + 1 < (unsigned)H}, cok[3] = {wo > 0, true, wo + 1 < (unsigned)W};
+        const unsigned base = (unsigned)(MW_ROWB + pl * MW_ROWB + lg * 16);
+        unsigned ad[10];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const int hi = ho + r - 1, wi = wo + s - 1;
-                if (ok && hi >= 0 && hi < H && wi >= 0 && wi < W) mk |= 1u << (r * 3 + s);
-            }
-        xbase[i] = (unsigned)(pl * MW_ROWB + lg * 16);
-        vmask[i] = mk;
+            for (int s2 = 0; s2 < 3; ++s2) ad[r * 3 + s2] = (rok[r] && cok[s2]) ? base + (unsigned)((r * W + s2) * MW_ROWB) : (unsigned)(lg * 16);
+        ad[9] = 0;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) xad[i][q] = ad[2 * q] | (ad[2 * q + 1] << 16);
     }
-    const unsigned zaddr = (unsigned)(a.nrows * MW_ROWB + lg * 16);
 
     // ---- filter fragments: lane (li, lg) of tile j, tap, chunk: wb[n0 + 16 j + li][tap][16 chunk + 4 lg ..]
     const int wvo = ((n0 + li) * 9 * a.Cin + 4 * lg) * 4;
@@ -331,30 +341,27 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_win_kernel(WinArgs a, const 
     wload(wa, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int chunk = 0; chunk < cchunks; ++chunk) {
-        // the operand addresses are loop invariants the optimiser would keep in 36 registers (and push the kernel to two waves per SIMD): recompute them per tap
-        const unsigned wino = (unsigned)((chunk & 1) * win_bytes);
-        unsigned xb[4], zb = zaddr + wino;
+    // one chunk: nine taps out of window buffer PAR (a compile-time distance: the immediate offset of the ds_reads)
+    auto chunk_body = [&](auto par, int chunk) {
+        constexpr int PAR = decltype(par)::value;
+        // (the unpacked addresses are loop invariants: hoisted, they would need 36 registers the kernel does not have)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { xb[i] = xbase[i] + wino; asm volatile("" : "+v"(vmask[i]), "+v"(xb[i])); }
-        asm volatile("" : "+v"(zb));
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 5; ++q) asm volatile("" : "+v"(xad[i][q]));
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             f32x4 (&wc)[4] = (tap & 1) ? wb2 : wa;
             f32x4 (&wn)[4] = (tap & 1) ? wa : wb2;
             if (tap < 8) wload(wn, chunk, tap + 1);                // requested a whole tap (64 MFMAs) before their first use
             else if (chunk + 1 < cchunks) wload(wn, chunk + 1, 0);
-            const unsigned d = (unsigned)(((tap / 3) * W + (tap % 3)) * MW_ROWB);
             f32x4 xv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const unsigned ad = ((vmask[i] >> tap) & 1u) ? xb[i] + d : zb;
-                xv[i] = *reinterpret_cast<const f32x4*>(mw_lds + ad);
-            }
+            for (int i = 0; i < 4; ++i) xv[i] = *reinterpret_cast<const f32x4*>(mw_lds + PAR * BSTRIDE + ((tap & 1) ? xad[i][tap >> 1] >> 16 : xad[i][tap >> 1] & 0xFFFFu));
             __builtin_amdgcn_sched_barrier(0);                     // (the scheduler would sink the loads behind the last use of the registers they overwrite)
             // the next window goes to the other buffer (last read in the previous chunk, which ended with a barrier); requested behind the first tap's operands:
             // vmcnt counts in order, so a wait for filter fragments also waits for every DMA issued before them
-            if (tap == 0 && chunk + 1 < cchunks) stage((chunk + 1) & 1, chunk + 1);
+            if (tap == 0 && chunk + 1 < cchunks) stage(PAR ^ 1, chunk + 1);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -367,7 +374,10 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_win_kernel(WinArgs a, const 
         for (int j = 0; j < 4; ++j) wa[j] = wb2[j];                // (nine taps: the fragments of the next chunk's first tap arrived in the second set)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's pieces of the next window have landed ...
         __syncthreads();                                           // ... and everybody's; every wave is done reading this one
-    }
+    };
+    int chunk = 0;
+    for (; chunk + 1 < cchunks; chunk += 2) { chunk_body(std::integral_constant<int, 0>{}, chunk); chunk_body(std::integral_constant<int, 1>{}, chunk + 1); }
+    if (chunk < cchunks) chunk_body(std::integral_constant<int, 0>{}, chunk);
 
     // ---- epilogue: acc[i][j][r] -> pixel m0 + 64 wave + 16 i + li, channel n0 + 16 j + 4 lg + r
     float ssum[4][4], ssq[4][4];
@@ -388,20 +398,12 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_win_kernel(WinArgs a, const 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float4 o;
-                // the accumulators live in AGPRs; read here, one tile at a time (left alone, the register allocator copies all 64 into VGPRs at the loop exit: 120
-                // VGPRs and two waves per SIMD for the whole kernel)
-                float c0, c1, c2, c3;
-                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(c0) : "a"(acc[i][j][0]));
-                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(c1) : "a"(acc[i][j][1]));
-                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(c2) : "a"(acc[i][j][2]));
-                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(c3) : "a"(acc[i][j][3]));
-                o.x = actf(c0 + bv[j].x); o.y = actf(c1 + bv[j].y); o.z = actf(c2 + bv[j].z); o.w = actf(c3 + bv[j].w);
+                o.x = actf(acc[i][j][0] + bv[j].x); o.y = actf(acc[i][j][1] + bv[j].y); o.z = actf(acc[i][j][2] + bv[j].z); o.w = actf(acc[i][j][3] + bv[j].w);
                 *reinterpret_cast<float4*>(yp + 16 * j) = o;
                 ssum[j][0] += o.x; ssq[j][0] += o.x * o.x; ssum[j][1] += o.y; ssq[j][1] += o.y * o.y;
                 ssum[j][2] += o.z; ssq[j][2] += o.z * o.z; ssum[j][3] += o.w; ssq[j][3] += o.w * o.w;
             }
         }
-        __builtin_amdgcn_sched_barrier(0);                         // one tile row at a time: the scheduler would first move all 64 accumulators into VGPRs (120 registers)
     }
     if (stats != nullptr) {
         // BatchNorm statistics partials of this 256-pixel tile: the 16 pixel lanes of a row (DPP, fixed order), then the four waves through LDS (the windows are dead:
@@ -1071,18 +1073,22 @@ static bool halo_plan(const MfmaArgs& m, int math, HaloArgs* h, size_t* smem) {
 
 // the window kernel's plan: fp32 3x3 / stride 1 / pad 1 / no dilation on the whole tensor (not a phase of a strided data gradient), 64-aligned output channels,
 // 32-bit buffer offsets, at least one block per CU.  DCV_MFMA_WIN=0 switches it off, =2 forces it for every shape it can run.
-static bool win_plan(const MfmaArgs& m, int math, WinArgs* w, size_t* smem) {
+static bool win_plan(const MfmaArgs& m, int math, WinArgs* w, size_t* smem, int* bstride) {
     static int mode = -1;
     if (mode < 0) { const char* e = getenv("DCV_MFMA_WIN"); mode = e ? atoi(e) : 1; }
     if (mode == 0 || math != DCV_MATH_FP32 || m.phase || m.R != 3 || m.S != 3 || m.sh != 1 || m.sw != 1 || m.ph != 1 || m.pw != 1 || m.dh != 1 || m.dw != 1) return false;
-    if (m.Hin != m.Hout || m.Win != m.Wout || m.Cout % 64 != 0 || m.Cin % 16 != 0 || m.Win > 256) return false;
+    if (m.Hin != m.Hout || m.Win != m.Wout || m.Cout % 64 != 0 || m.Cin % 16 != 0 || m.Win > 64 || m.Win < 2 || m.Hin < 2) return false;
     if ((size_t)m.M * m.Cin * 4 >= ((size_t)1 << 31) || (size_t)m.Cout * 9 * m.Cin * 4 >= ((size_t)1 << 31)) return false;
     const int tiles = (int)((m.M + 255) / 256);
     if (mode != 2 && (long)tiles * (m.Cout / 64) < DCV_NUM_CU) return false;
     w->N = m.N; w->H = m.Hin; w->W = m.Win; w->Cin = m.Cin; w->Cout = m.Cout; w->act = m.act; w->slope = m.slope; w->M = (int)m.M;
     w->x_bytes = (unsigned)((size_t)m.M * m.Cin * 4); w->w_bytes = (unsigned)((size_t)m.Cout * 9 * m.Cin * 4);
-    w->nrows = 256 + 2 * m.Win + 2; w->tiles = tiles;
-    *smem = (size_t)2 * (w->nrows + 1) * MW_ROWB;
+    w->nrows = 256 + 2 * m.Win + 2; w->ninstr = (w->nrows + 11) / 12; w->tiles = tiles;
+    w->magic_w = 0xFFFFFFFFu / (unsigned)m.Win + 1u; w->magic_h = 0xFFFFFFFFu / (unsigned)m.Hin + 1u;
+    const int buf = MW_ROWB + (12 * w->ninstr + 1) * MW_ROWB;      // zero row + the rows the DMA instructions cover
+    *bstride = buf <= 26624 ? 26624 : 32768;                       // (W <= 32: three blocks per CU; W <= 64: 31840 B)
+    if (buf > *bstride) return false;
+    *smem = (size_t)*bstride + buf;
     return true;
 }
 
@@ -1107,17 +1113,14 @@ static int run_mfma(const MfmaArgs& a, const float* x, const float* wb, const fl
 #undef DCV_HALO
         return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
     }
-    WinArgs wa{}; size_t wsm;
-    if (win_plan(a, math, &wa, &wsm)) {
-        static bool conf = false;
-        if (!conf) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_win_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DCV_ERR_LAUNCH;
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_win_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DCV_ERR_LAUNCH;
-            conf = true;
-        }
+    WinArgs wa{}; size_t wsm; int wbs;
+    if (win_plan(a, math, &wa, &wsm, &wbs)) {
         const dim3 wgrid((unsigned)wa.tiles, (unsigned)(a.Cout / 64));
-        if (a.act == DCV_ACT_NONE || a.act == DCV_ACT_RELU || a.act == DCV_ACT_LEAKY_RELU) hipLaunchKernelGGL(conv_mfma_win_kernel<true>, wgrid, dim3(256), wsm, st, wa, x, wb, bias, y, stats);
-        else hipLaunchKernelGGL(conv_mfma_win_kernel<false>, wgrid, dim3(256), wsm, st, wa, x, wb, bias, y, stats);
+        const bool plain = a.act == DCV_ACT_NONE || a.act == DCV_ACT_RELU || a.act == DCV_ACT_LEAKY_RELU;
+#define DCV_WIN(P_, B_) hipLaunchKernelGGL((conv_mfma_win_kernel<P_, B_>), wgrid, dim3(256), wsm, st, wa, x, wb, bias, y, stats)
+        if (wbs == 26624) { if (plain) DCV_WIN(true, 26624); else DCV_WIN(false, 26624); }
+        else { if (plain) DCV_WIN(true, 32768); else DCV_WIN(false, 32768); }
+#undef DCV_WIN
         return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
     }
     const int bn = pick_bn(a.Cout);
@@ -1143,8 +1146,8 @@ int dcv_mfma_conv2d_fwd_stats_rows(const dcv_conv2d_desc* d, int* rows_per_sampl
         MfmaArgs a{};
         a.N = d->n; a.Hin = d->h; a.Win = d->w; a.Cin = d->cin; a.Hout = d->ho; a.Wout = d->wo; a.Cout = d->cout;
         a.R = d->r; a.S = d->s; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w; a.M = M;
-        WinArgs wa{}; size_t wsm;
-        win = win_plan(a, d->math, &wa, &wsm);
+        WinArgs wa{}; size_t wsm; int wbs;
+        win = win_plan(a, d->math, &wa, &wsm, &wbs);
     }
     const int tile = win ? 256 : 64 * pick_bmr(M, d->cin, d->cout, pick_bn(d->cout));
     if (rows_per_sample && (d->ho * d->wo) % tile == 0) *rows_per_sample = d->ho * d->wo / tile;    // pixel tiles which never straddle images

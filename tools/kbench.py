@@ -84,13 +84,32 @@ n_, cin_, h_, w_, cout_, k_, _p = cfg
 flops = 2.0 * n_ * h_ * w_ * cout_ * cin_ * k_ * k_
 print(case, 'avg us', round(us, 2), 'TFLOP/s', round(flops / us / 1e6, 2))
 if __import__('os').environ.get('DCV_KBENCH_STAMPS') and case.endswith('p'):     # a tools/variants/*_stamps.py library: per-block time stamps (100 MHz) in the statistics buffer
-    nb = int(__import__('os').environ['DCV_KBENCH_STAMPS'])
-    stats.zero_(); torch.cuda.synchronize(); fn(); torch.cuda.synchronize()
-    s = stats.flatten()[:nb * 4].reshape(nb, 4).cpu().numpy() * 0.01       # us
-    t0 = s[:, 0].min()
     import numpy as np
+    nb = int(__import__('os').environ['DCV_KBENCH_STAMPS']); ns = int(__import__('os').environ.get('DCV_KBENCH_NSTAMPS', '4'))
+    stats.zero_(); torch.cuda.synchronize(); fn(); torch.cuda.synchronize()
+    s = stats.flatten()[:nb * ns].reshape(nb, ns).cpu().numpy() * 0.01       # us
+    t0 = s[:, 0].min()
     print('blocks', nb, 'span us', round(float(s[:, 3].max() - t0), 1))
-    print('mean prologue', round(float((s[:, 1] - s[:, 0]).mean()), 2), 'loop', round(float((s[:, 2] - s[:, 1]).mean()), 2), 'epilogue', round(float((s[:, 3] - s[:, 2]).mean()), 2))
+    first = (s[:, 0] - t0) < 5.0
+    for name, sel in (('first round', first), ('later rounds', ~first)):
+        if sel.sum() == 0: continue
+        g = s[sel]
+        line = f'{name} ({int(sel.sum())} blocks): prologue {np.mean(g[:, 1] - g[:, 0]):.2f} loop {np.mean(g[:, 2] - g[:, 1]):.2f} epilogue {np.mean(g[:, 3] - g[:, 2]):.2f}'
+        if ns >= 7: line += f' | prologue parts: index math {np.mean(g[:, 4] - g[:, 0]):.2f} request {np.mean(g[:, 5] - g[:, 4]):.2f} landed {np.mean(g[:, 6] - g[:, 5]):.2f} barrier {np.mean(g[:, 1] - g[:, 6]):.2f}'
+        print(line)
+    idx = np.arange(nb)
+    print('first-round loop time by XCD (block index % 8):', [round(float(np.mean((s[:, 2] - s[:, 1])[first & (idx % 8 == k)])), 1) for k in range(8)])
+    print('first-round exit time percentiles 0/10/50/90/100:', np.round(np.percentile(s[first, 3] - t0, [0, 10, 50, 90, 100]), 1).tolist())
+    if ns >= 8:      # slot 7: HW_ID[15:0] | XCC_ID << 16 (x 0.01 above)
+        hw = np.round(s[:, 7] * 100).astype(np.int64)
+        cu = ((hw >> 16) & 0xF) * 1000 + ((hw >> 13) & 7) * 100 + ((hw >> 12) & 1) * 50 + ((hw >> 8) & 0xF)      # xcc, se, sh, cu
+        ids, counts = np.unique(cu, return_counts=True)
+        print('CUs seen', len(ids), 'blocks per CU: min', counts.min(), 'max', counts.max(), 'histogram', np.bincount(counts).tolist())
+        ends = np.array([s[cu == c, 3].max() - t0 for c in ids])
+        print('last exit per CU percentiles 0/10/50/90/100:', np.round(np.percentile(ends, [0, 10, 50, 90, 100]), 1).tolist())
+        for c in ids[:3].tolist() + ids[-2:].tolist():
+            g = s[cu == c]; g = g[np.argsort(g[:, 0])]
+            print('CU', c, [(round(float(a - t0), 1), round(float(b - t0), 1)) for a, b in zip(g[:, 0], g[:, 3])])
     order = np.argsort(s[:, 0])
     print('entry times (sorted, every 64th):', np.round(s[order, 0][::64] - t0, 1).tolist())
     print('exit times of the same blocks   :', np.round(s[order, 3][::64] - t0, 1).tolist())

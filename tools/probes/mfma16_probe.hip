@@ -13,8 +13,9 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int ITER = 576;            // chunks per tile in the probe (16 tiles' worth of the 64 -> 64 3x3 layer)
 constexpr int LD = 20;
 
-template <int MODE>
-__global__ __launch_bounds__(256) void loop(const float* __restrict__ x, float* __restrict__ out, size_t xfloats) {
+// WPE: waves per SIMD promised to the compiler: with a register budget <= 256 it keeps the accumulators in VGPRs (v_mfma ... vgprcd), otherwise in AGPRs
+template <int MODE, int WPE>
+__global__ __launch_bounds__(256, WPE) void loop(const float* __restrict__ x, float* __restrict__ out, size_t xfloats, int iters) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* As = lds;                       // [2][256 * LD]
     float* Bs = lds + 2 * 256 * LD;        // [2][64 * LD]
@@ -34,14 +35,15 @@ __global__ __launch_bounds__(256) void loop(const float* __restrict__ x, float* 
     for (int j = 0; j < 4; ++j) ap[j] = x + (((size_t)blockIdx.x * 256 + (t >> 2) + 64 * j) * 64 + 4 * q) % (xfloats - 64 * ITER * 16);
     const float* bp = x + 4 * q + (size_t)(t >> 2) * 576;
     f4 va[4], vb;
-    for (int c = 0; c < ITER; ++c) {
+    unsigned junk[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+    for (int c = 0; c < iters; ++c) {
         const int buf = c & 1;
-        if (MODE >= 2) {
+        if (MODE == 2 || MODE == 3) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { va[j] = *reinterpret_cast<const f4*>(ap[j]); ap[j] += 16; }
             vb = *reinterpret_cast<const f4*>(bp); bp += 16; if ((c & 31) == 31) bp -= 512;
         }
-        if (MODE >= 1) {
+        if (MODE >= 1 && MODE <= 3) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const f4*>(&As[buf * 256 * LD + (wave * 64 + i * 16 + li) * LD + 4 * lg]);
 #pragma unroll
@@ -53,7 +55,14 @@ __global__ __launch_bounds__(256) void loop(const float* __restrict__ x, float* 
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
-        if (MODE >= 2) {
+        if (MODE == 4 || MODE == 5) {      // 64 (mode 4) / 256 (mode 5) independent VALU instructions per 64 MFMAs: do they cost matrix-pipe time?
+            constexpr int NV = MODE == 4 ? 8 : 32;
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) asm volatile("v_add_u32 %0, %0, 1" : "+v"(junk[u]));
+        }
+        if (MODE == 2 || MODE == 3) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) *reinterpret_cast<f4*>(&As[(buf ^ 1) * 256 * LD + ((t >> 2) + 64 * j) * LD + 4 * q]) = va[j];
             *reinterpret_cast<f4*>(&Bs[(buf ^ 1) * 64 * LD + (t >> 2) * LD + 4 * q]) = vb;
@@ -71,7 +80,7 @@ __global__ __launch_bounds__(256) void loop(const float* __restrict__ x, float* 
             __syncthreads();
         }
     }
-    float s = 0.f;
+    float s = (float)(junk[0] + junk[1] + junk[2] + junk[3] + junk[4] + junk[5] + junk[6] + junk[7]);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -79,32 +88,39 @@ __global__ __launch_bounds__(256) void loop(const float* __restrict__ x, float* 
     out[(size_t)blockIdx.x * 256 + t] = s;
 }
 
-template <int MODE>
-int run(const float* x, float* out, size_t xfloats, int per_cu) {
+template <int MODE, int WPE = 1>
+int run(const float* x, float* out, size_t xfloats, int per_cu, int iters = ITER, int rounds = 4) {
     const size_t smem = per_cu == 1 ? 150 * 1024 : (per_cu == 2 ? 78 * 1024 : 51200);
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(loop<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    const int grid = 256 * per_cu * 4;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(loop<MODE, WPE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    const int grid = 256 * per_cu * rounds;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(loop<MODE>, dim3(grid), dim3(256), smem, 0, x, out, xfloats);
+    hipLaunchKernelGGL((loop<MODE, WPE>), dim3(grid), dim3(256), smem, 0, x, out, xfloats, iters);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(loop<MODE>, dim3(grid), dim3(256), smem, 0, x, out, xfloats);
+    const int reps = iters == ITER ? 5 : 50;
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL((loop<MODE, WPE>), dim3(grid), dim3(256), smem, 0, x, out, xfloats, iters);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
-    const double flops = (double)grid * 4 * ITER * 64 * 2.0 * 1024;
-    printf("mode %d, %d block(s)/CU: %.1f us, %.1f TF (%.2f of 157.3)\n", MODE, per_cu, ms * 1e3, flops / ms * 1e-9, flops / ms * 1e-9 / 157.3);
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+    const double flops = (double)grid * 4 * iters * 64 * 2.0 * 1024;
+    printf("mode %d (waves/SIMD promised %d), %d block(s)/CU, %d chunks per block, %d round(s): %.1f us, %.1f TF (%.2f of 157.3)\n", MODE, WPE, per_cu, iters, rounds, ms * 1e3, flops / ms * 1e-9, flops / ms * 1e-9 / 157.3);
     return 0;
 }
 
 int main() {
     const size_t xfloats = (size_t)512 * 1024 * 64;     // the 64-channel 32x32 activation of 512 images
     float *x, *out;
-    CK(hipMalloc(&x, xfloats * 4)); CK(hipMemset(x, 0, xfloats * 4)); CK(hipMalloc(&out, (size_t)256 * 12 * 256 * 4));
+    CK(hipMalloc(&x, xfloats * 4)); CK(hipMemset(x, 0, xfloats * 4)); CK(hipMalloc(&out, (size_t)256 * 3 * 8 * 256 * 4));      // the largest grid below: 3 blocks per CU x 8 rounds
+    // short kernels: one tile's worth of MFMAs per block (36 chunks), one round of blocks, 50 launches back to back
+    for (int b = 1; b <= 3; ++b) { if (run<4, 3>(x, out, xfloats, b)) return 1; if (run<5, 3>(x, out, xfloats, b)) return 1; }
+    for (int b = 1; b <= 3; ++b) { if (run<0, 3>(x, out, xfloats, b, 36, 1)) return 1; if (run<1, 3>(x, out, xfloats, b, 36, 1)) return 1; if (run<0, 3>(x, out, xfloats, b, 36, 8)) return 1; }
     for (int b = 1; b <= 3; ++b) {
         if (run<0>(x, out, xfloats, b)) return 1;
         if (run<1>(x, out, xfloats, b)) return 1;
         if (run<2>(x, out, xfloats, b)) return 1;
         if (run<3>(x, out, xfloats, b)) return 1;
+        if (run<0, 3>(x, out, xfloats, b)) return 1;
+        if (run<1, 3>(x, out, xfloats, b)) return 1;
+        if (run<2, 3>(x, out, xfloats, b)) return 1;
     }
     return 0;
 }
