@@ -23,6 +23,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 // four consecutive K elements of a lane -> the bf16 operand of v_mfma_f32_16x16x16_bf16 (round to nearest even: v_cvt_pk_bf16_f32)
@@ -566,6 +567,7 @@ struct Wg9Args {
     int HWp;                        // pixels per image rounded up to a multiple of PS: a step never straddles images, the padding pixels contribute zeros
     long M, m_per_chunk;            // N * HWp; (padded) pixels per split-K chunk (multiple of PS)
     size_t wtotal;
+    unsigned magic_w;               // floor((2^32 - 1) / W) + 1: n / W = mulhi(n, magic_w) for n W < 2^32
 };
 #define W9_LDX 10                   // float4 loads of the x window per thread and step (XR * 16 <= 256 * W9_LDX)
 
@@ -581,14 +583,23 @@ __device__ __forceinline__ float4 w9_load4(const float* base, size_t idx) {
 }
 
 // IN16: x and dy are bf16 tensors (the bf16 storage path, conv2d_bf16.hip); they are widened while staged, everything downstream is unchanged
+// fp32 tensors are staged by LDS-DMA (round 3: with the staging through registers — 12 float4 loads with 64-bit address arithmetic, 48 selects and 12 LDS stores per
+// thread and step, every one of them paid in matrix-pipe time — the kernel spent 17 % of its time staging, tools/variants/mfma_wgrad9_skip.py): a wave instruction
+// writes 64 consecutive 16-B pieces = 3 padded rows of 17 pieces + the first 13 pieces of a fourth (which the next instruction writes again), lane l = row l / 17,
+// piece l % 17 (piece 16: the pad, fetched out of range); the buffer resource is the step's IMAGE (base x + n HW Cin, HW Cin 4 bytes), so window rows above / below
+// the image and the padding pixels behind it are out of range = zeros without a compare; one add per piece.  Each tile is followed by three spare rows for the last
+// instruction's overhang.
 template <int PS, bool BF16, bool PIPE, bool IN16 = false>
 __global__ __launch_bounds__(256, PIPE ? 1 : 2) void conv_mfma_wgrad9_kernel(Wg9Args a, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float smem9[];
     const int XR = a.XR;
-    float* Gs = smem9;                                           // [2][PS * WG_LD]   dy tile [pixel][co]
-    float* Xs = Gs + 2 * PS * WG_LD;                             // [2][XR * WG_LD]   x window [row][ci]
-    int* Cm = reinterpret_cast<int*>(Xs + 2 * XR * WG_LD);       // [2][PS]           bit 0: w > 0, bit 1: w < W - 1
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    constexpr int GRA = PS + 3;                                   // rows per dy tile / x window incl. three spare rows (instructions cover 3 n + 1 rows)
+    const int XRA = XR + 3;
+    float* Gs = smem9;                                           // [2][GRA * WG_LD]  dy tile [pixel][co]
+    float* Xs = Gs + 2 * GRA * WG_LD;                            // [2][XRA * WG_LD]  x window [row][ci]
+    int* Cm = reinterpret_cast<int*>(Xs + 2 * XRA * WG_LD);      // [2][PS]           bit 0: w > 0, bit 1: w < W - 1
+    float* Cf = reinterpret_cast<float*>(Cm + 2 * PS);           // [2][PS][2]        the same as factors: 1.f / 0.f for w > 0, w < W - 1
+    const int t = threadIdx.x, lane = t & 63, wave = IN16 ? (t >> 6) : __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 15, lg = lane >> 4;
     const int ci0 = blockIdx.y * WG_T, co0 = blockIdx.z * WG_T;
     const long mb = (long)blockIdx.x * a.m_per_chunk;
@@ -618,13 +629,42 @@ __global__ __launch_bounds__(256, PIPE ? 1 : 2) void conv_mfma_wgrad9_kernel(Wg9
     };
     auto store_step = [&](int buf, long m0) {
 #pragma unroll
-        for (int h = 0; h < PS / 16; ++h) *reinterpret_cast<float4*>(&Gs[(buf * PS + prow + 16 * h) * WG_LD + 4 * pc4]) = g[h];
+        for (int h = 0; h < PS / 16; ++h) *reinterpret_cast<float4*>(&Gs[(buf * GRA + prow + 16 * h) * WG_LD + 4 * pc4]) = g[h];
 #pragma unroll
         for (int u = 0; u < W9_LDX; ++u) {
             const int row = prow + 16 * u;
-            if (row < XR) *reinterpret_cast<float4*>(&Xs[((size_t)buf * XR + row) * WG_LD + 4 * pc4]) = xv[u];
+            if (row < XR) *reinterpret_cast<float4*>(&Xs[((size_t)buf * XRA + row) * WG_LD + 4 * pc4]) = xv[u];
         }
         if (t < PS) { const int w = (int)((m0 % a.HWp + t) % a.W); Cm[buf * PS + t] = (w > 0 ? 1 : 0) | (w < a.W - 1 ? 2 : 0); }
+    };
+    // ---- LDS-DMA staging (fp32 tensors)
+    const int lrow = (lane * 61) >> 10, lslot = lane - 17 * lrow;                // lane / 17, lane % 17
+    const unsigned vbx = lslot < 16 ? (unsigned)((lrow + 3 * wave - a.W - 1) * a.Cin * 4 + ci0 * 4 + lslot * 16) : 0x80000000u;     // (mod 2^32: rows above the image wrap out of range)
+    const unsigned vbg = lslot < 16 ? (unsigned)((lrow + 3 * wave) * a.Cout * 4 + co0 * 4 + lslot * 16) : 0x80000000u;
+    const int nix = (XR + 2) / 3, nig = (PS + 2) / 3;                             // wave instructions per x window / dy tile (three rows each)
+    int dn = 0, dp0 = 0;                                                         // image and first pixel of the NEXT step to stage (scalars)
+    auto dma_step = [&](int buf) {
+        typedef __attribute__((address_space(3))) void* lds_p;
+        __amdgpu_buffer_rsrc_t rxi = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)dn * HW * a.Cin), 0, HW * a.Cin * 4, 0x00020000);
+        __amdgpu_buffer_rsrc_t rgi = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + (size_t)dn * HW * a.Cout), 0, HW * a.Cout * 4, 0x00020000);
+        char* gb = reinterpret_cast<char*>(Gs + buf * GRA * WG_LD) + wave * (3 * WG_LD * 4);
+        char* xb = reinterpret_cast<char*>(Xs + (size_t)buf * XRA * WG_LD) + wave * (3 * WG_LD * 4);
+        unsigned vg = vbg + (unsigned)(dp0 * a.Cout * 4), vx = vbx + (unsigned)(dp0 * a.Cin * 4);
+        const unsigned sg = (unsigned)(12 * a.Cout * 4), sx = (unsigned)(12 * a.Cin * 4);      // four instructions (one per wave) further
+        for (int k = 0; 4 * k < nig; ++k) {
+            if (4 * k + wave < nig) __builtin_amdgcn_raw_ptr_buffer_load_lds(rgi, (lds_p)(gb + k * (12 * WG_LD * 4)), 16, (int)vg, 0, 0, 0);
+            vg += sg;
+        }
+        for (int k = 0; 4 * k < nix; ++k) {
+            if (4 * k + wave < nix) __builtin_amdgcn_raw_ptr_buffer_load_lds(rxi, (lds_p)(xb + k * (12 * WG_LD * 4)), 16, (int)vx, 0, 0, 0);
+            vx += sx;
+        }
+        if (t < PS) {
+            const unsigned v = (unsigned)(dp0 + t), w = v - __umulhi(v, a.magic_w) * (unsigned)a.W;
+            Cm[buf * PS + t] = (w > 0 ? 1 : 0) | (w + 1 < (unsigned)a.W ? 2 : 0);
+            *reinterpret_cast<float2*>(&Cf[(buf * PS + t) * 2]) = make_float2(w > 0 ? 1.f : 0.f, w + 1 < (unsigned)a.W ? 1.f : 0.f);
+        }
+        dp0 += PS; if (dp0 >= a.HWp) { dp0 = 0; ++dn; }
     };
 
     f32x4 acc[9][4];
@@ -632,17 +672,31 @@ __global__ __launch_bounds__(256, PIPE ? 1 : 2) void conv_mfma_wgrad9_kernel(Wg9
     for (int k = 0; k < 9; ++k)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[k][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // the fp32 two-waves-per-SIMD path accumulates in 32 x 32 tiles instead (v_mfma_f32_32x32x2_f32): wave = 32 output channels x 32 input channels x nine taps
+    constexpr bool W32 = !BF16 && !PIPE;
+    f32x16 acc32[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc32[k][r] = 0.f;
+    const int l31 = lane & 31, half = lane >> 5, cob = (wave >> 1) * 32, cib = (wave & 1) * 32;
 
-    load_step(mb);
-    store_step(0, mb);
+    if constexpr (IN16) {
+        load_step(mb);
+        store_step(0, mb);
+    } else {
+        dn = (int)(mb / a.HWp); dp0 = (int)(mb - (long)dn * a.HWp);
+        dma_step(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
     int it = 0;
     for (long m = mb; m < me; m += PS, ++it) {
         const int buf = it & 1;
         const bool has_next = (m + PS) < me;
-        if (has_next) load_step(m + PS);
-        const float* gs = Gs + buf * PS * WG_LD;
-        const float* xs = Xs + (size_t)buf * XR * WG_LD;
+        if (has_next) { if constexpr (IN16) load_step(m + PS); else dma_step(buf ^ 1); }
+        const float* gs = Gs + buf * GRA * WG_LD;
+        const float* xs = Xs + (size_t)buf * XRA * WG_LD;
         const int* cm = Cm + buf * PS;
         if constexpr (BF16) {
 #pragma unroll
@@ -667,23 +721,38 @@ __global__ __launch_bounds__(256, PIPE ? 1 : 2) void conv_mfma_wgrad9_kernel(Wg9
                     }
             }
         } else if constexpr (!PIPE) {
-            // two waves per SIMD: the other block's wave covers this wave's LDS round trips
-#pragma unroll 2
-            for (int kk = 0; kk < PS / 4; ++kk) {
-                const int prw = (kk >> 2) * 16 + 4 * lg + (kk & 3);
-                const float av = gs[prw * WG_LD + wave * 16 + li];
-                const int mk = cm[prw];
-                const float av0 = (mk & 1) ? av : 0.f, av2 = (mk & 2) ? av : 0.f;
+            // Two waves per SIMD: the other block's wave covers this wave's LDS round trips.  Every instruction a wave issues is paid in matrix-pipe time (~4 clocks per
+            // VALU, ~8 per LDS instruction, tools/probes/mfma16_probe.hip), and the 16x16x4 form above needs one operand read per MFMA of 32 clocks: 19 % of the loop.
+            // v_mfma_f32_32x32x2_f32 does 2048 MACs on the same two operand values per lane: K = 2 pixels per instruction, lanes 0 - 31 pixel k, lanes 32 - 63 pixel
+            // k + 8 (rows 8 apart are 32 banks apart with the 68-float row: conflict-free), two neighbouring pixel pairs per ds_read2_b32, the border factors as floats.
+            const float* cf = Cf + buf * PS * 2;
 #pragma unroll
-                for (int r = 0; r < 3; ++r)
+            for (int g16 = 0; g16 < PS / 16; ++g16)
 #pragma unroll
-                    for (int sx = 0; sx < 3; ++sx) {
-                        const float as = sx == 0 ? av0 : (sx == 1 ? av : av2);
-                        const float* xp = xs + (size_t)(prw + r * a.W + sx) * WG_LD + li;
+                for (int pp = 0; pp < 8; pp += 2) {
+                    const int row = 16 * g16 + pp + 8 * half;                                    // this lane's pixel of the first pair; the second pair: row + 1
+                    const float* gp = gs + row * WG_LD + cob + l31;
+                    const float av[2] = {gp[0], gp[WG_LD]};                                       // A'[i = co][k = pixel]
+                    const float4 mf = *reinterpret_cast<const float4*>(cf + row * 2);            // (row is even)
+                    const float a0[2] = {av[0] * mf.x, av[1] * mf.z}, a2[2] = {av[0] * mf.y, av[1] * mf.w};
+                    float bq[9][2];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[r * 3 + sx][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(as, xp[j * 16], acc[r * 3 + sx][j], 0, 0, 0);
-                    }
-            }
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int sx = 0; sx < 3; ++sx) {
+                            const float* xp = xs + (size_t)(row + r * a.W + sx) * WG_LD + cib + l31;  // B'[k = pixel shifted by the tap][j = ci]
+                            bq[r * 3 + sx][0] = xp[0]; bq[r * 3 + sx][1] = xp[WG_LD];
+                        }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int r = 0; r < 3; ++r)
+#pragma unroll
+                            for (int sx = 0; sx < 3; ++sx) {
+                                const float as = sx == 0 ? a0[u] : (sx == 1 ? av[u] : a2[u]);
+                                acc32[r * 3 + sx] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, bq[r * 3 + sx][u], acc32[r * 3 + sx], 0, 0, 0);
+                            }
+                }
         } else {
             // One wave per SIMD (the 36 accumulator tiles + a double-buffered operand set need more than 256 registers): nothing but this wave's own
             // instruction stream hides the LDS latency, so the 36 B operands (+ A and the column mask) of pixel quad kk + 1 are read while the 36 MFMAs of
@@ -726,12 +795,24 @@ __global__ __launch_bounds__(256, PIPE ? 1 : 2) void conv_mfma_wgrad9_kernel(Wg9
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (has_next) store_step(buf ^ 1, m + PS);
+        if constexpr (IN16) { if (has_next) store_step(buf ^ 1, m + PS); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the next step have landed
         __syncthreads();
     }
     // partial[chunk][tap][co][ci]: the accumulator layout as it stands (16 lanes = 64 contiguous bytes of one row); OIHW order (taps fastest) would make every
     // store instruction 64 scattered dwords, 36 B apart.  mfma_wgrad9_reduce_kernel sums the slabs and writes dw in OIHW order.
     float* dst = partial + (size_t)blockIdx.x * a.wtotal;
+    if constexpr (W32) {
+        // 32x32 accumulator layout: register r of lane l = row 8 (r / 4) + 4 (l / 32) + r % 4 (co), column l % 32 (ci): 128 contiguous bytes per row
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + cob + 8 * (r >> 2) + 4 * half + (r & 3), ci = ci0 + cib + l31;
+                dst[((size_t)k * a.Cout + co) * a.Cin + ci] = acc32[k][r];
+            }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 9; ++k)
 #pragma unroll
@@ -862,7 +943,7 @@ inline bool wg9_plan(const dcv_conv2d_desc* d, Wg9Args* a, int* ps, int* chunks,
     if (d->cin % WG_T != 0 || d->cout % WG_T != 0 || d->ho != d->h || d->wo != d->w) return false;
     const int hw = d->h * d->w;
     // step size: the one wasting fewer padding pixels per image, 32 on a tie; 16 when the 32-pixel window does not fit the LDS budget of two blocks per CU
-    auto smem_of = [&](int ps) { return ((size_t)2 * ps * WG_LD + (size_t)2 * (ps + 2 * d->w + 2) * WG_LD) * sizeof(float) + (size_t)2 * ps * sizeof(int); };
+    auto smem_of = [&](int ps) { return ((size_t)2 * (ps + 3) * WG_LD + (size_t)2 * (ps + 2 * d->w + 2 + 3) * WG_LD) * sizeof(float) + (size_t)2 * ps * sizeof(int) + (size_t)2 * ps * 2 * sizeof(float); };     // (three spare rows per tile; border masks as bits and as factors)
     auto fits = [&](int ps) { return (ps + 2 * d->w + 2) * 16 <= 256 * W9_LDX && smem_of(ps) <= (size_t)80 * 1024; };
     const int pad32 = (hw + 31) / 32 * 32, pad16 = (hw + 15) / 16 * 16;
     int PS = (pad32 <= pad16 && fits(32)) ? 32 : 16;
@@ -873,6 +954,8 @@ inline bool wg9_plan(const dcv_conv2d_desc* d, Wg9Args* a, int* ps, int* chunks,
     a->HWp = PS == 32 ? pad32 : pad16;
     a->M = (long)d->n * a->HWp;
     a->wtotal = (size_t)d->cout * d->cin * 9;
+    a->magic_w = 0xFFFFFFFFu / (unsigned)d->w + 1u;
+    if (d->w < 2 || (size_t)hw * d->cin * 4 >= ((size_t)1 << 31) || (size_t)hw * d->cout * 4 >= ((size_t)1 << 31)) return false;      // (32-bit buffer offsets inside an image)
     const long blocks_per_chunk = (long)(d->cin / WG_T) * (d->cout / WG_T);
     const long per_cu = wg9_mode() == 1 ? 1 : 2;                                     // resident blocks per CU (the kernel's register budget): one round
     long ch = (per_cu * DCV_NUM_CU + blocks_per_chunk - 1) / blocks_per_chunk;

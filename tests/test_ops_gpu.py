@@ -80,6 +80,12 @@ CONV_CASES = [
     (8, 256, 14, 14, 512, 3, 2, 1, 1, 1, False),
     (8, 64, 56, 56, 128, 3, 2, 1, 1, 1, False),
     (2, 3, 224, 224, 64, 7, 2, 3, 1, 1, True),     # stem
+    # the window kernel (conv_mfma_win_kernel: 3x3 / stride 1 / pad 1, 64-aligned output channels, at least one 256-pixel tile per CU), forward and data gradient;
+    # tanh / no activation: no kink for a rounding difference to flip
+    (66, 64, 32, 32, 64, 3, 1, 1, 1, 4, False),    # 264 tiles (XCD-contiguous tile order), four chunks, the general-activation instance
+    (70, 16, 31, 31, 64, 3, 1, 1, 1, 0, False),    # one chunk (the loop's tail body), ragged last tile, image rows which straddle tiles
+    (42, 48, 28, 28, 128, 3, 1, 1, 1, 0, False),   # three chunks, two output-channel tiles
+    (11, 64, 56, 56, 128, 3, 1, 1, 1, 4, False),   # W = 56: the 32 KB window stride (two blocks per CU)
     # the five stock layers at the BENCH batch size (BASELINE.json configs[1], N = 512): `tile_plan` picks its pixels-per-thread variant from the grid size,
     # so these are the instantiations bench.py times (conv_tile_kernel<4,5,2>, <4,3,2>, the halo-tile MFMA kernel with 512 samples, 512-block weight gradients).
     # tanh epilogue: with 2e6 outputs per layer a ReLU output lands within fp32 rounding of 0 about once, and one flipped act'(y) moves dx by ~1e-2 of its range
@@ -351,6 +357,8 @@ LAYER_CASES = [
     (2, 8, 12, 12, 12, 3, 2, 1, 4, 3, False),      # stride 2, tanh, 3 groups
     (70, 4, 8, 8, 8, 3, 1, 1, 0, 8, False),        # no activation; more samples than one wave of partials; one channel per group
     (2, 64, 14, 14, 64, 3, 1, 1, 1, 0, False),     # wide BN-only layer (resnet18_style shapes)
+    (66, 64, 32, 32, 64, 3, 1, 1, 4, 0, False),    # the window kernel's statistics epilogue: four 256-pixel rows per sample
+    (70, 64, 31, 31, 64, 3, 1, 1, 0, 0, False),    # ... tiles which straddle samples (no per-sample rows), ragged last tile
     # the stock layers at the bench batch size (N = 512): convolution with the statistics epilogue as the training step launches it, the norm chain's
     # register-resident per-sample path (nf_moments_kernel<4> / nf_bn_gn_apply_kernel at 512 samples), data gradient of the PPT = 2 / 4 tile variants;
     # tanh instead of ReLU: no kink for a rounding difference to flip (see CONV_CASES)
