@@ -24,6 +24,22 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// LDS-DMA issued from inline assembly.  The builtin (__builtin_amdgcn_raw_ptr_buffer_load_lds) makes the compiler track the load as a store to LDS: it then puts
+// `s_waitcnt vmcnt(0)` in front of the next LDS access it cannot prove disjoint — the step's first fragment read waited for the NEXT step's tiles, just requested
+// (conv_mfma_wgrad9_kernel: 13 % of its time) — and, counting in order, every wait for an older register load also waits for the requests behind it.  Issued like
+// this the compiler does not know about it; the kernels wait themselves (__builtin_amdgcn_s_waitcnt, which the compiler's own bookkeeping understands) before the
+// barrier that publishes the tiles.
+__device__ __forceinline__ i32x4 mf_buffer(const void* p, unsigned bytes) {      // raw buffer resource (what __builtin_amdgcn_make_buffer_rsrc(p, 0, bytes, 0x00020000) builds)
+    const unsigned long long a = (unsigned long long)p;
+    return (i32x4){(int)(unsigned)a, (int)(unsigned)((a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+}
+// 64 lanes x 16 bytes from rsrc[voffset + soffset] (voffset range-checked against the resource: beyond it the lanes fetch zeros) to LDS bytes [lds_addr, lds_addr + 1024)
+__device__ __forceinline__ void mf_dma16(i32x4 rsrc, unsigned lds_addr, unsigned voffset, unsigned soffset) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(voffset), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(soffset)) : "memory");
+}
+#define MF_WAIT_VMCNT0() __builtin_amdgcn_s_waitcnt(0x0F70)      // s_waitcnt vmcnt(0) (expcnt, lgkmcnt untouched)
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 // four consecutive K elements of a lane -> the bf16 operand of v_mfma_f32_16x16x16_bf16 (round to nearest even: v_cvt_pk_bf16_f32)
@@ -282,7 +298,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_win_kernel(WinArgs a, const 
     if ((a.tiles & 7) == 0) tile = (int)(blockIdx.x & 7u) * (a.tiles >> 3) + (int)(blockIdx.x >> 3);
     const int m0 = tile * 256, n0 = blockIdx.y * 64;
     const int W = a.W, H = a.H;
-    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)a.x_bytes, 0x00020000);
+    const i32x4 rx = mf_buffer(x, a.x_bytes);
     __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, (int)a.w_bytes, 0x00020000);
     if (t < 10) *reinterpret_cast<float4*>(mw_lds + (t >= 5 ? BSTRIDE : 0) + (t % 5) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);       // the two zero rows
 
@@ -292,10 +308,10 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_win_kernel(WinArgs a, const 
     const unsigned vb0 = lslot < 4 ? (unsigned)((m0 - W - 1 + 12 * wave + lrow) * a.Cin * 4 + lslot * 16) : MW_OOB;       // (mod 2^32, see above)
     const int kinstr = (a.ninstr + 3) >> 2;
     auto stage = [&](int buf, int chunk) {
-        char* base = mw_lds + buf * BSTRIDE + MW_ROWB + wave * 960;
+        const unsigned base = (unsigned)(size_t)mw_lds + (unsigned)(buf * BSTRIDE + MW_ROWB + wave * 960);
         unsigned vo = vb0;
         for (int k = 0; k < kinstr; ++k) {
-            if (4 * k + wave < a.ninstr) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (mw_lds_ptr)(base + k * 3840), 16, (int)vo, chunk * 64, 0, 0);
+            if (4 * k + wave < a.ninstr) mf_dma16(rx, base + (unsigned)(k * 3840), vo, (unsigned)(chunk * 64));
             vo += vstep;
         }
     };
@@ -340,7 +356,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_win_kernel(WinArgs a, const 
     f32x4 wa[4], wb2[4];                                           // filter fragments of the tap in flight and of the next one (register double buffer)
     stage(0, 0);
     wload(wa, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MF_WAIT_VMCNT0();
     __syncthreads();
     // one chunk: nine taps out of window buffer PAR (a compile-time distance: the immediate offset of the ds_reads)
     auto chunk_body = [&](auto par, int chunk) {
@@ -373,7 +389,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_win_kernel(WinArgs a, const 
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) wa[j] = wb2[j];                // (nine taps: the fragments of the next chunk's first tap arrived in the second set)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's pieces of the next window have landed ...
+        MF_WAIT_VMCNT0();                                          // this wave's pieces of the next window have landed ...
         __syncthreads();                                           // ... and everybody's; every wave is done reading this one
     };
     int chunk = 0;
@@ -644,25 +660,24 @@ __global__ __launch_bounds__(256, PIPE ? 1 : 2) void conv_mfma_wgrad9_kernel(Wg9
     const int nix = (XR + 2) / 3, nig = (PS + 2) / 3;                             // wave instructions per x window / dy tile (three rows each)
     int dn = 0, dp0 = 0;                                                         // image and first pixel of the NEXT step to stage (scalars)
     auto dma_step = [&](int buf) {
-        typedef __attribute__((address_space(3))) void* lds_p;
-        __amdgpu_buffer_rsrc_t rxi = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (size_t)dn * HW * a.Cin), 0, HW * a.Cin * 4, 0x00020000);
-        __amdgpu_buffer_rsrc_t rgi = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + (size_t)dn * HW * a.Cout), 0, HW * a.Cout * 4, 0x00020000);
-        char* gb = reinterpret_cast<char*>(Gs + buf * GRA * WG_LD) + wave * (3 * WG_LD * 4);
-        char* xb = reinterpret_cast<char*>(Xs + (size_t)buf * XRA * WG_LD) + wave * (3 * WG_LD * 4);
-        unsigned vg = vbg + (unsigned)(dp0 * a.Cout * 4), vx = vbx + (unsigned)(dp0 * a.Cin * 4);
-        const unsigned sg = (unsigned)(12 * a.Cout * 4), sx = (unsigned)(12 * a.Cin * 4);      // four instructions (one per wave) further
-        for (int k = 0; 4 * k < nig; ++k) {
-            if (4 * k + wave < nig) __builtin_amdgcn_raw_ptr_buffer_load_lds(rgi, (lds_p)(gb + k * (12 * WG_LD * 4)), 16, (int)vg, 0, 0, 0);
-            vg += sg;
-        }
-        for (int k = 0; 4 * k < nix; ++k) {
-            if (4 * k + wave < nix) __builtin_amdgcn_raw_ptr_buffer_load_lds(rxi, (lds_p)(xb + k * (12 * WG_LD * 4)), 16, (int)vx, 0, 0, 0);
-            vx += sx;
-        }
         if (t < PS) {
             const unsigned v = (unsigned)(dp0 + t), w = v - __umulhi(v, a.magic_w) * (unsigned)a.W;
             Cm[buf * PS + t] = (w > 0 ? 1 : 0) | (w + 1 < (unsigned)a.W ? 2 : 0);
             *reinterpret_cast<float2*>(&Cf[(buf * PS + t) * 2]) = make_float2(w > 0 ? 1.f : 0.f, w + 1 < (unsigned)a.W ? 1.f : 0.f);
+        }
+        const i32x4 rxi = mf_buffer(x + (size_t)dn * HW * a.Cin, (unsigned)(HW * a.Cin * 4));
+        const i32x4 rgi = mf_buffer(dy + (size_t)dn * HW * a.Cout, (unsigned)(HW * a.Cout * 4));
+        const unsigned gb = (unsigned)(size_t)(Gs + buf * GRA * WG_LD) + (unsigned)(wave * (3 * WG_LD * 4));
+        const unsigned xb = (unsigned)(size_t)(Xs + (size_t)buf * XRA * WG_LD) + (unsigned)(wave * (3 * WG_LD * 4));
+        unsigned vg = vbg + (unsigned)(dp0 * a.Cout * 4), vx = vbx + (unsigned)(dp0 * a.Cin * 4);
+        const unsigned sg = (unsigned)(12 * a.Cout * 4), sx = (unsigned)(12 * a.Cin * 4);      // four instructions (one per wave) further
+        for (int k = 0; 4 * k < nig; ++k) {
+            if (4 * k + wave < nig) mf_dma16(rgi, gb + (unsigned)(k * (12 * WG_LD * 4)), vg, 0u);
+            vg += sg;
+        }
+        for (int k = 0; 4 * k < nix; ++k) {
+            if (4 * k + wave < nix) mf_dma16(rxi, xb + (unsigned)(k * (12 * WG_LD * 4)), vx, 0u);
+            vx += sx;
         }
         dp0 += PS; if (dp0 >= a.HWp) { dp0 = 0; ++dn; }
     };
@@ -687,7 +702,7 @@ __global__ __launch_bounds__(256, PIPE ? 1 : 2) void conv_mfma_wgrad9_kernel(Wg9
     } else {
         dn = (int)(mb / a.HWp); dp0 = (int)(mb - (long)dn * a.HWp);
         dma_step(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MF_WAIT_VMCNT0();
     }
     __syncthreads();
     int it = 0;
@@ -796,7 +811,7 @@ __global__ __launch_bounds__(256, PIPE ? 1 : 2) void conv_mfma_wgrad9_kernel(Wg9
             }
         }
         if constexpr (IN16) { if (has_next) store_step(buf ^ 1, m + PS); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the next step have landed
+        else MF_WAIT_VMCNT0();                                    // this wave's pieces of the next step have landed
         __syncthreads();
     }
     // partial[chunk][tap][co][ci]: the accumulator layout as it stands (16 lanes = 64 contiguous bytes of one row); OIHW order (taps fastest) would make every

@@ -86,7 +86,9 @@ print(case, 'avg us', round(us, 2), 'TFLOP/s', round(flops / us / 1e6, 2))
 if __import__('os').environ.get('DCV_KBENCH_STAMPS') and case.endswith('p'):     # a tools/variants/*_stamps.py library: per-block time stamps (100 MHz) in the statistics buffer
     import numpy as np
     nb = int(__import__('os').environ['DCV_KBENCH_STAMPS']); ns = int(__import__('os').environ.get('DCV_KBENCH_NSTAMPS', '4'))
-    stats.zero_(); torch.cuda.synchronize(); fn(); torch.cuda.synchronize()
+    stats.zero_(); torch.cuda.synchronize()
+    for _ in range(30): fn()          # (the stamps of the LAST of 30 launches back to back: the clock of a single launch out of idle is not the clock of a running job)
+    torch.cuda.synchronize()
     s = stats.flatten()[:nb * ns].reshape(nb, ns).cpu().numpy() * 0.01       # us
     t0 = s[:, 0].min()
     print('blocks', nb, 'span us', round(float(s[:, 3].max() - t0), 1))
@@ -100,16 +102,23 @@ if __import__('os').environ.get('DCV_KBENCH_STAMPS') and case.endswith('p'):    
     idx = np.arange(nb)
     print('first-round loop time by XCD (block index % 8):', [round(float(np.mean((s[:, 2] - s[:, 1])[first & (idx % 8 == k)])), 1) for k in range(8)])
     print('first-round exit time percentiles 0/10/50/90/100:', np.round(np.percentile(s[first, 3] - t0, [0, 10, 50, 90, 100]), 1).tolist())
-    if ns >= 8:      # slot 7: HW_ID[15:0] | XCC_ID << 16 (x 0.01 above)
-        hw = np.round(s[:, 7] * 100).astype(np.int64)
-        cu = ((hw >> 16) & 0xF) * 1000 + ((hw >> 13) & 7) * 100 + ((hw >> 12) & 1) * 50 + ((hw >> 8) & 0xF)      # xcc, se, sh, cu
-        ids, counts = np.unique(cu, return_counts=True)
-        print('CUs seen', len(ids), 'blocks per CU: min', counts.min(), 'max', counts.max(), 'histogram', np.bincount(counts).tolist())
-        ends = np.array([s[cu == c, 3].max() - t0 for c in ids])
-        print('last exit per CU percentiles 0/10/50/90/100:', np.round(np.percentile(ends, [0, 10, 50, 90, 100]), 1).tolist())
-        for c in ids[:3].tolist() + ids[-2:].tolist():
-            g = s[cu == c]; g = g[np.argsort(g[:, 0])]
-            print('CU', c, [(round(float(a - t0), 1), round(float(b - t0), 1)) for a, b in zip(g[:, 0], g[:, 3])])
+    if ns >= 8:      # slot 7: core cycles per 100 MHz tick during the main loop (x 0.01 above)
+        clk = s[:, 7] * 100 * 100
+        print('core clock during the loop, MHz: min', round(float(clk.min())), 'mean', round(float(clk.mean())), 'max', round(float(clk.max())))
     order = np.argsort(s[:, 0])
     print('entry times (sorted, every 64th):', np.round(s[order, 0][::64] - t0, 1).tolist())
     print('exit times of the same blocks   :', np.round(s[order, 3][::64] - t0, 1).tolist())
+if __import__('os').environ.get('DCV_KBENCH_WSTAMPS') and case.startswith('wgrad'):     # tools/variants/mfma_wgrad9_stamps.py: per-block stamps in the first floats of each slab
+    import numpy as np
+    nb = int(__import__('os').environ['DCV_KBENCH_WSTAMPS'])
+    torch.cuda.synchronize()
+    for _ in range(30): fn()
+    torch.cuda.synchronize()
+    wtotal = cfg[1] * cfg[4] * 9
+    raw = ws.view(torch.float32)[:nb * wtotal].reshape(nb, wtotal)[:, :5].cpu().numpy()
+    sl = raw[:, :4] * 0.01
+    print('core clock during the loop (cycle counter / 100 MHz ticks), MHz: min', round(float(raw[:, 4].min() * 100)), 'mean', round(float(raw[:, 4].mean() * 100)), 'max', round(float(raw[:, 4].max() * 100)))
+    e = sl[:, 0] - sl[:, 0].min()
+    print('blocks', nb, 'entry spread us', round(float(e.max()), 1), 'mean prologue', round(float(sl[:, 1].mean()), 2), 'loop', round(float(sl[:, 2].mean()), 2), 'epilogue', round(float(sl[:, 3].mean()), 2),
+          'span', round(float((e + sl[:, 1] + sl[:, 2] + sl[:, 3]).max()), 1))
+    print('loop percentiles 0/10/50/90/100', np.round(np.percentile(sl[:, 2], [0, 10, 50, 90, 100]), 1).tolist(), 'epilogue percentiles', np.round(np.percentile(sl[:, 3], [0, 50, 100]), 1).tolist())
