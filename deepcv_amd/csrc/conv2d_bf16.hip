@@ -21,6 +21,7 @@
 // Replaces torch.nn.Conv2d forward / backward under autocast-style bf16 (reference src/deepcv/meta/submodule_creators.py:251, ignite_training.py:253).
 #include "conv2d_internal.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -44,6 +45,12 @@ struct Bf16Args {
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef int bw_i32x4 __attribute__((ext_vector_type(4)));
+// LDS-DMA from inline assembly (see conv2d_mfma.hip: the compiler must not track it as an LDS store); the kernel waits itself (s_waitcnt builtin) before its barrier
+__device__ __forceinline__ void bw_dma16(bw_i32x4 rsrc, unsigned lds_addr, unsigned voffset, unsigned soffset) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(voffset), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(soffset)) : "memory");
+}
+
 
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voffset) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds_wave_base, 16, (int)voffset, 0, 0, 0);
@@ -214,38 +221,44 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(Bf16Args a, const u16
 // LDS: 2 windows x (256 + 2 W + 2 rows rounded up to 64) x 128 B + a zero row + 2 x BN x 128 B = 122 KB at W = 32, BN = 128.
 // Bytes into LDS per 128 pixels x 128 channels x 256 input channels: 0.38 MB (window 0.09 + filters 0.29) against 1.18 MB above.
 // Same fragment layouts, swizzle (applied on the source side of the LDS-DMA), epilogue and statistics rows (one per 128 pixels: two per block) as above.
+// Round 3 (what the fp32 window kernel taught, conv2d_mfma.hip): every instruction a wave issues is paid in matrix-pipe time, and a tap of this kernel is only
+// 32 MFMAs x 8 clocks.  So: (1) the nine taps are unrolled — a tap's operand addresses are registers picked at compile time (the loop over taps selected them with a
+// chain of eight v_cndmask per tile row) and both window buffers / all filter stages lie at compile-time distances (immediate offsets of the ds_reads; windows of up
+// to 384 rows: W <= 32); (2) THREE filter stages: the filter tile of tap t + 2 is requested while tap t computes (one tap = 0.2 us is less than an L2 round trip);
+// the next chunk's window is requested one 64-row piece per tap, so that every request has the same two taps to land; waits are counted (vmcnt(N) with N = the
+// requests issued behind the one needed; the counter is in order); (3) LDS-DMA from inline assembly, so that the compiler does not wait for it in front of LDS reads.
+#define BH_WROWS 384                                                // rows of a window buffer (256 + 2 W + 2 <= 384)
+#define BH_WSTRIDE (BH_WROWS * 128 + 128)                           // window + its zero row
+#define BH_BST (2 * BH_WSTRIDE)                                     // the three filter stages
 template <int WN, bool OUT_BF16>
 __global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, const u16* __restrict__ x, const u16* __restrict__ wb, const float* __restrict__ bias,
                                                                  void* __restrict__ yv, double* __restrict__ stats, int win_rows) {
     constexpr int WM = 8 / WN, BMH = 256, TI = BMH / (16 * WM), BN = 64 * WN, PB = BN / 64;       // PB: 16-B pieces of the filter tile per thread and stage
     constexpr int B_BYTES = BN * 128;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 15, lg = lane >> 4;
     const long m0 = (long)blockIdx.x * BMH;
     const int n0 = blockIdx.y * BN;
     const int W = a.Win, H = a.Hin;
-    const int WIN_BYTES = win_rows * 128;                          // win_rows: a multiple of 64 >= 256 + 2 W + 2
-    char* const zrow = lds + 2 * WIN_BYTES;                         // 128 B of zeros
-    char* const bst = zrow + 128;                                   // two filter stages
+    const int npieces = win_rows >> 6;                              // 64-row pieces of a window (5 or 6)
 
-    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)a.x_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, (int)a.w_bytes, 0x00020000);
-    if (t < 8) *reinterpret_cast<uint4*>(zrow + t * 16) = make_uint4(0u, 0u, 0u, 0u);
+    const unsigned long long xa = (unsigned long long)x, wa = (unsigned long long)wb;
+    const bw_i32x4 rx = {(int)(unsigned)xa, (int)(unsigned)((xa >> 32) & 0xFFFFu), (int)a.x_bytes, 0x00020000};
+    const bw_i32x4 rw = {(int)(unsigned)wa, (int)(unsigned)((wa >> 32) & 0xFFFFu), (int)a.w_bytes, 0x00020000};
+    if (t < 16) *reinterpret_cast<uint4*>(lds + (t >> 3) * BH_WSTRIDE + BH_WROWS * 128 + (t & 7) * 16) = make_uint4(0u, 0u, 0u, 0u);      // the two zero rows
 
     // ---- staging roles (as above): piece p of this thread = LDS row 64 p + (t >> 3), physical slot t & 7, which holds logical slot (t & 7) ^ ((t >> 4) & 7)
     const int lslot = (t & 7) ^ ((t >> 4) & 7);
     const long q0 = m0 - W - 1;                                     // flat pixel index of window row 0
     const long Mtot = (long)a.N * H * W;
     const int cchunks = a.Cin / BF_BK;
-    auto stage_window = [&](int wbuf, int chunk) {
-        char* base = lds + wbuf * WIN_BYTES;
-        for (int p = 0; p * 64 < win_rows; ++p) {
-            const long q = q0 + 64 * p + (t >> 3);
-            const bool v = q >= 0 && q < Mtot;
-            dma16(rx, base + (p * 512 + (t & ~63)) * 16, v ? (unsigned)((q * a.Cin) * 2 + chunk * 128 + lslot * 16) : BF_OOB);
-        }
+    const unsigned lds0 = (unsigned)(size_t)lds + (unsigned)((t & ~63) * 16);
+    auto stage_window_piece = [&](int wbuf, int chunk, int p) {
+        const long q = q0 + 64 * p + (t >> 3);
+        const bool v = q >= 0 && q < Mtot;
+        bw_dma16(rx, lds0 + (unsigned)(wbuf * BH_WSTRIDE + p * 8192), v ? (unsigned)((q * a.Cin) * 2 + lslot * 16) : BF_OOB, (unsigned)(chunk * 128));
     };
     int offb[PB];
 #pragma unroll
@@ -254,15 +267,14 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, cons
         const int co = n0 + (rho & ~63) + 4 * (rho & 15) + ((rho >> 4) & 3);
         offb[p] = (co * a.Cin) * 2 + lslot * 16;
     }
-    auto stage_filter = [&](int buf, int chunk, int tap) {
-        char* base = bst + buf * B_BYTES;
-        const int ub = (tap * a.Cout) * a.Cin * 2 + chunk * 128;
+    auto stage_filter = [&](int stg, int chunk, int tap) {
+        const unsigned ub = (unsigned)((tap * a.Cout) * a.Cin * 2 + chunk * 128);
 #pragma unroll
-        for (int p = 0; p < PB; ++p) dma16(rw, base + (p * 512 + (t & ~63)) * 16, (unsigned)(offb[p] + ub));
+        for (int p = 0; p < PB; ++p) bw_dma16(rw, lds0 + (unsigned)(BH_BST + stg * B_BYTES + p * 8192), (unsigned)offb[p], ub);
     };
 
-    // ---- operand addresses: tile row i of this wave = pixel pl = 16 TI wm + 16 i + li of the block; tap (r, s) -> window row pl + r W + s, logical slot lg (K half 0;
-    // the other half is the address ^ 64), or the zero row when the tap leaves the image
+    // ---- operand addresses (relative to a window buffer): tile row i of this wave = pixel pl = 16 TI wm + 16 i + li of the block; tap (r, s) -> window row
+    // pl + r W + s, logical slot lg (K half 0; the other half is the address ^ 64), or the buffer's zero row when the tap leaves the image
     unsigned aaddr[TI][9];
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
@@ -278,12 +290,11 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, cons
                 const int hi = ho + r - 1, wi = wo + sx - 1;
                 const int R = pl + r * W + sx;
                 const bool v = ok && hi >= 0 && hi < H && wi >= 0 && wi < W;
-                aaddr[i][r * 3 + sx] = v ? (unsigned)(R * 128 + ((lg ^ ((R >> 1) & 7)) << 4)) : (unsigned)(2 * WIN_BYTES + lg * 16);
+                aaddr[i][r * 3 + sx] = v ? (unsigned)(R * 128 + ((lg ^ ((R >> 1) & 7)) << 4)) : (unsigned)(BH_WROWS * 128 + lg * 16);
             }
     }
     const int swz = (li >> 1) & 7;
-    const int b_row0 = (64 * wn + li) * 128;
-    const int s0 = ((0 + lg) ^ swz) * 16, s1 = ((4 + lg) ^ swz) * 16;
+    const unsigned bad0 = (unsigned)(BH_BST + (64 * wn + li) * 128 + ((0 + lg) ^ swz) * 16), bad1 = (unsigned)(BH_BST + (64 * wn + li) * 128 + ((4 + lg) ^ swz) * 16);
 
     f32x4 acc[TI][4];
 #pragma unroll
@@ -291,48 +302,42 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, cons
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    stage_window(0, 0);
+    for (int p = 0; p < npieces; ++p) stage_window_piece(0, 0, p);
     stage_filter(0, 0, 0);
-    int step = 0;
-    for (int chunk = 0; chunk < cchunks; ++chunk) {
-        const char* win = lds + (chunk & 1) * WIN_BYTES;
-#pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap, ++step) {
-            const int buf = step & 1;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of this step (and, at tap 0, of this chunk's window) have landed ...
-            __syncthreads();                                       // ... and everybody's; every wave is also done reading the other filter stage
-            if (tap == 0 && chunk + 1 < cchunks) stage_window((chunk + 1) & 1, chunk + 1);          // (the other window buffer: last read in the previous chunk)
-            if (tap + 1 < 9) stage_filter(buf ^ 1, chunk, tap + 1);
-            else if (chunk + 1 < cchunks) stage_filter(buf ^ 1, chunk + 1, 0);
-            const char* sb = bst + buf * B_BYTES;
-            unsigned ad[TI];
-            // (the tap index is a loop variable: select this tap's address per tile row)
+    stage_filter(1, 0, 1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0)
+    // one chunk out of window buffer PAR; tap t out of filter stage t % 3 (nine taps per chunk: the stages stay in step)
+    auto chunk_body = [&](auto par, int chunk) {
+        constexpr int PAR = decltype(par)::value;
+        const bool more = chunk + 1 < cchunks;
 #pragma unroll
-            for (int i = 0; i < TI; ++i) {
-                unsigned v = aaddr[i][0];
-#pragma unroll
-                for (int q = 1; q < 9; ++q) v = tap == q ? aaddr[i][q] : v;
-                ad[i] = v;
-            }
+        for (int tap = 0; tap < 9; ++tap) {
+            // the filter tile of this tap was requested two taps ago; behind it: the request(s) of the previous tap (PB filter pieces + one window piece while the
+            // next window is being fetched: taps 0 .. npieces - 1 >= 4)
+            if (tap == 8 && !more) __builtin_amdgcn_s_waitcnt(0x0F70);
+            else if (tap >= 1 && tap <= 5 && more) { if constexpr (PB == 2) __builtin_amdgcn_s_waitcnt(0x0F73); else __builtin_amdgcn_s_waitcnt(0x0F72); }       // vmcnt(PB + 1)
+            else { if constexpr (PB == 2) __builtin_amdgcn_s_waitcnt(0x0F72); else __builtin_amdgcn_s_waitcnt(0x0F71); }                                      // vmcnt(PB)
+            __syncthreads();                                       // everybody's pieces have landed; every wave is done reading filter stage (tap + 2) % 3
+            if (more && tap < npieces) stage_window_piece(PAR ^ 1, chunk + 1, tap);                 // (the other window buffer: last read in the previous chunk)
+            if (tap + 2 < 9) stage_filter((tap + 2) % 3, chunk, tap + 2);
+            else if (more) stage_filter((tap + 2) % 3, chunk + 1, tap - 7);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const int so = ks ? s1 : s0;
                 bf16x8 af[TI], bf[4];
 #pragma unroll
-                for (int i = 0; i < TI; ++i) {
-                    const unsigned adr = ks ? (ad[i] ^ 64u) : ad[i];
-                    const char* ap = adr >= (unsigned)(2 * WIN_BYTES) ? lds + adr : win + adr;
-                    af[i] = *reinterpret_cast<const bf16x8*>(ap);
-                }
+                for (int i = 0; i < TI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(lds + PAR * BH_WSTRIDE + (ks ? (aaddr[i][tap] ^ 64u) : aaddr[i][tap]));
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(sb + b_row0 + j * 2048 + so);
+                for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(lds + (tap % 3) * B_BYTES + j * 2048 + (ks ? bad1 : bad0));
 #pragma unroll
                 for (int i = 0; i < TI; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
             }
         }
-    }
+    };
+    int chunk = 0;
+    for (; chunk + 1 < cchunks; chunk += 2) { chunk_body(std::integral_constant<int, 0>{}, chunk); chunk_body(std::integral_constant<int, 1>{}, chunk + 1); }
+    if (chunk < cchunks) chunk_body(std::integral_constant<int, 0>{}, chunk);
 
     // ---- epilogue: acc[i][j][reg] -> pixel m0 + 16 TI wm + 16 i + 4 lg + reg, channel n0 + 64 wn + 4 li + j
     const int cbase = n0 + 64 * wn + 4 * li;
@@ -736,9 +741,8 @@ inline bool halo_plan(const Bf16Args& a, int bn, int* win_rows, size_t* smem) {
     // pixel count decides (every CU a 256-pixel tile).
     if (mode != 2 && a.M < 8192) return false;
     const int rows = (256 + 2 * a.Win + 2 + 63) / 64 * 64;
-    const size_t need = (size_t)2 * rows * 128 + 128 + (size_t)2 * bn * 128;
-    if (need > (size_t)160 * 1024) return false;
-    *win_rows = rows; *smem = need;
+    if (rows > BH_WROWS || rows < 256) return false;              // (W <= 32; at least four window pieces: the counted waits of the kernel assume them)
+    *win_rows = rows; *smem = (size_t)BH_BST + (size_t)3 * bn * 128;
     return true;
 }
 
