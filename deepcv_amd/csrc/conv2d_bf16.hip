@@ -408,10 +408,23 @@ struct W16Args {
     int HWp;                        // pixels per image rounded up to a multiple of 32
     long M, m_per_chunk;            // N * HWp; padded pixels per split-K chunk (multiple of 32)
     size_t wtotal;
+    int stages;                     // LDS stages of a wave group: 3 (tiles requested two steps ahead) where two blocks per CU can afford them, else 2
+    unsigned magic_w;               // n / W = mulhi(n, magic_w)
 };
 #define W16_PS 32
 #define W16_LD 160                  // LDS row stride in bytes
 #define W16_XP 8                    // 16-B pieces of the x window per thread and step (XR * 8 <= 256 * W16_XP)
+
+// s_waitcnt vmcnt(n) for a run-time n (the instruction takes an immediate): n = instructions per wave and step, 2 .. 12
+__device__ __forceinline__ void w16_wait(int n) {
+    switch (n) {
+        case 2: __builtin_amdgcn_s_waitcnt(0x0F72); break; case 3: __builtin_amdgcn_s_waitcnt(0x0F73); break; case 4: __builtin_amdgcn_s_waitcnt(0x0F74); break;
+        case 5: __builtin_amdgcn_s_waitcnt(0x0F75); break; case 6: __builtin_amdgcn_s_waitcnt(0x0F76); break; case 7: __builtin_amdgcn_s_waitcnt(0x0F77); break;
+        case 8: __builtin_amdgcn_s_waitcnt(0x0F78); break; case 9: __builtin_amdgcn_s_waitcnt(0x0F79); break; case 10: __builtin_amdgcn_s_waitcnt(0x0F7A); break;
+        case 11: __builtin_amdgcn_s_waitcnt(0x0F7B); break; case 12: __builtin_amdgcn_s_waitcnt(0x0F7C); break;
+        default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+    }
+}
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
@@ -422,16 +435,22 @@ __device__ __forceinline__ s16x4 tr_read(const char* p) { return __builtin_amdgc
 // the staging buffers are dead by then), which halves the number of fp32 partial slabs the ordered reduce has to read for the same number of resident waves.
 // TAPS: 9 (3x3 / pad 1) or 1 (1x1 / pad 0: a plain GEMM dW[co][ci] = sum over pixels — the weight gradient of a first layer rewritten as im2col + 1x1,
 // dcv_im2col_bf16): one tap, the x "window" is the step's 32 pixels themselves, no border masks.
+// Round 3: the tiles are staged by LDS-DMA (no VGPR round trip, no address selects: a step is only 36 MFMAs x 8 clocks per wave, and every other instruction is
+// paid in matrix-pipe time), TWO steps ahead where three stages fit the LDS budget of two blocks per CU (a step is shorter than a memory round trip).  A stage is one
+// array of 160-B rows: [36 rows of dz (32 + 4 that belong to the next step)][a gap row for the overhang][6 nix + 1 rows of the x window]; a wave instruction writes 64 consecutive 16-B pieces =
+// 6 rows of 10 pieces (8 of data, 2 of pad fetched out of range) + the first 4 pieces of a seventh row (which the next instruction writes again); the buffer
+// resources are the step's IMAGE, so window rows outside it and the padding pixels behind it read zeros.  Every wave issues the same number K of instructions per step
+// (the ones beyond the stage's 6 + nix go, all lanes out of range, to a scratch KB), so that `s_waitcnt vmcnt(K)` means "everything but the youngest step".
 template <int GROUPS, int TAPS = 9>
 __global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9_kernel(W16Args a, const u16* __restrict__ x, const u16* __restrict__ dy, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem16[];
-    const int XR = a.XR;
-    const int G_BYTES = W16_PS * W16_LD, X_BYTES = XR * W16_LD;
-    const int GROUP_BYTES = 2 * G_BYTES + 2 * X_BYTES + 2 * 16 * 2 * (int)sizeof(unsigned);
+    const int XR = a.XR, nix = (XR + 5) / 6, nst = a.stages;
+    const int STAGE_BYTES = (37 + 6 * nix + 1) * W16_LD;
+    const int GROUP_BYTES = nst * STAGE_BYTES + nst * 16 * 2 * (int)sizeof(unsigned) + 1024;
     const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), t = threadIdx.x & 255, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    char* Gs = smem16 + grp * GROUP_BYTES;                       // [2][32 rows]   dz tile [pixel][co]
-    char* Xs = Gs + 2 * G_BYTES;                                 // [2][XR rows]   x window [row][ci]
-    unsigned* Cm = reinterpret_cast<unsigned*>(Xs + 2 * X_BYTES);   // [2][16 pixel pairs][2]: and-masks of the pair's two bf16 for s = 0 (w > 0) and s = 2 (w < W - 1)
+    char* St = smem16 + grp * GROUP_BYTES;                       // [nst] stages: dz tile [36 rows][co], x window [6 nix + 1 rows][ci]
+    unsigned* Cm = reinterpret_cast<unsigned*>(St + nst * STAGE_BYTES);   // [nst][16 pixel pairs][2]: and-masks of the pair's two bf16 for s = 0 (w > 0) and s = 2 (w < W - 1)
+    const unsigned scratch = (unsigned)(size_t)St + (unsigned)(nst * STAGE_BYTES + nst * 128);
     const int li = lane & 15, lg = lane >> 4;
     const int ci0 = blockIdx.y * 64, co0 = blockIdx.z * 64;
     // pixel counts fit 32 bits (tensors are below 2 GiB); all of this is wave-uniform (scalar registers)
@@ -439,51 +458,32 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9_kernel(W16Ar
     const int mb = (int)blockIdx.x * (int)a.m_per_chunk + grp * per_group;
     int me = mb + per_group; if (me > (int)a.M) me = (int)a.M;
     const int nsteps = per_group / W16_PS;                       // the same for every group: they share the barriers
-    int l_n = mb / a.HWp, l_p0 = mb - l_n * a.HWp;               // image and first pixel of the next step to LOAD (a step never straddles images: 32 | HWp)
-    int s_p0 = 0;                                                // first pixel of the step whose tiles sit in registers
+    const int steps_g = me > mb ? (me - mb + W16_PS - 1) / W16_PS : 0;        // steps this group really has
+    int l_n = mb / a.HWp, l_p0 = mb - l_n * a.HWp;               // image and first pixel of the next step to STAGE (a step never straddles images: 32 | HWp)
     const int HW = a.H * a.W;
 
-    const int prow = t >> 3, piece = t & 7;
-    const int nxp = (XR + 31) / 32;                               // passes over the x window (block-uniform)
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    // Buffer loads: an out-of-range offset delivers zeros, so rows outside the image need no select on the loaded value (hipcc turns `ok ? load : 0` into a
-    // branch and a full vmcnt(0) drain per load) and no clamped address.
-    __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((size_t)a.N * HW * a.Cout * 2), 0x00020000);
-    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)((size_t)a.N * HW * a.Cin * 2), 0x00020000);
-    u32x4 g, xv[W16_XP];
-    auto load_step = [&]() {
-        const int n = l_n, p0 = l_p0;
-        s_p0 = p0;
-        l_p0 += W16_PS; if (l_p0 >= a.HWp) { l_p0 = 0; ++l_n; }
-        {
-            const int p = p0 + prow;
-            const unsigned off = (unsigned)(((n * HW + p) * a.Cout + co0 + 8 * piece) * 2);
-            g = __builtin_amdgcn_raw_buffer_load_b128(rdy, (int)(p < HW ? off : BF_OOB), 0, 0);
-        }
-        const int xbase = ((n * HW) * a.Cin + ci0 + 8 * piece) * 2;
-        const int q0 = TAPS == 9 ? p0 - a.W - 1 : p0;
-#pragma unroll
-        for (int u = 0; u < W16_XP; ++u)
-            if (u < nxp) {
-                const int row = prow + 32 * u, q = q0 + row;
-                const bool ok = row < XR && q >= 0 && q < HW;
-                xv[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(ok ? (unsigned)(xbase + q * a.Cin * 2) : BF_OOB), 0, 0);
-            }
-    };
-    auto store_step = [&](int buf) {
-        *reinterpret_cast<u32x4*>(Gs + buf * G_BYTES + prow * W16_LD + piece * 16) = g;
-#pragma unroll
-        for (int u = 0; u < W16_XP; ++u)
-            if (u < nxp) {
-                const int row = prow + 32 * u;
-                if (row < XR) *reinterpret_cast<u32x4*>(Xs + (size_t)buf * X_BYTES + row * W16_LD + piece * 16) = xv[u];
-            }
+    // ---- staging: lane l of an instruction = row l / 10, piece l % 10 of its six (and a bit) rows
+    const int lrow = (lane * 13) >> 7, lslot = lane - 10 * lrow;                 // lane / 10, lane % 10
+    const unsigned vbg = lslot < 8 ? (unsigned)((lrow * a.Cout + co0 + 8 * lslot) * 2) : BF_OOB;
+    const unsigned vbx = lslot < 8 ? (unsigned)(((lrow - (TAPS == 9 ? a.W + 1 : 0)) * a.Cin + ci0 + 8 * lslot) * 2) : BF_OOB;      // (mod 2^32: rows above the image wrap out of range)
+    const int ktot = (6 + nix + 3) >> 2;                          // instructions per wave and step
+    auto dma_step = [&](int stg) {
+        const unsigned long long ga = (unsigned long long)(dy + (size_t)l_n * HW * a.Cout), xa = (unsigned long long)(x + (size_t)l_n * HW * a.Cin);
+        const bw_i32x4 rg = {(int)(unsigned)ga, (int)(unsigned)((ga >> 32) & 0xFFFFu), HW * a.Cout * 2, 0x00020000};
+        const bw_i32x4 rxi = {(int)(unsigned)xa, (int)(unsigned)((xa >> 32) & 0xFFFFu), HW * a.Cin * 2, 0x00020000};
+        const unsigned sb = (unsigned)(size_t)St + (unsigned)(stg * STAGE_BYTES);
         if (TAPS == 9 && t < 16) {
-            const int pw = s_p0 + 2 * t;
-            const int w0 = pw % a.W, w1 = (pw + 1) % a.W;
-            Cm[(buf * 16 + t) * 2 + 0] = (w0 > 0 ? 0x0000ffffu : 0u) | (w1 > 0 ? 0xffff0000u : 0u);
-            Cm[(buf * 16 + t) * 2 + 1] = (w0 < a.W - 1 ? 0x0000ffffu : 0u) | (w1 < a.W - 1 ? 0xffff0000u : 0u);
+            const unsigned pw = (unsigned)(l_p0 + 2 * t), w0 = pw - __umulhi(pw, a.magic_w) * (unsigned)a.W, w1 = (w0 + 1 == (unsigned)a.W) ? 0u : w0 + 1;
+            Cm[(stg * 16 + t) * 2 + 0] = (w0 > 0 ? 0x0000ffffu : 0u) | (w1 > 0 ? 0xffff0000u : 0u);
+            Cm[(stg * 16 + t) * 2 + 1] = (w0 + 1 < (unsigned)a.W ? 0x0000ffffu : 0u) | (w1 + 1 < (unsigned)a.W ? 0xffff0000u : 0u);
         }
+        for (int k = 0; k < ktot; ++k) {
+            const int idx = 4 * k + wave;                         // (uniform)
+            if (idx < 6) bw_dma16(rg, sb + (unsigned)(idx * 960), vbg + (unsigned)((l_p0 + 6 * idx) * a.Cout * 2), 0u);
+            else if (idx < 6 + nix) bw_dma16(rxi, sb + (unsigned)(W16_LD + idx * 960), vbx + (unsigned)((l_p0 + 6 * (idx - 6)) * a.Cin * 2), 0u);
+            else bw_dma16(rxi, scratch, BF_OOB, 0u);
+        }
+        l_p0 += W16_PS; if (l_p0 >= a.HWp) { l_p0 = 0; ++l_n; }
     };
 
     f32x4 acc[TAPS][4];
@@ -497,19 +497,21 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9_kernel(W16Ar
     const int a_off = tr_row * W16_LD + tr_col;                  // + 32 t for output-channel tile t, + 16 rows for the second half of K
     const int b_off = tr_row * W16_LD + wave * 32 + tr_col;      // + (r W + s) rows for tap (r, s)
 
-    if (mb < me) { load_step(); store_step(0); }                 // (group-uniform)
-    __syncthreads();
+    // prologue: the first nst - 1 steps
+    for (int j = 0; j < nst - 1; ++j) if (j < steps_g) dma_step(j);
     for (int it = 0; it < nsteps; ++it) {
-        const int m = mb + it * W16_PS;
-        const int buf = it & 1;
-        const bool active = m < me, has_next = (m + W16_PS) < me;    // group-uniform: a group whose range ended early only keeps the barriers
-        if (has_next) load_step();
+        const int stg = it % nst;
+        const bool active = it < steps_g;                        // group-uniform: a group whose range ended early only keeps the barriers
+        // this step's tiles were requested nst - 1 steps ago; behind them (three stages): the K instructions of the next step, if it exists
+        if (active) { if (nst == 3 && it + 1 < steps_g) w16_wait(ktot); else __builtin_amdgcn_s_waitcnt(0x0F70); }
+        __syncthreads();                                         // everybody's pieces have landed; every wave is done with the stage of step it - 1
+        if (it + nst - 1 < steps_g) dma_step((it + nst - 1) % nst);
         if (active) {
-            const char* gs = Gs + buf * G_BYTES;
-            const char* xs = Xs + (size_t)buf * X_BYTES;
+            const char* gs = St + stg * STAGE_BYTES;
+            const char* xs = gs + 37 * W16_LD;
             // masks of this lane's eight pixels (pairs 2g, 2g+1 and 8+2g, 8+2g+1): {left01, right01, left23, right23}
-            const uint4 mk0 = *reinterpret_cast<const uint4*>(Cm + (buf * 16 + 2 * lg) * 2);
-            const uint4 mk1 = *reinterpret_cast<const uint4*>(Cm + (buf * 16 + 8 + 2 * lg) * 2);
+            const uint4 mk0 = *reinterpret_cast<const uint4*>(Cm + (stg * 16 + 2 * lg) * 2);
+            const uint4 mk1 = *reinterpret_cast<const uint4*>(Cm + (stg * 16 + 8 + 2 * lg) * 2);
             union Frag { bf16x8 v; s16x4 h[2]; unsigned u[4]; };
             Frag af[4];
 #pragma unroll
@@ -541,9 +543,8 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9_kernel(W16Ar
                 }
             }
         }
-        if (has_next) store_step(buf ^ 1);
-        __syncthreads();
     }
+    __syncthreads();                                             // (the stages are dead: group 1's accumulators go there)
     if constexpr (GROUPS == 2) {
         // acc of group 1 -> LDS -> added by group 0 (fixed order: group 0 + group 1)
         f32x4* red = reinterpret_cast<f32x4*>(smem16);
@@ -573,10 +574,14 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9_kernel(W16Ar
             }
 }
 
-inline int w16_groups() {              // wave groups per block (2: in-block sum of two pixel halves, half the partial slabs).  Measured at N = 512: a tie on
-    static int gr = -1;                // 64- and 256-channel layers (71.7 vs 72.3 us, 209.9 vs 209.2 us), 206 vs 195 us on 512 -> 512 @8x8: one group by default
-    if (gr < 0) { const char* e = getenv("DCV_BF16_WGRAD9_GROUPS"); gr = e ? atoi(e) : 1; if (gr != 2) gr = 1; }
-    return gr;
+// wave groups per block (2: in-block sum of two pixel halves, half the partial slabs).  The slabs are what this operator costs on narrow layers — 512 blocks x
+// 147 KB written and read again by the ordered sum: half of the 70 us of 64 -> 64 @32x32 at N = 512.  Measured at N = 512 with the DMA staging (round 3), two
+// groups against one: 65.7 vs 69.8 us (64 -> 64 @32x32), 64.1 vs 81.5 (256 -> 256 @8x8), ties at 128 -> 128 and 256 -> 256 @16x16, 192 vs 175 (512 -> 512 @8x8),
+// 105 vs 101 (512 -> 512 @4x4): two groups up to 16 (co, ci) tiles.  DCV_BF16_WGRAD9_GROUPS = 1 / 2 forces one setting.
+inline int w16_groups(int tiles) {
+    static int gr = -1;
+    if (gr < 0) { const char* e = getenv("DCV_BF16_WGRAD9_GROUPS"); gr = e ? atoi(e) : 0; if (gr != 1 && gr != 2) gr = 0; }
+    return gr ? gr : (tiles <= 16 ? 2 : 1);
 }
 
 inline bool w16_plan(const dcv_conv2d_desc* d, W16Args* a, int* chunks, size_t* smem, int* groups) {
@@ -589,15 +594,21 @@ inline bool w16_plan(const dcv_conv2d_desc* d, W16Args* a, int* chunks, size_t* 
     if (!one && (d->r != 3 || d->s != 3 || d->pad_h != 1 || d->pad_w != 1)) return false;
     if (d->cin % 64 != 0 || d->cout % 64 != 0 || d->ho != d->h || d->wo != d->w) return false;
     const int hw = d->h * d->w, XR = one ? W16_PS : W16_PS + 2 * d->w + 2;
-    if (XR * 8 > 256 * W16_XP) return false;
+    if (d->w < 2 || (size_t)hw * d->cin * 2 >= ((size_t)1 << 31) || (size_t)hw * d->cout * 2 >= ((size_t)1 << 31)) return false;      // (32-bit buffer offsets inside an image)
     const int hwp = (hw + W16_PS - 1) / W16_PS * W16_PS;
     if (hwp > 2 * hw) return false;                                                    // more than half of the steps' pixels would be padding (4x4 images: exactly half, still 2x the 16-pixel-step kernel)
-    const size_t group_bytes = (size_t)2 * W16_PS * W16_LD + (size_t)2 * XR * W16_LD + (size_t)2 * 16 * 2 * sizeof(unsigned);
-    int gr = w16_groups();
-    if (gr == 2 && 2 * group_bytes > (size_t)150 * 1024) gr = 1;
+    const int nix = (XR + 5) / 6;
+    if (6 + nix > 48) return false;                                                    // (at most 12 instructions per wave and step: w16_wait)
+    const size_t stage_bytes = (size_t)(37 + 6 * nix + 1) * W16_LD;
+    auto group_bytes_of = [&](int nst) { return (size_t)nst * stage_bytes + (size_t)nst * 16 * 2 * sizeof(unsigned) + 1024; };
+    int gr = w16_groups((d->cin / 64) * (d->cout / 64));
+    int nst = group_bytes_of(3) * gr <= (size_t)80 * 1024 ? 3 : 2;
+    if (gr == 2 && 2 * group_bytes_of(nst) > (size_t)150 * 1024) { gr = 1; nst = group_bytes_of(3) <= (size_t)80 * 1024 ? 3 : 2; }
+    const size_t group_bytes = group_bytes_of(nst);
     if (group_bytes > (size_t)80 * 1024) return false;
     *smem = gr == 2 ? (2 * group_bytes > (size_t)36 * 256 * 16 ? 2 * group_bytes : (size_t)36 * 256 * 16) : group_bytes;
     *groups = gr;
+    a->stages = nst; a->magic_w = 0xFFFFFFFFu / (unsigned)d->w + 1u;
     a->N = d->n; a->H = d->h; a->W = d->w; a->Cin = d->cin; a->Cout = d->cout; a->XR = XR; a->HWp = hwp;
     a->M = (long)d->n * hwp;
     a->wtotal = (size_t)d->cout * d->cin * (one ? 1 : 9);
