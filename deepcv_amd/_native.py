@@ -68,7 +68,7 @@ class NormChainDesc(ctypes.Structure):
                 ('bn_gamma', _c_void_p), ('bn_beta', _c_void_p), ('running_mean', _c_void_p), ('running_var', _c_void_p), ('num_batches_tracked', _c_void_p),
                 ('momentum', _c_float), ('bn_eps', _c_float), ('bn_mean', _c_void_p), ('bn_rstd', _c_void_p),
                 ('groups', _c_int), ('gn_gamma', _c_void_p), ('gn_beta', _c_void_p), ('gn_eps', _c_float), ('gn_mean', _c_void_p), ('gn_rstd', _c_void_p),
-                ('coef', _c_void_p), ('act', _c_int), ('act_slope', _c_float), ('io_dtype', _c_int)]
+                ('coef', _c_void_p), ('act', _c_int), ('act_slope', _c_float), ('io_dtype', _c_int), ('d_bias', _c_void_p)]
 
 
 RESIDENT_MAX_OPS = 10

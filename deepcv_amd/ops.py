@@ -866,11 +866,11 @@ class _ConvNormLayerFn(torch.autograd.Function):
             coef = torch.empty(int(lib.dcv_norm_chain_coef_floats(nc)), dtype=torch.float32, device=dev)
             nc.coef = coef.data_ptr()
             nc.io_dtype = nat.DTYPE_BF16 if ctx.io16 else nat.DTYPE_F32
+            if db is not None and not db_from_wgrad:
+                nc.d_bias = db.data_ptr()                    # summed while dz is written (no second pass over dz)
             ws = _ws(lib.dcv_norm_chain_ws_bytes(nc), dev)
             nat.check(lib.dcv_norm_chain_bwd(nc, dout.data_ptr(), y.data_ptr(), dz.data_ptr(), nat.ptr(d_bn_w), nat.ptr(d_bn_b), nat.ptr(d_gn_w), nat.ptr(d_gn_b),
                                              ws.data_ptr(), ws.numel(), st), 'dcv_norm_chain_bwd')
-            if db is not None and not db_from_wgrad:
-                _channel_sum(dz, db, d.n * hw, c, st)
         else:
             ws = _ws(lib.dcv_norm_chain_workspace_bytes(d.n, hw, c), dev)
             nat.check(lib.dcv_bn_gn_pool_act_bwd(dout.data_ptr(), y.data_ptr(), dz.data_ptr(), d.n, hw, c, nat.ptr(bn_w), nat.ptr(bn_b), bn_mean.data_ptr(), bn_rstd.data_ptr(),

@@ -299,7 +299,7 @@ int dcv_bn_gn_pool_act_bwd(const float* dout, const float* x, float* dz, int n, 
  *   dcv_norm_chain_coef_floats size of `coef` (scratch of one call: the forward keeps S, T there, the backward P, Q, R)
  *   stats / stats_rows / stats_rows_per_sample: [2][channels][stats_rows] sums of x, x^2 left by the producer (nullable); with groups > 0 they are only used
  *                              when aligned to samples (stats_rows == n * stats_rows_per_sample)
- * The convolution bias gradient is not produced here: dcv_conv2d_wgrad sums dz (dcv_conv2d_wgrad_fuses_bias) or dcv_channel_sum does. */
+ * The convolution bias gradient: dcv_norm_chain_desc::d_bias (summed by the backward's last launch), or dcv_conv2d_wgrad (dcv_conv2d_wgrad_fuses_bias) / dcv_channel_sum. */
 typedef struct dcv_norm_chain_desc {
     int n, hw, channels;           /* x: [n][hw][channels] fp32 NHWC, the activated convolution output */
     int width, pool;               /* pool > 0: out / dout are the pooled tensors [n][hw / pool^2][channels]; width = W of x */
@@ -313,6 +313,8 @@ typedef struct dcv_norm_chain_desc {
     float* coef;                                           /* dcv_norm_chain_coef_floats(d) floats */
     int act; float act_slope;                              /* activation which produced x (its derivative is taken from x) */
     int io_dtype;                                          /* element type of x / out / dout / dz: DCV_DTYPE_F32 (0, default) or DCV_DTYPE_BF16 (bf16 storage path) */
+    float* d_bias;                                         /* nullable; dcv_norm_chain_bwd only: [channels] sums of dz over (n, hw) — the bias gradient of the
+                                                              convolution which produced x, summed while dz is written (no second pass over dz) */
 } dcv_norm_chain_desc;
 int dcv_norm_chain_supported(const dcv_norm_chain_desc* d);
 size_t dcv_norm_chain_coef_floats(const dcv_norm_chain_desc* d);

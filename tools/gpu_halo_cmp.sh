@@ -1,4 +1,5 @@
 mkdir -p gpurun_out/r3s
-timeout -k 10 600 python -m pytest tests/test_bf16_gpu.py tests/test_model_gpu.py -x -q --timeout 400 -k "bf16 or wide" > gpurun_out/r3s/pytest_bf16.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -3 gpurun_out/r3s/pytest_bf16.log
+timeout -k 10 900 python -m pytest tests/test_bf16_gpu.py tests/test_model_gpu.py tests/test_ops_gpu.py -x -q --timeout 400 -k "bf16 or wide or conv_norm or model or train" > gpurun_out/r3s/pytest_bf16.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -3 gpurun_out/r3s/pytest_bf16.log
 [ $rc -eq 0 ] || exit $rc
-for m in 0 1 0; do echo "DCV_BF16_WGRAD9_GROUPS=$m"; DCV_BF16_WGRAD9_GROUPS=$m python tools/wide_bench.py cifar100_deep_model 512 20 graph,bf16 2>&1 | tail -1; DCV_BF16_WGRAD9_GROUPS=$m python tools/wide_bench.py resnet18_style_model 64 20 graph,bf16 2>&1 | tail -1; done
+python tools/wide_bench.py cifar100_deep_model 512 20 graph,bf16 2>&1 | tail -1; python tools/wide_bench.py resnet18_style_model 64 20 graph,bf16 2>&1 | tail -1
+python tools/wide_bench.py cifar100_deep_model 512 20 graph 2>&1 | tail -1
