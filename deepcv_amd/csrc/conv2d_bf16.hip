@@ -601,7 +601,7 @@ inline bool w16_plan(const dcv_conv2d_desc* d, W16Args* a, int* chunks, size_t* 
     if (6 + nix > 48) return false;                                                    // (at most 12 instructions per wave and step: w16_wait)
     const size_t stage_bytes = (size_t)(37 + 6 * nix + 1) * W16_LD;
     auto group_bytes_of = [&](int nst) { return (size_t)nst * stage_bytes + (size_t)nst * 16 * 2 * sizeof(unsigned) + 1024; };
-    int gr = w16_groups((d->cin / 64) * (d->cout / 64));
+    int gr = w16_groups(one ? 1000 : (d->cin / 64) * (d->cout / 64));      // (the one-tap GEMM of a first layer has few, long chunks: 134 us with one group, 211 with two on the ResNet stem)
     int nst = group_bytes_of(3) * gr <= (size_t)80 * 1024 ? 3 : 2;
     if (gr == 2 && 2 * group_bytes_of(nst) > (size_t)150 * 1024) { gr = 1; nst = group_bytes_of(3) <= (size_t)80 * 1024 ? 3 : 2; }
     const size_t group_bytes = group_bytes_of(nst);
