@@ -22,6 +22,13 @@ __device__ __forceinline__ void pl_ld4(const pl_u16* p, float (&v)[4]) {
 }
 __device__ __forceinline__ void pl_st(float* p, float v) { *p = v; }
 __device__ __forceinline__ void pl_st(pl_u16* p, float v) { const __bf16 h = (__bf16)v; *p = __builtin_bit_cast(pl_u16, h); }
+// four consecutive channels with ONE store (round 3: the kernels wrote them as four 2-byte / 4-byte stores and read the max indices one by one; the ResNet stem's
+// max-pool backward took 191 us for 77 MB)
+__device__ __forceinline__ void pl_st4(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void pl_st4(pl_u16* p, const float (&v)[4]) {
+    typedef __bf16 pl_bf4 __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<pl_bf4*>(p) = (pl_bf4){(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+}
 
 // IDX: unsigned (tensors below 2^32 elements: a 64-bit division is ~100 VALU instructions, and the index decode was most of these kernels' time) or size_t
 template <int VEC, int MODE, typename T, typename IDX>
@@ -57,10 +64,16 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(dcv_pool2d_desc d, const 
             }
         }
         const size_t o = (((size_t)n * d.ho + ho) * d.wo + wo) * d.c + c;
+        if constexpr (VEC == 4) {
+            if (MODE != DCV_POOL_MAX) {
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            pl_st(y + o + k, (MODE == DCV_POOL_MAX) ? acc[k] : acc[k] * inv);
-            if (MODE == DCV_POOL_MAX) argmax[o + k] = arg[k];
+                for (int k = 0; k < 4; ++k) acc[k] *= inv;
+            }
+            pl_st4(y + o, acc);
+            if (MODE == DCV_POOL_MAX) *reinterpret_cast<int4*>(argmax + o) = make_int4(arg[0], arg[1], arg[2], arg[3]);
+        } else {
+            pl_st(y + o, (MODE == DCV_POOL_MAX) ? acc[0] : acc[0] * inv);
+            if (MODE == DCV_POOL_MAX) argmax[o] = arg[0];
         }
     }
 }
@@ -91,15 +104,22 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(dcv_pool2d_desc d, const 
         for (int ho = holo; ho <= hohi; ++ho)
             for (int wo = wolo; wo <= wohi; ++wo) {
                 const size_t o = (((size_t)n * d.ho + ho) * d.wo + wo) * d.c + c;
+                if constexpr (VEC == 4) {
+                    float g[4]; pl_ld4(dy + o, g);
+                    if (MODE == DCV_POOL_MAX) {
+                        const int4 am = *reinterpret_cast<const int4*>(argmax + o);
+                        acc[0] += am.x == me ? g[0] : 0.f; acc[1] += am.y == me ? g[1] : 0.f; acc[2] += am.z == me ? g[2] : 0.f; acc[3] += am.w == me ? g[3] : 0.f;
+                    } else {
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    if (MODE == DCV_POOL_MAX) { if (argmax[o + k] == me) acc[k] += pl_ld(dy + o + k); }
-                    else acc[k] += pl_ld(dy + o + k) * inv;
+                        for (int k = 0; k < 4; ++k) acc[k] += g[k] * inv;
+                    }
+                } else {
+                    if (MODE == DCV_POOL_MAX) { if (argmax[o] == me) acc[0] += pl_ld(dy + o); }
+                    else acc[0] += pl_ld(dy + o) * inv;
                 }
             }
         const size_t xi = (((size_t)n * d.h + h) * d.w + w) * d.c + c;
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) pl_st(dx + xi + k, acc[k]);
+        if constexpr (VEC == 4) pl_st4(dx + xi, acc); else pl_st(dx + xi, acc[0]);
     }
 }
 
@@ -112,7 +132,8 @@ inline bool pool_desc_ok(const dcv_pool2d_desc* d) {
 
 template <typename T>
 int pool_fwd_launch(const dcv_pool2d_desc* d, const T* x, T* y, int32_t* argmax, hipStream_t st) {
-    const int vec = d->c % 4 == 0 ? 4 : 1;
+    // (four channels per thread need the vectors' alignment: 4 elements of T, 16 B for the max indices)
+    const int vec = (d->c % 4 == 0 && reinterpret_cast<uintptr_t>(x) % (4 * sizeof(T)) == 0 && reinterpret_cast<uintptr_t>(y) % (4 * sizeof(T)) == 0 && reinterpret_cast<uintptr_t>(argmax) % 16 == 0) ? 4 : 1;
     const size_t items = (size_t)d->n * d->ho * d->wo * (d->c / vec);
     const unsigned grid = dcv_stream_grid(items, 256);
     const bool small = (size_t)d->n * d->h * d->w * d->c < ((size_t)1 << 31);      // every element index fits 32 bits
@@ -126,7 +147,7 @@ int pool_fwd_launch(const dcv_pool2d_desc* d, const T* x, T* y, int32_t* argmax,
 
 template <typename T>
 int pool_bwd_launch(const dcv_pool2d_desc* d, const T* dy, const int32_t* argmax, T* dx, hipStream_t st) {
-    const int vec = d->c % 4 == 0 ? 4 : 1;
+    const int vec = (d->c % 4 == 0 && reinterpret_cast<uintptr_t>(dy) % (4 * sizeof(T)) == 0 && reinterpret_cast<uintptr_t>(dx) % (4 * sizeof(T)) == 0 && reinterpret_cast<uintptr_t>(argmax) % 16 == 0) ? 4 : 1;
     const unsigned grid = dcv_stream_grid((size_t)d->n * d->h * d->w * (d->c / vec), 256);
     const bool small = (size_t)d->n * d->h * d->w * d->c < ((size_t)1 << 31);
 #define DCV_POOL_BWD(V, M) do { if (small) hipLaunchKernelGGL((pool_bwd_kernel<V, M, T, unsigned>), dim3(grid), dim3(256), 0, st, *d, dy, argmax, dx); \
