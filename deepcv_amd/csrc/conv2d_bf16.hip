@@ -42,6 +42,7 @@ struct Bf16Args {
     long M;                        // N * Hout * Wout
     unsigned x_bytes, w_bytes;     // buffer sizes (num_records)
     int phase, oh_mul, ow_mul, oh_off, ow_off, Hfull, Wfull;      // strided data gradient: this launch writes phase (oh_off, ow_off) of the full tensor
+    unsigned magic_w, magic_h;     // the window kernel: floor((2^32 - 1) / Win) + 1, ... / Hin + 1: n / d = mulhi(n, magic) for n d < 2^32
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -252,13 +253,12 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, cons
     // ---- staging roles (as above): piece p of this thread = LDS row 64 p + (t >> 3), physical slot t & 7, which holds logical slot (t & 7) ^ ((t >> 4) & 7)
     const int lslot = (t & 7) ^ ((t >> 4) & 7);
     const long q0 = m0 - W - 1;                                     // flat pixel index of window row 0
-    const long Mtot = (long)a.N * H * W;
     const int cchunks = a.Cin / BF_BK;
     const unsigned lds0 = (unsigned)(size_t)lds + (unsigned)((t & ~63) * 16);
+    // (offsets modulo 2^32: a pixel in front of the tensor wraps beyond num_records, one behind it exceeds it — zeros either way, no compare; x_bytes < 2^31)
+    const unsigned wv0 = (unsigned)((int)q0 + (t >> 3)) * (unsigned)(a.Cin * 2) + (unsigned)(lslot * 16), wvstep = (unsigned)(64 * a.Cin * 2);
     auto stage_window_piece = [&](int wbuf, int chunk, int p) {
-        const long q = q0 + 64 * p + (t >> 3);
-        const bool v = q >= 0 && q < Mtot;
-        bw_dma16(rx, lds0 + (unsigned)(wbuf * BH_WSTRIDE + p * 8192), v ? (unsigned)((q * a.Cin) * 2 + lslot * 16) : BF_OOB, (unsigned)(chunk * 128));
+        bw_dma16(rx, lds0 + (unsigned)(wbuf * BH_WSTRIDE + p * 8192), wv0 + (unsigned)p * wvstep, (unsigned)(chunk * 128));
     };
     int offb[PB];
 #pragma unroll
@@ -275,22 +275,23 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, cons
 
     // ---- operand addresses (relative to a window buffer): tile row i of this wave = pixel pl = 16 TI wm + 16 i + li of the block; tap (r, s) -> window row
     // pl + r W + s, logical slot lg (K half 0; the other half is the address ^ 64), or the buffer's zero row when the tap leaves the image
+    // (index decode in 32 bits with multiply-high by host-made reciprocals: the 64-bit % and / this started with are ~150 instructions each — twelve of them were
+    // 5 us of every block's prologue, with nothing to overlap them at one block per CU)
+    const unsigned um0 = (unsigned)m0, q0w = __umulhi(um0, a.magic_w), wo0 = um0 - q0w * (unsigned)W, ho0 = q0w - __umulhi(q0w, a.magic_h) * (unsigned)H;
     unsigned aaddr[TI][9];
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
         const int pl = 16 * TI * wm + 16 * i + li;
-        const long m = m0 + pl;
-        const bool ok = m < a.M;
-        const long mm = ok ? m : 0;
-        const int wo = (int)(mm % W), ho = (int)((mm / W) % H);
+        const bool ok = m0 + pl < a.M;
+        const unsigned u = wo0 + (unsigned)pl, dq = __umulhi(u, a.magic_w), wo = u - dq * (unsigned)W;
+        const unsigned vv = ho0 + dq, ho = vv - __umulhi(vv, a.magic_h) * (unsigned)H;
+        const bool rok[3] = {ok && ho > 0, ok, ok && ho + 1 < (unsigned)H}, cok[3] = {wo > 0, true, wo + 1 < (unsigned)W};
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int sx = 0; sx < 3; ++sx) {
-                const int hi = ho + r - 1, wi = wo + sx - 1;
                 const int R = pl + r * W + sx;
-                const bool v = ok && hi >= 0 && hi < H && wi >= 0 && wi < W;
-                aaddr[i][r * 3 + sx] = v ? (unsigned)(R * 128 + ((lg ^ ((R >> 1) & 7)) << 4)) : (unsigned)(BH_WROWS * 128 + lg * 16);
+                aaddr[i][r * 3 + sx] = (rok[r] && cok[sx]) ? (unsigned)(R * 128 + ((lg ^ ((R >> 1) & 7)) << 4)) : (unsigned)(BH_WROWS * 128 + lg * 16);
             }
     }
     const int swz = (li >> 1) & 7;
@@ -752,7 +753,7 @@ inline bool halo_plan(const Bf16Args& a, int bn, int* win_rows, size_t* smem) {
     // pixel count decides (every CU a 256-pixel tile).
     if (mode != 2 && a.M < 8192) return false;
     const int rows = (256 + 2 * a.Win + 2 + 63) / 64 * 64;
-    if (rows > BH_WROWS || rows < 256) return false;              // (W <= 32; at least four window pieces: the counted waits of the kernel assume them)
+    if (rows > BH_WROWS || rows < 256 || a.Win < 2 || a.Hin < 2 || a.M >= ((long)1 << 31) || a.x_bytes >= 0x80000000u) return false;      // (W <= 56; at least four window pieces: the counted waits of the kernel assume them)
     *win_rows = rows; *smem = (size_t)BH_BST + (size_t)3 * bn * 128;
     return true;
 }
@@ -764,15 +765,17 @@ int launch(const Bf16Args& a, const u16* x, const u16* wb, const float* bias, vo
     {
         int win_rows = 0; size_t hs = 0;
         if (halo_plan(a, wide ? 128 : 64, &win_rows, &hs)) {
+            Bf16Args ah = a;
+            ah.magic_w = 0xFFFFFFFFu / (unsigned)a.Win + 1u; ah.magic_h = 0xFFFFFFFFu / (unsigned)a.Hin + 1u;
             static bool hconf[2] = {false, false};
             dim3 hgrid((unsigned)dcv_ceil_div((size_t)a.M, 256), (unsigned)(a.Cout / (wide ? 128 : 64)));
             if (hgrid.y > 65535) return DCV_ERR_UNSUPPORTED;
             if (wide) {
                 if (!hconf[0]) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_halo_kernel<2, OUT_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DCV_ERR_LAUNCH; hconf[0] = true; }
-                hipLaunchKernelGGL((conv_bf16_halo_kernel<2, OUT_BF16>), hgrid, dim3(512), hs, st, a, x, wb, bias, y, stats, win_rows);
+                hipLaunchKernelGGL((conv_bf16_halo_kernel<2, OUT_BF16>), hgrid, dim3(512), hs, st, ah, x, wb, bias, y, stats, win_rows);
             } else {
                 if (!hconf[1]) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_halo_kernel<1, OUT_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DCV_ERR_LAUNCH; hconf[1] = true; }
-                hipLaunchKernelGGL((conv_bf16_halo_kernel<1, OUT_BF16>), hgrid, dim3(512), hs, st, a, x, wb, bias, y, stats, win_rows);
+                hipLaunchKernelGGL((conv_bf16_halo_kernel<1, OUT_BF16>), hgrid, dim3(512), hs, st, ah, x, wb, bias, y, stats, win_rows);
             }
             return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
         }
