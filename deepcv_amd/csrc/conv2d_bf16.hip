@@ -84,7 +84,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(Bf16Args a, const u16
         const long m = m0 + 32 * p + (t >> 3);
         const bool ok = m < a.M;
         const long mm = ok ? m : 0;
-        const int wo = (int)(mm % a.Wout); const long r1 = mm / a.Wout; const int ho = (int)(r1 % a.Hout); const int n = (int)(r1 / a.Hout);
+        int wo, ho, n;
+        if (a.magic_w != 0u) {       // (uniform) 32-bit decode by multiply-high: three 64-bit divisions per row were several microseconds of every block's prologue
+            const unsigned um = (unsigned)mm, r1 = __umulhi(um, a.magic_w), nn = __umulhi(r1, a.magic_h);
+            wo = (int)(um - r1 * (unsigned)a.Wout); ho = (int)(r1 - nn * (unsigned)a.Hout); n = (int)nn;
+        } else { wo = (int)(mm % a.Wout); const long r1 = mm / a.Wout; ho = (int)(r1 % a.Hout); n = (int)(r1 / a.Hout); }
         const int hi0 = ho * a.sh - a.ph, wi0 = wo * a.sw - a.pw;
         offa[p] = (((n * a.Hin + hi0) * a.Win + wi0) * a.Cin) * 2 + lslot * 16;      // may be negative for border pixels: only used under its validity bit
         unsigned long long mk = 0;
@@ -176,7 +180,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(Bf16Args a, const u16
                 }
                 size_t off = (size_t)m;
                 if (a.phase) {
-                    const int jj = (int)(m % a.Wout); const long r1 = m / a.Wout; const int ii = (int)(r1 % a.Hout); const long nn = r1 / a.Hout;
+                    int jj, ii; long nn;
+                    if (a.magic_w != 0u) { const unsigned um = (unsigned)m, r1 = __umulhi(um, a.magic_w), n2 = __umulhi(r1, a.magic_h); jj = (int)(um - r1 * (unsigned)a.Wout); ii = (int)(r1 - n2 * (unsigned)a.Hout); nn = n2; }
+                    else { jj = (int)(m % a.Wout); const long r1 = m / a.Wout; ii = (int)(r1 % a.Hout); nn = r1 / a.Hout; }
                     off = ((size_t)nn * a.Hfull + (size_t)ii * a.oh_mul + a.oh_off) * a.Wfull + (size_t)jj * a.ow_mul + a.ow_off;
                 }
                 if constexpr (OUT_BF16) {
@@ -753,20 +759,23 @@ inline bool halo_plan(const Bf16Args& a, int bn, int* win_rows, size_t* smem) {
     // pixel count decides (every CU a 256-pixel tile).
     if (mode != 2 && a.M < 8192) return false;
     const int rows = (256 + 2 * a.Win + 2 + 63) / 64 * 64;
-    if (rows > BH_WROWS || rows < 256 || a.Win < 2 || a.Hin < 2 || a.M >= ((long)1 << 31) || a.x_bytes >= 0x80000000u) return false;      // (W <= 56; at least four window pieces: the counted waits of the kernel assume them)
+    if (rows > BH_WROWS || rows < 256 || a.magic_w == 0u || a.M >= ((long)1 << 31) || a.x_bytes >= 0x80000000u) return false;      // (W <= 56; at least four window pieces: the counted waits of the kernel assume them)
     *win_rows = rows; *smem = (size_t)BH_BST + (size_t)3 * bn * 128;
     return true;
 }
 
 template <bool OUT_BF16>
-int launch(const Bf16Args& a, const u16* x, const u16* wb, const float* bias, void* y, double* stats, hipStream_t st) {
+int launch(const Bf16Args& a0, const u16* x, const u16* wb, const float* bias, void* y, double* stats, hipStream_t st) {
+    Bf16Args a = a0;
+    // n / d = mulhi(n, floor((2^32 - 1) / d) + 1) is exact while n d < 2^32 (0: the kernels divide in 64 bits)
+    const bool small = a.Wout >= 2 && a.Hout >= 2 && (size_t)a.M * (size_t)(a.Wout > a.Hout ? a.Wout : a.Hout) < ((size_t)1 << 32);
+    a.magic_w = small ? 0xFFFFFFFFu / (unsigned)a.Wout + 1u : 0u; a.magic_h = small ? 0xFFFFFFFFu / (unsigned)a.Hout + 1u : 0u;
     static bool configured[2] = {false, false};
     const bool wide = a.Cout % 128 == 0;
     {
         int win_rows = 0; size_t hs = 0;
         if (halo_plan(a, wide ? 128 : 64, &win_rows, &hs)) {
-            Bf16Args ah = a;
-            ah.magic_w = 0xFFFFFFFFu / (unsigned)a.Win + 1u; ah.magic_h = 0xFFFFFFFFu / (unsigned)a.Hin + 1u;
+            const Bf16Args& ah = a;                               // (Win == Wout, Hin == Hout here: the reciprocals are the window's)
             static bool hconf[2] = {false, false};
             dim3 hgrid((unsigned)dcv_ceil_div((size_t)a.M, 256), (unsigned)(a.Cout / (wide ? 128 : 64)));
             if (hgrid.y > 65535) return DCV_ERR_UNSUPPORTED;
