@@ -58,6 +58,7 @@ struct MfmaArgs {
     long M;                        // N * Hout * Wout  (Hout x Wout: the grid of pixels this launch computes)
     // strided data gradient: this launch computes phase (oh_off, ow_off) of the full gradient, written at rows oh_mul*i + oh_off, columns ow_mul*j + ow_off
     int phase, oh_mul, ow_mul, oh_off, ow_off, Hfull, Wfull;
+    unsigned magic_w, magic_h;     // floor((2^32 - 1) / Wout) + 1, ... / Hout + 1 when M * max(Wout, Hout) < 2^32 (n / d = mulhi(n, magic)), else 0: 64-bit divisions
 };
 
 // wb[co][tap][ci] (fwd: w[co][ci][r][s]; dgrad: kernel-cout = original cin, kernel-cin = original cout, taps flipped)
@@ -101,7 +102,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaArgs a, const float*
         const long m = m0 + (t >> 2) + 64 * j;
         arow_ok[j] = m < a.M;
         const long mm = arow_ok[j] ? m : 0;
-        awo[j] = (int)(mm % a.Wout); const long r1 = mm / a.Wout; aho[j] = (int)(r1 % a.Hout); an[j] = (int)(r1 / a.Hout);
+        if (a.magic_w != 0u) {       // (uniform) 32-bit decode by multiply-high: three 64-bit divisions per row were microseconds of every block's prologue
+            const unsigned um = (unsigned)mm, r1 = __umulhi(um, a.magic_w), nn = __umulhi(r1, a.magic_h);
+            awo[j] = (int)(um - r1 * (unsigned)a.Wout); aho[j] = (int)(r1 - nn * (unsigned)a.Hout); an[j] = (int)nn;
+        } else { awo[j] = (int)(mm % a.Wout); const long r1 = mm / a.Wout; aho[j] = (int)(r1 % a.Hout); an[j] = (int)(r1 / a.Hout); }
     }
     const int brow = t >> 2;
     const bool b_active = brow < BN;
@@ -209,7 +213,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(MfmaArgs a, const float*
                     const float o = dcv_act_apply(acc[i][j][reg] + bv, a.act, a.slope);
                     size_t off = (size_t)m;
                     if (a.phase) {                                 // (n, i, j) of the phase grid -> position in the full tensor
-                        const int jj = (int)(m % a.Wout); const long r1 = m / a.Wout; const int ii = (int)(r1 % a.Hout); const long nn = r1 / a.Hout;
+                        int jj, ii; long nn;
+                        if (a.magic_w != 0u) { const unsigned um = (unsigned)m, r1 = __umulhi(um, a.magic_w), n2 = __umulhi(r1, a.magic_h); jj = (int)(um - r1 * (unsigned)a.Wout); ii = (int)(r1 - n2 * (unsigned)a.Hout); nn = n2; }
+                        else { jj = (int)(m % a.Wout); const long r1 = m / a.Wout; ii = (int)(r1 % a.Hout); nn = r1 / a.Hout; }
                         off = ((size_t)nn * a.Hfull + (size_t)ii * a.oh_mul + a.oh_off) * a.Wfull + (size_t)jj * a.ow_mul + a.ow_off;
                     }
                     y[off * a.Cout + co] = o;
@@ -1200,7 +1206,10 @@ static void launch_mfma(int bn, int bmr, dim3 grid, hipStream_t st, const MfmaAr
     }
 }
 
-static int run_mfma(const MfmaArgs& a, const float* x, const float* wb, const float* bias, float* y, hipStream_t st, double* stats = nullptr, int math = DCV_MATH_FP32) {
+static int run_mfma(const MfmaArgs& a0, const float* x, const float* wb, const float* bias, float* y, hipStream_t st, double* stats = nullptr, int math = DCV_MATH_FP32) {
+    MfmaArgs a = a0;
+    const bool small = a.Wout >= 2 && a.Hout >= 2 && (size_t)a.M * (size_t)(a.Wout > a.Hout ? a.Wout : a.Hout) < ((size_t)1 << 32);
+    a.magic_w = small ? 0xFFFFFFFFu / (unsigned)a.Wout + 1u : 0u; a.magic_h = small ? 0xFFFFFFFFu / (unsigned)a.Hout + 1u : 0u;
     HaloArgs h{}; size_t hsm;
     if (halo_plan(a, math, &h, &hsm)) {
         dim3 grid((unsigned)h.total_tiles, (unsigned)(a.Cout / 16));
