@@ -48,7 +48,9 @@ struct Bf16Args {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef int bw_i32x4 __attribute__((ext_vector_type(4)));
 // LDS-DMA from inline assembly (see conv2d_mfma.hip: the compiler must not track it as an LDS store); the kernel waits itself (s_waitcnt builtin) before its barrier
-__device__ __forceinline__ void bw_dma16(bw_i32x4 rsrc, unsigned lds_addr, unsigned voffset, unsigned soffset) {
+__device__ __forceinline__ void bw_dma16(bw_i32x4 rsrc0, unsigned lds_addr, unsigned voffset, unsigned soffset) {
+    // (under scalar-register pressure the compiler keeps the uniform resource words in VGPRs, which the instruction cannot take)
+    const bw_i32x4 rsrc = {__builtin_amdgcn_readfirstlane(rsrc0.x), __builtin_amdgcn_readfirstlane(rsrc0.y), __builtin_amdgcn_readfirstlane(rsrc0.z), __builtin_amdgcn_readfirstlane(rsrc0.w)};
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(voffset), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(soffset)) : "memory");
 }
 
@@ -234,10 +236,21 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(Bf16Args a, const u16
 // to 384 rows: W <= 32); (2) THREE filter stages: the filter tile of tap t + 2 is requested while tap t computes (one tap = 0.2 us is less than an L2 round trip);
 // the next chunk's window is requested one 64-row piece per tap, so that every request has the same two taps to land; waits are counted (vmcnt(N) with N = the
 // requests issued behind the one needed; the counter is in order); (3) LDS-DMA from inline assembly, so that the compiler does not wait for it in front of LDS reads.
+// s_waitcnt vmcnt(n) for a run-time n (the instruction takes an immediate): the window kernel's counted waits, n <= 2 + 1 + 16
+__device__ __forceinline__ void bh_wait(int n) {
+    switch (n) {
+        case 1: __builtin_amdgcn_s_waitcnt(0x0F71); break; case 2: __builtin_amdgcn_s_waitcnt(0x0F72); break; case 3: __builtin_amdgcn_s_waitcnt(0x0F73); break;
+        case 9: __builtin_amdgcn_s_waitcnt(0x0F79); break; case 10: __builtin_amdgcn_s_waitcnt(0x0F7A); break; case 11: __builtin_amdgcn_s_waitcnt(0x0F7B); break;
+        case 17: __builtin_amdgcn_s_waitcnt(0x4F71); break; case 18: __builtin_amdgcn_s_waitcnt(0x4F72); break; case 19: __builtin_amdgcn_s_waitcnt(0x4F73); break;
+        default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+    }
+}
 #define BH_WROWS 384                                                // rows of a window buffer (256 + 2 W + 2 <= 384)
 #define BH_WSTRIDE (BH_WROWS * 128 + 128)                           // window + its zero row
 #define BH_BST (2 * BH_WSTRIDE)                                     // the three filter stages
-template <int WN, bool OUT_BF16>
+// PERSIST (the 64-channel-wide instance: short K loops, where prologue and epilogue were half of a block's life — 454 -> 544 TF on 64 -> 64 @32x32; on the 128-wide
+// instance the extra state costs registers and the longer loops gain nothing: 1057 -> 973 TF on 256 -> 256 @8x8, so it keeps one tile per block)
+template <int WN, bool OUT_BF16, bool PERSIST = (WN == 1)>
 __global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, const u16* __restrict__ x, const u16* __restrict__ wb, const float* __restrict__ bias,
                                                                  void* __restrict__ yv, double* __restrict__ stats, int win_rows) {
     constexpr int WM = 8 / WN, BMH = 256, TI = BMH / (16 * WM), BN = 64 * WN, PB = BN / 64;       // PB: 16-B pieces of the filter tile per thread and stage
@@ -246,10 +259,15 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, cons
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 15, lg = lane >> 4;
-    const long m0 = (long)blockIdx.x * BMH;
     const int n0 = blockIdx.y * BN;
     const int W = a.Win, H = a.Hin;
     const int npieces = win_rows >> 6;                              // 64-row pieces of a window (5 or 6)
+    // PERSISTENT over tiles (tile = blockIdx.x + k gridDim.x): at one block per CU nothing overlaps a block's prologue (first window + filter tiles: a memory round
+    // trip) and epilogue (64 KB of stores draining) — 2.5 + 6.7 us of a 42 us block on 256 -> 256 @16x16, 2.1 + 3.0 of 9 us on 64 -> 64 @32x32 (per-block stamps,
+    // tools/halo_stamps.py).  The chunk sequence runs on across tiles: the next tile's first window and filter tiles are requested during this tile's last chunk, its
+    // stores drain under the next tile's taps.
+    const int ntiles = PERSIST ? (int)((a.M + BMH - 1) / BMH) : 0, gstep = PERSIST ? (int)gridDim.x : 0;      // (one tile per block otherwise)
+    int tile = blockIdx.x, m0 = tile * BMH;
 
     const unsigned long long xa = (unsigned long long)x, wa = (unsigned long long)wb;
     const bw_i32x4 rx = {(int)(unsigned)xa, (int)(unsigned)((xa >> 32) & 0xFFFFu), (int)a.x_bytes, 0x00020000};
@@ -258,13 +276,13 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, cons
 
     // ---- staging roles (as above): piece p of this thread = LDS row 64 p + (t >> 3), physical slot t & 7, which holds logical slot (t & 7) ^ ((t >> 4) & 7)
     const int lslot = (t & 7) ^ ((t >> 4) & 7);
-    const long q0 = m0 - W - 1;                                     // flat pixel index of window row 0
     const int cchunks = a.Cin / BF_BK;
     const unsigned lds0 = (unsigned)(size_t)lds + (unsigned)((t & ~63) * 16);
     // (offsets modulo 2^32: a pixel in front of the tensor wraps beyond num_records, one behind it exceeds it — zeros either way, no compare; x_bytes < 2^31)
-    const unsigned wv0 = (unsigned)((int)q0 + (t >> 3)) * (unsigned)(a.Cin * 2) + (unsigned)(lslot * 16), wvstep = (unsigned)(64 * a.Cin * 2);
-    auto stage_window_piece = [&](int wbuf, int chunk, int p) {
-        bw_dma16(rx, lds0 + (unsigned)(wbuf * BH_WSTRIDE + p * 8192), wv0 + (unsigned)p * wvstep, (unsigned)(chunk * 128));
+    const unsigned wvstep = (unsigned)(64 * a.Cin * 2);
+    auto wv_of = [&](int m0v) { return (unsigned)(m0v - W - 1 + (t >> 3)) * (unsigned)(a.Cin * 2) + (unsigned)(lslot * 16); };      // window row 0 = flat pixel m0 - W - 1
+    auto stage_window_piece = [&](int wbuf, unsigned wv, int chunk, int p) {
+        bw_dma16(rx, lds0 + (unsigned)(wbuf * BH_WSTRIDE + p * 8192), wv + (unsigned)p * wvstep, (unsigned)(chunk * 128));
     };
     int offb[PB];
 #pragma unroll
@@ -280,26 +298,28 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, cons
     };
 
     // ---- operand addresses (relative to a window buffer): tile row i of this wave = pixel pl = 16 TI wm + 16 i + li of the block; tap (r, s) -> window row
-    // pl + r W + s, logical slot lg (K half 0; the other half is the address ^ 64), or the buffer's zero row when the tap leaves the image
-    // (index decode in 32 bits with multiply-high by host-made reciprocals: the 64-bit % and / this started with are ~150 instructions each — twelve of them were
-    // 5 us of every block's prologue, with nothing to overlap them at one block per CU)
-    const unsigned um0 = (unsigned)m0, q0w = __umulhi(um0, a.magic_w), wo0 = um0 - q0w * (unsigned)W, ho0 = q0w - __umulhi(q0w, a.magic_h) * (unsigned)H;
+    // pl + r W + s, logical slot lg (K half 0; the other half is the address ^ 64), or the buffer's zero row when the tap leaves the image.  32-bit index decode with
+    // multiply-high by host-made reciprocals (the 64-bit % and / this started with are ~150 instructions each: twelve of them were 5 us of every prologue).
     unsigned aaddr[TI][9];
+    auto set_tile = [&](int m0v) __attribute__((always_inline)) {
+        const unsigned um0 = (unsigned)m0v, q0w = __umulhi(um0, a.magic_w), wo0 = um0 - q0w * (unsigned)W, ho0 = q0w - __umulhi(q0w, a.magic_h) * (unsigned)H;
 #pragma unroll
-    for (int i = 0; i < TI; ++i) {
-        const int pl = 16 * TI * wm + 16 * i + li;
-        const bool ok = m0 + pl < a.M;
-        const unsigned u = wo0 + (unsigned)pl, dq = __umulhi(u, a.magic_w), wo = u - dq * (unsigned)W;
-        const unsigned vv = ho0 + dq, ho = vv - __umulhi(vv, a.magic_h) * (unsigned)H;
-        const bool rok[3] = {ok && ho > 0, ok, ok && ho + 1 < (unsigned)H}, cok[3] = {wo > 0, true, wo + 1 < (unsigned)W};
+        for (int i = 0; i < TI; ++i) {
+            const int pl = 16 * TI * wm + 16 * i + li;
+            const bool ok = m0v + pl < (int)a.M;
+            const unsigned u = wo0 + (unsigned)pl, dq = __umulhi(u, a.magic_w), wo = u - dq * (unsigned)W;
+            const unsigned vv = ho0 + dq, ho = vv - __umulhi(vv, a.magic_h) * (unsigned)H;
+            const bool rok[3] = {ok && ho > 0, ok, ok && ho + 1 < (unsigned)H}, cok[3] = {wo > 0, true, wo + 1 < (unsigned)W};
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+            for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int sx = 0; sx < 3; ++sx) {
-                const int R = pl + r * W + sx;
-                aaddr[i][r * 3 + sx] = (rok[r] && cok[sx]) ? (unsigned)(R * 128 + ((lg ^ ((R >> 1) & 7)) << 4)) : (unsigned)(BH_WROWS * 128 + lg * 16);
-            }
-    }
+                for (int sx = 0; sx < 3; ++sx) {
+                    const int R = pl + r * W + sx;
+                    aaddr[i][r * 3 + sx] = (rok[r] && cok[sx]) ? (unsigned)(R * 128 + ((lg ^ ((R >> 1) & 7)) << 4)) : (unsigned)(BH_WROWS * 128 + lg * 16);
+                }
+        }
+    };
+    set_tile(m0);
     const int swz = (li >> 1) & 7;
     const unsigned bad0 = (unsigned)(BH_BST + (64 * wn + li) * 128 + ((0 + lg) ^ swz) * 16), bad1 = (unsigned)(BH_BST + (64 * wn + li) * 128 + ((4 + lg) ^ swz) * 16);
 
@@ -309,25 +329,86 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, cons
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int p = 0; p < npieces; ++p) stage_window_piece(0, 0, p);
+    // ---- epilogue of a tile: acc[i][j][reg] -> pixel m0 + 16 TI wm + 16 i + 4 lg + reg, channel n0 + 64 wn + 4 li + j; `dead`: the window buffer nobody reads any more
+    const int cbase = n0 + 64 * wn + 4 * li;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) { const float4 b4 = *reinterpret_cast<const float4*>(bias + cbase); bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w; }
+    auto finish_tile = [&](int dead) __attribute__((always_inline)) {
+        float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int m = m0 + 16 * TI * wm + 16 * i + 4 * lg + reg;
+                if (m < (int)a.M) {
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        o[j] = dcv_act_apply(acc[i][j][reg] + bv[j], a.act, a.slope);
+                        ssum[j] += o[j]; ssq[j] += o[j] * o[j];
+                    }
+                    if constexpr (OUT_BF16) {
+                        const bf16x4 h = (bf16x4){(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+                        *reinterpret_cast<bf16x4*>(reinterpret_cast<u16*>(yv) + (size_t)m * a.Cout + cbase) = h;
+                    } else {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(yv) + (size_t)m * a.Cout + cbase) = make_float4(o[0], o[1], o[2], o[3]);
+                    }
+                }
+            }
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (stats != nullptr) {
+            // statistics rows are per 128 pixels (the layout dcv_conv2d_bf16_fwd_stats_layout promises): the block's two halves = waves wm < WM / 2 and the others
+            __syncthreads();                                       // every wave is done reading the dead window
+            double* red = reinterpret_cast<double*>(lds + dead * BH_WSTRIDE);      // [8 waves][2][64]
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float s1v = ssum[j], s2v = ssq[j];
+                s1v += __shfl_xor(s1v, 16, 64); s2v += __shfl_xor(s2v, 16, 64);
+                s1v += __shfl_xor(s1v, 32, 64); s2v += __shfl_xor(s2v, 32, 64);
+                if (lg == 0) { red[(wave * 2 + 0) * 64 + 4 * li + j] = (double)s1v; red[(wave * 2 + 1) * 64 + 4 * li + j] = (double)s2v; }
+            }
+            __syncthreads();
+            const int rows_total = (int)((a.M + 127) / 128);
+            for (int e = t; e < 2 * 2 * BN; e += 512) {
+                const int half = e / (2 * BN), r2 = e - half * 2 * BN, q = r2 / BN, c = r2 - q * BN;
+                const int wnn = c >> 6, cc = c & 63;
+                double v = 0.0;
+#pragma unroll
+                for (int w = 0; w < WM / 2; ++w) v += red[(((half * (WM / 2) + w) * WN + wnn) * 2 + q) * 64 + cc];
+                const int row = 2 * tile + half;
+                if (row < rows_total) stats[((size_t)q * a.Cout + n0 + c) * rows_total + row] = v;            // [2][Cout][rows]
+            }
+        }
+    };
+
+    unsigned wv_cur = wv_of(m0), wv_nxt = (PERSIST && tile + gstep < ntiles) ? wv_of(m0 + gstep * BMH) : 0u;
+    for (int p = 0; p < npieces; ++p) stage_window_piece(0, wv_cur, 0, p);
     stage_filter(0, 0, 0);
     stage_filter(1, 0, 1);
     __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0)
+    const int total = PERSIST ? ((ntiles - tile + gstep - 1) / gstep) * cchunks : cchunks;      // chunks of all this block's tiles
+    int chunk = 0;
+    bool fresh = false;                                            // the 4 TI stores of the previous tile's epilogue are younger than the requests the first two taps wait for
     // one chunk out of window buffer PAR; tap t out of filter stage t % 3 (nine taps per chunk: the stages stay in step)
-    auto chunk_body = [&](auto par, int chunk) {
+    auto chunk_body = [&](auto par, int gc) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par)::value;
-        const bool more = chunk + 1 < cchunks;
+        const bool more = gc + 1 < total, last = chunk + 1 == cchunks;
+        const unsigned nwv = last ? wv_nxt : wv_cur;               // the next chunk's window: this tile's next 64 channels, or the next tile's first
+        const int nchunk = last ? 0 : chunk + 1;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            // the filter tile of this tap was requested two taps ago; behind it: the request(s) of the previous tap (PB filter pieces + one window piece while the
-            // next window is being fetched: taps 0 .. npieces - 1 >= 4)
+            // the filter tile of this tap was requested two taps ago; behind it (vmcnt counts in order, stores included): the request(s) of the previous tap — PB
+            // filter pieces + one window piece while the next window is being fetched (taps 0 .. npieces - 1 >= 4) — and, in a tile's first two taps, the stores
+            // of the previous tile
             if (tap == 8 && !more) __builtin_amdgcn_s_waitcnt(0x0F70);
-            else if (tap >= 1 && tap <= 5 && more) { if constexpr (PB == 2) __builtin_amdgcn_s_waitcnt(0x0F73); else __builtin_amdgcn_s_waitcnt(0x0F72); }       // vmcnt(PB + 1)
-            else { if constexpr (PB == 2) __builtin_amdgcn_s_waitcnt(0x0F72); else __builtin_amdgcn_s_waitcnt(0x0F71); }                                      // vmcnt(PB)
+            else bh_wait(PB + ((tap >= 1 && tap <= 5 && more) ? 1 : 0) + ((PERSIST && tap < 2 && fresh) ? 4 * TI : 0));
             __syncthreads();                                       // everybody's pieces have landed; every wave is done reading filter stage (tap + 2) % 3
-            if (more && tap < npieces) stage_window_piece(PAR ^ 1, chunk + 1, tap);                 // (the other window buffer: last read in the previous chunk)
+            if (more && tap < npieces) stage_window_piece(PAR ^ 1, nwv, nchunk, tap);               // (the other window buffer: last read in the previous chunk)
             if (tap + 2 < 9) stage_filter((tap + 2) % 3, chunk, tap + 2);
-            else if (more) stage_filter((tap + 2) % 3, chunk + 1, tap - 7);
+            else if (more) stage_filter((tap + 2) % 3, nchunk, tap - 7);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 af[TI], bf[4];
@@ -341,59 +422,19 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, cons
                     for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
             }
         }
+        if constexpr (PERSIST) {
+            fresh = false;
+            if (last) {
+                finish_tile(PAR);
+                chunk = 0; tile += gstep; m0 += gstep * BMH;
+                if (more) { set_tile(m0); wv_cur = wv_nxt; wv_nxt = tile + gstep < ntiles ? wv_of(m0 + gstep * BMH) : 0u; fresh = true; }
+            } else ++chunk;
+        } else ++chunk;
     };
-    int chunk = 0;
-    for (; chunk + 1 < cchunks; chunk += 2) { chunk_body(std::integral_constant<int, 0>{}, chunk); chunk_body(std::integral_constant<int, 1>{}, chunk + 1); }
-    if (chunk < cchunks) chunk_body(std::integral_constant<int, 0>{}, chunk);
-
-    // ---- epilogue: acc[i][j][reg] -> pixel m0 + 16 TI wm + 16 i + 4 lg + reg, channel n0 + 64 wn + 4 li + j
-    const int cbase = n0 + 64 * wn + 4 * li;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (bias) { const float4 b4 = *reinterpret_cast<const float4*>(bias + cbase); bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w; }
-    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const long m = m0 + 16 * TI * wm + 16 * i + 4 * lg + reg;
-            if (m < a.M) {
-                float o[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    o[j] = dcv_act_apply(acc[i][j][reg] + bv[j], a.act, a.slope);
-                    ssum[j] += o[j]; ssq[j] += o[j] * o[j];
-                }
-                if constexpr (OUT_BF16) {
-                    const bf16x4 h = (bf16x4){(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
-                    *reinterpret_cast<bf16x4*>(reinterpret_cast<u16*>(yv) + (size_t)m * a.Cout + cbase) = h;
-                } else {
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(yv) + (size_t)m * a.Cout + cbase) = make_float4(o[0], o[1], o[2], o[3]);
-                }
-            }
-        }
-    if (stats != nullptr) {
-        // statistics rows are per 128 pixels (the layout dcv_conv2d_bf16_fwd_stats_layout promises): the block's two halves = waves wm < WM / 2 and the others
-        __syncthreads();
-        double* red = reinterpret_cast<double*>(lds);              // [8 waves][2][64]
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float s1v = ssum[j], s2v = ssq[j];
-            s1v += __shfl_xor(s1v, 16, 64); s2v += __shfl_xor(s2v, 16, 64);
-            s1v += __shfl_xor(s1v, 32, 64); s2v += __shfl_xor(s2v, 32, 64);
-            if (lg == 0) { red[(wave * 2 + 0) * 64 + 4 * li + j] = (double)s1v; red[(wave * 2 + 1) * 64 + 4 * li + j] = (double)s2v; }
-        }
-        __syncthreads();
-        const int rows_total = (int)((a.M + 127) / 128);
-        for (int e = t; e < 2 * 2 * BN; e += 512) {
-            const int half = e / (2 * BN), r2 = e - half * 2 * BN, q = r2 / BN, c = r2 - q * BN;
-            const int wnn = c >> 6, cc = c & 63;
-            double v = 0.0;
-#pragma unroll
-            for (int w = 0; w < WM / 2; ++w) v += red[(((half * (WM / 2) + w) * WN + wnn) * 2 + q) * 64 + cc];
-            const int row = 2 * (int)blockIdx.x + half;
-            if (row < rows_total) stats[((size_t)q * a.Cout + n0 + c) * rows_total + row] = v;            // [2][Cout][rows]
-        }
-    }
+    int gc = 0;
+    for (; gc + 1 < total; gc += 2) { chunk_body(std::integral_constant<int, 0>{}, gc); chunk_body(std::integral_constant<int, 1>{}, gc + 1); }
+    if (gc < total) chunk_body(std::integral_constant<int, 0>{}, gc);
+    if constexpr (!PERSIST) finish_tile((cchunks - 1) & 1);         // (one tile: its epilogue once, behind the loop)
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient, all nine taps per block, bf16 operands
@@ -777,7 +818,10 @@ int launch(const Bf16Args& a0, const u16* x, const u16* wb, const float* bias, v
         if (halo_plan(a, wide ? 128 : 64, &win_rows, &hs)) {
             const Bf16Args& ah = a;                               // (Win == Wout, Hin == Hout here: the reciprocals are the window's)
             static bool hconf[2] = {false, false};
-            dim3 hgrid((unsigned)dcv_ceil_div((size_t)a.M, 256), (unsigned)(a.Cout / (wide ? 128 : 64)));
+            // persistent blocks: one per CU, each walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...
+            const unsigned hgy = (unsigned)(a.Cout / (wide ? 128 : 64)), htiles = (unsigned)dcv_ceil_div((size_t)a.M, 256);
+            unsigned hgx = wide ? htiles : DCV_NUM_CU / hgy; if (hgx < 1) hgx = 1; if (hgx > htiles) hgx = htiles;      // (the 128-wide instance: one tile per block)
+            dim3 hgrid(hgx, hgy);
             if (hgrid.y > 65535) return DCV_ERR_UNSUPPORTED;
             if (wide) {
                 if (!hconf[0]) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_halo_kernel<2, OUT_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DCV_ERR_LAUNCH; hconf[0] = true; }
