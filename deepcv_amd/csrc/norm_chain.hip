@@ -30,19 +30,27 @@ struct NcPool { int W, Wo, pk; float inv; };
 template <int VEC> struct NcVec { float v[VEC]; };
 template <int VEC> __device__ __forceinline__ NcVec<VEC> nc_load(const float* p) {
     NcVec<VEC> r;
-    if constexpr (VEC == 4) { const float4 q = *reinterpret_cast<const float4*>(p); r.v[0] = q.x; r.v[1] = q.y; r.v[2] = q.z; r.v[3] = q.w; }
+    if constexpr (VEC == 8) {
+        const float4 q = *reinterpret_cast<const float4*>(p), q2 = *reinterpret_cast<const float4*>(p + 4);
+        r.v[0] = q.x; r.v[1] = q.y; r.v[2] = q.z; r.v[3] = q.w; r.v[4] = q2.x; r.v[5] = q2.y; r.v[6] = q2.z; r.v[7] = q2.w;
+    } else if constexpr (VEC == 4) { const float4 q = *reinterpret_cast<const float4*>(p); r.v[0] = q.x; r.v[1] = q.y; r.v[2] = q.z; r.v[3] = q.w; }
     else r.v[0] = p[0];
     return r;
 }
 template <int VEC> __device__ __forceinline__ void nc_store(float* p, const NcVec<VEC>& r) {
-    if constexpr (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    if constexpr (VEC == 8) { *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]); *reinterpret_cast<float4*>(p + 4) = make_float4(r.v[4], r.v[5], r.v[6], r.v[7]); }
+    else if constexpr (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
     else p[0] = r.v[0];
 }
 // bf16 activations (io_dtype DCV_DTYPE_BF16: the layers of the bf16 storage convolution path): widened on load, rounded to nearest even on store
 typedef unsigned short nc_bf16;
 template <int VEC> __device__ __forceinline__ NcVec<VEC> nc_load(const nc_bf16* p) {
     NcVec<VEC> r;
-    if constexpr (VEC == 4) {
+    if constexpr (VEC == 8) {      // 16-byte accesses on bf16 tensors (round 3: with four channels per lane the streaming kernels moved 8 B per lane and load)
+        const uint4 q = *reinterpret_cast<const uint4*>(p);
+        r.v[0] = __uint_as_float(q.x << 16); r.v[1] = __uint_as_float(q.x & 0xffff0000u); r.v[2] = __uint_as_float(q.y << 16); r.v[3] = __uint_as_float(q.y & 0xffff0000u);
+        r.v[4] = __uint_as_float(q.z << 16); r.v[5] = __uint_as_float(q.z & 0xffff0000u); r.v[6] = __uint_as_float(q.w << 16); r.v[7] = __uint_as_float(q.w & 0xffff0000u);
+    } else if constexpr (VEC == 4) {
         const uint2 q = *reinterpret_cast<const uint2*>(p);
         r.v[0] = __uint_as_float(q.x << 16); r.v[1] = __uint_as_float(q.x & 0xffff0000u); r.v[2] = __uint_as_float(q.y << 16); r.v[3] = __uint_as_float(q.y & 0xffff0000u);
     } else r.v[0] = __uint_as_float((unsigned)p[0] << 16);
@@ -50,7 +58,9 @@ template <int VEC> __device__ __forceinline__ NcVec<VEC> nc_load(const nc_bf16* 
 }
 template <int VEC> __device__ __forceinline__ void nc_store(nc_bf16* p, const NcVec<VEC>& r) {
     typedef __bf16 nc_bf16x4 __attribute__((ext_vector_type(4)));
-    if constexpr (VEC == 4) *reinterpret_cast<nc_bf16x4*>(p) = (nc_bf16x4){(__bf16)r.v[0], (__bf16)r.v[1], (__bf16)r.v[2], (__bf16)r.v[3]};
+    typedef __bf16 nc_bf16x8 __attribute__((ext_vector_type(8)));
+    if constexpr (VEC == 8) *reinterpret_cast<nc_bf16x8*>(p) = (nc_bf16x8){(__bf16)r.v[0], (__bf16)r.v[1], (__bf16)r.v[2], (__bf16)r.v[3], (__bf16)r.v[4], (__bf16)r.v[5], (__bf16)r.v[6], (__bf16)r.v[7]};
+    else if constexpr (VEC == 4) *reinterpret_cast<nc_bf16x4*>(p) = (nc_bf16x4){(__bf16)r.v[0], (__bf16)r.v[1], (__bf16)r.v[2], (__bf16)r.v[3]};
     else { const __bf16 h = (__bf16)r.v[0]; p[0] = *reinterpret_cast<const nc_bf16*>(&h); }
 }
 
@@ -535,6 +545,11 @@ __global__ __launch_bounds__(64) void nc_rows_sum_kernel(const double* __restric
 
 // ------------------------------------------------------------------------------------------------ host side
 inline int nc_vec(int C) { return (C % 4 == 0) ? 4 : 1; }
+// channels per lane: 8 on bf16 tensors without GroupNorm / pooling (16-byte accesses) when the channel count allows it
+inline int nc_vec(const dcv_norm_chain_desc* d) {
+    if (d->io_dtype == DCV_DTYPE_BF16 && d->groups == 0 && d->pool == 0 && d->channels % 8 == 0 && ((d->channels / 8) & (d->channels / 8 - 1)) == 0 && d->channels / 8 <= NC_THREADS) return 8;
+    return nc_vec(d->channels);
+}
 inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 inline int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
 
@@ -563,7 +578,7 @@ inline int nc_skip() {
 
 inline bool nc_shape_ok(const dcv_norm_chain_desc* d) {
     if (!d || d->n <= 0 || d->n > 65535 || d->hw <= 0 || d->channels <= 0 || d->channels > NC_MAXC || d->groups < 0) return false;
-    const int vec = nc_vec(d->channels), cv = d->channels / vec;
+    const int vec = nc_vec(d), cv = d->channels / vec;
     if (!pow2(cv) || cv > NC_THREADS) return false;
     if (d->groups > 0) {
         if (d->channels % d->groups != 0 || !pow2(d->channels / d->groups) || d->channels > NC_THREADS) return false;   // one thread per channel
@@ -591,12 +606,12 @@ inline NcGn nc_gn(const dcv_norm_chain_desc* d) {
 }
 
 inline size_t nc_part_bytes(const dcv_norm_chain_desc* d) {
-    int bps, per; nc_split(d->hw * (d->channels / nc_vec(d->channels)), d->groups > 0, &bps, &per);
+    int bps, per; nc_split(d->hw * (d->channels / nc_vec(d)), d->groups > 0, &bps, &per);
     return dcv_align_up((size_t)4 * d->channels * (size_t)d->n * bps * sizeof(double), 256);
 }
 inline size_t nc_chan_bytes(const dcv_norm_chain_desc* d) { return dcv_align_up((size_t)2 * d->channels * sizeof(float), 256); }
 inline size_t nc_db_bytes(const dcv_norm_chain_desc* d) {      // [channels][blocks] partial sums of dz (the bias gradient, dcv_norm_chain_desc::d_bias)
-    int bps, per; nc_split(d->hw * (d->channels / nc_vec(d->channels)), d->groups > 0, &bps, &per);
+    int bps, per; nc_split(d->hw * (d->channels / nc_vec(d)), d->groups > 0, &bps, &per);
     return dcv_align_up((size_t)d->channels * (size_t)d->n * bps * sizeof(double), 256);
 }
 
@@ -624,7 +639,7 @@ int dcv_norm_chain_fwd(const dcv_norm_chain_desc* d, const void* xv, void* outv,
     DCV_CHECK_ARG(d->groups == 0 || (d->gn_mean && d->gn_rstd));
     if (ws_bytes < nc_part_bytes(d) + nc_chan_bytes(d)) return DCV_ERR_WORKSPACE;
     hipStream_t st = dcv_stream(stream);
-    const int C = d->channels, vec = nc_vec(C), CV = C / vec, G = d->groups;
+    const int C = d->channels, vec = nc_vec(d), CV = C / vec, G = d->groups;
     int bps, per; nc_split(d->hw * CV, G > 0, &bps, &per);
     const NcPool pm = nc_pool(d);
     const NcGn gn = nc_gn(d);
@@ -638,7 +653,8 @@ int dcv_norm_chain_fwd(const dcv_norm_chain_desc* d, const void* xv, void* outv,
         const dim3 sgrid((unsigned)bps, (unsigned)d->n);
         const NcBwdCtx none{};
         const nc_bf16* no16 = nullptr; const float* no32 = nullptr;
-        if (io16 && vec == 4) hipLaunchKernelGGL((nc_sample_sums_kernel<4, false, nc_bf16>), sgrid, dim3(NC_THREADS), 0, st, x16, no16, d->hw, C, per, nullptr, nullptr, pm, pw, rows, none);
+        if (io16 && vec == 8) hipLaunchKernelGGL((nc_sample_sums_kernel<8, false, nc_bf16>), sgrid, dim3(NC_THREADS), 0, st, x16, no16, d->hw, C, per, nullptr, nullptr, pm, pw, rows, none);
+        else if (io16 && vec == 4) hipLaunchKernelGGL((nc_sample_sums_kernel<4, false, nc_bf16>), sgrid, dim3(NC_THREADS), 0, st, x16, no16, d->hw, C, per, nullptr, nullptr, pm, pw, rows, none);
         else if (io16) hipLaunchKernelGGL((nc_sample_sums_kernel<1, false, nc_bf16>), sgrid, dim3(NC_THREADS), 0, st, x16, no16, d->hw, C, per, nullptr, nullptr, pm, pw, rows, none);
         else if (vec == 4) hipLaunchKernelGGL((nc_sample_sums_kernel<4, false>), sgrid, dim3(NC_THREADS), 0, st, x, no32, d->hw, C, per, nullptr, nullptr, pm, pw, rows, none);
         else hipLaunchKernelGGL((nc_sample_sums_kernel<1, false>), sgrid, dim3(NC_THREADS), 0, st, x, no32, d->hw, C, per, nullptr, nullptr, pm, pw, rows, none);
@@ -650,7 +666,8 @@ int dcv_norm_chain_fwd(const dcv_norm_chain_desc* d, const void* xv, void* outv,
     if (d->pool > 0) nc_split((d->hw / (d->pool * d->pool)) * CV, true, &abps, &aper);
     const dim3 agrid((unsigned)abps, (unsigned)d->n);
     if (nc_skip() & 4) DCV_RETURN_LAUNCH();
-    if (io16 && vec == 4) hipLaunchKernelGGL((nc_apply_kernel<4, nc_bf16>), agrid, dim3(NC_THREADS), 0, st, x16, out16, d->hw, C, aper, ab, part, rows, rps, gn, pm);
+    if (io16 && vec == 8) hipLaunchKernelGGL((nc_apply_kernel<8, nc_bf16>), agrid, dim3(NC_THREADS), 0, st, x16, out16, d->hw, C, aper, ab, part, rows, rps, gn, pm);
+    else if (io16 && vec == 4) hipLaunchKernelGGL((nc_apply_kernel<4, nc_bf16>), agrid, dim3(NC_THREADS), 0, st, x16, out16, d->hw, C, aper, ab, part, rows, rps, gn, pm);
     else if (io16) hipLaunchKernelGGL((nc_apply_kernel<1, nc_bf16>), agrid, dim3(NC_THREADS), 0, st, x16, out16, d->hw, C, aper, ab, part, rows, rps, gn, pm);
     else if (vec == 4) hipLaunchKernelGGL((nc_apply_kernel<4>), agrid, dim3(NC_THREADS), 0, st, x, out, d->hw, C, aper, ab, part, rows, rps, gn, pm);
     else hipLaunchKernelGGL((nc_apply_kernel<1>), agrid, dim3(NC_THREADS), 0, st, x, out, d->hw, C, aper, ab, part, rows, rps, gn, pm);
@@ -666,7 +683,7 @@ int dcv_norm_chain_bwd(const dcv_norm_chain_desc* d, const void* doutv, const vo
     DCV_CHECK_ARG(d->groups == 0 || (d->gn_mean && d->gn_rstd));
     if (ws_bytes < nc_part_bytes(d) + nc_chan_bytes(d) + (d->d_bias ? nc_db_bytes(d) : 0)) return DCV_ERR_WORKSPACE;
     hipStream_t st = dcv_stream(stream);
-    const int C = d->channels, vec = nc_vec(C), CV = C / vec, G = d->groups;
+    const int C = d->channels, vec = nc_vec(d), CV = C / vec, G = d->groups;
     int bps, per; nc_split(d->hw * CV, G > 0, &bps, &per);
     const NcPool pm = nc_pool(d);
     double* part = reinterpret_cast<double*>(ws);
@@ -676,6 +693,7 @@ int dcv_norm_chain_bwd(const dcv_norm_chain_desc* d, const void* doutv, const vo
     const dim3 sgrid((unsigned)bps, (unsigned)d->n);
     const NcBwdCtx bc{d->bn_gamma, d->bn_beta, d->bn_rstd, nc_gn(d), d->coef};
     if (nc_skip() & 1) {}
+    else if (io16 && vec == 8) hipLaunchKernelGGL((nc_sample_sums_kernel<8, true, nc_bf16>), sgrid, dim3(NC_THREADS), 0, st, x16, dout16, d->hw, C, per, d->bn_mean, d->bn_rstd, pm, part, rows, bc);
     else if (io16 && vec == 4) hipLaunchKernelGGL((nc_sample_sums_kernel<4, true, nc_bf16>), sgrid, dim3(NC_THREADS), 0, st, x16, dout16, d->hw, C, per, d->bn_mean, d->bn_rstd, pm, part, rows, bc);
     else if (io16) hipLaunchKernelGGL((nc_sample_sums_kernel<1, true, nc_bf16>), sgrid, dim3(NC_THREADS), 0, st, x16, dout16, d->hw, C, per, d->bn_mean, d->bn_rstd, pm, part, rows, bc);
     else if (vec == 4) hipLaunchKernelGGL((nc_sample_sums_kernel<4, true>), sgrid, dim3(NC_THREADS), 0, st, x, dout, d->hw, C, per, d->bn_mean, d->bn_rstd, pm, part, rows, bc);
@@ -685,7 +703,8 @@ int dcv_norm_chain_bwd(const dcv_norm_chain_desc* d, const void* doutv, const vo
     const int cstride = G > 0 ? 3 * C : 0;
     const float* ch = chan;
     if (nc_skip() & 4) DCV_RETURN_LAUNCH();
-    if (io16 && vec == 4) hipLaunchKernelGGL((nc_bwd_apply_kernel<4, nc_bf16>), sgrid, dim3(NC_THREADS), 0, st, dout16, x16, dz16, d->hw, C, per, d->coef, cstride, ch, d->bn_mean, d->bn_rstd, nc_act(d->act, d->act_slope), pm, dbp, rows);
+    if (io16 && vec == 8) hipLaunchKernelGGL((nc_bwd_apply_kernel<8, nc_bf16>), sgrid, dim3(NC_THREADS), 0, st, dout16, x16, dz16, d->hw, C, per, d->coef, cstride, ch, d->bn_mean, d->bn_rstd, nc_act(d->act, d->act_slope), pm, dbp, rows);
+    else if (io16 && vec == 4) hipLaunchKernelGGL((nc_bwd_apply_kernel<4, nc_bf16>), sgrid, dim3(NC_THREADS), 0, st, dout16, x16, dz16, d->hw, C, per, d->coef, cstride, ch, d->bn_mean, d->bn_rstd, nc_act(d->act, d->act_slope), pm, dbp, rows);
     else if (io16) hipLaunchKernelGGL((nc_bwd_apply_kernel<1, nc_bf16>), sgrid, dim3(NC_THREADS), 0, st, dout16, x16, dz16, d->hw, C, per, d->coef, cstride, ch, d->bn_mean, d->bn_rstd, nc_act(d->act, d->act_slope), pm, dbp, rows);
     else if (vec == 4) hipLaunchKernelGGL((nc_bwd_apply_kernel<4>), sgrid, dim3(NC_THREADS), 0, st, dout, x, dz, d->hw, C, per, d->coef, cstride, ch, d->bn_mean, d->bn_rstd, nc_act(d->act, d->act_slope), pm, dbp, rows);
     else hipLaunchKernelGGL((nc_bwd_apply_kernel<1>), sgrid, dim3(NC_THREADS), 0, st, dout, x, dz, d->hw, C, per, d->coef, cstride, ch, d->bn_mean, d->bn_rstd, nc_act(d->act, d->act_slope), pm, dbp, rows);
