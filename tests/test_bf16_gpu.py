@@ -27,6 +27,8 @@ CASES = [
     (90, 128, 10, 10, 64, 3, 1, 1, 1, 1, True),      # 9000 pixels: ragged last tile, tiles straddling images and image rows, 64-wide filter tile
     (40, 128, 16, 16, 128, 3, 1, 1, 1, 0, True),     # two chunks (two window buffers), 128-wide filter tile
     (9, 192, 40, 24, 64, 3, 1, 1, 1, 2, False),      # three chunks, non-square maps, leaky relu, no bias
+    (70, 64, 31, 31, 64, 3, 1, 1, 1, 1, True),       # 263 tiles on 256 persistent blocks (64-wide instance): blocks with two tiles, ragged last tile, odd width, one chunk
+    (34, 128, 31, 31, 64, 3, 1, 1, 1, 0, False),     # 128 tiles of two chunks: the chunk sequence running on across tiles is exercised by the N = 512 cases; here odd sizes
 ]
 
 
