@@ -690,6 +690,24 @@ __global__ __launch_bounds__(256) void prep_bf16_kernel(Bf16PrepList l) {
         // whole filter: a thread owns one (kernel-cout, kernel-cin) pair, reads its R*S taps (contiguous in OIHW) and writes one element of every tap plane:
         // reads are 4 R S-byte runs, writes of consecutive threads are consecutive bf16 of a plane (the element-wise form below gathers with stride R*S)
         const int pairs = e.kcout * e.kcin, taps = e.R * e.S;
+        if ((e.kcin & 3) == 0 && taps <= 9 && (reinterpret_cast<uintptr_t>(e.dst) & 7) == 0) {
+            // four consecutive kernel-cin per thread: one 8-byte store per tap plane instead of four 2-byte ones (round 3: the re-layout of all filters of
+            // cifar100_deep took 60 us per step for 114 MB)
+            for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < pairs / 4; i += gridDim.x * blockDim.x) {
+                const int ci = (i % (e.kcin / 4)) * 4, co = i / (e.kcin / 4);
+                float v[4][9];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float* src = e.dgrad ? e.w + ((size_t)(ci + k) * e.w_cin + co) * taps : e.w + ((size_t)co * e.w_cin + ci + k) * taps;
+#pragma unroll
+                    for (int tp = 0; tp < 9; ++tp) v[k][tp] = tp < taps ? src[e.dgrad ? taps - 1 - tp : tp] : 0.f;
+                }
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp)
+                    if (tp < taps) *reinterpret_cast<bf16x4*>(e.dst + ((size_t)tp * e.kcout + co) * e.kcin + ci) = (bf16x4){(__bf16)v[0][tp], (__bf16)v[1][tp], (__bf16)v[2][tp], (__bf16)v[3][tp]};
+            }
+            return;
+        }
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += gridDim.x * blockDim.x) {
             const int ci = i % e.kcin, co = i / e.kcin;
             const float* src = e.dgrad ? e.w + ((size_t)ci * e.w_cin + co) * taps : e.w + ((size_t)co * e.w_cin + ci) * taps;

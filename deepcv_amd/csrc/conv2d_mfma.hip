@@ -458,6 +458,7 @@ struct MfmaWgArgs {
     int idx32;                     // x and dy both have fewer than 2^31 elements
     long M, m_per_chunk;           // output pixels, pixels per split-K chunk (multiple of 16)
     size_t wtotal;
+    unsigned magic_w, magic_h;     // floor((2^32 - 1) / Wo) + 1, ... / Ho + 1 when M * max(Wo, Ho) < 2^32 (n / d = mulhi(n, magic)), else 0
 };
 
 #define WG_T 64                    // tile of output channels (rows) and of input channels (columns) per block
@@ -487,7 +488,8 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(MfmaWgArgs a, cons
     for (int h = 0; h < 2; ++h) {
         mrow[h] = mb + prow + 16 * h;
         const long mm = mrow[h] < a.M ? mrow[h] : a.M - 1;
-        pwo[h] = (int)(mm % a.Wo); const long r1 = mm / a.Wo; pho[h] = (int)(r1 % a.Ho); pn[h] = (int)(r1 / a.Ho);
+        if (a.magic_w != 0u) { const unsigned um = (unsigned)mm, r1 = __umulhi(um, a.magic_w), nn = __umulhi(r1, a.magic_h); pwo[h] = (int)(um - r1 * (unsigned)a.Wo); pho[h] = (int)(r1 - nn * (unsigned)a.Ho); pn[h] = (int)nn; }
+        else { pwo[h] = (int)(mm % a.Wo); const long r1 = mm / a.Wo; pho[h] = (int)(r1 % a.Ho); pn[h] = (int)(r1 / a.Ho); }
     }
     auto load_tiles = [&](float4 (&g)[2], float4 (&xv)[2]) {          // loads the rows at (mrow, pwo, pho, pn), then advances them by WG_PS pixels
 #pragma unroll
@@ -934,6 +936,10 @@ inline void wg_plan(const dcv_conv2d_desc* d, MfmaWgArgs* a, int* chunks) {
     a->step_w = WG_PS % d->wo; a->step_h = WG_PS / d->wo;
     a->idx32 = ((size_t)d->n * d->h * d->w * d->cin < ((size_t)1 << 31) && (size_t)d->n * d->ho * d->wo * d->cout < ((size_t)1 << 31)) ? 1 : 0;
     a->wtotal = (size_t)d->cout * d->cin * d->r * d->s;
+    {
+        const bool small = d->wo >= 2 && d->ho >= 2 && (size_t)a->M * (size_t)(d->wo > d->ho ? d->wo : d->ho) < ((size_t)1 << 32);
+        a->magic_w = small ? 0xFFFFFFFFu / (unsigned)d->wo + 1u : 0u; a->magic_h = small ? 0xFFFFFFFFu / (unsigned)d->ho + 1u : 0u;
+    }
     // enough blocks to fill the chip (>= ~2048) but partial slabs bounded to 256 MiB
     const long blocks_per_chunk = (long)d->r * d->s * (d->cin / WG_T) * (d->cout / WG_T);
     long ch = (2048 + blocks_per_chunk - 1) / blocks_per_chunk;
