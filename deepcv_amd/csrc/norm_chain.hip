@@ -637,6 +637,7 @@ int dcv_norm_chain_fwd(const dcv_norm_chain_desc* d, const void* xv, void* outv,
     const nc_bf16* x16 = reinterpret_cast<const nc_bf16*>(xv); nc_bf16* out16 = reinterpret_cast<nc_bf16*>(outv);
     DCV_CHECK_ARG(nc_shape_ok(d) && x && out && d->bn_mean && d->bn_rstd && d->coef && ws && (stats == nullptr || stats_rows > 0));
     DCV_CHECK_ARG(d->groups == 0 || (d->gn_mean && d->gn_rstd));
+    DCV_CHECK_ARG(nc_vec(d) != 8 || ((reinterpret_cast<uintptr_t>(xv) | reinterpret_cast<uintptr_t>(outv)) & 15) == 0);      // (eight bf16 channels per lane: 16-byte accesses)
     if (ws_bytes < nc_part_bytes(d) + nc_chan_bytes(d)) return DCV_ERR_WORKSPACE;
     hipStream_t st = dcv_stream(stream);
     const int C = d->channels, vec = nc_vec(d), CV = C / vec, G = d->groups;
@@ -681,6 +682,7 @@ int dcv_norm_chain_bwd(const dcv_norm_chain_desc* d, const void* doutv, const vo
     const bool io16 = d && d->io_dtype == DCV_DTYPE_BF16;
     DCV_CHECK_ARG(nc_shape_ok(d) && dout && x && dz && d->bn_mean && d->bn_rstd && d->coef && ws);
     DCV_CHECK_ARG(d->groups == 0 || (d->gn_mean && d->gn_rstd));
+    DCV_CHECK_ARG(nc_vec(d) != 8 || ((reinterpret_cast<uintptr_t>(doutv) | reinterpret_cast<uintptr_t>(xv) | reinterpret_cast<uintptr_t>(dzv)) & 15) == 0);
     if (ws_bytes < nc_part_bytes(d) + nc_chan_bytes(d) + (d->d_bias ? nc_db_bytes(d) : 0)) return DCV_ERR_WORKSPACE;
     hipStream_t st = dcv_stream(stream);
     const int C = d->channels, vec = nc_vec(d), CV = C / vec, G = d->groups;

@@ -312,7 +312,8 @@ typedef struct dcv_norm_chain_desc {
     float* gn_mean; float* gn_rstd;                        /* [n][groups]: written by the forward, read by the backward */
     float* coef;                                           /* dcv_norm_chain_coef_floats(d) floats */
     int act; float act_slope;                              /* activation which produced x (its derivative is taken from x) */
-    int io_dtype;                                          /* element type of x / out / dout / dz: DCV_DTYPE_F32 (0, default) or DCV_DTYPE_BF16 (bf16 storage path) */
+    int io_dtype;                                          /* element type of x / out / dout / dz: DCV_DTYPE_F32 (0, default) or DCV_DTYPE_BF16 (bf16 storage path:
+                                                              16-byte aligned tensors when channels % 8 == 0 without GroupNorm / pooling) */
     float* d_bias;                                         /* nullable; dcv_norm_chain_bwd only: [channels] sums of dz over (n, hw) — the bias gradient of the
                                                               convolution which produced x, summed while dz is written (no second pass over dz) */
 } dcv_norm_chain_desc;
