@@ -30,6 +30,7 @@ constexpr int RS_XIN = 1296;        // float4 per sample of the padded input til
 constexpr int RS_Y = 4096;          // floats per sample of a layer's activated convolution output
 constexpr int RS_MAXC = 16;         // channels of a resident layer
 constexpr int RS_MAXQ = 2 * RS_MAXC;
+constexpr int RS_WARM_LINES = 3;   // 64-B filter lines a lane touches in the forward prologue without looking at them (3 x 64 lines = 12 KiB: a 3x3 16 -> 16 filter)
 constexpr int RS_MAXG = 256;        // blocks
 constexpr int RS_GRAN_OP = RS_MAXQ * RS_MAXG + 2 * RS_MAXQ;   // granules of one synchronisation: hop-1 partials [RS_MAXQ][RS_MAXG], hop-2 totals [RS_MAXQ][2]
 constexpr int RS_SPINS = 1 << 16;   // gather polls before giving up (each at least a memory round trip: tens of milliseconds)
@@ -38,6 +39,7 @@ constexpr int RS_MAX_STAMPS = 120;
 
 typedef unsigned long long rs_u64;
 typedef __attribute__((address_space(1))) rs_u64 rs_gu64;
+typedef __attribute__((address_space(1))) float rs_gf32;
 typedef __attribute__((address_space(1))) unsigned rs_gu32;
 typedef __attribute__((address_space(4))) const float rs_cfloat;       // constant address space: wave-uniform loads go through the scalar cache
 #define RS_CONST(p) ((rs_cfloat*)(unsigned long long)(p))
@@ -92,6 +94,21 @@ __device__ __forceinline__ double rs_rsqrt(double v) {                   // as n
 // Exact x / d for 0 <= x < 2^20, 0 < d < 2^12 with inv = 1.f / d: the index decodes of the short phases (a 32-bit integer division is ~40 VALU
 // instructions, and with 16 waves on 4 SIMDs every instruction of a phase costs 16 cycles of the block's time)
 __device__ __forceinline__ int rs_fdiv(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
+// The program structs are kilobytes of kernel arguments which the prologues read field by field through scalar loads, each behind the branch the previous one
+// decided: a chain of scalar-cache misses.  One load per 64-B line of the argument segment (BYTES: all of it, the two pointers behind the struct included),
+// all in flight together (one asm statement per group: left to the compiler they go out eight at a time), and the chain hits the scalar cache.  Lines 0 - 30
+// for the backward program, 0 - 39 for the forward one; no line past the segment is touched.
+template <int BYTES>
+__device__ __forceinline__ void rs_kernarg_warm() {
+    static_assert((BYTES > 30 * 64 && BYTES <= 31 * 64) || (BYTES > 39 * 64 && BYTES <= 40 * 64), "rs_kernarg_warm: list the lines of this argument segment");
+    const __attribute__((address_space(4))) unsigned* ka = (const __attribute__((address_space(4))) unsigned*)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned d;
+    asm volatile("s_load_dword %0, %1, 0x0\n\t" "s_load_dword %0, %1, 0x40\n\t" "s_load_dword %0, %1, 0x80\n\t" "s_load_dword %0, %1, 0xc0\n\t" "s_load_dword %0, %1, 0x100\n\t" "s_load_dword %0, %1, 0x140\n\t" "s_load_dword %0, %1, 0x180\n\t" "s_load_dword %0, %1, 0x1c0\n\t" "s_load_dword %0, %1, 0x200\n\t" "s_load_dword %0, %1, 0x240\n\t" "s_load_dword %0, %1, 0x280\n\t" "s_load_dword %0, %1, 0x2c0\n\t" "s_load_dword %0, %1, 0x300\n\t" "s_load_dword %0, %1, 0x340\n\t" "s_load_dword %0, %1, 0x380\n\t" "s_load_dword %0, %1, 0x3c0\n\t" "s_load_dword %0, %1, 0x400\n\t" "s_load_dword %0, %1, 0x440\n\t" "s_load_dword %0, %1, 0x480\n\t" "s_load_dword %0, %1, 0x4c0\n\t" "s_load_dword %0, %1, 0x500\n\t" "s_load_dword %0, %1, 0x540\n\t" "s_load_dword %0, %1, 0x580\n\t" "s_load_dword %0, %1, 0x5c0\n\t" "s_load_dword %0, %1, 0x600\n\t" "s_load_dword %0, %1, 0x640\n\t" "s_load_dword %0, %1, 0x680\n\t" "s_load_dword %0, %1, 0x6c0\n\t" "s_load_dword %0, %1, 0x700\n\t" "s_load_dword %0, %1, 0x740\n\t" "s_load_dword %0, %1, 0x780\n\t"
+                 "s_waitcnt lgkmcnt(0)" : "=&s"(d) : "s"(ka) : "memory");
+    if constexpr (BYTES > 39 * 64)
+        asm volatile("s_load_dword %0, %1, 0x7c0\n\t" "s_load_dword %0, %1, 0x800\n\t" "s_load_dword %0, %1, 0x840\n\t" "s_load_dword %0, %1, 0x880\n\t" "s_load_dword %0, %1, 0x8c0\n\t" "s_load_dword %0, %1, 0x900\n\t" "s_load_dword %0, %1, 0x940\n\t" "s_load_dword %0, %1, 0x980\n\t" "s_load_dword %0, %1, 0x9c0\n\t"
+                     "s_waitcnt lgkmcnt(0)" : "=&s"(d) : "s"(ka) : "memory");
+}
 
 // Sums of the 8 values of every lane over the 64 lanes in ~30 instructions instead of 8 butterflies: each exchange step also halves what a lane keeps
 // (xor 1: half of the values, xor 2: half again), two rotations inside the rows of 16 lanes, two ds_bpermute across the rows.  On return lane l holds,
@@ -522,29 +539,52 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
     const int s_of_t = t >> 9, tt = t & 511;                                         // sample-major split of the block for the per-sample passes
     const int N = p.n, G = (int)gridDim.x;
     const bool valid0 = (int)blockIdx.x * RS_SPB < N, valid1 = (int)blockIdx.x * RS_SPB + 1 < N;
-    if (t == 0) { s_gen = __hip_atomic_load((rs_gu32*)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_fail = 0; }
-    const bool mute = ctl[2] == blockIdx.x + 1u;        // test hook (tests/test_resident_gpu.py): this block never publishes -> every block's bounded spin gives up
-    int n_stamp = 0;
+    rs_kernarg_warm<(int)(sizeof(dcv_resident_program) + 2 * sizeof(void*))>();
+    // the control words: requested here, first needed at the end of the prologue (the first stamp is taken unconditionally and written with the second one:
+    // a stamp which compared block indices here would put the words' round trip in front of every load below)
+    int lz = 0; asm volatile("" : "+v"(lz));                                         // (a zero the compiler takes for a per-lane value: uniform words would be moved to scalar registers here, i.e. waited for here)
+    const unsigned ctl_mute = ctl[2 + lz], ctl_stamp = ctl[3 + lz];                  // ctl[2]: test hook (tests/test_resident_gpu.py): block ctl[2] - 1 never publishes -> every block's bounded spin gives up
+    const unsigned gen0 = __hip_atomic_load((rs_gu32*)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const rs_u64 t_start = wall_clock64();
+    int n_stamp = 1;
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(ctl + 4);
-    const unsigned stamp_block = ctl[3];                // diagnostics: the block whose phase times are recorded (tools/resident_stamps.py), 0 by default
-    auto stamp = [&]() { if (blockIdx.x == stamp_block && t == 0 && n_stamp < RS_MAX_STAMPS) stamps[1 + n_stamp] = wall_clock64(); ++n_stamp; };
-    stamp();
+    // diagnostics: block ctl[3] records its phase times (tools/resident_stamps.py), block 0 by default
+    auto stamp = [&]() {
+        if (blockIdx.x == ctl_stamp && t == 0 && n_stamp < RS_MAX_STAMPS) { if (n_stamp == 1) stamps[1] = t_start; stamps[1 + n_stamp] = wall_clock64(); }
+        ++n_stamp;
+    };
     {   // ONE global round trip: every layer's per-channel parameters -> LDS (the coefficient phases never wait for memory), the two samples -> the first
         // layer's padded tile (loads issued before the tile is zeroed)
-        float pv[2] = {0.f, 0.f}; int pslot[2] = {-1, -1};                           // (up to 10 ops x 8 rows x 16 channels = 1280 slots: two per thread)
+        // a replayed step's batch: read through the address the host left in the mailbox for THIS replay (pinned host memory: the longest round trip of this
+        // prologue, requested first and — a vector load, counted in order — not waited for until the sample loads need it), and kept in the static tensor
+        // for the backward pass
+        const dcv_resident_op& o = p.op[0];
+        const float* batch = o.x;
+        rs_u64 batch_word = 0;
+        const bool from_mailbox = p.mailbox != nullptr && p.batch == nullptr;
+        if (from_mailbox) batch_word = __hip_atomic_load((rs_gu64*)&p.mailbox->src[p.x_job], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else if (p.mailbox != nullptr) batch = p.batch;
+        // a wave's slots belong to ONE op (128 slots each): its descriptor is read through scalar loads (rs_kernarg_warm above) and the row's pointer picked
+        // by selects — indexed per lane, the descriptor words, then the pointer, then the value were three dependent round trips ahead of everything below
+        // The loads are unconditional (a lane without a parameter reads a control word) and their results are not touched before the commit behind the
+        // barrier: under branches the loaded value meets its default in a copy right behind the load, i.e. a wait for everything in flight here.
+        float pl[2], pd[2]; int pslot[2]; bool pok[2];                               // (up to 10 ops x 8 rows x 16 channels = 1280 slots: two per thread)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int e = t + k * RS_T;
-            if (e < p.count * 8 * RS_MAXC) {
-                const int oi = e >> 7, r = e & 127, f = r >> 4, c = r & 15;
-                const dcv_resident_op& o = p.op[oi];
-                if (o.kind == DCV_RES_LAYER && c < o.cout && f < 7) {
-                    const float* src = f == 0 ? o.bn_gamma : f == 1 ? o.bn_beta : f == 2 ? o.running_mean : f == 3 ? o.running_var : f == 4 ? o.gn_gamma : f == 5 ? o.gn_beta : o.bias;
-                    pslot[k] = e;
-                    pv[k] = (f == 0 || f == 4) ? 1.f : 0.f;
-                    if (src != nullptr) pv[k] = src[c];
-                }
-            }
+            const int oi = __builtin_amdgcn_readfirstlane(e >> 7), oc = oi < p.count ? oi : 0;
+            const int r = e & 127, f = r >> 4, c = r & 15;
+            const dcv_resident_op& w = p.op[oc];
+            // (the pointers made opaque: the compiler turns a select among struct fields back into a load indexed by f)
+            const float* q0 = w.bn_gamma; const float* q1 = w.bn_beta; const float* q2 = w.running_mean; const float* q3 = w.running_var;
+            const float* q4 = w.gn_gamma; const float* q5 = w.gn_beta; const float* q6 = w.bias;
+            asm volatile("" : "+s"(q0), "+s"(q1), "+s"(q2), "+s"(q3), "+s"(q4), "+s"(q5), "+s"(q6));
+            const float* src = f == 0 ? q0 : f == 1 ? q1 : f == 2 ? q2 : f == 3 ? q3 : f == 4 ? q4 : f == 5 ? q5 : q6;
+            const bool slot = oi < p.count && w.kind == DCV_RES_LAYER && c < w.cout && f < 7;
+            pslot[k] = slot ? e : -1;
+            pd[k] = (f == 0 || f == 4) ? 1.f : 0.f;
+            pok[k] = slot && src != nullptr;
+            pl[k] = *(const rs_gf32*)(pok[k] ? src + c : reinterpret_cast<const float*>(ctl));
         }
         // ... the filters of the cin <= 4 -> 4 layers, element t of their [tap][co][ci] copy in LDS
         float fv[RS_FILT_OPS];
@@ -554,15 +594,18 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
             if (k < p.count && p.op[k].kind == DCV_RES_LAYER && rs_variant(p.op[k].cin, p.op[k].cout, p.op[k].k, p.op[k].w) == 1) fv[k] = rs_filt_fetch(p.op[k].filt, p.op[k].k, t);
         }
         // ... and one float of every 64-B line of every filter: the scalar loads of the convolutions then find them in L2 instead of HBM
+        float warm[RS_WARM_LINES] = {};
         {
-            const int oi = t >> 6, line = t & 63;
+            // (nobody needs the values: they are looked at once, behind the barrier below — looked at here, each load waited for everything in flight)
+            const int oi = __builtin_amdgcn_readfirstlane(t >> 6), line = t & 63;
             if (oi < p.count && p.op[oi].kind == DCV_RES_LAYER) {
                 const dcv_resident_op& w = p.op[oi];
                 const int floats = w.k * w.k * ((w.cin + 3) & ~3) * w.cout;
-                for (int f = line * 16; f < floats; f += 64 * 16) { const float v = w.filt[f]; asm volatile("" :: "v"(v)); }
+#pragma unroll
+                for (int i = 0; i < RS_WARM_LINES; ++i) { const int f = (line + 64 * i) * 16; warm[i] = *(const rs_gf32*)(w.filt + (f < floats ? f : 0)); }
+                for (int f = (line + 64 * RS_WARM_LINES) * 16; f < floats; f += 64 * 16) { const float v = w.filt[f]; asm volatile("" :: "v"(v)); }
             }
         }
-        const dcv_resident_op& o = p.op[0];
         const int pad = o.k / 2, XW = o.w + 2 * pad, XH = o.h + 2 * pad, HW = o.h * o.w, C = o.cin;
         const float inv_hw = 1.f / (float)HW, inv_w = 1.f / (float)o.w, inv_c = 1.f / (float)C, inv_cv = 1.f / (float)((C >> 2) > 0 ? (C >> 2) : 1);
         const int n = (int)blockIdx.x * RS_SPB + s_of_t;
@@ -573,9 +616,7 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
         float4 v4[SB]; float v1[SB];
 #pragma unroll
         for (int k = 0; k < SB; ++k) { v4[k] = make_float4(0.f, 0.f, 0.f, 0.f); v1[k] = 0.f; }
-        // a replayed step's batch: read through the address the host left in the mailbox for THIS replay, and kept in the static tensor for the backward pass
-        const float* batch = o.x;
-        if (p.mailbox != nullptr) batch = p.batch != nullptr ? p.batch : reinterpret_cast<const float*>(p.mailbox->src[p.x_job]);
+        if (from_mailbox) batch = reinterpret_cast<const float*>(batch_word);
         const bool keep = p.mailbox != nullptr && batch != o.x && n < N;
         const float* src = batch + (size_t)(n < N ? n : 0) * HW * C;
         float* stat = const_cast<float*>(o.x) + (size_t)(n < N ? n : 0) * HW * C;
@@ -594,9 +635,12 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
             for (int k = 0; k < SB; ++k) { const int e = tt + k * 512; v1[k] = src[e < total ? e : 0]; }
         }
         for (int i = t; i < RS_SPB * RS_XIN; i += RS_T) xin[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t == 0) { s_gen = gen0; s_fail = 0; }
         rs_barrier();
 #pragma unroll
-        for (int k = 0; k < 2; ++k) if (pslot[k] >= 0) (&s_par[0][0][0])[pslot[k]] = pv[k];
+        for (int k = 0; k < 2; ++k) if (pslot[k] >= 0) (&s_par[0][0][0])[pslot[k]] = pok[k] ? pl[k] : pd[k];
+#pragma unroll
+        for (int i = 0; i < RS_WARM_LINES; ++i) asm volatile("" :: "v"(warm[i]));
         if (t < RS_FILT_FLOATS) {
 #pragma unroll
             for (int k = 0; k < RS_FILT_OPS; ++k) s_filt[k][t] = fv[k];
@@ -722,7 +766,7 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                 for (int e = tt; e < v4; e += 512) yg[e] = ys[e];
             };
             if (o.bn) {
-                rs_allreduce_publish(go, epoch, 2 * C, mine, mute);
+                rs_allreduce_publish(go, epoch, 2 * C, mine, ctl_mute == blockIdx.x + 1u);
                 if (oi == 0 && p.mailbox != nullptr) {
                     // the mailbox's other jobs (labels, optimizer scalars: a few KB) travel while the first layer's partial sums do: job j by a block which
                     // owns no quantity of the all-reduce (blocks 32 ..: nobody waits for them), or by block j when the grid is that small.  The reads of
@@ -925,7 +969,7 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
         }
     }
     // every block read `gen` before its first publication and block 0 only gets here after it has gathered everybody's: the next launch is stream-ordered
-    if (blockIdx.x == stamp_block && t == 0) stamps[0] = (unsigned long long)n_stamp;
+    if (blockIdx.x == ctl_stamp && t == 0) stamps[0] = (unsigned long long)n_stamp;
     if (blockIdx.x == 0 && t == 0) __hip_atomic_store((rs_gu32*)ctl, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -1356,13 +1400,17 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
     const int s_of_t = t >> 9, tt = t & 511;
     const int N = p.n, G = (int)gridDim.x;
     const bool valid0 = (int)blockIdx.x * RS_SPB < N, valid1 = (int)blockIdx.x * RS_SPB + 1 < N;
-    if (t == 0) { s_gen = __hip_atomic_load((rs_gu32*)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_fail = 0; }
-    const bool mute = ctl[2] == blockIdx.x + 1u;        // test hook, as in the forward launch
-    int n_stamp = 0;
+    rs_kernarg_warm<(int)(sizeof(dcv_resident_bwd_program) + 2 * sizeof(void*))>();
+    int lz = 0; asm volatile("" : "+v"(lz));
+    const unsigned ctl_mute = ctl[2 + lz], ctl_stamp = ctl[3 + lz];                  // (as in the forward launch: first needed at the end of the prologue)
+    const unsigned gen0 = __hip_atomic_load((rs_gu32*)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const rs_u64 t_start = wall_clock64();
+    int n_stamp = 1;
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(ctl + 4);
-    const unsigned stamp_block = ctl[3];                // diagnostics: the block whose phase times are recorded (tools/resident_stamps.py), 0 by default
-    auto stamp = [&]() { if (blockIdx.x == stamp_block && t == 0 && n_stamp < RS_MAX_STAMPS) stamps[1 + n_stamp] = wall_clock64(); ++n_stamp; };
-    stamp();
+    auto stamp = [&]() {
+        if (blockIdx.x == ctl_stamp && t == 0 && n_stamp < RS_MAX_STAMPS) { if (n_stamp == 1) stamps[1] = t_start; stamps[1 + n_stamp] = wall_clock64(); }
+        ++n_stamp;
+    };
     // a sample's [HW * C] floats, HBM -> LDS region (flat), 8 float4 per thread in flight
     auto load_flat = [&](const float* src, float* region, int floats_per_sample) {
         const int n = (int)blockIdx.x * RS_SPB + s_of_t, v4 = floats_per_sample >> 2;
@@ -1398,32 +1446,6 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         }
     }
     {   // per-channel parameters of every layer -> LDS; y and dout of the first op (the last layer) -> LDS
-        float pv = 0.f; int pslot = -1;
-        if (t < p.count * 5 * RS_MAXC) {
-            const int oi = rs_fdiv(t, 1.f / (float)(5 * RS_MAXC)), r = t - oi * 5 * RS_MAXC, f = r >> 4, c = r & 15;
-            const dcv_resident_bwd_op& o = p.op[oi];
-            if (c < o.cout) {
-                const float* src = f == 0 ? o.bn_gamma : f == 1 ? o.bn_beta : f == 2 ? o.bn_mean : f == 3 ? o.bn_rstd : o.gn_gamma;
-                pslot = t;
-                pv = (f == 0 || f == 4) ? 1.f : 0.f;
-                if (src != nullptr) pv = src[c];
-            }
-        }
-        // the filters of the 4 <- 4 data gradients: the n-th such op owns slot n of s_filt (rb_filt_slot)
-        float fv[RB_FILT_SLOTS];
-#pragma unroll
-        for (int sl = 0; sl < RB_FILT_SLOTS; ++sl) fv[sl] = 0.f;
-        {
-            int ns = 0;
-#pragma unroll
-            for (int k = 0; k < DCV_RESIDENT_BWD_MAX_OPS; ++k) {
-                if (k < p.count && p.op[k].need_dx && rb_dgrad_variant(p.op[k].cin, p.op[k].cout, p.op[k].k, p.op[k].w) == 1) {
-#pragma unroll
-                    for (int sl = 0; sl < RB_FILT_SLOTS; ++sl) if (ns == sl) fv[sl] = rs_filt_fetch(p.op[k].filt, p.op[k].k, t);
-                    ++ns;
-                }
-            }
-        }
         const dcv_resident_bwd_op& o = p.op[0];
         const int pk = o.pool > 0 ? o.pool : 1;
         // y of the first op: requested now, committed to LDS behind the head's operand staging — the loss arithmetic of a captured step (2 us on half of the
@@ -1435,6 +1457,45 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
             const float4* g = reinterpret_cast<const float4*>(o.y) + (size_t)(yn < N ? yn : 0) * yv4;
 #pragma unroll
             for (int k = 0; k < 2; ++k) { const int i = tt + k * 512; y2[k] = g[i < yv4 ? i : 0]; }
+        }
+        // a pair of waves per op (128 slots: 5 rows of 16 channels used): the descriptor through scalar loads (rs_kernarg_warm), the row's pointer by selects —
+        // indexed per lane, descriptor, pointer and value were three dependent round trips which every load below waited behind
+        // (unconditional load, untouched until the commit below: see the forward launch)
+        float pl, pd; int pslot; bool pok;
+        {
+            const int oi = __builtin_amdgcn_readfirstlane(t >> 7), oc = oi < p.count ? oi : 0, f = (t >> 4) & 7, c = t & 15;
+            const dcv_resident_bwd_op& w = p.op[oc];
+            const float* q0 = w.bn_gamma; const float* q1 = w.bn_beta; const float* q2 = w.bn_mean; const float* q3 = w.bn_rstd; const float* q4 = w.gn_gamma;
+            asm volatile("" : "+s"(q0), "+s"(q1), "+s"(q2), "+s"(q3), "+s"(q4));   // (opaque: see the forward launch)
+            const float* src = f == 0 ? q0 : f == 1 ? q1 : f == 2 ? q2 : f == 3 ? q3 : q4;
+            const bool slot = oi < p.count && f < 5 && c < w.cout;
+            pslot = slot ? (oi * 5 + f) * RS_MAXC + c : -1;
+            pd = (f == 0 || f == 4) ? 1.f : 0.f;
+            pok = slot && src != nullptr;
+            pl = *(const rs_gf32*)(pok ? src + c : reinterpret_cast<const float*>(ctl));
+        }
+        // the filters of the 4 <- 4 data gradients: the n-th such op owns slot n of s_filt (rb_filt_slot)
+        float fv[RB_FILT_SLOTS];
+#pragma unroll
+        for (int sl = 0; sl < RB_FILT_SLOTS; ++sl) fv[sl] = 0.f;
+        {
+            // which op owns which slot: scalar arithmetic first, then ONE load per slot (a load per (op, slot) pair under `ns == sl` had the compiler wait
+            // for everything in flight between the ops: the pairs share their destination registers)
+            int slot_op[RB_FILT_SLOTS];
+#pragma unroll
+            for (int sl = 0; sl < RB_FILT_SLOTS; ++sl) slot_op[sl] = -1;
+            int ns = 0;
+#pragma unroll
+            for (int k = 0; k < DCV_RESIDENT_BWD_MAX_OPS; ++k) {
+                if (k < p.count && p.op[k].need_dx && rb_dgrad_variant(p.op[k].cin, p.op[k].cout, p.op[k].k, p.op[k].w) == 1) {
+#pragma unroll
+                    for (int sl = 0; sl < RB_FILT_SLOTS; ++sl) if (ns == sl) slot_op[sl] = k;
+                    ++ns;
+                }
+            }
+#pragma unroll
+            for (int sl = 0; sl < RB_FILT_SLOTS; ++sl)
+                if (slot_op[sl] >= 0) { const dcv_resident_bwd_op& w = p.op[slot_op[sl]]; fv[sl] = rs_filt_fetch(w.filt, w.k, t); }
         }
         if (stage_dz) {
             float* staged = reinterpret_cast<float*>(dzt);
@@ -1498,12 +1559,13 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
             for (int k = 0; k < 2; ++k) { const int i = tt + k * 512; if (i < yv4) d[i] = yn < N ? y2[k] : make_float4(0.f, 0.f, 0.f, 0.f); }
         } else load_flat(o.y, yreg, o.h * o.w * o.cout);
         if (!p.head.enabled) load_flat(o.dout, dor, (o.h / pk) * (o.w / pk) * o.cout);
-        if (pslot >= 0) (&s_par[0][0][0])[pslot] = pv;
+        if (pslot >= 0) (&s_par[0][0][0])[pslot] = pok ? pl : pd;
         if (t < RS_FILT_FLOATS) {
 #pragma unroll
             for (int sl = 0; sl < RB_FILT_SLOTS; ++sl) s_filt[sl][t] = fv[sl];
         }
     }
+    if (t == 0) { s_gen = gen0; s_fail = 0; }
     if (stage_dz) rs_barrier();
     stamp();
     if (p.head.enabled) {
@@ -1700,7 +1762,7 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         stamp();
         // ---- the batch totals of T1, T2: publish the block's partials, compute the PREVIOUS op's weight gradient while they travel (its dz and x tiles are
         // still intact), then reduce / collect
-        rs_allreduce_publish(go, epoch, 2 * C, mine, mute);
+        rs_allreduce_publish(go, epoch, 2 * C, mine, ctl_mute == blockIdx.x + 1u);
         rs_allreduce_reduce_owned(go, go + RS_MAXQ * RS_MAXG, epoch, 2 * C, G, s_red, &s_fail);   // the few owner blocks: before their own weight gradient, so that nobody waits for it
         }
         if (oi > 0 && p.op[oi - 1].dw_part != nullptr) rb_wgrad(p.op[oi - 1], xtt, dzt, s_wgq);
@@ -1888,7 +1950,7 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         stamp();
     }
     stamp();
-    if (blockIdx.x == stamp_block && t == 0) stamps[0] = (unsigned long long)n_stamp;
+    if (blockIdx.x == ctl_stamp && t == 0) stamps[0] = (unsigned long long)n_stamp;
     if (blockIdx.x == 0 && t == 0) __hip_atomic_store((rs_gu32*)ctl, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 

@@ -1,0 +1,17 @@
+# where the prologues of the two persistent launches spend their time: sub-stamps in the backward prologue (positions shift the names printed by
+# tools/resident_stamps.py: read the first five rows as issue / loads + loss arithmetic / barrier + writer / commits), and a forward launch which does not
+# read the batch address from the host mailbox (wrong on purpose: it reads the static tensor)
+SRC = 'resident.hip'
+VARIANTS = {
+    'bwdsub': [
+        ("        if (stage_dz) {\n            float* staged = reinterpret_cast<float*>(dzt);\n", "        stamp();\n        if (stage_dz) {\n            float* staged = reinterpret_cast<float*>(dzt);\n"),
+        ("                l = dcv_wave_sum(l); ok = dcv_wave_sum(ok);\n", "                stamp();\n                l = dcv_wave_sum(l); ok = dcv_wave_sum(ok);\n"),
+        ("        if (y_two) {\n            float4* d = reinterpret_cast<float4*>(yreg + s_of_t * RS_Y);\n", "        stamp();\n        if (y_two) {\n            float4* d = reinterpret_cast<float4*>(yreg + s_of_t * RS_Y);\n"),
+    ],
+    'nofence': [   # the loss publication of the backward launch without its two system-scope fences (unordered on purpose: what do they cost the step?)
+        ("                            __threadfence_system();\n", ""),
+    ],
+    'nomail': [
+        ("        if (p.mailbox != nullptr) batch = p.batch != nullptr ? p.batch : reinterpret_cast<const float*>(p.mailbox->src[p.x_job]);\n", ""),
+    ],
+}
