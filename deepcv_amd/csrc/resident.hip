@@ -1277,10 +1277,123 @@ __device__ __forceinline__ void rb_wgrad_c4x16(const dcv_resident_bwd_op& o, con
     rb_bias16(o, dzt, 6);
 }
 
-__device__ __forceinline__ void rb_wgrad(const dcv_resident_bwd_op& o, const float4* xt, const float4* dzt, float* scratch) {
+// ---- cin <= 4 -> 4, 5 x 5 on 32-column maps (the stock model's first three layers) on v_mfma_f32_4x4x1: D_b[co][ci] += dz_b[co] x_b[ci], block b of an
+// instruction = one of 16 consecutive pixels of an image row, so A is float `lane` of the dz tile's row segment and B float `lane` of the x tile's segment
+// shifted by the tap ([pixel][channel] tiles: 64 consecutive floats, one conflict-free ds_read_b32 each).  A piece = (sample, filter column kx, row range):
+// for each 16-column half it walks down the rows with the five x rows of the step in a register window — one new x read and one dz read per step feed FIVE
+// instructions (1280 MACs), where the VALU version (rb_wgrad_c4) spent 15 VALU instructions per 10 packed FMAs per step and was issue-bound at ~9 us.  The
+// 16 blocks of the accumulators are summed at the end (rb_sum_blocks24).  Work split, 200 instructions per wave: unit u = wave / 2 = (kx = u / 2 < 4,
+// sample u % 2); its even wave takes rows 0 - 19, its odd wave rows 20 - 31 and then a quarter (rows 8 q .. 8 q + 7, q = u / 2, sample u % 2) of filter column
+// 4.  The odd waves' partials meet the even waves' in LDS (sc_main, the per-wave moments' region: the moments were consumed by the algebra of wave 0, which
+// raises `flag` when it has read them), the quarters of column 4 in sc_q, in a fixed order.  The dz sums (bias gradient) ride along in the units of kx = 0
+// as one VALU add per step.
+// Sums of 24 values per lane over the 16 blocks of a 4x4x1 accumulator layout (lane = 4 b + j): two halving exchanges across the rows of 16 lanes
+// (v_permlane32_swap / v_permlane16_swap: no LDS crossbar), then rotations by 8 and 4 lanes inside the rows.  On return out[n] is the total of value
+// 4 n + 2 * (row & 1) + (row >> 1) (row = lane / 16) for the lane's j = lane % 4, in every lane.
+// (inline asm: hipcc 7.2 adds the FIRST result of __builtin_amdgcn_permlane{32,16}_swap to itself when both are used — tools/probes/permlane_probe.hip shows
+// the instructions themselves do what the ISA says; the s_nop around them stand in for the hazard recogniser, which does not look inside an asm statement)
+__device__ __forceinline__ float rb_swap32_add(float a, float b) { asm volatile("s_nop 4\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); return a + b; }
+__device__ __forceinline__ float rb_swap16_add(float a, float b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); return a + b; }
+__device__ __forceinline__ void rb_sum_blocks24(const float (&v)[24], float (&out)[6]) {
+    float s1[12];
+#pragma unroll
+    for (int m = 0; m < 12; ++m) s1[m] = rb_swap32_add(v[2 * m], v[2 * m + 1]);
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+        float s = rb_swap16_add(s1[2 * n], s1[2 * n + 1]);
+        s += rs_dpp_mov<0x128>(s);                                                  // row_ror:8
+        s += rs_dpp_mov<0x124>(s);                                                  // row_ror:4
+        out[n] = s;
+    }
+}
+__host__ __device__ __forceinline__ bool rb_wgrad_c4_mfma_ok(int cin, int cout, int k, int h, int w) { return cin <= 4 && cout == 4 && k == 5 && w == 32 && h == 32; }
+constexpr int RB_WGM_MAIN = 96, RB_WGM_Q = 80;                                       // floats per unit in sc_main ([6][4][4]) and sc_q ([5][4][4])
+__device__ __forceinline__ void rb_wgrad_c4_mfma(const dcv_resident_bwd_op& o, const float4* xt, const float4* dzt, float* sc_q, float* sc_main, volatile unsigned* flag, unsigned flag_value) {
+    constexpr int K = 5, pad = 2, XW = 32 + 2 * pad, RF = XW * 4;                    // RF: floats per tile row
+    const int t = rs_tid(), lane = t & 63, wave = rs_wave_of(t), u = wave >> 1, role = wave & 1, kxu = u >> 1, su = u & 1;
+    const int cin = o.cin;
+    const float* xf = reinterpret_cast<const float*>(xt);
+    const float* df = reinterpret_cast<const float*>(dzt);
+    rs_f4 acc[K];
+    float bsum;
+    // a piece's rows are unrolled (H = 32: 20, 12 and 8 rows): every read carries its row as an immediate offset and the window of five x rows is a matter
+    // of register names — in a rolled loop the four window moves, the address updates and the loop counter were 13 issue slots per five instructions, and
+    // an issue slot of ANY wave of the SIMD costs the matrix pipe as much as half such an instruction (the first version of this function: 9.7 us)
+    auto piece = [&](int s, int kx, int row0, auto rows_c, auto bias_c) {
+        constexpr int ROWS = decltype(rows_c)::value;
+        constexpr bool BIAS = decltype(bias_c)::value;
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = rs_f4{0.f, 0.f, 0.f, 0.f};
+        bsum = 0.f;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            const float* xb = xf + ((size_t)s * RS_XIN + row0 * XW + half * 16 + kx) * 4 + lane;
+            const float* db = df + ((size_t)s * RS_XIN + (row0 + pad) * XW + pad + half * 16) * 4 + lane;
+            float w[ROWS + K - 1];
+#pragma unroll
+            for (int r = 0; r < K - 1; ++r) w[r] = xb[r * RF];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                w[r + K - 1] = xb[(r + K - 1) * RF];
+                const float dc = db[r * RF];
+#pragma unroll
+                for (int ky = 0; ky < K; ++ky) acc[ky] = __builtin_amdgcn_mfma_f32_4x4x1f32(dc, w[r + ky], acc[ky], 0, 0, 0);
+                if constexpr (BIAS) bsum += dc;
+            }
+        }
+    };
+    using rows_a = std::integral_constant<int, 20>; using rows_b = std::integral_constant<int, 12>; using rows_q = std::integral_constant<int, 8>;
+    float tot[6];
+    auto reduce = [&]() {
+        float v[24];
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[k * 4 + i] = acc[k][i];
+        v[20] = bsum; v[21] = v[22] = v[23] = 0.f;                                  // (value 20: lane 4 b + j holds the dz sum of channel j over its pixels)
+        rb_sum_blocks24(v, tot);
+    };
+    const int row = lane >> 4, j = lane & 3, co = 2 * (row & 1) + (row >> 1);       // tot[n]: filter row n, output channel co, input channel j (n = 5, row 0: dz sum of channel j)
+    const bool writer = (lane & 12) == 0;
+    const int chunk0 = (int)blockIdx.x * RS_SPB, wsize = 4 * cin * K * K;
+    if (role == 1) {
+        if (kxu == 0) piece(su, kxu, 20, rows_b{}, std::true_type{}); else piece(su, kxu, 20, rows_b{}, std::false_type{});
+        reduce();
+        while (*flag != flag_value) { }
+        if (writer) {
+#pragma unroll
+            for (int n = 0; n < 6; ++n) sc_main[u * RB_WGM_MAIN + n * 16 + co * 4 + j] = tot[n];
+        }
+        piece(su, K - 1, (u >> 1) * 8, rows_q{}, std::false_type{});
+        reduce();
+        if (writer) {
+#pragma unroll
+            for (int n = 0; n < K; ++n) sc_q[u * RB_WGM_Q + n * 16 + co * 4 + j] = tot[n];
+        }
+    } else {
+        if (kxu == 0) piece(su, kxu, 0, rows_a{}, std::true_type{}); else piece(su, kxu, 0, rows_a{}, std::false_type{});
+        reduce();
+    }
+    rs_barrier();
+    if (role == 0 && writer) {
+        float* dst = o.dw_part + (size_t)(chunk0 + su) * wsize + (kxu * 4 + co) * cin + j;      // [tap][co][ci] slab, tap = ky * K + kx
+        const float* part = sc_main + u * RB_WGM_MAIN + co * 4 + j;
+#pragma unroll
+        for (int n = 0; n < K; ++n) if (j < cin) dst[n * K * 4 * cin] = tot[n] + part[n * 16];
+        if (kxu == 0 && row == 0 && o.db_part) o.db_part[(size_t)(chunk0 + su) * 4 + j] = tot[5] + sc_main[u * RB_WGM_MAIN + 5 * 16 + j];
+    }
+    if (t < RS_SPB * RB_WGM_Q) {                                                     // filter column 4: (sample, ky, co, ci), the four quarters in a fixed order
+        const int ss = t >= RB_WGM_Q ? 1 : 0, e = t - ss * RB_WGM_Q, n = e >> 4, c2 = (e >> 2) & 3, ci = e & 3;
+        const float* q = sc_q + ss * RB_WGM_Q + e;
+        const float v = (q[0] + q[2 * RB_WGM_Q]) + (q[4 * RB_WGM_Q] + q[6 * RB_WGM_Q]);
+        if (ci < cin) o.dw_part[(size_t)(chunk0 + ss) * wsize + ((n * K + (K - 1)) * 4 + c2) * cin + ci] = v;
+    }
+}
+__device__ __forceinline__ void rb_wgrad(const dcv_resident_bwd_op& o, const float4* xt, const float4* dzt, float* scratch, float* wave_sums, volatile unsigned* flag, unsigned flag_value) {
     const int var = rb_wgrad_variant(o.cin, o.cout, o.k, o.w);
     if (var == 1) {
-        if (o.k == 5) {
+        if (rb_wgrad_c4_mfma_ok(o.cin, o.cout, o.k, o.h, o.w)) rb_wgrad_c4_mfma(o, xt, dzt, scratch, wave_sums, flag, flag_value);
+        else if (o.k == 5) {
             if (o.w != 32) rb_wgrad_c4<5, 4, 0>(o, xt, dzt, scratch);
             else if (o.cin == 3) rb_wgrad_c4<5, 3, 36>(o, xt, dzt, scratch);
             else rb_wgrad_c4<5, 4, 36>(o, xt, dzt, scratch);
@@ -1394,7 +1507,7 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
     float* const s_dummy = s_scratch;
     float* const s_wgq = s_scratch;
     __shared__ __attribute__((aligned(16))) float s_filt[RB_FILT_SLOTS][RS_FILT_FLOATS];  // data-gradient filters of the 4 <- 4 layers as [tap][co][ci] (rs_conv_c4_co4)                                  // quarter-unit partials of the 5x5 weight gradient (rb_wgrad_c4)
-    __shared__ unsigned s_gen;
+    __shared__ unsigned s_gen, s_algebra;
     __shared__ int s_fail;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int s_of_t = t >> 9, tt = t & 511;
@@ -1565,7 +1678,7 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
             for (int sl = 0; sl < RB_FILT_SLOTS; ++sl) s_filt[sl][t] = fv[sl];
         }
     }
-    if (t == 0) { s_gen = gen0; s_fail = 0; }
+    if (t == 0) { s_gen = gen0; s_fail = 0; s_algebra = 0; }
     if (stage_dz) rs_barrier();
     stamp();
     if (p.head.enabled) {
@@ -1765,7 +1878,9 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         rs_allreduce_publish(go, epoch, 2 * C, mine, ctl_mute == blockIdx.x + 1u);
         rs_allreduce_reduce_owned(go, go + RS_MAXQ * RS_MAXG, epoch, 2 * C, G, s_red, &s_fail);   // the few owner blocks: before their own weight gradient, so that nobody waits for it
         }
-        if (oi > 0 && p.op[oi - 1].dw_part != nullptr) rb_wgrad(p.op[oi - 1], xtt, dzt, s_wgq);
+        // (s_wsum is free once wave 0 has read the moments in the algebra above: it says so in s_algebra, which the weight gradient's writers wait for)
+        if (t == 0) *(volatile unsigned*)&s_algebra = (unsigned)oi + 1u;
+        if (oi > 0 && p.op[oi - 1].dw_part != nullptr) rb_wgrad(p.op[oi - 1], xtt, dzt, s_wgq, s_wsum, &s_algebra, (unsigned)oi + 1u);
         else if (oi == 0 && fc_pg >= 0) {
             const rb_fc_args fa = {p.head.fc_dw, p.head.fc_db, p.head.classes, p.head.cc + p.head.cr, p.head.h * p.head.w, N, fc_pg};
             rb_fc_wgrad(fa, reinterpret_cast<const float*>(dzt), reinterpret_cast<float*>(xtt));      // (operands parked in the dz tile's region, the x tile is not in use yet)
