@@ -1329,16 +1329,17 @@ __device__ __forceinline__ void rb_wgrad_c4_mfma(const dcv_resident_bwd_op& o, c
         for (int half = 0; half < 2; ++half) {
             const float* xb = xf + ((size_t)s * RS_XIN + row0 * XW + half * 16 + kx) * 4 + lane;
             const float* db = df + ((size_t)s * RS_XIN + (row0 + pad) * XW + pad + half * 16) * 4 + lane;
-            float w[ROWS + K - 1];
+            // every operand of the half is requested before the first instruction (ROWS + 4 + ROWS registers): the LDS latency is paid once per half, the
+            // waits are counted
+            float w[ROWS + K - 1], d[ROWS];
 #pragma unroll
-            for (int r = 0; r < K - 1; ++r) w[r] = xb[r * RF];
+            for (int r = 0; r < ROWS + K - 1; ++r) { w[r] = xb[r * RF]; if (r < ROWS) d[r] = db[r * RF]; }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) {
-                w[r + K - 1] = xb[(r + K - 1) * RF];
-                const float dc = db[r * RF];
 #pragma unroll
-                for (int ky = 0; ky < K; ++ky) acc[ky] = __builtin_amdgcn_mfma_f32_4x4x1f32(dc, w[r + ky], acc[ky], 0, 0, 0);
-                if constexpr (BIAS) bsum += dc;
+                for (int ky = 0; ky < K; ++ky) acc[ky] = __builtin_amdgcn_mfma_f32_4x4x1f32(d[r], w[r + ky], acc[ky], 0, 0, 0);
+                if constexpr (BIAS) bsum += d[r];
             }
         }
     };
