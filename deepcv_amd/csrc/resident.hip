@@ -1282,9 +1282,9 @@ __device__ __forceinline__ void rb_wgrad_c4x16(const dcv_resident_bwd_op& o, con
 // shifted by the tap ([pixel][channel] tiles: 64 consecutive floats, one conflict-free ds_read_b32 each).  A piece = (sample, filter column kx, row range):
 // for each 16-column half it walks down the rows with the five x rows of the step in a register window — one new x read and one dz read per step feed FIVE
 // instructions (1280 MACs), where the VALU version (rb_wgrad_c4) spent 15 VALU instructions per 10 packed FMAs per step and was issue-bound at ~9 us.  The
-// 16 blocks of the accumulators are summed at the end (rb_sum_blocks24).  Work split, 200 instructions per wave: unit u = wave / 2 = (kx = u / 2 < 4,
-// sample u % 2); its even wave takes rows 0 - 19, its odd wave rows 20 - 31 and then a quarter (rows 8 q .. 8 q + 7, q = u / 2, sample u % 2) of filter column
-// 4.  The odd waves' partials meet the even waves' in LDS (sc_main, the per-wave moments' region: the moments were consumed by the algebra of wave 0, which
+// 16 blocks of the accumulators are summed at the end (rb_sum_blocks24).  Work split, 200 instructions per wave: unit u = (kx = u / 2 < 4,
+// sample u % 2) belongs to two waves; the first takes rows 0 - 19, the second rows 20 - 31 and then a quarter (rows 8 q .. 8 q + 7, q = u / 2, sample u % 2) of filter column
+// 4.  The second waves' partials meet the first waves' in LDS (sc_main, the per-wave moments' region: the moments were consumed by the algebra of wave 0, which
 // raises `flag` when it has read them), the quarters of column 4 in sc_q, in a fixed order.  The dz sums (bias gradient) ride along in the units of kx = 0
 // as one VALU add per step.
 // Sums of 24 values per lane over the 16 blocks of a 4x4x1 accumulator layout (lane = 4 b + j): two halving exchanges across the rows of 16 lanes
@@ -1292,12 +1292,16 @@ __device__ __forceinline__ void rb_wgrad_c4x16(const dcv_resident_bwd_op& o, con
 // 4 n + 2 * (row & 1) + (row >> 1) (row = lane / 16) for the lane's j = lane % 4, in every lane.
 // (inline asm: hipcc 7.2 adds the FIRST result of __builtin_amdgcn_permlane{32,16}_swap to itself when both are used — tools/probes/permlane_probe.hip shows
 // the instructions themselves do what the ISA says; the s_nop around them stand in for the hazard recogniser, which does not look inside an asm statement)
-__device__ __forceinline__ float rb_swap32_add(float a, float b) { asm volatile("s_nop 4\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); return a + b; }
+template <bool AFTER_MFMA> __device__ __forceinline__ float rb_swap32_add(float a, float b) {
+    if constexpr (AFTER_MFMA) asm volatile("s_nop 7\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));     // (operands fresh from the matrix pipe)
+    else asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
 __device__ __forceinline__ float rb_swap16_add(float a, float b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); return a + b; }
 __device__ __forceinline__ void rb_sum_blocks24(const float (&v)[24], float (&out)[6]) {
     float s1[12];
 #pragma unroll
-    for (int m = 0; m < 12; ++m) s1[m] = rb_swap32_add(v[2 * m], v[2 * m + 1]);
+    for (int m = 0; m < 12; ++m) s1[m] = m == 0 ? rb_swap32_add<true>(v[2 * m], v[2 * m + 1]) : rb_swap32_add<false>(v[2 * m], v[2 * m + 1]);
 #pragma unroll
     for (int n = 0; n < 6; ++n) {
         float s = rb_swap16_add(s1[2 * n], s1[2 * n + 1]);
@@ -1310,7 +1314,8 @@ __host__ __device__ __forceinline__ bool rb_wgrad_c4_mfma_ok(int cin, int cout, 
 constexpr int RB_WGM_MAIN = 96, RB_WGM_Q = 80;                                       // floats per unit in sc_main ([6][4][4]) and sc_q ([5][4][4])
 __device__ __forceinline__ void rb_wgrad_c4_mfma(const dcv_resident_bwd_op& o, const float4* xt, const float4* dzt, float* sc_q, float* sc_main, volatile unsigned* flag, unsigned flag_value) {
     constexpr int K = 5, pad = 2, XW = 32 + 2 * pad, RF = XW * 4;                    // RF: floats per tile row
-    const int t = rs_tid(), lane = t & 63, wave = rs_wave_of(t), u = wave >> 1, role = wave & 1, kxu = u >> 1, su = u & 1;
+    // (role by wave / 4: the four waves of a SIMD — wave % 4 — are two of each role, and the odd role's second reduction is spread over all SIMDs)
+    const int t = rs_tid(), lane = t & 63, wave = rs_wave_of(t), u = (wave & 3) + 4 * (wave >> 3), role = (wave >> 2) & 1, kxu = u >> 1, su = u & 1;
     const int cin = o.cin;
     const float* xf = reinterpret_cast<const float*>(xt);
     const float* df = reinterpret_cast<const float*>(dzt);
