@@ -317,8 +317,12 @@ __device__ __forceinline__ bool rs_conv_c4_co4(const dcv_resident_op& o, const f
 // counter with the LDS reads (lgkmcnt, and scalar loads return out of order), so the first wait for a tile vector also waited 1 - 1.5 us for the bias; (d) four
 // accumulation chains — per group one for the even and one for the odd input channels — so that no MFMA waits for its predecessor's result (one chain per
 // group: every wave spent 2.6 us after its last MFMA was issued waiting for the chain to drain).
-template <int K, int CI>
-__device__ __forceinline__ bool rs_conv_c4_co4_32(const dcv_resident_op& o, const float4* xin, float* yt, const float* wl, const float* bias_lds, float* wsum) {
+// MOM (the backward launch's data gradients): the output is the NEXT layer's dout, and the epilogue leaves that layer's two batch moments sum d, sum d u
+// (u = (y - mean) rstd of ITS y, `ynext`: the LDS region the output's pixels index too) per wave as [wave][4][RS_MAXC] where the moments pass would
+// (resident_bwd_kernel) — the pass itself (2.2 us of index arithmetic, a reduction and two barriers for two pixels per lane) is then skipped.
+template <int K, int CI, bool MOM = false>
+__device__ __forceinline__ bool rs_conv_c4_co4_32(const dcv_resident_op& o, const float4* xin, float* yt, const float* wl, const float* bias_lds, float* wsum,
+                                                  const float* ynext = nullptr, rs_f4 mom_mean = rs_f4{0.f, 0.f, 0.f, 0.f}, rs_f4 mom_rstd = rs_f4{0.f, 0.f, 0.f, 0.f}) {
     constexpr int XW = 32 + 2 * (K / 2), NS = (K + 1) * K, DEPTH = 2;
     const int t = rs_tid(), lane = t & 63, wave = rs_wave_of(t), s = wave >> 3, w8 = wave & 7;
     const int r0 = w8 * 4 + (lane >> 5) * 2, c = lane & 31;
@@ -358,22 +362,29 @@ __device__ __forceinline__ bool rs_conv_c4_co4_32(const dcv_resident_op& o, cons
     }
     float q8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float4* yo = reinterpret_cast<float4*>(yt + s * RS_Y) + r0 * 32 + c;
+    if constexpr (MOM) rs_barrier();                                                 // ynext was committed by all threads right before this call: by now a formality
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         float v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             v[i] = dcv_act_apply((g ? acc1[i] + acc1b[i] : acc0[i] + acc0b[i]) + (bias_lds ? bias_lds[i] : 0.f), act, slope);
-            q8[i] += v[i]; q8[4 + i] += v[i] * v[i];
+            if constexpr (!MOM) { q8[i] += v[i]; q8[4 + i] += v[i] * v[i]; }
+        }
+        if constexpr (MOM) {
+            const rs_f4 y4 = *reinterpret_cast<const rs_f4*>(reinterpret_cast<const float4*>(ynext + s * RS_Y) + r0 * 32 + c + g * 32);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const float u = (y4[i] - mom_mean[i]) * mom_rstd[i]; q8[i] += v[i]; q8[4 + i] += v[i] * u; }
         }
         yo[g * 32] = make_float4(v[0], v[1], v[2], v[3]);
     }
     float r[2];
     rs_reduce8(q8, r);                                                               // value index = quantity * 4 + channel
     if (lane < 4) {
+        constexpr int QS = MOM ? 4 : 2;                                              // quantities per wave in the caller's table
         const int vi = (lane & 1) * 4 + ((lane >> 1) & 1) * 2;                       // r[0], r[1] = values vi, vi + 1
-        wsum[(wave * 2 + (vi >> 2)) * RS_MAXC + (vi & 3)] = r[0];
-        wsum[(wave * 2 + (vi >> 2)) * RS_MAXC + (vi & 3) + 1] = r[1];
+        wsum[(wave * QS + (vi >> 2)) * RS_MAXC + (vi & 3)] = r[0];
+        wsum[(wave * QS + (vi >> 2)) * RS_MAXC + (vi & 3) + 1] = r[1];
     }
     return true;
 }
@@ -1508,7 +1519,7 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
     __shared__ __attribute__((aligned(16))) float s_coef[RS_SPB][3][RS_MAXC];        // dz = act'(y) (P d + Q u + R)
     __shared__ __attribute__((aligned(16))) float s_mr[2][RS_MAXC];                  // BatchNorm mean, rstd of the current layer
     __shared__ float s_abn[RS_SPB][RS_MAXC];                                         // BatchNorm gamma * rstd
-    __shared__ float s_par[DCV_RESIDENT_BWD_MAX_OPS][5][RS_MAXC];                    // bn gamma, beta, mean, rstd, gn gamma of every layer
+    __shared__ __attribute__((aligned(16))) float s_par[DCV_RESIDENT_BWD_MAX_OPS][5][RS_MAXC];   // bn gamma, beta, mean, rstd, gn gamma of every layer
     __shared__ float s_scratch[4 * RS_SPB * 4 * 5 * 4];                              // data-gradient phases: the convolutions' unused sums; weight-gradient phases: quarter-unit partials (rb_wgrad_c4)
     float* const s_dummy = s_scratch;
     float* const s_wgq = s_scratch;
@@ -1781,8 +1792,10 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
     stamp();
     // One more pass than ops: the last one (`tail`) only computes the first layer's weight gradient, which has no later all-reduce to hide behind — ONE
     // call site of rb_wgrad in the loop instead of a second copy of all its variants behind it.
+    bool moments_done = false;                                                       // the previous op's data gradient left this op's moments in s_wsum (rs_conv_c4_co4_32<.., true>)
     for (int oi = 0; oi <= p.count; ++oi) {
         const bool tail = oi == p.count;
+        bool moments_next = false;
         const dcv_resident_bwd_op& o = p.op[tail ? oi - 1 : oi];
         const int t = rs_tid(), lane = t & 63, wave = rs_wave_of(t), s_of_t = __builtin_amdgcn_readfirstlane(t >> 9), tt = t & 511;     // (per op: see rs_tid)
         const int C = o.cout, CV = C >> 2, H = o.h, W = o.w, HW = H * W, pk = o.pool > 0 ? o.pool : 1, Wo = W / pk;
@@ -1805,7 +1818,7 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         rs_barrier();
         // ---- four moments per (sample, channel): sum d, sum d u, sum u, sum u^2 with u = (y - mean) rstd, d = dout through the pooling map.  Wave w8 of the
         // sample owns channel vector w8 % CV and every (8 / CV)-th stripe of 64 pixels.
-        {
+        if (!moments_done) {
             const int w8 = wave & 7, cv = w8 & (CV - 1), stripes = 8 / CV, st0 = w8 / CV;
             const float4 mu = *reinterpret_cast<const float4*>(s_mr[0] + cv * 4), rs = *reinterpret_cast<const float4*>(s_mr[1] + cv * 4);
             const float4* ys = reinterpret_cast<const float4*>(yreg + s_of_t * RS_Y);
@@ -2052,7 +2065,17 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
                 const float* wl = s_filt[slot < RB_FILT_SLOTS ? slot : 0];
                 if (o.k == 3) rs_conv_c4_co4<3, 4, 0>(cv, dzt, dor, wl, nullptr, s_dummy);
                 else if (o.w != 32 || o.h != 32) rs_conv_c4_co4<5, 4, 0>(cv, dzt, dor, wl, nullptr, s_dummy);
-                else rs_conv_c4_co4_32<5, 4>(cv, dzt, dor, wl, nullptr, s_dummy);
+                else {
+                    // the next op's moments in this convolution's epilogue: same map, no pooling in between, nothing added to the result, and the forward
+                    // left that op's sums of y, y^2 (the moments pass would otherwise have to produce sum u, sum u^2 as well)
+                    const bool fuse = oi + 1 < p.count && p.op[oi + 1].pool <= 1 && p.op[oi + 1].sample_sums != nullptr && o.addend == nullptr && p.op[oi + 1].cout == 4
+                                      && p.op[oi + 1].h == H && p.op[oi + 1].w == W;
+                    if (fuse) {
+                        const rs_f4 nm = *reinterpret_cast<const rs_f4*>(s_par[oi + 1][2]), nr = *reinterpret_cast<const rs_f4*>(s_par[oi + 1][3]);
+                        rs_conv_c4_co4_32<5, 4, true>(cv, dzt, dor, wl, nullptr, s_wsum, yreg, nm, nr);
+                        moments_next = true;
+                    } else rs_conv_c4_co4_32<5, 4>(cv, dzt, dor, wl, nullptr, s_dummy);
+                }
             }
             else if (var == 4) rb_dgrad_c16_co4(o.filt, dzt, dor);
             else { float4 b4[9]; rs_load_bfrag_prepared(o.filt, b4); rs_conv_c16_mfma(cv, dzt, dor, b4, s_dummy); }
@@ -2069,6 +2092,7 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         }
         rs_barrier();
         stamp();
+        moments_done = moments_next;
     }
     stamp();
     if (blockIdx.x == ctl_stamp && t == 0) stamps[0] = (unsigned long long)n_stamp;
