@@ -709,6 +709,7 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
     bool conv_done = false;                                                          // this layer's convolution already ran (behind the previous apply step)
     bool sums_done = false;
     int fc_from_y = 0;                                                               // the FC input is the wide tensor a LINK left in yt
+    bool fc_done = false;                                                            // the FC behind a LINK ran in the LINK's branch (its weights travelled during the LINK)
     for (int oi = 0; oi < p.count; ++oi) {
         const dcv_resident_op& o = p.op[oi];
         const int t = rs_tid(), lane = t & 63, wave = rs_wave_of(t), s_of_t = __builtin_amdgcn_readfirstlane(t >> 9), tt = t & 511;     // (per op: see rs_tid)
@@ -913,6 +914,21 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
             const int Cc = o.cin, CVc = Cc >> 2, Cr = o.ref_c, Cw = Cc + Cr, HW = o.h * o.w, perw = HW * Cw;
             const float sh = o.align_corners ? (o.h > 1 ? (float)(o.ref_h - 1) / (float)(o.h - 1) : 0.f) : (float)o.ref_h / (float)o.h;
             const float sw = o.align_corners ? (o.w > 1 ? (float)(o.ref_w - 1) / (float)(o.w - 1) : 0.f) : (float)o.ref_w / (float)o.w;
+            // a fully connected op behind this one: wave j owns output j for BOTH samples, and the first 5 x 64 float4 of its weight row and its bias are
+            // requested here — they travel while the link is computed (in the op's own branch below, the round trip was the first half of its 2.4 us)
+            constexpr int FCB = 5;
+            const bool fc_next = oi + 1 < p.count && p.op[oi + 1].kind == DCV_RES_FC;
+            float4 fcw[FCB]; float fcb = 0.f;
+#pragma unroll
+            for (int u = 0; u < FCB; ++u) fcw[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (fc_next && wave < p.op[oi + 1].cout) {
+                const dcv_resident_op& f = p.op[oi + 1];
+                const int K4 = (f.h * f.w * f.cin) >> 2;
+                const float4* wr = reinterpret_cast<const float4*>(f.filt) + (size_t)wave * K4;
+#pragma unroll
+                for (int u = 0; u < FCB; ++u) { const int k = lane + 64 * u; fcw[u] = wr[k < K4 ? k : 0]; }
+                if (f.bias) fcb = f.bias[wave];
+            }
             __syncthreads();                                                         // full: every wave's earlier global stores (the referenced tensor) are done
             {   // referenced channels: one item per (sample, pixel, channel); loads first
                 const int per = HW * Cr;
@@ -952,6 +968,39 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
             rs_barrier();
             stamp();
             fc_from_y = 1;
+            if (fc_next) {
+                const dcv_resident_op& f = p.op[oi + 1];
+                const int K4 = (f.h * f.w * f.cin) >> 2, O = f.cout;
+                if (wave < O) {
+                    const float4* x0 = reinterpret_cast<const float4*>(yt), * x1 = reinterpret_cast<const float4*>(yt + RS_Y);
+                    const float4* wr = reinterpret_cast<const float4*>(f.filt) + (size_t)wave * K4;
+                    float a0 = 0.f, a1 = 0.f;
+                    for (int k0 = lane; k0 < K4; k0 += 64 * FCB) {
+#pragma unroll
+                        for (int u = 0; u < FCB; ++u) {
+                            const int k = k0 + 64 * u;
+                            if (k < K4) {
+                                const float4 w4 = fcw[u], p0 = x0[k], p1 = x1[k];
+                                a0 += p0.x * w4.x + p0.y * w4.y + p0.z * w4.z + p0.w * w4.w;
+                                a1 += p1.x * w4.x + p1.y * w4.y + p1.z * w4.z + p1.w * w4.w;
+                            }
+                        }
+                        if (k0 + 64 * FCB < K4) {                                    // (rows longer than 5 x 64 vectors: the next batch, now with its round trip exposed)
+#pragma unroll
+                            for (int u = 0; u < FCB; ++u) { const int k = k0 + 64 * (FCB + u); fcw[u] = wr[k < K4 ? k : 0]; }
+                        }
+                    }
+                    a0 = rs_wave_sum(a0); a1 = rs_wave_sum(a1);
+                    const int n0 = (int)blockIdx.x * RS_SPB;
+                    if (lane == 0 && n0 < N) f.out[(size_t)n0 * O + wave] = dcv_act_apply(a0 + fcb, f.act, f.slope);
+                    if (lane == 1 && n0 + 1 < N) f.out[(size_t)(n0 + 1) * O + wave] = dcv_act_apply(a1 + fcb, f.act, f.slope);
+                }
+                rs_barrier();
+                stamp();
+                fc_done = true;
+            }
+        } else if (o.kind == DCV_RES_FC && fc_done) {
+            // (computed in the LINK's branch)
         } else if (o.kind == DCV_RES_FC) {
             // logits[n][j] = act(bias[j] + sum_k x[n][k] w[j][k]), K = h * w * cin floats of the sample's flat NHWC activations; 32 lanes per (sample, j)
             const int K4 = (o.h * o.w * o.cin) >> 2, O = o.cout;
