@@ -2053,9 +2053,51 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         }
         // the dz tile: zero it (halo; the scratch dirtied it), interior below
         rs_barrier();
-        for (int i = t; i < RS_SPB * RS_XIN; i += RS_T) { dzt[i] = make_float4(0.f, 0.f, 0.f, 0.f); if (wg) xtt[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
-        rs_barrier();
+        // the stock model's 4-channel 32 x 32 layers with every extent a constant (as the forward launch's apply step): only the halos are zeroed — the
+        // interiors are written whole below, zeros for a missing sample —, no barrier between the two (disjoint words), one loop fills both tiles
+        const bool fast_tiles = C == 4 && H == 32 && W == 32 && o.k == 5 && (pk == 1 || pk == 2) && (!wg || xvec || xplanes);
+        if (fast_tiles) {
+            for (int i = t; i < RS_SPB * 272; i += RS_T) {
+                const int hs = i >= 272 ? 1 : 0, e = i - hs * 272;
+                int r, c;
+                if (e < 144) { r = (e * 1821) >> 16; c = e - r * 36; if (r >= 2) r += 32; }                     // (e / 36 for e < 144)
+                else { const int e2 = e - 144; r = 2 + (e2 >> 2); c = e2 & 3; if (c >= 2) c += 32; }
+                dzt[hs * RS_XIN + r * 36 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (wg) xtt[hs * RS_XIN + r * 36 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            for (int i = t; i < RS_SPB * RS_XIN; i += RS_T) { dzt[i] = make_float4(0.f, 0.f, 0.f, 0.f); if (wg) xtt[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+            rs_barrier();
+        }
         stamp();
+        if (fast_tiles) {
+            const int ss = s_of_t, n = (int)blockIdx.x * RS_SPB + ss;
+            const float4 Pv = *reinterpret_cast<const float4*>(s_coef[ss][0]), Qv = *reinterpret_cast<const float4*>(s_coef[ss][1]), Rv = *reinterpret_cast<const float4*>(s_coef[ss][2]);
+            const float4 mu = *reinterpret_cast<const float4*>(s_mr[0]), rs = *reinterpret_cast<const float4*>(s_mr[1]);
+            // (the activation decided once: ReLU / LeakyReLU — y > 0 ? 1 : slope, slope 0 for ReLU, the same values dcv_act_grad_from_out returns — or the switch)
+            const bool relu_like = o.act == DCV_ACT_RELU || o.act == DCV_ACT_LEAKY_RELU;
+            const float neg = o.act == DCV_ACT_RELU ? 0.f : o.slope;
+            auto fill = [&](auto relu_c) {
+                auto ag = [&](float y) { if constexpr (decltype(relu_c)::value) return y > 0.f ? 1.f : neg; else return rb_act_grad(y, o.act, o.slope); };
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int e = tt + k * 512, r = e >> 5, c = e & 31, at = ss * RS_XIN + (r + 2) * 36 + c + 2;
+                    if (wg) xtt[at] = n < N ? xpre[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float4 y4 = reinterpret_cast<const float4*>(yreg + ss * RS_Y)[e];
+                    const int di = pk > 1 ? (r >> 1) * 16 + (c >> 1) : e;
+                    const float4 d4 = reinterpret_cast<const float4*>(dor + ss * RS_Y)[di];
+                    float4 z;
+                    z.x = (Pv.x * (d4.x * pinv) + Qv.x * ((y4.x - mu.x) * rs.x) + Rv.x) * ag(y4.x);
+                    z.y = (Pv.y * (d4.y * pinv) + Qv.y * ((y4.y - mu.y) * rs.y) + Rv.y) * ag(y4.y);
+                    z.z = (Pv.z * (d4.z * pinv) + Qv.z * ((y4.z - mu.z) * rs.z) + Rv.z) * ag(y4.z);
+                    z.w = (Pv.w * (d4.w * pinv) + Qv.w * ((y4.w - mu.w) * rs.w) + Rv.w) * ag(y4.w);
+                    if (n >= N) z = make_float4(0.f, 0.f, 0.f, 0.f);
+                    else if (o.dz != nullptr) reinterpret_cast<float4*>(o.dz)[(size_t)n * 1024 + e] = z;
+                    dzt[at] = z;
+                }
+            };
+            if (relu_like) fill(std::true_type{}); else fill(std::false_type{});
+        } else {
         if (wg) {   // this op's x -> its zero-padded tile
             const int pad = o.k / 2, XW = W + 2 * pad, XH = H + 2 * pad, n = (int)blockIdx.x * RS_SPB + s_of_t;
             if (xvec) {
@@ -2119,6 +2161,7 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
                 else if (o.dz != nullptr) reinterpret_cast<float4*>(o.dz)[(size_t)n * per + e] = z;      // only when a weight-gradient launch will read it (dw_part == NULL)
                 dzt[ss * RS_XIN + (cv * XH + r + pad) * XW + c + pad] = z;
             }
+        }
         }
         rs_barrier();
         stamp();
