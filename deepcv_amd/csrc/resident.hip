@@ -490,6 +490,11 @@ __device__ __forceinline__ void rs_load_bfrag(const float* w, float4 (&b4)[9]) {
 }
 
 // the same fragments from the prepared data-gradient layout [n 16][kq 4][j 4][tap 9] (dcv_conv2d_prepare_filters op 4)
+__device__ __forceinline__ void rs_load_bfrag_lds(const float4* frag, float4 (&b4)[9]) {
+    const int lane = rs_tid() & 63;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) b4[q] = frag[q * 64 + lane];
+}
 __device__ __forceinline__ void rs_load_bfrag_prepared(const float* f, float4 (&b4)[9]) {
     const int lane = rs_tid() & 63, m = lane & 15, kq = lane >> 4;
     const float4* wp = reinterpret_cast<const float4*>(f + ((size_t)m * 4 + kq) * 36);
@@ -542,6 +547,7 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
     __shared__ __attribute__((aligned(16))) float s_T[RS_SPB][RS_MAXC];
     __shared__ __attribute__((aligned(16))) float s_par[DCV_RESIDENT_MAX_OPS][8][RS_MAXC];   // per-channel parameters of every layer: bn gamma, beta, running mean, var, gn gamma, beta, convolution bias
     __shared__ __attribute__((aligned(16))) float s_filt[RS_FILT_OPS][RS_FILT_FLOATS];  // filters of the cin <= 4 -> 4 layers as [tap][co][ci] (rs_conv_c4_co4)
+    __shared__ float4 s_bfrag[9 * 64];                                               // MFMA B fragments of the first 16 -> 16 layer, [q][lane] (rs_load_bfrag's registers): fetched in the prologue's round trip — at the layer itself the filter has left the L2 and the fetch was 2 us
     __shared__ double s_tot[RS_MAXQ], s_red[4];                                      // batch totals of the current synchronisation
     __shared__ unsigned s_w32[2 * RS_MAXQ];
     __shared__ unsigned s_gen;
@@ -564,6 +570,10 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
         if (blockIdx.x == ctl_stamp && t == 0 && n_stamp < RS_MAX_STAMPS) { if (n_stamp == 1) stamps[1] = t_start; stamps[1 + n_stamp] = wall_clock64(); }
         ++n_stamp;
     };
+    // MFMA B fragments of a 16 -> 16 layer travel two ops ahead: requested behind op oi's publish for op oi + 2 (the gather wait hides the trip), parked
+    // in s_bfrag when op oi + 1 starts; bfrag_op: the op whose fragments are there
+    int bfrag_op = -1, bfrag_pending = -1;
+    float4 bfv = make_float4(0.f, 0.f, 0.f, 0.f);
     {   // ONE global round trip: every layer's per-channel parameters -> LDS (the coefficient phases never wait for memory), the two samples -> the first
         // layer's padded tile (loads issued before the tile is zeroed)
         // a replayed step's batch: read through the address the host left in the mailbox for THIS replay (pinned host memory: the longest round trip of this
@@ -713,6 +723,7 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
     for (int oi = 0; oi < p.count; ++oi) {
         const dcv_resident_op& o = p.op[oi];
         const int t = rs_tid(), lane = t & 63, wave = rs_wave_of(t), s_of_t = __builtin_amdgcn_readfirstlane(t >> 9), tt = t & 511;     // (per op: see rs_tid)
+        if (bfrag_pending == oi + 1) { if (t < 9 * 64) s_bfrag[t] = bfv; bfrag_op = bfrag_pending; bfrag_pending = -1; }     // (this op's barriers separate the stores from their readers)
         if (o.kind == DCV_RES_LAYER) {
             const int C = o.cout, CV = C >> 2, H = o.h, W = o.w, HW = H * W;
             // ---- convolution + bias + activation: xin -> yt, per-wave sums of y, y^2 -> s_wsum
@@ -727,7 +738,7 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                 }
                 else if (var == 2) sums_done = o.k == 3 ? rs_conv_c4_wide<3>(o, xin, yt, s_wsum) : rs_conv_c4_wide<1>(o, xin, yt, s_wsum);
                 else if (var == 4) sums_done = o.k == 3 ? rs_conv_c4_mfma<3>(o, xin, yt, s_wsum) : rs_conv_c4_mfma<1>(o, xin, yt, s_wsum);
-                else { float4 b4[9]; rs_load_bfrag(o.filt, b4); sums_done = rs_conv_c16_mfma(o, xin, yt, b4, s_wsum); }
+                else { float4 b4[9]; if (oi == bfrag_op) rs_load_bfrag_lds(s_bfrag, b4); else rs_load_bfrag(o.filt, b4); sums_done = rs_conv_c16_mfma(o, xin, yt, b4, s_wsum); }
                 rs_barrier();
             }
             conv_done = false;
@@ -779,6 +790,11 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
             };
             if (o.bn) {
                 rs_allreduce_publish(go, epoch, 2 * C, mine, ctl_mute == blockIdx.x + 1u);
+                if (oi + 2 < p.count && p.op[oi + 2].kind == DCV_RES_LAYER && rs_variant(p.op[oi + 2].cin, p.op[oi + 2].cout, p.op[oi + 2].k, p.op[oi + 2].w) == 3) {
+                    const int l = t & 63, q = t >> 6;
+                    if (t < 9 * 64) { const rs_f4 v = *((const __attribute__((address_space(1))) rs_f4*)p.op[oi + 2].filt + 9 * (4 * (l & 15) + (l >> 4)) + q); bfv = make_float4(v[0], v[1], v[2], v[3]); }
+                    bfrag_pending = oi + 2;
+                }
                 if (oi == 0 && p.mailbox != nullptr) {
                     // the mailbox's other jobs (labels, optimizer scalars: a few KB) travel while the first layer's partial sums do: job j by a block which
                     // owns no quantity of the all-reduce (blocks 32 ..: nobody waits for them), or by block j when the grid is that small.  The reads of
@@ -881,6 +897,29 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                     }
                     return;
                 }
+                if (pk == 1 && C == 16 && H == 16 && W == 16 && nxt_layer && p.op[oi + 1].k == 3) {
+                    // the stock model's layer 4 (16 channels, 16 x 16, a 3x3 layer next: four channel-vector planes of 18 x 18), same idea
+                    const int ss = s_of_t, n = (int)blockIdx.x * RS_SPB + ss, cv = tt & 3;
+                    const float4 S = *reinterpret_cast<const float4*>(s_S[ss] + cv * 4), T = *reinterpret_cast<const float4*>(s_T[ss] + cv * 4);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int e = tt + k * 512, px = e >> 2, r = px >> 4, c = px & 15;
+                        const float4 v = reinterpret_cast<const float4*>(yt + ss * RS_Y)[e];
+                        float4 r4 = make_float4(0.f + (v.x * S.x + T.x), 0.f + (v.y * S.y + T.y), 0.f + (v.z * S.z + T.z), 0.f + (v.w * S.w + T.w));
+                        if (n < N) reinterpret_cast<float4*>(o.out)[(size_t)n * 1024 + e] = r4;
+                        else r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        xin[ss * RS_XIN + (cv * 18 + r + 1) * 18 + c + 1] = r4;
+                    }
+                    if (t < 8 * 68) {                                                // 8 planes x (2 x 18 + 16 x 2) halo vectors
+                        const int pl = (t * 964) >> 16, e = t - pl * 68;             // (t / 68 for t < 544)
+                        int r, c;
+                        if (e < 36) { r = e >= 18 ? 17 : 0; c = e - (e >= 18 ? 18 : 0); }
+                        else { const int e2 = e - 36; r = 1 + (e2 >> 1); c = (e2 & 1) ? 17 : 0; }
+                        const int hs = pl >> 2, cvp = pl & 3;
+                        xin[hs * RS_XIN + (cvp * 18 + r) * 18 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                    return;
+                }
                 const int npad = nxt_layer ? p.op[oi + 1].k / 2 : 0, XWn = Wo + 2 * npad, XHn = Ho + 2 * npad;
                 const float inv = 1.f / (float)(pk * pk), inv_cv = 1.f / (float)CV, inv_wo = 1.f / (float)Wo;
                 const int per = Ho * Wo * CV;
@@ -922,7 +961,8 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                 // 36 registers do not live across the op loop
                 apply_step();
                 float4 b4[9];
-                rs_load_bfrag(p.op[oi + 1].filt, b4);       // (requested in FRONT of the apply step, the 36 registers slowed its loops from 2.2 to 5.3 us)
+                if (oi + 1 == bfrag_op) rs_load_bfrag_lds(s_bfrag, b4);
+                else rs_load_bfrag(p.op[oi + 1].filt, b4);  // (requested in FRONT of the apply step, the 36 registers slowed the general step's loops from 2.2 to 5.3 us and spill in the constant-extent one)
                 rs_barrier();
                 stamp();
                 sums_done = rs_conv_c16_mfma(p.op[oi + 1], xin, yt, b4, s_wsum);
