@@ -2096,7 +2096,23 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         // the stock model's 4-channel 32 x 32 layers with every extent a constant (as the forward launch's apply step): only the halos are zeroed — the
         // interiors are written whole below, zeros for a missing sample —, no barrier between the two (disjoint words), one loop fills both tiles
         const bool fast_tiles = C == 4 && H == 32 && W == 32 && o.k == 5 && (pk == 1 || pk == 2) && (!wg || xvec || xplanes);
-        if (fast_tiles) {
+        // ... and its 16-channel 16 x 16 layers (3x3: channel-vector planes of 18 x 18; input of 16 or 4 channels)
+        const bool fast16 = C == 16 && H == 16 && W == 16 && o.k == 3 && (pk == 1 || pk == 2) && (!wg || (xvec && (o.cin == 16 || o.cin == 4)));
+        if (fast16) {
+            auto halo = [&](int e, int& r, int& c) {                                 // the e-th of a plane's 68 halo vectors
+                if (e < 36) { r = e >= 18 ? 17 : 0; c = e - (e >= 18 ? 18 : 0); }
+                else { const int e2 = e - 36; r = 1 + (e2 >> 1); c = (e2 & 1) ? 17 : 0; }
+            };
+            if (t < 8 * 68) { const int pl = (t * 964) >> 16, e = t - pl * 68; int r, c; halo(e, r, c); dzt[(pl >> 2) * RS_XIN + ((pl & 3) * 18 + r) * 18 + c] = make_float4(0.f, 0.f, 0.f, 0.f); }
+            if (wg) {
+                const int cvi = o.cin >> 2;                                          // 4 or 1 planes per sample
+                if (t < RS_SPB * cvi * 68) {
+                    const int pl = (t * 964) >> 16, e = t - pl * 68, hs = cvi == 4 ? pl >> 2 : pl, cvp = cvi == 4 ? pl & 3 : 0;
+                    int r, c; halo(e, r, c);
+                    xtt[hs * RS_XIN + (cvp * 18 + r) * 18 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        } else if (fast_tiles) {
             for (int i = t; i < RS_SPB * 272; i += RS_T) {
                 const int hs = i >= 272 ? 1 : 0, e = i - hs * 272;
                 int r, c;
@@ -2110,7 +2126,36 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
             rs_barrier();
         }
         stamp();
-        if (fast_tiles) {
+        if (fast16) {
+            const int ss = s_of_t, n = (int)blockIdx.x * RS_SPB + ss, cv = tt & 3;
+            const float4 Pv = *reinterpret_cast<const float4*>(s_coef[ss][0] + cv * 4), Qv = *reinterpret_cast<const float4*>(s_coef[ss][1] + cv * 4), Rv = *reinterpret_cast<const float4*>(s_coef[ss][2] + cv * 4);
+            const float4 mu = *reinterpret_cast<const float4*>(s_mr[0] + cv * 4), rs = *reinterpret_cast<const float4*>(s_mr[1] + cv * 4);
+            const bool relu_like = o.act == DCV_ACT_RELU || o.act == DCV_ACT_LEAKY_RELU;
+            const float neg = o.act == DCV_ACT_RELU ? 0.f : o.slope;
+            auto fill = [&](auto relu_c) {
+                auto ag = [&](float y) { if constexpr (decltype(relu_c)::value) return y > 0.f ? 1.f : neg; else return rb_act_grad(y, o.act, o.slope); };
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int e = tt + k * 512, px = e >> 2, r = px >> 4, c = px & 15, at = ss * RS_XIN + (cv * 18 + r + 1) * 18 + c + 1;
+                    if (wg) {
+                        if (o.cin == 16) xtt[at] = n < N ? xpre[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        else if (e < 256) xtt[ss * RS_XIN + ((e >> 4) + 1) * 18 + (e & 15) + 1] = n < N ? xpre[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                    const float4 y4 = reinterpret_cast<const float4*>(yreg + ss * RS_Y)[e];
+                    const int di = pk > 1 ? (r >> 1) * 8 + (c >> 1) : px;
+                    const float4 d4 = reinterpret_cast<const float4*>(dor + ss * RS_Y)[di * 4 + cv];
+                    float4 z;
+                    z.x = (Pv.x * (d4.x * pinv) + Qv.x * ((y4.x - mu.x) * rs.x) + Rv.x) * ag(y4.x);
+                    z.y = (Pv.y * (d4.y * pinv) + Qv.y * ((y4.y - mu.y) * rs.y) + Rv.y) * ag(y4.y);
+                    z.z = (Pv.z * (d4.z * pinv) + Qv.z * ((y4.z - mu.z) * rs.z) + Rv.z) * ag(y4.z);
+                    z.w = (Pv.w * (d4.w * pinv) + Qv.w * ((y4.w - mu.w) * rs.w) + Rv.w) * ag(y4.w);
+                    if (n >= N) z = make_float4(0.f, 0.f, 0.f, 0.f);
+                    else if (o.dz != nullptr) reinterpret_cast<float4*>(o.dz)[(size_t)n * 1024 + e] = z;
+                    dzt[at] = z;
+                }
+            };
+            if (relu_like) fill(std::true_type{}); else fill(std::false_type{});
+        } else if (fast_tiles) {
             const int ss = s_of_t, n = (int)blockIdx.x * RS_SPB + ss;
             const float4 Pv = *reinterpret_cast<const float4*>(s_coef[ss][0]), Qv = *reinterpret_cast<const float4*>(s_coef[ss][1]), Rv = *reinterpret_cast<const float4*>(s_coef[ss][2]);
             const float4 mu = *reinterpret_cast<const float4*>(s_mr[0]), rs = *reinterpret_cast<const float4*>(s_mr[1]);
