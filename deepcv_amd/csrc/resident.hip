@@ -920,6 +920,38 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                     }
                     return;
                 }
+                if (pk == 2 && ((C == 4 && H == 32 && W == 32 && nxt_layer && p.op[oi + 1].k == 3) || (C == 16 && H == 16 && W == 16 && !nxt_layer))) {
+                    // the stock model's pooled layers: 3 (4 channels, 32 x 32 -> 16 x 16, one 18 x 18 plane for the 3x3 layer next) and 5 (16 channels,
+                    // 16 x 16 -> 8 x 8, flat NHWC for the LINK): 256 outputs per sample, window elements accumulated in the general path's order
+                    const int ss = s_of_t, n = (int)blockIdx.x * RS_SPB + ss;
+                    const bool c4 = C == 4;
+                    if (tt < 256) {
+                        const int cv = c4 ? 0 : tt & 3, px = c4 ? tt : tt >> 2, ho = c4 ? px >> 4 : px >> 3, wo = c4 ? px & 15 : px & 7;
+                        const float4 S = *reinterpret_cast<const float4*>(s_S[ss] + cv * 4), T = *reinterpret_cast<const float4*>(s_T[ss] + cv * 4);
+                        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                            for (int kw = 0; kw < 2; ++kw) {
+                                const int yi = c4 ? (ho * 2 + kh) * 32 + wo * 2 + kw : ((ho * 2 + kh) * 16 + wo * 2 + kw) * 4 + cv;
+                                const float4 v = reinterpret_cast<const float4*>(yt + ss * RS_Y)[yi];
+                                acc[0] += v.x * S.x + T.x; acc[1] += v.y * S.y + T.y; acc[2] += v.z * S.z + T.z; acc[3] += v.w * S.w + T.w;
+                            }
+                        float4 r4 = make_float4(acc[0] * 0.25f, acc[1] * 0.25f, acc[2] * 0.25f, acc[3] * 0.25f);
+                        if (n < N) reinterpret_cast<float4*>(o.out)[(size_t)n * 256 + tt] = r4;
+                        else r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (c4) xin[ss * RS_XIN + (ho + 1) * 18 + wo + 1] = r4;
+                        else reinterpret_cast<float4*>(xinf + (size_t)ss * RS_XIN * 4)[tt] = r4;
+                    }
+                    if (c4 && t < RS_SPB * 68) {
+                        const int hs = t >= 68 ? 1 : 0, e = t - hs * 68;
+                        int r, c;
+                        if (e < 36) { r = e >= 18 ? 17 : 0; c = e - (e >= 18 ? 18 : 0); }
+                        else { const int e2 = e - 36; r = 1 + (e2 >> 1); c = (e2 & 1) ? 17 : 0; }
+                        xin[hs * RS_XIN + r * 18 + c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                    return;
+                }
                 const int npad = nxt_layer ? p.op[oi + 1].k / 2 : 0, XWn = Wo + 2 * npad, XHn = Ho + 2 * npad;
                 const float inv = 1.f / (float)(pk * pk), inv_cv = 1.f / (float)CV, inv_wo = 1.f / (float)Wo;
                 const int per = Ho * Wo * CV;
