@@ -1920,12 +1920,13 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
 #pragma unroll
                 for (int a = 0; a < RB_TAPS; ++a) {
                     const float wh = wtab[rh * RB_TAPS + a];
-                    if (wh == 0.f) continue;
+                    if (wh == 0.f) break;                                           // (the table packs its non-zero taps first: the first zero ends the row)
                     const int ho = itab[rh * RB_TAPS + a];
 #pragma unroll
                     for (int c = 0; c < RB_TAPS; ++c) {
                         const float ww = wtab[(RH + rw) * RB_TAPS + c];
-                        if (ww != 0.f) acc += wh * ww * tmp[s_of_t * RS_Y + (ho * hd.w + itab[(RH + rw) * RB_TAPS + c]) * Cr + cr];
+                        if (ww == 0.f) break;
+                        acc += wh * ww * tmp[s_of_t * RS_Y + (ho * hd.w + itab[(RH + rw) * RB_TAPS + c]) * Cr + cr];
                     }
                 }
                 const int n = (int)blockIdx.x * RS_SPB + s_of_t;
