@@ -12,6 +12,6 @@ VARIANTS = {
         ("                            __threadfence_system();\n", ""),
     ],
     'nomail': [
-        ("        if (p.mailbox != nullptr) batch = p.batch != nullptr ? p.batch : reinterpret_cast<const float*>(p.mailbox->src[p.x_job]);\n", ""),
+        ("        if (from_mailbox) batch_word = __hip_atomic_load((rs_gu64*)&p.mailbox->src[p.x_job], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);\n", "        if (from_mailbox) batch_word = (rs_u64)o.x;\n"),
     ],
 }
