@@ -48,6 +48,22 @@ __device__ __forceinline__ float dcv_act_grad_from_out(float y, int act, float s
     }
 }
 
+// A scalar for the host's early read-back (dcv_publish_scalars and the loss kernels which publish on their own).  Packed record — host_seq is the word
+// right behind host_vals[0], 8-byte aligned —: ONE system-scope 64-bit store {value, sequence number}; the host polls the sequence word and then reads the
+// value of the same write, no fence on the device (a release fence at system scope writes the XCD's L2 back: ~1 us on the publishing thread's block,
+// which the whole grid waits for at its next synchronisation).  Otherwise: the value into every slot, fence, the sequence number, as before.
+__device__ __forceinline__ void dcv_publish_value(float* host_vals, int* host_seq, int slots, float value, int seq) {
+    if (host_seq == reinterpret_cast<int*>(host_vals) + 1 && (reinterpret_cast<unsigned long long>(host_vals) & 7ull) == 0ull) {
+        const unsigned long long rec = ((unsigned long long)(unsigned)seq << 32) | (unsigned long long)__float_as_uint(value);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_vals), rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    for (int i = 0; i < slots; ++i) host_vals[i] = value;
+    __threadfence_system();                                              // the values are in host memory before the sequence number is
+    *reinterpret_cast<volatile int*>(host_seq) = seq;
+    __threadfence_system();
+}
+
 // full-wave (64 lanes) butterfly sum; every lane ends with the total
 template <typename T>
 __device__ __forceinline__ T dcv_wave_sum(T v) {

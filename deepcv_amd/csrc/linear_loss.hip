@@ -298,10 +298,7 @@ __global__ __launch_bounds__(1024) void ce_fwd_single_kernel(const float* __rest
         loss[0] = value;
         if (correct) correct[0] = k;
         if (pub.host_seq != nullptr) {                                   // early read-back of a replayed step (dcv_publish_scalars without its launch)
-            for (int i = 0; i < pub.slots; ++i) pub.host_vals[i] = value;
-            __threadfence_system();                                      // the values are in host memory before the sequence number is
-            *reinterpret_cast<volatile int*>(pub.host_seq) = pub.mailbox->seq;
-            __threadfence_system();
+            dcv_publish_value(pub.host_vals, pub.host_seq, pub.slots, value, pub.mailbox->seq);
         }
     }
 }

@@ -1721,6 +1721,7 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
             for (int k = 0; k < RB_FC_DZ_SLOTS; ++k) { const int i = t + k * RS_T; fc_g[k] = p.head.dlogits[i < total ? i : 0]; fc_l[k] = p.head.logits ? p.head.logits[i < total ? i : 0] : 0.f; }
         }
     }
+    int pub_seq_pre = 0;
     {   // per-channel parameters of every layer -> LDS; y and dout of the first op (the last layer) -> LDS
         const dcv_resident_bwd_op& o = p.op[0];
         const int pk = o.pool > 0 ? o.pool : 1;
@@ -1773,6 +1774,12 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
             for (int sl = 0; sl < RB_FILT_SLOTS; ++sl)
                 if (slot_op[sl] >= 0) { const dcv_resident_bwd_op& w = p.op[slot_op[sl]]; fv[sl] = rs_filt_fetch(w.filt, w.k, t); }
         }
+        // the mailbox's sequence number for the loss publication (the writer block only; every other thread reads a control word: unconditional, see above)
+        {
+            const bool pub_here = p.head.enabled && p.head.pub_seq != nullptr && blockIdx.x == (G > RS_MAXQ + DCV_MAX_COPY_JOBS ? (unsigned)(RS_MAXQ + DCV_MAX_COPY_JOBS) : 0u);
+            const int* sp = pub_here ? &p.head.pub_mailbox->seq : reinterpret_cast<const int*>(ctl);
+            pub_seq_pre = *(const __attribute__((address_space(1))) int*)sp;
+        }
         if (stage_dz) {
             float* staged = reinterpret_cast<float*>(dzt);
             const int total = N * p.head.classes;
@@ -1813,12 +1820,9 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
                         const float value = (float)(sum / (double)N);
                         p.head.ce_loss[0] = value;
                         if (p.head.ce_correct != nullptr) p.head.ce_correct[0] = k;
-                        if (p.head.pub_seq != nullptr) {                                 // early read-back, as dcv_cross_entropy_fwd_grad_publish
-                            for (int i = 0; i < p.head.pub_slots; ++i) p.head.pub_vals[i] = value;
-                            __threadfence_system();
-                            *reinterpret_cast<volatile int*>(p.head.pub_seq) = p.head.pub_mailbox->seq;
-                            __threadfence_system();
-                        }
+                        // early read-back, as dcv_cross_entropy_fwd_grad_publish (the sequence number was requested with the prologue's loads: this block
+                        // is the last to reach the first synchronisation, and a memory round trip plus two fences here were 1.8 us of every block's wait)
+                        if (p.head.pub_seq != nullptr) dcv_publish_value(p.head.pub_vals, p.head.pub_seq, p.head.pub_slots, value, pub_seq_pre);
                     }
                 }
             } else {

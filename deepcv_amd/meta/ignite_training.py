@@ -223,6 +223,7 @@ class GraphedTrainStep:
     _MB_PAYLOAD = 256                                              # byte offset of the scalar payload inside the mailbox
     _MB_COUNT_SEQ = 192                                            # ... of dcv_copy_jobs.count / .seq (behind 3 x 8 eight-byte words)
     _PUB_VALS, _PUB_SEQ = 768, 832                                 # byte offsets of the published loss values / their sequence number
+    _PUB_PACKED = 896                                              # ... of the packed record {float value; int seq} a loss kernel publishes with ONE 64-bit store (`dcv_publish_value`)
 
     def _mailbox_init(self, dev):
         from .. import _native as nat
@@ -311,7 +312,7 @@ class GraphedTrainStep:
             vals = OrderedDict((n, v.item()) for n, v in self._last_losses.items())
         else:
             self._wait_published()
-            vals = OrderedDict((n, float(self._pub_vals[i])) for i, n in enumerate(self.static_losses.keys()))
+            vals = OrderedDict((n, float(self._pub_vals[min(i, len(self._pub_vals) - 1)])) for i, n in enumerate(self.static_losses.keys()))
         if any(v != v for v in vals.values()):
             # a persistent launch which gave up waiting for its own blocks poisons the logits: say so instead of training on NaN (deepcv_amd/resident.py)
             from .. import resident
@@ -368,7 +369,8 @@ class GraphedTrainStep:
             fold = len(self.losses) == 1 and isinstance(next(iter(self.losses.values())), native.CrossEntropyLoss)
             if fold:
                 seq_src = self._mb_dev.data_ptr() if self._seq_shadowed else self.mailbox.data_ptr()
-                _ops.set_loss_publisher((seq_src, self.mailbox.data_ptr() + self._PUB_VALS, self.mailbox.data_ptr() + self._PUB_SEQ, 2))
+                # (packed record: the sequence word right behind the value — no fence in the publishing launch; both names of the loss read the one value)
+                _ops.set_loss_publisher((seq_src, self.mailbox.data_ptr() + self._PUB_PACKED, self.mailbox.data_ptr() + self._PUB_PACKED + 4, 1))
             _ops.defer_cross_entropy(fold)                 # ... and, on the LDS-resident path, leaves the loss itself to the backward launch
             try:
                 self.static_losses = _batch_losses(self.losses, self.weights, self.static_pred, self.static_y)
@@ -381,6 +383,8 @@ class GraphedTrainStep:
                 if len(terms) > 2 or any(t.data_ptr() != published.data_ptr() for t in terms):      # (one name or two for the one tensor: both slots carry it)
                     raise RuntimeError('deepcv_amd: the loss published by the cross-entropy launch is not the loss of the captured step')
                 self._publishes = True
+                self._pub_vals = self._mb[self._PUB_PACKED:self._PUB_PACKED + 4].view('<f4')
+                self._pub_seq = self._mb[self._PUB_PACKED + 4:self._PUB_PACKED + 8].view('<i4')
             elif 0 < len(terms) <= self._nat.MAX_COPY_JOBS and all(t.numel() == 1 and t.dtype == torch.float32 for t in terms):
                 import ctypes
                 ptrs = (ctypes.c_void_p * len(terms))(*[t.data_ptr() for t in terms])

@@ -488,7 +488,9 @@ int dcv_cross_entropy_fwd_grad(const float* logits, const int64_t* target, float
                                int n, int classes, void* ws, size_t ws_bytes, void* stream);
 /* as dcv_cross_entropy_fwd_grad; the one-launch case also publishes the loss to pinned host memory the way dcv_publish_scalars does (the value into
  * host_vals[0 .. slots), then mailbox->seq into *host_seq), sparing a replayed training step that launch — *published tells whether it did; host_seq NULL:
- * nothing is published. */
+ * nothing is published.  PACKED RECORD: when host_seq is the word right behind host_vals[0] and host_vals is 8-byte aligned, value and sequence number leave
+ * as ONE 64-bit system-scope store {value, seq} and no fence is issued on the device (slots is then 1); the host polls the sequence word and reads the
+ * value of the same write.  The same rule holds for the loss published by dcv_resident_backward's head (dcv_resident_bwd_head.pub_*). */
 int dcv_cross_entropy_fwd_grad_publish(const float* logits, const int64_t* target, float* loss, float* lse, int32_t* correct, float* dlogits_unit, int* produced,
                                        int n, int classes, void* ws, size_t ws_bytes, const dcv_copy_jobs* mailbox, float* host_vals, int* host_seq, int slots,
                                        int* published, void* stream);
