@@ -556,7 +556,10 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
     const int s_of_t = t >> 9, tt = t & 511;                                         // sample-major split of the block for the per-sample passes
     const int N = p.n, G = (int)gridDim.x;
     const bool valid0 = (int)blockIdx.x * RS_SPB < N, valid1 = (int)blockIdx.x * RS_SPB + 1 < N;
-    rs_kernarg_warm<(int)(sizeof(dcv_resident_program) + 2 * sizeof(void*))>();
+    // (wave 0 alone, the others behind a barrier: the scalar cache is the CU's, and in a hipGraph replay the argument segment is HOST memory — sixteen waves
+    // requesting 40 lines each at once were 160 k PCIe reads per launch: 0.2 -> 0.9 ms per step of the hipGraph fallback)
+    if (rs_wave_of(rs_tid()) == 0) rs_kernarg_warm<(int)(sizeof(dcv_resident_program) + 2 * sizeof(void*))>();
+    rs_barrier();
     // the control words: requested here, first needed at the end of the prologue (the first stamp is taken unconditionally and written with the second one:
     // a stamp which compared block indices here would put the words' round trip in front of every load below)
     int lz = 0; asm volatile("" : "+v"(lz));                                         // (a zero the compiler takes for a per-lane value: uniform words would be moved to scalar registers here, i.e. waited for here)
@@ -583,7 +586,9 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
         const float* batch = o.x;
         rs_u64 batch_word = 0;
         const bool from_mailbox = p.mailbox != nullptr && p.batch == nullptr;
-        if (from_mailbox) batch_word = __hip_atomic_load((rs_gu64*)&p.mailbox->src[p.x_job], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // (a plain load through a per-lane-looking address: a vector load, counted in order.  As a SYSTEM-scope atomic load this word took 700 us per launch
+        // when the step replayed as a hipGraph — and 4 us in the launch-list replay; pinned host memory is not cached on the device either way)
+        if (from_mailbox) batch_word = *((const rs_gu64*)&p.mailbox->src[p.x_job] + lz);
         else if (p.mailbox != nullptr) batch = p.batch;
         // a wave's slots belong to ONE op (128 slots each): its descriptor is read through scalar loads (rs_kernarg_warm above) and the row's pointer picked
         // by selects — indexed per lane, the descriptor words, then the pointer, then the value were three dependent round trips ahead of everything below
@@ -1676,7 +1681,8 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
     const int s_of_t = t >> 9, tt = t & 511;
     const int N = p.n, G = (int)gridDim.x;
     const bool valid0 = (int)blockIdx.x * RS_SPB < N, valid1 = (int)blockIdx.x * RS_SPB + 1 < N;
-    rs_kernarg_warm<(int)(sizeof(dcv_resident_bwd_program) + 2 * sizeof(void*))>();
+    if (rs_wave_of(rs_tid()) == 0) rs_kernarg_warm<(int)(sizeof(dcv_resident_bwd_program) + 2 * sizeof(void*))>();     // (wave 0 alone: see the forward launch)
+    rs_barrier();
     int lz = 0; asm volatile("" : "+v"(lz));
     const unsigned ctl_mute = ctl[2 + lz], ctl_stamp = ctl[3 + lz];                  // (as in the forward launch: first needed at the end of the prologue)
     const unsigned gen0 = __hip_atomic_load((rs_gu32*)ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -312,6 +312,39 @@ def test_forward_launch_stages_the_batch_of_a_replayed_step(device, params):
     assert curves[0] == curves[1], curves
 
 
+def test_hipgraph_replay_of_the_resident_step_is_not_a_slow_path(device, params):
+    """ The launch-list replay falls back to replaying the captured hipGraph (`DCV_REPLAY_LIST=0`, a step with foreign kernels, a failed verification): same
+    losses, and a comparable step time — a kernel's arguments and the mailbox sit in HOST memory for a graph node, and a system-scope atomic load of the
+    mailbox word by every wave once made the forward launch 700 us there (0.2 -> 0.9 ms per step) while the list replay, which every measurement used, did
+    not notice.  The bound is loose (3x): this is a tripwire, not a benchmark. """
+    import time
+    from deepcv_amd import modules, optim, resident
+    from deepcv_amd.meta.ignite_training import GraphedTrainStep, _setup_losses
+    g = torch.Generator().manual_seed(DATA_SEED)
+    batches = [(torch.randn(512, 3, 32, 32, generator=g).to(device), torch.randint(0, 10, (512,), generator=g).to(device)) for _ in range(4)]
+    curves, times = [], []
+    for replay_list in (True, False):
+        model = _model(params, 'image_classifier_model', device)
+        opt = optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-2)
+        losses, weights = _setup_losses(modules.CrossEntropyLoss(), None, device)
+        step = GraphedTrainStep(model, opt, losses, weights)
+        step._replay_list = replay_list
+        got = []
+        for i in range(8):                                   # eager step, capture, verification, first replays
+            out, _ = step(*batches[i % 4])
+            got.append(out['main_loss'].item())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(200):
+            step(*batches[i % 4])
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) / 200)
+        resident.check_status()
+        curves.append(got)
+    assert curves[0] == curves[1], curves
+    assert times[1] < 3.0 * times[0], f'hipGraph replay {times[1] * 1e3:.3f} ms/step against {times[0] * 1e3:.3f} ms/step of the launch-list replay'
+
+
 @pytest.mark.parametrize('which', ['forward', 'backward'])
 def test_a_block_which_never_arrives_is_reported_not_waited_for(device, params, which):
     """ The all-reduce's spins are bounded: with one block muted (test hook in the workspace's control words: it takes part in everything but never publishes
