@@ -1955,11 +1955,12 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         bool moments_next = false;
         const dcv_resident_bwd_op& o = p.op[tail ? oi - 1 : oi];
         const int t = rs_tid(), lane = t & 63, wave = rs_wave_of(t), s_of_t = __builtin_amdgcn_readfirstlane(t >> 9), tt = t & 511;     // (per op: see rs_tid)
-        const int C = o.cout, CV = C >> 2, H = o.h, W = o.w, HW = H * W, pk = o.pool > 0 ? o.pool : 1, Wo = W / pk;
-        const float pinv = 1.f / (float)(pk * pk), inv_w = 1.f / (float)W, inv_pk = 1.f / (float)pk;
+        // (every wave runs this scalar set-up once per op: the usual extents skip the ~25-instruction integer divisions and the IEEE divisions — same values)
+        const int C = o.cout, CV = C >> 2, H = o.h, W = o.w, HW = H * W, pk = o.pool > 0 ? o.pool : 1, Wo = pk == 1 ? W : pk == 2 ? W >> 1 : W / pk;
+        const float pinv = pk == 1 ? 1.f : pk == 2 ? 0.25f : 1.f / (float)(pk * pk), inv_w = W == 32 ? 0.03125f : W == 16 ? 0.0625f : 1.f / (float)W, inv_pk = pk == 1 ? 1.f : pk == 2 ? 0.5f : 1.f / (float)pk;
         // the (sample, channel) threads of wave 0 request their GroupNorm statistics now; used after the moments
         const int ac_ss = t >= C ? 1 : 0, ac_c = t - ac_ss * C, ac_n = (int)blockIdx.x * RS_SPB + ac_ss;
-        const int cpg = o.groups > 0 ? C / o.groups : 1;
+        const int cpg = o.groups <= 0 ? 1 : o.groups == 1 ? C : (o.groups & (o.groups - 1)) == 0 ? C >> (31 - __builtin_clz(o.groups)) : C / o.groups;
         const unsigned epoch = gen * DCV_RESIDENT_MAX_OPS + (unsigned)oi + 1u;
         rs_u64* go = gran + (size_t)(tail ? 0 : oi) * RS_GRAN_OP;
         if (!tail) {
