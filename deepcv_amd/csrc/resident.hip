@@ -857,14 +857,14 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                 }
                 float S = a, T = b;
                 if (o.groups > 0) {
-                    const int cpg = C / o.groups;
+                    const int cpg = (o.groups & (o.groups - 1)) == 0 ? C >> (31 - __builtin_clz(o.groups)) : C / o.groups;
                     const double hw = (double)HW, ad = (double)a, bd = (double)b, s1 = (double)s_samp[ss][0][c], s2 = (double)s_samp[ss][1][c];
                     double sv = ad * s1 + hw * bd, svv = ad * ad * s2 + 2.0 * ad * bd * s1 + hw * bd * bd;
                     for (int off = 1; off < cpg; off <<= 1) { sv += __shfl_xor(sv, off, 64); svv += __shfl_xor(svv, off, 64); }   // cpg: a power of two of adjacent lanes
                     const double mean = sv * o.inv_group;
                     double varc = svv * o.inv_group - mean * mean; if (varc < 0.0) varc = 0.0;
                     const float rstd = (float)rs_rsqrt(varc + (double)o.gn_eps);
-                    const int n = (int)blockIdx.x * RS_SPB + ss, g = rs_fdiv(c, 1.f / (float)cpg);
+                    const int n = (int)blockIdx.x * RS_SPB + ss, g = (cpg & (cpg - 1)) == 0 ? c >> (31 - __builtin_clz(cpg)) : rs_fdiv(c, 1.f / (float)cpg);
                     if (c == g * cpg && n < N) { o.gn_mean[(size_t)n * o.groups + g] = (float)mean; o.gn_rstd[(size_t)n * o.groups + g] = rstd; }
                     const float gg = s_par[oi][4][c], gb = s_par[oi][5][c];
                     S = a * rstd * gg; T = (b - (float)mean) * rstd * gg + gb;
@@ -1968,7 +1968,7 @@ __global__ __launch_bounds__(RS_T) void resident_bwd_kernel(dcv_resident_bwd_pro
         float e_sy = 0.f, e_syy = 0.f;                                               // the forward's sums of y, y^2 of (sample, channel), when it left them
         const bool have_sums = o.sample_sums != nullptr;
         if (t < RS_SPB * C && o.groups > 0 && ac_n < N) {
-            const int g = rs_fdiv(ac_c, 1.f / (float)cpg);
+            const int g = (cpg & (cpg - 1)) == 0 ? ac_c >> (31 - __builtin_clz(cpg)) : rs_fdiv(ac_c, 1.f / (float)cpg);
             e_gr = o.gn_rstd[(size_t)ac_n * o.groups + g]; e_gm = o.gn_mean[(size_t)ac_n * o.groups + g];
             if (have_sums) { e_sy = o.sample_sums[((size_t)ac_n * 2) * C + ac_c]; e_syy = o.sample_sums[((size_t)ac_n * 2 + 1) * C + ac_c]; }
         }
