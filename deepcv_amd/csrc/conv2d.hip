@@ -32,11 +32,18 @@ static_assert(sizeof(dcv_prep_entry) == 88, "dcv_adamw_prep_table reserves 88 by
 __global__ __launch_bounds__(1024) void adamw_prep_kernel(dcv_adamw_prep_table t, const float* __restrict__ hyper) {
     const dcv_opt_item& it = t.item[blockIdx.x];
     const dcv_adamw_scalars sc = dcv_adamw_load_scalars(hyper);
+    // the first two prepared layouts' descriptors are requested with the update's operands (scalar loads: they sit in registers across the barrier) — read
+    // behind the barrier they were one more memory round trip of a kernel which is nothing but three of them
+    const dcv_prep_entry* preps = reinterpret_cast<const dcv_prep_entry*>(t.prep);
+    dcv_prep_entry e0{}, e1{};
+    if (it.prep_count > 0) e0 = preps[it.prep_first];
+    if (it.prep_count > 1) e1 = preps[it.prep_first + 1];
     for (int i = threadIdx.x; i < it.numel; i += 1024) dcv_adamw_update<false>(sc, it.param, it.grad, it.state1, it.state2, nullptr, i);
     if (it.prep_count == 0) return;                                                  // block-uniform
     __syncthreads();                                                                 // the block's stores are visible to its own gathers below
-    const dcv_prep_entry* preps = reinterpret_cast<const dcv_prep_entry*>(t.prep);
-    for (int q = 0; q < it.prep_count; ++q) {
+    for (int i = threadIdx.x; i < e0.total; i += 1024) e0.dst[i] = dcv_prep_element(e0, i);
+    if (it.prep_count > 1) for (int i = threadIdx.x; i < e1.total; i += 1024) e1.dst[i] = dcv_prep_element(e1, i);
+    for (int q = 2; q < it.prep_count; ++q) {
         const dcv_prep_entry& e = preps[it.prep_first + q];
         for (int i = threadIdx.x; i < e.total; i += 1024) e.dst[i] = dcv_prep_element(e, i);
     }
