@@ -70,6 +70,43 @@ def test_resident_forward_matches_per_layer_kernels(device, params, bs, backward
         assert torch.allclose(ba.float(), bb.float(), rtol=1e-5, atol=1e-7), name
 
 
+@pytest.mark.parametrize('bs', [7, 64])
+def test_general_paths_on_a_3x3_variant_of_the_stock_model(device, params, bs):
+    """ The stock shapes run constant-extent paths in both persistent launches (5x5 layers on 32 x 32 maps: matrix-core weight gradient, fused moments, fixed
+    tile fills and apply steps); every other shape runs the general code those paths bypass.  The same stack with 3x3 filters in its first three layers
+    is such a shape (3x3 convolution / data-gradient variants, the VALU weight gradient, general apply / dz / moments passes): resident launches against the
+    per-layer kernels, as for the stock model. """
+    import copy
+    from deepcv_amd import resident
+    from deepcv_amd.classification.image import create_model
+    from deepcv_amd.meta.data.datasets import SyntheticImageDataset
+    hp = copy.deepcopy(params['image_classifier_model'])
+    convs = [m['conv2d'] for m in hp['architecture'][0]['_nested_deepcvmodule']['architecture'] if isinstance(m, dict) and 'conv2d' in m]
+    assert len(convs) == 5
+    for c in convs[:3]:
+        assert tuple(c['kernel_size']) == (5, 5)
+        c['kernel_size'], c['padding'] = (3, 3), 1
+
+    def build():
+        torch.manual_seed(SEED)
+        return create_model({'trainset': SyntheticImageDataset(8)}, hp).to(device)
+    g = torch.Generator().manual_seed(DATA_SEED)
+    x, y = torch.randn(bs, 3, 32, 32, generator=g).to(device), torch.randint(0, 10, (bs,), generator=g).to(device)
+    a, b = build(), build()
+    la, loss_a, n_a = _run(a, x, y, True, True)
+    lb, loss_b, n_b = _run(b, x, y, False)
+    assert n_a == 1, f'the resident path did not run: {resident.why_not(a, x)}'
+    assert n_b == 0
+    assert (la - lb).abs().max().item() <= 2e-6 * max(lb.abs().max().item(), 1.0)
+    assert abs(loss_a - loss_b) <= 1e-6 * abs(loss_b)
+    gscale = max(p.grad.abs().max().item() for p in b.parameters())
+    for (name, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        err = (pa.grad - pb.grad).abs().max().item()
+        assert err <= 2e-4 * pb.grad.abs().max().item() + 2e-6 * gscale, f'{name}: {err:.3e} (max {pb.grad.abs().max().item():.3e})'
+    for (name, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
+        assert torch.allclose(ba.float(), bb.float(), rtol=1e-5, atol=1e-7), name
+
+
 def test_weight_gradients_outside_the_backward_launch(device, params):
     """ `DCV_RESIDENT_WGRAD=0`: the persistent backward launch leaves the weight gradients to the multi-layer launch, which reads its dz tensors. """
     from deepcv_amd import resident
