@@ -1420,21 +1420,51 @@ __device__ __forceinline__ void rb_wgrad_c16(const dcv_resident_bwd_op& o, const
 }
 
 // cin <= 4 -> 16, 3x3, rows of 16 pixels: unit = (filter row, sample): M = (filter column 0..3, input channel), the fourth column is not a tap (dropped)
-__device__ __forceinline__ void rb_wgrad_c4x16(const dcv_resident_bwd_op& o, const float4* xt, const float4* dzt) {
+// (six units of 64 dependent instructions kept six of the sixteen waves busy: 3.1 us.  Each unit is cut into two row ranges on two waves — twelve half
+// units, 32 instructions each; the second halves' accumulators meet the first halves' in LDS: `part`, 192 floats per unit (rows kq < 3), in the per-wave
+// moments' region and the quarter-unit scratch (free here: see rb_wgrad_c4_mfma) — even H only, else the six whole units as before)
+__device__ __forceinline__ void rb_wgrad_c4x16(const dcv_resident_bwd_op& o, const float4* xt, const float4* dzt, float* scratch, float* wave_sums, volatile unsigned* flag, unsigned flag_value) {
     const int tw = rs_tid();
     const int H = o.h, XW = 18, XH = H + 2, lane = tw & 63, wave = rs_wave_of(tw), m = lane & 15, kq = lane >> 4;
     const float* xf = reinterpret_cast<const float*>(xt); const float* df = reinterpret_cast<const float*>(dzt);
-    for (int u = wave; u < RS_SPB * 3; u += 16) {
-        const int s = u >= 3 ? 1 : 0, ky = u - s * 3;
+    const bool split = (H & 1) == 0;
+    auto unit = [&](int s, int ky, int r0, int r1, rs_f4& acc) {
         const float* xa = xf + ((size_t)s * RS_XIN + ky * XW + (m >> 2) + kq) * 4 + (m & 3);                    // lane: (column m / 4, input channel m % 4), pixel kq
         const float* db = df + ((size_t)s * RS_XIN + ((m >> 2) * XH + 1) * XW + 1 + kq) * 4 + (m & 3);
-        rs_f4 acc = {0.f, 0.f, 0.f, 0.f};
-        rb_mfma_rows(xa, db, 0, H, XW, acc);
+        acc = rs_f4{0.f, 0.f, 0.f, 0.f};
+        rb_mfma_rows(xa, db, r0, r1, XW, acc);
+    };
+    auto store = [&](int s, int ky, const rs_f4& acc) {
         const int chunk = (int)blockIdx.x * RS_SPB + s, wsize = 16 * o.cin * 9;
         if (kq < 3) {                                                                // D rows 4 kq + i = (column kq, input channel i), output channel m
 #pragma unroll
             for (int i = 0; i < 4; ++i) if (i < o.cin) o.dw_part[(size_t)chunk * wsize + ((ky * 3 + kq) * 16 + m) * o.cin + i] = acc[i];                  // [tap][co][ci]
         }
+    };
+    if (split) {
+        rs_f4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int u = wave >> 1, half = wave & 1, s = u >= 3 ? 1 : 0, ky = u - s * 3;          // waves 0 - 11: unit u = wave / 2, row range wave % 2
+        float* part = u < 5 ? wave_sums + u * 192 : scratch;
+        if (wave < 12) {
+            unit(s, ky, half * (H >> 1), (half + 1) * (H >> 1), acc);
+            if (half == 1) {
+                while (*flag != flag_value) { }
+                if (kq < 3) *reinterpret_cast<rs_f4*>(part + lane * 4) = acc;
+            }
+        }
+        rs_barrier();
+        if (wave < 12 && half == 0) {
+            if (kq < 3) { const rs_f4 other = *reinterpret_cast<const rs_f4*>(part + lane * 4); acc[0] += other[0]; acc[1] += other[1]; acc[2] += other[2]; acc[3] += other[3]; }
+            store(s, ky, acc);
+        }
+        rb_bias16(o, dzt, 12);
+        return;
+    }
+    for (int u = wave; u < RS_SPB * 3; u += 16) {
+        const int s = u >= 3 ? 1 : 0, ky = u - s * 3;
+        rs_f4 acc;
+        unit(s, ky, 0, H, acc);
+        store(s, ky, acc);
     }
     rb_bias16(o, dzt, 6);
 }
@@ -1567,7 +1597,7 @@ __device__ __forceinline__ void rb_wgrad(const dcv_resident_bwd_op& o, const flo
             else rb_wgrad_c4<5, 4, 36>(o, xt, dzt, scratch);
         } else rb_wgrad_c4<3, 4, 0>(o, xt, dzt, scratch);
     }
-    else if (var == 2) rb_wgrad_c4x16(o, xt, dzt);
+    else if (var == 2) rb_wgrad_c4x16(o, xt, dzt, scratch, wave_sums, flag, flag_value);
     else rb_wgrad_c16(o, xt, dzt);
 }
 
