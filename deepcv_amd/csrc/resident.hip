@@ -1403,20 +1403,53 @@ __device__ __forceinline__ void rb_mfma_rows(const float* xa, const float* db, i
 
 // 16 -> 16, 3x3, rows of 16 pixels: unit = (tap, sample): D[ci][co] += A[ci][4 pixels] B[4 pixels][co] over the 64 pixel quads of the sample, one
 // v_mfma_f32_16x16x4_f32 each (A: x at the tap's offset, B: dz; one ds_read_b32 per operand and lane).
-__device__ __forceinline__ void rb_wgrad_c16(const dcv_resident_bwd_op& o, const float4* xt, const float4* dzt) {
+// (eighteen units on sixteen waves: two SIMDs carried five units, two carried four.  Units 16 and 17 are cut into two row ranges each, one half unit per
+// SIMD on waves 0 - 3: 4.5 units everywhere; the second halves' accumulators meet the first halves' in LDS — `wave_sums`, 2 x 256 floats, free here: see
+// rb_wgrad_c4_mfma — even H only)
+__device__ __forceinline__ void rb_wgrad_c16(const dcv_resident_bwd_op& o, const float4* xt, const float4* dzt, float* wave_sums, volatile unsigned* flag, unsigned flag_value) {
     const int tw = rs_tid();
     const int H = o.h, XW = 18, XH = H + 2, lane = tw & 63, wave = rs_wave_of(tw), m = lane & 15, kq = lane >> 4;
     const float* xf = reinterpret_cast<const float*>(xt); const float* df = reinterpret_cast<const float*>(dzt);
-    for (int u = wave; u < RS_SPB * 9; u += 16) {
+    auto unit = [&](int u, int r0, int r1, rs_f4& acc) {
         const int s = u >= 9 ? 1 : 0, tap = u - s * 9, ky = tap / 3, kx = tap - ky * 3;
         const float* xa = xf + ((size_t)s * RS_XIN + ((m >> 2) * XH + ky) * XW + kx + kq) * 4 + (m & 3);      // lane: input channel m, pixel kq of the quad
         const float* db = df + ((size_t)s * RS_XIN + ((m >> 2) * XH + 1) * XW + 1 + kq) * 4 + (m & 3);        // lane: output channel m, pixel kq of the quad
-        rs_f4 acc = {0.f, 0.f, 0.f, 0.f};
-        rb_mfma_rows(xa, db, 0, H, XW, acc);
-        const int chunk = (int)blockIdx.x * RS_SPB + s;
-        *reinterpret_cast<float4*>(o.dw_part + (size_t)chunk * 2304 + (tap * 16 + m) * 16 + 4 * kq) = make_float4(acc[0], acc[1], acc[2], acc[3]);     // D: input channels 4 kq .. + 3, output channel m -> [tap][co][ci]: 1 KB per wave, contiguous
+        acc = rs_f4{0.f, 0.f, 0.f, 0.f};
+        rb_mfma_rows(xa, db, r0, r1, XW, acc);
+    };
+    auto store = [&](int u, const rs_f4& acc) {
+        const int s = u >= 9 ? 1 : 0, tap = u - s * 9, chunk = (int)blockIdx.x * RS_SPB + s;
+        *reinterpret_cast<float4*>(o.dw_part + (size_t)chunk * 2304 + (tap * 16 + m) * 16 + 4 * kq) = make_float4(acc[0], acc[1], acc[2], acc[3]);     // D: input channels 4 kq .. + 3, output channel m -> [tap][co][ci]: 1 KB per wave
+    };
+    const bool split = (H & 1) == 0;
+    {
+        rs_f4 acc;
+        unit(wave, 0, H, acc);
+        store(wave, acc);
     }
-    rb_bias16(o, dzt, 2);
+    if (split) {
+        rs_f4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int u2 = 16 + (wave & 1), half = (wave >> 1) & 1;
+        float* part = wave_sums + (wave & 1) * 256;
+        if (wave < 4) {
+            unit(u2, half * (H >> 1), (half + 1) * (H >> 1), acc);
+            if (half == 1) {
+                while (*flag != flag_value) { }
+                *reinterpret_cast<rs_f4*>(part + lane * 4) = acc;
+            }
+        }
+        rs_barrier();
+        if (wave < 2) {
+            const rs_f4 other = *reinterpret_cast<const rs_f4*>(part + lane * 4);
+            acc[0] += other[0]; acc[1] += other[1]; acc[2] += other[2]; acc[3] += other[3];
+            store(u2, acc);
+        }
+    } else if (wave < 2) {
+        rs_f4 acc;
+        unit(16 + wave, 0, H, acc);
+        store(16 + wave, acc);
+    }
+    rb_bias16(o, dzt, 4);
 }
 
 // cin <= 4 -> 16, 3x3, rows of 16 pixels: unit = (filter row, sample): M = (filter column 0..3, input channel), the fourth column is not a tap (dropped)
@@ -1598,7 +1631,7 @@ __device__ __forceinline__ void rb_wgrad(const dcv_resident_bwd_op& o, const flo
         } else rb_wgrad_c4<3, 4, 0>(o, xt, dzt, scratch);
     }
     else if (var == 2) rb_wgrad_c4x16(o, xt, dzt, scratch, wave_sums, flag, flag_value);
-    else rb_wgrad_c16(o, xt, dzt);
+    else rb_wgrad_c16(o, xt, dzt, wave_sums, flag, flag_value);
 }
 
 __device__ __forceinline__ float rb_act_grad(float y, int act, float slope) { return dcv_act_grad_from_out(y, act, slope); }
