@@ -1388,13 +1388,18 @@ __device__ __forceinline__ void rb_bias16(const dcv_resident_bwd_op& o, const fl
 // load, load, MFMA is a chain of LDS latencies: 44 % of the matrix pipe)
 __device__ __forceinline__ void rb_mfma_rows(const float* xa, const float* db, int r0, int r1, int XW, rs_f4& acc) {
     int r = r0;
+    rs_f4 acc2 = {0.f, 0.f, 0.f, 0.f};                                               // (two chains: an instruction does not wait for the one just issued)
     for (; r + 1 < r1; r += 2) {
         float a[8], b[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) { const int off = ((r + (k >> 2)) * XW + (k & 3) * 4) * 4; a[k] = xa[off]; b[k] = db[off]; }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k], b[k], acc, 0, 0, 0);
+        for (int k = 0; k < 8; k += 2) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k], b[k], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k + 1], b[k + 1], acc2, 0, 0, 0);
+        }
     }
+    acc[0] += acc2[0]; acc[1] += acc2[1]; acc[2] += acc2[2]; acc[3] += acc2[3];
     if (r < r1) {
 #pragma unroll
         for (int c0 = 0; c0 < 16; c0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[(r * XW + c0) * 4], db[(r * XW + c0) * 4], acc, 0, 0, 0);
