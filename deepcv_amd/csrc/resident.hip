@@ -451,11 +451,14 @@ __device__ __forceinline__ void rs_mfma_sums(float sum, float sq, float* wsum) {
 // m = lane % 16, channel k = lane / 16) reads one float of the tile; B: w[co = lane % 16][ci = lane / 16][tap] straight from the OIHW filter (zero for
 // ci >= cin).  Wave w of a sample owns the rows w, w + 8, ...: 18 MFMAs on the stock 16x16 maps.
 template <int K>
-__device__ __forceinline__ bool rs_conv_c4_mfma(const dcv_resident_op& o, const float4* xin, float* yt, float* wsum) {
+__device__ __forceinline__ bool rs_conv_c4_mfma(const dcv_resident_op& o, const float4* xin, float* yt, float* wsum, const float* frag = nullptr, const float* bias_lds = nullptr) {
     const int H = o.h, pad = K / 2, XW = 16 + 2 * pad;
     const int t = rs_tid(), lane = t & 63, wave = rs_wave_of(t), m = lane & 15, kq = lane >> 4, s = wave >> 3;
     float breg[K * K];
-    {
+    if (frag != nullptr) {                                                           // (parked in LDS two ops ago: resident_fwd_kernel's s_c4frag)
+#pragma unroll
+        for (int q = 0; q < K * K; ++q) breg[q] = frag[q * 64 + lane];
+    } else {
         const float* wp = o.filt + ((size_t)m * o.cin + (kq < o.cin ? kq : 0)) * (K * K);
 #pragma unroll
         for (int q = 0; q < K * K; ++q) breg[q] = wp[q];
@@ -464,7 +467,7 @@ __device__ __forceinline__ bool rs_conv_c4_mfma(const dcv_resident_op& o, const 
             for (int q = 0; q < K * K; ++q) breg[q] = 0.f;
         }
     }
-    const float bias = o.bias ? o.bias[m] : 0.f;
+    const float bias = bias_lds ? bias_lds[m] : (o.bias ? o.bias[m] : 0.f);          // (the prologue left every layer's bias in LDS)
     const float* xf = reinterpret_cast<const float*>(xin);
     float sum = 0.f, sq = 0.f;
     for (int r = wave & 7; r < H; r += 8) {
@@ -547,6 +550,7 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
     __shared__ __attribute__((aligned(16))) float s_T[RS_SPB][RS_MAXC];
     __shared__ __attribute__((aligned(16))) float s_par[DCV_RESIDENT_MAX_OPS][8][RS_MAXC];   // per-channel parameters of every layer: bn gamma, beta, running mean, var, gn gamma, beta, convolution bias
     __shared__ __attribute__((aligned(16))) float s_filt[RS_FILT_OPS][RS_FILT_FLOATS];  // filters of the cin <= 4 -> 4 layers as [tap][co][ci] (rs_conv_c4_co4)
+    __shared__ float s_c4frag[9 * 64];                                               // [q][lane]: rs_conv_c4_mfma's filter registers
     __shared__ float4 s_bfrag[9 * 64];                                               // MFMA B fragments of the first 16 -> 16 layer, [q][lane] (rs_load_bfrag's registers): fetched in the prologue's round trip — at the layer itself the filter has left the L2 and the fetch was 2 us
     __shared__ double s_tot[RS_MAXQ], s_red[4];                                      // batch totals of the current synchronisation
     __shared__ unsigned s_w32[2 * RS_MAXQ];
@@ -576,6 +580,10 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
     // MFMA B fragments of a 16 -> 16 layer travel two ops ahead: requested behind op oi's publish for op oi + 2 (the gather wait hides the trip), parked
     // in s_bfrag when op oi + 1 starts; bfrag_op: the op whose fragments are there
     int bfrag_op = -1, bfrag_pending = -1;
+    // ... and the same for the per-lane filter registers of a 4 -> 16 layer on the matrix cores (rs_conv_c4_mfma: K * K floats per lane, read from memory at
+    // the head of its convolution until then)
+    int c4frag_op = -1, c4frag_pending = -1;
+    float c4v = 0.f;
     float4 bfv = make_float4(0.f, 0.f, 0.f, 0.f);
     {   // ONE global round trip: every layer's per-channel parameters -> LDS (the coefficient phases never wait for memory), the two samples -> the first
         // layer's padded tile (loads issued before the tile is zeroed)
@@ -728,6 +736,7 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
     for (int oi = 0; oi < p.count; ++oi) {
         const dcv_resident_op& o = p.op[oi];
         const int t = rs_tid(), lane = t & 63, wave = rs_wave_of(t), s_of_t = __builtin_amdgcn_readfirstlane(t >> 9), tt = t & 511;     // (per op: see rs_tid)
+        if (c4frag_pending == oi + 1) { if (t < 9 * 64) s_c4frag[t] = c4v; c4frag_op = c4frag_pending; c4frag_pending = -1; }
         if (bfrag_pending == oi + 1) { if (t < 9 * 64) s_bfrag[t] = bfv; bfrag_op = bfrag_pending; bfrag_pending = -1; }     // (this op's barriers separate the stores from their readers)
         if (o.kind == DCV_RES_LAYER) {
             const int C = o.cout, CV = C >> 2, H = o.h, W = o.w, HW = H * W;
@@ -742,7 +751,7 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                     else sums_done = o.cin == 3 ? rs_conv_c4_co4_32<5, 3>(o, xin, yt, wl, bl, s_wsum) : rs_conv_c4_co4_32<5, 4>(o, xin, yt, wl, bl, s_wsum);
                 }
                 else if (var == 2) sums_done = o.k == 3 ? rs_conv_c4_wide<3>(o, xin, yt, s_wsum) : rs_conv_c4_wide<1>(o, xin, yt, s_wsum);
-                else if (var == 4) sums_done = o.k == 3 ? rs_conv_c4_mfma<3>(o, xin, yt, s_wsum) : rs_conv_c4_mfma<1>(o, xin, yt, s_wsum);
+                else if (var == 4) { const float* fr = oi == c4frag_op ? s_c4frag : nullptr; const float* bl = o.bias ? s_par[oi][6] : nullptr; sums_done = o.k == 3 ? rs_conv_c4_mfma<3>(o, xin, yt, s_wsum, fr, bl) : rs_conv_c4_mfma<1>(o, xin, yt, s_wsum, fr, bl); }
                 else { float4 b4[9]; if (oi == bfrag_op) rs_load_bfrag_lds(s_bfrag, b4); else rs_load_bfrag(o.filt, b4); sums_done = rs_conv_c16_mfma(o, xin, yt, b4, s_wsum); }
                 rs_barrier();
             }
@@ -799,6 +808,13 @@ __global__ __launch_bounds__(RS_T) void resident_fwd_kernel(dcv_resident_program
                     const int l = t & 63, q = t >> 6;
                     if (t < 9 * 64) { const rs_f4 v = *((const __attribute__((address_space(1))) rs_f4*)p.op[oi + 2].filt + 9 * (4 * (l & 15) + (l >> 4)) + q); bfv = make_float4(v[0], v[1], v[2], v[3]); }
                     bfrag_pending = oi + 2;
+                }
+                if (oi + 2 < p.count && p.op[oi + 2].kind == DCV_RES_LAYER && rs_variant(p.op[oi + 2].cin, p.op[oi + 2].cout, p.op[oi + 2].k, p.op[oi + 2].w) == 4) {
+                    const dcv_resident_op& f = p.op[oi + 2];
+                    const int l = t & 63, q = t >> 6, fm = l & 15, fkq = l >> 4, kk = f.k * f.k;
+                    c4v = 0.f;
+                    if (t < 9 * 64 && q < kk && fkq < f.cin) c4v = *((const rs_gf32*)f.filt + ((size_t)fm * f.cin + fkq) * kk + q);
+                    c4frag_pending = oi + 2;
                 }
                 if (oi == 0 && p.mailbox != nullptr) {
                     // the mailbox's other jobs (labels, optimizer scalars: a few KB) travel while the first layer's partial sums do: job j by a block which
