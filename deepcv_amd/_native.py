@@ -249,6 +249,8 @@ _SIGNATURES = {
     'dcv_allreduce_unmap': (_c_int, [_P]),
     'dcv_allreduce_oneshot': (_c_int, [_P, _c_size_t, _c_int, _c_int, ctypes.POINTER(_c_void_p), _c_size_t, _P]),
     'dcv_allreduce_status': (_c_int, [_P, _P, ctypes.POINTER(_c_int)]),
+    'dcv_allreduce_set_error_word': (_c_int, [_P, _P]),
+    'dcv_launch_counts': (_c_int, [ctypes.POINTER(ctypes.c_ulonglong), _c_int]),
     'dcv_resident_supported': (_c_int, [ctypes.POINTER(ResidentProgram)]),
     'dcv_resident_ws_bytes': (_c_size_t, []),
     'dcv_resident_forward': (_c_int, [ctypes.POINTER(ResidentProgram), _P, _c_size_t, _P]),
@@ -357,9 +359,24 @@ def is_available() -> bool:
     return LIB_PATH.exists() and torch.cuda.is_available()
 
 
+KERNEL_FAMILIES = ('bf16_igemm', 'bf16_window', 'bf16_wgrad9', 'bf16_wgrad_tap', 'f32_igemm', 'f32_halo', 'f32_window', 'f32_wgrad9', 'f32_wgrad_tap')   # DCV_FAMILY_*
+
+
+def launch_counts() -> dict:
+    """ Launches per convolution kernel family since the library was loaded (`dcv_launch_counts`): tests read it around a step to assert which family ran. """
+    buf = (ctypes.c_ulonglong * len(KERNEL_FAMILIES))()
+    n = load().dcv_launch_counts(buf, len(KERNEL_FAMILIES))
+    assert n == len(KERNEL_FAMILIES), 'deepcv_amd._native.KERNEL_FAMILIES is out of step with DCV_KERNEL_FAMILIES'
+    return dict(zip(KERNEL_FAMILIES, (int(v) for v in buf)))
+
+
+def strerror(code: int) -> str:
+    return load().dcv_strerror(code).decode()
+
+
 def check(code: int, what: str = ''):
     if code != 0:
-        msg = load().dcv_strerror(code).decode()
+        msg = strerror(code)
         raise RuntimeError(f'deepcv_amd: {what or "native call"} failed with code {code}: {msg}')
 
 

@@ -10,9 +10,19 @@
 // shows the epoch (bounded spin) and adds the world values in RANK ORDER, its own in its place: every rank computes the same bits;  (3) writes sum / world
 // over its bucket.  The epoch is a counter in the inbox header which the launch advances itself when its last block is done (a replayed launch list or
 // hipGraph needs no per-step argument); two parities because a fast rank may push step k + 1 while a slow one still reads step k (it cannot get further
-// ahead: step k + 1 completes nowhere before every rank has pushed it).  Every spin is bounded; a rank which gives up writes an error word and NaN.
+// ahead: step k + 1 completes nowhere before every rank has pushed it).
+// Memory model (round 4): a launch polls words which OTHER devices store while it runs.  HIP promises cross-agent visibility inside a running kernel only for
+// fine-grained (or uncached) allocations — coarse-grained memory (plain hipMalloc) is only coherent at kernel boundaries, and that a poll of it sees a peer's
+// store at all is hardware behaviour, not a guarantee.  The inbox is therefore allocated FINE-GRAINED (hipExtMallocWithFlags(hipDeviceMallocFinegrained);
+// DCV_ALLREDUCE_MEM=uncached / coarse select the other kinds for experiments), and all accesses to it are system-scope atomics.
+// Waiting: a rank which is late (loader stall, checkpoint, first-replay verification) must not poison anybody — DistributedDataParallel would simply wait.  The
+// wait is bounded by TIME (s_memrealtime, 100 MHz), by default 600 s (`DCV_ALLREDUCE_TIMEOUT_S`, read by dcv_allreduce_oneshot at every call); only a peer
+// which is really gone ends it.  Then the WHOLE launch fails together: the thread which gave up raises the error word in the inbox header (and, when
+// dcv_allreduce_set_error_word registered one, in a pinned host word the training loop polls without synchronising), every thread of every block which sees
+// it stops waiting, and every element written after that is NaN.
 // Roofline: latency — one xGMI store propagation (~2 us) + the kernel boundary; 136 KB per peer and step.
 #include "common.h"
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -21,17 +31,20 @@ typedef unsigned long long ar_u64;
 typedef __attribute__((address_space(1))) ar_u64 ar_gu64;
 typedef __attribute__((address_space(1))) unsigned ar_gu32;
 
-constexpr int AR_HEADER_WORDS = 64;          // [0] epoch of the last completed launch, [1] blocks done in the running launch, [2] error word (1 + rank which never arrived)
-constexpr int AR_SPINS = 1 << 22;            // polls before giving up (each a memory round trip: seconds)
+constexpr int AR_HEADER_WORDS = 64;          // [0] epoch of the last completed launch, [1] blocks done in the running launch, [2] error word (1 + rank which never arrived),
+                                             // [4..5] address of a host-visible copy of the error word (0: none)
 constexpr int AR_T = 256;
+constexpr int AR_POLLS_PER_CLOCK_CHECK = 64; // the deadline and the launch's error word are looked at every that many polls
 
 struct ar_peers { ar_u64* inbox[DCV_ALLREDUCE_MAX_RANKS]; };
 
-__global__ __launch_bounds__(AR_T) void allreduce_oneshot_kernel(float* bucket, size_t count, int rank, int world, unsigned* header, ar_peers peers, size_t max_floats, float inv_world) {
-    const unsigned epoch = __hip_atomic_load((ar_gu32*)header, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;       // (advanced below, when EVERY block of this launch is done)
+__global__ __launch_bounds__(AR_T) void allreduce_oneshot_kernel(float* bucket, size_t count, int rank, int world, unsigned* header, ar_peers peers, size_t max_floats, float inv_world,
+                                                                 unsigned long long timeout_ticks) {
+    const unsigned epoch = __hip_atomic_load((ar_gu32*)header, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1u;      // (advanced below, when EVERY block of this launch is done)
     const size_t parity = (size_t)(epoch & 1u) * (size_t)world * max_floats;
     ar_u64* mine = peers.inbox[rank];
-    bool failed = false;
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+    bool failed = __hip_atomic_load((ar_gu32*)(header + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;          // an earlier launch failed: this bucket is not to be trusted either
     for (size_t i0 = (size_t)blockIdx.x * AR_T; i0 < count; i0 += (size_t)gridDim.x * AR_T) {
         const size_t i = i0 + threadIdx.x;
         const bool live = i < count;
@@ -44,17 +57,29 @@ __global__ __launch_bounds__(AR_T) void allreduce_oneshot_kernel(float* bucket, 
         float acc = 0.f;
         for (int q = 0; q < world; ++q) {                                            // rank order: the same sum on every rank
             float vq = v;
-            if (q != rank && live && !failed) {                                      // (a thread which gave up once does not wait again: NaN for the rest of its elements)
+            if (q != rank && live && !failed) {
                 const ar_gu64* src = (const ar_gu64*)(mine + parity + (size_t)q * max_floats + i);
                 ar_u64 g = 0;
                 bool got = false;
-                for (int spins = 0; spins < AR_SPINS; ++spins) {
+                for (unsigned polls = 1; ; ++polls) {
                     g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     got = (unsigned)(g >> 32) == epoch;
                     if (got) break;
+                    if (polls % AR_POLLS_PER_CLOCK_CHECK == 0u) {
+                        // somebody else of this launch gave up already, or the peer has been silent for the whole bound
+                        if (__hip_atomic_load((ar_gu32*)(header + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) break;
+                        if (__builtin_amdgcn_s_memrealtime() - t_start > timeout_ticks) break;
+                    }
                     __builtin_amdgcn_s_sleep(2);
                 }
-                if (!got) { failed = true; __hip_atomic_store((ar_gu32*)(header + 2), (unsigned)q + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                if (!got) {
+                    failed = true;
+                    unsigned expected = 0u;
+                    if (__hip_atomic_compare_exchange_strong((ar_gu32*)(header + 2), &expected, (unsigned)q + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
+                        const unsigned long long host_word = *reinterpret_cast<const unsigned long long*>(header + 4);
+                        if (host_word) __hip_atomic_store((ar_gu32*)host_word, (unsigned)q + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
                 vq = __uint_as_float((unsigned)g);
             }
             acc += vq;
@@ -66,9 +91,24 @@ __global__ __launch_bounds__(AR_T) void allreduce_oneshot_kernel(float* bucket, 
         const unsigned done = __hip_atomic_fetch_add((ar_gu32*)(header + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (done == gridDim.x - 1) {                                                 // the last block: nobody of this launch reads the epoch any more
             __hip_atomic_store((ar_gu32*)(header + 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store((ar_gu32*)header, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store((ar_gu32*)header, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+}
+
+// kind of memory the inbox lives in (see the memory-model note at the top)
+inline int ar_mem_kind() {
+    const char* e = getenv("DCV_ALLREDUCE_MEM");
+    if (e && !strcmp(e, "coarse")) return 0;
+    if (e && !strcmp(e, "uncached")) return 2;
+    return 1;
+}
+
+inline unsigned long long ar_timeout_ticks() {
+    const char* e = getenv("DCV_ALLREDUCE_TIMEOUT_S");
+    double s = e ? atof(e) : 600.0;
+    if (!(s > 0.0)) s = 600.0;
+    return (unsigned long long)(s * 1e8);                                            // s_memrealtime counts at 100 MHz
 }
 
 }  // namespace
@@ -84,7 +124,9 @@ size_t dcv_allreduce_inbox_bytes(int world, size_t max_floats) {
 int dcv_allreduce_alloc(size_t bytes, void** inbox) {
     DCV_CHECK_ARG(inbox && bytes >= (size_t)AR_HEADER_WORDS * 4);
     void* p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) return DCV_ERR_WORKSPACE;
+    const int kind = ar_mem_kind();
+    const hipError_t rc = kind == 0 ? hipMalloc(&p, bytes) : hipExtMallocWithFlags(&p, bytes, kind == 2 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained);
+    if (rc != hipSuccess) { (void)hipGetLastError(); return DCV_ERR_WORKSPACE; }
     if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return DCV_ERR_LAUNCH; }
     *inbox = p;
     return DCV_OK;
@@ -131,8 +173,17 @@ int dcv_allreduce_oneshot(float* bucket, size_t count, int rank, int world, void
     unsigned grid = (unsigned)dcv_ceil_div(count, AR_T);
     if (grid > 128u) grid = 128u;
     hipLaunchKernelGGL(allreduce_oneshot_kernel, dim3(grid), dim3(AR_T), 0, dcv_stream(stream), bucket, count, rank, world, reinterpret_cast<unsigned*>(inboxes[rank]), peers, max_floats,
-                       1.f / (float)world);
+                       1.f / (float)world, ar_timeout_ticks());
     DCV_RETURN_LAUNCH();
+}
+
+// `host_word`: a 4-byte word of pinned (device-visible) host memory, 0 at registration, which a failing launch sets to 1 + the rank it never heard from: the
+// training loop can look at it every step without synchronising anything.  nullptr unregisters.  Synchronises (like dcv_allreduce_status): setup time only.
+int dcv_allreduce_set_error_word(void* inbox, unsigned* host_word) {
+    DCV_CHECK_ARG(inbox);
+    const unsigned long long v = (unsigned long long)host_word;
+    if (hipMemcpy(reinterpret_cast<char*>(inbox) + 16, &v, sizeof(v), hipMemcpyHostToDevice) != hipSuccess) return DCV_ERR_LAUNCH;
+    return DCV_OK;
 }
 
 int dcv_allreduce_status(const void* inbox, void* stream, int* err) {

@@ -15,6 +15,11 @@ static inline hipStream_t dcv_stream(void* s) { return reinterpret_cast<hipStrea
 static inline size_t dcv_ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
 static inline size_t dcv_align_up(size_t a, size_t b) { return dcv_ceil_div(a, b) * b; }
 
+// Host-side launch counters per convolution kernel family (dcv_launch_counts): which kernel served a layer is decided by plans inside this library, and the
+// parity tests at the bench sizes assert that the family the bench times is the one they compared (relaxed increments on the launching host thread).
+extern unsigned long long dcv_launch_counter_[DCV_KERNEL_FAMILIES];
+static inline void dcv_count_launch(int family) { __atomic_fetch_add(&dcv_launch_counter_[family], 1ull, __ATOMIC_RELAXED); }
+
 // Ordered sums of partial slabs (slab_reduce in elementwise.hip): the second stage of every weight-gradient kernel, immediate or deferred.
 int dcv_launch_slab_reduce(int n, const dcv_slab_segment* segments, hipStream_t st);
 

@@ -1204,6 +1204,7 @@ static bool win_plan(const MfmaArgs& m, int math, WinArgs* w, size_t* smem, int*
 
 template <bool BF16>
 static void launch_mfma(int bn, int bmr, dim3 grid, hipStream_t st, const MfmaArgs& a, const float* x, const float* wb, const float* bias, float* y, double* stats) {
+    dcv_count_launch(DCV_FAMILY_F32_IGEMM);
     if (bmr == 4) hipLaunchKernelGGL((conv_mfma_kernel<64, 4, BF16>), grid, dim3(256), 0, st, a, x, wb, bias, y, stats);
     else switch (bn) {
         case 64: hipLaunchKernelGGL((conv_mfma_kernel<64, 2, BF16>), grid, dim3(256), 0, st, a, x, wb, bias, y, stats); break;
@@ -1220,6 +1221,7 @@ static int run_mfma(const MfmaArgs& a0, const float* x, const float* wb, const f
     if (halo_plan(a, math, &h, &hsm)) {
         dim3 grid((unsigned)h.total_tiles, (unsigned)(a.Cout / 16));
         const int taps = a.R * a.S;
+        dcv_count_launch(DCV_FAMILY_F32_HALO);
 #define DCV_HALO(C_, T_) hipLaunchKernelGGL((conv_mfma_halo_kernel<C_, T_>), grid, dim3(256), hsm, st, h, x, wb, bias, y, stats)
         if (a.Cin == 16) { if (taps == 9) DCV_HALO(16, 9); else if (taps == 25) DCV_HALO(16, 25); else DCV_HALO(16, 1); }
         else { if (taps == 9) DCV_HALO(32, 9); else DCV_HALO(32, 1); }
@@ -1230,6 +1232,7 @@ static int run_mfma(const MfmaArgs& a0, const float* x, const float* wb, const f
     if (win_plan(a, math, &wa, &wsm, &wbs)) {
         const dim3 wgrid((unsigned)wa.tiles, (unsigned)(a.Cout / 64));
         const bool plain = a.act == DCV_ACT_NONE || a.act == DCV_ACT_RELU || a.act == DCV_ACT_LEAKY_RELU;
+        dcv_count_launch(DCV_FAMILY_F32_WINDOW);
 #define DCV_WIN(P_, B_) hipLaunchKernelGGL((conv_mfma_win_kernel<P_, B_>), wgrid, dim3(256), wsm, st, wa, x, wb, bias, y, stats)
         if (wbs == 26624) { if (plain) DCV_WIN(true, 26624); else DCV_WIN(false, 26624); }
         else { if (plain) DCV_WIN(true, 32768); else DCV_WIN(false, 32768); }
@@ -1367,6 +1370,7 @@ static int launch_wgrad9(const Wg9Args& a, dim3 grid, size_t smem, hipStream_t s
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_wgrad9_kernel<PS, BF16, PIPE, IN16>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return DCV_ERR_LAUNCH;
         configured = true;
     }
+    if (!IN16) dcv_count_launch(DCV_FAMILY_F32_WGRAD9);             // (IN16: counted by dcv_conv2d_bf16_wgrad as the fp32-staging weight gradient of bf16 tensors)
     hipLaunchKernelGGL((conv_mfma_wgrad9_kernel<PS, BF16, PIPE, IN16>), grid, dim3(256), smem, st, a, x, dy, partial);
     return DCV_OK;
 }
@@ -1432,6 +1436,7 @@ int dcv_mfma_conv2d_wgrad(const dcv_conv2d_desc* d, const float* x, const float*
     float* partial = reinterpret_cast<float*>(ws);
     dim3 grid((unsigned)chunks, (unsigned)(d->r * d->s * (d->cin / WG_T)), (unsigned)(d->cout / WG_T));
     if (grid.y > 65535 || grid.z > 65535) return DCV_ERR_UNSUPPORTED;
+    dcv_count_launch(DCV_FAMILY_F32_WGRAD_TAP);
     if (d->math == DCV_MATH_BF16) hipLaunchKernelGGL((conv_mfma_wgrad_kernel<true>), grid, dim3(256), 0, st, a, x, dy, partial);
     else hipLaunchKernelGGL((conv_mfma_wgrad_kernel<false>), grid, dim3(256), 0, st, a, x, dy, partial);
     hipLaunchKernelGGL(mfma_wgrad_reduce_kernel, dim3((unsigned)dcv_ceil_div(a.wtotal, 32)), dim3(1024), 0, st, partial, dw, chunks, a.wtotal);

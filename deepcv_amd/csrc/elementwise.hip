@@ -463,6 +463,8 @@ int dcv_launch_slab_reduce(int n, const dcv_slab_segment* segments, hipStream_t 
     DCV_RETURN_LAUNCH();
 }
 
+unsigned long long dcv_launch_counter_[DCV_KERNEL_FAMILIES] = {};
+
 extern "C" {
 
 int dcv_slab_reduce(int n, const dcv_slab_segment* segments, void* stream) {
@@ -483,6 +485,11 @@ const char* dcv_strerror(int code) {
 }
 
 int dcv_version(void) { return 100; }
+
+int dcv_launch_counts(unsigned long long* counts, int n) {
+    if (counts) for (int i = 0; i < n && i < DCV_KERNEL_FAMILIES; ++i) counts[i] = __atomic_load_n(&dcv_launch_counter_[i], __ATOMIC_RELAXED);
+    return DCV_KERNEL_FAMILIES;
+}
 
 int dcv_device_info(int device, int* cu_count, int* wave_size, char* arch, int arch_len) {
     hipDeviceProp_t prop;

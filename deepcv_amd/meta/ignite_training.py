@@ -313,11 +313,25 @@ class GraphedTrainStep:
         else:
             self._wait_published()
             vals = OrderedDict((n, float(self._pub_vals[min(i, len(self._pub_vals) - 1)])) for i, n in enumerate(self.static_losses.keys()))
+        native = getattr(self.reducer, 'native', None)
+        if native is not None:
+            native.raise_if_failed()                               # the library all-reduce's pinned error word: a peer which never pushed (no synchronisation)
         if any(v != v for v in vals.values()):
             # a persistent launch which gave up waiting for its own blocks poisons the logits: say so instead of training on NaN (deepcv_amd/resident.py)
             from .. import resident
             resident.check_status()
+            if native is not None:
+                native.check_status()
         return vals
+
+    def _broadcast_buffers(self):
+        """ DistributedDataParallel's `broadcast_buffers=True` (reference `ignite_training.py:380`) for replayed steps: `DataParallelModel.forward` is not called by a
+        replay (and is skipped under capture), so rank 0's buffers are sent here, in front of every replay. """
+        m = self.model
+        if isinstance(m, DataParallelModel) and m.broadcast_buffers and torch.distributed.is_initialized() and torch.distributed.get_world_size(m.group) > 1:
+            with torch.no_grad():
+                for b in m.module.buffers():
+                    torch.distributed.broadcast(b.data, src=0, group=m.group)
 
     def _capture(self, x, y):
         dev = x.device
@@ -536,6 +550,7 @@ class GraphedTrainStep:
                 self._wait_published()
             out = self._on_side_stream(self._eager, x, y)
         else:
+            self._broadcast_buffers()
             out = self._replay(x, y)
         self._last_eager, self._last_losses = eager, out[0]
         return out
@@ -668,9 +683,14 @@ def train(hp: HYPERPARAMS_T, model: torch.nn.Module, losses: LOSS_FN_TERMS_T = N
         if graphed_step is not None:
             return dict(graphed_step.loss_values())               # per-step host read-back like the reference (`:255`), published right after the forward pass
         vals = {n: v.item() for n, v in batch_losses.items()}   # device -> host sync every step, like the reference (`:255`)
+        native_ar = getattr(reducer, 'native', None)
+        if native_ar is not None:
+            native_ar.raise_if_failed()
         if any(v != v for v in vals.values()):
             from .. import resident
             resident.check_status()
+            if native_ar is not None:
+                native_ar.check_status()
         return vals
 
     trainer = Engine(process_function)

@@ -49,18 +49,31 @@ class NativeAllReduce:
         if self.world > nat.ALLREDUCE_MAX_RANKS:
             raise ValueError(f'deepcv_amd.NativeAllReduce: at most {nat.ALLREDUCE_MAX_RANKS} ranks')
         lib = nat.lib
+        self._own, self._mapped, self._err_word = None, [], None
+        self.inboxes = (ctypes.c_void_p * self.world)()
         with torch.cuda.device(self.device):
+            # EVERY rank walks through the same two collectives whatever fails locally — an allocation or export which fails on one rank is a verdict it
+            # brings to the exchange (an empty handle), not an exception in front of it: the others would sit in `all_gather_object` for good
+            local_error = None
             nbytes = int(lib.dcv_allreduce_inbox_bytes(self.world, self.max_floats))
             inbox = ctypes.c_void_p()
-            nat.check(lib.dcv_allreduce_alloc(nbytes, ctypes.byref(inbox)), 'dcv_allreduce_alloc')
-            self._own = inbox.value
-            self.inboxes = (ctypes.c_void_p * self.world)()
-            self.inboxes[self.rank] = self._own
-            self._mapped: List[int] = []
+            if nbytes == 0:
+                local_error = 'dcv_allreduce_inbox_bytes refused the configuration'
+            else:
+                rc = lib.dcv_allreduce_alloc(nbytes, ctypes.byref(inbox))
+                if rc != 0:
+                    local_error = f'dcv_allreduce_alloc: {nat.strerror(rc)}'
+            if local_error is None:
+                self._own = inbox.value
+                self.inboxes[self.rank] = self._own
+                # a pinned host word the failing launch raises: the training loop looks at it every step without synchronising (`poll_error`)
+                self._err_word = torch.zeros(1, dtype=torch.int32).pin_memory()
+                rc = lib.dcv_allreduce_set_error_word(self._own, self._err_word.data_ptr())
+                if rc != 0:
+                    local_error = f'dcv_allreduce_set_error_word: {nat.strerror(rc)}'
             if self.world > 1:
-                # every rank walks through the same collectives whatever fails locally (a rank which raised early would leave the others waiting)
                 handle = ctypes.create_string_buffer(nat.ALLREDUCE_HANDLE_BYTES)
-                exported = lib.dcv_allreduce_export(self._own, handle) == 0
+                exported = local_error is None and lib.dcv_allreduce_export(self._own, handle) == 0
                 handles: List[Optional[bytes]] = [None] * self.world
                 dist.all_gather_object(handles, bytes(handle.raw) if exported else b'', group=group)
                 mapped_all = all(handles)
@@ -78,28 +91,42 @@ class NativeAllReduce:
                 dist.all_gather_object(verdicts, bool(mapped_all), group=group)     # (also the barrier: every inbox is mapped everywhere before anybody pushes)
                 if not all(verdicts):
                     self.close()
-                    raise RuntimeError(f'hipIpc could not share the inboxes between the ranks (export / import refused on rank(s) {[r for r, v in enumerate(verdicts) if not v]})')
+                    raise RuntimeError(f'hipIpc could not share the inboxes between the ranks (allocation / export / import refused on rank(s) {[r for r, v in enumerate(verdicts) if not v]}'
+                                       + (f'; here: {local_error}' if local_error else '') + ')')
+            elif local_error is not None:
+                self.close()
+                raise RuntimeError(f'deepcv_amd.NativeAllReduce: {local_error}')
 
     def self_test(self) -> bool:
-        """ One all-reduce of known values (rank r contributes r + 1 + i / 8): True when THIS rank received the exact mean.  Collective; used by
-        `GradientAllReducer.enable_native`, which keeps the process group's collective unless every rank passes. """
+        """ Four all-reduces of known values which DIFFER from round to round (rank r contributes 1000 k + r + 1 + i / 8 in round k), so that each parity of the
+        inbox is used twice with different contents: a poll which returned the stale granule of the round before last (same parity) would fail here, at setup,
+        instead of in a training step.  True when THIS rank received the exact mean every time.  Collective; used by `GradientAllReducer.enable_native`, which keeps
+        the process group's collective unless every rank passes. """
         n = min(self.max_floats, 4096)
         idx = torch.arange(n, dtype=torch.float32, device=self.device) * 0.125
-        flat = idx + float(self.rank + 1)
-        want = idx.clone()
-        for _ in range(2):                                       # both parities
-            cur = flat.clone()
+        for k in range(4):
+            cur = idx + float(1000 * k + self.rank + 1)
             self.reduce(cur)
             torch.cuda.synchronize(self.device)
             acc = torch.zeros_like(idx)
             for r in range(self.world):                          # the kernel's arithmetic: sum in rank order, times 1 / world
-                acc = acc + (idx + float(r + 1))
-            want = acc * (1.0 / self.world)
-            if not torch.equal(cur, want):
+                acc = acc + (idx + float(1000 * k + r + 1))
+            if not torch.equal(cur, acc * (1.0 / self.world)):
                 return False
         err = ctypes.c_int(0)
         nat.check(nat.lib.dcv_allreduce_status(self._own, nat.current_stream(self.device), ctypes.byref(err)), 'dcv_allreduce_status')
-        return err.value == 0
+        return err.value == 0 and self.poll_error() == 0
+
+    def poll_error(self) -> int:
+        """ 0, or 1 + the rank a launch of this process never heard from — read from the pinned host word the failing launch raises: no synchronisation, cheap enough
+        for every training step. """
+        return int(self._err_word[0]) if self._err_word is not None else 0
+
+    def raise_if_failed(self):
+        err = self.poll_error()
+        if err:
+            raise RuntimeError(f'deepcv_amd.NativeAllReduce: rank {self.rank} never received the gradients of rank {err - 1} within the bound (DCV_ALLREDUCE_TIMEOUT_S); '
+                               'the gradients of that step and of every later one are NaN — the peer is gone, this run cannot continue')
 
     def reduce(self, flat: torch.Tensor):
         assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous() and flat.numel() <= self.max_floats
@@ -111,7 +138,8 @@ class NativeAllReduce:
         err = ctypes.c_int(0)
         nat.check(nat.lib.dcv_allreduce_status(self._own, nat.current_stream(self.device), ctypes.byref(err)), 'dcv_allreduce_status')
         if err.value:
-            raise RuntimeError(f'deepcv_amd.NativeAllReduce: rank {self.rank} never received the values of rank {err.value - 1} (bounded wait); the gradients of that step are NaN')
+            raise RuntimeError(f'deepcv_amd.NativeAllReduce: rank {self.rank} never received the gradients of rank {err.value - 1} within the bound (DCV_ALLREDUCE_TIMEOUT_S); '
+                               'the gradients of that step and of every later one are NaN')
 
     def close(self):
         lib = nat.lib
@@ -121,6 +149,7 @@ class NativeAllReduce:
         if self._own:
             lib.dcv_allreduce_free(self._own)
             self._own = None
+        self._err_word = None
 
 
 def broadcast_module_state(module: torch.nn.Module, src: int = 0, group=None):

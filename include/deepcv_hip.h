@@ -50,6 +50,24 @@ extern "C" {
 
 const char* dcv_strerror(int code);
 int dcv_version(void);
+
+/* Launch counters of the convolution kernel families (host-side, per process; for tests and diagnostics): which hand-written kernel a layer runs on is a
+ * plan made inside the library (shape, pixel count, alignment), so a parity test at the bench sizes reads these around its step to assert that the family
+ * the bench times is the one it compared.  counts[f] = launches of family f since the library was loaded; fills min(n, DCV_KERNEL_FAMILIES) entries and
+ * returns DCV_KERNEL_FAMILIES.  No reference counterpart (the reference dispatches through ATen). */
+enum {
+    DCV_FAMILY_BF16_IGEMM = 0,      /* conv_bf16_kernel: bf16 implicit GEMM (strided layers, small maps, 1x1) */
+    DCV_FAMILY_BF16_WINDOW = 1,     /* conv_bf16_halo_kernel: bf16 3x3 window kernel */
+    DCV_FAMILY_BF16_WGRAD9 = 2,     /* conv_bf16_wgrad9_kernel: bf16 all-taps weight gradient (and its one-tap GEMM instance) */
+    DCV_FAMILY_BF16_WGRAD_TAP = 3,  /* dcv_conv2d_bf16_wgrad's fallback: the fp32-staging weight gradient kernels reading bf16 tensors (layers wgrad9 does not plan) */
+    DCV_FAMILY_F32_IGEMM = 4,       /* conv_mfma_kernel: fp32 implicit GEMM */
+    DCV_FAMILY_F32_HALO = 5,        /* conv_mfma_halo_kernel: narrow (16 / 32 channel) fp32 layers */
+    DCV_FAMILY_F32_WINDOW = 6,      /* conv_mfma_win_kernel: fp32 3x3 window kernel */
+    DCV_FAMILY_F32_WGRAD9 = 7,      /* conv_mfma_wgrad9_kernel: fp32 all-taps weight gradient */
+    DCV_FAMILY_F32_WGRAD_TAP = 8,   /* conv_mfma_wgrad_kernel<false>: fp32 per-tap weight gradient */
+    DCV_KERNEL_FAMILIES = 9
+};
+int dcv_launch_counts(unsigned long long* counts, int n);
 /* Fills multiprocessor (CU) count, wavefront size and the gcn arch name of HIP device `device`. */
 int dcv_device_info(int device, int* cu_count, int* wave_size, char* arch, int arch_len);
 
@@ -559,13 +577,16 @@ int dcv_pack_grads(const dcv_tensor_list* tl, float* dst_flat, void* stream);
  * when the backward pass has ended (the stock classifier: 68 KB): a latency problem.  Every rank owns an INBOX (device memory, one allocation, mapped into
  * the peer processes with hipIpc); a launch pushes its values as 8-byte {epoch, value} granules into every peer's inbox over xGMI, polls its own inbox for
  * the others' and adds the `world` values in rank order (the same bits on every rank), then scales by 1 / world, in place.  The epoch lives in the inbox
- * header and advances with every launch: a replayed launch list / hipGraph re-issues the identical call.  Bounded spins: a rank which never hears from
- * another sets an error word (dcv_allreduce_status -> 1 + that rank) and writes NaN.
+ * header and advances with every launch: a replayed launch list / hipGraph re-issues the identical call.  The inbox is FINE-GRAINED device memory (a running
+ * kernel polls words which other devices store; DCV_ALLREDUCE_MEM=uncached|coarse for experiments).  A late rank is waited for, as DistributedDataParallel
+ * would: the wait is bounded by time (DCV_ALLREDUCE_TIMEOUT_S, default 600 s); when it expires the whole launch fails together — error word in the header
+ * (dcv_allreduce_status -> 1 + the silent rank) and in the pinned host word registered with dcv_allreduce_set_error_word (no synchronisation needed to look at
+ * it), NaN in the bucket, and every later launch on this inbox yields NaN too.
  *   setup (once per process group):  bytes = dcv_allreduce_inbox_bytes(world, max_floats);  dcv_allreduce_alloc(bytes, &inbox);  dcv_allreduce_export(inbox, handle);
  *          exchange the handles (any host channel, e.g. torch.distributed.all_gather_object);  dcv_allreduce_import(handle_p, &inboxes[p]) for every p != rank,
  *          inboxes[rank] = inbox;   teardown: dcv_allreduce_unmap(inboxes[p]), dcv_allreduce_free(inbox)
  *   per step:  dcv_allreduce_oneshot(bucket, count, rank, world, inboxes, max_floats, stream)   — every rank the same count, the same number of calls
- * The only entry points of this library which allocate / map device memory (hipIpc exports whole allocations) and synchronise (alloc, status).
+ * The only entry points of this library which allocate / map device memory (hipIpc exports whole allocations) and synchronise (alloc, status, set_error_word).
  * ------------------------------------------------------------------------------------------------- */
 #define DCV_ALLREDUCE_MAX_RANKS 16
 #define DCV_ALLREDUCE_HANDLE_BYTES 64
@@ -577,6 +598,7 @@ int dcv_allreduce_import(const unsigned char* handle, void** peer_inbox);
 int dcv_allreduce_unmap(void* peer_inbox);
 int dcv_allreduce_oneshot(float* bucket, size_t count, int rank, int world, void* const* inboxes, size_t max_floats, void* stream);
 int dcv_allreduce_status(const void* inbox, void* stream, int* err);
+int dcv_allreduce_set_error_word(void* inbox, unsigned* host_word);   /* host_word: 4 bytes of pinned, device-visible host memory (0 now); NULL unregisters; synchronises */
 
 /* ---------------------------------------------------------------------------------------------------
  * LDS-resident network (resident.hip): the training forward of a small-channel DeepcvModule as ONE persistent launch.

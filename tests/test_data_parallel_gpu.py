@@ -32,8 +32,9 @@ def test_rccl_path_world_size_one_matches_single_process(device):
     one_graph = _bench(['--gpus', '1', '--force-dp', '--graph-collective'], launcher)       # the RCCL collective captured inside the step's graph
     native = _bench(['--gpus', '1', '--force-dp', '--native-allreduce'], launcher)          # the library's own all-reduce: one more launch of the list
     # a short captured step replays as launch lists on both sides of the eager collective; RCCL's launch is no library call, so a graph which contains it stays a graph
-    assert graphed['config']['step_mode'].startswith('launch-list') and eager['config']['step_mode'] == 'eager'
-    assert one_graph['config']['step_mode'] == 'hipgraph-replay' and native['config']['step_mode'].startswith('launch-list')
+    want = 'launch-list' if os.environ.get('DCV_REPLAY_LIST', '1') not in ('0', 'false', 'False') else 'hipgraph-replay'      # (the suite is green in both replay modes)
+    assert graphed['config']['step_mode'].startswith(want) and eager['config']['step_mode'] == 'eager'
+    assert one_graph['config']['step_mode'] == 'hipgraph-replay' and native['config']['step_mode'].startswith(want)
     assert 'RCCL' in graphed['config']['collective'] and 'dcv_allreduce_oneshot' in native['config']['collective']
     assert graphed['config']['final_loss'] == single['config']['final_loss'] == eager['config']['final_loss'] == one_graph['config']['final_loss'] == native['config']['final_loss']
     for r in (single, graphed, eager, one_graph, native):
@@ -228,3 +229,83 @@ def test_native_allreduce_two_virtual_ranks_in_one_process(device):
         torch.cuda.synchronize()
         for k in range(2):
             lib.dcv_allreduce_free(boxes[k])
+
+
+def test_native_allreduce_waits_for_a_late_rank_and_fails_together_when_a_peer_is_gone(device, monkeypatch):
+    """ rank skew must not become NaN.  (a) rank 1 launches a third of a second after rank 0: rank 0 simply waits (the bound is minutes) and both end
+    with the exact mean.  (b) a peer which never launches: with the bound set to half a second (`DCV_ALLREDUCE_TIMEOUT_S`, read at every call) the launch gives
+    up as a whole — every element NaN (not a mix of NaN and averages), the error word in the header and in the registered pinned host word name the silent
+    rank — and every later launch on that inbox yields NaN too, so a training loop cannot continue on poisoned weights unnoticed. """
+    import ctypes
+    import time
+    import torch
+    from deepcv_amd import _native as nat
+    lib = nat.lib
+    cap, n = 1 << 15, 17010
+    nbytes = int(lib.dcv_allreduce_inbox_bytes(2, cap))
+    boxes = (ctypes.c_void_p * 2)()
+    for k in range(2):
+        p = ctypes.c_void_p()
+        nat.check(lib.dcv_allreduce_alloc(nbytes, ctypes.byref(p)), 'alloc')
+        boxes[k] = p.value
+    words = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)]
+    for k in range(2):
+        nat.check(lib.dcv_allreduce_set_error_word(boxes[k], words[k].data_ptr()), 'set_error_word')
+    streams = [torch.cuda.Stream(device=device) for _ in range(2)]
+    try:
+        g = torch.Generator().manual_seed(11)
+        a, b = torch.randn(n, generator=g).to(device), torch.randn(n, generator=g).to(device)
+        ra, rb = a.clone(), b.clone()
+        torch.cuda.synchronize()
+        nat.check(lib.dcv_allreduce_oneshot(ra.data_ptr(), n, 0, 2, boxes, cap, streams[0].cuda_stream), 'oneshot rank 0')
+        time.sleep(0.35)
+        assert not streams[0].query(), 'rank 0 must still be waiting for rank 1'
+        nat.check(lib.dcv_allreduce_oneshot(rb.data_ptr(), n, 1, 2, boxes, cap, streams[1].cuda_stream), 'oneshot rank 1')
+        torch.cuda.synchronize()
+        want = (a + b) * 0.5
+        assert torch.equal(ra, want) and torch.equal(rb, want)
+        assert int(words[0][0]) == 0 and int(words[1][0]) == 0
+        # (b) rank 1 is gone
+        monkeypatch.setenv('DCV_ALLREDUCE_TIMEOUT_S', '0.5')
+        ra = a.clone()
+        t0 = time.monotonic()
+        nat.check(lib.dcv_allreduce_oneshot(ra.data_ptr(), n, 0, 2, boxes, cap, streams[0].cuda_stream), 'oneshot rank 0 alone')
+        streams[0].synchronize()
+        assert 0.4 <= time.monotonic() - t0 <= 10.0
+        assert bool(torch.isnan(ra).all()), 'the launch fails as a whole'
+        err = ctypes.c_int(-1)
+        nat.check(lib.dcv_allreduce_status(boxes[0], nat.current_stream(device), ctypes.byref(err)), 'status')
+        assert err.value == 2 and int(words[0][0]) == 2 and int(words[1][0]) == 0
+        # sticky: the next bucket on this inbox is NaN at once, whatever the peer does
+        ra, rb = a.clone(), b.clone()
+        t0 = time.monotonic()
+        for k, buf in enumerate((ra, rb)):
+            nat.check(lib.dcv_allreduce_oneshot(buf.data_ptr(), n, k, 2, boxes, cap, streams[k].cuda_stream), 'oneshot after a failure')
+        streams[0].synchronize()
+        assert time.monotonic() - t0 < 0.4 and bool(torch.isnan(ra).all())
+        torch.cuda.synchronize()
+    finally:
+        torch.cuda.synchronize()
+        for k in range(2):
+            lib.dcv_allreduce_free(boxes[k])
+
+
+def test_native_allreduce_driver_reports_a_failed_launch_without_synchronising(device):
+    """ `NativeAllReduce` at world size 1 (no process group): the setup self-test runs four rounds with values that differ from round to round, `poll_error` reads the
+    pinned word (no device call), `raise_if_failed` turns a raised word into the RuntimeError the training loop propagates (`GraphedTrainStep.loss_values`). """
+    import torch
+    from deepcv_amd.parallel import NativeAllReduce
+    ar = NativeAllReduce(device, 4096)
+    try:
+        assert ar.self_test() and ar.poll_error() == 0
+        ar.raise_if_failed()
+        x = torch.randn(1000, device=device)
+        y = x.clone()
+        ar.reduce(y)
+        torch.cuda.synchronize()
+        assert torch.equal(x, y)
+        ar._err_word[0] = 3                     # what a launch which never heard from rank 2 leaves behind
+        with pytest.raises(RuntimeError, match='never received the gradients of rank 2'):
+            ar.raise_if_failed()
+    finally:
+        ar.close()
