@@ -860,10 +860,16 @@ int launch(const Bf16Args& a0, const u16* x, const u16* wb, const float* bias, v
     const bool small = a.Wout >= 2 && a.Hout >= 2 && (size_t)a.M * (size_t)(a.Wout > a.Hout ? a.Wout : a.Hout) < ((size_t)1 << 32);
     a.magic_w = small ? 0xFFFFFFFFu / (unsigned)a.Wout + 1u : 0u; a.magic_h = small ? 0xFFFFFFFFu / (unsigned)a.Hout + 1u : 0u;
     static bool configured[2] = {false, false};
-    const bool wide = a.Cout % 128 == 0;
+    bool wide = a.Cout % 128 == 0;
     {
         int win_rows = 0; size_t hs = 0;
-        if (halo_plan(a, wide ? 128 : 64, &win_rows, &hs)) {
+        // few pixels (the deep layers of a CIFAR-sized model at 8x8 / 4x4): 256-pixel x 128-channel tiles leave CUs without a block (512 -> 512 @4x4, N = 512: 128 blocks
+        // on 256 CUs); the 64-channel-wide instance has twice the blocks.  DCV_BF16_HALO_WIDE_MIN_BLOCKS: the 128-wide instance needs at least that many tiles.
+        static int wide_min = -1;
+        if (wide_min < 0) { const char* e = getenv("DCV_BF16_HALO_WIDE_MIN_BLOCKS"); wide_min = e ? atoi(e) : 192; }
+        const bool wide_halo = wide && (long)dcv_ceil_div((size_t)a.M, 256) * (a.Cout / 128) >= wide_min;
+        if (halo_plan(a, wide_halo ? 128 : 64, &win_rows, &hs)) {
+            wide = wide_halo;
             const Bf16Args& ah = a;                               // (Win == Wout, Hin == Hout here: the reciprocals are the window's)
             static bool hconf[2] = {false, false};
             // persistent blocks: one per CU, each walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...

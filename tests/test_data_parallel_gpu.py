@@ -201,7 +201,9 @@ def test_native_allreduce_two_virtual_ranks_in_one_process(device):
         p = ctypes.c_void_p()
         nat.check(lib.dcv_allreduce_alloc(nbytes, ctypes.byref(p)), 'alloc')
         boxes[k] = p.value
-    streams = [torch.cuda.Stream(device=device) for _ in range(2)]
+    # (two virtual ranks wait for each other INSIDE their kernels: their streams must not share a hardware queue — HIP maps streams of one priority onto a few
+    # queues round-robin, and a process which has created several streams can land two of them on one; a normal and a high-priority stream never do)
+    streams = [torch.cuda.Stream(device=device, priority=0), torch.cuda.Stream(device=device, priority=-1)]
     try:
         g = torch.Generator().manual_seed(5)
         for n in (17010, 1, 255, 257, 100_003):
@@ -251,7 +253,10 @@ def test_native_allreduce_waits_for_a_late_rank_and_fails_together_when_a_peer_i
     words = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)]
     for k in range(2):
         nat.check(lib.dcv_allreduce_set_error_word(boxes[k], words[k].data_ptr()), 'set_error_word')
-    streams = [torch.cuda.Stream(device=device) for _ in range(2)]
+    # (two virtual ranks wait for each other INSIDE their kernels: their streams must not share a hardware queue — HIP maps streams of one priority onto a few
+    # queues round-robin, and a process which has created several streams can land two of them on one; a normal and a high-priority stream never do)
+    streams = [torch.cuda.Stream(device=device, priority=0), torch.cuda.Stream(device=device, priority=-1)]
+    monkeypatch.setenv('DCV_ALLREDUCE_TIMEOUT_S', '20')           # (a failing assertion below must not leave a launch waiting for the default ten minutes)
     try:
         g = torch.Generator().manual_seed(11)
         a, b = torch.randn(n, generator=g).to(device), torch.randn(n, generator=g).to(device)
