@@ -68,7 +68,8 @@ class NormChainDesc(ctypes.Structure):
                 ('bn_gamma', _c_void_p), ('bn_beta', _c_void_p), ('running_mean', _c_void_p), ('running_var', _c_void_p), ('num_batches_tracked', _c_void_p),
                 ('momentum', _c_float), ('bn_eps', _c_float), ('bn_mean', _c_void_p), ('bn_rstd', _c_void_p),
                 ('groups', _c_int), ('gn_gamma', _c_void_p), ('gn_beta', _c_void_p), ('gn_eps', _c_float), ('gn_mean', _c_void_p), ('gn_rstd', _c_void_p),
-                ('coef', _c_void_p), ('act', _c_int), ('act_slope', _c_float), ('io_dtype', _c_int), ('d_bias', _c_void_p)]
+                ('coef', _c_void_p), ('act', _c_int), ('act_slope', _c_float), ('io_dtype', _c_int), ('d_bias', _c_void_p),
+                ('d_bias_part', _c_void_p), ('moments', _c_void_p), ('moments_rows', _c_int)]
 
 
 RESIDENT_MAX_OPS = 10
@@ -161,6 +162,7 @@ _SIGNATURES = {
     'dcv_norm_chain_supported': (_c_int, [ctypes.POINTER(NormChainDesc)]),
     'dcv_norm_chain_coef_floats': (_c_size_t, [ctypes.POINTER(NormChainDesc)]),
     'dcv_norm_chain_ws_bytes': (_c_size_t, [ctypes.POINTER(NormChainDesc)]),
+    'dcv_norm_chain_bias_rows': (_c_int, [ctypes.POINTER(NormChainDesc)]),
     'dcv_norm_chain_fwd': (_c_int, [ctypes.POINTER(NormChainDesc), _P, _P, _P, _c_int, _c_int, _P, _c_size_t, _P]),
     'dcv_norm_chain_bwd': (_c_int, [ctypes.POINTER(NormChainDesc), _P, _P, _P, _P, _P, _P, _P, _P, _c_size_t, _P]),
     'dcv_conv2d_fwd_prepared': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _P, _P, _P]),
@@ -172,6 +174,7 @@ _SIGNATURES = {
     'dcv_conv2d_bf16_fwd_stats_layout': (_c_int, [ctypes.POINTER(Conv2dDesc), ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
     'dcv_conv2d_bf16_fwd': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _c_int, _P, _P]),
     'dcv_conv2d_bf16_dgrad': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _c_int, _P]),
+    'dcv_conv2d_bf16_dgrad_moments': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _P, _P, _P, _c_int, _P]),
     'dcv_conv2d_bf16_wgrad_workspace_bytes': (_c_size_t, [ctypes.POINTER(Conv2dDesc)]),
     'dcv_conv2d_bf16_wgrad': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _c_size_t, _P]),
     'dcv_cast_f32_to_bf16': (_c_int, [_P, _P, _c_size_t, _P]),

@@ -251,9 +251,13 @@ __device__ __forceinline__ void bh_wait(int n) {
 #define BH_BST (2 * BH_WSTRIDE)                                     // the three filter stages
 // PERSIST (the 64-channel-wide instance: short K loops, where prologue and epilogue were half of a block's life — 454 -> 544 TF on 64 -> 64 @32x32; on the 128-wide
 // instance the extra state costs registers and the longer loops gain nothing: 1057 -> 973 TF on 256 -> 256 @8x8, so it keeps one tile per block)
-template <int WN, bool OUT_BF16, bool PERSIST = (WN == 1)>
+// MOM (round 4; data gradients only): the statistics rows carry, instead of the sums of the result d and d^2, the two moments which the normalisation backward of
+// the layer BELOW needs from this gradient — sum d and sum d u, u = (yprev - mean) rstd, yprev that layer's activated convolution output (same pixels and
+// channels as d) — so that layer's pass over dout and y for these sums (nc_sample_sums_kernel: 8 % of cifar100_deep's bf16 step) is not launched at all.
+template <int WN, bool OUT_BF16, bool PERSIST = (WN == 1), bool MOM = false>
 __global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, const u16* __restrict__ x, const u16* __restrict__ wb, const float* __restrict__ bias,
-                                                                 void* __restrict__ yv, double* __restrict__ stats, int win_rows) {
+                                                                 void* __restrict__ yv, double* __restrict__ stats, int win_rows,
+                                                                 const u16* __restrict__ yprev = nullptr, const float* __restrict__ mom_mean = nullptr, const float* __restrict__ mom_rstd = nullptr) {
     constexpr int WM = 8 / WN, BMH = 256, TI = BMH / (16 * WM), BN = 64 * WN, PB = BN / 64;       // PB: 16-B pieces of the filter tile per thread and stage
     constexpr int B_BYTES = BN * 128;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
@@ -340,8 +344,23 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, cons
     const int cbase = n0 + 64 * wn + 4 * li;
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (bias) { const float4 b4 = *reinterpret_cast<const float4*>(bias + cbase); bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w; }
+    float mmu[4] = {0.f, 0.f, 0.f, 0.f}, mrs[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (MOM) {
+        const float4 m4 = *reinterpret_cast<const float4*>(mom_mean + cbase), r4 = *reinterpret_cast<const float4*>(mom_rstd + cbase);
+        mmu[0] = m4.x; mmu[1] = m4.y; mmu[2] = m4.z; mmu[3] = m4.w; mrs[0] = r4.x; mrs[1] = r4.y; mrs[2] = r4.z; mrs[3] = r4.w;
+    }
     auto finish_tile = [&](int dead) __attribute__((always_inline)) {
         float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+        uint2 yq[MOM ? TI : 1][4];                                  // MOM: the tile's yprev values, all requested before the first use
+        if constexpr (MOM) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int m = m0 + 16 * TI * wm + 16 * i + 4 * lg + reg;
+                    yq[i][reg] = *reinterpret_cast<const uint2*>(yprev + (size_t)(m < (int)a.M ? m : 0) * a.Cout + cbase);
+                }
+        }
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -349,10 +368,16 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, cons
                 const int m = m0 + 16 * TI * wm + 16 * i + 4 * lg + reg;
                 if (m < (int)a.M) {
                     float o[4];
+                    float uu[4] = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (MOM) {
+                        const uint2 q = yq[i][reg];
+                        uu[0] = (__uint_as_float(q.x << 16) - mmu[0]) * mrs[0]; uu[1] = (__uint_as_float(q.x & 0xffff0000u) - mmu[1]) * mrs[1];
+                        uu[2] = (__uint_as_float(q.y << 16) - mmu[2]) * mrs[2]; uu[3] = (__uint_as_float(q.y & 0xffff0000u) - mmu[3]) * mrs[3];
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         o[j] = dcv_act_apply(acc[i][j][reg] + bv[j], a.act, a.slope);
-                        ssum[j] += o[j]; ssq[j] += o[j] * o[j];
+                        ssum[j] += o[j]; ssq[j] += MOM ? o[j] * uu[j] : o[j] * o[j];
                     }
                     if constexpr (OUT_BF16) {
                         const bf16x4 h = (bf16x4){(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
@@ -488,6 +513,7 @@ struct W16Args {
     size_t wtotal;
     int stages;                     // LDS stages of a wave group: 3 (tiles requested two steps ahead) where two blocks per CU can afford them, else 2
     unsigned magic_w;               // n / W = mulhi(n, magic_w)
+    int ips;                        // images per step: 2 for maps of at most 16 pixels (round 4, below), else 1
 };
 #define W16_PS 32
 #define W16_LD 160                  // LDS row stride in bytes
@@ -519,11 +545,17 @@ __device__ __forceinline__ s16x4 tr_read(const char* p) { return __builtin_amdgc
 // 6 rows of 10 pieces (8 of data, 2 of pad fetched out of range) + the first 4 pieces of a seventh row (which the next instruction writes again); the buffer
 // resources are the step's IMAGE, so window rows outside it and the padding pixels behind it read zeros.  Every wave issues the same number K of instructions per step
 // (the ones beyond the stage's 6 + nix go, all lanes out of range, to a scratch KB), so that `s_waitcnt vmcnt(K)` means "everything but the youngest step".
+// Round 4, maps of at most 16 pixels (the 4 x 4 layers of a CIFAR-sized spec at its deepest stage): a step of 32 pixels of ONE image was half padding — half of the
+// MFMAs of three of cifar100_deep's ten layers multiplied zeros.  There a step takes TWO images (`ips` = 2): pixels 0 .. 15 of the K axis are image 2 l_n, pixels
+// 16 .. 31 image 2 l_n + 1 (a fragment's second K half), each with its own buffer resources, dz rows and x window; the stage is [19 rows of dz of the first image
+// (16 + the instruction granularity and its overhang)][19 of the second][window of the first: 6 nix + 1 rows][window of the second], so the second K half of
+// a fragment sits `dzh` / `xh` rows behind the first instead of 16.
 template <int GROUPS, int TAPS = 9>
 __global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9_kernel(W16Args a, const u16* __restrict__ x, const u16* __restrict__ dy, float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem16[];
-    const int XR = a.XR, nix = (XR + 5) / 6, nst = a.stages;
-    const int STAGE_BYTES = (37 + 6 * nix + 1) * W16_LD;
+    const int XR = a.XR, nix = (XR + 5) / 6, nst = a.stages, ips = a.ips;
+    const int dz_rows = ips == 2 ? 38 : 37, dzh = ips == 2 ? 19 : 16, xh = ips == 2 ? 6 * nix + 1 : 16;
+    const int STAGE_BYTES = (dz_rows + ips * (6 * nix + 1)) * W16_LD;
     const int GROUP_BYTES = nst * STAGE_BYTES + nst * 16 * 2 * (int)sizeof(unsigned) + 1024;
     const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), t = threadIdx.x & 255, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     char* St = smem16 + grp * GROUP_BYTES;                       // [nst] stages: dz tile [36 rows][co], x window [6 nix + 1 rows][ci]
@@ -544,17 +576,33 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9_kernel(W16Ar
     const int lrow = (lane * 13) >> 7, lslot = lane - 10 * lrow;                 // lane / 10, lane % 10
     const unsigned vbg = lslot < 8 ? (unsigned)((lrow * a.Cout + co0 + 8 * lslot) * 2) : BF_OOB;
     const unsigned vbx = lslot < 8 ? (unsigned)(((lrow - (TAPS == 9 ? a.W + 1 : 0)) * a.Cin + ci0 + 8 * lslot) * 2) : BF_OOB;      // (mod 2^32: rows above the image wrap out of range)
-    const int ktot = (6 + nix + 3) >> 2;                          // instructions per wave and step
+    const int ktot = (6 + ips * nix + 3) >> 2;                    // instructions per wave and step
     auto dma_step = [&](int stg) {
-        const unsigned long long ga = (unsigned long long)(dy + (size_t)l_n * HW * a.Cout), xa = (unsigned long long)(x + (size_t)l_n * HW * a.Cin);
+        const int img = l_n * ips;
+        const unsigned long long ga = (unsigned long long)(dy + (size_t)img * HW * a.Cout), xa = (unsigned long long)(x + (size_t)img * HW * a.Cin);
         const bw_i32x4 rg = {(int)(unsigned)ga, (int)(unsigned)((ga >> 32) & 0xFFFFu), HW * a.Cout * 2, 0x00020000};
         const bw_i32x4 rxi = {(int)(unsigned)xa, (int)(unsigned)((xa >> 32) & 0xFFFFu), HW * a.Cin * 2, 0x00020000};
         const unsigned sb = (unsigned)(size_t)St + (unsigned)(stg * STAGE_BYTES);
         if (TAPS == 9 && t < 16) {
-            const unsigned pw = (unsigned)(l_p0 + 2 * t), w0 = pw - __umulhi(pw, a.magic_w) * (unsigned)a.W, w1 = (w0 + 1 == (unsigned)a.W) ? 0u : w0 + 1;
+            const unsigned pw = ips == 2 ? (unsigned)(2 * (t & 7)) : (unsigned)(l_p0 + 2 * t), w0 = pw - __umulhi(pw, a.magic_w) * (unsigned)a.W, w1 = (w0 + 1 == (unsigned)a.W) ? 0u : w0 + 1;
             Cm[(stg * 16 + t) * 2 + 0] = (w0 > 0 ? 0x0000ffffu : 0u) | (w1 > 0 ? 0xffff0000u : 0u);
             Cm[(stg * 16 + t) * 2 + 1] = (w0 + 1 < (unsigned)a.W ? 0x0000ffffu : 0u) | (w1 + 1 < (unsigned)a.W ? 0xffff0000u : 0u);
         }
+        if (ips == 2) {
+            // the pair's second image: its own resources (an odd batch's last pair: zero records, every load delivers zeros)
+            const bool has2 = img + 1 < a.N;
+            const unsigned long long ga2 = ga + (unsigned long long)HW * a.Cout * 2, xa2 = xa + (unsigned long long)HW * a.Cin * 2;
+            const bw_i32x4 rg2 = {(int)(unsigned)ga2, (int)(unsigned)((ga2 >> 32) & 0xFFFFu), has2 ? HW * a.Cout * 2 : 0, 0x00020000};
+            const bw_i32x4 rx2 = {(int)(unsigned)xa2, (int)(unsigned)((xa2 >> 32) & 0xFFFFu), has2 ? HW * a.Cin * 2 : 0, 0x00020000};
+            for (int k = 0; k < ktot; ++k) {
+                const int idx = 4 * k + wave;                     // (uniform)
+                if (idx < 3) bw_dma16(rg, sb + (unsigned)(idx * 960), vbg + (unsigned)(6 * idx * a.Cout * 2), 0u);
+                else if (idx < 6) bw_dma16(rg2, sb + (unsigned)(19 * W16_LD + (idx - 3) * 960), vbg + (unsigned)(6 * (idx - 3) * a.Cout * 2), 0u);
+                else if (idx < 6 + nix) bw_dma16(rxi, sb + (unsigned)(38 * W16_LD + (idx - 6) * 960), vbx + (unsigned)(6 * (idx - 6) * a.Cin * 2), 0u);
+                else if (idx < 6 + 2 * nix) bw_dma16(rx2, sb + (unsigned)((38 + 6 * nix + 1) * W16_LD + (idx - 6 - nix) * 960), vbx + (unsigned)(6 * (idx - 6 - nix) * a.Cin * 2), 0u);
+                else bw_dma16(rxi, scratch, BF_OOB, 0u);
+            }
+        } else
         for (int k = 0; k < ktot; ++k) {
             const int idx = 4 * k + wave;                         // (uniform)
             if (idx < 6) bw_dma16(rg, sb + (unsigned)(idx * 960), vbg + (unsigned)((l_p0 + 6 * idx) * a.Cout * 2), 0u);
@@ -586,14 +634,14 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9_kernel(W16Ar
         if (it + nst - 1 < steps_g) dma_step((it + nst - 1) % nst);
         if (active) {
             const char* gs = St + stg * STAGE_BYTES;
-            const char* xs = gs + 37 * W16_LD;
+            const char* xs = gs + dz_rows * W16_LD;
             // masks of this lane's eight pixels (pairs 2g, 2g+1 and 8+2g, 8+2g+1): {left01, right01, left23, right23}
             const uint4 mk0 = *reinterpret_cast<const uint4*>(Cm + (stg * 16 + 2 * lg) * 2);
             const uint4 mk1 = *reinterpret_cast<const uint4*>(Cm + (stg * 16 + 8 + 2 * lg) * 2);
             union Frag { bf16x8 v; s16x4 h[2]; unsigned u[4]; };
             Frag af[4];
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt) { af[tt].h[0] = tr_read(gs + a_off + tt * 32); af[tt].h[1] = tr_read(gs + a_off + tt * 32 + 16 * W16_LD); }
+            for (int tt = 0; tt < 4; ++tt) { af[tt].h[0] = tr_read(gs + a_off + tt * 32); af[tt].h[1] = tr_read(gs + a_off + tt * 32 + dzh * W16_LD); }
             if constexpr (TAPS == 1) {
                 Frag bfr;
                 bfr.h[0] = tr_read(xs + b_off); bfr.h[1] = tr_read(xs + b_off + 16 * W16_LD);
@@ -615,7 +663,7 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9_kernel(W16Ar
                 for (int r = 0; r < 3; ++r) {
                     Frag bfr;
                     const char* bp = xs + b_off + (r * a.W + sx) * W16_LD;
-                    bfr.h[0] = tr_read(bp); bfr.h[1] = tr_read(bp + 16 * W16_LD);
+                    bfr.h[0] = tr_read(bp); bfr.h[1] = tr_read(bp + xh * W16_LD);
 #pragma unroll
                     for (int tt = 0; tt < 4; ++tt) acc[(r * 3 + sx) % TAPS][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[tt].v, bfr.v, acc[(r * 3 + sx) % TAPS][tt], 0, 0, 0);
                 }
@@ -671,13 +719,17 @@ inline bool w16_plan(const dcv_conv2d_desc* d, W16Args* a, int* chunks, size_t* 
     if (d->stride_h != 1 || d->stride_w != 1 || d->dil_h != 1 || d->dil_w != 1) return false;
     if (!one && (d->r != 3 || d->s != 3 || d->pad_h != 1 || d->pad_w != 1)) return false;
     if (d->cin % 64 != 0 || d->cout % 64 != 0 || d->ho != d->h || d->wo != d->w) return false;
-    const int hw = d->h * d->w, XR = one ? W16_PS : W16_PS + 2 * d->w + 2;
+    static int ips_on = -1;
+    if (ips_on < 0) { const char* e = getenv("DCV_BF16_WGRAD9_PAIRS"); ips_on = e ? atoi(e) : 1; }
+    const int hw = d->h * d->w;
+    const int ips = (!one && ips_on && hw <= 16) ? 2 : 1;                              // maps of at most 16 pixels: two images per step (the kernel's header)
+    const int XR = one ? W16_PS : (ips == 2 ? 16 : W16_PS) + 2 * d->w + 2;             // rows of ONE window
     if (d->w < 2 || (size_t)hw * d->cin * 2 >= ((size_t)1 << 31) || (size_t)hw * d->cout * 2 >= ((size_t)1 << 31)) return false;      // (32-bit buffer offsets inside an image)
-    const int hwp = (hw + W16_PS - 1) / W16_PS * W16_PS;
-    if (hwp > 2 * hw) return false;                                                    // more than half of the steps' pixels would be padding (4x4 images: exactly half, still 2x the 16-pixel-step kernel)
+    const int hwp = ips == 2 ? W16_PS : (hw + W16_PS - 1) / W16_PS * W16_PS;           // K-axis pixels per image (per PAIR of images with ips == 2)
+    if (hwp > 2 * hw * ips) return false;                                              // more than half of the steps' pixels would be padding
     const int nix = (XR + 5) / 6;
-    if (6 + nix > 48) return false;                                                    // (at most 12 instructions per wave and step: w16_wait)
-    const size_t stage_bytes = (size_t)(37 + 6 * nix + 1) * W16_LD;
+    if (6 + ips * nix > 48) return false;                                              // (at most 12 instructions per wave and step: w16_wait)
+    const size_t stage_bytes = (size_t)((ips == 2 ? 38 : 37) + ips * (6 * nix + 1)) * W16_LD;
     auto group_bytes_of = [&](int nst) { return (size_t)nst * stage_bytes + (size_t)nst * 16 * 2 * sizeof(unsigned) + 1024; };
     int gr = w16_groups(one ? 1000 : (d->cin / 64) * (d->cout / 64));      // (the one-tap GEMM of a first layer has few, long chunks: 134 us with one group, 211 with two on the ResNet stem)
     int nst = group_bytes_of(3) * gr <= (size_t)80 * 1024 ? 3 : 2;
@@ -687,8 +739,8 @@ inline bool w16_plan(const dcv_conv2d_desc* d, W16Args* a, int* chunks, size_t* 
     *smem = gr == 2 ? (2 * group_bytes > (size_t)36 * 256 * 16 ? 2 * group_bytes : (size_t)36 * 256 * 16) : group_bytes;
     *groups = gr;
     a->stages = nst; a->magic_w = 0xFFFFFFFFu / (unsigned)d->w + 1u;
-    a->N = d->n; a->H = d->h; a->W = d->w; a->Cin = d->cin; a->Cout = d->cout; a->XR = XR; a->HWp = hwp;
-    a->M = (long)d->n * hwp;
+    a->N = d->n; a->H = d->h; a->W = d->w; a->Cin = d->cin; a->Cout = d->cout; a->XR = XR; a->HWp = hwp; a->ips = ips;
+    a->M = (long)((d->n + ips - 1) / ips) * hwp;
     a->wtotal = (size_t)d->cout * d->cin * (one ? 1 : 9);
     const long blocks_per_chunk = (long)(d->cin / 64) * (d->cout / 64);
     const long resident = gr == 2 ? DCV_NUM_CU : 2 * DCV_NUM_CU;                       // blocks resident at once (two waves per SIMD either way): one round
@@ -754,6 +806,42 @@ __global__ __launch_bounds__(256) void prep_bf16_kernel(Bf16PrepList l) {
         else v = e.w[(((size_t)ci * e.w_cin + co) * e.Rw + (e.r0 + e.rstep * (e.R - 1 - r))) * e.Sw + (e.s0 + e.sstep * (e.S - 1 - s))];
         e.dst[i] = f32_to_bf16_bits(v);
     }
+}
+
+// Round 4: the forward AND the data-gradient layout of a whole filter from ONE coalesced read of the master weights, tiled through LDS.  prep_bf16_kernel above
+// gathers: a thread reads its 4 x R S taps as 36 four-byte loads 144 B apart from its neighbour's (64 cache lines per load instruction; the data-gradient layout
+// reads rows Cin R S floats apart) — 43 us per call, 140 us per step of cifar100_deep at bs 512 (6 % of it, profiles/r04) for 110 MB of traffic.  Here a block owns
+// a tile of 32 output x 32 input channels: the 32 runs of 32 R S consecutive floats go to LDS with coalesced loads, then every (tap, output channel) row of the
+// forward layout [tap][co][ci] and every (tap, input channel) row of the data-gradient layout [R S - 1 - tap][ci][co] leaves as 64 contiguous bytes (8-byte stores).
+struct Bf16Tile { const float* w; u16* dst_f; u16* dst_d; int Cout, Cin, taps, tiles_ci, first; };      // first: index of the entry's first tile in the launch
+#define BF_TILE_MAX 32
+struct Bf16TileList { int count, total; Bf16Tile e[BF_TILE_MAX]; };
+#define BF_TILE_LD (32 * 9 + 1)
+__global__ __launch_bounds__(256) void prep_bf16_tile_kernel(Bf16TileList l) {
+    __shared__ float tile[32 * BF_TILE_LD];
+    int ei = 0;
+    while (ei + 1 < l.count && (int)blockIdx.x >= l.e[ei + 1].first) ++ei;                 // (uniform: scalar loop)
+    const Bf16Tile& e = l.e[ei];
+    const int tl = (int)blockIdx.x - e.first, tco = tl / e.tiles_ci, tci = tl - tco * e.tiles_ci;
+    const int co0 = tco * 32, ci0 = tci * 32, taps = e.taps, run = 32 * taps, t = threadIdx.x;
+    for (int i = t; i < 32 * run; i += 256) {
+        const int r = i / run, c = i - r * run;
+        tile[r * BF_TILE_LD + c] = e.w[((size_t)(co0 + r) * e.Cin + ci0) * taps + c];
+    }
+    __syncthreads();
+    if (e.dst_f != nullptr)
+        for (int i = t; i < taps * 32 * 8; i += 256) {                                      // (tap, co row, group of four ci)
+            const int g = i & 7, r = (i >> 3) & 31, tp = i >> 8;
+            const float* s0 = tile + r * BF_TILE_LD + (4 * g) * taps + tp;
+            *reinterpret_cast<bf16x4*>(e.dst_f + ((size_t)tp * e.Cout + co0 + r) * e.Cin + ci0 + 4 * g) = (bf16x4){(__bf16)s0[0], (__bf16)s0[taps], (__bf16)s0[2 * taps], (__bf16)s0[3 * taps]};
+        }
+    if (e.dst_d != nullptr)
+        for (int i = t; i < taps * 32 * 8; i += 256) {                                      // (tap, ci row, group of four co)
+            const int g = i & 7, c = (i >> 3) & 31, tp = i >> 8;
+            const float* s0 = tile + (4 * g) * BF_TILE_LD + c * taps + tp;
+            *reinterpret_cast<bf16x4*>(e.dst_d + ((size_t)(taps - 1 - tp) * e.Cin + ci0 + c) * e.Cout + co0 + 4 * g) =
+                (bf16x4){(__bf16)s0[0], (__bf16)s0[BF_TILE_LD], (__bf16)s0[2 * BF_TILE_LD], (__bf16)s0[3 * BF_TILE_LD]};
+        }
 }
 
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float4* __restrict__ x, bf16x4* __restrict__ y, size_t n4, const float* __restrict__ xt, u16* __restrict__ yt, int tail) {
@@ -853,8 +941,9 @@ inline bool halo_plan(const Bf16Args& a, int bn, int* win_rows, size_t* smem) {
     return true;
 }
 
+struct MomArgs { const u16* yprev; const float* mean; const float* rstd; };
 template <bool OUT_BF16>
-int launch(const Bf16Args& a0, const u16* x, const u16* wb, const float* bias, void* y, double* stats, hipStream_t st) {
+int launch(const Bf16Args& a0, const u16* x, const u16* wb, const float* bias, void* y, double* stats, hipStream_t st, const MomArgs* mom = nullptr) {
     Bf16Args a = a0;
     // n / d = mulhi(n, floor((2^32 - 1) / d) + 1) is exact while n d < 2^32 (0: the kernels divide in 64 bits)
     const bool small = a.Wout >= 2 && a.Hout >= 2 && (size_t)a.M * (size_t)(a.Wout > a.Hout ? a.Wout : a.Hout) < ((size_t)1 << 32);
@@ -877,6 +966,20 @@ int launch(const Bf16Args& a0, const u16* x, const u16* wb, const float* bias, v
             unsigned hgx = wide ? htiles : DCV_NUM_CU / hgy; if (hgx < 1) hgx = 1; if (hgx > htiles) hgx = htiles;      // (the 128-wide instance: one tile per block)
             dim3 hgrid(hgx, hgy);
             if (hgrid.y > 65535) return DCV_ERR_UNSUPPORTED;
+            if constexpr (OUT_BF16) {
+                if (mom != nullptr) {
+                    static bool mconf[2] = {false, false};
+                    dcv_count_launch(DCV_FAMILY_BF16_WINDOW);
+                    if (wide) {
+                        if (!mconf[0]) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_halo_kernel<2, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DCV_ERR_LAUNCH; mconf[0] = true; }
+                        hipLaunchKernelGGL((conv_bf16_halo_kernel<2, true, false, true>), hgrid, dim3(512), hs, st, ah, x, wb, bias, y, stats, win_rows, mom->yprev, mom->mean, mom->rstd);
+                    } else {
+                        if (!mconf[1]) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_halo_kernel<1, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DCV_ERR_LAUNCH; mconf[1] = true; }
+                        hipLaunchKernelGGL((conv_bf16_halo_kernel<1, true, true, true>), hgrid, dim3(512), hs, st, ah, x, wb, bias, y, stats, win_rows, mom->yprev, mom->mean, mom->rstd);
+                    }
+                    return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
+                }
+            }
             if (wide) {
                 if (!hconf[0]) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_halo_kernel<2, OUT_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DCV_ERR_LAUNCH; hconf[0] = true; }
                 dcv_count_launch(DCV_FAMILY_BF16_WINDOW);
@@ -889,6 +992,7 @@ int launch(const Bf16Args& a0, const u16* x, const u16* wb, const float* bias, v
             return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
         }
     }
+    if (mom != nullptr) return DCV_ERR_UNSUPPORTED;                  // (only the window kernel has the moments epilogue)
     const size_t smem = wide ? (size_t)2 * (BF_BM + 128) * 128 : (size_t)2 * (BF_BM + 64) * 128;
     dim3 grid((unsigned)dcv_ceil_div((size_t)a.M, BF_BM), (unsigned)(a.Cout / (wide ? 128 : 64)));
     if (grid.y > 65535) return DCV_ERR_UNSUPPORTED;
@@ -1033,9 +1137,35 @@ int dcv_conv2d_bf16_prepare_filters(int count, const dcv_conv2d_desc* const* des
         hipLaunchKernelGGL(prep_bf16_kernel, dim3((unsigned)gx, (unsigned)l.count), dim3(256), 0, dcv_stream(stream), l);
         l.count = 0; max_total = 0;
     };
+    // whole filters of at most nine taps with 32-aligned channel counts: the tiled kernel, the two layouts of one weight from one read (DCV_BF16_PREP_TILED=0: off)
+    static int tiled = -1;
+    if (tiled < 0) { const char* e = getenv("DCV_BF16_PREP_TILED"); tiled = e ? atoi(e) : 1; }
+    Bf16TileList tlist{};
+    auto flush_tiles = [&]() {
+        if (tlist.count == 0) return;
+        hipLaunchKernelGGL(prep_bf16_tile_kernel, dim3((unsigned)tlist.total), dim3(256), 0, dcv_stream(stream), tlist);
+        tlist.count = 0; tlist.total = 0;
+    };
     for (int k = 0; k < count; ++k) {
         DCV_CHECK_ARG((ops[k] == 0 || ops[k] == 1) && w[k] && filters[k]);
         if (!supported(descs[k], ops[k])) return DCV_ERR_UNSUPPORTED;
+        const dcv_conv2d_desc* dk = descs[k];
+        if (tiled && dk->r * dk->s <= 9 && dk->cin % 32 == 0 && dk->cout % 32 == 0 && (ops[k] == 0 || (dk->stride_h == 1 && dk->stride_w == 1)) &&
+            (reinterpret_cast<uintptr_t>(filters[k]) & 7) == 0) {
+            int slot = -1;
+            for (int q = 0; q < tlist.count; ++q)
+                if (tlist.e[q].w == w[k] && tlist.e[q].Cout == dk->cout && tlist.e[q].Cin == dk->cin && tlist.e[q].taps == dk->r * dk->s &&
+                    (ops[k] == 0 ? tlist.e[q].dst_f == nullptr : tlist.e[q].dst_d == nullptr)) { slot = q; break; }
+            if (slot < 0) {
+                if (tlist.count == BF_TILE_MAX) flush_tiles();
+                slot = tlist.count++;
+                Bf16Tile& e = tlist.e[slot];
+                e = Bf16Tile{w[k], nullptr, nullptr, dk->cout, dk->cin, dk->r * dk->s, dk->cin / 32, tlist.total};
+                tlist.total += (dk->cout / 32) * (dk->cin / 32);
+            }
+            if (ops[k] == 0) tlist.e[slot].dst_f = reinterpret_cast<u16*>(filters[k]); else tlist.e[slot].dst_d = reinterpret_cast<u16*>(filters[k]);
+            continue;
+        }
         Bf16Prep pieces[DCV_PREP_PIECES]; int offs[DCV_PREP_PIECES];
         const int np = prep_pieces(descs[k], ops[k], pieces, offs);
         for (int q = 0; q < np; ++q) {
@@ -1048,6 +1178,7 @@ int dcv_conv2d_bf16_prepare_filters(int count, const dcv_conv2d_desc* const* des
         }
     }
     flush();
+    flush_tiles();
     DCV_RETURN_LAUNCH();
 }
 
@@ -1110,6 +1241,25 @@ int dcv_conv2d_bf16_dgrad(const dcv_conv2d_desc* d, const void* dy, const void* 
             if (rc != DCV_OK) return rc;
         }
     return DCV_OK;
+}
+
+// dcv_conv2d_bf16_dgrad (stride 1) whose statistics epilogue leaves the moments of dx the BatchNorm-only layer below needs (the kernel's header); rows of 128 pixels
+int dcv_conv2d_bf16_dgrad_moments(const dcv_conv2d_desc* d, const void* dy, const void* filter, void* dx, const void* y_prev, const float* mean, const float* rstd,
+                                  double* moments, int moments_rows, void* stream) {
+    DCV_CHECK_ARG(desc_ok(d) && dy && filter && dx && y_prev && mean && rstd && moments);
+    if (!supported(d, 1) || d->stride_h != 1 || d->stride_w != 1) return DCV_ERR_UNSUPPORTED;
+    DCV_CHECK_ARG(aligned16(dy) && aligned16(filter) && aligned16(dx) && aligned16(y_prev) && aligned16(mean) && aligned16(rstd));
+    const long M = (long)d->n * d->h * d->w;
+    if (moments_rows != (int)dcv_ceil_div((size_t)M, 128)) return DCV_ERR_INVALID_ARG;
+    Bf16Args a{};
+    a.N = d->n; a.Hin = d->ho; a.Win = d->wo; a.Cin = d->cout; a.Cout = d->cin;
+    a.sh = 1; a.sw = 1; a.dh = d->dil_h; a.dw = d->dil_w; a.act = DCV_ACT_NONE; a.slope = 0.f;
+    a.x_bytes = (unsigned)((size_t)d->n * d->ho * d->wo * d->cout * 2);
+    a.Hout = d->h; a.Wout = d->w; a.R = d->r; a.S = d->s;
+    a.ph = d->dil_h * (d->r - 1) - d->pad_h; a.pw = d->dil_w * (d->s - 1) - d->pad_w; a.M = M;
+    a.w_bytes = (unsigned)((size_t)d->cout * d->cin * d->r * d->s * 2);
+    const MomArgs mom{reinterpret_cast<const u16*>(y_prev), mean, rstd};
+    return launch<true>(a, reinterpret_cast<const u16*>(dy), reinterpret_cast<const u16*>(filter), nullptr, dx, moments, dcv_stream(stream), &mom);
 }
 
 // im2col of a small-cin first layer: out[m][k] (bf16, row stride kpad) = x[n][ci][ho sh - ph + r dh][wo sw - pw + s dw] for k = (ci R + r) S + s (the OIHW

@@ -25,7 +25,8 @@ namespace {
 #define NC_THREADS 256
 
 // pooled tensors: pixel (h, w) of the full-size map belongs to window (h / pk, w / pk); pk == 0: no pooling
-struct NcPool { int W, Wo, pk; float inv; };
+struct NcPool { int W, Wo, pk; float inv; int sh; };      // sh: log2(pk) when pk is a power of two (the window index by a shift), else -1
+__device__ __forceinline__ int nc_pdiv(int v, const NcPool& pm) { return pm.sh >= 0 ? v >> pm.sh : v / pm.pk; }
 
 template <int VEC> struct NcVec { float v[VEC]; };
 template <int VEC> __device__ __forceinline__ NcVec<VEC> nc_load(const float* p) {
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(NC_THREADS) void nc_sample_sums_kernel(const AT* __
             for (int k = 0; k < B; ++k) {
                 const bool ok = i + k * NC_THREADS < ck.i1;
                 xv[k] = nc_load<VEC>(xs + (size_t)(ok ? i + k * NC_THREADS : i) * VEC);
-                dv[k] = nc_load<VEC>(ds + (ok ? ((size_t)(h / pm.pk) * pm.Wo + w / pm.pk) * C : 0));
+                dv[k] = nc_load<VEC>(ds + (ok ? ((size_t)nc_pdiv(h, pm) * pm.Wo + nc_pdiv(w, pm)) * C : 0));
                 h += hstep; w += wstep;
                 if (w >= pm.W) { w -= pm.W; ++h; }
             }
@@ -392,6 +393,37 @@ __global__ __launch_bounds__(NC_THREADS) void nc_apply_kernel(const AT* __restri
     const AT* xc = xs + ck.cv * VEC; AT* os = out + (size_t)n * HoWo * C;
     int ho = ck.pix / pm.Wo, wo = ck.pix - ho * pm.Wo;
     const int hstep = ck.pstep / pm.Wo, wstep = ck.pstep - hstep * pm.Wo;
+    if (pm.pk == 2) {
+        // 2 x 2 windows (round 4: the pooled layers of the wide specs stream 67 MB each): the four vectors of a window are requested together, two windows per
+        // thread in flight; same sums in the same order as the general loop below
+        const size_t rowb = (size_t)pm.W * C;
+        for (int i = ck.i0; i < ck.i1; i += 2 * NC_THREADS) {
+            NcVec<VEC> xv[2][4];
+            int hh[2], ww[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                hh[k] = ho; ww[k] = wo;
+                const bool ok = i + k * NC_THREADS < ck.i1;
+                const AT* b = xc + (ok ? ((size_t)(2 * ho) * pm.W + 2 * wo) * C : 0);
+                xv[k][0] = nc_load<VEC>(b); xv[k][1] = nc_load<VEC>(b + C); xv[k][2] = nc_load<VEC>(b + rowb); xv[k][3] = nc_load<VEC>(b + rowb + C);
+                ho += hstep; wo += wstep;
+                if (wo >= pm.Wo) { wo -= pm.Wo; ++ho; }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                NcVec<VEC> o;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a += xv[k][q].v[v] * S.v[v] + T.v[v];
+                    o.v[v] = a * pm.inv;
+                }
+                if (i + k * NC_THREADS < ck.i1) nc_store<VEC>(os + (size_t)(i + k * NC_THREADS) * VEC, o);
+            }
+        }
+        return;
+    }
     for (int i = ck.i0; i < ck.i1; i += NC_THREADS) {
         float acc[VEC];
 #pragma unroll
@@ -442,7 +474,7 @@ template <int VEC, typename AT = float>
 __global__ __launch_bounds__(NC_THREADS) void nc_bwd_apply_kernel(const AT* __restrict__ dout, const AT* __restrict__ x, AT* __restrict__ dz, int HW, int C,
                                                                    int per, const float* __restrict__ coef, int coef_stride, const float* __restrict__ chan,
                                                                    const float* __restrict__ mean, const float* __restrict__ rstd, NcAct act, NcPool pm,
-                                                                   double* __restrict__ dbp, int dbrows) {
+                                                                   double* __restrict__ dbp, int dbrows, float* __restrict__ dbf) {
     // dbp != nullptr: the per-channel sums of dz over this block's pixels (the convolution bias gradient) go to dbp[channel][block] — a thread's channel vector
     // never changes, so it sums its own outputs in registers; the block's threads of one channel vector meet in LDS in a fixed order (round 3: a separate
     // dcv_channel_sum pass over dz cost 8 + 11 us per layer of cifar100_deep at bs 512: 6.6 % of the bf16 step)
@@ -499,7 +531,7 @@ __global__ __launch_bounds__(NC_THREADS) void nc_bwd_apply_kernel(const AT* __re
         for (int k = 0; k < B; ++k) {
             const bool ok = i + k * NC_THREADS < ck.i1;
             xv[k] = nc_load<VEC>(xs + (size_t)(ok ? i + k * NC_THREADS : i) * VEC);
-            dv[k] = nc_load<VEC>(ds + (ok ? ((size_t)(h / pm.pk) * pm.Wo + w / pm.pk) * C : 0));
+            dv[k] = nc_load<VEC>(ds + (ok ? ((size_t)nc_pdiv(h, pm) * pm.Wo + nc_pdiv(w, pm)) * C : 0));
             h += hstep; w += wstep;
             if (w >= pm.W) { w -= pm.W; ++h; }
         }
@@ -519,7 +551,7 @@ __global__ __launch_bounds__(NC_THREADS) void nc_bwd_apply_kernel(const AT* __re
         }
     }
     }
-    if (dbp != nullptr) {
+    if (dbp != nullptr || dbf != nullptr) {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) dbred[threadIdx.x * VEC + v] = sdz[v];
         __syncthreads();
@@ -528,7 +560,8 @@ __global__ __launch_bounds__(NC_THREADS) void nc_bwd_apply_kernel(const AT* __re
             const int cv = c / VEC, v = c - cv * VEC;
             float s = 0.f;
             for (int tq = cv; tq < NC_THREADS; tq += CV) s += dbred[tq * VEC + v];       // threads cv, cv + CV, ...: fixed order
-            dbp[(size_t)c * dbrows + block] = (double)s;
+            if (dbf != nullptr) dbf[(size_t)block * C + c] = s;                         // (round 4) [block][channel] fp32: summed with every other layer's slabs by ONE dcv_slab_reduce
+            else dbp[(size_t)c * dbrows + block] = (double)s;
         }
     }
 }
@@ -545,9 +578,9 @@ __global__ __launch_bounds__(64) void nc_rows_sum_kernel(const double* __restric
 
 // ------------------------------------------------------------------------------------------------ host side
 inline int nc_vec(int C) { return (C % 4 == 0) ? 4 : 1; }
-// channels per lane: 8 on bf16 tensors without GroupNorm / pooling (16-byte accesses) when the channel count allows it
+// channels per lane: 8 on bf16 tensors without GroupNorm (16-byte accesses) when the channel count allows it
 inline int nc_vec(const dcv_norm_chain_desc* d) {
-    if (d->io_dtype == DCV_DTYPE_BF16 && d->groups == 0 && d->pool == 0 && d->channels % 8 == 0 && ((d->channels / 8) & (d->channels / 8 - 1)) == 0 && d->channels / 8 <= NC_THREADS) return 8;
+    if (d->io_dtype == DCV_DTYPE_BF16 && d->groups == 0 && d->channels % 8 == 0 && ((d->channels / 8) & (d->channels / 8 - 1)) == 0 && d->channels / 8 <= NC_THREADS) return 8;
     return nc_vec(d->channels);
 }
 inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -585,12 +618,14 @@ inline bool nc_shape_ok(const dcv_norm_chain_desc* d) {
         if ((size_t)d->hw * cv > (size_t)NC_THREADS * 32) return false;         // one block per sample
     }
     if (d->pool < 0) return false;
-    if (d->pool > 0 && !(d->groups > 0 && d->width > 0 && d->hw % d->width == 0 && d->width % d->pool == 0 && (d->hw / d->width) % d->pool == 0)) return false;
+    // (round 4: fused pooling also without the GroupNorm stage — the BatchNorm-only layers of the wide specs: out = mean over the window of a[c] x + b[c])
+    if (d->pool > 0 && !(d->width > 0 && d->hw % d->width == 0 && d->width % d->pool == 0 && (d->hw / d->width) % d->pool == 0)) return false;
     return true;
 }
 
 inline NcPool nc_pool(const dcv_norm_chain_desc* d) {
-    return NcPool{d->width > 0 ? d->width : 1, d->pool > 0 ? d->width / d->pool : 1, d->pool, d->pool > 0 ? 1.f / (float)(d->pool * d->pool) : 1.f};
+    return NcPool{d->width > 0 ? d->width : 1, d->pool > 0 ? d->width / d->pool : 1, d->pool, d->pool > 0 ? 1.f / (float)(d->pool * d->pool) : 1.f,
+                  (d->pool > 0 && pow2(d->pool)) ? ilog2(d->pool) : -1};
 }
 inline NcAct nc_act(int act, float slope) {
     switch (act) {
@@ -624,6 +659,12 @@ int dcv_norm_chain_supported(const dcv_norm_chain_desc* d) { return (nc_enabled(
 size_t dcv_norm_chain_coef_floats(const dcv_norm_chain_desc* d) {
     if (!nc_shape_ok(d)) return 0;
     return (size_t)3 * d->channels * (d->groups > 0 ? (size_t)d->n : 1);
+}
+
+int dcv_norm_chain_bias_rows(const dcv_norm_chain_desc* d) {
+    if (!nc_shape_ok(d)) return 0;
+    int bps, per; nc_split(d->hw * (d->channels / nc_vec(d)), d->groups > 0, &bps, &per);
+    return d->n * bps;
 }
 
 size_t dcv_norm_chain_ws_bytes(const dcv_norm_chain_desc* d) {
@@ -664,7 +705,7 @@ int dcv_norm_chain_fwd(const dcv_norm_chain_desc* d, const void* xv, void* outv,
     if (!(nc_skip() & 2)) hipLaunchKernelGGL(nc_bn_fwd_finalize_kernel, dim3((unsigned)C), dim3(NC_THREADS), 0, st, part, rows, (double)d->n * (double)d->hw, C, d->bn_gamma, d->bn_beta,
                        d->running_mean, d->running_var, reinterpret_cast<long long*>(d->num_batches_tracked), d->momentum, d->bn_eps, d->bn_mean, d->bn_rstd, ab);
     int abps = bps, aper = per;
-    if (d->pool > 0) nc_split((d->hw / (d->pool * d->pool)) * CV, true, &abps, &aper);
+    if (d->pool > 0) nc_split((d->hw / (d->pool * d->pool)) * CV, G > 0, &abps, &aper);      // (a GroupNorm sample is one block: its prologue; else as many as it takes)
     const dim3 agrid((unsigned)abps, (unsigned)d->n);
     if (nc_skip() & 4) DCV_RETURN_LAUNCH();
     if (io16 && vec == 8) hipLaunchKernelGGL((nc_apply_kernel<8, nc_bf16>), agrid, dim3(NC_THREADS), 0, st, x16, out16, d->hw, C, aper, ab, part, rows, rps, gn, pm);
@@ -684,6 +725,7 @@ int dcv_norm_chain_bwd(const dcv_norm_chain_desc* d, const void* doutv, const vo
     DCV_CHECK_ARG(d->groups == 0 || (d->gn_mean && d->gn_rstd));
     DCV_CHECK_ARG(nc_vec(d) != 8 || ((reinterpret_cast<uintptr_t>(doutv) | reinterpret_cast<uintptr_t>(xv) | reinterpret_cast<uintptr_t>(dzv)) & 15) == 0);
     if (ws_bytes < nc_part_bytes(d) + nc_chan_bytes(d) + (d->d_bias ? nc_db_bytes(d) : 0)) return DCV_ERR_WORKSPACE;
+    DCV_CHECK_ARG(!(d->d_bias && d->d_bias_part) && (d->moments == nullptr || (d->groups == 0 && d->moments_rows > 0)));
     hipStream_t st = dcv_stream(stream);
     const int C = d->channels, vec = nc_vec(d), CV = C / vec, G = d->groups;
     int bps, per; nc_split(d->hw * CV, G > 0, &bps, &per);
@@ -692,24 +734,28 @@ int dcv_norm_chain_bwd(const dcv_norm_chain_desc* d, const void* doutv, const vo
     float* chan = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + nc_part_bytes(d));
     const int rows = d->n * bps;
     double* dbp = d->d_bias ? reinterpret_cast<double*>(reinterpret_cast<char*>(ws) + nc_part_bytes(d) + nc_chan_bytes(d)) : nullptr;
+    float* dbf = d->d_bias_part;
+    // `moments`: the producer of dout (dcv_conv2d_bf16_dgrad_moments) left the per-row sums of dout and dout * u: no pass over dout and x here
+    const double* fpart = d->moments ? d->moments : part;
+    const int frows = d->moments ? d->moments_rows : rows;
     const dim3 sgrid((unsigned)bps, (unsigned)d->n);
     const NcBwdCtx bc{d->bn_gamma, d->bn_beta, d->bn_rstd, nc_gn(d), d->coef};
-    if (nc_skip() & 1) {}
+    if ((nc_skip() & 1) || d->moments != nullptr) {}
     else if (io16 && vec == 8) hipLaunchKernelGGL((nc_sample_sums_kernel<8, true, nc_bf16>), sgrid, dim3(NC_THREADS), 0, st, x16, dout16, d->hw, C, per, d->bn_mean, d->bn_rstd, pm, part, rows, bc);
     else if (io16 && vec == 4) hipLaunchKernelGGL((nc_sample_sums_kernel<4, true, nc_bf16>), sgrid, dim3(NC_THREADS), 0, st, x16, dout16, d->hw, C, per, d->bn_mean, d->bn_rstd, pm, part, rows, bc);
     else if (io16) hipLaunchKernelGGL((nc_sample_sums_kernel<1, true, nc_bf16>), sgrid, dim3(NC_THREADS), 0, st, x16, dout16, d->hw, C, per, d->bn_mean, d->bn_rstd, pm, part, rows, bc);
     else if (vec == 4) hipLaunchKernelGGL((nc_sample_sums_kernel<4, true>), sgrid, dim3(NC_THREADS), 0, st, x, dout, d->hw, C, per, d->bn_mean, d->bn_rstd, pm, part, rows, bc);
     else hipLaunchKernelGGL((nc_sample_sums_kernel<1, true>), sgrid, dim3(NC_THREADS), 0, st, x, dout, d->hw, C, per, d->bn_mean, d->bn_rstd, pm, part, rows, bc);
-    if (!(nc_skip() & 2)) hipLaunchKernelGGL(nc_param_finalize_kernel, dim3((unsigned)C), dim3(NC_THREADS), 0, st, part, rows, (double)d->n * (double)d->hw, C, G > 0 ? 1 : 0, d->bn_gamma, d->bn_rstd,
+    if (!(nc_skip() & 2)) hipLaunchKernelGGL(nc_param_finalize_kernel, dim3((unsigned)C), dim3(NC_THREADS), 0, st, fpart, frows, (double)d->n * (double)d->hw, C, G > 0 ? 1 : 0, d->bn_gamma, d->bn_rstd,
                        d_bn_gamma, d_bn_beta, d_gn_gamma, d_gn_beta, chan, d->coef);
     const int cstride = G > 0 ? 3 * C : 0;
     const float* ch = chan;
     if (nc_skip() & 4) DCV_RETURN_LAUNCH();
-    if (io16 && vec == 8) hipLaunchKernelGGL((nc_bwd_apply_kernel<8, nc_bf16>), sgrid, dim3(NC_THREADS), 0, st, dout16, x16, dz16, d->hw, C, per, d->coef, cstride, ch, d->bn_mean, d->bn_rstd, nc_act(d->act, d->act_slope), pm, dbp, rows);
-    else if (io16 && vec == 4) hipLaunchKernelGGL((nc_bwd_apply_kernel<4, nc_bf16>), sgrid, dim3(NC_THREADS), 0, st, dout16, x16, dz16, d->hw, C, per, d->coef, cstride, ch, d->bn_mean, d->bn_rstd, nc_act(d->act, d->act_slope), pm, dbp, rows);
-    else if (io16) hipLaunchKernelGGL((nc_bwd_apply_kernel<1, nc_bf16>), sgrid, dim3(NC_THREADS), 0, st, dout16, x16, dz16, d->hw, C, per, d->coef, cstride, ch, d->bn_mean, d->bn_rstd, nc_act(d->act, d->act_slope), pm, dbp, rows);
-    else if (vec == 4) hipLaunchKernelGGL((nc_bwd_apply_kernel<4>), sgrid, dim3(NC_THREADS), 0, st, dout, x, dz, d->hw, C, per, d->coef, cstride, ch, d->bn_mean, d->bn_rstd, nc_act(d->act, d->act_slope), pm, dbp, rows);
-    else hipLaunchKernelGGL((nc_bwd_apply_kernel<1>), sgrid, dim3(NC_THREADS), 0, st, dout, x, dz, d->hw, C, per, d->coef, cstride, ch, d->bn_mean, d->bn_rstd, nc_act(d->act, d->act_slope), pm, dbp, rows);
+    if (io16 && vec == 8) hipLaunchKernelGGL((nc_bwd_apply_kernel<8, nc_bf16>), sgrid, dim3(NC_THREADS), 0, st, dout16, x16, dz16, d->hw, C, per, d->coef, cstride, ch, d->bn_mean, d->bn_rstd, nc_act(d->act, d->act_slope), pm, dbp, rows, dbf);
+    else if (io16 && vec == 4) hipLaunchKernelGGL((nc_bwd_apply_kernel<4, nc_bf16>), sgrid, dim3(NC_THREADS), 0, st, dout16, x16, dz16, d->hw, C, per, d->coef, cstride, ch, d->bn_mean, d->bn_rstd, nc_act(d->act, d->act_slope), pm, dbp, rows, dbf);
+    else if (io16) hipLaunchKernelGGL((nc_bwd_apply_kernel<1, nc_bf16>), sgrid, dim3(NC_THREADS), 0, st, dout16, x16, dz16, d->hw, C, per, d->coef, cstride, ch, d->bn_mean, d->bn_rstd, nc_act(d->act, d->act_slope), pm, dbp, rows, dbf);
+    else if (vec == 4) hipLaunchKernelGGL((nc_bwd_apply_kernel<4>), sgrid, dim3(NC_THREADS), 0, st, dout, x, dz, d->hw, C, per, d->coef, cstride, ch, d->bn_mean, d->bn_rstd, nc_act(d->act, d->act_slope), pm, dbp, rows, dbf);
+    else hipLaunchKernelGGL((nc_bwd_apply_kernel<1>), sgrid, dim3(NC_THREADS), 0, st, dout, x, dz, d->hw, C, per, d->coef, cstride, ch, d->bn_mean, d->bn_rstd, nc_act(d->act, d->act_slope), pm, dbp, rows, dbf);
     if (dbp) hipLaunchKernelGGL(nc_rows_sum_kernel, dim3((unsigned)C), dim3(64), 0, st, dbp, rows, d->d_bias);
     DCV_RETURN_LAUNCH();
 }

@@ -139,6 +139,8 @@ class DeepcvModule(torch.nn.Module):
                     referenced_output_features[name] = ref
                 else:
                     referenced_output_features[name] = x
+                    if getattr(x, '_dcv_producer', None) is not None:     # a second consumer (the referrer): its gradient is added to the next layer's (ops._Producer)
+                        x._dcv_producer = None
             i += 1
         return x
 

@@ -282,7 +282,7 @@ class LayerSequential(torch.nn.Sequential):
             return None
         mods = list(self._modules.values())
         plan = self._fused_layer_plan(mods)
-        if plan is None or plan[3] is None or plan[4] != len(mods):
+        if plan is None or plan[4] != len(mods):
             return None
         try:
             k, s, p = pool._geom()
@@ -292,6 +292,8 @@ class LayerSequential(torch.nn.Sequential):
             return None
         out_shape = plan[0].out_shape(x.shape)
         if out_shape[-2] % k[0] or out_shape[-1] % k[0]:
+            return None
+        if not ops.fused_pool_covered(out_shape[0], out_shape[1], out_shape[2], out_shape[3], plan[3].num_groups if plan[3] is not None else 0, k[0]):
             return None
         return self._run_fused_layer(x, plan, pool=k[0])
 

