@@ -534,6 +534,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
 __device__ __forceinline__ s16x4 tr_read(const char* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p); }
+__device__ __forceinline__ s16x4 tr_read_lds(unsigned lds_byte_address) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(unsigned long long)lds_byte_address); }
 
 // GROUPS: wave groups of 256 threads splitting the block's pixel range; their accumulators are summed through LDS at the end (group 1's 36 tiles = 144 KB,
 // the staging buffers are dead by then), which halves the number of fp32 partial slabs the ordered reduce has to read for the same number of resident waves.
@@ -698,6 +699,239 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9_kernel(W16Ar
                 const int co = co0 + tt * 16 + 4 * lg + reg, ci = ci0 + wave * 16 + li;
                 dst[((size_t)k * a.Cout + co) * a.Cin + ci] = acc[k][tt][reg];
             }
+}
+
+// ------------------------------------------------------------------------------------------------ round 4: the same operator on a zero-PADDED window, 128-byte rows
+// What the kernel above pays per 36 MFMAs of a wave and step (a 16-clock MFMA leaves its SIMD eight issue clocks: two other instructions): 26 transposed reads,
+// 32 v_and (the border masks of the s = 0 / s = 2 taps), four LDS-DMA instructions of 6.4 rows (160-byte rows: a quarter of every instruction fetches padding)
+// and their address arithmetic — about 70 instructions, i.e. the issue port, not the matrix pipe, sets the pace (0.23 - 0.35 of the peak).  Here, for the maps
+// whose width divides 32 (4, 8, 16, 32: the CIFAR-sized specs):
+//   * the x window is staged in PADDED coordinates — image row h at window rows (h - h0 + 1) (W + 2) + 1 + w, the two pad columns and the rows outside the image
+//     fetched out of range (zeros): a tap which leaves the image reads a zero row, NO masks; a step's 32 pixels are whole image rows, so a lane's window row is
+//     the same in every step: the 18 + 8 operand addresses of a lane are registers computed once;
+//   * rows are 128 bytes, bank-swizzled on the SOURCE side of the DMA: 32-byte column c of row q lies at c ^ ((q >> 1) & 3) — a transposed read's lane group
+//     touches eight consecutive rows (any tap offset), whose four same-parity rows then sit in four different columns: conflict-free like the 160-byte rows,
+//     but an instruction moves eight whole rows (dz: 4 instead of 6 instructions per step, the window of a 16-wide map 9 instead of 11);
+//   * three stages at compile-time distances (the step loop is unrolled by three): the stage offset is the immediate of the read.
+// Maps of at most 16 pixels take two images per step as above (two windows, the K halves of a fragment in different windows).
+struct W16pArgs {
+    int N, H, W, Cin, Cout;
+    int HWp;                        // K-axis pixels per image (per PAIR of images when ips == 2): a multiple of 32
+    long M, m_per_chunk;
+    size_t wtotal;
+    int ips, nx;                    // images per step; 8-row DMA instructions per window
+};
+#define W16P_XOFF 4096              // dz: 32 rows of 128 B
+#define W16P_STAGE (4096 + 13 * 1024)      // + the largest window: 104 rows (W = 32); two windows of 40 rows with image pairs
+#define W16P_GROUP (3 * W16P_STAGE)
+
+template <int GROUPS, int IPS>
+__global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9p_kernel(W16pArgs a, const u16* __restrict__ x, const u16* __restrict__ dy, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(1024))) char smem16p[];
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), t = threadIdx.x & 255, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const unsigned St = (unsigned)(size_t)smem16p + (unsigned)(grp * W16P_GROUP);
+    const int li = lane & 15, lg = lane >> 4;
+    const int ci0 = blockIdx.y * 64, co0 = blockIdx.z * 64;
+    constexpr int ips = IPS;
+    const int W = a.W, WP = W + 2, wsh = 31 - __builtin_clz((unsigned)W), NX = a.nx;
+    const int per_group = (int)(a.m_per_chunk / GROUPS);         // multiple of 32
+    const int mb = (int)blockIdx.x * (int)a.m_per_chunk + grp * per_group;
+    int me = mb + per_group; if (me > (int)a.M) me = (int)a.M;
+    const int nsteps = per_group / W16_PS;
+    const int steps_g = me > mb ? (me - mb + W16_PS - 1) / W16_PS : 0;
+    int l_n = __builtin_amdgcn_readfirstlane(mb / a.HWp), l_p0 = __builtin_amdgcn_readfirstlane(mb - (mb / a.HWp) * a.HWp);      // (scalars: the division runs on the vector unit)
+    const int HW = a.H * a.W;
+
+    // ---- operand addresses of this lane (bytes inside a stage, + the group's base): pixel j0 of each K half
+    const int j0 = 4 * lg + (li >> 2), sub = (li & 3) * 8;
+    auto wpos = [&](int j) { return W >= 32 ? j : ((j >> wsh) * WP + (j & (W - 1))); };      // K-axis pixel -> window row of its centre tap's column 0 ... (before the tap offset)
+    unsigned aaddr[2][4], baddr[2][9];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const int ra = j0 + 16 * hf;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) aaddr[hf][tt] = St + (unsigned)(ra * 128 + ((tt ^ ((ra >> 1) & 3)) << 5) + sub);
+        const int rb = ips == 2 ? hf * NX * 8 + wpos(j0) : wpos(j0 + 16 * hf);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int sx = 0; sx < 3; ++sx) {
+                const int row = rb + r * WP + sx;
+                baddr[hf][r * 3 + sx] = St + (unsigned)(W16P_XOFF + row * 128 + ((wave ^ ((row >> 1) & 3)) << 5) + sub);
+            }
+    }
+    // (opaque to the optimiser: left visible, the 26 addresses are re-derived from their common terms in front of every read — an addition per read)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) asm volatile("" : "+v"(aaddr[hf][tt]));
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) asm volatile("" : "+v"(baddr[hf][tp]));
+    }
+    // ---- staging, by wave ROLES (every per-step decision is a scalar of the wave; a step issues no dummy instructions: each wave counts its own requests):
+    // wave 0 stages the dz tile (4 instructions of 8 rows; image pairs: rows 16 .. 31 from the second image), waves 1 - 3 the window instructions
+    // j = wave - 1, wave + 2, ... (image pairs: instructions NX .. 2 NX - 1 are the second image's window).  Lane = row 8 j + lane / 8, 16-byte piece lane % 8,
+    // which holds logical piece (lane % 8) ^ 2 ((row >> 1) & 3).
+    const bool dzw = wave == 0;
+    const int Cw = dzw ? a.Cout : a.Cin;
+    const int cnt = dzw ? 4 : (ips * NX - (wave - 1) + 2) / 3;    // requests of this wave per step (<= 5)
+    const int n0 = dzw ? (ips == 2 ? 2 : 4) : (ips == 2 ? (NX - (wave - 1) + 2) / 3 : 5);      // the first n0 of them read the step's first image
+    unsigned voff[5];
+    const unsigned sdst0 = dzw ? 0u : (unsigned)(W16P_XOFF + (wave - 1) * 1024), sdstep = dzw ? 1024u : 3072u;      // LDS destination of request i: sdst0 + i sdstep
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int r8 = lane >> 3, piece = lane & 7;
+        unsigned v = BF_OOB;
+        if (dzw) {
+            const int row = 8 * i + r8, pix = ips == 2 ? (row & 15) : row;
+            v = (unsigned)((pix * a.Cout + co0) * 2 + ((piece ^ (((row >> 1) & 3) << 1)) << 4));
+        } else {
+            const int jx = (wave - 1) + 3 * i, wi = jx >= NX ? jx - NX : jx;
+            const int q = 8 * wi + r8, hh = q / WP, ww = q - hh * WP;
+            if (ww >= 1 && ww <= W) v = (unsigned)((((hh - 1) * W + ww - 1) * a.Cin + ci0) * 2 + ((piece ^ (((q >> 1) & 3) << 1)) << 4));      // (mod 2^32: the row above the image wraps out of range)
+        }
+        voff[i] = v;
+        asm volatile("" : "+v"(voff[i]));
+    }
+    const u16* tens = dzw ? dy : x;
+    const unsigned img_bytes = (unsigned)(HW * Cw * 2);
+    // the step's image (first image of the pair) as a byte address, advanced with l_n (two scalar registers instead of a 64-bit product per step)
+    unsigned long long ibase = (unsigned long long)tens + (unsigned long long)(l_n * ips) * img_bytes;
+    const unsigned sbase = St + sdst0;
+    auto dma_step = [&](int stg) {
+        const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)ibase), bhi = __builtin_amdgcn_readfirstlane((unsigned)(ibase >> 32));
+        const bw_i32x4 r0 = {(int)blo, (int)(bhi & 0xFFFFu), (int)img_bytes, 0x00020000};
+        const unsigned adv = (unsigned)(l_p0 * Cw * 2);
+        int c = __builtin_amdgcn_readfirstlane(cnt), c0 = __builtin_amdgcn_readfirstlane(n0);
+        unsigned sb2 = __builtin_amdgcn_readfirstlane(sbase);
+        asm volatile("" : "+s"(c), "+s"(c0), "+s"(sb2));         // (loop-variant to the optimiser: hoisted, the comparisons and the fifteen destinations below live in
+                                                                 //  scalar registers the kernel does not have, and the step counters move to vector registers)
+        unsigned dst = sb2 + (unsigned)(stg * W16P_STAGE);
+        if constexpr (IPS == 2) {
+            const unsigned long long b1 = ibase + img_bytes;
+            const bool has2 = l_n * 2 + 1 < a.N;                 // (an odd batch's last pair: zero records, every load delivers zeros)
+            const bw_i32x4 r1 = {(int)__builtin_amdgcn_readfirstlane((unsigned)b1), (int)(__builtin_amdgcn_readfirstlane((unsigned)(b1 >> 32)) & 0xFFFFu), has2 ? (int)img_bytes : 0, 0x00020000};
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                if (i < c) { if (i < c0) bw_dma16(r0, dst, voff[i], 0u); else bw_dma16(r1, dst, voff[i], 0u); }
+                dst += sdstep;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                if (i < c) bw_dma16(r0, dst, voff[i] + adv, 0u);
+                dst += sdstep;
+            }
+        }
+        l_p0 += W16_PS;
+        if (l_p0 >= a.HWp) { l_p0 = 0; ++l_n; ibase += (unsigned long long)ips * img_bytes; }
+        l_p0 = __builtin_amdgcn_readfirstlane(l_p0); l_n = __builtin_amdgcn_readfirstlane(l_n);
+    };
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[k][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    union Frag { bf16x8 v; s16x4 h[2]; };
+    auto body = [&](auto stgc, int it) __attribute__((always_inline)) {
+        constexpr int STG = decltype(stgc)::value;
+        const bool active = it < steps_g;                        // group-uniform: a group whose range ended early only keeps the barriers
+        if (active) { if (it + 1 < steps_g) w16_wait(cnt); else __builtin_amdgcn_s_waitcnt(0x0F70); }
+        __syncthreads();                                         // everybody's pieces of this step have landed; every wave is done with the stage of step it - 1
+        if (it + 2 < steps_g) dma_step((STG + 2) % 3);
+        if (active) {
+            constexpr unsigned SO = (unsigned)(STG * W16P_STAGE);
+            Frag af[4];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) { af[tt].h[0] = tr_read_lds(aaddr[0][tt] + SO); af[tt].h[1] = tr_read_lds(aaddr[1][tt] + SO); }
+            // the x fragments of tap t + 1 are requested in front of tap t's MFMAs (two fragment registers sets): a read has four MFMAs to land
+            Frag bq[2];
+            bq[0].h[0] = tr_read_lds(baddr[0][0] + SO); bq[0].h[1] = tr_read_lds(baddr[1][0] + SO);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                if (tap + 1 < 9) { bq[(tap + 1) & 1].h[0] = tr_read_lds(baddr[0][tap + 1] + SO); bq[(tap + 1) & 1].h[1] = tr_read_lds(baddr[1][tap + 1] + SO); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) acc[tap][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tt].v, bq[tap & 1].v, acc[tap][tt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    for (int j = 0; j < 2; ++j) if (j < steps_g) dma_step(j);
+    for (int it = 0; it < nsteps; it += 3) {
+        body(std::integral_constant<int, 0>{}, it);
+        if (it + 1 < nsteps) body(std::integral_constant<int, 1>{}, it + 1);
+        if (it + 2 < nsteps) body(std::integral_constant<int, 2>{}, it + 2);
+    }
+    __syncthreads();                                             // (the stages are dead: group 1's accumulators go there)
+    if constexpr (GROUPS == 2) {
+        f32x4* red = reinterpret_cast<f32x4*>(smem16p);
+        if (grp == 1) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) red[(k * 4 + tt) * 256 + t] = acc[k][tt];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) acc[k][tt] += red[(k * 4 + tt) * 256 + t];
+    }
+    // acc[tap][tt][reg]: co = co0 + 16 tt + 4 lg + reg, ci = ci0 + 16 wave + li
+    float* dst = partial + (size_t)blockIdx.x * a.wtotal;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int co = co0 + tt * 16 + 4 * lg + reg, ci = ci0 + wave * 16 + li;
+                dst[((size_t)k * a.Cout + co) * a.Cin + ci] = acc[k][tt][reg];
+            }
+}
+
+inline int w16_groups(int tiles);
+inline bool w16p_plan(const dcv_conv2d_desc* d, W16pArgs* a, int* chunks, size_t* smem, int* groups) {
+    static int enabled = -1;
+    if (enabled < 0) { const char* e = getenv("DCV_BF16_WGRAD9P"); enabled = e ? atoi(e) : 1; }
+    if (!enabled || d->groups != 1 || d->x_layout != DCV_LAYOUT_NHWC) return false;
+    if (d->r != 3 || d->s != 3 || d->pad_h != 1 || d->pad_w != 1 || d->stride_h != 1 || d->stride_w != 1 || d->dil_h != 1 || d->dil_w != 1) return false;
+    if (d->cin % 64 != 0 || d->cout % 64 != 0 || d->ho != d->h || d->wo != d->w) return false;
+    if (d->w != 4 && d->w != 8 && d->w != 16 && d->w != 32) return false;
+    const int hw = d->h * d->w;
+    if ((size_t)hw * d->cin * 2 >= ((size_t)1 << 30) || (size_t)hw * d->cout * 2 >= ((size_t)1 << 30)) return false;
+    const int ips = hw <= 16 ? 2 : 1;
+    if (ips == 1 && hw % W16_PS != 0) return false;             // a step is whole image rows of one image
+    if (ips == 2 && hw != 16) return false;                    // (a K half is exactly one image: no window rows beyond the staged ones are ever read)
+    const int rows_img = ips == 2 ? d->h : W16_PS / d->w;       // image rows of a step (per image)
+    const int xr = ((ips == 2 ? d->h : (d->w >= 32 ? 1 : rows_img)) + 2) * (d->w + 2);
+    const int nx = (xr + 7) / 8;
+    if (4096 + ips * nx * 1024 > W16P_STAGE) return false;
+    int gr = w16_groups((d->cin / 64) * (d->cout / 64));
+    a->N = d->n; a->H = d->h; a->W = d->w; a->Cin = d->cin; a->Cout = d->cout; a->ips = ips; a->nx = nx;
+    a->HWp = ips == 2 ? W16_PS : hw;
+    a->M = (long)((d->n + ips - 1) / ips) * a->HWp;
+    a->wtotal = (size_t)d->cout * d->cin * 9;
+    *smem = gr == 2 ? ((size_t)2 * W16P_GROUP + 2048 > (size_t)36 * 256 * 16 ? (size_t)2 * W16P_GROUP + 2048 : (size_t)36 * 256 * 16) : (size_t)W16P_GROUP + 1024;
+    *groups = gr;
+    const long blocks_per_chunk = (long)(d->cin / 64) * (d->cout / 64);
+    const long resident = gr == 2 ? DCV_NUM_CU : 2 * DCV_NUM_CU;
+    long ch = (resident + blocks_per_chunk - 1) / blocks_per_chunk;
+    const long unit = (long)gr * W16_PS;
+    const long max_by_m = a->M / (4 * unit) > 0 ? a->M / (4 * unit) : 1;
+    if (ch > max_by_m) ch = max_by_m;
+    const long max_by_bytes = (long)(((size_t)256 << 20) / (a->wtotal * sizeof(float)));
+    if (ch > max_by_bytes) ch = max_by_bytes;
+    if (ch < 1) ch = 1;
+    long mpc = (a->M + ch - 1) / ch;
+    mpc = (mpc + unit - 1) / unit * unit;
+    a->m_per_chunk = mpc;
+    *chunks = (int)((a->M + mpc - 1) / mpc);
+    return true;
 }
 
 // wave groups per block (2: in-block sum of two pixel halves, half the partial slabs).  The slabs are what this operator costs on narrow layers — 512 blocks x
@@ -1075,8 +1309,8 @@ extern "C" {
 
 int dcv_conv2d_bf16_supported(const dcv_conv2d_desc* d, int op) {
     if (op == 2) {
-        W16Args a{}; int chunks, groups; size_t smem;
-        return (desc_ok(d) && (dcv_mfma_conv2d_wgrad_in16_supported(d) || w16_plan(d, &a, &chunks, &smem, &groups))) ? 1 : 0;
+        W16Args a{}; W16pArgs ap{}; int chunks, groups; size_t smem;
+        return (desc_ok(d) && (dcv_mfma_conv2d_wgrad_in16_supported(d) || w16_plan(d, &a, &chunks, &smem, &groups) || w16p_plan(d, &ap, &chunks, &smem, &groups))) ? 1 : 0;
     }
     return (op == 0 || op == 1) && supported(d, op) ? 1 : 0;
 }
@@ -1086,6 +1320,8 @@ size_t dcv_conv2d_bf16_wgrad_workspace_bytes(const dcv_conv2d_desc* d) {
     size_t need = dcv_mfma_conv2d_wgrad_in16_supported(d) ? dcv_mfma_conv2d_ws(d, 2) : 0;
     W16Args a{}; int chunks, groups; size_t smem;
     if (w16_plan(d, &a, &chunks, &smem, &groups)) { const size_t n16 = dcv_align_up((size_t)chunks * a.wtotal * sizeof(float), 256); if (n16 > need) need = n16; }
+    W16pArgs ap{};
+    if (w16p_plan(d, &ap, &chunks, &smem, &groups)) { const size_t n16 = dcv_align_up((size_t)chunks * ap.wtotal * sizeof(float), 256); if (n16 > need) need = n16; }
     return need;
 }
 
@@ -1093,6 +1329,33 @@ int dcv_conv2d_bf16_wgrad(const dcv_conv2d_desc* d, const void* x, const void* d
     DCV_CHECK_ARG(desc_ok(d) && x && dy && dw);
     if (!dcv_conv2d_bf16_supported(d, 2)) return DCV_ERR_UNSUPPORTED;
     W16Args a{}; int chunks, groups; size_t smem;
+    W16pArgs ap{};
+    if (w16p_plan(d, &ap, &chunks, &smem, &groups)) {            // the padded-window kernel (maps 4 / 8 / 16 / 32 wide)
+        if (!ws || ws_bytes < (size_t)chunks * ap.wtotal * sizeof(float)) return DCV_ERR_WORKSPACE;
+        DCV_CHECK_ARG(aligned16(x) && aligned16(dy) && aligned16(ws));
+        dim3 grid((unsigned)chunks, (unsigned)(d->cin / 64), (unsigned)(d->cout / 64));
+        if (grid.y > 65535 || grid.z > 65535) return DCV_ERR_UNSUPPORTED;
+        static bool pconf = false;
+        if (!pconf) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_wgrad9p_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_wgrad9p_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_wgrad9p_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_wgrad9p_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DCV_ERR_LAUNCH;
+            pconf = true;
+        }
+        float* partial = reinterpret_cast<float*>(ws);
+        const u16* xs = reinterpret_cast<const u16*>(x); const u16* dys = reinterpret_cast<const u16*>(dy);
+        dcv_count_launch(DCV_FAMILY_BF16_WGRAD9);
+        if (ap.ips == 2) {
+            if (groups == 2) hipLaunchKernelGGL((conv_bf16_wgrad9p_kernel<2, 2>), grid, dim3(512), smem, dcv_stream(stream), ap, xs, dys, partial);
+            else hipLaunchKernelGGL((conv_bf16_wgrad9p_kernel<1, 2>), grid, dim3(256), smem, dcv_stream(stream), ap, xs, dys, partial);
+        } else {
+            if (groups == 2) hipLaunchKernelGGL((conv_bf16_wgrad9p_kernel<2, 1>), grid, dim3(512), smem, dcv_stream(stream), ap, xs, dys, partial);
+            else hipLaunchKernelGGL((conv_bf16_wgrad9p_kernel<1, 1>), grid, dim3(256), smem, dcv_stream(stream), ap, xs, dys, partial);
+        }
+        if (hipGetLastError() != hipSuccess) return DCV_ERR_LAUNCH;
+        return dcv_mfma_wgrad9_reduce(partial, dw, chunks, d->cout, d->cin, dcv_stream(stream));
+    }
     if (w16_plan(d, &a, &chunks, &smem, &groups)) {
         if (!ws || ws_bytes < (size_t)chunks * a.wtotal * sizeof(float)) return DCV_ERR_WORKSPACE;
         DCV_CHECK_ARG(aligned16(x) && aligned16(dy) && aligned16(ws));
