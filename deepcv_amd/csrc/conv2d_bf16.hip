@@ -43,6 +43,7 @@ struct Bf16Args {
     unsigned x_bytes, w_bytes;     // buffer sizes (num_records)
     int phase, oh_mul, ow_mul, oh_off, ow_off, Hfull, Wfull;      // strided data gradient: this launch writes phase (oh_off, ow_off) of the full tensor
     unsigned magic_w, magic_h;     // the window kernel: floor((2^32 - 1) / Win) + 1, ... / Hin + 1: n / d = mulhi(n, magic) for n d < 2^32
+    int stat_rows, stat_row0;      // a launch over a SLICE of the batch (tensors beyond 2 GiB run as several launches): rows of the whole statistics array (0: this launch's own) and this slice's first row
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(Bf16Args a, const u16
             double v = 0.0;
 #pragma unroll
             for (int w = 0; w < WM; ++w) v += red[((w * WN + wnn) * 2 + q) * 64 + cc];
-            stats[((size_t)q * a.Cout + n0 + c) * gridDim.x + blockIdx.x] = v;                     // [2][Cout][rows]
+            stats[((size_t)q * a.Cout + n0 + c) * (a.stat_rows ? a.stat_rows : (int)gridDim.x) + a.stat_row0 + blockIdx.x] = v;      // [2][Cout][rows]
         }
     }
 }
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, cons
                 if (lg == 0) { red[(wave * 2 + 0) * 64 + 4 * li + j] = (double)s1v; red[(wave * 2 + 1) * 64 + 4 * li + j] = (double)s2v; }
             }
             __syncthreads();
-            const int rows_total = (int)((a.M + 127) / 128);
+            const int rows_here = (int)((a.M + 127) / 128), rows_total = a.stat_rows ? a.stat_rows : rows_here;
             for (int e = t; e < 2 * 2 * BN; e += 512) {
                 const int half = e / (2 * BN), r2 = e - half * 2 * BN, q = r2 / BN, c = r2 - q * BN;
                 const int wnn = c >> 6, cc = c & 63;
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, cons
 #pragma unroll
                 for (int w = 0; w < WM / 2; ++w) v += red[(((half * (WM / 2) + w) * WN + wnn) * 2 + q) * 64 + cc];
                 const int row = 2 * tile + half;
-                if (row < rows_total) stats[((size_t)q * a.Cout + n0 + c) * rows_total + row] = v;            // [2][Cout][rows]
+                if (row < rows_here) stats[((size_t)q * a.Cout + n0 + c) * rows_total + a.stat_row0 + row] = v;            // [2][Cout][rows]
             }
         }
     };
@@ -1140,15 +1141,33 @@ inline int prep_pieces(const dcv_conv2d_desc* d, int op, Bf16Prep* out, int* off
     return n;
 }
 
+// Samples per launch when the tensor a kernel reads (or the pixel count) exceeds what its 32-bit byte offsets address: the largest slice of the batch whose input stays
+// below 2 GiB and whose pixel count is a multiple of 128 (so that the slices' statistics rows tile the whole array); 0: no such slice.  Round 4: the stem of
+// resnet18_style as im2col + 1x1 at the metric's 512 images per GPU reads a 2.5 GB matrix.
+inline size_t slice_limit() {                                       // DCV_BF16_SLICE_BYTES: tests force slicing at small sizes
+    static size_t lim = 0;
+    if (lim == 0) { const char* e = getenv("DCV_BF16_SLICE_BYTES"); lim = e ? (size_t)atoll(e) : ((size_t)1 << 31); if (lim == 0 || lim > ((size_t)1 << 31)) lim = (size_t)1 << 31; }
+    return lim;
+}
+inline int batch_slice(const dcv_conv2d_desc* d, int op) {
+    const size_t in1 = (op == 1 ? (size_t)d->ho * d->wo * d->cout : (size_t)d->h * d->w * d->cin) * 2;
+    const size_t out_pix = op == 1 ? (size_t)d->h * d->w : (size_t)d->ho * d->wo;
+    size_t ns = (slice_limit() - 1) / in1;
+    if (ns > (size_t)d->n) ns = (size_t)d->n;
+    while (ns > 0 && (ns * out_pix) % 128 != 0) --ns;
+    return (int)ns;
+}
+
 inline bool supported(const dcv_conv2d_desc* d, int op) {
     if (!desc_ok(d) || d->groups != 1 || d->x_layout != DCV_LAYOUT_NHWC) return false;
     if (d->r * d->s > 64) return false;                                               // tap validity is a 64-bit mask
     const int kcin = op == 1 ? d->cout : d->cin, kcout = op == 1 ? d->cin : d->cout;
     if (kcin % BF_BK != 0 || kcout % 64 != 0) return false;
-    // 32-bit buffer offsets with headroom for the out-of-range marker
-    const size_t xin = (size_t)d->n * (op == 1 ? (size_t)d->ho * d->wo * d->cout : (size_t)d->h * d->w * d->cin) * 2;
+    // 32-bit buffer offsets with headroom for the out-of-range marker: per LAUNCH — a larger batch runs as slices of the batch (batch_slice below)
+    const size_t xin1 = (op == 1 ? (size_t)d->ho * d->wo * d->cout : (size_t)d->h * d->w * d->cin) * 2;
     const size_t wbytes = (size_t)d->cout * d->cin * d->r * d->s * 2;
-    if (xin >= ((size_t)1 << 31) || wbytes >= ((size_t)1 << 31)) return false;
+    if (xin1 >= ((size_t)1 << 30) || wbytes >= ((size_t)1 << 31)) return false;
+    if ((size_t)d->n * xin1 >= slice_limit() && batch_slice(d, op) <= 0) return false;
     if (op == 1) {
         if (d->stride_h == 1 && d->stride_w == 1) {
             if (d->dil_h * (d->r - 1) < d->pad_h || d->dil_w * (d->s - 1) < d->pad_w) return false;
@@ -1463,9 +1482,28 @@ int dcv_conv2d_bf16_fwd(const dcv_conv2d_desc* d, const void* x, const void* fil
     a.N = d->n; a.Hin = d->h; a.Win = d->w; a.Cin = d->cin; a.Hout = d->ho; a.Wout = d->wo; a.Cout = d->cout;
     a.R = d->r; a.S = d->s; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
     a.act = d->act; a.slope = d->act_slope; a.M = (long)d->n * d->ho * d->wo;
-    a.x_bytes = (unsigned)((size_t)d->n * d->h * d->w * d->cin * 2); a.w_bytes = (unsigned)((size_t)d->cout * d->cin * d->r * d->s * 2);
+    a.w_bytes = (unsigned)((size_t)d->cout * d->cin * d->r * d->s * 2);
     const u16* xs = reinterpret_cast<const u16*>(x); const u16* ws = reinterpret_cast<const u16*>(filter);
-    return y_dtype == DCV_DTYPE_BF16 ? launch<true>(a, xs, ws, bias, y, stats, dcv_stream(stream)) : launch<false>(a, xs, ws, bias, y, stats, dcv_stream(stream));
+    const size_t in1 = (size_t)d->h * d->w * d->cin, out1 = (size_t)d->ho * d->wo * d->cout;      // elements per sample
+    if ((size_t)d->n * in1 * 2 < slice_limit()) {
+        a.x_bytes = (unsigned)((size_t)d->n * in1 * 2);
+        return y_dtype == DCV_DTYPE_BF16 ? launch<true>(a, xs, ws, bias, y, stats, dcv_stream(stream)) : launch<false>(a, xs, ws, bias, y, stats, dcv_stream(stream));
+    }
+    // the batch in slices (batch_slice): same kernels, the slices' statistics rows side by side in the one array dcv_conv2d_bf16_fwd_stats_layout describes
+    const int ns = batch_slice(d, 0);
+    if (ns <= 0) return DCV_ERR_UNSUPPORTED;
+    const int rows_total = (int)dcv_ceil_div((size_t)d->n * d->ho * d->wo, BF_BM);
+    const size_t yel = y_dtype == DCV_DTYPE_BF16 ? 2 : 4;
+    for (int n0 = 0; n0 < d->n; n0 += ns) {
+        const int nn = d->n - n0 < ns ? d->n - n0 : ns;
+        Bf16Args s = a;
+        s.N = nn; s.M = (long)nn * d->ho * d->wo; s.x_bytes = (unsigned)((size_t)nn * in1 * 2);
+        s.stat_rows = rows_total; s.stat_row0 = (int)((size_t)n0 * d->ho * d->wo / BF_BM);
+        void* ys = reinterpret_cast<char*>(y) + (size_t)n0 * out1 * yel;
+        const int rc = y_dtype == DCV_DTYPE_BF16 ? launch<true>(s, xs + (size_t)n0 * in1, ws, bias, ys, stats, dcv_stream(stream)) : launch<false>(s, xs + (size_t)n0 * in1, ws, bias, ys, stats, dcv_stream(stream));
+        if (rc != DCV_OK) return rc;
+    }
+    return DCV_OK;
 }
 
 int dcv_conv2d_bf16_dgrad(const dcv_conv2d_desc* d, const void* dy, const void* filter, void* dx, int dx_dtype, void* stream) {
@@ -1474,6 +1512,18 @@ int dcv_conv2d_bf16_dgrad(const dcv_conv2d_desc* d, const void* dy, const void* 
     DCV_CHECK_ARG(aligned16(dy) && aligned16(filter) && aligned16(dx));
     hipStream_t st = dcv_stream(stream);
     const u16* dys = reinterpret_cast<const u16*>(dy); const u16* ws = reinterpret_cast<const u16*>(filter);
+    if ((size_t)d->n * d->ho * d->wo * d->cout * 2 >= slice_limit()) {      // the batch in slices (batch_slice)
+        const int ns = batch_slice(d, 1);
+        if (ns <= 0) return DCV_ERR_UNSUPPORTED;
+        const size_t in1 = (size_t)d->ho * d->wo * d->cout, out1 = (size_t)d->h * d->w * d->cin, oel = dx_dtype == DCV_DTYPE_BF16 ? 2 : 4;
+        for (int n0 = 0; n0 < d->n; n0 += ns) {
+            dcv_conv2d_desc ds = *d;
+            ds.n = d->n - n0 < ns ? d->n - n0 : ns;
+            const int rc = dcv_conv2d_bf16_dgrad(&ds, dys + (size_t)n0 * in1, filter, reinterpret_cast<char*>(dx) + (size_t)n0 * out1 * oel, dx_dtype, stream);
+            if (rc != DCV_OK) return rc;
+        }
+        return DCV_OK;
+    }
     Bf16Args a{};
     a.N = d->n; a.Hin = d->ho; a.Win = d->wo; a.Cin = d->cout; a.Cout = d->cin;
     a.sh = 1; a.sw = 1; a.dh = d->dil_h; a.dw = d->dil_w; a.act = DCV_ACT_NONE; a.slope = 0.f;
@@ -1533,7 +1583,7 @@ int dcv_im2col_bf16(const dcv_conv2d_desc* d, const float* x, void* out, int kpa
     const int K = d->cin * d->r * d->s;
     if (d->groups != 1 || kpad < K || kpad > DCV_IM2COL_MAX_K || kpad % 64 != 0) return DCV_ERR_UNSUPPORTED;
     const size_t M = (size_t)d->n * d->ho * d->wo;
-    if ((size_t)d->cin * d->h * d->w >= ((size_t)1 << 31) || M * (size_t)kpad >= ((size_t)1 << 31)) return DCV_ERR_UNSUPPORTED;      // 32-bit item and element indices
+    if ((size_t)d->cin * d->h * d->w >= ((size_t)1 << 31) || M >= ((size_t)1 << 31)) return DCV_ERR_UNSUPPORTED;      // 32-bit indices inside an image and of pixels (the matrix itself is addressed in 64 bits: 2.5 GB for the resnet18_style stem at bs 512)
     Im2colArgs a{};
     a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Ho = d->ho; a.Wo = d->wo; a.R = d->r; a.S = d->s; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w;
     a.dh = d->dil_h; a.dw = d->dil_w; a.K = K; a.kpad = kpad; a.M = (unsigned)M; a.nchw = d->x_layout == DCV_LAYOUT_NCHW ? 1 : 0;

@@ -186,8 +186,6 @@ def _stem_as_gemm(x, weight, stride, padding, dilation):
     else:
         return None
     d = _conv_desc(x.shape, weight.shape, _pair(stride), _pair(padding), _pair(dilation), layout, nat.ACT_NONE, 0.)
-    if d.n * d.ho * d.wo * kpad * 2 >= (1 << 31):          # (the bf16 kernels index their tensors with 32-bit byte offsets)
-        return None
     d1 = _conv_desc((d.n, kpad, d.ho, d.wo), (cout, kpad, 1, 1), (1, 1), (0, 0), (1, 1), nat.LAYOUT_NHWC, nat.ACT_NONE, 0.)
     if not (lib.dcv_conv2d_bf16_supported(d1, 0) and lib.dcv_conv2d_bf16_supported(d1, 2)):
         return None

@@ -366,3 +366,52 @@ def test_bf16_pooling_and_add_equal_the_widened_fp32_path(device, mode, kernel, 
     assert s16.dtype == torch.bfloat16 and torch.equal(s16, (a.float() + b.float()).to(torch.bfloat16))
     odd = torch.randn(1003, device=device).to(torch.bfloat16)
     assert torch.equal(ops.add_tensors([odd, odd]), (odd.float() * 2).to(torch.bfloat16))
+
+
+def test_batch_slices_equal_the_whole_batch(device, tmp_path):
+    """ Tensors beyond 2 GiB (the im2col matrix of the resnet18_style stem at the metric's 512 images per GPU: 2.5 GB) run as slices of the batch through the same
+    kernels (`batch_slice`, conv2d_bf16.hip).  `DCV_BF16_SLICE_BYTES` forces the slicing at a small size in a child process; its forward (output AND statistics
+    rows), data gradient and the model-level result must equal the unsliced run of this process bit for bit. """
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / 'slices.py'
+    out = {}
+    script.write_text("""
+import ctypes, sys, torch
+sys.path.insert(0, %r)
+from deepcv_amd import _native as nat
+lib = nat.lib
+dev = torch.device('cuda:0')
+torch.manual_seed(3)
+res = {}
+for (n, cin, h, cout, k, pad) in ((12, 64, 16, 128, 1, 0), (10, 128, 16, 64, 3, 1)):
+    d = nat.Conv2dDesc(n, h, h, cin, cout, k, k, 1, 1, pad, pad, 1, 1, 1, h, h, nat.LAYOUT_NHWC, nat.ACT_RELU, 0., nat.MATH_BF16)
+    st = nat.current_stream(dev)
+    x = torch.randn(n, cin, h, h).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).to(dev)
+    dy = torch.randn(n, cout, h, h).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).to(dev)
+    wt = (torch.randn(cout, cin, k, k) * 0.05).to(dev); b = torch.randn(cout).to(dev)
+    fs = []
+    for op in (0, 1):
+        f = torch.empty(int(lib.dcv_conv2d_bf16_filter_bytes(d, op)), dtype=torch.uint8, device=dev)
+        nat.check(lib.dcv_conv2d_bf16_prepare_filters(1, (ctypes.POINTER(nat.Conv2dDesc) * 1)(ctypes.pointer(d)), (ctypes.c_int * 1)(op), (ctypes.c_void_p * 1)(wt.data_ptr()), (ctypes.c_void_p * 1)(f.data_ptr()), st))
+        fs.append(f)
+    rows, rps = ctypes.c_int(0), ctypes.c_int(0)
+    lib.dcv_conv2d_bf16_fwd_stats_layout(d, ctypes.byref(rows), ctypes.byref(rps))
+    stats = torch.zeros((2, cout, rows.value), dtype=torch.float64, device=dev)
+    y = torch.empty((n, cout, h, h), dtype=torch.bfloat16, device=dev).contiguous(memory_format=torch.channels_last)
+    nat.check(lib.dcv_conv2d_bf16_fwd(d, x.data_ptr(), fs[0].data_ptr(), b.data_ptr(), y.data_ptr(), nat.DTYPE_BF16, stats.data_ptr(), st))
+    dx = torch.empty((n, cin, h, h), dtype=torch.bfloat16, device=dev).contiguous(memory_format=torch.channels_last)
+    nat.check(lib.dcv_conv2d_bf16_dgrad(d, dy.data_ptr(), fs[1].data_ptr(), dx.data_ptr(), nat.DTYPE_BF16, st))
+    torch.cuda.synchronize()
+    res[(n, cin, h, cout, k)] = (y.float().cpu(), stats.cpu(), dx.float().cpu())
+torch.save(res, sys.argv[1])
+""" % str(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    for tag, env in (('whole', {}), ('sliced', {'DCV_BF16_SLICE_BYTES': str(64 * 16 * 16 * 2 * 5)})):      # 5 samples of the first case per launch (4 fit the pixel-count rule), 2 of the second
+        path = tmp_path / f'{tag}.pt'
+        subprocess.run([sys.executable, str(script), str(path)], check=True, env={**os.environ, **env}, timeout=300)
+        out[tag] = torch.load(path, weights_only=True)
+    for key, (y, stats, dx) in out['whole'].items():
+        y2, stats2, dx2 = out['sliced'][key]
+        assert torch.equal(y, y2) and torch.equal(dx, dx2), key
+        assert torch.allclose(stats, stats2, rtol=1e-12, atol=0), key      # (the window kernel sums a row's two halves per tile: same values, slices only move tile seams to multiples of 128 pixels)
