@@ -1095,6 +1095,38 @@ __global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const uint2* __restr
     if (blockIdx.x == 0 && (int)threadIdx.x < tail) yt[threadIdx.x] = __uint_as_float((unsigned)xt[threadIdx.x] << 16);
 }
 
+// ------------------------------------------------------------------------------------------------ weight gradient of the layers the all-taps kernels do not plan
+// (round 4: the 3x3 / stride 2 layers of resnet18_style ran their weight gradient per tap on fp32 copies of x and dz — conv_mfma_wgrad_kernel<true>, 539 us a layer
+// at bs 512 plus two cast launches, 9 % of the step).  Here x is gathered ONCE into the bf16 matrix [n ho wo][taps cin] (tap-major, the input channels of a tap
+// contiguous: 16-byte pieces), the weight gradient then is the plain GEMM dW[co][tap cin] = sum over pixels of dz[pix][co] xcol[pix][tap cin] on the one-tap instance
+// of the all-taps kernel, and the ordered slab sum transposes [co][tap][ci] into OIHW.
+struct ColArgs { int H, W, Cin, Ho, Wo, R, S, sh, sw, ph, pw, dh, dw; };
+__global__ __launch_bounds__(256) void gather_cols_bf16_kernel(ColArgs a, const uint4* __restrict__ x, uint4* __restrict__ out) {
+    // block = one output row (n, ho): pieces (wo, tap, 8 channels); x and out as 16-byte pieces
+    const int ho = blockIdx.x % a.Ho, n = blockIdx.x / a.Ho;
+    const int c8 = a.Cin >> 3, taps = a.R * a.S, per_pix = taps * c8, total = a.Wo * per_pix;
+    const uint4* xn = x + (size_t)n * a.H * a.W * c8;
+    uint4* orow = out + ((size_t)n * a.Ho + ho) * a.Wo * per_pix;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int wo = i / per_pix, r1 = i - wo * per_pix, tap = r1 / c8, c = r1 - tap * c8;
+        const int r = tap / a.S, sx = tap - r * a.S;
+        const int hi = ho * a.sh - a.ph + r * a.dh, wi = wo * a.sw - a.pw + sx * a.dw;
+        const bool ok = hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+        const uint4 v = xn[ok ? ((size_t)hi * a.W + wi) * c8 + c : 0];               // (unconditional load: no branch per piece)
+        orow[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+// dw[co][ci][tap] = sum over chunks of partial[chunk][co][tap][ci], chunks in order
+__global__ __launch_bounds__(256) void col_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int chunks, int Cout, int Cin, int taps) {
+    const size_t wtotal = (size_t)Cout * Cin * taps;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;                          // index in the slab's order: consecutive threads read consecutive words
+    if (e >= wtotal) return;
+    float sum = 0.f;
+    for (int c = 0; c < chunks; ++c) sum += partial[(size_t)c * wtotal + e];
+    const int ci = (int)(e % Cin); const size_t r1 = e / Cin; const int tap = (int)(r1 % taps), co = (int)(r1 / taps);
+    dw[((size_t)co * Cin + ci) * taps + tap] = sum;
+}
+
 struct PhaseAxis { int r0, taps, pad, count; };
 inline PhaseAxis phase_axis(int a, int size, int R, int stride, int pad) {
     PhaseAxis p{};
@@ -1324,12 +1356,29 @@ __global__ __launch_bounds__(256) void im2col_bf16_kernel(Im2colArgs a, const fl
     }
 }
 
+// the gathered-matrix weight gradient's plan: the layer as a 1x1 layer over [n][ho][wo][taps cin]
+inline bool col_plan(const dcv_conv2d_desc* d, dcv_conv2d_desc* d1, W16Args* a, int* chunks, size_t* smem, int* groups, size_t* col_bytes) {
+    static int enabled = -1;
+    if (enabled < 0) { const char* e = getenv("DCV_BF16_WGRAD_COL"); enabled = e ? atoi(e) : 1; }
+    if (!enabled || !desc_ok(d) || d->groups != 1 || d->x_layout != DCV_LAYOUT_NHWC) return false;
+    const int taps = d->r * d->s;
+    if (taps < 2 || taps > 25 || d->cin % 64 != 0 || d->cout % 64 != 0) return false;
+    const size_t cb = (size_t)d->n * d->ho * d->wo * taps * d->cin * 2;
+    if (cb > ((size_t)6 << 30) || (size_t)d->h * d->w * d->cin * 2 >= ((size_t)1 << 31)) return false;
+    *d1 = *d;
+    d1->h = d->ho; d1->w = d->wo; d1->cin = taps * d->cin; d1->r = d1->s = 1; d1->stride_h = d1->stride_w = 1; d1->pad_h = d1->pad_w = 0; d1->dil_h = d1->dil_w = 1;
+    if (!w16_plan(d1, a, chunks, smem, groups)) return false;
+    *col_bytes = dcv_align_up(cb, 256);
+    return true;
+}
+
 extern "C" {
 
 int dcv_conv2d_bf16_supported(const dcv_conv2d_desc* d, int op) {
     if (op == 2) {
-        W16Args a{}; W16pArgs ap{}; int chunks, groups; size_t smem;
-        return (desc_ok(d) && (dcv_mfma_conv2d_wgrad_in16_supported(d) || w16_plan(d, &a, &chunks, &smem, &groups) || w16p_plan(d, &ap, &chunks, &smem, &groups))) ? 1 : 0;
+        W16Args a{}; W16pArgs ap{}; int chunks, groups; size_t smem, cb; dcv_conv2d_desc d1;
+        return (desc_ok(d) && (dcv_mfma_conv2d_wgrad_in16_supported(d) || w16_plan(d, &a, &chunks, &smem, &groups) || w16p_plan(d, &ap, &chunks, &smem, &groups) ||
+                               col_plan(d, &d1, &a, &chunks, &smem, &groups, &cb))) ? 1 : 0;
     }
     return (op == 0 || op == 1) && supported(d, op) ? 1 : 0;
 }
@@ -1341,6 +1390,8 @@ size_t dcv_conv2d_bf16_wgrad_workspace_bytes(const dcv_conv2d_desc* d) {
     if (w16_plan(d, &a, &chunks, &smem, &groups)) { const size_t n16 = dcv_align_up((size_t)chunks * a.wtotal * sizeof(float), 256); if (n16 > need) need = n16; }
     W16pArgs ap{};
     if (w16p_plan(d, &ap, &chunks, &smem, &groups)) { const size_t n16 = dcv_align_up((size_t)chunks * ap.wtotal * sizeof(float), 256); if (n16 > need) need = n16; }
+    dcv_conv2d_desc d1; size_t cb;
+    if (need == 0 && col_plan(d, &d1, &a, &chunks, &smem, &groups, &cb)) need = cb + dcv_align_up((size_t)chunks * a.wtotal * sizeof(float), 256);
     return need;
 }
 
@@ -1399,6 +1450,30 @@ int dcv_conv2d_bf16_wgrad(const dcv_conv2d_desc* d, const void* x, const void* d
         if (hipGetLastError() != hipSuccess) return DCV_ERR_LAUNCH;
         if (one) return dcv_mfma_wgrad_reduce_plain(partial, dw, chunks, a.wtotal, dcv_stream(stream));      // slabs [co][ci] = dw's own order
         return dcv_mfma_wgrad9_reduce(partial, dw, chunks, d->cout, d->cin, dcv_stream(stream));
+    }
+    if (!dcv_mfma_conv2d_wgrad_in16_supported(d)) {
+        dcv_conv2d_desc d1; size_t cb;
+        if (!col_plan(d, &d1, &a, &chunks, &smem, &groups, &cb)) return DCV_ERR_UNSUPPORTED;
+        if (!ws || ws_bytes < cb + (size_t)chunks * a.wtotal * sizeof(float)) return DCV_ERR_WORKSPACE;
+        DCV_CHECK_ARG(aligned16(x) && aligned16(dy) && aligned16(ws));
+        u16* xcol = reinterpret_cast<u16*>(ws);
+        float* partial = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + cb);
+        const ColArgs ca{d->h, d->w, d->cin, d->ho, d->wo, d->r, d->s, d->stride_h, d->stride_w, d->pad_h, d->pad_w, d->dil_h, d->dil_w};
+        hipLaunchKernelGGL(gather_cols_bf16_kernel, dim3((unsigned)(d->n * d->ho)), dim3(256), 0, dcv_stream(stream), ca, reinterpret_cast<const uint4*>(x), reinterpret_cast<uint4*>(xcol));
+        dim3 grid((unsigned)chunks, (unsigned)(d1.cin / 64), (unsigned)(d1.cout / 64));
+        if (grid.y > 65535 || grid.z > 65535) return DCV_ERR_UNSUPPORTED;
+        static bool cconf = false;
+        if (!cconf) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_wgrad9_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_wgrad9_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DCV_ERR_LAUNCH;
+            cconf = true;
+        }
+        dcv_count_launch(DCV_FAMILY_BF16_WGRAD9);
+        const u16* dys = reinterpret_cast<const u16*>(dy);
+        if (groups == 2) hipLaunchKernelGGL((conv_bf16_wgrad9_kernel<2, 1>), grid, dim3(512), smem, dcv_stream(stream), a, xcol, dys, partial);
+        else hipLaunchKernelGGL((conv_bf16_wgrad9_kernel<1, 1>), grid, dim3(256), smem, dcv_stream(stream), a, xcol, dys, partial);
+        hipLaunchKernelGGL(col_wgrad_reduce_kernel, dim3((unsigned)dcv_ceil_div(a.wtotal, 256)), dim3(256), 0, dcv_stream(stream), partial, dw, chunks, d->cout, d->cin, d->r * d->s);
+        DCV_RETURN_LAUNCH();
     }
     dcv_count_launch(DCV_FAMILY_BF16_WGRAD_TAP);
     return dcv_mfma_conv2d_wgrad_in16(d, x, dy, dw, ws, ws_bytes, dcv_stream(stream));

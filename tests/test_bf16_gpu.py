@@ -154,7 +154,7 @@ def test_bf16_data_and_weight_gradients(device, case):
     else:
         assert dil != 1 and stride != 1
     if lib.dcv_conv2d_bf16_supported(d, 2):
-        assert k == 3 and stride == 1 and pad == 1 and dil == 1
+        # (the all-taps kernels: 3x3 / stride 1 / pad 1; round 4: every other multi-tap layer through the gathered matrix [n ho wo][taps cin] + the one-tap kernel)
         ws = torch.empty(int(lib.dcv_conv2d_bf16_wgrad_workspace_bytes(d)), dtype=torch.uint8, device=device)
         dw = torch.full((cout, cin, k, k), float('nan'), device=device)
         nat.check(lib.dcv_conv2d_bf16_wgrad(d, xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), st), 'wgrad')
