@@ -66,7 +66,7 @@ def _cpu_model() -> str:
     return platform.processor() or 'unknown'
 
 
-def cpu_baseline(params, budget_s: float = 24.0):
+def cpu_baseline(params, budget_s: float = 22.0):
     """ The oracle (torch CPU ops composed like the reference) timed on this box's host cores: same spec, batch size, optimizer and schedule:
     an all-cores figure (every core this process may use, at most the pool's 16-core share of a 1-GPU slot; `DCV_CPU_THREADS` overrides) and a 1-thread figure,
     each the MEDIAN of 5 repeats of a bounded number of steps after warm-up steps; CPU model and core counts on the record.  Baseline only. """
@@ -77,9 +77,9 @@ def cpu_baseline(params, budget_s: float = 24.0):
         avail = os.cpu_count() or 1
     share = max(1, min(avail, int(os.environ.get('DCV_CPU_THREADS', '16'))))
     hp = dict(params['train_image_classifier'])
-    batches = _make_batches(4, BATCH_PER_GPU, DATA_SEED)
 
-    def measure(threads: int, budget: float):
+    def measure(threads: int, budget: float, bs: int = BATCH_PER_GPU, max_steps: int = 10):
+        batches = _make_batches(4, bs, DATA_SEED)
         torch.set_num_threads(threads)
         torch.manual_seed(MODEL_SEED)
         model = O.create_model(IMAGE_SHAPE, params['image_classifier_model'], NUM_CLASSES)
@@ -88,22 +88,25 @@ def cpu_baseline(params, budget_s: float = 24.0):
         O.process_step(model, opt, *batches[0])
         O.process_step(model, opt, *batches[1])
         per_step = (time.perf_counter() - t0) / 2
-        steps = max(2, min(10, int(budget / 5 / max(per_step, 1e-3))))      # steps per repeat: 5 repeats within the budget
+        steps = max(2, min(max_steps, int(budget / 5 / max(per_step, 1e-3))))      # steps per repeat: 5 repeats within the budget
         rates, i = [], 2
         for _ in range(5):
             t0 = time.perf_counter()
             for _ in range(steps):
                 O.process_step(model, opt, *batches[i % 4]); i += 1
-            rates.append(steps * BATCH_PER_GPU / (time.perf_counter() - t0))
+            rates.append(steps * bs / (time.perf_counter() - t0))
         rates.sort()
         return rates[2], steps, rates
-    all_cores, steps_a, rates_a = measure(share, budget_s * 0.55)
-    one, steps_1, rates_1 = measure(1, budget_s * 0.45)
+    all_cores, steps_a, rates_a = measure(share, budget_s * 0.45)
+    one, steps_1, rates_1 = measure(1, budget_s * 0.35)
+    bs64, steps_64, rates_64 = measure(share, budget_s * 0.2, bs=64, max_steps=40)      # BASELINE.json configs[0]: the reference's own CPU-runnable case
     torch.set_num_threads(share)
     return {'value': round(all_cores, 1), 'unit': 'images/sec', 'cores': share, 'kind': 'port',
             'sample': f'median of 5 repeats of {steps_a} training steps of batch {BATCH_PER_GPU} of the PyTorch-CPU oracle (oracle/deepcv_oracle.py), AdamW, fp32, after 2 warm-up steps',
             'repeats': [round(r, 1) for r in rates_a],
             'one_thread': {'value': round(one, 1), 'unit': 'images/sec', 'cores': 1, 'sample': f'median of 5 repeats of {steps_1} steps', 'repeats': [round(r, 1) for r in rates_1]},
+            'batch_64': {'value': round(bs64, 1), 'unit': 'images/sec', 'cores': share, 'sample': f'BASELINE.json configs[0] (bs 64): median of 5 repeats of {steps_64} steps',
+                         'repeats': [round(r, 1) for r in rates_64]},
             'cpu_model': _cpu_model(), 'os_cpu_count': os.cpu_count(), 'usable_cores': avail,
             'threads_note': f'{share} threads = the cores this process may use (affinity {avail}), capped at the 16-core host share of a 1-GPU slot of this pool'}
 
@@ -251,7 +254,7 @@ def _time_launches(fn, launches: int, warm: int = 5) -> float:
     return e0.elapsed_time(e1) * 1e3 / launches
 
 
-def secondary_measurements(device, params, launches: int = 20):
+def secondary_measurements(device, params, launches: int = 20, legacy_bf16_operands: bool = False):
     """ North-star MFMA target on the record (never the headline): per-kernel TFLOP/s of the wide 3x3 convolutions of `cifar100_deep` at N = 512 through the
     C-ABI (fp32 MFMA; fraction of 157.3 TFLOP/s) and whole-step images/s of the two wide specs (fwd + CE + bwd + SGD-momentum, fp32 and bf16 MFMA math). """
     from deepcv_amd import _native as nat
@@ -266,7 +269,8 @@ def secondary_measurements(device, params, launches: int = 20):
         wt = torch.randn(cin, cin, k, k, device=device) * 0.05
         b, dw = torch.zeros(cin, device=device), torch.empty_like(wt)
         flops = 2.0 * n * hw * hw * cin * cin * k * k
-        for math, peak in ((nat.MATH_FP32, MFMA_F32_PEAK_TF), (nat.MATH_BF16, MFMA_BF16_PEAK_TF)):
+        # (`bf16-operands`: the fp32-storage kernels with operands rounded in registers — not what configs 3 / 5 run since round 2; only with --legacy-bf16-operands)
+        for math, peak in ((nat.MATH_FP32, MFMA_F32_PEAK_TF), (nat.MATH_BF16, MFMA_BF16_PEAK_TF)) if legacy_bf16_operands else ((nat.MATH_FP32, MFMA_F32_PEAK_TF),):
             d = nat.Conv2dDesc(n, hw, hw, cin, cin, k, k, 1, 1, 1, 1, 1, 1, 1, hw, hw, nat.LAYOUT_NHWC, nat.ACT_RELU, 0., math)
             dd = nat.Conv2dDesc.from_buffer_copy(d)
             ws = torch.empty(max(16, nat.lib.dcv_conv2d_fwd_workspace_bytes(d), nat.lib.dcv_conv2d_dgrad_workspace_bytes(dd), nat.lib.dcv_conv2d_wgrad_workspace_bytes(d)),
@@ -336,41 +340,66 @@ def _wide_model_steps(device, params):
     from deepcv_amd.meta.data.datasets import SyntheticImageDataset
     from deepcv_amd.meta.ignite_training import GraphedTrainStep, _setup_losses
     res = []
-    # resnet18_style: bs 64 (round-to-round comparison) and bs 256 in bf16 — the metric's 512 per GPU does not fit this path's 32-bit byte offsets (the bf16
-    # kernels index a tensor below 2 GiB: 512 x 64 x 112 x 112 x 2 B = 0.8 GB fits, the stem's im2col matrix 512 x 12544 x 192 x 2 B = 2.5 GB does not) and the
-    # deferred weight gradients keep every layer's x and dz alive until the flush
+    # Each wide spec in the step mode `train()` selects for it (`deepcv_amd/meta/ignite_training.py`: a captured step below 5 M parameters — cifar100_deep —, the eager
+    # step with autograd hooks above — resnet18_style, 11.5 M) AND in the other one, labelled.  resnet18_style: bs 64 (round-to-round comparison) and, since round 4,
+    # the metric's 512 images per GPU in bf16 (tensors beyond 2 GiB — the stem's 2.5 GB im2col matrix — run as slices of the batch, conv2d_bf16.hip `batch_slice`).
     for spec, shape, nc, bs, maths in (('cifar100_deep_model', (3, 32, 32), 100, 512, ('fp32', 'bf16')), ('resnet18_style_model', (3, 224, 224), 1000, 64, ('fp32', 'bf16')),
-                                       ('resnet18_style_model', (3, 224, 224), 1000, 256, ('bf16',))):
+                                       ('resnet18_style_model', (3, 224, 224), 1000, 512, ('bf16',))):
         for math in maths:
             prev = ops.set_conv_math(math)
             try:
                 torch.manual_seed(MODEL_SEED)
                 model = create_model({'trainset': SyntheticImageDataset(2, shape, nc)}, params[spec]).to(device)
+                trains_captured = sum(p.numel() for p in model.parameters()) < 5_000_000
                 opt = optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=5e-4)
                 losses, weights = _setup_losses(modules.CrossEntropyLoss(), None, device)
                 step = GraphedTrainStep(model, opt, losses, weights)
                 g = torch.Generator().manual_seed(DATA_SEED)
                 batches = [(torch.randn(bs, *shape, generator=g).to(device), torch.randint(0, nc, (bs,), generator=g).to(device)) for _ in range(2)]
 
-                def one(i):
-                    step(*batches[i % 2])                                  # eager first step, capture, then hipGraph replays (as `train()` runs a model of this size)
+                def one_captured(i):
+                    step(*batches[i % 2])                                  # eager first step, capture, then replays
                     return step.loss_values()['main_loss']
-                for i in range(4):
-                    one(i)
-                torch.cuda.synchronize()
-                t0, k = time.perf_counter(), 8
-                for i in range(k):
-                    last = one(i)
-                torch.cuda.synchronize()
-                dt = time.perf_counter() - t0
-                res.append({'kind': 'model', 'workload': f'{spec} {shape[0]}x{shape[1]}x{shape[2]} bs={bs}: fwd + CE + bwd + SGD-momentum, captured step (hipGraph replay), per-step loss read-back',
-                            'math': 'f32' if math == 'fp32' else 'bf16-storage (bf16 activations / gradients / prepared filters in HBM, fp32 accumulate, statistics and master weights)',
-                            'value': round(bs * k / dt, 1), 'unit': 'images/sec', 'ms_per_step': round(dt / k * 1e3, 3), 'final_loss': round(last, 4)})
+
+                def one_eager(i):
+                    out, _ = step._on_side_stream(step._eager, *batches[i % 2])
+                    return out['main_loss'].item()
+                for mode, one in (('eager', one_eager), ('captured', one_captured)):
+                    for i in range(4):
+                        one(i)
+                    torch.cuda.synchronize()
+                    t0, k = time.perf_counter(), 8
+                    for i in range(k):
+                        last = one(i)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                    default = (mode == 'captured') == trains_captured
+                    res.append({'kind': 'model', 'workload': f'{spec} {shape[0]}x{shape[1]}x{shape[2]} bs={bs}: fwd + CE + bwd + SGD-momentum, per-step loss read-back',
+                                'step_mode': ('captured step (hipGraph / launch-list replay)' if mode == 'captured' else 'eager step (autograd hooks)') + (': the mode train() selects for this spec' if default else ''),
+                                'train_default': default,
+                                'math': 'f32' if math == 'fp32' else 'bf16-storage (bf16 activations / gradients / prepared filters in HBM, fp32 accumulate, statistics and master weights)',
+                                'value': round(bs * k / dt, 1), 'unit': 'images/sec', 'ms_per_step': round(dt / k * 1e3, 3), 'final_loss': round(last, 4)})
                 del model, opt, step, batches
             finally:
                 ops.set_conv_math(prev)
             torch.cuda.empty_cache()
     return res
+
+
+def config3_roofline(secondary):
+    """ `roofline`-style entry for BASELINE config 3's dominant kernel: the bf16 3x3 window kernel (`conv_bf16_halo_kernel`, deepcv_amd/csrc/conv2d_bf16.hip) at the
+    shape the round-3 verdict names, 256 -> 256 @16x16, N = 512: FLOPs per launch (2 N H W Cout Cin 9) / the live HIP-event average of the C-ABI
+    call (one launch per call) against the 2.5 PFLOP/s dense bf16 MFMA peak; `also`: the other bf16 entries of the secondary list.  The rocprofv3 average of the same
+    kernel: profiles/r04_bf16_kernel_stats.csv; matrix-pipe busy (PMC): profiles/r04_pmc_bf16.json. """
+    rows = [r for r in secondary if r.get('kind') == 'kernel' and r.get('math') == 'bf16-storage']
+    pick = [r for r in rows if '256->256 @16x16' in r['op'] and r['op'].endswith('fwd')]
+    if not pick:
+        return None
+    r = pick[0]
+    return {'bound': 'mfma', 'kernel': 'conv_bf16_halo_kernel<2, bf16 out> (dcv_conv2d_bf16_fwd: 3x3 window kernel, 256 -> 256 @16x16, N = 512, statistics epilogue on)',
+            'achieved': r['achieved'], 'peak': MFMA_BF16_PEAK_TF, 'unit': 'TFLOP/s', 'frac': r['frac'], 'traffic': None, 'avg_launch_us': r['avg_launch_us'],
+            'algorithmic_flops_per_launch': 2.0 * BATCH_PER_GPU * 16 * 16 * 256 * 256 * 9,
+            'also': [{'op': q['op'], 'achieved': q['achieved'], 'frac': q['frac'], 'avg_launch_us': q['avg_launch_us']} for q in rows if q is not r]}
 
 
 def main():
@@ -385,6 +414,7 @@ def main():
     ap.add_argument('--native-allreduce', action='store_true', help="the library's one-shot all-reduce (dcv_allreduce_*) instead of RCCL for the gradient bucket (also DCV_NATIVE_ALLREDUCE=1)")
     ap.add_argument('--no-secondary', action='store_true', help='skip the wide-kernel / wide-model secondary measurements')
     ap.add_argument('--no-parity', action='store_true', help='skip the oracle replay of the first steps')
+    ap.add_argument('--legacy-bf16-operands', action='store_true', help='secondary list: also time the fp32-storage kernels in their operand-rounding bf16 mode')
     args = ap.parse_args()
     if os.environ.get('DCV_BENCH_WATCHDOG_S'):            # diagnostics: dump every thread's stack and exit if the run is still alive after that many seconds
         import faulthandler
@@ -494,7 +524,8 @@ def main():
         if not args.no_parity:
             result['parity'] = parity_check(params, first_losses, total_iters, world)
         if world == 1 and not args.no_secondary and not args.force_dp:
-            result['secondary'] = secondary_measurements(device, params)
+            result['secondary'] = secondary_measurements(device, params, legacy_bf16_operands=args.legacy_bf16_operands)
+            result['roofline_config3'] = config3_roofline(result['secondary'])
         print(json.dumps(result), flush=True)
         if world == 1 and not args.no_parity and not result['parity']['pass']:
             parity_failed = True

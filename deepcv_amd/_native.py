@@ -306,8 +306,9 @@ class LaunchRecorder:
     def __init__(self, stream: int):
         self.stream, self.calls = stream, []
 
-    def replay(self, stream: int):
-        for fn, args, k in self.calls:
+    def replay(self, stream: int, first: int = 0, last: Optional[int] = None):
+        """ Re-issues calls [first, last) (default: all) on `stream`. """
+        for fn, args, k in (self.calls if (first == 0 and last is None) else self.calls[first:last]):
             rc = fn(*args[:k], stream, *args[k + 1:])
             if rc != 0:
                 check(rc, f'replayed {fn.__name__}')

@@ -176,6 +176,10 @@ class GraphedTrainStep:
         self._replay_list = os.environ.get('DCV_REPLAY_LIST', '1') not in ('0', 'false', 'False')
         self._launch_list = None
         self._launch_list_opt = None         # with a data-parallel reducer whose collective runs between two graphs: the optimizer graph's launches
+        # a multi-bucket reducer: [(bucket index, number of the step's launches issued when the captured backward had produced the bucket's last gradient)] — a
+        # launch-list replay starts each bucket's collective there, on the communication stream (round 4: DDP's overlap, reference ignite_training.py:380, for
+        # captured steps; until then only the eager step's autograd hooks overlapped)
+        self._marks: List[Tuple[int, int]] = []
         self._list_verified = False
         self._staged_prog = None             # the forward program which stages the batch (launch-list replays hand it the batch's address directly)
         self._job0_src = None
@@ -348,6 +352,7 @@ class GraphedTrainStep:
         self._mailbox_write(x, y)
         self.optimizer.zero_grad(set_to_none=True)
         hooks_were = None
+        self._marks = []
         if self.reducer is not None:
             hooks_were, self.reducer.enabled = self.reducer.enabled, False     # no collectives inside the captured backward
         self._seed = torch.ones((), dtype=torch.float32, device=dev)
@@ -365,6 +370,10 @@ class GraphedTrainStep:
         # below could not tell whenever the ranks' gradients happen to be equal, e.g. in a group of one)
         rccl_in_graph = self.reducer is not None and self.graph_collective and self.reducer.capturable() and not self.reducer.native_active()
         recorder = self._nat.LaunchRecorder(self.stream.cuda_stream) if (self._replay_list and not rccl_in_graph) else None
+        segmented = (recorder is not None and self.reducer is not None and len(self.reducer.buckets) > 1 and self.reducer.overlap
+                     and not (self.reducer.capturable() and (self.graph_collective or self.reducer.native_active())))
+        if segmented:
+            self.reducer.mark_ready = lambda b: self._marks.append((self.reducer.buckets.index(b), len(recorder.calls)))
         with self._nat.recording(recorder), torch.cuda.graph(self.graph_fb, stream=self.stream, capture_error_mode=capture_mode):
             if stage_in_forward:
                 _resident.set_staging((self.mailbox.data_ptr(), 0, self.static_x.data_ptr()))
@@ -419,8 +428,15 @@ class GraphedTrainStep:
                 self.reducer.enabled = hooks_were
                 self.reducer.finish()                                        # all-reduce captured on the capture stream; p.grad -> bucket views
                 self.optimizer.step()
-        # (short steps only: the ~9 us a graph launch costs matter to a 0.23 ms step, not to one of a hundred launches — and Python re-issues those slowly)
-        self._launch_list = recorder if (recorder is not None and 0 < len(recorder.calls) <= 32) else None
+        if self.reducer is not None:
+            self.reducer.mark_ready = None
+            for b in self.reducer.buckets:
+                b.launched = False                                           # (marks are no launches)
+        # (short steps only: the ~9 us a graph launch costs matter to a 0.23 ms step, not to one of a hundred launches — and Python re-issues those slowly; a step
+        # whose buckets' collectives are to start inside the backward pass needs the list whatever its length: a few hundred launches of a few-millisecond step)
+        self._launch_list = recorder if (recorder is not None and 0 < len(recorder.calls) <= (1024 if self._marks else 32)) else None
+        if self._launch_list is None:
+            self._marks = []
         if self.reducer is not None and not in_graph:
             self.reducer.enabled = hooks_were
             self._static_grads = [p.grad for p in self.reducer.params]       # graph-pool gradient tensors written by every replay
@@ -497,7 +513,17 @@ class GraphedTrainStep:
         """ One captured step on the current stream, through the launch lists or through the graphs: forward + backward (+ the collective and the optimizer when they
         were captured with them), then — a reducer whose collective runs between two captures — the collective, eagerly, and the optimizer's captured part.  With
         a data-parallel reducer every rank makes the same calls whichever mechanism it uses (one collective per step). """
-        if use_list:
+        if use_list and self._marks and self.graph_opt is not None:
+            # the backward pass in segments: each bucket's collective starts on the communication stream where the captured pass had produced its last gradient
+            st, pos = self._launch_stream.cuda_stream, 0
+            for p, g in zip(self.reducer.params, self._static_grads):
+                p.grad = g
+            for bi, idx in self._marks:
+                self._launch_list.replay(st, pos, idx)
+                pos = idx
+                self.reducer.launch_overlapped(self.reducer.buckets[bi])
+            self._launch_list.replay(st, pos, None)
+        elif use_list:
             self._replay_launch_list()
         else:
             self.graph_fb.replay()
@@ -561,8 +587,8 @@ def graphed_train_step(model, optimizer, losses, weights, reducer=None, graph_co
     autograd hooks go (a captured backward cannot launch collectives; `finish()` reduces the buckets after the replay) while the gradient arena stays, so
     the captured backward kernels write the gradients straight into the all-reduce buckets and no pack launch runs. """
     step = GraphedTrainStep(model, optimizer, losses, weights, reducer=reducer, graph_collective=graph_collective)
-    if reducer is not None:
-        reducer.remove_hooks()
+    if reducer is not None and len(reducer.buckets) <= 1:
+        reducer.remove_hooks()            # (several buckets: the hooks stay — they mark, during the capture, where each bucket is complete: `GraphedTrainStep._marks`)
     return step
 
 

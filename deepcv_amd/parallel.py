@@ -197,6 +197,9 @@ class GradientAllReducer:
         # capture stream before the capture.
         self.isolate = False
         self._in_backward = False
+        # `GraphedTrainStep` while it captures a step of a multi-bucket model: called (with the bucket) where a bucket's last gradient has been produced, INSTEAD of
+        # launching its collective — the replayed step launches it there, on the communication stream (`launch_overlapped`)
+        self.mark_ready = None
         cap = max(1, int(bucket_cap_mb * 1024 * 1024 / 4))
         self.buckets: List[_Bucket] = []
         cur, cur_n = [], 0
@@ -307,6 +310,13 @@ class GradientAllReducer:
 
     def _on_grad_ready(self, p: torch.nn.Parameter):
         if not self.enabled:
+            if self.mark_ready is not None:
+                b = self._bucket_of[p]
+                b.pending.discard(p)
+                if not b.pending and not b.launched:
+                    b.launched = True
+                    slabs.flush()                  # gradients whose kernels were deferred to the end of the backward pass must be IN the step before this point
+                    self.mark_ready(b)
             return
         b = self._bucket_of[p]
         b.pending.discard(p)
@@ -316,6 +326,17 @@ class GradientAllReducer:
                 self._launch(b)
             finally:
                 self._in_backward = False
+
+    def launch_overlapped(self, b: _Bucket):
+        """ A replayed step at the point where the captured backward had finished bucket `b` (`mark_ready`): its collective goes to the communication stream,
+        behind the launches issued so far, and overlaps the rest of the replayed backward pass; `finish()` waits for it. """
+        if not self.enabled or b.launched:
+            return
+        self._in_backward = True
+        try:
+            self._launch(b)
+        finally:
+            self._in_backward = False
 
     def finish(self):
         """ Completes the exchange: launches buckets the hooks did not (unused parameters, hooks disabled), makes the compute stream wait for the

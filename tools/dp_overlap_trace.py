@@ -1,0 +1,38 @@
+"""World-1 rehearsal of the data-parallel captured step of a MULTI-BUCKET model (cifar100_deep, bf16, bucket cap 8 MB -> 5 buckets): RCCL process group of one rank,
+`force_collective`, launch-list replay in segments with each bucket's all-reduce started on the communication stream inside the backward pass (GraphedTrainStep._marks).
+Run under `rocprofv3 --kernel-trace`: tools/gpu_dp_overlap.sh prints the kernel sequence of one replayed step (RCCL's kernels between the backward's).
+usage: dp_overlap_trace.py [steps]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29571')
+os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1'); os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+import torch
+import torch.distributed as dist
+from deepcv_amd import modules, ops, optim
+from deepcv_amd.classification.image import create_model
+from deepcv_amd.meta.data.datasets import SyntheticImageDataset
+from deepcv_amd.meta.ignite_training import _setup_losses, graphed_train_step
+from deepcv_amd.parallel import DataParallelModel
+from deepcv_amd.utils import load_parameters
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+dev = torch.device('cuda:0'); torch.cuda.set_device(dev)
+dist.init_process_group('nccl', device_id=dev)
+ops.set_conv_math('bf16')
+P = load_parameters()
+torch.manual_seed(563454)
+model = create_model({'trainset': SyntheticImageDataset(2, (3, 32, 32), 100)}, P['cifar100_deep_model']).to(dev)
+dp = DataParallelModel(model, overlap=True, bucket_cap_mb=8.)
+dp.reducer.force_collective = True
+opt = optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4)
+losses, weights = _setup_losses(modules.CrossEntropyLoss(), None, dev)
+step = graphed_train_step(dp, opt, losses, weights, dp.reducer)
+g = torch.Generator().manual_seed(1)
+batches = [(torch.randn(512, 3, 32, 32, generator=g).to(dev), torch.randint(0, 100, (512,), generator=g).to(dev)) for _ in range(2)]
+for i in range(4):
+    step(*batches[i % 2]); step.loss_values()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for i in range(steps):
+    step(*batches[i % 2]); last = step.loss_values()['main_loss']
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print(f'buckets {len(dp.reducer.buckets)} marks {step._marks} list calls {len(step._launch_list.calls) if step._launch_list is not None else None}: {dt / steps * 1e3:.2f} ms/step, loss {last:.4f}', flush=True)
+dist.destroy_process_group()
