@@ -1,7 +1,8 @@
-"""World-1 rehearsal of the data-parallel captured step of a MULTI-BUCKET model (cifar100_deep, bf16, bucket cap 8 MB -> 5 buckets): RCCL process group of one rank,
-`force_collective`, launch-list replay in segments with each bucket's all-reduce started on the communication stream inside the backward pass (GraphedTrainStep._marks).
-Run under `rocprofv3 --kernel-trace`: tools/gpu_dp_overlap.sh prints the kernel sequence of one replayed step (RCCL's kernels between the backward's).
-usage: dp_overlap_trace.py [steps]"""
+"""World-1 rehearsal of the data-parallel captured step of a MULTI-BUCKET model: the bn-only stock spec at bs 512 (a step made of this library's launches only: it
+replays as a launch list) with a bucket cap of 4 KB (several buckets), RCCL process group of one rank, `force_collective`; the list is replayed in segments with each
+bucket's all-reduce started on the communication stream inside the backward pass (GraphedTrainStep._marks).  RCCL launches nothing in a group of one, so every
+collective is followed here — in this tool only — by a marker launch on the same stream (dcv_scale by 1.0: the values keep their bits), which is what the kernel trace
+shows between the backward's kernels (tools/gpu_dp_overlap.sh).  usage: dp_overlap_trace.py [steps]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29571')
@@ -17,17 +18,22 @@ from deepcv_amd.utils import load_parameters
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 dev = torch.device('cuda:0'); torch.cuda.set_device(dev)
 dist.init_process_group('nccl', device_id=dev)
-ops.set_conv_math('bf16')
+from deepcv_amd import _native as nat
 P = load_parameters()
 torch.manual_seed(563454)
-model = create_model({'trainset': SyntheticImageDataset(2, (3, 32, 32), 100)}, P['cifar100_deep_model']).to(dev)
-dp = DataParallelModel(model, overlap=True, bucket_cap_mb=8.)
+model = create_model({'trainset': SyntheticImageDataset(2, (3, 32, 32), 10)}, P['image_classifier_bn_only_model']).to(dev)
+dp = DataParallelModel(model, overlap=True, bucket_cap_mb=0.004)
 dp.reducer.force_collective = True
-opt = optim.SGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4)
+_orig = dp.reducer._all_reduce_mean
+def _marked(b):
+    _orig(b)
+    nat.check(nat.lib.dcv_scale(b.flat.data_ptr(), 1.0, b.flat.data_ptr(), b.flat.numel(), nat.current_stream(dev)), 'marker')
+dp.reducer._all_reduce_mean = _marked
+opt = optim.AdamW(model.parameters(), lr=1e-3)
 losses, weights = _setup_losses(modules.CrossEntropyLoss(), None, dev)
 step = graphed_train_step(dp, opt, losses, weights, dp.reducer)
 g = torch.Generator().manual_seed(1)
-batches = [(torch.randn(512, 3, 32, 32, generator=g).to(dev), torch.randint(0, 100, (512,), generator=g).to(dev)) for _ in range(2)]
+batches = [(torch.randn(512, 3, 32, 32, generator=g).to(dev), torch.randint(0, 10, (512,), generator=g).to(dev)) for _ in range(2)]
 for i in range(4):
     step(*batches[i % 2]); step.loss_values()
 torch.cuda.synchronize(); t0 = time.perf_counter()

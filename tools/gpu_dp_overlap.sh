@@ -10,16 +10,21 @@ import csv, glob, sys
 O = sys.argv[1]
 f = glob.glob(O + '/tr/**/*kernel_trace.csv', recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-# the last replayed step: from the last im2col launch on
-starts = [i for i, r in enumerate(rows) if 'im2col' in r['Kernel_Name']]
+import re
+def short(name):
+    name = name.replace('(anonymous namespace)::', '').replace('void ', '')
+    m = re.match(r'[A-Za-z_0-9:]+', name)
+    return (m.group(0) if m else name)[:48]
+# the last replayed step: from the last staging launch (dcv_indirect_copy) on
+starts = [i for i, r in enumerate(rows) if 'indirect_copy' in r['Kernel_Name']]
 seg = rows[starts[-1]:]
 out = []
 t0 = int(seg[0]['Start_Timestamp'])
 for r in seg:
-    n = r['Kernel_Name'].split('(')[0].split('::')[-1][:60]
+    n = short(r['Kernel_Name'])
     out.append(f"{(int(r['Start_Timestamp']) - t0) / 1e3:9.1f} us  +{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:7.1f}  stream/queue {r.get('Queue_Id', '?'):>3}  {n}")
 open(O + '/dp_overlap.txt', 'w').write('\n'.join(out) + '\n')
-nccl = [i for i, r in enumerate(seg) if 'nccl' in r['Kernel_Name'].lower() or 'rccl' in r['Kernel_Name'].lower()]
-print(f'{len(seg)} kernels in the step, RCCL kernels at positions {nccl}')
+mk = [i for i, r in enumerate(seg) if 'scale_kernel' in r['Kernel_Name']]
+print(f'{len(seg)} kernels in the step; collective markers (scale_kernel, communication stream) at positions {mk}')
 PY
 rm -rf $O/tr
