@@ -367,8 +367,8 @@ def _wide_model_steps(device, params):
     from deepcv_amd.meta.data.datasets import SyntheticImageDataset
     from deepcv_amd.meta.ignite_training import GraphedTrainStep, _setup_losses
     res = []
-    # Each wide spec in the step mode `train()` selects for it (`deepcv_amd/meta/ignite_training.py`: a captured step below 5 M parameters — cifar100_deep —, the eager
-    # step with autograd hooks above — resnet18_style, 11.5 M) AND in the other one, labelled.  resnet18_style: bs 64 (round-to-round comparison) and, since round 4,
+    # Each wide spec in the step mode `train()` selects for it in one process (`deepcv_amd/meta/ignite_training.py`: the captured step; under data parallelism a model
+    # of 5 M parameters or more — both wide specs — takes the eager step with autograd hooks) AND in the other one, labelled.  resnet18_style: bs 64 (round-to-round comparison) and, since round 4,
     # the metric's 512 images per GPU in bf16 (tensors beyond 2 GiB — the stem's 2.5 GB im2col matrix — run as slices of the batch, conv2d_bf16.hip `batch_slice`).
     for spec, shape, nc, bs, maths in (('cifar100_deep_model', (3, 32, 32), 100, 512, ('fp32', 'bf16')), ('resnet18_style_model', (3, 224, 224), 1000, 64, ('fp32', 'bf16')),
                                        ('resnet18_style_model', (3, 224, 224), 1000, 512, ('bf16',))):
@@ -377,7 +377,7 @@ def _wide_model_steps(device, params):
             try:
                 torch.manual_seed(MODEL_SEED)
                 model = create_model({'trainset': SyntheticImageDataset(2, shape, nc)}, params[spec]).to(device)
-                trains_captured = sum(p.numel() for p in model.parameters()) < 5_000_000
+                trains_captured = True                  # one process: `train()` captures every spec (deepcv_amd/meta/ignite_training.py `hip_graph` auto); under data parallelism: below 5 M parameters
                 opt = optim.SGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=5e-4)
                 losses, weights = _setup_losses(modules.CrossEntropyLoss(), None, device)
                 step = GraphedTrainStep(model, opt, losses, weights)
