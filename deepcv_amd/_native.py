@@ -243,6 +243,7 @@ _SIGNATURES = {
     'dcv_sgd_step': (_c_int, [ctypes.POINTER(TensorList), _P, _c_int, _P]),
     'dcv_adamw_prep_build': (_c_int, [ctypes.POINTER(TensorList), _c_int, _c_int, _P, _P, _P, _P, ctypes.POINTER(AdamwPrepTable)]),
     'dcv_adamw_step_prep': (_c_int, [ctypes.POINTER(AdamwPrepTable), _P, _P]),
+    'dcv_adamw_step_prep_slabs': (_c_int, [ctypes.POINTER(AdamwPrepTable), _c_int, ctypes.POINTER(SlabSegment), _P, _P]),
     'dcv_pack_grads': (_c_int, [ctypes.POINTER(TensorList), _P, _P]),
     'dcv_allreduce_inbox_bytes': (_c_size_t, [_c_int, _c_size_t]),
     'dcv_allreduce_alloc': (_c_int, [_c_size_t, ctypes.POINTER(_c_void_p)]),
@@ -346,10 +347,12 @@ class _LazyLib:
         raw = getattr(load(), name)
 
         def call(*args, _raw=raw):
+            rc = _raw(*args)
             rec = _recorder
-            if rec is not None and args and isinstance(args[-1], int) and args[-1] == rec.stream and rec.stream:      # (the stream is every entry point's last argument)
+            # (the stream is every entry point's last argument; a call which refused — DCV_ERR_UNSUPPORTED: the caller takes another path — launched nothing)
+            if rec is not None and args and isinstance(args[-1], int) and args[-1] == rec.stream and rec.stream and not (isinstance(rc, int) and rc == ERR_UNSUPPORTED):
                 rec.calls.append((_raw, args, len(args) - 1))
-            return _raw(*args)
+            return rc
         call.__name__ = name
         setattr(self, name, call)
         return call

@@ -4,6 +4,7 @@
 // Replaces torch.nn.Conv2d (reference src/deepcv/meta/submodule_creators.py:251) forward and autograd backward.
 #include "conv2d_internal.h"
 #include "optim_update.h"
+#include "slab_sum.h"
 
 namespace {
 
@@ -47,6 +48,41 @@ __global__ __launch_bounds__(1024) void adamw_prep_kernel(dcv_adamw_prep_table t
         const dcv_prep_entry& e = preps[it.prep_first + q];
         for (int i = threadIdx.x; i < e.total; i += 1024) e.dst[i] = dcv_prep_element(e, i);
     }
+}
+
+// Round 4: the ordered slab sums of the step, AdamW and the filter re-layout in ONE launch (the stock step's two trailing launches -> one).  Blocks [0, slab blocks):
+// the body of slab_reduce_kernel (slab_sum.h: same summation tree, same bits); a thread which finishes an entry stores the gradient, updates the parameter the entry
+// belongs to (`item_of`: the optimizer item whose gradient tensor the segment writes) and SCATTERS the new value into every prepared layout of that tensor
+// (dcv_prep_scatter_index) — no second kernel, no barrier between the sums and the update, no gather from whole tensors.  Blocks behind them: the items no slab
+// segment writes (BatchNorm parameters, the fully connected layer's weight: their gradients are final when the backward launch ends), a block per item as in
+// adamw_prep_kernel but scattering.  Same arithmetic as dcv_slab_reduce + dcv_adamw_step + dcv_conv2d_prepare_filters, bit for bit.
+struct TailTable { SlabTable slabs; int slab_blocks; short item_of[DCV_MAX_SLAB_SEGMENTS]; short direct_count; short direct[DCV_OPT_MAX_ITEMS]; };
+__device__ __forceinline__ void tail_update(const dcv_adamw_prep_table& t, const dcv_adamw_scalars& sc, const dcv_opt_item& it, int off, float g) {
+    const float pnew = dcv_adamw_update_value<false>(sc, it.param, g, it.state1, it.state2, nullptr, off);
+    const dcv_prep_entry* preps = reinterpret_cast<const dcv_prep_entry*>(t.prep);
+    for (int q = 0; q < it.prep_count; ++q) {
+        const dcv_prep_entry& e = preps[it.prep_first + q];
+        const int idx = dcv_prep_scatter_index(e, off);
+        if (idx >= 0) e.dst[idx] = pnew;
+    }
+}
+__global__ __launch_bounds__(1024) void adamw_prep_slabs_kernel(dcv_adamw_prep_table t, TailTable tt, const float* __restrict__ hyper) {
+    __shared__ float red[16][SLAB_WIDE];
+    const dcv_adamw_scalars sc = dcv_adamw_load_scalars(hyper);
+    if ((int)blockIdx.x < tt.slab_blocks) {
+        int si = 0;
+        while (si + 1 < tt.slabs.count && (int)blockIdx.x >= tt.slabs.block_start[si + 1]) ++si;
+        const dcv_slab_segment& g = tt.slabs.seg[si];
+        float v; size_t di;
+        if (dcv_slab_block_sum(g, tt.slabs.wshift[si], (int)blockIdx.x - tt.slabs.block_start[si], red, v, di)) {
+            g.dst[di] = v;
+            const int ii = tt.item_of[si];
+            if (ii >= 0) { const dcv_opt_item& it = t.item[ii]; tail_update(t, sc, it, (int)((g.dst + di) - it.grad), v); }
+        }
+        return;
+    }
+    const dcv_opt_item& it = t.item[tt.direct[(int)blockIdx.x - tt.slab_blocks]];
+    for (int i = threadIdx.x; i < it.numel; i += 1024) tail_update(t, sc, it, i, it.grad[i]);
 }
 
 // op 2: the weight [O][C * H * W] of a Linear which follows a Flatten of [N][C][H][W] activations, re-laid as [O][H * W][C] so that the Linear reads the
@@ -224,6 +260,50 @@ int dcv_adamw_prep_build(const dcv_tensor_list* lists, int n_lists, int n_filter
     for (int f = 0; f < n_filters; ++f) if (!used[f]) return DCV_ERR_UNSUPPORTED;    // a filter of a weight which is not updated here would go stale
     *out = t;
     return DCV_OK;
+}
+
+int dcv_adamw_step_prep_slabs(const dcv_adamw_prep_table* table, int n_segments, const dcv_slab_segment* segments, const float* hyper, void* stream) {
+    DCV_CHECK_ARG(table && hyper && table->items > 0 && table->items <= DCV_OPT_MAX_ITEMS && table->preps >= 0 && table->preps <= DCV_OPT_MAX_PREPS && n_segments >= 0 && (n_segments == 0 || segments));
+    if (n_segments > DCV_MAX_SLAB_SEGMENTS) return DCV_ERR_UNSUPPORTED;
+    const dcv_prep_entry* preps = reinterpret_cast<const dcv_prep_entry*>(table->prep);
+    for (int q = 0; q < table->preps; ++q) if (!dcv_prep_scatterable(preps[q])) return DCV_ERR_UNSUPPORTED;
+    TailTable tt{};
+    bool covered[DCV_OPT_MAX_ITEMS] = {};
+    int blocks = 0;
+    for (int i = 0; i < n_segments; ++i) {
+        const dcv_slab_segment& g = segments[i];
+        if (!g.src || !g.dst || g.chunks < 1 || g.stride < g.count) return DCV_ERR_INVALID_ARG;
+        if (g.tr_a < 0 || g.tr_b < 0 || ((g.tr_a > 0) != (g.tr_b > 0)) || (g.tr_a > 0 && g.count % ((unsigned long long)g.tr_a * g.tr_b) != 0)) return DCV_ERR_INVALID_ARG;
+        if (g.count == 0) continue;
+        const int k = tt.slabs.count;
+        const int ws = g.count >= SLAB_WIDE_COUNT ? 5 : 3;          // (as dcv_launch_slab_reduce: the summation tree depends on it)
+        tt.slabs.block_start[k] = blocks; tt.slabs.wshift[k] = ws; tt.slabs.seg[k] = g;
+        tt.item_of[k] = -1;
+        for (int it = 0; it < table->items; ++it) {
+            const dcv_opt_item& o = table->item[it];
+            if (g.dst >= o.grad && g.dst < o.grad + o.numel) {
+                // the segment writes (a part of) this item's gradient: all of it must lie inside the item
+                if (g.dst + g.count > o.grad + o.numel) return DCV_ERR_UNSUPPORTED;
+                tt.item_of[k] = (short)it; covered[it] = true;
+                break;
+            }
+        }
+        // a tensor split into several items (the rows of a Linear weight) whose gradient one segment writes as a whole: not representable here
+        if (tt.item_of[k] < 0)
+            for (int it = 0; it < table->items; ++it) { const dcv_opt_item& o = table->item[it]; if (o.grad >= g.dst && o.grad < g.dst + g.count) return DCV_ERR_UNSUPPORTED; }
+        ++tt.slabs.count;
+        blocks += (int)dcv_ceil_div((size_t)g.count, (size_t)1 << ws);
+    }
+    tt.slabs.block_start[tt.slabs.count] = blocks;
+    tt.slab_blocks = blocks;
+    // an item only partly covered by segments would be updated twice or not at all: every covered item must be covered entirely by ONE segment
+    for (int k = 0; k < tt.slabs.count; ++k)
+        if (tt.item_of[k] >= 0 && (tt.slabs.seg[k].dst != table->item[tt.item_of[k]].grad || (long long)tt.slabs.seg[k].count != table->item[tt.item_of[k]].numel)) return DCV_ERR_UNSUPPORTED;
+    for (int it = 0; it < table->items; ++it) if (!covered[it]) tt.direct[tt.direct_count++] = (short)it;
+    const int total = blocks + tt.direct_count;
+    if (total <= 0) return DCV_OK;
+    hipLaunchKernelGGL(adamw_prep_slabs_kernel, dim3((unsigned)total), dim3(1024), 0, dcv_stream(stream), *table, tt, hyper);
+    DCV_RETURN_LAUNCH();
 }
 
 int dcv_adamw_step_prep(const dcv_adamw_prep_table* table, const float* hyper, void* stream) {

@@ -77,6 +77,28 @@ static __device__ __forceinline__ float dcv_prep_element(const dcv_prep_entry& e
     if (!e.dgrad) return e.w[(((size_t)co * e.w_cin + ci) * e.R + r) * e.S + s];
     return e.w[(((size_t)ci * e.w_cin + co) * e.Rw + (e.r0 + e.rstep * (e.R - 1 - r))) * e.Sw + (e.s0 + e.sstep * (e.S - 1 - s))];
 }
+// The inverse map (round 4: the optimizer's tail launch SCATTERS an updated weight into its prepared layouts instead of gathering whole layouts behind a barrier):
+// index in e.dst of element `off` of e.w (OIHW: [first][w_cin][R][S]), or -1 when the layout has no such element.  Pad positions of a layout (zeros) are written by
+// the gather which creates it and never change.  Supported: kinds 0 and 2, kind 1 forward filters (dcv_prep_scatterable).
+static __host__ __device__ __forceinline__ bool dcv_prep_scatterable(const dcv_prep_entry& e) { return e.kind == 0 || e.kind == 2 || (e.kind == 1 && !e.dgrad); }
+static __device__ __forceinline__ int dcv_prep_scatter_index(const dcv_prep_entry& e, int off) {
+    const int taps = e.R * e.S;
+    const int tap_w = off % taps; int t = off / taps;
+    const int b = t % e.w_cin, a = t / e.w_cin;                    // w[a][b][tap_w]
+    if (e.kind == 0) {
+        const int cog = e.dgrad ? b : a, ci = e.dgrad ? a : b, tap = e.dgrad ? taps - 1 - tap_w : tap_w;
+        if (cog >= e.kcout || ci >= e.kcin) return -1;
+        const int tile = cog / e.tco, co = cog - tile * e.tco;
+        return ((tile * taps + tap) * e.cin_pad + ci) * e.tco + co;                        // [tile][R][S][cin_pad][tco]
+    }
+    if (e.kind == 2) {
+        const int co = a, n = b;                                                           // value(n, kq, j, tap) = w[co = 4 kq + j][n][taps - 1 - tap]
+        if (n >= e.kcout || co >= e.kcin) return -1;
+        return ((n * 4 + (co >> 2)) * 4 + (co & 3)) * taps + (taps - 1 - tap_w);
+    }
+    if (a >= e.kcout || b >= e.kcin) return -1;
+    return (a * taps + tap_w) * e.kcin + b;                                                // [co][r][s][ci]
+}
 // number of prepared-filter pieces of (d, op) written to out[] (<= DCV_PREP_PIECES); 0 when the kernel serving it reads the OIHW filter directly.
 // op: 0 forward, 1 data gradient (a strided data gradient on the MFMA kernels has one piece per output phase)
 #define DCV_PREP_PIECES 16

@@ -4,6 +4,7 @@
 // Replaces: `act_fn()` modules (reference src/deepcv/meta/nn.py:553), torch.cat (submodule_creators.py:56,323),
 // F.interpolate (nn.py:675), torch.nn.Flatten on channels-last data (conf/base/parameters.yml:87).
 #include "colreduce.h"
+#include "slab_sum.h"
 #include <string.h>
 
 namespace {
@@ -399,45 +400,13 @@ __global__ __launch_bounds__(256) void resize_concat_kernel(ResizeConcatTable t,
 // of a wave are merged by a fixed xor butterfly, the 16 waves in order through LDS -> the result only depends on (segment shape, entry), not on the launch.
 // Long segments (>= SLAB_WIDE_COUNT entries: the linear layer's 12.8 k, a 16->16 3x3 filter's 2.3 k) use blocks of 32 entries x 32 slab lanes instead:
 // 128-B runs per slab row instead of 32-B ones (8.5 of this kernel's 9.5 MB on the stock step).
-#define SLAB_W 8
-#define SLAB_WIDE 32
-#define SLAB_WIDE_COUNT 1024
-struct SlabTable {
-    int count;
-    int wshift[DCV_MAX_SLAB_SEGMENTS];      // log2 of the segment's entries per block (3 or 5)
-    int block_start[DCV_MAX_SLAB_SEGMENTS + 1];
-    dcv_slab_segment seg[DCV_MAX_SLAB_SEGMENTS];
-};
-
 __global__ __launch_bounds__(1024) void slab_reduce_kernel(SlabTable t) {
     __shared__ float red[16][SLAB_WIDE];
     int si = 0;
     while (si + 1 < t.count && (int)blockIdx.x >= t.block_start[si + 1]) ++si;          // wave-uniform: scalar loop
     const dcv_slab_segment& g = t.seg[si];
-    const int ws = t.wshift[si], W = 1 << ws, lanes = 1024 >> ws;
-    const int wl = threadIdx.x & (W - 1), cl = threadIdx.x >> ws, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const size_t wi = ((size_t)((int)blockIdx.x - t.block_start[si]) << ws) + wl;
-    const float* __restrict__ src = g.src;
-    float s = 0.f;
-    if (wi < g.count) {
-#pragma unroll 4
-        for (int c = cl; c < g.chunks; c += lanes) s += src[(size_t)c * g.stride + wi];
-    }
-    for (int off = W; off < 64; off <<= 1) s += __shfl_xor(s, off, 64);
-    if (lane < W) red[wave][lane] = s;
-    __syncthreads();
-    if ((int)threadIdx.x < W && wi < g.count) {
-        float v = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v += red[k][threadIdx.x];
-        size_t di = wi;
-        if (g.tr_a > 0) {                                                                // [o][tr_a][tr_b] -> [o][tr_b][tr_a]
-            const size_t ab = (size_t)g.tr_a * g.tr_b, o = wi / ab, rem = wi - o * ab;
-            const size_t pp = rem / g.tr_b, c = rem - pp * g.tr_b;
-            di = o * ab + c * g.tr_a + pp;
-        }
-        g.dst[di] = v;
-    }
+    float v; size_t di;
+    if (dcv_slab_block_sum(g, t.wshift[si], (int)blockIdx.x - t.block_start[si], red, v, di)) g.dst[di] = v;      // (the body: slab_sum.h, shared with the optimizer's tail launch)
 }
 
 }  // namespace

@@ -18,11 +18,12 @@ static __device__ __forceinline__ dcv_adamw_scalars dcv_adamw_load_scalars(const
     return s;
 }
 
+// (the gradient as a VALUE: the optimizer's tail launch — conv2d.hip, adamw_prep_slabs_kernel — updates an element in the thread which has just finished its slab sum)
 template <bool AMSGRAD>
-static __device__ __forceinline__ void dcv_adamw_update(const dcv_adamw_scalars& s, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                        float* __restrict__ v, float* __restrict__ vmax, long long i) {
-    // every operation spelled out (no contraction left to the compiler): the two kernels which share this function must agree to the bit
-    const float gi = __fmul_rn(g[i], s.gs);
+static __device__ __forceinline__ float dcv_adamw_update_value(const dcv_adamw_scalars& s, float* __restrict__ p, float g_raw, float* __restrict__ m,
+                                                               float* __restrict__ v, float* __restrict__ vmax, long long i) {
+    // every operation spelled out (no contraction left to the compiler): the kernels which share this function must agree to the bit
+    const float gi = __fmul_rn(g_raw, s.gs);
     float pi = __fmul_rn(p[i], __fsub_rn(1.f, __fmul_rn(s.lr, s.wd)));
     const float m0 = m[i];
     const float mi = __fmaf_rn(__fsub_rn(1.f, s.b1), __fsub_rn(gi, m0), m0);      // torch: exp_avg.lerp_(grad, 1 - beta1)
@@ -33,5 +34,12 @@ static __device__ __forceinline__ void dcv_adamw_update(const dcv_adamw_scalars&
     const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vden), s.bc2_sqrt), s.eps);
     pi = __fmaf_rn(-s.step_size, __fdiv_rn(mi, denom), pi);
     p[i] = pi;
+    return pi;
+}
+
+template <bool AMSGRAD>
+static __device__ __forceinline__ void dcv_adamw_update(const dcv_adamw_scalars& s, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, float* __restrict__ vmax, long long i) {
+    dcv_adamw_update_value<AMSGRAD>(s, p, g[i], m, v, vmax, i);
 }
 #endif

@@ -415,6 +415,9 @@ class GraphedTrainStep:
                                                                   self.mailbox.data_ptr() + self._PUB_SEQ, self._nat.current_stream(dev)), 'dcv_publish_scalars')
                 self._publishes = True
             main = self.static_losses[MAIN_TRAINING_LOSS_NAME]
+            from .. import slabs as _slabs
+            # the optimizer follows the backward pass at once (no collective in between): its launch takes the pass's ordered slab sums with it (`slabs.hold`)
+            _slabs.hold(self.reducer is None)
             main.backward(gradient=self._seed if main.shape == self._seed.shape else None)   # preallocated seed: no ones-fill kernel per replay
             pending_plan = getattr(getattr(self.static_pred, 'grad_fn', None), 'res_plan', None)
             if pending_plan is not None:
@@ -423,11 +426,16 @@ class GraphedTrainStep:
             # (`graph_collective`) when it is RCCL's
             in_graph = self.reducer is not None and self.reducer.capturable() and (self.graph_collective or self.reducer.native_active())
             if self.reducer is None:
-                self.optimizer.step()
+                try:
+                    self.optimizer.step()
+                finally:
+                    _slabs.hold(False)
             elif in_graph:
                 self.reducer.enabled = hooks_were
                 self.reducer.finish()                                        # all-reduce captured on the capture stream; p.grad -> bucket views
                 self.optimizer.step()
+        from .. import slabs as _slabs_after
+        _slabs_after.hold(False)                                             # (idempotent: an exception between the backward pass and the optimizer must not leave sums parked)
         if self.reducer is not None:
             self.reducer.mark_ready = None
             for b in self.reducer.buckets:

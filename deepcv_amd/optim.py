@@ -148,6 +148,12 @@ class _NativeOptimizer(torch.optim.Optimizer):
         capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
         slabs.flush()
         slabs.reset_uses()
+        try:
+            return self._step_groups(capturing, loss)
+        finally:
+            slabs.release_held()          # ordered sums a captured step parked for this update's launch (`slabs.hold`) and which it did not take
+
+    def _step_groups(self, capturing: bool, loss):
         if not capturing:
             self.sync_hyper()
         for gi, group in enumerate(self.param_groups):
@@ -170,6 +176,7 @@ class _NativeOptimizer(torch.optim.Optimizer):
                 table = self._filter_tables[gi] = filters.RefreshTable(group['params'])
             if capturing and self._launch_with_filters(lists, table, buf['hyper'].data_ptr(), group, stream):
                 continue         # one launch updated the weights AND re-laid their prepared filters
+            slabs.release_held()     # (ordered sums parked for a launch which is not coming: the gradients must be final before the update below)
             for tl in lists:
                 self._launch(tl, buf['hyper'].data_ptr(), group, stream)
             # the weights just changed behind `Tensor._version`: refresh every prepared convolution filter of this group in one launch
@@ -253,7 +260,23 @@ class AdamW(_NativeOptimizer):
         if rc == nat.ERR_UNSUPPORTED:
             return False
         nat.check(rc, 'dcv_adamw_prep_build')
-        nat.check(lib.dcv_adamw_step_prep(ctypes.byref(packed), hyper_ptr, stream), 'dcv_adamw_step_prep')
+        # the step's parked ordered slab sums (a captured step: `slabs.hold`) in front of the update, in the same launch: the stock step's two trailing launches as one
+        dev = group['params'][0].device
+        segs, keep = slabs.take_held(dev, stream) if os.environ.get('DCV_ADAMW_PREP_SLABS', '1') not in ('0', 'false', 'False') else ([], [])
+        done = False
+        if segs:
+            sarr = (nat.SlabSegment * len(segs))(*segs)
+            rc = lib.dcv_adamw_step_prep_slabs(ctypes.byref(packed), len(segs), sarr, hyper_ptr, stream)
+            if rc == nat.ERR_UNSUPPORTED:
+                slabs.give_back(dev, stream, segs, keep)
+                slabs.release_held()                      # the plain ordered sum, then the update below
+            else:
+                nat.check(rc, 'dcv_adamw_step_prep_slabs')
+                self._tail_keep = (sarr, keep)            # (alive as long as the captured step which holds this launch)
+                done = True
+        if not done:
+            slabs.release_held()                          # (nothing of this step's sums may still be parked when the update reads the gradients)
+            nat.check(lib.dcv_adamw_step_prep(ctypes.byref(packed), hyper_ptr, stream), 'dcv_adamw_step_prep')
         table.refresh(stream, capturing=True, launched_by=entries)
         return True
 

@@ -24,7 +24,8 @@ import torch
 from . import _native as nat
 from ._native import lib
 
-__all__ = ['enabled', 'set_enabled', 'note_use', 'unnote_use', 'may_defer', 'would_defer', 'before_flush', 'reset_uses', 'defer', 'defer_wgrad', 'flush', 'pending']
+__all__ = ['enabled', 'set_enabled', 'note_use', 'unnote_use', 'may_defer', 'would_defer', 'before_flush', 'reset_uses', 'defer', 'defer_wgrad', 'flush', 'pending',
+           'hold', 'take_held', 'give_back', 'release_held']
 
 _enabled = True
 _lock = threading.Lock()
@@ -108,6 +109,53 @@ def would_defer(*params) -> bool:
 
 
 _preflush: List = []
+# Round 4: while `hold(True)` (a training step being captured, `GraphedTrainStep`: the optimizer follows the backward pass at once and nothing reads a gradient in
+# between) a flush does not launch the ordered sums but parks their segments here; the optimizer's update takes them into ITS launch (`take_held`,
+# `dcv_adamw_step_prep_slabs`: the stock step's two trailing launches become one) or gives them back (`release_held`: the plain `dcv_slab_reduce`).
+_hold = False
+_held: List[Tuple[torch.device, int, List[nat.SlabSegment], list]] = []
+
+
+def hold(on: bool):
+    """ Switches the parking of flushed slab sums on / off; switching it off launches whatever is still parked. """
+    global _hold
+    _hold = bool(on)
+    if not _hold:
+        release_held()
+
+
+def take_held(device: torch.device, stream: int):
+    """ The parked segments of (device, stream) — and the tensors which must outlive their sum — for a launch which sums them itself; ([], []) when none. """
+    with _lock:
+        mine = [h for h in _held if h[0] == device and h[1] == stream]
+        for h in mine:
+            _held.remove(h)
+    segs, keep = [], []
+    for _, _, sg, kp in mine:
+        segs += sg
+        keep += kp
+    return segs, keep
+
+
+def give_back(device: torch.device, stream: int, segs, keep):
+    if segs:
+        with _lock:
+            _held.append((device, stream, list(segs), list(keep)))
+
+
+def release_held():
+    """ Launches the plain ordered sum for everything still parked. """
+    with _lock:
+        mine = list(_held)
+        _held.clear()
+    for dev, st, segs, keep in mine:
+        if segs:
+            arr = (nat.SlabSegment * len(segs))(*segs)
+            nat.check(lib.dcv_slab_reduce(len(segs), arr, nat.current_stream(dev)), 'dcv_slab_reduce')
+            cur = nat.current_stream(dev)
+            if cur != st:
+                for t in keep:
+                    t.record_stream(torch.cuda.current_stream(dev))
 
 
 def before_flush(fn):
@@ -227,7 +275,10 @@ def flush():
                 s = nat.SlabSegment()
                 ctypes.pointer(s)[0] = sarr[i]
                 segs.append(s)
-        if segs:
+        if segs and _hold and cur == st:
+            with _lock:
+                _held.append((dev, st, segs, list(g['keep'])))        # summed by the optimizer's launch (`hold`)
+        elif segs:
             arr = (nat.SlabSegment * len(segs))(*segs)
             nat.check(lib.dcv_slab_reduce(len(segs), arr, cur), 'dcv_slab_reduce')
         if cur != st:

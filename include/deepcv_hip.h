@@ -574,6 +574,11 @@ typedef struct dcv_adamw_prep_table { int items; int preps; dcv_opt_item item[DC
 int dcv_adamw_prep_build(const dcv_tensor_list* lists, int n_lists, int n_filters, const dcv_conv2d_desc* const* descs, const int* ops,
                          const float* const* weights, void* const* filters, dcv_adamw_prep_table* out);
 int dcv_adamw_step_prep(const dcv_adamw_prep_table* table, const float* hyper, void* stream);
+/* ... with the step's pending ordered slab sums in front, in the SAME launch (round 4: `optimizer.step()` at ignite_training.py:254 behind `loss.backward()` at :253
+ * as one trailing launch instead of dcv_slab_reduce + dcv_adamw_step_prep): a thread which finishes an entry of a segment stores the gradient, applies AdamW to the
+ * parameter behind it and scatters the new value into that tensor's prepared layouts.  Same bits as the two launches.  DCV_ERR_UNSUPPORTED (nothing launched): more than
+ * DCV_MAX_SLAB_SEGMENTS segments, a segment which does not write exactly one whole item's gradient, a prepared layout without an inverse map. */
+int dcv_adamw_step_prep_slabs(const dcv_adamw_prep_table* table, int n_segments, const dcv_slab_segment* segments, const float* hyper, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * C1 helper  gradient bucket pack for the data-parallel all-reduce (RCCL over xGMI is driven from Python through

@@ -271,9 +271,10 @@ def _run_plain(model, x, y):
 
 
 def test_cross_entropy_inside_the_backward_launch(device, params):
-    """ At the bench batch size a captured step is four launches: the loss (value, early read-back, arg-max hits, d loss / d logits) is computed by the
-    head of the persistent backward launch from the forward launch's logits — the same arithmetic as the loss kernel the eager steps run: losses and hit
-    counts equal bit for bit.  `DCV_CE_IN_BACKWARD` off: five launches, the same numbers. """
+    """ At the bench batch size a captured step is THREE launches (round 4: forward, backward, and ONE trailing launch — the ordered slab sums, AdamW and the
+    filter re-layout, `dcv_adamw_step_prep_slabs` —; four until then): the loss (value, early read-back, arg-max hits, d loss / d logits) is computed by the
+    head of the persistent backward launch from the forward launch's logits — the same arithmetic as the loss kernel the eager steps run, and the trailing launch
+    the same arithmetic as the eager steps' three: losses and hit counts equal bit for bit.  `DCV_CE_IN_BACKWARD` off: four launches, the same numbers. """
     from deepcv_amd import modules, optim, resident
     from deepcv_amd.meta.ignite_training import GraphedTrainStep, _setup_losses
     g = torch.Generator().manual_seed(DATA_SEED)
@@ -298,7 +299,7 @@ def test_cross_entropy_inside_the_backward_launch(device, params):
             torch.cuda.synchronize()
             resident.check_status()
             if mode != 'eager':
-                _assert_replay_mechanism(step, 4 if mode == 'in backward' else 5)
+                _assert_replay_mechanism(step, 3 if mode == 'in backward' else 4)
             curves.append(got)
         finally:
             resident._ce_in_backward = prev
