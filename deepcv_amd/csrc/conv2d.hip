@@ -57,14 +57,16 @@ __global__ __launch_bounds__(1024) void adamw_prep_kernel(dcv_adamw_prep_table t
 // segment writes (BatchNorm parameters, the fully connected layer's weight: their gradients are final when the backward launch ends), a block per item as in
 // adamw_prep_kernel but scattering.  Same arithmetic as dcv_slab_reduce + dcv_adamw_step + dcv_conv2d_prepare_filters, bit for bit.
 struct TailTable { SlabTable slabs; int slab_blocks; short item_of[DCV_MAX_SLAB_SEGMENTS]; short direct_count; short direct[DCV_OPT_MAX_ITEMS]; };
-__device__ __forceinline__ void tail_update(const dcv_adamw_prep_table& t, const dcv_adamw_scalars& sc, const dcv_opt_item& it, int off, float g) {
-    const float pnew = dcv_adamw_update_value<false>(sc, it.param, g, it.state1, it.state2, nullptr, off);
+__device__ __forceinline__ void tail_scatter(const dcv_adamw_prep_table& t, const dcv_opt_item& it, int off, float pnew) {
     const dcv_prep_entry* preps = reinterpret_cast<const dcv_prep_entry*>(t.prep);
     for (int q = 0; q < it.prep_count; ++q) {
         const dcv_prep_entry& e = preps[it.prep_first + q];
         const int idx = dcv_prep_scatter_index(e, off);
         if (idx >= 0) e.dst[idx] = pnew;
     }
+}
+__device__ __forceinline__ void tail_update(const dcv_adamw_prep_table& t, const dcv_adamw_scalars& sc, const dcv_opt_item& it, int off, float g) {
+    tail_scatter(t, it, off, dcv_adamw_update_value<false>(sc, it.param, g, it.state1, it.state2, nullptr, off));
 }
 __global__ __launch_bounds__(1024) void adamw_prep_slabs_kernel(dcv_adamw_prep_table t, TailTable tt, const float* __restrict__ hyper) {
     __shared__ float red[16][SLAB_WIDE];
@@ -73,11 +75,27 @@ __global__ __launch_bounds__(1024) void adamw_prep_slabs_kernel(dcv_adamw_prep_t
         int si = 0;
         while (si + 1 < tt.slabs.count && (int)blockIdx.x >= tt.slabs.block_start[si + 1]) ++si;
         const dcv_slab_segment& g = tt.slabs.seg[si];
+        // the entry this thread will finish (threads < W of the block: slab_sum.h) and its parameter / moments, requested NOW: the update's loads travel with the
+        // sum's instead of behind them (one memory round trip of a kernel which is two)
+        const int ws = tt.slabs.wshift[si], lb = (int)blockIdx.x - tt.slabs.block_start[si], ii = tt.item_of[si];
+        float p0 = 0.f, m0 = 0.f, v0 = 0.f; int off = -1;
+        if (ii >= 0 && (int)threadIdx.x < (1 << ws)) {
+            const size_t wi = ((size_t)lb << ws) + threadIdx.x;
+            if (wi < g.count) {
+                size_t di = wi;
+                if (g.tr_a > 0) { const size_t ab = (size_t)g.tr_a * g.tr_b, o = wi / ab, rem = wi - o * ab, pp = rem / g.tr_b, c = rem - pp * g.tr_b; di = o * ab + c * g.tr_a + pp; }
+                const dcv_opt_item& it = t.item[ii];
+                off = (int)((g.dst + di) - it.grad);
+                p0 = it.param[off]; m0 = it.state1[off]; v0 = it.state2[off];
+            }
+        }
         float v; size_t di;
-        if (dcv_slab_block_sum(g, tt.slabs.wshift[si], (int)blockIdx.x - tt.slabs.block_start[si], red, v, di)) {
+        if (dcv_slab_block_sum(g, ws, lb, red, v, di)) {
             g.dst[di] = v;
-            const int ii = tt.item_of[si];
-            if (ii >= 0) { const dcv_opt_item& it = t.item[ii]; tail_update(t, sc, it, (int)((g.dst + di) - it.grad), v); }
+            if (ii >= 0) {
+                const dcv_opt_item& it = t.item[ii];
+                tail_scatter(t, it, off, dcv_adamw_update_loaded<false>(sc, it.param, v, it.state1, it.state2, nullptr, off, p0, m0, v0));
+            }
         }
         return;
     }

@@ -721,7 +721,12 @@ struct W16pArgs {
     long M, m_per_chunk;
     size_t wtotal;
     int ips, nx;                    // images per step; 8-row DMA instructions per window
+    int sw, segs;                   // the window's geometry: segment width (a power of two <= 32) and segments per VIRTUAL image row (below)
 };
+// Maps of any width up to 64 (round 4, second step: resnet18_style's 56 / 28 / 14 / 7): the image is treated as VH x VW VIRTUAL pixels, VW the next power of two,
+// cut into segments of `sw` = min(VW, 32) columns; a step is 32 / sw rows of one segment.  Virtual pixels beyond the image's columns are fetched out of range (dz
+// zeros: they add nothing), the window's columns come from the neighbouring segment or from beyond the image's edge (zeros); global addresses use the TRUE width.
+// A lane's validity pattern depends on the segment only: two sets of staging offsets (segment 0 / 1), picked per step by a scalar.
 #define W16P_XOFF 4096              // dz: 32 rows of 128 B
 #define W16P_STAGE (4096 + 13 * 1024)      // + the largest window: 104 rows (W = 32); two windows of 40 rows with image pairs
 #define W16P_GROUP (3 * W16P_STAGE)
@@ -734,7 +739,7 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9p_kernel(W16p
     const int li = lane & 15, lg = lane >> 4;
     const int ci0 = blockIdx.y * 64, co0 = blockIdx.z * 64;
     constexpr int ips = IPS;
-    const int W = a.W, WP = W + 2, wsh = 31 - __builtin_clz((unsigned)W), NX = a.nx;
+    const int Wt = a.W, SW = a.sw, WP = SW + 2, wsh = 31 - __builtin_clz((unsigned)SW), NX = a.nx, ssh = a.segs > 1 ? 1 : 0;
     const int per_group = (int)(a.m_per_chunk / GROUPS);         // multiple of 32
     const int mb = (int)blockIdx.x * (int)a.m_per_chunk + grp * per_group;
     int me = mb + per_group; if (me > (int)a.M) me = (int)a.M;
@@ -745,7 +750,7 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9p_kernel(W16p
 
     // ---- operand addresses of this lane (bytes inside a stage, + the group's base): pixel j0 of each K half
     const int j0 = 4 * lg + (li >> 2), sub = (li & 3) * 8;
-    auto wpos = [&](int j) { return W >= 32 ? j : ((j >> wsh) * WP + (j & (W - 1))); };      // K-axis pixel -> window row of its centre tap's column 0 ... (before the tap offset)
+    auto wpos = [&](int j) { return (j >> wsh) * WP + (j & (SW - 1)); };      // K-axis pixel -> window row (before the tap offset: the centre tap is + WP + 1)
     unsigned aaddr[2][4], baddr[2][9];
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
@@ -777,23 +782,25 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9p_kernel(W16p
     const int Cw = dzw ? a.Cout : a.Cin;
     const int cnt = dzw ? 4 : (ips * NX - (wave - 1) + 2) / 3;    // requests of this wave per step (<= 5)
     const int n0 = dzw ? (ips == 2 ? 2 : 4) : (ips == 2 ? (NX - (wave - 1) + 2) / 3 : 5);      // the first n0 of them read the step's first image
-    unsigned voff[5];
+    unsigned voff[2][5];                                         // [segment][request]: offsets relative to the step's first pixel (h0, c0)
     const unsigned sdst0 = dzw ? 0u : (unsigned)(W16P_XOFF + (wave - 1) * 1024), sdstep = dzw ? 1024u : 3072u;      // LDS destination of request i: sdst0 + i sdstep
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int r8 = lane >> 3, piece = lane & 7;
-        unsigned v = BF_OOB;
-        if (dzw) {
-            const int row = 8 * i + r8, pix = ips == 2 ? (row & 15) : row;
-            v = (unsigned)((pix * a.Cout + co0) * 2 + ((piece ^ (((row >> 1) & 3) << 1)) << 4));
-        } else {
-            const int jx = (wave - 1) + 3 * i, wi = jx >= NX ? jx - NX : jx;
-            const int q = 8 * wi + r8, hh = q / WP, ww = q - hh * WP;
-            if (ww >= 1 && ww <= W) v = (unsigned)((((hh - 1) * W + ww - 1) * a.Cin + ci0) * 2 + ((piece ^ (((q >> 1) & 3) << 1)) << 4));      // (mod 2^32: the row above the image wraps out of range)
+    for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int r8 = lane >> 3, piece = lane & 7;
+            unsigned v = BF_OOB;
+            if (dzw) {
+                const int row = 8 * i + r8, j = ips == 2 ? (row & 15) : row, jr = j >> wsh, jc = j & (SW - 1);
+                if (sg * SW + jc < Wt) v = (unsigned)(((jr * Wt + jc) * a.Cout + co0) * 2 + ((piece ^ (((row >> 1) & 3) << 1)) << 4));
+            } else {
+                const int jx = (wave - 1) + 3 * i, wi = jx >= NX ? jx - NX : jx;
+                const int q = 8 * wi + r8, hh = q / WP, ww = q - hh * WP, col = sg * SW - 1 + ww;
+                if (col >= 0 && col < Wt) v = (unsigned)((((hh - 1) * Wt + ww - 1) * a.Cin + ci0) * 2 + ((piece ^ (((q >> 1) & 3) << 1)) << 4));      // (mod 2^32: the row above the image wraps out of range)
+            }
+            voff[sg][i] = v;
+            asm volatile("" : "+v"(voff[sg][i]));
         }
-        voff[i] = v;
-        asm volatile("" : "+v"(voff[i]));
-    }
     const u16* tens = dzw ? dy : x;
     const unsigned img_bytes = (unsigned)(HW * Cw * 2);
     // the step's image (first image of the pair) as a byte address, advanced with l_n (two scalar registers instead of a 64-bit product per step)
@@ -802,7 +809,9 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9p_kernel(W16p
     auto dma_step = [&](int stg) {
         const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)ibase), bhi = __builtin_amdgcn_readfirstlane((unsigned)(ibase >> 32));
         const bw_i32x4 r0 = {(int)blo, (int)(bhi & 0xFFFFu), (int)img_bytes, 0x00020000};
-        const unsigned adv = (unsigned)(l_p0 * Cw * 2);
+        // the step's first pixel: step t of the image = (row block t >> ssh, segment t & ssh)
+        const int tstep = l_p0 >> 5, seg = tstep & ssh, h0 = (tstep >> ssh) << (5 - wsh);
+        const unsigned adv = (unsigned)(((h0 * Wt + (seg << wsh)) * Cw) * 2);
         int c = __builtin_amdgcn_readfirstlane(cnt), c0 = __builtin_amdgcn_readfirstlane(n0);
         unsigned sb2 = __builtin_amdgcn_readfirstlane(sbase);
         asm volatile("" : "+s"(c), "+s"(c0), "+s"(sb2));         // (loop-variant to the optimiser: hoisted, the comparisons and the fifteen destinations below live in
@@ -814,13 +823,13 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9p_kernel(W16p
             const bw_i32x4 r1 = {(int)__builtin_amdgcn_readfirstlane((unsigned)b1), (int)(__builtin_amdgcn_readfirstlane((unsigned)(b1 >> 32)) & 0xFFFFu), has2 ? (int)img_bytes : 0, 0x00020000};
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
-                if (i < c) { if (i < c0) bw_dma16(r0, dst, voff[i], 0u); else bw_dma16(r1, dst, voff[i], 0u); }
+                if (i < c) { if (i < c0) bw_dma16(r0, dst, voff[0][i], 0u); else bw_dma16(r1, dst, voff[0][i], 0u); }
                 dst += sdstep;
             }
         } else {
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
-                if (i < c) bw_dma16(r0, dst, voff[i] + adv, 0u);
+                if (i < c) bw_dma16(r0, dst, (seg ? voff[1][i] : voff[0][i]) + adv, 0u);
                 dst += sdstep;
             }
         }
@@ -902,19 +911,21 @@ inline bool w16p_plan(const dcv_conv2d_desc* d, W16pArgs* a, int* chunks, size_t
     if (!enabled || d->groups != 1 || d->x_layout != DCV_LAYOUT_NHWC) return false;
     if (d->r != 3 || d->s != 3 || d->pad_h != 1 || d->pad_w != 1 || d->stride_h != 1 || d->stride_w != 1 || d->dil_h != 1 || d->dil_w != 1) return false;
     if (d->cin % 64 != 0 || d->cout % 64 != 0 || d->ho != d->h || d->wo != d->w) return false;
-    if (d->w != 4 && d->w != 8 && d->w != 16 && d->w != 32) return false;
+    if (d->w < 4 || d->w > 64) return false;
     const int hw = d->h * d->w;
     if ((size_t)hw * d->cin * 2 >= ((size_t)1 << 30) || (size_t)hw * d->cout * 2 >= ((size_t)1 << 30)) return false;
-    const int ips = hw <= 16 ? 2 : 1;
-    if (ips == 1 && hw % W16_PS != 0) return false;             // a step is whole image rows of one image
-    if (ips == 2 && hw != 16) return false;                    // (a K half is exactly one image: no window rows beyond the staged ones are ever read)
-    const int rows_img = ips == 2 ? d->h : W16_PS / d->w;       // image rows of a step (per image)
-    const int xr = ((ips == 2 ? d->h : (d->w >= 32 ? 1 : rows_img)) + 2) * (d->w + 2);
+    const int ips = (hw == 16 && d->w == 4) ? 2 : 1;            // 4 x 4 maps: two images per step (a K half is exactly one image)
+    int vw = 4; while (vw < d->w) vw <<= 1;                     // virtual width
+    const int sw = vw < 32 ? vw : 32, segs = vw / sw;
+    const int rows_step = ips == 2 ? d->h : W16_PS / sw;        // image rows of a step (per image)
+    const int vh = (d->h + rows_step - 1) / rows_step * rows_step;
+    if (ips == 1 && (long)vh * vw * 2 > (long)hw * 3) return false;      // more than a third of the virtual pixels would be padding (the masked kernel takes those)
+    const int xr = (rows_step + 2) * (sw + 2);
     const int nx = (xr + 7) / 8;
     if (4096 + ips * nx * 1024 > W16P_STAGE) return false;
     int gr = w16_groups((d->cin / 64) * (d->cout / 64));
-    a->N = d->n; a->H = d->h; a->W = d->w; a->Cin = d->cin; a->Cout = d->cout; a->ips = ips; a->nx = nx;
-    a->HWp = ips == 2 ? W16_PS : hw;
+    a->N = d->n; a->H = d->h; a->W = d->w; a->Cin = d->cin; a->Cout = d->cout; a->ips = ips; a->nx = nx; a->sw = sw; a->segs = segs;
+    a->HWp = ips == 2 ? W16_PS : vh * vw;
     a->M = (long)((d->n + ips - 1) / ips) * a->HWp;
     a->wtotal = (size_t)d->cout * d->cin * 9;
     *smem = gr == 2 ? ((size_t)2 * W16P_GROUP + 2048 > (size_t)36 * 256 * 16 ? (size_t)2 * W16P_GROUP + 2048 : (size_t)36 * 256 * 16) : (size_t)W16P_GROUP + 1024;

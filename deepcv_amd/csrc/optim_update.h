@@ -18,16 +18,16 @@ static __device__ __forceinline__ dcv_adamw_scalars dcv_adamw_load_scalars(const
     return s;
 }
 
-// (the gradient as a VALUE: the optimizer's tail launch — conv2d.hip, adamw_prep_slabs_kernel — updates an element in the thread which has just finished its slab sum)
+// (the gradient as a VALUE and the element's parameter / moments as values requested earlier: the optimizer's tail launch — conv2d.hip, adamw_prep_slabs_kernel —
+// updates an element in the thread which has just finished its slab sum, with the three loads already in flight behind the sum's)
 template <bool AMSGRAD>
-static __device__ __forceinline__ float dcv_adamw_update_value(const dcv_adamw_scalars& s, float* __restrict__ p, float g_raw, float* __restrict__ m,
-                                                               float* __restrict__ v, float* __restrict__ vmax, long long i) {
+static __device__ __forceinline__ float dcv_adamw_update_loaded(const dcv_adamw_scalars& s, float* __restrict__ p, float g_raw, float* __restrict__ m,
+                                                                float* __restrict__ v, float* __restrict__ vmax, long long i, float p0, float m0, float v0) {
     // every operation spelled out (no contraction left to the compiler): the kernels which share this function must agree to the bit
     const float gi = __fmul_rn(g_raw, s.gs);
-    float pi = __fmul_rn(p[i], __fsub_rn(1.f, __fmul_rn(s.lr, s.wd)));
-    const float m0 = m[i];
+    float pi = __fmul_rn(p0, __fsub_rn(1.f, __fmul_rn(s.lr, s.wd)));
     const float mi = __fmaf_rn(__fsub_rn(1.f, s.b1), __fsub_rn(gi, m0), m0);      // torch: exp_avg.lerp_(grad, 1 - beta1)
-    const float vi = __fmaf_rn(__fmul_rn(__fsub_rn(1.f, s.b2), gi), gi, __fmul_rn(s.b2, v[i]));
+    const float vi = __fmaf_rn(__fmul_rn(__fsub_rn(1.f, s.b2), gi), gi, __fmul_rn(s.b2, v0));
     m[i] = mi; v[i] = vi;
     float vden = vi;
     if (AMSGRAD) { vden = fmaxf(vmax[i], vi); vmax[i] = vden; }
@@ -35,6 +35,11 @@ static __device__ __forceinline__ float dcv_adamw_update_value(const dcv_adamw_s
     pi = __fmaf_rn(-s.step_size, __fdiv_rn(mi, denom), pi);
     p[i] = pi;
     return pi;
+}
+template <bool AMSGRAD>
+static __device__ __forceinline__ float dcv_adamw_update_value(const dcv_adamw_scalars& s, float* __restrict__ p, float g_raw, float* __restrict__ m,
+                                                               float* __restrict__ v, float* __restrict__ vmax, long long i) {
+    return dcv_adamw_update_loaded<AMSGRAD>(s, p, g_raw, m, v, vmax, i, p[i], m[i], v[i]);
 }
 
 template <bool AMSGRAD>
