@@ -174,7 +174,7 @@ _SIGNATURES = {
     'dcv_conv2d_bf16_fwd_stats_layout': (_c_int, [ctypes.POINTER(Conv2dDesc), ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
     'dcv_conv2d_bf16_fwd': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _c_int, _P, _P]),
     'dcv_conv2d_bf16_dgrad': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _c_int, _P]),
-    'dcv_conv2d_bf16_dgrad_moments': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _P, _P, _P, _c_int, _P]),
+    'dcv_conv2d_bf16_dgrad_moments': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _P, _P, _P, _P, _c_int, _P]),
     'dcv_conv2d_bf16_wgrad_workspace_bytes': (_c_size_t, [ctypes.POINTER(Conv2dDesc)]),
     'dcv_conv2d_bf16_wgrad': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _c_size_t, _P]),
     'dcv_cast_f32_to_bf16': (_c_int, [_P, _P, _c_size_t, _P]),

@@ -258,7 +258,8 @@ __device__ __forceinline__ void bh_wait(int n) {
 template <int WN, bool OUT_BF16, bool PERSIST = (WN == 1), bool MOM = false>
 __global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, const u16* __restrict__ x, const u16* __restrict__ wb, const float* __restrict__ bias,
                                                                  void* __restrict__ yv, double* __restrict__ stats, int win_rows,
-                                                                 const u16* __restrict__ yprev = nullptr, const float* __restrict__ mom_mean = nullptr, const float* __restrict__ mom_rstd = nullptr) {
+                                                                 const u16* __restrict__ yprev = nullptr, const float* __restrict__ mom_mean = nullptr, const float* __restrict__ mom_rstd = nullptr,
+                                                                 const u16* __restrict__ addend = nullptr) {
     constexpr int WM = 8 / WN, BMH = 256, TI = BMH / (16 * WM), BN = 64 * WN, PB = BN / 64;       // PB: 16-B pieces of the filter tile per thread and stage
     constexpr int B_BYTES = BN * 128;
     extern __shared__ __attribute__((aligned(1024))) char lds[];
@@ -346,20 +347,26 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, cons
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (bias) { const float4 b4 = *reinterpret_cast<const float4*>(bias + cbase); bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w; }
     float mmu[4] = {0.f, 0.f, 0.f, 0.f}, mrs[4] = {0.f, 0.f, 0.f, 0.f};
+    // (the MOM instance serves three uses, block-uniform: moments (yprev), a second gradient added to the result before it is stored — the residual link's,
+    //  which autograd otherwise adds with a kernel of its own (`addend`) —, or both)
     if constexpr (MOM) {
-        const float4 m4 = *reinterpret_cast<const float4*>(mom_mean + cbase), r4 = *reinterpret_cast<const float4*>(mom_rstd + cbase);
-        mmu[0] = m4.x; mmu[1] = m4.y; mmu[2] = m4.z; mmu[3] = m4.w; mrs[0] = r4.x; mrs[1] = r4.y; mrs[2] = r4.z; mrs[3] = r4.w;
+        if (yprev != nullptr) {
+            const float4 m4 = *reinterpret_cast<const float4*>(mom_mean + cbase), r4 = *reinterpret_cast<const float4*>(mom_rstd + cbase);
+            mmu[0] = m4.x; mmu[1] = m4.y; mmu[2] = m4.z; mmu[3] = m4.w; mrs[0] = r4.x; mrs[1] = r4.y; mrs[2] = r4.z; mrs[3] = r4.w;
+        }
     }
     auto finish_tile = [&](int dead) __attribute__((always_inline)) {
         float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
-        uint2 yq[MOM ? TI : 1][4];                                  // MOM: the tile's yprev values, all requested before the first use
+        uint2 yq[MOM ? TI : 1][4], aq[MOM ? TI : 1][4];             // MOM: the tile's yprev / addend values, all requested before the first use
         if constexpr (MOM) {
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int m = m0 + 16 * TI * wm + 16 * i + 4 * lg + reg;
-                    yq[i][reg] = *reinterpret_cast<const uint2*>(yprev + (size_t)(m < (int)a.M ? m : 0) * a.Cout + cbase);
+                    const size_t at = (size_t)(m < (int)a.M ? m : 0) * a.Cout + cbase;
+                    yq[i][reg] = yprev != nullptr ? *reinterpret_cast<const uint2*>(yprev + at) : make_uint2(0u, 0u);
+                    aq[i][reg] = addend != nullptr ? *reinterpret_cast<const uint2*>(addend + at) : make_uint2(0u, 0u);
                 }
         }
 #pragma unroll
@@ -375,9 +382,14 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, cons
                         uu[0] = (__uint_as_float(q.x << 16) - mmu[0]) * mrs[0]; uu[1] = (__uint_as_float(q.x & 0xffff0000u) - mmu[1]) * mrs[1];
                         uu[2] = (__uint_as_float(q.y << 16) - mmu[2]) * mrs[2]; uu[3] = (__uint_as_float(q.y & 0xffff0000u) - mmu[3]) * mrs[3];
                     }
+                    float ad[4] = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (MOM) {
+                        const uint2 q = aq[i][reg];
+                        ad[0] = __uint_as_float(q.x << 16); ad[1] = __uint_as_float(q.x & 0xffff0000u); ad[2] = __uint_as_float(q.y << 16); ad[3] = __uint_as_float(q.y & 0xffff0000u);
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        o[j] = dcv_act_apply(acc[i][j][reg] + bv[j], a.act, a.slope);
+                        o[j] = dcv_act_apply(acc[i][j][reg] + bv[j], a.act, a.slope) + ad[j];
                         ssum[j] += o[j]; ssq[j] += MOM ? o[j] * uu[j] : o[j] * o[j];
                     }
                     if constexpr (OUT_BF16) {
@@ -1237,7 +1249,7 @@ inline bool halo_plan(const Bf16Args& a, int bn, int* win_rows, size_t* smem) {
     return true;
 }
 
-struct MomArgs { const u16* yprev; const float* mean; const float* rstd; };
+struct MomArgs { const u16* yprev; const float* mean; const float* rstd; const u16* addend; };
 template <bool OUT_BF16>
 int launch(const Bf16Args& a0, const u16* x, const u16* wb, const float* bias, void* y, double* stats, hipStream_t st, const MomArgs* mom = nullptr) {
     Bf16Args a = a0;
@@ -1268,10 +1280,10 @@ int launch(const Bf16Args& a0, const u16* x, const u16* wb, const float* bias, v
                     dcv_count_launch(DCV_FAMILY_BF16_WINDOW);
                     if (wide) {
                         if (!mconf[0]) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_halo_kernel<2, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DCV_ERR_LAUNCH; mconf[0] = true; }
-                        hipLaunchKernelGGL((conv_bf16_halo_kernel<2, true, false, true>), hgrid, dim3(512), hs, st, ah, x, wb, bias, y, stats, win_rows, mom->yprev, mom->mean, mom->rstd);
+                        hipLaunchKernelGGL((conv_bf16_halo_kernel<2, true, false, true>), hgrid, dim3(512), hs, st, ah, x, wb, bias, y, stats, win_rows, mom->yprev, mom->mean, mom->rstd, mom->addend);
                     } else {
                         if (!mconf[1]) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_halo_kernel<1, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DCV_ERR_LAUNCH; mconf[1] = true; }
-                        hipLaunchKernelGGL((conv_bf16_halo_kernel<1, true, true, true>), hgrid, dim3(512), hs, st, ah, x, wb, bias, y, stats, win_rows, mom->yprev, mom->mean, mom->rstd);
+                        hipLaunchKernelGGL((conv_bf16_halo_kernel<1, true, true, true>), hgrid, dim3(512), hs, st, ah, x, wb, bias, y, stats, win_rows, mom->yprev, mom->mean, mom->rstd, mom->addend);
                     }
                     return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
                 }
@@ -1643,13 +1655,14 @@ int dcv_conv2d_bf16_dgrad(const dcv_conv2d_desc* d, const void* dy, const void* 
 }
 
 // dcv_conv2d_bf16_dgrad (stride 1) whose statistics epilogue leaves the moments of dx the BatchNorm-only layer below needs (the kernel's header); rows of 128 pixels
-int dcv_conv2d_bf16_dgrad_moments(const dcv_conv2d_desc* d, const void* dy, const void* filter, void* dx, const void* y_prev, const float* mean, const float* rstd,
-                                  double* moments, int moments_rows, void* stream) {
-    DCV_CHECK_ARG(desc_ok(d) && dy && filter && dx && y_prev && mean && rstd && moments);
+int dcv_conv2d_bf16_dgrad_moments(const dcv_conv2d_desc* d, const void* dy, const void* filter, void* dx, const void* addend, const void* y_prev, const float* mean,
+                                  const float* rstd, double* moments, int moments_rows, void* stream) {
+    DCV_CHECK_ARG(desc_ok(d) && dy && filter && dx && (addend || y_prev) && (!y_prev || (mean && rstd && moments)));
     if (!supported(d, 1) || d->stride_h != 1 || d->stride_w != 1) return DCV_ERR_UNSUPPORTED;
-    DCV_CHECK_ARG(aligned16(dy) && aligned16(filter) && aligned16(dx) && aligned16(y_prev) && aligned16(mean) && aligned16(rstd));
+    DCV_CHECK_ARG(aligned16(dy) && aligned16(filter) && aligned16(dx) && (!y_prev || (aligned16(y_prev) && aligned16(mean) && aligned16(rstd))) && (!addend || aligned16(addend)));
     const long M = (long)d->n * d->h * d->w;
-    if (moments_rows != (int)dcv_ceil_div((size_t)M, 128)) return DCV_ERR_INVALID_ARG;
+    if (y_prev && moments_rows != (int)dcv_ceil_div((size_t)M, 128)) return DCV_ERR_INVALID_ARG;
+    if ((size_t)d->n * d->ho * d->wo * d->cout * 2 >= slice_limit()) return DCV_ERR_UNSUPPORTED;
     Bf16Args a{};
     a.N = d->n; a.Hin = d->ho; a.Win = d->wo; a.Cin = d->cout; a.Cout = d->cin;
     a.sh = 1; a.sw = 1; a.dh = d->dil_h; a.dw = d->dil_w; a.act = DCV_ACT_NONE; a.slope = 0.f;
@@ -1657,8 +1670,8 @@ int dcv_conv2d_bf16_dgrad_moments(const dcv_conv2d_desc* d, const void* dy, cons
     a.Hout = d->h; a.Wout = d->w; a.R = d->r; a.S = d->s;
     a.ph = d->dil_h * (d->r - 1) - d->pad_h; a.pw = d->dil_w * (d->s - 1) - d->pad_w; a.M = M;
     a.w_bytes = (unsigned)((size_t)d->cout * d->cin * d->r * d->s * 2);
-    const MomArgs mom{reinterpret_cast<const u16*>(y_prev), mean, rstd};
-    return launch<true>(a, reinterpret_cast<const u16*>(dy), reinterpret_cast<const u16*>(filter), nullptr, dx, moments, dcv_stream(stream), &mom);
+    const MomArgs mom{reinterpret_cast<const u16*>(y_prev), mean, rstd, reinterpret_cast<const u16*>(addend)};
+    return launch<true>(a, reinterpret_cast<const u16*>(dy), reinterpret_cast<const u16*>(filter), nullptr, dx, y_prev ? moments : nullptr, dcv_stream(stream), &mom);
 }
 
 // im2col of a small-cin first layer: out[m][k] (bf16, row stride kpad) = x[n][ci][ho sh - ph + r dh][wo sw - pw + s dw] for k = (ci R + r) S + s (the OIHW

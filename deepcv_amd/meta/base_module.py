@@ -132,7 +132,7 @@ class DeepcvModule(torch.nn.Module):
                     x = subm(x)
             referrers = sum(1 for r in remaining_refs.values() if name in r)
             if referrers:
-                if (referrers == 1 and isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.requires_grad and torch.is_grad_enabled()
+                if (referrers == 1 and isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16) and x.requires_grad and torch.is_grad_enabled()
                         and i + 1 < len(items) and not getattr(items[i + 1][1], 'referenced_submodules', None)):
                     # ONE later referrer and a regular consumer next: the referrer's gradient can be added by the consumer's data-gradient kernel
                     x, ref, fan_slots[name] = native_ops.fan_out(x)

@@ -198,6 +198,9 @@ def _stem_as_gemm(x, weight, stride, padding, dilation):
 
 
 _dgrad_moments = os.environ.get('DCV_DGRAD_MOMENTS', '1') not in ('0', 'false', 'False', '')
+# how often the fused epilogues of the bf16 data-gradient kernel were taken (tests read it around a step): 'addend' = a residual link's gradient added there,
+# 'moments' = left for the layer below, 'moments_used' = that layer's normalisation backward skipped its sums pass
+fusion_counts = {'addend': 0, 'moments': 0, 'moments_used': 0}
 
 
 class _Producer:
@@ -242,15 +245,28 @@ def _conv_bwd16_launch(ctx, d, x_saved, dz, weight, dx_needed: bool, dw, st):
             dz16 = _to_bf16(dz, st) if dz16 is None else dz16
             f = filters.get(weight, dd, 1, bf16=True)
             prod, done = getattr(ctx, 'in_producer', None), False
-            if (prod is not None and prod.consumers == 1 and dx.dtype == torch.bfloat16 and d.stride_h == 1 and d.stride_w == 1
-                    and tuple(prod.y.shape) == tuple(dx.shape) and prod.y.dtype == torch.bfloat16):
-                # the layer below is BatchNorm-only on bf16 tensors: this kernel's epilogue leaves the moments its normalisation backward needs from dx
+            fused_ok = dx.dtype == torch.bfloat16 and d.stride_h == 1 and d.stride_w == 1
+            # the gradient a later `_from` referrer of x left in the fan-out slot (a residual link's): added in this kernel's epilogue instead of by autograd
+            addend = _fan_addend(getattr(ctx, 'fan_slot', None), dx.shape) if fused_ok else None
+            if addend is not None and addend.dtype != torch.bfloat16:
+                addend = None
+            want_mom = (fused_ok and prod is not None and prod.consumers == 1 and tuple(prod.y.shape) == tuple(dx.shape) and prod.y.dtype == torch.bfloat16)
+            if addend is not None or want_mom:
+                # ... and / or: the layer below is BatchNorm-only on bf16 tensors — the epilogue leaves the moments its normalisation backward needs from dx
                 rows = (d.n * d.h * d.w + 127) // 128
-                mom = torch.empty((2, d.cin, rows), dtype=torch.float64, device=dev)
-                rc = lib.dcv_conv2d_bf16_dgrad_moments(dd, dz16.data_ptr(), f.data_ptr(), dx.data_ptr(), prod.y.data_ptr(), prod.mean.data_ptr(), prod.rstd.data_ptr(),
-                                                       mom.data_ptr(), rows, st)
+                mom = torch.empty((2, d.cin, rows), dtype=torch.float64, device=dev) if want_mom else None
+                rc = lib.dcv_conv2d_bf16_dgrad_moments(dd, dz16.data_ptr(), f.data_ptr(), dx.data_ptr(), nat.ptr(addend),
+                                                       prod.y.data_ptr() if want_mom else None, prod.mean.data_ptr() if want_mom else None,
+                                                       prod.rstd.data_ptr() if want_mom else None, nat.ptr(mom), rows if want_mom else 0, st)
                 if rc == 0:
-                    prod.moments, done = (mom, rows, dx.data_ptr(), dx._version), True
+                    done = True
+                    if addend is not None:
+                        ctx.fan_slot.consumed = True
+                        ctx._addend_keep = addend
+                        fusion_counts['addend'] += 1
+                    if want_mom:
+                        prod.moments = (mom, rows, dx.data_ptr(), dx._version)
+                        fusion_counts['moments'] += 1
                 elif rc != nat.ERR_UNSUPPORTED:
                     nat.check(rc, 'dcv_conv2d_bf16_dgrad_moments')
             if not done:
@@ -356,8 +372,11 @@ class _FanOutFn(torch.autograd.Function):
         total = parts[0]
         for g in parts[1:]:
             a, b = to_nhwc(total) if total.dim() == 4 else total.contiguous(), to_nhwc(g) if g.dim() == 4 else g.contiguous()
+            if a.dtype != b.dtype:
+                a, b = _f32(a), _f32(b)
             out = torch.empty_like(a)
-            nat.check(lib.dcv_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), out.numel(), nat.current_stream(out.device)), 'dcv_add')
+            add = lib.dcv_add_bf16 if a.dtype == torch.bfloat16 else lib.dcv_add
+            nat.check(add(a.data_ptr(), b.data_ptr(), out.data_ptr(), out.numel(), nat.current_stream(out.device)), 'dcv_add')
             total = out
         return total, None
 
@@ -380,6 +399,9 @@ def fan_out(x: torch.Tensor):
     slot = _FanSlot()
     main, ref = _FanOutFn.apply(x, slot)
     main._dcv_fan_slot = slot
+    prod = getattr(x, '_dcv_producer', None)
+    if prod is not None:
+        main._dcv_producer = prod         # (the main consumer's data-gradient kernel adds the referrer's gradient itself: what it stores IS the gradient of x, `_Producer`)
     return main, ref, slot
 
 
@@ -933,6 +955,7 @@ class _ConvNormLayerFn(torch.autograd.Function):
                 mom, mrows, mptr, mver = prod.moments
                 if dout.data_ptr() == mptr and dout._version == mver and tuple(dout.shape) == tuple(y.shape):
                     nc.moments, nc.moments_rows = mom.data_ptr(), mrows      # the consumer's data-gradient kernel left them (`_Producer`)
+                    fusion_counts['moments_used'] += 1
                 prod.moments = None
             ws = _ws(lib.dcv_norm_chain_ws_bytes(nc), dev)
             nat.check(lib.dcv_norm_chain_bwd(nc, dout.data_ptr(), y.data_ptr(), dz.data_ptr(), nat.ptr(d_bn_w), nat.ptr(d_bn_b), nat.ptr(d_gn_w), nat.ptr(d_gn_b),
@@ -1210,7 +1233,13 @@ def add_tensors(tensors: Sequence[torch.Tensor], mean: bool = False) -> torch.Te
         tensors = [_f32(t) for t in tensors]
     if len(tensors) == 1:
         return tensors[0]
-    return _AddFn.apply(1. / len(tensors) if mean else 1., *tensors)
+    out = _AddFn.apply(1. / len(tensors) if mean else 1., *tensors)
+    prods = [getattr(t, '_dcv_producer', None) for t in tensors]
+    if not mean and sum(p is not None for p in prods) == 1:
+        # a plain sum hands its output's gradient to every input unchanged: the BatchNorm-only layer behind ONE of them can take its backward moments from the
+        # data-gradient kernel of the sum's consumer (`_Producer`: a residual link: layer output + skip)
+        out._dcv_producer = next(p for p in prods if p is not None)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ flatten (NHWC memory -> reference C-major feature order)

@@ -186,12 +186,16 @@ int dcv_conv2d_bf16_prepare_filters(int count, const dcv_conv2d_desc* const* des
 int dcv_conv2d_bf16_fwd_stats_layout(const dcv_conv2d_desc* d, int* rows, int* rows_per_sample);   /* as dcv_conv2d_fwd_stats_layout, for the kernel below */
 int dcv_conv2d_bf16_fwd(const dcv_conv2d_desc* d, const void* x_bf16, const void* filter, const float* bias, void* y, int y_dtype, double* stats, void* stream);
 int dcv_conv2d_bf16_dgrad(const dcv_conv2d_desc* d, const void* dy_bf16, const void* filter, void* dx, int dx_dtype, void* stream);
-/* the stride-1 data gradient (dx bf16) which ALSO leaves what the normalisation backward of the BatchNorm-only layer below needs from dx (autograd's
- * BatchNorm backward, reference nn.py:487-501): moments[0][c][row] = sum of dx, moments[1][c][row] = sum of dx * (y_prev - mean[c]) * rstd[c] over row blocks of
- * 128 pixels (moments_rows = ceil(n h w / 128)); y_prev: that layer's activated convolution output, bf16 [n][h][w][cin]; hand them to dcv_norm_chain_bwd
- * (dcv_norm_chain_desc::moments).  DCV_ERR_UNSUPPORTED when the kernel serving the shape has no such epilogue: call dcv_conv2d_bf16_dgrad. */
-int dcv_conv2d_bf16_dgrad_moments(const dcv_conv2d_desc* d, const void* dy_bf16, const void* filter, void* dx_bf16, const void* y_prev_bf16, const float* mean,
-                                  const float* rstd, double* moments, int moments_rows, void* stream);
+/* the stride-1 data gradient (dx bf16) with a fused epilogue, either or both of:
+ *   addend (nullable): a second gradient of dx's shape (bf16) added to the result before it is stored and summed — the residual link's gradient, which autograd's
+ *     engine otherwise adds with a kernel of its own (reference submodule_creators.py:272-327, the `_from` links);
+ *   y_prev / mean / rstd / moments (nullable as a group): what the normalisation backward of the BatchNorm-only layer below needs from dx (autograd's BatchNorm
+ *     backward, reference nn.py:487-501): moments[0][c][row] = sum of dx, moments[1][c][row] = sum of dx * (y_prev - mean[c]) * rstd[c] over row blocks of 128
+ *     pixels (moments_rows = ceil(n h w / 128)); y_prev: that layer's activated convolution output, bf16 [n][h][w][cin]; hand them to dcv_norm_chain_bwd
+ *     (dcv_norm_chain_desc::moments).
+ * DCV_ERR_UNSUPPORTED when the kernel serving the shape has no such epilogue: call dcv_conv2d_bf16_dgrad (and add / sum separately). */
+int dcv_conv2d_bf16_dgrad_moments(const dcv_conv2d_desc* d, const void* dy_bf16, const void* filter, void* dx_bf16, const void* addend_bf16, const void* y_prev_bf16,
+                                  const float* mean, const float* rstd, double* moments, int moments_rows, void* stream);
 size_t dcv_conv2d_bf16_wgrad_workspace_bytes(const dcv_conv2d_desc* d);
 int dcv_conv2d_bf16_wgrad(const dcv_conv2d_desc* d, const void* x_bf16, const void* dy_bf16, float* dw, void* ws, size_t ws_bytes, void* stream);
 /* element type conversion (round to nearest even, NaN stays NaN); n elements, x 16-B (fp32) / 8-B (bf16) aligned */

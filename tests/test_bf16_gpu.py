@@ -283,7 +283,10 @@ def test_bf16_kernels_at_the_bench_shapes(device, case):
     mom = torch.full((2, cin, mrows), float('nan'), dtype=torch.float64, device=device)
     dx16 = torch.empty((n, cin, h, w), dtype=torch.bfloat16, device=device).contiguous(memory_format=torch.channels_last)
     ypd, md, rd = yp.to(device), mean.to(device), rstd.to(device)
-    rc = lib.dcv_conv2d_bf16_dgrad_moments(d0, dyd.data_ptr(), f1.data_ptr(), dx16.data_ptr(), ypd.data_ptr(), md.data_ptr(), rd.data_ptr(), mom.data_ptr(), mrows, st)
+    add = _bf(torch.randn(n, cin, h, w) * 0.5).contiguous(memory_format=torch.channels_last)      # a second gradient (the residual link's) added in the epilogue
+    addd = add.to(device)
+    rc = lib.dcv_conv2d_bf16_dgrad_moments(d0, dyd.data_ptr(), f1.data_ptr(), dx16.data_ptr(), addd.data_ptr(), ypd.data_ptr(), md.data_ptr(), rd.data_ptr(), mom.data_ptr(), mrows, st)
+    ref_dx32 = ref_dx32 + add.float()
     assert rc == 0, f'dcv_conv2d_bf16_dgrad_moments: {rc} (the window kernel serves every bench shape)'
     torch.cuda.synchronize()
     assert _rel(dx16, ref_dx32) <= 4.5e-3

@@ -246,9 +246,10 @@ def test_wide_models_match_oracle_at_the_bench_batch(device, params, spec, nc, s
     native, oracle = _build({'smooth': smooth}, 'smooth', nc, image_shape=shape)
     prev = ops.set_conv_math(math)
     try:
-        before = nat.launch_counts()
+        before, fused_before = nat.launch_counts(), dict(ops.fusion_counts)
         e_logits, e_loss = _fwd_bwd_pair(native.to(device), oracle, x, y, device)
         ran = _family_delta(before, nat.launch_counts())
+        fused = {k: ops.fusion_counts[k] - fused_before[k] for k in fused_before}
         errs = _grad_rel_errors(native, oracle)
         worst = max(errs, key=errs.get)
         _report(f'{spec}[bs {n}, {math}, tanh twin]: logits rel err {e_logits:.3e}, loss rel err {e_loss:.3e}, worst grad rel err {errs[worst]:.3e} ({worst}); kernels {ran}')
@@ -261,6 +262,11 @@ def test_wide_models_match_oracle_at_the_bench_batch(device, params, spec, nc, s
             assert 1e-5 < e_logits <= 1e-1 and e_loss <= 1e-2
             assert errs[worst] <= 0.3, f'gradient rel err {errs[worst]:.3e} at {worst}'
             assert ran.get('bf16_window', 0) > 0 and ran.get('bf16_wgrad9', 0) > 0, f'the bf16 window / all-taps kernels did not run: {ran}'
+            # round 4: the data-gradient kernel's fused epilogues are part of what the bench times — the moments of the layer below (both specs), the residual
+            # links' gradients (resnet18_style) — so the gradients compared above came through them
+            assert fused['moments'] >= 4 and fused['moments_used'] == fused['moments'], fused
+            if 'resnet' in spec:
+                assert fused['addend'] >= 4, fused
         del native, oracle
         # the spec itself (ReLU): forward and loss
         native, oracle = _build(params, spec, nc, image_shape=shape)
