@@ -179,6 +179,7 @@ _SIGNATURES = {
     'dcv_conv2d_bf16_wgrad': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _P, _P, _c_size_t, _P]),
     'dcv_cast_f32_to_bf16': (_c_int, [_P, _P, _c_size_t, _P]),
     'dcv_im2col_bf16': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _c_int, _P]),
+    'dcv_space_to_depth_bf16': (_c_int, [ctypes.POINTER(Conv2dDesc), _P, _P, _c_int, _c_int, _c_int, _P]),
     'dcv_cast_bf16_to_f32': (_c_int, [_P, _P, _c_size_t, _P]),
     'dcv_act_fwd': (_c_int, [_P, _P, _c_size_t, _c_int, _c_float, _P]),
     'dcv_act_bwd_workspace_bytes': (_c_size_t, [_c_size_t, _c_int]),

@@ -43,6 +43,7 @@ struct Bf16Args {
     unsigned x_bytes, w_bytes;     // buffer sizes (num_records)
     int phase, oh_mul, ow_mul, oh_off, ow_off, Hfull, Wfull;      // strided data gradient: this launch writes phase (oh_off, ow_off) of the full tensor
     unsigned magic_w, magic_h;     // the window kernel: floor((2^32 - 1) / Win) + 1, ... / Hin + 1: n / d = mulhi(n, magic) for n d < 2^32
+    int pix;                       // elements between neighbouring pixels of the tensor read (Cin; the folded first layer: the real channel count, see fold_rows below)
     int stat_rows, stat_row0;      // a launch over a SLICE of the batch (tensors beyond 2 GiB run as several launches): rows of the whole statistics array (0: this launch's own) and this slice's first row
 };
 
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(Bf16Args a, const u16
             wo = (int)(um - r1 * (unsigned)a.Wout); ho = (int)(r1 - nn * (unsigned)a.Hout); n = (int)nn;
         } else { wo = (int)(mm % a.Wout); const long r1 = mm / a.Wout; ho = (int)(r1 % a.Hout); n = (int)(r1 / a.Hout); }
         const int hi0 = ho * a.sh - a.ph, wi0 = wo * a.sw - a.pw;
-        offa[p] = (((n * a.Hin + hi0) * a.Win + wi0) * a.Cin) * 2 + lslot * 16;      // may be negative for border pixels: only used under its validity bit
+        offa[p] = (((n * a.Hin + hi0) * a.Win + wi0) * a.pix) * 2 + lslot * 16;      // may be negative for border pixels: only used under its validity bit
         unsigned long long mk = 0;
         if (ok)
             for (int r = 0; r < a.R; ++r) {
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(Bf16Args a, const u16
     int l_tap = 0, l_chunk = 0, l_r = 0, l_s = 0;
     auto stage = [&](int buf) {
         char* base = lds + buf * STAGE;
-        const int ua = ((l_r * a.dh) * a.Win + l_s * a.dw) * a.Cin * 2 + l_chunk * 128;
+        const int ua = ((l_r * a.dh) * a.Win + l_s * a.dw) * a.pix * 2 + l_chunk * 128;
         const int ub = (l_tap * a.Cout) * a.Cin * 2 + l_chunk * 128;
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
@@ -916,7 +917,240 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9p_kernel(W16p
             }
 }
 
+// ------------------------------------------------------------------------------------------------ round 4: the one-tap weight gradient as a proper GEMM
+// dW[co][k] = sum over pixels of dz[p][co] xm[p][k] for a matrix xm [n hw][Kc] (a first layer's im2col matrix, the gathered matrix of a strided layer).  The one-tap
+// instance of the all-taps kernel above gives a wave one 16-column group of k and four MFMAs per step for ten transposed reads (2.5 LDS reads per MFMA: 600 us per
+// call on resnet18_style at bs 512, 15 % of its step).  Here a block owns 64 output channels x NT groups of 64 columns: a wave's x fragments feed 4 NT MFMAs per
+// 8 + 2 NT reads (1.0 per MFMA at NT = 4), the tiles staged as in the padded-window kernel (128-byte source-swizzled rows, LDS-DMA of eight rows, three stages at
+// compile-time distances); every wave issues one dz instruction and NT x instructions per step (its rows 8 w .. 8 w + 7 of every tile).
+struct W16gArgs {
+    int N, HW, HWp, Kc, Cout; long M, m_per_chunk; size_t wtotal;
+    // IMPL: the matrix is never written — column group g = (tap, 64 channels cg of cig) of pixel (ho, wo) is the 128 bytes of the layer's INPUT at
+    // ((ho sh - ph + r dh) W + wo sw - pw + s dw) pix_bytes + 128 cg (zeros outside the image: rows by the per-image buffer range, columns by a per-lane test)
+    int Wo, W, pix_bytes, sh, sw, ph, pw, dh, dw, S, cig; unsigned magic_wo, x_img;
+};
+#define W16G_STAGE(CT, NT) ((CT) * 1024 + (NT) * 4096)
+
+// CT: 16-channel output tiles per wave (4 or 8: the block owns 64 or 128 output channels).  What a block moves per step is 32 pixels x (16 CT + 64 NT) values for
+// 32 x 16 CT x 64 NT multiply-adds: 51 flop per byte at 64 x 256, 85 at 128 x 256 — the L2 -> LDS stream, not the matrix pipe, is what the 64-channel tile ran at
+// (8.4 TB/s summed over the chip at 485 TFLOP/s on 256 -> 512 / stride 2).
+template <int GROUPS, int CT, int NT, bool IMPL = false>
+__global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgradg_kernel(W16gArgs a, const u16* __restrict__ xm, const u16* __restrict__ dy, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(1024))) char smem16g[];
+    constexpr int STAGE = W16G_STAGE(CT, NT), GROUP = 3 * STAGE, XOFF = CT * 1024, DS = CT / 4;
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), t = threadIdx.x & 255, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const unsigned St = (unsigned)(size_t)smem16g + (unsigned)(grp * GROUP);
+    const int li = lane & 15, lg = lane >> 4;
+    const int k0 = blockIdx.y * 64 * NT, co0 = blockIdx.z * 16 * CT;
+    const int per_group = (int)(a.m_per_chunk / GROUPS);
+    const int mb = (int)blockIdx.x * (int)a.m_per_chunk + grp * per_group;
+    int me = mb + per_group; if (me > (int)a.M) me = (int)a.M;
+    const int nsteps = per_group / W16_PS;
+    const int steps_g = me > mb ? (me - mb + W16_PS - 1) / W16_PS : 0;
+    int l_n = __builtin_amdgcn_readfirstlane(mb / a.HWp), l_p0 = __builtin_amdgcn_readfirstlane(mb - (mb / a.HWp) * a.HWp);
+    // operand addresses: pixel j0 of each K half; dz tile tt & 3 of the first 64 channels (the second 64: + 4096), this wave's 16 columns of x tile 0 (tile q: + 4096 q)
+    const int j0 = 4 * lg + (li >> 2), sub = (li & 3) * 8;
+    unsigned aaddr[2][4], baddr[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const int ra = j0 + 16 * hf;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) { aaddr[hf][tt] = St + (unsigned)(ra * 128 + ((tt ^ ((ra >> 1) & 3)) << 5) + sub); asm volatile("" : "+v"(aaddr[hf][tt])); }
+        baddr[hf] = St + (unsigned)(XOFF + ra * 128 + ((wave ^ ((ra >> 1) & 3)) << 5) + sub);
+        asm volatile("" : "+v"(baddr[hf]));
+    }
+    // staging: this wave's rows 8 wave .. 8 wave + 7 of every 4 KB sub-tile (32 pixels x 128 bytes; the lane's 16-byte piece holds logical piece ^ 2 ((row >> 1) & 3))
+    const int row = 8 * wave + (lane >> 3), piece = lane & 7, swz = (piece ^ (((row >> 1) & 3) << 1)) << 4;
+    unsigned vdz = (unsigned)((row * a.Cout + co0) * 2 + swz), vx = (unsigned)((row * a.Kc + k0) * 2 + swz);
+    asm volatile("" : "+v"(vdz), "+v"(vx));
+    const unsigned dz_img = (unsigned)(a.HW * a.Cout * 2), x_img = IMPL ? a.x_img : (unsigned)(a.HW * a.Kc * 2);
+    unsigned long long gbase = (unsigned long long)dy + (unsigned long long)l_n * dz_img, xbase = (unsigned long long)xm + (unsigned long long)l_n * x_img;
+    const unsigned sdz = St + (unsigned)(wave * 1024);
+    // IMPL: the block's NT column groups as (byte offset of the tap and channel group, the tap's column shift)
+    int toff[NT], scol[NT];
+    if constexpr (IMPL) {
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            const int g = blockIdx.y * NT + q, tap = g / a.cig, cg = g - tap * a.cig, r = tap / a.S, sx = tap - r * a.S;
+            toff[q] = __builtin_amdgcn_readfirstlane((r * a.dh * a.W + sx * a.dw) * a.pix_bytes + cg * 128);
+            scol[q] = __builtin_amdgcn_readfirstlane(sx * a.dw - a.pw);
+        }
+    }
+    auto dma_step = [&](int stg) {
+        const bw_i32x4 rg = {(int)__builtin_amdgcn_readfirstlane((unsigned)gbase), (int)(__builtin_amdgcn_readfirstlane((unsigned)(gbase >> 32)) & 0xFFFFu), (int)dz_img, 0x00020000};
+        const bw_i32x4 rx = {(int)__builtin_amdgcn_readfirstlane((unsigned)xbase), (int)(__builtin_amdgcn_readfirstlane((unsigned)(xbase >> 32)) & 0xFFFFu), (int)x_img, 0x00020000};
+        unsigned sb2 = __builtin_amdgcn_readfirstlane(sdz);
+        asm volatile("" : "+s"(sb2));
+        const unsigned dst = sb2 + (unsigned)(stg * STAGE);
+        const unsigned vg = vdz + (unsigned)(l_p0 * a.Cout * 2);
+#pragma unroll
+        for (int q = 0; q < DS; ++q) bw_dma16(rg, dst + (unsigned)(q * 4096), vg, (unsigned)(q * 128));
+        if constexpr (IMPL) {
+            const unsigned pp = (unsigned)(l_p0 + row), ho = __umulhi(pp, a.magic_wo), wo = pp - ho * (unsigned)a.Wo;
+            const int iw0 = (int)wo * a.sw;
+            const unsigned vb = (unsigned)((((int)ho * a.sh - a.ph) * a.W + iw0 - a.pw) * a.pix_bytes + swz);      // (mod 2^32: rows above the image wrap out of range)
+#pragma unroll
+            for (int q = 0; q < NT; ++q) {
+                const bool ok = (unsigned)(iw0 + scol[q]) < (unsigned)a.W;
+                bw_dma16(rx, dst + (unsigned)(XOFF + q * 4096), ok ? vb + (unsigned)toff[q] : BF_OOB, 0u);
+            }
+        } else {
+            const unsigned vo = vx + (unsigned)(l_p0 * a.Kc * 2);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) bw_dma16(rx, dst + (unsigned)(XOFF + q * 4096), vo, (unsigned)(q * 128));
+        }
+        l_p0 += W16_PS;
+        if (l_p0 >= a.HWp) { l_p0 = 0; ++l_n; gbase += dz_img; xbase += x_img; }
+        l_p0 = __builtin_amdgcn_readfirstlane(l_p0); l_n = __builtin_amdgcn_readfirstlane(l_n);
+    };
+    f32x4 acc[NT][CT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[q][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    union Frag { bf16x8 v; s16x4 h[2]; };
+    auto body = [&](auto stgc, int it) __attribute__((always_inline)) {
+        constexpr int STG = decltype(stgc)::value;
+        const bool active = it < steps_g;
+        if (active) { if (it + 1 < steps_g) w16_wait(DS + NT); else __builtin_amdgcn_s_waitcnt(0x0F70); }
+        __syncthreads();
+        if (it + 2 < steps_g) dma_step((STG + 2) % 3);
+        if (active) {
+            constexpr unsigned SO = (unsigned)(STG * STAGE);
+            Frag af[CT], bq[2];
+#pragma unroll
+            for (int tt = 0; tt < CT; ++tt) {
+                af[tt].h[0] = tr_read_lds(aaddr[0][tt & 3] + SO + (unsigned)((tt >> 2) * 4096));
+                af[tt].h[1] = tr_read_lds(aaddr[1][tt & 3] + SO + (unsigned)((tt >> 2) * 4096));
+            }
+            bq[0].h[0] = tr_read_lds(baddr[0] + SO); bq[0].h[1] = tr_read_lds(baddr[1] + SO);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) {
+                if (q + 1 < NT) { bq[(q + 1) & 1].h[0] = tr_read_lds(baddr[0] + SO + (unsigned)((q + 1) * 4096)); bq[(q + 1) & 1].h[1] = tr_read_lds(baddr[1] + SO + (unsigned)((q + 1) * 4096)); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tt = 0; tt < CT; ++tt) acc[q][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tt].v, bq[q & 1].v, acc[q][tt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    for (int j = 0; j < 2; ++j) if (j < steps_g) dma_step(j);
+    for (int it = 0; it < nsteps; it += 3) {
+        body(std::integral_constant<int, 0>{}, it);
+        if (it + 1 < nsteps) body(std::integral_constant<int, 1>{}, it + 1);
+        if (it + 2 < nsteps) body(std::integral_constant<int, 2>{}, it + 2);
+    }
+    __syncthreads();
+    if constexpr (GROUPS == 2) {
+        f32x4* red = reinterpret_cast<f32x4*>(smem16g);
+        if (grp == 1) {
+#pragma unroll
+            for (int q = 0; q < NT; ++q)
+#pragma unroll
+                for (int tt = 0; tt < CT; ++tt) red[(q * CT + tt) * 256 + t] = acc[q][tt];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int q = 0; q < NT; ++q)
+#pragma unroll
+            for (int tt = 0; tt < CT; ++tt) acc[q][tt] += red[(q * CT + tt) * 256 + t];
+    }
+    // acc[q][tt][reg]: co = co0 + 16 tt + 4 lg + reg, k = k0 + 64 q + 16 wave + li; slab [co][Kc]
+    float* dst = partial + (size_t)blockIdx.x * a.wtotal;
+#pragma unroll
+    for (int q = 0; q < NT; ++q)
+#pragma unroll
+        for (int tt = 0; tt < CT; ++tt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                dst[(size_t)(co0 + tt * 16 + 4 * lg + reg) * a.Kc + k0 + 64 * q + wave * 16 + li] = acc[q][tt][reg];
+}
+
 inline int w16_groups(int tiles);
+// the GEMM's tile (CT x NT), wave groups and chunks for cout x Kc over N images of hw pixels
+struct W16gPlan { int ct, nt, groups, chunks, implicit; size_t smem; };
+inline bool w16g_choose(int n, int hw, int cout, int kc, W16gArgs* a, W16gPlan* p) {
+    static int wide = -1;
+    if (wide < 0) { const char* e = getenv("DCV_BF16_WGRADG_WIDE"); wide = e ? atoi(e) : 1; }
+    const int hwp = (hw + W16_PS - 1) / W16_PS * W16_PS;
+    if (hw < 16 || (long)hwp * 2 > (long)hw * 3 || (size_t)hw * cout * 2 >= ((size_t)1 << 30) || kc % 64 != 0 || cout % 64 != 0) return false;
+    const int g64 = kc / 64;
+    const int NT = g64 % 4 == 0 ? 4 : g64 % 3 == 0 ? 3 : g64 % 2 == 0 ? 2 : 1;
+    const int CT = (wide && cout % 128 == 0) ? 8 : 4;
+    const long tiles = (long)(g64 / NT) * (cout / (16 * CT));
+    a->N = n; a->HW = hw; a->HWp = hwp; a->Kc = kc; a->Cout = cout;
+    a->M = (long)n * hwp;
+    a->wtotal = (size_t)cout * kc;
+    // chunks: the blocks of one chunk (its tiles) read the same pixels — dz once per column group, the matrix once per output-channel tile.  Workgroups go to the
+    // eight XCDs round-robin in launch order (x fastest), so a chunk count that is a multiple of 8 puts a chunk's tiles behind ONE L2 and the re-reads stay there
+    // (the matrix of a strided layer is taps x its input: 462 MB for 64 -> 128 / stride 2 at 56 x 56 x 512 images; measured on 256 -> 512 / stride 2: 8 chunks of
+    // 72 tiles 122 us, 7 chunks — no second round of blocks, but every chunk spread over all XCDs — 166 us).  One or two wave groups: whichever fills more of the chip.
+    const size_t stage = (size_t)W16G_STAGE(CT, NT), red_bytes = (size_t)NT * CT * 256 * 16;
+    long best_ch = 0; int best_gr = 1; long best_busy = -1;
+    for (int gr = 2; gr >= 1; --gr) {
+        const size_t smem = gr == 2 ? (6 * stage > red_bytes ? 6 * stage : red_bytes) : 3 * stage;
+        if (smem > 160 * 1024) continue;
+        const long slots_xcd = (gr == 2 ? 1 : 2) * DCV_NUM_CU / 8;
+        long ch = tiles <= slots_xcd ? 8 * (slots_xcd / tiles) : 8;
+        const long unit = (long)gr * W16_PS;
+        const long max_by_m = a->M / (4 * unit) > 0 ? a->M / (4 * unit) : 1;
+        if (ch > max_by_m) ch = max_by_m >= 8 ? max_by_m / 8 * 8 : max_by_m;
+        const long max_by_bytes = (long)(((size_t)256 << 20) / (a->wtotal * sizeof(float)));
+        if (ch > max_by_bytes) ch = max_by_bytes >= 8 ? max_by_bytes / 8 * 8 : max_by_bytes;
+        if (ch < 1) ch = 1;
+        long busy = ch * tiles * gr;                             // wave groups at work (of 2 x 256 slots)
+        if (busy > 2 * DCV_NUM_CU) busy = 2 * DCV_NUM_CU;
+        if (busy > best_busy) { best_busy = busy; best_ch = ch; best_gr = gr; }
+    }
+    if (best_busy < 0) return false;
+    const int gr = best_gr;
+    const long unit = (long)gr * W16_PS;
+    long mpc = (a->M + best_ch - 1) / best_ch;
+    mpc = (mpc + unit - 1) / unit * unit;
+    a->m_per_chunk = mpc;
+    p->ct = CT; p->nt = NT; p->groups = gr; p->implicit = 0;
+    p->chunks = (int)((a->M + mpc - 1) / mpc);
+    p->smem = gr == 2 ? (6 * stage > red_bytes ? 6 * stage : red_bytes) : 3 * stage;
+    return true;
+}
+// ... for a "1x1 layer" descriptor (h, w = the pixel map, cin = Kc): a matrix in memory
+inline bool w16g_plan(const dcv_conv2d_desc* d, W16gArgs* a, W16gPlan* p) {
+    static int enabled = -1;
+    if (enabled < 0) { const char* e = getenv("DCV_BF16_WGRADG"); enabled = e ? atoi(e) : 1; }
+    if (!enabled || d->groups != 1 || d->x_layout != DCV_LAYOUT_NHWC) return false;
+    if (d->r != 1 || d->s != 1 || d->pad_h != 0 || d->pad_w != 0 || d->stride_h != 1 || d->stride_w != 1) return false;
+    if ((size_t)d->h * d->w * d->cin * 2 >= ((size_t)1 << 30)) return false;
+    return w16g_choose(d->n, d->h * d->w, d->cout, d->cin, a, p);
+}
+inline bool fold_rows(const dcv_conv2d_desc* d);
+// ... for a layer of several taps read in place (IMPL): strided / dilated / 5x5 layers of 64-aligned channel counts (the gathered matrix of the earlier version of
+// this round — written once, read once: 462 + 462 MB for 64 -> 128 / stride 2 at 56 x 56 x 512 images, the layer's input is 205 MB), and the folded first layer
+inline bool w16i_plan(const dcv_conv2d_desc* d, W16gArgs* a, W16gPlan* p) {
+    static int enabled = -1;
+    if (enabled < 0) { const char* e = getenv("DCV_BF16_WGRAD_IMPLICIT"); enabled = e ? atoi(e) : 1; }
+    if (!enabled || d->groups != 1 || d->x_layout != DCV_LAYOUT_NHWC || d->r * d->s < 2) return false;
+    const bool fold = fold_rows(d);
+    if (!fold && d->cin % 64 != 0) return false;
+    const int cinv = fold ? 64 : d->cin, S = fold ? 1 : d->s, taps = d->r * S;
+    if (taps > 64 || (size_t)d->h * d->w * d->cin * 2 >= ((size_t)1 << 30)) return false;
+    if (!w16g_choose(d->n, d->ho * d->wo, d->cout, taps * cinv, a, p)) return false;
+    if ((size_t)a->HWp * (size_t)d->wo >= ((size_t)1 << 32)) return false;
+    p->implicit = 1;
+    a->Wo = d->wo; a->W = d->w; a->pix_bytes = d->cin * 2; a->sh = d->stride_h; a->sw = d->stride_w; a->ph = d->pad_h; a->pw = fold ? 0 : d->pad_w;
+    a->dh = d->dil_h; a->dw = fold ? 1 : d->dil_w; a->S = S; a->cig = cinv / 64;
+    a->magic_wo = 0xFFFFFFFFu / (unsigned)d->wo + 1u; a->x_img = (unsigned)((size_t)d->h * d->w * d->cin * 2);
+    return true;
+}
+template <int GROUPS, int CT, bool IMPL>
+inline int w16g_launch(int nt, dim3 grid, size_t smem, hipStream_t st, const W16gArgs& a, const u16* xm, const u16* dy, float* partial) {
+#define DCV_W16G(NTV) do { static bool conf = false; if (!conf) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_wgradg_kernel<GROUPS, CT, NTV, IMPL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DCV_ERR_LAUNCH; conf = true; } \
+        hipLaunchKernelGGL((conv_bf16_wgradg_kernel<GROUPS, CT, NTV, IMPL>), grid, dim3(256 * GROUPS), smem, st, a, xm, dy, partial); } while (0)
+    if (nt == 4) DCV_W16G(4); else if (nt == 3) DCV_W16G(3); else if (nt == 2) DCV_W16G(2); else DCV_W16G(1);
+#undef DCV_W16G
+    return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
+}
+
 inline bool w16p_plan(const dcv_conv2d_desc* d, W16pArgs* a, int* chunks, size_t* smem, int* groups) {
     static int enabled = -1;
     if (enabled < 0) { const char* e = getenv("DCV_BF16_WGRAD9P"); enabled = e ? atoi(e) : 1; }
@@ -1018,7 +1252,7 @@ inline bool w16_plan(const dcv_conv2d_desc* d, W16Args* a, int* chunks, size_t* 
 
 // ------------------------------------------------------------------------------------------------ prepared filters, casts
 // dst[tap][kcout][kcin] bf16 from the fp32 OIHW master filter (fwd), or its transposed + flipped (sub-)filter (data gradient; conv2d_internal.h)
-struct Bf16Prep { const float* w; u16* dst; int kcout, kcin, R, S, w_cin, dgrad, r0, rstep, Rw, s0, sstep, Sw, total; };
+struct Bf16Prep { const float* w; u16* dst; int kcout, kcin, R, S, w_cin, dgrad, r0, rstep, Rw, s0, sstep, Sw, total, fold; };      // fold: layout [r][co][s][ci] (fold_rows)
 #define BF_PREP_MAX 24
 struct Bf16PrepList { int count; Bf16Prep e[BF_PREP_MAX]; };
 
@@ -1026,7 +1260,7 @@ __device__ __forceinline__ u16 f32_to_bf16_bits(float v) { const __bf16 h = (__b
 
 __global__ __launch_bounds__(256) void prep_bf16_kernel(Bf16PrepList l) {
     const Bf16Prep& e = l.e[blockIdx.y];
-    if (e.rstep == 1 && e.sstep == 1 && e.R == e.Rw && e.S == e.Sw) {
+    if (e.rstep == 1 && e.sstep == 1 && e.R == e.Rw && e.S == e.Sw && !e.fold) {
         // whole filter: a thread owns one (kernel-cout, kernel-cin) pair, reads its R*S taps (contiguous in OIHW) and writes one element of every tap plane:
         // reads are 4 R S-byte runs, writes of consecutive threads are consecutive bf16 of a plane (the element-wise form below gathers with stride R*S)
         const int pairs = e.kcout * e.kcin, taps = e.R * e.S;
@@ -1062,7 +1296,7 @@ __global__ __launch_bounds__(256) void prep_bf16_kernel(Bf16PrepList l) {
         float v;
         if (!e.dgrad) v = e.w[(((size_t)co * e.w_cin + ci) * e.Rw + r) * e.Sw + s];
         else v = e.w[(((size_t)ci * e.w_cin + co) * e.Rw + (e.r0 + e.rstep * (e.R - 1 - r))) * e.Sw + (e.s0 + e.sstep * (e.S - 1 - s))];
-        e.dst[i] = f32_to_bf16_bits(v);
+        e.dst[e.fold ? (((size_t)r * e.kcout + co) * e.S + s) * e.kcin + ci : (size_t)i] = f32_to_bf16_bits(v);
     }
 }
 
@@ -1161,6 +1395,14 @@ inline PhaseAxis phase_axis(int a, int size, int R, int stride, int pad) {
     return p;
 }
 
+// Round 4: the FOLDED first layer.  A layer of few input channels whose S horizontal taps x cin channels are exactly one K step (S cin = 64: the 7x7 / 2 stem of a
+// ResNet after space-to-depth — dcv_space_to_depth_bf16: 4x4 taps over 16 channels) needs no im2col matrix: in NHWC the S pixels of a tap row ARE 64 consecutive
+// values, so the layer runs as R taps of 64 "channels" over a view of the tensor whose pixels overlap (pixel stride cin, not 64).  Forward: the implicit-GEMM kernel
+// with Bf16Args::pix; weight gradient: the implicit instance of the GEMM kernel (w16i_plan).  No padding or dilation along w (every tap of a row is inside the image).
+inline bool fold_rows(const dcv_conv2d_desc* d) {
+    return d->cin < 64 && d->cin % 8 == 0 && d->cin * d->s == 64 && d->pad_w == 0 && d->dil_w == 1 && d->groups == 1;
+}
+
 inline bool desc_ok(const dcv_conv2d_desc* d) {
     if (!d) return false;
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->cin <= 0 || d->cout <= 0 || d->r <= 0 || d->s <= 0) return false;
@@ -1177,7 +1419,7 @@ inline int prep_pieces(const dcv_conv2d_desc* d, int op, Bf16Prep* out, int* off
     Bf16Prep e{};
     e.w_cin = d->cin; e.dgrad = op ? 1 : 0;
     e.kcout = op ? d->cin : d->cout; e.kcin = op ? d->cout : d->cin;
-    e.Rw = d->r; e.Sw = d->s;
+    e.Rw = d->r; e.Sw = d->s; e.fold = (op == 0 && fold_rows(d)) ? 1 : 0;
     if (op == 0 || (d->stride_h == 1 && d->stride_w == 1)) {
         e.R = d->r; e.S = d->s; e.r0 = e.s0 = 0; e.rstep = e.sstep = 1;
         e.total = d->cout * d->cin * d->r * d->s;
@@ -1217,7 +1459,7 @@ inline bool supported(const dcv_conv2d_desc* d, int op) {
     if (!desc_ok(d) || d->groups != 1 || d->x_layout != DCV_LAYOUT_NHWC) return false;
     if (d->r * d->s > 64) return false;                                               // tap validity is a 64-bit mask
     const int kcin = op == 1 ? d->cout : d->cin, kcout = op == 1 ? d->cin : d->cout;
-    if (kcin % BF_BK != 0 || kcout % 64 != 0) return false;
+    if ((kcin % BF_BK != 0 && !(op == 0 && fold_rows(d))) || kcout % 64 != 0) return false;
     // 32-bit buffer offsets with headroom for the out-of-range marker: per LAUNCH — a larger batch runs as slices of the batch (batch_slice below)
     const size_t xin1 = (op == 1 ? (size_t)d->ho * d->wo * d->cout : (size_t)d->h * d->w * d->cin) * 2;
     const size_t wbytes = (size_t)d->cout * d->cin * d->r * d->s * 2;
@@ -1323,6 +1565,31 @@ int launch(const Bf16Args& a0, const u16* x, const u16* wb, const float* bias, v
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// space-to-depth of a strided first layer's fp32 input into bf16 NHWC: out[n][i][j][(a sw + b) cin + c] = x[n][c][i sh + a - ph][j sw + b - pw], zeros outside the
+// image and in the channels >= sh sw cin.  A thread writes one 16-byte piece (8 channels) of one pixel.
+struct S2dArgs { int H, W, Cin, sh, sw, ph, pw, Hs, Ws, CP, nchw; unsigned total; };
+__global__ __launch_bounds__(256) void space_to_depth_bf16_kernel(S2dArgs a, const float* __restrict__ x, uint4* __restrict__ out) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= a.total) return;
+    const unsigned pieces = (unsigned)a.CP >> 3, piece = i % pieces, pixel = i / pieces;
+    const unsigned j = pixel % (unsigned)a.Ws, r1 = pixel / (unsigned)a.Ws, ii = r1 % (unsigned)a.Hs, n = r1 / (unsigned)a.Hs;
+    const int real = a.sh * a.sw * a.Cin;
+    union { uint4 u; __bf16 h[8]; } o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int e = (int)piece * 8 + k;
+        float v = 0.f;
+        if (e < real) {
+            const int c = e % a.Cin, ab = e / a.Cin, pa = ab / a.sw, pb = ab - pa * a.sw;
+            const int ih = (int)ii * a.sh + pa - a.ph, iw = (int)j * a.sw + pb - a.pw;
+            if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
+                v = a.nchw ? x[(((size_t)n * a.Cin + c) * a.H + ih) * a.W + iw] : x[(((size_t)n * a.H + ih) * a.W + iw) * a.Cin + c];
+        }
+        o.h[k] = (__bf16)v;
+    }
+    out[i] = o.u;
+}
+
 }  // namespace
 
 struct Im2colArgs { int H, W, Cin, Ho, Wo, R, S, sh, sw, ph, pw, dh, dw, K, kpad, nchw; unsigned M; int TH, PH, PW, tiles_w, tiles_h; };
@@ -1395,13 +1662,26 @@ inline bool col_plan(const dcv_conv2d_desc* d, dcv_conv2d_desc* d1, W16Args* a, 
     return true;
 }
 
+// the GEMM weight-gradient launch over a pixel matrix (partial slabs [chunk][co][Kc])
+inline int wgradg_run(const W16gArgs& ag, const W16gPlan& p, const u16* xm, const u16* dy, float* partial, hipStream_t st) {
+    dim3 grid((unsigned)p.chunks, (unsigned)(ag.Kc / (64 * p.nt)), (unsigned)(ag.Cout / (16 * p.ct)));
+    if (grid.y > 65535 || grid.z > 65535) return DCV_ERR_UNSUPPORTED;
+    dcv_count_launch(DCV_FAMILY_BF16_WGRAD9);
+    if (p.implicit) {
+        if (p.ct == 8) return p.groups == 2 ? w16g_launch<2, 8, true>(p.nt, grid, p.smem, st, ag, xm, dy, partial) : w16g_launch<1, 8, true>(p.nt, grid, p.smem, st, ag, xm, dy, partial);
+        return p.groups == 2 ? w16g_launch<2, 4, true>(p.nt, grid, p.smem, st, ag, xm, dy, partial) : w16g_launch<1, 4, true>(p.nt, grid, p.smem, st, ag, xm, dy, partial);
+    }
+    if (p.ct == 8) return p.groups == 2 ? w16g_launch<2, 8, false>(p.nt, grid, p.smem, st, ag, xm, dy, partial) : w16g_launch<1, 8, false>(p.nt, grid, p.smem, st, ag, xm, dy, partial);
+    return p.groups == 2 ? w16g_launch<2, 4, false>(p.nt, grid, p.smem, st, ag, xm, dy, partial) : w16g_launch<1, 4, false>(p.nt, grid, p.smem, st, ag, xm, dy, partial);
+}
+
 extern "C" {
 
 int dcv_conv2d_bf16_supported(const dcv_conv2d_desc* d, int op) {
     if (op == 2) {
-        W16Args a{}; W16pArgs ap{}; int chunks, groups; size_t smem, cb; dcv_conv2d_desc d1;
+        W16Args a{}; W16pArgs ap{}; int chunks, groups; size_t smem, cb; dcv_conv2d_desc d1; W16gArgs ag{}; W16gPlan gp{};
         return (desc_ok(d) && (dcv_mfma_conv2d_wgrad_in16_supported(d) || w16_plan(d, &a, &chunks, &smem, &groups) || w16p_plan(d, &ap, &chunks, &smem, &groups) ||
-                               col_plan(d, &d1, &a, &chunks, &smem, &groups, &cb))) ? 1 : 0;
+                               w16i_plan(d, &ag, &gp) || col_plan(d, &d1, &a, &chunks, &smem, &groups, &cb))) ? 1 : 0;
     }
     return (op == 0 || op == 1) && supported(d, op) ? 1 : 0;
 }
@@ -1411,10 +1691,17 @@ size_t dcv_conv2d_bf16_wgrad_workspace_bytes(const dcv_conv2d_desc* d) {
     size_t need = dcv_mfma_conv2d_wgrad_in16_supported(d) ? dcv_mfma_conv2d_ws(d, 2) : 0;
     W16Args a{}; int chunks, groups; size_t smem;
     if (w16_plan(d, &a, &chunks, &smem, &groups)) { const size_t n16 = dcv_align_up((size_t)chunks * a.wtotal * sizeof(float), 256); if (n16 > need) need = n16; }
+    W16gArgs ag{}; W16gPlan gp{};
+    if (w16g_plan(d, &ag, &gp)) { const size_t n16 = dcv_align_up((size_t)gp.chunks * ag.wtotal * sizeof(float), 256); if (n16 > need) need = n16; }
     W16pArgs ap{};
     if (w16p_plan(d, &ap, &chunks, &smem, &groups)) { const size_t n16 = dcv_align_up((size_t)chunks * ap.wtotal * sizeof(float), 256); if (n16 > need) need = n16; }
+    if ((fold_rows(d) || !dcv_mfma_conv2d_wgrad_in16_supported(d)) && w16i_plan(d, &ag, &gp)) { const size_t n16 = dcv_align_up((size_t)gp.chunks * ag.wtotal * sizeof(float), 256); if (n16 > need) need = n16; }
     dcv_conv2d_desc d1; size_t cb;
-    if (need == 0 && col_plan(d, &d1, &a, &chunks, &smem, &groups, &cb)) need = cb + dcv_align_up((size_t)chunks * a.wtotal * sizeof(float), 256);
+    if (need == 0 && col_plan(d, &d1, &a, &chunks, &smem, &groups, &cb)) {
+        size_t slabs = (size_t)chunks * a.wtotal * sizeof(float);
+        if (w16g_plan(&d1, &ag, &gp) && (size_t)gp.chunks * ag.wtotal * sizeof(float) > slabs) slabs = (size_t)gp.chunks * ag.wtotal * sizeof(float);
+        need = cb + dcv_align_up(slabs, 256);
+    }
     return need;
 }
 
@@ -1449,6 +1736,15 @@ int dcv_conv2d_bf16_wgrad(const dcv_conv2d_desc* d, const void* x, const void* d
         if (hipGetLastError() != hipSuccess) return DCV_ERR_LAUNCH;
         return dcv_mfma_wgrad9_reduce(partial, dw, chunks, d->cout, d->cin, dcv_stream(stream));
     }
+    W16gArgs ag{}; W16gPlan gp{};
+    if (w16g_plan(d, &ag, &gp)) {                                // a 1x1 layer over a pixel matrix (a first layer's im2col matrix): the GEMM
+        if (!ws || ws_bytes < (size_t)gp.chunks * ag.wtotal * sizeof(float)) return DCV_ERR_WORKSPACE;
+        DCV_CHECK_ARG(aligned16(x) && aligned16(dy) && aligned16(ws));
+        float* partial = reinterpret_cast<float*>(ws);
+        const int rc = wgradg_run(ag, gp, reinterpret_cast<const u16*>(x), reinterpret_cast<const u16*>(dy), partial, dcv_stream(stream));
+        if (rc != DCV_OK) return rc;
+        return dcv_mfma_wgrad_reduce_plain(partial, dw, gp.chunks, ag.wtotal, dcv_stream(stream));
+    }
     if (w16_plan(d, &a, &chunks, &smem, &groups)) {
         if (!ws || ws_bytes < (size_t)chunks * a.wtotal * sizeof(float)) return DCV_ERR_WORKSPACE;
         DCV_CHECK_ARG(aligned16(x) && aligned16(dy) && aligned16(ws));
@@ -1474,6 +1770,15 @@ int dcv_conv2d_bf16_wgrad(const dcv_conv2d_desc* d, const void* x, const void* d
         if (one) return dcv_mfma_wgrad_reduce_plain(partial, dw, chunks, a.wtotal, dcv_stream(stream));      // slabs [co][ci] = dw's own order
         return dcv_mfma_wgrad9_reduce(partial, dw, chunks, d->cout, d->cin, dcv_stream(stream));
     }
+    if ((fold_rows(d) || !dcv_mfma_conv2d_wgrad_in16_supported(d)) && w16i_plan(d, &ag, &gp)) {      // several taps read in place
+        if (!ws || ws_bytes < (size_t)gp.chunks * ag.wtotal * sizeof(float)) return DCV_ERR_WORKSPACE;
+        DCV_CHECK_ARG(aligned16(x) && aligned16(dy) && aligned16(ws));
+        float* partial = reinterpret_cast<float*>(ws);
+        const int rc = wgradg_run(ag, gp, reinterpret_cast<const u16*>(x), reinterpret_cast<const u16*>(dy), partial, dcv_stream(stream));
+        if (rc != DCV_OK) return rc;
+        hipLaunchKernelGGL(col_wgrad_reduce_kernel, dim3((unsigned)dcv_ceil_div(ag.wtotal, 256)), dim3(256), 0, dcv_stream(stream), partial, dw, gp.chunks, d->cout, d->cin, d->r * d->s);
+        DCV_RETURN_LAUNCH();
+    }
     if (!dcv_mfma_conv2d_wgrad_in16_supported(d)) {
         dcv_conv2d_desc d1; size_t cb;
         if (!col_plan(d, &d1, &a, &chunks, &smem, &groups, &cb)) return DCV_ERR_UNSUPPORTED;
@@ -1483,6 +1788,13 @@ int dcv_conv2d_bf16_wgrad(const dcv_conv2d_desc* d, const void* x, const void* d
         float* partial = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + cb);
         const ColArgs ca{d->h, d->w, d->cin, d->ho, d->wo, d->r, d->s, d->stride_h, d->stride_w, d->pad_h, d->pad_w, d->dil_h, d->dil_w};
         hipLaunchKernelGGL(gather_cols_bf16_kernel, dim3((unsigned)(d->n * d->ho)), dim3(256), 0, dcv_stream(stream), ca, reinterpret_cast<const uint4*>(x), reinterpret_cast<uint4*>(xcol));
+        if (w16g_plan(&d1, &ag, &gp)) {
+            if (ws_bytes < cb + (size_t)gp.chunks * ag.wtotal * sizeof(float)) return DCV_ERR_WORKSPACE;
+            const int rc = wgradg_run(ag, gp, xcol, reinterpret_cast<const u16*>(dy), partial, dcv_stream(stream));
+            if (rc != DCV_OK) return rc;
+            hipLaunchKernelGGL(col_wgrad_reduce_kernel, dim3((unsigned)dcv_ceil_div(ag.wtotal, 256)), dim3(256), 0, dcv_stream(stream), partial, dw, gp.chunks, d->cout, d->cin, d->r * d->s);
+            DCV_RETURN_LAUNCH();
+        }
         dim3 grid((unsigned)chunks, (unsigned)(d1.cin / 64), (unsigned)(d1.cout / 64));
         if (grid.y > 65535 || grid.z > 65535) return DCV_ERR_UNSUPPORTED;
         static bool cconf = false;
@@ -1577,8 +1889,9 @@ int dcv_conv2d_bf16_fwd(const dcv_conv2d_desc* d, const void* x, const void* fil
     if (!supported(d, 0)) return DCV_ERR_UNSUPPORTED;
     DCV_CHECK_ARG(aligned16(x) && aligned16(filter) && aligned16(y) && (!bias || aligned16(bias)));
     Bf16Args a{};
-    a.N = d->n; a.Hin = d->h; a.Win = d->w; a.Cin = d->cin; a.Hout = d->ho; a.Wout = d->wo; a.Cout = d->cout;
+    a.N = d->n; a.Hin = d->h; a.Win = d->w; a.Cin = d->cin; a.pix = d->cin; a.Hout = d->ho; a.Wout = d->wo; a.Cout = d->cout;
     a.R = d->r; a.S = d->s; a.sh = d->stride_h; a.sw = d->stride_w; a.ph = d->pad_h; a.pw = d->pad_w; a.dh = d->dil_h; a.dw = d->dil_w;
+    if (fold_rows(d)) { a.Cin = 64; a.S = 1; }                   // a tap row = 64 consecutive values of the tensor: S pixels x cin channels
     a.act = d->act; a.slope = d->act_slope; a.M = (long)d->n * d->ho * d->wo;
     a.w_bytes = (unsigned)((size_t)d->cout * d->cin * d->r * d->s * 2);
     const u16* xs = reinterpret_cast<const u16*>(x); const u16* ws = reinterpret_cast<const u16*>(filter);
@@ -1623,7 +1936,7 @@ int dcv_conv2d_bf16_dgrad(const dcv_conv2d_desc* d, const void* dy, const void* 
         return DCV_OK;
     }
     Bf16Args a{};
-    a.N = d->n; a.Hin = d->ho; a.Win = d->wo; a.Cin = d->cout; a.Cout = d->cin;
+    a.N = d->n; a.Hin = d->ho; a.Win = d->wo; a.Cin = d->cout; a.pix = d->cout; a.Cout = d->cin;
     a.sh = 1; a.sw = 1; a.dh = d->dil_h; a.dw = d->dil_w; a.act = DCV_ACT_NONE; a.slope = 0.f;
     a.x_bytes = (unsigned)((size_t)d->n * d->ho * d->wo * d->cout * 2);
     if (d->stride_h == 1 && d->stride_w == 1) {
@@ -1664,7 +1977,7 @@ int dcv_conv2d_bf16_dgrad_moments(const dcv_conv2d_desc* d, const void* dy, cons
     if (y_prev && moments_rows != (int)dcv_ceil_div((size_t)M, 128)) return DCV_ERR_INVALID_ARG;
     if ((size_t)d->n * d->ho * d->wo * d->cout * 2 >= slice_limit()) return DCV_ERR_UNSUPPORTED;
     Bf16Args a{};
-    a.N = d->n; a.Hin = d->ho; a.Win = d->wo; a.Cin = d->cout; a.Cout = d->cin;
+    a.N = d->n; a.Hin = d->ho; a.Win = d->wo; a.Cin = d->cout; a.pix = d->cout; a.Cout = d->cin;
     a.sh = 1; a.sw = 1; a.dh = d->dil_h; a.dw = d->dil_w; a.act = DCV_ACT_NONE; a.slope = 0.f;
     a.x_bytes = (unsigned)((size_t)d->n * d->ho * d->wo * d->cout * 2);
     a.Hout = d->h; a.Wout = d->w; a.R = d->r; a.S = d->s;
@@ -1697,6 +2010,16 @@ int dcv_im2col_bf16(const dcv_conv2d_desc* d, const float* x, void* out, int kpa
     if (blocks >= ((size_t)1 << 31)) return DCV_ERR_UNSUPPORTED;
     const size_t smem = ((size_t)a.Cin * a.PH * a.PW + 1) * sizeof(float);
     hipLaunchKernelGGL(im2col_bf16_kernel, dim3((unsigned)blocks), dim3(256), smem, dcv_stream(stream), a, x, reinterpret_cast<u16*>(out));
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_space_to_depth_bf16(const dcv_conv2d_desc* d, const float* x, void* out, int hs, int ws, int cp, void* stream) {
+    DCV_CHECK_ARG(desc_ok(d) && x && out && aligned16(out));
+    if (d->groups != 1 || d->dil_h != 1 || d->dil_w != 1 || cp % 8 != 0 || cp > 64 || d->stride_h * d->stride_w * d->cin > cp || hs <= 0 || ws <= 0) return DCV_ERR_UNSUPPORTED;
+    const size_t total = (size_t)d->n * hs * ws * (cp / 8);
+    if (total >= ((size_t)1 << 32) - 256) return DCV_ERR_UNSUPPORTED;
+    S2dArgs a{d->h, d->w, d->cin, d->stride_h, d->stride_w, d->pad_h, d->pad_w, hs, ws, cp, d->x_layout == DCV_LAYOUT_NCHW ? 1 : 0, (unsigned)total};
+    hipLaunchKernelGGL(space_to_depth_bf16_kernel, dim3((unsigned)dcv_ceil_div(total, 256)), dim3(256), 0, dcv_stream(stream), a, x, reinterpret_cast<uint4*>(out));
     DCV_RETURN_LAUNCH();
 }
 

@@ -186,6 +186,9 @@ def _stem_as_gemm(x, weight, stride, padding, dilation):
     else:
         return None
     d = _conv_desc(x.shape, weight.shape, _pair(stride), _pair(padding), _pair(dilation), layout, nat.ACT_NONE, 0.)
+    folded = _stem_as_folded_rows(x, weight, d)
+    if folded is not None:
+        return folded
     d1 = _conv_desc((d.n, kpad, d.ho, d.wo), (cout, kpad, 1, 1), (1, 1), (0, 0), (1, 1), nat.LAYOUT_NHWC, nat.ACT_NONE, 0.)
     if not (lib.dcv_conv2d_bf16_supported(d1, 0) and lib.dcv_conv2d_bf16_supported(d1, 2)):
         return None
@@ -195,6 +198,36 @@ def _stem_as_gemm(x, weight, stride, padding, dilation):
         nat.check(lib.dcv_im2col_bf16(d, x.data_ptr(), x_col.data_ptr(), kpad, nat.current_stream(x.device)), 'dcv_im2col_bf16')
     w_col = torch.nn.functional.pad(weight.reshape(cout, k), (0, kpad - k)).reshape(cout, kpad, 1, 1)
     return x_col, w_col
+
+
+_stem_s2d = os.environ.get('DCV_STEM_S2D', '1') not in ('0', 'false', 'False', '')
+
+
+def _stem_as_folded_rows(x, weight, d):
+    """ A STRIDED first layer (the 7x7 / 2 stem of a ResNet) without the im2col matrix — 2.5 GB written and read twice per step at 512 x 3 x 224 x 224, a quarter
+    of resnet18_style's bf16 step.  `dcv_space_to_depth_bf16` moves the stride into the channels: X[n][i][j][(a sw + b) cin + c] = x[n][c][i sh + a - ph][j sw + b - pw]
+    (bf16 NHWC, 16 channels, 217 MB), over which the layer is a stride-1, pad-0 layer of A x A taps, A = ceil(R / stride) = 4, whose filter is the zero-extended
+    OIHW filter regrouped the same way (plain torch ops on the parameter: autograd carries dW back).  Four taps x 16 channels of a row are 64 consecutive values of
+    X, so the bf16 kernels run it in place as four taps of 64 channels ("folded rows", conv2d_bf16.hip).  Returns (X, w2) or None. """
+    sh, sw = d.stride_h, d.stride_w
+    if not _stem_s2d or sh != sw or sh < 2 or d.r != d.s or d.dil_h != 1 or d.dil_w != 1:
+        return None
+    a = -(-d.r // sh)
+    if a != 4 or sh * sw * d.cin > 16:
+        return None
+    cout, cin = d.cout, d.cin
+    hs, ws = d.ho + a - 1, d.wo + a - 1
+    d2 = _conv_desc((d.n, 16, hs, ws), (cout, 16, a, a), (1, 1), (0, 0), (1, 1), nat.LAYOUT_NHWC, nat.ACT_NONE, 0.)
+    if not (lib.dcv_conv2d_bf16_supported(d2, 0) and lib.dcv_conv2d_bf16_supported(d2, 2)):
+        return None
+    nat.require_device(x)
+    with torch.no_grad():
+        xs = torch.empty((d.n, 16, hs, ws), dtype=torch.bfloat16, device=x.device, memory_format=_CL)
+        nat.check(lib.dcv_space_to_depth_bf16(d, x.data_ptr(), xs.data_ptr(), hs, ws, 16, nat.current_stream(x.device)), 'dcv_space_to_depth_bf16')
+    w = torch.nn.functional.pad(weight, (0, a * sw - d.s, 0, a * sh - d.r))                       # [co][c][A sh][A sw]: taps beyond R, S are zero
+    w = w.reshape(cout, cin, a, sh, a, sw).permute(0, 3, 5, 1, 2, 4).reshape(cout, sh * sw * cin, a, a)      # [co][(a, b, c)][ra][rb]
+    w2 = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 16 - sh * sw * cin))
+    return xs, w2
 
 
 _dgrad_moments = os.environ.get('DCV_DGRAD_MOMENTS', '1') not in ('0', 'false', 'False', '')

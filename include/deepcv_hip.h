@@ -208,6 +208,14 @@ int dcv_cast_f32_to_bf16(const float* x, void* y_bf16, size_t n, void* stream);
  * in bf16 math mode (submodule_creators.py:251). */
 #define DCV_IM2COL_MAX_K 256
 int dcv_im2col_bf16(const dcv_conv2d_desc* d, const float* x, void* out_bf16, int kpad, void* stream);
+/* A STRIDED first layer without the im2col matrix (round 4: the 7x7 / 2 stem of resnet18_style at 512 images wrote and re-read 2.5 GB of it per step).  The fp32
+ * input goes ONCE through space-to-depth into the bf16 NHWC tensor out[n][hs][ws][cp], out[n][i][j][(a sw + b) cin + c] = x[n][c][i sh + a - ph][j sw + b - pw]
+ * (zeros outside the image and in the channels >= sh sw cin; cp a multiple of 8, at most 64; d: the ORIGINAL layer, x in d->x_layout), over which the layer is a
+ * stride-1, pad-0 convolution of A x A taps, A = ceil(R / stride), hs = ho + A - 1, ws = wo + A - 1, with the filter
+ * w2[co][(a sw + b) cin + c][ra][rb] = w[co][c][ra sh + a][rb sw + b] (zero beyond R, S).  With cp A = 64 that layer is one the bf16 entry points serve in place
+ * ("folded rows": dcv_conv2d_bf16_supported(d2, 0 / 2) for cin = cp, r = s = A — forward and weight gradient; there is no data gradient), 217 MB instead of
+ * 2.5 GB at 512 x 3 x 224 x 224.  replaces the first Conv2d of a wide spec in bf16 math mode (submodule_creators.py:251). */
+int dcv_space_to_depth_bf16(const dcv_conv2d_desc* d, const float* x, void* out_bf16, int hs, int ws, int cp, void* stream);
 int dcv_cast_bf16_to_f32(const void* x_bf16, float* y, size_t n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------

@@ -346,6 +346,75 @@ def test_first_layer_as_im2col_plus_one_tap_kernels(device, case, nchw):
     assert _rel(dw[:, :K].reshape(cout, cin, k, k), ref_dw) <= 2e-5 and (dw[:, K:] == 0).all()
 
 
+def _s2d_reference(x, k, s, p, ho, wo):
+    """ torch restatement of dcv_space_to_depth_bf16 (16 channels): X[n][(a s + b) cin + c][i][j] = x[n][c][i s + a - p][j s + b - p] """
+    n, cin, h, w = x.shape
+    a = -(-k // s)
+    hs, ws = ho + a - 1, wo + a - 1
+    xp = F.pad(x, (p, s * ws - w - p, p, s * hs - h - p))
+    xs = xp.reshape(n, cin, hs, s, ws, s).permute(0, 3, 5, 1, 2, 4).reshape(n, s * s * cin, hs, ws)
+    return F.pad(xs, (0, 0, 0, 0, 0, 16 - s * s * cin))
+
+
+def _s2d_filter(wt, s):
+    cout, cin, k, _ = wt.shape
+    a = -(-k // s)
+    w = F.pad(wt, (0, a * s - k, 0, a * s - k)).reshape(cout, cin, a, s, a, s).permute(0, 3, 5, 1, 2, 4).reshape(cout, s * s * cin, a, a)
+    return F.pad(w, (0, 0, 0, 0, 0, 16 - s * s * cin))
+
+
+@pytest.mark.parametrize('case', [(3, 3, 56, 56, 64, 7, 2, 3), (2, 3, 40, 50, 128, 7, 2, 3), (5, 4, 33, 31, 64, 8, 2, 3), (2, 1, 48, 48, 64, 13, 4, 6)],
+                         ids=['resnet_stem', 'wide128', 'odd_sizes_k8', 'stride4'])
+@pytest.mark.parametrize('nchw', [True, False], ids=['nchw', 'nhwc'])
+def test_strided_first_layer_as_space_to_depth_plus_folded_rows(device, case, nchw):
+    """ `dcv_space_to_depth_bf16` + the folded-rows instances of the bf16 kernels (4 x 4 taps over 16 channels read in place as four taps of 64) = a strided
+    first layer without an im2col matrix: the regrouped tensor bit for bit against torch, forward and weight gradient against fp64 torch convolutions of the
+    ORIGINAL layer on the same rounded operands (the filter regrouped as `ops._stem_as_folded_rows` regroups it; its zero taps must come back as zeros). """
+    from deepcv_amd import _native as nat
+    lib = nat.lib
+    n, cin, h, w, cout, k, stride, pad = case
+    torch.manual_seed(sum(case))
+    st = nat.current_stream(device)
+    d = nat.Conv2dDesc(n, h, w, cin, cout, k, k, stride, stride, pad, pad, 1, 1, 1, (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1,
+                       nat.LAYOUT_NCHW if nchw else nat.LAYOUT_NHWC, 0, 0., nat.MATH_BF16)
+    a = -(-k // stride)
+    assert a == 4
+    hs, ws = d.ho + a - 1, d.wo + a - 1
+    x = torch.randn(n, cin, h, w)
+    xd = x.to(device) if nchw else x.to(device).contiguous(memory_format=torch.channels_last)
+    xs = torch.full((n, 16, hs, ws), float('nan'), dtype=torch.bfloat16, device=device).contiguous(memory_format=torch.channels_last)
+    nat.check(lib.dcv_space_to_depth_bf16(d, xd.data_ptr(), xs.data_ptr(), hs, ws, 16, st), 's2d')
+    torch.cuda.synchronize()
+    ref_xs = _s2d_reference(_bf(x), k, stride, pad, d.ho, d.wo)
+    assert torch.equal(xs.float().cpu(), ref_xs.float())
+    d2 = _desc(nat, n, 16, hs, ws, cout, a, 1, 0, 1, 0)
+    assert d2.ho == d.ho and d2.wo == d.wo
+    assert lib.dcv_conv2d_bf16_supported(d2, 0) and lib.dcv_conv2d_bf16_supported(d2, 2) and not lib.dcv_conv2d_bf16_supported(d2, 1)
+    wt = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
+    w2 = _s2d_filter(wt, stride)
+    f = _prepared(nat, lib, d2, 0, w2.to(device), st)
+    y = torch.empty((n, cout, d.ho, d.wo), dtype=torch.float32, device=device).contiguous(memory_format=torch.channels_last)
+    stats_rows = (n * d.ho * d.wo + 127) // 128
+    stats = torch.zeros((2, cout, stats_rows), dtype=torch.float64, device=device)
+    nat.check(lib.dcv_conv2d_bf16_fwd(d2, xs.data_ptr(), f.data_ptr(), None, y.data_ptr(), nat.DTYPE_F32, stats.data_ptr(), st), 'fwd')
+    ref = F.conv2d(_bf(x).double(), _bf(wt).double(), None, stride, pad)
+    torch.cuda.synchronize()
+    assert _rel(y, ref) <= 2e-5
+    assert (stats[0].sum(1).cpu() - ref.sum((0, 2, 3))).abs().max().item() <= 1e-4 * ref.abs().sum((0, 2, 3)).max().item()
+    dy = _bf(torch.randn(n, cout, d.ho, d.wo)).contiguous(memory_format=torch.channels_last)
+    wsb = torch.empty(int(lib.dcv_conv2d_bf16_wgrad_workspace_bytes(d2)), dtype=torch.uint8, device=device)
+    dw2 = torch.full((cout, 16, a, a), float('nan'), device=device)
+    nat.check(lib.dcv_conv2d_bf16_wgrad(d2, xs.data_ptr(), dy.to(device).data_ptr(), dw2.data_ptr(), wsb.data_ptr(), wsb.numel(), st), 'wgrad')
+    torch.cuda.synchronize()
+    ref_dw = torch.nn.grad.conv2d_weight(_bf(x).double(), (cout, cin, k, k), dy.double(), stride, pad)
+    ref_dw2 = torch.nn.grad.conv2d_weight(ref_xs.double(), (cout, 16, a, a), dy.double())
+    assert _rel(dw2, ref_dw2) <= 2e-5
+    # ... and through the regrouping back to the layer's own filter (what autograd does with `_stem_as_folded_rows`' torch ops)
+    wl = wt.double().clone().requires_grad_(True)
+    (_s2d_filter(wl, stride) * dw2.double().cpu()).sum().backward()
+    assert _rel(wl.grad, ref_dw) <= 2e-5
+
+
 @pytest.mark.parametrize('mode,kernel,stride,pad', [('avg', 2, 2, 0), ('max', 3, 2, 1), ('avg', 4, 4, 0)], ids=['avg2', 'max3s2p1', 'avg4'])
 def test_bf16_pooling_and_add_equal_the_widened_fp32_path(device, mode, kernel, stride, pad):
     """ Pooling and the residual sum on bf16 tensors: fp32 arithmetic rounded once, i.e. bit for bit what widening to fp32, running the fp32 kernel and narrowing
