@@ -506,6 +506,222 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, cons
     if constexpr (!PERSIST) finish_tile((cchunks - 1) & 1);         // (one tile: its epilogue once, behind the loop)
 }
 
+// ------------------------------------------------------------------------------------------------ round 4: 64 input channels — the filters in REGISTERS
+// With Cin = 64 a tile of the window kernel above is ONE chunk: nine taps of sixteen MFMAs per wave (its 64-channel-wide instance), each behind a barrier and a
+// filter-tile request — 0.17 - 0.23 of the bf16 peak on 64 -> 64 at 32 x 32 and 56 x 56 (cifar100_deep's largest layer, four layers of resnet18_style: the slowest
+// convolutions of both steps).  But the whole filter of 64 output channels is 9 x 64 x 64 values = 288 registers per lane as MFMA B fragments: a block of FOUR
+// waves (one per SIMD: 512 registers each), wave tile 64 pixels x 64 channels, loads them ONCE and then walks its tiles with nothing but the window in LDS
+// (two buffers: the next tile's lands under this tile's taps), four fragment reads per sixteen MFMAs, no barrier inside a tile and no filter traffic at all.
+// Same window layout, border handling (zero row), epilogue (activation, bf16 store, statistics rows per 128 pixels / the MOM moments and addend) as above.
+// The filter fragments live in the ACCUMULATION registers and the MFMA reads them there (gfx950 takes AGPRs as A / B sources): left to the compiler, B operands are
+// vector registers and the 288 - 256 that do not fit were copied back (v_accvgpr_read) in front of every group of MFMAs — 16 copies + the operand addresses in front
+// of 16 MFMAs on a block with ONE wave per SIMD: a tap took 1200 clocks for 512 of MFMAs.  Inline assembly is opaque to the hazard recogniser: the accumulators are
+// read by vector instructions only behind rf_mfma_drain().
+__device__ __forceinline__ void rf_mfma_a(f32x4& c, const bf16x8& av, const bf16x8& b) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(av), "a"(b)); }
+__device__ __forceinline__ void rf_mfma_v(f32x4& c, const bf16x8& av, const bf16x8& b) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(av), "v"(b)); }
+__device__ __forceinline__ void rf_mfma_drain() { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory"); }
+#define RF_ATAPS 8                  // taps whose fragments are held in AGPRs (8 x 32 = 256); the ninth in vector registers
+
+template <bool MOM>
+__global__ __launch_bounds__(256, 1) void conv_bf16_halo_rf_kernel(Bf16Args a, const u16* __restrict__ x, const u16* __restrict__ wb, const float* __restrict__ bias,
+                                                                    u16* __restrict__ yv, double* __restrict__ stats, int win_rows,
+                                                                    const u16* __restrict__ yprev, const float* __restrict__ mom_mean, const float* __restrict__ mom_rstd,
+                                                                    const u16* __restrict__ addend) {
+    constexpr int BMH = 256, TI = 4;
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int t = threadIdx.x, lane = t & 63, wm = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int li = lane & 15, lg = lane >> 4;
+    const int n0 = blockIdx.y * 64;
+    const int W = a.Win, H = a.Hin;
+    const int nhalf = win_rows >> 5;                                // 32-row pieces of a window (a piece = one LDS-DMA instruction of the block's four waves)
+    const int ntiles = (int)((a.M + BMH - 1) / BMH), gstep = (int)gridDim.x;
+    int tile = blockIdx.x, m0 = tile * BMH;
+    const unsigned long long xa = (unsigned long long)x;
+    const bw_i32x4 rx = {(int)(unsigned)xa, (int)(unsigned)((xa >> 32) & 0xFFFFu), (int)a.x_bytes, 0x00020000};
+    if (t < 16) *reinterpret_cast<uint4*>(lds + (t >> 3) * BH_WSTRIDE + BH_WROWS * 128 + (t & 7) * 16) = make_uint4(0u, 0u, 0u, 0u);      // the two zero rows
+
+    // ---- the filter: B fragment (tap, K half ks, channel tile j) of lane (li, lg) = channel n0 + 4 li + j, input channels 32 ks + 8 lg .. + 7 of [tap][Cout][64]
+    bf16x8 fb[9][2][4];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                fb[tap][ks][j] = *reinterpret_cast<const bf16x8*>(wb + ((size_t)(tap * a.Cout + n0 + 4 * li + j) * 64 + 32 * ks + 8 * lg));
+
+    // ---- window staging: piece hp = rows 32 hp + (t >> 3), physical slot t & 7 holds logical slot (t & 7) ^ (row & 6)
+    const int lslot_w = (t & 7) ^ ((t >> 3) & 6);
+    const unsigned lds0 = (unsigned)(size_t)lds + (unsigned)((t & ~63) * 16);
+    const unsigned wvstep = (unsigned)(32 * 64 * 2);
+    auto wv_of = [&](int m0v) { return (unsigned)(m0v - W - 1 + (t >> 3)) * 128u + (unsigned)(lslot_w * 16); };
+    auto stage_piece = [&](int wbuf, unsigned wv, int hp) __attribute__((always_inline)) {
+        bw_dma16(rx, lds0 + (unsigned)(wbuf * BH_WSTRIDE + hp * 4096), wv + (unsigned)hp * wvstep, 0u);
+    };
+    auto stage_window = [&](int wbuf, unsigned wv) {
+        for (int hp = 0; hp < nhalf; ++hp) stage_piece(wbuf, wv, hp);
+    };
+    // ---- operand addresses (relative to a window buffer; the other K half is the address ^ 64).  Tile row i = pixel pl = 64 wm + 16 i + li of the block reads, for
+    // tap (r, s), window row R = pl + r W + s: R changes by 16 per i, the swizzle term (R & 6) does not — ONE address per tap and lane (rc[tap], row i at + 2048 i,
+    // an immediate of the read) is the same for every tile.  What a tile changes is which taps leave the image: 36 bits per lane (vmask: bit 9 i + tap), decoded
+    // once per tile; a tap outside reads the buffer's zero row (zc[i] = its address - 2048 i).  (The first version kept the 36 selected addresses: with the 288
+    // filter registers that spilled, and the reloads waited for the window request in front of them — 7 us of every 18 us tile.)
+    unsigned rc[9], zc[TI];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int sx = 0; sx < 3; ++sx) { const int R = 64 * wm + li + r * W + sx; rc[r * 3 + sx] = (unsigned)(R * 128 + ((lg ^ (R & 6)) << 4)); }
+#pragma unroll
+    for (int i = 0; i < TI; ++i) zc[i] = (unsigned)(BH_WROWS * 128 + lg * 16 - 2048 * i);
+    // (opaque values: left visible, the select between two array elements below becomes an indexed load from a stack copy of the arrays)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) asm volatile("" : "+v"(rc[k]));
+#pragma unroll
+    for (int i = 0; i < TI; ++i) asm volatile("" : "+v"(zc[i]));
+    unsigned aaddr[TI][9];                                          // this tile's: rc[tap] or zc[i]
+    auto set_tile = [&](int m0v) __attribute__((always_inline)) {
+        const unsigned um0 = (unsigned)m0v, q0w = __umulhi(um0, a.magic_w), wo0 = um0 - q0w * (unsigned)W, ho0 = q0w - __umulhi(q0w, a.magic_h) * (unsigned)H;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int pl = 64 * wm + 16 * i + li;
+            const unsigned u = wo0 + (unsigned)pl, dq = __umulhi(u, a.magic_w), wo = u - dq * (unsigned)W;
+            const unsigned vv = ho0 + dq, ho = vv - __umulhi(vv, a.magic_h) * (unsigned)H;
+            // (pixels beyond the tensor's end compute garbage nobody stores)
+            const bool rok[3] = {ho > 0, true, ho + 1 < (unsigned)H}, cok[3] = {wo > 0, true, wo + 1 < (unsigned)W};
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                unsigned rv_ = rc[tap], zv_ = zc[i];
+                asm("" : "+v"(rv_), "+v"(zv_));                      // (a select of two loads is folded into a load from a selected address, and the arrays stay in memory)
+                aaddr[i][tap] = (rok[tap / 3] && cok[tap % 3]) ? rv_ : zv_;
+            }
+        }
+    };
+    set_tile(m0);
+    f32x4 acc[TI][4];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int cbase = n0 + 4 * li;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) { const float4 b4 = *reinterpret_cast<const float4*>(bias + cbase); bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w; }
+    float mmu[4] = {0.f, 0.f, 0.f, 0.f}, mrs[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (MOM) {
+        if (yprev != nullptr) {
+            const float4 m4 = *reinterpret_cast<const float4*>(mom_mean + cbase), r4 = *reinterpret_cast<const float4*>(mom_rstd + cbase);
+            mmu[0] = m4.x; mmu[1] = m4.y; mmu[2] = m4.z; mmu[3] = m4.w; mrs[0] = r4.x; mrs[1] = r4.y; mrs[2] = r4.z; mrs[3] = r4.w;
+        }
+    }
+    // the epilogue of a tile: acc[i][j][reg] -> pixel m0 + 64 wm + 16 i + 4 lg + reg, channel cbase + j; `dead`: the window buffer the tile has finished with.
+    // ACT: the activation as a compile-time constant (-1: the descriptor's, decided per element), FULL: all 256 pixels inside the tensor — the per-element form
+    // (a five-way switch and a bounds test around each of a lane's 64 results, on a block which has no second wave per SIMD to hide them behind) was 13 of the
+    // first version's 18 us per tile.
+    auto finish_tile = [&](int dead, auto actc, auto fullc) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(actc)::value;
+        constexpr bool FULL = decltype(fullc)::value;
+        const int act = ACT >= 0 ? ACT : a.act;
+        float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            uint2 yq[MOM ? 4 : 1], aq[MOM ? 4 : 1];
+            if constexpr (MOM) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int m = m0 + 64 * wm + 16 * i + 4 * lg + reg;
+                    const size_t at = (size_t)((FULL || m < (int)a.M) ? m : 0) * a.Cout + cbase;
+                    yq[reg] = yprev != nullptr ? *reinterpret_cast<const uint2*>(yprev + at) : make_uint2(0u, 0u);
+                    aq[reg] = addend != nullptr ? *reinterpret_cast<const uint2*>(addend + at) : make_uint2(0u, 0u);
+                }
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int m = m0 + 64 * wm + 16 * i + 4 * lg + reg;
+                if (FULL || m < (int)a.M) {
+                    float o[4], uu[4] = {0.f, 0.f, 0.f, 0.f}, ad[4] = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (MOM) {
+                        const uint2 q = yq[reg], q2 = aq[reg];
+                        uu[0] = (__uint_as_float(q.x << 16) - mmu[0]) * mrs[0]; uu[1] = (__uint_as_float(q.x & 0xffff0000u) - mmu[1]) * mrs[1];
+                        uu[2] = (__uint_as_float(q.y << 16) - mmu[2]) * mrs[2]; uu[3] = (__uint_as_float(q.y & 0xffff0000u) - mmu[3]) * mrs[3];
+                        ad[0] = __uint_as_float(q2.x << 16); ad[1] = __uint_as_float(q2.x & 0xffff0000u); ad[2] = __uint_as_float(q2.y << 16); ad[3] = __uint_as_float(q2.y & 0xffff0000u);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        o[j] = dcv_act_apply(acc[i][j][reg] + bv[j], act, a.slope) + ad[j];
+                        ssum[j] += o[j]; ssq[j] += MOM ? o[j] * uu[j] : o[j] * o[j];
+                    }
+                    *reinterpret_cast<bf16x4*>(yv + (size_t)m * a.Cout + cbase) = (bf16x4){(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (stats != nullptr) {
+            // statistics rows per 128 pixels: the tile's halves = waves 0, 1 and waves 2, 3 (same butterfly and wave order as the window kernel's 64-wide instance)
+            __syncthreads();                                       // every wave is done reading the dead window
+            double* red = reinterpret_cast<double*>(lds + dead * BH_WSTRIDE);      // [4 waves][2][64]
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float s1v = ssum[j], s2v = ssq[j];
+                s1v += __shfl_xor(s1v, 16, 64); s2v += __shfl_xor(s2v, 16, 64);
+                s1v += __shfl_xor(s1v, 32, 64); s2v += __shfl_xor(s2v, 32, 64);
+                if (lg == 0) { red[(wm * 2 + 0) * 64 + 4 * li + j] = (double)s1v; red[(wm * 2 + 1) * 64 + 4 * li + j] = (double)s2v; }
+            }
+            __syncthreads();
+            const int rows_here = (int)((a.M + 127) / 128), rows_total = a.stat_rows ? a.stat_rows : rows_here;
+            {
+                const int half = t >> 7, q = (t >> 6) & 1, c = t & 63;      // 256 threads = 2 halves x 2 sums x 64 channels
+                const double v = red[((half * 2 + 0) * 2 + q) * 64 + c] + red[((half * 2 + 1) * 2 + q) * 64 + c];
+                const int row = 2 * tile + half;
+                if (row < rows_here) stats[((size_t)q * a.Cout + n0 + c) * rows_total + a.stat_row0 + row] = v;
+            }
+        }
+    };
+
+    stage_window(0, wv_of(m0));
+    unsigned k64 = 64u;
+    bf16x8 fa0[TI], fa1[TI];
+    int par = 0;
+    bool first = true;
+    for (; tile < ntiles; tile += gstep, m0 += gstep * BMH, par ^= 1) {
+        // this tile's window was requested a tile ago; younger than it: the previous tile's 16 stores
+        if (first) __builtin_amdgcn_s_waitcnt(0x0F70); else __builtin_amdgcn_s_waitcnt(0x4F70);      // vmcnt(0) / vmcnt(16)
+        __syncthreads();                                           // everybody's pieces have landed; every wave is done with the other buffer (its taps, its statistics scratch)
+        // the next tile's window: its 32-row pieces are requested one or two per tap (an LDS-DMA instruction costs its wave 60 - 185 issue clocks: ten to twelve in a
+        // row were half a microsecond in front of every tile's first MFMA)
+        const bool more = tile + gstep < ntiles;
+        const unsigned nwv = more ? wv_of(m0 + gstep * BMH) : 0u;
+        if (!first) set_tile(m0);
+        first = false;
+        asm volatile("" : "+s"(k64));
+        const char* wbase = lds + par * BH_WSTRIDE;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) fa0[i] = *reinterpret_cast<const bf16x8*>(wbase + aaddr[i][0] + 2048 * i);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i) fa1[i] = *reinterpret_cast<const bf16x8*>(wbase + (aaddr[i][tap] ^ k64) + 2048 * i);
+            if (more) { if (tap < nhalf) stage_piece(par ^ 1, nwv, tap); if (tap + 9 < nhalf) stage_piece(par ^ 1, nwv, tap + 9); }
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { if (tap < RF_ATAPS) rf_mfma_a(acc[i][j], fa0[i], fb[tap][0][j]); else rf_mfma_v(acc[i][j], fa0[i], fb[tap][0][j]); }
+            if (tap + 1 < 9) {
+#pragma unroll
+                for (int i = 0; i < TI; ++i) fa0[i] = *reinterpret_cast<const bf16x8*>(wbase + aaddr[i][tap + 1] + 2048 * i);
+            }
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { if (tap < RF_ATAPS) rf_mfma_a(acc[i][j], fa1[i], fb[tap][1][j]); else rf_mfma_v(acc[i][j], fa1[i], fb[tap][1][j]); }
+        }
+        rf_mfma_drain();
+        if (m0 + BMH <= (int)a.M && a.act == DCV_ACT_NONE) finish_tile(par, std::integral_constant<int, DCV_ACT_NONE>{}, std::true_type{});
+        else if (m0 + BMH <= (int)a.M && a.act == DCV_ACT_RELU) finish_tile(par, std::integral_constant<int, DCV_ACT_RELU>{}, std::true_type{});
+        else finish_tile(par, std::integral_constant<int, -1>{}, std::false_type{});
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradient, all nine taps per block, bf16 operands
 // dW[tap][co][ci] = sum over pixels of dz[p][co] * x[p (+) tap][ci] for 3x3 / stride 1 / pad 1 layers: GEMM with M = co, N = ci, K = pixels.  Both operands
 // are K-strided in memory ([pixel][channel] rows), so the LDS images keep the natural layout and the fragments are read TRANSPOSED (`ds_read_b64_tr_b16`:
@@ -1517,6 +1733,24 @@ int launch(const Bf16Args& a0, const u16* x, const u16* wb, const float* bias, v
             dim3 hgrid(hgx, hgy);
             if (hgrid.y > 65535) return DCV_ERR_UNSUPPORTED;
             if constexpr (OUT_BF16) {
+                // 64 input channels: the filters-in-registers kernel (DCV_BF16_HALO_RF=0: off)
+                static int rf = -1;
+                if (rf < 0) { const char* e = getenv("DCV_BF16_HALO_RF"); rf = e ? atoi(e) : 1; }
+                if (rf && a.Cin == 64) {
+                    static bool rconf[2] = {false, false};
+                    const unsigned gy = (unsigned)(a.Cout / 64);
+                    unsigned gx = DCV_NUM_CU / gy; if (gx < 1) gx = 1; if (gx > htiles) gx = htiles;
+                    const size_t rs = (size_t)2 * BH_WSTRIDE;
+                    dcv_count_launch(DCV_FAMILY_BF16_WINDOW);
+                    if (mom != nullptr) {
+                        if (!rconf[1]) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_halo_rf_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DCV_ERR_LAUNCH; rconf[1] = true; }
+                        hipLaunchKernelGGL((conv_bf16_halo_rf_kernel<true>), dim3(gx, gy), dim3(256), rs, st, ah, x, wb, bias, reinterpret_cast<u16*>(y), stats, win_rows, mom->yprev, mom->mean, mom->rstd, mom->addend);
+                    } else {
+                        if (!rconf[0]) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_halo_rf_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DCV_ERR_LAUNCH; rconf[0] = true; }
+                        hipLaunchKernelGGL((conv_bf16_halo_rf_kernel<false>), dim3(gx, gy), dim3(256), rs, st, ah, x, wb, bias, reinterpret_cast<u16*>(y), stats, win_rows, (const u16*)nullptr, (const float*)nullptr, (const float*)nullptr, (const u16*)nullptr);
+                    }
+                    return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
+                }
                 if (mom != nullptr) {
                     static bool mconf[2] = {false, false};
                     dcv_count_launch(DCV_FAMILY_BF16_WINDOW);
