@@ -566,6 +566,214 @@ __global__ __launch_bounds__(NC_THREADS) void nc_bwd_apply_kernel(const AT* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------------ round 4: a following MAX pooling with overlapping windows
+// Conv -> act -> BatchNorm -> MaxPool2d(k, stride, pad), k <= 2 stride (the 3x3 / 2 pooling behind the stem of a ResNet; BatchNorm only, bf16 tensors, eight
+// channels per lane).  Unfused, the stem of resnet18_style at 512 images moved 0.82 GB four times forward (affine: read + write, pooling: read) and 5 GB backward
+// (pooling backward writes the full-size gradient, the sums pass and the apply pass read it and x again): 1.9 ms of a 13.6 ms step.  Fused:
+//   forward   one thread per POOLED (pixel, channel vector): out = max over the window of bf16(S x + T) — the values the unfused pair compares, first maximum wins,
+//             a NaN always wins (torch) — and the window position r k + s of the winner as one byte per element; the full-size affine is never written;
+//   backward  sums: per pooled element d = dout and u = (x - mean) rstd at the winner's pixel -> sum d, sum d u (the gradient of the full-size affine is zero
+//             anywhere else); apply: per full-size pixel the gradients of the at most four windows it won, dz = act'(x) (P d + Q u + R) with nc_param_finalize's
+//             coefficients — the full-size gradient is never written either.
+struct NcMax { int H, W, Ho, Wo, k, st, pad; };
+
+template <int K>                                                  // compile-time window (2, 3): its K x K loads are all requested before the first compare; 0: the descriptor's
+__global__ __launch_bounds__(NC_THREADS) void nc_maxpool_fwd_kernel(const nc_bf16* __restrict__ x, nc_bf16* __restrict__ out, unsigned char* __restrict__ arg, int C,
+                                                                     const float* __restrict__ ab, NcMax pm, unsigned total) {
+    const unsigned i = blockIdx.x * NC_THREADS + threadIdx.x;
+    if (i >= total) return;
+    const unsigned CV = (unsigned)C >> 3, cv = i % CV;
+    unsigned p = i / CV;
+    const int wo = (int)(p % (unsigned)pm.Wo); p /= (unsigned)pm.Wo;
+    const int ho = (int)(p % (unsigned)pm.Ho), n = (int)(p / (unsigned)pm.Ho);
+    const NcVec<8> S = nc_load<8>(ab + cv * 8), T = nc_load<8>(ab + C + cv * 8);
+    const nc_bf16* xs = x + (size_t)n * pm.H * pm.W * C + cv * 8;
+    const int h0 = ho * pm.st - pm.pad, w0 = wo * pm.st - pm.pad;
+    float best[8]; unsigned bi[8];
+    const unsigned first = (unsigned)((h0 < 0 ? -h0 : 0) * pm.k + (w0 < 0 ? -w0 : 0));      // torch initialises the index to the window's first in-range element
+#pragma unroll
+    for (int v = 0; v < 8; ++v) { best[v] = -INFINITY; bi[v] = first; }
+    auto take = [&](const NcVec<8>& xv, unsigned pos) __attribute__((always_inline)) {
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            const float a = (float)(__bf16)(xv.v[v] * S.v[v] + T.v[v]);          // the bf16 value the unfused layer stores and the pooling compares
+            if (a > best[v] || a != a) { best[v] = a; bi[v] = pos; }
+        }
+    };
+    if constexpr (K > 0) {
+        NcVec<8> xv[K * K];
+        bool ok[K * K];
+#pragma unroll
+        for (int r = 0; r < K; ++r)
+#pragma unroll
+            for (int sx = 0; sx < K; ++sx) {
+                const int h = h0 + r, w = w0 + sx;
+                ok[r * K + sx] = h >= 0 && h < pm.H && w >= 0 && w < pm.W;
+                xv[r * K + sx] = nc_load<8>(xs + (ok[r * K + sx] ? ((size_t)h * pm.W + w) * C : 0));
+            }
+#pragma unroll
+        for (int q = 0; q < K * K; ++q) if (ok[q]) take(xv[q], (unsigned)q);
+    } else {
+        for (int r = 0; r < pm.k; ++r) {
+            const int h = h0 + r;
+            if (h < 0 || h >= pm.H) continue;
+            for (int sx = 0; sx < pm.k; ++sx) {
+                const int w = w0 + sx;
+                if (w < 0 || w >= pm.W) continue;
+                take(nc_load<8>(xs + ((size_t)h * pm.W + w) * C), (unsigned)(r * pm.k + sx));
+            }
+        }
+    }
+    NcVec<8> o;
+#pragma unroll
+    for (int v = 0; v < 8; ++v) o.v[v] = best[v];
+    nc_store<8>(out + (size_t)i * 8, o);
+    *reinterpret_cast<uint2*>(arg + (size_t)i * 8) = make_uint2(bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24), bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24));
+}
+
+// sums of d and d u over the pooled elements of this block's chunk of one sample -> part[2][C][rows] (row = sample * gridDim.x + chunk)
+__global__ __launch_bounds__(NC_THREADS) void nc_maxpool_bwd_sums_kernel(const nc_bf16* __restrict__ x, const nc_bf16* __restrict__ dout, const unsigned char* __restrict__ arg,
+                                                                          int C, int per, const float* __restrict__ mean, const float* __restrict__ rstd, NcMax pm,
+                                                                          double* __restrict__ part, int rows) {
+    __shared__ float sm[16][NC_THREADS];
+    const int CV = C >> 3, nvp = pm.Ho * pm.Wo * CV;
+    const NcChunk ck = nc_chunk(nvp, CV, per);
+    const NcVec<8> mu = nc_load<8>(mean + ck.cv * 8), rs = nc_load<8>(rstd + ck.cv * 8);
+    const nc_bf16* xs = x + (size_t)ck.n * pm.H * pm.W * C + ck.cv * 8;
+    const nc_bf16* ds = dout + (size_t)ck.n * nvp * 8;
+    const unsigned char* as = arg + (size_t)ck.n * nvp * 8;
+    float acc[2][8];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) { acc[0][v] = 0.f; acc[1][v] = 0.f; }
+    int ho = ck.pix / pm.Wo, wo = ck.pix - ho * pm.Wo;
+    const int hstep = ck.pstep / pm.Wo, wstep = ck.pstep - hstep * pm.Wo;
+    for (int i = ck.i0; i < ck.i1; i += NC_THREADS) {
+        const NcVec<8> d = nc_load<8>(ds + (size_t)i * 8);
+        const uint2 aw = *reinterpret_cast<const uint2*>(as + (size_t)i * 8);
+        const int h0 = ho * pm.st - pm.pad, w0 = wo * pm.st - pm.pad;
+        // the winner's x per channel: eight two-byte loads, all requested before the first use (the winner is inside the image by construction)
+        float xw[8];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            const unsigned av = ((v < 4 ? aw.x : aw.y) >> (8 * (v & 3))) & 0xffu;
+            const int r = (int)(av / (unsigned)pm.k), sx = (int)av - r * pm.k;
+            xw[v] = __uint_as_float((unsigned)xs[((size_t)(h0 + r) * pm.W + (w0 + sx)) * C + v] << 16);
+        }
+#pragma unroll
+        for (int v = 0; v < 8; ++v) { acc[0][v] += d.v[v]; acc[1][v] += d.v[v] * ((xw[v] - mu.v[v]) * rs.v[v]); }
+        ho += hstep; wo += wstep;
+        if (wo >= pm.Wo) { wo -= pm.Wo; ++ho; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        if (off >= CV) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int v = 0; v < 8; ++v) acc[q][v] += __shfl_xor(acc[q][v], off, 64);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int v = 0; v < 8; ++v) sm[q * 8 + v][threadIdx.x] = acc[q][v];
+    __syncthreads();
+    const int stride = CV > 64 ? CV : 64, holders = NC_THREADS / stride;
+    for (int o = threadIdx.x; o < 2 * C; o += NC_THREADS) {
+        const int q = o / C, c = o - q * C, cvi = c >> 3, v = c & 7;
+        float sacc = 0.f;
+        for (int k = 0; k < holders; ++k) sacc += sm[q * 8 + v][cvi + k * stride];
+        part[((size_t)q * C + c) * rows + (size_t)blockIdx.y * gridDim.x + blockIdx.x] = (double)sacc;
+    }
+}
+
+// dz = act'(x) (P d + Q u + R), d = the gradients of the windows this pixel won; the chunks and the bias partials (dbp / dbf) as nc_bwd_apply_kernel's
+template <int K, int ST>                                         // compile-time window and stride (0: the descriptor's): the per-pixel window ranges are divisions by the stride
+__global__ __launch_bounds__(NC_THREADS) void nc_maxpool_bwd_apply_kernel(const nc_bf16* __restrict__ dout, const unsigned char* __restrict__ arg, const nc_bf16* __restrict__ x,
+                                                                           nc_bf16* __restrict__ dz, int C, int per, const float* __restrict__ coef,
+                                                                           const float* __restrict__ mean, const float* __restrict__ rstd, NcAct act, NcMax pm,
+                                                                           double* __restrict__ dbp, int dbrows, float* __restrict__ dbf) {
+    __shared__ float dbred[NC_THREADS * 8];
+    float sdz[8];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) sdz[v] = 0.f;
+    const int CV = C >> 3, HW = pm.H * pm.W;
+    const NcChunk ck = nc_chunk(HW * CV, CV, per);
+    const float* cf = coef + ck.cv * 8;
+    const NcVec<8> P = nc_load<8>(cf), Q = nc_load<8>(cf + C), R = nc_load<8>(cf + 2 * C);
+    const NcVec<8> mu = nc_load<8>(mean + ck.cv * 8), rs = nc_load<8>(rstd + ck.cv * 8);
+    const nc_bf16* xs = x + (size_t)ck.n * HW * C; nc_bf16* zs = dz + (size_t)ck.n * HW * C;
+    const size_t pooled = (size_t)ck.n * pm.Ho * pm.Wo * C + ck.cv * 8;
+    const nc_bf16* ds = dout + pooled; const unsigned char* as = arg + pooled;
+    int h = ck.pix / pm.W, w = ck.pix - h * pm.W;
+    const int hstep = ck.pstep / pm.W, wstep = ck.pstep - hstep * pm.W;
+    const int kk = K > 0 ? K : pm.k, ss = ST > 0 ? ST : pm.st;
+    constexpr int B = 2;                                          // pixels per thread in flight: x, and the gradient + winner bytes of the 2 x 2 candidate windows of each
+    for (int i = ck.i0; i < ck.i1; i += B * NC_THREADS) {
+        NcVec<8> xv[B], g[B][4];
+        uint2 aw[B][4];
+        unsigned me[B][4];
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            const bool live = i + b * NC_THREADS < ck.i1;
+            xv[b] = nc_load<8>(xs + (size_t)(live ? i + b * NC_THREADS : i) * 8);
+            // the windows o with o st - pad <= i < o st - pad + k, per axis: o_hi = (i + pad) / st and o_hi - 1 (k <= 2 st), those inside [o_lo, Ho - 1]
+            const int th = h + pm.pad, tw = w + pm.pad;
+            const int hhi = th / ss, whi = tw / ss;
+            const int hlo = th - kk + 1 <= 0 ? 0 : (th - kk + ss) / ss, wlo = tw - kk + 1 <= 0 ? 0 : (tw - kk + ss) / ss;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ho = hhi - (q >> 1), wo = whi - (q & 1);
+                const bool ok = live && ho >= hlo && ho < pm.Ho && wo >= wlo && wo < pm.Wo;
+                const size_t o = ok ? ((size_t)ho * pm.Wo + wo) * C : 0;
+                g[b][q] = nc_load<8>(ds + o);
+                aw[b][q] = *reinterpret_cast<const uint2*>(as + o);
+                me[b][q] = ok ? (unsigned)((h - (ho * ss - pm.pad)) * kk + (w - (wo * ss - pm.pad))) : 0xffffu;
+            }
+            h += hstep; w += wstep;
+            if (w >= pm.W) { w -= pm.W; ++h; }
+        }
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            float d[8];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) d[v] = 0.f;
+            // (summed in the order ho ascending, wo ascending: the order of the plain loop this replaces)
+#pragma unroll
+            for (int q = 3; q >= 0; --q)
+#pragma unroll
+                for (int v = 0; v < 8; ++v) {
+                    const unsigned av = ((v < 4 ? aw[b][q].x : aw[b][q].y) >> (8 * (v & 3))) & 0xffu;
+                    d[v] += av == me[b][q] ? g[b][q].v[v] : 0.f;
+                }
+            NcVec<8> o8;
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                const float u = (xv[b].v[v] - mu.v[v]) * rs.v[v];
+                o8.v[v] = (P.v[v] * d[v] + Q.v[v] * u + R.v[v]) * nc_act_grad(xv[b].v[v], act);
+            }
+            if (i + b * NC_THREADS < ck.i1) {
+                nc_store<8>(zs + (size_t)(i + b * NC_THREADS) * 8, o8);
+#pragma unroll
+                for (int v = 0; v < 8; ++v) sdz[v] += o8.v[v];
+            }
+        }
+    }
+    if (dbp != nullptr || dbf != nullptr) {
+#pragma unroll
+        for (int v = 0; v < 8; ++v) dbred[threadIdx.x * 8 + v] = sdz[v];
+        __syncthreads();
+        const int block = blockIdx.y * gridDim.x + blockIdx.x;
+        for (int c = threadIdx.x; c < C; c += NC_THREADS) {
+            const int cv = c >> 3, v = c & 7;
+            float sacc = 0.f;
+            for (int tq = cv; tq < NC_THREADS; tq += CV) sacc += dbred[tq * 8 + v];
+            if (dbf != nullptr) dbf[(size_t)block * C + c] = sacc;
+            else dbp[(size_t)c * dbrows + block] = (double)sacc;
+        }
+    }
+}
+
 // out[c] = sum of part[c][0 .. rows): one wave per channel, lanes stride over the contiguous row (coalesced), fixed-order butterfly
 __global__ __launch_bounds__(64) void nc_rows_sum_kernel(const double* __restrict__ part, int rows, float* __restrict__ out) {
     const int c = blockIdx.x, lane = threadIdx.x;
@@ -618,6 +826,16 @@ inline bool nc_shape_ok(const dcv_norm_chain_desc* d) {
         if ((size_t)d->hw * cv > (size_t)NC_THREADS * 32) return false;         // one block per sample
     }
     if (d->pool < 0) return false;
+    if (d->pool_mode == 1) {
+        // a following max pooling with overlapping windows (nc_maxpool_*): BatchNorm only, bf16 tensors, eight channels per lane, every pixel in at most 2 x 2 windows
+        if (d->pool != 0 || d->groups != 0 || d->io_dtype != DCV_DTYPE_BF16 || vec != 8 || d->width <= 0 || d->hw % d->width != 0) return false;
+        if (d->pool_k < 2 || d->pool_k > 15 || d->pool_stride < 1 || d->pool_k > 2 * d->pool_stride || d->pool_pad < 0 || 2 * d->pool_pad > d->pool_k) return false;
+        const int H = d->hw / d->width, ho = (H + 2 * d->pool_pad - d->pool_k) / d->pool_stride + 1, wo = (d->width + 2 * d->pool_pad - d->pool_k) / d->pool_stride + 1;
+        if (H + 2 * d->pool_pad < d->pool_k || d->width + 2 * d->pool_pad < d->pool_k || ho <= 0 || wo <= 0) return false;
+        if ((size_t)d->n * ho * wo * cv >= ((size_t)1 << 32) - NC_THREADS) return false;
+        return true;
+    }
+    if (d->pool_mode != 0) return false;
     // (round 4: fused pooling also without the GroupNorm stage — the BatchNorm-only layers of the wide specs: out = mean over the window of a[c] x + b[c])
     if (d->pool > 0 && !(d->width > 0 && d->hw % d->width == 0 && d->width % d->pool == 0 && (d->hw / d->width) % d->pool == 0)) return false;
     return true;
@@ -626,6 +844,10 @@ inline bool nc_shape_ok(const dcv_norm_chain_desc* d) {
 inline NcPool nc_pool(const dcv_norm_chain_desc* d) {
     return NcPool{d->width > 0 ? d->width : 1, d->pool > 0 ? d->width / d->pool : 1, d->pool, d->pool > 0 ? 1.f / (float)(d->pool * d->pool) : 1.f,
                   (d->pool > 0 && pow2(d->pool)) ? ilog2(d->pool) : -1};
+}
+inline NcMax nc_max(const dcv_norm_chain_desc* d) {
+    const int H = d->hw / d->width;
+    return NcMax{H, d->width, (H + 2 * d->pool_pad - d->pool_k) / d->pool_stride + 1, (d->width + 2 * d->pool_pad - d->pool_k) / d->pool_stride + 1, d->pool_k, d->pool_stride, d->pool_pad};
 }
 inline NcAct nc_act(int act, float slope) {
     switch (act) {
@@ -704,6 +926,17 @@ int dcv_norm_chain_fwd(const dcv_norm_chain_desc* d, const void* xv, void* outv,
     }
     if (!(nc_skip() & 2)) hipLaunchKernelGGL(nc_bn_fwd_finalize_kernel, dim3((unsigned)C), dim3(NC_THREADS), 0, st, part, rows, (double)d->n * (double)d->hw, C, d->bn_gamma, d->bn_beta,
                        d->running_mean, d->running_var, reinterpret_cast<long long*>(d->num_batches_tracked), d->momentum, d->bn_eps, d->bn_mean, d->bn_rstd, ab);
+    if (d->pool_mode == 1) {
+        DCV_CHECK_ARG(d->pool_arg != nullptr && (reinterpret_cast<uintptr_t>(d->pool_arg) & 7) == 0);
+        if (nc_skip() & 4) DCV_RETURN_LAUNCH();
+        const NcMax mx = nc_max(d);
+        const size_t total = (size_t)d->n * mx.Ho * mx.Wo * CV;
+        const dim3 fgrid((unsigned)dcv_ceil_div(total, NC_THREADS));
+        if (mx.k == 3) hipLaunchKernelGGL((nc_maxpool_fwd_kernel<3>), fgrid, dim3(NC_THREADS), 0, st, x16, out16, d->pool_arg, C, ab, mx, (unsigned)total);
+        else if (mx.k == 2) hipLaunchKernelGGL((nc_maxpool_fwd_kernel<2>), fgrid, dim3(NC_THREADS), 0, st, x16, out16, d->pool_arg, C, ab, mx, (unsigned)total);
+        else hipLaunchKernelGGL((nc_maxpool_fwd_kernel<0>), fgrid, dim3(NC_THREADS), 0, st, x16, out16, d->pool_arg, C, ab, mx, (unsigned)total);
+        DCV_RETURN_LAUNCH();
+    }
     int abps = bps, aper = per;
     if (d->pool > 0) nc_split((d->hw / (d->pool * d->pool)) * CV, G > 0, &abps, &aper);      // (a GroupNorm sample is one block: its prologue; else as many as it takes)
     const dim3 agrid((unsigned)abps, (unsigned)d->n);
@@ -739,6 +972,21 @@ int dcv_norm_chain_bwd(const dcv_norm_chain_desc* d, const void* doutv, const vo
     const double* fpart = d->moments ? d->moments : part;
     const int frows = d->moments ? d->moments_rows : rows;
     const dim3 sgrid((unsigned)bps, (unsigned)d->n);
+    if (d->pool_mode == 1) {
+        DCV_CHECK_ARG(d->pool_arg != nullptr && d->moments == nullptr && (reinterpret_cast<uintptr_t>(d->pool_arg) & 7) == 0);
+        const NcMax mx = nc_max(d);
+        int pbps, pper; nc_split(mx.Ho * mx.Wo * CV, false, &pbps, &pper);        // (fewer vectors than the full-size map: the rows fit the same workspace)
+        const int prows = d->n * pbps;
+        if (!(nc_skip() & 1)) hipLaunchKernelGGL(nc_maxpool_bwd_sums_kernel, dim3((unsigned)pbps, (unsigned)d->n), dim3(NC_THREADS), 0, st, x16, dout16, d->pool_arg, C, pper, d->bn_mean, d->bn_rstd, mx, part, prows);
+        if (!(nc_skip() & 2)) hipLaunchKernelGGL(nc_param_finalize_kernel, dim3((unsigned)C), dim3(NC_THREADS), 0, st, part, prows, (double)d->n * (double)d->hw, C, 0, d->bn_gamma, d->bn_rstd,
+                           d_bn_gamma, d_bn_beta, d_gn_gamma, d_gn_beta, chan, d->coef);
+        if (nc_skip() & 4) DCV_RETURN_LAUNCH();
+        if (mx.k == 3 && mx.st == 2) hipLaunchKernelGGL((nc_maxpool_bwd_apply_kernel<3, 2>), sgrid, dim3(NC_THREADS), 0, st, dout16, d->pool_arg, x16, dz16, C, per, d->coef, d->bn_mean, d->bn_rstd, nc_act(d->act, d->act_slope), mx, dbp, rows, dbf);
+        else if (mx.k == 2 && mx.st == 2) hipLaunchKernelGGL((nc_maxpool_bwd_apply_kernel<2, 2>), sgrid, dim3(NC_THREADS), 0, st, dout16, d->pool_arg, x16, dz16, C, per, d->coef, d->bn_mean, d->bn_rstd, nc_act(d->act, d->act_slope), mx, dbp, rows, dbf);
+        else hipLaunchKernelGGL((nc_maxpool_bwd_apply_kernel<0, 0>), sgrid, dim3(NC_THREADS), 0, st, dout16, d->pool_arg, x16, dz16, C, per, d->coef, d->bn_mean, d->bn_rstd, nc_act(d->act, d->act_slope), mx, dbp, rows, dbf);
+        if (dbp) hipLaunchKernelGGL(nc_rows_sum_kernel, dim3((unsigned)C), dim3(64), 0, st, dbp, rows, d->d_bias);
+        DCV_RETURN_LAUNCH();
+    }
     const NcBwdCtx bc{d->bn_gamma, d->bn_beta, d->bn_rstd, nc_gn(d), d->coef};
     if ((nc_skip() & 1) || d->moments != nullptr) {}
     else if (io16 && vec == 8) hipLaunchKernelGGL((nc_sample_sums_kernel<8, true, nc_bf16>), sgrid, dim3(NC_THREADS), 0, st, x16, dout16, d->hw, C, per, d->bn_mean, d->bn_rstd, pm, part, rows, bc);

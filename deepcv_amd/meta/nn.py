@@ -265,20 +265,20 @@ class LayerSequential(torch.nn.Sequential):
             gn, i = mods[i], i + 1
         return mods[0], act, bn, gn, i
 
-    def _run_fused_layer(self, x: torch.Tensor, plan, pool: int = 0) -> torch.Tensor:
+    def _run_fused_layer(self, x: torch.Tensor, plan, pool: int = 0, max_pool=None) -> torch.Tensor:
         conv, act, bn, gn, _ = plan
         conv._check()
         code, slope = ops.act_code(act)
         return ops.conv_norm_layer(x, conv.weight, conv.bias, conv.stride, conv._padding_pair(), conv.dilation, code, slope,
                                    bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum, bn.eps,
                                    gn.num_groups if gn is not None else 0, gn.weight if gn is not None else None, gn.bias if gn is not None else None,
-                                   gn.eps if gn is not None else 1e-5, pool=pool)
+                                   gn.eps if gn is not None else 1e-5, pool=pool, max_pool=max_pool)
 
     def forward_with_pool(self, x, pool: torch.nn.Module) -> Optional[torch.Tensor]:
         """ This layer followed by the non-overlapping average pooling `pool` (the next sub-module of the architecture, reference
         `submodule_creators.py:168`) through the fused training kernels: the pooling rides in the normalisation kernels of both directions.
         None when the pair is not covered (the caller then applies the two modules one after the other). """
-        if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4 and type(pool) is native.AvgPool2d):
+        if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4 and type(pool) in (native.AvgPool2d, native.MaxPool2d)):
             return None
         mods = list(self._modules.values())
         plan = self._fused_layer_plan(mods)
@@ -288,6 +288,17 @@ class LayerSequential(torch.nn.Sequential):
             k, s, p = pool._geom()
         except NotImplementedError:
             return None
+        if type(pool) is native.MaxPool2d:
+            # a max pooling with overlapping windows behind a BatchNorm-only layer on the bf16 storage path (the 3x3 / 2 / 1 pooling behind a ResNet stem, round 4)
+            if k[0] != k[1] or s[0] != s[1] or p[0] != p[1] or plan[3] is not None:
+                return None
+            out_shape = plan[0].out_shape(x.shape)
+            if not ops.fused_max_pool_covered(out_shape[0], out_shape[1], out_shape[2], out_shape[3], k[0], s[0], p[0]):
+                return None
+            try:
+                return self._run_fused_layer(x, plan, max_pool=(k[0], s[0], p[0]))
+            except ops.FusedPoolUnavailable:                      # (raised before any launch: the layer is not on the bf16 storage path)
+                return None
         if k[0] != k[1] or tuple(s) != tuple(k) or tuple(p) != (0, 0) or k[0] < 2:
             return None
         out_shape = plan[0].out_shape(x.shape)

@@ -768,10 +768,45 @@ def fused_pool_covered(n: int, c: int, ho: int, wo: int, groups: int, pool: int)
     return True
 
 
+class FusedPoolUnavailable(ValueError):
+    """ Raised by `conv_norm_layer(max_pool=...)` BEFORE anything is launched when the layer does not run on the kernels which carry the pooling. """
+
+
+def _max_pool_code(k: int, stride: int, pad: int) -> int:
+    """ A following MaxPool2d(k, stride, pad) in the `pool` slot of a layer's configuration tuple (positive values: non-overlapping average pooling). """
+    return -(k * 10000 + stride * 100 + pad)
+
+
+def _pool_geom(pool: int):
+    """ (kernel, stride, padding) of the pooling a layer's configuration names; (0, 0, 0): none. """
+    if pool >= 0:
+        return pool, pool, 0
+    return (-pool) // 10000, ((-pool) // 100) % 100, (-pool) % 100
+
+
+def _pooled_hw(d, pool: int):
+    k, s, p = _pool_geom(pool)
+    return (d.ho, d.wo) if not pool else ((d.ho + 2 * p - k) // s + 1, (d.wo + 2 * p - k) // s + 1)
+
+
+def fused_max_pool_covered(n: int, c: int, ho: int, wo: int, k: int, stride: int, pad: int) -> bool:
+    """ Can a BatchNorm-only bf16 layer with these output extents take a following MaxPool2d(k, stride, pad) into its normalisation kernels
+    (`dcv_norm_chain_desc::pool_mode` 1: overlapping windows, the 3x3 / 2 / 1 pooling behind a ResNet stem)? """
+    if not (_norm_streaming and _conv_math == nat.MATH_BF16 and _bf16_storage) or os.environ.get('DCV_FUSED_MAX_POOL', '1') in ('0', 'false', 'False', ''):
+        return False
+    nc = nat.NormChainDesc(n, ho * wo, c, wo, 0, None, None, None, None, None, 0.1, 1e-5, None, None, 0, None, None, 1e-5, None, None, None, nat.ACT_NONE, 0.)
+    nc.io_dtype, nc.pool_mode, nc.pool_k, nc.pool_stride, nc.pool_pad = nat.DTYPE_BF16, 1, k, stride, pad
+    return bool(lib.dcv_norm_chain_supported(nc))
+
+
 def _norm_chain_desc(d, cfg, bn_w, bn_b, running_mean, running_var, nbt, bn_mean, bn_rstd, gn_w, gn_b, gn_mean, gn_rstd) -> nat.NormChainDesc:
     stride, padding, dilation, act, slope, momentum, bn_eps, groups, gn_eps, pool = cfg
-    return nat.NormChainDesc(d.n, d.ho * d.wo, d.cout, d.wo, pool, nat.ptr(bn_w), nat.ptr(bn_b), nat.ptr(running_mean), nat.ptr(running_var), nat.ptr(nbt), momentum, bn_eps,
-                             nat.ptr(bn_mean), nat.ptr(bn_rstd), groups, nat.ptr(gn_w), nat.ptr(gn_b), gn_eps, nat.ptr(gn_mean), nat.ptr(gn_rstd), None, act, slope)
+    nc = nat.NormChainDesc(d.n, d.ho * d.wo, d.cout, d.wo, max(pool, 0), nat.ptr(bn_w), nat.ptr(bn_b), nat.ptr(running_mean), nat.ptr(running_var), nat.ptr(nbt), momentum, bn_eps,
+                           nat.ptr(bn_mean), nat.ptr(bn_rstd), groups, nat.ptr(gn_w), nat.ptr(gn_b), gn_eps, nat.ptr(gn_mean), nat.ptr(gn_rstd), None, act, slope)
+    if pool < 0:
+        nc.pool_mode, (nc.pool_k, nc.pool_stride, nc.pool_pad) = 1, _pool_geom(pool)
+        nc.io_dtype = nat.DTYPE_BF16                              # (a fused max pooling exists on the bf16 storage path only)
+    return nc
 
 
 class _ConvNormLayerFn(torch.autograd.Function):
@@ -821,7 +856,7 @@ class _ConvNormLayerFn(torch.autograd.Function):
         nc = _norm_chain_desc(d, cfg, bn_w, bn_b, running_mean, running_var, nbt, bn_mean, bn_rstd, gn_w, gn_b, gn_mean, gn_rstd)
         ctx.streaming = _norm_streaming and bool(lib.dcv_norm_chain_supported(nc))
         if pool and not groups and not ctx.streaming:
-            raise ValueError('deepcv_amd.conv_norm_layer: fused average pooling without the GroupNorm stage needs the streaming norm chain (ops.fused_pool_covered)')
+            raise ValueError('deepcv_amd.conv_norm_layer: fused pooling without the GroupNorm stage needs the streaming norm chain (ops.fused_pool_covered)')
         if rec is not None:
             # recorded: same outputs, saved tensors and autograd node, no launch here (the backward pass below is the per-layer one, unchanged)
             if not ctx.streaming:
@@ -845,6 +880,8 @@ class _ConvNormLayerFn(torch.autograd.Function):
         ctx.use16 = _use_bf16_storage(d, layout)
         # bf16 storage path: the convolution output, the layer output and (backward) their gradients are bf16 tensors when the streaming chain serves the layer
         ctx.io16 = ctx.use16 and ctx.streaming
+        if pool < 0 and not ctx.io16:                             # (nothing has been launched or updated yet: the caller applies the two modules one after the other)
+            raise FusedPoolUnavailable('deepcv_amd.conv_norm_layer: a fused max pooling needs the bf16 storage path (ops.fused_max_pool_covered)')
         adt = torch.bfloat16 if ctx.io16 else torch.float32
         y = torch.empty((d.n, d.cout, d.ho, d.wo), dtype=adt, device=dev, memory_format=_CL)
         if ctx.use16:
@@ -855,8 +892,10 @@ class _ConvNormLayerFn(torch.autograd.Function):
         else:
             x = _to_f32(x, st)
             stats = _conv_fwd_launch(d, x, weight, bias, y, st, want_stats=True)
-        # `pool` > 0: the layer is followed by a non-overlapping average pooling, applied by the same kernel (only the pooled tensor is written)
-        out = torch.empty_like(y) if not pool else torch.empty((d.n, d.cout, d.ho // pool, d.wo // pool), dtype=adt, device=dev, memory_format=_CL)
+        # `pool` > 0: the layer is followed by a non-overlapping average pooling, applied by the same kernel (only the pooled tensor is written);
+        # `pool` < 0 (`_max_pool_code`): by a max pooling with overlapping windows — the winners' window positions are kept for the backward pass
+        out = torch.empty_like(y) if not pool else torch.empty((d.n, d.cout) + _pooled_hw(d, pool), dtype=adt, device=dev, memory_format=_CL)
+        ctx.pool_arg = torch.empty(out.shape, dtype=torch.uint8, device=dev, memory_format=_CL) if pool < 0 else None
         if ctx.streaming:
             rows, rps = ctypes.c_int(0), ctypes.c_int(0)
             if stats is not None and ctx.use16:
@@ -866,6 +905,7 @@ class _ConvNormLayerFn(torch.autograd.Function):
             coef = torch.empty(int(lib.dcv_norm_chain_coef_floats(nc)), dtype=torch.float32, device=dev)
             nc.coef = coef.data_ptr()
             nc.io_dtype = nat.DTYPE_BF16 if ctx.io16 else nat.DTYPE_F32
+            nc.pool_arg = nat.ptr(ctx.pool_arg)
             ws = _ws(lib.dcv_norm_chain_ws_bytes(nc), dev)
             nat.check(lib.dcv_norm_chain_fwd(nc, y.data_ptr(), out.data_ptr(), nat.ptr(stats), rows.value, rps.value, ws.data_ptr(), ws.numel(), st), 'dcv_norm_chain_fwd')
         else:
@@ -973,6 +1013,7 @@ class _ConvNormLayerFn(torch.autograd.Function):
             coef = torch.empty(int(lib.dcv_norm_chain_coef_floats(nc)), dtype=torch.float32, device=dev)
             nc.coef = coef.data_ptr()
             nc.io_dtype = nat.DTYPE_BF16 if ctx.io16 else nat.DTYPE_F32
+            nc.pool_arg = nat.ptr(getattr(ctx, 'pool_arg', None))
             db_part = None
             if db is not None and not db_from_wgrad:
                 if ctx.use16 and slabs.may_defer(ctx.bias_ref):
@@ -1024,12 +1065,14 @@ class _ConvNormLayerFn(torch.autograd.Function):
 
 
 def conv_norm_layer(x, weight, bias, stride, padding, dilation, act: int, slope: float, bn_w, bn_b, running_mean, running_var, num_batches_tracked,
-                    momentum: float, bn_eps: float, gn_groups: int = 0, gn_w=None, gn_b=None, gn_eps: float = 1e-5, pool: int = 0) -> torch.Tensor:
+                    momentum: float, bn_eps: float, gn_groups: int = 0, gn_w=None, gn_b=None, gn_eps: float = 1e-5, pool: int = 0, max_pool=None) -> torch.Tensor:
     """ Training-mode `GroupNorm?(BatchNorm(act(conv2d(x))))` with batch statistics and running-stat update, fused (see `_ConvNormLayerFn`).
     `pool` > 0 appends `avg_pool2d(kernel_size=pool, stride=pool)` (output sizes must be multiples of `pool`): same kernels, the unpooled output is
     never written. """
-    if pool < 0:
-        raise ValueError('deepcv_amd.conv_norm_layer: pool must be >= 0')
+    if pool < 0 or (pool and max_pool is not None):
+        raise ValueError('deepcv_amd.conv_norm_layer: pool must be >= 0 (and not combined with max_pool)')
+    if max_pool is not None:                                      # (kernel, stride, padding) of a following MaxPool2d (`fused_max_pool_covered`)
+        pool = _max_pool_code(int(max_pool[0]), int(max_pool[1]), int(max_pool[2]))
     gemm = _stem_as_gemm(x, weight, stride, padding, dilation) if resident.recorder() is None else None
     if gemm is not None:
         (x, weight), stride, padding, dilation = gemm, 1, 0, 1

@@ -357,6 +357,15 @@ typedef struct dcv_norm_chain_desc {
     const double* moments; int moments_rows;               /* nullable; dcv_norm_chain_bwd only, groups == 0: [2][channels][moments_rows] sums of dout and of dout * u
                                                               (u = (x - bn_mean) bn_rstd) over row blocks of (n, hw), left by the kernel which produced dout
                                                               (dcv_conv2d_bf16_dgrad_moments): the backward's pass over dout and x for these sums is skipped */
+    int pool_mode;                                         /* 0: `pool` (non-overlapping average pooling, or none); 1 (round 4): the chain ends in MaxPool2d(pool_k,
+                                                              pool_stride, pool_pad) with OVERLAPPING windows (the 3x3 / 2 / 1 pooling behind a ResNet stem): out / dout are
+                                                              the pooled tensors [n][ho][wo][channels], ho = (h + 2 pad - k) / stride + 1; BatchNorm only, bf16 tensors,
+                                                              channels % 8 == 0, k <= 2 stride, pool == 0; torch semantics (first maximum wins, NaN wins; the values compared
+                                                              are the bf16-rounded affine outputs the unfused pair compares); neither the full-size output nor its gradient
+                                                              is written.  replaces torch.nn.MaxPool2d behind a layer (nn_spec.py:158-169) */
+    int pool_k, pool_stride, pool_pad;
+    unsigned char* pool_arg;                               /* pool_mode 1: [n][ho][wo][channels] window position r k + s of each maximum: written by the forward, read by
+                                                              the backward; 8-byte aligned */
 } dcv_norm_chain_desc;
 int dcv_norm_chain_supported(const dcv_norm_chain_desc* d);
 size_t dcv_norm_chain_coef_floats(const dcv_norm_chain_desc* d);

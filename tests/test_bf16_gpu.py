@@ -212,6 +212,66 @@ def test_fused_layer_with_bf16_activations(device, groups, pool):
     assert (nbt.item() == 1) and _rel(rm, 0.1 * z.detach().mean(dim=(0, 2, 3))) <= 1e-2
 
 
+@pytest.mark.parametrize('geom', [(3, 2, 1, 20, 24), (2, 2, 0, 16, 16), (3, 2, 0, 17, 19), (2, 1, 0, 9, 12)], ids=['k3s2p1', 'k2s2', 'k3s2_odd', 'k2s1'])
+def test_fused_layer_with_a_following_max_pooling(device, geom, monkeypatch):
+    """ `ops.conv_norm_layer(max_pool=(k, stride, pad))` (round 4: a MaxPool2d with overlapping windows carried by the normalisation kernels of both directions,
+    `dcv_norm_chain_desc::pool_mode` 1) against the unfused pair — the layer, then `ops.pool2d` — on the same tensors: the pooled output bit for bit (the fused
+    kernel compares the bf16-rounded affine values the unfused pooling reads; first maximum wins), the running statistics bit for bit, the gradients within the
+    bf16 rounding of the full-size gradient which the unfused pair stores and the fused one never forms; the output also against a double-precision torch graph. """
+    from deepcv_amd import ops, _native as nat
+    k, st, pad, h, w = geom
+    n, cin, cout = 6, 64, 64
+    torch.manual_seed(11 + k + st + pad)
+    x = _bf(torch.randn(n, cin, h, w)).float()
+    wt = _bf(torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5).float()
+    b = torch.randn(cout) * 0.1
+    bn_w, bn_b = torch.rand(cout) + 0.5, torch.randn(cout) * 0.1
+    bn_w[::5] *= -1.                                              # negative scales: the maximum of the affine is the minimum of the convolution output
+    ho, wo = (h + 2 * pad - k) // st + 1, (w + 2 * pad - k) // st + 1
+    dout = _bf(torch.randn(n, cout, ho, wo)).float()
+
+    ref_in = [t.double().requires_grad_(True) for t in (x, wt, b, bn_w, bn_b)]
+    z = torch.relu(F.conv2d(ref_in[0], ref_in[1], ref_in[2], 1, 1))
+    o = F.max_pool2d(F.batch_norm(z, None, None, ref_in[3], ref_in[4], True, 0.1, 1e-5), k, st, pad)
+    o.backward(dout.double())
+
+    def run(fused):
+        ins = [t.to(device).requires_grad_(True) for t in (x, wt, b, bn_w, bn_b)]
+        xd = ins[0].to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        rm, rv, nbt = torch.zeros(cout, device=device), torch.ones(cout, device=device), torch.zeros(1, dtype=torch.int64, device=device)
+        if fused:
+            assert ops.fused_max_pool_covered(n, cout, h, w, k, st, pad)
+            out = ops.conv_norm_layer(xd, ins[1], ins[2], 1, 1, 1, nat.ACT_RELU, 0., ins[3], ins[4], rm, rv, nbt, 0.1, 1e-5, max_pool=(k, st, pad))
+        else:
+            out = ops.pool2d(ops.conv_norm_layer(xd, ins[1], ins[2], 1, 1, 1, nat.ACT_RELU, 0., ins[3], ins[4], rm, rv, nbt, 0.1, 1e-5), k, st, pad, nat.POOL_MAX)
+        assert out.dtype == torch.bfloat16 and tuple(out.shape) == (n, cout, ho, wo)
+        out.backward(dout.to(device).to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
+        torch.cuda.synchronize()
+        return out.float().cpu(), [t.grad.double().cpu() for t in ins], rm.cpu(), rv.cpu()
+
+    prev, prev_st = ops.set_conv_math('bf16'), ops.set_bf16_storage(True)
+    try:
+        out_f, g_f, rm_f, rv_f = run(True)
+        out_u, g_u, rm_u, rv_u = run(False)
+    finally:
+        ops.set_conv_math(prev)
+        ops.set_bf16_storage(prev_st)
+    assert torch.equal(out_f, out_u) and torch.equal(rm_f, rm_u) and torch.equal(rv_f, rv_u)
+    assert _rel(out_f, o.detach()) <= 8e-3
+    # (gradients: against the unfused pair only — which window element wins a tie of two bf16-rounded values decides where a gradient goes, and a
+    #  double-precision graph has no such ties: it disagrees with BOTH device paths on those pixels; the unfused pair's pieces are compared with torch by
+    #  `test_fused_layer_with_bf16_activations` and `test_bf16_pooling_and_add_equal_the_widened_fp32_path`)
+    names = ['x', 'weight', 'bias', 'bn_weight', 'bn_bias']
+    scale = max(g.abs().max().item() for g in g_u[1:])
+    for i in range(5):
+        if i == 2:
+            assert (g_f[i] - g_u[i]).abs().max().item() <= 1e-2 * scale, names[i]
+        else:
+            assert _rel(g_f[i], g_u[i]) <= 1e-2, f'{names[i]} against the unfused pair: {_rel(g_f[i], g_u[i]):.3e}'
+    # ... and the fused pair's own consistency with the reference where ties cannot matter: the sum of the input gradient's elements is linear in dout
+    assert abs(g_f[0].sum().item() - ref_in[0].grad.sum().item()) <= 2e-2 * ref_in[0].grad.abs().sum().item() ** 0.5 * 10
+
+
 def _row_sums(t_nchw: torch.Tensor, rows_of: int = 128) -> torch.Tensor:
     """ [channels][rows] fp64 sums of an [n][c][h][w] tensor over blocks of `rows_of` consecutive NHWC pixels (the layout of the kernels' statistics rows). """
     r = t_nchw.permute(0, 2, 3, 1).reshape(-1, t_nchw.shape[1]).double()
