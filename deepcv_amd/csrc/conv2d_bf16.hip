@@ -220,6 +220,166 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(Bf16Args a, const u16
     }
 }
 
+// ------------------------------------------------------------------------------------------------ round 4: SHORT K (at most four K steps) — the filter in registers
+// conv_bf16_kernel above on a layer whose whole reduction is one to four K steps (the folded first layer of a ResNet: four tap rows of 64; a CIFAR first layer as
+// im2col + 1x1: one) is all prologue and epilogue: a block lives for four dependent memory round trips and an epilogue, 10 us for 64 MFMAs per wave — 683 us for the
+// stem of resnet18_style at 512 images (217 MB in, 822 MB out).  Here the block's 64 output channels x <= 256 reduction values are MFMA B fragments in REGISTERS
+// (<= 128 per lane), the blocks are persistent (two per CU), and the 128-pixel x 64-value A tiles of consecutive K steps — of consecutive tiles — flow through a
+// ring of four LDS stages requested three steps ahead: no filter traffic, no pipeline restart between tiles, an epilogue every nk steps.
+// Same A image (rows of 128 bytes, slot ^ ((row >> 1) & 7)), tap masks, epilogue and statistics rows (one per 128-pixel tile) as conv_bf16_kernel<4, 1>.
+#define RFK_STAGES 4
+__device__ __forceinline__ void rfk_wait(int n) {                   // s_waitcnt vmcnt(n) for n = 8 + 8 e, e = tile epilogues (8 stores each) among the last three steps
+    switch (n) {
+        case 8: __builtin_amdgcn_s_waitcnt(0x0F78); break; case 16: __builtin_amdgcn_s_waitcnt(0x4F70); break;
+        case 24: __builtin_amdgcn_s_waitcnt(0x4F78); break; case 32: __builtin_amdgcn_s_waitcnt(0x8F70); break;
+        default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+    }
+}
+template <int ACT>                                                // the activation at compile time (-1: the descriptor's, a five-way switch around each of a lane's 32 results per tile)
+__global__ __launch_bounds__(256, 2) void conv_bf16_rfk_kernel(Bf16Args a, const u16* __restrict__ x, const u16* __restrict__ wb, const float* __restrict__ bias,
+                                                                u16* __restrict__ yv, double* __restrict__ stats) {
+    constexpr int TI = 2, PA = 4, A_BYTES = BF_BM * 128;
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int n0 = blockIdx.y * 64;
+    const int cchunks = a.Cin / BF_BK, taps = a.R * a.S, nk = taps * cchunks;      // 1 .. 4
+    const int ntiles = (int)((a.M + BF_BM - 1) / BF_BM), gstep = (int)gridDim.x;
+    const int my_tiles = (int)blockIdx.x < ntiles ? (ntiles - (int)blockIdx.x + gstep - 1) / gstep : 0, total = my_tiles * nk;
+    const unsigned long long xa = (unsigned long long)x;
+    const bw_i32x4 rx = {(int)(unsigned)xa, (int)(unsigned)((xa >> 32) & 0xFFFFu), (int)a.x_bytes, 0x00020000};
+    const unsigned lds0 = (unsigned)(size_t)lds + (unsigned)((t & ~63) * 16);
+
+    // ---- the filter: B fragment (step, K half ks, channel tile j) of lane (li, lg) = channel n0 + 4 li + j, reduction values 32 ks + 8 lg .. + 7 of step (tap, chunk)
+    bf16x8 fb[4][2][4];
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx) {
+        const int tap = sidx / cchunks, chunk = sidx - tap * cchunks;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                fb[sidx][ks][j] = *reinterpret_cast<const bf16x8*>(wb + (sidx < nk ? ((size_t)(tap * a.Cout + n0 + 4 * li + j) * a.Cin + chunk * 64 + 32 * ks + 8 * lg) : 0));
+    }
+    // ---- staging of a tile's A pieces (as conv_bf16_kernel): piece p = LDS row 32 p + (t >> 3), physical slot t & 7 holds logical slot (t & 7) ^ ((t >> 4) & 7)
+    const int lslot = (t & 7) ^ ((t >> 4) & 7);
+    int offa[PA]; unsigned mka[PA];                                 // of the tile the NEXT request belongs to (taps <= 16: a 32-bit mask)
+    auto decode = [&](int tile) __attribute__((always_inline)) {
+        const long m0 = (long)tile * BF_BM;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const long m = m0 + 32 * p + (t >> 3);
+            const bool ok = m < a.M;
+            const unsigned um = (unsigned)(ok ? m : 0), r1 = __umulhi(um, a.magic_w), nn = __umulhi(r1, a.magic_h);
+            const int wo = (int)(um - r1 * (unsigned)a.Wout), ho = (int)(r1 - nn * (unsigned)a.Hout), n = (int)nn;
+            const int hi0 = ho * a.sh - a.ph, wi0 = wo * a.sw - a.pw;
+            offa[p] = (((n * a.Hin + hi0) * a.Win + wi0) * a.pix) * 2 + lslot * 16;
+            unsigned mk = 0u;
+            if (ok)
+                for (int r = 0; r < a.R; ++r) {
+                    const int hi = hi0 + r * a.dh;
+                    for (int sx = 0; sx < a.S; ++sx) {
+                        const int wi = wi0 + sx * a.dw;
+                        if (hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win) mk |= 1u << (r * a.S + sx);
+                    }
+                }
+            mka[p] = mk;
+        }
+    };
+    int l_g = 0, l_ts = 0, l_tile = blockIdx.x;                    // the next step to REQUEST: global index, step of its tile, its tile
+    auto request = [&]() __attribute__((always_inline)) {
+        if (l_ts == 0) decode(l_tile);
+        const int tap = l_ts / cchunks, chunk = l_ts - tap * cchunks, r = tap / a.S, sx = tap - r * a.S;
+        const int ua = ((r * a.dh) * a.Win + sx * a.dw) * a.pix * 2 + chunk * 128;
+        const unsigned base = lds0 + (unsigned)((l_g % RFK_STAGES) * A_BYTES);
+#pragma unroll
+        for (int p = 0; p < PA; ++p)
+            bw_dma16(rx, base + (unsigned)(p * 4096), ((mka[p] >> tap) & 1u) ? (unsigned)(offa[p] + ua) : BF_OOB, 0u);      // (inline assembly: the compiler does not wait for it in front of LDS reads)
+        ++l_g;
+        if (++l_ts == nk) { l_ts = 0; l_tile += gstep; }
+    };
+    f32x4 acc[TI][4];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int swz = (li >> 1) & 7;
+    const int a_row0 = (16 * TI * wave + li) * 128;
+    const int s0 = ((0 + lg) ^ swz) * 16, s1 = ((4 + lg) ^ swz) * 16;
+    const int cbase = n0 + 4 * li;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) { const float4 b4 = *reinterpret_cast<const float4*>(bias + cbase); bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w; }
+    double* red = reinterpret_cast<double*>(lds + RFK_STAGES * A_BYTES);      // [4 waves][2][64]
+
+    for (int k = 0; k < 3; ++k) if (l_g < total) request();
+    int tile = blockIdx.x, ts = 0, ends = 0;                        // ends: bit e set = the step e + 1 iterations ago closed a tile (its 8 stores are younger than this step's request)
+    for (int g = 0; g < total; ++g) {
+        if (g + 2 < total) rfk_wait(8 + 8 * __builtin_popcount(ends & 7));
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                           // everybody's pieces of step g have landed; every wave is done with the stage of step g - 1
+        if (l_g < total) request();                                // step g + 3 into the stage of step g - 1
+        const char* sb = lds + (g % RFK_STAGES) * A_BYTES;
+        bf16x8 af[2][TI];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < TI; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(sb + a_row0 + i * 2048 + (ks ? s1 : s0));
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx)
+            if (sidx == ts) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < TI; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], fb[sidx][ks][j], acc[i][j], 0, 0, 0);
+            }
+        ends <<= 1;
+        if (++ts < nk) continue;
+        // ---- the tile's epilogue (conv_bf16_kernel's): acc[i][j][reg] -> pixel m0 + 32 wave + 16 i + 4 lg + reg, channel cbase + j
+        ts = 0; ends |= 1;
+        const long m0 = (long)tile * BF_BM;
+        float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const long m = m0 + 16 * TI * wave + 16 * i + 4 * lg + reg;
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[j] = dcv_act_apply(acc[i][j][reg] + bv[j], ACT >= 0 ? ACT : a.act, a.slope);
+                    if (m < a.M) { ssum[j] += o[j]; ssq[j] += o[j] * o[j]; }
+                }
+                // (the counted waits above assume eight stores per tile and lane: stores are only skipped in the tensor's last tile, which is its block's last)
+                if (m < a.M) *reinterpret_cast<bf16x4*>(yv + (size_t)m * a.Cout + cbase) = (bf16x4){(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+            }
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (stats != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float s1v = ssum[j], s2v = ssq[j];
+                s1v += __shfl_xor(s1v, 16, 64); s2v += __shfl_xor(s2v, 16, 64);
+                s1v += __shfl_xor(s1v, 32, 64); s2v += __shfl_xor(s2v, 32, 64);
+                if (lg == 0) { red[(wave * 2 + 0) * 64 + 4 * li + j] = (double)s1v; red[(wave * 2 + 1) * 64 + 4 * li + j] = (double)s2v; }
+            }
+            __syncthreads();
+            if (t < 128) {
+                const int q = t >> 6, c = t & 63;
+                double v = 0.0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) v += red[(w * 2 + q) * 64 + c];
+                stats[((size_t)q * a.Cout + n0 + c) * (a.stat_rows ? a.stat_rows : ntiles) + a.stat_row0 + tile] = v;      // [2][Cout][rows]
+            }
+            // (the next write of `red` is a whole tile — at least one barrier — away)
+        }
+        tile += gstep;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ 3x3 / stride 1 / pad 1: the input window staged once for all nine taps
 // conv_bf16_kernel above re-stages its 128-pixel x tile for every K step — nine times per pixel for a 3x3 layer — and keeps the matrix pipe busy 20 % of the
 // time on cifar100_deep (profiles/r03_pmc_cifar100_deep_bf16.json): it is bound by the bytes it moves into LDS (24 - 32 KB per K step of 16 - 32 us of MFMAs per
@@ -1777,6 +1937,30 @@ int launch(const Bf16Args& a0, const u16* x, const u16* wb, const float* bias, v
         }
     }
     if (mom != nullptr) return DCV_ERR_UNSUPPORTED;                  // (only the window kernel has the moments epilogue)
+    if constexpr (OUT_BF16) {
+        // at most four K steps: the filter-in-registers kernel (DCV_BF16_RFK=0: off)
+        static int rfk = -1;
+        if (rfk < 0) { const char* e = getenv("DCV_BF16_RFK"); rfk = e ? atoi(e) : 1; }
+        const int nk = a.R * a.S * (a.Cin / BF_BK);
+        if (rfk && nk <= 4 && a.R * a.S <= 16 && !a.phase && small && a.M < ((long)1 << 31) && a.Cout % 64 == 0) {
+            static bool kconf = false;
+            const size_t ks = (size_t)RFK_STAGES * BF_BM * 128 + 4096;
+            if (!kconf) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_rfk_kernel<DCV_ACT_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ks) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_rfk_kernel<DCV_ACT_RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ks) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_rfk_kernel<-1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ks) != hipSuccess) return DCV_ERR_LAUNCH;
+                kconf = true;
+            }
+            const unsigned gy = (unsigned)(a.Cout / 64), ntl = (unsigned)dcv_ceil_div((size_t)a.M, BF_BM);
+            unsigned gx = 2 * DCV_NUM_CU / gy; if (gx < 1) gx = 1; if (gx > ntl) gx = ntl;
+            if (gy > 65535) return DCV_ERR_UNSUPPORTED;
+            dcv_count_launch(DCV_FAMILY_BF16_IGEMM);
+            if (a.act == DCV_ACT_NONE) hipLaunchKernelGGL((conv_bf16_rfk_kernel<DCV_ACT_NONE>), dim3(gx, gy), dim3(256), ks, st, a, x, wb, bias, reinterpret_cast<u16*>(y), stats);
+            else if (a.act == DCV_ACT_RELU) hipLaunchKernelGGL((conv_bf16_rfk_kernel<DCV_ACT_RELU>), dim3(gx, gy), dim3(256), ks, st, a, x, wb, bias, reinterpret_cast<u16*>(y), stats);
+            else hipLaunchKernelGGL((conv_bf16_rfk_kernel<-1>), dim3(gx, gy), dim3(256), ks, st, a, x, wb, bias, reinterpret_cast<u16*>(y), stats);
+            return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
+        }
+    }
     const size_t smem = wide ? (size_t)2 * (BF_BM + 128) * 128 : (size_t)2 * (BF_BM + 64) * 128;
     dim3 grid((unsigned)dcv_ceil_div((size_t)a.M, BF_BM), (unsigned)(a.Cout / (wide ? 128 : 64)));
     if (grid.y > 65535) return DCV_ERR_UNSUPPORTED;

@@ -397,6 +397,17 @@ def test_first_layer_as_im2col_plus_one_tap_kernels(device, case, nchw):
     ref = F.conv2d(_bf(x).double(), _bf(wt).double(), None, stride, pad, dil)
     torch.cuda.synchronize()
     assert _rel(y, ref) <= 2e-5
+    # bf16 output with the statistics epilogue and a bias (one to three K steps: the filter-in-registers kernel, `conv_bf16_rfk_kernel`)
+    bias = torch.randn(cout, device=device)
+    y32 = torch.empty_like(y)
+    rows = (n * d.ho * d.wo + 127) // 128
+    st32 = torch.zeros((2, cout, rows), dtype=torch.float64, device=device)
+    nat.check(lib.dcv_conv2d_bf16_fwd(d1, col.data_ptr(), f.data_ptr(), bias.data_ptr(), y32.data_ptr(), nat.DTYPE_F32, st32.data_ptr(), st), 'fwd')
+    y16 = torch.full((n, cout, d.ho, d.wo), float('nan'), dtype=torch.bfloat16, device=device).contiguous(memory_format=torch.channels_last)
+    st16 = torch.full((2, cout, rows), float('nan'), dtype=torch.float64, device=device)
+    nat.check(lib.dcv_conv2d_bf16_fwd(d1, col.data_ptr(), f.data_ptr(), bias.data_ptr(), y16.data_ptr(), nat.DTYPE_BF16, st16.data_ptr(), st), 'fwd bf16')
+    torch.cuda.synchronize()
+    assert torch.equal(y16.float(), y32.to(torch.bfloat16).float()) and _rel(st16, st32) <= 1e-6
     dy = _bf(torch.randn(n, cout, d.ho, d.wo)).contiguous(memory_format=torch.channels_last)
     ws = torch.empty(int(lib.dcv_conv2d_bf16_wgrad_workspace_bytes(d1)), dtype=torch.uint8, device=device)
     dw = torch.full((cout, kpad), float('nan'), device=device)
@@ -461,6 +472,12 @@ def test_strided_first_layer_as_space_to_depth_plus_folded_rows(device, case, nc
     torch.cuda.synchronize()
     assert _rel(y, ref) <= 2e-5
     assert (stats[0].sum(1).cpu() - ref.sum((0, 2, 3))).abs().max().item() <= 1e-4 * ref.abs().sum((0, 2, 3)).max().item()
+    # bf16 output (what the storage path asks for): four K steps — the filter-in-registers kernel (`conv_bf16_rfk_kernel`); same accumulation order, one rounding
+    y16 = torch.full((n, cout, d.ho, d.wo), float('nan'), dtype=torch.bfloat16, device=device).contiguous(memory_format=torch.channels_last)
+    stats16 = torch.full((2, cout, stats_rows), float('nan'), dtype=torch.float64, device=device)
+    nat.check(lib.dcv_conv2d_bf16_fwd(d2, xs.data_ptr(), f.data_ptr(), None, y16.data_ptr(), nat.DTYPE_BF16, stats16.data_ptr(), st), 'fwd bf16')
+    torch.cuda.synchronize()
+    assert torch.equal(y16.float(), y.to(torch.bfloat16).float()) and _rel(stats16, stats) <= 1e-6
     dy = _bf(torch.randn(n, cout, d.ho, d.wo)).contiguous(memory_format=torch.channels_last)
     wsb = torch.empty(int(lib.dcv_conv2d_bf16_wgrad_workspace_bytes(d2)), dtype=torch.uint8, device=device)
     dw2 = torch.full((cout, 16, a, a), float('nan'), device=device)
