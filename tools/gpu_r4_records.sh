@@ -28,7 +28,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv 
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/w -o w -- $CMD > $O/w.log 2>&1 || { tail -5 $O/w.log; exit 1; }
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/m -o m -- $CMD > $O/m.log 2>&1 || { tail -5 $O/m.log; exit 1; }
 python3 $R/tools/pmc_kernels.py $O/r04_pmc_cifar100_deep_bf16.json r04 $C "rocprofv3 --kernel-trace --pmc <FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES> -- python3 tools/wide_bench.py cifar100_deep_model 512 6 eager,bf16 (separate passes)" \
-  $O/f $O/w $O/m nc_apply_kernel nc_bwd_apply_kernel nc_sample_sums_kernel conv_bf16_halo_kernel conv_bf16_kernel conv_bf16_wgrad9p_kernel conv_bf16_wgrad9_kernel im2col_bf16_kernel prep_bf16_tile_kernel mfma_wgrad9_reduce > $O/summary.txt || { tail -5 $O/summary.txt; exit 1; }
+  $O/f $O/w $O/m nc_apply_kernel nc_bwd_apply_kernel nc_sample_sums_kernel conv_bf16_halo_kernel conv_bf16_halo_rf_kernel conv_bf16_kernel conv_bf16_rfk_kernel conv_bf16_wgrad9p_kernel conv_bf16_wgradg_kernel im2col_bf16_kernel prep_bf16_tile_kernel mfma_wgrad9_reduce > $O/summary.txt || { tail -5 $O/summary.txt; exit 1; }
 python3 -c "import json; r=json.load(open('$O/r04_pmc_cifar100_deep_bf16.json')); [print(k, v.get('avg_duration_us'), v.get('hbm_frac_of_8TBps'), v.get('mfma_busy_frac_of_simd_cycles')) for k, v in r['kernels'].items()]"
 rm -rf $O/f $O/w $O/m
 echo "--- PMC, bf16 entry points at the bench shapes"
