@@ -520,9 +520,16 @@ def main():
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     last = None
+    stamps = [] if os.environ.get('DCV_BENCH_STEP_TIMES') else None      # diagnostics: when each step's loss reached the host (stderr; a list append per step)
     for _ in range(args.steps):
         last = one_step(it); it += 1
+        if stamps is not None:
+            stamps.append(time.perf_counter())
     torch.cuda.synchronize(device)
+    if stamps is not None:
+        t_sync = time.perf_counter()
+        print('step times (us, loss-to-loss): first ' + f'{(stamps[0] - t0) * 1e6:.0f}, ' + ' '.join(f'{(b - a) * 1e6:.0f}' for a, b in zip(stamps, stamps[1:])) +
+              f'; final synchronize {(t_sync - stamps[-1]) * 1e6:.0f}', file=sys.stderr)
     if use_dp:
         dist.barrier()
     torch.cuda.synchronize(device)
