@@ -228,10 +228,15 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(Bf16Args a, const u16
 // ring of four LDS stages requested three steps ahead: no filter traffic, no pipeline restart between tiles, an epilogue every nk steps.
 // Same A image (rows of 128 bytes, slot ^ ((row >> 1) & 7)), tap masks, epilogue and statistics rows (one per 128-pixel tile) as conv_bf16_kernel<4, 1>.
 #define RFK_STAGES 4
+// s_waitcnt vmcnt(n) (expcnt / lgkmcnt untouched) as its immediate: vmcnt = n[3:0] | n[5:4] << 14
+#define DCV_VMCNT(n) (0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
 __device__ __forceinline__ void rfk_wait(int n) {                   // s_waitcnt vmcnt(n) for n = 8 + 8 e, e = tile epilogues (8 stores each) among the last three steps
+    // (exactly the number of younger operations: one too few and the wave waits for the FIRST STORE of the previous tile's epilogue — a trip to memory per tile)
     switch (n) {
-        case 8: __builtin_amdgcn_s_waitcnt(0x0F78); break; case 16: __builtin_amdgcn_s_waitcnt(0x4F70); break;
-        case 24: __builtin_amdgcn_s_waitcnt(0x4F78); break; case 32: __builtin_amdgcn_s_waitcnt(0x8F70); break;
+        case 8: __builtin_amdgcn_s_waitcnt(DCV_VMCNT(8)); break; case 16: __builtin_amdgcn_s_waitcnt(DCV_VMCNT(16)); break;
+        case 24: __builtin_amdgcn_s_waitcnt(DCV_VMCNT(24)); break; case 32: __builtin_amdgcn_s_waitcnt(DCV_VMCNT(32)); break;
+        case 17: __builtin_amdgcn_s_waitcnt(DCV_VMCNT(17)); break; case 26: __builtin_amdgcn_s_waitcnt(DCV_VMCNT(26)); break;
+        case 35: __builtin_amdgcn_s_waitcnt(DCV_VMCNT(35)); break;
         default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
     }
 }
@@ -312,9 +317,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_rfk_kernel(Bf16Args a, const
     double* red = reinterpret_cast<double*>(lds + RFK_STAGES * A_BYTES);      // [4 waves][2][64]
 
     for (int k = 0; k < 3; ++k) if (l_g < total) request();
+    const int xst = (stats != nullptr && t < 128) ? 1 : 0;           // this wave's statistics store behind a tile's eight
     int tile = blockIdx.x, ts = 0, ends = 0;                        // ends: bit e set = the step e + 1 iterations ago closed a tile (its 8 stores are younger than this step's request)
     for (int g = 0; g < total; ++g) {
-        if (g + 2 < total) rfk_wait(8 + 8 * __builtin_popcount(ends & 7));
+        if (g + 2 < total) rfk_wait(8 + (8 + xst) * __builtin_popcount(ends & 7));
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                           // everybody's pieces of step g have landed; every wave is done with the stage of step g - 1
         if (l_g < total) request();                                // step g + 3 into the stage of step g - 1
@@ -378,6 +384,161 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_rfk_kernel(Bf16Args a, const
         }
         tile += gstep;
     }
+}
+
+// ------------------------------------------------------------------------------------------------ round 4: the FOLDED first layer on a window staged once
+// conv_bf16_rfk_kernel above requests, for every 128-pixel tile of the folded stem, four A tiles of 128 rows x 128 bytes — sixteen LDS-DMA instructions per wave
+// for 64 MFMAs, and the ISSUE of those requests (60 - 185 clocks each) sets its time: 403 us of the 690 with every request answered with zeros.  But the rows
+// overlap (pixel stride 32 bytes under 128-byte rows): the tile's whole input is its 128 pixels + R - 1 rows of the tensor = ~490 pixels of 32 bytes = 16 KB,
+// four requests per wave, and a K step's A fragment is 16 pixels x 64 consecutive bytes of it — lane (li, lg) reads bytes 16 lg .. + 15 behind pixel li, pixels
+// 32 bytes apart, which the 16-lane groups of ds_read_b128 serve without bank conflicts (34 distinct 16-byte slots, no two of a group 256 bytes apart).
+// Filter in registers (R x 64 x 64 values: 32 R per lane), persistent blocks (two per CU), two window buffers, tiles of 128 output pixels of ONE image (the
+// statistics rows' granularity; the pixel count of an image must be a multiple of 128), epilogue of conv_bf16_rfk_kernel.
+#define BFW_MAX_PX 1024                                              // pixels of a window buffer (32 KB at 16 channels)
+template <int ACT>
+__global__ __launch_bounds__(256, 2) void conv_bf16_foldwin_kernel(Bf16Args a, const u16* __restrict__ x, const u16* __restrict__ wb, const float* __restrict__ bias,
+                                                                    u16* __restrict__ yv, double* __restrict__ stats, int win_px) {
+    constexpr int TI = 2;
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int n0 = blockIdx.y * 64;
+    const int PB = a.pix * 2;                                       // bytes per pixel of the tensor (32)
+    const int ntiles = (int)(a.M / BF_BM), gstep = (int)gridDim.x, tpi = a.Hout * a.Wout / BF_BM;      // tiles per image
+    const unsigned long long xa = (unsigned long long)x;
+    const bw_i32x4 rx = {(int)(unsigned)xa, (int)(unsigned)((xa >> 32) & 0xFFFFu), (int)a.x_bytes, 0x00020000};
+    const unsigned lds0 = (unsigned)(size_t)lds + (unsigned)(t * 16);
+    const int wbuf_bytes = win_px * PB;
+    // ---- the filter: B fragment (tap row r, K half ks, channel tile j) of lane (li, lg) = channel n0 + 4 li + j, values 32 ks + 8 lg .. + 7 of [r][Cout][64]
+    bf16x8 fb[4][2][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                fb[r][ks][j] = *reinterpret_cast<const bf16x8*>(wb + (r < a.R ? ((size_t)(r * a.Cout + n0 + 4 * li + j) * 64 + 32 * ks + 8 * lg) : 0));
+    // the window of tile `tile`: pixels [q0, q0 + win_px) of the flat tensor, q0 = the tile's first output pixel as an input pixel (stride 1: same row, same column)
+    auto tile_q0 = [&](int tile) { const int n = tile / tpi, p0 = (tile - n * tpi) * BF_BM, ho = p0 / a.Wout, wo = p0 - ho * a.Wout; return (n * a.Hin + ho * a.sh) * a.Win + wo * a.sw; };
+    auto request = [&](int buf, int tile) {
+        const unsigned base = (unsigned)(tile_q0(tile) * PB) + (unsigned)(t * 16);
+        for (int k = 0; k * 4096 < wbuf_bytes; ++k) bw_dma16(rx, lds0 + (unsigned)(buf * wbuf_bytes + k * 4096), base + (unsigned)(k * 4096), 0u);
+    };
+    f32x4 acc[TI][4];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int cbase = n0 + 4 * li;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) { const float4 b4 = *reinterpret_cast<const float4*>(bias + cbase); bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w; }
+    double* red = reinterpret_cast<double*>(lds + 2 * wbuf_bytes);   // [2 slots][4 waves][2][64]
+    const int nreq = (wbuf_bytes + 4095) / 4096;                     // requests per thread and window
+
+    int pend_tile = -1, pend_par = 0;                              // a tile whose statistics partials wait in red[pend_par] for the next barrier
+    bool row_stored = false;                                       // ... and whether the previous iteration stored such a row (one more store younger than this tile's window)
+    bool have_out = false;                                         // a tile before this one has stored its output
+    auto stats_row = [&](int tl, int pr) {
+        if (t < 128) {
+            const int q = t >> 6, c = t & 63;
+            const double* rk = red + pr * 512;
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += rk[(w * 2 + q) * 64 + c];
+            stats[((size_t)q * a.Cout + n0 + c) * (a.stat_rows ? a.stat_rows : ntiles) + a.stat_row0 + tl] = v;      // [2][Cout][rows]
+        }
+    };
+    int tile = blockIdx.x, par = 0;
+    if (tile < ntiles) request(0, tile);
+    for (; tile < ntiles; tile += gstep, par ^= 1) {
+        // exactly the operations younger than this tile's window request (rfk_wait): the previous tile's four 16-byte stores and, on two waves, the statistics
+        // row which the previous iteration stored (of the tile before it)
+        {
+            const int young = (have_out ? 4 : 0) + ((row_stored && t < 128) ? 1 : 0);
+            if (young == 5) __builtin_amdgcn_s_waitcnt(DCV_VMCNT(5)); else if (young == 4) __builtin_amdgcn_s_waitcnt(DCV_VMCNT(4)); else __builtin_amdgcn_s_waitcnt(0x0F70);
+        }
+        __syncthreads();                                           // everybody's pieces have landed; every wave is done with the other buffer
+        if (tile + gstep < ntiles) request(par ^ 1, tile + gstep);
+        row_stored = pend_tile >= 0;
+        if (row_stored) { stats_row(pend_tile, pend_par); pend_tile = -1; }
+        // operand addresses: tile row i of this wave = output pixel pl = 32 wave + 16 i + li of the tile -> input pixel q - q0 (its row and column in the image)
+        const int nimg = tile / tpi, p0 = (tile - nimg * tpi) * BF_BM, ho0 = p0 / a.Wout, wo0 = p0 - ho0 * a.Wout;
+        unsigned arow[TI];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int pl = 32 * wave + 16 * i + li, u = wo0 + pl, dh = u / a.Wout, wo = u - dh * a.Wout;
+            arow[i] = (unsigned)(par * wbuf_bytes + ((dh * a.sh * a.Win + wo * a.sw) - wo0 * a.sw) * PB + lg * 16);
+        }
+        const char* lb = lds;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (r < a.R) {
+                const unsigned roff = (unsigned)(r * a.dh * a.Win * PB);
+                bf16x8 af[2][TI];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < TI; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(lb + arow[i] + roff + ks * 64);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < TI; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], fb[r][ks][j], acc[i][j], 0, 0, 0);
+            }
+        }
+        // ---- epilogue: acc[i][j][reg] -> pixel m0 + 32 wave + 16 i + 4 lg + reg, channel cbase + j.  The phase-skip builds (tools/variants/foldwin.py: 476 us; 218
+        // without this epilogue, 347 without its stores, 396 without the statistics row) say the layer's 822 MB of output are what it waits for: neighbouring lanes
+        // swap halves (DPP) so that a lane stores two pixels x 8 channels as 16 bytes, and the waves' statistics partials wait in a second LDS slot for the NEXT
+        // tile's opening barrier instead of a barrier of their own (together 476 -> 459 us; stores spread over the next tile's taps: 491, a start skew between
+        // the two blocks of a CU: no effect).
+        const long m0 = (long)tile * BF_BM;
+        float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool odd = (li & 1) != 0;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            unsigned pk[4][2];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[j] = dcv_act_apply(acc[i][j][reg] + bv[j], ACT >= 0 ? ACT : a.act, a.slope);
+                    ssum[j] += o[j]; ssq[j] += o[j] * o[j];
+                }
+                union { bf16x4 h; unsigned u[2]; } cv; cv.h = (bf16x4){(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+                pk[reg][0] = cv.u[0]; pk[reg][1] = cv.u[1];
+            }
+            // even lanes keep pixels reg 0, 1 and take the odd neighbour's four channels of them; odd lanes keep reg 2, 3
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const unsigned s0 = odd ? pk[q][0] : pk[q + 2][0], s1 = odd ? pk[q][1] : pk[q + 2][1];
+                const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xF, 0xF, false), r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xF, 0xF, false);
+                const int reg = odd ? q + 2 : q;
+                const long m = m0 + 16 * TI * wave + 16 * i + 4 * lg + reg;
+                const uint4 v = odd ? make_uint4(r0, r1, pk[q + 2][0], pk[q + 2][1]) : make_uint4(pk[q][0], pk[q][1], r0, r1);
+                *reinterpret_cast<uint4*>(yv + (size_t)m * a.Cout + n0 + 8 * (li >> 1)) = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        have_out = true;
+        if (stats != nullptr) {
+            double* rk = red + (par * 512);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float s1v = ssum[j], s2v = ssq[j];
+                s1v += __shfl_xor(s1v, 16, 64); s2v += __shfl_xor(s2v, 16, 64);
+                s1v += __shfl_xor(s1v, 32, 64); s2v += __shfl_xor(s2v, 32, 64);
+                if (lg == 0) { rk[(wave * 2 + 0) * 64 + 4 * li + j] = (double)s1v; rk[(wave * 2 + 1) * 64 + 4 * li + j] = (double)s2v; }
+            }
+            pend_tile = tile; pend_par = par;
+        }
+    }
+    if (pend_tile >= 0) { __syncthreads(); stats_row(pend_tile, pend_par); }
+    (void)nreq;
 }
 
 // ------------------------------------------------------------------------------------------------ 3x3 / stride 1 / pad 1: the input window staged once for all nine taps
@@ -845,7 +1006,8 @@ __global__ __launch_bounds__(256, 1) void conv_bf16_halo_rf_kernel(Bf16Args a, c
     bool first = true;
     for (; tile < ntiles; tile += gstep, m0 += gstep * BMH, par ^= 1) {
         // this tile's window was requested a tile ago; younger than it: the previous tile's 16 stores
-        if (first) __builtin_amdgcn_s_waitcnt(0x0F70); else __builtin_amdgcn_s_waitcnt(0x4F70);      // vmcnt(0) / vmcnt(16)
+        // (exactly the younger operations — 16 stores, and the statistics store when there is one: one too few waits for the first store's trip to memory)
+        if (first) __builtin_amdgcn_s_waitcnt(0x0F70); else if (stats != nullptr) __builtin_amdgcn_s_waitcnt(DCV_VMCNT(17)); else __builtin_amdgcn_s_waitcnt(DCV_VMCNT(16));
         __syncthreads();                                           // everybody's pieces have landed; every wave is done with the other buffer (its taps, its statistics scratch)
         // the next tile's window: its 32-row pieces are requested one or two per tap (an LDS-DMA instruction costs its wave 60 - 185 issue clocks: ten to twelve in a
         // row were half a microsecond in front of every tile's first MFMA)
@@ -1938,6 +2100,33 @@ int launch(const Bf16Args& a0, const u16* x, const u16* wb, const float* bias, v
     }
     if (mom != nullptr) return DCV_ERR_UNSUPPORTED;                  // (only the window kernel has the moments epilogue)
     if constexpr (OUT_BF16) {
+        // a folded first layer (pixel stride below 64 values) on a window staged once per tile (DCV_BF16_FOLDWIN=0: off)
+        static int fwin = -1;
+        if (fwin < 0) { const char* e = getenv("DCV_BF16_FOLDWIN"); fwin = e ? atoi(e) : 1; }
+        const int hw1 = a.Hout * a.Wout;
+        // (the tile's pixels + R - 1 rows of the tensor + the 3 extra pixels of a row's last tap + the row ends a tile crosses)
+        const int need_px = (BF_BM / a.Wout + 2) * a.sh * a.Win + (a.R - 1) * a.dh * a.Win + (64 / a.pix) + a.sw * a.Wout;
+        const int win_px = (need_px + 127) / 128 * 128;
+        if (fwin && a.pix < 64 && a.Cin == 64 && a.S == 1 && a.R <= 4 && !a.phase && a.ph == 0 && a.pw == 0 && hw1 % BF_BM == 0 && a.M % BF_BM == 0 && a.Cout % 64 == 0 &&
+            a.M < ((long)1 << 31) && win_px <= BFW_MAX_PX && a.stat_rows == 0) {
+            static bool wconf = false;
+            const size_t ws2 = (size_t)2 * win_px * a.pix * 2 + 8192;
+            if (!wconf) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_foldwin_kernel<DCV_ACT_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_foldwin_kernel<DCV_ACT_RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_foldwin_kernel<-1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DCV_ERR_LAUNCH;
+                wconf = true;
+            }
+            const unsigned gy = (unsigned)(a.Cout / 64), ntl = (unsigned)(a.M / BF_BM);
+            unsigned gx = 2 * DCV_NUM_CU / gy; if (gx < 1) gx = 1; if (gx > ntl) gx = ntl;
+            if (gy > 65535) return DCV_ERR_UNSUPPORTED;
+            dcv_count_launch(DCV_FAMILY_BF16_IGEMM);
+            u16* y16 = reinterpret_cast<u16*>(y);
+            if (a.act == DCV_ACT_NONE) hipLaunchKernelGGL((conv_bf16_foldwin_kernel<DCV_ACT_NONE>), dim3(gx, gy), dim3(256), ws2, st, a, x, wb, bias, y16, stats, win_px);
+            else if (a.act == DCV_ACT_RELU) hipLaunchKernelGGL((conv_bf16_foldwin_kernel<DCV_ACT_RELU>), dim3(gx, gy), dim3(256), ws2, st, a, x, wb, bias, y16, stats, win_px);
+            else hipLaunchKernelGGL((conv_bf16_foldwin_kernel<-1>), dim3(gx, gy), dim3(256), ws2, st, a, x, wb, bias, y16, stats, win_px);
+            return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
+        }
         // at most four K steps: the filter-in-registers kernel (DCV_BF16_RFK=0: off)
         static int rfk = -1;
         if (rfk < 0) { const char* e = getenv("DCV_BF16_RFK"); rfk = e ? atoi(e) : 1; }

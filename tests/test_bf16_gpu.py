@@ -434,8 +434,9 @@ def _s2d_filter(wt, s):
     return F.pad(w, (0, 0, 0, 0, 0, 16 - s * s * cin))
 
 
-@pytest.mark.parametrize('case', [(3, 3, 56, 56, 64, 7, 2, 3), (2, 3, 40, 50, 128, 7, 2, 3), (5, 4, 33, 31, 64, 8, 2, 3), (2, 1, 48, 48, 64, 13, 4, 6)],
-                         ids=['resnet_stem', 'wide128', 'odd_sizes_k8', 'stride4'])
+@pytest.mark.parametrize('case', [(3, 3, 56, 56, 64, 7, 2, 3), (2, 3, 40, 50, 128, 7, 2, 3), (5, 4, 33, 31, 64, 8, 2, 3), (2, 1, 48, 48, 64, 13, 4, 6),
+                                  (5, 3, 64, 64, 128, 7, 2, 3), (3, 3, 96, 32, 64, 7, 2, 3)],
+                         ids=['resnet_stem', 'wide128', 'odd_sizes_k8', 'stride4', 'window_32x32', 'window_48x16'])      # (the last two: 128-aligned maps, bf16 output on `conv_bf16_foldwin_kernel`)
 @pytest.mark.parametrize('nchw', [True, False], ids=['nchw', 'nhwc'])
 def test_strided_first_layer_as_space_to_depth_plus_folded_rows(device, case, nchw):
     """ `dcv_space_to_depth_bf16` + the folded-rows instances of the bf16 kernels (4 x 4 taps over 16 channels read in place as four taps of 64) = a strided
