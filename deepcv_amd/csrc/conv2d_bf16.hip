@@ -862,14 +862,25 @@ __global__ __launch_bounds__(256, 1) void conv_bf16_halo_rf_kernel(Bf16Args a, c
     if (t < 16) *reinterpret_cast<uint4*>(lds + (t >> 3) * BH_WSTRIDE + BH_WROWS * 128 + (t & 7) * 16) = make_uint4(0u, 0u, 0u, 0u);      // the two zero rows
 
     // ---- the filter: B fragment (tap, K half ks, channel tile j) of lane (li, lg) = channel n0 + 4 li + j, input channels 32 ks + 8 lg .. + 7 of [tap][Cout][64]
-    bf16x8 fb[9][2][4];
+    // Taps 0 .. 7: 256 AGPRs.  The ninth tap's eight fragments stay in LDS ([ks][j][lane], 8 KB behind the window buffers; the same for every wave) and are read
+    // while the eighth tap computes: as 32 more vector registers they pushed the MOM instance (moments / addend epilogue) into scratch — 260 us against 149 for
+    // the plain one on 64 -> 64 @56x56.
+    bf16x8 fb[RF_ATAPS][2][4];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+    for (int tap = 0; tap < RF_ATAPS; ++tap)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 fb[tap][ks][j] = *reinterpret_cast<const bf16x8*>(wb + ((size_t)(tap * a.Cout + n0 + 4 * li + j) * 64 + 32 * ks + 8 * lg));
+    bf16x8* const fb8 = reinterpret_cast<bf16x8*>(lds + 2 * BH_WSTRIDE);
+    if (wm == 0) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                fb8[(ks * 4 + j) * 64 + lane] = *reinterpret_cast<const bf16x8*>(wb + ((size_t)(8 * a.Cout + n0 + 4 * li + j) * 64 + 32 * ks + 8 * lg));
+    }
 
     // ---- window staging: piece hp = rows 32 hp + (t >> 3), physical slot t & 7 holds logical slot (t & 7) ^ (row & 6)
     const int lslot_w = (t & 7) ^ ((t >> 3) & 6);
@@ -1013,12 +1024,23 @@ __global__ __launch_bounds__(256, 1) void conv_bf16_halo_rf_kernel(Bf16Args a, c
         // row were half a microsecond in front of every tile's first MFMA)
         const bool more = tile + gstep < ntiles;
         const unsigned nwv = more ? wv_of(m0 + gstep * BMH) : 0u;
+        // MOM: the epilogue reads this tile's rows of yprev / addend (128 bytes per pixel and tensor) four times a tile with nothing to hide a trip to memory
+        // behind (one wave per SIMD; 32 + 32 more registers to prefetch them do not exist): one dword of each row is requested NOW, by the thread of that pixel,
+        // into a register nobody reads — the line waits in L2 when the epilogue asks for it.  (The register stays reserved until the epilogue's loads, younger and
+        // returned in order, have been waited for.)
+        unsigned pf0 = 0u, pf1 = 0u;
+        if constexpr (MOM) {
+            const int mp = m0 + t < (int)a.M ? m0 + t : m0;
+            if (yprev != nullptr) { const u16* q = yprev + (size_t)mp * a.Cout + n0; asm volatile("global_load_dword %0, %1, off" : "=v"(pf0) : "v"(q)); }
+            if (addend != nullptr) { const u16* q = addend + (size_t)mp * a.Cout + n0; asm volatile("global_load_dword %0, %1, off" : "=v"(pf1) : "v"(q)); }
+        }
         if (!first) set_tile(m0);
         first = false;
         asm volatile("" : "+s"(k64));
         const char* wbase = lds + par * BH_WSTRIDE;
 #pragma unroll
         for (int i = 0; i < TI; ++i) fa0[i] = *reinterpret_cast<const bf16x8*>(wbase + aaddr[i][0] + 2048 * i);
+        bf16x8 f8[2][4];                                            // the ninth tap's fragments: requested in front of the eighth tap's second half
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
@@ -1027,20 +1049,27 @@ __global__ __launch_bounds__(256, 1) void conv_bf16_halo_rf_kernel(Bf16Args a, c
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { if (tap < RF_ATAPS) rf_mfma_a(acc[i][j], fa0[i], fb[tap][0][j]); else rf_mfma_v(acc[i][j], fa0[i], fb[tap][0][j]); }
+                for (int j = 0; j < 4; ++j) { if (tap < RF_ATAPS) rf_mfma_a(acc[i][j], fa0[i], fb[tap < RF_ATAPS ? tap : 0][0][j]); else rf_mfma_v(acc[i][j], fa0[i], f8[0][j]); }
             if (tap + 1 < 9) {
 #pragma unroll
                 for (int i = 0; i < TI; ++i) fa0[i] = *reinterpret_cast<const bf16x8*>(wbase + aaddr[i][tap + 1] + 2048 * i);
             }
+            if (tap == RF_ATAPS - 1) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) f8[ks][j] = fb8[(ks * 4 + j) * 64 + lane];
+            }
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { if (tap < RF_ATAPS) rf_mfma_a(acc[i][j], fa1[i], fb[tap][1][j]); else rf_mfma_v(acc[i][j], fa1[i], fb[tap][1][j]); }
+                for (int j = 0; j < 4; ++j) { if (tap < RF_ATAPS) rf_mfma_a(acc[i][j], fa1[i], fb[tap < RF_ATAPS ? tap : 0][1][j]); else rf_mfma_v(acc[i][j], fa1[i], f8[1][j]); }
         }
         rf_mfma_drain();
         if (m0 + BMH <= (int)a.M && a.act == DCV_ACT_NONE) finish_tile(par, std::integral_constant<int, DCV_ACT_NONE>{}, std::true_type{});
         else if (m0 + BMH <= (int)a.M && a.act == DCV_ACT_RELU) finish_tile(par, std::integral_constant<int, DCV_ACT_RELU>{}, std::true_type{});
         else finish_tile(par, std::integral_constant<int, -1>{}, std::false_type{});
+        if constexpr (MOM) asm volatile("" :: "v"(pf0), "v"(pf1));
     }
 }
 
@@ -2062,7 +2091,7 @@ int launch(const Bf16Args& a0, const u16* x, const u16* wb, const float* bias, v
                     static bool rconf[2] = {false, false};
                     const unsigned gy = (unsigned)(a.Cout / 64);
                     unsigned gx = DCV_NUM_CU / gy; if (gx < 1) gx = 1; if (gx > htiles) gx = htiles;
-                    const size_t rs = (size_t)2 * BH_WSTRIDE;
+                    const size_t rs = (size_t)2 * BH_WSTRIDE + 8192;                   // two windows + the ninth tap's fragments
                     dcv_count_launch(DCV_FAMILY_BF16_WINDOW);
                     if (mom != nullptr) {
                         if (!rconf[1]) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_halo_rf_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DCV_ERR_LAUNCH; rconf[1] = true; }
