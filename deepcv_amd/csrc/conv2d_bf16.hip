@@ -837,10 +837,15 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, cons
 // The filter fragments live in the ACCUMULATION registers and the MFMA reads them there (gfx950 takes AGPRs as A / B sources): left to the compiler, B operands are
 // vector registers and the 288 - 256 that do not fit were copied back (v_accvgpr_read) in front of every group of MFMAs — 16 copies + the operand addresses in front
 // of 16 MFMAs on a block with ONE wave per SIMD: a tap took 1200 clocks for 512 of MFMAs.  Inline assembly is opaque to the hazard recogniser: the accumulators are
-// read by vector instructions only behind rf_mfma_drain().
+// read by vector instructions only behind rf_mfma_drain(acc).
 __device__ __forceinline__ void rf_mfma_a(f32x4& c, const bf16x8& av, const bf16x8& b) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(av), "a"(b)); }
 __device__ __forceinline__ void rf_mfma_v(f32x4& c, const bf16x8& av, const bf16x8& b) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(av), "v"(b)); }
-__device__ __forceinline__ void rf_mfma_drain() { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory"); }
+// (the accumulators are operands of the drain: every later read of them depends on it, so the scheduler cannot place one between the last MFMA and the nops)
+__device__ __forceinline__ void rf_mfma_drain(f32x4 (&c)[4][4]) {
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7"
+                 : "+v"(c[0][0]), "+v"(c[0][1]), "+v"(c[0][2]), "+v"(c[0][3]), "+v"(c[1][0]), "+v"(c[1][1]), "+v"(c[1][2]), "+v"(c[1][3]),
+                   "+v"(c[2][0]), "+v"(c[2][1]), "+v"(c[2][2]), "+v"(c[2][3]), "+v"(c[3][0]), "+v"(c[3][1]), "+v"(c[3][2]), "+v"(c[3][3]) :: "memory");
+}
 #define RF_ATAPS 8                  // taps whose fragments are held in AGPRs (8 x 32 = 256); the ninth in vector registers
 
 template <bool MOM>
@@ -1065,7 +1070,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16_halo_rf_kernel(Bf16Args a, c
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { if (tap < RF_ATAPS) rf_mfma_a(acc[i][j], fa1[i], fb[tap < RF_ATAPS ? tap : 0][1][j]); else rf_mfma_v(acc[i][j], fa1[i], f8[1][j]); }
         }
-        rf_mfma_drain();
+        rf_mfma_drain(acc);
         if (m0 + BMH <= (int)a.M && a.act == DCV_ACT_NONE) finish_tile(par, std::integral_constant<int, DCV_ACT_NONE>{}, std::true_type{});
         else if (m0 + BMH <= (int)a.M && a.act == DCV_ACT_RELU) finish_tile(par, std::integral_constant<int, DCV_ACT_RELU>{}, std::true_type{});
         else finish_tile(par, std::integral_constant<int, -1>{}, std::false_type{});
