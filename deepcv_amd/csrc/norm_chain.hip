@@ -292,7 +292,18 @@ __global__ __launch_bounds__(NC_THREADS) void nc_bn_fwd_finalize_kernel(const do
     if (t == 0) { g = gamma ? gamma[c] : 1.f; b = beta ? beta[c] : 0.f; rm = running_mean ? running_mean[c] : 0.f; rv = running_var ? running_var[c] : 0.f; }
     double s[2] = {0.0, 0.0};
     const double* p0 = part + (size_t)c * rows; const double* p1 = part + ((size_t)C + c) * rows;
-    for (int j = t; j < rows; j += NC_THREADS) { s[0] += p0[j]; s[1] += p1[j]; }
+    // (four rows per thread in flight, four partial sums combined in a fixed order: with one dependent load per iteration a channel of 12 544 rows — a 56 x 56 map at
+    //  512 images — took 14 us on its one block)
+    {
+        double q0[4] = {0.0, 0.0, 0.0, 0.0}, q1[4] = {0.0, 0.0, 0.0, 0.0};
+        int j = t;
+        for (; j + 3 * NC_THREADS < rows; j += 4 * NC_THREADS) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { q0[k] += p0[j + k * NC_THREADS]; q1[k] += p1[j + k * NC_THREADS]; }
+        }
+        for (int k = 0; j < rows; j += NC_THREADS, ++k) { q0[k] += p0[j]; q1[k] += p1[j]; }
+        s[0] = (q0[0] + q0[1]) + (q0[2] + q0[3]); s[1] = (q1[0] + q1[1]) + (q1[2] + q1[3]);
+    }
     nc_block_sums<2>(s, red);
     if (t != 0) return;
     if (c == 0 && nbt) nbt[0] += 1;
@@ -459,7 +470,17 @@ __global__ __launch_bounds__(NC_THREADS) void nc_param_finalize_kernel(const dou
     const double* p0 = part + (size_t)c * rows;
     double s[4] = {0.0, 0.0, 0.0, 0.0};
     if (gn) { for (int j = t; j < rows; j += NC_THREADS) { s[0] += p0[j]; s[1] += p0[cr + j]; s[2] += p0[2 * cr + j]; s[3] += p0[3 * cr + j]; } }
-    else { for (int j = t; j < rows; j += NC_THREADS) { s[2] += p0[j]; s[3] += p0[cr + j]; } }
+    else {
+        // (as nc_bn_fwd_finalize_kernel: four rows per thread in flight)
+        double q0[4] = {0.0, 0.0, 0.0, 0.0}, q1[4] = {0.0, 0.0, 0.0, 0.0};
+        int j = t;
+        for (; j + 3 * NC_THREADS < rows; j += 4 * NC_THREADS) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { q0[k] += p0[j + k * NC_THREADS]; q1[k] += p0[cr + j + k * NC_THREADS]; }
+        }
+        for (int k = 0; j < rows; j += NC_THREADS, ++k) { q0[k] += p0[j]; q1[k] += p0[cr + j]; }
+        s[2] = (q0[0] + q0[1]) + (q0[2] + q0[3]); s[3] = (q1[0] + q1[1]) + (q1[2] + q1[3]);
+    }
     nc_block_sums<4>(s, red);
     if (t != 0) return;
     if (gn) { if (d_gn_beta) d_gn_beta[c] = (float)s[0]; if (d_gn_gamma) d_gn_gamma[c] = (float)s[1]; }
