@@ -320,20 +320,28 @@ __global__ __launch_bounds__(NC_THREADS) void nc_bn_fwd_finalize_kernel(const do
 // out = S x + T.  Prologue (GroupNorm): the block's sample -> statistics of v = a x + b over each group from the sample's sums of x, x^2 (`part`, rps rows per
 // sample), S = a * rstd_g * gn_gamma, T = (b - mean_g) * rstd_g * gn_gamma + gn_beta, shared through LDS; the first loads of x are already in flight.
 // Pooled: one thread per pooled (pixel, channel vector), the mean of the affine over its window (same per-element rounding as affine + AvgPool2d).
-template <int VEC, typename AT = float>
+// ADD (round 4): out = S x + T + addend — a residual link's sum with a same-shape tensor rides in the layer's apply pass (unpooled layers only)
+template <int VEC, typename AT = float, bool ADD = false>
 __global__ __launch_bounds__(NC_THREADS) void nc_apply_kernel(const AT* __restrict__ x, AT* __restrict__ out, int HW, int C, int per,
-                                                               const float* __restrict__ ab, const double* __restrict__ part, int rows, int rps, NcGn gn, NcPool pm) {
+                                                               const float* __restrict__ ab, const double* __restrict__ part, int rows, int rps, NcGn gn, NcPool pm,
+                                                               const AT* __restrict__ addend = nullptr) {
     __shared__ float sS[NC_THREADS], sT[NC_THREADS];           // GroupNorm chains: C <= NC_THREADS
     const int CV = C / VEC;
     const int n = blockIdx.y;
     constexpr int PF = 4;                                       // vectors per thread requested before the prologue
     const AT* xs = x + (size_t)n * HW * C;
-    NcVec<VEC> pre[PF];
+    NcVec<VEC> pre[PF], prea[ADD ? PF : 1];
+    const AT* as = ADD ? addend + (size_t)n * HW * C : nullptr;
     NcChunk ck;
     if (pm.pk == 0) {
         ck = nc_chunk(HW * CV, CV, per);
 #pragma unroll
-        for (int k = 0; k < PF; ++k) { const int i = ck.i0 + k * NC_THREADS; pre[k] = nc_load<VEC>(xs + (size_t)(i < ck.i1 ? i : ck.i0 < ck.i1 ? ck.i0 : 0) * VEC); }
+        for (int k = 0; k < PF; ++k) {
+            const int i = ck.i0 + k * NC_THREADS;
+            const size_t at = (size_t)(i < ck.i1 ? i : ck.i0 < ck.i1 ? ck.i0 : 0) * VEC;
+            pre[k] = nc_load<VEC>(xs + at);
+            if constexpr (ADD) prea[k] = nc_load<VEC>(as + at);
+        }
     }
     NcVec<VEC> S, T;
     if (gn.G > 0) {
@@ -381,19 +389,23 @@ __global__ __launch_bounds__(NC_THREADS) void nc_apply_kernel(const AT* __restri
             if (i < ck.i1) {
                 NcVec<VEC> o;
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) o.v[v] = pre[k].v[v] * S.v[v] + T.v[v];
+                for (int v = 0; v < VEC; ++v) o.v[v] = pre[k].v[v] * S.v[v] + T.v[v] + (ADD ? prea[ADD ? k : 0].v[v] : 0.f);
                 nc_store<VEC>(os + (size_t)i * VEC, o);
             }
         }
         for (int i = ck.i0 + PF * NC_THREADS; i < ck.i1; i += PF * NC_THREADS) {
-            NcVec<VEC> xv[PF];
+            NcVec<VEC> xv[PF], av[ADD ? PF : 1];
 #pragma unroll
-            for (int k = 0; k < PF; ++k) xv[k] = nc_load<VEC>(xs + (size_t)(i + k * NC_THREADS < ck.i1 ? i + k * NC_THREADS : i) * VEC);
+            for (int k = 0; k < PF; ++k) {
+                const size_t at = (size_t)(i + k * NC_THREADS < ck.i1 ? i + k * NC_THREADS : i) * VEC;
+                xv[k] = nc_load<VEC>(xs + at);
+                if constexpr (ADD) av[k] = nc_load<VEC>(as + at);
+            }
 #pragma unroll
             for (int k = 0; k < PF; ++k) {
                 NcVec<VEC> o;
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) o.v[v] = xv[k].v[v] * S.v[v] + T.v[v];
+                for (int v = 0; v < VEC; ++v) o.v[v] = xv[k].v[v] * S.v[v] + T.v[v] + (ADD ? av[ADD ? k : 0].v[v] : 0.f);
                 if (i + k * NC_THREADS < ck.i1) nc_store<VEC>(os + (size_t)(i + k * NC_THREADS) * VEC, o);
             }
         }
@@ -948,7 +960,7 @@ int dcv_norm_chain_fwd(const dcv_norm_chain_desc* d, const void* xv, void* outv,
     if (!(nc_skip() & 2)) hipLaunchKernelGGL(nc_bn_fwd_finalize_kernel, dim3((unsigned)C), dim3(NC_THREADS), 0, st, part, rows, (double)d->n * (double)d->hw, C, d->bn_gamma, d->bn_beta,
                        d->running_mean, d->running_var, reinterpret_cast<long long*>(d->num_batches_tracked), d->momentum, d->bn_eps, d->bn_mean, d->bn_rstd, ab);
     if (d->pool_mode == 1) {
-        DCV_CHECK_ARG(d->pool_arg != nullptr && (reinterpret_cast<uintptr_t>(d->pool_arg) & 7) == 0);
+        DCV_CHECK_ARG(d->pool_arg != nullptr && d->addend == nullptr && (reinterpret_cast<uintptr_t>(d->pool_arg) & 7) == 0);
         if (nc_skip() & 4) DCV_RETURN_LAUNCH();
         const NcMax mx = nc_max(d);
         const size_t total = (size_t)d->n * mx.Ho * mx.Wo * CV;
@@ -962,6 +974,17 @@ int dcv_norm_chain_fwd(const dcv_norm_chain_desc* d, const void* xv, void* outv,
     if (d->pool > 0) nc_split((d->hw / (d->pool * d->pool)) * CV, G > 0, &abps, &aper);      // (a GroupNorm sample is one block: its prologue; else as many as it takes)
     const dim3 agrid((unsigned)abps, (unsigned)d->n);
     if (nc_skip() & 4) DCV_RETURN_LAUNCH();
+    if (d->addend != nullptr) {
+        // out = S x + T + addend (a residual link behind the layer): the streaming instances without pooling
+        DCV_CHECK_ARG(d->pool == 0 && (nc_vec(d) != 8 || (reinterpret_cast<uintptr_t>(d->addend) & 15) == 0));
+        const nc_bf16* a16 = reinterpret_cast<const nc_bf16*>(d->addend); const float* a32 = reinterpret_cast<const float*>(d->addend);
+        if (io16 && vec == 8) hipLaunchKernelGGL((nc_apply_kernel<8, nc_bf16, true>), agrid, dim3(NC_THREADS), 0, st, x16, out16, d->hw, C, aper, ab, part, rows, rps, gn, pm, a16);
+        else if (io16 && vec == 4) hipLaunchKernelGGL((nc_apply_kernel<4, nc_bf16, true>), agrid, dim3(NC_THREADS), 0, st, x16, out16, d->hw, C, aper, ab, part, rows, rps, gn, pm, a16);
+        else if (io16) hipLaunchKernelGGL((nc_apply_kernel<1, nc_bf16, true>), agrid, dim3(NC_THREADS), 0, st, x16, out16, d->hw, C, aper, ab, part, rows, rps, gn, pm, a16);
+        else if (vec == 4) hipLaunchKernelGGL((nc_apply_kernel<4, float, true>), agrid, dim3(NC_THREADS), 0, st, x, out, d->hw, C, aper, ab, part, rows, rps, gn, pm, a32);
+        else hipLaunchKernelGGL((nc_apply_kernel<1, float, true>), agrid, dim3(NC_THREADS), 0, st, x, out, d->hw, C, aper, ab, part, rows, rps, gn, pm, a32);
+        DCV_RETURN_LAUNCH();
+    }
     if (io16 && vec == 8) hipLaunchKernelGGL((nc_apply_kernel<8, nc_bf16>), agrid, dim3(NC_THREADS), 0, st, x16, out16, d->hw, C, aper, ab, part, rows, rps, gn, pm);
     else if (io16 && vec == 4) hipLaunchKernelGGL((nc_apply_kernel<4, nc_bf16>), agrid, dim3(NC_THREADS), 0, st, x16, out16, d->hw, C, aper, ab, part, rows, rps, gn, pm);
     else if (io16) hipLaunchKernelGGL((nc_apply_kernel<1, nc_bf16>), agrid, dim3(NC_THREADS), 0, st, x16, out16, d->hw, C, aper, ab, part, rows, rps, gn, pm);

@@ -8,6 +8,7 @@ hand-written HIP kernels.  `DeepcvModuleWithSharedImageBlock` (half-implemented 
 (SURVEY.md §2.1 row 1); `DeepcvModuleDescriptor` is kept in a compact form for `describe()` / `__str__`. """
 import copy
 import logging
+import os
 from collections import OrderedDict
 from functools import partial
 from typing import Any, Callable, Dict, List, Optional, Sequence, Set, Tuple, Type, Union
@@ -23,6 +24,8 @@ from .. import resident as native_resident
 from . import nn_spec
 from .submodule_creators import ForwardCallbackSubmodule
 from .types_aliases import *
+
+_FUSE_RESIDUAL_SUM = os.environ.get('DCV_FUSE_RESIDUAL_SUM', '1') not in ('0', 'false', 'False', '')      # a layer + a residual 'sum' link as one fused layer
 
 __all__ = ['DeepcvModule', 'DeepcvModuleDescriptor']
 
@@ -125,6 +128,20 @@ class DeepcvModule(torch.nn.Module):
                 fused = None
                 if i + 1 < len(items) and not any(name in r for r in remaining_refs.values()) and not getattr(items[i + 1][1], 'referenced_submodules', None):
                     fused = self._fused_pair(subm, items[i + 1][1], x)
+                elif i + 1 < len(items) and not any(name in r for r in remaining_refs.values()) and _FUSE_RESIDUAL_SUM:
+                    # `subm` + a residual link ('sum') with ONE same-shape reference: the sum rides in the layer's normalisation kernels (round 4)
+                    lname, link = items[i + 1]
+                    lrefs = getattr(link, 'referenced_submodules', None)
+                    if (lrefs and len(lrefs) == 1 and getattr(link, 'dcv_link_reduction', None) == 'sum' and isinstance(subm, deepcv_nn.LayerSequential)
+                            and isinstance(referenced_output_features.get(lrefs[0]), torch.Tensor) and subm.addend_dtype(x, referenced_output_features[lrefs[0]])):
+                        ref = lrefs[0]
+                        t = referenced_output_features[ref]
+                        if ref in fan_slots:                      # (as for any referrer: the tap node is created now)
+                            t = native_ops.ref_tap(t, fan_slots.pop(ref))
+                        del remaining_refs[lname]
+                        if not any(ref in r for r in remaining_refs.values()):
+                            del referenced_output_features[ref]
+                        fused = subm.forward_with_addend(x, t)
                 if fused is not None:                             # `subm` + the sub-module which follows it, in one go: its output is the second one's
                     i += 1
                     name, x = items[i][0], fused

@@ -308,6 +308,34 @@ class LayerSequential(torch.nn.Sequential):
             return None
         return self._run_fused_layer(x, plan, pool=k[0])
 
+    def addend_dtype(self, x, ref) -> bool:
+        """ Whether this layer can take the same-shape tensor `ref` of a following residual link ('sum') into its normalisation kernels' apply pass
+        (`ops.conv_norm_layer(addend=...)`, round 4: the sum otherwise reads two tensors and writes one more): the whole module is one fused training layer
+        on the streaming chain, no pooling, and `ref` has the output's shape, element type and memory layout.  No launch. """
+        if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4 and isinstance(ref, torch.Tensor) and ref.is_cuda and ref.dim() == 4):
+            return False
+        mods = list(self._modules.values())
+        plan = self._fused_layer_plan(mods)
+        if plan is None or plan[4] != len(mods):
+            return False
+        conv = plan[0]
+        if tuple(conv.out_shape(x.shape)) != tuple(ref.shape) or not ref.is_contiguous(memory_format=torch.channels_last):
+            return False
+        dt = ops.layer_out_dtype(x, conv.weight, conv.stride, conv._padding_pair(), conv.dilation, plan[3].num_groups if plan[3] is not None else 0)
+        return dt is not None and dt == ref.dtype
+
+    def forward_with_addend(self, x, ref) -> torch.Tensor:
+        """ layer(x) + ref in the layer's own kernels (`addend_dtype` said so). """
+        mods = list(self._modules.values())
+        plan = self._fused_layer_plan(mods)
+        conv, act, bn, gn, _ = plan
+        conv._check()
+        code, slope = ops.act_code(act)
+        return ops.conv_norm_layer(x, conv.weight, conv.bias, conv.stride, conv._padding_pair(), conv.dilation, code, slope,
+                                   bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.momentum, bn.eps,
+                                   gn.num_groups if gn is not None else 0, gn.weight if gn is not None else None, gn.bias if gn is not None else None,
+                                   gn.eps if gn is not None else 1e-5, addend=ref)
+
     def forward_after_flatten(self, x, flatten: torch.nn.Module) -> Optional[torch.Tensor]:
         """ `self(flatten(x))` for a `Flatten` sub-module followed by this fully connected layer (reference `parameters.yml:87-88`): the `Linear` reads the
         NHWC activations in place through a re-laid copy of its weight instead of a transposed copy of the batch.  None when not covered. """

@@ -254,7 +254,9 @@ def add_residual_dense_link_creator(is_residual: bool, creator_name: str, submod
                         y = deepcv_nn.interpolate(y, out[0].shape[channel_dim + 1:], scaling_mode=scaling_mode, align_corners=scaling_align_corners)
                     out.append(y)
             return reduction_fn(out)
-        return ForwardCallbackSubmodule(_forward_callback)
+        link = ForwardCallbackSubmodule(_forward_callback)
+        link.dcv_link_reduction = reduction           # ('sum': `DeepcvModule.forward` may hand a same-shape reference to the layer in front of it, `forward_with_addend`)
+        return link
 
     _link_creator.__doc__ = add_residual_dense_link_creator.__doc__
     return _link_creator

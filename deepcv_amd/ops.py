@@ -18,7 +18,7 @@ from . import resident
 from . import slabs
 from ._native import lib
 
-__all__ = ['conv2d', 'set_conv_math', 'set_bf16_storage', 'set_norm_streaming', 'conv_norm_layer', 'fan_out', 'ref_tap', 'activation', 'batch_norm', 'sync_batch_norm', 'group_norm', 'pool2d', 'interpolate_bilinear', 'concat_channels', 'resize_concat', 'add_tensors', 'flatten_nchw_order',
+__all__ = ['conv2d', 'set_conv_math', 'set_bf16_storage', 'set_norm_streaming', 'conv_norm_layer', 'layer_out_dtype', 'fan_out', 'ref_tap', 'activation', 'batch_norm', 'sync_batch_norm', 'group_norm', 'pool2d', 'interpolate_bilinear', 'concat_channels', 'resize_concat', 'add_tensors', 'flatten_nchw_order',
            'linear', 'linear_nhwc', 'cross_entropy', 'act_code', 'to_nhwc', 'nchw_to_nhwc']
 
 _CL = torch.channels_last
@@ -418,11 +418,13 @@ class _RefTapFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, slot):
         ctx.slot = slot
+        ctx.set_materialize_grads(False)                        # (no gradient: nothing to park — a fused layer which owns the slot parks its own, `self_tap`)
         return x.view_as(x)
 
     @staticmethod
     def backward(ctx, g):
-        ctx.slot.grad = g                                       # picked up by the main consumer's data gradient, or by _FanOutFn.backward
+        if g is not None:
+            ctx.slot.grad = g                                   # picked up by the main consumer's data gradient, or by _FanOutFn.backward
         return None, None
 
 
@@ -439,7 +441,9 @@ def fan_out(x: torch.Tensor):
 
 
 def ref_tap(ref: torch.Tensor, slot) -> torch.Tensor:
-    return _RefTapFn.apply(ref, slot)
+    out = _RefTapFn.apply(ref, slot)
+    out._dcv_tap_slot = slot               # (a fused layer which takes BOTH aliases — x = main, addend = this tap — recognises its own slot, `_ConvNormLayerFn`)
+    return out
 
 
 def _fan_addend(slot, like_shape) -> Optional[torch.Tensor]:
@@ -816,7 +820,7 @@ class _ConvNormLayerFn(torch.autograd.Function):
     apply -> dz), then the convolution's data and weight gradients (the bias gradient comes out of the weight-gradient kernel's dz tiles). """
 
     @staticmethod
-    def forward(ctx, x, weight, bias, bn_w, bn_b, running_mean, running_var, nbt, gn_w, gn_b, cfg):
+    def forward(ctx, x, weight, bias, bn_w, bn_b, running_mean, running_var, nbt, gn_w, gn_b, cfg, addend=None):
         stride, padding, dilation, act, slope, momentum, bn_eps, groups, gn_eps, pool = cfg
         _require_f32(weight, bias, bn_w, bn_b, running_mean, running_var, gn_w, gn_b)
         nat.require_device(x)
@@ -838,12 +842,17 @@ class _ConvNormLayerFn(torch.autograd.Function):
             x, layout = to_nhwc(_to_f32(x.contiguous(), st) if x.dtype == torch.bfloat16 else x), nat.LAYOUT_NHWC
         ctx.weight_ref, ctx.bias_ref, ctx.norm_refs = weight, bias, (bn_w, bn_b, gn_w, gn_b)
         ctx.fan_slot = getattr(x, '_dcv_fan_slot', None)          # x is also referenced by a later link: its gradient may ride in our data gradient
+        # ... and when that link is the residual sum behind THIS layer (out = layer(x) + x: addend is the tap of x's own slot), the referrer's gradient is our own
+        # dout: known before the tap's backward could park it
+        ctx.self_tap = addend is not None and ctx.fan_slot is not None and getattr(addend, '_dcv_tap_slot', None) is ctx.fan_slot
         d = _conv_desc(x.shape, weight.shape, stride, padding, dilation, layout, act, slope)
         if rec is not None:
             if x.dtype != torch.float32 or not weight.is_contiguous():
                 raise resident.Ineligible('layer: element type / weight layout')
             if pool and not groups:
                 raise resident.Ineligible('layer: fused pooling without the GroupNorm stage')
+            if addend is not None:
+                raise resident.Ineligible('layer: a residual sum in the apply pass')
             rec.check_layer(x, d, cfg, layout)
             rec.note(weight if ctx.needs_input_grad[1] else None, bias if ctx.needs_input_grad[2] else None)
         slabs.note_use(weight if ctx.needs_input_grad[1] else None, bias if ctx.needs_input_grad[2] else None)
@@ -883,6 +892,8 @@ class _ConvNormLayerFn(torch.autograd.Function):
         if pool < 0 and not ctx.io16:                             # (nothing has been launched or updated yet: the caller applies the two modules one after the other)
             raise FusedPoolUnavailable('deepcv_amd.conv_norm_layer: a fused max pooling needs the bf16 storage path (ops.fused_max_pool_covered)')
         adt = torch.bfloat16 if ctx.io16 else torch.float32
+        if addend is not None and not (ctx.streaming and not pool and addend.dtype == adt and tuple(addend.shape) == (d.n, d.cout, d.ho, d.wo) and _is_nhwc(addend)):
+            raise FusedPoolUnavailable('deepcv_amd.conv_norm_layer: the residual sum does not fit the layer\'s apply pass (ops.layer_out_dtype)')
         y = torch.empty((d.n, d.cout, d.ho, d.wo), dtype=adt, device=dev, memory_format=_CL)
         if ctx.use16:
             x16 = _to_bf16(x, st)
@@ -906,6 +917,7 @@ class _ConvNormLayerFn(torch.autograd.Function):
             nc.coef = coef.data_ptr()
             nc.io_dtype = nat.DTYPE_BF16 if ctx.io16 else nat.DTYPE_F32
             nc.pool_arg = nat.ptr(ctx.pool_arg)
+            nc.addend = nat.ptr(addend)                             # out = chain(y) + addend: a residual link's sum in the apply pass (round 4)
             ws = _ws(lib.dcv_norm_chain_ws_bytes(nc), dev)
             nat.check(lib.dcv_norm_chain_fwd(nc, y.data_ptr(), out.data_ptr(), nat.ptr(stats), rows.value, rps.value, ws.data_ptr(), ws.numel(), st), 'dcv_norm_chain_fwd')
         else:
@@ -1006,8 +1018,11 @@ class _ConvNormLayerFn(torch.autograd.Function):
                         keep.append(dz)
                         _conv_wgrad_launch(d, x, dz, ctx.weight_ref, ctx.bias_ref, dw, db, st)  # deferred: runs at the flush, after the launch above
                 plan.add(op, dx, keep, st)
-                return dx, dw, db, d_bn_w, d_bn_b, None, None, None, d_gn_w, d_gn_b, None
+                return dx, dw, db, d_bn_w, d_bn_b, None, None, None, d_gn_w, d_gn_b, None, None
         dz = torch.empty_like(y)
+        d_add = dout if need[11] else None                            # out = chain(y) + addend
+        if d_add is not None and getattr(ctx, 'self_tap', False):
+            ctx.fan_slot.grad, d_add = dout, None                     # (what the tap's backward would park: our data gradient adds it, or `_FanOutFn.backward` does): the sum hands its gradient to both inputs unchanged
         if ctx.streaming:
             nc = _norm_chain_desc(d, ctx.cfg, bn_w, bn_b, None, None, None, bn_mean, bn_rstd, gn_w, None, gn_mean, gn_rstd)
             coef = torch.empty(int(lib.dcv_norm_chain_coef_floats(nc)), dtype=torch.float32, device=dev)
@@ -1048,7 +1063,7 @@ class _ConvNormLayerFn(torch.autograd.Function):
         if ctx.use16:
             dw = _grad_buffer(ctx.weight_ref, like=weight) if need[1] else None
             dx = _conv_bwd16_launch(ctx, d, x, dz, weight, need[0], dw, st)
-            return dx, dw, db, d_bn_w, d_bn_b, None, None, None, d_gn_w, d_gn_b, None
+            return dx, dw, db, d_bn_w, d_bn_b, None, None, None, d_gn_w, d_gn_b, None, d_add
         if need[0]:
             dd = nat.Conv2dDesc.from_buffer_copy(d)
             dd.x_layout = nat.LAYOUT_NHWC
@@ -1061,14 +1076,16 @@ class _ConvNormLayerFn(torch.autograd.Function):
         if need[1]:
             dw = _grad_buffer(ctx.weight_ref, like=weight)
             _conv_wgrad_launch(d, x, dz, ctx.weight_ref, ctx.bias_ref, dw, db if db_from_wgrad else None, st)
-        return dx, dw, db, d_bn_w, d_bn_b, None, None, None, d_gn_w, d_gn_b, None
+        return dx, dw, db, d_bn_w, d_bn_b, None, None, None, d_gn_w, d_gn_b, None, d_add
 
 
 def conv_norm_layer(x, weight, bias, stride, padding, dilation, act: int, slope: float, bn_w, bn_b, running_mean, running_var, num_batches_tracked,
-                    momentum: float, bn_eps: float, gn_groups: int = 0, gn_w=None, gn_b=None, gn_eps: float = 1e-5, pool: int = 0, max_pool=None) -> torch.Tensor:
+                    momentum: float, bn_eps: float, gn_groups: int = 0, gn_w=None, gn_b=None, gn_eps: float = 1e-5, pool: int = 0, max_pool=None,
+                    addend: Optional[torch.Tensor] = None) -> torch.Tensor:
     """ Training-mode `GroupNorm?(BatchNorm(act(conv2d(x))))` with batch statistics and running-stat update, fused (see `_ConvNormLayerFn`).
     `pool` > 0 appends `avg_pool2d(kernel_size=pool, stride=pool)` (output sizes must be multiples of `pool`): same kernels, the unpooled output is
-    never written. """
+    never written.  `addend`: a tensor of the output's shape and element type which is added to it (a residual link's sum behind the layer, `layer_out_dtype`):
+    it rides in the chain's apply pass; raises `FusedPoolUnavailable` before any launch when it does not fit. """
     if pool < 0 or (pool and max_pool is not None):
         raise ValueError('deepcv_amd.conv_norm_layer: pool must be >= 0 (and not combined with max_pool)')
     if max_pool is not None:                                      # (kernel, stride, padding) of a following MaxPool2d (`fused_max_pool_covered`)
@@ -1077,7 +1094,28 @@ def conv_norm_layer(x, weight, bias, stride, padding, dilation, act: int, slope:
     if gemm is not None:
         (x, weight), stride, padding, dilation = gemm, 1, 0, 1
     cfg = (_pair(stride), _pair(padding), _pair(dilation), int(act), float(slope), float(momentum), float(bn_eps), int(gn_groups), float(gn_eps), int(pool))
-    return _ConvNormLayerFn.apply(x, weight, bias, bn_w, bn_b, running_mean, running_var, num_batches_tracked, gn_w, gn_b, cfg)
+    return _ConvNormLayerFn.apply(x, weight, bias, bn_w, bn_b, running_mean, running_var, num_batches_tracked, gn_w, gn_b, cfg, addend)
+
+
+def layer_out_dtype(x: torch.Tensor, weight: torch.Tensor, stride, padding, dilation, gn_groups: int = 0):
+    """ Element type of `conv_norm_layer`'s output for this input — bf16 on the bf16 storage path, fp32 on the other streaming-chain layers —, or None when the
+    layer would not run on the streaming normalisation chain or would be rewritten first (first layers of few channels).  No launch: what `LayerSequential.
+    forward_with_addend` asks before it hands a residual link's tensor to the layer. """
+    if not (_norm_streaming and isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16)) or weight.shape[1] <= 4:
+        return None
+    if resident.recorder() is not None:
+        return None
+    if _is_nhwc(x):
+        layout = nat.LAYOUT_NHWC
+    elif x.is_contiguous() and x.dtype == torch.float32:
+        layout = nat.LAYOUT_NCHW
+    else:
+        return None
+    d = _conv_desc(x.shape, weight.shape, _pair(stride), _pair(padding), _pair(dilation), layout, nat.ACT_NONE, 0.)
+    nc = nat.NormChainDesc(d.n, d.ho * d.wo, d.cout, d.wo, 0, None, None, None, None, None, 0.1, 1e-5, None, None, int(gn_groups), None, None, 1e-5, None, None, None, nat.ACT_NONE, 0.)
+    if not lib.dcv_norm_chain_supported(nc):
+        return None
+    return torch.bfloat16 if _use_bf16_storage(d, layout) else torch.float32
 
 
 # ------------------------------------------------------------------------------------------------ pooling

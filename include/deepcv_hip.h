@@ -366,6 +366,9 @@ typedef struct dcv_norm_chain_desc {
     int pool_k, pool_stride, pool_pad;
     unsigned char* pool_arg;                               /* pool_mode 1: [n][ho][wo][channels] window position r k + s of each maximum: written by the forward, read by
                                                               the backward; 8-byte aligned */
+    const void* addend;                                    /* nullable; dcv_norm_chain_fwd only, pool == 0, pool_mode == 0: out = chain(x) + addend, addend a tensor of out's
+                                                              shape and element type — a residual link's sum behind the layer (submodule_creators.py:272-327) in the
+                                                              layer's own pass over x; the backward is unchanged (the sum hands its gradient to both inputs) */
 } dcv_norm_chain_desc;
 int dcv_norm_chain_supported(const dcv_norm_chain_desc* d);
 size_t dcv_norm_chain_coef_floats(const dcv_norm_chain_desc* d);

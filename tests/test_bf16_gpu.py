@@ -272,6 +272,58 @@ def test_fused_layer_with_a_following_max_pooling(device, geom, monkeypatch):
     assert abs(g_f[0].sum().item() - ref_in[0].grad.sum().item()) <= 2e-2 * ref_in[0].grad.abs().sum().item() ** 0.5 * 10
 
 
+@pytest.mark.parametrize('own_input', [False, True], ids=['other_tensor', 'own_input'])
+@pytest.mark.parametrize('storage', [True, False], ids=['bf16', 'fp32'])
+def test_fused_layer_with_a_residual_sum_in_its_apply_pass(device, storage, own_input):
+    """ `ops.conv_norm_layer(addend=r)` (round 4: a residual link's sum with a same-shape tensor rides in the normalisation chain's apply pass,
+    `dcv_norm_chain_desc::addend`) against the layer followed by `ops.add_tensors`: the output within ONE rounding of the element type (the fused form adds in
+    fp32 before rounding), every gradient — the addend's included: the sum hands its gradient to both inputs — equal to the unfused pair's, and the layer's
+    statistics untouched by the addend.  `own_input`: out = layer(x) + x through `fan_out` / `ref_tap` as `DeepcvModule.forward` builds it (the link's gradient is
+    then the layer's own dout: parked in the slot by the layer itself, added by its data-gradient kernel or by the fan-out's backward). """
+    from deepcv_amd import ops, _native as nat
+    n, cin, h, cout = 8, 64, 16, 64
+    torch.manual_seed(23)
+    x = _bf(torch.randn(n, cin, h, h)).float()
+    wt = _bf(torch.randn(cout, cin, 3, 3) / (cin * 9) ** 0.5).float()
+    b, bn_w, bn_b = torch.randn(cout) * 0.1, torch.rand(cout) + 0.5, torch.randn(cout) * 0.1
+    r = _bf(torch.randn(n, cout, h, h)).float()
+    dout = _bf(torch.randn(n, cout, h, h)).float()
+    adt = torch.bfloat16 if storage else torch.float32
+
+    def run(fused):
+        ins = [t.to(device).requires_grad_(True) for t in (x, wt, b, bn_w, bn_b, r)]
+        xd = ins[0].to(adt).contiguous(memory_format=torch.channels_last)
+        rd = ins[5].to(adt).contiguous(memory_format=torch.channels_last)
+        rm, rv, nbt = torch.zeros(cout, device=device), torch.ones(cout, device=device), torch.zeros(1, dtype=torch.int64, device=device)
+        if own_input:
+            xd, ref, slot = ops.fan_out(xd)
+            rd = ops.ref_tap(ref, slot)
+        args = (xd, ins[1], ins[2], 1, 1, 1, nat.ACT_RELU, 0., ins[3], ins[4], rm, rv, nbt, 0.1, 1e-5)
+        if fused:
+            assert ops.layer_out_dtype(xd, ins[1], 1, 1, 1) == adt
+            out = ops.conv_norm_layer(*args, addend=rd)
+        else:
+            out = ops.add_tensors([ops.conv_norm_layer(*args), rd])
+        assert out.dtype == adt
+        out.backward(dout.to(device).to(adt).contiguous(memory_format=torch.channels_last))
+        torch.cuda.synchronize()
+        return out.float().cpu(), [None if t.grad is None else t.grad.double().cpu() for t in ins], rm.cpu(), rv.cpu()
+
+    prev, prev_st = ops.set_conv_math('bf16' if storage else 'fp32'), ops.set_bf16_storage(storage)
+    try:
+        out_f, g_f, rm_f, rv_f = run(True)
+        out_u, g_u, rm_u, rv_u = run(False)
+    finally:
+        ops.set_conv_math(prev)
+        ops.set_bf16_storage(prev_st)
+    assert torch.equal(rm_f, rm_u) and torch.equal(rv_f, rv_u)
+    assert _rel(out_f, out_u) <= (8e-3 if storage else 1e-6)
+    for i, name in enumerate(['x', 'weight', 'bias', 'bn_weight', 'bn_bias', 'addend']):
+        if name == 'addend' and own_input:
+            continue                                              # (the leaf is not used)
+        assert torch.equal(g_f[i], g_u[i]), name                  # (the backward does not see the addend: same kernels on the same tensors)
+
+
 def _row_sums(t_nchw: torch.Tensor, rows_of: int = 128) -> torch.Tensor:
     """ [channels][rows] fp64 sums of an [n][c][h][w] tensor over blocks of `rows_of` consecutive NHWC pixels (the layout of the kernels' statistics rows). """
     r = t_nchw.permute(0, 2, 3, 1).reshape(-1, t_nchw.shape[1]).double()
