@@ -829,9 +829,14 @@ inline int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
 
 // blocks per sample / vectors per block for `nv` vectors per sample (`per` a multiple of NC_THREADS).  With GroupNorm a sample is ONE block (its statistics
 // and backward algebra are finished inside the block): up to 32 vectors per thread; without, <= 16 vectors per thread and as many blocks as that takes.
-inline void nc_split(int nv, bool one_block, int* bps, int* per) {
+// n (round 4): the batch — n x bps is the number of rows every partial-sum array of the chain has (statistics, moments, bias partials), and whoever sums them does
+// it with a few blocks per channel: at 512 x 3 x 224 x 224 the stem of resnet18_style had 12 800 rows, the step's slab sum waited 84 us for its eight blocks.  Past
+// 4096 rows a block takes up to 64 vectors per thread instead of 16.
+inline void nc_split(int nv, bool one_block, int* bps, int* per, int n = 1) {
     if (one_block) { *bps = 1; *per = (int)dcv_align_up((size_t)nv, NC_THREADS); return; }
     int b = (int)dcv_ceil_div((size_t)nv, (size_t)NC_THREADS * 16);
+    const int bmin = (int)dcv_ceil_div((size_t)nv, (size_t)NC_THREADS * 64);
+    while ((long)n * b > 4096 && b > bmin && b > 1) b = (b + 1) / 2 > bmin ? (b + 1) / 2 : bmin;
     if (b < 1) b = 1;
     const int p = (int)dcv_align_up(dcv_ceil_div((size_t)nv, (size_t)b), NC_THREADS);
     *bps = (int)dcv_ceil_div((size_t)nv, (size_t)p); *per = p;
@@ -896,12 +901,12 @@ inline NcGn nc_gn(const dcv_norm_chain_desc* d) {
 }
 
 inline size_t nc_part_bytes(const dcv_norm_chain_desc* d) {
-    int bps, per; nc_split(d->hw * (d->channels / nc_vec(d)), d->groups > 0, &bps, &per);
+    int bps, per; nc_split(d->hw * (d->channels / nc_vec(d)), d->groups > 0, &bps, &per, d->n);
     return dcv_align_up((size_t)4 * d->channels * (size_t)d->n * bps * sizeof(double), 256);
 }
 inline size_t nc_chan_bytes(const dcv_norm_chain_desc* d) { return dcv_align_up((size_t)2 * d->channels * sizeof(float), 256); }
 inline size_t nc_db_bytes(const dcv_norm_chain_desc* d) {      // [channels][blocks] partial sums of dz (the bias gradient, dcv_norm_chain_desc::d_bias)
-    int bps, per; nc_split(d->hw * (d->channels / nc_vec(d)), d->groups > 0, &bps, &per);
+    int bps, per; nc_split(d->hw * (d->channels / nc_vec(d)), d->groups > 0, &bps, &per, d->n);
     return dcv_align_up((size_t)d->channels * (size_t)d->n * bps * sizeof(double), 256);
 }
 
@@ -918,7 +923,7 @@ size_t dcv_norm_chain_coef_floats(const dcv_norm_chain_desc* d) {
 
 int dcv_norm_chain_bias_rows(const dcv_norm_chain_desc* d) {
     if (!nc_shape_ok(d)) return 0;
-    int bps, per; nc_split(d->hw * (d->channels / nc_vec(d)), d->groups > 0, &bps, &per);
+    int bps, per; nc_split(d->hw * (d->channels / nc_vec(d)), d->groups > 0, &bps, &per, d->n);
     return d->n * bps;
 }
 
@@ -937,7 +942,7 @@ int dcv_norm_chain_fwd(const dcv_norm_chain_desc* d, const void* xv, void* outv,
     if (ws_bytes < nc_part_bytes(d) + nc_chan_bytes(d)) return DCV_ERR_WORKSPACE;
     hipStream_t st = dcv_stream(stream);
     const int C = d->channels, vec = nc_vec(d), CV = C / vec, G = d->groups;
-    int bps, per; nc_split(d->hw * CV, G > 0, &bps, &per);
+    int bps, per; nc_split(d->hw * CV, G > 0, &bps, &per, d->n);
     const NcPool pm = nc_pool(d);
     const NcGn gn = nc_gn(d);
     const bool io16 = d->io_dtype == DCV_DTYPE_BF16;
@@ -971,7 +976,7 @@ int dcv_norm_chain_fwd(const dcv_norm_chain_desc* d, const void* xv, void* outv,
         DCV_RETURN_LAUNCH();
     }
     int abps = bps, aper = per;
-    if (d->pool > 0) nc_split((d->hw / (d->pool * d->pool)) * CV, G > 0, &abps, &aper);      // (a GroupNorm sample is one block: its prologue; else as many as it takes)
+    if (d->pool > 0) nc_split((d->hw / (d->pool * d->pool)) * CV, G > 0, &abps, &aper, d->n);      // (a GroupNorm sample is one block: its prologue; else as many as it takes)
     const dim3 agrid((unsigned)abps, (unsigned)d->n);
     if (nc_skip() & 4) DCV_RETURN_LAUNCH();
     if (d->addend != nullptr) {
@@ -1005,7 +1010,7 @@ int dcv_norm_chain_bwd(const dcv_norm_chain_desc* d, const void* doutv, const vo
     DCV_CHECK_ARG(!(d->d_bias && d->d_bias_part) && (d->moments == nullptr || (d->groups == 0 && d->moments_rows > 0)));
     hipStream_t st = dcv_stream(stream);
     const int C = d->channels, vec = nc_vec(d), CV = C / vec, G = d->groups;
-    int bps, per; nc_split(d->hw * CV, G > 0, &bps, &per);
+    int bps, per; nc_split(d->hw * CV, G > 0, &bps, &per, d->n);
     const NcPool pm = nc_pool(d);
     double* part = reinterpret_cast<double*>(ws);
     float* chan = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + nc_part_bytes(d));
@@ -1019,7 +1024,7 @@ int dcv_norm_chain_bwd(const dcv_norm_chain_desc* d, const void* doutv, const vo
     if (d->pool_mode == 1) {
         DCV_CHECK_ARG(d->pool_arg != nullptr && d->moments == nullptr && (reinterpret_cast<uintptr_t>(d->pool_arg) & 7) == 0);
         const NcMax mx = nc_max(d);
-        int pbps, pper; nc_split(mx.Ho * mx.Wo * CV, false, &pbps, &pper);        // (fewer vectors than the full-size map: the rows fit the same workspace)
+        int pbps, pper; nc_split(mx.Ho * mx.Wo * CV, false, &pbps, &pper, d->n);        // (fewer vectors than the full-size map: the rows fit the same workspace)
         const int prows = d->n * pbps;
         if (!(nc_skip() & 1)) hipLaunchKernelGGL(nc_maxpool_bwd_sums_kernel, dim3((unsigned)pbps, (unsigned)d->n), dim3(NC_THREADS), 0, st, x16, dout16, d->pool_arg, C, pper, d->bn_mean, d->bn_rstd, mx, part, prows);
         if (!(nc_skip() & 2)) hipLaunchKernelGGL(nc_param_finalize_kernel, dim3((unsigned)C), dim3(NC_THREADS), 0, st, part, prows, (double)d->n * (double)d->hw, C, 0, d->bn_gamma, d->bn_rstd,
