@@ -81,6 +81,64 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
     }
 }
 
+// Wide heads at large batches (round 4: 512 x 2048 -> 100 of cifar100_deep, 512 x 512 -> 1000 of resnet18_style): with one sample row per wave every wave reads
+// the whole weight chunk — 410 MB / 1 GB of L2 traffic for a 0.2 / 0.5 GFLOP product, 27 / 77 us.  Here a wave owns RW = 4 sample rows: each weight vector it
+// loads meets four rows of x in registers (a quarter of the traffic); per (row, feature) the same products are summed in the same order as linear_fwd_kernel<4, 8>
+// (bit-identical results).
+template <int RW, int XR>
+__global__ __launch_bounds__(256) void linear_fwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                               float* __restrict__ y, int N, int K, int O, int act, float slope) {
+    constexpr int OB = 8;                                       // XR: float4 of a row per lane (K <= 256 XR)
+    const int lane = threadIdx.x & 63;
+    const int n0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RW;
+    if (n0 >= N) return;
+    const int KV = K >> 2, iters = (KV + 63) / 64;               // iters <= XR (the launcher checks)
+    float4 xv[RW][XR];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const float4* xr = reinterpret_cast<const float4*>(x + (size_t)(n0 + r < N ? n0 + r : n0) * K);
+#pragma unroll
+        for (int i = 0; i < XR; ++i) {
+            const int k = lane + 64 * i;
+            xv[r][i] = (i < iters && k < KV) ? xr[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    // (eight output features per wave: a 0.2 GFLOP product is latency-bound — as many waves as the traffic allows)
+    const int o_begin = blockIdx.y * OB, o_end = (o_begin + OB < O) ? o_begin + OB : O;
+    for (int o0 = o_begin; o0 < o_end; o0 += OB) {
+        float acc[RW][OB];
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int j = 0; j < OB; ++j) acc[r][j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < XR; ++i) {
+            if (i < iters) {
+                const int k = lane + 64 * i, kc = k < KV ? k : KV - 1;
+#pragma unroll
+                for (int j = 0; j < OB; ++j) {
+                    const int o = (o0 + j < O) ? o0 + j : O - 1;
+                    const float4 b = reinterpret_cast<const float4*>(w + (size_t)o * K)[kc];
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) acc[r][j] += xv[r][i].x * b.x + xv[r][i].y * b.y + xv[r][i].z * b.z + xv[r][i].w * b.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int j = 0; j < OB; ++j) acc[r][j] = dcv_wave_sum(acc[r][j]);
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < RW; ++r)
+                if (n0 + r < N)
+#pragma unroll
+                    for (int j = 0; j < OB; ++j)
+                        if (o0 + j < O) y[(size_t)(n0 + r) * O + o0 + j] = dcv_act_apply(acc[r][j] + (bias ? bias[o0 + j] : 0.f), act, slope);
+        }
+    }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int N, int K, int O) {
     const int KV = K / VEC;
@@ -381,6 +439,12 @@ int dcv_linear_fwd(const float* x, const float* w, const float* bias, float* y, 
         if (O <= 8) hipLaunchKernelGGL((linear_fwd_row_kernel<8>), dim3((unsigned)n), dim3(256), 0, st, x, w, bias, y, K, O, act, slope);
         else if (O <= 10) hipLaunchKernelGGL((linear_fwd_row_kernel<10>), dim3((unsigned)n), dim3(256), 0, st, x, w, bias, y, K, O, act, slope);
         else hipLaunchKernelGGL((linear_fwd_row_kernel<16>), dim3((unsigned)n), dim3(256), 0, st, x, w, bias, y, K, O, act, slope);
+    }
+    else if (v4 && O > 16 && n >= 256 && K > 512 && K <= 4 * 64 * 8) {      // a wide head of long rows at a large batch: four sample rows per wave (27 -> 16 us on
+                                                                            // 512 x 2048 -> 100; short rows — 512 -> 1000 — are bound by the per-wave reductions and stores, not by
+                                                                            // the weight traffic: 77 us on the kernel below, 83 / 137 us with 4 / 16 rows per wave)
+        const dim3 rgrid((unsigned)dcv_ceil_div(n, 16), (unsigned)dcv_ceil_div(O, 8));
+        hipLaunchKernelGGL((linear_fwd_rows_kernel<4, 8>), rgrid, dim3(256), 0, st, x, w, bias, y, n, K, O, act, slope);
     }
     else if (v4 && O <= 10 && O > 8) hipLaunchKernelGGL((linear_fwd_kernel<4, 10>), grid, dim3(256), 0, st, x, w, bias, y, n, K, O, act, slope);
     else if (v4) hipLaunchKernelGGL((linear_fwd_kernel<4, 8>), grid, dim3(256), 0, st, x, w, bias, y, n, K, O, act, slope);

@@ -261,7 +261,8 @@ def test_concat_add_flatten(device):
     _check('nchw_to_nhwc', ops.nchw_to_nhwc(x.to(device)), x, 0.)
 
 
-@pytest.mark.parametrize('n,k,o,act', [(8, 1280, 10, 3), (64, 512, 100, 0), (5, 37, 7, 1), (4, 64, 3, 4), (16, 2048, 16, 0), (4, 516, 5, 1)], ids=str)
+@pytest.mark.parametrize('n,k,o,act', [(8, 1280, 10, 3), (64, 512, 100, 0), (5, 37, 7, 1), (4, 64, 3, 4), (16, 2048, 16, 0), (4, 516, 5, 1),
+                                       (258, 2048, 100, 0), (301, 512, 1000, 1)], ids=str)      # (the last two: wide heads at large batches — four sample rows per wave, ragged last wave)
 def test_linear(device, n, k, o, act):
     from deepcv_amd import ops
     from oracle import ops_ref
