@@ -165,38 +165,50 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(Bf16Args a, const u16
         }
     }
 
-    // ---- epilogue: acc[i][j][reg] -> pixel m0 + 16 TI wm + 16 i + 4 lg + reg, channel n0 + 64 wn + 4 li + j
+    // ---- epilogue: acc[i][j][reg] -> pixel m0 + 16 TI wm + 16 i + 4 lg + reg, channel n0 + 64 wn + 4 li + j; the activation and the bounds test as compile-time
+    // cases (round 4, as in the window kernel: the per-element five-way switch was most of the epilogue's instructions)
     const int cbase = n0 + 64 * wn + 4 * li;
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (bias) { const float4 b4 = *reinterpret_cast<const float4*>(bias + cbase); bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w; }
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+    auto epilogue = [&](auto actc, auto fullc) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(actc)::value;
+        constexpr bool FULL = decltype(fullc)::value;
+        const int act = ACT >= 0 ? ACT : a.act;
 #pragma unroll
-    for (int i = 0; i < TI; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const long m = m0 + 16 * TI * wm + 16 * i + 4 * lg + reg;
-            if (m < a.M) {
-                float o[4];
+            for (int reg = 0; reg < 4; ++reg) {
+                const long m = m0 + 16 * TI * wm + 16 * i + 4 * lg + reg;
+                if (FULL || m < a.M) {
+                    float o[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    o[j] = dcv_act_apply(acc[i][j][reg] + bv[j], a.act, a.slope);
-                    ssum[j] += o[j]; ssq[j] += o[j] * o[j];
-                }
-                size_t off = (size_t)m;
-                if (a.phase) {
-                    int jj, ii; long nn;
-                    if (a.magic_w != 0u) { const unsigned um = (unsigned)m, r1 = __umulhi(um, a.magic_w), n2 = __umulhi(r1, a.magic_h); jj = (int)(um - r1 * (unsigned)a.Wout); ii = (int)(r1 - n2 * (unsigned)a.Hout); nn = n2; }
-                    else { jj = (int)(m % a.Wout); const long r1 = m / a.Wout; ii = (int)(r1 % a.Hout); nn = r1 / a.Hout; }
-                    off = ((size_t)nn * a.Hfull + (size_t)ii * a.oh_mul + a.oh_off) * a.Wfull + (size_t)jj * a.ow_mul + a.ow_off;
-                }
-                if constexpr (OUT_BF16) {
-                    const bf16x4 h = (bf16x4){(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
-                    *reinterpret_cast<bf16x4*>(reinterpret_cast<u16*>(yv) + off * a.Cout + cbase) = h;
-                } else {
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(yv) + off * a.Cout + cbase) = make_float4(o[0], o[1], o[2], o[3]);
+                    for (int j = 0; j < 4; ++j) {
+                        o[j] = dcv_act_apply(acc[i][j][reg] + bv[j], act, a.slope);
+                        ssum[j] += o[j]; ssq[j] += o[j] * o[j];
+                    }
+                    size_t off = (size_t)m;
+                    if (a.phase) {
+                        int jj, ii; long nn;
+                        if (a.magic_w != 0u) { const unsigned um = (unsigned)m, r1 = __umulhi(um, a.magic_w), n2 = __umulhi(r1, a.magic_h); jj = (int)(um - r1 * (unsigned)a.Wout); ii = (int)(r1 - n2 * (unsigned)a.Hout); nn = n2; }
+                        else { jj = (int)(m % a.Wout); const long r1 = m / a.Wout; ii = (int)(r1 % a.Hout); nn = r1 / a.Hout; }
+                        off = ((size_t)nn * a.Hfull + (size_t)ii * a.oh_mul + a.oh_off) * a.Wfull + (size_t)jj * a.ow_mul + a.ow_off;
+                    }
+                    if constexpr (OUT_BF16) {
+                        const bf16x4 h = (bf16x4){(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+                        *reinterpret_cast<bf16x4*>(reinterpret_cast<u16*>(yv) + off * a.Cout + cbase) = h;
+                    } else {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(yv) + off * a.Cout + cbase) = make_float4(o[0], o[1], o[2], o[3]);
+                    }
                 }
             }
-        }
+    };
+    {
+        const bool full = m0 + BF_BM <= a.M;
+        if (full && a.act == DCV_ACT_NONE) epilogue(std::integral_constant<int, DCV_ACT_NONE>{}, std::true_type{});
+        else if (full && a.act == DCV_ACT_RELU) epilogue(std::integral_constant<int, DCV_ACT_RELU>{}, std::true_type{});
+        else epilogue(std::integral_constant<int, -1>{}, std::false_type{});
+    }
     if (stats != nullptr) {
         // per-block partial sums: lanes li, li + 16, li + 32, li + 48 hold the same four channels (fixed-order butterfly), then the WM waves of a column
         __syncthreads();                                           // the last K step's fragment reads are done: the stages are free
@@ -677,7 +689,12 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, cons
             mmu[0] = m4.x; mmu[1] = m4.y; mmu[2] = m4.z; mmu[3] = m4.w; mrs[0] = r4.x; mrs[1] = r4.y; mrs[2] = r4.z; mrs[3] = r4.w;
         }
     }
-    auto finish_tile = [&](int dead) __attribute__((always_inline)) {
+    // ACT: the activation as a compile-time constant (-1: the descriptor's, decided per element), FULL: all 256 pixels inside the tensor (round 4: the per-element
+    // five-way switch and bounds test around each of a lane's 16 TI results were most of a tile's epilogue — 6.7 us of a 42 us block on 256 -> 256 @16x16)
+    auto finish_tile_as = [&](int dead, auto actc, auto fullc) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(actc)::value;
+        constexpr bool FULL = decltype(fullc)::value;
+        const int act = ACT >= 0 ? ACT : a.act;
         float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
         uint2 yq[MOM ? TI : 1][4], aq[MOM ? TI : 1][4];             // MOM: the tile's yprev / addend values, all requested before the first use
         if constexpr (MOM) {
@@ -686,7 +703,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, cons
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int m = m0 + 16 * TI * wm + 16 * i + 4 * lg + reg;
-                    const size_t at = (size_t)(m < (int)a.M ? m : 0) * a.Cout + cbase;
+                    const size_t at = (size_t)((FULL || m < (int)a.M) ? m : 0) * a.Cout + cbase;
                     yq[i][reg] = yprev != nullptr ? *reinterpret_cast<const uint2*>(yprev + at) : make_uint2(0u, 0u);
                     aq[i][reg] = addend != nullptr ? *reinterpret_cast<const uint2*>(addend + at) : make_uint2(0u, 0u);
                 }
@@ -696,7 +713,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, cons
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int m = m0 + 16 * TI * wm + 16 * i + 4 * lg + reg;
-                if (m < (int)a.M) {
+                if (FULL || m < (int)a.M) {
                     float o[4];
                     float uu[4] = {0.f, 0.f, 0.f, 0.f};
                     if constexpr (MOM) {
@@ -711,7 +728,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, cons
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        o[j] = dcv_act_apply(acc[i][j][reg] + bv[j], a.act, a.slope) + ad[j];
+                        o[j] = dcv_act_apply(acc[i][j][reg] + bv[j], act, a.slope) + ad[j];
                         ssum[j] += o[j]; ssq[j] += MOM ? o[j] * uu[j] : o[j] * o[j];
                     }
                     if constexpr (OUT_BF16) {
@@ -749,6 +766,12 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, cons
                 if (row < rows_here) stats[((size_t)q * a.Cout + n0 + c) * rows_total + a.stat_row0 + row] = v;            // [2][Cout][rows]
             }
         }
+    };
+    auto finish_tile = [&](int dead) __attribute__((always_inline)) {
+        const bool full = m0 + BMH <= (int)a.M;
+        if (full && a.act == DCV_ACT_NONE) finish_tile_as(dead, std::integral_constant<int, DCV_ACT_NONE>{}, std::true_type{});
+        else if (full && a.act == DCV_ACT_RELU) finish_tile_as(dead, std::integral_constant<int, DCV_ACT_RELU>{}, std::true_type{});
+        else finish_tile_as(dead, std::integral_constant<int, -1>{}, std::false_type{});
     };
 
     unsigned wv_cur = wv_of(m0), wv_nxt = (PERSIST && tile + gstep < ntiles) ? wv_of(m0 + gstep * BMH) : 0u;
