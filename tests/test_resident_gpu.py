@@ -117,6 +117,39 @@ def test_general_paths_on_a_3x3_variant_of_the_stock_model(device, params, bs):
         assert torch.allclose(ba.float(), bb.float(), rtol=1e-5, atol=1e-7), name
 
 
+@pytest.mark.parametrize('offset', [0.0, 12.0])
+def test_channels_far_from_zero_against_the_oracle_in_double_precision(device, params, offset):
+    """ The backward launch derives a sample's sums of u, u^2 (GroupNorm algebra) from the forward's fp32 sums of y, y^2; with a channel mean many standard
+    deviations from zero (every convolution bias moved by `offset`: 20 - 40 sigma of the pre-activations) that subtraction cancels.  The
+    referee is the oracle in DOUBLE precision: the derived sums stay consistent with the forward's GroupNorm statistics (same inputs), and the launches
+    end up closer to it than the per-layer kernels (tools/offset_err.py: 1.5e-4 against 7.3e-4 of a tensor's largest gradient at offset 12). """
+    import copy
+    from test_model_gpu import _build
+    from deepcv_amd import resident
+    g = torch.Generator().manual_seed(DATA_SEED)
+    x, y = torch.randn(64, 3, 32, 32, generator=g), torch.randint(0, 10, (64,), generator=g)
+    a, oracle = _build(params, 'image_classifier_model', 10)
+    b = copy.deepcopy(a)
+    a, b, oracle = a.to(device), b.to(device), oracle.double()
+    shifted = 0
+    for m in (a, b, oracle):
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Conv2d) and mod.bias is not None:
+                with torch.no_grad(): mod.bias.add_(offset)
+                shifted += 1
+    assert shifted == 3 * 5
+    oracle.train()
+    torch.nn.CrossEntropyLoss()(oracle(x.double()), y).backward()
+    _, _, n_a = _run(a, x.to(device), y.to(device), True, True)
+    _run(b, x.to(device), y.to(device), False)
+    assert n_a == 1, f'the resident path did not run: {resident.why_not(a, x.to(device))}'
+    gscale = max(p.grad.abs().max().item() for p in oracle.parameters())
+    for tag, m, rel in (('persistent launches', a, 2e-4 if offset == 0.0 else 1e-3), ('per-layer kernels', b, 2e-4 if offset == 0.0 else 5e-3)):
+        for (name, pm), (_, po) in zip(m.named_parameters(), oracle.named_parameters()):
+            err = (pm.grad.double().cpu() - po.grad).abs().max().item()
+            assert err <= rel * max(po.grad.abs().max().item(), 1e-2 * gscale), f'{tag}, {name}: {err:.3e} (max {po.grad.abs().max().item():.3e}, model {gscale:.3e})'
+
+
 def test_weight_gradients_outside_the_backward_launch(device, params):
     """ `DCV_RESIDENT_WGRAD=0`: the persistent backward launch leaves the weight gradients to the multi-layer launch, which reads its dz tensors. """
     from deepcv_amd import resident

@@ -1,5 +1,5 @@
 """Throughput of the bf16 storage convolution entry points (C-ABI dcv_conv2d_bf16_fwd / _dgrad / _wgrad), timed with HIP events on the launch stream.
-usage: bf16_bench.py [launches] [case ...]    case = Cin,H,Cout[,N]   (3x3, stride 1, pad 1)"""
+usage: bf16_bench.py [launches] [case ...]    case = Cin,H,Cout[,N[,stride]]   (3x3, pad 1)"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -25,20 +25,22 @@ def timed(fn):
 for case in cases:
     cin, h, cout = case[:3]
     n = case[3] if len(case) > 3 else 512
-    d = nat.Conv2dDesc(n, h, h, cin, cout, 3, 3, 1, 1, 1, 1, 1, 1, 1, h, h, nat.LAYOUT_NHWC, nat.ACT_RELU, 0., nat.MATH_BF16)
+    sd = case[4] if len(case) > 4 else 1
+    ho = (h + 2 - 3) // sd + 1
+    d = nat.Conv2dDesc(n, h, h, cin, cout, 3, 3, sd, sd, 1, 1, 1, 1, 1, ho, ho, nat.LAYOUT_NHWC, nat.ACT_RELU, 0., nat.MATH_BF16)
     x = torch.randn(n, cin, h, h, device=dev).to(torch.bfloat16).contiguous(memory_format=cl)
-    dy = torch.randn(n, cout, h, h, device=dev).to(torch.bfloat16).contiguous(memory_format=cl)
+    dy = torch.randn(n, cout, ho, ho, device=dev).to(torch.bfloat16).contiguous(memory_format=cl)
     wt = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
     b = torch.zeros(cout, device=dev)
-    flops = 2.0 * n * h * h * cout * cin * 9
-    line = f'{cin}->{cout} 3x3 @{h}x{h} N={n}:'
+    flops = 2.0 * n * ho * ho * cout * cin * 9
+    line = f'{cin}->{cout} 3x3{"" if sd == 1 else " / %d" % sd} @{h}x{h} N={n}:'
     for op in (0, 1):
         f = torch.empty(int(lib.dcv_conv2d_bf16_filter_bytes(d, op)), dtype=torch.uint8, device=dev)
         nat.check(lib.dcv_conv2d_bf16_prepare_filters(1, (ctypes.POINTER(nat.Conv2dDesc) * 1)(ctypes.pointer(d)), (ctypes.c_int * 1)(op), (ctypes.c_void_p * 1)(wt.data_ptr()),
                                                       (ctypes.c_void_p * 1)(f.data_ptr()), st))
         for odt, tag in ((torch.bfloat16, 'bf16'), (torch.float32, 'f32')):
             if op == 0:
-                y = torch.empty((n, cout, h, h), dtype=odt, device=dev).contiguous(memory_format=cl)
+                y = torch.empty((n, cout, ho, ho), dtype=odt, device=dev).contiguous(memory_format=cl)
                 rows, rps = ctypes.c_int(0), ctypes.c_int(0)
                 lib.dcv_conv2d_bf16_fwd_stats_layout(d, ctypes.byref(rows), ctypes.byref(rps))
                 stats = torch.empty((2, cout, rows.value), dtype=torch.float64, device=dev)
