@@ -226,6 +226,7 @@ _SIGNATURES = {
     'dcv_add': (_c_int, [_P, _P, _P, _c_size_t, _P]),
     'dcv_add_bf16': (_c_int, [_P, _P, _P, _c_size_t, _P]),
     'dcv_scale': (_c_int, [_P, _c_float, _P, _c_size_t, _P]),
+    'dcv_gather_f32': (_c_int, [_P, _P, _P, _c_size_t, _P]),
     'dcv_transpose_inner': (_c_int, [_P, _P, _c_int, _c_int, _c_int, _P]),
     'dcv_linear_bwd_workspace_bytes': (_c_size_t, [_c_int, _c_int, _c_int]),
     'dcv_linear_bwd': (_c_int, [_P, _P, _c_int, _c_float, _P, _P, _P, _P, _P, _c_int, _c_int, _c_int, _P, _c_size_t, _P]),

@@ -210,6 +210,12 @@ __global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ a,
     }
 }
 
+// dst[i] = src[index[i]], 0 where index[i] < 0: a small tensor re-laid by an index map made once on the host (a first layer's filter regrouped for the im2col /
+// folded-rows kernels and its gradient on the way back, deepcv_amd/ops.py `_RegroupFn`: as a library launch the re-layout is part of a replayed launch list)
+__global__ __launch_bounds__(256) void gather_f32_kernel(const float* __restrict__ src, const int* __restrict__ index, float* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { const int k = index[i]; dst[i] = k >= 0 ? src[k] : 0.f; }
+}
+
 // [N][A][B] -> [N][B][A] through a 32x33 LDS tile (coalesced on both sides; +1 padding avoids bank conflicts)
 __global__ __launch_bounds__(256) void transpose_inner_kernel(const float* __restrict__ x, float* __restrict__ y, int A, int B) {
     __shared__ float tile[32][33];
@@ -649,6 +655,12 @@ int dcv_scale(const float* a, float alpha, float* out, size_t numel, void* strea
     hipStream_t st = dcv_stream(stream);
     if (numel % 4 == 0 && aligned16(a) && aligned16(out)) hipLaunchKernelGGL((scale_kernel<4>), dim3(dcv_stream_grid(numel / 4, 256)), dim3(256), 0, st, a, alpha, out, numel / 4);
     else hipLaunchKernelGGL((scale_kernel<1>), dim3(dcv_stream_grid(numel, 256)), dim3(256), 0, st, a, alpha, out, numel);
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_gather_f32(const float* src, const int* index, float* dst, size_t numel, void* stream) {
+    DCV_CHECK_ARG(src && index && dst && numel > 0);
+    hipLaunchKernelGGL(gather_f32_kernel, dim3(dcv_stream_grid(numel, 256)), dim3(256), 0, dcv_stream(stream), src, index, dst, numel);
     DCV_RETURN_LAUNCH();
 }
 

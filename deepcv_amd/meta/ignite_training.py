@@ -607,7 +607,7 @@ def train(hp: HYPERPARAMS_T, model: torch.nn.Module, losses: LOSS_FN_TERMS_T = N
 
     Args:
         - hp: hyper-parameters; required: `optimizer_opts`, `epochs`, `batch_size`; optional: see `TRAINING_HP_DEFAULTS` below (reference `:201-203`), plus
-          `hip_graph` (None = auto: capture the step into a hipGraph — always in one process, below 5M parameters under data parallelism), `graph_collective` (capture the
+          `hip_graph` (None = auto: capture the step into a hipGraph — in one process and under data parallelism alike), `graph_collective` (capture the
           RCCL gradient all-reduce inside that graph; None = `DCV_GRAPH_COLLECTIVE`, off by default), `num_workers`, `bucket_cap_mb`,
           `device_transform` (callable applied on the device to the images of every prefetched batch, e.g. `DeviceNormalize` for raw uint8 pixels),
           `conv_math` ('fp32' | 'bf16': arithmetic of the MFMA convolution kernels, see `deepcv_amd.ops.set_conv_math`), `native_allreduce` (None =
@@ -688,10 +688,12 @@ def train(hp: HYPERPARAMS_T, model: torch.nn.Module, losses: LOSS_FN_TERMS_T = N
 
     use_graph = hp['hip_graph']
     if use_graph is None:
-        # auto: one process -> always (the captured step is the faster one for every spec measured: 261 k against 199 k img/s on cifar100_deep, 30.0 k against 29.7 k
-        # on resnet18_style at bs 512, bf16); data parallel -> below 5 M parameters (one gradient bucket: nothing to overlap); above, the eager step's autograd hooks
-        # start each bucket's all-reduce inside the backward pass, which a captured step only does when it replays as a launch list (`GraphedTrainStep._marks`)
-        use_graph = backend_conf.is_cuda and (not backend_conf.distributed or sum(p.numel() for p in model.parameters()) < 5_000_000)
+        # auto: always.  One process: the captured step is the faster one for every spec measured (277 k against 174 k img/s on cifar100_deep, 45.8 k against 44.8 k
+        # on resnet18_style at bs 512, bf16).  Data parallel: a captured step of several gradient buckets replays as a launch list in segments, each bucket's
+        # all-reduce started inside the backward pass (`GraphedTrainStep._marks`) — since round 4's last session also for the wide specs, whose steps now consist of
+        # this library's launches only (`ops._regroup`); world-size-1 rehearsal with forced collectives (`tools/wide_dp_bench.py`, bs 512, bf16): cifar100_deep
+        # 2.00 ms captured against 3.62 eager with hooks (six 8 MB buckets), 1.91 against 2.54 (one bucket), resnet18_style 11.58 against 11.77 (two buckets)
+        use_graph = backend_conf.is_cuda
     if hp['use_sync_batch_norm'] and backend_conf.distributed:
         use_graph = False    # SyncBatchNorm all-reduces statistics inside forward and backward: collectives are not captured into the step graph
     graphed_step = graphed_train_step(model, optimizer, losses, weights, reducer, graph_collective=hp['graph_collective']) if (use_graph and backend_conf.is_cuda) else None

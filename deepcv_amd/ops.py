@@ -162,6 +162,49 @@ def _f32(x):
     return x
 
 
+_regroup_maps = {}
+
+
+def _regroup(weight: torch.Tensor, key, relayout) -> torch.Tensor:
+    """ `relayout(weight)` — a re-layout of a small filter made of pad / reshape / permute — as ONE library launch with autograd (`_RegroupFn`): the index map is
+    made once per (key, shape, device) by running `relayout` over the element numbers on the host.  As torch operators the re-layout and its gradient were the
+    only kernels of a captured wide-spec step which were not this library's (`tools/foreign_ops.py`), i.e. what kept such a step from replaying as a launch list. """
+    mk = (key, tuple(weight.shape), weight.device)
+    maps = _regroup_maps.get(mk)
+    if maps is None:
+        n = weight.numel()
+        if n >= (1 << 24):
+            return relayout(weight)                                # (element numbers are carried in fp32)
+        out = relayout(torch.arange(1, n + 1, dtype=torch.float32).reshape(weight.shape))      # 0 where the re-layout pads
+        fwd = out.reshape(-1).to(torch.int64) - 1
+        inv = torch.full((n,), -1, dtype=torch.int64)
+        pos = torch.nonzero(fwd >= 0).reshape(-1)
+        inv[fwd[pos]] = pos
+        maps = _regroup_maps[mk] = (fwd.to(torch.int32).to(weight.device), inv.to(torch.int32).to(weight.device), tuple(out.shape))
+    return _RegroupFn.apply(weight, *maps)
+
+
+class _RegroupFn(torch.autograd.Function):
+    """ out[i] = weight[fwd[i]] (0 where fwd[i] < 0); backward: dweight[j] = dout[inv[j]] (every element of the weight occurs once in the re-layout). """
+
+    @staticmethod
+    def forward(ctx, weight, fwd, inv, shape):
+        nat.require_device(weight)
+        w = weight.detach().contiguous()
+        out = torch.empty(shape, dtype=torch.float32, device=w.device)
+        nat.check(lib.dcv_gather_f32(w.data_ptr(), fwd.data_ptr(), out.data_ptr(), out.numel(), nat.current_stream(w.device)), 'dcv_gather_f32')
+        ctx.inv, ctx.weight_ref = inv, weight
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        weight = ctx.weight_ref
+        g = g if g.is_contiguous() else g.contiguous()
+        dw = _grad_buffer(weight, like=weight)
+        nat.check(lib.dcv_gather_f32(g.data_ptr(), ctx.inv.data_ptr(), dw.data_ptr(), dw.numel(), nat.current_stream(g.device)), 'dcv_gather_f32')
+        return dw, None, None, None
+
+
 _stem_gemm = os.environ.get('DCV_STEM_GEMM', '1') not in ('0', 'false', 'False', '')
 
 
@@ -169,8 +212,7 @@ def _stem_as_gemm(x, weight, stride, padding, dilation):
     """ A first layer (cin <= 4: the 3x3 layer of a CIFAR spec, the 7x7 / 2 stem of a ResNet) in bf16 storage mode: its K = cin * R * S is far too small for the
     implicit-GEMM kernels (they step over 64 input channels of one tap) and the direct / sliding-window kernels which served it ran on the VALU (resnet18_style,
     bs 64: 0.40 ms forward + 0.83 ms weight gradient of a 6.4 ms step).  Rewritten as im2col + 1x1: `dcv_im2col_bf16` expands the input once into a bf16 matrix
-    [n ho wo][kpad], the OIHW filter flattened per output channel and zero-padded to kpad is the 1x1 layer's filter (plain torch ops on the parameter: autograd
-    carries dW back), and the bf16 kernels do the rest — forward as any 1x1 layer, weight gradient on the one-tap instance of the all-taps kernel.  Only for
+    [n ho wo][kpad], the OIHW filter flattened per output channel and zero-padded to kpad is the 1x1 layer's filter (`_regroup`: one library launch each way), and the bf16 kernels do the rest — forward as any 1x1 layer, weight gradient on the one-tap instance of the all-taps kernel.  Only for
     inputs which need no gradient (the model input).  Returns (x_col, w_col) or None. """
     if not (_stem_gemm and _conv_math == nat.MATH_BF16 and _bf16_storage) or x.dtype != torch.float32 or x.dim() != 4 or x.requires_grad or not x.is_cuda:
         return None
@@ -196,7 +238,7 @@ def _stem_as_gemm(x, weight, stride, padding, dilation):
     with torch.no_grad():
         x_col = torch.empty((d.n, kpad, d.ho, d.wo), dtype=torch.bfloat16, device=x.device, memory_format=_CL)
         nat.check(lib.dcv_im2col_bf16(d, x.data_ptr(), x_col.data_ptr(), kpad, nat.current_stream(x.device)), 'dcv_im2col_bf16')
-    w_col = torch.nn.functional.pad(weight.reshape(cout, k), (0, kpad - k)).reshape(cout, kpad, 1, 1)
+    w_col = _regroup(weight, ('col', kpad), lambda w: torch.nn.functional.pad(w.reshape(cout, k), (0, kpad - k)).reshape(cout, kpad, 1, 1))
     return x_col, w_col
 
 
@@ -207,7 +249,7 @@ def _stem_as_folded_rows(x, weight, d):
     """ A STRIDED first layer (the 7x7 / 2 stem of a ResNet) without the im2col matrix — 2.5 GB written and read twice per step at 512 x 3 x 224 x 224, a quarter
     of resnet18_style's bf16 step.  `dcv_space_to_depth_bf16` moves the stride into the channels: X[n][i][j][(a sw + b) cin + c] = x[n][c][i sh + a - ph][j sw + b - pw]
     (bf16 NHWC, 16 channels, 217 MB), over which the layer is a stride-1, pad-0 layer of A x A taps, A = ceil(R / stride) = 4, whose filter is the zero-extended
-    OIHW filter regrouped the same way (plain torch ops on the parameter: autograd carries dW back).  Four taps x 16 channels of a row are 64 consecutive values of
+    OIHW filter regrouped the same way (`_regroup`: one library launch each way).  Four taps x 16 channels of a row are 64 consecutive values of
     X, so the bf16 kernels run it in place as four taps of 64 channels ("folded rows", conv2d_bf16.hip).  Returns (X, w2) or None. """
     sh, sw = d.stride_h, d.stride_w
     if not _stem_s2d or sh != sw or sh < 2 or d.r != d.s or d.dil_h != 1 or d.dil_w != 1:
@@ -224,10 +266,13 @@ def _stem_as_folded_rows(x, weight, d):
     with torch.no_grad():
         xs = torch.empty((d.n, 16, hs, ws), dtype=torch.bfloat16, device=x.device, memory_format=_CL)
         nat.check(lib.dcv_space_to_depth_bf16(d, x.data_ptr(), xs.data_ptr(), hs, ws, 16, nat.current_stream(x.device)), 'dcv_space_to_depth_bf16')
-    w = torch.nn.functional.pad(weight, (0, a * sw - d.s, 0, a * sh - d.r))                       # [co][c][A sh][A sw]: taps beyond R, S are zero
-    w = w.reshape(cout, cin, a, sh, a, sw).permute(0, 3, 5, 1, 2, 4).reshape(cout, sh * sw * cin, a, a)      # [co][(a, b, c)][ra][rb]
-    w2 = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 16 - sh * sw * cin))
-    return xs, w2
+    r_, s_ = d.r, d.s
+
+    def fold(w):
+        w = torch.nn.functional.pad(w, (0, a * sw - s_, 0, a * sh - r_))                        # [co][c][A sh][A sw]: taps beyond R, S are zero
+        w = w.reshape(cout, cin, a, sh, a, sw).permute(0, 3, 5, 1, 2, 4).reshape(cout, sh * sw * cin, a, a)      # [co][(a, b, c)][ra][rb]
+        return torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 16 - sh * sw * cin))
+    return xs, _regroup(weight, ('fold', sh, sw, a), fold)
 
 
 _dgrad_moments = os.environ.get('DCV_DGRAD_MOMENTS', '1') not in ('0', 'false', 'False', '')

@@ -423,6 +423,10 @@ int dcv_add(const float* a, const float* b, float* out, size_t numel, void* stre
 int dcv_add_bf16(const void* a_bf16, const void* b_bf16, void* out_bf16, size_t numel, void* stream);   /* bf16 tensors (16-byte aligned), fp32 sum rounded once */
 /* out = alpha * a */
 int dcv_scale(const float* a, float alpha, float* out, size_t numel, void* stream);
+/* dst[i] = index[i] >= 0 ? src[index[i]] : 0 for i < numel — the re-layout of a small tensor through a host-made index map.  Replaces the torch operators
+ * (pad / reshape / permute on the parameter, and their autograd) with which a first layer's OIHW filter (`submodule_creators.py:251`: Conv2d(**params)) was
+ * regrouped for the im2col and folded-rows kernels: as a library launch the re-layout and its gradient are part of a replayed launch list. */
+int dcv_gather_f32(const float* src, const int* index, float* dst, size_t numel, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Input side: uint8 images -> normalised fp32 activations on the device, fusing torchvision's ToTensor (HWC u8 -> CHW f32 / 255)

@@ -67,7 +67,7 @@ def _dp_global_batches():
     return [(torch.randn(16, 3, 32, 32, generator=g), torch.randint(0, 10, (16,), generator=g)) for _ in range(DP_STEPS)]
 
 
-def _hip_dp_worker(rank, port, out_dir, backend, spec, graph, native=False, bucket_mb=32.):
+def _hip_dp_worker(rank, port, out_dir, backend, spec, graph, native=False, bucket_mb=32., bf16=False, classes=10):
     """ One rank of a data-parallel run on the HIP path, built the way `train()` builds it: native model, `DataParallelModel` (rank-0 broadcast, gradient arena),
     native AdamW, `graphed_train_step` (or the eager step with autograd hooks).  `gloo`: both ranks share GPU 0; `nccl` (RCCL): one GPU per rank. """
     import torch
@@ -89,8 +89,11 @@ def _hip_dp_worker(rank, port, out_dir, backend, spec, graph, native=False, buck
     else:
         dist.init_process_group('gloo', rank=rank, world_size=WORLD)
     params = load_parameters()
+    if bf16:
+        from deepcv_amd import ops as _ops
+        _ops.set_conv_math('bf16'); _ops.set_bf16_storage(True)
     torch.manual_seed(SEED + rank)            # different init per rank: the wrapper's broadcast must make the replicas identical
-    model = create_model({'trainset': SyntheticImageDataset(8)}, params[spec]).to(device)
+    model = create_model({'trainset': SyntheticImageDataset(8, (3, 32, 32), classes)}, params[spec]).to(device)
     dp = DataParallelModel(model, overlap=True, native_allreduce=native, bucket_cap_mb=bucket_mb)
     assert dp.reducer.native_active() == bool(native)
     hp = dict(params['train_image_classifier']); hp['epochs'] = 1
@@ -122,20 +125,26 @@ def _hip_dp_worker(rank, port, out_dir, backend, spec, graph, native=False, buck
     dist.destroy_process_group()
 
 
-def _run_hip_dp(backend, spec, graph, params, native=False, bucket_mb=32.):
+def _spawn_hip_dp(backend, spec, graph, native=False, bucket_mb=32., bf16=False, classes=10):
     import socket
     import tempfile
     import torch
     import torch.multiprocessing as mp
-    from oracle import deepcv_oracle as O
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_hip_dp_worker, args=(port, d, backend, spec, graph, native, bucket_mb), nprocs=WORLD, join=True)
+        mp.spawn(_hip_dp_worker, args=(port, d, backend, spec, graph, native, bucket_mb, bf16, classes), nprocs=WORLD, join=True)
         r = [torch.load(Path(d) / f'rank{k}.pt', weights_only=False) for k in range(WORLD)]
     for a, b in zip(r[0]['params'], r[1]['params']):
         assert torch.equal(a, b), 'replicas must stay bit-identical'
+    return r
+
+
+def _run_hip_dp(backend, spec, graph, params, native=False, bucket_mb=32.):
+    import torch
+    from oracle import deepcv_oracle as O
+    r = _spawn_hip_dp(backend, spec, graph, native, bucket_mb)
     torch.manual_seed(SEED)                   # the replicas start from rank 0's weights
     ref_model = O.create_model((3, 32, 32), params[spec], 10)
     hp = dict(params['train_image_classifier']); hp['epochs'] = 1
@@ -183,6 +192,23 @@ def test_captured_steps_start_each_bucket_collective_inside_the_backward_pass(de
         assert idx == sorted(idx) and 0 < idx[0] and idx[-1] <= x['list_calls']
         assert len({b for b, _ in x['marks']}) == len(x['marks'])           # every bucket marked once
     assert r[0]['graph_replays'] == DP_STEPS - 2
+
+
+def test_captured_steps_of_a_wide_bf16_spec_replay_as_segmented_launch_lists(device):
+    """ cifar100_deep on the bf16 storage path, two ranks over gloo, 4 MB buckets: since the first layer's filter re-layout is a library launch (`ops._regroup`,
+    `dcv_gather_f32`) a captured step of a wide spec consists of this library's launches only, passes the list-against-graph verification and replays in
+    segments with every bucket's all-reduce started inside the backward pass — what only the small specs did before.  Referee: the same run on the eager step
+    with autograd hooks (same kernels, same collectives: the losses of every step and rank agree to fp32 rounding of the bucket means). """
+    cap = _spawn_hip_dp('gloo', 'cifar100_deep_model', True, bucket_mb=4., bf16=True, classes=100)
+    eag = _spawn_hip_dp('gloo', 'cifar100_deep_model', False, bucket_mb=4., bf16=True, classes=100)
+    lists = os.environ.get('DCV_REPLAY_LIST', '1') not in ('0', 'false', 'False')
+    for k in range(WORLD):
+        assert cap[k]['buckets'] >= 4, cap[k]['buckets']
+        for a, b in zip(cap[k]['losses'], eag[k]['losses']):
+            assert abs(a - b) <= 2e-5 * abs(b), (cap[k]['losses'], eag[k]['losses'])
+        if lists:
+            assert cap[k]['list_replay'] and len(cap[k]['marks']) >= 3, (cap[k]['list_replay'], cap[k]['marks'], cap[k]['list_calls'])
+    assert cap[0]['graph_replays'] == DP_STEPS - 2
 
 
 @pytest.mark.parametrize('graph', [True, False], ids=['hipgraph', 'eager-hooks'])

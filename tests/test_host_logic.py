@@ -261,3 +261,45 @@ def test_resident_recording_state_is_per_thread():
         assert resident.staged_program() is None and not resident.staging_consumed()      # the other thread's staging request is its own
     assert seen == {'recorder': None, 'raised': False, 'staging': False}
     assert resident.recorder() is None
+
+
+@pytest.mark.parametrize('shape,kind', [((64, 3, 3, 3), 'col'), ((64, 3, 7, 7), 'fold'), ((128, 1, 13, 13), 'fold4')])
+def test_filter_regroup_index_maps_reproduce_the_torch_relayout_and_its_gradient(monkeypatch, shape, kind):
+    """ `ops._regroup` replaces pad / reshape / permute on a first layer's filter by one gather launch each way; the index maps are host logic: forward map =
+    the re-layout, inverse map = its autograd (every filter element occurs once, padding is zero).  The launch itself is stood in for by index_select here. """
+    import torch.nn.functional as F
+    from deepcv_amd import ops
+
+    class Gather(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, w, fwd, inv, out_shape):
+            ctx.inv, ctx.wshape = inv, w.shape
+            flat = torch.cat([w.reshape(-1), w.new_zeros(1)])
+            return flat[fwd.long()].reshape(out_shape)             # (index -1 -> the appended zero)
+
+        @staticmethod
+        def backward(ctx, g):
+            flat = torch.cat([g.reshape(-1), g.new_zeros(1)])
+            return flat[ctx.inv.long()].reshape(ctx.wshape), None, None, None
+    monkeypatch.setattr(ops, '_RegroupFn', Gather)
+    cout, cin, r, s = shape
+    if kind == 'col':
+        k, kpad = cin * r * s, 64
+        relayout, key = (lambda w: F.pad(w.reshape(cout, k), (0, kpad - k)).reshape(cout, kpad, 1, 1)), ('col', kpad)
+    else:
+        sh = 2 if kind == 'fold' else 4
+        a = -(-r // sh)
+
+        def relayout(w):
+            w = F.pad(w, (0, a * sh - s, 0, a * sh - r))
+            w = w.reshape(cout, cin, a, sh, a, sh).permute(0, 3, 5, 1, 2, 4).reshape(cout, sh * sh * cin, a, a)
+            return F.pad(w, (0, 0, 0, 0, 0, 16 - sh * sh * cin))
+        key = ('fold', sh, sh, a)
+    torch.manual_seed(3)
+    w1 = torch.randn(shape, requires_grad=True)
+    w2 = w1.detach().clone().requires_grad_(True)
+    ref, got = relayout(w1), ops._regroup(w2, key, relayout)
+    assert got.shape == ref.shape and torch.equal(got, ref)
+    g = torch.randn_like(ref)
+    ref.backward(g); got.backward(g)
+    assert torch.equal(w1.grad, w2.grad)
