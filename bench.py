@@ -423,8 +423,19 @@ def config3_roofline(secondary):
     if not pick:
         return None
     r = pick[0]
+    # HBM bytes per launch of the bf16-output instance of the kernel at this shape (forward and data gradient are the same instance on same-sized tensors),
+    # from the latest round's PMC passes over tools/bf16_bench.py (tools/gpu_r4_records.sh -> tools/pmc_kernels.py); the kernel is bound by the matrix pipe:
+    # the bytes say how far it is from the memory roof (67 MB in + 67 MB out are the algorithmic ones)
+    traffic = traffic_src = None
+    for pmc in sorted((ROOT / 'profiles').glob('r*_pmc_bf16_256_16_256.json'), reverse=True):
+        rec = json.loads(pmc.read_text())
+        k = rec.get('kernels', {}).get('conv_bf16_halo_kernel<2, true, false, false>')
+        if k:
+            traffic, traffic_src = k['read_bytes_per_dispatch'] + k['write_bytes_per_dispatch'], f'{pmc.name} @ {rec.get("commit", "?")}'
+        break
     return {'bound': 'mfma', 'kernel': 'conv_bf16_halo_kernel<2, bf16 out> (dcv_conv2d_bf16_fwd: 3x3 window kernel, 256 -> 256 @16x16, N = 512, statistics epilogue on)',
-            'achieved': r['achieved'], 'peak': MFMA_BF16_PEAK_TF, 'unit': 'TFLOP/s', 'frac': r['frac'], 'traffic': None, 'avg_launch_us': r['avg_launch_us'],
+            'achieved': r['achieved'], 'peak': MFMA_BF16_PEAK_TF, 'unit': 'TFLOP/s', 'frac': r['frac'], 'traffic': traffic,
+            'traffic_unit': 'bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE)', 'traffic_source': traffic_src, 'avg_launch_us': r['avg_launch_us'],
             'algorithmic_flops_per_launch': 2.0 * BATCH_PER_GPU * 16 * 16 * 256 * 256 * 9,
             'also': [{'op': q['op'], 'achieved': q['achieved'], 'frac': q['frac'], 'avg_launch_us': q['avg_launch_us']} for q in rows if q is not r]}
 

@@ -1,9 +1,9 @@
 #!/bin/bash
-# kernel trace of the multi-bucket data-parallel rehearsal (tools/dp_overlap_trace.py): prints where RCCL's kernels sit in a replayed step; gpurun_out/r4/dp_overlap.txt
+# kernel trace of the multi-bucket data-parallel rehearsal (tools/dp_overlap_trace.py [spec] [bucket_mb]): prints where RCCL's kernels sit in a replayed step; gpurun_out/r4/dp_overlap.txt
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $O/tr -o t -- python3 $R/tools/dp_overlap_trace.py 4 > $O/dp_overlap.log 2>&1 || { tail -8 $O/dp_overlap.log; exit 1; }
+timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $O/tr -o t -- python3 $R/tools/dp_overlap_trace.py 4 $1 $2 > $O/dp_overlap.log 2>&1 || { tail -8 $O/dp_overlap.log; exit 1; }
 tail -2 $O/dp_overlap.log
 python3 - "$O" <<'PY'
 import csv, glob, sys

@@ -38,7 +38,7 @@ for case in 256,16,256 512,8,512; do
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/w -o w -- $CMD > $O/w.log 2>&1 || { tail -5 $O/w.log; exit 1; }
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/m -o m -- $CMD > $O/m.log 2>&1 || { tail -5 $O/m.log; exit 1; }
   python3 $R/tools/pmc_kernels.py $O/r04_pmc_bf16_${case//,/_}.json r04 $C "rocprofv3 --kernel-trace --pmc <...> -- python3 tools/bf16_bench.py 10 $case (N = 512, 3x3; separate passes)" \
-    $O/f $O/w $O/m conv_bf16_halo_kernel conv_bf16_wgrad9p_kernel mfma_wgrad9_reduce > $O/summary.txt || { tail -5 $O/summary.txt; exit 1; }
+    $O/f $O/w $O/m conv_bf16_halo_kernel "conv_bf16_halo_kernel<2, true, false, false>" conv_bf16_wgrad9p_kernel mfma_wgrad9_reduce > $O/summary.txt || { tail -5 $O/summary.txt; exit 1; }
   python3 -c "import json; r=json.load(open('$O/r04_pmc_bf16_${case//,/_}.json')); [print('$case', k, v.get('avg_duration_us'), v.get('mfma_busy_frac_of_simd_cycles')) for k, v in r['kernels'].items()]"
   rm -rf $O/f $O/w $O/m
 done
