@@ -44,6 +44,7 @@ struct Bf16Args {
     int phase, oh_mul, ow_mul, oh_off, ow_off, Hfull, Wfull;      // strided data gradient: this launch writes phase (oh_off, ow_off) of the full tensor
     unsigned magic_w, magic_h;     // the window kernel: floor((2^32 - 1) / Win) + 1, ... / Hin + 1: n / d = mulhi(n, magic) for n d < 2^32
     int pix;                       // elements between neighbouring pixels of the tensor read (Cin; the folded first layer: the real channel count, see fold_rows below)
+    int xcd_tiles;                 // the one-tile-per-block window kernel: > 0 = pixel tiles of the launch, blocks mapped so that a tile's channel tiles share an XCD (below)
     int stat_rows, stat_row0;      // a launch over a SLICE of the batch (tensors beyond 2 GiB run as several launches): rows of the whole statistics array (0: this launch's own) and this slice's first row
 };
 
@@ -73,8 +74,15 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(Bf16Args a, const u16
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 15, lg = lane >> 4;
-    const long m0 = (long)blockIdx.x * BF_BM;
-    const int n0 = blockIdx.y * BN;
+    // (XCD-aware block order when the launch has several channel tiles: see conv_bf16_halo_kernel — a pixel tile's channel tiles read the same pixels)
+    int bx = blockIdx.x, by = blockIdx.y, gx = gridDim.x;
+    if (a.xcd_tiles > 0) {
+        const int cts = a.Cout / BN, L = (int)blockIdx.x, grp = L / (8 * cts), r = L - grp * 8 * cts;
+        bx = grp * 8 + (r & 7); by = r >> 3; gx = a.xcd_tiles;
+        if (bx >= gx) return;
+    }
+    const long m0 = (long)bx * BF_BM;
+    const int n0 = by * BN;
 
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (int)a.x_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, (int)a.w_bytes, 0x00020000);
@@ -227,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(Bf16Args a, const u16
             double v = 0.0;
 #pragma unroll
             for (int w = 0; w < WM; ++w) v += red[((w * WN + wnn) * 2 + q) * 64 + cc];
-            stats[((size_t)q * a.Cout + n0 + c) * (a.stat_rows ? a.stat_rows : (int)gridDim.x) + a.stat_row0 + blockIdx.x] = v;      // [2][Cout][rows]
+            stats[((size_t)q * a.Cout + n0 + c) * (a.stat_rows ? a.stat_rows : gx) + a.stat_row0 + bx] = v;      // [2][Cout][rows]
         }
     }
 }
@@ -600,7 +608,17 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, cons
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 15, lg = lane >> 4;
-    const int n0 = blockIdx.y * BN;
+    // XCD-aware block order of the one-tile-per-block instance (round 4): the channel tiles of one pixel tile read the SAME input window, but as grid (tiles, channel
+    // tiles) they were hundreds of blocks apart — the second one fetched the window again from beyond the L2 (PMC: 258 MB per launch on 256 -> 256 @16x16, N = 512,
+    // against 134 MB of tensors).  Blocks are dispatched round-robin over the eight XCDs in linear order, so in a 1-D grid the ids L and L + 8 share an XCD and run
+    // side by side: L = (tile / 8) 8 cts + ct 8 + tile % 8.
+    int tile0 = blockIdx.x, ct0 = blockIdx.y;
+    if (!PERSIST && a.xcd_tiles > 0) {
+        const int cts = a.Cout / BN, L = (int)blockIdx.x, grp = L / (8 * cts), r = L - grp * 8 * cts;
+        tile0 = grp * 8 + (r & 7); ct0 = r >> 3;
+        if (tile0 >= a.xcd_tiles) return;                            // (the last group of eight may be partial)
+    }
+    const int n0 = ct0 * BN;
     const int W = a.Win, H = a.Hin;
     const int npieces = win_rows >> 6;                              // 64-row pieces of a window (5 or 6)
     // PERSISTENT over tiles (tile = blockIdx.x + k gridDim.x): at one block per CU nothing overlaps a block's prologue (first window + filter tiles: a memory round
@@ -608,7 +626,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_halo_kernel(Bf16Args a, cons
     // tools/halo_stamps.py).  The chunk sequence runs on across tiles: the next tile's first window and filter tiles are requested during this tile's last chunk, its
     // stores drain under the next tile's taps.
     const int ntiles = PERSIST ? (int)((a.M + BMH - 1) / BMH) : 0, gstep = PERSIST ? (int)gridDim.x : 0;      // (one tile per block otherwise)
-    int tile = blockIdx.x, m0 = tile * BMH;
+    int tile = tile0, m0 = tile * BMH;
 
     const unsigned long long xa = (unsigned long long)x, wa = (unsigned long long)wb;
     const bw_i32x4 rx = {(int)(unsigned)xa, (int)(unsigned)((xa >> 32) & 0xFFFFu), (int)a.x_bytes, 0x00020000};
@@ -2111,6 +2129,10 @@ int launch(const Bf16Args& a0, const u16* x, const u16* wb, const float* bias, v
             unsigned hgx = wide ? htiles : DCV_NUM_CU / hgy; if (hgx < 1) hgx = 1; if (hgx > htiles) hgx = htiles;      // (the 128-wide instance: one tile per block)
             dim3 hgrid(hgx, hgy);
             if (hgrid.y > 65535) return DCV_ERR_UNSUPPORTED;
+            // the 128-wide instance with several channel tiles: a 1-D grid in XCD-aware order (the kernel's header; DCV_BF16_HALO_XCD=0: the 2-D grid)
+            static int xcd = -1;
+            if (xcd < 0) { const char* e = getenv("DCV_BF16_HALO_XCD"); xcd = e ? atoi(e) : 1; }
+            if (wide && xcd && hgy > 1 && 8 * hgy <= DCV_NUM_CU) { a.xcd_tiles = (int)htiles; hgrid = dim3((htiles + 7) / 8 * 8 * hgy, 1); }
             if constexpr (OUT_BF16) {
                 // 64 input channels: the filters-in-registers kernel (DCV_BF16_HALO_RF=0: off)
                 static int rf = -1;
@@ -2210,6 +2232,11 @@ int launch(const Bf16Args& a0, const u16* x, const u16* wb, const float* bias, v
     const size_t smem = wide ? (size_t)2 * (BF_BM + 128) * 128 : (size_t)2 * (BF_BM + 64) * 128;
     dim3 grid((unsigned)dcv_ceil_div((size_t)a.M, BF_BM), (unsigned)(a.Cout / (wide ? 128 : 64)));
     if (grid.y > 65535) return DCV_ERR_UNSUPPORTED;
+    {   // several channel tiles: the 1-D grid in XCD-aware order (DCV_BF16_HALO_XCD=0: the 2-D grid)
+        static int xcd = -1;
+        if (xcd < 0) { const char* e = getenv("DCV_BF16_HALO_XCD"); xcd = e ? atoi(e) : 1; }
+        if (xcd && grid.y > 1 && 8 * grid.y <= 2 * DCV_NUM_CU && (size_t)(grid.x + 7) / 8 * 8 * grid.y < ((size_t)1 << 31)) { a.xcd_tiles = (int)grid.x; grid = dim3((grid.x + 7) / 8 * 8 * grid.y, 1); }
+    }
     dcv_count_launch(DCV_FAMILY_BF16_IGEMM);
     if (wide) {
         if (!configured[0]) {
