@@ -70,7 +70,7 @@ class NormChainDesc(ctypes.Structure):
                 ('groups', _c_int), ('gn_gamma', _c_void_p), ('gn_beta', _c_void_p), ('gn_eps', _c_float), ('gn_mean', _c_void_p), ('gn_rstd', _c_void_p),
                 ('coef', _c_void_p), ('act', _c_int), ('act_slope', _c_float), ('io_dtype', _c_int), ('d_bias', _c_void_p),
                 ('d_bias_part', _c_void_p), ('moments', _c_void_p), ('moments_rows', _c_int),
-                ('pool_mode', _c_int), ('pool_k', _c_int), ('pool_stride', _c_int), ('pool_pad', _c_int), ('pool_arg', _c_void_p), ('addend', _c_void_p)]
+                ('pool_mode', _c_int), ('pool_k', _c_int), ('pool_stride', _c_int), ('pool_pad', _c_int), ('pool_arg', _c_void_p), ('addend', _c_void_p), ('pool_x', _c_void_p)]
 
 
 RESIDENT_MAX_OPS = 10

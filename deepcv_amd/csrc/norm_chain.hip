@@ -324,7 +324,7 @@ __global__ __launch_bounds__(NC_THREADS) void nc_bn_fwd_finalize_kernel(const do
 template <int VEC, typename AT = float, bool ADD = false>
 __global__ __launch_bounds__(NC_THREADS) void nc_apply_kernel(const AT* __restrict__ x, AT* __restrict__ out, int HW, int C, int per,
                                                                const float* __restrict__ ab, const double* __restrict__ part, int rows, int rps, NcGn gn, NcPool pm,
-                                                               const AT* __restrict__ addend = nullptr) {
+                                                               const AT* __restrict__ addend = nullptr, AT* __restrict__ pooled_x = nullptr) {
     __shared__ float sS[NC_THREADS], sT[NC_THREADS];           // GroupNorm chains: C <= NC_THREADS
     const int CV = C / VEC;
     const int n = blockIdx.y;
@@ -414,6 +414,9 @@ __global__ __launch_bounds__(NC_THREADS) void nc_apply_kernel(const AT* __restri
     const int H = HW / pm.W, HoWo = (H / pm.pk) * pm.Wo;
     ck = nc_chunk(HoWo * CV, CV, per);
     const AT* xc = xs + ck.cv * VEC; AT* os = out + (size_t)n * HoWo * C;
+    // `pooled_x` (dcv_norm_chain_desc::pool_x): the window means of x itself, for the moments epilogue of the consumer's data-gradient kernel (the mean of
+    // u = (x - mean) rstd over a window is (mean of x - mean) rstd: what a pooled gradient multiplies in the sum of d u)
+    AT* px = pooled_x ? pooled_x + (size_t)n * HoWo * C : nullptr;
     int ho = ck.pix / pm.Wo, wo = ck.pix - ho * pm.Wo;
     const int hstep = ck.pstep / pm.Wo, wstep = ck.pstep - hstep * pm.Wo;
     if (pm.pk == 2) {
@@ -443,24 +446,36 @@ __global__ __launch_bounds__(NC_THREADS) void nc_apply_kernel(const AT* __restri
                     o.v[v] = a * pm.inv;
                 }
                 if (i + k * NC_THREADS < ck.i1) nc_store<VEC>(os + (size_t)(i + k * NC_THREADS) * VEC, o);
+                if (px != nullptr && i + k * NC_THREADS < ck.i1) {
+                    NcVec<VEC> m;
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) m.v[v] = (xv[k][0].v[v] + xv[k][1].v[v] + xv[k][2].v[v] + xv[k][3].v[v]) * pm.inv;
+                    nc_store<VEC>(px + (size_t)(i + k * NC_THREADS) * VEC, m);
+                }
             }
         }
         return;
     }
     for (int i = ck.i0; i < ck.i1; i += NC_THREADS) {
-        float acc[VEC];
+        float acc[VEC], accx[VEC];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        for (int v = 0; v < VEC; ++v) { acc[v] = 0.f; accx[v] = 0.f; }
         for (int kh = 0; kh < pm.pk; ++kh)
             for (int kw = 0; kw < pm.pk; ++kw) {
                 const NcVec<VEC> xv = nc_load<VEC>(xc + ((size_t)(ho * pm.pk + kh) * pm.W + wo * pm.pk + kw) * C);
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) acc[v] += xv.v[v] * S.v[v] + T.v[v];
+                for (int v = 0; v < VEC; ++v) { acc[v] += xv.v[v] * S.v[v] + T.v[v]; accx[v] += xv.v[v]; }
             }
         NcVec<VEC> o;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) o.v[v] = acc[v] * pm.inv;
         nc_store<VEC>(os + (size_t)i * VEC, o);
+        if (px != nullptr) {
+            NcVec<VEC> m;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) m.v[v] = accx[v] * pm.inv;
+            nc_store<VEC>(px + (size_t)i * VEC, m);
+        }
         ho += hstep; wo += wstep;
         if (wo >= pm.Wo) { wo -= pm.Wo; ++ho; }
     }
@@ -979,6 +994,8 @@ int dcv_norm_chain_fwd(const dcv_norm_chain_desc* d, const void* xv, void* outv,
     if (d->pool > 0) nc_split((d->hw / (d->pool * d->pool)) * CV, G > 0, &abps, &aper, d->n);      // (a GroupNorm sample is one block: its prologue; else as many as it takes)
     const dim3 agrid((unsigned)abps, (unsigned)d->n);
     if (nc_skip() & 4) DCV_RETURN_LAUNCH();
+    DCV_CHECK_ARG(d->pool_x == nullptr || (d->pool > 0 && d->pool_mode == 0 && (nc_vec(d) != 8 || (reinterpret_cast<uintptr_t>(d->pool_x) & 15) == 0)));
+    nc_bf16* px16 = reinterpret_cast<nc_bf16*>(d->pool_x); float* px32 = reinterpret_cast<float*>(d->pool_x);
     if (d->addend != nullptr) {
         // out = S x + T + addend (a residual link behind the layer): the streaming instances without pooling
         DCV_CHECK_ARG(d->pool == 0 && (nc_vec(d) != 8 || (reinterpret_cast<uintptr_t>(d->addend) & 15) == 0));
@@ -990,11 +1007,11 @@ int dcv_norm_chain_fwd(const dcv_norm_chain_desc* d, const void* xv, void* outv,
         else hipLaunchKernelGGL((nc_apply_kernel<1, float, true>), agrid, dim3(NC_THREADS), 0, st, x, out, d->hw, C, aper, ab, part, rows, rps, gn, pm, a32);
         DCV_RETURN_LAUNCH();
     }
-    if (io16 && vec == 8) hipLaunchKernelGGL((nc_apply_kernel<8, nc_bf16>), agrid, dim3(NC_THREADS), 0, st, x16, out16, d->hw, C, aper, ab, part, rows, rps, gn, pm);
-    else if (io16 && vec == 4) hipLaunchKernelGGL((nc_apply_kernel<4, nc_bf16>), agrid, dim3(NC_THREADS), 0, st, x16, out16, d->hw, C, aper, ab, part, rows, rps, gn, pm);
-    else if (io16) hipLaunchKernelGGL((nc_apply_kernel<1, nc_bf16>), agrid, dim3(NC_THREADS), 0, st, x16, out16, d->hw, C, aper, ab, part, rows, rps, gn, pm);
-    else if (vec == 4) hipLaunchKernelGGL((nc_apply_kernel<4>), agrid, dim3(NC_THREADS), 0, st, x, out, d->hw, C, aper, ab, part, rows, rps, gn, pm);
-    else hipLaunchKernelGGL((nc_apply_kernel<1>), agrid, dim3(NC_THREADS), 0, st, x, out, d->hw, C, aper, ab, part, rows, rps, gn, pm);
+    if (io16 && vec == 8) hipLaunchKernelGGL((nc_apply_kernel<8, nc_bf16>), agrid, dim3(NC_THREADS), 0, st, x16, out16, d->hw, C, aper, ab, part, rows, rps, gn, pm, (const nc_bf16*)nullptr, px16);
+    else if (io16 && vec == 4) hipLaunchKernelGGL((nc_apply_kernel<4, nc_bf16>), agrid, dim3(NC_THREADS), 0, st, x16, out16, d->hw, C, aper, ab, part, rows, rps, gn, pm, (const nc_bf16*)nullptr, px16);
+    else if (io16) hipLaunchKernelGGL((nc_apply_kernel<1, nc_bf16>), agrid, dim3(NC_THREADS), 0, st, x16, out16, d->hw, C, aper, ab, part, rows, rps, gn, pm, (const nc_bf16*)nullptr, px16);
+    else if (vec == 4) hipLaunchKernelGGL((nc_apply_kernel<4>), agrid, dim3(NC_THREADS), 0, st, x, out, d->hw, C, aper, ab, part, rows, rps, gn, pm, (const float*)nullptr, px32);
+    else hipLaunchKernelGGL((nc_apply_kernel<1>), agrid, dim3(NC_THREADS), 0, st, x, out, d->hw, C, aper, ab, part, rows, rps, gn, pm, (const float*)nullptr, px32);
     DCV_RETURN_LAUNCH();
 }
 

@@ -276,6 +276,7 @@ def _stem_as_folded_rows(x, weight, d):
 
 
 _dgrad_moments = os.environ.get('DCV_DGRAD_MOMENTS', '1') not in ('0', 'false', 'False', '')
+_pooled_moments = os.environ.get('DCV_POOLED_MOMENTS', '1') not in ('0', 'false', 'False', '')      # ... also for layers followed by a fused average pooling
 # how often the fused epilogues of the bf16 data-gradient kernel were taken (tests read it around a step): 'addend' = a residual link's gradient added there,
 # 'moments' = left for the layer below, 'moments_used' = that layer's normalisation backward skipped its sums pass
 fusion_counts = {'addend': 0, 'moments': 0, 'moments_used': 0}
@@ -963,6 +964,9 @@ class _ConvNormLayerFn(torch.autograd.Function):
             nc.io_dtype = nat.DTYPE_BF16 if ctx.io16 else nat.DTYPE_F32
             nc.pool_arg = nat.ptr(ctx.pool_arg)
             nc.addend = nat.ptr(addend)                             # out = chain(y) + addend: a residual link's sum in the apply pass (round 4)
+            # a following average pooling: the window means of y itself, for the moments epilogue of the consumer's data-gradient kernel (`_Producer`)
+            pooled_y = torch.empty_like(out) if (_dgrad_moments and _pooled_moments and ctx.io16 and not groups and pool > 0) else None
+            nc.pool_x = nat.ptr(pooled_y)
             ws = _ws(lib.dcv_norm_chain_ws_bytes(nc), dev)
             nat.check(lib.dcv_norm_chain_fwd(nc, y.data_ptr(), out.data_ptr(), nat.ptr(stats), rows.value, rps.value, ws.data_ptr(), ws.numel(), st), 'dcv_norm_chain_fwd')
         else:
@@ -975,6 +979,8 @@ class _ConvNormLayerFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight, bias, y, bn_w, bn_b, bn_mean, bn_rstd, gn_w, gn_mean, gn_rstd)
         if _dgrad_moments and ctx.io16 and ctx.streaming and not groups and not pool:
             ctx.producer = out._dcv_producer = _Producer(y, bn_mean, bn_rstd)
+        elif ctx.streaming and pooled_y is not None:
+            ctx.producer = out._dcv_producer = _Producer(pooled_y, bn_mean, bn_rstd)      # (a pooled gradient multiplies the window mean of u: `dcv_norm_chain_desc::pool_x`)
         return out
 
     @staticmethod
@@ -1087,7 +1093,7 @@ class _ConvNormLayerFn(torch.autograd.Function):
             prod = getattr(ctx, 'producer', None)
             if prod is not None and prod.moments is not None and prod.consumers == 1:
                 mom, mrows, mptr, mver = prod.moments
-                if dout.data_ptr() == mptr and dout._version == mver and tuple(dout.shape) == tuple(y.shape):
+                if dout.data_ptr() == mptr and dout._version == mver and tuple(dout.shape) == tuple(prod.y.shape):
                     nc.moments, nc.moments_rows = mom.data_ptr(), mrows      # the consumer's data-gradient kernel left them (`_Producer`)
                     fusion_counts['moments_used'] += 1
                 prod.moments = None

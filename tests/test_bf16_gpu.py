@@ -212,6 +212,55 @@ def test_fused_layer_with_bf16_activations(device, groups, pool):
     assert (nbt.item() == 1) and _rel(rm, 0.1 * z.detach().mean(dim=(0, 2, 3))) <= 1e-2
 
 
+@pytest.mark.parametrize('pool', [2, 4])
+def test_pooled_layer_takes_its_backward_moments_from_the_consumers_data_gradient(device, pool, monkeypatch):
+    """ A BatchNorm-only bf16 layer followed by a fused average pooling, consumed by a 3x3 layer: the consumer's data-gradient kernel leaves the two moments the
+    pooled layer's normalisation backward starts from (`dcv_norm_chain_desc::pool_x`: the forward also writes the window means of y, which a pooled gradient
+    multiplies in the sum of d u), and the sums pass over y and dout is skipped — as for unpooled layers.  Against a double-precision torch graph (the bounds of
+    the single-layer test) and against the same stack with the sums pass (`ops._pooled_moments` off: same kernels otherwise). """
+    from deepcv_amd import ops
+    n, c, h = 40, 64, 16 * pool                                  # 40 x 16 x 16 pooled pixels: the consumer runs the window kernel (>= 8192 pixels)
+    torch.manual_seed(31 + pool)
+    x = _bf(torch.randn(n, c, h, h)).float()
+    w1, w2 = (_bf(torch.randn(c, c, 3, 3) / (c * 9) ** 0.5).float() for _ in range(2))
+    g1, b1, g2, b2 = torch.rand(c) + 0.5, torch.randn(c) * 0.1, torch.rand(c) + 0.5, torch.randn(c) * 0.1
+    dout = _bf(torch.randn(n, c, h // pool, h // pool)).float()
+    ref = [t.double().requires_grad_(True) for t in (w1, g1, b1, w2, g2, b2)]
+    o = F.avg_pool2d(F.batch_norm(torch.relu(F.conv2d(x.double(), ref[0], None, 1, 1)), None, None, ref[1], ref[2], True, 0.1, 1e-5), pool)
+    o = F.batch_norm(torch.relu(F.conv2d(o, ref[3], None, 1, 1)), None, None, ref[4], ref[5], True, 0.1, 1e-5)
+    o.backward(dout.double())
+
+    def run(pooled_moments: bool):
+        monkeypatch.setattr(ops, '_pooled_moments', pooled_moments)
+        p = [t.to(device).requires_grad_(True) for t in (w1, g1, b1, w2, g2, b2)]
+        xd = x.to(device).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        st = lambda: (torch.zeros(c, device=device), torch.ones(c, device=device), torch.zeros(1, dtype=torch.int64, device=device))
+        before = dict(ops.fusion_counts)
+        prev, prev_st = ops.set_conv_math('bf16'), ops.set_bf16_storage(True)
+        try:
+            m = ops.conv_norm_layer(xd, p[0], None, 1, 1, 1, 1, 0., p[1], p[2], *st(), 0.1, 1e-5, 0, None, None, 1e-5, pool)
+            out = ops.conv_norm_layer(m, p[3], None, 1, 1, 1, 1, 0., p[4], p[5], *st(), 0.1, 1e-5)
+            out.backward(dout.to(device).to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
+        finally:
+            ops.set_conv_math(prev)
+            ops.set_bf16_storage(prev_st)
+        torch.cuda.synchronize()
+        return out, [t.grad for t in p], {k: ops.fusion_counts[k] - before[k] for k in before}
+    out_a, grads_a, fused_a = run(True)
+    out_b, grads_b, fused_b = run(False)
+    assert fused_a['moments'] == 1 and fused_a['moments_used'] == 1, fused_a
+    assert fused_b['moments'] == 0 and fused_b['moments_used'] == 0, fused_b
+    assert torch.equal(out_a, out_b) and _rel(out_a.float(), o.detach()) <= 1.6e-2
+    names = ('weight 1', 'bn weight 1', 'bn bias 1', 'weight 2', 'bn weight 2', 'bn bias 2')
+    e_ref = [_rel(grads_a[k], ref[k].grad) for k in range(6)]
+    e_ref_b = [_rel(grads_b[k], ref[k].grad) for k in range(6)]
+    e_ab = [_rel(grads_a[k], grads_b[k]) for k in range(6)]
+    report = '; '.join(f'{names[k]}: {e_ref[k]:.2e} (sums pass {e_ref_b[k]:.2e}, between them {e_ab[k]:.2e})' for k in range(6))
+    # (two ReLU layers on bf16 tensors: the double-precision graph is a loose referee — rounding flips ReLUs —, the same stack with the sums pass a tight one)
+    assert all(e <= max(8e-2, 1.2 * eb) for e, eb in zip(e_ref, e_ref_b)), report
+    assert all(e == 0. for e in e_ab[3:]) and all(e <= 8e-3 for e in e_ab[:3]), report      # (the window means of y are stored as bf16: 2^-9 per pooled element)
+
+
 @pytest.mark.parametrize('geom', [(3, 2, 1, 20, 24), (2, 2, 0, 16, 16), (3, 2, 0, 17, 19), (2, 1, 0, 9, 12)], ids=['k3s2p1', 'k2s2', 'k3s2_odd', 'k2s1'])
 def test_fused_layer_with_a_following_max_pooling(device, geom, monkeypatch):
     """ `ops.conv_norm_layer(max_pool=(k, stride, pad))` (round 4: a MaxPool2d with overlapping windows carried by the normalisation kernels of both directions,

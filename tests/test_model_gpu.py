@@ -264,7 +264,7 @@ def test_wide_models_match_oracle_at_the_bench_batch(device, params, spec, nc, s
             assert ran.get('bf16_window', 0) > 0 and ran.get('bf16_wgrad9', 0) > 0, f'the bf16 window / all-taps kernels did not run: {ran}'
             # round 4: the data-gradient kernel's fused epilogues are part of what the bench times — the moments of the layer below (both specs), the residual
             # links' gradients (resnet18_style) — so the gradients compared above came through them
-            assert fused['moments'] >= 4 and fused['moments_used'] == fused['moments'], fused
+            assert fused['moments'] >= (8 if 'cifar100' in spec else 4) and fused['moments_used'] == fused['moments'], fused      # (cifar100_deep: its three pooled layers too)
             if 'resnet' in spec:
                 assert fused['addend'] >= 4, fused
         del native, oracle
