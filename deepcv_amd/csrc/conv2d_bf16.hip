@@ -1929,9 +1929,25 @@ __global__ __launch_bounds__(256) void prep_bf16_tile_kernel(Bf16TileList l) {
     const Bf16Tile& e = l.e[ei];
     const int tl = (int)blockIdx.x - e.first, tco = tl / e.tiles_ci, tci = tl - tco * e.tiles_ci;
     const int co0 = tco * 32, ci0 = tci * 32, taps = e.taps, run = 32 * taps, t = threadIdx.x;
-    for (int i = t; i < 32 * run; i += 256) {
-        const int r = i / run, c = i - r * run;
-        tile[r * BF_TILE_LD + c] = e.w[((size_t)(co0 + r) * e.Cin + ci0) * taps + c];
+    // (row, column) of element i = t + 256 k walk on without a division (run = 32 taps >= 32); six loads in flight per thread: the kernel is a few hundred
+    // blocks of one memory round trip after another (12.7 us per call at 1.5 TB/s before)
+    {
+        int r = t / run, c = t - r * run;
+        const int dr = 256 / run, dc = 256 - dr * run, total = 32 * run;
+        const float* wrow = e.w + ((size_t)co0 * e.Cin + ci0) * taps;
+        const size_t rstride = (size_t)e.Cin * taps;
+        for (int i = t; i < total; i += 6 * 256) {
+            float v[6]; int at[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                at[k] = r * BF_TILE_LD + c;
+                v[k] = i + k * 256 < total ? wrow[(size_t)r * rstride + c] : 0.f;
+                r += dr; c += dc;
+                if (c >= run) { c -= run; ++r; }
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) if (i + k * 256 < total) tile[at[k]] = v[k];
+        }
     }
     __syncthreads();
     if (e.dst_f != nullptr)
