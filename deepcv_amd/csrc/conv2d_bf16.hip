@@ -2002,15 +2002,41 @@ __global__ __launch_bounds__(256) void gather_cols_bf16_kernel(ColArgs a, const 
         orow[i] = ok ? v : make_uint4(0u, 0u, 0u, 0u);
     }
 }
-// dw[co][ci][tap] = sum over chunks of partial[chunk][co][tap][ci], chunks in order
+// dw[co][ci][tap] = sum over chunks of partial[chunk][co][tap][ci] (deterministic).  Block = 8 float4 columns x 32 chunk lanes (mfma_wgrad9_reduce_kernel's shape:
+// one thread walking all chunks of its element was a chain of up to 256 dependent loads — 34 us per call on resnet18_style's strided layers); a lane adds its
+// chunks c = cl, cl + 32, ... in order, the 32 lanes are combined through LDS in lane order.  Cin % 4 == 0.
 __global__ __launch_bounds__(256) void col_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int chunks, int Cout, int Cin, int taps) {
+    __shared__ float4 red[32][8];
+    const int v4 = threadIdx.x & 7, cl = threadIdx.x >> 3;
     const size_t wtotal = (size_t)Cout * Cin * taps;
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;                          // index in the slab's order: consecutive threads read consecutive words
-    if (e >= wtotal) return;
-    float sum = 0.f;
-    for (int c = 0; c < chunks; ++c) sum += partial[(size_t)c * wtotal + e];
-    const int ci = (int)(e % Cin); const size_t r1 = e / Cin; const int tap = (int)(r1 % taps), co = (int)(r1 / taps);
-    dw[((size_t)co * Cin + ci) * taps + tap] = sum;
+    const size_t e = ((size_t)blockIdx.x * 8 + v4) * 4;              // index in the slab's order [co][tap][ci]: four consecutive input channels
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < wtotal) {
+        const float* src = partial + e;
+        int c = cl;
+        for (; c + 96 < chunks; c += 128) {                          // four slabs in flight per thread (same summation order as the plain loop)
+            const float4 v0 = *reinterpret_cast<const float4*>(src + (size_t)c * wtotal), v1 = *reinterpret_cast<const float4*>(src + (size_t)(c + 32) * wtotal);
+            const float4 v2 = *reinterpret_cast<const float4*>(src + (size_t)(c + 64) * wtotal), v3 = *reinterpret_cast<const float4*>(src + (size_t)(c + 96) * wtotal);
+            s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+            s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+            s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+            s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+        }
+        for (; c < chunks; c += 32) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)c * wtotal);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    red[cl][v4] = s;
+    __syncthreads();
+    if (cl == 0 && e < wtotal) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 32; ++k) { const float4 v = red[k][v4]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        const int ci = (int)(e % Cin); const size_t r1 = e / Cin; const int tap = (int)(r1 % taps), co = (int)(r1 / taps);
+        float* d = dw + ((size_t)co * Cin + ci) * taps + tap;
+        d[0] = t.x; d[taps] = t.y; d[2 * taps] = t.z; d[3 * taps] = t.w;
+    }
 }
 
 struct PhaseAxis { int r0, taps, pad, count; };
@@ -2483,7 +2509,7 @@ int dcv_conv2d_bf16_wgrad(const dcv_conv2d_desc* d, const void* x, const void* d
         float* partial = reinterpret_cast<float*>(ws);
         const int rc = wgradg_run(ag, gp, reinterpret_cast<const u16*>(x), reinterpret_cast<const u16*>(dy), partial, dcv_stream(stream));
         if (rc != DCV_OK) return rc;
-        hipLaunchKernelGGL(col_wgrad_reduce_kernel, dim3((unsigned)dcv_ceil_div(ag.wtotal, 256)), dim3(256), 0, dcv_stream(stream), partial, dw, gp.chunks, d->cout, d->cin, d->r * d->s);
+        hipLaunchKernelGGL(col_wgrad_reduce_kernel, dim3((unsigned)dcv_ceil_div(ag.wtotal, 32)), dim3(256), 0, dcv_stream(stream), partial, dw, gp.chunks, d->cout, d->cin, d->r * d->s);
         DCV_RETURN_LAUNCH();
     }
     if (!dcv_mfma_conv2d_wgrad_in16_supported(d)) {
@@ -2499,7 +2525,7 @@ int dcv_conv2d_bf16_wgrad(const dcv_conv2d_desc* d, const void* x, const void* d
             if (ws_bytes < cb + (size_t)gp.chunks * ag.wtotal * sizeof(float)) return DCV_ERR_WORKSPACE;
             const int rc = wgradg_run(ag, gp, xcol, reinterpret_cast<const u16*>(dy), partial, dcv_stream(stream));
             if (rc != DCV_OK) return rc;
-            hipLaunchKernelGGL(col_wgrad_reduce_kernel, dim3((unsigned)dcv_ceil_div(ag.wtotal, 256)), dim3(256), 0, dcv_stream(stream), partial, dw, gp.chunks, d->cout, d->cin, d->r * d->s);
+            hipLaunchKernelGGL(col_wgrad_reduce_kernel, dim3((unsigned)dcv_ceil_div(ag.wtotal, 32)), dim3(256), 0, dcv_stream(stream), partial, dw, gp.chunks, d->cout, d->cin, d->r * d->s);
             DCV_RETURN_LAUNCH();
         }
         dim3 grid((unsigned)chunks, (unsigned)(d1.cin / 64), (unsigned)(d1.cout / 64));
@@ -2514,7 +2540,7 @@ int dcv_conv2d_bf16_wgrad(const dcv_conv2d_desc* d, const void* x, const void* d
         const u16* dys = reinterpret_cast<const u16*>(dy);
         if (groups == 2) hipLaunchKernelGGL((conv_bf16_wgrad9_kernel<2, 1>), grid, dim3(512), smem, dcv_stream(stream), a, xcol, dys, partial);
         else hipLaunchKernelGGL((conv_bf16_wgrad9_kernel<1, 1>), grid, dim3(256), smem, dcv_stream(stream), a, xcol, dys, partial);
-        hipLaunchKernelGGL(col_wgrad_reduce_kernel, dim3((unsigned)dcv_ceil_div(a.wtotal, 256)), dim3(256), 0, dcv_stream(stream), partial, dw, chunks, d->cout, d->cin, d->r * d->s);
+        hipLaunchKernelGGL(col_wgrad_reduce_kernel, dim3((unsigned)dcv_ceil_div(a.wtotal, 32)), dim3(256), 0, dcv_stream(stream), partial, dw, chunks, d->cout, d->cin, d->r * d->s);
         DCV_RETURN_LAUNCH();
     }
     dcv_count_launch(DCV_FAMILY_BF16_WGRAD_TAP);

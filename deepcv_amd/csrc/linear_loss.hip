@@ -81,6 +81,46 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
     }
 }
 
+// Wide heads on the matrix cores (round 4, last session): y[16 rows][16 features] per block on v_mfma_f32_16x16x4_f32, the K steps of 16 dealt round-robin to the
+// block's four waves and their accumulators summed through LDS in wave order (deterministic).  A lane's float4 of x (row li, k = 16 s + 4 lg ..) and of w (feature
+// li, same k) are the A / B fragments of four MFMAs.  The kernels above keep one (or four) sample rows per WAVE and reduce every (row, feature) product across the
+// wave: 26 us for 512 x 512 -> 100 (cifar100_deep), 77 us for 512 x 512 -> 1000 (resnet18_style) — a 0.05 / 0.5 GFLOP product.
+typedef float lin_f32x4 __attribute__((ext_vector_type(4)));
+inline bool mfma_head() { static int on = -1; if (on < 0) { const char* e = getenv("DCV_LINEAR_MFMA"); on = e ? atoi(e) : 1; } return on != 0; }
+__global__ __launch_bounds__(256) void linear_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                               float* __restrict__ y, int N, int K, int O, int act, float slope) {
+    __shared__ lin_f32x4 red[3][64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
+    const int n0 = blockIdx.x * 16, o0 = blockIdx.y * 16;
+    const int row = n0 + li < N ? n0 + li : N - 1, feat = o0 + li < O ? o0 + li : O - 1;      // (clamped: their results are not stored)
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * K) + lg;
+    const float4* wr = reinterpret_cast<const float4*>(w + (size_t)feat * K) + lg;
+    lin_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int steps = K >> 4;
+#pragma unroll 4
+    for (int s = wave; s < steps; s += 4) {
+        const float4 a = xr[4 * s], b = wr[4 * s];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+    }
+    if (wave > 0) red[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave > 0) return;
+    // acc[reg]: row n0 + 4 lg + reg, feature o0 + li
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const lin_f32x4 v = red[k][lane]; acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3]; }
+    const int o = o0 + li;
+    if (o >= O) return;
+    const float bv = bias ? bias[o] : 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int n = n0 + 4 * lg + reg;
+        if (n < N) y[(size_t)n * O + o] = dcv_act_apply(acc[reg] + bv, act, slope);
+    }
+}
+
 // Wide heads at large batches (round 4: 512 x 2048 -> 100 of cifar100_deep, 512 x 512 -> 1000 of resnet18_style): with one sample row per wave every wave reads
 // the whole weight chunk — 410 MB / 1 GB of L2 traffic for a 0.2 / 0.5 GFLOP product, 27 / 77 us.  Here a wave owns RW = 4 sample rows: each weight vector it
 // loads meets four rows of x in registers (a quarter of the traffic); per (row, feature) the same products are summed in the same order as linear_fwd_kernel<4, 8>
@@ -440,6 +480,9 @@ int dcv_linear_fwd(const float* x, const float* w, const float* bias, float* y, 
         else if (O <= 10) hipLaunchKernelGGL((linear_fwd_row_kernel<10>), dim3((unsigned)n), dim3(256), 0, st, x, w, bias, y, K, O, act, slope);
         else hipLaunchKernelGGL((linear_fwd_row_kernel<16>), dim3((unsigned)n), dim3(256), 0, st, x, w, bias, y, K, O, act, slope);
     }
+    else if (v4 && O > 16 && n >= 64 && K % 16 == 0 && K >= 64 && mfma_head()) {          // wide heads: the matrix cores (DCV_LINEAR_MFMA=0: the kernels below)
+        hipLaunchKernelGGL(linear_fwd_mfma_kernel, dim3((unsigned)dcv_ceil_div(n, 16), (unsigned)dcv_ceil_div(O, 16)), dim3(256), 0, st, x, w, bias, y, n, K, O, act, slope);
+    }
     else if (v4 && O > 16 && n >= 256 && K > 512 && K <= 4 * 64 * 8) {      // a wide head of long rows at a large batch: four sample rows per wave (27 -> 16 us on
                                                                             // 512 x 2048 -> 100; short rows — 512 -> 1000 — are bound by the per-wave reductions and stores, not by
                                                                             // the weight traffic: 77 us on the kernel below, 83 / 137 us with 4 / 16 rows per wave)
@@ -533,6 +576,103 @@ int dcv_cross_entropy_bwd(const float* logits, const int64_t* target, const floa
 }
 
 
+// The backward of a wide head on the matrix cores (same shape of kernel as linear_fwd_mfma_kernel: a 16 x 16 result tile per block, the reduction axis dealt to the
+// four waves in steps of 16, accumulators summed through LDS in wave order).  dz = dy act'(y) is formed while the fragments are loaded.
+//   data gradient    dx[n][k]  = sum over o of dz[n][o] w[o][k]:  A = dz rows (float4 along o), B = w (four rows o of 16 consecutive k)
+//   weight gradient  dw[o][k]  = sum over n of dz[n][o] x[n][k]:  A = dz columns (four samples of 16 consecutive o), B = x (four samples of 16 consecutive k);
+//                    db[o] = sum over n of dz[n][o] by the blocks of k tile 0, from the same fragments.  The whole batch in one block: no partial slabs.
+// The row-per-block kernels above took 41 + 48 us (+ 2 MB partial slabs per 32 samples for the step's slab sum) on 512 x 512 -> 1000.
+__global__ __launch_bounds__(256) void linear_dgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ y, int act, float slope, const float* __restrict__ w,
+                                                                 float* __restrict__ dx, int N, int K, int O) {
+    __shared__ lin_f32x4 red[3][64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
+    const int n0 = blockIdx.x * 16, k0 = blockIdx.y * 16;
+    const int row = n0 + li < N ? n0 + li : N - 1, k = k0 + li < K ? k0 + li : K - 1;
+    const float* dyr = dy + (size_t)row * O; const float* yr = y ? y + (size_t)row * O : nullptr;
+    lin_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int steps = (O + 15) >> 4;
+#pragma unroll 2
+    for (int s = wave; s < steps; s += 4) {
+        const int o = 16 * s + 4 * lg;                               // this lane's four features (O % 4 == 0: all inside or all outside)
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        float b[4] = {0.f, 0.f, 0.f, 0.f};
+        if (o < O) {
+            a = *reinterpret_cast<const float4*>(dyr + o);
+            if (yr) {
+                const float4 yv = *reinterpret_cast<const float4*>(yr + o);
+                a.x *= dcv_act_grad_from_out(yv.x, act, slope); a.y *= dcv_act_grad_from_out(yv.y, act, slope);
+                a.z *= dcv_act_grad_from_out(yv.z, act, slope); a.w *= dcv_act_grad_from_out(yv.w, act, slope);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = w[(size_t)(o + j) * K + k];
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[3], acc, 0, 0, 0);
+    }
+    if (wave > 0) red[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { const lin_f32x4 v = red[q][lane]; acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3]; }
+    if (k0 + li >= K) return;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int n = n0 + 4 * lg + reg;                             // acc[reg]: row n0 + 4 lg + reg, column k0 + li
+        if (n < N) dx[(size_t)n * K + k0 + li] = acc[reg];
+    }
+}
+
+__global__ __launch_bounds__(256) void linear_wgrad_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y, int act, float slope,
+                                                                 float* __restrict__ dw, float* __restrict__ db, int N, int K, int O) {
+    __shared__ lin_f32x4 red[3][64];
+    __shared__ float redb[4][64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lg = lane >> 4;
+    const int o0 = blockIdx.x * 16, k0 = blockIdx.y * 16;
+    const int o = o0 + li < O ? o0 + li : O - 1, k = k0 + li < K ? k0 + li : K - 1;
+    lin_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    const int steps = (N + 15) >> 4;
+#pragma unroll 2
+    for (int s = wave; s < steps; s += 4) {
+        float a[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = 16 * s + 4 * lg + j;
+            const bool in = n < N;
+            const size_t at = (size_t)(in ? n : 0) * O + o;
+            float g = in ? dy[at] : 0.f;
+            if (y && in) g *= dcv_act_grad_from_out(y[at], act, slope);
+            a[j] = g;
+            b[j] = in ? x[(size_t)n * K + k] : 0.f;
+            bsum += g;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
+    }
+    if (wave > 0) red[wave - 1][lane] = acc;
+    redb[wave][lane] = bsum;
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { const lin_f32x4 v = red[q][lane]; acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3]; }
+    if (db != nullptr && blockIdx.y == 0 && lg == 0 && o0 + li < O) {
+        float sb = 0.f;                                              // feature o0 + li: the four K groups of the four waves, in order
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) sb += redb[q][16 * g + li];
+        db[o0 + li] = sb;
+    }
+    if (dw == nullptr || k0 + li >= K) return;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int oo = o0 + 4 * lg + reg;                            // acc[reg]: row (feature) o0 + 4 lg + reg, column k0 + li
+        if (oo < O) dw[(size_t)oo * K + k0 + li] = acc[reg];
+    }
+}
+
 size_t dcv_linear_bwd_workspace_bytes(int n, int K, int O) {
     if (n <= 0 || K <= 0 || O <= 0) return 0;
     return dcv_align_up(dcv_ceil_div(n, LIN_WG_CHUNK) * ((size_t)O * K + O) * sizeof(float), 256);
@@ -544,6 +684,12 @@ static int linear_bwd_impl(const float* dy, const float* y, int act, float slope
     hipStream_t st = dcv_stream(stream);
     const float* yy = act == DCV_ACT_NONE ? nullptr : y;
     const bool v4 = K % 4 == 0 && aligned16(x) && aligned16(w) && (!dx || aligned16(dx));
+    if (mfma_head() && O > 16 && O % 4 == 0 && n >= 64 && K >= 64 && aligned16(dy) && (!yy || aligned16(yy)) && dcv_ceil_div(K, 16) <= 65535) {
+        // a wide head: both gradients on the matrix cores, the weight gradient over the whole batch in one block (no partial slabs, nothing to defer)
+        if (dx) hipLaunchKernelGGL(linear_dgrad_mfma_kernel, dim3((unsigned)dcv_ceil_div(n, 16), (unsigned)dcv_ceil_div(K, 16)), dim3(256), 0, st, dy, yy, act, slope, w, dx, n, K, O);
+        if (dw || db) hipLaunchKernelGGL(linear_wgrad_mfma_kernel, dim3((unsigned)dcv_ceil_div(O, 16), (unsigned)dcv_ceil_div(K, 16)), dim3(256), 0, st, x, dy, yy, act, slope, dw, db, n, K, O);
+        DCV_RETURN_LAUNCH();
+    }
     if (dx) {
         DCV_CHECK_ARG(dcv_ceil_div(K, 32) <= 65535);
         if (v4) hipLaunchKernelGGL((linear_dgrad_act_kernel<4>), dim3((unsigned)n, (unsigned)dcv_ceil_div(K / 4, 32)), dim3(256), 0, st, dy, yy, act, slope, w, dx, n, K, O);

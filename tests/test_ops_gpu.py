@@ -262,7 +262,9 @@ def test_concat_add_flatten(device):
 
 
 @pytest.mark.parametrize('n,k,o,act', [(8, 1280, 10, 3), (64, 512, 100, 0), (5, 37, 7, 1), (4, 64, 3, 4), (16, 2048, 16, 0), (4, 516, 5, 1),
-                                       (258, 2048, 100, 0), (301, 512, 1000, 1)], ids=str)      # (the last two: wide heads at large batches — four sample rows per wave, ragged last wave)
+                                       (258, 2048, 100, 0), (301, 512, 1000, 1), (70, 72, 36, 4), (64, 64, 20, 2), (513, 512, 100, 1)], ids=str)
+# (from (258, 2048, 100) on: wide heads — the matrix-core kernels, forward and both gradients: ragged row / feature / K tiles, every activation's gradient; (70, 72, 36): K is
+#  no multiple of 16 -> the forward stays on the row kernels, the gradients' K tiles are ragged)
 def test_linear(device, n, k, o, act):
     from deepcv_amd import ops
     from oracle import ops_ref
