@@ -627,7 +627,7 @@ struct NcMax { int H, W, Ho, Wo, k, st, pad; };
 
 template <int K>                                                  // compile-time window (2, 3): its K x K loads are all requested before the first compare; 0: the descriptor's
 __global__ __launch_bounds__(NC_THREADS) void nc_maxpool_fwd_kernel(const nc_bf16* __restrict__ x, nc_bf16* __restrict__ out, unsigned char* __restrict__ arg, int C,
-                                                                     const float* __restrict__ ab, NcMax pm, unsigned total) {
+                                                                     const float* __restrict__ ab, NcMax pm, unsigned total, nc_bf16* __restrict__ xwin) {
     const unsigned i = blockIdx.x * NC_THREADS + threadIdx.x;
     if (i >= total) return;
     const unsigned CV = (unsigned)C >> 3, cv = i % CV;
@@ -637,15 +637,15 @@ __global__ __launch_bounds__(NC_THREADS) void nc_maxpool_fwd_kernel(const nc_bf1
     const NcVec<8> S = nc_load<8>(ab + cv * 8), T = nc_load<8>(ab + C + cv * 8);
     const nc_bf16* xs = x + (size_t)n * pm.H * pm.W * C + cv * 8;
     const int h0 = ho * pm.st - pm.pad, w0 = wo * pm.st - pm.pad;
-    float best[8]; unsigned bi[8];
+    float best[8], bx[8]; unsigned bi[8];                       // bx: x itself at the winner (`xwin`, dcv_norm_chain_desc::pool_x: what a pooled gradient multiplies in sum d u)
     const unsigned first = (unsigned)((h0 < 0 ? -h0 : 0) * pm.k + (w0 < 0 ? -w0 : 0));      // torch initialises the index to the window's first in-range element
 #pragma unroll
-    for (int v = 0; v < 8; ++v) { best[v] = -INFINITY; bi[v] = first; }
+    for (int v = 0; v < 8; ++v) { best[v] = -INFINITY; bi[v] = first; bx[v] = 0.f; }
     auto take = [&](const NcVec<8>& xv, unsigned pos) __attribute__((always_inline)) {
 #pragma unroll
         for (int v = 0; v < 8; ++v) {
             const float a = (float)(__bf16)(xv.v[v] * S.v[v] + T.v[v]);          // the bf16 value the unfused layer stores and the pooling compares
-            if (a > best[v] || a != a) { best[v] = a; bi[v] = pos; }
+            if (a > best[v] || a != a) { best[v] = a; bi[v] = pos; bx[v] = xv.v[v]; }
         }
     };
     if constexpr (K > 0) {
@@ -676,6 +676,11 @@ __global__ __launch_bounds__(NC_THREADS) void nc_maxpool_fwd_kernel(const nc_bf1
 #pragma unroll
     for (int v = 0; v < 8; ++v) o.v[v] = best[v];
     nc_store<8>(out + (size_t)i * 8, o);
+    if (xwin != nullptr) {
+#pragma unroll
+        for (int v = 0; v < 8; ++v) o.v[v] = bx[v];
+        nc_store<8>(xwin + (size_t)i * 8, o);
+    }
     *reinterpret_cast<uint2*>(arg + (size_t)i * 8) = make_uint2(bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24), bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24));
 }
 
@@ -980,14 +985,14 @@ int dcv_norm_chain_fwd(const dcv_norm_chain_desc* d, const void* xv, void* outv,
     if (!(nc_skip() & 2)) hipLaunchKernelGGL(nc_bn_fwd_finalize_kernel, dim3((unsigned)C), dim3(NC_THREADS), 0, st, part, rows, (double)d->n * (double)d->hw, C, d->bn_gamma, d->bn_beta,
                        d->running_mean, d->running_var, reinterpret_cast<long long*>(d->num_batches_tracked), d->momentum, d->bn_eps, d->bn_mean, d->bn_rstd, ab);
     if (d->pool_mode == 1) {
-        DCV_CHECK_ARG(d->pool_arg != nullptr && d->addend == nullptr && (reinterpret_cast<uintptr_t>(d->pool_arg) & 7) == 0);
+        DCV_CHECK_ARG(d->pool_arg != nullptr && d->addend == nullptr && (reinterpret_cast<uintptr_t>(d->pool_arg) & 7) == 0 && (reinterpret_cast<uintptr_t>(d->pool_x) & 15) == 0);
         if (nc_skip() & 4) DCV_RETURN_LAUNCH();
         const NcMax mx = nc_max(d);
         const size_t total = (size_t)d->n * mx.Ho * mx.Wo * CV;
         const dim3 fgrid((unsigned)dcv_ceil_div(total, NC_THREADS));
-        if (mx.k == 3) hipLaunchKernelGGL((nc_maxpool_fwd_kernel<3>), fgrid, dim3(NC_THREADS), 0, st, x16, out16, d->pool_arg, C, ab, mx, (unsigned)total);
-        else if (mx.k == 2) hipLaunchKernelGGL((nc_maxpool_fwd_kernel<2>), fgrid, dim3(NC_THREADS), 0, st, x16, out16, d->pool_arg, C, ab, mx, (unsigned)total);
-        else hipLaunchKernelGGL((nc_maxpool_fwd_kernel<0>), fgrid, dim3(NC_THREADS), 0, st, x16, out16, d->pool_arg, C, ab, mx, (unsigned)total);
+        if (mx.k == 3) hipLaunchKernelGGL((nc_maxpool_fwd_kernel<3>), fgrid, dim3(NC_THREADS), 0, st, x16, out16, d->pool_arg, C, ab, mx, (unsigned)total, reinterpret_cast<nc_bf16*>(d->pool_x));
+        else if (mx.k == 2) hipLaunchKernelGGL((nc_maxpool_fwd_kernel<2>), fgrid, dim3(NC_THREADS), 0, st, x16, out16, d->pool_arg, C, ab, mx, (unsigned)total, reinterpret_cast<nc_bf16*>(d->pool_x));
+        else hipLaunchKernelGGL((nc_maxpool_fwd_kernel<0>), fgrid, dim3(NC_THREADS), 0, st, x16, out16, d->pool_arg, C, ab, mx, (unsigned)total, reinterpret_cast<nc_bf16*>(d->pool_x));
         DCV_RETURN_LAUNCH();
     }
     int abps = bps, aper = per;
@@ -1039,12 +1044,13 @@ int dcv_norm_chain_bwd(const dcv_norm_chain_desc* d, const void* doutv, const vo
     const int frows = d->moments ? d->moments_rows : rows;
     const dim3 sgrid((unsigned)bps, (unsigned)d->n);
     if (d->pool_mode == 1) {
-        DCV_CHECK_ARG(d->pool_arg != nullptr && d->moments == nullptr && (reinterpret_cast<uintptr_t>(d->pool_arg) & 7) == 0);
+        DCV_CHECK_ARG(d->pool_arg != nullptr && (reinterpret_cast<uintptr_t>(d->pool_arg) & 7) == 0);
         const NcMax mx = nc_max(d);
         int pbps, pper; nc_split(mx.Ho * mx.Wo * CV, false, &pbps, &pper, d->n);        // (fewer vectors than the full-size map: the rows fit the same workspace)
         const int prows = d->n * pbps;
-        if (!(nc_skip() & 1)) hipLaunchKernelGGL(nc_maxpool_bwd_sums_kernel, dim3((unsigned)pbps, (unsigned)d->n), dim3(NC_THREADS), 0, st, x16, dout16, d->pool_arg, C, pper, d->bn_mean, d->bn_rstd, mx, part, prows);
-        if (!(nc_skip() & 2)) hipLaunchKernelGGL(nc_param_finalize_kernel, dim3((unsigned)C), dim3(NC_THREADS), 0, st, part, prows, (double)d->n * (double)d->hw, C, 0, d->bn_gamma, d->bn_rstd,
+        // (`moments`: the consumer's data-gradient kernel left the sums of dout and dout u over the POOLED elements, u at the winners — `pool_x` of the forward)
+        if (!(nc_skip() & 1) && d->moments == nullptr) hipLaunchKernelGGL(nc_maxpool_bwd_sums_kernel, dim3((unsigned)pbps, (unsigned)d->n), dim3(NC_THREADS), 0, st, x16, dout16, d->pool_arg, C, pper, d->bn_mean, d->bn_rstd, mx, part, prows);
+        if (!(nc_skip() & 2)) hipLaunchKernelGGL(nc_param_finalize_kernel, dim3((unsigned)C), dim3(NC_THREADS), 0, st, d->moments ? d->moments : part, d->moments ? d->moments_rows : prows, (double)d->n * (double)d->hw, C, 0, d->bn_gamma, d->bn_rstd,
                            d_bn_gamma, d_bn_beta, d_gn_gamma, d_gn_beta, chan, d->coef);
         if (nc_skip() & 4) DCV_RETURN_LAUNCH();
         if (mx.k == 3 && mx.st == 2) hipLaunchKernelGGL((nc_maxpool_bwd_apply_kernel<3, 2>), sgrid, dim3(NC_THREADS), 0, st, dout16, d->pool_arg, x16, dz16, C, per, d->coef, d->bn_mean, d->bn_rstd, nc_act(d->act, d->act_slope), mx, dbp, rows, dbf);

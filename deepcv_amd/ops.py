@@ -964,8 +964,8 @@ class _ConvNormLayerFn(torch.autograd.Function):
             nc.io_dtype = nat.DTYPE_BF16 if ctx.io16 else nat.DTYPE_F32
             nc.pool_arg = nat.ptr(ctx.pool_arg)
             nc.addend = nat.ptr(addend)                             # out = chain(y) + addend: a residual link's sum in the apply pass (round 4)
-            # a following average pooling: the window means of y itself, for the moments epilogue of the consumer's data-gradient kernel (`_Producer`)
-            pooled_y = torch.empty_like(out) if (_dgrad_moments and _pooled_moments and ctx.io16 and not groups and pool > 0) else None
+            # a following pooling: the window means of y itself (a max pooling: y at the window's winner), for the moments epilogue of the consumer's data-gradient kernel (`_Producer`)
+            pooled_y = torch.empty_like(out) if (_dgrad_moments and _pooled_moments and ctx.io16 and not groups and pool != 0) else None      # (pool < 0, a max pooling: y at the winners)
             nc.pool_x = nat.ptr(pooled_y)
             ws = _ws(lib.dcv_norm_chain_ws_bytes(nc), dev)
             nat.check(lib.dcv_norm_chain_fwd(nc, y.data_ptr(), out.data_ptr(), nat.ptr(stats), rows.value, rps.value, ws.data_ptr(), ws.numel(), st), 'dcv_norm_chain_fwd')

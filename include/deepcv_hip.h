@@ -369,11 +369,12 @@ typedef struct dcv_norm_chain_desc {
     const void* addend;                                    /* nullable; dcv_norm_chain_fwd only, pool == 0, pool_mode == 0: out = chain(x) + addend, addend a tensor of out's
                                                               shape and element type — a residual link's sum behind the layer (submodule_creators.py:272-327) in the
                                                               layer's own pass over x; the backward is unchanged (the sum hands its gradient to both inputs) */
-    void* pool_x;                                          /* nullable; dcv_norm_chain_fwd only, pool > 0, pool_mode == 0: the window means of x itself, a tensor of out's shape
+    void* pool_x;                                          /* nullable; dcv_norm_chain_fwd only, pool > 0 or pool_mode == 1: the window means of x itself (pool_mode 1: x at the
+                                                              window's winner), a tensor of out's shape
                                                               and element type.  With it the data-gradient kernel of the layer above can leave this layer's backward moments
                                                               (dcv_conv2d_bf16_dgrad_moments with y_prev = pool_x: a pooled gradient multiplies the window mean of u, and the
                                                               mean of (x - mean) rstd is (mean of x - mean) rstd), so the backward's sums pass over x and dout is skipped for
-                                                              layers followed by avg_pooling (submodule_creators.py:163-176) as it is for unpooled ones */
+                                                              layers followed by avg_pooling (submodule_creators.py:163-176) or a MaxPool2d as it is for unpooled ones */
 } dcv_norm_chain_desc;
 int dcv_norm_chain_supported(const dcv_norm_chain_desc* d);
 size_t dcv_norm_chain_coef_floats(const dcv_norm_chain_desc* d);

@@ -212,13 +212,15 @@ def test_fused_layer_with_bf16_activations(device, groups, pool):
     assert (nbt.item() == 1) and _rel(rm, 0.1 * z.detach().mean(dim=(0, 2, 3))) <= 1e-2
 
 
-@pytest.mark.parametrize('pool', [2, 4])
+@pytest.mark.parametrize('pool', [2, 4, 'max'])
 def test_pooled_layer_takes_its_backward_moments_from_the_consumers_data_gradient(device, pool, monkeypatch):
     """ A BatchNorm-only bf16 layer followed by a fused average pooling, consumed by a 3x3 layer: the consumer's data-gradient kernel leaves the two moments the
     pooled layer's normalisation backward starts from (`dcv_norm_chain_desc::pool_x`: the forward also writes the window means of y, which a pooled gradient
     multiplies in the sum of d u), and the sums pass over y and dout is skipped — as for unpooled layers.  Against a double-precision torch graph (the bounds of
     the single-layer test) and against the same stack with the sums pass (`ops._pooled_moments` off: same kernels otherwise). """
     from deepcv_amd import ops
+    mx = pool == 'max'                                            # MaxPool2d(3, 2, 1): the forward keeps y at every window's winner instead of the window mean
+    pool = 2 if mx else pool
     n, c, h = 40, 64, 16 * pool                                  # 40 x 16 x 16 pooled pixels: the consumer runs the window kernel (>= 8192 pixels)
     torch.manual_seed(31 + pool)
     x = _bf(torch.randn(n, c, h, h)).float()
@@ -226,7 +228,8 @@ def test_pooled_layer_takes_its_backward_moments_from_the_consumers_data_gradien
     g1, b1, g2, b2 = torch.rand(c) + 0.5, torch.randn(c) * 0.1, torch.rand(c) + 0.5, torch.randn(c) * 0.1
     dout = _bf(torch.randn(n, c, h // pool, h // pool)).float()
     ref = [t.double().requires_grad_(True) for t in (w1, g1, b1, w2, g2, b2)]
-    o = F.avg_pool2d(F.batch_norm(torch.relu(F.conv2d(x.double(), ref[0], None, 1, 1)), None, None, ref[1], ref[2], True, 0.1, 1e-5), pool)
+    o = F.batch_norm(torch.relu(F.conv2d(x.double(), ref[0], None, 1, 1)), None, None, ref[1], ref[2], True, 0.1, 1e-5)
+    o = F.max_pool2d(o, 3, 2, 1) if mx else F.avg_pool2d(o, pool)
     o = F.batch_norm(torch.relu(F.conv2d(o, ref[3], None, 1, 1)), None, None, ref[4], ref[5], True, 0.1, 1e-5)
     o.backward(dout.double())
 
@@ -238,7 +241,7 @@ def test_pooled_layer_takes_its_backward_moments_from_the_consumers_data_gradien
         before = dict(ops.fusion_counts)
         prev, prev_st = ops.set_conv_math('bf16'), ops.set_bf16_storage(True)
         try:
-            m = ops.conv_norm_layer(xd, p[0], None, 1, 1, 1, 1, 0., p[1], p[2], *st(), 0.1, 1e-5, 0, None, None, 1e-5, pool)
+            m = ops.conv_norm_layer(xd, p[0], None, 1, 1, 1, 1, 0., p[1], p[2], *st(), 0.1, 1e-5, 0, None, None, 1e-5, 0 if mx else pool, (3, 2, 1) if mx else None)
             out = ops.conv_norm_layer(m, p[3], None, 1, 1, 1, 1, 0., p[4], p[5], *st(), 0.1, 1e-5)
             out.backward(dout.to(device).to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
         finally:
@@ -257,7 +260,7 @@ def test_pooled_layer_takes_its_backward_moments_from_the_consumers_data_gradien
     e_ab = [_rel(grads_a[k], grads_b[k]) for k in range(6)]
     report = '; '.join(f'{names[k]}: {e_ref[k]:.2e} (sums pass {e_ref_b[k]:.2e}, between them {e_ab[k]:.2e})' for k in range(6))
     # (two ReLU layers on bf16 tensors: the double-precision graph is a loose referee — rounding flips ReLUs —, the same stack with the sums pass a tight one)
-    assert all(e <= max(8e-2, 1.2 * eb) for e, eb in zip(e_ref, e_ref_b)), report
+    assert all(e <= max(2.5e-1 if mx else 8e-2, 1.2 * eb) for e, eb in zip(e_ref, e_ref_b)), report      # (max pooling over bf16 values has ties the double-precision graph does not have)
     assert all(e == 0. for e in e_ab[3:]) and all(e <= 8e-3 for e in e_ab[:3]), report      # (the window means of y are stored as bf16: 2^-9 per pooled element)
 
 
