@@ -2323,6 +2323,41 @@ __global__ __launch_bounds__(256) void space_to_depth_bf16_kernel(S2dArgs a, con
     out[i] = o.u;
 }
 
+// The ResNet stem's instance (NCHW input, three channels, stride 2: sixteen output channels = (a, b, c) in 2 x 2 x 3 + four zeros) with a thread per OUTPUT PIXEL:
+// twelve loads whose lanes walk a plane's row at a stride of two floats (the b = 0 / b = 1 loads of a (c, a) pair cover the same lines), two 16-byte stores of
+// consecutive lanes' consecutive pixels, no division (grid = (column blocks, output rows, images)).  The general kernel above decodes (c, a, b) per element with
+// integer divisions and moves the same bytes at 2.3 TB/s: 233 us for the 308 + 217 MB of resnet18_style's batch of 512.
+__global__ __launch_bounds__(128) void space_to_depth_rgb2_bf16_kernel(S2dArgs a, const float* __restrict__ x, uint4* __restrict__ out) {
+    const int j = blockIdx.x * 128 + threadIdx.x, i = blockIdx.y, n = blockIdx.z;
+    if (j >= a.Ws) return;
+    const float* xn = x + (size_t)n * 3 * a.H * a.W;
+    const int iw0 = 2 * j - a.pw;
+    float v[12];                                                    // v[(pa * 2 + pb) * 3 + c]
+#pragma unroll
+    for (int pa = 0; pa < 2; ++pa) {
+        const int ih = 2 * i + pa - a.ph;
+        const bool rok = ih >= 0 && ih < a.H;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* row = xn + ((size_t)c * a.H + (rok ? ih : 0)) * a.W;
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                const int iw = iw0 + pb;
+                const bool ok = rok && iw >= 0 && iw < a.W;
+                const float q = row[ok ? iw : 0];
+                v[(pa * 2 + pb) * 3 + c] = ok ? q : 0.f;
+            }
+        }
+    }
+    union { uint4 u[2]; __bf16 h[16]; } o;
+#pragma unroll
+    for (int e = 0; e < 12; ++e) o.h[e] = (__bf16)v[e];
+#pragma unroll
+    for (int e = 12; e < 16; ++e) o.h[e] = (__bf16)0.f;
+    uint4* dst = out + (((size_t)n * a.Hs + i) * a.Ws + j) * 2;
+    dst[0] = o.u[0]; dst[1] = o.u[1];
+}
+
 }  // namespace
 
 struct Im2colArgs { int H, W, Cin, Ho, Wo, R, S, sh, sw, ph, pw, dh, dw, K, kpad, nchw; unsigned M; int TH, PH, PW, tiles_w, tiles_h; };
@@ -2752,7 +2787,12 @@ int dcv_space_to_depth_bf16(const dcv_conv2d_desc* d, const float* x, void* out,
     const size_t total = (size_t)d->n * hs * ws * (cp / 8);
     if (total >= ((size_t)1 << 32) - 256) return DCV_ERR_UNSUPPORTED;
     S2dArgs a{d->h, d->w, d->cin, d->stride_h, d->stride_w, d->pad_h, d->pad_w, hs, ws, cp, d->x_layout == DCV_LAYOUT_NCHW ? 1 : 0, (unsigned)total};
-    hipLaunchKernelGGL(space_to_depth_bf16_kernel, dim3((unsigned)dcv_ceil_div(total, 256)), dim3(256), 0, dcv_stream(stream), a, x, reinterpret_cast<uint4*>(out));
+    static int rgb2 = -1;
+    if (rgb2 < 0) { const char* e = getenv("DCV_S2D_RGB2"); rgb2 = e ? atoi(e) : 1; }
+    if (rgb2 && a.nchw && d->cin == 3 && d->stride_h == 2 && d->stride_w == 2 && cp == 16 && hs <= 65535 && d->n <= 65535)
+        hipLaunchKernelGGL(space_to_depth_rgb2_bf16_kernel, dim3((unsigned)dcv_ceil_div(ws, 128), (unsigned)hs, (unsigned)d->n), dim3(128), 0, dcv_stream(stream), a, x, reinterpret_cast<uint4*>(out));
+    else
+        hipLaunchKernelGGL(space_to_depth_bf16_kernel, dim3((unsigned)dcv_ceil_div(total, 256)), dim3(256), 0, dcv_stream(stream), a, x, reinterpret_cast<uint4*>(out));
     DCV_RETURN_LAUNCH();
 }
 
