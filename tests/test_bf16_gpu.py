@@ -29,6 +29,9 @@ CASES = [
     (9, 192, 40, 24, 64, 3, 1, 1, 1, 2, False),      # three chunks, non-square maps, leaky relu, no bias
     (70, 64, 31, 31, 64, 3, 1, 1, 1, 1, True),       # 263 tiles on 256 persistent blocks (64-wide instance): blocks with two tiles, ragged last tile, odd width, one chunk
     (34, 128, 31, 31, 64, 3, 1, 1, 1, 0, False),     # 128 tiles of two chunks: the chunk sequence running on across tiles is exercised by the N = 512 cases; here odd sizes
+    # XCD-aware block order (round 4): pixel-tile counts which are no multiple of eight leave the last group of blocks partial
+    (100, 128, 16, 16, 256, 3, 1, 1, 1, 1, True),    # window kernel, 128-wide instance: 100 tiles x 2 channel tiles
+    (3, 64, 10, 10, 256, 1, 1, 0, 1, 0, False),      # implicit-GEMM kernel: 3 pixel tiles x 2 channel tiles
     # maps of at most 16 pixels: the all-taps weight gradient takes two images per 32-pixel step (round 4)
     (7, 128, 4, 4, 64, 3, 1, 1, 1, 0, True),         # 4 x 4, odd batch: the last pair has one image
     (6, 64, 5, 3, 128, 3, 1, 1, 1, 1, False),        # 15 pixels per image, odd width
