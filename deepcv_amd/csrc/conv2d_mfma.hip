@@ -888,16 +888,27 @@ __global__ __launch_bounds__(256) void mfma_wgrad9_reduce_kernel(const float* __
 // output goes out as 4-B stores 36 B apart.  Here a thread sums all slabs of one (tap, 4 input channels) item itself (every load independent), the block
 // gathers the nine taps of (one output channel, CB input channels) in LDS and writes them as one contiguous run of dw.
 template <int CB>
-__global__ __launch_bounds__(256) void mfma_wgrad9_reduce_few_kernel(const float* __restrict__ partial, float* __restrict__ dw, int chunks, int Cout, int Cin) {
+__global__ __launch_bounds__(9 * CB / 4 + 32) void mfma_wgrad9_reduce_few_kernel(const float* __restrict__ partial, float* __restrict__ dw, int chunks, int Cout, int Cin) {
+    // block = 9 CB / 4 items rounded up to whole waves (CB = 128: 288 of 320 threads, CB = 64: 144 of 192): ONE round of items (with 256 threads the 288 items
+    // of CB = 128 took two rounds, the second on 32 threads), up to sixteen independent 16-byte loads per thread in flight; the slabs are added in the same order
+    constexpr int ITEMS = 9 * (CB / 4), THREADS = 9 * CB / 4 + 32;
     __shared__ __attribute__((aligned(16))) float out[CB * 9];
     const int co = blockIdx.y, ci0 = blockIdx.x * CB;
     const size_t wtotal = (size_t)9 * Cout * Cin;
-    for (int i = threadIdx.x; i < 9 * (CB / 4); i += 256) {
+    const int i = threadIdx.x;
+    if (i < ITEMS) {
         const int tap = i / (CB / 4), v4 = i - tap * (CB / 4);
         const float* src = partial + ((size_t)tap * Cout + co) * Cin + ci0 + 4 * v4;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-        for (int c = 0; c < chunks; ++c) {
+        int c = 0;
+        for (; c + 8 <= chunks; c += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4*>(src + (size_t)(c + k) * wtotal);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s.x += v[k].x; s.y += v[k].y; s.z += v[k].z; s.w += v[k].w; }
+        }
+        for (; c < chunks; ++c) {
             const float4 v = *reinterpret_cast<const float4*>(src + (size_t)c * wtotal);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
@@ -905,7 +916,7 @@ __global__ __launch_bounds__(256) void mfma_wgrad9_reduce_few_kernel(const float
     }
     __syncthreads();
     float4* dst = reinterpret_cast<float4*>(dw + ((size_t)co * Cin + ci0) * 9);
-    for (int i = threadIdx.x; i < CB * 9 / 4; i += 256) dst[i] = reinterpret_cast<const float4*>(out)[i];
+    for (int j = threadIdx.x; j < CB * 9 / 4; j += THREADS) dst[j] = reinterpret_cast<const float4*>(out)[j];
 }
 
 __global__ __launch_bounds__(1024) void mfma_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int chunks, size_t wtotal) {
@@ -1383,8 +1394,8 @@ int dcv_mfma_wgrad_reduce_plain(const float* partial, float* dw, int chunks, siz
 
 int dcv_mfma_wgrad9_reduce(const float* partial, float* dw, int chunks, int cout, int cin, hipStream_t st) {
     if (chunks <= 16 && cin % 64 == 0 && cout <= 65535 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0) {
-        if (cin % 128 == 0) hipLaunchKernelGGL(mfma_wgrad9_reduce_few_kernel<128>, dim3((unsigned)(cin / 128), (unsigned)cout), dim3(256), 0, st, partial, dw, chunks, cout, cin);
-        else hipLaunchKernelGGL(mfma_wgrad9_reduce_few_kernel<64>, dim3((unsigned)(cin / 64), (unsigned)cout), dim3(256), 0, st, partial, dw, chunks, cout, cin);
+        if (cin % 128 == 0) hipLaunchKernelGGL(mfma_wgrad9_reduce_few_kernel<128>, dim3((unsigned)(cin / 128), (unsigned)cout), dim3(320), 0, st, partial, dw, chunks, cout, cin);
+        else hipLaunchKernelGGL(mfma_wgrad9_reduce_few_kernel<64>, dim3((unsigned)(cin / 64), (unsigned)cout), dim3(176), 0, st, partial, dw, chunks, cout, cin);
         return (hipGetLastError() == hipSuccess) ? DCV_OK : DCV_ERR_LAUNCH;
     }
     hipLaunchKernelGGL(mfma_wgrad9_reduce_kernel, dim3((unsigned)dcv_ceil_div((size_t)9 * cout * cin / 4, 8)), dim3(256), 0, st, partial, dw, chunks, cout, cin);

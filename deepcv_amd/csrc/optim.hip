@@ -2,7 +2,7 @@
 //
 // Roofline: HBM.  Algorithmic bytes per parameter: AdamW 28 B (read p,g,m,v; write p,m,v), SGD-momentum 20 B.
 // One launch updates up to DCV_MAX_TENSORS parameter tensors: the tensor table travels by value in the kernel arguments (no
-// H2D copy), grid = (chunks of the largest tensor, tensors).  Step-dependent scalars (lr, momentum, bias corrections) are read
+// H2D copy), grid = one row of 1024-element blocks, tensor after tensor (`list_block`).  Step-dependent scalars (lr, momentum, bias corrections) are read
 // from DEVICE memory so that a captured hipGraph replays with the scheduler's current values.
 //
 // Replaces torch.optim.AdamW (reference classification/image.py:71; options conf/base/parameters.yml:129-134), torch.optim.SGD
@@ -24,13 +24,25 @@ __global__ void optim_prepare_kernel(float* __restrict__ hyper, int64_t* __restr
     hyper[DCV_HYP_FIRST_STEP] = (s == 1) ? 1.f : 0.f;
 }
 
+// Block -> (tensor, first element): the grid is ONE row of blocks, tensor after tensor (round 4, last session: grid = (blocks of the largest tensor, tensors) launched
+// 92 000 blocks for the 40 tensors of cifar100_deep, of which 4 800 had work — dispatching the empty ones was a third of the kernel).  A scalar walk over the
+// table's element counts (at most DCV_MAX_TENSORS steps).
+__device__ __forceinline__ bool list_block(const dcv_tensor_list& tl, int& t, int64_t& base) {
+    int64_t b = blockIdx.x;
+    for (int k = 0; k < tl.count; ++k) {
+        const int64_t nb = (tl.numel[k] + OPT_ELEMS_PER_BLOCK - 1) / OPT_ELEMS_PER_BLOCK;
+        if (b < nb) { t = k; base = b * OPT_ELEMS_PER_BLOCK; return true; }
+        b -= nb;
+    }
+    return false;
+}
+
 // (the update itself: optim_update.h, shared with the update + filter re-layout kernel of conv2d.hip)
 template <bool AMSGRAD>
 __global__ __launch_bounds__(OPT_BLOCK) void adamw_kernel(dcv_tensor_list tl, const float* __restrict__ hyper) {
-    const int t = blockIdx.y;
+    int t; int64_t base;
+    if (!list_block(tl, t, base)) return;
     const int64_t n = tl.numel[t];
-    const int64_t base = (int64_t)blockIdx.x * OPT_ELEMS_PER_BLOCK;
-    if (base >= n) return;
     const dcv_adamw_scalars sc = dcv_adamw_load_scalars(hyper);
     float* __restrict__ p = tl.param[t]; const float* __restrict__ g = tl.grad[t];
     float* __restrict__ m = tl.state1[t]; float* __restrict__ v = tl.state2[t]; float* __restrict__ vmax = tl.state3[t];
@@ -42,37 +54,57 @@ __global__ __launch_bounds__(OPT_BLOCK) void adamw_kernel(dcv_tensor_list tl, co
 }
 
 // torch.optim.SGD semantics: g += wd*p ; buf = (first step) g : mu*buf + (1-dampening)*g ; g = nesterov ? g + mu*buf : buf ; p -= lr*g
+// (one element's update, shared by the 16-byte and the scalar path of the kernel below: the same expression tree, the same bits)
+template <bool NESTEROV>
+__device__ __forceinline__ void sgd_one(float& pi, float gi, float& bi, bool has_buf, bool first, float lr, float mu, float damp, float wd, float gs) {
+    gi = gi * gs + wd * pi;
+    if (has_buf) {
+        bi = first ? gi : mu * bi + (1.f - damp) * gi;
+        gi = NESTEROV ? gi + mu * bi : bi;
+    }
+    pi = pi - lr * gi;
+}
+
+// A thread owns four CONSECUTIVE elements: 16-byte loads / stores when the tensor's pointers allow it (round 4, last session: the 4-byte accesses ran the
+// 4.9 M parameters of cifar100_deep at 2.2 TB/s, 44 us per step).
 template <bool NESTEROV>
 __global__ __launch_bounds__(OPT_BLOCK) void sgd_kernel(dcv_tensor_list tl, const float* __restrict__ hyper) {
-    const int t = blockIdx.y;
+    int t; int64_t base;
+    if (!list_block(tl, t, base)) return;
     const int64_t n = tl.numel[t];
-    const int64_t base = (int64_t)blockIdx.x * OPT_ELEMS_PER_BLOCK;
-    if (base >= n) return;
     const float lr = hyper[DCV_HYP_LR], mu = hyper[DCV_HYP_BETA1], damp = hyper[DCV_HYP_BETA2];
     const float wd = hyper[DCV_HYP_WEIGHT_DECAY], gs = hyper[DCV_HYP_GRAD_SCALE];
     const bool first = hyper[DCV_HYP_FIRST_STEP] != 0.f;
     float* __restrict__ p = tl.param[t]; const float* __restrict__ g = tl.grad[t]; float* __restrict__ buf = tl.state1[t];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int64_t i = base + (int64_t)k * OPT_BLOCK + threadIdx.x;
-        if (i < n) {
-            const float pi = p[i];
-            float gi = g[i] * gs + wd * pi;
-            if (buf != nullptr) {
-                const float bi = first ? gi : mu * buf[i] + (1.f - damp) * gi;
-                buf[i] = bi;
-                gi = NESTEROV ? gi + mu * bi : bi;
-            }
-            p[i] = pi - lr * gi;
-        }
+    const bool has_buf = buf != nullptr;
+    const int64_t i0 = base + 4 * (int64_t)threadIdx.x;
+    if (i0 >= n) return;
+    const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(buf)) & 15) == 0 && i0 + 3 < n;
+    if (vec) {
+        float4 pv = *reinterpret_cast<const float4*>(p + i0);
+        const float4 gv = *reinterpret_cast<const float4*>(g + i0);
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has_buf && !first) bv = *reinterpret_cast<const float4*>(buf + i0);
+        sgd_one<NESTEROV>(pv.x, gv.x, bv.x, has_buf, first, lr, mu, damp, wd, gs);
+        sgd_one<NESTEROV>(pv.y, gv.y, bv.y, has_buf, first, lr, mu, damp, wd, gs);
+        sgd_one<NESTEROV>(pv.z, gv.z, bv.z, has_buf, first, lr, mu, damp, wd, gs);
+        sgd_one<NESTEROV>(pv.w, gv.w, bv.w, has_buf, first, lr, mu, damp, wd, gs);
+        if (has_buf) *reinterpret_cast<float4*>(buf + i0) = bv;
+        *reinterpret_cast<float4*>(p + i0) = pv;
+        return;
+    }
+    for (int64_t i = i0; i < i0 + 4 && i < n; ++i) {
+        float pi = p[i], bi = (has_buf && !first) ? buf[i] : 0.f;
+        sgd_one<NESTEROV>(pi, g[i], bi, has_buf, first, lr, mu, damp, wd, gs);
+        if (has_buf) buf[i] = bi;
+        p[i] = pi;
     }
 }
 
 __global__ __launch_bounds__(OPT_BLOCK) void pack_kernel(dcv_tensor_list tl, float* __restrict__ dst) {
-    const int t = blockIdx.y;
+    int t; int64_t base;
+    if (!list_block(tl, t, base)) return;
     const int64_t n = tl.numel[t];
-    const int64_t base = (int64_t)blockIdx.x * OPT_ELEMS_PER_BLOCK;
-    if (base >= n) return;
     float* __restrict__ out = tl.param[t];                        // explicit destination (bucket slices with alignment padding) ...
     if (out == nullptr) {                                         // ... or the tensors back to back in `dst`
         int64_t off = 0;
@@ -96,11 +128,10 @@ inline int list_grid(const dcv_tensor_list* tl, dim3* grid, bool need_param, boo
         if (need_state1 && !tl->state1[i]) return DCV_ERR_INVALID_ARG;
         if (need_state2 && !tl->state2[i]) return DCV_ERR_INVALID_ARG;
         if (need_state3 && !tl->state3[i]) return DCV_ERR_INVALID_ARG;
-        if (tl->numel[i] > mx) mx = tl->numel[i];
+        mx += (tl->numel[i] + OPT_ELEMS_PER_BLOCK - 1) / OPT_ELEMS_PER_BLOCK;
     }
-    const int64_t bx = (mx + OPT_ELEMS_PER_BLOCK - 1) / OPT_ELEMS_PER_BLOCK;
-    if (bx > 0x7fffffffLL) return DCV_ERR_UNSUPPORTED;
-    *grid = dim3((unsigned)bx, (unsigned)tl->count, 1);
+    if (mx > 0x7fffffffLL) return DCV_ERR_UNSUPPORTED;
+    *grid = dim3((unsigned)mx, 1, 1);
     return DCV_OK;
 }
 
