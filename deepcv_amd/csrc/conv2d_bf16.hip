@@ -1377,7 +1377,9 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9p_kernel(W16p
     // ---- operand addresses of this lane (bytes inside a stage, + the group's base): pixel j0 of each K half
     const int j0 = 4 * lg + (li >> 2), sub = (li & 3) * 8;
     auto wpos = [&](int j) { return (j >> wsh) * WP + (j & (SW - 1)); };      // K-axis pixel -> window row (before the tap offset: the centre tap is + WP + 1)
+    // (computed BEHIND the first two steps' requests — `operand_addresses()` below —: a few hundred instructions which used to run in front of them)
     unsigned aaddr[2][4], baddr[2][9];
+    auto operand_addresses = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
         const int ra = j0 + 16 * hf;
@@ -1400,6 +1402,7 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9p_kernel(W16p
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) asm volatile("" : "+v"(baddr[hf][tp]));
     }
+    };
     // ---- staging, by wave ROLES (every per-step decision is a scalar of the wave; a step issues no dummy instructions: each wave counts its own requests):
     // wave 0 stages the dz tile (4 instructions of 8 rows; image pairs: rows 16 .. 31 from the second image), waves 1 - 3 the window instructions
     // j = wave - 1, wave + 2, ... (image pairs: instructions NX .. 2 NX - 1 are the second image's window).  Lane = row 8 j + lane / 8, 16-byte piece lane % 8,
@@ -1409,6 +1412,7 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9p_kernel(W16p
     const int cnt = dzw ? 4 : (ips * NX - (wave - 1) + 2) / 3;    // requests of this wave per step (<= 5)
     const int n0 = dzw ? (ips == 2 ? 2 : 4) : (ips == 2 ? (NX - (wave - 1) + 2) / 3 : 5);      // the first n0 of them read the step's first image
     unsigned voff[2][5];                                         // [segment][request]: offsets relative to the step's first pixel (h0, c0)
+    const unsigned wp_magic = 65536u / (unsigned)WP + 1u;        // WP = 6 / 10 / 18 / 34: one division instead of ten
     const unsigned sdst0 = dzw ? 0u : (unsigned)(W16P_XOFF + (wave - 1) * 1024), sdstep = dzw ? 1024u : 3072u;      // LDS destination of request i: sdst0 + i sdstep
 #pragma unroll
     for (int sg = 0; sg < 2; ++sg)
@@ -1421,7 +1425,7 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9p_kernel(W16p
                 if (sg * SW + jc < Wt) v = (unsigned)(((jr * Wt + jc) * a.Cout + co0) * 2 + ((piece ^ (((row >> 1) & 3) << 1)) << 4));
             } else {
                 const int jx = (wave - 1) + 3 * i, wi = jx >= NX ? jx - NX : jx;
-                const int q = 8 * wi + r8, hh = q / WP, ww = q - hh * WP, col = sg * SW - 1 + ww;
+                const int q = 8 * wi + r8, hh = (int)(((unsigned)q * wp_magic) >> 16), ww = q - hh * WP, col = sg * SW - 1 + ww;      // (q / WP: exact for q < 2000)
                 if (col >= 0 && col < Wt) v = (unsigned)((((hh - 1) * Wt + ww - 1) * a.Cin + ci0) * 2 + ((piece ^ (((q >> 1) & 3) << 1)) << 4));      // (mod 2^32: the row above the image wraps out of range)
             }
             voff[sg][i] = v;
@@ -1496,6 +1500,7 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9p_kernel(W16p
         }
     };
     for (int j = 0; j < 2; ++j) if (j < steps_g) dma_step(j);
+    operand_addresses();
     for (int it = 0; it < nsteps; it += 3) {
         body(std::integral_constant<int, 0>{}, it);
         if (it + 1 < nsteps) body(std::integral_constant<int, 1>{}, it + 1);
@@ -1518,15 +1523,18 @@ __global__ __launch_bounds__(256 * GROUPS, 2) void conv_bf16_wgrad9p_kernel(W16p
             for (int tt = 0; tt < 4; ++tt) acc[k][tt] += red[(k * 4 + tt) * 256 + t];
     }
     // acc[tap][tt][reg]: co = co0 + 16 tt + 4 lg + reg, ci = ci0 + 16 wave + li
-    float* dst = partial + (size_t)blockIdx.x * a.wtotal;
+    // a store = a wave-uniform row pointer (tap, 16-channel tile, register: scalar arithmetic) + the lane's own 32-bit offset (the 64-bit index product per store
+    // was ~1200 vector instructions on the one wave per SIMD which is left here)
+    float* dst = partial + (size_t)blockIdx.x * a.wtotal + (size_t)co0 * a.Cin + ci0 + wave * 16;
+    const unsigned lane_off = (unsigned)(4 * lg * a.Cin + li);
 #pragma unroll
     for (int k = 0; k < 9; ++k)
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const int co = co0 + tt * 16 + 4 * lg + reg, ci = ci0 + wave * 16 + li;
-                dst[((size_t)k * a.Cout + co) * a.Cin + ci] = acc[k][tt][reg];
+                float* row = dst + ((size_t)k * a.Cout + tt * 16 + reg) * a.Cin;
+                row[lane_off] = acc[k][tt][reg];
             }
 }
 
