@@ -151,7 +151,7 @@ _WARNED_NON_NATIVE = set()
 
 
 def _warn_if_not_native(module: Any) -> Any:
-    """ Modules this package has no HIP kernels for (1-D / 3-D operators, LayerNorm, InstanceNorm, LocalResponseNorm: none is on a BASELINE config) run on
+    """ Modules this package has no HIP kernels for (1-D / 3-D operators, LayerNorm, LocalResponseNorm: none is on a BASELINE config) run on
     torch's own ATen / MIOpen kernels; say so once per type instead of silently mixing back-ends (native 2-D modules raise on CPU tensors, these do not). """
     cls = type(module)
     if isinstance(module, torch.nn.Module) and cls.__module__.startswith('torch.nn') and cls not in _WARNED_NON_NATIVE:
@@ -173,7 +173,7 @@ conv_nd = functools.partial(nd_support, {1: torch.nn.Conv1d, 2: native.Conv2d, 3
 conv_transpose_nd = functools.partial(nd_support, {1: torch.nn.ConvTranspose1d, 2: torch.nn.ConvTranspose2d, 3: torch.nn.ConvTranspose3d}, _name='conv_transpose_nd')
 avg_pooling_nd = functools.partial(nd_support, {1: torch.nn.AvgPool1d, 2: native.AvgPool2d, 3: torch.nn.AvgPool3d}, _name='avg_pooling_nd')
 batch_norm_nd = functools.partial(nd_support, {0: native.BatchNorm1d, 1: native.BatchNorm1d, 2: native.BatchNorm2d, 3: torch.nn.BatchNorm3d}, _name='batch_norm_nd')
-instance_norm_nd = functools.partial(nd_support, {1: torch.nn.InstanceNorm1d, 2: torch.nn.InstanceNorm2d, 3: torch.nn.InstanceNorm3d}, _name='instance_norm_nd')
+instance_norm_nd = functools.partial(nd_support, {1: torch.nn.InstanceNorm1d, 2: native.InstanceNorm2d, 3: torch.nn.InstanceNorm3d}, _name='instance_norm_nd')
 
 
 class NormTechnique(enum.Enum):

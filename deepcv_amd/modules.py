@@ -148,6 +148,19 @@ class GroupNorm(torch.nn.GroupNorm):
         return ops.group_norm(x, self.weight, self.bias, self.num_groups, self.eps)
 
 
+class InstanceNorm2d(torch.nn.InstanceNorm2d):
+    """ Per-(sample, channel) normalisation over the map (reference normalisation factory, `nn.py:444-445`: `instance_norm`) on the GroupNorm kernels with ONE
+    channel per group (`dcv_groupnorm_fwd / _bwd`, groups = C; the affine — off by default like torch's — is GroupNorm's per-channel one).  With
+    `track_running_stats=True` (off by default) the module keeps batch-averaged statistics GroupNorm has no notion of: that configuration runs on torch's kernel. """
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if _shape_only(x):
+            return torch.zeros(x.shape)
+        if self.track_running_stats or x.dim() != 4:
+            return super().forward(x)
+        self._check_input_dim(x)
+        return ops.group_norm(x, self.weight, self.bias, x.shape[1], self.eps)
+
+
 class AvgPool2d(torch.nn.AvgPool2d):
     def _geom(self):
         if self.ceil_mode or not self.count_include_pad or self.divisor_override is not None:

@@ -192,6 +192,39 @@ def test_group_norm(device, shape, groups):
     _check(name + '.dbeta', bd.grad, ref['dbeta'], 3e-4)
 
 
+@pytest.mark.parametrize('affine', [False, True], ids=['plain', 'affine'])
+@pytest.mark.parametrize('shape', [(4, 16, 16, 16), (3, 12, 5, 7), (2, 64, 8, 8)], ids=str)
+def test_instance_norm_module_on_the_group_norm_kernels(device, shape, affine):
+    """ `instance_norm` of the normalisation factory (reference `nn.py:444-445`) = `deepcv_amd.modules.InstanceNorm2d`: GroupNorm kernels with one channel per
+    group, against torch's instance normalisation in double precision (forward, dx and — with the affine — the parameter gradients). """
+    from deepcv_amd import modules
+    from deepcv_amd.meta import nn as dnn
+    g = torch.Generator().manual_seed(11 + shape[1])
+    c = shape[1]
+    x = torch.randn(*shape, generator=g) * 1.7 + 0.4
+    dy = torch.randn(*shape, generator=g)
+    m = dnn.instance_norm_nd(2, c, affine=affine)
+    assert isinstance(m, modules.InstanceNorm2d)
+    m = m.to(device).train()
+    w64 = b64 = None
+    if affine:
+        with torch.no_grad():
+            m.weight.copy_(torch.rand(c, generator=g) + 0.5); m.bias.copy_(torch.randn(c, generator=g))
+        w64, b64 = m.weight.detach().cpu().double().requires_grad_(True), m.bias.detach().cpu().double().requires_grad_(True)
+    x64 = x.double().requires_grad_(True)
+    ref = torch.nn.functional.instance_norm(x64, weight=w64, bias=b64, eps=m.eps)
+    ref.backward(dy.double())
+    xd = _cl(x.to(device)).requires_grad_(True)
+    y = m(xd)
+    y.backward(_cl(dy.to(device)))
+    name = f'in{shape}{"a" if affine else ""}'
+    _check(name + '.y', y, ref.detach().float(), 1e-4)
+    _check(name + '.dx', xd.grad, x64.grad.float(), 3e-4)
+    if affine:
+        _check(name + '.dgamma', m.weight.grad, w64.grad.float(), 3e-4)
+        _check(name + '.dbeta', m.bias.grad, b64.grad.float(), 3e-4)
+
+
 @pytest.mark.parametrize('mode', ['avg', 'max'])
 @pytest.mark.parametrize('shape,k,s,p', [((8, 4, 32, 32), 2, 2, 0), ((8, 16, 16, 16), 2, 2, 0), ((2, 8, 15, 17), 3, 2, 1), ((2, 3, 9, 9), 3, 1, 1), ((2, 64, 7, 7), 7, 7, 0)], ids=str)
 def test_pool2d(device, mode, shape, k, s, p):
