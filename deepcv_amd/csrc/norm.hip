@@ -805,6 +805,50 @@ __global__ void bn_coef_from_sums_kernel(const double* __restrict__ sums, double
 
 inline size_t bn_ws_partial_bytes(size_t rows, int C) { return dcv_align_up((size_t)dcv_colreduce_blocks(rows, C) * 2 * C * sizeof(double), 256); }
 
+// ------------------------------------------------------------------------------------------------ LayerNorm's elementwise affine
+// torch.nn.LayerNorm over the last two ([H][W]: what the reference's factory builds, normalized_shape = input_shape[1:]) or three ([C][H][W]) dimensions of an
+// [N][C][H][W] tensor stored NHWC: the statistics are GroupNorm's with one channel per group (resp. one group) and no affine — gn_fwd_kernel / gn_bwd_kernel
+// above —, what is left is the per-ELEMENT affine y = xhat * w + b with w indexed [H][W] (wc_stride = 0: shared by the channels) or [C][H][W]
+// (wc_stride = HW) while the activations are [HW][C].  Forward: in place over xhat.  Backward: a thread per (pixel, channel) element walks the samples in
+// order (xhat recomputed from x and the saved statistics), leaves dxhat = dy * w for gn_bwd_kernel and its fp64 sums of dy * xhat and dy; a second kernel
+// adds the channels of a pixel in order where the weight is shared (fixed summation order: the same bits on every run).
+__global__ __launch_bounds__(256) void ln_affine_fwd_kernel(float* __restrict__ y, size_t total, int per_sample, int C, int wc_stride,
+                                                            const float* __restrict__ w, const float* __restrict__ b) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int e = (int)(i % (size_t)per_sample), p = e / C, c = e - p * C, wi = c * wc_stride + p;
+        y[i] = y[i] * w[wi] + (b ? b[wi] : 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void ln_affine_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, int n, int per_sample, int C, int G, int wc_stride,
+                                                            const float* __restrict__ w, float* __restrict__ dxhat, double* __restrict__ part) {
+    const int e = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (e >= per_sample) return;
+    const int p = e / C, c = e - p * C, g = G == 1 ? 0 : c;
+    const float wv = w[c * wc_stride + p];
+    double s_dyx = 0.0, s_dy = 0.0;
+#pragma unroll 4
+    for (int s = 0; s < n; ++s) {
+        const size_t i = (size_t)s * per_sample + e;
+        const float d = dy[i], xh = (x[i] - mean[(size_t)s * G + g]) * rstd[(size_t)s * G + g];
+        s_dy += (double)d; s_dyx += (double)d * (double)xh;
+        dxhat[i] = d * wv;
+    }
+    part[e] = s_dyx; part[(size_t)per_sample + e] = s_dy;
+}
+
+__global__ __launch_bounds__(256) void ln_affine_param_grad_kernel(const double* __restrict__ part, int per_sample, int C, int hw, int wc_stride,
+                                                                   float* __restrict__ dw, float* __restrict__ db) {
+    const int wi = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (wi >= (wc_stride ? per_sample : hw)) return;
+    double a = 0.0, b = 0.0;
+    if (wc_stride) { const int c = wi / hw, p = wi - c * hw; a = part[p * C + c]; b = part[(size_t)per_sample + p * C + c]; }
+    else for (int c = 0; c < C; ++c) { a += part[wi * C + c]; b += part[(size_t)per_sample + wi * C + c]; }
+    if (dw) dw[wi] = (float)a;
+    if (db) db[wi] = (float)b;
+}
+
 }  // namespace
 
 extern "C" {
@@ -912,6 +956,34 @@ int dcv_groupnorm_bwd(const float* dy, const float* x, float* dx, int n, int hw,
     else hipLaunchKernelGGL((gn_bwd_kernel<1>), dim3(n), dim3(DCV_CR_THREADS), smem, st, dy, x, dx, hw, C, G, gamma, save_mean, save_rstd, partial);
     if (need_param_grads)
         hipLaunchKernelGGL(gn_param_grad_kernel, dim3((unsigned)C), dim3(64), 0, st, partial, n, C, dgamma, dbeta);
+    DCV_RETURN_LAUNCH();
+}
+
+
+size_t dcv_layernorm_affine_workspace_bytes(int hw, int channels) {
+    if (hw <= 0 || channels <= 0) return 0;
+    return dcv_align_up((size_t)2 * hw * channels * sizeof(double), 256);
+}
+
+int dcv_layernorm_affine_fwd(float* y, int n, int hw, int C, int per_channel, const float* weight, const float* bias, void* stream) {
+    DCV_CHECK_ARG(y && weight && n > 0 && hw > 0 && C > 0 && (size_t)hw * C <= 0x7fffffffu);
+    const size_t total = (size_t)n * hw * C;
+    const size_t blocks = dcv_ceil_div(total, (size_t)256);
+    hipLaunchKernelGGL(ln_affine_fwd_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, dcv_stream(stream), y, total, hw * C, C, per_channel ? hw : 0, weight, bias);
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_layernorm_affine_bwd(const float* dy, const float* x, const float* save_mean, const float* save_rstd, int n, int hw, int C, int per_channel,
+                             const float* weight, float* dxhat, float* dweight, float* dbias, void* ws, size_t ws_bytes, void* stream) {
+    DCV_CHECK_ARG(dy && x && save_mean && save_rstd && weight && dxhat && n > 0 && hw > 0 && C > 0 && (size_t)hw * C <= 0x7fffffffu);
+    if (!ws || ws_bytes < dcv_layernorm_affine_workspace_bytes(hw, C)) return DCV_ERR_WORKSPACE;
+    hipStream_t st = dcv_stream(stream);
+    const int per_sample = hw * C, nw = per_channel ? per_sample : hw;
+    double* part = reinterpret_cast<double*>(ws);
+    hipLaunchKernelGGL(ln_affine_bwd_kernel, dim3((unsigned)dcv_ceil_div((size_t)per_sample, (size_t)256)), dim3(256), 0, st, dy, x, save_mean, save_rstd, n, per_sample, C,
+                       per_channel ? 1 : C, per_channel ? hw : 0, weight, dxhat, part);
+    if (dweight || dbias)
+        hipLaunchKernelGGL(ln_affine_param_grad_kernel, dim3((unsigned)dcv_ceil_div((size_t)nw, (size_t)256)), dim3(256), 0, st, part, per_sample, C, hw, per_channel ? hw : 0, dweight, dbias);
     DCV_RETURN_LAUNCH();
 }
 

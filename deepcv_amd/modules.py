@@ -17,7 +17,7 @@ import torch.nn
 from . import _native as nat
 from . import ops
 
-__all__ = ['shape_inference', 'in_shape_inference', 'Conv2d', 'Linear', 'BatchNorm1d', 'BatchNorm2d', 'SyncBatchNorm2d', 'GroupNorm', 'AvgPool2d', 'MaxPool2d', 'Flatten',
+__all__ = ['shape_inference', 'in_shape_inference', 'Conv2d', 'Linear', 'BatchNorm1d', 'BatchNorm2d', 'SyncBatchNorm2d', 'GroupNorm', 'InstanceNorm2d', 'LayerNorm', 'AvgPool2d', 'MaxPool2d', 'Flatten',
            'ReLU', 'LeakyReLU', 'Sigmoid', 'Tanh', 'CrossEntropyLoss', 'NATIVE_MODULE_TYPES', 'native_type', 'native_activation', 'is_native']
 
 _state = threading.local()
@@ -161,6 +161,27 @@ class InstanceNorm2d(torch.nn.InstanceNorm2d):
         return ops.group_norm(x, self.weight, self.bias, x.shape[1], self.eps)
 
 
+class LayerNorm(torch.nn.LayerNorm):
+    """ `torch.nn.LayerNorm` (reference normalisation factory, `nn.py:444`; `normalized_shape = input_shape[1:]` at `nn.py:492-493`, i.e. the map's [H, W]: statistics
+    per (sample, channel), ONE weight / bias per pixel shared by the channels) on the GroupNorm statistics kernels + `dcv_layernorm_affine_fwd / _bwd`.  Covered:
+    4-D inputs normalised over [H, W] or [C, H, W]; anything else (1-D / 3-D maps, a normalised shape of the last dimension alone) runs on torch's kernel. """
+    def _native_case(self, x: torch.Tensor) -> Optional[bool]:
+        if x.dim() != 4 or (self.bias is not None and self.weight is None):
+            return None
+        shape = tuple(self.normalized_shape)
+        if shape == tuple(x.shape[2:]):
+            return False
+        return True if shape == tuple(x.shape[1:]) else None
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if _shape_only(x):
+            return torch.zeros(x.shape)
+        per_channel = self._native_case(x)
+        if per_channel is None:
+            return super().forward(x)
+        return ops.layer_norm(x, self.weight, self.bias, per_channel, self.eps)
+
+
 class AvgPool2d(torch.nn.AvgPool2d):
     def _geom(self):
         if self.ceil_mode or not self.count_include_pad or self.divisor_override is not None:
@@ -245,7 +266,7 @@ class CrossEntropyLoss(torch.nn.CrossEntropyLoss):
 
 
 NATIVE_MODULE_TYPES = {torch.nn.Conv2d: Conv2d, torch.nn.Linear: Linear, torch.nn.BatchNorm1d: BatchNorm1d, torch.nn.BatchNorm2d: BatchNorm2d,
-                       torch.nn.GroupNorm: GroupNorm, torch.nn.AvgPool2d: AvgPool2d, torch.nn.MaxPool2d: MaxPool2d, torch.nn.Flatten: Flatten,
+                       torch.nn.GroupNorm: GroupNorm, torch.nn.LayerNorm: LayerNorm, torch.nn.AvgPool2d: AvgPool2d, torch.nn.MaxPool2d: MaxPool2d, torch.nn.Flatten: Flatten,
                        torch.nn.ReLU: ReLU, torch.nn.LeakyReLU: LeakyReLU, torch.nn.Sigmoid: Sigmoid, torch.nn.Tanh: Tanh,
                        torch.nn.CrossEntropyLoss: CrossEntropyLoss}
 

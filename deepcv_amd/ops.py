@@ -788,6 +788,58 @@ def group_norm(x, gamma, beta, groups: int, eps: float) -> torch.Tensor:
     return _GroupNormFn.apply(x, gamma, beta, int(groups), float(eps))
 
 
+class _LayerNormFn(torch.autograd.Function):
+    """ `torch.nn.LayerNorm` over the last two ([H, W]: the shape the reference's normalisation factory passes, `nn.py:492-493`) or three ([C, H, W]) dimensions
+    of a 4-D tensor: GroupNorm's statistics kernels without affine (one channel per group, resp. one group) + the per-element affine of
+    `dcv_layernorm_affine_fwd / _bwd`. """
+    @staticmethod
+    def forward(ctx, x, weight, bias, per_channel, eps):
+        _require_f32(x, weight, bias)
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        dev = x.device
+        groups = 1 if per_channel else c
+        y = torch.empty_like(x)
+        save_mean = torch.empty(n * groups, dtype=torch.float32, device=dev)
+        save_rstd = torch.empty(n * groups, dtype=torch.float32, device=dev)
+        st = nat.current_stream(dev)
+        nat.check(lib.dcv_groupnorm_fwd(x.data_ptr(), y.data_ptr(), n, h * w, c, groups, None, None, eps, save_mean.data_ptr(), save_rstd.data_ptr(), st), 'dcv_groupnorm_fwd')
+        if weight is not None:
+            nat.check(lib.dcv_layernorm_affine_fwd(y.data_ptr(), n, h * w, c, int(per_channel), weight.data_ptr(), nat.ptr(bias), st), 'dcv_layernorm_affine_fwd')
+        ctx.per_channel, ctx.groups, ctx.has_bias = bool(per_channel), groups, bias is not None
+        ctx.save_for_backward(x, weight, save_mean, save_rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, save_mean, save_rstd = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dev = dy.device
+        dy = to_nhwc(dy)
+        st = nat.current_stream(dev)
+        dweight = dbias = None
+        if weight is not None:
+            dxhat = torch.empty_like(x)
+            dweight = torch.empty_like(weight)
+            dbias = torch.empty_like(weight) if ctx.has_bias else None
+            ws = _ws(lib.dcv_layernorm_affine_workspace_bytes(h * w, c), dev)
+            nat.check(lib.dcv_layernorm_affine_bwd(dy.data_ptr(), x.data_ptr(), save_mean.data_ptr(), save_rstd.data_ptr(), n, h * w, c, int(ctx.per_channel),
+                                                   weight.data_ptr(), dxhat.data_ptr(), dweight.data_ptr(), nat.ptr(dbias), ws.data_ptr(), ws.numel(), st),
+                      'dcv_layernorm_affine_bwd')
+            dy = dxhat
+        dx = torch.empty_like(x)
+        nat.check(lib.dcv_groupnorm_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), n, h * w, c, ctx.groups, None, save_mean.data_ptr(), save_rstd.data_ptr(),
+                                        None, None, None, 0, st), 'dcv_groupnorm_bwd')
+        return dx, dweight, dbias, None, None
+
+
+def layer_norm(x, weight, bias, per_channel: bool, eps: float) -> torch.Tensor:
+    """ `per_channel`: the normalised shape is [C, H, W] (weight per element of the sample) instead of [H, W] (weight shared by the channels). """
+    resident.forbid('a standalone layer_norm')
+    x = _f32(x)
+    return _LayerNormFn.apply(x, weight, bias, bool(per_channel), float(eps))
+
+
 # ------------------------------------------------------------------------------------------------ fused layer: conv + act + BatchNorm [+ GroupNorm]
 
 _norm_streaming = True

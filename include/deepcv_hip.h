@@ -268,6 +268,18 @@ int dcv_groupnorm_bwd(const float* dy, const float* x, float* dx, int n, int hw,
                       void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * K6b  LayerNorm's per-element affine, NHWC [N][HW][C] activations
+ * replaces torch.nn.LayerNorm of the normalisation factory (nn.py:444, normalized_shape = input_shape[1:] at nn.py:492-493: the map's [H][W]).  The
+ * statistics are dcv_groupnorm_fwd / _bwd with groups = channels (weight [H][W], per_channel = 0) or groups = 1 (weight [C][H][W], per_channel = 1) and
+ * no affine; these entry points apply y = xhat * weight + bias in place over xhat, and give dxhat = dy * weight (the dy of dcv_groupnorm_bwd), dweight
+ * and dbias (fp64 sums in a fixed order).  `ws`: dcv_layernorm_affine_workspace_bytes(hw, channels).
+ * ------------------------------------------------------------------------------------------------- */
+size_t dcv_layernorm_affine_workspace_bytes(int hw, int channels);
+int dcv_layernorm_affine_fwd(float* y, int n, int hw, int channels, int per_channel, const float* weight, const float* bias /* may be NULL */, void* stream);
+int dcv_layernorm_affine_bwd(const float* dy, const float* x, const float* save_mean, const float* save_rstd, int n, int hw, int channels, int per_channel,
+                             const float* weight, float* dxhat, float* dweight, float* dbias, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * K5 split in two phases for cross-GPU statistics (`use_sync_batch_norm`, ignite_training.py:203,386-388 -> torch.nn.SyncBatchNorm; collective C4):
  * the caller all-reduces `sums` ([2][channels] doubles) over the process group between the phases and passes the global row count.
  *   forward : dcv_batchnorm_stats (sum x, sum x^2 of the local rows)            -> all-reduce -> dcv_batchnorm_fwd_from_sums

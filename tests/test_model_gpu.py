@@ -224,6 +224,42 @@ def test_wide_models_match_oracle(device, params, spec, nc, shape, n):
     assert med <= 3e-2 and max(errs.values()) <= 0.5, f'gradient rel err: median {med:.3e}, worst {max(errs.values()):.3e} at {max(errs, key=errs.get)}'
 
 
+def _other_norms_spec():
+    """ A small spec in the reference's grammar whose layers use the OTHER normalisations of the factory (`nn.py:444-445`): LayerNorm (normalised over the
+    map's [H, W], `nn.py:492-493`), InstanceNorm with its affine, and LayerNorm behind a BatchNorm; Tanh everywhere (no kink can hide a gradient error). """
+    conv = {'kernel_size': [3, 3], 'padding': 1}
+    return {'act_fn': torch.nn.Tanh, 'dropout_prob': 0.0, 'batch_norm': None, 'spectral_norm': None, 'architecture': [
+        {'conv2d': dict(conv, out_channels=8, layer_norm={'eps': 1e-5})},
+        {'conv2d': dict(conv, out_channels=8, instance_norm={'eps': 1e-5, 'affine': True})},
+        {'avg_pooling': {'kernel_size': [2, 2], 'stride': [2, 2]}},
+        {'conv2d': dict(conv, out_channels=16, batch_norm={'affine': True, 'eps': 1e-5, 'momentum': 0.1}, layer_norm={'eps': 1e-5})},
+        {'avg_pooling': {'kernel_size': [2, 2], 'stride': [2, 2]}},
+        torch.nn.Flatten,
+        {'fully_connected': {'act_fn': torch.nn.Sigmoid, 'dropout_prob': 0., 'batch_norm': None}}]}
+
+
+def test_layer_and_instance_norm_layers_match_oracle(device, caplog):
+    """ The factory's LayerNorm / InstanceNorm inside `layer()` (reference `submodule_creators.py:251`, `nn.py:487-501`): native modules (no torch-kernel warning),
+    forward / loss / every gradient against the CPU oracle at the fp32 bars. """
+    import logging
+    from deepcv_amd import modules
+    from deepcv_amd.meta import nn as dnn
+    dnn._WARNED_NON_NATIVE.clear()
+    with caplog.at_level(logging.WARNING):
+        native, oracle = _build({'m': _other_norms_spec()}, 'm', 10)
+    assert not [r for r in caplog.records if 'no hand-written HIP kernel' in r.getMessage()]
+    kinds = [type(m) for m in native.modules()]
+    assert kinds.count(modules.LayerNorm) == 2 and kinds.count(modules.InstanceNorm2d) == 1
+    for (kn, vn), (ko, vo) in zip(native.state_dict().items(), oracle.state_dict().items()):
+        assert kn == ko and torch.equal(vn, vo), kn
+    (x, y), = _batches(1, 16)
+    e_logits, e_loss = _fwd_bwd_pair(native.to(device), oracle, x, y, device)
+    errs = _grad_rel_errors(native, oracle)
+    _report(f'other norms spec: logits rel err {e_logits:.3e}, loss rel err {e_loss:.3e}, worst grad rel err {max(errs.values()):.3e} ({max(errs, key=errs.get)})')
+    assert e_logits <= 1e-3 and e_loss <= 1e-4
+    assert max(errs.values()) <= 2e-3, f'gradient rel err {max(errs.values()):.3e} at {max(errs, key=errs.get)}'
+
+
 def _family_delta(before: dict, after: dict) -> dict:
     return {k: after[k] - before[k] for k in after if after[k] != before[k]}
 

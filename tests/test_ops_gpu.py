@@ -225,6 +225,48 @@ def test_instance_norm_module_on_the_group_norm_kernels(device, shape, affine):
         _check(name + '.dbeta', m.bias.grad, b64.grad.float(), 3e-4)
 
 
+@pytest.mark.parametrize('affine', ['plain', 'weight', 'affine'])
+@pytest.mark.parametrize('per_channel', [False, True], ids=['hw', 'chw'])
+@pytest.mark.parametrize('shape', [(4, 16, 16, 16), (3, 12, 5, 7), (37, 3, 8, 8), (2, 64, 8, 8)], ids=str)
+def test_layer_norm_module_on_the_group_norm_kernels(device, shape, per_channel, affine):
+    """ `layer_norm` of the normalisation factory (reference `nn.py:444`, normalised shape = the map's [H, W] by `nn.py:492-493`) = `deepcv_amd.modules.LayerNorm`:
+    GroupNorm statistics kernels (one channel per group; one group for a [C, H, W] shape) + `dcv_layernorm_affine_fwd / _bwd`, against torch's layer
+    normalisation in double precision (forward, dx, parameter gradients); NCHW-order parameters, NHWC activations. """
+    from deepcv_amd import modules
+    from deepcv_amd.meta import nn as dnn
+    g = torch.Generator().manual_seed(13 + shape[1] + shape[0])
+    x = torch.randn(*shape, generator=g) * 1.7 + 0.4
+    dy = torch.randn(*shape, generator=g)
+    if per_channel:
+        m = modules.LayerNorm(list(shape[1:]), elementwise_affine=affine != 'plain', bias=affine == 'affine')
+    else:
+        m = dnn.normalization_techniques(input_shape=torch.Size(shape[1:]), layer_norm={'eps': 1e-5, 'elementwise_affine': affine != 'plain', 'bias': affine == 'affine'})[0]
+    assert isinstance(m, modules.LayerNorm) and m._native_case(x) is per_channel
+    m = m.to(device).train()
+    w64 = b64 = None
+    if affine != 'plain':
+        with torch.no_grad():
+            m.weight.copy_(torch.rand(*m.weight.shape, generator=g) + 0.5)
+        w64 = m.weight.detach().cpu().double().requires_grad_(True)
+    if affine == 'affine':
+        with torch.no_grad():
+            m.bias.copy_(torch.randn(*m.bias.shape, generator=g))
+        b64 = m.bias.detach().cpu().double().requires_grad_(True)
+    x64 = x.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(x64, list(m.normalized_shape), weight=w64, bias=b64, eps=m.eps)
+    ref.backward(dy.double())
+    xd = _cl(x.to(device)).requires_grad_(True)
+    y = m(xd)
+    y.backward(_cl(dy.to(device)))
+    name = f'ln{shape}{"chw" if per_channel else "hw"}{affine}'
+    _check(name + '.y', y, ref.detach().float(), 1e-4)
+    _check(name + '.dx', xd.grad, x64.grad.float(), 3e-4)
+    if w64 is not None:
+        _check(name + '.dweight', m.weight.grad, w64.grad.float(), 3e-4)
+    if b64 is not None:
+        _check(name + '.dbias', m.bias.grad, b64.grad.float(), 3e-4)
+
+
 @pytest.mark.parametrize('mode', ['avg', 'max'])
 @pytest.mark.parametrize('shape,k,s,p', [((8, 4, 32, 32), 2, 2, 0), ((8, 16, 16, 16), 2, 2, 0), ((2, 8, 15, 17), 3, 2, 1), ((2, 3, 9, 9), 3, 1, 1), ((2, 64, 7, 7), 7, 7, 0)], ids=str)
 def test_pool2d(device, mode, shape, k, s, p):
