@@ -250,7 +250,7 @@ class LayerSequential(torch.nn.Sequential):
     def _fused_layer_plan(self, mods):
         """ (conv, act, batch_norm, group_norm | None, next index) when the children start with `Conv2d - act? - BatchNorm2d - GroupNorm?` (the post-activation
         layout of `layer()`) in a state the fused training kernels cover, else None. """
-        if not (self.training and len(mods) >= 2 and isinstance(mods[0], native.Conv2d)) or native.in_shape_inference():
+        if not (self.training and len(mods) >= 2 and isinstance(mods[0], native.Conv2d) and mods[0].groups == 1) or native.in_shape_inference():
             return None
         i, act = 1, None
         if isinstance(mods[i], native._NativeAct):

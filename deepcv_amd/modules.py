@@ -52,11 +52,12 @@ def _pair(v) -> Tuple[int, int]:
 
 
 class Conv2d(torch.nn.Conv2d):
-    """ `torch.nn.Conv2d` with HIP forward/backward (direct NHWC kernels for small channel counts, MFMA implicit GEMM for wide ones). """
+    """ `torch.nn.Conv2d` with HIP forward/backward (direct NHWC kernels for small channel counts, MFMA implicit GEMM for wide ones; `groups > 1`: each
+    channel group on those kernels, `ops.grouped_conv2d`). """
 
     def _check(self):
-        if self.groups != 1 or self.padding_mode != 'zeros':
-            raise NotImplementedError('deepcv_amd.Conv2d: only groups=1 and padding_mode="zeros" have native kernels')
+        if self.padding_mode != 'zeros':
+            raise NotImplementedError('deepcv_amd.Conv2d: only padding_mode="zeros" has native kernels')
 
     def _padding_pair(self) -> Tuple[int, int]:
         if isinstance(self.padding, str):
@@ -78,6 +79,9 @@ class Conv2d(torch.nn.Conv2d):
         self._check()
         if _shape_only(x):
             return torch.zeros(self.out_shape(x.shape))
+        if self.groups != 1:       # independent channel groups on the ungrouped kernels (`ops._GroupedConv2dFn`); the activation is its own launch
+            y = ops.grouped_conv2d(x, self.weight, self.bias, self.stride, self._padding_pair(), self.dilation, self.groups)
+            return y if fused_act[0] == nat.ACT_NONE else ops.activation(y, fused_act[0], fused_act[1])
         return ops.conv2d(x, self.weight, self.bias, self.stride, self._padding_pair(), self.dilation, fused_act[0], fused_act[1])
 
 

@@ -592,6 +592,74 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return _Conv2dFn.apply(x, weight, bias, _pair(stride), _pair(padding), _pair(dilation), int(act), float(slope))
 
 
+class _GroupedConv2dFn(torch.autograd.Function):
+    """ `torch.nn.Conv2d(groups=g)` (the reference's `conv2d` creator forwards every `torch.nn.Conv2d` keyword, `submodule_creators.py:251,263`): the channel groups
+    are independent convolutions — the input's channel groups are pulled apart (`dcv_copy_channels`), each runs on the ungrouped kernels with ITS contiguous slice
+    of the weight / bias (`dcv_conv2d_fwd / _dgrad / _wgrad`, fp32) and the outputs are put side by side; the backward pass mirrors it and writes each group's weight
+    gradient into its slice of dw.  Not on a BASELINE config: correctness first, one launch per group and direction. """
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, dilation, groups):
+        _require_f32(weight, bias)
+        nat.require_device(x)
+        x = to_nhwc(_f32(x))
+        weight = weight.contiguous()
+        n, cin, h, w = x.shape
+        cout, cig, r, s = weight.shape
+        if cin % groups or cout % groups or cig * groups != cin:
+            raise ValueError(f'deepcv_amd.grouped_conv2d: {cin} input / {cout} output channels and a weight of {cig} input channels do not split into {groups} groups')
+        cog = cout // groups
+        dev, st, rows_in = x.device, nat.current_stream(x.device), n * h * w
+        d = _conv_desc((n, cig, h, w), (cog, cig, r, s), stride, padding, dilation, nat.LAYOUT_NHWC, nat.ACT_NONE, 0.)
+        y = torch.empty((n, cout, d.ho, d.wo), dtype=torch.float32, device=dev, memory_format=_CL)
+        ws = _ws(lib.dcv_conv2d_fwd_workspace_bytes(d), dev)
+        xs = []
+        yg = torch.empty((n, cog, d.ho, d.wo), dtype=torch.float32, device=dev, memory_format=_CL)
+        for g in range(groups):
+            xg = torch.empty((n, cig, h, w), dtype=torch.float32, device=dev, memory_format=_CL)
+            nat.check(lib.dcv_copy_channels(x.data_ptr(), cin, g * cig, xg.data_ptr(), cig, 0, cig, rows_in, st), 'dcv_copy_channels')
+            nat.check(lib.dcv_conv2d_fwd(d, xg.data_ptr(), weight[g * cog:(g + 1) * cog].data_ptr(), nat.ptr(bias[g * cog:(g + 1) * cog] if bias is not None else None),
+                                         yg.data_ptr(), ws.data_ptr(), ws.numel(), st), 'dcv_conv2d_fwd')
+            nat.check(lib.dcv_copy_channels(yg.data_ptr(), cog, 0, y.data_ptr(), cout, g * cog, cog, n * d.ho * d.wo, st), 'dcv_copy_channels')
+            xs.append(xg)
+        ctx.desc, ctx.groups, ctx.has_bias = d, groups, bias is not None
+        ctx.save_for_backward(weight, *xs)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        weight, *xs = ctx.saved_tensors
+        d, groups = ctx.desc, ctx.groups
+        cog, cig = d.cout, d.cin
+        cout, cin = cog * groups, cig * groups
+        dev = dy.device
+        st = nat.current_stream(dev)
+        dy = to_nhwc(_f32(dy))
+        rows_out, rows_in = d.n * d.ho * d.wo, d.n * d.h * d.w
+        dx = torch.empty((d.n, cin, d.h, d.w), dtype=torch.float32, device=dev, memory_format=_CL) if ctx.needs_input_grad[0] else None
+        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        dw = torch.empty_like(weight) if need_w else None
+        db = torch.empty(cout, dtype=torch.float32, device=dev) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        dzg = torch.empty((d.n, cog, d.ho, d.wo), dtype=torch.float32, device=dev, memory_format=_CL)
+        dxg = torch.empty((d.n, cig, d.h, d.w), dtype=torch.float32, device=dev, memory_format=_CL) if dx is not None else None
+        ws_d = _ws(lib.dcv_conv2d_dgrad_workspace_bytes(d), dev) if dx is not None else None
+        ws_w = _ws(lib.dcv_conv2d_wgrad_workspace_bytes(d), dev) if need_w else None
+        for g in range(groups):
+            nat.check(lib.dcv_copy_channels(dy.data_ptr(), cout, g * cog, dzg.data_ptr(), cog, 0, cog, rows_out, st), 'dcv_copy_channels')
+            wg = weight[g * cog:(g + 1) * cog]
+            if dx is not None:
+                nat.check(lib.dcv_conv2d_dgrad(d, dzg.data_ptr(), wg.data_ptr(), dxg.data_ptr(), ws_d.data_ptr(), ws_d.numel(), st), 'dcv_conv2d_dgrad')
+                nat.check(lib.dcv_copy_channels(dxg.data_ptr(), cig, 0, dx.data_ptr(), cin, g * cig, cig, rows_in, st), 'dcv_copy_channels')
+            if need_w:
+                nat.check(lib.dcv_conv2d_wgrad(d, xs[g].data_ptr(), dzg.data_ptr(), dw[g * cog:(g + 1) * cog].data_ptr(),
+                                               nat.ptr(db[g * cog:(g + 1) * cog] if db is not None else None), ws_w.data_ptr(), ws_w.numel(), st), 'dcv_conv2d_wgrad')
+        return dx, (dw if ctx.needs_input_grad[1] else None), db, None, None, None, None
+
+
+def grouped_conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], stride, padding, dilation, groups: int) -> torch.Tensor:
+    resident.forbid('a grouped conv2d')
+    return _GroupedConv2dFn.apply(x, weight, bias, _pair(stride), _pair(padding), _pair(dilation), int(groups))
+
+
 # ------------------------------------------------------------------------------------------------ standalone activation
 
 class _ActFn(torch.autograd.Function):

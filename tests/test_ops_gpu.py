@@ -225,6 +225,45 @@ def test_instance_norm_module_on_the_group_norm_kernels(device, shape, affine):
         _check(name + '.dbeta', m.bias.grad, b64.grad.float(), 3e-4)
 
 
+@pytest.mark.parametrize('n,cin,h,w,cout,k,stride,pad,groups,bias,act', [
+    (4, 8, 16, 16, 8, 3, 1, 1, 2, True, None), (3, 12, 9, 11, 6, 3, 2, 1, 3, False, 'relu'), (2, 16, 8, 8, 16, 3, 1, 1, 16, True, 'leaky'),
+    (2, 64, 8, 8, 128, 3, 1, 1, 2, True, None), (5, 6, 7, 7, 12, 1, 1, 0, 6, True, None)], ids=str)
+def test_grouped_conv2d_module(device, n, cin, h, w, cout, k, stride, pad, groups, bias, act):
+    """ `deepcv_amd.modules.Conv2d(groups=g)` (the `conv2d` creator forwards `groups` to `torch.nn.Conv2d`, reference `submodule_creators.py:251,263`): every channel
+    group on the ungrouped kernels, depthwise included; forward, dx, dw, db against torch's grouped convolution in double precision, inside a `layer()`-style
+    Conv + activation pair where `act` is given (`LayerSequential` hands the activation to the convolution's forward). """
+    from deepcv_amd import modules
+    from deepcv_amd.meta import nn as dnn
+    g = torch.Generator().manual_seed(5 + cin + cout + groups)
+    x, dy_seed = torch.randn(n, cin, h, w, generator=g), torch.Generator().manual_seed(9)
+    conv = modules.Conv2d(cin, cout, k, stride=stride, padding=pad, groups=groups, bias=bias)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * 0.3)
+        if bias:
+            conv.bias.copy_(torch.randn(cout, generator=g))
+    act_t = {None: None, 'relu': torch.nn.ReLU, 'leaky': torch.nn.LeakyReLU}[act]
+    w64 = conv.weight.detach().double().requires_grad_(True)
+    b64 = conv.bias.detach().double().requires_grad_(True) if bias else None
+    x64 = x.double().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(x64, w64, b64, stride=stride, padding=pad, groups=groups)
+    if act_t is not None:
+        ref = act_t()(ref)
+    dy = torch.randn(ref.shape, generator=dy_seed)
+    ref.backward(dy.double())
+    mods = [conv] + ([modules.native_type(act_t)()] if act_t is not None else [])
+    m = dnn.LayerSequential(*mods).to(device).train()
+    xd = _cl(x.to(device)).requires_grad_(True)
+    y = m(xd)
+    y.backward(_cl(dy.to(device)))
+    name = f'gconv{(n, cin, h, w, cout, k, stride, pad, groups)}'
+    tol = 1e-4                                       # (measured 5e-8 .. 6e-7, the wide groups on the matrix cores' fp32 path included)
+    _check(name + '.y', y, ref.detach().float(), tol)
+    _check(name + '.dx', xd.grad, x64.grad.float(), max(tol, 3e-4))
+    _check(name + '.dw', conv.weight.grad, w64.grad.float(), max(tol, 3e-4))
+    if bias:
+        _check(name + '.db', conv.bias.grad, b64.grad.float(), 3e-4)
+
+
 @pytest.mark.parametrize('affine', ['plain', 'weight', 'affine'])
 @pytest.mark.parametrize('per_channel', [False, True], ids=['hw', 'chw'])
 @pytest.mark.parametrize('shape', [(4, 16, 16, 16), (3, 12, 5, 7), (37, 3, 8, 8), (2, 64, 8, 8)], ids=str)
