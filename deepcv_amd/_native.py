@@ -201,6 +201,8 @@ _SIGNATURES = {
     'dcv_layernorm_affine_workspace_bytes': (_c_size_t, [_c_int, _c_int]),
     'dcv_layernorm_affine_fwd': (_c_int, [_P, _c_int, _c_int, _c_int, _c_int, _P, _P, _P]),
     'dcv_layernorm_affine_bwd': (_c_int, [_P, _P, _P, _P, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _c_size_t, _P]),
+    'dcv_lrn_fwd': (_c_int, [_P, _P, _c_size_t, _c_int, _c_int, _c_float, _c_float, _c_float, _P]),
+    'dcv_lrn_bwd': (_c_int, [_P, _P, _P, _c_size_t, _c_int, _c_int, _c_float, _c_float, _c_float, _P]),
     'dcv_norm_chain_workspace_bytes': (_c_size_t, [_c_int, _c_int, _c_int]),
     'dcv_bn_gn_fwd_train': (_c_int, [_P, _P, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _c_float, _c_float, _P, _P, _c_int, _P, _P, _c_float, _P, _P, _P, _c_int, _P, _c_size_t, _P]),
     'dcv_bn_gn_act_bwd': (_c_int, [_P, _P, _P, _c_int, _c_int, _c_int, _P, _P, _P, _P, _c_int, _P, _P, _P, _c_int, _c_float, _P, _P, _P, _P, _P, _P, _c_size_t, _P]),

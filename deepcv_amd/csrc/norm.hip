@@ -849,6 +849,39 @@ __global__ __launch_bounds__(256) void ln_affine_param_grad_kernel(const double*
     if (db) db[wi] = (float)b;
 }
 
+// ------------------------------------------------------------------------------------------------ LocalResponseNorm
+// torch.nn.LocalResponseNorm over the channels of a pixel (NHWC: the window is contiguous): scale_c = k + alpha / size * sum of x^2 over the channels
+// [c - size / 2, c + (size - 1) / 2] inside the tensor, y_c = x_c * scale_c^-beta.  Backward: dx_c = dy_c scale_c^-beta - (2 alpha beta / size) x_c * sum over the
+// channels c' whose window holds c of dy_c' x_c' scale_c'^(-beta - 1).  A thread per element; the window's values come from the row the neighbouring lanes just read (L1 / L2).
+__device__ __forceinline__ float lrn_scale(const float* __restrict__ row, int c, int C, int size, float alpha_over_size, float k) {
+    const int lo = max(c - size / 2, 0), hi = min(c + (size - 1) / 2, C - 1);
+    float s = 0.f;
+    for (int j = lo; j <= hi; ++j) s += row[j] * row[j];
+    return k + alpha_over_size * s;
+}
+
+__global__ __launch_bounds__(256) void lrn_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t total, int C, int size, float alpha_over_size, float beta, float k) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % (size_t)C);
+        const float* row = x + (i - c);
+        y[i] = row[c] * powf(lrn_scale(row, c, C, size, alpha_over_size, k), -beta);
+    }
+}
+
+__global__ __launch_bounds__(256) void lrn_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx, size_t total, int C, int size,
+                                                      float alpha_over_size, float beta, float k) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % (size_t)C);
+        const float* row = x + (i - c);
+        const float* drow = dy + (i - c);
+        // c lies in the window of c' when c' - size / 2 <= c <= c' + (size - 1) / 2
+        const int lo = max(c - (size - 1) / 2, 0), hi = min(c + size / 2, C - 1);
+        float acc = 0.f;
+        for (int j = lo; j <= hi; ++j) acc += drow[j] * row[j] * powf(lrn_scale(row, j, C, size, alpha_over_size, k), -beta - 1.f);
+        dx[i] = drow[c] * powf(lrn_scale(row, c, C, size, alpha_over_size, k), -beta) - 2.f * alpha_over_size * beta * row[c] * acc;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -984,6 +1017,21 @@ int dcv_layernorm_affine_bwd(const float* dy, const float* x, const float* save_
                        per_channel ? 1 : C, per_channel ? hw : 0, weight, dxhat, part);
     if (dweight || dbias)
         hipLaunchKernelGGL(ln_affine_param_grad_kernel, dim3((unsigned)dcv_ceil_div((size_t)nw, (size_t)256)), dim3(256), 0, st, part, per_sample, C, hw, per_channel ? hw : 0, dweight, dbias);
+    DCV_RETURN_LAUNCH();
+}
+
+
+int dcv_lrn_fwd(const float* x, float* y, size_t rows, int C, int size, float alpha, float beta, float k, void* stream) {
+    DCV_CHECK_ARG(x && y && rows > 0 && C > 0 && size > 0);
+    const size_t total = rows * (size_t)C, blocks = dcv_ceil_div(total, (size_t)256);
+    hipLaunchKernelGGL(lrn_fwd_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, dcv_stream(stream), x, y, total, C, size, alpha / (float)size, beta, k);
+    DCV_RETURN_LAUNCH();
+}
+
+int dcv_lrn_bwd(const float* dy, const float* x, float* dx, size_t rows, int C, int size, float alpha, float beta, float k, void* stream) {
+    DCV_CHECK_ARG(dy && x && dx && rows > 0 && C > 0 && size > 0);
+    const size_t total = rows * (size_t)C, blocks = dcv_ceil_div(total, (size_t)256);
+    hipLaunchKernelGGL(lrn_bwd_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, dcv_stream(stream), dy, x, dx, total, C, size, alpha / (float)size, beta, k);
     DCV_RETURN_LAUNCH();
 }
 

@@ -151,7 +151,7 @@ _WARNED_NON_NATIVE = set()
 
 
 def _warn_if_not_native(module: Any) -> Any:
-    """ Modules this package has no HIP kernels for (1-D / 3-D operators, LocalResponseNorm: none is on a BASELINE config) run on
+    """ Modules this package has no HIP kernels for (1-D / 3-D operators: none is on a BASELINE config) run on
     torch's own ATen / MIOpen kernels; say so once per type instead of silently mixing back-ends (native 2-D modules raise on CPU tensors, these do not). """
     cls = type(module)
     if isinstance(module, torch.nn.Module) and cls.__module__.startswith('torch.nn') and cls not in _WARNED_NON_NATIVE:
@@ -191,7 +191,7 @@ def _layer_norm_with_mean_only_batch_norm(*args, **kwargs):
 
 
 NORM_TECHNIQUES_MODULES = {NormTechnique.BATCH_NORM: batch_norm_nd, NormTechnique.LAYER_NORM: native.LayerNorm, NormTechnique.INSTANCE_NORM: instance_norm_nd,
-                           NormTechnique.GROUP_NORM: native.GroupNorm, NormTechnique.LOCAL_RESPONSE_NORM: torch.nn.LocalResponseNorm,
+                           NormTechnique.GROUP_NORM: native.GroupNorm, NormTechnique.LOCAL_RESPONSE_NORM: native.LocalResponseNorm,
                            NormTechnique.LAYER_NORM_WITH_MEAN_ONLY_BATCH_NORM: _layer_norm_with_mean_only_batch_norm}
 
 

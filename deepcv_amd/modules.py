@@ -17,7 +17,7 @@ import torch.nn
 from . import _native as nat
 from . import ops
 
-__all__ = ['shape_inference', 'in_shape_inference', 'Conv2d', 'Linear', 'BatchNorm1d', 'BatchNorm2d', 'SyncBatchNorm2d', 'GroupNorm', 'InstanceNorm2d', 'LayerNorm', 'AvgPool2d', 'MaxPool2d', 'Flatten',
+__all__ = ['shape_inference', 'in_shape_inference', 'Conv2d', 'Linear', 'BatchNorm1d', 'BatchNorm2d', 'SyncBatchNorm2d', 'GroupNorm', 'InstanceNorm2d', 'LayerNorm', 'LocalResponseNorm', 'AvgPool2d', 'MaxPool2d', 'Flatten',
            'ReLU', 'LeakyReLU', 'Sigmoid', 'Tanh', 'CrossEntropyLoss', 'NATIVE_MODULE_TYPES', 'native_type', 'native_activation', 'is_native']
 
 _state = threading.local()
@@ -186,6 +186,16 @@ class LayerNorm(torch.nn.LayerNorm):
         return ops.layer_norm(x, self.weight, self.bias, per_channel, self.eps)
 
 
+class LocalResponseNorm(torch.nn.LocalResponseNorm):
+    """ `torch.nn.LocalResponseNorm` (reference normalisation factory, `nn.py:445`) for 4-D inputs: `dcv_lrn_fwd / _bwd`; other ranks run on torch's kernels. """
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if _shape_only(x):
+            return torch.zeros(x.shape)
+        if x.dim() != 4:
+            return super().forward(x)
+        return ops.local_response_norm(x, self.size, self.alpha, self.beta, self.k)
+
+
 class AvgPool2d(torch.nn.AvgPool2d):
     def _geom(self):
         if self.ceil_mode or not self.count_include_pad or self.divisor_override is not None:
@@ -270,7 +280,7 @@ class CrossEntropyLoss(torch.nn.CrossEntropyLoss):
 
 
 NATIVE_MODULE_TYPES = {torch.nn.Conv2d: Conv2d, torch.nn.Linear: Linear, torch.nn.BatchNorm1d: BatchNorm1d, torch.nn.BatchNorm2d: BatchNorm2d,
-                       torch.nn.GroupNorm: GroupNorm, torch.nn.LayerNorm: LayerNorm, torch.nn.AvgPool2d: AvgPool2d, torch.nn.MaxPool2d: MaxPool2d, torch.nn.Flatten: Flatten,
+                       torch.nn.GroupNorm: GroupNorm, torch.nn.LayerNorm: LayerNorm, torch.nn.LocalResponseNorm: LocalResponseNorm, torch.nn.AvgPool2d: AvgPool2d, torch.nn.MaxPool2d: MaxPool2d, torch.nn.Flatten: Flatten,
                        torch.nn.ReLU: ReLU, torch.nn.LeakyReLU: LeakyReLU, torch.nn.Sigmoid: Sigmoid, torch.nn.Tanh: Tanh,
                        torch.nn.CrossEntropyLoss: CrossEntropyLoss}
 

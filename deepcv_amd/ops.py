@@ -908,6 +908,33 @@ def layer_norm(x, weight, bias, per_channel: bool, eps: float) -> torch.Tensor:
     return _LayerNormFn.apply(x, weight, bias, bool(per_channel), float(eps))
 
 
+class _LocalResponseNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, size, alpha, beta, k):
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        y = torch.empty_like(x)
+        nat.check(lib.dcv_lrn_fwd(x.data_ptr(), y.data_ptr(), n * h * w, c, size, alpha, beta, k, nat.current_stream(x.device)), 'dcv_lrn_fwd')
+        ctx.cfg = (size, alpha, beta, k)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dy = to_nhwc(dy)
+        dx = torch.empty_like(x)
+        nat.check(lib.dcv_lrn_bwd(dy.data_ptr(), x.data_ptr(), dx.data_ptr(), n * h * w, c, *ctx.cfg, nat.current_stream(x.device)), 'dcv_lrn_bwd')
+        return dx, None, None, None, None
+
+
+def local_response_norm(x, size: int, alpha: float, beta: float, k: float) -> torch.Tensor:
+    """ `torch.nn.LocalResponseNorm` on a 4-D tensor (reference normalisation factory, `nn.py:445`): `dcv_lrn_fwd / _bwd`. """
+    resident.forbid('a standalone local_response_norm')
+    return _LocalResponseNormFn.apply(_f32(x), int(size), float(alpha), float(beta), float(k))
+
+
 # ------------------------------------------------------------------------------------------------ fused layer: conv + act + BatchNorm [+ GroupNorm]
 
 _norm_streaming = True

@@ -280,6 +280,14 @@ int dcv_layernorm_affine_bwd(const float* dy, const float* x, const float* save_
                              const float* weight, float* dxhat, float* dweight, float* dbias, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * K6c  LocalResponseNorm over the channels of a pixel, NHWC [rows][C]
+ * replaces torch.nn.LocalResponseNorm of the normalisation factory (nn.py:445): y = x * (k + alpha / size * sum of x^2 over the channel window)^-beta,
+ * the window [c - size / 2, c + (size - 1) / 2] clipped to the tensor (torch's zero padding).
+ * ------------------------------------------------------------------------------------------------- */
+int dcv_lrn_fwd(const float* x, float* y, size_t rows, int channels, int size, float alpha, float beta, float k, void* stream);
+int dcv_lrn_bwd(const float* dy, const float* x, float* dx, size_t rows, int channels, int size, float alpha, float beta, float k, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * K5 split in two phases for cross-GPU statistics (`use_sync_batch_norm`, ignite_training.py:203,386-388 -> torch.nn.SyncBatchNorm; collective C4):
  * the caller all-reduces `sums` ([2][channels] doubles) over the process group between the phases and passes the global row count.
  *   forward : dcv_batchnorm_stats (sum x, sum x^2 of the local rows)            -> all-reduce -> dcv_batchnorm_fwd_from_sums

@@ -204,24 +204,25 @@ def test_state_dict_roundtrip_with_reference_modules(params):
 
 
 def test_modules_without_hip_kernels_say_so_once(caplog):
-    """ LocalResponseNorm and 1-D / 3-D operators stay on torch's kernels (outside every BASELINE config): warned, not silent.  InstanceNorm2d and LayerNorm are
-    native modules on the GroupNorm statistics kernels (one channel per group; LayerNorm + its per-pixel affine, `dcv_layernorm_affine_*`): no warning; the
-    factory hands LayerNorm the map's [H, W] as its normalised shape (reference `nn.py:492-493`). """
+    """ 1-D / 3-D operators stay on torch's kernels (outside every BASELINE config): warned once per type, not silent.  InstanceNorm2d, LayerNorm and
+    LocalResponseNorm are native modules (GroupNorm statistics kernels with one channel per group; LayerNorm + its per-pixel affine, `dcv_layernorm_affine_*`;
+    `dcv_lrn_*`): no warning; the factory hands LayerNorm the map's [H, W] as its normalised shape (reference `nn.py:492-493`). """
     import logging
     from deepcv_amd.meta import nn as dnn
     dnn._WARNED_NON_NATIVE.clear()
     with caplog.at_level(logging.WARNING):
         mods = dnn.normalization_techniques(input_shape=torch.Size((8, 4, 4)), layer_norm={'eps': 1e-5}, instance_norm={'eps': 1e-5})
-        dnn.normalization_techniques_impl('local_response_norm', {'size': 3})
-        dnn.normalization_techniques_impl('local_response_norm', {'size': 3})
+        lrn = dnn.normalization_techniques_impl('local_response_norm', {'size': 3})[0]
         dnn.conv_nd(1, 3, 4, 3)
+        dnn.conv_nd(1, 3, 4, 3)
+        dnn.conv_nd(3, 3, 4, 3)
     assert [type(m).__name__ for m in mods] == ['LayerNorm', 'InstanceNorm2d']
     from deepcv_amd import modules
     assert isinstance(mods[0], modules.LayerNorm) and tuple(mods[0].normalized_shape) == (4, 4) and mods[0].weight.shape == (4, 4)
-    assert isinstance(mods[1], modules.InstanceNorm2d)
-    assert modules.native_type(torch.nn.LayerNorm) is modules.LayerNorm
+    assert isinstance(mods[1], modules.InstanceNorm2d) and isinstance(lrn, modules.LocalResponseNorm)
+    assert modules.native_type(torch.nn.LayerNorm) is modules.LayerNorm and modules.native_type(torch.nn.LocalResponseNorm) is modules.LocalResponseNorm
     msgs = [r.getMessage() for r in caplog.records if 'no hand-written HIP kernel' in r.getMessage()]
-    assert len(msgs) == 2 and any('LocalResponseNorm' in m for m in msgs) and any('Conv1d' in m for m in msgs) and not any('InstanceNorm' in m or 'LayerNorm' in m for m in msgs)
+    assert len(msgs) == 2 and any('Conv3d' in m for m in msgs) and any('Conv1d' in m for m in msgs) and not any('Norm' in m for m in msgs)
 
 
 def test_resident_recording_is_refused_for_models_with_foreign_leaf_modules(params):

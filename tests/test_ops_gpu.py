@@ -264,6 +264,29 @@ def test_grouped_conv2d_module(device, n, cin, h, w, cout, k, stride, pad, group
         _check(name + '.db', conv.bias.grad, b64.grad.float(), 3e-4)
 
 
+@pytest.mark.parametrize('size,alpha,beta,k', [(5, 1e-4, 0.75, 1.0), (2, 0.3, 0.5, 2.0), (3, 1.5, 1.0, 0.5), (9, 0.8, 0.75, 1.0)], ids=str)
+@pytest.mark.parametrize('shape', [(4, 16, 16, 16), (3, 7, 5, 9), (2, 64, 8, 8), (5, 1, 4, 4)], ids=str)
+def test_local_response_norm_module(device, shape, size, alpha, beta, k):
+    """ `local_response_norm` of the normalisation factory (reference `nn.py:445`) = `deepcv_amd.modules.LocalResponseNorm` on `dcv_lrn_fwd / _bwd`, against
+    torch's module in double precision (even and odd windows, windows wider than the channel count, strong alpha so that the cross-channel term of dx matters). """
+    from deepcv_amd import modules
+    from deepcv_amd.meta import nn as dnn
+    g = torch.Generator().manual_seed(17 + shape[1] + size)
+    x = torch.randn(*shape, generator=g) * 1.3 + 0.2
+    dy = torch.randn(*shape, generator=g)
+    m = dnn.normalization_techniques_impl('local_response_norm', {'size': size, 'alpha': alpha, 'beta': beta, 'k': k})[0]
+    assert isinstance(m, modules.LocalResponseNorm)
+    x64 = x.double().requires_grad_(True)
+    ref = torch.nn.functional.local_response_norm(x64, size, alpha=alpha, beta=beta, k=k)
+    ref.backward(dy.double())
+    xd = _cl(x.to(device)).requires_grad_(True)
+    y = m.to(device)(xd)
+    y.backward(_cl(dy.to(device)))
+    name = f'lrn{shape}{(size, alpha, beta, k)}'
+    _check(name + '.y', y, ref.detach().float(), 1e-5)
+    _check(name + '.dx', xd.grad, x64.grad.float(), 1e-4)
+
+
 @pytest.mark.parametrize('affine', ['plain', 'weight', 'affine'])
 @pytest.mark.parametrize('per_channel', [False, True], ids=['hw', 'chw'])
 @pytest.mark.parametrize('shape', [(4, 16, 16, 16), (3, 12, 5, 7), (37, 3, 8, 8), (2, 64, 8, 8)], ids=str)
