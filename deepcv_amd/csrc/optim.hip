@@ -27,11 +27,12 @@ __global__ void optim_prepare_kernel(float* __restrict__ hyper, int64_t* __restr
 // Block -> (tensor, first element): the grid is ONE row of blocks, tensor after tensor (round 4, last session: grid = (blocks of the largest tensor, tensors) launched
 // 92 000 blocks for the 40 tensors of cifar100_deep, of which 4 800 had work — dispatching the empty ones was a third of the kernel).  A scalar walk over the
 // table's element counts (at most DCV_MAX_TENSORS steps).
+template <int EPB = OPT_ELEMS_PER_BLOCK>
 __device__ __forceinline__ bool list_block(const dcv_tensor_list& tl, int& t, int64_t& base) {
     int64_t b = blockIdx.x;
     for (int k = 0; k < tl.count; ++k) {
-        const int64_t nb = (tl.numel[k] + OPT_ELEMS_PER_BLOCK - 1) / OPT_ELEMS_PER_BLOCK;
-        if (b < nb) { t = k; base = b * OPT_ELEMS_PER_BLOCK; return true; }
+        const int64_t nb = (tl.numel[k] + EPB - 1) / EPB;
+        if (b < nb) { t = k; base = b * EPB; return true; }
         b -= nb;
     }
     return false;
@@ -65,39 +66,54 @@ __device__ __forceinline__ void sgd_one(float& pi, float gi, float& bi, bool has
     pi = pi - lr * gi;
 }
 
-// A thread owns four CONSECUTIVE elements: 16-byte loads / stores when the tensor's pointers allow it (round 4, last session: the 4-byte accesses ran the
-// 4.9 M parameters of cifar100_deep at 2.2 TB/s, 44 us per step).
+// A thread owns SGD_VECS groups of four CONSECUTIVE elements, a block 4096 elements: 16-byte loads / stores when the tensor's pointers allow it (round 4: the
+// 4-byte accesses ran the 4.9 M parameters of cifar100_deep at 2.2 TB/s, 44 us per step; 16-byte accesses with ONE group per thread 41 us: 4 800 blocks of three
+// loads per thread each — the last session of round 4 issues every load of the four groups before the first update, a quarter of the blocks).
+#define SGD_VECS 4
+#define SGD_ELEMS_PER_BLOCK (OPT_BLOCK * 4 * SGD_VECS)
 template <bool NESTEROV>
 __global__ __launch_bounds__(OPT_BLOCK) void sgd_kernel(dcv_tensor_list tl, const float* __restrict__ hyper) {
     int t; int64_t base;
-    if (!list_block(tl, t, base)) return;
+    if (!list_block<SGD_ELEMS_PER_BLOCK>(tl, t, base)) return;
     const int64_t n = tl.numel[t];
-    const float lr = hyper[DCV_HYP_LR], mu = hyper[DCV_HYP_BETA1], damp = hyper[DCV_HYP_BETA2];
-    const float wd = hyper[DCV_HYP_WEIGHT_DECAY], gs = hyper[DCV_HYP_GRAD_SCALE];
-    const bool first = hyper[DCV_HYP_FIRST_STEP] != 0.f;
     float* __restrict__ p = tl.param[t]; const float* __restrict__ g = tl.grad[t]; float* __restrict__ buf = tl.state1[t];
     const bool has_buf = buf != nullptr;
-    const int64_t i0 = base + 4 * (int64_t)threadIdx.x;
-    if (i0 >= n) return;
-    const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(buf)) & 15) == 0 && i0 + 3 < n;
-    if (vec) {
-        float4 pv = *reinterpret_cast<const float4*>(p + i0);
-        const float4 gv = *reinterpret_cast<const float4*>(g + i0);
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (has_buf && !first) bv = *reinterpret_cast<const float4*>(buf + i0);
-        sgd_one<NESTEROV>(pv.x, gv.x, bv.x, has_buf, first, lr, mu, damp, wd, gs);
-        sgd_one<NESTEROV>(pv.y, gv.y, bv.y, has_buf, first, lr, mu, damp, wd, gs);
-        sgd_one<NESTEROV>(pv.z, gv.z, bv.z, has_buf, first, lr, mu, damp, wd, gs);
-        sgd_one<NESTEROV>(pv.w, gv.w, bv.w, has_buf, first, lr, mu, damp, wd, gs);
-        if (has_buf) *reinterpret_cast<float4*>(buf + i0) = bv;
-        *reinterpret_cast<float4*>(p + i0) = pv;
-        return;
+    const bool first = hyper[DCV_HYP_FIRST_STEP] != 0.f;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(buf)) & 15) == 0;
+    const bool rd_buf = has_buf && !first;
+    float4 pv[SGD_VECS], gv[SGD_VECS], bv[SGD_VECS];
+    bool vec[SGD_VECS];
+#pragma unroll
+    for (int k = 0; k < SGD_VECS; ++k) {
+        const int64_t i0 = base + 4 * ((int64_t)k * OPT_BLOCK + threadIdx.x);
+        vec[k] = aligned && i0 + 3 < n;
+        bv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (vec[k]) {
+            pv[k] = *reinterpret_cast<const float4*>(p + i0);
+            gv[k] = *reinterpret_cast<const float4*>(g + i0);
+            if (rd_buf) bv[k] = *reinterpret_cast<const float4*>(buf + i0);
+        }
     }
-    for (int64_t i = i0; i < i0 + 4 && i < n; ++i) {
-        float pi = p[i], bi = (has_buf && !first) ? buf[i] : 0.f;
-        sgd_one<NESTEROV>(pi, g[i], bi, has_buf, first, lr, mu, damp, wd, gs);
-        if (has_buf) buf[i] = bi;
-        p[i] = pi;
+    const float lr = hyper[DCV_HYP_LR], mu = hyper[DCV_HYP_BETA1], damp = hyper[DCV_HYP_BETA2];
+    const float wd = hyper[DCV_HYP_WEIGHT_DECAY], gs = hyper[DCV_HYP_GRAD_SCALE];
+#pragma unroll
+    for (int k = 0; k < SGD_VECS; ++k) {
+        const int64_t i0 = base + 4 * ((int64_t)k * OPT_BLOCK + threadIdx.x);
+        if (vec[k]) {
+            sgd_one<NESTEROV>(pv[k].x, gv[k].x, bv[k].x, has_buf, first, lr, mu, damp, wd, gs);
+            sgd_one<NESTEROV>(pv[k].y, gv[k].y, bv[k].y, has_buf, first, lr, mu, damp, wd, gs);
+            sgd_one<NESTEROV>(pv[k].z, gv[k].z, bv[k].z, has_buf, first, lr, mu, damp, wd, gs);
+            sgd_one<NESTEROV>(pv[k].w, gv[k].w, bv[k].w, has_buf, first, lr, mu, damp, wd, gs);
+            if (has_buf) *reinterpret_cast<float4*>(buf + i0) = bv[k];
+            *reinterpret_cast<float4*>(p + i0) = pv[k];
+        } else {
+            for (int64_t i = i0; i < i0 + 4 && i < n; ++i) {
+                float pi = p[i], bi = rd_buf ? buf[i] : 0.f;
+                sgd_one<NESTEROV>(pi, g[i], bi, has_buf, first, lr, mu, damp, wd, gs);
+                if (has_buf) buf[i] = bi;
+                p[i] = pi;
+            }
+        }
     }
 }
 
@@ -119,7 +135,7 @@ __global__ __launch_bounds__(OPT_BLOCK) void pack_kernel(dcv_tensor_list tl, flo
     }
 }
 
-inline int list_grid(const dcv_tensor_list* tl, dim3* grid, bool need_param, bool need_state1, bool need_state2, bool need_state3) {
+inline int list_grid(const dcv_tensor_list* tl, dim3* grid, bool need_param, bool need_state1, bool need_state2, bool need_state3, int epb = OPT_ELEMS_PER_BLOCK) {
     if (!tl || tl->count <= 0 || tl->count > DCV_MAX_TENSORS) return DCV_ERR_INVALID_ARG;
     int64_t mx = 0;
     for (int i = 0; i < tl->count; ++i) {
@@ -128,7 +144,7 @@ inline int list_grid(const dcv_tensor_list* tl, dim3* grid, bool need_param, boo
         if (need_state1 && !tl->state1[i]) return DCV_ERR_INVALID_ARG;
         if (need_state2 && !tl->state2[i]) return DCV_ERR_INVALID_ARG;
         if (need_state3 && !tl->state3[i]) return DCV_ERR_INVALID_ARG;
-        mx += (tl->numel[i] + OPT_ELEMS_PER_BLOCK - 1) / OPT_ELEMS_PER_BLOCK;
+        mx += (tl->numel[i] + epb - 1) / epb;
     }
     if (mx > 0x7fffffffLL) return DCV_ERR_UNSUPPORTED;
     *grid = dim3((unsigned)mx, 1, 1);
@@ -158,7 +174,7 @@ int dcv_adamw_step(const dcv_tensor_list* tl, const float* hyper, int amsgrad, v
 int dcv_sgd_step(const dcv_tensor_list* tl, const float* hyper, int nesterov, void* stream) {
     DCV_CHECK_ARG(hyper);
     dim3 grid;
-    const int rc = list_grid(tl, &grid, true, false, false, false);
+    const int rc = list_grid(tl, &grid, true, false, false, false, SGD_ELEMS_PER_BLOCK);
     if (rc != DCV_OK) return rc;
     if (nesterov) hipLaunchKernelGGL((sgd_kernel<true>), grid, dim3(OPT_BLOCK), 0, dcv_stream(stream), *tl, hyper);
     else hipLaunchKernelGGL((sgd_kernel<false>), grid, dim3(OPT_BLOCK), 0, dcv_stream(stream), *tl, hyper);

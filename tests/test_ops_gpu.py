@@ -455,7 +455,7 @@ def test_optimizers(device, kind):
     from deepcv_amd import optim
     from oracle import ops_ref
     g = torch.Generator().manual_seed(53)
-    shapes = [(4, 3, 5, 5), (4,), (16, 16, 3, 3), (10, 1280), (10,), (1,)] + [(3, 3)] * 70   # > 64 tensors: two launches
+    shapes = [(4, 3, 5, 5), (4,), (16, 16, 3, 3), (10, 1280), (10,), (1,), (4099,), (3, 2731)] + [(3, 3)] * 70   # > 64 tensors: two launches
     params = [torch.randn(*s, generator=g) for s in shapes]
     grads = [[torch.randn(*s, generator=g) for s in shapes] for _ in range(4)]
     lrs = [0.0, 1e-3, 2e-3, 5e-4]
